@@ -1,0 +1,134 @@
+/*
+ * sdvpcm.h - C-ABI of the MI355X-native SDVPCMdecoder decode engine (libsdvpcm_hip.so).
+ *
+ * Plain C, POD only, caller-allocated buffers.  This is the boundary a maintainer of
+ * Fagear/SDVPCMdecoder binds: the Qt workers VideoToDigital and
+ * STC007DataStitcher stay, their inner per-line / per-block calls are replaced by whole-batch
+ * calls into this library.
+ *
+ * Each entry point cites the reference interface it replaces (file:line in the reference tree).
+ * All "device" pointers are HIP device pointers (hipMalloc / torch CUDA tensors); the *_host
+ * convenience variants take host pointers and stage through PCIe.
+ */
+#ifndef SDVPCM_H
+#define SDVPCM_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDV_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------------
+ * 0..4 mirror Binarizer::LB_RET_* (binarizer.h:268-275); 16.. mirror STC007Deinterleaver::DI_RET_*
+ * (stc007deinterleaver.h:97-103); negative = engine/runtime errors (no reference equivalent:
+ * the reference has no device boundary). */
+enum {
+    SDV_OK = 0,
+    SDV_ERR_NULL_VIDEO = 1,     /* LB_RET_NULL_VIDEO */
+    SDV_ERR_NULL_PCM = 2,       /* LB_RET_NULL_PCM */
+    SDV_ERR_SHORT_LINE = 3,     /* LB_RET_SHORT_LINE: line shorter than the format's bit count */
+    SDV_ERR_NO_COORD = 4,       /* LB_RET_NO_COORD */
+    SDV_ERR_NULL_LINES = 16,    /* DI_RET_NULL_LINES */
+    SDV_ERR_NULL_BLOCK = 17,    /* DI_RET_NULL_BLOCK */
+    SDV_ERR_NO_DATA = 18,       /* DI_RET_NO_DATA */
+    SDV_ERR_BAD_ARG = -1,
+    SDV_ERR_HIP = -2,           /* HIP runtime failure, see sdv_last_error() */
+    SDV_ERR_NO_DEVICE = -3,
+    SDV_ERR_UNSUPPORTED = -4
+};
+
+/* PCM formats (PCMLine::TYPE_*, pcmline.h:77-84) */
+enum { SDV_PCM_PCM1 = 0, SDV_PCM_PCM16X0 = 1, SDV_PCM_STC007 = 2 };
+/* Binarizer::MODE_* (binarizer.h:207-214) */
+enum { SDV_MODE_DRAFT = 0, SDV_MODE_FAST = 1, SDV_MODE_NORMAL = 2, SDV_MODE_INSANE = 3 };
+/* PCMLine::SRVLINE_* (pcmline.h:104-115) */
+enum {
+    SDV_SRV_NO = 0, SDV_SRV_NEW_FILE, SDV_SRV_END_FILE, SDV_SRV_FILLER, SDV_SRV_END_FIELD,
+    SDV_SRV_END_FRAME, SDV_SRV_HEADER_LINE, SDV_SRV_CTRL_BLOCK
+};
+
+/* sdv_line_rec.flags */
+enum {
+    SDV_LF_REF_SWEEPED = 1 << 0,    /* PCMLine::ref_level_sweeped   */
+    SDV_LF_COORDS_SWEEPED = 1 << 1, /* PCMLine::coords_sweeped      */
+    SDV_LF_BY_EXT_TUNE = 1 << 2,    /* PCMLine::data_by_ext_tune    */
+    SDV_LF_BW_SET = 1 << 3,         /* PCMLine::hasBWSet()          */
+    SDV_LF_COORDS_SET = 1 << 4,     /* PCMLine::hasDataCoordSet()   */
+    SDV_LF_FORCED_BAD = 1 << 5,     /* PCMLine::isForcedBad()       */
+    SDV_LF_CRC_VALID = 1 << 6,      /* PCMLine::isCRCValid()        */
+    SDV_LF_FROM_DOUBLED = 1 << 7    /* PCMLine::isSourceDoubleWidth() */
+};
+/* sdv_line_rec.word_state */
+enum { SDV_WS_WORD_CRC = 1 << 0, SDV_WS_WORD_VALID = 1 << 1 };
+
+/* One binarized STC-007 line: everything needed to re-hydrate an STC007Line through its
+ * public API (stc007line.h:153-221, pcmline.h:137-186).  48 bytes, no padding. */
+typedef struct sdv_line_rec {
+    uint32_t frame_number;          /* PCMLine::frame_number */
+    uint16_t line_number;           /* PCMLine::line_number (1-based; 0 for trailing service lines) */
+    uint16_t words[9];              /* STC007Line::words: 8 x 14-bit + CRCC as read */
+    uint16_t calc_crc;              /* PCMLine::getCalculatedCRC() */
+    int16_t data_start, data_stop;  /* PCMLine::coords */
+    uint16_t marker_start_bg_coord, marker_start_ed_coord, marker_stop_ed_coord;
+    uint8_t black_level, white_level, ref_low, ref_level, ref_high;
+    uint8_t hysteresis_depth, shift_stage;
+    uint8_t service_type;           /* SDV_SRV_* */
+    uint8_t mark_st_stage, mark_ed_stage;
+    uint8_t flags;                  /* SDV_LF_* */
+    uint8_t word_state;             /* SDV_WS_* (uniform over the 9 words at binarizer output) */
+} sdv_line_rec;
+
+/* bin_preset_t (binarizer.h:163-186) */
+typedef struct sdv_bin_preset {
+    uint8_t max_black_lvl, min_white_lvl, min_contrast, min_ref_lvl, max_ref_lvl, min_valid_crcs;
+    uint8_t mark_max_dist, left_bit_pick, right_bit_pick;
+    uint8_t en_force_coords, en_coord_search, en_first_line_dup, en_good_no_marker;
+    uint8_t _pad;
+    int16_t horiz_start, horiz_stop;    /* bin_preset_t::horiz_coords */
+} sdv_bin_preset;
+
+/* Preset incoming "good parameters" of a Binarizer (Binarizer::setGoodParameters, binarizer.cpp:353-377):
+ * all-zero = nothing preset. */
+typedef struct sdv_bin_state {
+    uint8_t in_def_black, in_def_white, in_def_reference, _pad;
+    int16_t in_def_start, in_def_stop;      /* CoordinatePair::NO_COORD_LEFT/RIGHT when unset */
+    uint8_t in_def_from_doubled, _pad2;
+} sdv_bin_state;
+
+typedef struct sdv_engine sdv_engine;
+
+/* ---- engine lifetime ------------------------------------------------------------------------ */
+/* Creates an engine bound to HIP device `device` (one engine per GPU / per process rank).
+ * Replaces: construction of VideoToDigital + its member Binarizer (videotodigital.h:114,
+ * videotodigital.cpp:3-25).  Returns NULL on failure; sdv_last_error(NULL) then holds the reason. */
+sdv_engine *sdv_engine_create(int device);
+void sdv_engine_destroy(sdv_engine *e);
+const char *sdv_last_error(const sdv_engine *e);
+int sdv_abi_version(void);
+
+/* ---- settings ------------------------------------------------------------------------------- */
+/* Binarizer::getDefaultFineSettings (binarizer.cpp:380-385) */
+void sdv_default_bin_preset(sdv_bin_preset *out);
+/* Binarizer::setFineSettings (binarizer.cpp:394-403) */
+int sdv_set_bin_preset(sdv_engine *e, const sdv_bin_preset *p);
+/* Binarizer::setMode (binarizer.cpp:120-177) via VideoToDigital::setBinarizationMode */
+int sdv_set_mode(sdv_engine *e, int mode);
+
+/* ---- hot path: per-line binarizer ------------------------------------------------------------
+ * Replaces Binarizer::processLine (binarizer.cpp:443-1724) for a BATCH of independent STC-007
+ * scanlines, each evaluated from the same preset state (what one Binarizer does for one line after
+ * setGoodParameters()).  luma: n_lines rows of `width` bytes at `stride`.  states: one per line or
+ * NULL (= nothing preset, the cold path).  All pointers are device pointers.  Asynchronous on
+ * `stream` (a hipStream_t, 0 = default stream). */
+int sdv_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t stride, int width, int n_lines,
+                       const uint32_t *frame_numbers, const uint16_t *line_numbers,
+                       const sdv_bin_state *states, sdv_line_rec *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDVPCM_H */
