@@ -99,6 +99,39 @@ typedef struct sdv_bin_state {
     uint8_t in_def_from_doubled, _pad2;
 } sdv_bin_state;
 
+/* FrameBinDescriptor (frametrimset.h:69-97) as emitted by VideoToDigital at END_FRAME
+ * (videotodigital.cpp:1636-1714); time_odd/time_even are wall clock in the reference and are
+ * not reproduced. 32 bytes. */
+typedef struct sdv_frame_stats {
+    uint32_t frame_id;
+    uint16_t line_length;
+    uint16_t lines_odd, lines_even;
+    uint16_t lines_pcm_odd, lines_pcm_even;
+    uint16_t lines_bad_odd, lines_bad_even;
+    uint16_t lines_dup_odd, lines_dup_even;
+    int16_t data_start, data_stop;      /* data_coord */
+    uint8_t data_from_doubled, data_not_sure;
+    uint8_t _pad[4];
+} sdv_frame_stats;
+
+/* The frame-to-frame state VideoToDigital::doBinarize carries (videotodigital.cpp:706-720 locals +
+ * the Binarizer presets in_def_*, binarizer.h:310-313).  It is everything a frame's result depends
+ * on besides its own pixels, which is what lets the engine decode frames of one stream in parallel
+ * and still return the sequential reference result (DESIGN.md "chain speculation"). 144 bytes. */
+typedef struct sdv_coord { int16_t data_start, data_stop; } sdv_coord;
+typedef struct sdv_v2d_state {
+    sdv_bin_state bin;                  /* line_converter presets after the last line */
+    uint8_t do_ref_lvl_sweep;           /* Binarizer::do_ref_lvl_sweep (sticky, binarizer.cpp:1104-1128) */
+    uint8_t reset_stats;                /* VideoToDigital::reset_stats (videotodigital.cpp:778-790) */
+    uint8_t n_last_valid;               /* last_valid_coord_list.size() <= COORD_HISTORY_DEPTH (9) */
+    uint8_t n_long_valid;               /* long_valid_coords.size()     <= COORD_LONG_HISTORY (16) */
+    uint8_t last_valid_doubled_mask_lo, last_valid_doubled_mask_hi; /* from_doubled bit per entry */
+    uint16_t long_valid_doubled_mask;
+    sdv_coord last_valid[9];
+    sdv_coord long_valid[16];
+    uint8_t _pad[2];
+} sdv_v2d_state;
+
 typedef struct sdv_engine sdv_engine;
 
 /* ---- engine lifetime ------------------------------------------------------------------------ */

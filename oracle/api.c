@@ -92,3 +92,80 @@ int orc_bin_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16
     orc_line_to_rec(&h->out, out);
     return ret;
 }
+
+/* ------------------------------------------------------------------ VideoToDigital level */
+#include "v2d.h"
+
+static void stats_to_pod(const orc_frame_stats *q, sdv_frame_stats *s)
+{
+    memset(s, 0, sizeof(*s));
+    s->frame_id = q->frame_id; s->line_length = q->line_length;
+    s->lines_odd = q->lines_odd; s->lines_even = q->lines_even;
+    s->lines_pcm_odd = q->lines_pcm_odd; s->lines_pcm_even = q->lines_pcm_even;
+    s->lines_bad_odd = q->lines_bad_odd; s->lines_bad_even = q->lines_bad_even;
+    s->lines_dup_odd = q->lines_dup_odd; s->lines_dup_even = q->lines_dup_even;
+    s->data_start = q->data_coord.data_start; s->data_stop = q->data_coord.data_stop;
+    s->data_from_doubled = q->data_coord.from_doubled; s->data_not_sure = q->data_coord.not_sure;
+}
+
+void *orc_v2d_new(void) { orc_v2d *v = (orc_v2d *)malloc(sizeof(orc_v2d)); orc_v2d_init(v); return v; }
+void orc_v2d_delete(void *v) { orc_v2d_free((orc_v2d *)v); free(v); }
+void orc_v2d_set_mode(void *v, int mode) { if (mode >= 0 && mode < 4) ((orc_v2d *)v)->binarization_mode = (uint8_t)mode; }
+void orc_v2d_set_check_line_dup(void *v, int on) { ((orc_v2d *)v)->check_line_copy = on != 0; }
+void orc_v2d_set_m2(void *v, int on) { ((orc_v2d *)v)->m2_format = on != 0; }
+void orc_v2d_set_preset(void *vv, const sdv_bin_preset *p)
+{
+    orc_bin_preset s; orc_bin_preset_reset(&s);
+    s.max_black_lvl = p->max_black_lvl; s.min_white_lvl = p->min_white_lvl; s.min_contrast = p->min_contrast;
+    s.min_ref_lvl = p->min_ref_lvl; s.max_ref_lvl = p->max_ref_lvl; s.min_valid_crcs = p->min_valid_crcs;
+    s.mark_max_dist = p->mark_max_dist; s.left_bit_pick = p->left_bit_pick; s.right_bit_pick = p->right_bit_pick;
+    s.en_force_coords = p->en_force_coords; s.en_coord_search = p->en_coord_search;
+    s.en_first_line_dup = p->en_first_line_dup; s.en_good_no_marker = p->en_good_no_marker;
+    s.horiz_coords.data_start = p->horiz_start; s.horiz_coords.data_stop = p->horiz_stop;
+    orc_v2d_set_fine_settings((orc_v2d *)vv, &s);
+}
+
+/* Runs n_frames consecutive frames (frame numbers first_frame_no..). Records: per frame height+3
+ * (+1 NEW_FILE before the first frame when new_file). Returns total records written. */
+long orc_v2d_run(void *vv, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                 int new_file, int doubled, sdv_line_rec *out, sdv_frame_stats *stats)
+{
+    orc_v2d *v = (orc_v2d *)vv;
+    long n = 0;
+    for (int f = 0; f < n_frames; f++) {
+        orc_frame_stats q;
+        n += orc_v2d_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
+                           new_file && f == 0, doubled != 0, out + n, &q);
+        if (stats) stats_to_pod(&q, &stats[f]);
+    }
+    return n;
+}
+
+/* Export of the frame-to-frame chain state (what the HIP engine speculates on, include/sdvpcm.h). */
+void orc_v2d_get_state(void *vv, sdv_v2d_state *s)
+{
+    orc_v2d *v = (orc_v2d *)vv;
+    memset(s, 0, sizeof(*s));
+    s->bin.in_def_black = v->line_converter.in_def_black; s->bin.in_def_white = v->line_converter.in_def_white;
+    s->bin.in_def_reference = v->line_converter.in_def_reference;
+    s->bin.in_def_start = v->line_converter.in_def_coord.data_start; s->bin.in_def_stop = v->line_converter.in_def_coord.data_stop;
+    s->bin.in_def_from_doubled = v->line_converter.in_def_coord.from_doubled;
+    s->do_ref_lvl_sweep = v->line_converter.do_ref_lvl_sweep;
+    s->reset_stats = v->reset_stats;
+    s->n_last_valid = (uint8_t)v->last_valid_coord_list.n;
+    s->n_long_valid = (uint8_t)v->long_valid_coords.n;
+    uint16_t m = 0;
+    for (int i = 0; i < v->last_valid_coord_list.n && i < 9; i++) {
+        s->last_valid[i].data_start = v->last_valid_coord_list.v[i].data_start;
+        s->last_valid[i].data_stop = v->last_valid_coord_list.v[i].data_stop;
+        if (v->last_valid_coord_list.v[i].from_doubled) m |= (uint16_t)(1u << i);
+    }
+    s->last_valid_doubled_mask_lo = (uint8_t)(m & 0xFF); s->last_valid_doubled_mask_hi = (uint8_t)(m >> 8);
+    m = 0;
+    for (int i = 0; i < v->long_valid_coords.n && i < 16; i++) {
+        s->long_valid[i].data_start = v->long_valid_coords.v[i].data_start;
+        s->long_valid[i].data_stop = v->long_valid_coords.v[i].data_stop;
+        if (v->long_valid_coords.v[i].from_doubled) m |= (uint16_t)(1u << i);
+    }
+    s->long_valid_doubled_mask = m;
+}

@@ -138,3 +138,138 @@ int ref_bin_process(void *h, const uint8_t *px, int len, uint32_t frame, uint16_
 }
 
 } /* extern "C" */
+
+/* ------------------------------------------------------------------ VideoToDigital level */
+#include <thread>
+#include <chrono>
+#include <QMutex>
+#include <QObject>
+#include "videotodigital.h"
+
+struct RefV2D {
+    VideoToDigital v2d;
+    std::deque<VideoLine> in_q;
+    std::deque<STC007Line> out_q;
+    QMutex in_mtx, out_mtx;
+    std::deque<FrameBinDescriptor> stats_q;
+    QMutex stats_mtx;
+    std::thread th;
+    bool started;
+    RefV2D() : started(false) {}
+};
+
+static void stats_to_pod(FrameBinDescriptor &q, sdv_frame_stats *s)
+{
+    memset(s, 0, sizeof(*s));
+    s->frame_id = q.frame_id; s->line_length = q.line_length;
+    s->lines_odd = q.lines_odd; s->lines_even = q.lines_even;
+    s->lines_pcm_odd = q.lines_pcm_odd; s->lines_pcm_even = q.lines_pcm_even;
+    s->lines_bad_odd = q.lines_bad_odd; s->lines_bad_even = q.lines_bad_even;
+    s->lines_dup_odd = q.lines_dup_odd; s->lines_dup_even = q.lines_dup_even;
+    s->data_start = q.data_coord.data_start; s->data_stop = q.data_coord.data_stop;
+    s->data_from_doubled = q.data_coord.from_doubled; s->data_not_sure = q.data_coord.not_sure;
+}
+
+extern "C" {
+
+void *ref_v2d_new(void)
+{
+    RefV2D *r = new RefV2D();
+    r->v2d.setInputPointers(&r->in_q, &r->in_mtx);
+    r->v2d.setOutSTC007Pointers(&r->out_q, &r->out_mtx);
+    r->v2d.setPCMType(VideoToDigital::TYPE_STC007);
+    QObject::connect(&r->v2d, &VideoToDigital::guiUpdFrameBin, [r](FrameBinDescriptor d) {
+        r->stats_mtx.lock(); r->stats_q.push_back(d); r->stats_mtx.unlock();
+    });
+    return r;
+}
+void ref_v2d_delete(void *h)
+{
+    RefV2D *r = (RefV2D *)h;
+    if (r->started) { r->v2d.stop(); r->th.join(); }
+    delete r;
+}
+void ref_v2d_set_mode(void *h, int mode) { ((RefV2D *)h)->v2d.setBinarizationMode((uint8_t)mode); }
+void ref_v2d_set_check_line_dup(void *h, int on) { ((RefV2D *)h)->v2d.setCheckLineDup(on != 0); }
+void ref_v2d_set_m2(void *h, int on) { ((RefV2D *)h)->v2d.setPCMType(on ? VideoToDigital::TYPE_M2 : VideoToDigital::TYPE_STC007); }
+void ref_v2d_set_preset(void *h, const sdv_bin_preset *p)
+{
+    RefV2D *r = (RefV2D *)h;
+    bin_preset_t s;
+    s.max_black_lvl = p->max_black_lvl; s.min_white_lvl = p->min_white_lvl; s.min_contrast = p->min_contrast;
+    s.min_ref_lvl = p->min_ref_lvl; s.max_ref_lvl = p->max_ref_lvl; s.min_valid_crcs = p->min_valid_crcs;
+    s.mark_max_dist = p->mark_max_dist; s.left_bit_pick = p->left_bit_pick; s.right_bit_pick = p->right_bit_pick;
+    s.en_force_coords = p->en_force_coords; s.en_coord_search = p->en_coord_search;
+    s.en_first_line_dup = p->en_first_line_dup; s.en_good_no_marker = p->en_good_no_marker;
+    s.horiz_coords.data_start = p->horiz_start; s.horiz_coords.data_stop = p->horiz_stop;
+    r->v2d.setFineSettings(s);
+}
+
+static void push_service(std::deque<VideoLine> &q, int kind, uint32_t frame, uint16_t line)
+{
+    VideoLine s;
+    if (kind == SDV_SRV_NEW_FILE) s.setServNewFile("synthetic.avi");
+    else if (kind == SDV_SRV_END_FIELD) s.setServEndField();
+    else if (kind == SDV_SRV_END_FRAME) s.setServEndFrame();
+    else if (kind == SDV_SRV_END_FILE) s.setServEndFile();
+    else if (kind == SDV_SRV_FILLER) s.setServFiller();
+    s.frame_number = frame; s.line_number = line;
+    q.push_back(s);
+}
+
+/* Feeds n_frames frames in VideoInFFMPEG::spliceFrame order (vin_ffmpeg.cpp:213-364) through the REAL
+ * VideoToDigital worker loop and collects its STC007Line output and FrameBinDescriptor emissions. */
+long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                 int new_file, int doubled, sdv_line_rec *out, sdv_frame_stats *stats)
+{
+    RefV2D *r = (RefV2D *)h;
+    if (!r->started) { r->started = true; r->th = std::thread([r]() { r->v2d.doBinarize(); }); }
+    long expect = (long)n_frames * (height + 3) + (new_file ? 1 : 0);
+    long got = 0; int fed = 0; int nstats = 0;
+    while (got < expect || nstats < n_frames) {
+        /* keep a few frames queued */
+        r->in_mtx.lock();
+        size_t qs = r->in_q.size();
+        r->in_mtx.unlock();
+        while (fed < n_frames && qs < (size_t)(3 * (height + 4))) {
+            std::deque<VideoLine> tmp;
+            uint32_t fno = first_frame_no + (uint32_t)fed;
+            const uint8_t *fr = luma + (size_t)fed * stride * (size_t)height;
+            if (new_file && fed == 0) push_service(tmp, SDV_SRV_NEW_FILE, fno, 0);
+            uint16_t line_num = 0;
+            for (int field = 0; field < 2; field++) {
+                int line_offset = field;
+                line_num = (uint16_t)(line_offset + 1);
+                for (;;) {
+                    VideoLine v;
+                    v.frame_number = fno; v.line_number = line_num;
+                    v.setDoubleWidth(doubled != 0);
+                    v.pixel_data.assign(fr + (size_t)line_offset * stride, fr + (size_t)line_offset * stride + width);
+                    tmp.push_back(v);
+                    if (line_offset < (height - 2)) line_offset += 2;
+                    else { line_num += 2; break; }
+                    line_num += 2;
+                }
+                push_service(tmp, SDV_SRV_END_FIELD, fno, line_num);
+            }
+            line_num += 2;
+            push_service(tmp, SDV_SRV_END_FRAME, fno, line_num);
+            r->in_mtx.lock();
+            for (auto &l : tmp) r->in_q.push_back(l);
+            qs = r->in_q.size();
+            r->in_mtx.unlock();
+            fed++;
+        }
+        /* drain */
+        r->out_mtx.lock();
+        while (!r->out_q.empty() && got < expect) { line_to_rec(r->out_q.front(), &out[got++]); r->out_q.pop_front(); }
+        r->out_mtx.unlock();
+        r->stats_mtx.lock();
+        while (!r->stats_q.empty() && nstats < n_frames) { if (stats) stats_to_pod(r->stats_q.front(), &stats[nstats]); nstats++; r->stats_q.pop_front(); }
+        r->stats_mtx.unlock();
+        if (got < expect || nstats < n_frames) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return got;
+}
+
+} /* extern "C" */

@@ -7,7 +7,8 @@ Line layout (stc007line.h:79-101): 4 START bits "1010", 8 x 14-bit words (L0 R0 
 16-bit CRCC, 5 STOP bits "01111"  = 137 bit cells.
 Interleave (stc007deinterleaver.cpp:420-424): word k of block b sits in line b + 16*k, slot k.
 P = XOR of the six audio words; Q = T^6 L0 + T^5 R0 + T^4 L1 + T^3 R1 + T^2 L2 + T R2 over GF(2)^14
-(stc007deinterleaver.cpp:1297-1317), T = companion matrix of x^14 + x^8 + 1 (see q_matrix()).
+(stc007deinterleaver.cpp:1297-1317); T (row table stc007deinterleaver.cpp:8-11) is "multiply by x" in
+GF(2)[x]/(x^14 + x^8 + 1): T v = (v << 1) ^ (0x0101 if v bit 13 else 0), see t_mul().
 """
 from __future__ import annotations
 
@@ -91,3 +92,78 @@ def random_lines(n: int, seed: int = 0, width: int = 720, **kw):
     w9 = np.concatenate([words, crc[:, None].astype(np.uint32)], axis=1).astype(np.uint16)
     luma = render_lines(line_bits(w9), width=width, rng=rng, **kw)
     return luma, w9
+
+
+def t_mul(v: np.ndarray) -> np.ndarray:
+    """One application of the Q-code matrix T to 14-bit vectors (multiply by x mod x^14+x^8+1)."""
+    v = np.asarray(v).astype(np.uint32)
+    hi = (v >> 13) & 1
+    return (((v << 1) & WORD_MASK) ^ (hi * 0x0101)).astype(np.uint32)
+
+
+def pq_words(audio: np.ndarray):
+    """audio (n, 6) 14-bit words L0 R0 L1 R1 L2 R2 -> (P, Q) per block
+    (calcPcode/calcQcode, stc007deinterleaver.cpp:1297-1317)."""
+    a = np.asarray(audio).astype(np.uint32)
+    p = a[:, 0] ^ a[:, 1] ^ a[:, 2] ^ a[:, 3] ^ a[:, 4] ^ a[:, 5]
+    q = np.zeros(a.shape[0], dtype=np.uint32)
+    for k in range(6):
+        q = t_mul(q ^ a[:, k])     # Horner: T^6 L0 + T^5 R0 + ... + T R2
+    return p, q
+
+
+def interleave_stream(audio: np.ndarray) -> np.ndarray:
+    """(n_blocks, 6) audio words -> (n_blocks, 9) line words: line m, slot k = word k of block m-16k
+    (stc007deinterleaver.cpp:420-424; zero before the stream starts), CRC appended."""
+    n = audio.shape[0]
+    p, q = pq_words(audio)
+    blk = np.concatenate([np.asarray(audio).astype(np.uint32), p[:, None], q[:, None]], axis=1)   # (n, 8)
+    lines = np.zeros((n, 8), dtype=np.uint32)
+    for k in range(8):
+        lines[16 * k:, k] = blk[:n - 16 * k, k]
+    crc = crc16_words14(lines)
+    return np.concatenate([lines, crc[:, None].astype(np.uint32)], axis=1).astype(np.uint16)
+
+
+CTRL_BLOCK_WORDS = (0x3333, 0x0CCC, 0x3333, 0x0CCC, 0x0000)   # cue x4 + ID (stc007line.cpp:493-504)
+
+
+def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 486,
+                  lines_per_field: int = 245, cut_top: int | None = None, ctrl_block: bool = False,
+                  audio: np.ndarray | None = None, silent: bool = False, **render_kw):
+    """Synthetic STC-007 video: one continuous interleaved line stream, `lines_per_field` PCM lines per field
+    (config.h:80-81), of which `height//2` are visible starting at `cut_top` (default: as many as do not fit
+    are cut from the top, e.g. 2 for 486 rows).  Frame row 2r   <- odd field line cut_top + r,
+                                                 frame row 2r+1 <- even field line cut_top + r
+    (field/row order of VideoInFFMPEG::spliceFrame, vin_ffmpeg.cpp:281-347).
+    ctrl_block=True overwrites stream line 0 of every field with a Control Block line.
+    Returns (luma (n_frames, height, width) u8, line words (n_stream_lines, 9) u16, audio (n_blocks, 6))."""
+    rng = np.random.default_rng(seed)
+    vis = height // 2
+    if cut_top is None:
+        cut_top = max(0, lines_per_field - vis)
+    n_stream = n_frames * 2 * lines_per_field
+    if audio is None:
+        if silent:
+            audio = np.zeros((n_stream, 6), dtype=np.uint32)
+        else:
+            audio = rng.integers(0, 1 << 14, size=(n_stream, 6), dtype=np.uint32)
+    w9 = interleave_stream(audio)
+    if ctrl_block:
+        cb = np.zeros(8, dtype=np.uint32)
+        cb[:5] = CTRL_BLOCK_WORDS
+        cb[7] = 0x0000          # control bits: P and Q present, emphasis on, copy allowed
+        idx = np.arange(0, n_stream, lines_per_field)
+        w9[idx, :8] = cb.astype(np.uint16)
+        w9[idx, 8] = crc16_words14(cb[None, :])[0]
+    # stream line index for every frame row
+    f = np.arange(n_frames)[:, None]
+    r = np.arange(vis)[None, :]
+    odd = f * 2 * lines_per_field + cut_top + r
+    even = odd + lines_per_field
+    idx = np.empty((n_frames, height), dtype=np.int64)
+    idx[:, 0:2 * vis:2] = odd
+    idx[:, 1:2 * vis:2] = even
+    flat = idx.reshape(-1)
+    luma = render_lines(line_bits(w9[flat]), width=width, rng=rng, **render_kw)
+    return luma.reshape(n_frames, height, width), w9, audio
