@@ -117,7 +117,7 @@ typedef struct sdv_frame_stats {
 /* The frame-to-frame state VideoToDigital::doBinarize carries (videotodigital.cpp:706-720 locals +
  * the Binarizer presets in_def_*, binarizer.h:310-313).  It is everything a frame's result depends
  * on besides its own pixels, which is what lets the engine decode frames of one stream in parallel
- * and still return the sequential reference result (DESIGN.md "chain speculation"). 144 bytes. */
+ * and still return the sequential reference result (DESIGN.md "chain speculation"). 120 bytes. */
 typedef struct sdv_coord { int16_t data_start, data_stop; } sdv_coord;
 typedef struct sdv_v2d_state {
     sdv_bin_state bin;                  /* line_converter presets after the last line */
@@ -151,15 +151,56 @@ int sdv_set_bin_preset(sdv_engine *e, const sdv_bin_preset *p);
 /* Binarizer::setMode (binarizer.cpp:120-177) via VideoToDigital::setBinarizationMode */
 int sdv_set_mode(sdv_engine *e, int mode);
 
-/* ---- hot path: per-line binarizer ------------------------------------------------------------
- * Replaces Binarizer::processLine (binarizer.cpp:443-1724) for a BATCH of independent STC-007
- * scanlines, each evaluated from the same preset state (what one Binarizer does for one line after
- * setGoodParameters()).  luma: n_lines rows of `width` bytes at `stride`.  states: one per line or
- * NULL (= nothing preset, the cold path).  All pointers are device pointers.  Asynchronous on
- * `stream` (a hipStream_t, 0 = default stream). */
-int sdv_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t stride, int width, int n_lines,
-                       const uint32_t *frame_numbers, const uint16_t *line_numbers,
-                       const sdv_bin_state *states, sdv_line_rec *out, void *stream);
+/* VideoToDigital::setCheckLineDup (videotodigital.cpp:645-664) */
+int sdv_set_check_line_dup(sdv_engine *e, int on);
+/* VideoToDigital::setPCMType (videotodigital.cpp:557-604); m2_sample_format = TYPE_M2 */
+int sdv_set_pcm_type(sdv_engine *e, int pcm_type, int m2_sample_format);
+/* Forget the stream: equivalent to a freshly constructed VideoToDigital (reset_stats = true). */
+int sdv_reset_stream(sdv_engine *e);
+/* The feedback state after the last frame decoded so far (and a way to resume from a saved one). */
+int sdv_get_chain_state(const sdv_engine *e, sdv_v2d_state *out);
+int sdv_set_chain_state(sdv_engine *e, const sdv_v2d_state *in);
+
+/* flags of sdv_binarize_frames */
+enum {
+    SDV_FLAG_NEW_FILE = 1u << 0,    /* first frame of a source: a NEW_FILE service line precedes it (vin_ffmpeg.cpp:275-280) */
+    SDV_FLAG_DOUBLED = 1u << 1      /* rows were width-doubled upstream (VideoLine::isDoubleWidth, ffmpegwrapper.cpp:179-186) */
+};
+
+/* How the last sdv_binarize_frames call was scheduled (chain speculation). */
+typedef struct sdv_run_info {
+    uint32_t frames;            /* frames in the call */
+    uint32_t rounds;            /* speculation rounds (kernel launches) needed; 1 = fully parallel */
+    uint32_t frames_launched;   /* frame decodes executed, including re-decodes after a misprediction */
+    uint32_t _pad;
+} sdv_run_info;
+int sdv_get_run_info(const sdv_engine *e, sdv_run_info *out);
+
+/* records emitted per frame: `height` scanlines + 2 END_FIELD + 1 END_FRAME service lines */
+size_t sdv_records_per_frame(int height);
+
+/* ---- hot path: binarize + bit-extract + CRC for a batch of whole frames ------------------------
+ * Replaces the body of VideoToDigital::doBinarize (videotodigital.cpp:698-1815) including every call
+ * it makes into its Binarizer (setMode/setSource/setOutput/processLine/setGoodParameters/
+ * setDataCoordinates/setBWLevels, videotodigital.cpp:834-1003, 1198, 1369, 1468-1521) for `n_frames`
+ * consecutive frames of one stream.  Continues from the state the previous call left
+ * (sdv_reset_stream() to start over).
+ *
+ *  luma         device pointer; frame f, row r at luma + f*frame_stride + r*row_stride, `width` bytes
+ *               of 8-bit luma per row (the pixel_data of the reference's VideoLine, videoline.h:37-88).
+ *               Rows should be 16-byte aligned for full-rate loads (any alignment is accepted).
+ *  out_lines    device pointer, (height+3)*n_frames records (+1 leading NEW_FILE record with
+ *               SDV_FLAG_NEW_FILE), in exactly the order VideoToDigital pushes STC007Line objects
+ *               into its output queue: odd-field rows (line numbers 1,3,..), END_FIELD, even-field
+ *               rows (2,4,..), END_FIELD, END_FRAME (vin_ffmpeg.cpp:281-350).
+ *  out_stats    device pointer, one FrameBinDescriptor per frame (signal guiUpdFrameBin).
+ *  stream       hipStream_t (NULL = default stream).  The call returns after the device work of the
+ *               batch has been validated (it synchronises `stream` at least once).
+ * Returns SDV_OK or an SDV_ERR_* code; invalid input is refused up front like the reference's early
+ * returns (binarizer.cpp:465-478, 582-589). */
+int sdv_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
+                        int n_frames, uint32_t first_frame_no, unsigned flags,
+                        sdv_line_rec *out_lines, sdv_frame_stats *out_stats, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,67 @@
+"""Build recipes. `build_all()` is what __graft_entry__.build() runs.
+
+Product:  sdvpcmdecoder_amd/libsdvpcm_hip.so   hipcc --offload-arch=gfx950 (cross-compiles without a GPU)
+Test infrastructure (never loaded by the product):
+          oracle/liborc.so                     gcc, plain C restatement of the reference path
+          oracle/_ref/libsdvref.so             the real reference, only where /root/reference exists
+          tests/emu/libsdvpcm_emu.so           the kernel source under the CPU SIMT emulator
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+HIP_LIB = os.path.join(PKG, "libsdvpcm_hip.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def build_hip(force=False):
+    csrc = os.path.join(PKG, "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("sdvpcm_hip.hip", "stc007_device.h", "engine.inc")] + \
+           [os.path.join(ROOT, "include", "sdvpcm.h")]
+    if not force and not _newer(HIP_LIB, srcs):
+        return HIP_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", HIP_LIB, os.path.join(csrc, "sdvpcm_hip.hip")]
+    subprocess.check_call(cmd, cwd=csrc)
+    return HIP_LIB
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def build_reference():
+    """Only possible where the reference tree is mounted (the build container)."""
+    if not os.path.isdir("/root/reference"):
+        return False
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j4"])
+    return True
+
+
+def build_emu(force=False):
+    d = os.path.join(ROOT, "tests", "emu")
+    out = os.path.join(d, "libsdvpcm_emu.so")
+    srcs = [os.path.join(d, "emu_engine.cpp"), os.path.join(d, "hip_emu.h"),
+            os.path.join(PKG, "csrc", "stc007_device.h"), os.path.join(PKG, "csrc", "engine.inc"),
+            os.path.join(ROOT, "include", "sdvpcm.h")]
+    if not force and not _newer(out, srcs):
+        return out
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", out,
+                           os.path.join(d, "emu_engine.cpp")])
+    return out
+
+
+def build_all():
+    build_hip()
+    build_oracle()
+    build_reference()
+    build_emu()

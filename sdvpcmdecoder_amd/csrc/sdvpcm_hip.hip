@@ -1,0 +1,7 @@
+/*
+ * sdvpcm_hip.hip - the one translation unit of libsdvpcm_hip.so (product): HIP kernels for gfx950
+ * plus the C-ABI engine.  Build: see sdvpcmdecoder_amd/build.py (hipcc --offload-arch=gfx950).
+ */
+#include <hip/hip_runtime.h>
+#include "stc007_device.h"
+#include "engine.inc"

@@ -1,0 +1,1598 @@
+/*
+ * stc007_device.h - HIP device code of the STC-007 binarize path for gfx950 (wave64).
+ *
+ * One wavefront decodes one video frame: it walks the frame's scanlines in the order
+ * VideoInFFMPEG::spliceFrame emits them (vin_ffmpeg.cpp:213-364) and carries the
+ * VideoToDigital/Binarizer feedback state from line to line (videotodigital.cpp:825-1717),
+ * because in the reference every line's result depends on the previous good line
+ * (Binarizer::setGoodParameters, binarizer.cpp:353-377).  Frames of a batch run in parallel
+ * from speculated incoming states that the host validates afterwards.
+ *
+ * Per scanline: the row is read from HBM once (coalesced 16-byte loads), staged in LDS, and every
+ * retry of the closed-loop binarizer (hysteresis x pixel-shift ladder, 24 marker hysteresis levels,
+ * the <=234-level reference sweep) re-reads LDS only.
+ *
+ * Wave-level building blocks:
+ *   - bit extraction: each lane samples 2 of the 128 bit cells; the reference's 2-state hysteresis
+ *     automaton (binarizer.cpp:7377-7399) is solved for all 128 cells at once from four v_cmp ballots
+ *     (bit-parallel "last constant + toggle parity" formulation, see fill_bits());
+ *   - CRC-16/CCITT-FALSE (pcmline.cpp:461-487): linear over GF(2) => 16 lanes each take one CRC bit as
+ *     parity(popcount(bits & K_j)), result assembled with one ballot;
+ *   - brightness histograms: LDS atomics, one row per wave;
+ *   - marker search at 24 hysteresis levels: one lane per level;
+ *   - reference-level sweep: one lane per level (4 rounds of 64), statistics/vote replayed serially.
+ *
+ * Collectives are only used in wave-uniform control flow.  The same source is compiled by g++ with
+ * tests/emu/hip_emu.h (-DSDV_EMU) so the logic can be exercised without a GPU in tests.
+ *
+ * Reference citations are file:line in Fagear/SDVPCMdecoder v0.99.7.
+ */
+#ifndef SDV_STC007_DEVICE_H
+#define SDV_STC007_DEVICE_H
+
+#include "../../include/sdvpcm.h"
+
+#ifndef SDV_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+#define SDV_MAX_WIDTH 1536          /* staged scanline bytes per wave (720 px SD, 1440 px doubled) */
+#define SDV_MAX_HEIGHT 640          /* LINES_PER_FRAME_MAX, config.h:79 */
+
+namespace sdv {
+
+/* ---- constants of the reference (pcmline.h, stc007line.h, binarizer.h, videotodigital.h) ---- */
+enum { BITS_IN_LINE = 137, BITS_DATA = 128, BITS_BETWEEN = 132, BITS_START = 4 };
+enum { MARK_ST_START = 0, MARK_ST_TOP_1, MARK_ST_BOT_1, MARK_ST_TOP_2, MARK_ST_BOT_2 };
+enum { MARK_ED_START = 0, MARK_ED_TOP, MARK_ED_BOT, MARK_ED_LEN_OK };
+enum { HYST_DEPTH_SAFE = 4, HYST_DEPTH_MAX = 10, SHIFT_STAGES_MIN = 0, SHIFT_STAGES_SAFE = 2, SHIFT_STAGES_MAX = 4 };
+enum { STG_INPUT_ALL = 0, STG_INPUT_LEVEL, STG_REF_FIND, STG_REF_SWEEP_RUN, STG_READ_PCM, STG_DATA_OK, STG_NO_GOOD, STG_MAX };
+enum { REF_NO_PCM = 0, REF_BAD_CRC, REF_CRC_COLL, REF_CRC_OK };
+enum { SPAN_NOT_FOUND = 0, SPAN_TOO_NARROW, SPAN_OK };
+enum { MAX_COLL_CRCS = 32, MIN_VALID_CRCS = 5 };
+enum { FIELD_INIT = 0, FIELD_NEW, FIELD_SAFE, FIELD_UNSAFE };
+enum { COORD_HISTORY_DEPTH = 9, COORD_LONG_HISTORY = 16, BIT_DIFF_THRES_DIV = 32 };
+enum { NO_COORD_LEFT = -32768, NO_COORD_RIGHT = 32767 };
+enum { CRC_SILENT = 0xA96A };
+
+/* ---- CRC-16/CCITT-FALSE as a GF(2)-linear map of the 112 data bits -------------------------- */
+struct CrcTables { uint64_t klo[16], khi[16]; uint16_t init; };
+
+constexpr uint16_t crc16_step(uint16_t crc, int bit)
+{
+    bool msb = (crc & 0x8000) != 0;
+    crc = (uint16_t)(crc << 1);
+    if (msb != (bit != 0)) crc ^= 0x1021;
+    return crc;
+}
+constexpr CrcTables make_crc_tables()
+{
+    CrcTables t{};
+    /* contribution of the init value: CRC of 112 zero bits from 0xFFFF */
+    uint16_t c = 0xFFFF;
+    for (int i = 0; i < 112; i++) c = crc16_step(c, 0);
+    t.init = c;
+    for (int b = 0; b < 112; b++) {
+        /* CRC (from init 0) of the message with only data bit b set */
+        uint16_t v = 0;
+        for (int i = 0; i < 112; i++) v = crc16_step(v, i == b);
+        for (int j = 0; j < 16; j++)
+            if (v & (1u << j)) { if (b < 64) t.klo[j] |= (1ull << b); else t.khi[j] |= (1ull << (b - 64)); }
+    }
+    return t;
+}
+#ifdef SDV_EMU
+static const CrcTables c_crc = make_crc_tables();
+#else
+__device__ __constant__ const CrcTables c_crc = make_crc_tables();
+#endif
+
+/* ---- per-wave LDS --------------------------------------------------------------------------- */
+struct SweepEnt { uint8_t result, hyst, shift, pad; uint16_t crc; int16_t start, stop; uint16_t pad2; };
+struct CrcStat { uint8_t result, hyst, shift, idx; uint16_t crc; };
+struct WaveLds {
+    uint8_t px[SDV_MAX_WIDTH];
+    uint32_t hist[256];
+    SweepEnt sweep[256];
+    CrcStat crc_stats[MAX_COLL_CRCS + 1];
+    uint32_t lv_keys[COORD_HISTORY_DEPTH];   /* last_valid_coord_list as sort keys (videotodigital.cpp:707) */
+    uint32_t long_keys[COORD_LONG_HISTORY];  /* long_valid_coords (videotodigital.cpp:710) */
+};
+
+/* ---- launch parameters ---------------------------------------------------------------------- */
+struct FrameArgs {
+    const uint8_t *luma;            /* frame f, row r at luma + f*frame_stride + r*row_stride */
+    size_t frame_stride, row_stride;
+    int width, height;
+    uint32_t first_frame_no;        /* frame_number of frame index 0 */
+    int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch */
+    int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
+    uint8_t doubled, mode, check_line_copy, coordinate_damper, m2_format;
+    sdv_bin_preset preset;
+    const sdv_v2d_state *states_in; /* [n frames] speculated incoming chain state */
+    sdv_v2d_state *states_out;      /* [n frames] outgoing chain state */
+    sdv_line_rec *recs;             /* frame f: recs + f*(height+3) (+1 for every frame after new_file_frame...) */
+    sdv_frame_stats *stats;         /* [n frames] */
+    uint32_t *scratch;              /* per frame 2*height u32 (frame_valid / frame_invalid coordinate keys) */
+};
+
+/* ---- uniform per-wave state (kept in registers; identical in all lanes) ---------------------- */
+struct Coords { int16_t start, stop; bool doubled; };
+
+struct Line {                       /* PCMLine + STC007Line (pcmline.h:137-166, stc007line.h:153-165) */
+    uint32_t frame_number; uint16_t line_number;
+    uint8_t black, white, ref_low, ref_level, ref_high;
+    Coords coords;
+    uint8_t hyst, shift;
+    bool ref_sweeped, by_ext_tune;
+    uint16_t calc_crc;
+    bool bw_set, coords_set, forced_bad;
+    uint8_t service;
+    uint16_t pixel_start, pixel_stop;
+    int16_t pso; uint32_t psm, hpsm;
+    uint8_t mark_st, mark_ed;
+    uint16_t m_st_bg, m_st_ed, m_sp_ed;
+    bool m2;
+    bool word_crc07, word_valid07, word_crc8, word_valid8;   /* flags of words 0..7 / of the CRC word */
+    uint16_t words[9];
+};
+
+struct Bin {                        /* Binarizer (binarizer.h:306-337) */
+    uint8_t in_black, in_white, in_ref;
+    Coords in_coord;
+    uint8_t in_max_hyst, in_max_shift;
+    bool do_ref_lvl_sweep;
+    uint8_t mode, hyst_lim, shift_lim;
+    uint16_t line_length, scan_start, scan_end, mark_start_max, mark_end_min, estimated_ppb;
+    bool was_bw_scanned;
+    bool vl_doubled;
+};
+
+struct Markers { uint8_t st_stage, ed_stage; uint16_t st1s, st1e, st3e, ed_start, ed_end; bool has_start; };
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ bool coords_valid(const Coords &c)    /* frametrimset.cpp:153-156 */
+{
+    return (c.start != NO_COORD_LEFT) && (c.stop != NO_COORD_RIGHT) && (c.start < c.stop);
+}
+__device__ __forceinline__ void coords_clear(Coords &c) { c.start = NO_COORD_LEFT; c.stop = NO_COORD_RIGHT; c.doubled = false; }
+__device__ __forceinline__ bool coords_set(Coords &c, int16_t s, int16_t e) { if (e > s) { c.start = s; c.stop = e; return true; } return false; }
+__device__ __forceinline__ bool coords_ne(const Coords &a, const Coords &b) { return a.start != b.start || a.stop != b.stop || a.doubled != b.doubled; }
+/* sort key of CoordinatePair::operator< (frametrimset.cpp:63-98): start ascending, then stop descending
+ * (reference field is always 0 on this path) */
+__device__ __forceinline__ uint32_t coords_key(int16_t s, int16_t e) { return ((uint32_t)(uint16_t)(s + 32768) << 16) | (uint32_t)(uint16_t)(0xFFFF - (uint16_t)(e + 32768)); }
+__device__ __forceinline__ int16_t key_start(uint32_t k) { return (int16_t)((int)(k >> 16) - 32768); }
+__device__ __forceinline__ int16_t key_stop(uint32_t k) { return (int16_t)((int)(0xFFFF - (k & 0xFFFF)) - 32768); }
+
+__device__ __forceinline__ uint8_t get_low_level(uint8_t l, uint8_t d) { return (l > d) ? (uint8_t)(l - d) : (uint8_t)1; }            /* binarizer.cpp:3476-3487 */
+__device__ __forceinline__ uint8_t get_high_level(uint8_t l, uint8_t d) { return (l < (255 - d)) ? (uint8_t)(l + d) : (uint8_t)254; }  /* :3490-3501 */
+
+__device__ inline uint8_t pick_center_ref_level(const sdv_bin_preset &ps, uint8_t lvl_black, uint8_t lvl_white)   /* :3504-3548 */
+{
+    uint8_t br_delta = (uint8_t)(lvl_white - lvl_black), res;
+    if (br_delta >= ps.min_contrast) {
+        br_delta = br_delta / 2;
+        res = (uint8_t)(br_delta + lvl_black);
+        if (res < ps.min_ref_lvl) res = ps.min_ref_lvl;
+        else if (res > ps.max_ref_lvl) res = ps.max_ref_lvl;
+    } else {
+        res = (lvl_white < ps.max_ref_lvl) ? ps.max_ref_lvl : ps.min_ref_lvl;
+    }
+    return res;
+}
+
+/* ---- CRC helpers (bit-serial form for the few scalar uses) ----------------------------------- */
+__device__ inline uint16_t crc16_words(const uint16_t *w)     /* stc007line.cpp:245-251 */
+{
+    uint16_t crc = 0xFFFF;
+    for (int k = 0; k < 8; k++)
+        for (int bit = 13; bit >= 0; bit--) crc = crc16_step(crc, (w[k] >> bit) & 1);
+    return crc;
+}
+
+/* ---- Line helpers ---------------------------------------------------------------------------- */
+__device__ inline void pcmline_clear(Line &l)      /* PCMLine::clear, pcmline.cpp:96-116 */
+{
+    l.frame_number = 0; l.line_number = 0;
+    l.black = l.white = 0; l.ref_low = l.ref_level = l.ref_high = 0;
+    coords_clear(l.coords);
+    l.hyst = l.shift = 0;
+    l.ref_sweeped = l.by_ext_tune = false;
+    l.calc_crc = 0;
+    l.bw_set = l.coords_set = l.forced_bad = false;
+    l.service = SDV_SRV_NO;
+    l.pixel_start = 0; l.pixel_stop = 1; l.pso = 0; l.psm = 128; l.hpsm = 64;
+}
+__device__ inline void stc_clear(Line &l)          /* STC007Line::clear, stc007line.cpp:64-93 */
+{
+    pcmline_clear(l);
+    l.mark_st = MARK_ST_START; l.mark_ed = MARK_ED_START;
+    l.m_st_bg = l.m_st_ed = l.m_sp_ed = 0;
+    l.m2 = false;
+    for (int i = 0; i < 8; i++) l.words[i] = 0;
+    l.word_crc07 = l.word_valid07 = l.word_crc8 = l.word_valid8 = false;
+    l.calc_crc = CRC_SILENT;
+    l.words[8] = (uint16_t)~l.calc_crc;
+}
+__device__ __forceinline__ bool crc_valid_ignore_forced(const Line &l) { return l.calc_crc == l.words[8]; }
+__device__ __forceinline__ bool crc_valid(const Line &l) { return !l.forced_bad && crc_valid_ignore_forced(l); }
+__device__ __forceinline__ bool has_start(const Line &l) { return l.mark_st == MARK_ST_BOT_2; }
+__device__ __forceinline__ bool has_stop(const Line &l) { return l.mark_ed == MARK_ED_LEN_OK; }
+__device__ __forceinline__ bool has_markers(const Line &l) { return has_start(l) && has_stop(l); }
+__device__ __forceinline__ void set_invalid_crc(Line &l) { l.words[8] = (uint16_t)~l.calc_crc; }
+__device__ __forceinline__ void apply_crc_state_per_word(Line &l) { bool v = crc_valid(l); l.word_crc07 = l.word_valid07 = l.word_crc8 = l.word_valid8 = v; }
+__device__ inline void set_source_pixels(Line &l, uint16_t a, uint16_t b)   /* pcmline.cpp:202-213 */
+{
+    if (b > a) if (BITS_BETWEEN <= (b - a)) { l.pixel_start = a; l.pixel_stop = b; }
+}
+__device__ inline void set_service(Line &l, uint8_t srv)   /* pcmline.cpp:118-171, 489-503 (base clear only) */
+{
+    uint32_t f = l.frame_number; uint16_t n = l.line_number;
+    pcmline_clear(l);
+    l.frame_number = f; l.line_number = n; l.service = srv;
+}
+__device__ inline int16_t stc_get_sample(const Line &l, int index)   /* stc007line.cpp:282-326 */
+{
+    uint16_t w = l.words[index];
+    if (!l.m2) w = (uint16_t)(w << 2);
+    else {
+        if ((w & (1 << 13)) == 0) w = (uint16_t)(w << 3);
+        else {
+            bool pos = (w & (1 << 12)) == 0;
+            w = (uint16_t)(w & ~(1 << 13));
+            if (!pos) w |= (1 << 15) | (1 << 14) | (1 << 13);
+        }
+    }
+    return (int16_t)w;
+}
+__device__ inline bool stc_is_almost_silent(const Line &l)   /* stc007line.cpp:568-599 */
+{
+    int n = 0;
+    for (int i = 0; i <= 5; i++) { int16_t s = stc_get_sample(l, i); if (!(s >= 16) && !(s < -16)) n++; }
+    return n >= 2;
+}
+__device__ inline bool has_control_block(const Line &l)      /* stc007line.cpp:493-504 */
+{
+    return l.words[0] == 0x3333 && l.words[1] == 0x0CCC && l.words[2] == 0x3333 && l.words[3] == 0x0CCC && l.words[4] == 0 && (l.words[7] & 0x0FF0) == 0;
+}
+__device__ inline void set_serv_ctrl_blk(Line &l)             /* stc007line.cpp:96-129 */
+{
+    uint16_t w4 = l.words[4], w5 = l.words[5], w6 = l.words[6], w7 = l.words[7];
+    uint32_t f = l.frame_number; uint16_t n = l.line_number;
+    stc_clear(l);
+    l.frame_number = f; l.line_number = n;
+    l.words[4] = w4; l.words[5] = w5; l.words[6] = w6; l.words[7] = w7;
+    l.calc_crc = crc16_words(l.words);
+    l.words[8] = l.calc_crc;
+    l.service = SDV_SRV_CTRL_BLOCK;
+}
+
+__device__ inline void line_to_rec(const Line &l, sdv_line_rec *r)
+{
+    r->frame_number = l.frame_number; r->line_number = l.line_number;
+    for (int i = 0; i < 9; i++) r->words[i] = l.words[i];
+    r->calc_crc = l.calc_crc;
+    r->data_start = l.coords.start; r->data_stop = l.coords.stop;
+    r->marker_start_bg_coord = l.m_st_bg; r->marker_start_ed_coord = l.m_st_ed; r->marker_stop_ed_coord = l.m_sp_ed;
+    r->black_level = l.black; r->white_level = l.white; r->ref_low = l.ref_low; r->ref_level = l.ref_level; r->ref_high = l.ref_high;
+    r->hysteresis_depth = l.hyst; r->shift_stage = l.shift; r->service_type = l.service;
+    r->mark_st_stage = l.mark_st; r->mark_ed_stage = l.mark_ed;
+    uint8_t f = 0;
+    if (l.ref_sweeped) f |= SDV_LF_REF_SWEEPED;
+    if (l.by_ext_tune) f |= SDV_LF_BY_EXT_TUNE;
+    if (l.bw_set) f |= SDV_LF_BW_SET;
+    if (l.coords_set) f |= SDV_LF_COORDS_SET;
+    if (l.forced_bad) f |= SDV_LF_FORCED_BAD;
+    if (crc_valid(l)) f |= SDV_LF_CRC_VALID;
+    if (l.coords.doubled) f |= SDV_LF_FROM_DOUBLED;
+    r->flags = f;
+    uint8_t ws = 0;
+    if (!l.forced_bad && l.word_crc07) ws |= SDV_WS_WORD_CRC;
+    if (!l.forced_bad && l.word_valid07) ws |= SDV_WS_WORD_VALID;
+    r->word_state = ws;
+}
+
+/* ======================================================================================== */
+/* Bit extraction                                                                            */
+/* ======================================================================================== */
+
+/* PCMLine::setPPB (pcmline.cpp:506-519) */
+__device__ inline void set_ppb(Line &l, const Coords &c)
+{
+    l.psm = (uint32_t)((int)c.stop - (int)c.start);
+    l.psm = (l.psm * 128u + BITS_BETWEEN / 2) / BITS_BETWEEN;
+    l.pso = c.start;
+    l.hpsm = (l.psm + 1) / 2;
+}
+/* PCMLine::getVideoPixeBylCalc (pcmline.cpp:249-311) for data bit `bit` (+3 START bits), before the
+ * per-stage pixel shift */
+__device__ __forceinline__ int32_t bit_center(const Line &l, int bit)
+{
+    uint32_t pcm_bit = (uint32_t)(bit + (BITS_START - 1));
+    int32_t vp = (int32_t)(pcm_bit * l.psm + l.hpsm);
+    vp = vp / 128;
+    return vp + l.pso;
+}
+__device__ __forceinline__ int32_t shift_clamp(const Line &l, int32_t vp, int stage)
+{
+    /* PIX_SH_BG_TBL == PIX_SH_ED_TBL == {0,+1,-1,+2,-2} (pcmline.h:63-71): the shift is uniform */
+    int sh = (stage == 0) ? 0 : ((stage & 1) ? ((stage + 1) >> 1) : -(stage >> 1));
+    vp += sh;
+    if (vp < (int32_t)l.pixel_start) vp = l.pixel_start;
+    else if (vp >= (int32_t)l.pixel_stop) vp = (int32_t)l.pixel_stop - 1;
+    return vp;
+}
+
+/* number of set bits of `m` strictly below this lane */
+__device__ __forceinline__ int prefix_count(uint64_t m)
+{
+    return __popcll(m & ((1ull << lane_id()) - 1ull));
+}
+
+/* Solves s[b] = s[b-1] ? B[b] : A[b], s[-1] = 0, for the 128 cells (the hysteresis automaton of
+ * Binarizer::fillSTC007, binarizer.cpp:7377-7399: A = "px > low", B = "px >= high").
+ * A==B cells force the state, A!=B cells keep (A=0,B=1) or toggle (A=1,B=0) it, so
+ *   s[b] = C[j] ^ parity(toggles in (j, b])   with j = last forcing cell <= b (or the initial 0).
+ * With PT = inclusive prefix parity of the toggle mask: s = PT ^ fill_forward((C ^ PT) at forcing cells).
+ * The fill-forward is done with one 128-bit integer addition (carry ripples through the non-forcing runs). */
+__device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, uint64_t &s_lo, uint64_t &s_hi)
+{
+    uint64_t e_lo = ~(a_lo ^ b_lo), e_hi = ~(a_hi ^ b_hi);       /* forcing cells */
+    uint64_t t_lo = a_lo & ~b_lo, t_hi = a_hi & ~b_hi;           /* toggling cells */
+    /* inclusive prefix parity of t, lane i owns cells i and i+64 */
+    int lane = lane_id();
+    int c_lo = prefix_count(t_lo) + (int)((t_lo >> lane) & 1);
+    int c_hi = __popcll(t_lo) + prefix_count(t_hi) + (int)((t_hi >> lane) & 1);
+    uint64_t pt_lo = __ballot(c_lo & 1);
+    uint64_t pt_hi = __ballot(c_hi & 1);
+    uint64_t u_lo = ((a_lo & b_lo) ^ pt_lo) & e_lo, u_hi = ((a_hi & b_hi) ^ pt_hi) & e_hi;   /* head values */
+    uint64_t x_lo = u_lo | ~e_lo, x_hi = u_hi | ~e_hi;
+    uint64_t y_lo = x_lo + u_lo;
+    uint64_t carry = (y_lo < x_lo) ? 1ull : 0ull;
+    uint64_t y_hi = x_hi + u_hi + carry;
+    uint64_t d_lo = ((y_lo ^ x_lo) & ~e_lo) | u_lo;
+    uint64_t d_hi = ((y_hi ^ x_hi) & ~e_hi) | u_hi;
+    s_lo = d_lo ^ pt_lo;
+    s_hi = d_hi ^ pt_hi;
+}
+
+__device__ __forceinline__ uint16_t rev14(uint32_t v) { return (uint16_t)(__brev(v) >> 18); }
+__device__ __forceinline__ uint16_t rev16(uint32_t v) { return (uint16_t)(__brev(v) >> 16); }
+
+/* Binarizer::fillSTC007 (binarizer.cpp:7322-7445) for the whole wave: samples the 128 cells from the
+ * LDS-staged scanline at pixel-shift `stage`, packs the words MSB first and recomputes the CRC. */
+__device__ inline void fill_stc007(Line &l, const WaveLds &lds, int32_t vp0, int32_t vp1, int stage)
+{
+    uint8_t p0 = lds.px[shift_clamp(l, vp0, stage)];
+    uint8_t p1 = lds.px[shift_clamp(l, vp1, stage)];
+    uint64_t a_lo = __ballot(p0 > l.ref_low), b_lo = __ballot(p0 >= l.ref_high);
+    uint64_t a_hi = __ballot(p1 > l.ref_low), b_hi = __ballot(p1 >= l.ref_high);
+    uint64_t s_lo, s_hi;
+    solve_automaton(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+    /* words: cell 14k..14k+13 -> word k, first cell = MSB */
+    l.words[0] = rev14((uint32_t)(s_lo & 0x3FFF));
+    l.words[1] = rev14((uint32_t)((s_lo >> 14) & 0x3FFF));
+    l.words[2] = rev14((uint32_t)((s_lo >> 28) & 0x3FFF));
+    l.words[3] = rev14((uint32_t)((s_lo >> 42) & 0x3FFF));
+    l.words[4] = rev14((uint32_t)(((s_lo >> 56) | (s_hi << 8)) & 0x3FFF));
+    l.words[5] = rev14((uint32_t)((s_hi >> 6) & 0x3FFF));
+    l.words[6] = rev14((uint32_t)((s_hi >> 20) & 0x3FFF));
+    l.words[7] = rev14((uint32_t)((s_hi >> 34) & 0x3FFF));
+    l.words[8] = rev16((uint32_t)((s_hi >> 48) & 0xFFFF));
+    l.word_crc07 = l.word_valid07 = false;            /* setWord(index, word) clears the flags of words 0..7 */
+    int lane = lane_id();
+    uint64_t klo = (lane < 16) ? c_crc.klo[lane & 15] : 0ull;
+    uint64_t khi = (lane < 16) ? c_crc.khi[lane & 15] : 0ull;
+    int par = (__popcll(s_lo & klo) + __popcll(s_hi & khi)) & 1;
+    uint64_t cb = __ballot(par);
+    l.calc_crc = (uint16_t)((uint16_t)(cb & 0xFFFF) ^ c_crc.init);
+}
+
+/* Binarizer::fillDataWords (binarizer.cpp:7560-7691) */
+__device__ inline bool fill_data_words(Line &l, const WaveLds &lds, int32_t vp0, int32_t vp1, uint8_t ref_delta, uint8_t shift_stg)
+{
+    if (ref_delta > HYST_DEPTH_MAX) return false;
+    if (shift_stg > SHIFT_STAGES_MAX) return false;
+    uint8_t low_ref = get_low_level(l.ref_level, ref_delta), high_ref = get_high_level(l.ref_level, ref_delta);
+    l.ref_low = low_ref; l.ref_high = high_ref;
+    if (low_ref <= l.black) { set_invalid_crc(l); return false; }
+    if (high_ref >= l.white) { set_invalid_crc(l); return false; }
+    l.hyst = ref_delta; l.shift = shift_stg;
+    fill_stc007(l, lds, vp0, vp1, shift_stg);
+    return true;
+}
+
+/* Binarizer::readPCMdata (binarizer.cpp:7695-8055).  The CRC bookkeeping arrays of the reference
+ * (shift_crcs/hyst_crcs/crc_stats) reduce, for a single candidate, to "first (hysteresis, shift) pair in
+ * lexicographic order with a valid CRC, else (0,0)"; the ladder stops at the first hysteresis depth whose
+ * levels leave (black, white). */
+__device__ inline void read_pcm_data(Bin &b, Line &l, const WaveLds &lds)
+{
+    set_ppb(l, l.coords);
+    int lane = lane_id();
+    int32_t vp0 = bit_center(l, lane), vp1 = bit_center(l, lane + 64);
+    if (b.hyst_lim > HYST_DEPTH_MAX) b.hyst_lim = HYST_DEPTH_MAX;
+    if (b.shift_lim > SHIFT_STAGES_MAX) b.shift_lim = SHIFT_STAGES_MAX;
+    uint8_t valid_delta, valid_shift;
+    if (!l.ref_sweeped) {
+        valid_delta = 0; valid_shift = 0;
+        bool found = false, last_is_target = false;
+        for (int h = 0; h <= (int)b.hyst_lim && !found; h++) {
+            bool invalid_hyst = false;
+            for (int s = 0; s <= (int)b.shift_lim; s++) {
+                if (!fill_data_words(l, lds, vp0, vp1, (uint8_t)h, (uint8_t)s)) { invalid_hyst = true; break; }
+                if (crc_valid(l)) { found = true; valid_delta = (uint8_t)h; valid_shift = (uint8_t)s; last_is_target = true; break; }
+            }
+            if (invalid_hyst) break;
+        }
+        if (last_is_target) return;    /* the final re-read with the winning pair is idempotent */
+    } else {
+        valid_delta = b.hyst_lim; valid_shift = b.shift_lim;
+    }
+    fill_data_words(l, lds, vp0, vp1, valid_delta, valid_shift);
+}
+
+/* ======================================================================================== */
+/* Serial (one candidate per lane) versions used inside the lane-parallel searches           */
+/* ======================================================================================== */
+
+/* Binarizer::searchSTC007Markers (binarizer.cpp:5275-5595) for one hysteresis level; pure function of the
+ * staged scanline, the line's ref_level and the scan limits.  Runs independently in every lane. */
+__device__ inline Markers search_markers(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, uint8_t ref_level, uint8_t hyst_lvl)
+{
+    Markers m;
+    uint8_t stage = MARK_ST_START, pv;
+    uint8_t bin_level = ref_level;
+    uint8_t bin_low = get_low_level(bin_level, hyst_lvl);
+    if (bin_low < ps.min_ref_lvl) bin_low = ps.min_ref_lvl;
+    uint8_t bin_high = bin_level;
+    uint16_t st1s = 0, st1e = 0, st3s = 0, st3e = 0;
+    uint16_t pixel_limit = (uint16_t)(b.mark_start_max + b.estimated_ppb * 5);
+    if (pixel_limit > b.line_length) pixel_limit = b.line_length;
+    uint16_t pixel = b.scan_start;
+    while (pixel < pixel_limit) {
+        pv = lds.px[pixel];
+        if (stage == MARK_ST_START) {
+            if (pixel > b.mark_start_max) break;
+            if (pv >= bin_low) { st1s = pixel; stage = MARK_ST_TOP_1; }
+        } else if (stage == MARK_ST_TOP_1) {
+            if (pv < bin_low) { st1e = pixel; stage = MARK_ST_BOT_1; }
+        } else if (stage == MARK_ST_BOT_1) {
+            if (pv >= bin_high) {
+                st3s = pixel;
+                if (((st3s - st1e) > (b.estimated_ppb * 2)) || ((st3s - st1e) < (b.estimated_ppb / 2))) stage = MARK_ST_START;
+                else stage = MARK_ST_TOP_2;
+            }
+        } else if (stage == MARK_ST_TOP_2) {
+            if (pv < bin_high) {
+                st3e = pixel;
+                if (((st3e - st3s) > (b.estimated_ppb * 2)) || ((st3e - st3s) < (b.estimated_ppb / 2))) stage = MARK_ST_START;
+                else { stage = MARK_ST_BOT_2; break; }
+            }
+        }
+        pixel++;
+    }
+    m.st_stage = stage; m.st1s = st1s; m.st1e = st1e; m.st3e = st3e;
+    m.has_start = (stage == MARK_ST_BOT_2);
+    stage = MARK_ED_START;
+    uint16_t ed_start = 0, ed_end = 0;
+    if (m.has_start) {
+        bin_low = bin_level;
+        if (b.mark_end_min > (b.estimated_ppb * 6)) pixel_limit = (uint16_t)(b.mark_end_min - b.estimated_ppb * 6);
+        else pixel_limit = 0;
+        pixel = b.scan_end;
+        while (pixel > pixel_limit) {
+            pv = lds.px[pixel];
+            if (stage == MARK_ED_START) {
+                if (pixel < b.mark_end_min) break;
+                if (pv >= bin_low) { ed_end = (uint16_t)(pixel + 1); stage = MARK_ED_TOP; }
+            } else if (stage == MARK_ED_TOP) {
+                if (pv < bin_high) {
+                    ed_start = (uint16_t)(pixel + 1);
+                    stage = MARK_ED_BOT;
+                    if (((ed_end - ed_start) >= (b.estimated_ppb * 2)) && ((ed_end - ed_start) <= (b.estimated_ppb * 5))) { stage = MARK_ED_LEN_OK; break; }
+                    else stage = MARK_ED_START;
+                }
+            }
+            pixel--;
+        }
+    }
+    m.ed_stage = stage; m.ed_start = ed_start; m.ed_end = ed_end;
+    return m;
+}
+
+/* applies a search result to a line exactly as the tail of searchSTC007Markers does (:5459-5594) */
+__device__ inline void apply_markers(Line &l, const Markers &m)
+{
+    l.mark_st = m.st_stage; l.m_st_bg = m.st1s; l.m_st_ed = m.st3e;
+    if (m.has_start) l.mark_ed = m.ed_stage;
+    coords_set(l.coords, (int16_t)m.st1e, (int16_t)m.ed_start);
+    l.m_sp_ed = m.ed_end;
+    l.coords_set = has_markers(l);
+}
+
+/* Binarizer::findSTC007Coordinates (binarizer.cpp:6047-6113), per-lane serial version (used inside the
+ * reference sweep where every lane owns a different reference level). */
+__device__ inline void find_coordinates_serial(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, Line &l)
+{
+    uint8_t best_hyst = 0;
+    bool have = false; uint32_t best_key = 0;
+    uint8_t carried_ed = l.mark_ed;      /* temp_line keeps mark_ed_stage between iterations when START is missing */
+    for (uint8_t h = 0; h < 24; h++) {
+        Markers m = search_markers(b, ps, lds, l.ref_level, h);
+        if (m.has_start) carried_ed = m.ed_stage;
+        if (m.has_start && carried_ed == MARK_ED_LEN_OK) {
+            uint32_t k = coords_key((int16_t)m.st1e, (int16_t)m.ed_start);
+            if (!have || k < best_key) { best_key = k; best_hyst = h; have = true; }   /* ties keep the lower hysteresis */
+        }
+    }
+    Markers m = search_markers(b, ps, lds, l.ref_level, best_hyst);
+    apply_markers(l, m);
+}
+
+/* wave-parallel version: lanes 0..23 each try one hysteresis level */
+__device__ inline void find_coordinates_wave(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, Line &l)
+{
+    int lane = lane_id();
+    uint8_t h = (uint8_t)(lane < 24 ? lane : 23);
+    Markers m = search_markers(b, ps, lds, l.ref_level, h);
+    bool ok = (lane < 24) && m.has_start && (m.ed_stage == MARK_ED_LEN_OK);
+    uint32_t k = coords_key((int16_t)m.st1e, (int16_t)m.ed_start);
+    uint64_t okm = __ballot(ok);
+    int best = 0;
+    if (okm != 0) {
+        /* minimum key, lowest lane on ties: tournament over the (at most 24) candidates */
+        uint32_t best_key = 0xFFFFFFFFu; bool have = false;
+        for (int i = 0; i < 24; i++) {
+            uint32_t ki = (uint32_t)__shfl((int)k, i);
+            if ((okm >> i) & 1ull) { if (!have || ki < best_key) { best_key = ki; best = i; have = true; } }
+        }
+    }
+    /* final search with the chosen level == that lane's result */
+    Markers r;
+    r.st_stage = (uint8_t)__shfl((int)m.st_stage, best);
+    r.ed_stage = (uint8_t)__shfl((int)m.ed_stage, best);
+    r.st1s = (uint16_t)__shfl((int)m.st1s, best);
+    r.st1e = (uint16_t)__shfl((int)m.st1e, best);
+    r.st3e = (uint16_t)__shfl((int)m.st3e, best);
+    r.ed_start = (uint16_t)__shfl((int)m.ed_start, best);
+    r.ed_end = (uint16_t)__shfl((int)m.ed_end, best);
+    r.has_start = (r.st_stage == MARK_ST_BOT_2);
+    apply_markers(l, r);
+}
+
+/* serial fill (one lane = one candidate): Binarizer::fillSTC007 literally */
+__device__ inline void fill_stc007_serial(Line &l, const WaveLds &lds, int stage)
+{
+    bool prev_high = false;
+    uint16_t w = 0; int bitpos = 13, widx = 0;
+    uint16_t crc = 0xFFFF;
+    for (int bit = 0; bit < BITS_DATA; bit++) {
+        uint8_t pv = lds.px[shift_clamp(l, bit_center(l, bit), stage)];
+        int v;
+        if (!prev_high) { v = pv > l.ref_low; if (v) prev_high = true; }
+        else { v = pv >= l.ref_high; if (!v) prev_high = false; }
+        if (v) w |= (uint16_t)(1u << bitpos);
+        if (bit < 112) crc = crc16_step(crc, v);
+        if (bitpos == 0) {
+            l.words[widx] = w; w = 0; widx++;
+            bitpos = (bit == 111) ? 16 : 14;
+        }
+        bitpos--;
+    }
+    l.word_crc07 = l.word_valid07 = false;
+    l.calc_crc = crc;
+}
+__device__ inline bool fill_data_words_serial(Line &l, const WaveLds &lds, uint8_t ref_delta, uint8_t shift_stg)
+{
+    if (ref_delta > HYST_DEPTH_MAX) return false;
+    if (shift_stg > SHIFT_STAGES_MAX) return false;
+    uint8_t low_ref = get_low_level(l.ref_level, ref_delta), high_ref = get_high_level(l.ref_level, ref_delta);
+    l.ref_low = low_ref; l.ref_high = high_ref;
+    if (low_ref <= l.black) { set_invalid_crc(l); return false; }
+    if (high_ref >= l.white) { set_invalid_crc(l); return false; }
+    l.hyst = ref_delta; l.shift = shift_stg;
+    fill_stc007_serial(l, lds, shift_stg);
+    return true;
+}
+__device__ inline void read_pcm_data_serial(uint8_t hyst_lim, uint8_t shift_lim, Line &l, const WaveLds &lds)
+{
+    set_ppb(l, l.coords);
+    if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
+    if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
+    uint8_t valid_delta = 0, valid_shift = 0;
+    bool found = false;
+    for (int h = 0; h <= (int)hyst_lim && !found; h++) {
+        bool invalid_hyst = false;
+        for (int s = 0; s <= (int)shift_lim; s++) {
+            if (!fill_data_words_serial(l, lds, (uint8_t)h, (uint8_t)s)) { invalid_hyst = true; break; }
+            if (crc_valid(l)) { found = true; valid_delta = (uint8_t)h; valid_shift = (uint8_t)s; break; }
+        }
+        if (invalid_hyst) break;
+    }
+    if (found) return;
+    fill_data_words_serial(l, lds, valid_delta, valid_shift);
+}
+
+
+/* ======================================================================================== */
+/* AGC: BLACK / WHITE levels                                                                 */
+/* ======================================================================================== */
+
+__device__ inline void hist_clear(WaveLds &lds)
+{
+    __syncthreads();
+    for (int i = lane_id(); i < 256; i += 64) lds.hist[i] = 0;
+    __syncthreads();
+}
+/* adds pixels [from, to) (ascending) to the histogram, lanes striding */
+__device__ inline void hist_add_range(WaveLds &lds, int from, int to)
+{
+    for (int p = from + lane_id(); p < to; p += 64) atomicAdd(&lds.hist[lds.px[p]], 1u);
+    __syncthreads();
+}
+
+/* brightness-spread counters are uint16_t in the reference (binarizer.cpp:3125): a line is at most
+ * 65535 px (uint16_t line_length), so no counter can wrap - 32-bit LDS counters are equivalent. */
+__device__ inline uint16_t most_frequent_brightness_count(const WaveLds &lds)   /* :2450-2468 */
+{
+    uint32_t hf = 0;
+    for (int lev = 255; lev >= 0; lev--) if (lds.hist[lev] > hf) hf = lds.hist[lev];
+    return (uint16_t)hf;
+}
+__device__ inline uint8_t usefull_low_level(const sdv_bin_preset &ps, const WaveLds &lds)   /* :2471-2513 */
+{
+    bool filtered_found = false;
+    uint8_t brt_lev = 0, lowest_lev = 0;
+    uint16_t min_freq = most_frequent_brightness_count(lds) / 64;
+    while (brt_lev < ps.max_black_lvl) {
+        if (lds.hist[brt_lev] > min_freq) { lowest_lev = brt_lev; filtered_found = true; break; }
+        brt_lev++;
+    }
+    if (!filtered_found)
+        while (brt_lev < ps.max_black_lvl) {
+            if (lds.hist[brt_lev] > 0) { lowest_lev = brt_lev; break; }
+            brt_lev++;
+        }
+    return lowest_lev;
+}
+__device__ inline uint8_t usefull_high_level(const sdv_bin_preset &ps, const WaveLds &lds)  /* :2516-2557 */
+{
+    uint8_t brt_lev = 255, highest_lev = 255;
+    uint16_t min_freq = most_frequent_brightness_count(lds) / 64;
+    while (brt_lev >= ps.min_white_lvl) {
+        if (lds.hist[brt_lev] > min_freq) { highest_lev = brt_lev; break; }
+        brt_lev--;
+    }
+    /* filtered_found is never set in the reference, so the unfiltered pass always follows */
+    while (brt_lev >= ps.min_white_lvl) {
+        if (lds.hist[brt_lev] > 0) { highest_lev = brt_lev; break; }
+        brt_lev--;
+    }
+    return highest_lev;
+}
+
+/* Binarizer::findSTC007BW (binarizer.cpp:2684-3070); leaves the brightness spread to analyse in lds.hist */
+__device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &line)
+{
+    uint8_t brt_lev, stage, br_mark_white, useful_low, useful_high, high_scan_limit, low_scan_limit, range_limit, bin_level, bin_low, bin_high, pv;
+    uint16_t pixel, pixel_limit, ed_start, ed_end, search_lim;
+    uint32_t white_lvl_count, temp_calc;
+    bool white_level_detected;
+
+    hist_clear(lds);
+    search_lim = (uint16_t)(b.scan_start + b.estimated_ppb * 10);
+    hist_add_range(lds, b.scan_start, search_lim);
+    search_lim = (uint16_t)(b.scan_end - b.estimated_ppb * 20);
+    hist_add_range(lds, search_lim, (int)b.scan_end + 1);
+
+    useful_low = low_scan_limit = usefull_low_level(ps, lds);
+    useful_high = high_scan_limit = br_mark_white = usefull_high_level(ps, lds);
+    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
+    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 4));
+    bin_high = range_limit / 8;
+    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
+    while (brt_lev >= high_scan_limit) {
+        if (lds.hist[brt_lev] > white_lvl_count) { white_lvl_count = lds.hist[brt_lev]; br_mark_white = brt_lev; white_level_detected = true; }
+        if (white_level_detected) if (((int)br_mark_white - (int)brt_lev) >= (int)bin_high) break;
+        brt_lev--;
+    }
+    pixel_limit = (uint16_t)(b.scan_end - b.scan_start);
+    temp_calc = pixel_limit / 8;
+    pixel_limit = (uint16_t)(b.scan_start + (uint16_t)temp_calc);
+    search_lim = (uint16_t)(b.scan_end - (uint16_t)temp_calc);
+    hist_clear(lds);
+    hist_add_range(lds, pixel_limit, search_lim);
+
+    stage = MARK_ED_START; ed_start = ed_end = 0;
+    if (white_level_detected) {
+        bin_level = pick_center_ref_level(ps, useful_low, br_mark_white);
+        bin_high = bin_low = bin_level;
+        if (b.mark_end_min > (b.estimated_ppb * 6)) pixel_limit = (uint16_t)(b.mark_end_min - b.estimated_ppb * 6);
+        else pixel_limit = 0;
+        pixel = b.scan_end;
+        while (pixel > pixel_limit) {
+            pv = lds.px[pixel];
+            if (stage == MARK_ED_START) {
+                if (pixel < b.mark_end_min) break;
+                if (pv >= bin_low) { ed_end = (uint16_t)(pixel + 1); stage = MARK_ED_TOP; }
+            } else if (stage == MARK_ED_TOP) {
+                if (pv < bin_high) {
+                    ed_start = (uint16_t)(pixel + 1);
+                    stage = MARK_ED_BOT;
+                    if ((ed_end - ed_start) >= (b.estimated_ppb * 2)) { stage = MARK_ED_LEN_OK; break; }
+                    else stage = MARK_ED_START;
+                }
+            }
+            pixel--;
+        }
+        line.mark_ed = stage;
+        line.coords.stop = (int16_t)ed_start;
+        line.m_sp_ed = ed_end;
+        if (has_stop(line)) {
+            search_lim = (uint16_t)(b.estimated_ppb * 64);
+            if (search_lim > ed_start) search_lim = b.mark_start_max;
+            else search_lim = (uint16_t)(ed_start - search_lim);
+            hist_clear(lds);
+            /* pixels ed_start-1 down to search_lim+1 */
+            int cnt = ((int)ed_start - 1) - (int)search_lim;
+            if (cnt < 0) cnt = 0;
+            hist_add_range(lds, (int)search_lim + 1, (int)ed_start);
+            if (cnt < 32) {
+                pixel_limit = (uint16_t)(b.scan_end - b.scan_start);
+                pixel_limit = pixel_limit / 8;
+                search_lim = (uint16_t)(b.scan_end - pixel_limit);
+                hist_add_range(lds, pixel_limit, search_lim);
+            }
+        }
+    }
+}
+
+/* Binarizer::findBlackWhite (binarizer.cpp:3116-3473), STC-007 branch */
+__device__ inline bool find_black_white(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &line)
+{
+    uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
+    uint32_t black_lvl_count, white_lvl_count, temp_calc;
+    uint16_t search_lim;
+    bool black_level_detected, white_level_detected;
+
+    find_stc007_bw(b, ps, lds, line);
+
+    useful_low = low_scan_limit = br_black = usefull_low_level(ps, lds);
+    useful_high = high_scan_limit = br_white = usefull_high_level(ps, lds);
+    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
+    low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
+    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
+    temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
+    temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
+    search_lim = most_frequent_brightness_count(lds);
+    search_lim = search_lim / 64;
+
+    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
+    while (brt_lev <= low_scan_limit) {
+        if (lds.hist[brt_lev] > black_lvl_count) {
+            black_lvl_count = lds.hist[brt_lev];
+            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
+        }
+        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
+        brt_lev++;
+    }
+    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
+    if (black_level_detected) {
+        while (brt_lev >= high_scan_limit) {
+            if ((int)brt_lev < ((int)br_black + (int)ps.min_contrast)) break;
+            if (lds.hist[brt_lev] > white_lvl_count) {
+                white_lvl_count = lds.hist[brt_lev];
+                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
+            }
+            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
+            brt_lev--;
+        }
+    }
+    if (black_level_detected && white_level_detected) {
+        bool invalidate = false;
+        if (br_white < br_black) invalidate = true;
+        else if (((int)br_white - (int)br_black) < (int)ps.min_contrast) invalidate = true;
+        else if (b.do_ref_lvl_sweep && (((int)br_white - (int)br_black) < (int)ps.min_valid_crcs)) invalidate = true;
+        else if (br_black > ps.max_black_lvl) invalidate = true;
+        else if (br_white < ps.min_white_lvl) invalidate = true;
+        if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
+    }
+    b.was_bw_scanned = true;
+    line.black = br_black; line.white = br_white;
+    line.bw_set = black_level_detected && white_level_detected;
+    return line.bw_set;
+}
+
+/* ======================================================================================== */
+/* CRC statistics (binarizer.cpp:1771-2383) on LDS arrays; serial, wave-uniform               */
+/* ======================================================================================== */
+
+__device__ inline void crc_stats_reset(WaveLds &lds, int count)
+{
+    for (int i = 0; i < count; i++) { lds.crc_stats[i].result = 0; lds.crc_stats[i].crc = 0; lds.crc_stats[i].hyst = lds.crc_stats[i].shift = 0x0f; lds.crc_stats[i].idx = 0; }
+}
+__device__ inline void crc_stats_update(WaveLds &lds, uint16_t crc, uint8_t hyst, uint8_t shift, uint8_t &valid_cnt)   /* :1789-1826 */
+{
+    bool found = false;
+    if (valid_cnt >= MAX_COLL_CRCS) valid_cnt = MAX_COLL_CRCS - 1;
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (lds.crc_stats[i].crc == crc) { lds.crc_stats[i].result++; found = true; break; }
+    if (!found) {
+        valid_cnt++;
+        if (valid_cnt < MAX_COLL_CRCS) {
+            lds.crc_stats[valid_cnt].crc = crc; lds.crc_stats[valid_cnt].hyst = hyst; lds.crc_stats[valid_cnt].shift = shift;
+            lds.crc_stats[valid_cnt].result++;
+        }
+    }
+}
+__device__ inline void crc_stats_most_frequent(WaveLds &lds, uint8_t &valid_cnt)   /* :1829-1928, skip_equal = true */
+{
+    CrcStat *a = lds.crc_stats;
+    a[0].result = 0; a[0].idx = 0; a[0].hyst = 0; a[0].shift = 0;
+    if (valid_cnt >= MAX_COLL_CRCS) valid_cnt = MAX_COLL_CRCS - 1;
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[i].result > a[0].result) { a[0].result = a[i].result; a[0].crc = a[i].crc; a[0].hyst = a[i].hyst; a[0].shift = a[i].shift; a[0].idx = i; }
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[0].idx != i)
+            if ((int)a[0].result <= (2 * (int)a[i].result)) { a[0].result = 0; a[0].hyst = 0; a[0].shift = 0; break; }
+    if (a[0].result == 0) valid_cnt = 0;
+}
+__device__ inline void sweep_invalidate_non_frequent(WaveLds &lds, uint8_t low_level, uint8_t high_level, uint8_t valid_cnt, uint16_t target_crc)   /* :1931-1982 */
+{
+    uint8_t index = high_level;
+    while (index >= low_level) {
+        if (lds.sweep[index].result == REF_CRC_OK)
+            if ((valid_cnt == 0) || (lds.sweep[index].crc != target_crc)) lds.sweep[index].result = REF_CRC_COLL;
+        if (index == low_level) break;
+        index--;
+    }
+}
+__device__ inline uint8_t pick_level_by_crc_stats(const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+                                                  uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :1985-2140 */
+{
+    const SweepEnt *crcs = lds.sweep;
+    bool good_ref_det = false, range_lock = false, second_start_lock = false;
+    uint8_t index, low_depth = 0xFF, low_shift = 0xFF, low_ref = 0, high_ref = 0, tst_low_ref = 0, tst_high_ref = 0, picked_ref;
+    index = high_lvl;
+    while (index >= low_lvl) {
+        if ((crcs[index].result == target_result) && (crcs[index].hyst <= max_hyst) && (crcs[index].shift <= max_shift)) {
+            good_ref_det = true;
+            if (crcs[index].hyst < low_depth) { low_depth = crcs[index].hyst; low_shift = crcs[index].shift; high_ref = index; }
+            else if (crcs[index].hyst == low_depth) if (crcs[index].shift < low_shift) { low_shift = crcs[index].shift; high_ref = index; }
+        }
+        if (index == low_lvl) break;
+        index--;
+    }
+    if (!good_ref_det) return SPAN_NOT_FOUND;
+    index = high_ref;
+    while (index >= low_lvl) {
+        if ((crcs[index].result == target_result) && (crcs[index].hyst == low_depth) && (crcs[index].shift == low_shift)) {
+            if (!range_lock) low_ref = index;
+            else { if (!second_start_lock) { tst_high_ref = index; second_start_lock = true; } tst_low_ref = index; }
+        } else {
+            range_lock = true;
+            if (second_start_lock) {
+                second_start_lock = false;
+                if (((int)tst_high_ref - (int)tst_low_ref) >= ((int)high_ref - (int)low_ref)) { low_ref = tst_low_ref; high_ref = tst_high_ref; }
+            }
+        }
+        if (index == low_lvl) break;
+        index--;
+    }
+    picked_ref = (uint8_t)(high_ref - low_ref);
+    picked_ref = picked_ref / 2;
+    picked_ref = (uint8_t)(low_ref + picked_ref);
+    *ref_result = picked_ref;
+    return SPAN_OK;
+}
+__device__ inline uint8_t pick_level_by_crc_stats_opt(const sdv_bin_preset &ps, const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+                                                      uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :2143-2383 */
+{
+    const SweepEnt *crcs = lds.sweep;
+    bool range_lock = false, good_ref_det = false;
+    uint8_t index, hold_cnt, same_cnt, low_depth, low_shift = 0, high_shift = 0, low_ref = 0, high_ref = 0, picked_ref;
+    index = high_lvl;
+    while (index >= low_lvl) {
+        if ((crcs[index].result == target_result) && (crcs[index].hyst <= max_hyst) && (crcs[index].shift <= max_shift)) {
+            if (!good_ref_det) { good_ref_det = true; low_ref = high_ref = index; }
+            else { low_ref = index; if (low_ref == low_lvl) { low_shift = low_ref; high_shift = high_ref; range_lock = true; } }
+        } else if (good_ref_det) {
+            if (((int)high_ref - (int)low_ref + 1) >= ((int)high_shift - (int)low_shift + 1)) { low_shift = low_ref; high_shift = high_ref; range_lock = true; }
+            good_ref_det = false;
+        }
+        if (index == low_lvl) break;
+        index--;
+    }
+    if (range_lock) { high_lvl = high_shift; low_lvl = low_shift; }
+    good_ref_det = false;
+    hold_cnt = 0; low_depth = low_shift = 255; same_cnt = MIN_VALID_CRCS;
+    low_ref = high_ref = ps.max_ref_lvl;
+    index = high_lvl;
+    while (index >= low_lvl) {
+        if ((crcs[index].result == target_result) && (crcs[index].hyst <= max_hyst) && (crcs[index].shift <= max_shift)) {
+            good_ref_det = true;
+            if (low_depth > crcs[index].hyst) { low_depth = crcs[index].hyst; low_shift = crcs[index].shift; low_ref = high_ref = index; hold_cnt = MIN_VALID_CRCS; }
+            else if (low_depth == crcs[index].hyst) {
+                if (low_shift > crcs[index].shift) { low_shift = crcs[index].shift; low_ref = high_ref = index; same_cnt = MIN_VALID_CRCS; hold_cnt = MIN_VALID_CRCS; }
+                else if (low_shift == crcs[index].shift) { low_ref = index; same_cnt--; if (same_cnt == 0) { hold_cnt = 0; break; } }
+                else { hold_cnt--; if (hold_cnt == 0) break; }
+            } else { hold_cnt--; if (hold_cnt == 0) break; }
+        }
+        if (index == low_lvl) break;
+        index--;
+    }
+    if (good_ref_det) {
+        picked_ref = (uint8_t)(high_ref - low_ref);
+        picked_ref = picked_ref / 2;
+        picked_ref = (uint8_t)(low_ref + picked_ref);
+        *ref_result = picked_ref;
+        return SPAN_OK;
+    }
+    return SPAN_NOT_FOUND;
+}
+
+/* ======================================================================================== */
+/* Reference level sweep (binarizer.cpp:3551-4120)                                           */
+/* ======================================================================================== */
+
+__device__ inline void calc_forced_coords(const Bin &b, const sdv_bin_preset &ps, Coords &fc)   /* :631-641 */
+{
+    coords_clear(fc);
+    if (ps.en_force_coords) {
+        fc.start = (int16_t)((int16_t)b.scan_start + ps.horiz_start);
+        fc.stop = (int16_t)((int16_t)b.scan_end - ps.horiz_stop);
+        if (b.vl_doubled) { fc.start = (int16_t)(fc.start + ps.horiz_start); fc.stop = (int16_t)(fc.stop - ps.horiz_stop); }
+    }
+}
+
+/* One sweep level (body of the while loop, :3626-3816) evaluated by ONE lane from a given carried
+ * source-CRC word.  Returns the entry to store (result REF_NO_PCM = nothing stored). */
+__device__ inline SweepEnt sweep_one_level(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, const Coords &forced_coords,
+                                           uint8_t low_lvl, uint8_t high_lvl, uint8_t ref_index, uint16_t carried_word8, uint8_t carried_mark_ed,
+                                           uint16_t *word8_out, uint8_t *mark_ed_out, bool *did_read)
+{
+    Line t;
+    stc_clear(t);                       /* only the base part matters; STC parts that persist are passed in explicitly */
+    pcmline_clear(t);                   /* :3629 PCMLine::clear(): calc_crc = 0 */
+    t.words[8] = carried_word8;
+    t.mark_ed = carried_mark_ed;
+    set_source_pixels(t, 0, (uint16_t)(b.line_length - 1));
+    t.coords.doubled = b.vl_doubled;
+    t.black = low_lvl; t.white = high_lvl; t.ref_level = ref_index;
+    bool read = false;
+    if (!coords_valid(forced_coords)) {
+        if (coords_valid(b.in_coord)) {
+            bool skip_bin = false;
+            if (ps.en_good_no_marker) {
+                find_coordinates_serial(b, ps, lds, t);
+                if (!has_markers(t)) skip_bin = true;
+            }
+            if (skip_bin) { t.coords = b.in_coord; read_pcm_data_serial(b.hyst_lim, b.shift_lim, t, lds); read = true; }
+        }
+    }
+    if (!crc_valid(t)) {
+        if (!coords_valid(forced_coords)) find_coordinates_serial(b, ps, lds, t);
+        else { t.coords = forced_coords; t.coords_set = true; }
+        if (t.coords_set) { read_pcm_data_serial(b.hyst_lim, b.shift_lim, t, lds); read = true; }
+    }
+    if (t.hyst > 0x0F) t.hyst = 0x0F;
+    SweepEnt e; e.result = REF_NO_PCM; e.hyst = 0; e.shift = 0; e.pad = 0; e.crc = 0; e.start = 0; e.stop = 0; e.pad2 = 0;
+    if (crc_valid(t) && coords_valid(t.coords)) e.result = REF_CRC_OK;
+    else if (t.coords_set) e.result = REF_BAD_CRC;
+    if (e.result != REF_NO_PCM) { e.start = t.coords.start; e.stop = t.coords.stop; e.hyst = t.hyst; e.shift = t.shift; e.crc = t.calc_crc; }
+    *word8_out = t.words[8]; *mark_ed_out = t.mark_ed; *did_read = read;
+    return e;
+}
+
+/* Binarizer::sweepRefLevel: lanes take levels high_lvl, high_lvl-1, ...  Level L of the reference starts
+ * from whatever source-CRC word level L+1 left in the shared temp line (PCMLine::clear() through a base
+ * pointer does not reset the STC007Line part, :3629).  That word only matters when it is 0x0000 (then
+ * "calc_crc == source CRC" holds before anything was read), so levels are evaluated independently with a
+ * non-zero carried word and the whole sweep is replayed serially in the rare case any level left 0x0000. */
+__device__ inline void sweep_ref_level(const Bin &b, const sdv_bin_preset &ps, WaveLds &lds, const Line &pcm_line)
+{
+    Coords forced_coords; calc_forced_coords(b, ps, forced_coords);
+    uint8_t low_lvl = (uint8_t)(pcm_line.black + 1), high_lvl = (uint8_t)(pcm_line.white - 1);
+    if (ps.min_ref_lvl > low_lvl) low_lvl = ps.min_ref_lvl;
+    if (ps.max_ref_lvl < high_lvl) high_lvl = ps.max_ref_lvl;
+    int lane = lane_id();
+    bool zero_seen = false;
+    uint16_t silent_word8 = (uint16_t)~CRC_SILENT;
+    for (int base = (int)high_lvl; base >= (int)low_lvl; base -= 64) {
+        int lvl = base - lane;
+        bool active = lvl >= (int)low_lvl;
+        uint16_t w8 = silent_word8; uint8_t med = MARK_ED_START; bool rd = false;
+        SweepEnt e; e.result = REF_NO_PCM; e.hyst = 0; e.shift = 0; e.pad = 0; e.crc = 0; e.start = 0; e.stop = 0; e.pad2 = 0;
+        if (active) {
+            e = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, silent_word8, MARK_ED_START, &w8, &med, &rd);
+            if (e.result != REF_NO_PCM) lds.sweep[lvl] = e;
+            if (rd && w8 == 0) zero_seen = true;
+        }
+        if (__ballot(zero_seen) != 0ull) zero_seen = true;
+    }
+    __syncthreads();
+    if (zero_seen) {
+        /* exact serial replay (all lanes redundantly, results identical) */
+        for (int i = lane; i < 256; i += 64) { SweepEnt z; z.result = 0; z.hyst = z.shift = 0x0f; z.pad = 0; z.crc = 0; z.start = z.stop = 0; z.pad2 = 0; lds.sweep[i] = z; }
+        __syncthreads();
+        uint16_t w8 = silent_word8; uint8_t med = MARK_ED_START;
+        for (int lvl = (int)high_lvl; lvl >= (int)low_lvl; lvl--) {
+            bool rd; uint16_t w8n; uint8_t medn;
+            SweepEnt e = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, w8, med, &w8n, &medn, &rd);
+            w8 = w8n; med = medn;
+            if (e.result != REF_NO_PCM && lane == 0) lds.sweep[lvl] = e;
+        }
+        __syncthreads();
+    }
+}
+
+/* Binarizer::calcRefLevelBySweep (binarizer.cpp:3821-4120) */
+__device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &l)
+{
+    uint8_t fast_ref, valid_crc_cnt = 0, span_res;
+    Coords forced_coords;
+    fast_ref = pick_center_ref_level(ps, l.black, l.white);
+    b.hyst_lim = b.in_max_hyst; b.shift_lim = b.in_max_shift;
+    calc_forced_coords(b, ps, forced_coords);
+    __syncthreads();
+    for (int i = lane_id(); i < 256; i += 64) { SweepEnt z; z.result = 0; z.hyst = z.shift = 0x0f; z.pad = 0; z.crc = 0; z.start = z.stop = 0; z.pad2 = 0; lds.sweep[i] = z; }
+    __syncthreads();
+    sweep_ref_level(b, ps, lds, l);
+    span_res = SPAN_NOT_FOUND;
+    __syncthreads();
+    if (lane_id() == 0) { crc_stats_reset(lds, MAX_COLL_CRCS + 1); lds.crc_stats[0].hyst = 0; lds.crc_stats[0].shift = 0; }
+    __syncthreads();
+    /* statistics and vote: serial; lane 0 mutates LDS, everyone then reads the same values */
+    uint8_t blk1 = (uint8_t)(l.black + 1), wht1 = (uint8_t)(l.white - 1);
+    if (lane_id() == 0) {
+        for (uint8_t bin_level = wht1; bin_level > l.black; bin_level--)
+            if (lds.sweep[bin_level].result == REF_CRC_OK) crc_stats_update(lds, lds.sweep[bin_level].crc, lds.sweep[bin_level].hyst, lds.sweep[bin_level].shift, valid_crc_cnt);
+        uint8_t first_cnt = valid_crc_cnt;
+        if (valid_crc_cnt > 0) {
+            crc_stats_most_frequent(lds, valid_crc_cnt);
+            sweep_invalidate_non_frequent(lds, blk1, wht1, valid_crc_cnt, lds.crc_stats[0].crc);
+        }
+        lds.crc_stats[0].idx = (uint8_t)((first_cnt > 0 ? 1 : 0) | (valid_crc_cnt > 0 ? 2 : 0));   /* hand the two flags to the other lanes */
+    }
+    __syncthreads();
+    bool had_any = (lds.crc_stats[0].idx & 1) != 0, still_valid = (lds.crc_stats[0].idx & 2) != 0;
+    if (had_any && still_valid) {
+        if (lds.crc_stats[0].result < ps.min_valid_crcs) span_res = SPAN_TOO_NARROW;
+        else span_res = pick_level_by_crc_stats(lds, &l.ref_level, blk1, wht1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX);
+    }
+    if (span_res == SPAN_OK) {
+        SweepEnt t = lds.sweep[l.ref_level];
+        l.ref_sweeped = true;
+        coords_set(l.coords, t.start, t.stop);
+        l.coords_set = true;
+        if (!coords_valid(forced_coords)) find_coordinates_wave(b, ps, lds, l);
+        b.hyst_lim = t.hyst;
+        if (b.hyst_lim > HYST_DEPTH_MAX) b.hyst_lim = HYST_DEPTH_MAX;
+        b.shift_lim = t.shift;
+    } else {
+        if (span_res == SPAN_TOO_NARROW) {
+            span_res = pick_level_by_crc_stats_opt(ps, lds, &l.ref_level, blk1, wht1, REF_CRC_OK, b.hyst_lim, b.shift_lim);
+            l.forced_bad = true;
+        } else {
+            span_res = pick_level_by_crc_stats(lds, &l.ref_level, blk1, wht1, REF_BAD_CRC, 0xFF, 0xFF);
+        }
+        if (span_res == SPAN_OK) {
+            SweepEnt t = lds.sweep[l.ref_level];
+            coords_set(l.coords, t.start, t.stop);
+            l.coords_set = true;
+            if (!coords_valid(forced_coords)) find_coordinates_wave(b, ps, lds, l);
+        } else if (b.in_ref >= ps.min_ref_lvl) {
+            l.ref_level = b.in_ref;
+            if (coords_valid(b.in_coord)) l.coords = b.in_coord;
+        } else {
+            l.ref_level = fast_ref;
+            if (!coords_valid(b.in_coord)) coords_set(l.coords, (int16_t)(b.scan_start + b.estimated_ppb), (int16_t)(b.scan_end - (4 * b.estimated_ppb)));
+            else l.coords = b.in_coord;
+        }
+        b.hyst_lim = 0; b.shift_lim = SHIFT_STAGES_MIN;
+    }
+}
+
+/* ======================================================================================== */
+/* Binarizer setters (binarizer.cpp:240-438)                                                 */
+/* ======================================================================================== */
+__device__ inline void bin_set_bw_levels(Bin &b, const sdv_bin_preset &ps, uint8_t blk, uint8_t wht)
+{
+    if ((blk < wht) && (blk < ps.max_black_lvl) && (wht > ps.min_white_lvl) && (wht != 0)) { b.in_black = blk; b.in_white = wht; }
+    else b.in_black = b.in_white = 0;
+}
+__device__ inline void bin_set_data_coordinates(Bin &b, const Coords &c) { if (coords_valid(c)) b.in_coord = c; else coords_clear(b.in_coord); }
+__device__ inline void bin_set_data_coordinates2(Bin &b, int16_t s, int16_t e)
+{
+    Coords t; coords_clear(t);
+    if ((s < e) && (e != 0) && (s != NO_COORD_LEFT) && (e != NO_COORD_RIGHT)) coords_set(t, s, e);
+    bin_set_data_coordinates(b, t);
+}
+__device__ inline void bin_set_good_parameters_reset(Bin &b, const sdv_bin_preset &ps)
+{
+    b.in_ref = 0; bin_set_data_coordinates2(b, 0, 0); bin_set_bw_levels(b, ps, 0, 0);
+}
+__device__ inline void bin_set_good_parameters(Bin &b, const sdv_bin_preset &ps, const Line &l)
+{
+    if (crc_valid_ignore_forced(l)) { b.in_ref = l.ref_level; bin_set_data_coordinates(b, l.coords); bin_set_bw_levels(b, ps, l.black, l.white); }
+}
+__device__ __forceinline__ bool is_ref_level_preset(const Bin &b, const sdv_bin_preset &ps) { return b.in_ref >= ps.min_ref_lvl; }
+__device__ inline bool are_bw_levels_preset(const Bin &b, const sdv_bin_preset &ps)
+{
+    if ((b.in_white > ps.min_white_lvl) && (b.in_black < ps.max_black_lvl)) {
+        if (is_ref_level_preset(b, ps)) if ((b.in_ref <= b.in_black) || (b.in_ref >= b.in_white)) return false;
+        return true;
+    }
+    return false;
+}
+__device__ inline void bin_set_mode(Bin &b, uint8_t m)   /* :120-152 */
+{
+    if (m == SDV_MODE_DRAFT) { b.mode = m; b.in_max_hyst = HYST_DEPTH_SAFE; b.in_max_shift = SHIFT_STAGES_MIN; }
+    else if (m == SDV_MODE_FAST) { b.mode = m; b.in_max_hyst = 7; b.in_max_shift = SHIFT_STAGES_SAFE; }
+    else if (m == SDV_MODE_INSANE) { b.mode = m; b.in_max_hyst = HYST_DEPTH_MAX; b.in_max_shift = SHIFT_STAGES_MAX; }
+    else { b.mode = SDV_MODE_NORMAL; b.in_max_hyst = HYST_DEPTH_SAFE; b.in_max_shift = SHIFT_STAGES_SAFE; }
+}
+
+/* ======================================================================================== */
+/* Binarizer::processLine (binarizer.cpp:443-1724) for a regular (non-service, non-empty) line */
+/* that is already staged in lds.px.  Returns LB_RET_*.                                        */
+/* ======================================================================================== */
+__device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &out, uint32_t frame_no, uint16_t line_no, int width, bool doubled)
+{
+    Coords forced_coords;
+    stc_clear(out);
+    out.frame_number = frame_no; out.line_number = line_no;
+    b.line_length = (uint16_t)width; b.vl_doubled = doubled;
+    out.coords.doubled = doubled;
+    b.scan_start = 0; b.scan_end = (uint16_t)(b.line_length - 1);
+    set_source_pixels(out, b.scan_start, b.scan_end);
+    if (b.line_length < BITS_IN_LINE) return SDV_ERR_SHORT_LINE;
+    b.mark_start_max = (uint16_t)(b.line_length * ps.mark_max_dist);
+    b.mark_start_max = b.mark_start_max / 100;
+    b.mark_end_min = (uint16_t)(b.scan_end - b.mark_start_max);
+    b.mark_start_max = (uint16_t)(b.scan_start + b.mark_start_max);
+    uint32_t tmp_calc = (uint32_t)b.line_length * 128u;
+    tmp_calc = tmp_calc / BITS_IN_LINE;
+    b.estimated_ppb = (uint16_t)((tmp_calc + 64) / 128);
+    coords_set(out.coords, (int16_t)b.scan_start, (int16_t)b.scan_end);
+    calc_forced_coords(b, ps, forced_coords);
+    if (ps.en_force_coords && coords_valid(forced_coords)) { out.coords = forced_coords; out.coords_set = true; }
+
+    int state = STG_REF_FIND;
+    b.was_bw_scanned = false;
+    if (are_bw_levels_preset(b, ps)) { out.black = b.in_black; out.white = b.in_white; out.bw_set = true; }
+    if (is_ref_level_preset(b, ps)) state = coords_valid(b.in_coord) ? STG_INPUT_ALL : STG_INPUT_LEVEL;
+    b.hyst_lim = b.in_max_hyst; b.shift_lim = b.in_max_shift;
+
+    int stage_count = 0;
+    for (;;) {
+        stage_count++;
+        if (state == STG_INPUT_ALL) {                       /* :774-931 */
+            if (!out.bw_set) find_black_white(b, ps, lds, out);
+            if (!coords_valid(forced_coords)) out.coords = b.in_coord;
+            out.ref_level = b.in_ref;
+            out.ref_sweeped = false;
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else if ((b.in_ref >= out.white) || (b.in_ref <= out.black)) state = STG_REF_FIND;
+            else {
+                bool force_level_find = false;
+                if (!coords_valid(forced_coords) && !ps.en_good_no_marker) {      /* do_coord_search is always on for STC-007 (videotodigital.cpp:953) */
+                    find_coordinates_wave(b, ps, lds, out);
+                    out.coords = b.in_coord;
+                    if (!has_markers(out)) force_level_find = true;
+                }
+                read_pcm_data(b, out, lds);
+                if (crc_valid(out)) {
+                    if (!force_level_find) { out.by_ext_tune = true; state = STG_DATA_OK; }
+                    else state = STG_REF_FIND;
+                } else state = !coords_valid(forced_coords) ? STG_INPUT_LEVEL : STG_REF_FIND;
+            }
+        } else if (state == STG_INPUT_LEVEL) {              /* :932-1072 */
+            if (!b.was_bw_scanned) find_black_white(b, ps, lds, out);
+            if (!coords_valid(forced_coords)) coords_set(out.coords, (int16_t)b.scan_start, (int16_t)b.scan_end);
+            out.ref_level = b.in_ref;
+            out.ref_sweeped = false;
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else {
+                state = STG_REF_FIND;
+                if ((b.in_ref < out.white) && (b.in_ref > out.black)) {
+                    find_coordinates_wave(b, ps, lds, out);
+                    if (has_markers(out)) {
+                        if (!coords_valid(b.in_coord) || coords_ne(out.coords, b.in_coord)) {
+                            read_pcm_data(b, out, lds);
+                            if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; }
+                        }
+                    }
+                }
+            }
+        } else if (state == STG_REF_FIND) {                 /* :1073-1390 */
+            if (!b.was_bw_scanned) find_black_white(b, ps, lds, out);
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else {
+                b.do_ref_lvl_sweep = (b.mode == SDV_MODE_NORMAL) || (b.mode == SDV_MODE_INSANE);
+                if (b.do_ref_lvl_sweep) state = STG_REF_SWEEP_RUN;
+                else {
+                    b.hyst_lim = HYST_DEPTH_SAFE; b.shift_lim = SHIFT_STAGES_MIN;
+                    state = STG_READ_PCM;
+                    out.ref_level = pick_center_ref_level(ps, out.black, out.white);
+                    if (coords_valid(forced_coords)) { out.coords = forced_coords; out.coords_set = true; }
+                    else {
+                        find_coordinates_wave(b, ps, lds, out);
+                        if (!has_markers(out)) { b.hyst_lim = HYST_DEPTH_SAFE; b.shift_lim = SHIFT_STAGES_MIN; }
+                        else { b.hyst_lim = b.in_max_hyst; b.shift_lim = b.in_max_shift; }
+                    }
+                }
+            }
+        } else if (state == STG_REF_SWEEP_RUN) {            /* :1391-1400 */
+            calc_ref_level_by_sweep(b, ps, lds, out);
+            state = STG_READ_PCM;
+        } else if (state == STG_READ_PCM) {                 /* :1401-1533 */
+            if (coords_valid(forced_coords)) { b.hyst_lim = HYST_DEPTH_SAFE; b.shift_lim = SHIFT_STAGES_MIN; }
+            if (out.coords_set) read_pcm_data(b, out, lds);
+            if (crc_valid(out)) state = STG_DATA_OK;
+            if (state != STG_DATA_OK) {
+                if (coords_valid(b.in_coord) && !coords_valid(forced_coords) && !b.do_ref_lvl_sweep && !out.forced_bad && !out.coords_set) {
+                    if (coords_ne(out.coords, b.in_coord)) {
+                        out.coords = b.in_coord;
+                        out.m_st_bg = 0; out.m_st_ed = 0; out.m_sp_ed = 0;
+                        read_pcm_data(b, out, lds);
+                        if (crc_valid(out)) state = STG_DATA_OK;
+                    }
+                }
+                if (state != STG_DATA_OK) state = STG_NO_GOOD;
+            }
+        } else if (state == STG_DATA_OK) {                  /* :1534-1621 */
+            if (out.forced_bad) state = STG_NO_GOOD;
+            else {
+                if (!ps.en_good_no_marker && !has_markers(out)) { out.forced_bad = true; state = STG_NO_GOOD; continue; }
+                apply_crc_state_per_word(out);
+                if (has_control_block(out)) set_serv_ctrl_blk(out);
+                out.coords.doubled = doubled;
+                break;
+            }
+        } else if (state == STG_NO_GOOD) {                  /* :1622-1669 */
+            if (crc_valid(out)) set_invalid_crc(out);
+            apply_crc_state_per_word(out);
+            if (coords_valid(forced_coords) && out.bw_set) { out.mark_st = MARK_ST_BOT_2; out.mark_ed = MARK_ED_LEN_OK; }
+            out.coords.doubled = doubled;
+            break;
+        } else break;
+        if (stage_count > STG_MAX) break;
+    }
+    return SDV_OK;
+}
+
+/* ======================================================================================== */
+/* VideoToDigital::doBinarize per-frame driver (videotodigital.cpp:698-1815), STC-007          */
+/* ======================================================================================== */
+struct V2D {
+    Bin bin;
+    uint8_t field_state;
+    bool reset_stats;
+    uint16_t good_coords_in_field, pcm_lines_in_field, line_in_field_cnt;
+    Coords frame_avg;
+    int n_last, n_long, nfv, nfi;
+    uint16_t last_words[8];                 /* last_stc007_line.words (only the words are ever compared) */
+    /* FrameBinDescriptor signal_quality */
+    uint16_t q_line_length, q_odd, q_even, q_pcm_odd, q_pcm_even, q_bad_odd, q_bad_even, q_dup_odd, q_dup_even;
+};
+
+__device__ inline uint32_t wave_min_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o < v ? o : v; } return v; }
+__device__ inline uint32_t wave_max_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o > v ? o : v; } return v; }
+
+/* VideoToDigital::medianCoordinates (videotodigital.cpp:348-371): element of rank n/2 under
+ * CoordinatePair::operator<.  keys[] readable by every lane (LDS or own global stores). */
+__device__ inline bool median_keys(const uint32_t *keys, int n, uint32_t *out_key)
+{
+    if (n <= 0) return false;
+    int lane = lane_id();
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+    for (int j = lane; j < n; j += 64) { uint32_t k = keys[j]; mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
+    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+    if (mn == mx) { *out_key = mn; return true; }
+    int target = n / 2;
+    uint32_t res = 0;
+    for (int base = 0; base < n; base += 64) {          /* uniform trip count */
+        int i = base + lane;
+        bool hit = false; uint32_t ki = 0;
+        if (i < n) {
+            ki = keys[i];
+            int less = 0, leq = 0;
+            for (int j = 0; j < n; j++) { uint32_t kj = keys[j]; less += (kj < ki); leq += (kj <= ki); }
+            hit = (less <= target) && (target < leq);
+        }
+        uint64_t m = __ballot(hit);
+        if (m != 0ull) { res = (uint32_t)__shfl((int)ki, __ffsll((unsigned long long)m) - 1); *out_key = res; return true; }
+    }
+    *out_key = res;
+    return false;
+}
+
+__device__ inline Coords key_to_coords(uint32_t k, bool doubled) { Coords c; c.start = key_start(k); c.stop = key_stop(k); c.doubled = doubled; return c; }
+
+/* getWordsDiffBitCount (stc007line.cpp:329-357): the XOR is truncated to uint8_t in the reference */
+__device__ inline uint8_t words_diff_bit_count(const uint16_t *a, const uint16_t *bw)
+{
+    uint8_t cnt = 0;
+    for (int i = 0; i < 8; i++) cnt = (uint8_t)(cnt + __popc((uint32_t)(uint8_t)(a[i] ^ bw[i])));
+    return cnt;
+}
+
+__device__ inline void v2d_begin_frame(V2D &v, const FrameArgs &a, WaveLds &lds)   /* :772-822 */
+{
+    v.field_state = FIELD_NEW;
+    v.good_coords_in_field = v.pcm_lines_in_field = 0;
+    if (v.reset_stats) {
+        v.reset_stats = false;
+        v.n_last = v.nfv = v.nfi = v.n_long = 0;
+        coords_clear(v.frame_avg);
+        bin_set_good_parameters_reset(v.bin, a.preset);
+    }
+    coords_clear(v.frame_avg);
+    if (!a.preset.en_force_coords) {
+        uint32_t k;
+        if (median_keys(lds.long_keys, v.n_long, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
+        if (coords_valid(v.frame_avg)) bin_set_data_coordinates2(v.bin, v.frame_avg.start, v.frame_avg.stop);
+    }
+}
+
+/* service lines: Binarizer::processLine :539-568 + VideoToDigital :1006-1114 */
+__device__ inline void v2d_service_line(V2D &v, const FrameArgs &a, WaveLds &lds, Line &wl, uint32_t frame_no, uint16_t line_no, uint8_t srv)
+{
+    stc_clear(wl);
+    wl.frame_number = frame_no; wl.line_number = line_no;
+    set_service(wl, srv);
+    if (srv == SDV_SRV_NEW_FILE || srv == SDV_SRV_END_FILE) {
+        v.line_in_field_cnt = 0;
+        v.n_last = v.nfv = v.nfi = v.n_long = 0;
+        if (srv == SDV_SRV_END_FILE || !coords_valid(v.frame_avg)) bin_set_good_parameters_reset(v.bin, a.preset);
+    } else if (srv == SDV_SRV_END_FIELD) {
+        v.field_state = FIELD_NEW;
+        v.line_in_field_cnt = 0;
+        v.good_coords_in_field = 0; v.pcm_lines_in_field = 0;
+        for (int i = 0; i < 8; i++) v.last_words[i] = 0;
+    }
+}
+
+/* regular line, after Binarizer::processLine: VideoToDigital :1115-1634 */
+__device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, Line &wl, uint32_t *fv_keys, uint32_t *fi_keys, bool even_line)
+{
+    const sdv_bin_preset &ps = a.preset;
+    if (wl.service != SDV_SRV_NO) {
+        /* Control Block (setServCtrlBlk inside processLine) */
+        if (wl.service == SDV_SRV_CTRL_BLOCK && v.field_state == FIELD_NEW) v.field_state = FIELD_SAFE;
+        return;
+    }
+    bool count_has_data = has_markers(wl);
+    bool count_has_pcm = crc_valid(wl) || count_has_data;
+    wl.m2 = a.m2_format != 0;
+    if (count_has_pcm && v.field_state == FIELD_NEW) v.field_state = FIELD_UNSAFE;
+    if (crc_valid(wl)) {
+        v.good_coords_in_field++;
+        v.q_line_length = (uint16_t)a.width;
+        if (a.check_line_copy) {
+            if (v.field_state == FIELD_UNSAFE) {
+                bin_set_good_parameters(v.bin, ps, wl);
+                if (ps.en_first_line_dup) wl.forced_bad = true;
+            } else {
+                uint8_t diff = words_diff_bit_count(wl.words, v.last_words);
+                bool same_words = diff <= (BITS_DATA / BIT_DIFF_THRES_DIV);
+                if (!stc_is_almost_silent(wl) && same_words) { wl.forced_bad = true; if (!even_line) v.q_dup_odd++; else v.q_dup_even++; }
+            }
+        }
+        if (crc_valid_ignore_forced(wl)) {
+            uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
+            /* last_valid_coord_list: push_back, keep the newest COORD_HISTORY_DEPTH */
+            __syncthreads();
+            if (lane_id() == 0) {
+                if (v.n_last == COORD_HISTORY_DEPTH) for (int i = 0; i < COORD_HISTORY_DEPTH - 1; i++) lds.lv_keys[i] = lds.lv_keys[i + 1];
+                lds.lv_keys[v.n_last == COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
+            }
+            if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
+            __syncthreads();
+            fv_keys[v.nfv++] = key;
+            if (a.coordinate_damper && !ps.en_force_coords && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
+                Coords target; coords_clear(target);
+                uint32_t k;
+                if (median_keys(lds.lv_keys, v.n_last, &k)) target = key_to_coords(k, false);
+                if (!coords_valid(target)) target = v.frame_avg;
+                if (coords_valid(target)) {
+                    int16_t ds = (int16_t)(wl.coords.start - target.start), de = (int16_t)(wl.coords.stop - target.stop);
+                    uint8_t in_delta = (uint8_t)(((uint8_t)(wl.psm / 128u)) * 3);
+                    bool warn = ((int)ds <= -(int)in_delta) || ((int)ds >= (int)in_delta) || ((int)de <= -(int)in_delta) || ((int)de >= (int)in_delta);
+                    if (warn) wl.forced_bad = true;
+                }
+            }
+        }
+        if (crc_valid(wl)) bin_set_good_parameters(v.bin, ps, wl);
+        else { if (!even_line) v.q_bad_odd++; else v.q_bad_even++; }
+        v.field_state = FIELD_INIT;
+    } else {
+        if (v.q_line_length == 0) v.q_line_length = (uint16_t)a.width;
+        if (coords_valid(wl.coords)) fi_keys[v.nfi++] = coords_key(wl.coords.start, wl.coords.stop);
+        if (count_has_data) {
+            Coords preset_coords; coords_clear(preset_coords);
+            if (!even_line) v.q_bad_odd++; else v.q_bad_even++;
+            if (!ps.en_force_coords) {
+                uint32_t k;
+                if (median_keys(lds.lv_keys, v.n_last, &k)) preset_coords = key_to_coords(k, a.doubled != 0);
+                if (!coords_valid(preset_coords)) preset_coords = v.frame_avg;
+            }
+            v.field_state = FIELD_INIT;
+#ifdef SDV_EMU_DEBUG
+            if (lane_id()==0) { printf("DBG bad line %u/%u n_last=%d preset=(%d,%d) keys:", wl.frame_number, wl.line_number, v.n_last, preset_coords.start, preset_coords.stop); for (int i=0;i<v.n_last;i++) printf(" (%d,%d)", key_start(lds.lv_keys[i]), key_stop(lds.lv_keys[i])); printf("\n"); }
+#endif
+            bin_set_data_coordinates(v.bin, preset_coords);
+            bin_set_bw_levels(v.bin, ps, 0, 0);
+        } else {
+            bin_set_bw_levels(v.bin, ps, 0, 0);
+        }
+    }
+    if (!even_line) v.q_odd++; else v.q_even++;
+    if (count_has_pcm) {
+        if (!even_line) v.q_pcm_odd++; else v.q_pcm_even++;
+        v.pcm_lines_in_field++;
+        for (int i = 0; i < 8; i++) v.last_words[i] = wl.words[i];
+    }
+    v.line_in_field_cnt++;
+}
+
+/* END_FRAME bookkeeping (videotodigital.cpp:1636-1714) */
+__device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, uint32_t frame_no, const uint32_t *fv_keys, const uint32_t *fi_keys, sdv_frame_stats *out)
+{
+    if (v.q_pcm_odd > v.q_odd) v.q_pcm_odd = v.q_odd;
+    if (v.q_pcm_even > v.q_even) v.q_pcm_even = v.q_even;
+    if (v.q_bad_odd > v.q_odd) v.q_bad_odd = v.q_odd;
+    if (v.q_bad_even > v.q_even) v.q_bad_even = v.q_even;
+    bool not_sure = false;
+    uint32_t k;
+    coords_clear(v.frame_avg);
+    if (median_keys(fv_keys, v.nfv, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
+    if (coords_valid(v.frame_avg)) {
+        __syncthreads();
+        if (lane_id() == 0) {
+            if (v.n_long == COORD_LONG_HISTORY) for (int i = 0; i < COORD_LONG_HISTORY - 1; i++) lds.long_keys[i] = lds.long_keys[i + 1];
+            lds.long_keys[v.n_long == COORD_LONG_HISTORY ? COORD_LONG_HISTORY - 1 : v.n_long] = coords_key(v.frame_avg.start, v.frame_avg.stop);
+        }
+        if (v.n_long < COORD_LONG_HISTORY) v.n_long++;
+        __syncthreads();
+    } else {
+        coords_clear(v.frame_avg);
+        if (median_keys(fi_keys, v.nfi, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
+        if (!coords_valid(v.frame_avg)) { coords_clear(v.frame_avg); if (median_keys(lds.long_keys, v.n_long, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0); }
+        not_sure = true;
+    }
+    v.nfv = v.nfi = 0;
+    if (lane_id() == 0) {
+        sdv_frame_stats s;
+        s.frame_id = frame_no; s.line_length = v.q_line_length;
+        s.lines_odd = v.q_odd; s.lines_even = v.q_even; s.lines_pcm_odd = v.q_pcm_odd; s.lines_pcm_even = v.q_pcm_even;
+        s.lines_bad_odd = v.q_bad_odd; s.lines_bad_even = v.q_bad_even; s.lines_dup_odd = v.q_dup_odd; s.lines_dup_even = v.q_dup_even;
+        s.data_start = v.frame_avg.start; s.data_stop = v.frame_avg.stop;
+        s.data_from_doubled = v.frame_avg.doubled ? 1 : 0; s.data_not_sure = not_sure ? 1 : 0;
+        s._pad[0] = s._pad[1] = s._pad[2] = s._pad[3] = 0;
+        *out = s;
+    }
+    v.q_line_length = v.q_odd = v.q_even = v.q_pcm_odd = v.q_pcm_even = v.q_bad_odd = v.q_bad_even = v.q_dup_odd = v.q_dup_even = 0;
+}
+
+/* ---- chain state <-> registers ---------------------------------------------------------------- */
+__device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state *s, const FrameArgs &a)
+{
+    v.bin.in_black = s->bin.in_def_black; v.bin.in_white = s->bin.in_def_white; v.bin.in_ref = s->bin.in_def_reference;
+    v.bin.in_coord.start = s->bin.in_def_start; v.bin.in_coord.stop = s->bin.in_def_stop; v.bin.in_coord.doubled = s->bin.in_def_from_doubled != 0;
+    v.bin.do_ref_lvl_sweep = s->do_ref_lvl_sweep != 0;
+    bin_set_mode(v.bin, a.mode);
+    v.bin.hyst_lim = 0; v.bin.shift_lim = 0;
+    v.bin.line_length = 0; v.bin.scan_start = v.bin.scan_end = 0; v.bin.mark_start_max = 0; v.bin.mark_end_min = 0xFFFF; v.bin.estimated_ppb = 0;
+    v.bin.was_bw_scanned = false; v.bin.vl_doubled = false;
+    v.reset_stats = s->reset_stats != 0;
+    v.n_last = s->n_last_valid; v.n_long = s->n_long_valid;
+    for (int i = 0; i < COORD_HISTORY_DEPTH; i++) lds.lv_keys[i] = coords_key(s->last_valid[i].data_start, s->last_valid[i].data_stop);
+    for (int i = 0; i < COORD_LONG_HISTORY; i++) lds.long_keys[i] = coords_key(s->long_valid[i].data_start, s->long_valid[i].data_stop);
+    v.field_state = FIELD_INIT;
+    v.good_coords_in_field = v.pcm_lines_in_field = v.line_in_field_cnt = 0;
+    coords_clear(v.frame_avg);
+    v.nfv = v.nfi = 0;
+    for (int i = 0; i < 8; i++) v.last_words[i] = 0;
+    v.q_line_length = v.q_odd = v.q_even = v.q_pcm_odd = v.q_pcm_even = v.q_bad_odd = v.q_bad_even = v.q_dup_odd = v.q_dup_even = 0;
+}
+__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a)
+{
+    if (lane_id() != 0) return;
+    sdv_v2d_state o;
+    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin._pad = 0;
+    o.bin.in_def_start = v.bin.in_coord.start; o.bin.in_def_stop = v.bin.in_coord.stop;
+    o.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.bin._pad2 = 0;
+    o.do_ref_lvl_sweep = v.bin.do_ref_lvl_sweep ? 1 : 0; o.reset_stats = v.reset_stats ? 1 : 0;
+    o.n_last_valid = (uint8_t)v.n_last; o.n_long_valid = (uint8_t)v.n_long;
+    uint16_t lm = a.doubled ? (uint16_t)((1u << v.n_last) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
+    o.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); o.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+    o.long_valid_doubled_mask = gm;
+    for (int i = 0; i < COORD_HISTORY_DEPTH; i++) {
+        if (i < v.n_last) { o.last_valid[i].data_start = key_start(lds.lv_keys[i]); o.last_valid[i].data_stop = key_stop(lds.lv_keys[i]); }
+        else { o.last_valid[i].data_start = 0; o.last_valid[i].data_stop = 0; }
+    }
+    for (int i = 0; i < COORD_LONG_HISTORY; i++) {
+        if (i < v.n_long) { o.long_valid[i].data_start = key_start(lds.long_keys[i]); o.long_valid[i].data_stop = key_stop(lds.long_keys[i]); }
+        else { o.long_valid[i].data_start = 0; o.long_valid[i].data_stop = 0; }
+    }
+    o._pad[0] = o._pad[1] = 0;
+    *s = o;
+}
+
+/* stage one scanline into LDS: coalesced 16-byte loads when the row is 16-byte aligned */
+__device__ inline void stage_row(WaveLds &lds, const uint8_t *row, int width)
+{
+    __syncthreads();
+    int lane = lane_id();
+    if ((((uintptr_t)row) & 15) == 0) {
+        int nvec = width >> 4;
+        const uint4 *src = (const uint4 *)row;
+        uint4 *dst = (uint4 *)lds.px;
+        for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+        for (int i = (nvec << 4) + lane; i < width; i += 64) lds.px[i] = row[i];
+    } else {
+        for (int i = lane; i < width; i += 64) lds.px[i] = row[i];
+    }
+    __syncthreads();
+}
+
+__device__ inline void emit_record(const Line &wl, sdv_line_rec *dst)
+{
+    if (lane_id() == 0) { sdv_line_rec r; line_to_rec(wl, &r); *dst = r; }
+}
+
+/* ======================================================================================== */
+/* Kernel: one wavefront (= one workgroup of 64) per frame                                   */
+/* ======================================================================================== */
+__device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
+{
+    V2D v; Line wl;
+    v2d_load_state(v, lds, &a.states_in[f], a);
+    const uint32_t frame_no = a.first_frame_no + (uint32_t)f;
+    const uint8_t *frame = a.luma + (size_t)f * a.frame_stride;
+    uint32_t *fv_keys = a.scratch + (size_t)f * 2u * (size_t)a.height;
+    uint32_t *fi_keys = fv_keys + a.height;
+    size_t rec_base = (size_t)f * (size_t)(a.height + 3);
+    if (a.new_file_frame >= 0 && f > a.new_file_frame) rec_base += 1;
+    sdv_line_rec *rec = a.recs + rec_base;
+    const bool doubled = a.doubled != 0;
+
+    v2d_begin_frame(v, a, lds);
+    if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
+    uint16_t line_num = 0;
+    for (int field = 0; field < 2; field++) {
+        int line_offset = field;
+        line_num = (uint16_t)(line_offset + 1);
+        for (;;) {
+            stage_row(lds, frame + (size_t)line_offset * a.row_stride, a.width);
+            v.bin.mode = a.mode; bin_set_mode(v.bin, a.mode);
+            process_line(v.bin, a.preset, lds, wl, frame_no, line_num, a.width, doubled);
+            v2d_post_line(v, a, lds, wl, fv_keys, fi_keys, (line_num % 2) == 0);
+            emit_record(wl, rec++);
+            if (line_offset < (a.height - 2)) line_offset += 2;
+            else { line_num = (uint16_t)(line_num + 2); break; }
+            line_num = (uint16_t)(line_num + 2);
+        }
+        v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
+        emit_record(wl, rec++);
+    }
+    line_num = (uint16_t)(line_num + 2);
+    v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
+    v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f]);
+    emit_record(wl, rec++);
+    v2d_store_state(v, lds, &a.states_out[f], a);
+}
+
+} // namespace sdv
+
+__global__ void __launch_bounds__(64) sdv_k_stc007_frames(sdv::FrameArgs a)
+{
+    __shared__ sdv::WaveLds lds;
+    int f = a.frame_lo + (int)blockIdx.x;
+    if (f < a.frame_hi) sdv::frame_body(a, lds, f);
+}
+#endif

@@ -1,0 +1,170 @@
+"""Python mirror of the reference's operator interface for the binarize path.
+
+`Engine` exposes the VideoToDigital slots a Qt front-end drives (videotodigital.h:137-147) with the same
+names and argument meaning - setPCMType, setBinarizationMode, setCheckLineDup, setFineSettings,
+setDefaultFineSettings - plus `binarize_frames`, the batch replacement of the doBinarize worker loop.
+Everything computes on the GPU through the C-ABI; torch is only used for device memory."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_PKG, "libsdvpcm_hip.so")
+
+LINE_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words", "<u2", (9,)),
+                       ("calc_crc", "<u2"), ("data_start", "<i2"), ("data_stop", "<i2"),
+                       ("marker_start_bg_coord", "<u2"), ("marker_start_ed_coord", "<u2"),
+                       ("marker_stop_ed_coord", "<u2"),
+                       ("black_level", "u1"), ("white_level", "u1"), ("ref_low", "u1"), ("ref_level", "u1"),
+                       ("ref_high", "u1"), ("hysteresis_depth", "u1"), ("shift_stage", "u1"),
+                       ("service_type", "u1"), ("mark_st_stage", "u1"), ("mark_ed_stage", "u1"),
+                       ("flags", "u1"), ("word_state", "u1")])
+STATS_DTYPE = np.dtype([("frame_id", "<u4"), ("line_length", "<u2"), ("lines_odd", "<u2"), ("lines_even", "<u2"),
+                        ("lines_pcm_odd", "<u2"), ("lines_pcm_even", "<u2"), ("lines_bad_odd", "<u2"),
+                        ("lines_bad_even", "<u2"), ("lines_dup_odd", "<u2"), ("lines_dup_even", "<u2"),
+                        ("data_start", "<i2"), ("data_stop", "<i2"), ("data_from_doubled", "u1"),
+                        ("data_not_sure", "u1"), ("_pad", "u1", (4,))])
+assert LINE_DTYPE.itemsize == 48 and STATS_DTYPE.itemsize == 32
+
+# enums of include/sdvpcm.h
+PCM_PCM1, PCM_PCM16X0, PCM_STC007 = 0, 1, 2
+TYPE_M2 = 3                      # VideoToDigital::TYPE_M2 (videotodigital.h:77)
+MODE_DRAFT, MODE_FAST, MODE_NORMAL, MODE_INSANE = 0, 1, 2, 3
+FLAG_NEW_FILE, FLAG_DOUBLED = 1, 2
+
+
+class BinPreset(C.Structure):
+    """bin_preset_t (binarizer.h:163-186)"""
+    _fields_ = [(n, C.c_uint8) for n in ("max_black_lvl", "min_white_lvl", "min_contrast", "min_ref_lvl",
+                                          "max_ref_lvl", "min_valid_crcs", "mark_max_dist", "left_bit_pick",
+                                          "right_bit_pick", "en_force_coords", "en_coord_search",
+                                          "en_first_line_dup", "en_good_no_marker", "_pad")] + \
+               [("horiz_start", C.c_int16), ("horiz_stop", C.c_int16)]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Loads libsdvpcm_hip.so. Raises (never falls back) when the HIP extension is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    lib.sdv_engine_create.restype = C.c_void_p
+    lib.sdv_engine_create.argtypes = [C.c_int]
+    lib.sdv_engine_destroy.argtypes = [C.c_void_p]
+    lib.sdv_last_error.restype = C.c_char_p
+    lib.sdv_last_error.argtypes = [C.c_void_p]
+    lib.sdv_abi_version.restype = C.c_int
+    lib.sdv_default_bin_preset.argtypes = [C.POINTER(BinPreset)]
+    lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.POINTER(BinPreset)]
+    lib.sdv_set_check_line_dup.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_set_pcm_type.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.sdv_reset_stream.argtypes = [C.c_void_p]
+    lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
+    lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sdv_set_chain_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sdv_records_per_frame.restype = C.c_size_t
+    lib.sdv_records_per_frame.argtypes = [C.c_int]
+    lib.sdv_binarize_frames.restype = C.c_int
+    lib.sdv_binarize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                        C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class Engine:
+    """One decode engine per GPU (per process rank)."""
+
+    def __init__(self, device: int = 0, lib=None):
+        self.lib = lib or load_library()
+        self.device = device
+        self._h = self.lib.sdv_engine_create(device)
+        if not self._h:
+            raise RuntimeError("sdv_engine_create failed: " + self.lib.sdv_last_error(None).decode())
+        self._h = C.c_void_p(self._h)
+
+    def close(self):
+        if self._h:
+            self.lib.sdv_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"sdvpcm error {rc}: " + self.lib.sdv_last_error(self._h).decode())
+
+    # ---- VideoToDigital slots (videotodigital.h:137-147) ----
+    def setPCMType(self, in_pcm: int = PCM_STC007):
+        if in_pcm == TYPE_M2:
+            self._check(self.lib.sdv_set_pcm_type(self._h, PCM_STC007, 1))
+        else:
+            self._check(self.lib.sdv_set_pcm_type(self._h, in_pcm, 0))
+
+    def setBinarizationMode(self, in_mode: int = MODE_NORMAL):
+        self._check(self.lib.sdv_set_mode(self._h, in_mode))
+
+    def setCheckLineDup(self, flag: bool = True):
+        self._check(self.lib.sdv_set_check_line_dup(self._h, int(flag)))
+
+    def getDefaultFineSettings(self) -> BinPreset:
+        p = BinPreset()
+        self.lib.sdv_default_bin_preset(C.byref(p))
+        return p
+
+    def setFineSettings(self, in_set: BinPreset):
+        self._check(self.lib.sdv_set_bin_preset(self._h, C.byref(in_set)))
+
+    def setDefaultFineSettings(self):
+        self.setFineSettings(self.getDefaultFineSettings())
+
+    def reset_stream(self):
+        self._check(self.lib.sdv_reset_stream(self._h))
+
+    def run_info(self) -> RunInfo:
+        info = RunInfo()
+        self.lib.sdv_get_run_info(self._h, C.byref(info))
+        return info
+
+    # ---- batch replacement of doBinarize ----
+    def records_per_frame(self, height: int) -> int:
+        return int(self.lib.sdv_records_per_frame(height))
+
+    def binarize_frames(self, luma, first_frame_no: int = 1, new_file: bool = False, doubled: bool = False,
+                        out_lines=None, out_stats=None, stream=None):
+        """luma: torch.uint8 CUDA tensor (n_frames, height, width), rows contiguous.
+        Returns (lines, stats) as torch.uint8 CUDA tensors shaped (n_records, 48) and (n_frames, 32)."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 3 and luma.stride(2) == 1
+        n, h, w = luma.shape
+        nrec = n * (h + 3) + (1 if new_file else 0)
+        if out_lines is None:
+            out_lines = torch.empty((nrec, 48), dtype=torch.uint8, device=luma.device)
+        if out_stats is None:
+            out_stats = torch.empty((n, 32), dtype=torch.uint8, device=luma.device)
+        flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        rc = self.lib.sdv_binarize_frames(self._h, C.c_void_p(luma.data_ptr()), luma.stride(1), luma.stride(0), w, h, n,
+                                          first_frame_no, flags, C.c_void_p(out_lines.data_ptr()),
+                                          C.c_void_p(out_stats.data_ptr()), sptr)
+        self._check(rc)
+        return out_lines, out_stats

@@ -1,0 +1,11 @@
+/*
+ * emu_engine.cpp - TEST-ONLY build of the engine: the same kernel source (stc007_device.h) and the
+ * same host logic (engine.inc) compiled with g++ on top of the SIMT emulator in hip_emu.h, so that
+ * `-m "not gpu"` tests can run the device code lane by lane against the oracle in the GPU-less
+ * container.  Produces tests/emu/libsdvpcm_emu.so; never loaded by the product package.
+ */
+#define SDV_EMU 1
+#include "hip_emu.h"
+struct uint4 { uint32_t x, y, z, w; };
+#include "../../sdvpcmdecoder_amd/csrc/stc007_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/engine.inc"

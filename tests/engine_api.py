@@ -1,0 +1,51 @@
+"""ctypes binding of the C-ABI in include/sdvpcm.h, usable with either the product library
+(sdvpcmdecoder_amd/libsdvpcm_hip.so, device pointers) or the test-only emulator build
+(tests/emu/libsdvpcm_emu.so, host pointers)."""
+import ctypes as C
+import numpy as np
+import libs
+
+STATS_DTYPE = np.dtype([("frame_id", "<u4"), ("line_length", "<u2"), ("lines_odd", "<u2"), ("lines_even", "<u2"),
+                        ("lines_pcm_odd", "<u2"), ("lines_pcm_even", "<u2"), ("lines_bad_odd", "<u2"),
+                        ("lines_bad_even", "<u2"), ("lines_dup_odd", "<u2"), ("lines_dup_even", "<u2"),
+                        ("data_start", "<i2"), ("data_stop", "<i2"), ("data_from_doubled", "u1"),
+                        ("data_not_sure", "u1"), ("_pad", "u1", (4,))])
+assert STATS_DTYPE.itemsize == 32
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+def bind(lib):
+    lib.sdv_engine_create.restype = C.c_void_p
+    lib.sdv_engine_create.argtypes = [C.c_int]
+    lib.sdv_engine_destroy.argtypes = [C.c_void_p]
+    lib.sdv_last_error.restype = C.c_char_p
+    lib.sdv_last_error.argtypes = [C.c_void_p]
+    lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.POINTER(libs.BinPreset)]
+    lib.sdv_set_check_line_dup.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_set_pcm_type.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.sdv_reset_stream.argtypes = [C.c_void_p]
+    lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
+    lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sdv_set_chain_state.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sdv_records_per_frame.restype = C.c_size_t
+    lib.sdv_records_per_frame.argtypes = [C.c_int]
+    lib.sdv_binarize_frames.restype = C.c_int
+    lib.sdv_binarize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                        C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1):
+    """Host-memory call (emulator build only)."""
+    n, h, w = luma.shape
+    nrec = n * (h + 3) + (1 if flags & 1 else 0)
+    recs = np.zeros(nrec, dtype=libs.LINE_DTYPE)
+    stats = np.zeros(n, dtype=STATS_DTYPE)
+    luma = np.ascontiguousarray(luma)
+    rc = lib.sdv_binarize_frames(eng, luma.ctypes.data, w, w * h, w, h, n, first_frame_no, flags, recs.ctypes.data,
+                                 stats.ctypes.data, None)
+    return rc, recs, stats

@@ -1,0 +1,92 @@
+"""CPU tests of the HIP kernel SOURCE: sdvpcmdecoder_amd/csrc/stc007_device.h + engine.inc compiled with g++
+on the single-wavefront SIMT emulator (tests/emu/hip_emu.h) and compared bit-for-bit with the oracle.
+This is not the product path (the product has no CPU path); it lets the kernel logic and the
+chain-speculation scheduler be checked in the GPU-less container.  Sizes are small: the emulator is slow."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import engine_api
+import golden_cases
+import libs
+from oracle_run import oracle_binarize
+from sdvpcmdecoder_amd import synth
+
+
+def emu_run(emu, luma, mode, flags=1, first=1, eng=None):
+    own = eng is None
+    if own:
+        eng = C.c_void_p(emu.sdv_engine_create(0))
+        emu.sdv_set_mode(eng, mode)
+    rc, recs, stats = engine_api.emu_binarize(emu, eng, luma, first_frame_no=first, flags=flags)
+    info = engine_api.RunInfo()
+    emu.sdv_get_run_info(eng, C.byref(info))
+    if own:
+        emu.sdv_engine_destroy(eng)
+    assert rc == 0
+    return recs, stats, info
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_emu_small_frames(emu_lib, oracle_lib, mode):
+    cases = [dict(n_frames=3, seed=1, height=48),
+             dict(n_frames=2, seed=2, height=40, noise_sigma=10.0, blur=2),
+             dict(n_frames=3, seed=3, height=50, lines_per_field=25, ctrl_block=True),
+             dict(n_frames=2, seed=4, height=24 if mode >= 2 else 40, noise_sigma=25.0, blur=3)]
+    for kw in cases:
+        luma, _, _ = synth.stc007_frames(**kw)
+        want, want_stats = oracle_binarize(luma, mode=mode)
+        got, got_stats, info = emu_run(emu_lib, luma, mode)
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+
+
+def test_emu_golden_rough_draft(emu_lib):
+    mode, luma, want, want_stats = golden_cases.load("ntsc_rough_draft")
+    got, got_stats, _ = emu_run(emu_lib, luma, mode)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+
+
+def test_emu_speculation_rounds(emu_lib, oracle_lib):
+    """Clean stream: cold frame alone, then every remaining frame in ONE parallel round; the chain state
+    is carried across calls."""
+    luma, _, _ = synth.stc007_frames(6, seed=9, height=32)
+    want, want_stats = oracle_binarize(luma, mode=1)
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    emu_lib.sdv_set_mode(eng, 1)
+    a, sa, ia = emu_run(emu_lib, luma[:4], 1, flags=1, first=1, eng=eng)
+    assert ia.rounds == 2 and ia.frames_launched == 4
+    b, sb, ib = emu_run(emu_lib, luma[4:], 1, flags=0, first=5, eng=eng)
+    assert ib.rounds == 1 and ib.frames_launched == 2
+    emu_lib.sdv_engine_destroy(eng)
+    got = np.concatenate([a, b])
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert np.concatenate([sa, sb]).view(np.uint8).tobytes() == want_stats.tobytes()
+
+
+def test_emu_misprediction_is_repaired(emu_lib, oracle_lib):
+    """A disturbance in the middle of the batch changes the tuning the later frames inherit: the first
+    parallel round mispredicts, the engine re-decodes from the break and still matches the oracle."""
+    luma, _, _ = synth.stc007_frames(6, seed=12, height=32)
+    luma = luma.copy()
+    luma[3:] = np.roll(luma[3:], 7, axis=2)                  # the data window moves by 7 px from frame 3 on
+    want, want_stats = oracle_binarize(luma, mode=1)
+    got, got_stats, info = emu_run(emu_lib, luma, 1)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    assert info.rounds >= 3 and info.frames_launched > 6
+
+
+def test_emu_bad_arguments(emu_lib):
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    buf = np.zeros((1, 8, 200), np.uint8)
+    recs = np.zeros(11, dtype=libs.LINE_DTYPE)
+    st = np.zeros(32, np.uint8)
+    f = emu_lib.sdv_binarize_frames
+    assert f(eng, None, 200, 1600, 200, 8, 1, 1, 0, recs.ctypes.data, st.ctypes.data, None) == 1      # SDV_ERR_NULL_VIDEO
+    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 1, 1, 0, None, st.ctypes.data, None) == 2         # SDV_ERR_NULL_PCM
+    assert f(eng, buf.ctypes.data, 100, 800, 100, 8, 1, 1, 0, recs.ctypes.data, st.ctypes.data, None) == 3  # SHORT_LINE
+    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 0, 1, 0, recs.ctypes.data, st.ctypes.data, None) == -1  # BAD_ARG
+    emu_lib.sdv_engine_destroy(eng)

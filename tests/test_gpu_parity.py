@@ -1,0 +1,135 @@
+"""GPU parity tests: the HIP path through the C-ABI vs the committed reference goldens and vs the oracle."""
+import numpy as np
+import pytest
+
+import golden_cases
+from oracle_run import oracle_binarize
+from sdvpcmdecoder_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def gpu_run(torch, luma, mode, new_file=True, first=1, eng=None, **kw):
+    from sdvpcmdecoder_amd import Engine, LINE_DTYPE
+    own = eng is None
+    if own:
+        eng = Engine(0)
+        eng.setBinarizationMode(mode)
+    d = torch.from_numpy(np.ascontiguousarray(luma)).to("cuda:0")
+    lines, stats = eng.binarize_frames(d, first_frame_no=first, new_file=new_file, **kw)
+    torch.cuda.synchronize()
+    info = eng.run_info()
+    recs = lines.cpu().numpy().view(LINE_DTYPE).reshape(-1)
+    st = stats.cpu().numpy()
+    if own:
+        eng.close()
+    return recs, st, info
+
+
+@pytest.mark.parametrize("name", list(golden_cases.CASES))
+def test_hip_matches_reference_golden(torch_cuda, name):
+    mode, luma, want, want_stats = golden_cases.load(name)
+    got, got_stats, _ = gpu_run(torch_cuda, luma, mode)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_hip_vs_oracle_degraded(torch_cuda, mode):
+    cases = [dict(n_frames=6, seed=21, noise_sigma=8.0, blur=1),
+             dict(n_frames=4, seed=22, noise_sigma=18.0, blur=2, height=120 if mode >= 2 else 486),
+             dict(n_frames=3, seed=23, black=70, white=130, noise_sigma=5.0, height=200),
+             dict(n_frames=3, seed=24, width=1440, x0=24, x1=1416, height=100),
+             dict(n_frames=3, seed=25, width=360, x0=6, x1=354, height=100)]
+    for kw in cases:
+        luma, _, _ = synth.stc007_frames(**kw)
+        want, want_stats = oracle_binarize(luma, mode=mode)
+        got, got_stats, _ = gpu_run(torch_cuda, luma, mode)
+        assert got.tobytes() == want.tobytes(), (kw, golden_cases.diff_report(got, want))
+        assert got_stats.tobytes() == want_stats.tobytes()
+
+
+def test_hip_jitter_and_dropouts(torch_cuda):
+    rng = np.random.default_rng(31)
+    luma, _, _ = synth.stc007_frames(8, seed=31, noise_sigma=5.0, blur=1)
+    luma = luma.copy()
+    for f in range(8):
+        rows = rng.integers(0, 486, 12)
+        for r in rows:
+            luma[f, r] = np.roll(luma[f, r], int(rng.integers(-3, 4)))
+        luma[f, rng.integers(0, 486, 4)] = 16
+    want, want_stats = oracle_binarize(luma, mode=2)
+    got, got_stats, info = gpu_run(torch_cuda, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
+
+
+def test_hip_stream_continuation_and_rounds(torch_cuda):
+    from sdvpcmdecoder_amd import Engine
+    luma, _, _ = synth.stc007_frames(64, seed=41)
+    want, want_stats = oracle_binarize(luma, mode=2)
+    eng = Engine(0)
+    eng.setBinarizationMode(2)
+    a, sa, ia = gpu_run(torch_cuda, luma[:40], 2, new_file=True, first=1, eng=eng)
+    b, sb, ib = gpu_run(torch_cuda, luma[40:], 2, new_file=False, first=41, eng=eng)
+    eng.close()
+    assert ia.rounds == 2 and ib.rounds == 1, (ia.rounds, ib.rounds)
+    got = np.concatenate([a, b])
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert np.concatenate([sa, sb]).tobytes() == want_stats.tobytes()
+
+
+def test_hip_doubled_and_m2_and_presets(torch_cuda):
+    from sdvpcmdecoder_amd import Engine
+    import libs
+    luma, _, _ = synth.stc007_frames(3, seed=51, width=1440, x0=24, x1=1416, height=80, noise_sigma=6.0)
+    want, want_stats = oracle_binarize(luma, mode=1, doubled=True, m2=True, check_line_dup=False)
+    eng = Engine(0)
+    eng.setPCMType(3)           # TYPE_M2
+    eng.setBinarizationMode(1)
+    eng.setCheckLineDup(False)
+    got, got_stats, _ = gpu_run(torch_cuda, luma, 1, eng=eng, doubled=True)
+    eng.close()
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
+    # fine settings: markers required, tighter contrast
+    p = libs.default_preset()
+    p.en_good_no_marker = 0
+    p.min_contrast = 40
+    luma, _, _ = synth.stc007_frames(3, seed=52, height=80, noise_sigma=12.0, blur=2)
+    want, want_stats = oracle_binarize(luma, mode=2, preset=p)
+    eng = Engine(0)
+    eng.setBinarizationMode(2)
+    ep = eng.getDefaultFineSettings()
+    ep.en_good_no_marker = 0
+    ep.min_contrast = 40
+    eng.setFineSettings(ep)
+    got, got_stats, _ = gpu_run(torch_cuda, luma, 2, eng=eng)
+    eng.close()
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+
+
+def test_hip_full_size_properties(torch_cuda):
+    """Size-independent properties on a big batch (oracle too slow to run here in full): every clean line must
+    decode to the generator's words with a valid CRC, except the first line of each field (FIELD_UNSAFE rule,
+    videotodigital.cpp:1159-1211), and the schedule must be 2 rounds."""
+    n = 512
+    luma, w9, _ = synth.stc007_frames(n, seed=61)
+    got, st, info = gpu_run(torch_cuda, luma, 2)
+    assert info.rounds == 2 and info.frames_launched == n
+    body = got[1:].reshape(n, 489)
+    lines = np.concatenate([body[:, :243], body[:, 244:487]], axis=1)      # odd rows, even rows
+    f = np.arange(n)[:, None]
+    r = np.arange(243)[None, :]
+    idx = np.concatenate([f * 490 + 2 + r, f * 490 + 245 + 2 + r], axis=1)
+    assert (lines["words"] == w9[idx]).all()
+    valid = (lines["flags"] & 64) != 0
+    assert valid[:, 1:243].all() and valid[:, 244:].all() and not valid[:, 0].any() and not valid[:, 243].any()
+    assert (body[:, 243]["service_type"] == 4).all() and (body[:, 487]["service_type"] == 4).all() and (body[:, 488]["service_type"] == 5).all()
