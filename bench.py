@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on BASELINE.json's metric: decoded video frames/s (720x486 STC-007).
+
+A "step" = one pass of the binarize path (Binarizer + VideoToDigital bit-cell extraction + per-line CRC)
+over one batch of synthetic NTSC frames that is already resident in HBM (workload = BASELINE.json
+configs[1]: 10k-frame synthetic STC-007 NTSC batch, 1 x MI355X, binarize + bit-extract + CRC only).
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1: launched by torch.distributed.run, one rank per GPU; every rank decodes its own stream of
+  `--frames` frames (weak scaling; the binarize path needs no data-path collective), timing is
+  barrier + synchronize bracketed, MAX over ranks, rank 0 prints ONE JSON line.
+
+Extra objects in the JSON line: "roofline" (HBM: algorithmic bytes per launch / HIP-event kernel time,
+measured live on the stream the kernel runs on) and "cpu_baseline" (the real reference, or the oracle
+port when the reference build is not loadable, timed on this host on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_frame(width, height):
+    """luma plane read once + packed outputs written once:
+    W*H luma + (H+3) x 48 B line records + 32 B frame descriptor."""
+    return width * height + (height + 3) * 48 + 32
+
+
+def cpu_baseline(luma_sample, mode):
+    """Times the CPU path on this host: the real reference (oracle/_ref, VideoToDigital worker thread)
+    when it loads, else the C port in oracle/.  Only used as a reported baseline."""
+    import ctypes as C
+    import numpy as np
+    import libs
+    n, h, w = luma_sample.shape
+    kind = "port"
+    try:
+        if libs.ref_available():
+            from golden.make_golden import run_ref  # noqa: F401
+            kind = "reference"
+    except Exception:
+        kind = "port"
+    if kind == "reference":
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+            mg = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mg)
+            fd = os.dup(2)                        # the reference logs "[V2D] Launched..." to stderr
+            devnull = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(devnull, 2)
+            try:
+                t0 = time.perf_counter()
+                recs, _ = mg.run_ref(luma_sample, mode)
+                dt = time.perf_counter() - t0
+            finally:
+                os.dup2(fd, 2)
+                os.close(devnull)
+                os.close(fd)
+        except Exception:
+            kind = "port"
+    if kind == "port":
+        from oracle_run import oracle_binarize
+        t0 = time.perf_counter()
+        recs, _ = oracle_binarize(luma_sample, mode=mode)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"first {n} frames of the same synthetic batch, {dt:.1f} s of CPU work, single worker thread "
+                      f"(the reference runs the path on one thread per stage)"}, recs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU per step")
+    ap.add_argument("--mode", type=int, default=2, help="Binarizer mode (2 = NORMAL, the reference default)")
+    ap.add_argument("--noise", type=float, default=4.0)
+    ap.add_argument("--cpu-frames", type=int, default=3000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sdvpcmdecoder_amd import Engine, synth, LINE_DTYPE
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the decode engine has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H = 720, 486
+    n = args.frames
+    luma, w9 = synth.stc007_frames_torch(n, seed=2 + rank, device=dev, width=W, height=H, noise_sigma=args.noise)
+    eng = Engine(local_rank)
+    eng.setBinarizationMode(args.mode)
+    eng.set_profiling(True)
+    nrec = n * (H + 3)
+    out_lines = torch.empty((nrec + 1, 48), dtype=torch.uint8, device=dev)
+    out_stats = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # first pass: start of the stream (cold chain: NEW_FILE, first frame decoded alone)
+    eng.binarize_frames(luma, first_frame_no=1, new_file=True, out_lines=out_lines, out_stats=out_stats, stream=stream)
+    torch.cuda.synchronize(dev)
+    first_recs = out_lines[:1 + 4 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(-1) if rank == 0 else None
+    # steady state: every step decodes the batch as the continuation of the stream
+    for _ in range(args.warmup):
+        eng.binarize_frames(luma, first_frame_no=1, new_file=False, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+    barrier()
+    kernel_ms = 0.0
+    rounds = 0
+    launched = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.binarize_frames(luma, first_frame_no=1, new_file=False, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+        info = eng.run_info()
+        kernel_ms += info.kernel_ms
+        rounds += info.rounds
+        launched += info.frames_launched
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # correctness of what was timed: all lines decode to the generator's words
+    recs = out_lines[1:1 + nrec].view(-1)  # device bytes
+    host = out_lines[1:1 + 8 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(8, H + 3)
+    lines = np.concatenate([host[:, :243], host[:, 244:487]], axis=1)
+    f = np.arange(8)[:, None]
+    r = np.arange(243)[None, :]
+    idx = np.concatenate([f * 490 + 2 + r, f * 490 + 245 + 2 + r], axis=1)
+    words_ok = bool((lines["words"] == w9.cpu().numpy()[idx].astype(np.uint16)).all())
+
+    if rank == 0:
+        total_frames = n * world * args.steps
+        value = total_frames / dt
+        bpf = algorithmic_bytes_per_frame(W, H)
+        avg_launch_ms = kernel_ms / max(rounds, 1)
+        frames_per_launch = launched / max(rounds, 1)
+        achieved = (bpf * frames_per_launch) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        out = {
+            "metric": "decoded video frames/sec (720x486 STC-007), binarize+bit-extract+CRC, bit-exact vs CPU",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {n}-frame synthetic STC-007 NTSC 720x486 batch per GPU resident in HBM, "
+                                   f"Binarizer mode {args.mode}, noise sigma {args.noise}, binarize+bit-extract+CRC only",
+                       "frames_per_gpu_per_step": n, "speculation_rounds_per_step": rounds / args.steps,
+                       "decoded_words_match_generator": words_ok},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sdv_k_stc007_frames", "avg_launch_ms": avg_launch_ms,
+                         "algorithmic_bytes_per_launch": bpf * frames_per_launch},
+        }
+        if not args.no_cpu and world == 1:
+            ncpu = min(args.cpu_frames, n)
+            sample = luma[:ncpu].cpu().numpy()
+            cb, cpu_recs = cpu_baseline(sample, args.mode)
+            # the CPU path and the GPU path decode the same stream start: compare what both produced
+            k = min(len(first_recs), len(cpu_recs))
+            cb["bit_exact_vs_gpu_on_overlap"] = bool(first_recs[:k].tobytes() == cpu_recs[:k].tobytes())
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

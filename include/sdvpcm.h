@@ -170,11 +170,15 @@ enum {
 /* How the last sdv_binarize_frames call was scheduled (chain speculation). */
 typedef struct sdv_run_info {
     uint32_t frames;            /* frames in the call */
-    uint32_t rounds;            /* speculation rounds (kernel launches) needed; 1 = fully parallel */
+    uint32_t rounds;            /* speculation rounds (launches of the frame kernel) needed; 1 = fully parallel */
     uint32_t frames_launched;   /* frame decodes executed, including re-decodes after a misprediction */
     uint32_t _pad;
+    float kernel_ms;            /* HIP-event time of the frame kernel launches of this call (sdv_set_profiling) */
+    float _pad2;
 } sdv_run_info;
 int sdv_get_run_info(const sdv_engine *e, sdv_run_info *out);
+/* Bracket every frame-kernel launch with hipEvents on the caller's stream and report the sum in sdv_run_info. */
+int sdv_set_profiling(sdv_engine *e, int on);
 
 /* records emitted per frame: `height` scanlines + 2 END_FIELD + 1 END_FRAME service lines */
 size_t sdv_records_per_frame(int height);

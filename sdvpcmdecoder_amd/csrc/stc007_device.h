@@ -151,6 +151,10 @@ struct Bin {                        /* Binarizer (binarizer.h:306-337) */
 struct Markers { uint8_t st_stage, ed_stage; uint16_t st1s, st1e, st3e, ed_start, ed_end; bool has_start; };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+/* Wave-uniform values that reach us through vector memory (global/LDS/scratch loads) are re-declared
+ * uniform so the compiler keeps them in SGPRs and branches on them with scalar branches. */
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uniu(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 __device__ __forceinline__ bool coords_valid(const Coords &c)    /* frametrimset.cpp:153-156 */
 {
@@ -1288,10 +1292,11 @@ __device__ inline bool median_keys(const uint32_t *keys, int n, uint32_t *out_ke
 {
     if (n <= 0) return false;
     int lane = lane_id();
-    uint32_t mn = 0xFFFFFFFFu, mx = 0;
-    for (int j = lane; j < n; j += 64) { uint32_t k = keys[j]; mn = k < mn ? k : mn; mx = k > mx ? k : mx; }
-    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
-    if (mn == mx) { *out_key = mn; return true; }
+    /* common case: every entry identical (steady tuning) -> one ballot */
+    uint32_t k0 = keys[0];
+    bool differs = false;
+    for (int j = lane; j < n; j += 64) differs = differs || (keys[j] != k0);
+    if (__ballot(differs) == 0ull) { *out_key = uniu(k0); return true; }
     int target = n / 2;
     uint32_t res = 0;
     for (int base = 0; base < n; base += 64) {          /* uniform trip count */
@@ -1304,7 +1309,7 @@ __device__ inline bool median_keys(const uint32_t *keys, int n, uint32_t *out_ke
             hit = (less <= target) && (target < leq);
         }
         uint64_t m = __ballot(hit);
-        if (m != 0ull) { res = (uint32_t)__shfl((int)ki, __ffsll((unsigned long long)m) - 1); *out_key = res; return true; }
+        if (m != 0ull) { res = uniu((uint32_t)__shfl((int)ki, __ffsll((unsigned long long)m) - 1)); *out_key = res; return true; }
     }
     *out_key = res;
     return false;
@@ -1478,6 +1483,29 @@ __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, u
     v.q_line_length = v.q_odd = v.q_even = v.q_pcm_odd = v.q_pcm_even = v.q_bad_odd = v.q_bad_even = v.q_dup_odd = v.q_dup_even = 0;
 }
 
+/* re-declare the whole hot state wave-uniform (after loading it from memory) */
+__device__ inline void v2d_make_uniform(V2D &v)
+{
+    Bin &b = v.bin;
+    b.in_black = (uint8_t)uni(b.in_black); b.in_white = (uint8_t)uni(b.in_white); b.in_ref = (uint8_t)uni(b.in_ref);
+    b.in_coord.start = (int16_t)uni(b.in_coord.start); b.in_coord.stop = (int16_t)uni(b.in_coord.stop); b.in_coord.doubled = uni(b.in_coord.doubled) != 0;
+    b.in_max_hyst = (uint8_t)uni(b.in_max_hyst); b.in_max_shift = (uint8_t)uni(b.in_max_shift);
+    b.do_ref_lvl_sweep = uni(b.do_ref_lvl_sweep) != 0; b.mode = (uint8_t)uni(b.mode);
+    b.hyst_lim = (uint8_t)uni(b.hyst_lim); b.shift_lim = (uint8_t)uni(b.shift_lim);
+    b.line_length = (uint16_t)uni(b.line_length); b.scan_start = (uint16_t)uni(b.scan_start); b.scan_end = (uint16_t)uni(b.scan_end);
+    b.mark_start_max = (uint16_t)uni(b.mark_start_max); b.mark_end_min = (uint16_t)uni(b.mark_end_min); b.estimated_ppb = (uint16_t)uni(b.estimated_ppb);
+    b.was_bw_scanned = uni(b.was_bw_scanned) != 0; b.vl_doubled = uni(b.vl_doubled) != 0;
+    v.field_state = (uint8_t)uni(v.field_state); v.reset_stats = uni(v.reset_stats) != 0;
+    v.good_coords_in_field = (uint16_t)uni(v.good_coords_in_field); v.pcm_lines_in_field = (uint16_t)uni(v.pcm_lines_in_field);
+    v.line_in_field_cnt = (uint16_t)uni(v.line_in_field_cnt);
+    v.frame_avg.start = (int16_t)uni(v.frame_avg.start); v.frame_avg.stop = (int16_t)uni(v.frame_avg.stop); v.frame_avg.doubled = uni(v.frame_avg.doubled) != 0;
+    v.n_last = uni(v.n_last); v.n_long = uni(v.n_long); v.nfv = uni(v.nfv); v.nfi = uni(v.nfi);
+    for (int i = 0; i < 8; i++) v.last_words[i] = (uint16_t)uni(v.last_words[i]);
+    v.q_line_length = (uint16_t)uni(v.q_line_length); v.q_odd = (uint16_t)uni(v.q_odd); v.q_even = (uint16_t)uni(v.q_even);
+    v.q_pcm_odd = (uint16_t)uni(v.q_pcm_odd); v.q_pcm_even = (uint16_t)uni(v.q_pcm_even); v.q_bad_odd = (uint16_t)uni(v.q_bad_odd);
+    v.q_bad_even = (uint16_t)uni(v.q_bad_even); v.q_dup_odd = (uint16_t)uni(v.q_dup_odd); v.q_dup_even = (uint16_t)uni(v.q_dup_even);
+}
+
 /* ---- chain state <-> registers ---------------------------------------------------------------- */
 __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state *s, const FrameArgs &a)
 {
@@ -1498,6 +1526,7 @@ __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state 
     v.nfv = v.nfi = 0;
     for (int i = 0; i < 8; i++) v.last_words[i] = 0;
     v.q_line_length = v.q_odd = v.q_even = v.q_pcm_odd = v.q_pcm_even = v.q_bad_odd = v.q_bad_even = v.q_dup_odd = v.q_dup_even = 0;
+    v2d_make_uniform(v);
 }
 __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a)
 {
@@ -1523,16 +1552,31 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
     *s = o;
 }
 
-/* stage one scanline into LDS: coalesced 16-byte loads when the row is 16-byte aligned */
-__device__ inline void stage_row(WaveLds &lds, const uint8_t *row, int width)
+/* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
+ * hides under the decode of the current line) -> LDS.  Rows that are not 16-byte aligned take the slow
+ * byte path at commit time. */
+struct RowPrefetch { uint4 v0, v1; const uint8_t *row; };
+
+__device__ inline void row_prefetch(RowPrefetch &pf, const uint8_t *row, int width)
+{
+    pf.row = row;
+    if (row != nullptr && (((uintptr_t)row) & 15) == 0) {
+        int lane = lane_id(), nvec = width >> 4;
+        const uint4 *src = (const uint4 *)row;
+        if (lane < nvec) pf.v0 = src[lane];
+        if (lane + 64 < nvec) pf.v1 = src[lane + 64];
+    }
+}
+__device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width)
 {
     __syncthreads();
     int lane = lane_id();
+    const uint8_t *row = pf.row;
     if ((((uintptr_t)row) & 15) == 0) {
         int nvec = width >> 4;
-        const uint4 *src = (const uint4 *)row;
         uint4 *dst = (uint4 *)lds.px;
-        for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+        if (lane < nvec) dst[lane] = pf.v0;
+        if (lane + 64 < nvec) dst[lane + 64] = pf.v1;
         for (int i = (nvec << 4) + lane; i < width; i += 64) lds.px[i] = row[i];
     } else {
         for (int i = lane; i < width; i += 64) lds.px[i] = row[i];
@@ -1548,6 +1592,146 @@ __device__ inline void emit_record(const Line &wl, sdv_line_rec *dst)
 /* ======================================================================================== */
 /* Kernel: one wavefront (= one workgroup of 64) per frame                                   */
 /* ======================================================================================== */
+/* ---------------------------------------------------------------------------------------------
+ * Fast path: the steady state of a good recording.  Everything the previous good line tuned is preset
+ * (B/W levels, reference level, data coordinates), so Binarizer::processLine goes STG_INPUT_ALL ->
+ * readPCMdata -> STG_DATA_OK (binarizer.cpp:774-931, 1534-1621) and VideoToDigital only does its
+ * per-line bookkeeping (videotodigital.cpp:1155-1396, 1524-1633).  This function restates exactly that
+ * branch with the minimum of live state; whenever any condition of the branch does not hold it returns
+ * false WITHOUT side effects and the general slow_line() decodes the line from scratch.
+ * --------------------------------------------------------------------------------------------- */
+struct Geo { int16_t start, stop; uint32_t psm; int32_t vp0, vp1; bool valid; };      /* cached bit-cell centres */
+struct LaneConst { uint64_t klo, khi; };                                              /* CRC parity masks of this lane */
+
+__device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &g, const LaneConst &lc,
+                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec)
+{
+    const sdv_bin_preset &ps = a.preset;
+    Bin &b = v.bin;
+    if (ps.en_force_coords || !ps.en_good_no_marker) return false;
+    if (!(are_bw_levels_preset(b, ps) && is_ref_level_preset(b, ps) && coords_valid(b.in_coord))) return false;
+    if (a.width < BITS_IN_LINE || (a.width - 1) < BITS_BETWEEN) return false;
+    const int lane = lane_id();
+    const uint16_t pixel_start = 0, pixel_stop = (uint16_t)(a.width - 1);
+    if (!g.valid || g.start != b.in_coord.start || g.stop != b.in_coord.stop) {
+        Line t; t.pixel_start = pixel_start; t.pixel_stop = pixel_stop;
+        set_ppb(t, b.in_coord);
+        g.start = b.in_coord.start; g.stop = b.in_coord.stop; g.psm = t.psm; g.valid = true;
+        g.vp0 = bit_center(t, lane); g.vp1 = bit_center(t, lane + 64);
+    }
+    uint8_t hyst_lim = b.in_max_hyst, shift_lim = b.in_max_shift;
+    if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
+    if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
+    uint64_t s_lo = 0, s_hi = 0; uint16_t calc_crc = 0; uint8_t ref_low = 0, ref_high = 0; int fh = 0, fs = 0;
+    bool found = false;
+    for (int h = 0; h <= (int)hyst_lim && !found; h++) {
+        ref_low = get_low_level(b.in_ref, (uint8_t)h); ref_high = get_high_level(b.in_ref, (uint8_t)h);
+        if (ref_low <= b.in_black || ref_high >= b.in_white) break;       /* fillDataWords level clipping */
+        for (int st = 0; st <= (int)shift_lim; st++) {
+            int sh = (st == 0) ? 0 : ((st & 1) ? ((st + 1) >> 1) : -(st >> 1));
+            int32_t x0 = g.vp0 + sh, x1 = g.vp1 + sh;
+            x0 = x0 < (int32_t)pixel_start ? (int32_t)pixel_start : (x0 >= (int32_t)pixel_stop ? (int32_t)pixel_stop - 1 : x0);
+            x1 = x1 < (int32_t)pixel_start ? (int32_t)pixel_start : (x1 >= (int32_t)pixel_stop ? (int32_t)pixel_stop - 1 : x1);
+            uint8_t p0 = lds.px[x0], p1 = lds.px[x1];
+            uint64_t a_lo = __ballot(p0 > ref_low), b_lo = __ballot(p0 >= ref_high);
+            uint64_t a_hi = __ballot(p1 > ref_low), b_hi = __ballot(p1 >= ref_high);
+            solve_automaton(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+            int par = (__popcll(s_lo & lc.klo) + __popcll(s_hi & lc.khi)) & 1;
+            calc_crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc.init);
+            if (calc_crc == rev16((uint32_t)((s_hi >> 48) & 0xFFFF))) { found = true; fh = h; fs = st; break; }
+        }
+    }
+    if (!found) return false;
+    uint16_t w[9];
+    w[0] = rev14((uint32_t)(s_lo & 0x3FFF));
+    w[1] = rev14((uint32_t)((s_lo >> 14) & 0x3FFF));
+    w[2] = rev14((uint32_t)((s_lo >> 28) & 0x3FFF));
+    w[3] = rev14((uint32_t)((s_lo >> 42) & 0x3FFF));
+    w[4] = rev14((uint32_t)(((s_lo >> 56) | (s_hi << 8)) & 0x3FFF));
+    w[5] = rev14((uint32_t)((s_hi >> 6) & 0x3FFF));
+    w[6] = rev14((uint32_t)((s_hi >> 20) & 0x3FFF));
+    w[7] = rev14((uint32_t)((s_hi >> 34) & 0x3FFF));
+    w[8] = calc_crc;
+    if (w[0] == 0x3333 && w[1] == 0x0CCC && w[2] == 0x3333 && w[3] == 0x0CCC && w[4] == 0 && (w[7] & 0x0FF0) == 0) return false;   /* Control Block: general path */
+
+    /* ---- VideoToDigital bookkeeping for a line with valid CRC ---- */
+    const bool even_line = (line_num % 2) == 0;
+    const bool doubled = a.doubled != 0;
+    bool forced_bad = false;
+    if (v.field_state == FIELD_NEW) v.field_state = FIELD_UNSAFE;
+    v.good_coords_in_field++;
+    v.q_line_length = (uint16_t)a.width;
+    if (a.check_line_copy) {
+        if (v.field_state == FIELD_UNSAFE) {
+            b.in_coord.doubled = doubled;                   /* setGoodParameters(): same levels, same pair */
+            if (ps.en_first_line_dup) forced_bad = true;
+        } else {
+            uint8_t diff = words_diff_bit_count(w, v.last_words);
+            Line t; t.m2 = a.m2_format != 0; for (int i = 0; i < 6; i++) t.words[i] = w[i];
+            if (!stc_is_almost_silent(t) && diff <= (BITS_DATA / BIT_DIFF_THRES_DIV)) { forced_bad = true; if (!even_line) v.q_dup_odd++; else v.q_dup_even++; }
+        }
+    }
+    {
+        uint32_t key = coords_key(b.in_coord.start, b.in_coord.stop);
+        __syncthreads();
+        if (lane == 0) {
+            if (v.n_last == COORD_HISTORY_DEPTH) for (int i = 0; i < COORD_HISTORY_DEPTH - 1; i++) lds.lv_keys[i] = lds.lv_keys[i + 1];
+            lds.lv_keys[v.n_last == COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
+        }
+        if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
+        __syncthreads();
+        fv_keys[v.nfv++] = key;
+        if (a.coordinate_damper && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
+            Coords target; coords_clear(target);
+            uint32_t k;
+            if (median_keys(lds.lv_keys, v.n_last, &k)) target = key_to_coords(k, false);
+            if (!coords_valid(target)) target = v.frame_avg;
+            if (coords_valid(target)) {
+                int16_t ds = (int16_t)(b.in_coord.start - target.start), de = (int16_t)(b.in_coord.stop - target.stop);
+                uint8_t in_delta = (uint8_t)(((uint8_t)(g.psm / 128u)) * 3);
+                if (((int)ds <= -(int)in_delta) || ((int)ds >= (int)in_delta) || ((int)de <= -(int)in_delta) || ((int)de >= (int)in_delta)) forced_bad = true;
+            }
+        }
+    }
+    if (!forced_bad) b.in_coord.doubled = doubled;           /* setGoodParameters(work_line) */
+    else { if (!even_line) v.q_bad_odd++; else v.q_bad_even++; }
+    v.field_state = FIELD_INIT;
+    if (!even_line) { v.q_odd++; v.q_pcm_odd++; } else { v.q_even++; v.q_pcm_even++; }
+    v.pcm_lines_in_field++;
+    for (int i = 0; i < 8; i++) v.last_words[i] = w[i];
+    v.line_in_field_cnt++;
+    b.line_length = (uint16_t)a.width;
+
+    if (lane == 0) {
+        sdv_line_rec r;
+        r.frame_number = frame_no; r.line_number = line_num;
+        for (int i = 0; i < 9; i++) r.words[i] = w[i];
+        r.calc_crc = calc_crc;
+        r.data_start = b.in_coord.start; r.data_stop = b.in_coord.stop;
+        r.marker_start_bg_coord = 0; r.marker_start_ed_coord = 0; r.marker_stop_ed_coord = 0;
+        r.black_level = b.in_black; r.white_level = b.in_white; r.ref_low = ref_low; r.ref_level = b.in_ref; r.ref_high = ref_high;
+        r.hysteresis_depth = (uint8_t)fh; r.shift_stage = (uint8_t)fs; r.service_type = SDV_SRV_NO;
+        r.mark_st_stage = MARK_ST_START; r.mark_ed_stage = MARK_ED_START;
+        r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | (forced_bad ? SDV_LF_FORCED_BAD : SDV_LF_CRC_VALID) | (doubled ? SDV_LF_FROM_DOUBLED : 0));
+        r.word_state = forced_bad ? 0 : (uint8_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
+        *rec = r;
+    }
+    return true;
+}
+
+/* General path for one regular line, out of line so that its register appetite (reference sweep, marker
+ * searches) does not spill into the hot loop.  State crosses the call in memory. */
+struct SlowCtx { FrameArgs a; V2D v; Line wl; };
+
+__device__ __attribute__((noinline)) void slow_line(SlowCtx *c, WaveLds *lds, uint32_t frame_no, uint16_t line_num,
+                                                    uint32_t *fv_keys, uint32_t *fi_keys, sdv_line_rec *rec)
+{
+    bin_set_mode(c->v.bin, c->a.mode);
+    process_line(c->v.bin, c->a.preset, *lds, c->wl, frame_no, line_num, c->a.width, c->a.doubled != 0);
+    v2d_post_line(c->v, c->a, *lds, c->wl, fv_keys, fi_keys, (line_num % 2) == 0);
+    emit_record(c->wl, rec);
+}
+
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 {
     V2D v; Line wl;
@@ -1559,20 +1743,34 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     size_t rec_base = (size_t)f * (size_t)(a.height + 3);
     if (a.new_file_frame >= 0 && f > a.new_file_frame) rec_base += 1;
     sdv_line_rec *rec = a.recs + rec_base;
-    const bool doubled = a.doubled != 0;
+    Geo geo; geo.valid = false; geo.start = geo.stop = 0; geo.psm = 0; geo.vp0 = geo.vp1 = 0;
+    LaneConst lc;
+    lc.klo = (lane_id() < 16) ? c_crc.klo[lane_id() & 15] : 0ull;
+    lc.khi = (lane_id() < 16) ? c_crc.khi[lane_id() & 15] : 0ull;
 
     v2d_begin_frame(v, a, lds);
     if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
     uint16_t line_num = 0;
+    RowPrefetch pf;
+    pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
+    row_prefetch(pf, frame, a.width);
     for (int field = 0; field < 2; field++) {
         int line_offset = field;
         line_num = (uint16_t)(line_offset + 1);
         for (;;) {
-            stage_row(lds, frame + (size_t)line_offset * a.row_stride, a.width);
-            v.bin.mode = a.mode; bin_set_mode(v.bin, a.mode);
-            process_line(v.bin, a.preset, lds, wl, frame_no, line_num, a.width, doubled);
-            v2d_post_line(v, a, lds, wl, fv_keys, fi_keys, (line_num % 2) == 0);
-            emit_record(wl, rec++);
+            row_commit(lds, pf, a.width);
+            {   /* next row of the frame in decode order (nullptr after the last one) */
+                int next = (line_offset < (a.height - 2)) ? line_offset + 2 : (field == 0 ? 1 : -1);
+                row_prefetch(pf, next >= 0 ? frame + (size_t)next * a.row_stride : nullptr, a.width);
+            }
+            if (!fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec)) {
+                SlowCtx c;
+                c.a = a; c.v = v;
+                slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
+                v = c.v;
+                v2d_make_uniform(v);
+            }
+            rec++;
             if (line_offset < (a.height - 2)) line_offset += 2;
             else { line_num = (uint16_t)(line_num + 2); break; }
             line_num = (uint16_t)(line_num + 2);
@@ -1589,7 +1787,10 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 
 } // namespace sdv
 
-__global__ void __launch_bounds__(64) sdv_k_stc007_frames(sdv::FrameArgs a)
+#ifndef SDV_WAVES_PER_EU
+#define SDV_WAVES_PER_EU 1
+#endif
+__global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
     int f = a.frame_lo + (int)blockIdx.x;

@@ -46,7 +46,8 @@ class BinPreset(C.Structure):
 
 
 class RunInfo(C.Structure):
-    _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32)]
+    _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32),
+                ("kernel_ms", C.c_float), ("_pad2", C.c_float)]
 
 
 _lib = None
@@ -57,7 +58,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or _LIB_PATH
+    p = path or os.environ.get("SDVPCM_LIB") or _LIB_PATH   # SDVPCM_LIB: alternative builds of the same HIP library (tuning experiments)
     if not os.path.exists(p):
         raise RuntimeError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -75,6 +76,7 @@ def load_library(path: str | None = None):
     lib.sdv_set_pcm_type.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.sdv_reset_stream.argtypes = [C.c_void_p]
     lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
+    lib.sdv_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.sdv_set_chain_state.argtypes = [C.c_void_p, C.c_void_p]
     lib.sdv_records_per_frame.restype = C.c_size_t
@@ -139,6 +141,9 @@ class Engine:
 
     def reset_stream(self):
         self._check(self.lib.sdv_reset_stream(self._h))
+
+    def set_profiling(self, on: bool = True):
+        self._check(self.lib.sdv_set_profiling(self._h, int(on)))
 
     def run_info(self) -> RunInfo:
         info = RunInfo()

@@ -167,3 +167,74 @@ def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 
     flat = idx.reshape(-1)
     luma = render_lines(line_bits(w9[flat]), width=width, rng=rng, **render_kw)
     return luma.reshape(n_frames, height, width), w9, audio
+
+
+# ------------------------------------------------------------------------------------------------
+# torch version of the frame generator (runs on the GPU so that the 10k-frame benchmark batch is
+# created directly in HBM).  Same construction as stc007_frames(); its own RNG stream.
+# ------------------------------------------------------------------------------------------------
+def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int = 720, height: int = 486,
+                        lines_per_field: int = 245, cut_top: int | None = None, black: int = 30, white: int = 200,
+                        x0: int = 12, x1: int | None = None, noise_sigma: float = 0.0, chunk_frames: int = 256):
+    """Returns (luma (n_frames, height, width) uint8 on `device`, words (n_stream_lines, 9) int32 on `device`)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    vis = height // 2
+    if cut_top is None:
+        cut_top = max(0, lines_per_field - vis)
+    if x1 is None:
+        x1 = width - 12
+    n_stream = n_frames * 2 * lines_per_field
+    audio = torch.randint(0, 1 << 14, (n_stream, 6), generator=g, device=device, dtype=torch.int32)
+    p = audio[:, 0] ^ audio[:, 1] ^ audio[:, 2] ^ audio[:, 3] ^ audio[:, 4] ^ audio[:, 5]
+    q = torch.zeros(n_stream, dtype=torch.int32, device=device)
+    for k in range(6):
+        v = q ^ audio[:, k]
+        q = ((v << 1) & WORD_MASK) ^ (((v >> 13) & 1) * 0x0101)
+    blk = torch.cat([audio, p[:, None], q[:, None]], dim=1)
+    lines = torch.zeros((n_stream, 8), dtype=torch.int32, device=device)
+    for k in range(8):
+        lines[16 * k:, k] = blk[:n_stream - 16 * k, k]
+    crc = torch.full((n_stream,), 0xFFFF, dtype=torch.int32, device=device)
+    for k in range(8):
+        for bit in range(13, -1, -1):
+            inb = (lines[:, k] >> bit) & 1
+            msb = (crc >> 15) & 1
+            crc = (crc << 1) & 0xFFFF
+            crc = torch.where(msb != inb, crc ^ 0x1021, crc)
+    w9 = torch.cat([lines, crc[:, None]], dim=1)
+    # raster
+    x = torch.arange(width, device=device)
+    cell = ((x - x0) * BITS_IN_LINE) // (x1 - x0)
+    inside = (x >= x0) & (x < x1)
+    cell = cell.clamp(0, BITS_IN_LINE - 1)
+    luma = torch.empty((n_frames, height, width), dtype=torch.uint8, device=device)
+    for f0 in range(0, n_frames, chunk_frames):
+        f1 = min(n_frames, f0 + chunk_frames)
+        f = torch.arange(f0, f1, device=device)[:, None]
+        r = torch.arange(vis, device=device)[None, :]
+        odd = f * 2 * lines_per_field + cut_top + r
+        even = odd + lines_per_field
+        idx = torch.empty((f1 - f0, height), dtype=torch.long, device=device)
+        idx[:, 0:2 * vis:2] = odd
+        idx[:, 1:2 * vis:2] = even
+        w = w9[idx.reshape(-1)]                                          # (L, 9)
+        bits = torch.zeros((w.shape[0], BITS_IN_LINE), dtype=torch.uint8, device=device)
+        bits[:, 0] = 1
+        bits[:, 2] = 1
+        pos = 4
+        for k in range(8):
+            for bit in range(13, -1, -1):
+                bits[:, pos] = ((w[:, k] >> bit) & 1).to(torch.uint8)
+                pos += 1
+        for bit in range(15, -1, -1):
+            bits[:, pos] = ((w[:, 8] >> bit) & 1).to(torch.uint8)
+            pos += 1
+        bits[:, pos + 1:pos + 5] = 1
+        b = torch.index_select(bits, 1, cell) * inside.to(torch.uint8)[None, :]
+        img = b.to(torch.float32) * float(white - black) + float(black)
+        if noise_sigma > 0:
+            img = img + torch.randn(img.shape, generator=g, device=device) * noise_sigma
+        luma[f0:f1] = img.round().clamp(0, 255).to(torch.uint8).reshape(f1 - f0, height, width)
+    return luma, w9

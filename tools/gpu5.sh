@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/bench_cur.json 2> gpurun_out/bench_cur.err; echo "rc=$?"
+python -c "
+import json;d=json.load(open('gpurun_out/bench_cur.json'));print('cur', d['value'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config']['decoded_words_match_generator'])"
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-include-regex 'sdv_k_stc007' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/pmc1.err; echo "rc=$?"
