@@ -32,6 +32,20 @@ def algorithmic_bytes_per_frame(width, height):
     return width * height + (height + 3) * 48 + 32
 
 
+def measured_hbm_traffic(frames_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command, profiles/r01_pmc_sdv_k_stc007_frames.json): FETCH_SIZE is in KB and, on gfx950, reports half
+    of a wide coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE in KB. Scaled per frame."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sdv_k_stc007_frames.json")
+    try:
+        d = json.load(open(path))
+        fetch = float(d["pmc3"]["FETCH_SIZE"]) * 1024.0 * 2.0
+        write = float(d["pmc4"]["WRITE_SIZE"]) * 1024.0
+        return (fetch + write) / 10000.0 * frames_per_launch
+    except Exception:
+        return None
+
+
 def cpu_baseline(luma_sample, mode):
     """Times the CPU path on this host: the real reference (oracle/_ref, VideoToDigital worker thread)
     when it loads, else the C port in oracle/.  Only used as a reported baseline."""
@@ -169,7 +183,8 @@ def main():
                        "frames_per_gpu_per_step": n, "speculation_rounds_per_step": rounds / args.steps,
                        "decoded_words_match_generator": words_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(frames_per_launch),
+                         "traffic_unit": "bytes per launch, from the rocprofv3 PMC passes committed under profiles/",
                          "kernel": "sdv_k_stc007_frames", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_launch": bpf * frames_per_launch},
         }

@@ -1602,19 +1602,26 @@ __device__ inline void emit_record(const Line &wl, sdv_line_rec *dst)
  * --------------------------------------------------------------------------------------------- */
 struct Geo { int16_t start, stop; uint32_t psm; int32_t vp0, vp1; bool valid; };      /* cached bit-cell centres */
 struct LaneConst { uint64_t klo, khi; };                                              /* CRC parity masks of this lane */
+struct FastBits { uint64_t s_lo, s_hi; uint16_t calc_crc; uint8_t ref_low, ref_high, h, s; bool ctrl_block; };
 
-__device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &g, const LaneConst &lc,
-                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec)
+/* are the conditions of the STG_INPUT_ALL branch met for the coming line? (wave-uniform, no side effects) */
+__device__ inline bool fast_eligible(const FrameArgs &a, const Bin &b)
 {
     const sdv_bin_preset &ps = a.preset;
-    Bin &b = v.bin;
     if (ps.en_force_coords || !ps.en_good_no_marker) return false;
     if (!(are_bw_levels_preset(b, ps) && is_ref_level_preset(b, ps) && coords_valid(b.in_coord))) return false;
     if (a.width < BITS_IN_LINE || (a.width - 1) < BITS_BETWEEN) return false;
+    return true;
+}
+
+/* readPCMdata under the preset tuning for the scanline staged in LDS: the (hysteresis, shift) ladder of
+ * binarizer.cpp:7769-7954 with the wave-parallel fill.  Returns false when no pair gives a valid CRC. */
+__device__ inline bool fast_decode(const FrameArgs &a, const WaveLds &lds, const Bin &b, Geo &g, const LaneConst &lc, FastBits &o)
+{
     const int lane = lane_id();
-    const uint16_t pixel_start = 0, pixel_stop = (uint16_t)(a.width - 1);
+    const int32_t pixel_start = 0, pixel_stop = a.width - 1;
     if (!g.valid || g.start != b.in_coord.start || g.stop != b.in_coord.stop) {
-        Line t; t.pixel_start = pixel_start; t.pixel_stop = pixel_stop;
+        Line t; t.pixel_start = (uint16_t)pixel_start; t.pixel_stop = (uint16_t)pixel_stop;
         set_ppb(t, b.in_coord);
         g.start = b.in_coord.start; g.stop = b.in_coord.stop; g.psm = t.psm; g.valid = true;
         g.vp0 = bit_center(t, lane); g.vp1 = bit_center(t, lane + 64);
@@ -1630,8 +1637,8 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         for (int st = 0; st <= (int)shift_lim; st++) {
             int sh = (st == 0) ? 0 : ((st & 1) ? ((st + 1) >> 1) : -(st >> 1));
             int32_t x0 = g.vp0 + sh, x1 = g.vp1 + sh;
-            x0 = x0 < (int32_t)pixel_start ? (int32_t)pixel_start : (x0 >= (int32_t)pixel_stop ? (int32_t)pixel_stop - 1 : x0);
-            x1 = x1 < (int32_t)pixel_start ? (int32_t)pixel_start : (x1 >= (int32_t)pixel_stop ? (int32_t)pixel_stop - 1 : x1);
+            x0 = x0 < pixel_start ? pixel_start : (x0 >= pixel_stop ? pixel_stop - 1 : x0);
+            x1 = x1 < pixel_start ? pixel_start : (x1 >= pixel_stop ? pixel_stop - 1 : x1);
             uint8_t p0 = lds.px[x0], p1 = lds.px[x1];
             uint64_t a_lo = __ballot(p0 > ref_low), b_lo = __ballot(p0 >= ref_high);
             uint64_t a_hi = __ballot(p1 > ref_low), b_hi = __ballot(p1 >= ref_high);
@@ -1642,7 +1649,16 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         }
     }
     if (!found) return false;
-    uint16_t w[9];
+    o.s_lo = s_lo; o.s_hi = s_hi; o.calc_crc = calc_crc; o.ref_low = ref_low; o.ref_high = ref_high; o.h = (uint8_t)fh; o.s = (uint8_t)fs;
+    /* Control Block pattern on the raw cells (stc007line.cpp:493-504): words 0..4 fixed, word 7 bits 4..11 zero */
+    uint16_t w0 = rev14((uint32_t)(s_lo & 0x3FFF)), w1 = rev14((uint32_t)((s_lo >> 14) & 0x3FFF)), w2 = rev14((uint32_t)((s_lo >> 28) & 0x3FFF));
+    uint16_t w3 = rev14((uint32_t)((s_lo >> 42) & 0x3FFF)), w4 = rev14((uint32_t)(((s_lo >> 56) | (s_hi << 8)) & 0x3FFF)), w7 = rev14((uint32_t)((s_hi >> 34) & 0x3FFF));
+    o.ctrl_block = (w0 == 0x3333 && w1 == 0x0CCC && w2 == 0x3333 && w3 == 0x0CCC && w4 == 0 && (w7 & 0x0FF0) == 0);
+    return true;
+}
+
+__device__ inline void bits_to_words(uint64_t s_lo, uint64_t s_hi, uint16_t *w)
+{
     w[0] = rev14((uint32_t)(s_lo & 0x3FFF));
     w[1] = rev14((uint32_t)((s_lo >> 14) & 0x3FFF));
     w[2] = rev14((uint32_t)((s_lo >> 28) & 0x3FFF));
@@ -1651,10 +1667,23 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
     w[5] = rev14((uint32_t)((s_hi >> 6) & 0x3FFF));
     w[6] = rev14((uint32_t)((s_hi >> 20) & 0x3FFF));
     w[7] = rev14((uint32_t)((s_hi >> 34) & 0x3FFF));
-    w[8] = calc_crc;
-    if (w[0] == 0x3333 && w[1] == 0x0CCC && w[2] == 0x3333 && w[3] == 0x0CCC && w[4] == 0 && (w[7] & 0x0FF0) == 0) return false;   /* Control Block: general path */
+}
 
-    /* ---- VideoToDigital bookkeeping for a line with valid CRC ---- */
+/* one line through the fast path (decode already staged in LDS); false = not handled, nothing changed */
+__device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &g, const LaneConst &lc,
+                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec)
+{
+    const sdv_bin_preset &ps = a.preset;
+    Bin &b = v.bin;
+    if (!fast_eligible(a, b)) return false;
+    FastBits fb;
+    if (!fast_decode(a, lds, b, g, lc, fb) || fb.ctrl_block) return false;
+    const int lane = lane_id();
+    uint16_t w[9];
+    bits_to_words(fb.s_lo, fb.s_hi, w);
+    w[8] = fb.calc_crc;
+
+    /* ---- VideoToDigital bookkeeping for a line with valid CRC (videotodigital.cpp:1155-1396, 1524-1633) ---- */
     const bool even_line = (line_num % 2) == 0;
     const bool doubled = a.doubled != 0;
     bool forced_bad = false;
@@ -1706,17 +1735,123 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         sdv_line_rec r;
         r.frame_number = frame_no; r.line_number = line_num;
         for (int i = 0; i < 9; i++) r.words[i] = w[i];
-        r.calc_crc = calc_crc;
+        r.calc_crc = fb.calc_crc;
         r.data_start = b.in_coord.start; r.data_stop = b.in_coord.stop;
         r.marker_start_bg_coord = 0; r.marker_start_ed_coord = 0; r.marker_stop_ed_coord = 0;
-        r.black_level = b.in_black; r.white_level = b.in_white; r.ref_low = ref_low; r.ref_level = b.in_ref; r.ref_high = ref_high;
-        r.hysteresis_depth = (uint8_t)fh; r.shift_stage = (uint8_t)fs; r.service_type = SDV_SRV_NO;
+        r.black_level = b.in_black; r.white_level = b.in_white; r.ref_low = fb.ref_low; r.ref_level = b.in_ref; r.ref_high = fb.ref_high;
+        r.hysteresis_depth = fb.h; r.shift_stage = fb.s; r.service_type = SDV_SRV_NO;
         r.mark_st_stage = MARK_ST_START; r.mark_ed_stage = MARK_ED_START;
         r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | (forced_bad ? SDV_LF_FORCED_BAD : SDV_LF_CRC_VALID) | (doubled ? SDV_LF_FROM_DOUBLED : 0));
         r.word_state = forced_bad ? 0 : (uint8_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
         *rec = r;
     }
     return true;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Line-batch fast path.  In the steady state the tuning does not change from line to line, so up to
+ * 64 consecutive lines of a field are decoded one after another by the whole wave (phase A), each
+ * line's 128 raw cells + CRC parked in "its" lane; then the per-line VideoToDigital bookkeeping -
+ * word packing, duplicate-line test against the previous line, flags, the 48-byte record - runs for
+ * all of them at once, one lane per line (phase B).  Preconditions (checked per batch) make the
+ * bookkeeping of line k independent of lines < k except through the previous line's words:
+ *   - the STG_INPUT_ALL conditions hold (fast_eligible);
+ *   - last_valid_coord_list is full and holds only the preset pair, so pushing it again changes
+ *     nothing and the coordinate damper sees a zero delta (videotodigital.cpp:1295-1363).
+ * The first line that does not decode this way ends the batch and goes through the sequential path.
+ * --------------------------------------------------------------------------------------------- */
+struct BatchLane { uint32_t d0, d1, d2, d3, meta; };      /* raw cells + (calc_crc | h<<16 | s<<20) of "my" line */
+
+__device__ inline bool batch_eligible(const FrameArgs &a, const WaveLds &lds, const V2D &v, const Geo &g)
+{
+    if (!fast_eligible(a, v.bin)) return false;
+    if (v.n_last != COORD_HISTORY_DEPTH) return false;
+    uint32_t key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
+    bool differs = (lane_id() < COORD_HISTORY_DEPTH) && (lds.lv_keys[lane_id() < COORD_HISTORY_DEPTH ? lane_id() : 0] != key);
+    if (__ballot(differs) != 0ull) return false;
+    if (a.coordinate_damper) {
+        /* in_delta = getPPB()*3 as uint8_t must be > 0 or the damper would flag a zero delta */
+        uint32_t psm = (uint32_t)((int)v.bin.in_coord.stop - (int)v.bin.in_coord.start);
+        psm = (psm * 128u + BITS_BETWEEN / 2) / BITS_BETWEEN;
+        if ((uint8_t)(((uint8_t)(psm / 128u)) * 3) == 0) return false;
+    }
+    return true;
+}
+
+/* phase B for `n` (1..64) decoded lines: lane k owns line k of the batch */
+__device__ inline void batch_finish(const FrameArgs &a, V2D &v, const BatchLane &bl, int n, uint32_t frame_no, uint16_t first_line_num,
+                                    uint32_t *fv_keys, sdv_line_rec *rec)
+{
+    const sdv_bin_preset &ps = a.preset;
+    Bin &b = v.bin;
+    const int lane = lane_id();
+    const bool active = lane < n;
+    const bool doubled = a.doubled != 0;
+    const bool even_line = (first_line_num % 2) == 0;           /* the same for every line of a field */
+    uint64_t s_lo = (uint64_t)bl.d0 | ((uint64_t)bl.d1 << 32), s_hi = (uint64_t)bl.d2 | ((uint64_t)bl.d3 << 32);
+    uint16_t w[8];
+    bits_to_words(s_lo, s_hi, w);
+    uint32_t p01 = (uint32_t)w[0] | ((uint32_t)w[1] << 16), p23 = (uint32_t)w[2] | ((uint32_t)w[3] << 16);
+    uint32_t p45 = (uint32_t)w[4] | ((uint32_t)w[5] << 16), p67 = (uint32_t)w[6] | ((uint32_t)w[7] << 16);
+    /* words of the previous PCM line: the lane below, or the line before the batch */
+    int src = lane > 0 ? lane - 1 : 0;
+    uint32_t q01 = (uint32_t)__shfl((int)p01, src), q23 = (uint32_t)__shfl((int)p23, src);
+    uint32_t q45 = (uint32_t)__shfl((int)p45, src), q67 = (uint32_t)__shfl((int)p67, src);
+    if (lane == 0) {
+        q01 = (uint32_t)v.last_words[0] | ((uint32_t)v.last_words[1] << 16); q23 = (uint32_t)v.last_words[2] | ((uint32_t)v.last_words[3] << 16);
+        q45 = (uint32_t)v.last_words[4] | ((uint32_t)v.last_words[5] << 16); q67 = (uint32_t)v.last_words[6] | ((uint32_t)v.last_words[7] << 16);
+    }
+    /* getWordsDiffBitCount: XOR truncated to uint8_t per word (stc007line.cpp:329-357) */
+    uint32_t m = 0x00FF00FFu;
+    int diff = __popc((p01 ^ q01) & m) + __popc((p23 ^ q23) & m) + __popc((p45 ^ q45) & m) + __popc((p67 ^ q67) & m);
+    Line t; t.m2 = a.m2_format != 0; for (int i = 0; i < 6; i++) t.words[i] = w[i];
+    bool silent = stc_is_almost_silent(t);
+    uint8_t fs0 = v.field_state;
+    if (fs0 == FIELD_NEW) fs0 = FIELD_UNSAFE;
+    bool first_unsafe = (lane == 0) && (fs0 == FIELD_UNSAFE);
+    bool forced_bad = false, dup = false;
+    if (a.check_line_copy) {
+        if (first_unsafe) forced_bad = ps.en_first_line_dup != 0;
+        else { dup = !silent && diff <= (BITS_DATA / BIT_DIFF_THRES_DIV); forced_bad = dup; }
+    }
+    uint64_t dup_m = __ballot(active && dup), bad_m = __ballot(active && forced_bad);
+    uint64_t setgood_m = __ballot(active && ((a.check_line_copy && first_unsafe) || !forced_bad));
+    /* record */
+    if (active) {
+        uint8_t h = (uint8_t)((bl.meta >> 16) & 0xF), sft = (uint8_t)((bl.meta >> 20) & 0xF);
+        sdv_line_rec r;
+        r.frame_number = frame_no; r.line_number = (uint16_t)(first_line_num + 2 * lane);
+        for (int i = 0; i < 8; i++) r.words[i] = w[i];
+        r.words[8] = (uint16_t)(bl.meta & 0xFFFF);
+        r.calc_crc = (uint16_t)(bl.meta & 0xFFFF);
+        r.data_start = b.in_coord.start; r.data_stop = b.in_coord.stop;
+        r.marker_start_bg_coord = 0; r.marker_start_ed_coord = 0; r.marker_stop_ed_coord = 0;
+        r.black_level = b.in_black; r.white_level = b.in_white;
+        r.ref_low = get_low_level(b.in_ref, h); r.ref_level = b.in_ref; r.ref_high = get_high_level(b.in_ref, h);
+        r.hysteresis_depth = h; r.shift_stage = sft; r.service_type = SDV_SRV_NO;
+        r.mark_st_stage = MARK_ST_START; r.mark_ed_stage = MARK_ED_START;
+        r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | (forced_bad ? SDV_LF_FORCED_BAD : SDV_LF_CRC_VALID) | (doubled ? SDV_LF_FROM_DOUBLED : 0));
+        r.word_state = forced_bad ? 0 : (uint8_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
+        rec[lane] = r;
+        fv_keys[v.nfv + lane] = coords_key(b.in_coord.start, b.in_coord.stop);
+    }
+    /* wave-uniform state after the n lines */
+    int nd = __popcll(dup_m), nb = __popcll(bad_m);
+    v.nfv += n;
+    v.good_coords_in_field = (uint16_t)(v.good_coords_in_field + n);
+    v.pcm_lines_in_field = (uint16_t)(v.pcm_lines_in_field + n);
+    v.line_in_field_cnt = (uint16_t)(v.line_in_field_cnt + n);
+    v.q_line_length = (uint16_t)a.width;
+    if (!even_line) { v.q_odd = (uint16_t)(v.q_odd + n); v.q_pcm_odd = (uint16_t)(v.q_pcm_odd + n); v.q_dup_odd = (uint16_t)(v.q_dup_odd + nd); v.q_bad_odd = (uint16_t)(v.q_bad_odd + nb); }
+    else { v.q_even = (uint16_t)(v.q_even + n); v.q_pcm_even = (uint16_t)(v.q_pcm_even + n); v.q_dup_even = (uint16_t)(v.q_dup_even + nd); v.q_bad_even = (uint16_t)(v.q_bad_even + nb); }
+    if (setgood_m != 0ull) b.in_coord.doubled = doubled;
+    v.field_state = FIELD_INIT;
+    b.line_length = (uint16_t)a.width;
+    int last = n - 1;
+    uint32_t l01 = (uint32_t)__shfl((int)p01, last), l23 = (uint32_t)__shfl((int)p23, last), l45 = (uint32_t)__shfl((int)p45, last), l67 = (uint32_t)__shfl((int)p67, last);
+    l01 = uniu(l01); l23 = uniu(l23); l45 = uniu(l45); l67 = uniu(l67);
+    v.last_words[0] = (uint16_t)(l01 & 0xFFFF); v.last_words[1] = (uint16_t)(l01 >> 16); v.last_words[2] = (uint16_t)(l23 & 0xFFFF); v.last_words[3] = (uint16_t)(l23 >> 16);
+    v.last_words[4] = (uint16_t)(l45 & 0xFFFF); v.last_words[5] = (uint16_t)(l45 >> 16); v.last_words[6] = (uint16_t)(l67 & 0xFFFF); v.last_words[7] = (uint16_t)(l67 >> 16);
 }
 
 /* General path for one regular line, out of line so that its register appetite (reference sweep, marker
@@ -1747,22 +1882,55 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     LaneConst lc;
     lc.klo = (lane_id() < 16) ? c_crc.klo[lane_id() & 15] : 0ull;
     lc.khi = (lane_id() < 16) ? c_crc.khi[lane_id() & 15] : 0ull;
+    const int lane = lane_id();
 
     v2d_begin_frame(v, a, lds);
     if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
-    uint16_t line_num = 0;
+    /* decode order of VideoInFFMPEG::spliceFrame (vin_ffmpeg.cpp:281-347): field 0 = rows 0,2,4.., field 1 = rows 1,3,5.. */
+    const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
     pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
     row_prefetch(pf, frame, a.width);
+    uint16_t line_num = 0;
     for (int field = 0; field < 2; field++) {
-        int line_offset = field;
-        line_num = (uint16_t)(line_offset + 1);
-        for (;;) {
-            row_commit(lds, pf, a.width);
-            {   /* next row of the frame in decode order (nullptr after the last one) */
-                int next = (line_offset < (a.height - 2)) ? line_offset + 2 : (field == 0 ? 1 : -1);
-                row_prefetch(pf, next >= 0 ? frame + (size_t)next * a.row_stride : nullptr, a.width);
+        const int nl = n_field[field];
+        int idx = 0;
+        while (idx < nl) {
+            bool staged = false;
+            if (batch_eligible(a, lds, v, geo)) {
+                int nb = nl - idx; if (nb > 64) nb = 64;
+                BatchLane bl; bl.d0 = bl.d1 = bl.d2 = bl.d3 = bl.meta = 0;
+                int j = 0;
+                for (; j < nb; j++) {
+                    row_commit(lds, pf, a.width);
+                    {
+                        int k = idx + j + 1;                    /* next row in decode order */
+                        const uint8_t *nxt = (k < nl) ? frame + (size_t)(2 * k + field) * a.row_stride
+                                                      : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : nullptr);
+                        row_prefetch(pf, nxt, a.width);
+                    }
+                    FastBits fb;
+                    if (!fast_decode(a, lds, v.bin, geo, lc, fb) || fb.ctrl_block) break;
+                    bool mine = lane == j;
+                    bl.d0 = mine ? (uint32_t)fb.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb.s_lo >> 32) : bl.d1;
+                    bl.d2 = mine ? (uint32_t)fb.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb.s_hi >> 32) : bl.d3;
+                    bl.meta = mine ? ((uint32_t)fb.calc_crc | ((uint32_t)fb.h << 16) | ((uint32_t)fb.s << 20)) : bl.meta;
+                }
+                if (j > 0) {
+                    batch_finish(a, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
+                    rec += j; idx += j;
+                }
+                if (j == nb) continue;
+                staged = true;                                  /* line idx sits in LDS and needs the sequential path */
             }
+            if (!staged) {
+                row_commit(lds, pf, a.width);
+                int k = idx + 1;
+                const uint8_t *nxt = (k < nl) ? frame + (size_t)(2 * k + field) * a.row_stride
+                                              : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : nullptr);
+                row_prefetch(pf, nxt, a.width);
+            }
+            line_num = (uint16_t)(field + 1 + 2 * idx);
             if (!fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec)) {
                 SlowCtx c;
                 c.a = a; c.v = v;
@@ -1770,11 +1938,10 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 v = c.v;
                 v2d_make_uniform(v);
             }
-            rec++;
-            if (line_offset < (a.height - 2)) line_offset += 2;
-            else { line_num = (uint16_t)(line_num + 2); break; }
-            line_num = (uint16_t)(line_num + 2);
+            rec++; idx++;
         }
+        /* spliceFrame: END_FIELD carries the number the next line of the field would have had */
+        line_num = (uint16_t)(field + 1 + 2 * nl);
         v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
         emit_record(wl, rec++);
     }
@@ -1788,7 +1955,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 } // namespace sdv
 
 #ifndef SDV_WAVES_PER_EU
-#define SDV_WAVES_PER_EU 1
+#define SDV_WAVES_PER_EU 8   /* measured best on MI355X (profiles/r01_tuning_notes.md) */
 #endif
 __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {

@@ -42,6 +42,38 @@ def test_emu_small_frames(emu_lib, oracle_lib, mode):
         assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
 
 
+def test_emu_batch_path_corner_cases(emu_lib, oracle_lib):
+    """Exercises the line-batch fast path: duplicated rows (dup-line rule), silent audio (almost-silent lines are
+    exempt from it), a bad row in the middle of a batch, doubled-width sources, dup check switched off."""
+    luma, _, _ = synth.stc007_frames(3, seed=5, height=80)
+    luma = luma.copy()
+    luma[1, 20] = luma[1, 18]            # same field: line copies the previous one
+    luma[1, 41] = luma[1, 39]
+    luma[2, 30] = 20                     # dropout inside a batch
+    for kw in (dict(mode=2), dict(mode=1, check_line_dup=False)):
+        want, want_stats = oracle_binarize(luma, **kw)
+        eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+        emu_lib.sdv_set_mode(eng, kw["mode"])
+        emu_lib.sdv_set_check_line_dup(eng, int(kw.get("check_line_dup", True)))
+        got, got_stats, _ = emu_run(emu_lib, luma, kw["mode"], eng=eng)
+        emu_lib.sdv_engine_destroy(eng)
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    luma, _, _ = synth.stc007_frames(2, seed=6, height=60, silent=True)
+    want, want_stats = oracle_binarize(luma, mode=2)
+    got, got_stats, _ = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    luma, _, _ = synth.stc007_frames(2, seed=7, height=40, width=1440, x0=24, x1=1416)
+    want, want_stats = oracle_binarize(luma, mode=1, doubled=True, m2=True)
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    emu_lib.sdv_set_pcm_type(eng, 2, 1)
+    emu_lib.sdv_set_mode(eng, 1)
+    rc, got, got_stats = engine_api.emu_binarize(emu_lib, eng, luma, first_frame_no=1, flags=3)
+    emu_lib.sdv_engine_destroy(eng)
+    assert rc == 0 and got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+
+
 def test_emu_golden_rough_draft(emu_lib):
     mode, luma, want, want_stats = golden_cases.load("ntsc_rough_draft")
     got, got_stats, _ = emu_run(emu_lib, luma, mode)
