@@ -132,6 +132,46 @@ typedef struct sdv_v2d_state {
     uint8_t _pad[2];
 } sdv_v2d_state;
 
+/* ---- deinterleave / error-correction stage ---------------------------------------------------- */
+/* STC007Deinterleaver::RES_MODE_* (stc007deinterleaver.h:106-113) */
+enum { SDV_RES_MODE_14BIT = 0, SDV_RES_MODE_14BIT_AUTO = 1, SDV_RES_MODE_16BIT_AUTO = 2, SDV_RES_MODE_16BIT = 3 };
+/* STC007DataBlock::RES_* / AUD_* (stc007datablock.h:95-111) */
+enum { SDV_RES_14BIT = 0, SDV_RES_16BIT = 1 };
+enum { SDV_AUD_ORIG = 0, SDV_AUD_FIX_P = 1, SDV_AUD_FIX_Q = 2, SDV_AUD_BROKEN = 3 };
+
+/* What STC007Deinterleaver::setWordData reads of one assembled STC007Line (stc007deinterleaver.cpp:1126-1294).
+ * 24 bytes. */
+enum { SDV_DL_FIXED_BY_CWD = 1 << 0,    /* STC007Line::isFixedByCWD() */
+       SDV_DL_COORDS_BW_OK = 1 << 1 };  /* coords.areValid() && hasBWSet(): the word validity when CRCs are ignored */
+typedef struct sdv_deint_line {
+    uint32_t frame_number;
+    uint16_t line_number;
+    uint16_t words[8];          /* STC007Line::getWord(0..7) */
+    uint8_t word_crc_ok;        /* bit i = STC007Line::isWordCRCOk(i), i = 0..7 */
+    uint8_t flags;              /* SDV_DL_* */
+} sdv_deint_line;
+
+/* STC007Deinterleaver settings (stc007deinterleaver.h:151-161; setters :133-282) */
+typedef struct sdv_deint_settings {
+    uint8_t res_mode;           /* SDV_RES_MODE_* (setResMode) */
+    uint8_t ignore_crc;         /* setIgnoreCRC */
+    uint8_t force_ecc_check;    /* setForcedErrorCheck */
+    uint8_t en_p_code, en_q_code, en_cwd;   /* setPCorrection / setQCorrection / setCWDCorrection */
+    uint8_t _pad[2];
+} sdv_deint_settings;
+
+/* One STC007DataBlock (stc007datablock.h:144-160). 72 bytes. Bit i of the three masks = word i. */
+typedef struct sdv_block_rec {
+    uint32_t w_frame[8];
+    uint16_t w_line[8];
+    uint16_t words[8];
+    uint8_t line_crc, cwd_fixed, word_valid;
+    uint8_t resolution;         /* SDV_RES_* */
+    uint8_t audio_state;        /* SDV_AUD_* */
+    uint8_t cwd_applied;
+    uint16_t sample_rate;
+} sdv_block_rec;
+
 typedef struct sdv_engine sdv_engine;
 
 /* ---- engine lifetime ------------------------------------------------------------------------ */

@@ -169,3 +169,61 @@ void orc_v2d_get_state(void *vv, sdv_v2d_state *s)
     }
     s->long_valid_doubled_mask = m;
 }
+
+/* ------------------------------------------------------------------ deinterleaver level */
+#include "deint.h"
+
+static void deint_line_to_orc(const sdv_deint_line *in, orc_stc_line *l)
+{
+    orc_stc_clear(l);
+    l->frame_number = in->frame_number; l->line_number = in->line_number;
+    for (int i = 0; i < 8; i++) { l->words[i] = in->words[i]; l->word_crc[i] = l->word_valid[i] = (in->word_crc_ok >> i) & 1; }
+    orc_stc_calc_crc(l);
+    l->words[8] = l->calc_crc;                       /* CRC state itself is only read through isFixedByCWD() */
+    if (in->flags & SDV_DL_FIXED_BY_CWD) {
+        /* a line repaired by CWD: CRC valid, at least one word with word_crc false but word_valid true */
+        int done = 0;
+        for (int i = 0; i < 8 && !done; i++) if (!l->word_crc[i]) { l->word_valid[i] = true; done = 1; }
+        if (!done) { l->word_crc[0] = false; l->word_valid[0] = true; }
+    } else {
+        /* make sure isFixedByCWD() is false */
+        bool any = false;
+        for (int i = 0; i < 8; i++) if (!l->word_crc[i]) any = true;
+        if (any) l->words[8] = (uint16_t)~l->calc_crc;
+    }
+    if (in->flags & SDV_DL_COORDS_BW_OK) { l->blk_wht_set = true; orc_coords_set(&l->coords, 10, 700); }
+}
+
+static void block_to_rec(const orc_stc_block *b, sdv_block_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    for (int i = 0; i < 8; i++) {
+        r->w_frame[i] = b->w_frame[i]; r->w_line[i] = b->w_line[i]; r->words[i] = b->words[i];
+        if (b->line_crc[i]) r->line_crc |= (uint8_t)(1u << i);
+        if (b->cwd_fixed[i]) r->cwd_fixed |= (uint8_t)(1u << i);
+        if (b->word_valid[i]) r->word_valid |= (uint8_t)(1u << i);
+    }
+    r->resolution = b->resolution; r->audio_state = b->audio_state; r->cwd_applied = b->cwd_applied; r->sample_rate = b->sample_rate;
+}
+
+/* processBlock(line_shift) for every shift 0..n_blocks-1 over the same line buffer */
+int orc_deint_run(const sdv_deint_line *lines, size_t n_lines, const sdv_deint_settings *st, sdv_block_rec *out, size_t n_blocks)
+{
+    orc_stc_line *l = (orc_stc_line *)malloc(n_lines * sizeof(orc_stc_line));
+    for (size_t i = 0; i < n_lines; i++) deint_line_to_orc(&lines[i], &l[i]);
+    orc_deint d; orc_deint_init(&d);
+    d.data_res_mode = st->res_mode; d.ignore_crc = st->ignore_crc; d.force_ecc_check = st->force_ecc_check;
+    d.en_p_code = st->en_p_code; d.en_q_code = st->en_q_code; d.en_cwd = st->en_cwd;
+    int rc = ORC_DI_RET_OK;
+    for (size_t s = 0; s < n_blocks; s++) {
+        orc_stc_block b;
+        orc_block_clear(&b);
+        rc = orc_deint_process_block(&d, l, n_lines, (uint16_t)s, &b);
+        if (rc != ORC_DI_RET_OK) break;
+        block_to_rec(&b, &out[s]);
+    }
+    free(l);
+    return rc;
+}
+uint16_t orc_q_code(const uint16_t *w6) { return orc_calc_q(w6); }
+uint16_t orc_p_code(const uint16_t *w6) { return orc_calc_p(w6); }

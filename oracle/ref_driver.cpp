@@ -273,3 +273,55 @@ long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int hei
 }
 
 } /* extern "C" */
+
+/* ------------------------------------------------------------------ deinterleaver level */
+static void block_to_rec(STC007DataBlock &b, sdv_block_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    for (int i = 0; i < 8; i++) {
+        r->w_frame[i] = b.w_frame[i]; r->w_line[i] = b.w_line[i]; r->words[i] = b.getWord(i);
+        if (b.isWordLineCRCOk(i)) r->line_crc |= (uint8_t)(1u << i);
+        if (b.isWordCWDFixed(i)) r->cwd_fixed |= (uint8_t)(1u << i);
+        if (b.isWordValid(i)) r->word_valid |= (uint8_t)(1u << i);
+    }
+    r->resolution = b.getResolution(); r->audio_state = b.getAudioState(); r->cwd_applied = b.cwd_applied; r->sample_rate = b.sample_rate;
+}
+
+extern "C" int ref_deint_run(const sdv_deint_line *lines, size_t n_lines, const sdv_deint_settings *st, sdv_block_rec *out, size_t n_blocks)
+{
+    std::deque<STC007Line> q;
+    for (size_t i = 0; i < n_lines; i++) {
+        const sdv_deint_line &in = lines[i];
+        STC007Line l;
+        l.frame_number = in.frame_number; l.line_number = in.line_number;
+        for (uint8_t k = 0; k < 8; k++) l.setWord(k, in.words[k], (in.word_crc_ok >> k) & 1);
+        l.calcCRC();
+        l.setSourceCRC(l.getCalculatedCRC());
+        if (in.flags & SDV_DL_FIXED_BY_CWD) {
+            bool done = false;
+            for (uint8_t k = 0; k < 8 && !done; k++) if (!l.isWordCRCOk(k)) { l.setFixed(k); done = true; }
+            if (!done) { l.setWord(0, in.words[0], false); l.setFixed(0); }
+        } else {
+            bool any = false;
+            for (uint8_t k = 0; k < 8; k++) if (!l.isWordCRCOk(k)) any = true;
+            if (any) l.setInvalidCRC();
+        }
+        if (in.flags & SDV_DL_COORDS_BW_OK) { l.setBWLevelsState(true); l.coords.setCoordinates(10, 700); }
+        q.push_back(l);
+    }
+    STC007Deinterleaver d;
+    d.setInput(&q);
+    d.setResMode(st->res_mode); d.setIgnoreCRC(st->ignore_crc); d.setForcedErrorCheck(st->force_ecc_check);
+    /* set the three switches directly in the dependency-safe order of the GUI (stitcher: setPCorrection/Q/CWD) */
+    d.setPCorrection(true); d.setQCorrection(st->en_q_code); d.setCWDCorrection(st->en_cwd);
+    if (!st->en_p_code) d.setPCorrection(false);
+    int rc = STC007Deinterleaver::DI_RET_OK;
+    for (size_t s = 0; s < n_blocks; s++) {
+        STC007DataBlock b;
+        d.setOutput(&b);
+        rc = d.processBlock((uint16_t)s);
+        if (rc != STC007Deinterleaver::DI_RET_OK) break;
+        block_to_rec(b, &out[s]);
+    }
+    return rc;
+}

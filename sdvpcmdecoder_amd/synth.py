@@ -238,3 +238,22 @@ def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int 
             img = img + torch.randn(img.shape, generator=g, device=device) * noise_sigma
         luma[f0:f1] = img.round().clamp(0, 255).to(torch.uint8).reshape(f1 - f0, height, width)
     return luma, w9
+
+
+def interleave_stream_f1(audio16: np.ndarray) -> np.ndarray:
+    """PCM-F1 16-bit variant (stc007datablock.h:80-92, stc007deinterleaver.cpp:1230-1274): slots 0..6 carry the 14 MSBs
+    of L0 R0 L1 R1 L2 R2 P (P = XOR of the six 16-bit words), slot 7 (the S-word) the 2 LSBs of the seven words that sit
+    in the SAME line at shifts 12,10,8,6,4,2,0."""
+    a = np.asarray(audio16).astype(np.uint32) & 0xFFFF
+    n = a.shape[0]
+    p = a[:, 0] ^ a[:, 1] ^ a[:, 2] ^ a[:, 3] ^ a[:, 4] ^ a[:, 5]
+    blk = np.concatenate([a, p[:, None]], axis=1)                      # (n, 7) 16-bit
+    full = np.zeros((n, 7), dtype=np.uint32)
+    for k in range(7):
+        full[16 * k:, k] = blk[:n - 16 * k, k]
+    lines = np.zeros((n, 8), dtype=np.uint32)
+    lines[:, :7] = full >> 2
+    shifts = np.array([12, 10, 8, 6, 4, 2, 0], dtype=np.uint32)
+    lines[:, 7] = ((full & 3) << shifts[None, :]).sum(axis=1)
+    crc = crc16_words14(lines)
+    return np.concatenate([lines, crc[:, None].astype(np.uint32)], axis=1).astype(np.uint16)
