@@ -246,6 +246,16 @@ int sdv_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, s
                         int n_frames, uint32_t first_frame_no, unsigned flags,
                         sdv_line_rec *out_lines, sdv_frame_stats *out_stats, void *stream);
 
+/* ---- hot path: deinterleave + P/Q error correction for a batch of data blocks -------------------
+ * Replaces STC007Deinterleaver::processBlock(line_shift) (stc007deinterleaver.cpp:286-1123) called for
+ * line_shift = 0 .. n_blocks-1 over one buffer of assembled lines - the loops of STC007DataStitcher::tryPadding,
+ * performCWD and performDeinterleave (stc007datastitcher.cpp:1546-1561, 5919-5939, 6682-6717).
+ * Block s is assembled from lines s, s+16, .., s+112 (stc007datablock.h:40-58), so n_lines must exceed
+ * 112 + (n_blocks-1), else SDV_ERR_NO_DATA (DI_RET_NO_DATA).  Device pointers; asynchronous on `stream`. */
+void sdv_default_deint_settings(sdv_deint_settings *st);
+int sdv_deinterleave_blocks(sdv_engine *e, const sdv_deint_line *lines, size_t n_lines, const sdv_deint_settings *settings,
+                            sdv_block_rec *out_blocks, size_t n_blocks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

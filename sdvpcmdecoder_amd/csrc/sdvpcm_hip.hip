@@ -4,4 +4,5 @@
  */
 #include <hip/hip_runtime.h>
 #include "stc007_device.h"
+#include "stc007_deint_device.h"
 #include "engine.inc"

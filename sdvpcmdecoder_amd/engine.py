@@ -45,6 +45,20 @@ class BinPreset(C.Structure):
                [("horiz_start", C.c_int16), ("horiz_stop", C.c_int16)]
 
 
+class DeintSettings(C.Structure):
+    """STC007Deinterleaver settings (stc007deinterleaver.h:151-161)"""
+    _fields_ = [("res_mode", C.c_uint8), ("ignore_crc", C.c_uint8), ("force_ecc_check", C.c_uint8),
+                ("en_p_code", C.c_uint8), ("en_q_code", C.c_uint8), ("en_cwd", C.c_uint8), ("_pad", C.c_uint8 * 2)]
+
+
+DEINT_LINE_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words", "<u2", (8,)),
+                             ("word_crc_ok", "u1"), ("flags", "u1")])
+BLOCK_DTYPE = np.dtype([("w_frame", "<u4", (8,)), ("w_line", "<u2", (8,)), ("words", "<u2", (8,)),
+                        ("line_crc", "u1"), ("cwd_fixed", "u1"), ("word_valid", "u1"), ("resolution", "u1"),
+                        ("audio_state", "u1"), ("cwd_applied", "u1"), ("sample_rate", "<u2")])
+assert DEINT_LINE_DTYPE.itemsize == 24 and BLOCK_DTYPE.itemsize == 72
+
+
 class RunInfo(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32),
                 ("kernel_ms", C.c_float), ("_pad2", C.c_float)]
@@ -84,6 +98,10 @@ def load_library(path: str | None = None):
     lib.sdv_binarize_frames.restype = C.c_int
     lib.sdv_binarize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                         C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sdv_default_deint_settings.argtypes = [C.POINTER(DeintSettings)]
+    lib.sdv_deinterleave_blocks.restype = C.c_int
+    lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DeintSettings), C.c_void_p, C.c_size_t,
+                                            C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -149,6 +167,27 @@ class Engine:
         info = RunInfo()
         self.lib.sdv_get_run_info(self._h, C.byref(info))
         return info
+
+    # ---- STC007Deinterleaver (stc007deinterleaver.h:163-176) ----
+    def default_deint_settings(self) -> DeintSettings:
+        st = DeintSettings()
+        self.lib.sdv_default_deint_settings(C.byref(st))
+        return st
+
+    def deinterleave_blocks(self, lines, settings: DeintSettings, n_blocks: int | None = None, out=None, stream=None):
+        """processBlock(line_shift) for line_shift = 0..n_blocks-1 over `lines` (torch.uint8 CUDA tensor (n_lines, 24)).
+        Returns torch.uint8 CUDA tensor (n_blocks, 72) of sdv_block_rec."""
+        import torch
+        assert lines.is_cuda and lines.dtype == torch.uint8 and lines.dim() == 2 and lines.shape[1] == 24 and lines.is_contiguous()
+        n_lines = lines.shape[0]
+        if n_blocks is None:
+            n_blocks = max(0, n_lines - 112)
+        if out is None:
+            out = torch.empty((n_blocks, 72), dtype=torch.uint8, device=lines.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)
+        self._check(self.lib.sdv_deinterleave_blocks(self._h, C.c_void_p(lines.data_ptr()), n_lines, C.byref(settings),
+                                                     C.c_void_p(out.data_ptr()), n_blocks, sptr))
+        return out
 
     # ---- batch replacement of doBinarize ----
     def records_per_frame(self, height: int) -> int:

@@ -53,6 +53,11 @@ def make_lines(w9, frame0=1, line0=1, rng=None, p_bad=0.0, p_corrupt_valid=0.0, 
     lines["words"] = words
     flags = np.full(n, 2, dtype=np.uint8)                      # SDV_DL_COORDS_BW_OK
     flags[rng.random(n) < 0.1] = 0
-    flags[rng.random(n) < p_cwd] |= 1
+    cwd = rng.random(n) < p_cwd
+    flags[cwd] |= 1
     lines["flags"] = flags
+    # a line can only be "fixed by CWD" if at least one of its words failed the CRC (stc007line.cpp:628-641)
+    crc = lines["word_crc_ok"]
+    crc[cwd & (crc == 0xFF)] = 0xFE
+    lines["word_crc_ok"] = crc
     return lines

@@ -8,4 +8,5 @@
 #include "hip_emu.h"
 struct uint4 { uint32_t x, y, z, w; };
 #include "../../sdvpcmdecoder_amd/csrc/stc007_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/stc007_deint_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/engine.inc"

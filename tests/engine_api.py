@@ -37,6 +37,9 @@ def bind(lib):
     lib.sdv_binarize_frames.restype = C.c_int
     lib.sdv_binarize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                         C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    import deint_api as da
+    lib.sdv_deinterleave_blocks.restype = C.c_int
+    lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(da.DeintSettings), C.c_void_p, C.c_size_t, C.c_void_p]
     return lib
 
 
