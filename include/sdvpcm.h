@@ -172,6 +172,56 @@ typedef struct sdv_block_rec {
     uint16_t sample_rate;
 } sdv_block_rec;
 
+/* ---- stitch stage ------------------------------------------------------------------------------ */
+/* PCMSamplePair (pcmsamplepair.h:77-143) / PCMSample (:31-74). 12 bytes. */
+enum { SDV_SF_BLOCK_OK = 1 << 0,    /* PCMSample::data_block_ok */
+       SDV_SF_WORD_VALID = 1 << 1,  /* PCMSample::word_valid    */
+       SDV_SF_WORD_FIXED = 1 << 2,  /* PCMSample::word_fixed    */
+       SDV_SF_WORD_MASKED = 1 << 3  /* PCMSample::word_masked   */ };
+enum { SDV_PAIR_SRV_NO = 0, SDV_PAIR_SRV_NEW_FILE = 1, SDV_PAIR_SRV_END_FILE = 2 };   /* PCMSamplePair::SRV_* */
+typedef struct sdv_sample_pair {
+    int16_t audio_word[2];          /* CH_LEFT, CH_RIGHT */
+    uint8_t sample_flags[2];        /* SDV_SF_* per channel */
+    uint16_t sample_rate;           /* 44056 / 44100 */
+    uint8_t emphasis;
+    uint8_t service_type;           /* SDV_PAIR_SRV_* */
+    uint16_t _pad;
+} sdv_sample_pair;
+
+/* FrameAsmSTC007 (frametrimset.h:116-275) as emitted with guiUpdFrameAsm (stc007datastitcher.cpp:7431). 64 bytes. */
+typedef struct sdv_frame_asm {
+    uint32_t frame_number;
+    uint16_t odd_std_lines, even_std_lines, odd_data_lines, even_data_lines, odd_valid_lines, even_valid_lines;
+    uint16_t odd_top_data, odd_bottom_data, even_top_data, even_bottom_data, odd_sample_rate, even_sample_rate;
+    uint16_t blocks_total, blocks_drop, samples_drop;
+    uint16_t inner_padding, outer_padding;
+    uint16_t blocks_broken_field, blocks_broken_seam, blocks_fix_p, blocks_fix_q, blocks_fix_cwd;
+    uint8_t field_order, odd_ref, even_ref, service_type;
+    uint8_t video_standard, tff_cnt, bff_cnt, odd_resolution, even_resolution;
+    uint8_t flags;                  /* SDV_FA_* */
+    uint8_t flags2;
+    int8_t ctrl_index, ctrl_hour, ctrl_minute, ctrl_second, ctrl_field;
+} sdv_frame_asm;
+enum { SDV_FA_ORDER_PRESET = 1 << 0, SDV_FA_ORDER_GUESSED = 1 << 1, SDV_FA_TRIM_OK = 1 << 2, SDV_FA_INNER_OK = 1 << 3,
+       SDV_FA_OUTER_OK = 1 << 4, SDV_FA_INNER_SILENCE = 1 << 5, SDV_FA_OUTER_SILENCE = 1 << 6, SDV_FA_VID_STD_PRESET = 1 << 7 };
+enum { SDV_FA2_ODD_EMPHASIS = 1 << 0, SDV_FA2_EVEN_EMPHASIS = 1 << 1, SDV_FA2_VID_STD_GUESSED = 1 << 2 };
+
+/* STC007DataStitcher settings (slots stc007datastitcher.h:331-350, defaults :20-31, :7228-7236) */
+typedef struct sdv_stitch_settings {
+    uint8_t video_standard;         /* setVideoStandard: FrameAsmDescriptor::VID_* (0 = auto) */
+    uint8_t field_order;            /* setFieldOrder: ORDER_* (0 = auto) */
+    uint8_t enable_p, enable_q, enable_cwd;     /* setPCorrection / setQCorrection / setCWDCorrection */
+    uint8_t m2_format;              /* setM2SampleFormat */
+    uint8_t resolution_preset;      /* setResolutionPreset: SAMPLE_RES_* (0 = auto) */
+    uint8_t max_unch_14, max_unch_16;           /* setFineMaxUnch14/16 */
+    uint8_t use_ecc;                /* setFineUseECC (ignore_CRC = !use_ecc) */
+    uint8_t mask_seams;             /* setFineMaskSeams */
+    uint8_t broke_mask;             /* setFineBrokeMask */
+    uint8_t top_line_fix;           /* setFineTopLineFix */
+    uint8_t _pad;
+    uint16_t sample_rate_preset;    /* setSampleRatePreset (1 = auto) */
+} sdv_stitch_settings;
+
 typedef struct sdv_engine sdv_engine;
 
 /* ---- engine lifetime ------------------------------------------------------------------------ */

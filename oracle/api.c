@@ -227,3 +227,95 @@ int orc_deint_run(const sdv_deint_line *lines, size_t n_lines, const sdv_deint_s
 }
 uint16_t orc_q_code(const uint16_t *w6) { return orc_calc_q(w6); }
 uint16_t orc_p_code(const uint16_t *w6) { return orc_calc_p(w6); }
+
+/* ------------------------------------------------------------------ stitcher level */
+#include "stitcher.h"
+
+/* re-hydrates an STC007Line from a binarizer record (what INTEGRATION.md's toLine() does on the reference side) */
+void orc_rec_to_line(const sdv_line_rec *r, orc_stc_line *l)
+{
+    orc_stc_clear(l);
+    l->frame_number = r->frame_number; l->line_number = r->line_number;
+    if (r->service_type != SDV_SRV_NO && r->service_type != SDV_SRV_CTRL_BLOCK) { orc_stc_set_service(l, r->service_type); return; }
+    for (int i = 0; i < 9; i++) l->words[i] = r->words[i];
+    l->calc_crc = r->calc_crc;
+    l->black_level = r->black_level; l->white_level = r->white_level;
+    l->ref_low = r->ref_low; l->ref_level = r->ref_level; l->ref_high = r->ref_high;
+    l->coords.data_start = r->data_start; l->coords.data_stop = r->data_stop; l->coords.from_doubled = (r->flags & SDV_LF_FROM_DOUBLED) != 0;
+    l->hysteresis_depth = r->hysteresis_depth; l->shift_stage = r->shift_stage;
+    l->ref_level_sweeped = (r->flags & SDV_LF_REF_SWEEPED) != 0; l->data_by_ext_tune = (r->flags & SDV_LF_BY_EXT_TUNE) != 0;
+    l->blk_wht_set = (r->flags & SDV_LF_BW_SET) != 0; l->coords_set = (r->flags & SDV_LF_COORDS_SET) != 0;
+    l->forced_bad = (r->flags & SDV_LF_FORCED_BAD) != 0;
+    l->mark_st_stage = r->mark_st_stage; l->mark_ed_stage = r->mark_ed_stage;
+    l->marker_start_bg_coord = r->marker_start_bg_coord; l->marker_start_ed_coord = r->marker_start_ed_coord; l->marker_stop_ed_coord = r->marker_stop_ed_coord;
+    bool v = orc_stc_crc_valid(l);                   /* applyCRCStatePerWord */
+    for (int i = 0; i < 9; i++) l->word_crc[i] = l->word_valid[i] = v;
+    l->service_type = r->service_type;               /* SDV_SRV_NO or CTRL_BLOCK */
+}
+
+static void frasm_to_pod(const orc_frasm *f, sdv_frame_asm *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->frame_number = f->frame_number;
+    o->odd_std_lines = f->odd_std_lines; o->even_std_lines = f->even_std_lines; o->odd_data_lines = f->odd_data_lines; o->even_data_lines = f->even_data_lines;
+    o->odd_valid_lines = f->odd_valid_lines; o->even_valid_lines = f->even_valid_lines;
+    o->odd_top_data = f->odd_top_data; o->odd_bottom_data = f->odd_bottom_data; o->even_top_data = f->even_top_data; o->even_bottom_data = f->even_bottom_data;
+    o->odd_sample_rate = f->odd_sample_rate; o->even_sample_rate = f->even_sample_rate;
+    o->blocks_total = f->blocks_total; o->blocks_drop = f->blocks_drop; o->samples_drop = f->samples_drop;
+    o->inner_padding = f->inner_padding; o->outer_padding = f->outer_padding;
+    o->blocks_broken_field = f->blocks_broken_field; o->blocks_broken_seam = f->blocks_broken_seam;
+    o->blocks_fix_p = f->blocks_fix_p; o->blocks_fix_q = f->blocks_fix_q; o->blocks_fix_cwd = f->blocks_fix_cwd;
+    o->field_order = f->field_order; o->odd_ref = f->odd_ref; o->even_ref = f->even_ref; o->service_type = f->service_type;
+    o->video_standard = f->video_standard; o->tff_cnt = f->tff_cnt; o->bff_cnt = f->bff_cnt; o->odd_resolution = f->odd_resolution; o->even_resolution = f->even_resolution;
+    o->flags = (uint8_t)((f->order_preset ? SDV_FA_ORDER_PRESET : 0) | (f->order_guessed ? SDV_FA_ORDER_GUESSED : 0) | (f->trim_ok ? SDV_FA_TRIM_OK : 0) |
+                         (f->inner_padding_ok ? SDV_FA_INNER_OK : 0) | (f->outer_padding_ok ? SDV_FA_OUTER_OK : 0) | (f->inner_silence ? SDV_FA_INNER_SILENCE : 0) |
+                         (f->outer_silence ? SDV_FA_OUTER_SILENCE : 0) | (f->vid_std_preset ? SDV_FA_VID_STD_PRESET : 0));
+    o->flags2 = (uint8_t)((f->odd_emphasis ? SDV_FA2_ODD_EMPHASIS : 0) | (f->even_emphasis ? SDV_FA2_EVEN_EMPHASIS : 0) | (f->vid_std_guessed ? SDV_FA2_VID_STD_GUESSED : 0));
+    o->ctrl_index = f->ctrl_index; o->ctrl_hour = f->ctrl_hour; o->ctrl_minute = f->ctrl_minute; o->ctrl_second = f->ctrl_second; o->ctrl_field = f->ctrl_field;
+}
+
+void orc_default_stitch_settings(sdv_stitch_settings *st)
+{
+    memset(st, 0, sizeof(*st));
+    st->enable_p = 0; st->enable_q = 0; st->enable_cwd = 1;       /* ctor :28-30 (the GUI switches P/Q on) */
+    st->max_unch_14 = ORC_MAX_BURST_UNCH_14BIT; st->max_unch_16 = ORC_MAX_BURST_UNCH_16BIT;
+    st->use_ecc = 1; st->mask_seams = 1; st->broke_mask = ORC_UNCH_MASK_DURATION; st->top_line_fix = 0; st->sample_rate_preset = 1;
+}
+
+/* feeds all records, runs the stitcher until the queue holds less than two frames; returns number of pairs
+ * (<0: output buffer too small) */
+long orc_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                    sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames)
+{
+    orc_stitcher *s = (orc_stitcher *)malloc(sizeof(orc_stitcher));
+    orc_stitcher_init(s);
+    if (st->video_standard < ORC_VID_MAX) s->preset_video_mode = st->video_standard;
+    if (st->field_order < ORC_ORDER_MAX) s->preset_field_order = st->field_order;
+    s->enable_P_code = st->enable_p; s->enable_Q_code = st->enable_q; s->enable_CWD = st->enable_cwd; s->mode_m2 = st->m2_format;
+    if (st->resolution_preset < ORC_SAMPLE_RES_MAX) s->preset_audio_res = st->resolution_preset;
+    s->preset_sample_rate = st->sample_rate_preset;
+    s->max_unchecked_14b_blocks = st->max_unch_14; s->max_unchecked_16b_blocks = st->max_unch_16;
+    s->ignore_CRC = !st->use_ecc; s->mask_seams = st->mask_seams; s->broken_mask_dur = st->broke_mask; s->fix_cut_above = st->top_line_fix;
+    orc_stc_line l;
+    for (size_t i = 0; i < n_recs; i++) { orc_rec_to_line(&recs[i], &l); orc_stitcher_push_line(s, &l); }
+    while (orc_stitcher_step(s)) {}
+    long n = (long)s->out_n;
+    if (s->out_n > out_cap) n = -1;
+    else for (size_t i = 0; i < s->out_n; i++) {
+        const orc_sample_pair *p = &s->out[i];
+        sdv_sample_pair *o = &out[i];
+        memset(o, 0, sizeof(*o));
+        for (int c = 0; c < 2; c++) {
+            o->audio_word[c] = p->audio_word[c];
+            o->sample_flags[c] = (uint8_t)((p->data_block_ok[c] ? SDV_SF_BLOCK_OK : 0) | (p->word_valid[c] ? SDV_SF_WORD_VALID : 0) |
+                                           (p->word_fixed[c] ? SDV_SF_WORD_FIXED : 0) | (p->word_masked[c] ? SDV_SF_WORD_MASKED : 0));
+        }
+        o->sample_rate = p->sample_rate; o->emphasis = p->emphasis; o->service_type = p->service_type;
+    }
+    size_t nf = s->frames_n < frames_cap ? s->frames_n : frames_cap;
+    for (size_t i = 0; i < nf; i++) frasm_to_pod(&s->frames[i], &frames[i]);
+    if (n_frames) *n_frames = s->frames_n;
+    orc_stitcher_free(s);
+    free(s);
+    return n;
+}

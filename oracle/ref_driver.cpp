@@ -325,3 +325,117 @@ extern "C" int ref_deint_run(const sdv_deint_line *lines, size_t n_lines, const 
     }
     return rc;
 }
+
+/* ------------------------------------------------------------------ stitcher level */
+#include "stc007datastitcher.h"
+#include "pcmsamplepair.h"
+
+static void rec_to_line(const sdv_line_rec &r, STC007Line &l)     /* the binding of INTEGRATION.md */
+{
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    switch (r.service_type) {
+        case SDV_SRV_NEW_FILE: l.setServNewFile("synthetic.avi"); return;
+        case SDV_SRV_END_FILE: l.setServEndFile(); return;
+        case SDV_SRV_FILLER: l.setServFiller(); return;
+        case SDV_SRV_END_FIELD: l.setServEndField(); return;
+        case SDV_SRV_END_FRAME: l.setServEndFrame(); return;
+        default: break;
+    }
+    for (uint8_t i = 0; i < 8; i++) l.setWord(i, r.words[i]);
+    l.setSourceCRC(r.words[8]); l.calcCRC();
+    l.black_level = r.black_level; l.white_level = r.white_level;
+    l.ref_low = r.ref_low; l.ref_level = r.ref_level; l.ref_high = r.ref_high;
+    l.coords.data_start = r.data_start; l.coords.data_stop = r.data_stop;
+    l.setFromDoubledState((r.flags & SDV_LF_FROM_DOUBLED) != 0);
+    l.hysteresis_depth = r.hysteresis_depth; l.shift_stage = r.shift_stage;
+    l.setSweepedReference((r.flags & SDV_LF_REF_SWEEPED) != 0);
+    l.data_by_ext_tune = (r.flags & SDV_LF_BY_EXT_TUNE) != 0;
+    l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
+    l.setDataCoordinatesState((r.flags & SDV_LF_COORDS_SET) != 0);
+    l.mark_st_stage = r.mark_st_stage; l.mark_ed_stage = r.mark_ed_stage;
+    l.marker_start_bg_coord = r.marker_start_bg_coord; l.marker_start_ed_coord = r.marker_start_ed_coord; l.marker_stop_ed_coord = r.marker_stop_ed_coord;
+    if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+    l.applyCRCStatePerWord();
+    if (r.service_type == SDV_SRV_CTRL_BLOCK) l.setServCtrlBlk();
+}
+
+static void frasm_to_pod(FrameAsmSTC007 &f, sdv_frame_asm *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->frame_number = f.frame_number;
+    o->odd_std_lines = f.odd_std_lines; o->even_std_lines = f.even_std_lines; o->odd_data_lines = f.odd_data_lines; o->even_data_lines = f.even_data_lines;
+    o->odd_valid_lines = f.odd_valid_lines; o->even_valid_lines = f.even_valid_lines;
+    o->odd_top_data = f.odd_top_data; o->odd_bottom_data = f.odd_bottom_data; o->even_top_data = f.even_top_data; o->even_bottom_data = f.even_bottom_data;
+    o->odd_sample_rate = f.odd_sample_rate; o->even_sample_rate = f.even_sample_rate;
+    o->blocks_total = f.blocks_total; o->blocks_drop = f.blocks_drop; o->samples_drop = f.samples_drop;
+    o->inner_padding = f.inner_padding; o->outer_padding = f.outer_padding;
+    o->blocks_broken_field = f.blocks_broken_field; o->blocks_broken_seam = f.blocks_broken_seam;
+    o->blocks_fix_p = f.blocks_fix_p; o->blocks_fix_q = f.blocks_fix_q; o->blocks_fix_cwd = f.blocks_fix_cwd;
+    o->field_order = f.field_order; o->odd_ref = f.odd_ref; o->even_ref = f.even_ref;
+    o->service_type = f.isServNewFile() ? 1 : (f.isServEndFile() ? 2 : 0);
+    o->video_standard = f.video_standard; o->tff_cnt = f.tff_cnt; o->bff_cnt = f.bff_cnt; o->odd_resolution = f.odd_resolution; o->even_resolution = f.even_resolution;
+    o->flags = (uint8_t)((f.isOrderPreset() ? SDV_FA_ORDER_PRESET : 0) | (f.isOrderGuessed() ? SDV_FA_ORDER_GUESSED : 0) | (f.trim_ok ? SDV_FA_TRIM_OK : 0) |
+                         (f.inner_padding_ok ? SDV_FA_INNER_OK : 0) | (f.outer_padding_ok ? SDV_FA_OUTER_OK : 0) | (f.inner_silence ? SDV_FA_INNER_SILENCE : 0) |
+                         (f.outer_silence ? SDV_FA_OUTER_SILENCE : 0) | (f.vid_std_preset ? SDV_FA_VID_STD_PRESET : 0));
+    o->flags2 = (uint8_t)((f.odd_emphasis ? SDV_FA2_ODD_EMPHASIS : 0) | (f.even_emphasis ? SDV_FA2_EVEN_EMPHASIS : 0) | (f.vid_std_guessed ? SDV_FA2_VID_STD_GUESSED : 0));
+    o->ctrl_index = f.ctrl_index; o->ctrl_hour = f.ctrl_hour; o->ctrl_minute = f.ctrl_minute; o->ctrl_second = f.ctrl_second; o->ctrl_field = f.ctrl_field;
+}
+
+extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                               sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames)
+{
+    STC007DataStitcher *ds = new STC007DataStitcher();
+    std::deque<STC007Line> in_q;
+    std::deque<PCMSamplePair> out_q;
+    QMutex in_mtx, out_mtx, fr_mtx;
+    std::vector<FrameAsmSTC007> fr;
+    ds->setInputPointers(&in_q, &in_mtx);
+    ds->setOutputPointers(&out_q, &out_mtx);
+    QObject::connect(ds, &STC007DataStitcher::guiUpdFrameAsm, [&](FrameAsmSTC007 d) { fr_mtx.lock(); fr.push_back(d); fr_mtx.unlock(); });
+    ds->setVideoStandard(st->video_standard); ds->setFieldOrder(st->field_order);
+    ds->setPCorrection(st->enable_p); ds->setQCorrection(st->enable_q); ds->setCWDCorrection(st->enable_cwd);
+    ds->setM2SampleFormat(st->m2_format); ds->setResolutionPreset(st->resolution_preset); ds->setSampleRatePreset(st->sample_rate_preset);
+    ds->setFineMaxUnch14(st->max_unch_14); ds->setFineMaxUnch16(st->max_unch_16); ds->setFineUseECC(st->use_ecc);
+    ds->setFineMaskSeams(st->mask_seams); ds->setFineBrokeMask(st->broke_mask); ds->setFineTopLineFix(st->top_line_fix);
+    std::thread th([ds]() { ds->doFrameReassemble(); });
+    size_t fed = 0; long got = 0; bool overflow = false;
+    size_t idle = 0;
+    STC007Line l;
+    while (true) {
+        /* feed up to the reference's input queue limit, frame by frame */
+        in_mtx.lock();
+        size_t qs = in_q.size();
+        while (fed < n_recs && qs < (size_t)(MAX_PCMLINE_QUEUE_SIZE - 1)) { rec_to_line(recs[fed], l); in_q.push_back(l); fed++; qs++; }
+        in_mtx.unlock();
+        out_mtx.lock();
+        size_t drained = out_q.size();
+        while (!out_q.empty()) {
+            PCMSamplePair &p = out_q.front();
+            if ((size_t)got < out_cap) {
+                sdv_sample_pair *o = &out[got];
+                memset(o, 0, sizeof(*o));
+                for (int c = 0; c < 2; c++) {
+                    o->audio_word[c] = p.samples[c].audio_word;
+                    o->sample_flags[c] = (uint8_t)((p.samples[c].data_block_ok ? SDV_SF_BLOCK_OK : 0) | (p.samples[c].word_valid ? SDV_SF_WORD_VALID : 0) |
+                                                   (p.samples[c].word_fixed ? SDV_SF_WORD_FIXED : 0) | (p.samples[c].word_masked ? SDV_SF_WORD_MASKED : 0));
+                }
+                o->sample_rate = p.sample_rate; o->emphasis = p.emphasis; o->service_type = p.service_type;
+            } else overflow = true;
+            got++;
+            out_q.pop_front();
+        }
+        out_mtx.unlock();
+        /* done when everything is fed and the stitcher has stopped making progress (it keeps < 2 frames queued) */
+        in_mtx.lock(); qs = in_q.size(); in_mtx.unlock();
+        if (fed == n_recs && drained == 0) { idle++; if (idle > 150) break; } else idle = 0;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    ds->stop();
+    th.join();
+    size_t nf = fr.size() < frames_cap ? fr.size() : frames_cap;
+    for (size_t i = 0; i < nf; i++) frasm_to_pod(fr[i], &frames[i]);
+    if (n_frames) *n_frames = fr.size();
+    delete ds;
+    return overflow ? -1 : got;
+}

@@ -130,13 +130,17 @@ CTRL_BLOCK_WORDS = (0x3333, 0x0CCC, 0x3333, 0x0CCC, 0x0000)   # cue x4 + ID (stc
 
 def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 486,
                   lines_per_field: int = 245, cut_top: int | None = None, ctrl_block: bool = False,
-                  audio: np.ndarray | None = None, silent: bool = False, **render_kw):
+                  audio: np.ndarray | None = None, silent: bool = False, words: np.ndarray | None = None,
+                  bff: bool = False, cut_top_per_frame=None, **render_kw):
     """Synthetic STC-007 video: one continuous interleaved line stream, `lines_per_field` PCM lines per field
     (config.h:80-81), of which `height//2` are visible starting at `cut_top` (default: as many as do not fit
     are cut from the top, e.g. 2 for 486 rows).  Frame row 2r   <- odd field line cut_top + r,
                                                  frame row 2r+1 <- even field line cut_top + r
     (field/row order of VideoInFFMPEG::spliceFrame, vin_ffmpeg.cpp:281-347).
     ctrl_block=True overwrites stream line 0 of every field with a Control Block line.
+    words: explicit (n_stream_lines, 9) line words (e.g. interleave_stream_f1() for 16-bit PCM-F1) instead of `audio`.
+    bff: the even rows carry the field that is first in time (bottom field first).
+    cut_top_per_frame: (n_frames, 2) per-field vertical offsets (tape tracking drift: the data moves inside the frame).
     Returns (luma (n_frames, height, width) u8, line words (n_stream_lines, 9) u16, audio (n_blocks, 6))."""
     rng = np.random.default_rng(seed)
     vis = height // 2
@@ -148,7 +152,7 @@ def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 
             audio = np.zeros((n_stream, 6), dtype=np.uint32)
         else:
             audio = rng.integers(0, 1 << 14, size=(n_stream, 6), dtype=np.uint32)
-    w9 = interleave_stream(audio)
+    w9 = interleave_stream(audio) if words is None else np.array(words[:n_stream], dtype=np.uint16)
     if ctrl_block:
         cb = np.zeros(8, dtype=np.uint32)
         cb[:5] = CTRL_BLOCK_WORDS
@@ -159,13 +163,25 @@ def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 
     # stream line index for every frame row
     f = np.arange(n_frames)[:, None]
     r = np.arange(vis)[None, :]
-    odd = f * 2 * lines_per_field + cut_top + r
-    even = odd + lines_per_field
+    if cut_top_per_frame is None:
+        ct = np.full((n_frames, 2), cut_top, dtype=np.int64)
+    else:
+        ct = np.asarray(cut_top_per_frame, dtype=np.int64).reshape(n_frames, 2)
+    first = f * 2 * lines_per_field + ct[:, 0:1] + r
+    second = f * 2 * lines_per_field + lines_per_field + ct[:, 1:2] + r
+    odd, even = (second, first) if bff else (first, second)
     idx = np.empty((n_frames, height), dtype=np.int64)
     idx[:, 0:2 * vis:2] = odd
     idx[:, 1:2 * vis:2] = even
     flat = idx.reshape(-1)
-    luma = render_lines(line_bits(w9[flat]), width=width, rng=rng, **render_kw)
+    # rows that fall outside their field's PCM lines (vertical offset too large) are blanking: no PCM there
+    blank = np.empty((n_frames, height), dtype=bool)
+    blank[:, 0:2 * vis:2] = ((ct[:, 1:2] if bff else ct[:, 0:1]) + r) >= lines_per_field
+    blank[:, 1:2 * vis:2] = ((ct[:, 0:1] if bff else ct[:, 1:2]) + r) >= lines_per_field
+    blank = blank.reshape(-1)
+    luma = render_lines(line_bits(w9[np.minimum(flat, n_stream - 1)]), width=width, rng=rng, **render_kw)
+    if blank.any():
+        luma[blank] = np.uint8(render_kw.get("black", 30))
     return luma.reshape(n_frames, height, width), w9, audio
 
 

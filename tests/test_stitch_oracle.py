@@ -1,0 +1,73 @@
+"""Stitch stage (STC007DataStitcher -> PCMSamplePair): the C restatement in oracle/stitcher.c is pinned against
+(1) golden fixtures produced by the real reference (tests/golden/stitch_*.npz) and (2), when the reference build is
+loadable, the real STC007DataStitcher run live on every scenario of stitch_cases.CASES."""
+import os
+
+import numpy as np
+import pytest
+
+import libs
+import stitch_api as sa
+import stitch_cases as sc
+from oracle_run import oracle_binarize
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _report(po, pr, fo, fr):
+    out = [f"pairs {len(po)} vs {len(pr)}, frames {len(fo)} vs {len(fr)}"]
+    for i in range(min(len(fo), len(fr))):
+        if fo[i].tobytes() != fr[i].tobytes():
+            out.append(f" frame {i}: " + str([(n, fo[i][n], fr[i][n]) for n in sa.FRASM_DTYPE.names if fo[i][n] != fr[i][n]]))
+    n = min(len(po), len(pr))
+    d = np.nonzero((po[:n].view(np.uint8).reshape(n, 12) != pr[:n].view(np.uint8).reshape(n, 12)).any(axis=1))[0]
+    out.append(f" {len(d)} pairs differ, first at {d[:5]}")
+    return "\n".join(out)
+
+
+def _oracle(name):
+    recs, st = sc.make_input(name, lambda luma: oracle_binarize(luma, mode=2))
+    pairs, frames = sa.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    return recs, st, pairs, frames
+
+
+@pytest.mark.parametrize("name", sc.GOLDEN)
+def test_oracle_matches_golden(name, oracle_lib):
+    z = np.load(os.path.join(GOLD, "stitch_" + name + ".npz"))
+    recs, st, pairs, frames = _oracle(name)
+    assert sc.digest(recs) == str(z["input_sha256"]), "regenerated input stream differs from the one the fixture was made from"
+    assert bytes(st) == z["settings"].tobytes()
+    want_p = np.ascontiguousarray(z["pairs"]).view(sa.PAIR_DTYPE).reshape(-1)
+    want_f = np.ascontiguousarray(z["frames"]).view(sa.FRASM_DTYPE).reshape(-1)
+    assert len(pairs) == len(want_p) and pairs.tobytes() == want_p.tobytes() and frames.tobytes() == want_f.tobytes(), \
+        _report(pairs, want_p, frames, want_f)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("name", list(sc.CASES))
+def test_oracle_matches_live_reference(name, oracle_lib):
+    if not libs.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available")
+    recs, st, pairs, frames = _oracle(name)
+    rp, rf = sa.run_cpu(libs.load_ref(), "ref_", recs, st)
+    assert len(pairs) == len(rp) and pairs.tobytes() == rp.tobytes() and len(frames) == len(rf) and frames.tobytes() == rf.tobytes(), \
+        _report(pairs, rp, frames, rf)
+
+
+def test_clean_stream_recovers_audio(oracle_lib):
+    """Property: with no damage every block is assembled intact and the PCM stream equals the generator's samples."""
+    from sdvpcmdecoder_amd import synth
+    n = 5
+    luma, w9, audio = synth.stc007_frames(n, seed=77, noise_sigma=2.0)
+    recs, _ = oracle_binarize(luma, mode=2)
+    pairs, frames = sa.run_cpu(libs.load_oracle(), "orc_", sa.with_end_file(recs), sa.default_settings())
+    got = pairs[pairs["service_type"] == 0]
+    # generator samples as the 16-bit signed words the stitcher outputs (14-bit word << 2), one (L, R) pair per row
+    exp = (audio.astype(np.int32) << 2).astype(np.int16).reshape(-1, 2)
+    where = {exp[i].tobytes(): i for i in range(len(exp))}
+    idx = np.array([where.get(got["audio_word"][i].tobytes(), -1) for i in range(len(got))])
+    hit = np.nonzero(idx >= 0)[0]
+    assert len(hit) > 0.9 * len(got)
+    assert (np.diff(hit) == 1).all() and (np.diff(idx[hit]) == 1).all(), "decoded audio is not one continuous run of the source"
+    assert ((got["sample_flags"][hit] & 3) == 3).all()          # block ok + word valid
+    assert frames["blocks_drop"].sum() == 0 and frames["samples_drop"].sum() == 0
