@@ -43,10 +43,31 @@ def default_settings(**kw):
 
 
 def with_end_file(recs):
-    """Appends the END_FILE service line the input plugin puts after the last frame (vin_ffmpeg.cpp)."""
-    tail = np.zeros(1, dtype=libs.LINE_DTYPE)
-    tail["frame_number"] = recs["frame_number"][-1]
-    tail["service_type"] = 2        # SDV_SRV_END_FILE
+    """Appends what the input plugin puts after the last frame of a file (VideoInFFMPEG::insertDummyFrame(true, false),
+    vin_ffmpeg.cpp:367-523, as it passes through VideoToDigital): one frame of FILLER service lines in field order
+    (rows 1,3,5.. END_FIELD, rows 2,4,6.. END_FIELD), then END_FILE and END_FRAME."""
+    last = recs["frame_number"][-1]
+    h = int(((recs["frame_number"] == last) & (recs["service_type"] == 0)).sum())
+    tail = np.zeros(h + 4, dtype=libs.LINE_DTYPE)
+    tail["frame_number"] = last + 1
+    k = 0
+    ln = 0
+    for first in (1, 2):
+        for ln in range(first, h + 1, 2):
+            tail["line_number"][k] = ln
+            tail["service_type"][k] = 3         # SDV_SRV_FILLER
+            k += 1
+        ln += 2
+        tail["line_number"][k] = ln
+        tail["service_type"][k] = 4             # SDV_SRV_END_FIELD
+        k += 1
+    ln += 2
+    tail["line_number"][k] = ln
+    tail["service_type"][k] = 2                 # SDV_SRV_END_FILE
+    ln += 2
+    tail["line_number"][k + 1] = ln
+    tail["service_type"][k + 1] = 5             # SDV_SRV_END_FRAME
+    assert k + 2 == len(tail)
     return np.concatenate([recs, tail])
 
 
