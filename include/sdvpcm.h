@@ -306,6 +306,43 @@ void sdv_default_deint_settings(sdv_deint_settings *st);
 int sdv_deinterleave_blocks(sdv_engine *e, const sdv_deint_line *lines, size_t n_lines, const sdv_deint_settings *settings,
                             sdv_block_rec *out_blocks, size_t n_blocks, void *stream);
 
+/* ---- stitch stage: STC007DataStitcher (stc007datastitcher.h:74-353) ------------------------------------------- */
+/* How the last sdv_stitch_frames call was scheduled (parallel turns in rounds). */
+typedef struct sdv_stitch_info {
+    uint32_t steps;             /* stitcher turns (frame pairs) completed by the call */
+    uint32_t rounds;            /* parallel rounds until every turn had run from its predecessor's final output */
+    uint32_t steps_launched;    /* turn executions over all rounds */
+    uint32_t _pad;
+    float device_ms;            /* analysis + rounds + packing on the device (profiling on) */
+    float _pad2;
+} sdv_stitch_info;
+
+/* Defaults of the STC007DataStitcher constructor / setDefaultFineSettings (stc007datastitcher.cpp:20-31, 7228-7236),
+ * with P and Q correction on as the application sets them. */
+void sdv_default_stitch_settings(sdv_stitch_settings *st);
+/* setVideoStandard / setFieldOrder / setPCorrection / setQCorrection / setCWDCorrection / setM2SampleFormat /
+ * setResolutionPreset / setSampleRatePreset / setFine* slots (stc007datastitcher.h:331-350) in one call. */
+int sdv_set_stitch_settings(sdv_engine *e, const sdv_stitch_settings *st);
+/* A freshly constructed STC007DataStitcher: statistics, previous-frame memory and queued lines are dropped. */
+int sdv_reset_stitcher(sdv_engine *e);
+int sdv_get_stitch_info(const sdv_engine *e, sdv_stitch_info *out);
+
+/* STC007DataStitcher::doFrameReassemble (stc007datastitcher.cpp:7239-7488) over a span of the binarized line stream.
+ * `lines` is what VideoToDigital puts into the stitcher's input deque<STC007Line> (sdv_binarize_frames' out_lines,
+ * service lines included; a file ends with the filler frame + END_FILE + END_FRAME the input plugin appends,
+ * vin_ffmpeg.cpp:367-523).  Every frame that has a successor in the stream is reassembled: trim, field order and
+ * padding detection, assembly, CWD, deinterleave + P/Q correction, masking of broken seams.  The PCMSamplePair
+ * stream goes to out_pairs (what outputSamplePair / outputFileStart / outputFileStop push into the output deque,
+ * :6483-6672), one FrameAsmSTC007 per guiUpdFrameAsm emission to out_frames.  The last frame of the span waits
+ * inside the engine for the next call, exactly as it would wait in the reference's queue for its successor.
+ * Restrictions (SDV_ERR_UNSUPPORTED otherwise): the lines of a frame carry one frame number and the numbers increase
+ * along the stream (what VideoInFFMPEG produces); records behind an END_FILE frame are discarded like the queue flush
+ * at :7380-7400 - feed one source per stream.
+ * All buffers are device pointers.  The call returns when the outputs are complete; *n_pairs / *n_frames receive the
+ * counts (also when SDV_ERR_BAD_ARG reports that pairs_cap / frames_cap were too small). */
+int sdv_stitch_frames(sdv_engine *e, const sdv_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
+                      size_t *n_pairs, sdv_frame_asm *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

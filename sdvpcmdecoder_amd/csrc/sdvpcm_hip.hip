@@ -5,4 +5,6 @@
 #include <hip/hip_runtime.h>
 #include "stc007_device.h"
 #include "stc007_deint_device.h"
+#include "stc007_stitch_device.h"
 #include "engine.inc"
+#include "stitch_engine.inc"

@@ -109,11 +109,18 @@ __device__ inline uint16_t calc_q(const uint16_t *w)
     return q;
 }
 
-__device__ inline void set_word_data(const sdv_deint_settings &st, const sdv_deint_line *lines, size_t base, Block &b, uint8_t res)
+/* where the assembled lines come from: a plain array (the deinterleave kernel) or one of the stitch stage's queues */
+struct PtrSrc {
+    const sdv_deint_line *p;
+    __device__ inline const sdv_deint_line &line(size_t i) const { return p[i]; }
+};
+
+template <class Src>
+__device__ inline void set_word_data(const sdv_deint_settings &st, const Src &lines, size_t base, Block &b, uint8_t res)
 {
     const int s_ofs[7] = { 12, 10, 8, 6, 4, 2, 0 };
     for (int k = 0; k < 8; k++) {
-        const sdv_deint_line &l = lines[base + (size_t)INTERLEAVE_OFS * k];
+        const sdv_deint_line l = lines.line(base + (size_t)INTERLEAVE_OFS * k);
         bool bw_ok = (l.flags & SDV_DL_COORDS_BW_OK) != 0;
         bool ok = !st.ignore_crc ? bit(l.word_crc_ok, k) : bw_ok;
         bool cwd = (l.flags & SDV_DL_FIXED_BY_CWD) != 0;
@@ -177,7 +184,8 @@ __device__ inline uint8_t fix_by_q(Block &b, uint8_t first_bad, uint8_t second_b
 }
 
 /* STC007Deinterleaver::processBlock for the block that starts at assembled line `base` */
-__device__ inline void process_block(const sdv_deint_settings &st, const sdv_deint_line *lines, size_t base, Block &out)
+template <class Src>
+__device__ inline void process_block(const sdv_deint_settings &st, const Src &lines, size_t base, Block &out)
 {
     uint8_t run_res, stage_count = 0, fill_passes, all_errs = 0, aud_errs = 0, first_bad = NO_ERR_INDEX, second_bad = NO_ERR_INDEX, fix, state = STG_DATA_FILL;
     if (st.res_mode == SDV_RES_MODE_14BIT) { run_res = SDV_RES_14BIT; fill_passes = MAX_PASSES; }
@@ -282,7 +290,8 @@ struct DeintArgs { const sdv_deint_line *lines; size_t n_blocks; sdv_deint_setti
 __device__ inline void deint_body(const DeintArgs &a, size_t s)
 {
     Block b;
-    process_block(a.st, a.lines, s, b);
+    PtrSrc src; src.p = a.lines;
+    process_block(a.st, src, s, b);
     sdv_block_rec r;
     for (int i = 0; i < 8; i++) { r.w_frame[i] = b.w_frame[i]; r.w_line[i] = b.w_line[i]; r.words[i] = b.words[i]; }
     r.line_crc = b.line_crc; r.cwd_fixed = b.cwd_fixed; r.word_valid = b.word_valid; r.resolution = b.resolution;

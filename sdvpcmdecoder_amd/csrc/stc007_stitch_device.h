@@ -1,0 +1,1371 @@
+/*
+ * stc007_stitch_device.h - HIP device code of the STC-007 stitch stage: STC007DataStitcher
+ * (stc007datastitcher.cpp:3-7488) from binarized line records to PCMSamplePair records.
+ *
+ * One wave64 per stitcher turn ("step": frame A = segment k of the record stream, frame B = segment k+1):
+ *   sdv_k_stitch_analyze  frame-local work, once per frame: findFramesTrim (:259-734), splitFramesToFields (:737-985),
+ *                         getFieldResolution (:996-1211)
+ *   sdv_k_stitch_step     everything that depends on the previous turn: findFieldStitching (:2929-4275) with
+ *                         tryPadding / findPadding (:1417-2054), fillFrameForOutput (:4588-5387), the CWD pre-scan
+ *                         (:5905-6452) and performDeinterleave (:6675-6885) with the PCMSamplePair output (:6525-6569)
+ *   sdv_k_stitch_compact  packs the per-step outputs into the contiguous streams the reference's queues hold
+ * The control flow of a turn is wave-uniform (every lane follows the reference's state machines with the same values);
+ * the lanes split the data-block decodes (tryPadding windows, resolution probes, final deinterleave) and the line
+ * copies.  The CWD pre-scan runs one lane per residue class modulo 16: a block at offset i only touches lines
+ * i + 16k, so the 16 classes are independent and each is processed in the reference's order.
+ *
+ * What links the turns (previous frame's FrameAsmSTC007, padding counter, broken countdown, the last 112 assembled
+ * lines) travels in StepChain; the engine (stitch_engine.inc) iterates the turns of a batch in parallel until every
+ * turn has been run from exactly what its predecessor produced ("stitch stage").
+ */
+#ifndef SDV_STC007_STITCH_DEVICE_H
+#define SDV_STC007_STITCH_DEVICE_H
+
+#include "stc007_deint_device.h"
+
+namespace sdvs {
+using sdvd::Block;
+
+enum { VID_UNKNOWN = 0, VID_PAL, VID_NTSC, VID_MAX };
+enum { ORDER_UNK = 0, ORDER_TFF, ORDER_BFF, ORDER_MAX };
+enum { LINES_PF_NTSC = 245, LINES_PF_PAL = 294, LINES_PF_MAX_PAL = 294 + 16, LINES_PF_MAX_NTSC = 294 - 32 };   /* config.h:80-81, stc007datastitcher.h */
+enum { BUF_FIELD = 294, BUF_TRIM = 3 * 640 * 3, MIN_GOOD_LINES_PF = 245 - 8, MIN_FILL_LINES_PF = 56 };
+enum { MAX_PADDING_14BIT = 32, MAX_PADDING_16BIT = 16, MAX_BURST_SILENCE = 8, MAX_BURST_BROKEN = 1, MAX_BURST_UNCH_DELTA = 8 };
+enum { SRES_UNKNOWN = 0, SRES_14BIT, SRES_16BIT, SRES_MAX };
+enum { DS_NO_DATA = 0, DS_SILENCE, DS_BROKE, DS_NO_PAD, DS_OK };
+enum { CRC_SILENT = 0xA96A, CRC_POLY = 0x1021, CRC_INIT = 0xFFFF };
+enum { MIN_DEINT = sdvd::MIN_DEINT_DATA, ILV = sdvd::INTERLEAVE_OFS };
+enum { QCAP = 1024 };               /* conv_queue capacity per wave: 112 + 80 + 2 x 294 + 112 + CWD look-ahead 112 */
+enum { PAIR_SLOT = 2352, FRASM_SLOT = 3 };   /* per-step output slots: 3 pairs x (QCAP - 112 - 128) blocks + 2 service pairs */
+enum { MST_BOT_2 = 4, MED_LEN_OK = 3 };      /* STC007Line::MARK_ST_BOT_2 / MARK_ED_LEN_OK */
+enum { NO_COORD_L = -32768, NO_COORD_R = 32767 };
+
+/* ---- a line as the stitcher needs it (STC007Line minus the pixel side). 32 bytes. ----------------------------- */
+enum { SL_FORCED_BAD = 1, SL_COORDS_VALID = 2, SL_BW_SET = 4 };
+struct alignas(16) SLine {
+    uint32_t frame; uint16_t line; uint16_t words[9]; uint16_t calc_crc;
+    uint16_t wcrc, wvalid;          /* bit i = word_crc[i] / word_valid[i], i = 0..8 */
+    uint8_t flags, ref_level;
+};
+
+__device__ inline uint16_t crc16_update(uint16_t crc, uint16_t data, int bits)   /* pcmline.cpp:461-487 */
+{
+    for (int i = 0; i < bits; i++) {
+        bool msb = (crc & 0x8000) != 0, inb = (data & (1 << (bits - 1))) != 0;
+        crc = (uint16_t)(crc << 1);
+        if (msb != inb) crc ^= CRC_POLY;
+        data = (uint16_t)(data << 1);
+    }
+    return crc;
+}
+__device__ inline uint16_t crc_words(const uint16_t *w)   /* stc007line.cpp:245-251 */
+{
+    uint16_t crc = CRC_INIT;
+    for (int i = 0; i < 8; i++) crc = crc16_update(crc, w[i], 14);
+    return crc;
+}
+__device__ inline SLine sline_empty(uint32_t frame, uint16_t line)   /* STC007Line::clear, stc007line.cpp:64-93 */
+{
+    SLine l;
+    l.frame = frame; l.line = line;
+    for (int i = 0; i < 8; i++) l.words[i] = 0;
+    l.words[8] = (uint16_t)~CRC_SILENT; l.calc_crc = CRC_SILENT;
+    l.wcrc = l.wvalid = 0; l.flags = 0; l.ref_level = 0;
+    return l;
+}
+/* what toLine() of INTEGRATION.md makes of a record (STC007Line setters + applyCRCStatePerWord, stc007line.cpp:198-204) */
+__device__ inline SLine sline_from_rec(const sdv_line_rec &r)
+{
+    if (r.service_type != SDV_SRV_NO && r.service_type != SDV_SRV_CTRL_BLOCK) {
+        SLine l = sline_empty(r.frame_number, r.line_number);      /* filler: PCMLine::clear() on a cleared line */
+        l.calc_crc = 0;
+        return l;
+    }
+    SLine l;
+    l.frame = r.frame_number; l.line = r.line_number;
+    for (int i = 0; i < 9; i++) l.words[i] = r.words[i];
+    l.calc_crc = r.calc_crc;
+    bool forced = (r.flags & SDV_LF_FORCED_BAD) != 0;
+    bool cv = r.data_start != NO_COORD_L && r.data_stop != NO_COORD_R && r.data_start < r.data_stop;
+    l.flags = (uint8_t)((forced ? SL_FORCED_BAD : 0) | (cv ? SL_COORDS_VALID : 0) | ((r.flags & SDV_LF_BW_SET) ? SL_BW_SET : 0));
+    bool v = !forced && l.calc_crc == l.words[8];
+    l.wcrc = l.wvalid = v ? 0x1FF : 0;
+    l.ref_level = r.ref_level;
+    return l;
+}
+__device__ inline bool crc_valid_if(const SLine &l) { return l.calc_crc == l.words[8]; }                 /* isCRCValidIgnoreForced */
+__device__ inline bool crc_valid(const SLine &l) { return !(l.flags & SL_FORCED_BAD) && crc_valid_if(l); }   /* isCRCValid */
+__device__ inline sdv_deint_line view(const SLine &l)     /* what STC007Deinterleaver::setWordData reads of a line */
+{
+    sdv_deint_line d;
+    d.frame_number = l.frame; d.line_number = l.line;
+    for (int i = 0; i < 8; i++) d.words[i] = l.words[i];
+    d.word_crc_ok = (l.flags & SL_FORCED_BAD) ? 0 : (uint8_t)(l.wcrc & 0xFF);
+    bool fixed = crc_valid(l) && ((~l.wcrc & l.wvalid & 0xFF) != 0);                                      /* isFixedByCWD, stc007line.cpp:628-641 */
+    d.flags = (uint8_t)((fixed ? SDV_DL_FIXED_BY_CWD : 0) | (((l.flags & SL_COORDS_VALID) && (l.flags & SL_BW_SET)) ? SDV_DL_COORDS_BW_OK : 0));
+    return d;
+}
+
+/* ---- FrameAsmSTC007 (frametrimset.h:116-275, frametrimset.cpp:383-959) ------------------------------------------ */
+struct Frasm {
+    uint32_t frame_number;
+    uint16_t odd_std_lines, even_std_lines, odd_data_lines, even_data_lines, odd_valid_lines, even_valid_lines;
+    uint16_t odd_top_data, odd_bottom_data, even_top_data, even_bottom_data, odd_sample_rate, even_sample_rate;
+    uint16_t blocks_total, blocks_drop, samples_drop, inner_padding, outer_padding;
+    uint16_t blocks_broken_field, blocks_broken_seam, blocks_fix_p, blocks_fix_q, blocks_fix_cwd;
+    uint8_t field_order, odd_ref, even_ref, service_type, video_standard, tff_cnt, bff_cnt, odd_resolution, even_resolution;
+    uint8_t odd_emphasis, even_emphasis, order_preset, order_guessed, trim_ok, inner_padding_ok, outer_padding_ok;
+    uint8_t inner_silence, outer_silence, vid_std_preset, vid_std_guessed;
+    int8_t ctrl_index, ctrl_hour, ctrl_minute, ctrl_second, ctrl_field;
+    uint8_t _pad[2];
+};
+__host__ __device__ inline void frasm_clear_asm_stats(Frasm &f)
+{
+    f.odd_ref = f.even_ref = 0; f.blocks_total = f.blocks_drop = f.samples_drop = 0;
+    f.blocks_broken_field = f.blocks_broken_seam = f.blocks_fix_p = f.blocks_fix_q = f.blocks_fix_cwd = 0;
+}
+__host__ __device__ inline void frasm_clear_misc(Frasm &f)
+{
+    f.odd_std_lines = f.even_std_lines = f.odd_data_lines = f.even_data_lines = f.odd_valid_lines = f.even_valid_lines = 0;
+    f.odd_sample_rate = f.even_sample_rate = 0;
+    f.field_order = ORDER_UNK; f.odd_emphasis = f.even_emphasis = 0; f.order_preset = f.order_guessed = 0; f.service_type = 0;
+    f.video_standard = VID_UNKNOWN; f.tff_cnt = f.bff_cnt = 0; f.odd_resolution = f.even_resolution = 0;
+    f.inner_padding = f.outer_padding = 0;
+    f.trim_ok = 0; f.inner_padding_ok = f.outer_padding_ok = 0; f.inner_silence = f.outer_silence = 1;
+    f.vid_std_preset = f.vid_std_guessed = 0;
+    f.ctrl_index = f.ctrl_hour = f.ctrl_minute = f.ctrl_second = f.ctrl_field = -1;
+    frasm_clear_asm_stats(f);
+}
+__host__ __device__ inline void frasm_clear(Frasm &f)
+{
+    f.frame_number = 0; f.odd_top_data = 0; f.odd_bottom_data = 0xFFFF; f.even_top_data = 0; f.even_bottom_data = 0xFFFF;
+    f._pad[0] = f._pad[1] = 0;
+    frasm_clear_misc(f);
+}
+__device__ inline bool order_set(const Frasm &f) { return f.field_order == ORDER_TFF || f.field_order == ORDER_BFF; }
+__device__ inline void preset_order(Frasm &f, uint8_t o) { f.order_preset = 1; f.order_guessed = 0; f.field_order = o; }
+__device__ inline void set_order_unknown(Frasm &f) { if (!f.order_preset) { f.field_order = ORDER_UNK; f.order_guessed = 0; } }
+__device__ inline void set_order(Frasm &f, uint8_t o) { if (!f.order_preset) f.field_order = o; }
+__device__ inline void frasm_to_pod(const Frasm &f, sdv_frame_asm &o)
+{
+    o.frame_number = f.frame_number;
+    o.odd_std_lines = f.odd_std_lines; o.even_std_lines = f.even_std_lines; o.odd_data_lines = f.odd_data_lines; o.even_data_lines = f.even_data_lines;
+    o.odd_valid_lines = f.odd_valid_lines; o.even_valid_lines = f.even_valid_lines;
+    o.odd_top_data = f.odd_top_data; o.odd_bottom_data = f.odd_bottom_data; o.even_top_data = f.even_top_data; o.even_bottom_data = f.even_bottom_data;
+    o.odd_sample_rate = f.odd_sample_rate; o.even_sample_rate = f.even_sample_rate;
+    o.blocks_total = f.blocks_total; o.blocks_drop = f.blocks_drop; o.samples_drop = f.samples_drop;
+    o.inner_padding = f.inner_padding; o.outer_padding = f.outer_padding;
+    o.blocks_broken_field = f.blocks_broken_field; o.blocks_broken_seam = f.blocks_broken_seam;
+    o.blocks_fix_p = f.blocks_fix_p; o.blocks_fix_q = f.blocks_fix_q; o.blocks_fix_cwd = f.blocks_fix_cwd;
+    o.field_order = f.field_order; o.odd_ref = f.odd_ref; o.even_ref = f.even_ref; o.service_type = f.service_type;
+    o.video_standard = f.video_standard; o.tff_cnt = f.tff_cnt; o.bff_cnt = f.bff_cnt; o.odd_resolution = f.odd_resolution; o.even_resolution = f.even_resolution;
+    o.flags = (uint8_t)((f.order_preset ? SDV_FA_ORDER_PRESET : 0) | (f.order_guessed ? SDV_FA_ORDER_GUESSED : 0) | (f.trim_ok ? SDV_FA_TRIM_OK : 0) |
+                        (f.inner_padding_ok ? SDV_FA_INNER_OK : 0) | (f.outer_padding_ok ? SDV_FA_OUTER_OK : 0) | (f.inner_silence ? SDV_FA_INNER_SILENCE : 0) |
+                        (f.outer_silence ? SDV_FA_OUTER_SILENCE : 0) | (f.vid_std_preset ? SDV_FA_VID_STD_PRESET : 0));
+    o.flags2 = (uint8_t)((f.odd_emphasis ? SDV_FA2_ODD_EMPHASIS : 0) | (f.even_emphasis ? SDV_FA2_EVEN_EMPHASIS : 0) | (f.vid_std_guessed ? SDV_FA2_VID_STD_GUESSED : 0));
+    o.ctrl_index = f.ctrl_index; o.ctrl_hour = f.ctrl_hour; o.ctrl_minute = f.ctrl_minute; o.ctrl_second = f.ctrl_second; o.ctrl_field = f.ctrl_field;
+}
+
+/* ---- per-frame facts that do not depend on other frames (sdv_k_stitch_analyze) ---------------------------------- */
+enum { FL_NEW_FILE = 1, FL_END_FILE = 2, FL_TRIM_OK = 4, FL_BAD_NUMBERS = 8 };
+struct FrameLocal {
+    uint32_t frame_number;          /* of the END_FRAME line that closes the segment */
+    uint32_t seg_start, seg_len;    /* the frame's records, END_FRAME included */
+    uint16_t top[2], bottom[2];     /* [0] odd lines, [1] even lines */
+    uint16_t data_lines[2], valid_lines[2];
+    uint16_t max_line;
+    uint8_t ref[2];
+    uint8_t flags;
+    uint8_t field_res[2];           /* getFieldResolution: SRES_* */
+    int8_t ctrl[5];
+    uint16_t idx[2][BUF_FIELD];     /* record index (relative to seg_start) of every line kept in the field buffers */
+};
+
+/* the record stream of a call: what was left over from the previous call, then the caller's records */
+struct RecSrc {
+    const sdv_line_rec *carry; uint32_t n_carry; const sdv_line_rec *recs;
+    __device__ inline const sdv_line_rec &at(uint32_t i) const { return i < n_carry ? carry[i] : recs[i - n_carry]; }
+};
+
+/* STC007DataStitcher settings as the kernels need them */
+struct Cfg {
+    uint8_t preset_video_mode, preset_field_order, preset_audio_res, en_p, en_q, en_cwd, m2, ignore_crc;
+    uint8_t max_unch_14, max_unch_16, mask_seams, broken_mask_dur, fix_cut_above, _pad;
+    uint16_t preset_sample_rate;
+};
+
+/* ---- block helpers (STC007DataBlock, stc007datablock.cpp) ------------------------------------------------------- */
+__device__ inline uint8_t ind_mask(const Block &b) { return b.resolution == SDV_RES_16BIT ? 0x7F : 0xFF; }
+__device__ inline int errors_audio_fixed(const Block &b) { return __popc((uint32_t)(~b.word_valid & 0x3F)); }
+__device__ inline bool blk_valid(const Block &b) { return (b.word_valid & 0x3F) == 0x3F; }                                   /* isBlockValid :305-312 */
+__device__ inline int errors_total_cwd(const Block &b) { return __popc((uint32_t)(~b.line_crc & ~b.cwd_fixed & ind_mask(b))); }   /* :653-678 */
+__device__ inline bool can_force_check(const Block &b)                                                                         /* :246-272 */
+{
+    if (b.audio_state == SDV_AUD_BROKEN) return false;
+    return b.resolution == SDV_RES_14BIT ? errors_total_cwd(b) <= 1 : errors_total_cwd(b) == 0;
+}
+__device__ inline int16_t get_sample(const Block &b, int i, bool m2)                                                          /* :507-562 */
+{
+    if (!m2) return b.resolution == SDV_RES_16BIT ? (int16_t)b.words[i] : (int16_t)(b.words[i] << 2);
+    uint16_t w = b.words[i];
+    if ((w & (1 << 13)) == 0) w = (uint16_t)(w << 3);
+    else {
+        bool pos = (w & (1 << 12)) == 0;
+        w = (uint16_t)(w & ~(1 << 13));
+        if (!pos) w |= (1 << 15) | (1 << 14) | (1 << 13);
+    }
+    return (int16_t)w;
+}
+__device__ inline bool blk_silent(const Block &b, bool m2) { for (int i = 0; i < 6; i++) if (get_sample(b, i, m2) != 0) return false; return true; }   /* :465-478 */
+__device__ inline void mark_unsafe(Block &b)                                                                                   /* :168-201 */
+{
+    if (b.audio_state == SDV_AUD_BROKEN) return;
+    uint8_t m = ind_mask(b);
+    b.word_valid = (uint8_t)((b.word_valid & ~m) | (b.line_crc & m));
+    b.line_crc &= (uint8_t)~m; b.cwd_fixed &= (uint8_t)~m;
+    b.audio_state = SDV_AUD_ORIG; b.cwd_applied = false;
+}
+
+/* resolution rules for a seam (stc007datastitcher.cpp:1214-1269) */
+__device__ inline uint8_t res_mode_for_seam(uint8_t r1, uint8_t r2)
+{
+    uint8_t fin = SDV_RES_MODE_16BIT_AUTO;
+    if (r1 == r2) { fin = r1; if (r1 == SDV_RES_MODE_14BIT_AUTO) fin = SDV_RES_MODE_14BIT; else if (r1 == SDV_RES_MODE_16BIT_AUTO) fin = SDV_RES_MODE_16BIT; }
+    else if (r1 == SDV_RES_MODE_14BIT) { if (r2 == SDV_RES_MODE_14BIT_AUTO) fin = SDV_RES_MODE_14BIT_AUTO; }
+    else if (r1 == SDV_RES_MODE_14BIT_AUTO) { if (r2 == SDV_RES_MODE_14BIT) fin = SDV_RES_MODE_14BIT_AUTO; }
+    else if (r1 == SDV_RES_MODE_16BIT) { if (r2 == SDV_RES_MODE_14BIT) fin = SDV_RES_MODE_14BIT_AUTO; }
+    return fin;
+}
+__device__ inline uint8_t res_for_seam(uint8_t r1, uint8_t r2)
+{
+    uint8_t fin = res_mode_for_seam(r1, r2);
+    return (fin == SDV_RES_MODE_16BIT || fin == SDV_RES_MODE_16BIT_AUTO) ? SDV_RES_16BIT : SDV_RES_14BIT;
+}
+
+/* effective deinterleaver switches after the reference's setter coupling (stc007deinterleaver.cpp:210-260) */
+__device__ inline sdv_deint_settings deint_cfg(uint8_t res_mode, bool ignore_crc, bool force, bool p, bool q, bool cwd)
+{
+    sdv_deint_settings st;
+    st.res_mode = res_mode; st.ignore_crc = ignore_crc; st.force_ecc_check = force;
+    st.en_q_code = q; st.en_p_code = p || q; st.en_cwd = cwd;
+    st._pad[0] = st._pad[1] = 0;
+    return st;
+}
+
+/* ---- line sources for processBlock ------------------------------------------------------------------------------- */
+/* one of the four field buffers (frame1_odd/even, frame2_odd/even): lines come straight from the records */
+struct Field {
+    const FrameLocal *fl; int parity; int size;            /* size = data lines */
+    RecSrc src;
+    __device__ inline SLine get(int i) const { return sline_from_rec(src.at(fl->seg_start + fl->idx[parity][i])); }
+    __device__ inline uint32_t frame_of(int) const { return fl->frame_number; }
+};
+struct FieldSrc {
+    Field f;
+    __device__ inline sdv_deint_line line(size_t i) const { return view(f.get((int)i)); }
+};
+/* tryPadding's queue: tail of field 1, `pad` empty lines, head of field 2 (stc007datastitcher.cpp:1455-1520) */
+struct PadQueue {
+    Field f1, f2; int a0, n0, npad, n2; uint32_t pad_frame; uint16_t pad_line0; bool m2;
+    __device__ inline int size() const { return n0 + npad + n2; }
+    __device__ inline SLine get(int i) const
+    {
+        if (i < n0) return f1.get(a0 + i);
+        if (i < n0 + npad) {
+            SLine e = sline_empty(pad_frame, (uint16_t)(pad_line0 + 2 * (i - n0)));
+            if (m2) { for (int w = 0; w < 8; w++) e.words[w] = 1 << 13; e.calc_crc = crc_words(e.words); }
+            return e;
+        }
+        return f2.get(i - n0 - npad);
+    }
+    __device__ inline sdv_deint_line line(size_t i) const { return view(get((int)i)); }
+};
+struct WsSrc {
+    const SLine *q;
+    __device__ inline sdv_deint_line line(size_t i) const { return view(q[i]); }
+};
+
+/* ================================================================================================================== */
+/* sdv_k_stitch_analyze: one wave per frame segment                                                                    */
+/* ================================================================================================================== */
+struct FrameBrief { uint32_t frame_number; uint8_t flags, field_res[2], _pad; };     /* what the host needs of a FrameLocal */
+struct AnalyzeArgs {
+    RecSrc src; const uint32_t *seg_end; uint32_t n_seg;      /* seg_end[k] = index of the k-th END_FRAME record */
+    Cfg cfg; FrameLocal *fl; FrameBrief *brief;
+};
+
+__device__ inline uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+/* STC007DataStitcher::getFieldResolution (stc007datastitcher.cpp:996-1211) for one field buffer, blocks split over the lanes */
+__device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int lane)
+{
+    if (cfg.preset_audio_res == SRES_14BIT) return SRES_14BIT;
+    if (cfg.preset_audio_res == SRES_16BIT) return SRES_16BIT;
+    if (f.size > BUF_FIELD || f.size <= MIN_DEINT) return SRES_UNKNOWN;
+    int test = f.size - MIN_DEINT;
+    FieldSrc src; src.f = f;
+    uint16_t res[2] = { 0, 0 };
+    for (int c = 0; c * 64 < test; c++) {
+        int i = c * 64 + lane;
+        bool act = i < test;
+        uint64_t good[2], brk[2];
+        for (int m = 0; m < 2; m++) {
+            bool g = false, k = false;
+            if (act) {
+                Block b;
+                sdvd::process_block(deint_cfg(m == 0 ? SDV_RES_MODE_14BIT : SDV_RES_MODE_16BIT, false, true, true, false, false), src, (size_t)i, b);
+                g = blk_valid(b) && can_force_check(b) && !blk_silent(b, cfg.m2);
+                k = b.audio_state == SDV_AUD_BROKEN;
+            }
+            good[m] = __ballot(g); brk[m] = __ballot(k);
+        }
+        int cnt = test - c * 64; if (cnt > 64) cnt = 64;
+        for (int j = 0; j < cnt; j++)
+            for (int m = 0; m < 2; m++) {
+                if ((good[m] >> j) & 1) res[m]++;
+                else if (((brk[m] >> j) & 1) && res[m] > 0) res[m]--;
+            }
+    }
+    if (res[0] > (ILV * 2)) {
+        uint16_t t = (uint16_t)(res[1] * 128);
+        t = (uint16_t)(t / res[0]);
+        return t > 32 ? SRES_16BIT : SRES_14BIT;
+    }
+    return SRES_UNKNOWN;
+}
+
+__device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
+{
+    const uint32_t start = k == 0 ? 0u : a.seg_end[k - 1] + 1u, end = a.seg_end[k];      /* [start, end) + END_FRAME at end */
+    const uint32_t n = end - start;
+    const uint32_t fnum = a.src.at(end).frame_number;
+    FrameLocal *fl = &a.fl[k];
+    /* pass 1 (findFramesTrim, first loop :300-470): good lines per field, service flags, first Control Block */
+    uint32_t good[2] = { 0, 0 }, first_good = 0xFFFFFFFFu, ctrl_pos = 0xFFFFFFFFu;
+    bool new_file = false, end_file = false, bad_numbers = false;
+    for (uint32_t c = 0; c < n; c += 64) {
+        uint32_t i = c + (uint32_t)lane;
+        bool act = i < n, g = false, odd = false, nf = false, ef = false, cb = false, bn = false;
+        if (act) {
+            const sdv_line_rec &r = a.src.at(start + i);
+            bn = r.frame_number != fnum;
+            if (r.service_type == SDV_SRV_NO) { g = !(r.flags & SDV_LF_FORCED_BAD) && r.calc_crc == r.words[8]; odd = (r.line_number % 2) != 0; }
+            else if (r.service_type == SDV_SRV_NEW_FILE) nf = true;
+            else if (r.service_type == SDV_SRV_END_FILE) ef = true;
+            else if (r.service_type == SDV_SRV_CTRL_BLOCK) cb = true;
+        }
+        uint64_t mg = __ballot(g), mo = __ballot(g && odd), mc = __ballot(cb);
+        new_file = new_file || __ballot(nf) != 0; end_file = end_file || __ballot(ef) != 0; bad_numbers = bad_numbers || __ballot(bn) != 0;
+        good[0] += (uint32_t)__popcll(mo); good[1] += (uint32_t)__popcll(mg & ~mo);
+        if (mg != 0 && first_good == 0xFFFFFFFFu) first_good = c + (uint32_t)(__ffsll((unsigned long long)mg) - 1);
+        /* a Control Block counts while no good line has been seen yet: keep the last such one */
+        while (mc != 0) {
+            uint32_t pos = c + (uint32_t)(__ffsll((unsigned long long)mc) - 1);
+            mc &= mc - 1;
+            if (pos < first_good) ctrl_pos = pos;
+        }
+    }
+    bool skip[2] = { good[0] > MIN_GOOD_LINES_PF, good[1] > MIN_GOOD_LINES_PF };
+    /* pass 2 (second loop :480-700): top / bottom data line of each field, in stream order */
+    uint16_t top[2] = { 0, 0 }, bottom[2] = { 0, 0 }, max_line = 0;
+    bool have[2] = { false, false };
+    for (uint32_t c = 0; c < n; c += 64) {
+        uint32_t i = c + (uint32_t)lane;
+        bool act = i < n, q = false, odd = false;
+        uint16_t ln = 0;
+        if (act) {
+            const sdv_line_rec &r = a.src.at(start + i);
+            ln = r.line_number; odd = (ln % 2) != 0;
+            if (r.service_type == SDV_SRV_NO) {
+                bool crc_if = r.calc_crc == r.words[8];
+                bool markers = r.mark_st_stage == MST_BOT_2 && r.mark_ed_stage == MED_LEN_OK;
+                q = skip[odd ? 0 : 1] ? crc_if : (markers || crc_if);
+            }
+        }
+        for (int p = 0; p < 2; p++) {
+            uint64_t m = __ballot(q && (odd == (p == 0)));
+            if (m != 0) {
+                int lo = __ffsll((unsigned long long)m) - 1, hi = 63 - __clzll((unsigned long long)m);
+                uint16_t l_lo = (uint16_t)__shfl((int)ln, lo), l_hi = (uint16_t)__shfl((int)ln, hi);
+                if (!have[p]) { top[p] = l_lo; have[p] = true; }
+                bottom[p] = l_hi;
+            }
+        }
+    }
+    bool trim_ok = have[0] && have[1];
+    /* pass 3 (splitFramesToFields :737-985): the field buffers, valid counts, mean reference level */
+    uint32_t cnt[2] = { 0, 0 }, valid[2] = { 0, 0 }, ref_all[2] = { 0, 0 }, ref_ok[2] = { 0, 0 };
+    for (uint32_t c = 0; c < n; c += 64) {
+        uint32_t i = c + (uint32_t)lane;
+        bool act = i < n, sel = false, odd = false, ok = false;
+        uint16_t ln = 0; uint32_t ref = 0;
+        if (act) {
+            const sdv_line_rec &r = a.src.at(start + i);
+            if (r.service_type == SDV_SRV_NO || r.service_type == SDV_SRV_FILLER) {
+                ln = r.line_number; odd = (ln % 2) != 0;
+                int p = odd ? 0 : 1;
+                bool in = ln >= top[p] && ln <= bottom[p];
+                if (!odd) in = in && ((top[1] != bottom[1]) || (top[1] != 0));
+                sel = in;
+                if (r.service_type == SDV_SRV_NO) { ok = !(r.flags & SDV_LF_FORCED_BAD) && r.calc_crc == r.words[8]; ref = r.ref_level; }
+            } else ln = 0;
+            if (r.service_type != SDV_SRV_NO && r.service_type != SDV_SRV_FILLER) ln = 0;
+        }
+        /* f_max_line: over all data / filler lines */
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { uint16_t o = (uint16_t)__shfl((int)ln, (lane + ofs) & 63); if (o > ln) ln = o; }
+        uint16_t mx = (uint16_t)__shfl((int)ln, 0);
+        if (mx > max_line) max_line = mx;
+        for (int p = 0; p < 2; p++) {
+            bool mine = sel && (odd == (p == 0));
+            uint64_t m = __ballot(mine);
+            uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
+            bool kept = mine && rank < BUF_FIELD;
+            if (kept) fl->idx[p][rank] = (uint16_t)i;
+            uint64_t mk = __ballot(kept), mv = __ballot(kept && ok);
+            /* sums of the reference level over kept lines / kept valid lines */
+            uint32_t ra = kept ? ref : 0, ro = (kept && ok) ? ref : 0;
+            for (int ofs = 32; ofs > 0; ofs >>= 1) { ra += (uint32_t)__shfl((int)ra, (lane + ofs) & 63); ro += (uint32_t)__shfl((int)ro, (lane + ofs) & 63); }
+            ref_all[p] += (uint32_t)__shfl((int)ra, 0); ref_ok[p] += (uint32_t)__shfl((int)ro, 0);
+            cnt[p] += (uint32_t)__popcll(mk); valid[p] += (uint32_t)__popcll(mv);
+        }
+    }
+    int8_t ctrl[5] = { -1, -1, -1, -1, -1 };
+    if (ctrl_pos != 0xFFFFFFFFu) {
+        const sdv_line_rec &r = a.src.at(start + ctrl_pos);          /* stc007line.cpp:375-445 */
+        ctrl[0] = (int8_t)((r.words[5] >> 8) & 0x3F);
+        ctrl[1] = (int8_t)((r.words[5] >> 4) & 0x0F);
+        ctrl[2] = (int8_t)(((r.words[6] >> 12) & 0x03) + ((r.words[5] & 0x0F) << 2));
+        ctrl[3] = (int8_t)((r.words[6] >> 6) & 0x3F);
+        ctrl[4] = (int8_t)(r.words[6] & 0x3F);
+    }
+    if (lane == 0) {
+        fl->frame_number = fnum; fl->seg_start = start; fl->seg_len = n + 1;
+        for (int p = 0; p < 2; p++) {
+            fl->top[p] = top[p]; fl->bottom[p] = bottom[p]; fl->data_lines[p] = (uint16_t)cnt[p]; fl->valid_lines[p] = (uint16_t)valid[p];
+            fl->ref[p] = valid[p] > 0 ? (uint8_t)(ref_ok[p] / valid[p]) : (cnt[p] > 0 ? (uint8_t)(ref_all[p] / cnt[p]) : 0);
+        }
+        fl->max_line = max_line;
+        fl->flags = (uint8_t)((new_file ? FL_NEW_FILE : 0) | (end_file ? FL_END_FILE : 0) | (trim_ok ? FL_TRIM_OK : 0) | ((bad_numbers || n > BUF_TRIM / 2) ? FL_BAD_NUMBERS : 0));
+        for (int i = 0; i < 5; i++) fl->ctrl[i] = ctrl[i];
+    }
+    __syncthreads();            /* the index lists are read back through processBlock below */
+    uint8_t fres[2];
+    for (int p = 0; p < 2; p++) {
+        Field f; f.fl = fl; f.parity = p; f.size = (int)cnt[p]; f.src = a.src;
+        fres[p] = field_resolution(a.cfg, f, lane);
+    }
+    if (lane == 0) {
+        fl->field_res[0] = fres[0]; fl->field_res[1] = fres[1];
+        FrameBrief br; br.frame_number = fnum; br.flags = fl->flags; br.field_res[0] = fres[0]; br.field_res[1] = fres[1]; br._pad = 0;
+        a.brief[k] = br;
+    }
+}
+} // namespace sdvs
+
+namespace sdvs {
+/* ================================================================================================================== */
+/* sdv_k_stitch_step: one wave per stitcher turn                                                                       */
+/* ================================================================================================================== */
+/* what one turn hands to the next (STC007DataStitcher members that survive a turn of doFrameReassemble) */
+struct StepChain {
+    Frasm f0;                               /* frasm_f0 */
+    uint8_t last_pad_counter, broken_countdown;
+    uint16_t tail_n;                        /* lines left in conv_queue (<= 112) */
+    uint32_t _pad[3];
+    SLine tail[MIN_DEINT];
+};
+struct StepInfo { uint32_t n_pairs; uint8_t n_frasm, changed, push_order, _pad; };
+struct StepArgs {
+    RecSrc src; const FrameLocal *fl; Cfg cfg;
+    const uint32_t *work; uint32_t n_work;  /* steps to run: k | which[k-1] << 30 | which[k] << 31 (buffer holding the current output) */
+    const StepChain *chain0;                /* the stream's state before step 0 */
+    StepChain *chain[2];
+    const uint8_t *prob_order, *prob_res;   /* getProbableFieldOrder() before the step's own push / getProbableResolution() after its pushes */
+    SLine *ws;                              /* QCAP lines per wave */
+    sdv_sample_pair *pairs; sdv_frame_asm *frasm; StepInfo *info;
+    uint32_t first_round;
+};
+
+struct FieldStitchStats { uint16_t index, valid, silent, unchecked, broken; };    /* frametrimset.h:278-300 */
+__device__ inline void stats_clear(FieldStitchStats &t) { t.index = t.valid = 0; t.silent = t.unchecked = t.broken = 0xFF; }
+__device__ inline bool stats_lt(const FieldStitchStats &a, const FieldStitchStats &b)   /* frametrimset.cpp:312-371 */
+{
+    if (a.broken != b.broken) return a.broken < b.broken;
+    if (a.valid != b.valid) return a.valid > b.valid;
+    if (a.unchecked != b.unchecked) return a.unchecked < b.unchecked;
+    if (a.silent != b.silent) return a.silent < b.silent;
+    return a.index < b.index;
+}
+/* the two smallest entries, which is all findPadding reads of the sorted array */
+__device__ inline void stats_best2(const FieldStitchStats *sd, int n, FieldStitchStats &s0, FieldStitchStats &s1)
+{
+    int i0 = 0;
+    for (int i = 1; i < n; i++) if (stats_lt(sd[i], sd[i0])) i0 = i;
+    int i1 = i0 == 0 ? 1 : 0;
+    for (int i = 0; i < n; i++) if (i != i0 && i != i1 && stats_lt(sd[i], sd[i1])) i1 = i;
+    s0 = sd[i0]; s1 = sd[i1];
+}
+
+enum { STG_TRY_PREVIOUS = 0, STG_TRY_TFF_TO_TFF, STG_TRY_BFF_TO_BFF, STG_A_PREPARE, STG_A_PAD_TFF, STG_A_PAD_BFF, STG_AB_UNK_PREPARE,
+       STG_AB_TFF_TO_TFF, STG_AB_TFF_TO_BFF, STG_AB_BFF_TO_BFF, STG_AB_BFF_TO_TFF, STG_PAD_NO_GOOD, STG_PAD_SILENCE, STG_PAD_OK, STG_PAD_MAX };
+
+struct Step {
+    Cfg cfg; RecSrc src; const FrameLocal *fl1, *fl2;
+    Frasm f0, f1, f2;
+    uint8_t last_pad_counter, broken_countdown, prob_order, prob_res, push_order;
+    bool file_start, file_end;
+    SLine *q; int qn;                       /* conv_queue */
+    int lane;
+
+    __device__ inline Field field(int frame, int parity) const
+    {
+        Field f; f.fl = frame == 1 ? fl1 : fl2; f.parity = parity; f.src = src;
+        const Frasm &fr = frame == 1 ? f1 : f2;
+        f.size = parity == 0 ? fr.odd_data_lines : fr.even_data_lines;
+        return f;
+    }
+    /* resolution a line was detected with (getDataBlockResolution's per-line lookup, :1290-1400) */
+    __device__ inline uint8_t line_res(uint32_t frame, uint16_t line) const
+    {
+        bool even = (line % 2) == 0;
+        if (frame == f2.frame_number) return even ? f2.even_resolution : f2.odd_resolution;
+        if (frame == f1.frame_number) return even ? f1.even_resolution : f1.odd_resolution;
+        if (frame == f0.frame_number) return even ? f0.even_resolution : f0.odd_resolution;
+        return SDV_RES_MODE_14BIT;
+    }
+    __device__ inline uint8_t block_res_mode(const SLine &first, const SLine &last) const
+    {
+        return res_mode_for_seam(line_res(first.frame, first.line), line_res(last.frame, last.line));
+    }
+
+    /* ---- tryPadding (:1417-1740) ---- */
+    __device__ inline uint8_t try_padding(const Field &fa, const Field &fb, uint16_t padding, FieldStitchStats *st)
+    {
+        if (fa.size > BUF_FIELD || fb.size > BUF_FIELD) return DS_NO_DATA;
+        PadQueue pq; pq.f1 = fa; pq.f2 = fb; pq.m2 = cfg.m2 != 0;
+        int keep = MIN_DEINT + ILV / 2 - (int)padding;
+        pq.a0 = fa.size > keep ? fa.size - keep : 0;
+        pq.n0 = fa.size - pq.a0;
+        pq.npad = padding;
+        if (fa.size > 0) { SLine l = fa.get(fa.size - 1); pq.pad_frame = l.frame; pq.pad_line0 = (uint16_t)(l.line + 2); }
+        else { pq.pad_frame = 0; pq.pad_line0 = 2; }
+        pq.n2 = fb.size > (MIN_DEINT + ILV / 2) ? (MIN_DEINT + ILV / 2) : fb.size;
+        const int n = pq.size();
+        if (n < MIN_DEINT) return DS_NO_DATA;
+        const uint8_t unchecked_lim = cfg.en_q ? cfg.max_unch_14 : cfg.max_unch_16;
+        uint8_t mode = SDV_RES_MODE_14BIT;
+        if (!cfg.m2) mode = n <= MIN_DEINT ? (uint8_t)SDV_RES_MODE_14BIT_AUTO : block_res_mode(pq.get(0), pq.get(MIN_DEINT));
+        const sdv_deint_settings ds = deint_cfg(mode, cfg.ignore_crc, true, cfg.en_p, cfg.en_q, false);
+        const int nblk = n - MIN_DEINT;
+        uint16_t valid_cnt = 0, silence_cnt = 0, uncheck_cnt = 0, broken_count = 0, valid_max = 0, silence_max = 0, uncheck_max = 0;
+        for (int c = 0; c * 64 < nblk; c++) {
+            int i = c * 64 + lane;
+            bool v = false, sl = false, u = false, br = false;
+            if (i < nblk) {
+                Block b;
+                sdvd::process_block(ds, pq, (size_t)i, b);
+                bool silent = blk_silent(b, cfg.m2), force = can_force_check(b);
+                v = blk_valid(b) && !silent && force;
+                sl = silent;
+                u = cfg.en_q ? (!force || b.audio_state == SDV_AUD_FIX_Q) : (b.audio_state == SDV_AUD_FIX_P);
+                br = b.audio_state == SDV_AUD_BROKEN;
+            }
+            uint64_t mv = __ballot(v), ms = __ballot(sl), mu = __ballot(u), mb = __ballot(br);
+            int cnt = nblk - c * 64; if (cnt > 64) cnt = 64;
+            for (int j = 0; j < cnt; j++) {
+                if ((mv >> j) & 1) valid_cnt++; else if (valid_cnt > valid_max) valid_max = valid_cnt;
+                if ((ms >> j) & 1) { silence_cnt++; if (silence_cnt >= MAX_BURST_SILENCE) valid_cnt = 0; }
+                else { if (silence_cnt > silence_max) silence_max = silence_cnt; silence_cnt = 0; }
+                if ((mu >> j) & 1) { uncheck_cnt++; if (uncheck_cnt >= unchecked_lim) valid_cnt = 0; }
+                else { if (uncheck_cnt > uncheck_max) uncheck_max = uncheck_cnt; uncheck_cnt = 0; }
+                if ((mb >> j) & 1) { broken_count++; if (broken_count >= MAX_BURST_BROKEN) valid_cnt = 0; }
+            }
+        }
+        if (valid_cnt > valid_max) valid_max = valid_cnt;
+        if (silence_cnt > silence_max) silence_max = silence_cnt;
+        if (uncheck_cnt > uncheck_max) uncheck_max = uncheck_cnt;
+        if (st) { st->index = padding; st->valid = valid_max; st->silent = silence_max; st->unchecked = uncheck_max; st->broken = broken_count; }
+        if (broken_count >= MAX_BURST_BROKEN) return DS_BROKE;
+        if (silence_max > MAX_BURST_SILENCE) return DS_SILENCE;
+        if (uncheck_max > unchecked_lim) return DS_NO_PAD;
+        if (valid_max == 0) return DS_NO_PAD;
+        return DS_OK;
+    }
+
+    /* ---- findPadding (:1743-2054) ---- */
+    __device__ inline uint8_t find_padding(const Field &fa, const Field &fb, uint8_t in_std, uint8_t in_resolution, uint16_t *padding)
+    {
+        uint8_t stitch_res = DS_NO_PAD;
+        uint16_t pad = (uint16_t)fa.size;
+        if (in_std == VID_PAL) *padding = pad > LINES_PF_PAL ? 0 : (uint16_t)(LINES_PF_PAL - pad);
+        else if (in_std == VID_NTSC) *padding = pad > LINES_PF_NTSC ? 0 : (uint16_t)(LINES_PF_NTSC - pad);
+        else *padding = 0;
+        int max_padding = MAX_PADDING_14BIT; uint8_t unchecked_lim = cfg.max_unch_14;
+        if (in_resolution == SDV_RES_16BIT || !cfg.en_q) { max_padding = MAX_PADDING_16BIT; unchecked_lim = cfg.max_unch_16; }
+        last_pad_counter = 0xFF;
+        if (cfg.en_p || cfg.en_q) {
+            FieldStitchStats sd[MAX_PADDING_14BIT], s0, s1;
+            for (int i = 0; i < max_padding; i++) stats_clear(sd[i]);
+            uint16_t min_broken = 0xFFFF; int no_brk_idx = 0;
+            for (int p = 0; p < max_padding; p++) {
+                try_padding(fa, fb, (uint16_t)p, &sd[p]);
+                if (min_broken > sd[p].broken) { min_broken = sd[p].broken; if (min_broken == 0) no_brk_idx = p; }
+                else if (min_broken == 0) {
+                    if (sd[no_brk_idx].valid > 0 && sd[no_brk_idx].unchecked < unchecked_lim && sd[p].broken > 0) break;
+                }
+            }
+            stats_best2(sd, max_padding, s0, s1);
+            last_pad_counter = (uint8_t)s0.broken;
+            if (s0.silent < MAX_BURST_SILENCE) {
+                if (s0.unchecked < unchecked_lim) {
+                    if (s0.broken < 2 && s0.broken < s1.broken) { stitch_res = DS_OK; *padding = s0.index; }
+                    else if ((((int16_t)s0.valid - (int16_t)s1.valid) > MAX_BURST_UNCH_DELTA) && s0.broken == 0) { stitch_res = DS_OK; *padding = s0.index; }
+                } else {
+                    for (int p = 0; p < max_padding; p++) { sd[p].broken = min_broken; if (sd[p].unchecked >= unchecked_lim) sd[p].broken = 0xFF; }
+                    stats_best2(sd, max_padding, s0, s1);
+                    if (s0.unchecked < unchecked_lim)
+                        if (((int16_t)s0.valid - (int16_t)s1.valid) > MAX_BURST_UNCH_DELTA) { stitch_res = DS_OK; *padding = s0.index; }
+                }
+            } else stitch_res = DS_SILENCE;
+        }
+        return stitch_res;
+    }
+
+    /* ---- detectAudioResolution (:2207-2763); the statistics pushes are replayed by the engine ---- */
+    __device__ static inline void set_pair(uint8_t known_res, uint8_t &known, uint8_t &other)
+    {
+        if (known_res == SRES_16BIT) { known = SDV_RES_MODE_16BIT; other = SDV_RES_MODE_16BIT_AUTO; }
+        else { known = SDV_RES_MODE_14BIT; other = SDV_RES_MODE_14BIT_AUTO; }
+    }
+    __device__ inline void detect_audio_resolution()
+    {
+        if (cfg.m2) { f1.odd_resolution = f1.even_resolution = f2.odd_resolution = f2.even_resolution = SDV_RES_MODE_14BIT; return; }
+        const uint8_t f1o = fl1->field_res[0], f1e = fl1->field_res[1], f2o = fl2->field_res[0], f2e = fl2->field_res[1];
+        const uint8_t prob_mode = prob_res == SRES_16BIT ? SDV_RES_MODE_16BIT_AUTO : SDV_RES_MODE_14BIT_AUTO;
+        if (f1o == SRES_UNKNOWN && f1e == SRES_UNKNOWN) {
+            if (f2o == SRES_UNKNOWN && f2e == SRES_UNKNOWN) f1.odd_resolution = f1.even_resolution = f2.odd_resolution = f2.even_resolution = prob_mode;
+            else if (f2o == SRES_UNKNOWN) {
+                if (f2e == SRES_16BIT) { f2.even_resolution = SDV_RES_MODE_16BIT; f1.odd_resolution = f1.even_resolution = f2.odd_resolution = SDV_RES_MODE_16BIT_AUTO; }
+                else { f2.even_resolution = SDV_RES_MODE_14BIT; f1.odd_resolution = f1.even_resolution = f2.odd_resolution = SDV_RES_MODE_14BIT_AUTO; }
+            } else if (f2e == SRES_UNKNOWN) {
+                if (f2o == SRES_16BIT) { f2.odd_resolution = SDV_RES_MODE_16BIT; f1.odd_resolution = f1.even_resolution = f2.even_resolution = SDV_RES_MODE_16BIT_AUTO; }
+                else { f2.odd_resolution = SDV_RES_MODE_14BIT; f1.odd_resolution = f1.even_resolution = f2.even_resolution = SDV_RES_MODE_14BIT_AUTO; }
+            } else if (f2o == f2e && f2o == SRES_16BIT) { f2.odd_resolution = f2.even_resolution = SDV_RES_MODE_16BIT; f1.odd_resolution = f1.even_resolution = SDV_RES_MODE_16BIT_AUTO; }
+            else {
+                f2.odd_resolution = f2o == SRES_16BIT ? SDV_RES_MODE_16BIT : SDV_RES_MODE_14BIT;
+                f2.even_resolution = f2e == SRES_16BIT ? SDV_RES_MODE_16BIT : SDV_RES_MODE_14BIT;
+                f1.odd_resolution = f1.even_resolution = SDV_RES_MODE_14BIT_AUTO;
+            }
+        } else {
+            if (f1o == SRES_UNKNOWN) set_pair(f1e, f1.even_resolution, f1.odd_resolution);
+            else if (f1e == SRES_UNKNOWN) set_pair(f1o, f1.odd_resolution, f1.even_resolution);
+            else {
+                f1.odd_resolution = f1o == SRES_16BIT ? SDV_RES_MODE_16BIT : SDV_RES_MODE_14BIT;
+                f1.even_resolution = f1e == SRES_16BIT ? SDV_RES_MODE_16BIT : SDV_RES_MODE_14BIT;
+            }
+            if (f2o == SRES_UNKNOWN && f2e == SRES_UNKNOWN) f2.odd_resolution = f2.even_resolution = prob_mode;
+            else if (f2o == SRES_UNKNOWN) set_pair(f2e, f2.even_resolution, f2.odd_resolution);
+            else if (f2e == SRES_UNKNOWN) set_pair(f2o, f2.odd_resolution, f2.even_resolution);
+            else {
+                f2.odd_resolution = f2o == SRES_16BIT ? SDV_RES_MODE_16BIT : SDV_RES_MODE_14BIT;
+                f2.even_resolution = f2e == SRES_16BIT ? SDV_RES_MODE_16BIT : SDV_RES_MODE_14BIT;
+            }
+        }
+    }
+
+    /* ---- detectVideoStandard (:2773-2925) ---- */
+    __device__ inline void detect_video_standard()
+    {
+        f1.video_standard = VID_UNKNOWN; f1.odd_std_lines = f1.even_std_lines = 0;
+        if (cfg.preset_video_mode == VID_UNKNOWN) {
+            f1.vid_std_preset = 0;
+            uint16_t a = f1.odd_data_lines, b = f1.even_data_lines, c = f2.odd_data_lines, d = f2.even_data_lines;
+            if (a > LINES_PF_MAX_PAL || b > LINES_PF_MAX_PAL || c > LINES_PF_MAX_PAL || d > LINES_PF_MAX_PAL) f1.video_standard = VID_UNKNOWN;
+            else if (a > LINES_PF_MAX_NTSC || b > LINES_PF_MAX_NTSC || c > LINES_PF_MAX_NTSC || d > LINES_PF_MAX_NTSC) f1.video_standard = VID_PAL;
+            else f1.video_standard = fl1->max_line <= ((LINES_PF_PAL - ILV) * 2) ? VID_NTSC : VID_PAL;
+        } else { f1.vid_std_preset = 1; f1.video_standard = cfg.preset_video_mode; }
+        if (f1.video_standard == VID_UNKNOWN) f1.video_standard = f0.video_standard;
+        if (f1.video_standard == VID_NTSC) f1.odd_std_lines = f1.even_std_lines = LINES_PF_NTSC;
+        else if (f1.video_standard == VID_PAL) f1.odd_std_lines = f1.even_std_lines = LINES_PF_PAL;
+        if (cfg.preset_field_order == ORDER_TFF) { preset_order(f1, ORDER_TFF); preset_order(f2, ORDER_TFF); }
+        else if (cfg.preset_field_order == ORDER_BFF) { preset_order(f1, ORDER_BFF); preset_order(f2, ORDER_BFF); }
+        else { f2.order_preset = 0; set_order_unknown(f2); }
+    }
+
+    /* ---- findFieldStitching (:2929-4275) ---- */
+    __device__ inline void find_field_stitching()
+    {
+        bool en_sw_order = true;
+        uint8_t proc_state = STG_TRY_PREVIOUS, stage_count = 0, stitch_resolution, f_res;
+        detect_audio_resolution();
+        detect_video_standard();
+        const Field f1o = field(1, 0), f1e = field(1, 1), f2o = field(2, 0), f2e = field(2, 1);
+        for (;;) {
+            stage_count++;
+            if (proc_state == STG_TRY_PREVIOUS) {
+                proc_state = STG_A_PREPARE;
+                if (f0.odd_data_lines == f1.odd_data_lines && f0.even_data_lines == f1.even_data_lines && f0.inner_padding_ok && f0.outer_padding_ok) {
+                    if (!f1.order_preset || f0.field_order == f1.field_order) {
+                        f1.inner_silence = f1.outer_silence = f2.inner_silence = f2.outer_silence = 1;
+                        f2.inner_padding_ok = f2.outer_padding_ok = 0; f2.inner_padding = f2.outer_padding = 0;
+                        if (f1.odd_data_lines < MIN_FILL_LINES_PF && f1.even_data_lines < MIN_FILL_LINES_PF) {
+                            set_order_unknown(f1);
+                            f1.inner_padding_ok = f1.outer_padding_ok = 0; f1.inner_padding = f1.outer_padding = 0;
+                            proc_state = STG_PAD_NO_GOOD;
+                        } else {
+                            f_res = DS_NO_PAD;
+                            if (f0.field_order == ORDER_TFF) f_res = try_padding(f1o, f1e, f0.inner_padding, NULL);
+                            else if (f0.field_order == ORDER_BFF) f_res = try_padding(f1e, f1o, f0.inner_padding, NULL);
+                            if (f_res == DS_OK) {
+                                if (!f1.vid_std_preset && f0.video_standard < VID_MAX) f1.video_standard = f0.video_standard;
+                                f1.field_order = f0.field_order;
+                                f1.inner_padding = f0.inner_padding; f1.inner_padding_ok = 1; f1.inner_silence = 0;
+                                if (f1.field_order == ORDER_TFF) { f1.tff_cnt = last_pad_counter; proc_state = STG_TRY_TFF_TO_TFF; }
+                                else { f1.bff_cnt = last_pad_counter; proc_state = STG_TRY_BFF_TO_BFF; }
+                            }
+                        }
+                    }
+                }
+            } else if (proc_state == STG_TRY_TFF_TO_TFF) {
+                f_res = DS_NO_PAD;
+                if (f2.odd_data_lines >= MIN_FILL_LINES_PF) f_res = try_padding(f1e, f2o, f0.outer_padding, NULL);
+                if (f_res == DS_OK) { f1.outer_padding = f0.outer_padding; f1.outer_padding_ok = 1; set_order(f2, ORDER_TFF); f1.outer_silence = 0; proc_state = STG_PAD_OK; }
+                else { proc_state = STG_AB_TFF_TO_TFF; en_sw_order = false; }
+            } else if (proc_state == STG_TRY_BFF_TO_BFF) {
+                f_res = DS_NO_PAD;
+                if (f2.even_data_lines >= MIN_FILL_LINES_PF) f_res = try_padding(f1o, f2e, f0.outer_padding, NULL);
+                if (f_res == DS_OK) { f1.outer_padding = f0.outer_padding; f1.outer_padding_ok = 1; set_order(f2, ORDER_BFF); f1.outer_silence = 0; proc_state = STG_PAD_OK; }
+                else { proc_state = STG_AB_BFF_TO_BFF; en_sw_order = false; }
+            } else if (proc_state == STG_A_PREPARE) {
+                f1.inner_padding_ok = f1.outer_padding_ok = 0; f1.inner_padding = f1.outer_padding = 0; f1.tff_cnt = f1.bff_cnt = 0;
+                if (f1.odd_data_lines < MIN_FILL_LINES_PF && f1.even_data_lines < MIN_FILL_LINES_PF) {
+                    if (!f1.order_preset) set_order_unknown(f1);
+                    proc_state = STG_PAD_NO_GOOD;
+                } else if (f1.even_data_lines < MIN_FILL_LINES_PF) {
+                    if (f1.field_order == ORDER_TFF) { f1.outer_padding_ok = 0; f1.outer_padding = 0; proc_state = STG_PAD_NO_GOOD; }
+                    else { proc_state = STG_AB_BFF_TO_BFF; en_sw_order = false; }
+                } else if (f1.odd_data_lines < MIN_FILL_LINES_PF) {
+                    if (f1.field_order == ORDER_BFF) { f1.outer_padding_ok = 0; f1.outer_padding = 0; proc_state = STG_PAD_NO_GOOD; }
+                    else { proc_state = STG_AB_TFF_TO_TFF; en_sw_order = false; }
+                } else {
+                    if (f1.field_order == ORDER_BFF) { proc_state = STG_A_PAD_BFF; en_sw_order = false; }
+                    else if (f1.field_order == ORDER_TFF) { proc_state = STG_A_PAD_TFF; en_sw_order = false; }
+                    else { proc_state = prob_order == ORDER_BFF ? STG_A_PAD_BFF : STG_A_PAD_TFF; en_sw_order = true; }
+                }
+            } else if (proc_state == STG_A_PAD_TFF || proc_state == STG_A_PAD_BFF) {
+                const bool tff = proc_state == STG_A_PAD_TFF;
+                f1.inner_padding = 0;
+                if (tff) {
+                    stitch_resolution = res_for_seam(f1.odd_resolution, f1.even_resolution);
+                    f_res = find_padding(f1o, f1e, f1.video_standard, stitch_resolution, &f1.inner_padding);
+                    f1.tff_cnt = last_pad_counter;
+                } else {
+                    stitch_resolution = res_for_seam(f1.even_resolution, f1.odd_resolution);
+                    f_res = find_padding(f1e, f1o, f1.video_standard, stitch_resolution, &f1.inner_padding);
+                    f1.bff_cnt = last_pad_counter;
+                }
+                f1.inner_silence = 0;
+                if (f_res == DS_OK) {
+                    set_order(f1, tff ? ORDER_TFF : ORDER_BFF);
+                    f1.inner_padding_ok = 1;
+                    proc_state = tff ? STG_AB_TFF_TO_TFF : STG_AB_BFF_TO_BFF; en_sw_order = false;
+                } else if (f_res == DS_SILENCE) {
+                    f1.inner_silence = 1; f1.outer_silence = 1; f1.inner_padding_ok = 0; f1.inner_padding = 0;
+                    proc_state = STG_PAD_SILENCE;
+                } else {
+                    f1.inner_padding = 0;
+                    if ((tff && f1.field_order == ORDER_TFF) || (!tff && f1.field_order == ORDER_BFF)) {
+                        f1.inner_padding_ok = 0;
+                        proc_state = tff ? STG_AB_TFF_TO_TFF : STG_AB_BFF_TO_BFF; en_sw_order = false;
+                    } else if (en_sw_order) { proc_state = tff ? STG_A_PAD_BFF : STG_A_PAD_TFF; en_sw_order = false; }
+                    else proc_state = STG_AB_UNK_PREPARE;
+                }
+            } else if (proc_state == STG_AB_UNK_PREPARE) {
+                f1.inner_padding = 0; f1.inner_padding_ok = 0; set_order_unknown(f1);
+                proc_state = prob_order == ORDER_BFF ? STG_AB_BFF_TO_BFF : STG_AB_TFF_TO_TFF;
+                en_sw_order = true;
+            } else if (proc_state == STG_AB_TFF_TO_TFF || proc_state == STG_AB_BFF_TO_BFF) {
+                const bool tt = proc_state == STG_AB_TFF_TO_TFF;
+                const uint16_t need = tt ? f2.odd_data_lines : f2.even_data_lines, other = tt ? f2.even_data_lines : f2.odd_data_lines;
+                if (f2.odd_data_lines < MIN_FILL_LINES_PF && f2.even_data_lines < MIN_FILL_LINES_PF) {
+                    f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0; proc_state = STG_PAD_NO_GOOD;
+                } else if (need < MIN_FILL_LINES_PF) {
+                    if (!f1.order_preset) proc_state = tt ? STG_AB_TFF_TO_BFF : STG_AB_BFF_TO_TFF;
+                    else { f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0; proc_state = STG_PAD_NO_GOOD; }
+                } else {
+                    if (tt) {
+                        stitch_resolution = res_for_seam(f1.even_resolution, f2.odd_resolution);
+                        f_res = find_padding(f1e, f2o, f1.video_standard, stitch_resolution, &f1.outer_padding);
+                    } else {
+                        stitch_resolution = res_for_seam(f1.odd_resolution, f2.even_resolution);
+                        f_res = find_padding(f1o, f2e, f1.video_standard, stitch_resolution, &f1.outer_padding);
+                    }
+                    f1.outer_silence = 0;
+                    if (f_res == DS_OK) {
+                        f1.outer_padding_ok = 1;
+                        set_order(f2, tt ? ORDER_TFF : ORDER_BFF);
+                        proc_state = STG_PAD_OK;
+                        if (!order_set(f1)) set_order(f1, tt ? ORDER_TFF : ORDER_BFF);
+                        else if ((tt && f1.field_order == ORDER_BFF) || (!tt && f1.field_order == ORDER_TFF)) { f1.outer_padding_ok = 0; proc_state = STG_PAD_NO_GOOD; }
+                    } else if (f_res == DS_SILENCE) {
+                        f1.outer_silence = 1; f1.outer_padding = 0; f1.outer_padding_ok = 0; proc_state = STG_PAD_SILENCE;
+                    } else {
+                        if (other < MIN_FILL_LINES_PF) { f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0; proc_state = STG_PAD_NO_GOOD; }
+                        else if (!f1.order_preset) proc_state = tt ? STG_AB_TFF_TO_BFF : STG_AB_BFF_TO_TFF;
+                        else { f1.outer_padding = 0; f1.outer_padding_ok = 0; proc_state = STG_PAD_NO_GOOD; }
+                    }
+                }
+            } else if (proc_state == STG_AB_TFF_TO_BFF || proc_state == STG_AB_BFF_TO_TFF) {
+                const bool tb = proc_state == STG_AB_TFF_TO_BFF;
+                if (tb) {
+                    stitch_resolution = res_for_seam(f1.even_resolution, f2.even_resolution);
+                    f_res = find_padding(f1e, f2e, f1.video_standard, stitch_resolution, &f1.outer_padding);
+                } else {
+                    stitch_resolution = res_for_seam(f1.odd_resolution, f2.odd_resolution);
+                    f_res = find_padding(f1o, f2o, f1.video_standard, stitch_resolution, &f1.outer_padding);
+                }
+                f1.outer_silence = 0;
+                if (f_res == DS_OK) {
+                    f1.outer_padding_ok = 1;
+                    set_order(f2, tb ? ORDER_BFF : ORDER_TFF);
+                    proc_state = STG_PAD_OK;
+                    if (!order_set(f1)) set_order(f1, tb ? ORDER_TFF : ORDER_BFF);
+                    else if ((tb && f1.field_order == ORDER_BFF) || (!tb && f1.field_order == ORDER_TFF)) { f1.outer_padding_ok = 0; proc_state = STG_PAD_NO_GOOD; }
+                } else if (f_res == DS_SILENCE) {
+                    f1.outer_silence = 1; f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0; proc_state = STG_PAD_SILENCE;
+                } else {
+                    f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0;
+                    if (en_sw_order && f1.even_data_lines >= MIN_FILL_LINES_PF) { proc_state = tb ? STG_AB_BFF_TO_BFF : STG_AB_TFF_TO_TFF; en_sw_order = false; }
+                    else proc_state = STG_PAD_NO_GOOD;
+                }
+            } else break;
+            if (stage_count > STG_PAD_MAX) break;
+        }
+    }
+
+    /* ---- getAssemblyFieldOrder (:4278-4380) ---- */
+    __device__ inline uint8_t get_assembly_field_order()
+    {
+        uint8_t cur = ORDER_UNK;
+        if (order_set(f1)) { cur = f1.field_order; if (!f1.order_preset) push_order = cur; }
+        else {
+            if (f2.order_preset && order_set(f2)) cur = f2.field_order;
+            else if (order_set(f0) && f0.outer_padding_ok) cur = f0.field_order;
+        }
+        if (cur != ORDER_TFF && cur != ORDER_BFF) {
+            if (prob_order == ORDER_TFF || prob_order == ORDER_BFF) cur = prob_order;
+            else if (f1.tff_cnt < f1.bff_cnt) cur = ORDER_TFF;
+            else if (f1.tff_cnt > f1.bff_cnt) cur = ORDER_BFF;
+            else cur = ORDER_TFF;
+        }
+        if (!order_set(f1)) { f1.field_order = cur; if (!f1.order_preset) f1.order_guessed = 1; }
+        return cur;
+    }
+
+    /* ---- conv_queue writers (addLinesFromField :4452-4518, addFieldPadding :4521-4571) ---- */
+    __device__ inline uint16_t add_lines(const Field &f, uint16_t start, uint16_t count, uint16_t &last_line)
+    {
+        if (!(BUF_FIELD >= (int)start && BUF_FIELD >= (int)start + (int)count)) return 0;
+        for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) q[qn + i] = f.get(start + i);
+        if (count > 0) last_line = (uint16_t)(f.get(start + count - 1).line + 2);
+        qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; }
+        return count;
+    }
+    __device__ inline uint16_t add_padding(uint32_t frame, uint16_t count, uint16_t &last_line)
+    {
+        for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) q[qn + i] = sline_empty(frame, (uint16_t)(last_line + 2 * i));
+        last_line = (uint16_t)(last_line + 2 * count);
+        qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; }
+        return count;
+    }
+    bool overflow;
+
+    /* ---- fillFrameForOutput (:4588-5387) ---- */
+    __device__ inline void fill_frame_for_output()
+    {
+        uint16_t c1, c2, last_line = 0, lines_to_fill = 0, added_inner = 0, added_outer = 0;
+        const uint8_t order = get_assembly_field_order();
+        Field p1, p2;
+        if (order == ORDER_TFF) {
+            p1 = field(1, 0); p2 = field(1, 1);
+            if (order_set(f0) && f0.field_order != ORDER_TFF) f0.outer_padding_ok = 0;
+        } else {
+            p1 = field(1, 1); p2 = field(1, 0);
+            if (order_set(f0) && f0.field_order != ORDER_BFF) f0.outer_padding_ok = 0;
+        }
+        c1 = (uint16_t)p1.size; c2 = (uint16_t)p2.size;
+        const int target = f1.video_standard == VID_PAL ? LINES_PF_PAL : LINES_PF_NTSC;
+        if (c1 > target) c1 = (uint16_t)target;
+        if (c2 > target) c2 = (uint16_t)target;
+        const bool insert_top_line = cfg.fix_cut_above != 0;
+        const uint32_t fr = f1.frame_number;
+        const uint16_t first_ln = order == ORDER_TFF ? 1 : 2, second_ln = order == ORDER_TFF ? 2 : 1;
+#define FIRST()  (last_line = first_ln)
+#define SECOND() (last_line = second_ln)
+#define LINES(p, st, cnt) add_lines((p), (uint16_t)(st), (uint16_t)(cnt), last_line)
+#define PAD(cnt) add_padding(fr, (uint16_t)(cnt), last_line)
+        if (file_start) {
+            f0.frame_number = 0;
+            f0.even_resolution = f0.odd_resolution = order == ORDER_TFF ? f1.odd_resolution : f1.even_resolution;
+            last_line = f1.video_standard == VID_PAL ? LINES_PF_PAL : LINES_PF_NTSC;
+            const uint8_t add_count = 80;             /* STC007DataBlock::LINE_R2 */
+            last_line = (uint16_t)((last_line * 2) - (add_count * 2));
+            add_padding(0, add_count, last_line);
+            last_line = 0;
+        }
+        if (f0.outer_padding_ok) {
+            if (f1.inner_padding_ok) {
+                if (f1.outer_padding_ok) {
+                    lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding + f1.outer_padding);
+                    if ((target * 2) == lines_to_fill) {
+                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                        SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                    } else if ((target * 2) > lines_to_fill) {
+                        lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                        SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding); added_outer = (uint16_t)(added_outer + PAD(lines_to_fill));
+                        f1.outer_padding_ok = 0; set_order_unknown(f2);
+                    } else {
+                        lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding);
+                        if ((target * 2) >= lines_to_fill) {
+                            lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                            FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                            SECOND(); LINES(p2, 0, c2); added_outer = PAD(lines_to_fill);
+                        } else {
+                            lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                            FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                            SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                        }
+                        f1.outer_padding_ok = 0; set_order_unknown(f2);
+                    }
+                } else {
+                    lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding);
+                    if ((target * 2) >= lines_to_fill) {
+                        lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                        SECOND(); LINES(p2, 0, c2); added_outer = PAD(lines_to_fill);
+                    } else {
+                        lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                        SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                    }
+                }
+            } else if (f1.outer_padding_ok) {
+                lines_to_fill = (uint16_t)(c1 + c2 + f1.outer_padding);
+                if ((target * 2) >= lines_to_fill) {
+                    lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(lines_to_fill);
+                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                } else {
+                    lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                    FIRST(); LINES(p1, 0, c1);
+                    SECOND(); LINES(p2, lines_to_fill, c2 - lines_to_fill); added_outer = PAD(f1.outer_padding);
+                }
+            } else {
+                lines_to_fill = (uint16_t)(c1 + c2);
+                if ((target * 2) >= lines_to_fill) {
+                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(target - c1);
+                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(target - c2);
+                } else {
+                    lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                    FIRST(); LINES(p1, 0, c1);
+                    SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                }
+            }
+        } else if (f1.inner_padding_ok) {
+            if (f1.outer_padding_ok) {
+                lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding + f1.outer_padding);
+                if ((target * 2) >= lines_to_fill) {
+                    lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                    FIRST(); added_inner = PAD(lines_to_fill); LINES(p1, 0, c1); added_inner = (uint16_t)(added_inner + PAD(f1.inner_padding));
+                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                } else {
+                    lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                    FIRST(); LINES(p1, lines_to_fill, c1 - lines_to_fill); added_inner = PAD(f1.inner_padding);
+                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                }
+            } else {
+                lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding);
+                if ((target * 2) >= lines_to_fill) {
+                    lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(lines_to_fill);
+                } else {
+                    lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
+                    SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                }
+            }
+        } else if (f1.outer_padding_ok) {
+            lines_to_fill = (uint16_t)(c1 + c2 + f1.outer_padding);
+            if ((target * 2) >= lines_to_fill) {
+                lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
+                FIRST(); LINES(p1, 0, c1); added_inner = PAD(lines_to_fill);
+                SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+            } else {
+                lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
+                FIRST(); LINES(p1, 0, c1 - lines_to_fill);
+                SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+            }
+        } else {
+            lines_to_fill = (uint16_t)(c1 + c2);
+            if ((target * 2) >= lines_to_fill) {
+                FIRST();
+                if (insert_top_line && c1 > 0 && c2 > 0) {
+                    if (order == ORDER_BFF) {
+                        added_outer = PAD(1); LINES(p1, 0, c1); c1++; added_inner = PAD(target - c1);
+                        SECOND(); LINES(p2, 0, c2); added_outer = (uint16_t)(added_outer + PAD(target - c2));
+                    } else {
+                        LINES(p1, 0, c1); added_inner = PAD(target - c1 + 1);
+                        SECOND(); LINES(p2, 0, c2); c2++; added_outer = PAD(target - c2);
+                    }
+                } else {
+                    LINES(p1, 0, c1); added_inner = PAD(target - c1);
+                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(target - c2);
+                }
+            } else {
+                FIRST();
+                if (c1 < target) { LINES(p1, 0, c1); added_inner = PAD(target - c1); } else LINES(p1, 0, target);
+                SECOND();
+                if (c2 < target) { LINES(p2, 0, c2); added_outer = PAD(target - c2); } else LINES(p2, 0, target);
+            }
+        }
+#undef FIRST
+#undef SECOND
+#undef LINES
+#undef PAD
+        if (file_end) { last_line = 1; add_padding(f2.frame_number, MIN_DEINT, last_line); }
+        f1.inner_padding = added_inner;
+        f1.outer_padding = added_outer;
+    }
+
+    /* ---- CWD pre-scan (prescanFrame :6401-6452, performCWD :5905-6398) ---- */
+    __device__ inline uint8_t queue_res_mode() const      /* getDataBlockResolution(queue, 0) */
+    {
+        if (cfg.m2) return SDV_RES_MODE_14BIT;
+        if (qn <= MIN_DEINT) return SDV_RES_MODE_14BIT_AUTO;
+        return block_res_mode(q[0], q[MIN_DEINT]);
+    }
+    __device__ static inline void cwd_after_patch(SLine &l, bool &fixed)
+    {
+        if (crc_valid_if(l)) { l.wvalid = 0x1FF; fixed = true; }
+    }
+    __device__ inline bool perform_cwd()
+    {
+        const sdv_deint_settings ds = deint_cfg(queue_res_mode(), cfg.ignore_crc, !cfg.ignore_crc, cfg.en_p, cfg.en_q, true);
+        const int nblk = qn - MIN_DEINT;
+        bool fixed_any = false;
+        WsSrc src; src.q = q;
+        if (lane < ILV) {
+            for (int ofs = lane; ofs < nblk; ofs += ILV) {
+                if (!cfg.ignore_crc) {
+                    /* nothing to learn from a block whose eight lines all passed their CRC */
+                    bool all_ok = true;
+                    for (int k = 0; k < 8; k++) { const SLine &l = q[ofs + ILV * k]; all_ok = all_ok && !(l.flags & SL_FORCED_BAD) && ((l.wcrc & 0xFF) == 0xFF); }
+                    if (all_ok) continue;
+                }
+                Block b;
+                sdvd::process_block(ds, src, (size_t)ofs, b);
+                const int max_fixable = (!cfg.en_q || b.resolution == SDV_RES_16BIT) ? sdvd::WORD_P0 : sdvd::WORD_Q0;
+                const bool data_fixed = (~b.line_crc & b.word_valid & 0xFF) != 0;          /* isDataFixed, stc007datablock.cpp:371-384 */
+                if (!(blk_valid(b) && data_fixed)) continue;
+                for (int wi = 0; wi <= max_fixable; wi++) {
+                    if (sdvd::bit(b.line_crc, wi)) continue;
+                    SLine l = q[ofs + ILV * wi];
+                    const bool forced = (l.flags & SL_FORCED_BAD) != 0;
+                    if (!crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced && l.frame != f2.frame_number) {
+                        const uint16_t wbit = (uint16_t)(1u << wi);
+                        if (b.resolution == SDV_RES_14BIT) {
+                            if (l.words[wi] != b.words[wi]) {
+                                l.words[wi] = (uint16_t)(b.words[wi] & 0x3FFF);      /* setWord keeps the word's CRC flag */
+                                l.calc_crc = crc_words(l.words);
+                                l.wvalid |= wbit;
+                                cwd_after_patch(l, fixed_any);
+                            } else l.wvalid |= wbit;
+                            if (!crc_valid_if(l)) {
+                                if ((l.wvalid & 0xFF) == 0xFF) { l.calc_crc = crc_words(l.words); l.words[8] = l.calc_crc; l.wvalid |= 0x100; fixed_any = true; }
+                            }
+                        } else {
+                            const int s_ofs[7] = { 12, 10, 8, 6, 4, 2, 0 };
+                            const uint16_t old_word = l.words[wi];
+                            uint16_t old_bitword = l.words[7], new_word = b.words[wi], new_bitword = (uint16_t)(new_word & 3);
+                            new_word = (uint16_t)(new_word >> 2);
+                            const int ofs_b = s_ofs[wi];
+                            new_bitword = (uint16_t)(new_bitword << ofs_b);
+                            old_bitword = (uint16_t)(old_bitword & (3 << ofs_b));
+                            if (old_word != new_word) {
+                                /* setWord(index, word, isWordCRCOk(index)) also rewrites word_valid with the CRC flag (stc007line.cpp:158-173) */
+                                const bool wc = !forced && (l.wcrc & wbit);
+                                l.words[wi] = (uint16_t)(new_word & 0x3FFF);
+                                l.wcrc = wc ? (l.wcrc | wbit) : (l.wcrc & ~wbit);
+                                l.calc_crc = crc_words(l.words);
+                                l.wvalid |= wbit;
+                                cwd_after_patch(l, fixed_any);
+                            }
+                            if (!crc_valid_if(l)) {
+                                if (old_bitword != new_bitword) {
+                                    old_bitword = (uint16_t)(l.words[7] & ~(3 << ofs_b));
+                                    const bool qc = !forced && (l.wcrc & 0x80);
+                                    l.words[7] = (uint16_t)((old_bitword | new_bitword) & 0x3FFF);
+                                    l.wcrc = qc ? (l.wcrc | 0x80) : (l.wcrc & ~0x80);
+                                    l.wvalid = qc ? (l.wvalid | 0x80) : (l.wvalid & ~0x80);
+                                    l.calc_crc = crc_words(l.words);
+                                    cwd_after_patch(l, fixed_any);
+                                }
+                            }
+                        }
+                        q[ofs + ILV * wi] = l;
+                    } else if (crc_valid(l)) {
+                        if (b.resolution == SDV_RES_14BIT && l.words[wi] != b.words[wi]) { l.flags |= SL_FORCED_BAD; q[ofs + ILV * wi] = l; }
+                    }
+                }
+            }
+        }
+        return __ballot(fixed_any) != 0;
+    }
+    __device__ inline void prescan_frame()
+    {
+        if (!cfg.en_cwd) return;
+        bool next = false;
+        if (f1.outer_padding_ok && order_set(f1)) {                   /* fillNextFieldForCWD :5390-5456 */
+            uint16_t last_line = f1.field_order == ORDER_TFF ? 1 : 2;
+            Field p = f1.field_order == ORDER_TFF ? field(2, 0) : field(2, 1);
+            uint16_t cnt = (uint16_t)p.size;
+            if (cnt > MIN_DEINT) cnt = MIN_DEINT;
+            add_lines(p, 0, cnt, last_line);
+            next = true;
+        }
+        __syncthreads();
+        for (;;) { bool more = perform_cwd(); __syncthreads(); if (!more) break; }
+        if (next) while (qn > 0 && q[qn - 1].frame == f2.frame_number) qn--;      /* removeNextFieldAfterCWD */
+    }
+
+    /* ---- performDeinterleave (:6675-6885) + outputSamplePair (:6525-6569) ---- */
+    sdv_sample_pair *out_pairs; uint32_t n_pairs;
+    __device__ static inline sdv_sample_pair service_pair(uint8_t srv)
+    {
+        sdv_sample_pair p;
+        p.audio_word[0] = p.audio_word[1] = 0; p.sample_flags[0] = p.sample_flags[1] = 0; p.sample_rate = 44056; p.emphasis = 0; p.service_type = srv; p._pad = 0;
+        return p;
+    }
+    __device__ inline sdv_sample_pair make_pair(const Block &b, int il, int ir, uint16_t rate) const
+    {
+        sdv_sample_pair p = service_pair(SDV_PAIR_SRV_NO);
+        if (rate < 44101) p.sample_rate = rate;
+        bool block_state = false, wl = false, wr = false, fl = false, fr = false;
+        if (b.audio_state != SDV_AUD_BROKEN) {
+            block_state = blk_valid(b);
+            if (block_state) { fl = sdvd::bit(b.line_crc, il); fr = sdvd::bit(b.line_crc, ir); }
+            wl = sdvd::bit(b.word_valid, il); wr = sdvd::bit(b.word_valid, ir);
+        }
+        p.audio_word[0] = get_sample(b, il, cfg.m2); p.audio_word[1] = get_sample(b, ir, cfg.m2);
+        p.sample_flags[0] = (uint8_t)((block_state ? SDV_SF_BLOCK_OK : 0) | (wl ? SDV_SF_WORD_VALID : 0) | (fl ? SDV_SF_WORD_FIXED : 0));
+        p.sample_flags[1] = (uint8_t)((block_state ? SDV_SF_BLOCK_OK : 0) | (wr ? SDV_SF_WORD_VALID : 0) | (fr ? SDV_SF_WORD_FIXED : 0));
+        return p;
+    }
+    __device__ inline void perform_deinterleave()
+    {
+        const int nblk = qn > MIN_DEINT ? qn - MIN_DEINT : 0;
+        WsSrc src; src.q = q;
+        uint16_t rate = (cfg.preset_sample_rate == 44100 || cfg.preset_sample_rate == 44056) ? cfg.preset_sample_rate
+                        : (f1.video_standard == VID_NTSC ? (uint16_t)44056 : (uint16_t)44100);        /* setBlockSampleRate :6455-6480 */
+        uint8_t cd = broken_countdown;
+        uint32_t fix_p = 0, fix_q = 0, fix_cwd = 0, drop = 0, sdrop = 0, brk_field = 0;
+        for (int c = 0; c * 64 < nblk; c++) {
+            const int i = c * 64 + lane;
+            const bool act = i < nblk;
+            Block b; sdvd::blk_clear(b);
+            bool ns = false, seam = false, brk = false;
+            if (act) {
+                uint8_t mode = cfg.m2 ? (uint8_t)SDV_RES_MODE_14BIT : block_res_mode(q[i], q[i + MIN_DEINT]);
+                sdvd::process_block(deint_cfg(mode, cfg.ignore_crc, !cfg.ignore_crc, cfg.en_p, cfg.en_q, cfg.en_cwd), src, (size_t)i, b);
+                ns = !blk_silent(b, cfg.m2);
+                if (ns && cfg.mask_seams) {
+                    if (!f1.inner_padding_ok && !f1.inner_silence)
+                        if (b.w_line[0] > b.w_line[7] && b.w_frame[0] == f1.frame_number && b.w_frame[0] == b.w_frame[7]) seam = true;
+                    if (!f0.outer_padding_ok && !f0.outer_silence)
+                        if (b.w_frame[0] != b.w_frame[7] && b.w_frame[0] == f0.frame_number && b.w_frame[7] == f1.frame_number) seam = true;
+                }
+                brk = b.audio_state == SDV_AUD_BROKEN;
+                if (seam) mark_unsafe(b);
+            }
+            const uint64_t m_ns = __ballot(ns), m_seam = __ballot(seam), m_brk = __ballot(brk);
+            uint64_t m_cd = 0;
+            int cnt = nblk - c * 64; if (cnt > 64) cnt = 64;
+            for (int j = 0; j < cnt; j++) {
+                if (((m_ns >> j) & 1) && !((m_seam >> j) & 1)) {
+                    if (cfg.broken_mask_dur > 0 && cd == 0 && ((m_brk >> j) & 1)) cd = cfg.broken_mask_dur;
+                    if (cd != 0) m_cd |= 1ull << j;
+                }
+                if (cd > 0) cd--;
+            }
+            bool rep = false, valid = false;
+            int errs = 0;
+            if (act) {
+                if ((m_cd >> lane) & 1) mark_unsafe(b);
+                rep = !((file_start && b.w_frame[0] == f0.frame_number) || (file_end && b.w_frame[7] == f2.frame_number));      /* isBlockNoReport */
+                valid = blk_valid(b);
+                errs = errors_audio_fixed(b);
+            }
+            fix_p += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_P));
+            fix_q += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_Q));
+            fix_cwd += (uint32_t)__popcll(__ballot(rep && valid && b.cwd_applied && b.cwd_fixed != 0));
+            drop += (uint32_t)__popcll(__ballot(rep && !valid));
+            brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
+            for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
+            if (act) {
+                sdv_sample_pair *o = out_pairs + n_pairs + 3u * (uint32_t)i;
+                if (n_pairs + 3u * (uint32_t)i + 3u <= PAIR_SLOT) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
+            }
+        }
+        if (nblk > 0) {
+            f1.blocks_total = (uint16_t)(f1.blocks_total + nblk);
+            f1.odd_sample_rate = f1.even_sample_rate = rate;
+            f1.blocks_fix_p = (uint16_t)(f1.blocks_fix_p + fix_p); f1.blocks_fix_q = (uint16_t)(f1.blocks_fix_q + fix_q); f1.blocks_fix_cwd = (uint16_t)(f1.blocks_fix_cwd + fix_cwd);
+            f1.blocks_drop = (uint16_t)(f1.blocks_drop + drop); f1.samples_drop = (uint16_t)(f1.samples_drop + sdrop);
+            f1.blocks_broken_field = (uint16_t)(f1.blocks_broken_field + brk_field);
+            n_pairs += 3u * (uint32_t)nblk; if (n_pairs > PAIR_SLOT) { n_pairs = PAIR_SLOT; overflow = true; }
+        }
+        broken_countdown = cd;
+        /* what stays in conv_queue: the last (at most) 112 lines */
+        tail_ofs = nblk;
+    }
+    int tail_ofs;
+};
+
+__device__ inline void reset_state(Step &s)      /* resetState :69-89 (the statistics rings live in the engine) */
+{
+    s.qn = 0; s.last_pad_counter = 0xFF; s.broken_countdown = 0;
+    frasm_clear(s.f0); frasm_clear_misc(s.f1); frasm_clear_misc(s.f2);
+}
+
+/* one turn of doFrameReassemble (:7284-7457) for step k */
+__device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot, int lane)
+{
+    const uint32_t k = work & 0x3FFFFFFFu;
+    const int w_prev = (work >> 30) & 1, w_cur = (work >> 31) & 1;
+    const StepChain *in = k == 0 ? a.chain0 : &a.chain[w_prev][k - 1];
+    StepChain *out = &a.chain[w_cur ^ 1][k];
+    const StepChain *old = &a.chain[w_cur][k];
+    Step s;
+    s.cfg = a.cfg; s.src = a.src; s.fl1 = &a.fl[k]; s.fl2 = &a.fl[k + 1]; s.lane = lane;
+    s.q = a.ws + (size_t)slot * QCAP; s.overflow = false;
+    s.prob_order = a.prob_order[k]; s.prob_res = a.prob_res[k]; s.push_order = ORDER_UNK;
+    s.out_pairs = a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
+    if (a.first_round && k > 0) {
+        /* first round: nothing is known about the predecessor yet, start from a freshly reset stitcher */
+        frasm_clear(s.f0); s.last_pad_counter = 0xFF; s.broken_countdown = 0; s.qn = 0;
+    } else {
+        s.f0 = in->f0; s.last_pad_counter = in->last_pad_counter; s.broken_countdown = in->broken_countdown;
+        s.qn = in->tail_n;
+        for (int i = lane; i < s.qn; i += 64) s.q[i] = in->tail[i];
+    }
+    /* waitForTwoFrames / findFramesTrim / splitFramesToFields results come from the analysis pass */
+    frasm_clear(s.f1); frasm_clear(s.f2);
+    s.f1.frame_number = s.fl1->frame_number; s.f2.frame_number = s.fl2->frame_number;
+    s.file_start = (s.fl1->flags & FL_NEW_FILE) != 0;
+    s.file_end = ((s.fl1->flags | s.fl2->flags) & FL_END_FILE) != 0;
+    for (int f = 0; f < 2; f++) {
+        Frasm &fr = f == 0 ? s.f1 : s.f2; const FrameLocal *fl = f == 0 ? s.fl1 : s.fl2;
+        fr.odd_top_data = fl->top[0]; fr.odd_bottom_data = fl->bottom[0]; fr.even_top_data = fl->top[1]; fr.even_bottom_data = fl->bottom[1];
+        fr.trim_ok = (fl->flags & FL_TRIM_OK) != 0;
+        fr.ctrl_index = fl->ctrl[0]; fr.ctrl_hour = fl->ctrl[1]; fr.ctrl_minute = fl->ctrl[2]; fr.ctrl_second = fl->ctrl[3]; fr.ctrl_field = fl->ctrl[4];
+    }
+    if (s.file_start) reset_state(s);
+    for (int f = 0; f < 2; f++) {
+        Frasm &fr = f == 0 ? s.f1 : s.f2; const FrameLocal *fl = f == 0 ? s.fl1 : s.fl2;
+        fr.odd_data_lines = fl->data_lines[0]; fr.even_data_lines = fl->data_lines[1]; fr.odd_valid_lines = fl->valid_lines[0]; fr.even_valid_lines = fl->valid_lines[1];
+    }
+    frasm_clear_asm_stats(s.f1);
+    s.f1.odd_ref = s.fl1->ref[0]; s.f1.even_ref = s.fl1->ref[1];
+    s.find_field_stitching();
+    sdv_frame_asm *fo = a.frasm + (size_t)k * FRASM_SLOT;
+    uint8_t n_frasm = 0;
+    if (s.file_start) {
+        Frasm sd; frasm_clear(sd); sd.service_type = 1;
+        if (lane == 0) { frasm_to_pod(sd, fo[n_frasm]); s.out_pairs[0] = Step::service_pair(SDV_PAIR_SRV_NEW_FILE); }
+        n_frasm++; s.n_pairs = 1;
+    }
+    s.fill_frame_for_output();
+    s.prescan_frame();
+    __syncthreads();
+    s.perform_deinterleave();
+    if (lane == 0) frasm_to_pod(s.f1, fo[n_frasm]);
+    n_frasm++;
+    s.f0 = s.f1;
+    /* the next turn reads frasm_f0's geometry, order, paddings and resolutions only: keep the per-frame statistics out of
+     * the hand-over so that it does not differ between rounds without consequence */
+    frasm_clear_asm_stats(s.f0); s.f0.odd_sample_rate = s.f0.even_sample_rate = 0; s.f0.odd_valid_lines = s.f0.even_valid_lines = 0;
+    int tail_n = s.qn - s.tail_ofs;
+    if (s.file_end) {
+        Frasm sd; frasm_clear(sd); sd.service_type = 2;
+        if (lane == 0) { frasm_to_pod(sd, fo[n_frasm]); if (s.n_pairs < PAIR_SLOT) s.out_pairs[s.n_pairs] = Step::service_pair(SDV_PAIR_SRV_END_FILE); }
+        n_frasm++; s.n_pairs++;
+        reset_state(s); tail_n = 0;
+    }
+    /* hand over to the next turn; note whether anything differs from what this turn produced last time */
+    bool diff = false;
+    {
+        const uint32_t *x = (const uint32_t *)&s.f0, *y = (const uint32_t *)&old->f0;
+        if (lane < (int)(sizeof(Frasm) / 4)) diff = x[lane] != y[lane];
+        if (lane == 0) diff = diff || old->last_pad_counter != s.last_pad_counter || old->broken_countdown != s.broken_countdown || old->tail_n != (uint16_t)tail_n;
+        for (int i = lane; i < tail_n; i += 64) {
+            const SLine l = s.q[s.tail_ofs + i];
+            const uint32_t *u = (const uint32_t *)&l, *v = (const uint32_t *)&old->tail[i];
+            for (int w = 0; w < 8; w++) diff = diff || u[w] != v[w];
+            out->tail[i] = l;
+        }
+        if (lane == 0) { out->f0 = s.f0; out->last_pad_counter = s.last_pad_counter; out->broken_countdown = s.broken_countdown; out->tail_n = (uint16_t)tail_n; out->_pad[0] = out->_pad[1] = out->_pad[2] = 0; }
+    }
+    const bool changed = __ballot(diff) != 0 || a.first_round != 0;
+    if (lane == 0) {
+        StepInfo inf; inf.n_pairs = s.n_pairs; inf.n_frasm = n_frasm; inf.changed = changed ? 1 : 0; inf.push_order = s.push_order; inf._pad = s.overflow ? 1 : 0;
+        a.info[k] = inf;
+    }
+    __syncthreads();
+}
+
+/* ---- sdv_k_stitch_compact: per-step slots -> contiguous streams ---------------------------------------------------- */
+struct CompactArgs {
+    const sdv_sample_pair *pairs; const sdv_frame_asm *frasm; const StepInfo *info;
+    const uint64_t *pair_ofs; const uint32_t *frasm_ofs;      /* exclusive prefix sums over the steps (host) */
+    sdv_sample_pair *out_pairs; sdv_frame_asm *out_frasm; uint32_t n_steps;
+};
+__device__ inline void compact_body(const CompactArgs &a, uint32_t k, int lane, int width)
+{
+    const StepInfo inf = a.info[k];
+    const uint32_t *src = (const uint32_t *)(a.pairs + (size_t)k * PAIR_SLOT);
+    uint32_t *dst = (uint32_t *)(a.out_pairs + a.pair_ofs[k]);
+    for (uint32_t i = (uint32_t)lane; i < inf.n_pairs * 3u; i += (uint32_t)width) dst[i] = src[i];
+    const uint32_t *fs = (const uint32_t *)(a.frasm + (size_t)k * FRASM_SLOT);
+    uint32_t *fd = (uint32_t *)(a.out_frasm + a.frasm_ofs[k]);
+    for (uint32_t i = (uint32_t)lane; i < inf.n_frasm * 16u; i += (uint32_t)width) fd[i] = fs[i];
+}
+
+/* ---- END_FRAME search: positions of the END_FRAME records, in stream order -------------------------------------- */
+struct SegArgs { RecSrc src; uint32_t n_recs; uint32_t *block_count; const uint32_t *block_ofs; uint32_t *seg_end; int write; };
+enum { SEG_CHUNK = 4096 };
+__device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
+{
+    const uint32_t lo = blk * SEG_CHUNK;
+    uint32_t hi = lo + SEG_CHUNK; if (hi > a.n_recs) hi = a.n_recs;
+    uint32_t cnt = 0;
+    for (uint32_t c = lo; c < hi; c += 64) {
+        const uint32_t i = c + (uint32_t)lane;
+        const bool ef = i < hi && a.src.at(i).service_type == SDV_SRV_END_FRAME;
+        const uint64_t m = __ballot(ef);
+        if (a.write && ef) a.seg_end[a.block_ofs[blk] + cnt + (uint32_t)__popcll(m & lanemask_lt(lane))] = i;
+        cnt += (uint32_t)__popcll(m);
+    }
+    if (!a.write && lane == 0) a.block_count[blk] = cnt;
+}
+} // namespace sdvs
+
+__global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a) { sdvs::analyze_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_stitch_step(sdvs::StepArgs a)
+{
+    for (uint32_t w = blockIdx.x; w < a.n_work; w += gridDim.x) sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x);
+}
+__global__ void __launch_bounds__(64) sdv_k_stitch_compact(sdvs::CompactArgs a) { sdvs::compact_body(a, blockIdx.x, (int)threadIdx.x, 64); }
+#endif

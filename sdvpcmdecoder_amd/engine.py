@@ -59,6 +59,24 @@ BLOCK_DTYPE = np.dtype([("w_frame", "<u4", (8,)), ("w_line", "<u2", (8,)), ("wor
 assert DEINT_LINE_DTYPE.itemsize == 24 and BLOCK_DTYPE.itemsize == 72
 
 
+class StitchSettings(C.Structure):
+    """STC007DataStitcher settings (slots stc007datastitcher.h:331-350)"""
+    _fields_ = [("video_standard", C.c_uint8), ("field_order", C.c_uint8), ("enable_p", C.c_uint8), ("enable_q", C.c_uint8),
+                ("enable_cwd", C.c_uint8), ("m2_format", C.c_uint8), ("resolution_preset", C.c_uint8), ("max_unch_14", C.c_uint8),
+                ("max_unch_16", C.c_uint8), ("use_ecc", C.c_uint8), ("mask_seams", C.c_uint8), ("broke_mask", C.c_uint8),
+                ("top_line_fix", C.c_uint8), ("_pad", C.c_uint8), ("sample_rate_preset", C.c_uint16)]
+
+
+class StitchInfo(C.Structure):
+    _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("_pad", C.c_uint32),
+                ("device_ms", C.c_float), ("_pad2", C.c_float)]
+
+
+PAIR_DTYPE = np.dtype([("audio_word", "<i2", (2,)), ("sample_flags", "u1", (2,)), ("sample_rate", "<u2"),
+                       ("emphasis", "u1"), ("service_type", "u1"), ("_pad", "<u2")])
+assert PAIR_DTYPE.itemsize == 12 and C.sizeof(StitchSettings) == 16
+
+
 class RunInfo(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32),
                 ("kernel_ms", C.c_float), ("_pad2", C.c_float)]
@@ -102,6 +120,13 @@ def load_library(path: str | None = None):
     lib.sdv_deinterleave_blocks.restype = C.c_int
     lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DeintSettings), C.c_void_p, C.c_size_t,
                                             C.c_void_p]
+    lib.sdv_default_stitch_settings.argtypes = [C.POINTER(StitchSettings)]
+    lib.sdv_set_stitch_settings.argtypes = [C.c_void_p, C.POINTER(StitchSettings)]
+    lib.sdv_reset_stitcher.argtypes = [C.c_void_p]
+    lib.sdv_get_stitch_info.argtypes = [C.c_void_p, C.POINTER(StitchInfo)]
+    lib.sdv_stitch_frames.restype = C.c_int
+    lib.sdv_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -188,6 +213,41 @@ class Engine:
         self._check(self.lib.sdv_deinterleave_blocks(self._h, C.c_void_p(lines.data_ptr()), n_lines, C.byref(settings),
                                                      C.c_void_p(out.data_ptr()), n_blocks, sptr))
         return out
+
+    # ---- STC007DataStitcher (stc007datastitcher.h:331-350) ----
+    def default_stitch_settings(self) -> StitchSettings:
+        st = StitchSettings()
+        self.lib.sdv_default_stitch_settings(C.byref(st))
+        return st
+
+    def set_stitch_settings(self, st: StitchSettings):
+        self._check(self.lib.sdv_set_stitch_settings(self._h, C.byref(st)))
+
+    def reset_stitcher(self):
+        self._check(self.lib.sdv_reset_stitcher(self._h))
+
+    def stitch_info(self) -> StitchInfo:
+        info = StitchInfo()
+        self.lib.sdv_get_stitch_info(self._h, C.byref(info))
+        return info
+
+    def stitch_frames(self, lines, out_pairs=None, out_frames=None, stream=None):
+        """doFrameReassemble over a span of the binarized line stream: `lines` is a torch.uint8 CUDA tensor (n_records, 48)
+        (what binarize_frames returns).  Returns (pairs, frames): torch.uint8 CUDA tensors (n_pairs, 12) of sdv_sample_pair
+        and (n_frames, 64) of sdv_frame_asm - views of out_pairs / out_frames when those are given."""
+        import torch
+        assert lines.is_cuda and lines.dtype == torch.uint8 and lines.dim() == 2 and lines.shape[1] == 48 and lines.is_contiguous()
+        n = lines.shape[0]
+        if out_pairs is None:
+            out_pairs = torch.empty((n * 3 + 8192, 12), dtype=torch.uint8, device=lines.device)
+        if out_frames is None:
+            out_frames = torch.empty((n // 8 + 64, 64), dtype=torch.uint8, device=lines.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)
+        npairs, nframes = C.c_size_t(0), C.c_size_t(0)
+        rc = self.lib.sdv_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
+                                        C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
+        self._check(rc)
+        return out_pairs[:npairs.value], out_frames[:nframes.value]
 
     # ---- batch replacement of doBinarize ----
     def records_per_frame(self, height: int) -> int:

@@ -18,6 +18,11 @@ class RunInfo(C.Structure):
                 ("kernel_ms", C.c_float), ("_pad2", C.c_float)]
 
 
+class StitchInfo(C.Structure):
+    _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("_pad", C.c_uint32),
+                ("device_ms", C.c_float), ("_pad2", C.c_float)]
+
+
 def bind(lib):
     lib.sdv_engine_create.restype = C.c_void_p
     lib.sdv_engine_create.argtypes = [C.c_int]
@@ -40,7 +45,32 @@ def bind(lib):
     import deint_api as da
     lib.sdv_deinterleave_blocks.restype = C.c_int
     lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(da.DeintSettings), C.c_void_p, C.c_size_t, C.c_void_p]
+    import stitch_api as sa
+    lib.sdv_default_stitch_settings.argtypes = [C.POINTER(sa.StitchSettings)]
+    lib.sdv_set_stitch_settings.argtypes = [C.c_void_p, C.POINTER(sa.StitchSettings)]
+    lib.sdv_reset_stitcher.argtypes = [C.c_void_p]
+    lib.sdv_get_stitch_info.argtypes = [C.c_void_p, C.POINTER(StitchInfo)]
+    lib.sdv_stitch_frames.restype = C.c_int
+    lib.sdv_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     return lib
+
+
+def emu_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
+    """Host-memory call (emulator build only): one sdv_stitch_frames call over `recs`."""
+    import stitch_api as sa
+    if settings is not None:
+        assert lib.sdv_set_stitch_settings(eng, C.byref(settings)) == 0
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == 5).sum()) + 2
+    pair_cap = pair_cap or nfr * 2400 + 16
+    frame_cap = frame_cap or nfr * 3
+    pairs = np.zeros(pair_cap, dtype=sa.PAIR_DTYPE)
+    frames = np.zeros(frame_cap, dtype=sa.FRASM_DTYPE)
+    npairs, nframes = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.sdv_stitch_frames(eng, recs.ctypes.data, len(recs), pairs.ctypes.data, pair_cap, C.byref(npairs),
+                               frames.ctypes.data, frame_cap, C.byref(nframes), None)
+    return rc, pairs[:npairs.value], frames[:nframes.value]
 
 
 def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1):
