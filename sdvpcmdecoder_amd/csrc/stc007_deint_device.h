@@ -71,20 +71,30 @@ __device__ inline uint16_t tki_inv(uint16_t v, int k)
     return r;
 }
 
-/* STC007DataBlock in registers: three 8-bit masks instead of three bool[8] */
+/* STC007DataBlock in registers: three 8-bit masks instead of three bool[8]; the eight words packed into two 64-bit
+ * values so that the error-position-dependent reads and writes of fixByP / fixByQ are shifts, not indexed memory */
 struct Block {
-    uint32_t w_frame[8]; uint16_t w_line[8]; uint16_t words[8];
+    uint32_t w_frame[8]; uint16_t w_line[8];
+    uint64_t wlo, whi;              /* words 0..3, 4..7: 16 bits each */
     uint8_t line_crc, cwd_fixed, word_valid, resolution, audio_state; bool cwd_applied;
+    __device__ inline uint16_t w(int i) const { return (uint16_t)(((i & 4) ? whi : wlo) >> (16 * (i & 3))); }
+    __device__ inline void setw(int i, uint16_t v)
+    {
+        const int sh = 16 * (i & 3);
+        const uint64_t m = ~(0xFFFFull << sh), x = (uint64_t)v << sh;
+        if (i & 4) whi = (whi & m) | x; else wlo = (wlo & m) | x;
+    }
 };
 __device__ inline void blk_clear(Block &b)
 {
-    for (int i = 0; i < 8; i++) { b.w_frame[i] = 0; b.w_line[i] = 0; b.words[i] = 0; }
+    for (int i = 0; i < 8; i++) { b.w_frame[i] = 0; b.w_line[i] = 0; }
+    b.wlo = b.whi = 0;
     b.line_crc = b.cwd_fixed = b.word_valid = 0; b.resolution = SDV_RES_14BIT; b.audio_state = SDV_AUD_ORIG; b.cwd_applied = false;
 }
 __device__ inline void blk_set_word(Block &b, int i, uint16_t w, bool line_valid, bool cwd_fixed)
 {
     uint8_t m = (uint8_t)(1u << i);
-    b.words[i] = w;
+    b.setw(i, w);
     b.line_crc = line_valid ? (b.line_crc | m) : (b.line_crc & ~m);
     b.word_valid = line_valid ? (b.word_valid | m) : (b.word_valid & ~m);
     b.cwd_fixed = cwd_fixed ? (b.cwd_fixed | m) : (b.cwd_fixed & ~m);
@@ -100,12 +110,12 @@ __device__ inline void blk_mark_broken(Block &b)
     b.word_valid &= (uint8_t)~m; b.line_crc &= (uint8_t)~m; b.cwd_fixed &= (uint8_t)~m;
     b.audio_state = SDV_AUD_BROKEN; b.cwd_applied = false;
 }
-__device__ inline uint16_t calc_p(const uint16_t *w) { return (uint16_t)(w[0] ^ w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5]); }
-__device__ inline uint16_t calc_q(const uint16_t *w)
+__device__ inline uint16_t calc_p(const Block &b) { return (uint16_t)(b.w(0) ^ b.w(1) ^ b.w(2) ^ b.w(3) ^ b.w(4) ^ b.w(5)); }
+__device__ inline uint16_t calc_q(const Block &b)
 {
     /* Horner: T(T(T(T(T(T L0 + R0) + L1) + R1) + L2) + R2) = T^6 L0 + T^5 R0 + ... + T R2 (14-bit row masks: upper bits ignored) */
     uint16_t q = 0;
-    for (int k = 0; k < 6; k++) q = t_mul((uint16_t)((q ^ w[k]) & 0x3FFF));
+    for (int k = 0; k < 6; k++) q = t_mul((uint16_t)((q ^ b.w(k)) & 0x3FFF));
     return q;
 }
 
@@ -118,7 +128,6 @@ struct PtrSrc {
 template <class Src>
 __device__ inline void set_word_data(const sdv_deint_settings &st, const Src &lines, size_t base, Block &b, uint8_t res)
 {
-    const int s_ofs[7] = { 12, 10, 8, 6, 4, 2, 0 };
     for (int k = 0; k < 8; k++) {
         const sdv_deint_line l = lines.line(base + (size_t)INTERLEAVE_OFS * k);
         bool bw_ok = (l.flags & SDV_DL_COORDS_BW_OK) != 0;
@@ -127,7 +136,7 @@ __device__ inline void set_word_data(const sdv_deint_settings &st, const Src &li
         if (res == SDV_RES_14BIT) blk_set_word(b, k, l.words[k], ok, cwd);
         else if (k < 7) {
             bool sok = !st.ignore_crc ? bit(l.word_crc_ok, WORD_Q0) : bw_ok;
-            uint16_t f1 = (uint16_t)(l.words[k] << 2), s = (uint16_t)((l.words[WORD_Q0] >> s_ofs[k]) & 3);
+            uint16_t f1 = (uint16_t)(l.words[k] << 2), s = (uint16_t)((l.words[WORD_Q0] >> (12 - 2 * k)) & 3);
             blk_set_word(b, k, (uint16_t)(f1 + s), ok && sok, cwd);
         } else blk_set_word(b, WORD_Q0, 0, true, false);
         b.w_frame[k] = l.frame_number; b.w_line[k] = l.line_number;
@@ -137,17 +146,17 @@ __device__ inline void set_word_data(const sdv_deint_settings &st, const Src &li
 
 __device__ inline void recalc_p(Block &b)
 {
-    uint16_t p = calc_p(b.words);
-    if (b.words[WORD_P0] != p) { blk_set_word(b, WORD_P0, p, bit(b.line_crc, WORD_P0), false); blk_set_fixed(b, WORD_P0); }
+    uint16_t p = calc_p(b);
+    if (b.w(WORD_P0) != p) { blk_set_word(b, WORD_P0, p, bit(b.line_crc, WORD_P0), false); blk_set_fixed(b, WORD_P0); }
     else blk_set_valid(b, WORD_P0);
 }
 __device__ inline uint8_t fix_by_p(Block &b, uint8_t first_bad)
 {
     b.audio_state = SDV_AUD_ORIG;
-    uint16_t check = (uint16_t)(calc_p(b.words) ^ b.words[WORD_P0]);
+    uint16_t check = (uint16_t)(calc_p(b) ^ b.w(WORD_P0));
     if (check == 0) { if (first_bad != NO_ERR_INDEX) blk_set_valid(b, first_bad); return FIX_NOT_NEED; }
     if (first_bad == NO_ERR_INDEX) return FIX_BROKEN;
-    uint16_t fix = (uint16_t)(check ^ b.words[first_bad]);
+    uint16_t fix = (uint16_t)(check ^ b.w(first_bad));
     blk_set_word(b, first_bad, fix, false, bit(b.word_valid, first_bad));
     blk_set_fixed(b, first_bad);
     return FIX_DONE;
@@ -157,11 +166,11 @@ __device__ inline uint8_t fix_by_q(Block &b, uint8_t first_bad, uint8_t second_b
     uint16_t synd_p = 0, synd_q, e1 = 0, e2 = 0;
     b.audio_state = SDV_AUD_ORIG;
     if (second_bad == NO_ERR_INDEX && !bit(b.word_valid, WORD_P0)) second_bad = WORD_P0;
-    synd_q = (uint16_t)(calc_q(b.words) ^ b.words[WORD_Q0]);
+    synd_q = (uint16_t)(calc_q(b) ^ b.w(WORD_Q0));
     if (second_bad == WORD_P0) {
         if (synd_q == 0) { if (first_bad != NO_ERR_INDEX) blk_set_valid(b, first_bad); recalc_p(b); return FIX_NOT_NEED; }
     } else {
-        synd_p = (uint16_t)(calc_p(b.words) ^ b.words[WORD_P0]);
+        synd_p = (uint16_t)(calc_p(b) ^ b.w(WORD_P0));
         if (synd_p == 0 && synd_q == 0) { blk_set_valid(b, first_bad); blk_set_valid(b, second_bad); return FIX_NOT_NEED; }
     }
     if (second_bad != WORD_P0 && !bit(b.word_valid, WORD_P0)) return FIX_NA;
@@ -173,11 +182,11 @@ __device__ inline uint8_t fix_by_q(Block &b, uint8_t first_bad, uint8_t second_b
         e1 = tki_inv(e1, (int)second_bad - (int)first_bad);
         e2 = (uint16_t)(e1 ^ synd_p);
     } else return FIX_BROKEN;
-    uint16_t old1 = b.words[first_bad];
+    uint16_t old1 = b.w(first_bad);
     if (e1 != 0) { blk_set_word(b, first_bad, (uint16_t)(old1 ^ e1), false, bit(b.cwd_fixed, first_bad)); blk_set_fixed(b, first_bad); }
     else blk_set_valid(b, first_bad);
-    uint16_t old2 = b.words[second_bad];
-    if (second_bad == WORD_P0) e2 = (uint16_t)(old2 ^ calc_p(b.words));
+    uint16_t old2 = b.w(second_bad);
+    if (second_bad == WORD_P0) e2 = (uint16_t)(old2 ^ calc_p(b));
     if (e2 != 0) { blk_set_word(b, second_bad, (uint16_t)(old2 ^ e2), false, bit(b.cwd_fixed, second_bad)); blk_set_fixed(b, second_bad); }
     else blk_set_valid(b, second_bad);
     return (e1 == 0 && e2 == 0) ? FIX_NOT_NEED : FIX_DONE;
@@ -247,10 +256,10 @@ __device__ inline void process_block(const sdv_deint_settings &st, const Src &li
                     else if (fix == FIX_NOT_NEED && first_bad < WORD_P0) out.audio_state = SDV_AUD_FIX_P;
                     if (run_res == SDV_RES_14BIT && st.en_q_code) {
                         if (bit(out.word_valid, WORD_Q0)) {
-                            if (st.force_ecc_check && (uint16_t)(calc_q(out.words) ^ out.words[WORD_Q0]) != 0) { state = STG_BAD_BLOCK; blk_mark_broken(out); }
+                            if (st.force_ecc_check && (uint16_t)(calc_q(out) ^ out.w(WORD_Q0)) != 0) { state = STG_BAD_BLOCK; blk_mark_broken(out); }
                         } else {
-                            uint16_t q = calc_q(out.words);
-                            if (out.words[WORD_Q0] != q) { blk_set_word(out, WORD_Q0, q, bit(out.line_crc, WORD_Q0), false); blk_set_fixed(out, WORD_Q0); }
+                            uint16_t q = calc_q(out);
+                            if (out.w(WORD_Q0) != q) { blk_set_word(out, WORD_Q0, q, bit(out.line_crc, WORD_Q0), false); blk_set_fixed(out, WORD_Q0); }
                             else blk_set_valid(out, WORD_Q0);
                         }
                     }
@@ -270,9 +279,9 @@ __device__ inline void process_block(const sdv_deint_settings &st, const Src &li
                 else if (fix == FIX_BROKEN) blk_mark_broken(out);
             } else if (first_bad == NO_ERR_INDEX) {
                 state = STG_NO_CHECK;
-                uint16_t ecc = calc_p(out.words);
+                uint16_t ecc = calc_p(out);
                 blk_set_word(out, WORD_P0, ecc, false, bit(out.cwd_fixed, WORD_P0)); blk_set_fixed(out, WORD_P0);
-                ecc = calc_q(out.words);
+                ecc = calc_q(out);
                 blk_set_word(out, WORD_Q0, ecc, false, bit(out.cwd_fixed, WORD_Q0)); blk_set_fixed(out, WORD_Q0);
             }
         } else if (state == STG_BAD_BLOCK) {
@@ -293,7 +302,7 @@ __device__ inline void deint_body(const DeintArgs &a, size_t s)
     PtrSrc src; src.p = a.lines;
     process_block(a.st, src, s, b);
     sdv_block_rec r;
-    for (int i = 0; i < 8; i++) { r.w_frame[i] = b.w_frame[i]; r.w_line[i] = b.w_line[i]; r.words[i] = b.words[i]; }
+    for (int i = 0; i < 8; i++) { r.w_frame[i] = b.w_frame[i]; r.w_line[i] = b.w_line[i]; r.words[i] = b.w(i); }
     r.line_crc = b.line_crc; r.cwd_fixed = b.cwd_fixed; r.word_valid = b.word_valid; r.resolution = b.resolution;
     r.audio_state = b.audio_state; r.cwd_applied = b.cwd_applied ? 1 : 0; r.sample_rate = 44056;   /* STC007DataBlock::clear, stc007datablock.cpp:55 */
     a.out[s] = r;

@@ -117,8 +117,9 @@ struct Frasm {
     uint8_t odd_emphasis, even_emphasis, order_preset, order_guessed, trim_ok, inner_padding_ok, outer_padding_ok;
     uint8_t inner_silence, outer_silence, vid_std_preset, vid_std_guessed;
     int8_t ctrl_index, ctrl_hour, ctrl_minute, ctrl_second, ctrl_field;
-    uint8_t _pad[2];
+    uint8_t _pad[3];                /* no implicit padding: the hand-over between turns is compared as words */
 };
+static_assert(sizeof(Frasm) == 76, "Frasm layout");
 __host__ __device__ inline void frasm_clear_asm_stats(Frasm &f)
 {
     f.odd_ref = f.even_ref = 0; f.blocks_total = f.blocks_drop = f.samples_drop = 0;
@@ -139,7 +140,7 @@ __host__ __device__ inline void frasm_clear_misc(Frasm &f)
 __host__ __device__ inline void frasm_clear(Frasm &f)
 {
     f.frame_number = 0; f.odd_top_data = 0; f.odd_bottom_data = 0xFFFF; f.even_top_data = 0; f.even_bottom_data = 0xFFFF;
-    f._pad[0] = f._pad[1] = 0;
+    f._pad[0] = f._pad[1] = f._pad[2] = 0;
     frasm_clear_misc(f);
 }
 __device__ inline bool order_set(const Frasm &f) { return f.field_order == ORDER_TFF || f.field_order == ORDER_BFF; }
@@ -178,7 +179,6 @@ struct FrameLocal {
     uint8_t flags;
     uint8_t field_res[2];           /* getFieldResolution: SRES_* */
     int8_t ctrl[5];
-    uint16_t idx[2][BUF_FIELD];     /* record index (relative to seg_start) of every line kept in the field buffers */
 };
 
 /* the record stream of a call: what was left over from the previous call, then the caller's records */
@@ -206,8 +206,8 @@ __device__ inline bool can_force_check(const Block &b)                          
 }
 __device__ inline int16_t get_sample(const Block &b, int i, bool m2)                                                          /* :507-562 */
 {
-    if (!m2) return b.resolution == SDV_RES_16BIT ? (int16_t)b.words[i] : (int16_t)(b.words[i] << 2);
-    uint16_t w = b.words[i];
+    if (!m2) return b.resolution == SDV_RES_16BIT ? (int16_t)b.w(i) : (int16_t)(b.w(i) << 2);
+    uint16_t w = b.w(i);
     if ((w & (1 << 13)) == 0) w = (uint16_t)(w << 3);
     else {
         bool pos = (w & (1 << 12)) == 0;
@@ -253,13 +253,13 @@ __device__ inline sdv_deint_settings deint_cfg(uint8_t res_mode, bool ignore_crc
 }
 
 /* ---- line sources for processBlock ------------------------------------------------------------------------------- */
-/* one of the four field buffers (frame1_odd/even, frame2_odd/even): lines come straight from the records */
+/* one of the four field buffers (frame1_odd/even, frame2_odd/even) */
 struct Field {
-    const FrameLocal *fl; int parity; int size;            /* size = data lines */
-    RecSrc src;
-    __device__ inline SLine get(int i) const { return sline_from_rec(src.at(fl->seg_start + fl->idx[parity][i])); }
-    __device__ inline uint32_t frame_of(int) const { return fl->frame_number; }
+    const SLine *lines; int size;               /* size = data lines */
+    __device__ inline SLine get(int i) const { return lines[i]; }
 };
+/* the field buffers of all frames: BUF_FIELD lines for (frame k, odd) then (frame k, even), written by the analysis pass */
+__device__ inline const SLine *field_lines(const SLine *fields, uint32_t k, int parity) { return fields + ((size_t)k * 2 + (size_t)parity) * BUF_FIELD; }
 struct FieldSrc {
     Field f;
     __device__ inline sdv_deint_line line(size_t i) const { return view(f.get((int)i)); }
@@ -291,10 +291,20 @@ struct WsSrc {
 struct FrameBrief { uint32_t frame_number; uint8_t flags, field_res[2], _pad; };     /* what the host needs of a FrameLocal */
 struct AnalyzeArgs {
     RecSrc src; const uint32_t *seg_end; uint32_t n_seg;      /* seg_end[k] = index of the k-th END_FRAME record */
-    Cfg cfg; FrameLocal *fl; FrameBrief *brief;
+    Cfg cfg; FrameLocal *fl; FrameBrief *brief; SLine *fields;
 };
 
 __device__ inline uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+/* the turn's control values are the same in every lane: say so, and they live in scalar registers */
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <class T> __device__ inline void make_uniform(T &x)
+{
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &x, sizeof(T));
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = uni(w[i]);
+    __builtin_memcpy(&x, w, sizeof(T));
+}
 
 /* STC007DataStitcher::getFieldResolution (stc007datastitcher.cpp:996-1211) for one field buffer, blocks split over the lanes */
 __device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int lane)
@@ -420,7 +430,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
             uint64_t m = __ballot(mine);
             uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
             bool kept = mine && rank < BUF_FIELD;
-            if (kept) fl->idx[p][rank] = (uint16_t)i;
+            if (kept) a.fields[((size_t)k * 2 + (size_t)p) * BUF_FIELD + rank] = sline_from_rec(a.src.at(start + i));
             uint64_t mk = __ballot(kept), mv = __ballot(kept && ok);
             /* sums of the reference level over kept lines / kept valid lines */
             uint32_t ra = kept ? ref : 0, ro = (kept && ok) ? ref : 0;
@@ -448,10 +458,10 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
         fl->flags = (uint8_t)((new_file ? FL_NEW_FILE : 0) | (end_file ? FL_END_FILE : 0) | (trim_ok ? FL_TRIM_OK : 0) | ((bad_numbers || n > BUF_TRIM / 2) ? FL_BAD_NUMBERS : 0));
         for (int i = 0; i < 5; i++) fl->ctrl[i] = ctrl[i];
     }
-    __syncthreads();            /* the index lists are read back through processBlock below */
+    __syncthreads();            /* the field buffers are read back through processBlock below */
     uint8_t fres[2];
     for (int p = 0; p < 2; p++) {
-        Field f; f.fl = fl; f.parity = p; f.size = (int)cnt[p]; f.src = a.src;
+        Field f; f.lines = field_lines(a.fields, k, p); f.size = (int)cnt[p];
         fres[p] = field_resolution(a.cfg, f, lane);
     }
     if (lane == 0) {
@@ -474,9 +484,10 @@ struct StepChain {
     uint32_t _pad[3];
     SLine tail[MIN_DEINT];
 };
-struct StepInfo { uint32_t n_pairs; uint8_t n_frasm, changed, push_order, _pad; };
+enum { SI_OVERFLOW = 1, SI_STEADY = 2 };
+struct StepInfo { uint32_t n_pairs; uint8_t n_frasm, changed, push_order, bits; };
 struct StepArgs {
-    RecSrc src; const FrameLocal *fl; Cfg cfg;
+    const SLine *fields; const FrameLocal *fl; Cfg cfg;
     const uint32_t *work; uint32_t n_work;  /* steps to run: k | which[k-1] << 30 | which[k] << 31 (buffer holding the current output) */
     const StepChain *chain0;                /* the stream's state before step 0 */
     StepChain *chain[2];
@@ -484,6 +495,7 @@ struct StepArgs {
     SLine *ws;                              /* QCAP lines per wave */
     sdv_sample_pair *pairs; sdv_frame_asm *frasm; StepInfo *info;
     uint32_t first_round;
+    unsigned long long *timing;             /* optional: 8 cycle stamps per step (SDV_STITCH_TIMING=1), NULL otherwise */
 };
 
 struct FieldStitchStats { uint16_t index, valid, silent, unchecked, broken; };    /* frametrimset.h:278-300 */
@@ -510,7 +522,7 @@ enum { STG_TRY_PREVIOUS = 0, STG_TRY_TFF_TO_TFF, STG_TRY_BFF_TO_BFF, STG_A_PREPA
        STG_AB_TFF_TO_TFF, STG_AB_TFF_TO_BFF, STG_AB_BFF_TO_BFF, STG_AB_BFF_TO_TFF, STG_PAD_NO_GOOD, STG_PAD_SILENCE, STG_PAD_OK, STG_PAD_MAX };
 
 struct Step {
-    Cfg cfg; RecSrc src; const FrameLocal *fl1, *fl2;
+    Cfg cfg; const SLine *fields; uint32_t k; FrameLocal l1, l2; const FrameLocal *fl1, *fl2;
     Frasm f0, f1, f2;
     uint8_t last_pad_counter, broken_countdown, prob_order, prob_res, push_order;
     bool file_start, file_end;
@@ -519,7 +531,7 @@ struct Step {
 
     __device__ inline Field field(int frame, int parity) const
     {
-        Field f; f.fl = frame == 1 ? fl1 : fl2; f.parity = parity; f.src = src;
+        Field f; f.lines = field_lines(fields, frame == 1 ? k : k + 1, parity);
         const Frasm &fr = frame == 1 ? f1 : f2;
         f.size = parity == 0 ? fr.odd_data_lines : fr.even_data_lines;
         return f;
@@ -547,14 +559,14 @@ struct Step {
         pq.a0 = fa.size > keep ? fa.size - keep : 0;
         pq.n0 = fa.size - pq.a0;
         pq.npad = padding;
-        if (fa.size > 0) { SLine l = fa.get(fa.size - 1); pq.pad_frame = l.frame; pq.pad_line0 = (uint16_t)(l.line + 2); }
+        if (fa.size > 0) { SLine l = fa.get(fa.size - 1); pq.pad_frame = uni(l.frame); pq.pad_line0 = (uint16_t)uni((uint32_t)(l.line + 2)); }
         else { pq.pad_frame = 0; pq.pad_line0 = 2; }
         pq.n2 = fb.size > (MIN_DEINT + ILV / 2) ? (MIN_DEINT + ILV / 2) : fb.size;
         const int n = pq.size();
         if (n < MIN_DEINT) return DS_NO_DATA;
         const uint8_t unchecked_lim = cfg.en_q ? cfg.max_unch_14 : cfg.max_unch_16;
         uint8_t mode = SDV_RES_MODE_14BIT;
-        if (!cfg.m2) mode = n <= MIN_DEINT ? (uint8_t)SDV_RES_MODE_14BIT_AUTO : block_res_mode(pq.get(0), pq.get(MIN_DEINT));
+        if (!cfg.m2) mode = n <= MIN_DEINT ? (uint8_t)SDV_RES_MODE_14BIT_AUTO : (uint8_t)uni(block_res_mode(pq.get(0), pq.get(MIN_DEINT)));
         const sdv_deint_settings ds = deint_cfg(mode, cfg.ignore_crc, true, cfg.en_p, cfg.en_q, false);
         const int nblk = n - MIN_DEINT;
         uint16_t valid_cnt = 0, silence_cnt = 0, uncheck_cnt = 0, broken_count = 0, valid_max = 0, silence_max = 0, uncheck_max = 0;
@@ -592,43 +604,78 @@ struct Step {
         return DS_OK;
     }
 
-    /* ---- findPadding (:1743-2054) ---- */
-    __device__ inline uint8_t find_padding(const Field &fa, const Field &fb, uint8_t in_std, uint8_t in_resolution, uint16_t *padding)
+    /* ---- findPadding (:1743-2054) and the single tryPadding of the "same as last frame" path, behind one call site ----
+     * find = false: tryPadding(fa, fb, pad_in) -> its return code.
+     * find = true : findPadding(fa, fb, in_std, in_resolution, &padding); *found receives what the reference leaves in *padding. */
+    __device__ inline uint8_t pad_search(bool find, const Field &fa, const Field &fb, uint16_t pad_in, uint8_t in_std, uint8_t in_resolution, uint16_t *found)
     {
         uint8_t stitch_res = DS_NO_PAD;
-        uint16_t pad = (uint16_t)fa.size;
-        if (in_std == VID_PAL) *padding = pad > LINES_PF_PAL ? 0 : (uint16_t)(LINES_PF_PAL - pad);
-        else if (in_std == VID_NTSC) *padding = pad > LINES_PF_NTSC ? 0 : (uint16_t)(LINES_PF_NTSC - pad);
-        else *padding = 0;
-        int max_padding = MAX_PADDING_14BIT; uint8_t unchecked_lim = cfg.max_unch_14;
-        if (in_resolution == SDV_RES_16BIT || !cfg.en_q) { max_padding = MAX_PADDING_16BIT; unchecked_lim = cfg.max_unch_16; }
-        last_pad_counter = 0xFF;
-        if (cfg.en_p || cfg.en_q) {
-            FieldStitchStats sd[MAX_PADDING_14BIT], s0, s1;
-            for (int i = 0; i < max_padding; i++) stats_clear(sd[i]);
-            uint16_t min_broken = 0xFFFF; int no_brk_idx = 0;
-            for (int p = 0; p < max_padding; p++) {
-                try_padding(fa, fb, (uint16_t)p, &sd[p]);
-                if (min_broken > sd[p].broken) { min_broken = sd[p].broken; if (min_broken == 0) no_brk_idx = p; }
-                else if (min_broken == 0) {
-                    if (sd[no_brk_idx].valid > 0 && sd[no_brk_idx].unchecked < unchecked_lim && sd[p].broken > 0) break;
-                }
-            }
-            stats_best2(sd, max_padding, s0, s1);
-            last_pad_counter = (uint8_t)s0.broken;
-            if (s0.silent < MAX_BURST_SILENCE) {
-                if (s0.unchecked < unchecked_lim) {
-                    if (s0.broken < 2 && s0.broken < s1.broken) { stitch_res = DS_OK; *padding = s0.index; }
-                    else if ((((int16_t)s0.valid - (int16_t)s1.valid) > MAX_BURST_UNCH_DELTA) && s0.broken == 0) { stitch_res = DS_OK; *padding = s0.index; }
-                } else {
-                    for (int p = 0; p < max_padding; p++) { sd[p].broken = min_broken; if (sd[p].unchecked >= unchecked_lim) sd[p].broken = 0xFF; }
-                    stats_best2(sd, max_padding, s0, s1);
-                    if (s0.unchecked < unchecked_lim)
-                        if (((int16_t)s0.valid - (int16_t)s1.valid) > MAX_BURST_UNCH_DELTA) { stitch_res = DS_OK; *padding = s0.index; }
-                }
-            } else stitch_res = DS_SILENCE;
+        int max_padding = 1; uint8_t unchecked_lim = cfg.max_unch_14;
+        if (find) {
+            const uint16_t pad = (uint16_t)fa.size;
+            if (in_std == VID_PAL) *found = pad > LINES_PF_PAL ? 0 : (uint16_t)(LINES_PF_PAL - pad);
+            else if (in_std == VID_NTSC) *found = pad > LINES_PF_NTSC ? 0 : (uint16_t)(LINES_PF_NTSC - pad);
+            else *found = 0;
+            max_padding = MAX_PADDING_14BIT;
+            if (in_resolution == SDV_RES_16BIT || !cfg.en_q) { max_padding = MAX_PADDING_16BIT; unchecked_lim = cfg.max_unch_16; }
+            last_pad_counter = 0xFF;
+            if (!(cfg.en_p || cfg.en_q)) return stitch_res;
         }
+        /* findPadding only reads the two best entries of its sorted statistics; paddings never tried (early break) keep
+         * FieldStitchStats' cleared value and take part in the ranking like the reference's untouched slots */
+        FieldStitchStats cur, s0, s1, no_brk;
+        stats_clear(no_brk);
+        uint16_t min_broken = 0xFFFF;
+        int p_end = 0;
+        for (int p = 0; p < max_padding; p++) {
+            const uint8_t code = try_padding(fa, fb, find ? (uint16_t)p : pad_in, &cur);
+            if (!find) return code;
+            p_end = p + 1;
+            sd_store(p, cur);
+            if (min_broken > cur.broken) { min_broken = cur.broken; if (min_broken == 0) no_brk = cur; }
+            else if (min_broken == 0) {
+                if (no_brk.valid > 0 && no_brk.unchecked < unchecked_lim && cur.broken > 0) break;
+            }
+        }
+        /* ranking: tried entries from the table, the rest are cleared entries */
+        sd_best2(p_end, max_padding, false, 0, unchecked_lim, s0, s1);
+        last_pad_counter = (uint8_t)s0.broken;
+        if (s0.silent < MAX_BURST_SILENCE) {
+            if (s0.unchecked < unchecked_lim) {
+                if (s0.broken < 2 && s0.broken < s1.broken) { stitch_res = DS_OK; *found = s0.index; }
+                else if ((((int16_t)s0.valid - (int16_t)s1.valid) > MAX_BURST_UNCH_DELTA) && s0.broken == 0) { stitch_res = DS_OK; *found = s0.index; }
+            } else {
+                sd_best2(p_end, max_padding, true, min_broken, unchecked_lim, s0, s1);
+                if (s0.unchecked < unchecked_lim)
+                    if (((int16_t)s0.valid - (int16_t)s1.valid) > MAX_BURST_UNCH_DELTA) { stitch_res = DS_OK; *found = s0.index; }
+            }
+        } else stitch_res = DS_SILENCE;
         return stitch_res;
+    }
+    /* findPadding's statistics table lives in LDS (one wave per workgroup): lane-uniform values, written by lane 0 */
+    __device__ inline void sd_store(int p, const FieldStitchStats &v)
+    {
+        __shared__ FieldStitchStats s_sd[MAX_PADDING_14BIT];
+        if (lane == 0) s_sd[p] = v;
+        sd_table = s_sd;
+        __syncthreads();
+    }
+    FieldStitchStats *sd_table;
+    /* the two smallest entries of the table under FieldStitchStats::operator< ; remap = the second ranking of findPadding
+     * (:1990-2030): broken := min_broken, or 0xFF where unchecked >= limit - applied to untouched entries too */
+    __device__ inline void sd_best2(int n_tried, int n_total, bool remap, uint16_t min_broken, uint8_t unchecked_lim, FieldStitchStats &s0, FieldStitchStats &s1)
+    {
+        FieldStitchStats b0, b1; bool h0 = false, h1 = false;
+        for (int i = 0; i < n_total; i++) {
+            FieldStitchStats e;
+            if (i < n_tried) e = sd_table[i]; else stats_clear(e);
+            if (remap) { e.broken = min_broken; if (e.unchecked >= unchecked_lim) e.broken = 0xFF; }
+            if (!h0) { b0 = e; h0 = true; }
+            else if (stats_lt(e, b0)) { b1 = b0; h1 = true; b0 = e; }
+            else if (!h1 || stats_lt(e, b1)) { b1 = e; h1 = true; }
+        }
+        if (!h1) stats_clear(b1);
+        s0 = b0; s1 = b1;
     }
 
     /* ---- detectAudioResolution (:2207-2763); the statistics pushes are replayed by the engine ---- */
@@ -692,53 +739,75 @@ struct Step {
         else { f2.order_preset = 0; set_order_unknown(f2); }
     }
 
-    /* ---- findFieldStitching (:2929-4275) ---- */
+    /* ---- findFieldStitching (:2929-4275) ----
+     * Same stages as the reference; every stage first says which padding search it needs (if any), the search runs at one
+     * call site, then the stage consumes its result - so the padding search exists once in the kernel's code. */
     __device__ inline void find_field_stitching()
     {
         bool en_sw_order = true;
-        uint8_t proc_state = STG_TRY_PREVIOUS, stage_count = 0, stitch_resolution, f_res;
+        uint8_t proc_state = STG_TRY_PREVIOUS, stage_count = 0, f_res;
         detect_audio_resolution();
         detect_video_standard();
         const Field f1o = field(1, 0), f1e = field(1, 1), f2o = field(2, 0), f2e = field(2, 1);
         for (;;) {
             stage_count++;
+            /* -- 1. the search this stage asks for: kind 0 none, 1 tryPadding(fa, fb, pad_in), 2 findPadding(fa, fb) */
+            int kind = 0, a_sel = 0, b_sel = 0;          /* field selectors: 0 f1o, 1 f1e, 2 f2o, 3 f2e */
+            uint16_t pad_in = 0; uint8_t sres = SDV_RES_14BIT;
+            const bool f1_small = f1.odd_data_lines < MIN_FILL_LINES_PF && f1.even_data_lines < MIN_FILL_LINES_PF;
+            const bool f2_small = f2.odd_data_lines < MIN_FILL_LINES_PF && f2.even_data_lines < MIN_FILL_LINES_PF;
+            if (proc_state == STG_TRY_PREVIOUS) {
+                if (f0.odd_data_lines == f1.odd_data_lines && f0.even_data_lines == f1.even_data_lines && f0.inner_padding_ok && f0.outer_padding_ok &&
+                    (!f1.order_preset || f0.field_order == f1.field_order) && !f1_small && order_set(f0)) {
+                    kind = 1; pad_in = f0.inner_padding;
+                    if (f0.field_order == ORDER_TFF) { a_sel = 0; b_sel = 1; } else { a_sel = 1; b_sel = 0; }
+                }
+            } else if (proc_state == STG_TRY_TFF_TO_TFF) {
+                if (f2.odd_data_lines >= MIN_FILL_LINES_PF) { kind = 1; a_sel = 1; b_sel = 2; pad_in = f0.outer_padding; }
+            } else if (proc_state == STG_TRY_BFF_TO_BFF) {
+                if (f2.even_data_lines >= MIN_FILL_LINES_PF) { kind = 1; a_sel = 0; b_sel = 3; pad_in = f0.outer_padding; }
+            } else if (proc_state == STG_A_PAD_TFF) { kind = 2; a_sel = 0; b_sel = 1; sres = res_for_seam(f1.odd_resolution, f1.even_resolution); }
+            else if (proc_state == STG_A_PAD_BFF) { kind = 2; a_sel = 1; b_sel = 0; sres = res_for_seam(f1.even_resolution, f1.odd_resolution); }
+            else if (proc_state == STG_AB_TFF_TO_TFF) {
+                if (!f2_small && f2.odd_data_lines >= MIN_FILL_LINES_PF) { kind = 2; a_sel = 1; b_sel = 2; sres = res_for_seam(f1.even_resolution, f2.odd_resolution); }
+            } else if (proc_state == STG_AB_BFF_TO_BFF) {
+                if (!f2_small && f2.even_data_lines >= MIN_FILL_LINES_PF) { kind = 2; a_sel = 0; b_sel = 3; sres = res_for_seam(f1.odd_resolution, f2.even_resolution); }
+            } else if (proc_state == STG_AB_TFF_TO_BFF) { kind = 2; a_sel = 1; b_sel = 3; sres = res_for_seam(f1.even_resolution, f2.even_resolution); }
+            else if (proc_state == STG_AB_BFF_TO_TFF) { kind = 2; a_sel = 0; b_sel = 2; sres = res_for_seam(f1.odd_resolution, f2.odd_resolution); }
+            uint16_t found = 0;
+            f_res = DS_NO_PAD;
+            if (kind != 0) {
+                const Field &fa = a_sel == 0 ? f1o : f1e;
+                const Field &fb = b_sel == 0 ? f1o : (b_sel == 1 ? f1e : (b_sel == 2 ? f2o : f2e));
+                f_res = pad_search(kind == 2, fa, fb, pad_in, f1.video_standard, sres, &found);
+            }
+            /* -- 2. the stage */
             if (proc_state == STG_TRY_PREVIOUS) {
                 proc_state = STG_A_PREPARE;
                 if (f0.odd_data_lines == f1.odd_data_lines && f0.even_data_lines == f1.even_data_lines && f0.inner_padding_ok && f0.outer_padding_ok) {
                     if (!f1.order_preset || f0.field_order == f1.field_order) {
                         f1.inner_silence = f1.outer_silence = f2.inner_silence = f2.outer_silence = 1;
                         f2.inner_padding_ok = f2.outer_padding_ok = 0; f2.inner_padding = f2.outer_padding = 0;
-                        if (f1.odd_data_lines < MIN_FILL_LINES_PF && f1.even_data_lines < MIN_FILL_LINES_PF) {
+                        if (f1_small) {
                             set_order_unknown(f1);
                             f1.inner_padding_ok = f1.outer_padding_ok = 0; f1.inner_padding = f1.outer_padding = 0;
                             proc_state = STG_PAD_NO_GOOD;
-                        } else {
-                            f_res = DS_NO_PAD;
-                            if (f0.field_order == ORDER_TFF) f_res = try_padding(f1o, f1e, f0.inner_padding, NULL);
-                            else if (f0.field_order == ORDER_BFF) f_res = try_padding(f1e, f1o, f0.inner_padding, NULL);
-                            if (f_res == DS_OK) {
-                                if (!f1.vid_std_preset && f0.video_standard < VID_MAX) f1.video_standard = f0.video_standard;
-                                f1.field_order = f0.field_order;
-                                f1.inner_padding = f0.inner_padding; f1.inner_padding_ok = 1; f1.inner_silence = 0;
-                                if (f1.field_order == ORDER_TFF) { f1.tff_cnt = last_pad_counter; proc_state = STG_TRY_TFF_TO_TFF; }
-                                else { f1.bff_cnt = last_pad_counter; proc_state = STG_TRY_BFF_TO_BFF; }
-                            }
+                        } else if (f_res == DS_OK) {
+                            if (!f1.vid_std_preset && f0.video_standard < VID_MAX) f1.video_standard = f0.video_standard;
+                            f1.field_order = f0.field_order;
+                            f1.inner_padding = f0.inner_padding; f1.inner_padding_ok = 1; f1.inner_silence = 0;
+                            if (f1.field_order == ORDER_TFF) { f1.tff_cnt = last_pad_counter; proc_state = STG_TRY_TFF_TO_TFF; }
+                            else { f1.bff_cnt = last_pad_counter; proc_state = STG_TRY_BFF_TO_BFF; }
                         }
                     }
                 }
-            } else if (proc_state == STG_TRY_TFF_TO_TFF) {
-                f_res = DS_NO_PAD;
-                if (f2.odd_data_lines >= MIN_FILL_LINES_PF) f_res = try_padding(f1e, f2o, f0.outer_padding, NULL);
-                if (f_res == DS_OK) { f1.outer_padding = f0.outer_padding; f1.outer_padding_ok = 1; set_order(f2, ORDER_TFF); f1.outer_silence = 0; proc_state = STG_PAD_OK; }
-                else { proc_state = STG_AB_TFF_TO_TFF; en_sw_order = false; }
-            } else if (proc_state == STG_TRY_BFF_TO_BFF) {
-                f_res = DS_NO_PAD;
-                if (f2.even_data_lines >= MIN_FILL_LINES_PF) f_res = try_padding(f1o, f2e, f0.outer_padding, NULL);
-                if (f_res == DS_OK) { f1.outer_padding = f0.outer_padding; f1.outer_padding_ok = 1; set_order(f2, ORDER_BFF); f1.outer_silence = 0; proc_state = STG_PAD_OK; }
-                else { proc_state = STG_AB_BFF_TO_BFF; en_sw_order = false; }
+            } else if (proc_state == STG_TRY_TFF_TO_TFF || proc_state == STG_TRY_BFF_TO_BFF) {
+                const bool tt = proc_state == STG_TRY_TFF_TO_TFF;
+                if (f_res == DS_OK) { f1.outer_padding = f0.outer_padding; f1.outer_padding_ok = 1; set_order(f2, tt ? ORDER_TFF : ORDER_BFF); f1.outer_silence = 0; proc_state = STG_PAD_OK; }
+                else { proc_state = tt ? STG_AB_TFF_TO_TFF : STG_AB_BFF_TO_BFF; en_sw_order = false; }
             } else if (proc_state == STG_A_PREPARE) {
                 f1.inner_padding_ok = f1.outer_padding_ok = 0; f1.inner_padding = f1.outer_padding = 0; f1.tff_cnt = f1.bff_cnt = 0;
-                if (f1.odd_data_lines < MIN_FILL_LINES_PF && f1.even_data_lines < MIN_FILL_LINES_PF) {
+                if (f1_small) {
                     if (!f1.order_preset) set_order_unknown(f1);
                     proc_state = STG_PAD_NO_GOOD;
                 } else if (f1.even_data_lines < MIN_FILL_LINES_PF) {
@@ -754,16 +823,8 @@ struct Step {
                 }
             } else if (proc_state == STG_A_PAD_TFF || proc_state == STG_A_PAD_BFF) {
                 const bool tff = proc_state == STG_A_PAD_TFF;
-                f1.inner_padding = 0;
-                if (tff) {
-                    stitch_resolution = res_for_seam(f1.odd_resolution, f1.even_resolution);
-                    f_res = find_padding(f1o, f1e, f1.video_standard, stitch_resolution, &f1.inner_padding);
-                    f1.tff_cnt = last_pad_counter;
-                } else {
-                    stitch_resolution = res_for_seam(f1.even_resolution, f1.odd_resolution);
-                    f_res = find_padding(f1e, f1o, f1.video_standard, stitch_resolution, &f1.inner_padding);
-                    f1.bff_cnt = last_pad_counter;
-                }
+                f1.inner_padding = found;
+                if (tff) f1.tff_cnt = last_pad_counter; else f1.bff_cnt = last_pad_counter;
                 f1.inner_silence = 0;
                 if (f_res == DS_OK) {
                     set_order(f1, tff ? ORDER_TFF : ORDER_BFF);
@@ -787,19 +848,13 @@ struct Step {
             } else if (proc_state == STG_AB_TFF_TO_TFF || proc_state == STG_AB_BFF_TO_BFF) {
                 const bool tt = proc_state == STG_AB_TFF_TO_TFF;
                 const uint16_t need = tt ? f2.odd_data_lines : f2.even_data_lines, other = tt ? f2.even_data_lines : f2.odd_data_lines;
-                if (f2.odd_data_lines < MIN_FILL_LINES_PF && f2.even_data_lines < MIN_FILL_LINES_PF) {
+                if (f2_small) {
                     f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0; proc_state = STG_PAD_NO_GOOD;
                 } else if (need < MIN_FILL_LINES_PF) {
                     if (!f1.order_preset) proc_state = tt ? STG_AB_TFF_TO_BFF : STG_AB_BFF_TO_TFF;
                     else { f1.outer_padding = 0; f1.outer_padding_ok = 0; f2.inner_padding_ok = 0; proc_state = STG_PAD_NO_GOOD; }
                 } else {
-                    if (tt) {
-                        stitch_resolution = res_for_seam(f1.even_resolution, f2.odd_resolution);
-                        f_res = find_padding(f1e, f2o, f1.video_standard, stitch_resolution, &f1.outer_padding);
-                    } else {
-                        stitch_resolution = res_for_seam(f1.odd_resolution, f2.even_resolution);
-                        f_res = find_padding(f1o, f2e, f1.video_standard, stitch_resolution, &f1.outer_padding);
-                    }
+                    f1.outer_padding = found;
                     f1.outer_silence = 0;
                     if (f_res == DS_OK) {
                         f1.outer_padding_ok = 1;
@@ -817,13 +872,7 @@ struct Step {
                 }
             } else if (proc_state == STG_AB_TFF_TO_BFF || proc_state == STG_AB_BFF_TO_TFF) {
                 const bool tb = proc_state == STG_AB_TFF_TO_BFF;
-                if (tb) {
-                    stitch_resolution = res_for_seam(f1.even_resolution, f2.even_resolution);
-                    f_res = find_padding(f1e, f2e, f1.video_standard, stitch_resolution, &f1.outer_padding);
-                } else {
-                    stitch_resolution = res_for_seam(f1.odd_resolution, f2.odd_resolution);
-                    f_res = find_padding(f1o, f2o, f1.video_standard, stitch_resolution, &f1.outer_padding);
-                }
+                f1.outer_padding = found;
                 f1.outer_silence = 0;
                 if (f_res == DS_OK) {
                     f1.outer_padding_ok = 1;
@@ -867,7 +916,7 @@ struct Step {
     {
         if (!(BUF_FIELD >= (int)start && BUF_FIELD >= (int)start + (int)count)) return 0;
         for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) q[qn + i] = f.get(start + i);
-        if (count > 0) last_line = (uint16_t)(f.get(start + count - 1).line + 2);
+        if (count > 0) last_line = (uint16_t)uni((uint32_t)(f.get(start + count - 1).line + 2));
         qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; }
         return count;
     }
@@ -1044,7 +1093,7 @@ struct Step {
     {
         if (cfg.m2) return SDV_RES_MODE_14BIT;
         if (qn <= MIN_DEINT) return SDV_RES_MODE_14BIT_AUTO;
-        return block_res_mode(q[0], q[MIN_DEINT]);
+        return (uint8_t)uni(block_res_mode(q[0], q[MIN_DEINT]));
     }
     __device__ static inline void cwd_after_patch(SLine &l, bool &fixed)
     {
@@ -1056,14 +1105,34 @@ struct Step {
         const int nblk = qn - MIN_DEINT;
         bool fixed_any = false;
         WsSrc src; src.q = q;
+        /* Every change below is made to a line whose word failed its CRC (block.line_crc false) and that is either still
+         * unrepaired and eligible (bad CRC, valid coordinates, not forced bad, not of frame B) or already repaired (CRC valid
+         * again: it may get forced bad).  A block none of whose eight lines is such a line cannot change anything, so each
+         * class only decodes the blocks that touch one: candidate bits of the queue by ballot, then per class. */
+        __shared__ uint64_t s_bad[QCAP / 64];
+        for (int c = 0; c * 64 < qn; c++) {
+            const int i = c * 64 + lane;
+            bool bad = false;
+            if (i < qn) {
+                const SLine &l = q[i];
+                const bool forced = (l.flags & SL_FORCED_BAD) != 0, failed = forced || ((l.wcrc & 0xFF) != 0xFF);
+                const bool eligible = !crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced && l.frame != f2.frame_number;
+                bad = failed && (eligible || crc_valid(l));
+            }
+            const uint64_t m = __ballot(bad);
+            if (lane == 0) s_bad[c] = m;
+        }
+        __syncthreads();
         if (lane < ILV) {
-            for (int ofs = lane; ofs < nblk; ofs += ILV) {
-                if (!cfg.ignore_crc) {
-                    /* nothing to learn from a block whose eight lines all passed their CRC */
-                    bool all_ok = true;
-                    for (int k = 0; k < 8; k++) { const SLine &l = q[ofs + ILV * k]; all_ok = all_ok && !(l.flags & SL_FORCED_BAD) && ((l.wcrc & 0xFF) == 0xFF); }
-                    if (all_ok) continue;
-                }
+            uint64_t need = ~0ull;
+            if (!cfg.ignore_crc) {
+                uint64_t cb = 0;
+                for (int j = 0; lane + ILV * j < qn; j++) { const int i = lane + ILV * j; cb |= ((s_bad[i >> 6] >> (i & 63)) & 1ull) << j; }
+                need = cb | (cb >> 1) | (cb >> 2) | (cb >> 3) | (cb >> 4) | (cb >> 5) | (cb >> 6) | (cb >> 7);
+            }
+            for (int j = 0; lane + ILV * j < nblk; j++) {
+                if (!((need >> j) & 1)) continue;
+                const int ofs = lane + ILV * j;
                 Block b;
                 sdvd::process_block(ds, src, (size_t)ofs, b);
                 const int max_fixable = (!cfg.en_q || b.resolution == SDV_RES_16BIT) ? sdvd::WORD_P0 : sdvd::WORD_Q0;
@@ -1076,8 +1145,8 @@ struct Step {
                     if (!crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced && l.frame != f2.frame_number) {
                         const uint16_t wbit = (uint16_t)(1u << wi);
                         if (b.resolution == SDV_RES_14BIT) {
-                            if (l.words[wi] != b.words[wi]) {
-                                l.words[wi] = (uint16_t)(b.words[wi] & 0x3FFF);      /* setWord keeps the word's CRC flag */
+                            if (l.words[wi] != b.w(wi)) {
+                                l.words[wi] = (uint16_t)(b.w(wi) & 0x3FFF);      /* setWord keeps the word's CRC flag */
                                 l.calc_crc = crc_words(l.words);
                                 l.wvalid |= wbit;
                                 cwd_after_patch(l, fixed_any);
@@ -1086,11 +1155,10 @@ struct Step {
                                 if ((l.wvalid & 0xFF) == 0xFF) { l.calc_crc = crc_words(l.words); l.words[8] = l.calc_crc; l.wvalid |= 0x100; fixed_any = true; }
                             }
                         } else {
-                            const int s_ofs[7] = { 12, 10, 8, 6, 4, 2, 0 };
                             const uint16_t old_word = l.words[wi];
-                            uint16_t old_bitword = l.words[7], new_word = b.words[wi], new_bitword = (uint16_t)(new_word & 3);
+                            uint16_t old_bitword = l.words[7], new_word = b.w(wi), new_bitword = (uint16_t)(new_word & 3);
                             new_word = (uint16_t)(new_word >> 2);
-                            const int ofs_b = s_ofs[wi];
+                            const int ofs_b = 12 - 2 * wi;
                             new_bitword = (uint16_t)(new_bitword << ofs_b);
                             old_bitword = (uint16_t)(old_bitword & (3 << ofs_b));
                             if (old_word != new_word) {
@@ -1116,7 +1184,11 @@ struct Step {
                         }
                         q[ofs + ILV * wi] = l;
                     } else if (crc_valid(l)) {
-                        if (b.resolution == SDV_RES_14BIT && l.words[wi] != b.words[wi]) { l.flags |= SL_FORCED_BAD; q[ofs + ILV * wi] = l; }
+                        if (b.resolution == SDV_RES_14BIT && l.words[wi] != b.w(wi)) {
+                            l.flags |= SL_FORCED_BAD; q[ofs + ILV * wi] = l;
+                            const int jl = j + wi;                      /* the line now counts as failed for the blocks still to come */
+                            need |= jl >= 7 ? (0xFFull << (jl - 7)) : (0xFFull >> (7 - jl));
+                        }
                     }
                 }
             }
@@ -1137,7 +1209,7 @@ struct Step {
         }
         __syncthreads();
         for (;;) { bool more = perform_cwd(); __syncthreads(); if (!more) break; }
-        if (next) while (qn > 0 && q[qn - 1].frame == f2.frame_number) qn--;      /* removeNextFieldAfterCWD */
+        if (next) while (qn > 0 && uni(q[qn - 1].frame) == f2.frame_number) qn--;      /* removeNextFieldAfterCWD */
     }
 
     /* ---- performDeinterleave (:6675-6885) + outputSamplePair (:6525-6569) ---- */
@@ -1240,26 +1312,29 @@ __device__ inline void reset_state(Step &s)      /* resetState :69-89 (the stati
 }
 
 /* one turn of doFrameReassemble (:7284-7457) for step k */
+#ifdef SDV_EMU
+#define ST_STAMP(i) ((void)0)
+#else
+#define ST_STAMP(i) do { if (a.timing && lane == 0) a.timing[(size_t)k * 8 + (i)] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+#endif
 __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot, int lane)
 {
     const uint32_t k = work & 0x3FFFFFFFu;
     const int w_prev = (work >> 30) & 1, w_cur = (work >> 31) & 1;
+    ST_STAMP(0);
     const StepChain *in = k == 0 ? a.chain0 : &a.chain[w_prev][k - 1];
     StepChain *out = &a.chain[w_cur ^ 1][k];
     const StepChain *old = &a.chain[w_cur][k];
     Step s;
-    s.cfg = a.cfg; s.src = a.src; s.fl1 = &a.fl[k]; s.fl2 = &a.fl[k + 1]; s.lane = lane;
+    s.cfg = a.cfg; s.fields = a.fields; s.k = k; s.lane = lane;
+    s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2); s.fl1 = &s.l1; s.fl2 = &s.l2;
     s.q = a.ws + (size_t)slot * QCAP; s.overflow = false;
-    s.prob_order = a.prob_order[k]; s.prob_res = a.prob_res[k]; s.push_order = ORDER_UNK;
+    s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     s.out_pairs = a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
-    if (a.first_round && k > 0) {
-        /* first round: nothing is known about the predecessor yet, start from a freshly reset stitcher */
-        frasm_clear(s.f0); s.last_pad_counter = 0xFF; s.broken_countdown = 0; s.qn = 0;
-    } else {
-        s.f0 = in->f0; s.last_pad_counter = in->last_pad_counter; s.broken_countdown = in->broken_countdown;
-        s.qn = in->tail_n;
-        for (int i = lane; i < s.qn; i += 64) s.q[i] = in->tail[i];
-    }
+    s.f0 = in->f0; make_uniform(s.f0);
+    s.last_pad_counter = (uint8_t)uni(in->last_pad_counter); s.broken_countdown = (uint8_t)uni(in->broken_countdown);
+    s.qn = (int)uni(in->tail_n);
+    for (int i = lane; i < s.qn; i += 64) s.q[i] = in->tail[i];
     /* waitForTwoFrames / findFramesTrim / splitFramesToFields results come from the analysis pass */
     frasm_clear(s.f1); frasm_clear(s.f2);
     s.f1.frame_number = s.fl1->frame_number; s.f2.frame_number = s.fl2->frame_number;
@@ -1278,7 +1353,9 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     }
     frasm_clear_asm_stats(s.f1);
     s.f1.odd_ref = s.fl1->ref[0]; s.f1.even_ref = s.fl1->ref[1];
+    ST_STAMP(1);
     s.find_field_stitching();
+    ST_STAMP(2);
     sdv_frame_asm *fo = a.frasm + (size_t)k * FRASM_SLOT;
     uint8_t n_frasm = 0;
     if (s.file_start) {
@@ -1287,9 +1364,12 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
         n_frasm++; s.n_pairs = 1;
     }
     s.fill_frame_for_output();
+    ST_STAMP(3);
     s.prescan_frame();
     __syncthreads();
+    ST_STAMP(4);
     s.perform_deinterleave();
+    ST_STAMP(5);
     if (lane == 0) frasm_to_pod(s.f1, fo[n_frasm]);
     n_frasm++;
     s.f0 = s.f1;
@@ -1306,23 +1386,78 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     /* hand over to the next turn; note whether anything differs from what this turn produced last time */
     bool diff = false;
     {
-        const uint32_t *x = (const uint32_t *)&s.f0, *y = (const uint32_t *)&old->f0;
-        if (lane < (int)(sizeof(Frasm) / 4)) diff = x[lane] != y[lane];
-        if (lane == 0) diff = diff || old->last_pad_counter != s.last_pad_counter || old->broken_countdown != s.broken_countdown || old->tail_n != (uint16_t)tail_n;
+        uint32_t xw[sizeof(Frasm) / 4], yw[sizeof(Frasm) / 4];
+        const Frasm of = old->f0;
+        __builtin_memcpy(xw, &s.f0, sizeof(Frasm)); __builtin_memcpy(yw, &of, sizeof(Frasm));
+        for (unsigned i = 0; i < sizeof(Frasm) / 4; i++) diff = diff || xw[i] != yw[i];
+        diff = diff || old->last_pad_counter != s.last_pad_counter || old->broken_countdown != s.broken_countdown || old->tail_n != (uint16_t)tail_n;
         for (int i = lane; i < tail_n; i += 64) {
-            const SLine l = s.q[s.tail_ofs + i];
-            const uint32_t *u = (const uint32_t *)&l, *v = (const uint32_t *)&old->tail[i];
+            const SLine l = s.q[s.tail_ofs + i], ol = old->tail[i];
+            uint32_t u[8], v[8];
+            __builtin_memcpy(u, &l, 32); __builtin_memcpy(v, &ol, 32);
             for (int w = 0; w < 8; w++) diff = diff || u[w] != v[w];
             out->tail[i] = l;
         }
         if (lane == 0) { out->f0 = s.f0; out->last_pad_counter = s.last_pad_counter; out->broken_countdown = s.broken_countdown; out->tail_n = (uint16_t)tail_n; out->_pad[0] = out->_pad[1] = out->_pad[2] = 0; }
     }
-    const bool changed = __ballot(diff) != 0 || a.first_round != 0;
+    const bool changed = __ballot(diff) != 0;
     if (lane == 0) {
-        StepInfo inf; inf.n_pairs = s.n_pairs; inf.n_frasm = n_frasm; inf.changed = changed ? 1 : 0; inf.push_order = s.push_order; inf._pad = s.overflow ? 1 : 0;
+        StepInfo inf; inf.n_pairs = s.n_pairs; inf.n_frasm = n_frasm; inf.changed = changed ? 1 : 0; inf.push_order = s.push_order;
+        inf.bits = (uint8_t)((s.overflow ? SI_OVERFLOW : 0) | ((s.f0.inner_padding_ok && s.f0.outer_padding_ok && order_set(s.f0)) ? SI_STEADY : 0));
         a.info[k] = inf;
     }
     __syncthreads();
+    ST_STAMP(6);
+}
+
+
+/* ---- sdv_k_stitch_predict: what turn j will most likely hand over, for all j at once --------------------------------
+ * A tape in steady state keeps its field order and paddings (the reference's own fast path, STG_TRY_PREVIOUS): turn j's
+ * outcome is the template's decisions on frame j's own geometry, and its hand-over lines are the unpatched tail of
+ * frame j assembled with those paddings.  The prediction only has to be right often: every turn compares what it really
+ * produced with the prediction its successor was started from, and the successor is re-run on any difference. */
+struct PredictStArgs { const SLine *fields; const FrameLocal *fl; const StepChain *tmpl; StepChain *out; uint32_t first, n; };
+__device__ inline void predict_st_body(const PredictStArgs &a, uint32_t j, int lane)
+{
+    StepChain *o = &a.out[j];
+    Frasm f = a.tmpl->f0;
+    const uint8_t lpc = a.tmpl->last_pad_counter;
+    const FrameLocal *fl = &a.fl[j];
+    const bool steady = f.inner_padding_ok && f.outer_padding_ok && order_set(f);
+    int tail_n = 0;
+    if (!steady) { frasm_clear(f); }
+    else {
+        f.frame_number = fl->frame_number;
+        f.odd_top_data = fl->top[0]; f.odd_bottom_data = fl->bottom[0]; f.even_top_data = fl->top[1]; f.even_bottom_data = fl->bottom[1];
+        f.odd_data_lines = fl->data_lines[0]; f.even_data_lines = fl->data_lines[1];
+        f.trim_ok = (fl->flags & FL_TRIM_OK) != 0;
+        f.ctrl_index = fl->ctrl[0]; f.ctrl_hour = fl->ctrl[1]; f.ctrl_minute = fl->ctrl[2]; f.ctrl_second = fl->ctrl[3]; f.ctrl_field = fl->ctrl[4];
+        f.tff_cnt = f.field_order == ORDER_TFF ? lpc : 0; f.bff_cnt = f.field_order == ORDER_BFF ? lpc : 0;
+        /* tail of [first field, inner padding, second field, outer padding] */
+        const int p1 = f.field_order == ORDER_TFF ? 0 : 1, p2 = 1 - p1;
+        const int target = f.video_standard == VID_PAL ? LINES_PF_PAL : LINES_PF_NTSC;
+        int c1 = fl->data_lines[p1], c2 = fl->data_lines[p2];
+        if (c1 > target) c1 = target;
+        if (c2 > target) c2 = target;
+        const int in_pad = f.inner_padding, out_pad = f.outer_padding, total = c1 + in_pad + c2 + out_pad;
+        const SLine *l1 = field_lines(a.fields, j, p1), *l2 = field_lines(a.fields, j, p2);
+        const uint16_t ln1 = c1 > 0 ? (uint16_t)(l1[c1 - 1].line + 2) : (uint16_t)(p1 == 0 ? 1 : 2);
+        const uint16_t ln2 = c2 > 0 ? (uint16_t)(l2[c2 - 1].line + 2) : (uint16_t)(p2 == 0 ? 1 : 2);
+        tail_n = total < MIN_DEINT ? total : MIN_DEINT;
+        for (int i = lane; i < tail_n; i += 64) {
+            const int pos = total - tail_n + i;
+            SLine l;
+            if (pos < c1) l = l1[pos];
+            else if (pos < c1 + in_pad) l = sline_empty(fl->frame_number, (uint16_t)(ln1 + 2 * (pos - c1)));
+            else if (pos < c1 + in_pad + c2) l = l2[pos - c1 - in_pad];
+            else l = sline_empty(fl->frame_number, (uint16_t)(ln2 + 2 * (pos - c1 - in_pad - c2)));
+            o->tail[i] = l;
+        }
+    }
+    if (lane == 0) {
+        o->f0 = f; o->last_pad_counter = steady ? lpc : (uint8_t)0xFF; o->broken_countdown = 0; o->tail_n = (uint16_t)tail_n;
+        o->_pad[0] = o->_pad[1] = o->_pad[2] = 0;
+    }
 }
 
 /* ---- sdv_k_stitch_compact: per-step slots -> contiguous streams ---------------------------------------------------- */
@@ -1363,9 +1498,13 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a) { sdvs::analyze_body(a, blockIdx.x, (int)threadIdx.x); }
-__global__ void __launch_bounds__(64) sdv_k_stitch_step(sdvs::StepArgs a)
+#ifndef SDV_ST_WAVES
+#define SDV_ST_WAVES 1
+#endif
+__global__ void __launch_bounds__(64, SDV_ST_WAVES) sdv_k_stitch_step(sdvs::StepArgs a)
 {
     for (uint32_t w = blockIdx.x; w < a.n_work; w += gridDim.x) sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x);
 }
+__global__ void __launch_bounds__(64) sdv_k_stitch_predict(sdvs::PredictStArgs a) { sdvs::predict_st_body(a, a.first + blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_compact(sdvs::CompactArgs a) { sdvs::compact_body(a, blockIdx.x, (int)threadIdx.x, 64); }
 #endif

@@ -1,0 +1,22 @@
+"""Profiling driver of the stitch stage: N synthetic NTSC frames -> binarize -> stitch (3 timed calls)."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+from sdvpcmdecoder_amd import Engine, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+eng = Engine(0)
+luma, _ = synth.stc007_frames_torch(n, seed=2, device='cuda', noise_sigma=4.0)
+lines, _ = eng.binarize_frames(luma, first_frame_no=1, new_file=True)
+torch.cuda.synchronize()
+eng.set_profiling(True)
+out_p = torch.empty((n * 1470 + 20000, 12), dtype=torch.uint8, device='cuda')
+out_f = torch.empty((n + 64, 64), dtype=torch.uint8, device='cuda')
+for it in range(reps):
+    eng.reset_stitcher()
+    t0 = time.perf_counter()
+    p, f = eng.stitch_frames(lines, out_pairs=out_p, out_frames=out_f)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    info = eng.stitch_info()
+    print(f"n={n} it={it}: wall {dt*1e3:.2f} ms device {info.device_ms:.2f} ms steps {info.steps} rounds {info.rounds} launched {info.steps_launched} pairs {p.shape[0]}", flush=True)
