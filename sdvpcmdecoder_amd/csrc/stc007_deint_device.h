@@ -125,6 +125,18 @@ struct PtrSrc {
     __device__ inline const sdv_deint_line &line(size_t i) const { return p[i]; }
 };
 
+/* the eight lines of one block (line base + 16k -> slot k), gathered once so that a resolution re-try or the fast path
+ * below does not go back to memory */
+struct Lines8 {
+    sdv_deint_line l[8];
+    __device__ inline const sdv_deint_line &line(size_t i) const { return l[i / INTERLEAVE_OFS]; }
+};
+template <class Src>
+__device__ inline void gather8(const Src &src, size_t base, Lines8 &out)
+{
+    for (int k = 0; k < 8; k++) out.l[k] = src.line(base + (size_t)INTERLEAVE_OFS * k);
+}
+
 template <class Src>
 __device__ inline void set_word_data(const sdv_deint_settings &st, const Src &lines, size_t base, Block &b, uint8_t res)
 {
@@ -192,10 +204,10 @@ __device__ inline uint8_t fix_by_q(Block &b, uint8_t first_bad, uint8_t second_b
     return (e1 == 0 && e2 == 0) ? FIX_NOT_NEED : FIX_DONE;
 }
 
-/* STC007Deinterleaver::processBlock for the block that starts at assembled line `base` */
-template <class Src>
-__device__ inline void process_block(const sdv_deint_settings &st, const Src &lines, size_t base, Block &out)
+/* the full state machine of STC007Deinterleaver::processBlock (process_block() below tries its two short cuts first) */
+__device__ inline void process_block_fsm(const sdv_deint_settings &st, const Lines8 &lines, Block &out)
 {
+    const size_t base = 0;
     uint8_t run_res, stage_count = 0, fill_passes, all_errs = 0, aud_errs = 0, first_bad = NO_ERR_INDEX, second_bad = NO_ERR_INDEX, fix, state = STG_DATA_FILL;
     if (st.res_mode == SDV_RES_MODE_14BIT) { run_res = SDV_RES_14BIT; fill_passes = MAX_PASSES; }
     else if (st.res_mode == SDV_RES_MODE_14BIT_AUTO) { run_res = SDV_RES_14BIT; fill_passes = 0; }
@@ -294,13 +306,66 @@ __device__ inline void process_block(const sdv_deint_settings &st, const Src &li
     }
 }
 
+/* STC007Deinterleaver::processBlock for the block whose eight lines were gathered into `lines` (base = 0) */
+__device__ inline void process_block(const sdv_deint_settings &st, const Lines8 &lines, size_t base, Block &out)
+{
+    uint8_t run_res;
+    run_res = (st.res_mode == SDV_RES_MODE_14BIT || st.res_mode == SDV_RES_MODE_14BIT_AUTO) ? SDV_RES_14BIT : SDV_RES_16BIT;
+    /* Short cut for the block a clean tape is made of: no word failed its CRC.  The stages then reduce to
+     * ERROR_CHECK (no errors) -> TASK_SELECTION -> [P_CORR: P syndrome 0 -> FIX_NOT_NEED -> Q syndrome 0] -> DATA_OK
+     * and leave the block exactly as DATA_FILL made it.  Anything else takes the full state machine below. */
+    blk_clear(out);
+    set_word_data(st, lines, base, out, run_res);
+    out.audio_state = SDV_AUD_ORIG;
+    const uint8_t bad = (uint8_t)(~out.line_crc & total_mask(out));
+    if (bad == 0) {
+        if (!st.force_ecc_check || !st.en_p_code) return;
+        if ((uint16_t)(calc_p(out) ^ out.w(WORD_P0)) == 0) {
+            if (!(run_res == SDV_RES_14BIT && st.en_q_code)) return;
+            if ((uint16_t)(calc_q(out) ^ out.w(WORD_Q0)) == 0) return;
+        }
+    } else if (run_res == SDV_RES_14BIT && (bad & (bad - 1)) == 0) {
+        /* Second short cut, the block next to a lost line: exactly one word failed its CRC (14-bit mode).
+         *   audio word k: TASK_SELECTION -> P_CORR: fixByP(k) (FIX_DONE or FIX_NOT_NEED) -> audio state FIX_P -> Q syndrome check
+         *   P word      : P_CORR finds P invalid -> Q_CORR: fixByQ(none, P): Q syndrome 0 -> recalcP -> FIX_NOT_NEED
+         *   Q word      : P_CORR: fixByP(none): P syndrome 0 -> FIX_NOT_NEED -> Q word recomputed
+         * Whatever does not end well here (a syndrome that does not vanish) restarts in the state machine below. */
+        if (bad & 0x3F) {
+            if (st.en_p_code) {
+                const uint8_t k = (uint8_t)(__ffs((int)bad) - 1);
+                (void)fix_by_p(out, k);
+                blk_clear_cwd(out, k);
+                out.audio_state = SDV_AUD_FIX_P;
+                if (!st.en_q_code) return;
+                if (!(st.force_ecc_check && (uint16_t)(calc_q(out) ^ out.w(WORD_Q0)) != 0)) return;
+            }
+        } else if (bad == (1u << WORD_P0)) {
+            if (!st.force_ecc_check || !st.en_p_code || !st.en_q_code) return;      /* DATA_OK / NO_CHECK / P_CORR -> NO_CHECK */
+            if ((uint16_t)(calc_q(out) ^ out.w(WORD_Q0)) == 0) { recalc_p(out); blk_clear_cwd(out, WORD_P0); return; }
+        } else {
+            if (!st.force_ecc_check || !st.en_p_code) return;
+            if ((uint16_t)(calc_p(out) ^ out.w(WORD_P0)) == 0) {
+                if (st.en_q_code) {
+                    const uint16_t q = calc_q(out);
+                    if (out.w(WORD_Q0) != q) { blk_set_word(out, WORD_Q0, q, false, false); blk_set_fixed(out, WORD_Q0); }
+                    else blk_set_valid(out, WORD_Q0);
+                }
+                return;
+            }
+        }
+    }
+    process_block_fsm(st, lines, out);
+}
+
 struct DeintArgs { const sdv_deint_line *lines; size_t n_blocks; sdv_deint_settings st; sdv_block_rec *out; };
 
 __device__ inline void deint_body(const DeintArgs &a, size_t s)
 {
     Block b;
     PtrSrc src; src.p = a.lines;
-    process_block(a.st, src, s, b);
+    Lines8 l8;
+    gather8(src, s, l8);
+    process_block(a.st, l8, 0, b);
     sdv_block_rec r;
     for (int i = 0; i < 8; i++) { r.w_frame[i] = b.w_frame[i]; r.w_line[i] = b.w_line[i]; r.words[i] = b.w(i); }
     r.line_crc = b.line_crc; r.cwd_fixed = b.cwd_fixed; r.word_valid = b.word_valid; r.resolution = b.resolution;

@@ -93,6 +93,8 @@ __device__ inline SLine sline_from_rec(const sdv_line_rec &r)
     l.ref_level = r.ref_level;
     return l;
 }
+__device__ inline uint16_t sl_word(const SLine &l, int i) { uint16_t r = 0; for (int k = 0; k < 8; k++) r = k == i ? l.words[k] : r; return r; }
+__device__ inline void sl_set_word(SLine &l, int i, uint16_t v) { for (int k = 0; k < 8; k++) l.words[k] = k == i ? v : l.words[k]; }
 __device__ inline bool crc_valid_if(const SLine &l) { return l.calc_crc == l.words[8]; }                 /* isCRCValidIgnoreForced */
 __device__ inline bool crc_valid(const SLine &l) { return !(l.flags & SL_FORCED_BAD) && crc_valid_if(l); }   /* isCRCValid */
 __device__ inline sdv_deint_line view(const SLine &l)     /* what STC007Deinterleaver::setWordData reads of a line */
@@ -319,11 +321,13 @@ __device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int l
         int i = c * 64 + lane;
         bool act = i < test;
         uint64_t good[2], brk[2];
+        sdvd::Lines8 l8;
+        if (act) sdvd::gather8(src, (size_t)i, l8);
         for (int m = 0; m < 2; m++) {
             bool g = false, k = false;
             if (act) {
                 Block b;
-                sdvd::process_block(deint_cfg(m == 0 ? SDV_RES_MODE_14BIT : SDV_RES_MODE_16BIT, false, true, true, false, false), src, (size_t)i, b);
+                sdvd::process_block(deint_cfg(m == 0 ? SDV_RES_MODE_14BIT : SDV_RES_MODE_16BIT, false, true, true, false, false), l8, 0, b);
                 g = blk_valid(b) && can_force_check(b) && !blk_silent(b, cfg.m2);
                 k = b.audio_state == SDV_AUD_BROKEN;
             }
@@ -522,7 +526,7 @@ enum { STG_TRY_PREVIOUS = 0, STG_TRY_TFF_TO_TFF, STG_TRY_BFF_TO_BFF, STG_A_PREPA
        STG_AB_TFF_TO_TFF, STG_AB_TFF_TO_BFF, STG_AB_BFF_TO_BFF, STG_AB_BFF_TO_TFF, STG_PAD_NO_GOOD, STG_PAD_SILENCE, STG_PAD_OK, STG_PAD_MAX };
 
 struct Step {
-    Cfg cfg; const SLine *fields; uint32_t k; FrameLocal l1, l2; const FrameLocal *fl1, *fl2;
+    Cfg cfg; const SLine *fields; uint32_t k; FrameLocal l1, l2;      /* frame A, frame B */
     Frasm f0, f1, f2;
     uint8_t last_pad_counter, broken_countdown, prob_order, prob_res, push_order;
     bool file_start, file_end;
@@ -539,10 +543,11 @@ struct Step {
     /* resolution a line was detected with (getDataBlockResolution's per-line lookup, :1290-1400) */
     __device__ inline uint8_t line_res(uint32_t frame, uint16_t line) const
     {
-        bool even = (line % 2) == 0;
-        if (frame == f2.frame_number) return even ? f2.even_resolution : f2.odd_resolution;
-        if (frame == f1.frame_number) return even ? f1.even_resolution : f1.odd_resolution;
-        if (frame == f0.frame_number) return even ? f0.even_resolution : f0.odd_resolution;
+        /* (both fields read, then blended: a conditional read would keep the whole turn state in memory) */
+        const uint32_t m = (line % 2) == 0 ? 0xFFu : 0u;
+        if (frame == f2.frame_number) return (uint8_t)((f2.even_resolution & m) | (f2.odd_resolution & ~m));
+        if (frame == f1.frame_number) return (uint8_t)((f1.even_resolution & m) | (f1.odd_resolution & ~m));
+        if (frame == f0.frame_number) return (uint8_t)((f0.even_resolution & m) | (f0.odd_resolution & ~m));
         return SDV_RES_MODE_14BIT;
     }
     __device__ inline uint8_t block_res_mode(const SLine &first, const SLine &last) const
@@ -574,8 +579,9 @@ struct Step {
             int i = c * 64 + lane;
             bool v = false, sl = false, u = false, br = false;
             if (i < nblk) {
-                Block b;
-                sdvd::process_block(ds, pq, (size_t)i, b);
+                Block b; sdvd::Lines8 l8;
+                sdvd::gather8(pq, (size_t)i, l8);
+                sdvd::process_block(ds, l8, 0, b);
                 bool silent = blk_silent(b, cfg.m2), force = can_force_check(b);
                 v = blk_valid(b) && !silent && force;
                 sl = silent;
@@ -653,14 +659,12 @@ struct Step {
         return stitch_res;
     }
     /* findPadding's statistics table lives in LDS (one wave per workgroup): lane-uniform values, written by lane 0 */
+    __device__ static inline FieldStitchStats *sd_tab() { __shared__ FieldStitchStats s_sd[MAX_PADDING_14BIT]; return s_sd; }
     __device__ inline void sd_store(int p, const FieldStitchStats &v)
     {
-        __shared__ FieldStitchStats s_sd[MAX_PADDING_14BIT];
-        if (lane == 0) s_sd[p] = v;
-        sd_table = s_sd;
+        if (lane == 0) sd_tab()[p] = v;
         __syncthreads();
     }
-    FieldStitchStats *sd_table;
     /* the two smallest entries of the table under FieldStitchStats::operator< ; remap = the second ranking of findPadding
      * (:1990-2030): broken := min_broken, or 0xFF where unchecked >= limit - applied to untouched entries too */
     __device__ inline void sd_best2(int n_tried, int n_total, bool remap, uint16_t min_broken, uint8_t unchecked_lim, FieldStitchStats &s0, FieldStitchStats &s1)
@@ -668,7 +672,7 @@ struct Step {
         FieldStitchStats b0, b1; bool h0 = false, h1 = false;
         for (int i = 0; i < n_total; i++) {
             FieldStitchStats e;
-            if (i < n_tried) e = sd_table[i]; else stats_clear(e);
+            if (i < n_tried) e = sd_tab()[i]; else stats_clear(e);
             if (remap) { e.broken = min_broken; if (e.unchecked >= unchecked_lim) e.broken = 0xFF; }
             if (!h0) { b0 = e; h0 = true; }
             else if (stats_lt(e, b0)) { b1 = b0; h1 = true; b0 = e; }
@@ -687,7 +691,7 @@ struct Step {
     __device__ inline void detect_audio_resolution()
     {
         if (cfg.m2) { f1.odd_resolution = f1.even_resolution = f2.odd_resolution = f2.even_resolution = SDV_RES_MODE_14BIT; return; }
-        const uint8_t f1o = fl1->field_res[0], f1e = fl1->field_res[1], f2o = fl2->field_res[0], f2e = fl2->field_res[1];
+        const uint8_t f1o = l1.field_res[0], f1e = l1.field_res[1], f2o = l2.field_res[0], f2e = l2.field_res[1];
         const uint8_t prob_mode = prob_res == SRES_16BIT ? SDV_RES_MODE_16BIT_AUTO : SDV_RES_MODE_14BIT_AUTO;
         if (f1o == SRES_UNKNOWN && f1e == SRES_UNKNOWN) {
             if (f2o == SRES_UNKNOWN && f2e == SRES_UNKNOWN) f1.odd_resolution = f1.even_resolution = f2.odd_resolution = f2.even_resolution = prob_mode;
@@ -729,7 +733,7 @@ struct Step {
             uint16_t a = f1.odd_data_lines, b = f1.even_data_lines, c = f2.odd_data_lines, d = f2.even_data_lines;
             if (a > LINES_PF_MAX_PAL || b > LINES_PF_MAX_PAL || c > LINES_PF_MAX_PAL || d > LINES_PF_MAX_PAL) f1.video_standard = VID_UNKNOWN;
             else if (a > LINES_PF_MAX_NTSC || b > LINES_PF_MAX_NTSC || c > LINES_PF_MAX_NTSC || d > LINES_PF_MAX_NTSC) f1.video_standard = VID_PAL;
-            else f1.video_standard = fl1->max_line <= ((LINES_PF_PAL - ILV) * 2) ? VID_NTSC : VID_PAL;
+            else f1.video_standard = l1.max_line <= ((LINES_PF_PAL - ILV) * 2) ? VID_NTSC : VID_PAL;
         } else { f1.vid_std_preset = 1; f1.video_standard = cfg.preset_video_mode; }
         if (f1.video_standard == VID_UNKNOWN) f1.video_standard = f0.video_standard;
         if (f1.video_standard == VID_NTSC) f1.odd_std_lines = f1.even_std_lines = LINES_PF_NTSC;
@@ -777,8 +781,10 @@ struct Step {
             uint16_t found = 0;
             f_res = DS_NO_PAD;
             if (kind != 0) {
-                const Field &fa = a_sel == 0 ? f1o : f1e;
-                const Field &fb = b_sel == 0 ? f1o : (b_sel == 1 ? f1e : (b_sel == 2 ? f2o : f2e));
+                Field fa, fb;
+                fa.lines = a_sel == 0 ? f1o.lines : f1e.lines; fa.size = a_sel == 0 ? f1o.size : f1e.size;
+                fb.lines = b_sel == 0 ? f1o.lines : (b_sel == 1 ? f1e.lines : (b_sel == 2 ? f2o.lines : f2e.lines));
+                fb.size = b_sel == 0 ? f1o.size : (b_sel == 1 ? f1e.size : (b_sel == 2 ? f2o.size : f2e.size));
                 f_res = pad_search(kind == 2, fa, fb, pad_in, f1.video_standard, sres, &found);
             }
             /* -- 2. the stage */
@@ -1133,8 +1139,9 @@ struct Step {
             for (int j = 0; lane + ILV * j < nblk; j++) {
                 if (!((need >> j) & 1)) continue;
                 const int ofs = lane + ILV * j;
-                Block b;
-                sdvd::process_block(ds, src, (size_t)ofs, b);
+                Block b; sdvd::Lines8 l8;
+                sdvd::gather8(src, (size_t)ofs, l8);
+                sdvd::process_block(ds, l8, 0, b);
                 const int max_fixable = (!cfg.en_q || b.resolution == SDV_RES_16BIT) ? sdvd::WORD_P0 : sdvd::WORD_Q0;
                 const bool data_fixed = (~b.line_crc & b.word_valid & 0xFF) != 0;          /* isDataFixed, stc007datablock.cpp:371-384 */
                 if (!(blk_valid(b) && data_fixed)) continue;
@@ -1145,8 +1152,8 @@ struct Step {
                     if (!crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced && l.frame != f2.frame_number) {
                         const uint16_t wbit = (uint16_t)(1u << wi);
                         if (b.resolution == SDV_RES_14BIT) {
-                            if (l.words[wi] != b.w(wi)) {
-                                l.words[wi] = (uint16_t)(b.w(wi) & 0x3FFF);      /* setWord keeps the word's CRC flag */
+                            if (sl_word(l, wi) != b.w(wi)) {
+                                sl_set_word(l, wi, (uint16_t)(b.w(wi) & 0x3FFF));      /* setWord keeps the word's CRC flag */
                                 l.calc_crc = crc_words(l.words);
                                 l.wvalid |= wbit;
                                 cwd_after_patch(l, fixed_any);
@@ -1155,7 +1162,7 @@ struct Step {
                                 if ((l.wvalid & 0xFF) == 0xFF) { l.calc_crc = crc_words(l.words); l.words[8] = l.calc_crc; l.wvalid |= 0x100; fixed_any = true; }
                             }
                         } else {
-                            const uint16_t old_word = l.words[wi];
+                            const uint16_t old_word = sl_word(l, wi);
                             uint16_t old_bitword = l.words[7], new_word = b.w(wi), new_bitword = (uint16_t)(new_word & 3);
                             new_word = (uint16_t)(new_word >> 2);
                             const int ofs_b = 12 - 2 * wi;
@@ -1164,7 +1171,7 @@ struct Step {
                             if (old_word != new_word) {
                                 /* setWord(index, word, isWordCRCOk(index)) also rewrites word_valid with the CRC flag (stc007line.cpp:158-173) */
                                 const bool wc = !forced && (l.wcrc & wbit);
-                                l.words[wi] = (uint16_t)(new_word & 0x3FFF);
+                                sl_set_word(l, wi, (uint16_t)(new_word & 0x3FFF));
                                 l.wcrc = wc ? (l.wcrc | wbit) : (l.wcrc & ~wbit);
                                 l.calc_crc = crc_words(l.words);
                                 l.wvalid |= wbit;
@@ -1184,7 +1191,7 @@ struct Step {
                         }
                         q[ofs + ILV * wi] = l;
                     } else if (crc_valid(l)) {
-                        if (b.resolution == SDV_RES_14BIT && l.words[wi] != b.w(wi)) {
+                        if (b.resolution == SDV_RES_14BIT && sl_word(l, wi) != b.w(wi)) {
                             l.flags |= SL_FORCED_BAD; q[ofs + ILV * wi] = l;
                             const int jl = j + wi;                      /* the line now counts as failed for the blocks still to come */
                             need |= jl >= 7 ? (0xFFull << (jl - 7)) : (0xFFull >> (7 - jl));
@@ -1249,8 +1256,15 @@ struct Step {
             Block b; sdvd::blk_clear(b);
             bool ns = false, seam = false, brk = false;
             if (act) {
-                uint8_t mode = cfg.m2 ? (uint8_t)SDV_RES_MODE_14BIT : block_res_mode(q[i], q[i + MIN_DEINT]);
-                sdvd::process_block(deint_cfg(mode, cfg.ignore_crc, !cfg.ignore_crc, cfg.en_p, cfg.en_q, cfg.en_cwd), src, (size_t)i, b);
+                sdvd::Lines8 l8;
+                sdvd::gather8(src, (size_t)i, l8);
+                const uint8_t mode = cfg.m2 ? (uint8_t)SDV_RES_MODE_14BIT
+                                     : res_mode_for_seam(line_res(l8.l[0].frame_number, l8.l[0].line_number), line_res(l8.l[7].frame_number, l8.l[7].line_number));
+#if SDV_ST_ABL != 1
+                sdvd::process_block(deint_cfg(mode, cfg.ignore_crc, !cfg.ignore_crc, cfg.en_p, cfg.en_q, cfg.en_cwd), l8, 0, b);
+#else
+                b.wlo = l8.l[0].words[0] + mode; b.w_frame[0] = l8.l[0].frame_number; b.w_frame[7] = l8.l[7].frame_number;
+#endif
                 ns = !blk_silent(b, cfg.m2);
                 if (ns && cfg.mask_seams) {
                     if (!f1.inner_padding_ok && !f1.inner_silence)
@@ -1279,15 +1293,21 @@ struct Step {
                 valid = blk_valid(b);
                 errs = errors_audio_fixed(b);
             }
+#if SDV_ST_ABL != 2
             fix_p += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_P));
             fix_q += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_Q));
             fix_cwd += (uint32_t)__popcll(__ballot(rep && valid && b.cwd_applied && b.cwd_fixed != 0));
             drop += (uint32_t)__popcll(__ballot(rep && !valid));
             brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
             for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
+#endif
             if (act) {
                 sdv_sample_pair *o = out_pairs + n_pairs + 3u * (uint32_t)i;
+#if SDV_ST_ABL == 3
+                if (n_pairs + 3u * (uint32_t)i + 3u <= PAIR_SLOT && b.wlo == 12345) { o[0] = make_pair(b, 0, 1, rate); }
+#else
                 if (n_pairs + 3u * (uint32_t)i + 3u <= PAIR_SLOT) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
+#endif
             }
         }
         if (nblk > 0) {
@@ -1305,6 +1325,16 @@ struct Step {
     int tail_ofs;
 };
 
+__device__ inline void frasm_set_trim(Frasm &fr, const FrameLocal &fl)      /* what findFramesTrim left in the descriptor */
+{
+    fr.odd_top_data = fl.top[0]; fr.odd_bottom_data = fl.bottom[0]; fr.even_top_data = fl.top[1]; fr.even_bottom_data = fl.bottom[1];
+    fr.trim_ok = (fl.flags & FL_TRIM_OK) != 0;
+    fr.ctrl_index = fl.ctrl[0]; fr.ctrl_hour = fl.ctrl[1]; fr.ctrl_minute = fl.ctrl[2]; fr.ctrl_second = fl.ctrl[3]; fr.ctrl_field = fl.ctrl[4];
+}
+__device__ inline void frasm_set_counts(Frasm &fr, const FrameLocal &fl)    /* what splitFramesToFields counted */
+{
+    fr.odd_data_lines = fl.data_lines[0]; fr.even_data_lines = fl.data_lines[1]; fr.odd_valid_lines = fl.valid_lines[0]; fr.even_valid_lines = fl.valid_lines[1];
+}
 __device__ inline void reset_state(Step &s)      /* resetState :69-89 (the statistics rings live in the engine) */
 {
     s.qn = 0; s.last_pad_counter = 0xFF; s.broken_countdown = 0;
@@ -1327,7 +1357,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     const StepChain *old = &a.chain[w_cur][k];
     Step s;
     s.cfg = a.cfg; s.fields = a.fields; s.k = k; s.lane = lane;
-    s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2); s.fl1 = &s.l1; s.fl2 = &s.l2;
+    s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2);
     s.q = a.ws + (size_t)slot * QCAP; s.overflow = false;
     s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     s.out_pairs = a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
@@ -1337,22 +1367,14 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     for (int i = lane; i < s.qn; i += 64) s.q[i] = in->tail[i];
     /* waitForTwoFrames / findFramesTrim / splitFramesToFields results come from the analysis pass */
     frasm_clear(s.f1); frasm_clear(s.f2);
-    s.f1.frame_number = s.fl1->frame_number; s.f2.frame_number = s.fl2->frame_number;
-    s.file_start = (s.fl1->flags & FL_NEW_FILE) != 0;
-    s.file_end = ((s.fl1->flags | s.fl2->flags) & FL_END_FILE) != 0;
-    for (int f = 0; f < 2; f++) {
-        Frasm &fr = f == 0 ? s.f1 : s.f2; const FrameLocal *fl = f == 0 ? s.fl1 : s.fl2;
-        fr.odd_top_data = fl->top[0]; fr.odd_bottom_data = fl->bottom[0]; fr.even_top_data = fl->top[1]; fr.even_bottom_data = fl->bottom[1];
-        fr.trim_ok = (fl->flags & FL_TRIM_OK) != 0;
-        fr.ctrl_index = fl->ctrl[0]; fr.ctrl_hour = fl->ctrl[1]; fr.ctrl_minute = fl->ctrl[2]; fr.ctrl_second = fl->ctrl[3]; fr.ctrl_field = fl->ctrl[4];
-    }
+    s.f1.frame_number = s.l1.frame_number; s.f2.frame_number = s.l2.frame_number;
+    s.file_start = (s.l1.flags & FL_NEW_FILE) != 0;
+    s.file_end = ((s.l1.flags | s.l2.flags) & FL_END_FILE) != 0;
+    frasm_set_trim(s.f1, s.l1); frasm_set_trim(s.f2, s.l2);
     if (s.file_start) reset_state(s);
-    for (int f = 0; f < 2; f++) {
-        Frasm &fr = f == 0 ? s.f1 : s.f2; const FrameLocal *fl = f == 0 ? s.fl1 : s.fl2;
-        fr.odd_data_lines = fl->data_lines[0]; fr.even_data_lines = fl->data_lines[1]; fr.odd_valid_lines = fl->valid_lines[0]; fr.even_valid_lines = fl->valid_lines[1];
-    }
+    frasm_set_counts(s.f1, s.l1); frasm_set_counts(s.f2, s.l2);
     frasm_clear_asm_stats(s.f1);
-    s.f1.odd_ref = s.fl1->ref[0]; s.f1.even_ref = s.fl1->ref[1];
+    s.f1.odd_ref = s.l1.ref[0]; s.f1.even_ref = s.l1.ref[1];
     ST_STAMP(1);
     s.find_field_stitching();
     ST_STAMP(2);
@@ -1498,6 +1520,9 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a) { sdvs::analyze_body(a, blockIdx.x, (int)threadIdx.x); }
+#ifndef SDV_ST_ABL
+#define SDV_ST_ABL 0
+#endif
 #ifndef SDV_ST_WAVES
 #define SDV_ST_WAVES 1
 #endif

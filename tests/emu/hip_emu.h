@@ -142,6 +142,7 @@ inline Idx3 gdim() { return Idx3{ st().grid_dim.x, 1, 1 }; }
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 static inline unsigned __brev(unsigned v)

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-SDV_STITCH_TIMING=1 python3 tools/stitch_prof.py 10000 2 2>&1 | tail -4
-SDV_STITCH_TIMING=1 python3 tools/stitch_prof.py 256 2 2>&1 | tail -4
+for v in "" build/variants/st_a4.so; do
+  echo "== variant: ${v:-default}"
+  SDV_STITCH_TIMING=1 SDVPCM_LIB=$v python3 tools/stitch_prof.py 256 2 2>&1 | tail -2 | head -1
+done
