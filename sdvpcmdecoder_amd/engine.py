@@ -239,7 +239,7 @@ class Engine:
         assert lines.is_cuda and lines.dtype == torch.uint8 and lines.dim() == 2 and lines.shape[1] == 48 and lines.is_contiguous()
         n = lines.shape[0]
         if out_pairs is None:
-            out_pairs = torch.empty((n * 3 + 8192, 12), dtype=torch.uint8, device=lines.device)
+            out_pairs = torch.empty((n * 13 // 4 + 8192, 12), dtype=torch.uint8, device=lines.device)   # 3 pairs per assembled line + padding
         if out_frames is None:
             out_frames = torch.empty((n // 8 + 64, 64), dtype=torch.uint8, device=lines.device)
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)

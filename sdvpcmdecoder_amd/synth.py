@@ -191,8 +191,10 @@ def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 
 # ------------------------------------------------------------------------------------------------
 def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int = 720, height: int = 486,
                         lines_per_field: int = 245, cut_top: int | None = None, black: int = 30, white: int = 200,
-                        x0: int = 12, x1: int | None = None, noise_sigma: float = 0.0, chunk_frames: int = 256):
-    """Returns (luma (n_frames, height, width) uint8 on `device`, words (n_stream_lines, 9) int32 on `device`)."""
+                        x0: int = 12, x1: int | None = None, noise_sigma: float = 0.0, chunk_frames: int = 256, cyclic: bool = False):
+    """Returns (luma (n_frames, height, width) uint8 on `device`, words (n_stream_lines, 9) int32 on `device`).
+    cyclic=True interleaves the audio blocks around the end of the batch, so that playing the batch again and again is one
+    seamless tape (used by the benchmark, which keeps a single batch resident in HBM)."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -211,7 +213,10 @@ def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int 
     blk = torch.cat([audio, p[:, None], q[:, None]], dim=1)
     lines = torch.zeros((n_stream, 8), dtype=torch.int32, device=device)
     for k in range(8):
-        lines[16 * k:, k] = blk[:n_stream - 16 * k, k]
+        if cyclic:
+            lines[:, k] = torch.roll(blk[:, k], 16 * k)
+        else:
+            lines[16 * k:, k] = blk[:n_stream - 16 * k, k]
     crc = torch.full((n_stream,), 0xFFFF, dtype=torch.int32, device=device)
     for k in range(8):
         for bit in range(13, -1, -1):
