@@ -254,7 +254,10 @@ int sdv_set_chain_state(sdv_engine *e, const sdv_v2d_state *in);
 /* flags of sdv_binarize_frames */
 enum {
     SDV_FLAG_NEW_FILE = 1u << 0,    /* first frame of a source: a NEW_FILE service line precedes it (vin_ffmpeg.cpp:275-280) */
-    SDV_FLAG_DOUBLED = 1u << 1      /* rows were width-doubled upstream (VideoLine::isDoubleWidth, ffmpegwrapper.cpp:179-186) */
+    SDV_FLAG_DOUBLED = 1u << 1,     /* rows were width-doubled upstream (VideoLine::isDoubleWidth, ffmpegwrapper.cpp:179-186) */
+    SDV_FLAG_END_FILE = 1u << 2     /* last frames of a source: the filler frame + END_FILE line the input plugin appends follow them
+                                     * (VideoInFFMPEG::insertDummyFrame(true, false), vin_ffmpeg.cpp:367-523): height + 4 more records,
+                                     * one more sdv_frame_stats row */
 };
 
 /* How the last sdv_binarize_frames call was scheduled (chain speculation). */
@@ -286,8 +289,11 @@ size_t sdv_records_per_frame(int height);
  *  out_lines    device pointer, (height+3)*n_frames records (+1 leading NEW_FILE record with
  *               SDV_FLAG_NEW_FILE), in exactly the order VideoToDigital pushes STC007Line objects
  *               into its output queue: odd-field rows (line numbers 1,3,..), END_FIELD, even-field
- *               rows (2,4,..), END_FIELD, END_FRAME (vin_ffmpeg.cpp:281-350).
- *  out_stats    device pointer, one FrameBinDescriptor per frame (signal guiUpdFrameBin).
+ *               rows (2,4,..), END_FIELD, END_FRAME (vin_ffmpeg.cpp:281-350).  With SDV_FLAG_END_FILE height+4 more:
+ *               the filler frame (frame number first_frame_no + n_frames): FILLER lines in the same field order, END_FIELD
+ *               twice, END_FILE, END_FRAME.
+ *  out_stats    device pointer, one FrameBinDescriptor per frame (signal guiUpdFrameBin); one more row with
+ *               SDV_FLAG_END_FILE (the worker reports the filler frame too).
  *  stream       hipStream_t (NULL = default stream).  The call returns after the device work of the
  *               batch has been validated (it synchronises `stream` at least once).
  * Returns SDV_OK or an SDV_ERR_* code; invalid input is refused up front like the reference's early

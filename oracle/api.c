@@ -135,8 +135,13 @@ long orc_v2d_run(void *vv, const uint8_t *luma, size_t stride, int width, int he
     for (int f = 0; f < n_frames; f++) {
         orc_frame_stats q;
         n += orc_v2d_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
-                           new_file && f == 0, doubled != 0, out + n, &q);
+                           (new_file & 1) && f == 0, doubled != 0, out + n, &q);
         if (stats) stats_to_pod(&q, &stats[f]);
+    }
+    if (new_file & 2) {     /* bit 1: the file ends here (out needs height + 4 more records, stats one more row) */
+        orc_frame_stats q;
+        n += orc_v2d_end_file_frame(v, height, first_frame_no + (uint32_t)n_frames, out + n, &q);
+        if (stats) stats_to_pod(&q, &stats[n_frames]);
     }
     return n;
 }

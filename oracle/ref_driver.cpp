@@ -224,7 +224,11 @@ long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int hei
 {
     RefV2D *r = (RefV2D *)h;
     if (!r->started) { r->started = true; r->th = std::thread([r]() { r->v2d.doBinarize(); }); }
-    long expect = (long)n_frames * (height + 3) + (new_file ? 1 : 0);
+    const bool end_file = (new_file & 2) != 0;       /* bit 1: append VideoInFFMPEG::insertDummyFrame(true, false) */
+    new_file &= 1;
+    const int n_real = n_frames;
+    if (end_file) n_frames++;
+    long expect = (long)n_real * (height + 3) + (new_file ? 1 : 0) + (end_file ? height + 4 : 0);
     long got = 0; int fed = 0; int nstats = 0;
     while (got < expect || nstats < n_frames) {
         /* keep a few frames queued */
@@ -237,6 +241,26 @@ long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int hei
             const uint8_t *fr = luma + (size_t)fed * stride * (size_t)height;
             if (new_file && fed == 0) push_service(tmp, SDV_SRV_NEW_FILE, fno, 0);
             uint16_t line_num = 0;
+            if (fed >= n_real) {                      /* the filler frame that closes the file (vin_ffmpeg.cpp:367-523) */
+                for (int field = 0; field < 2; field++) {
+                    int line_offset = field;
+                    for (;;) {
+                        line_num = (uint16_t)(line_offset + 1);
+                        push_service(tmp, SDV_SRV_FILLER, fno, line_num);
+                        if (line_offset < (height - 2)) line_offset += 2;
+                        else { line_num += 2; break; }
+                    }
+                    push_service(tmp, SDV_SRV_END_FIELD, fno, line_num);
+                }
+                line_num += 2; push_service(tmp, SDV_SRV_END_FILE, fno, line_num);
+                line_num += 2; push_service(tmp, SDV_SRV_END_FRAME, fno, line_num);
+                r->in_mtx.lock();
+                for (auto &l : tmp) r->in_q.push_back(l);
+                qs = r->in_q.size();
+                r->in_mtx.unlock();
+                fed++;
+                continue;
+            }
             for (int field = 0; field < 2; field++) {
                 int line_offset = field;
                 line_num = (uint16_t)(line_offset + 1);

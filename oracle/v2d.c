@@ -281,3 +281,35 @@ int orc_v2d_frame(orc_v2d *v, const uint8_t *luma, size_t stride, int width, int
     orc_v2d_line(v, &vl, &out[n++], out_stats);
     return n;
 }
+
+/* The frame VideoInFFMPEG::insertDummyFrame(true, false) (vin_ffmpeg.cpp:367-523) appends after the last frame of a file, as it
+ * passes through the worker: height FILLER service lines in field order, END_FIELD after each field, then END_FILE and END_FRAME.
+ * Returns the number of records written (height + 4). */
+int orc_v2d_end_file_frame(orc_v2d *v, int height, uint32_t frame_no, sdv_line_rec *out, orc_frame_stats *out_stats)
+{
+    int n = 0;
+    orc_video_line vl;
+    uint16_t line_num = 0;
+    orc_v2d_begin_frame(v);
+    memset(&vl, 0, sizeof(vl));
+    vl.frame_number = frame_no; vl.empty = true; vl.pixels = NULL; vl.length = 0;
+    for (int field = 0; field < 2; field++) {
+        int line_offset = field;
+        for (;;) {
+            line_num = (uint16_t)(line_offset + 1);
+            vl.line_number = line_num; vl.service_type = ORC_SRV_FILLER;
+            orc_v2d_line(v, &vl, &out[n++], out_stats);
+            if (line_offset < (height - 2)) line_offset += 2;
+            else { line_num = (uint16_t)(line_num + 2); break; }
+        }
+        vl.line_number = line_num; vl.service_type = ORC_SRV_END_FIELD;
+        orc_v2d_line(v, &vl, &out[n++], out_stats);
+    }
+    line_num = (uint16_t)(line_num + 2);
+    vl.line_number = line_num; vl.service_type = ORC_SRV_END_FILE;
+    orc_v2d_line(v, &vl, &out[n++], out_stats);
+    line_num = (uint16_t)(line_num + 2);
+    vl.line_number = line_num; vl.service_type = ORC_SRV_END_FRAME;
+    orc_v2d_line(v, &vl, &out[n++], out_stats);
+    return n;
+}

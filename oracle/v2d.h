@@ -36,6 +36,7 @@ void orc_v2d_free(orc_v2d *v);
 void orc_v2d_set_fine_settings(orc_v2d *v, const orc_bin_preset *p);
 void orc_v2d_begin_frame(orc_v2d *v);
 bool orc_v2d_line(orc_v2d *v, const orc_video_line *src, sdv_line_rec *out_rec, orc_frame_stats *out_stats);
+int orc_v2d_end_file_frame(orc_v2d *v, int height, uint32_t frame_no, sdv_line_rec *out, orc_frame_stats *out_stats);
 int orc_v2d_frame(orc_v2d *v, const uint8_t *luma, size_t stride, int width, int height, uint32_t frame_no,
                   bool new_file, bool doubled, sdv_line_rec *out, orc_frame_stats *out_stats);
 #ifdef __cplusplus

@@ -107,6 +107,7 @@ struct FrameArgs {
     uint32_t first_frame_no;        /* frame_number of frame index 0 */
     int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch */
     int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
+    int end_file_frame;             /* frame index of the filler frame that closes the file (no pixels: FILLER lines, END_FILE), or -1 */
     uint8_t doubled, mode, check_line_copy, coordinate_damper, m2_format;
     sdv_bin_preset preset;
     const sdv_v2d_state *states_in; /* [n frames] speculated incoming chain state */
@@ -1885,6 +1886,31 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int lane = lane_id();
 
     v2d_begin_frame(v, a, lds);
+    if (f == a.end_file_frame) {
+        /* VideoInFFMPEG::insertDummyFrame(true, false) (vin_ffmpeg.cpp:367-523) through the worker: FILLER lines in field order,
+         * END_FIELD after each field, END_FILE, END_FRAME */
+        uint16_t ln = 0;
+        for (int field = 0; field < 2; field++) {
+            const int nl = field == 0 ? (a.height + 1) / 2 : a.height / 2;
+            for (int i = 0; i < nl; i++) {
+                ln = (uint16_t)(field + 1 + 2 * i);
+                v2d_service_line(v, a, lds, wl, frame_no, ln, SDV_SRV_FILLER);
+                emit_record(wl, rec++);
+            }
+            ln = (uint16_t)(ln + 2);
+            v2d_service_line(v, a, lds, wl, frame_no, ln, SDV_SRV_END_FIELD);
+            emit_record(wl, rec++);
+        }
+        ln = (uint16_t)(ln + 2);
+        v2d_service_line(v, a, lds, wl, frame_no, ln, SDV_SRV_END_FILE);
+        emit_record(wl, rec++);
+        ln = (uint16_t)(ln + 2);
+        v2d_service_line(v, a, lds, wl, frame_no, ln, SDV_SRV_END_FRAME);
+        v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f]);
+        emit_record(wl, rec++);
+        v2d_store_state(v, lds, &a.states_out[f], a);
+        return;
+    }
     if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
     /* decode order of VideoInFFMPEG::spliceFrame (vin_ffmpeg.cpp:281-347): field 0 = rows 0,2,4.., field 1 = rows 1,3,5.. */
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };

@@ -33,7 +33,7 @@ assert LINE_DTYPE.itemsize == 48 and STATS_DTYPE.itemsize == 32
 PCM_PCM1, PCM_PCM16X0, PCM_STC007 = 0, 1, 2
 TYPE_M2 = 3                      # VideoToDigital::TYPE_M2 (videotodigital.h:77)
 MODE_DRAFT, MODE_FAST, MODE_NORMAL, MODE_INSANE = 0, 1, 2, 3
-FLAG_NEW_FILE, FLAG_DOUBLED = 1, 2
+FLAG_NEW_FILE, FLAG_DOUBLED, FLAG_END_FILE = 1, 2, 4
 
 
 class BinPreset(C.Structure):
@@ -254,18 +254,18 @@ class Engine:
         return int(self.lib.sdv_records_per_frame(height))
 
     def binarize_frames(self, luma, first_frame_no: int = 1, new_file: bool = False, doubled: bool = False,
-                        out_lines=None, out_stats=None, stream=None):
+                        out_lines=None, out_stats=None, stream=None, end_file: bool = False):
         """luma: torch.uint8 CUDA tensor (n_frames, height, width), rows contiguous.
         Returns (lines, stats) as torch.uint8 CUDA tensors shaped (n_records, 48) and (n_frames, 32)."""
         import torch
         assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 3 and luma.stride(2) == 1
         n, h, w = luma.shape
-        nrec = n * (h + 3) + (1 if new_file else 0)
+        nrec = n * (h + 3) + (1 if new_file else 0) + (h + 4 if end_file else 0)      # end_file: the filler frame that closes a source
         if out_lines is None:
             out_lines = torch.empty((nrec, 48), dtype=torch.uint8, device=luma.device)
         if out_stats is None:
-            out_stats = torch.empty((n, 32), dtype=torch.uint8, device=luma.device)
-        flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0)
+            out_stats = torch.empty((n + (1 if end_file else 0), 32), dtype=torch.uint8, device=luma.device)
+        flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0) | (FLAG_END_FILE if end_file else 0)
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
         rc = self.lib.sdv_binarize_frames(self._h, C.c_void_p(luma.data_ptr()), luma.stride(1), luma.stride(0), w, h, n,
                                           first_frame_no, flags, C.c_void_p(out_lines.data_ptr()),

@@ -76,9 +76,9 @@ def emu_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
 def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1):
     """Host-memory call (emulator build only)."""
     n, h, w = luma.shape
-    nrec = n * (h + 3) + (1 if flags & 1 else 0)
+    nrec = n * (h + 3) + (1 if flags & 1 else 0) + (h + 4 if flags & 4 else 0)
     recs = np.zeros(nrec, dtype=libs.LINE_DTYPE)
-    stats = np.zeros(n, dtype=STATS_DTYPE)
+    stats = np.zeros(n + (1 if flags & 4 else 0), dtype=STATS_DTYPE)
     luma = np.ascontiguousarray(luma)
     rc = lib.sdv_binarize_frames(eng, luma.ctypes.data, w, w * h, w, h, n, first_frame_no, flags, recs.ctypes.data,
                                  stats.ctypes.data, None)

@@ -43,7 +43,7 @@ def make_luma(kw, edit):
     return luma
 
 
-def run_ref(luma, mode, first=1, new_file=1):
+def run_ref(luma, mode, first=1, new_file=1, end_file=0):
     lib = libs.load_ref()
     lib.ref_v2d_new.restype = C.c_void_p
     lib.ref_v2d_run.restype = C.c_long
@@ -54,9 +54,9 @@ def run_ref(luma, mode, first=1, new_file=1):
     h = C.c_void_p(lib.ref_v2d_new())
     lib.ref_v2d_set_mode(h, mode)
     n, hh, w = luma.shape
-    recs = np.zeros(n * (hh + 3) + new_file, dtype=libs.LINE_DTYPE)
-    stats = np.zeros((n, 32), dtype=np.uint8)
-    got = lib.ref_v2d_run(h, luma.ctypes.data, w, w, hh, n, first, new_file, 0, recs.ctypes.data, stats.ctypes.data)
+    recs = np.zeros(n * (hh + 3) + new_file + (hh + 4 if end_file else 0), dtype=libs.LINE_DTYPE)
+    stats = np.zeros((n + (1 if end_file else 0), 32), dtype=np.uint8)
+    got = lib.ref_v2d_run(h, luma.ctypes.data, w, w, hh, n, first, new_file | (2 if end_file else 0), 0, recs.ctypes.data, stats.ctypes.data)
     lib.ref_v2d_delete(h)
     assert got == len(recs)
     return recs, stats

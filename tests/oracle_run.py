@@ -5,7 +5,7 @@ import libs
 
 
 def oracle_binarize(luma, mode=2, first_frame_no=1, new_file=True, doubled=False, preset=None, check_line_dup=True,
-                    m2=False, handle=None, return_state=False):
+                    m2=False, handle=None, return_state=False, end_file=False):
     lib = libs.load_oracle()
     lib.orc_v2d_new.restype = C.c_void_p
     lib.orc_v2d_run.restype = C.c_long
@@ -27,9 +27,9 @@ def oracle_binarize(luma, mode=2, first_frame_no=1, new_file=True, doubled=False
             lib.orc_v2d_set_preset(h, C.byref(preset))
     luma = np.ascontiguousarray(luma, dtype=np.uint8)
     n, hgt, w = luma.shape
-    recs = np.zeros(n * (hgt + 3) + (1 if new_file else 0), dtype=libs.LINE_DTYPE)
-    stats = np.zeros((n, 32), dtype=np.uint8)
-    got = lib.orc_v2d_run(h, luma.ctypes.data, w, w, hgt, n, first_frame_no, int(new_file), int(doubled), recs.ctypes.data,
+    recs = np.zeros(n * (hgt + 3) + (1 if new_file else 0) + (hgt + 4 if end_file else 0), dtype=libs.LINE_DTYPE)
+    stats = np.zeros((n + (1 if end_file else 0), 32), dtype=np.uint8)
+    got = lib.orc_v2d_run(h, luma.ctypes.data, w, w, hgt, n, first_frame_no, int(new_file) | (2 if end_file else 0), int(doubled), recs.ctypes.data,
                           stats.ctypes.data)
     assert got == len(recs)
     state = None

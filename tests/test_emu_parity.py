@@ -42,6 +42,31 @@ def test_emu_small_frames(emu_lib, oracle_lib, mode):
         assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
 
 
+def test_emu_end_of_file_frame_and_next_source(emu_lib, oracle_lib):
+    """SDV_FLAG_END_FILE appends the filler frame + END_FILE the input plugin emits (vin_ffmpeg.cpp:367-523); the worker's
+    statistics are reset by it, so a second source decoded by the same engine starts like the oracle's."""
+    emu = emu_lib
+    luma, _, _ = synth.stc007_frames(n_frames=3, seed=21, height=48, noise_sigma=3.0)
+    luma2, _, _ = synth.stc007_frames(n_frames=2, seed=22, height=48, x0=20, x1=690)
+    lib = libs.load_oracle()
+    lib.orc_v2d_new.restype = C.c_void_p
+    h = C.c_void_p(lib.orc_v2d_new())
+    lib.orc_v2d_set_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_v2d_set_mode(h, 2)
+    want1, ws1 = oracle_binarize(luma, handle=h, new_file=True, end_file=True)
+    want2, ws2 = oracle_binarize(luma2, handle=h, new_file=True, first_frame_no=1)
+    eng = C.c_void_p(emu.sdv_engine_create(0))
+    emu.sdv_set_mode(eng, 2)
+    got1, gs1, _ = emu_run(emu, luma, 2, flags=1 | 4, eng=eng)
+    got2, gs2, _ = emu_run(emu, luma2, 2, flags=1, eng=eng)
+    emu.sdv_engine_destroy(eng)
+    assert len(got1) == 3 * 51 + 1 + 52 and (got1["service_type"][-52:] != 0).all()
+    assert got1.tobytes() == want1.tobytes(), golden_cases.diff_report(got1, want1)
+    assert gs1.view(np.uint8).tobytes() == ws1.tobytes()
+    assert got2.tobytes() == want2.tobytes(), golden_cases.diff_report(got2, want2)
+    assert gs2.view(np.uint8).tobytes() == ws2.tobytes()
+
+
 def test_emu_batch_path_corner_cases(emu_lib, oracle_lib):
     """Exercises the line-batch fast path: duplicated rows (dup-line rule), silent audio (almost-silent lines are
     exempt from it), a bad row in the middle of a batch, doubled-width sources, dup check switched off."""

@@ -128,6 +128,45 @@ def test_gpu_matches_golden_from_reference(name):
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
 
 
+def _e2e_fixture():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_stitch", os.path.join(GOLD, "make_golden_stitch.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    z = np.load(os.path.join(GOLD, "e2e_ntsc_file.npz"))
+    want_p = np.ascontiguousarray(z["pairs"]).view(sa.PAIR_DTYPE).reshape(-1)
+    want_f = np.ascontiguousarray(z["frames"]).view(sa.FRASM_DTYPE).reshape(-1)
+    return mg.make_e2e_luma(), z, want_p, want_f
+
+
+def test_oracle_whole_file_matches_reference_golden(oracle_lib):
+    """video -> oracle VideoToDigital (NEW_FILE .. filler frame + END_FILE) -> oracle stitcher == both real reference workers"""
+    luma, z, want_p, want_f = _e2e_fixture()
+    recs, stats = oracle_binarize(luma, mode=2, new_file=True, end_file=True)
+    assert sc.digest(recs) == str(z["recs_sha256"]) and stats.tobytes() == z["stats"].tobytes()
+    pairs, frames = sa.run_cpu(libs.load_oracle(), "orc_", recs, sa.default_settings())
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+    assert (pairs["service_type"] == 1).sum() == 1 and pairs["service_type"][-1] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_whole_file_matches_reference_golden():
+    """The drop-in path end to end on the GPU: sdv_binarize_frames(NEW_FILE | END_FILE) -> sdv_stitch_frames, device
+    buffers handed from one stage to the next, against the output of the real reference's two workers."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, LINE_DTYPE
+    luma, z, want_p, want_f = _e2e_fixture()
+    eng = Engine(0)
+    lines, stats = eng.binarize_frames(torch.from_numpy(luma).cuda(), first_frame_no=1, new_file=True, end_file=True)
+    assert sc.digest(lines.cpu().numpy().reshape(-1).view(LINE_DTYPE)) == str(z["recs_sha256"])
+    assert stats.cpu().numpy().tobytes() == z["stats"].tobytes()
+    eng.set_stitch_settings(_settings(sa.default_settings()))
+    p, f = eng.stitch_frames(lines)
+    pairs = p.cpu().numpy().reshape(-1).view(sa.PAIR_DTYPE)
+    frames = f.cpu().numpy().reshape(-1).view(sa.FRASM_DTYPE)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
 @pytest.mark.gpu
 def test_gpu_long_stream_in_batches():
     """300 frames with dropouts, stitched in three calls: the PCM stream equals the oracle's sequential run and every
