@@ -6,9 +6,11 @@ over one batch of synthetic NTSC frames that is already resident in HBM (workloa
 configs[1]: 10k-frame synthetic STC-007 NTSC batch, 1 x MI355X, binarize + bit-extract + CRC only).
 
   python bench.py --gpus N --steps K --warmup W
-  N > 1: launched by torch.distributed.run, one rank per GPU; every rank decodes its own stream of
-  `--frames` frames (weak scaling; the binarize path needs no data-path collective), timing is
-  barrier + synchronize bracketed, MAX over ranks, rank 0 prints ONE JSON line.
+  N > 1: launched by torch.distributed.run, one rank per GPU; ONE tape of N x `--frames` frames per step is sharded
+  over the ranks in contiguous frame ranges (weak scaling: per-GPU work fixed).  The only collective is the all-gather
+  (RCCL) of every rank's 120-byte final chain state per step, against which each rank checks the state it started its
+  range from (sdvpcmdecoder_amd/sharded.py); timing is barrier + synchronize bracketed, MAX over ranks, rank 0 prints
+  ONE JSON line.
 
 Extra objects in the JSON line: "roofline" (HBM: algorithmic bytes per launch / HIP-event kernel time,
 measured live on the stream the kernel runs on) and "cpu_baseline" (the real reference, or the oracle
@@ -110,16 +112,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SDV_BENCH_BACKEND", "nccl")     # nccl = RCCL; "gloo" lets the N > 1 path be exercised on a 1-GPU box
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the decode engine has no CPU path)"
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     W, H = 720, 486
     n = args.frames
-    luma, w9 = synth.stc007_frames_torch(n, seed=2 + rank, device=dev, width=W, height=H, noise_sigma=args.noise, cyclic=True)
+    # one seamless (cyclic) tape of world*n frames; this rank renders and keeps its own contiguous part of it
+    luma, w9 = synth.stc007_frames_torch(n * world, seed=2, device=dev, width=W, height=H, noise_sigma=args.noise, cyclic=True,
+                                         frame_range=(rank * n, (rank + 1) * n))
+    w9 = w9[rank * n * 2 * 245:(rank + 1) * n * 2 * 245]
     eng = Engine(local_rank)
     eng.setBinarizationMode(args.mode)
     eng.set_profiling(True)
@@ -133,20 +141,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if world > 1:
+        from sdvpcmdecoder_amd.sharded import ShardedBinarizeLoop, torch_all_gather
+        loop = ShardedBinarizeLoop(eng, rank, world, torch_all_gather(dev if backend == "nccl" else None))
+
+        def decode_batch(first_frame_no, new_file, out):
+            loop.step(luma, first_frame_no + rank * n, new_file=new_file, out_lines=out, out_stats=out_stats, stream=stream)
+    else:
+        loop = None
+
+        def decode_batch(first_frame_no, new_file, out):
+            eng.binarize_frames(luma, first_frame_no=first_frame_no, new_file=new_file, out_lines=out, out_stats=out_stats, stream=stream)
+
     # first pass: start of the stream (cold chain: NEW_FILE, first frame decoded alone)
-    eng.binarize_frames(luma, first_frame_no=1, new_file=True, out_lines=out_lines, out_stats=out_stats, stream=stream)
+    decode_batch(1, True, out_lines if rank == 0 else out_lines[1:])
     torch.cuda.synchronize(dev)
     first_recs = out_lines[:1 + 4 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(-1) if rank == 0 else None
     # steady state: every step decodes the batch as the continuation of the stream
+    tape_pos = 1 + n * world
     for _ in range(args.warmup):
-        eng.binarize_frames(luma, first_frame_no=1, new_file=False, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+        decode_batch(tape_pos, False, out_lines[1:])
+        tape_pos += n * world
     barrier()
     kernel_ms = 0.0
     rounds = 0
     launched = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.binarize_frames(luma, first_frame_no=1, new_file=False, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+        decode_batch(tape_pos, False, out_lines[1:])
+        tape_pos += n * world
         info = eng.run_info()
         kernel_ms += info.kernel_ms
         rounds += info.rounds
@@ -154,14 +177,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # beyond BASELINE's metric: the stitch stage (STC007DataStitcher -> PCMSamplePair) over the records just produced, and the
     # whole path frames -> PCM, both as a continuing stream (every step continues the tape, like the binarize steps above)
     stitch = None
-    if not args.no_stitch:
+    if not args.no_stitch and world == 1:
         eng.reset_stitcher()
         lines_all = out_lines[:1 + nrec]                                  # NEW_FILE line + n frames
         sp = torch.empty((n * 1470 + 65536, 12), dtype=torch.uint8, device=dev)
@@ -217,6 +240,8 @@ def main():
             "config": {"workload": f"configs[1]: {n}-frame synthetic STC-007 NTSC 720x486 batch per GPU resident in HBM, "
                                    f"Binarizer mode {args.mode}, noise sigma {args.noise}, binarize+bit-extract+CRC only",
                        "frames_per_gpu_per_step": n, "speculation_rounds_per_step": rounds / args.steps,
+                       "sharding": ("one tape of %d frames per step in contiguous ranges, 120-byte state all-gather per step, %d range re-decodes"
+                                    % (n * world, loop.redo)) if world > 1 else "single GPU",
                        "decoded_words_match_generator": words_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(frames_per_launch),

@@ -333,6 +333,16 @@ int sdv_set_stitch_settings(sdv_engine *e, const sdv_stitch_settings *st);
 int sdv_reset_stitcher(sdv_engine *e);
 int sdv_get_stitch_info(const sdv_engine *e, sdv_stitch_info *out);
 
+/* The stitcher's stream state as an opaque blob (previous frame's descriptor, statistics rings, the 112 hand-over lines):
+ * checkpointing, and handing a tape over to the engine of the next GPU when one stream is sharded across GPUs (the "field
+ * seam" that travels by all-gather).  sdv_set_stitch_state drops lines that still wait for a successor
+ * frame.  sdv_saturate_stitch_stats fills the two statistics rings with their current majority - for an engine that joined
+ * the stream after a short warm-up and is about to compare its state with the true one. */
+size_t sdv_stitch_state_size(void);
+int sdv_get_stitch_state(sdv_engine *e, void *out, size_t cap);
+int sdv_set_stitch_state(sdv_engine *e, const void *in, size_t n);
+int sdv_saturate_stitch_stats(sdv_engine *e);
+
 /* STC007DataStitcher::doFrameReassemble (stc007datastitcher.cpp:7239-7488) over a span of the binarized line stream.
  * `lines` is what VideoToDigital puts into the stitcher's input deque<STC007Line> (sdv_binarize_frames' out_lines,
  * service lines included; a file ends with the filler frame + END_FILE + END_FRAME the input plugin appends,

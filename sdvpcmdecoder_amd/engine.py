@@ -127,6 +127,10 @@ def load_library(path: str | None = None):
     lib.sdv_stitch_frames.restype = C.c_int
     lib.sdv_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    lib.sdv_stitch_state_size.restype = C.c_size_t
+    lib.sdv_get_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_set_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_saturate_stitch_stats.argtypes = [C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -184,6 +188,28 @@ class Engine:
 
     def reset_stream(self):
         self._check(self.lib.sdv_reset_stream(self._h))
+
+    # ---- stream state as bytes (checkpoints, hand-over between the GPUs of a sharded stream) ----
+    def get_chain_state(self) -> bytes:
+        buf = C.create_string_buffer(120)
+        self._check(self.lib.sdv_get_chain_state(self._h, buf))
+        return buf.raw
+
+    def set_chain_state(self, state: bytes):
+        assert len(state) == 120
+        self._check(self.lib.sdv_set_chain_state(self._h, C.create_string_buffer(state, 120)))
+
+    def get_stitch_state(self) -> bytes:
+        n = self.lib.sdv_stitch_state_size()
+        buf = C.create_string_buffer(n)
+        self._check(self.lib.sdv_get_stitch_state(self._h, buf, n))
+        return buf.raw
+
+    def set_stitch_state(self, state: bytes):
+        self._check(self.lib.sdv_set_stitch_state(self._h, C.create_string_buffer(state, len(state)), len(state)))
+
+    def saturate_stitch_stats(self):
+        self._check(self.lib.sdv_saturate_stitch_stats(self._h))
 
     def set_profiling(self, on: bool = True):
         self._check(self.lib.sdv_set_profiling(self._h, int(on)))

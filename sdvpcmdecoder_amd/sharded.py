@@ -1,0 +1,170 @@
+"""One tape decoded by several GPUs: contiguous frame ranges per rank, bit-exact with the sequential decode.
+
+The reference decodes a tape strictly in order because both of its workers carry state from frame to frame (VideoToDigital:
+binarizer tuning and coordinate histories, 120 bytes; STC007DataStitcher: previous frame's descriptor, statistics rings and the
+112 assembled lines that wait in conv_queue for the next frame's blocks - the "field seam").  Sharding therefore speculates once
+more, at rank granularity, with the same scheme the engine uses inside a batch:
+
+  1. rank r > 0 first decodes a short warm-up (the frames just before its range) from a freshly reset engine, discards the
+     output and keeps the state it ends in - its *prediction* of the state rank r-1 will hand over;
+  2. every rank decodes its own range from that state and all-gathers its final state (the only collective: 120 bytes
+     per rank for the binarize stage, ~4 KB per rank - the seam lines - for the stitch stage; RCCL over xGMI on the GPU box);
+  3. a rank whose prediction differs from what its predecessor really ended in decodes its range again from the true
+     state; repeated until every rank started from exactly its predecessor's final state.
+
+On a tape in steady state the prediction holds (the histories saturate within the warm-up), so step 3 does not run.
+The frames a rank needs beyond its range: `warmup` frames before it and one frame after it (the successor every
+stitcher turn needs); the last rank appends the end-of-file frame instead."""
+from __future__ import annotations
+
+
+def shard_bounds(n_frames: int, rank: int, world: int):
+    return n_frames * rank // world, n_frames * (rank + 1) // world
+
+
+class ShardedDecoder:
+    """`eng`: an engine with the methods of sdvpcmdecoder_amd.Engine (binarize_frames, stitch_frames, reset_stream,
+    reset_stitcher, get/set_chain_state, get/set_stitch_state, saturate_stitch_stats).
+    `all_gather(bytes) -> list[bytes]`: one entry per rank, in rank order (torch.distributed.all_gather of a uint8 tensor).
+    `records_of(lines, a, b)`: rows a..b of a record buffer (tensor or array slicing)."""
+
+    def __init__(self, eng, rank: int, world: int, all_gather, height: int, warmup: int = 20, stitch_warmup: int = 4):
+        self.eng, self.rank, self.world, self.all_gather = eng, rank, world, all_gather
+        self.height, self.warmup, self.stitch_warmup = height, warmup, stitch_warmup
+        self.stats = {"binarize_redo": 0, "stitch_redo": 0, "gathers": 0}
+
+    def frames_needed(self, n_frames: int):
+        """(first, last+1) of the frames this rank has to be given: warm-up, own range, successor frame."""
+        lo, hi = shard_bounds(n_frames, self.rank, self.world)
+        lead = min(self.warmup, lo)
+        look = 1 if hi < n_frames else 0
+        return lo - lead, hi + look
+
+    def decode(self, luma, n_frames: int, first_frame_no: int = 1):
+        """luma: frames frames_needed(n_frames) of the tape (index 0 = frame frames_needed()[0]).
+        Returns (pairs, frame_descriptors) of this rank's turns = frames lo..hi-1 of the tape; concatenated over the ranks
+        they are the output of one engine decoding the whole tape (NEW_FILE ... END_FILE)."""
+        eng, rank, world, rpf = self.eng, self.rank, self.world, self.height + 3
+        lo, hi = shard_bounds(n_frames, rank, world)
+        f0, f1 = self.frames_needed(n_frames)
+        lead, look, n_own = lo - f0, f1 - hi, hi - lo
+        last = rank == world - 1
+        assert luma.shape[0] == f1 - f0 and n_own > 0
+
+        # ---- binarize stage ------------------------------------------------------------------------------------------
+        eng.reset_stream()
+        predicted, warm = None, None
+        if lead:
+            warm, _ = eng.binarize_frames(luma[:lead], first_frame_no=first_frame_no + f0, new_file=False)
+            predicted = eng.get_chain_state()
+
+        def run_range():
+            own, _ = eng.binarize_frames(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
+            final = eng.get_chain_state()
+            extra = None
+            if look:        # the successor frame of this range's last stitcher turn (rank r+1 decodes it again as its first frame)
+                extra, _ = eng.binarize_frames(luma[lead + n_own:], first_frame_no=first_frame_no + hi, new_file=False)
+            return own, extra, final
+        own, extra, final = run_range()
+        while True:
+            finals = self.all_gather(final)
+            self.stats["gathers"] += 1
+            ok = rank == 0 or predicted == finals[rank - 1]
+            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
+                break
+            if not ok:
+                self.stats["binarize_redo"] += 1
+                predicted = finals[rank - 1]
+                eng.set_chain_state(predicted)
+                own, extra, final = run_range()
+
+        # ---- stitch stage --------------------------------------------------------------------------------------------
+        # own = [NEW_FILE record on rank 0] + frames lo..hi-1 [+ the end-of-file frame on the last rank]
+        whole = _cat(own, extra) if extra is not None else own
+        eng.reset_stitcher()
+        s_pred = None
+        s_lead = min(self.stitch_warmup, lead)
+        if s_lead:
+            # warm-up turns lo-s_lead .. lo-1 (output discarded); frame lo then waits inside the engine for its successor
+            eng.stitch_frames(_cat(warm[(lead - s_lead) * rpf:], own[:rpf]))
+            eng.saturate_stitch_stats()
+            s_pred = eng.get_stitch_state()
+            pairs, frames = eng.stitch_frames(whole[rpf:])
+        else:
+            pairs, frames = eng.stitch_frames(whole)
+        s_final = eng.get_stitch_state()
+        while True:
+            finals = self.all_gather(s_final)
+            self.stats["gathers"] += 1
+            ok = rank == 0 or s_pred == finals[rank - 1]
+            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
+                break
+            if not ok:
+                self.stats["stitch_redo"] += 1
+                s_pred = finals[rank - 1]
+                eng.set_stitch_state(s_pred)                  # drops the waiting frame: the whole range is fed again
+                pairs, frames = eng.stitch_frames(whole)
+                s_final = eng.get_stitch_state()
+        return pairs, frames
+
+
+class ShardedBinarizeLoop:
+    """The binarize stage of a tape that keeps coming, batch after batch, each batch split over the ranks (what `bench.py --gpus N`
+    times): batch s = frames [s*B, (s+1)*B) of the tape, rank r owns its r-th part.  Rank r's incoming state for batch s is rank
+    r-1's final state of the same batch (rank 0: the last rank's final state of batch s-1, known exactly).  Each rank simply
+    carries on from where its own engine stopped - on a tape in steady state that *is* what the predecessor hands over - then
+    the 120-byte final states are all-gathered and every rank checks; a rank that guessed wrong decodes its part again from the
+    true state."""
+
+    def __init__(self, eng, rank: int, world: int, all_gather):
+        self.eng, self.rank, self.world, self.all_gather = eng, rank, world, all_gather
+        self.prev_last = None           # final state of the last rank in the previous batch
+        self.redo = 0
+
+    def step(self, luma, first_frame_no: int, new_file: bool = False, **kw):
+        eng, rank = self.eng, self.rank
+        if rank == 0 and self.prev_last is not None:
+            eng.set_chain_state(self.prev_last)
+        assumed = eng.get_chain_state()
+        out = eng.binarize_frames(luma, first_frame_no=first_frame_no, new_file=new_file and rank == 0, **kw)
+        final = eng.get_chain_state()
+        while True:
+            finals = self.all_gather(final)
+            ok = rank == 0 or assumed == finals[rank - 1]
+            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
+                break
+            if not ok:
+                self.redo += 1
+                assumed = finals[rank - 1]
+                eng.set_chain_state(assumed)
+                out = eng.binarize_frames(luma, first_frame_no=first_frame_no, new_file=False, **kw)
+                final = eng.get_chain_state()
+        self.prev_last = finals[self.world - 1]
+        return out
+
+
+def torch_all_gather(device=None):
+    """all_gather of equally sized byte strings over the default process group (backend nccl = RCCL on the GPU box: pass the
+    rank's device; gloo on CPU: leave None)."""
+    import torch
+    import torch.distributed as dist
+
+    def gather(b: bytes):
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        if device is not None:
+            t = t.to(device)
+        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, t)
+        return [o.cpu().numpy().tobytes() for o in outs]
+    return gather
+
+
+def _cat(a, b):
+    try:
+        import torch
+        if isinstance(a, torch.Tensor):
+            return torch.cat([a, b], dim=0)
+    except ImportError:
+        pass
+    import numpy as np
+    return np.concatenate([a, b])

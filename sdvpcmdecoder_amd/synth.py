@@ -191,10 +191,12 @@ def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 
 # ------------------------------------------------------------------------------------------------
 def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int = 720, height: int = 486,
                         lines_per_field: int = 245, cut_top: int | None = None, black: int = 30, white: int = 200,
-                        x0: int = 12, x1: int | None = None, noise_sigma: float = 0.0, chunk_frames: int = 256, cyclic: bool = False):
+                        x0: int = 12, x1: int | None = None, noise_sigma: float = 0.0, chunk_frames: int = 256, cyclic: bool = False, frame_range=None):
     """Returns (luma (n_frames, height, width) uint8 on `device`, words (n_stream_lines, 9) int32 on `device`).
     cyclic=True interleaves the audio blocks around the end of the batch, so that playing the batch again and again is one
-    seamless tape (used by the benchmark, which keeps a single batch resident in HBM)."""
+    seamless tape (used by the benchmark, which keeps a single batch resident in HBM).
+    frame_range=(lo, hi) renders only those frames of the n_frames-frame tape (one rank's part of a sharded tape); the returned
+    luma then has hi-lo frames, the words still describe the whole tape."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -230,9 +232,12 @@ def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int 
     cell = ((x - x0) * BITS_IN_LINE) // (x1 - x0)
     inside = (x >= x0) & (x < x1)
     cell = cell.clamp(0, BITS_IN_LINE - 1)
-    luma = torch.empty((n_frames, height, width), dtype=torch.uint8, device=device)
-    for f0 in range(0, n_frames, chunk_frames):
-        f1 = min(n_frames, f0 + chunk_frames)
+    r_lo, r_hi = (0, n_frames) if frame_range is None else frame_range
+    luma = torch.empty((r_hi - r_lo, height, width), dtype=torch.uint8, device=device)
+    if noise_sigma > 0 and r_lo > 0:
+        g.manual_seed(seed * 1000003 + r_lo)         # noise of a part does not have to replay the parts before it
+    for f0 in range(r_lo, r_hi, chunk_frames):
+        f1 = min(r_hi, f0 + chunk_frames)
         f = torch.arange(f0, f1, device=device)[:, None]
         r = torch.arange(vis, device=device)[None, :]
         odd = f * 2 * lines_per_field + cut_top + r
@@ -257,7 +262,7 @@ def stc007_frames_torch(n_frames: int, seed: int = 0, device="cuda", width: int 
         img = b.to(torch.float32) * float(white - black) + float(black)
         if noise_sigma > 0:
             img = img + torch.randn(img.shape, generator=g, device=device) * noise_sigma
-        luma[f0:f1] = img.round().clamp(0, 255).to(torch.uint8).reshape(f1 - f0, height, width)
+        luma[f0 - r_lo:f1 - r_lo] = img.round().clamp(0, 255).to(torch.uint8).reshape(f1 - f0, height, width)
     return luma, w9
 
 

@@ -1,0 +1,63 @@
+"""The emulator build (tests/emu/libsdvpcm_emu.so, host pointers) behind the method names of sdvpcmdecoder_amd.Engine, so that
+host-side orchestration written for the product (sdvpcmdecoder_amd/sharded.py) can be exercised on CPU."""
+import ctypes as C
+
+import numpy as np
+
+import engine_api as ea
+import libs
+import stitch_api as sa
+
+
+class EmuEngine:
+    def __init__(self, lib, mode=2):
+        self.lib = ea.bind(lib)
+        self.lib.sdv_stitch_state_size.restype = C.c_size_t
+        self.lib.sdv_get_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.lib.sdv_set_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.lib.sdv_saturate_stitch_stats.argtypes = [C.c_void_p]
+        self.h = C.c_void_p(self.lib.sdv_engine_create(0))
+        self.lib.sdv_set_mode(self.h, mode)
+
+    def close(self):
+        self.lib.sdv_engine_destroy(self.h)
+
+    def reset_stream(self):
+        assert self.lib.sdv_reset_stream(self.h) == 0
+
+    def reset_stitcher(self):
+        assert self.lib.sdv_reset_stitcher(self.h) == 0
+
+    def binarize_frames(self, luma, first_frame_no=1, new_file=False, end_file=False):
+        rc, recs, stats = ea.emu_binarize(self.lib, self.h, np.ascontiguousarray(luma), first_frame_no=first_frame_no,
+                                          flags=(1 if new_file else 0) | (4 if end_file else 0))
+        assert rc == 0, self.lib.sdv_last_error(self.h)
+        return recs, stats
+
+    def stitch_frames(self, recs):
+        rc, pairs, frames = ea.emu_stitch(self.lib, self.h, recs, None, pair_cap=len(recs) * 4 + 8192, frame_cap=len(recs) // 8 + 64)
+        assert rc == 0, self.lib.sdv_last_error(self.h)
+        return pairs.copy(), frames.copy()
+
+    def set_stitch_settings(self, st):
+        assert self.lib.sdv_set_stitch_settings(self.h, C.byref(st)) == 0
+
+    def get_chain_state(self):
+        buf = C.create_string_buffer(120)
+        assert self.lib.sdv_get_chain_state(self.h, buf) == 0
+        return buf.raw
+
+    def set_chain_state(self, b):
+        assert self.lib.sdv_set_chain_state(self.h, C.create_string_buffer(b, 120)) == 0
+
+    def get_stitch_state(self):
+        n = self.lib.sdv_stitch_state_size()
+        buf = C.create_string_buffer(n)
+        assert self.lib.sdv_get_stitch_state(self.h, buf, n) == 0
+        return buf.raw
+
+    def set_stitch_state(self, b):
+        assert self.lib.sdv_set_stitch_state(self.h, C.create_string_buffer(b, len(b)), len(b)) == 0
+
+    def saturate_stitch_stats(self):
+        assert self.lib.sdv_saturate_stitch_stats(self.h) == 0

@@ -1,0 +1,68 @@
+"""One tape sharded over two ranks (gloo, CPU, emulator build of the kernels): the concatenated per-rank output equals the
+sequential decode of the whole tape by the oracle, whether the ranks' state predictions hold or have to be repaired."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import libs
+import stitch_api as sa
+from oracle_run import oracle_binarize
+from sdvpcmdecoder_amd import synth
+from sdvpcmdecoder_amd.sharded import shard_bounds
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_bounds_cover_the_tape():
+    for n in (1, 7, 10000, 100003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+@pytest.mark.parametrize("n_frames,warmup,s_warm,expect_redo", [(6, 3, 2, False), (10, 3, 2, True)])
+def test_two_ranks_one_tape(tmp_path, emu_lib, oracle_lib, n_frames, warmup, s_warm, expect_redo):
+    world = 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(tmp_path), str(n_frames), str(warmup), str(s_warm)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    # the sequential truth: the whole file through the oracle's two workers
+    luma, _, _ = synth.stc007_frames(n_frames, seed=41, noise_sigma=3.0)
+    recs, _ = oracle_binarize(luma, mode=2, new_file=True, end_file=True)
+    want_p, want_f = sa.run_cpu(libs.load_oracle(), "orc_", recs, sa.default_settings())
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    pairs = np.concatenate([np.ascontiguousarray(z["pairs"]).view(sa.PAIR_DTYPE).reshape(-1) for z in parts])
+    frames = np.concatenate([np.ascontiguousarray(z["frames"]).view(sa.FRASM_DTYPE).reshape(-1) for z in parts])
+    assert len(pairs) == len(want_p) and pairs.tobytes() == want_p.tobytes()
+    assert len(frames) == len(want_f) and frames.tobytes() == want_f.tobytes()
+    # a warm-up shorter than the predecessor's history cannot reproduce its coordinate history: the repair has to run
+    assert (parts[1]["redo"][0] >= 1) == expect_redo, parts[1]["redo"]
+
+
+def test_two_ranks_binarize_loop(tmp_path, emu_lib, oracle_lib):
+    """What bench.py --gpus N times: batches of one continuing tape, each split over the ranks.  The geometry of the video changes
+    from batch to batch, so ranks that simply carry on from their own previous state guess wrong and have to repair."""
+    import ctypes as C
+    n_frames, world = 4, 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31500 + os.getpid() % 2000), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(tmp_path), str(n_frames), "-1", "0"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    lib = libs.load_oracle()
+    lib.orc_v2d_new.restype = C.c_void_p
+    h = C.c_void_p(lib.orc_v2d_new())
+    lib.orc_v2d_set_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_v2d_set_mode(h, 2)
+    parts = [np.load(os.path.join(tmp_path, f"loop{r}.npz")) for r in range(world)]
+    for batch in range(3):
+        luma, _, _ = synth.stc007_frames(n_frames, seed=50 + batch, height=60, noise_sigma=3.0, x0=12 + 9 * batch, x1=700 - 5 * batch)
+        want, _ = oracle_binarize(luma, handle=h, new_file=(batch == 0), first_frame_no=1 + batch * n_frames)
+        got = np.concatenate([np.ascontiguousarray(z[f"b{batch}"]).view(libs.LINE_DTYPE).reshape(-1) for z in parts])
+        assert got.tobytes() == want.tobytes(), f"batch {batch}"
+    assert int(parts[1]["redo"]) >= 1
