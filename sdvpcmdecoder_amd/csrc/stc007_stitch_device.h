@@ -1260,11 +1260,7 @@ struct Step {
                 sdvd::gather8(src, (size_t)i, l8);
                 const uint8_t mode = cfg.m2 ? (uint8_t)SDV_RES_MODE_14BIT
                                      : res_mode_for_seam(line_res(l8.l[0].frame_number, l8.l[0].line_number), line_res(l8.l[7].frame_number, l8.l[7].line_number));
-#if SDV_ST_ABL != 1
                 sdvd::process_block(deint_cfg(mode, cfg.ignore_crc, !cfg.ignore_crc, cfg.en_p, cfg.en_q, cfg.en_cwd), l8, 0, b);
-#else
-                b.wlo = l8.l[0].words[0] + mode; b.w_frame[0] = l8.l[0].frame_number; b.w_frame[7] = l8.l[7].frame_number;
-#endif
                 ns = !blk_silent(b, cfg.m2);
                 if (ns && cfg.mask_seams) {
                     if (!f1.inner_padding_ok && !f1.inner_silence)
@@ -1293,21 +1289,15 @@ struct Step {
                 valid = blk_valid(b);
                 errs = errors_audio_fixed(b);
             }
-#if SDV_ST_ABL != 2
             fix_p += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_P));
             fix_q += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_Q));
             fix_cwd += (uint32_t)__popcll(__ballot(rep && valid && b.cwd_applied && b.cwd_fixed != 0));
             drop += (uint32_t)__popcll(__ballot(rep && !valid));
             brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
             for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
-#endif
             if (act) {
                 sdv_sample_pair *o = out_pairs + n_pairs + 3u * (uint32_t)i;
-#if SDV_ST_ABL == 3
-                if (n_pairs + 3u * (uint32_t)i + 3u <= PAIR_SLOT && b.wlo == 12345) { o[0] = make_pair(b, 0, 1, rate); }
-#else
                 if (n_pairs + 3u * (uint32_t)i + 3u <= PAIR_SLOT) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
-#endif
             }
         }
         if (nblk > 0) {
@@ -1520,9 +1510,6 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a) { sdvs::analyze_body(a, blockIdx.x, (int)threadIdx.x); }
-#ifndef SDV_ST_ABL
-#define SDV_ST_ABL 0
-#endif
 #ifndef SDV_ST_WAVES
 #define SDV_ST_WAVES 1
 #endif
