@@ -192,3 +192,51 @@ def test_gpu_long_stream_in_batches():
     pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
     assert max(rounds) <= 12, rounds
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_audio_recovery():
+    """BASELINE's batch size through the whole path (10 000 NTSC frames -> 14.7 M sample pairs): too big for the oracle, so the check
+    is the property the format was built for - although every field loses three lines (two cut off by the 486-row frame, the
+    first visible one discarded by the duplicate-line rule), P/Q correction recovers every audio word of the generator, in order,
+    and no block is dropped."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, synth
+    n = 10000
+    eng = Engine(0)
+    luma, w9 = synth.stc007_frames_torch(n, seed=2, device="cuda", noise_sigma=4.0, cyclic=True)
+    lines, _ = eng.binarize_frames(luma, first_frame_no=1, new_file=True, end_file=True)
+    del luma
+    eng.set_stitch_settings(_settings(sa.default_settings()))
+    pairs, frames = eng.stitch_frames(lines)
+    info = eng.stitch_info()
+    assert info.steps == n and info.rounds <= 3
+    nb = w9.shape[0]                                            # one block starts at every line of the tape
+    b = torch.arange(nb, device="cuda")
+    exp = torch.stack([w9[(b + 16 * k) % nb, k] for k in range(6)], dim=1)           # L0 R0 L1 R1 L2 R2 of block b
+    exp = ((exp << 2) & 0xFFFF).to(torch.int32)
+    exp = torch.where(exp >= 32768, exp - 65536, exp).to(torch.int16).reshape(nb, 3, 2)
+    p = pairs.contiguous()
+    words = p[:, 0:4].contiguous().view(torch.int16).reshape(-1, 2)
+    flags, service = p[:, 4:6], p[:, 9]
+    assert int((service == 1).sum()) == 1 and int(service[0]) == 1 and int(service[-1]) == 2 and int((service != 0).sum()) == 2
+    body, bflags = words[1:-1], flags[1:-1]                     # 3 pairs per block
+    assert body.shape[0] % 3 == 0
+    blocks = body.reshape(-1, 3, 2)
+    # align: a block well inside the tape must be one block of the generator
+    probe = blocks[3000]
+    hit = torch.nonzero((exp == probe[None]).all(dim=2).all(dim=1)).reshape(-1)
+    assert hit.numel() == 1
+    b0 = int(hit[0]) - 3000                                      # generator block of decoded block 0
+    k = torch.arange(blocks.shape[0], device="cuda")
+    want = exp[(b0 + k) % nb]
+    same = (blocks == want).all(dim=2).all(dim=1)
+    # the first blocks reach into the filler lines in front of the tape, the last ones into the end-of-file flush: 112 lines each
+    inner = same[200:-200]
+    assert bool(inner.all()), f"{int((~inner).sum())} blocks differ from the generator"
+    ok = ((bflags.reshape(-1, 3, 2)[200:-200] & 3) == 3)
+    assert bool(ok.all())                                        # block ok + word valid everywhere
+    fr = frames.cpu().numpy().reshape(-1).view(sa.FRASM_DTYPE)
+    real = fr[fr["service_type"] == 0]
+    assert len(real) == n and (real["blocks_drop"][1:-1] == 0).all() and (real["blocks_total"][1:-1] == 490).all()
+    assert ((real["flags"][1:-1] & 0x18) == 0x18).all()         # inner and outer padding found (the last frame borders the filler frame)
