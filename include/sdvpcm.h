@@ -265,7 +265,7 @@ typedef struct sdv_run_info {
     uint32_t frames;            /* frames in the call */
     uint32_t rounds;            /* speculation rounds (launches of the frame kernel) needed; 1 = fully parallel */
     uint32_t frames_launched;   /* frame decodes executed, including re-decodes after a misprediction */
-    uint32_t _pad;
+    uint32_t frames_general;    /* of those, by the full kernel (the lean one has no general path and gives such frames up) */
     float kernel_ms;            /* HIP-event time of the frame kernel launches of this call (sdv_set_profiling) */
     float _pad2;
 } sdv_run_info;

@@ -1605,6 +1605,21 @@ struct Geo { int16_t start, stop; uint32_t psm; int32_t vp0, vp1; bool valid; };
 struct LaneConst { uint64_t klo, khi; };                                              /* CRC parity masks of this lane */
 struct FastBits { uint64_t s_lo, s_hi; uint16_t calc_crc; uint8_t ref_low, ref_high, h, s; bool ctrl_block; };
 
+/* Control Block pattern (stc007line.cpp:493-504: words 0..3 = 0x3333 0x0CCC 0x3333 0x0CCC, word 4 = 0, bits 4..11 of word 7 = 0)
+ * tested on the raw cells: cell 14k+i holds bit 13-i of word k, lane i owns cells i (s_lo) and i+64 (s_hi). */
+constexpr uint64_t ctrl_cells_0_55()
+{
+    const uint16_t w[4] = { 0x3333, 0x0CCC, 0x3333, 0x0CCC };
+    uint64_t m = 0;
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 14; i++) if ((w[k] >> (13 - i)) & 1) m |= 1ull << (14 * k + i);
+    return m;
+}
+__device__ __forceinline__ bool ctrl_block_cells(uint64_t s_lo, uint64_t s_hi)
+{
+    constexpr uint64_t K = ctrl_cells_0_55();
+    return (s_lo & ((1ull << 56) - 1)) == K && (s_lo >> 56) == 0 && (s_hi & 0x3Full) == 0 && (s_hi & (0xFFull << 36)) == 0;
+}
+
 /* are the conditions of the STG_INPUT_ALL branch met for the coming line? (wave-uniform, no side effects) */
 __device__ inline bool fast_eligible(const FrameArgs &a, const Bin &b)
 {
@@ -1651,10 +1666,45 @@ __device__ inline bool fast_decode(const FrameArgs &a, const WaveLds &lds, const
     }
     if (!found) return false;
     o.s_lo = s_lo; o.s_hi = s_hi; o.calc_crc = calc_crc; o.ref_low = ref_low; o.ref_high = ref_high; o.h = (uint8_t)fh; o.s = (uint8_t)fs;
-    /* Control Block pattern on the raw cells (stc007line.cpp:493-504): words 0..4 fixed, word 7 bits 4..11 zero */
-    uint16_t w0 = rev14((uint32_t)(s_lo & 0x3FFF)), w1 = rev14((uint32_t)((s_lo >> 14) & 0x3FFF)), w2 = rev14((uint32_t)((s_lo >> 28) & 0x3FFF));
-    uint16_t w3 = rev14((uint32_t)((s_lo >> 42) & 0x3FFF)), w4 = rev14((uint32_t)(((s_lo >> 56) | (s_hi << 8)) & 0x3FFF)), w7 = rev14((uint32_t)((s_hi >> 34) & 0x3FFF));
-    o.ctrl_block = (w0 == 0x3333 && w1 == 0x0CCC && w2 == 0x3333 && w3 == 0x0CCC && w4 == 0 && (w7 & 0x0FF0) == 0);
+    o.ctrl_block = ctrl_block_cells(s_lo, s_hi);
+    return true;
+}
+
+/* What does not change while a batch of lines is decoded with the inherited tuning: the sampling positions of the two cells a
+ * lane owns at shift stage 0 and the hysteresis-depth-0 levels.  fast_try0 is the first rung of fast_decode's ladder with these
+ * hoisted; a line that does not pass it goes through fast_decode itself. */
+struct FastPre { int32_t x0, x1; uint8_t ref_low, ref_high; bool ok; };
+__device__ inline FastPre fast_pre(const FrameArgs &a, const Bin &b, Geo &g)
+{
+    FastPre p;
+    const int lane = lane_id();
+    const int32_t pixel_start = 0, pixel_stop = a.width - 1;
+    if (!g.valid || g.start != b.in_coord.start || g.stop != b.in_coord.stop) {
+        Line t; t.pixel_start = (uint16_t)pixel_start; t.pixel_stop = (uint16_t)pixel_stop;
+        set_ppb(t, b.in_coord);
+        g.start = b.in_coord.start; g.stop = b.in_coord.stop; g.psm = t.psm; g.valid = true;
+        g.vp0 = bit_center(t, lane); g.vp1 = bit_center(t, lane + 64);
+    }
+    p.ref_low = get_low_level(b.in_ref, 0); p.ref_high = get_high_level(b.in_ref, 0);
+    p.ok = !(p.ref_low <= b.in_black || p.ref_high >= b.in_white);
+    int32_t x0 = g.vp0, x1 = g.vp1;
+    p.x0 = x0 < pixel_start ? pixel_start : (x0 >= pixel_stop ? pixel_stop - 1 : x0);
+    p.x1 = x1 < pixel_start ? pixel_start : (x1 >= pixel_stop ? pixel_stop - 1 : x1);
+    return p;
+}
+__device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const LaneConst &lc, FastBits &o)
+{
+    if (!p.ok) return false;
+    uint8_t p0 = lds.px[p.x0], p1 = lds.px[p.x1];
+    uint64_t a_lo = __ballot(p0 > p.ref_low), b_lo = __ballot(p0 >= p.ref_high);
+    uint64_t a_hi = __ballot(p1 > p.ref_low), b_hi = __ballot(p1 >= p.ref_high);
+    uint64_t s_lo, s_hi;
+    solve_automaton(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+    int par = (__popcll(s_lo & lc.klo) + __popcll(s_hi & lc.khi)) & 1;
+    uint16_t calc_crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc.init);
+    if (calc_crc != rev16((uint32_t)((s_hi >> 48) & 0xFFFF))) return false;
+    o.s_lo = s_lo; o.s_hi = s_hi; o.calc_crc = calc_crc; o.ref_low = p.ref_low; o.ref_high = p.ref_high; o.h = 0; o.s = 0;
+    o.ctrl_block = ctrl_block_cells(s_lo, s_hi);
     return true;
 }
 
@@ -1868,6 +1918,13 @@ __device__ __attribute__((noinline)) void slow_line(SlowCtx *c, WaveLds *lds, ui
     emit_record(c->wl, rec);
 }
 
+/* kLean: the build of the frame loop without the general path.  The general path (reference sweep, marker searches at 24
+ * hysteresis levels) is rare on a tape that plays, but as a callee its registers count for the whole kernel and hold the
+ * occupancy at 3 waves per SIMD; without it the loop fits 5.  A lean wave that meets a line it cannot take through the fast
+ * paths gives the frame up: it marks its outgoing state (sdv_v2d_state::_pad[0]) and the engine decodes from that frame on
+ * with the full kernel. */
+enum { STATE_ABORTED = 0xA5 };
+template <bool kLean>
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 {
     V2D v; Line wl;
@@ -1926,6 +1983,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             if (batch_eligible(a, lds, v, geo)) {
                 int nb = nl - idx; if (nb > 64) nb = 64;
                 BatchLane bl; bl.d0 = bl.d1 = bl.d2 = bl.d3 = bl.meta = 0;
+                const FastPre pre = fast_pre(a, v.bin, geo);
                 int j = 0;
                 for (; j < nb; j++) {
                     row_commit(lds, pf, a.width);
@@ -1936,7 +1994,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                         row_prefetch(pf, nxt, a.width);
                     }
                     FastBits fb;
-                    if (!fast_decode(a, lds, v.bin, geo, lc, fb) || fb.ctrl_block) break;
+                    if (!fast_try0(lds, pre, lc, fb) && !fast_decode(a, lds, v.bin, geo, lc, fb)) break;
+                    if (fb.ctrl_block) break;
                     bool mine = lane == j;
                     bl.d0 = mine ? (uint32_t)fb.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb.s_lo >> 32) : bl.d1;
                     bl.d2 = mine ? (uint32_t)fb.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb.s_hi >> 32) : bl.d3;
@@ -1958,11 +2017,16 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             }
             line_num = (uint16_t)(field + 1 + 2 * idx);
             if (!fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec)) {
-                SlowCtx c;
-                c.a = a; c.v = v;
-                slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
-                v = c.v;
-                v2d_make_uniform(v);
+                if (kLean) {
+                    if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; }
+                    return;
+                } else {
+                    SlowCtx c;
+                    c.a = a; c.v = v;
+                    slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
+                    v = c.v;
+                    v2d_make_uniform(v);
+                }
             }
             rec++; idx++;
         }
@@ -1987,6 +2051,15 @@ __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv:
 {
     __shared__ sdv::WaveLds lds;
     int f = a.frame_lo + (int)blockIdx.x;
-    if (f < a.frame_hi) sdv::frame_body(a, lds, f);
+    if (f < a.frame_hi) sdv::frame_body<false>(a, lds, f);
+}
+#ifndef SDV_LEAN_WAVES_PER_EU
+#define SDV_LEAN_WAVES_PER_EU 5   /* 1.26 ms vs 1.46 (4), 1.28 (6), 1.45 (8) per 10 000 frames (profiles/r01_tuning_notes.md) */
+#endif
+__global__ void __launch_bounds__(64, SDV_LEAN_WAVES_PER_EU) sdv_k_stc007_frames_lean(sdv::FrameArgs a)
+{
+    __shared__ sdv::WaveLds lds;
+    int f = a.frame_lo + (int)blockIdx.x;
+    if (f < a.frame_hi) sdv::frame_body<true>(a, lds, f);
 }
 #endif

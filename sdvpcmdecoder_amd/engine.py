@@ -78,7 +78,7 @@ assert PAIR_DTYPE.itemsize == 12 and C.sizeof(StitchSettings) == 16
 
 
 class RunInfo(C.Structure):
-    _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("_pad", C.c_uint32),
+    _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("frames_general", C.c_uint32),
                 ("kernel_ms", C.c_float), ("_pad2", C.c_float)]
 
 
