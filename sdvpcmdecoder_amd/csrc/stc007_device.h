@@ -353,9 +353,15 @@ __device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_
     uint64_t pt_hi = __ballot(c_hi & 1);
     uint64_t u_lo = ((a_lo & b_lo) ^ pt_lo) & e_lo, u_hi = ((a_hi & b_hi) ^ pt_hi) & e_hi;   /* head values */
     uint64_t x_lo = u_lo | ~e_lo, x_hi = u_hi | ~e_hi;
+#ifdef SDV_EMU
     uint64_t y_lo = x_lo + u_lo;
     uint64_t carry = (y_lo < x_lo) ? 1ull : 0ull;
     uint64_t y_hi = x_hi + u_hi + carry;
+#else
+    unsigned long long c1 = 0, c2 = 0;             /* one scalar add-with-carry chain (no 64-bit unsigned compare on the scalar unit) */
+    uint64_t y_lo = __builtin_addcll(x_lo, u_lo, 0ull, &c1);
+    uint64_t y_hi = __builtin_addcll(x_hi, u_hi, c1, &c2);
+#endif
     uint64_t d_lo = ((y_lo ^ x_lo) & ~e_lo) | u_lo;
     uint64_t d_hi = ((y_hi ^ x_hi) & ~e_hi) | u_hi;
     s_lo = d_lo ^ pt_lo;
@@ -1556,12 +1562,12 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
  * hides under the decode of the current line) -> LDS.  Rows that are not 16-byte aligned take the slow
  * byte path at commit time. */
-struct RowPrefetch { uint4 v0, v1; const uint8_t *row; };
+struct RowPrefetch { uint4 v0, v1; const uint8_t *row; bool vec; };    /* vec: every row of the frame starts 16-byte aligned */
 
 __device__ inline void row_prefetch(RowPrefetch &pf, const uint8_t *row, int width)
 {
     pf.row = row;
-    if (row != nullptr && (((uintptr_t)row) & 15) == 0) {
+    if (row != nullptr && pf.vec) {
         int lane = lane_id(), nvec = width >> 4;
         const uint4 *src = (const uint4 *)row;
         if (lane < nvec) pf.v0 = src[lane];
@@ -1573,7 +1579,7 @@ __device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width
     __syncthreads();
     int lane = lane_id();
     const uint8_t *row = pf.row;
-    if ((((uintptr_t)row) & 15) == 0) {
+    if (pf.vec) {
         int nvec = width >> 4;
         uint4 *dst = (uint4 *)lds.px;
         if (lane < nvec) dst[lane] = pf.v0;
@@ -1973,7 +1979,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
     pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
+    pf.vec = ((((uintptr_t)frame) | (uintptr_t)a.row_stride) & 15) == 0;
     row_prefetch(pf, frame, a.width);
+    const size_t row_step = 2 * a.row_stride;                  /* the next row of a field */
     uint16_t line_num = 0;
     for (int field = 0; field < 2; field++) {
         const int nl = n_field[field];
@@ -1989,7 +1997,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     row_commit(lds, pf, a.width);
                     {
                         int k = idx + j + 1;                    /* next row in decode order */
-                        const uint8_t *nxt = (k < nl) ? frame + (size_t)(2 * k + field) * a.row_stride
+                        const uint8_t *nxt = (k < nl) ? pf.row + row_step
                                                       : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : nullptr);
                         row_prefetch(pf, nxt, a.width);
                     }
@@ -2011,7 +2019,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             if (!staged) {
                 row_commit(lds, pf, a.width);
                 int k = idx + 1;
-                const uint8_t *nxt = (k < nl) ? frame + (size_t)(2 * k + field) * a.row_stride
+                const uint8_t *nxt = (k < nl) ? pf.row + row_step
                                               : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : nullptr);
                 row_prefetch(pf, nxt, a.width);
             }
