@@ -358,9 +358,14 @@ __device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_
     uint64_t carry = (y_lo < x_lo) ? 1ull : 0ull;
     uint64_t y_hi = x_hi + u_hi + carry;
 #else
-    unsigned long long c1 = 0, c2 = 0;             /* one scalar add-with-carry chain (no 64-bit unsigned compare on the scalar unit) */
-    uint64_t y_lo = __builtin_addcll(x_lo, u_lo, 0ull, &c1);
-    uint64_t y_hi = __builtin_addcll(x_hi, u_hi, c1, &c2);
+    /* one scalar add-with-carry chain over the four 32-bit limbs (there is no 64-bit unsigned compare on the scalar unit to
+     * recover the carry of a 64-bit add) */
+    unsigned c = 0;
+    uint32_t y0 = __builtin_addc((uint32_t)x_lo, (uint32_t)u_lo, 0u, &c);
+    uint32_t y1 = __builtin_addc((uint32_t)(x_lo >> 32), (uint32_t)(u_lo >> 32), c, &c);
+    uint32_t y2 = __builtin_addc((uint32_t)x_hi, (uint32_t)u_hi, c, &c);
+    uint32_t y3 = __builtin_addc((uint32_t)(x_hi >> 32), (uint32_t)(u_hi >> 32), c, &c);
+    uint64_t y_lo = ((uint64_t)y1 << 32) | y0, y_hi = ((uint64_t)y3 << 32) | y2;
 #endif
     uint64_t d_lo = ((y_lo ^ x_lo) & ~e_lo) | u_lo;
     uint64_t d_hi = ((y_hi ^ x_hi) & ~e_hi) | u_hi;
