@@ -36,14 +36,15 @@ def algorithmic_bytes_per_frame(width, height):
 
 def measured_hbm_traffic(frames_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-    this same command, profiles/r01_pmc_sdv_k_stc007_frames.json): FETCH_SIZE is in KB and, on gfx950, reports half
-    of a wide coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE in KB. Scaled per frame."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sdv_k_stc007_frames.json")
+    this same command, profiles/r01_pmc_sdv_k_stc007_frames_lean.json, made by tools/pmc_to_json.py): FETCH_SIZE is in KB
+    and, on gfx950, reports half of a wide coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE in KB.
+    Scaled per frame."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sdv_k_stc007_frames_lean.json")
     try:
         d = json.load(open(path))
         fetch = float(d["pmc3"]["FETCH_SIZE"]) * 1024.0 * 2.0
         write = float(d["pmc4"]["WRITE_SIZE"]) * 1024.0
-        return (fetch + write) / 10000.0 * frames_per_launch
+        return (fetch + write) / (float(d["pmc3"].get("grid_size", 640000)) / 64.0) * frames_per_launch
     except Exception:
         return None
 
@@ -166,6 +167,7 @@ def main():
     kernel_ms = 0.0
     rounds = 0
     launched = 0
+    general = 0             # frames that needed the full kernel (0 on a tape in steady state)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         decode_batch(tape_pos, False, out_lines[1:])
@@ -174,6 +176,7 @@ def main():
         kernel_ms += info.kernel_ms
         rounds += info.rounds
         launched += info.frames_launched
+        general += info.frames_general
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -246,7 +249,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(frames_per_launch),
                          "traffic_unit": "bytes per launch, from the rocprofv3 PMC passes committed under profiles/",
-                         "kernel": "sdv_k_stc007_frames", "avg_launch_ms": avg_launch_ms,
+                         "kernel": "sdv_k_stc007_frames_lean" if general == 0 else "sdv_k_stc007_frames_lean + sdv_k_stc007_frames", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_launch": bpf * frames_per_launch},
         }
         if stitch is not None:

@@ -1567,16 +1567,20 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
  * hides under the decode of the current line) -> LDS.  Rows that are not 16-byte aligned take the slow
  * byte path at commit time. */
-struct RowPrefetch { uint4 v0, v1; const uint8_t *row; bool vec; };    /* vec: every row of the frame starts 16-byte aligned */
+struct RowPrefetch {
+    uint4 v0, v1; const uint8_t *row;
+    bool vec;           /* every row of the frame starts 16-byte aligned: 16-byte vectors, else the byte path */
+    int i0;             /* this lane's vector of a row, clamped to the last one (lanes past the row reload it: no exec juggling) */
+};
 
+/* `row` is always a readable row of the frame (the caller passes any valid row when there is no next one) */
 __device__ inline void row_prefetch(RowPrefetch &pf, const uint8_t *row, int width)
 {
     pf.row = row;
-    if (row != nullptr && pf.vec) {
-        int lane = lane_id(), nvec = width >> 4;
+    if (pf.vec) {
         const uint4 *src = (const uint4 *)row;
-        if (lane < nvec) pf.v0 = src[lane];
-        if (lane + 64 < nvec) pf.v1 = src[lane + 64];
+        pf.v0 = src[pf.i0];
+        if (width > 1024) { int lane = lane_id(), nvec = width >> 4; if (lane + 64 < nvec) pf.v1 = src[lane + 64]; }
     }
 }
 __device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width)
@@ -1585,11 +1589,10 @@ __device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width
     int lane = lane_id();
     const uint8_t *row = pf.row;
     if (pf.vec) {
-        int nvec = width >> 4;
         uint4 *dst = (uint4 *)lds.px;
-        if (lane < nvec) dst[lane] = pf.v0;
-        if (lane + 64 < nvec) dst[lane + 64] = pf.v1;
-        for (int i = (nvec << 4) + lane; i < width; i += 64) lds.px[i] = row[i];
+        dst[lane] = pf.v0;                      /* lanes past the row write into the unused end of px (64 x 16 <= SDV_MAX_WIDTH) */
+        if (width > 1024) { int nvec = width >> 4; if (lane + 64 < nvec) dst[lane + 64] = pf.v1; }
+        if (width & 15) for (int i = (width & ~15) + lane; i < width; i += 64) lds.px[i] = row[i];
     } else {
         for (int i = lane; i < width; i += 64) lds.px[i] = row[i];
     }
@@ -1984,7 +1987,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
     pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
-    pf.vec = ((((uintptr_t)frame) | (uintptr_t)a.row_stride) & 15) == 0;
+    pf.vec = ((((uintptr_t)frame) | (uintptr_t)a.row_stride) & 15) == 0 && a.width >= 16;
+    { int nvec = a.width >> 4; pf.i0 = lane < nvec ? lane : (nvec > 0 ? nvec - 1 : 0); }
     row_prefetch(pf, frame, a.width);
     const size_t row_step = 2 * a.row_stride;                  /* the next row of a field */
     uint16_t line_num = 0;
@@ -2003,12 +2007,13 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     {
                         int k = idx + j + 1;                    /* next row in decode order */
                         const uint8_t *nxt = (k < nl) ? pf.row + row_step
-                                                      : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : nullptr);
+                                                      : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : frame);
                         row_prefetch(pf, nxt, a.width);
                     }
                     FastBits fb;
-                    if (!fast_try0(lds, pre, lc, fb) && !fast_decode(a, lds, v.bin, geo, lc, fb)) break;
-                    if (fb.ctrl_block) break;
+                    /* only the first rung of the ladder inside the batch: a line that needs another shift stage or hysteresis
+                     * depth ends the batch and takes the sequential path below (keeps this loop's control flow flat) */
+                    if (!fast_try0(lds, pre, lc, fb) || fb.ctrl_block) break;
                     bool mine = lane == j;
                     bl.d0 = mine ? (uint32_t)fb.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb.s_lo >> 32) : bl.d1;
                     bl.d2 = mine ? (uint32_t)fb.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb.s_hi >> 32) : bl.d3;
@@ -2025,7 +2030,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 row_commit(lds, pf, a.width);
                 int k = idx + 1;
                 const uint8_t *nxt = (k < nl) ? pf.row + row_step
-                                              : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : nullptr);
+                                              : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : frame);
                 row_prefetch(pf, nxt, a.width);
             }
             line_num = (uint16_t)(field + 1 + 2 * idx);

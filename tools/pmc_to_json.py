@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc1..pmc4 (rocprofv3 --pmc passes of tools/gpu_validate.sh) -> profiles/<round>_pmc_<kernel>.json:
+per-launch counter sums of the last full-batch dispatch of the given kernel."""
+import collections, csv, glob, json, sys
+kernel = sys.argv[1] if len(sys.argv) > 1 else "sdv_k_stc007_frames_lean"
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_%s.json" % kernel
+res = {}
+for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    agg = collections.OrderedDict()
+    for f in glob.glob("gpurun_out/%s/**/*_counter_collection.csv" % p, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if not r["Kernel_Name"].startswith(kernel + "("):
+                continue
+            k = (int(r["Dispatch_Id"]), int(r["Grid_Size"]))
+            d = agg.setdefault(k, {"vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "scratch": r["Scratch_Size"], "lds": r["LDS_Block_Size"]})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    if not agg:
+        continue
+    big = max(g for (_, g) in agg)
+    last = max(k for k in agg if k[1] == big)
+    res[p] = dict(agg[last], grid_size=big)
+json.dump(res, open(out, "w"), indent=1)
+print(out, {p: {k: v for k, v in d.items() if k.isupper()} for p, d in res.items()})
