@@ -359,12 +359,13 @@ __device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_
     uint64_t y_hi = x_hi + u_hi + carry;
 #else
     /* one scalar add-with-carry chain over the four 32-bit limbs (there is no 64-bit unsigned compare on the scalar unit to
-     * recover the carry of a 64-bit add) */
-    unsigned c = 0;
-    uint32_t y0 = __builtin_addc((uint32_t)x_lo, (uint32_t)u_lo, 0u, &c);
-    uint32_t y1 = __builtin_addc((uint32_t)(x_lo >> 32), (uint32_t)(u_lo >> 32), c, &c);
-    uint32_t y2 = __builtin_addc((uint32_t)x_hi, (uint32_t)u_hi, c, &c);
-    uint32_t y3 = __builtin_addc((uint32_t)(x_hi >> 32), (uint32_t)(u_hi >> 32), c, &c);
+     * recover the carry of a 64-bit add, and the compiler re-materialises SCC between the limbs when left to itself) */
+    uint32_t y0, y1, y2, y3;
+    asm volatile("s_add_u32 %0, %4, %8\n\ts_addc_u32 %1, %5, %9\n\ts_addc_u32 %2, %6, %10\n\ts_addc_u32 %3, %7, %11"
+                 : "=&s"(y0), "=&s"(y1), "=&s"(y2), "=&s"(y3)
+                 : "s"((uint32_t)x_lo), "s"((uint32_t)(x_lo >> 32)), "s"((uint32_t)x_hi), "s"((uint32_t)(x_hi >> 32)),
+                   "s"((uint32_t)u_lo), "s"((uint32_t)(u_lo >> 32)), "s"((uint32_t)u_hi), "s"((uint32_t)(u_hi >> 32))
+                 : "scc");
     uint64_t y_lo = ((uint64_t)y1 << 32) | y0, y_hi = ((uint64_t)y3 << 32) | y2;
 #endif
     uint64_t d_lo = ((y_lo ^ x_lo) & ~e_lo) | u_lo;
@@ -1631,6 +1632,7 @@ constexpr uint64_t ctrl_cells_0_55()
 __device__ __forceinline__ bool ctrl_block_cells(uint64_t s_lo, uint64_t s_hi)
 {
     constexpr uint64_t K = ctrl_cells_0_55();
+    if ((uint32_t)s_lo != (uint32_t)K) return false;            /* one compare settles nearly every line */
     return (s_lo & ((1ull << 56) - 1)) == K && (s_lo >> 56) == 0 && (s_hi & 0x3Full) == 0 && (s_hi & (0xFFull << 36)) == 0;
 }
 
@@ -1706,9 +1708,8 @@ __device__ inline FastPre fast_pre(const FrameArgs &a, const Bin &b, Geo &g)
     p.x1 = x1 < pixel_start ? pixel_start : (x1 >= pixel_stop ? pixel_stop - 1 : x1);
     return p;
 }
-__device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const LaneConst &lc, FastBits &o)
+__device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const LaneConst &lc, FastBits &o)     /* needs p.ok */
 {
-    if (!p.ok) return false;
     uint8_t p0 = lds.px[p.x0], p1 = lds.px[p.x1];
     uint64_t a_lo = __ballot(p0 > p.ref_low), b_lo = __ballot(p0 >= p.ref_high);
     uint64_t a_hi = __ballot(p1 > p.ref_low), b_hi = __ballot(p1 >= p.ref_high);
@@ -1997,18 +1998,24 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
         int idx = 0;
         while (idx < nl) {
             bool staged = false;
-            if (batch_eligible(a, lds, v, geo)) {
+            /* the batch loop is the 16-byte-vector, single-vector-per-lane case (rows aligned, width a multiple of 16 up to 1024:
+             * SD video); everything else takes the sequential path below */
+            FastPre pre; pre.ok = false;
+            if (pf.vec && a.width <= 1024 && (a.width & 15) == 0 && batch_eligible(a, lds, v, geo)) pre = fast_pre(a, v.bin, geo);
+            if (pre.ok) {
                 int nb = nl - idx; if (nb > 64) nb = 64;
                 BatchLane bl; bl.d0 = bl.d1 = bl.d2 = bl.d3 = bl.meta = 0;
-                const FastPre pre = fast_pre(a, v.bin, geo);
                 int j = 0;
                 for (; j < nb; j++) {
-                    row_commit(lds, pf, a.width);
-                    {
+                    {   /* row_commit / row_prefetch of the plain case, without their case distinctions */
+                        __syncthreads();
+                        ((uint4 *)lds.px)[lane] = pf.v0;
+                        __syncthreads();
                         int k = idx + j + 1;                    /* next row in decode order */
                         const uint8_t *nxt = (k < nl) ? pf.row + row_step
                                                       : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : frame);
-                        row_prefetch(pf, nxt, a.width);
+                        pf.row = nxt;
+                        pf.v0 = ((const uint4 *)nxt)[pf.i0];
                     }
                     FastBits fb;
                     /* only the first rung of the ladder inside the batch: a line that needs another shift stage or hysteresis
