@@ -91,7 +91,7 @@ __device__ __constant__ const CrcTables c_crc = make_crc_tables();
 struct SweepEnt { uint8_t result, hyst, shift, pad; uint16_t crc; int16_t start, stop; uint16_t pad2; };
 struct CrcStat { uint8_t result, hyst, shift, idx; uint16_t crc; };
 struct WaveLds {
-    uint8_t px[SDV_MAX_WIDTH];
+    alignas(16) uint8_t px[SDV_MAX_WIDTH];
     uint32_t hist[256];
     SweepEnt sweep[256];
     CrcStat crc_stats[MAX_COLL_CRCS + 1];
@@ -1689,7 +1689,7 @@ __device__ inline bool fast_decode(const FrameArgs &a, const WaveLds &lds, const
 /* What does not change while a batch of lines is decoded with the inherited tuning: the sampling positions of the two cells a
  * lane owns at shift stage 0 and the hysteresis-depth-0 levels.  fast_try0 is the first rung of fast_decode's ladder with these
  * hoisted; a line that does not pass it goes through fast_decode itself. */
-struct FastPre { int32_t x0, x1; uint8_t ref_low, ref_high; bool ok; };
+struct FastPre { int32_t x0, x1; uint32_t ref_low, ref_high; bool ok; };
 __device__ inline FastPre fast_pre(const FrameArgs &a, const Bin &b, Geo &g)
 {
     FastPre p;
@@ -1718,10 +1718,12 @@ __device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const Lan
     int par = (__popcll(s_lo & lc.klo) + __popcll(s_hi & lc.khi)) & 1;
     uint16_t calc_crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc.init);
     if (calc_crc != rev16((uint32_t)((s_hi >> 48) & 0xFFFF))) return false;
-    o.s_lo = s_lo; o.s_hi = s_hi; o.calc_crc = calc_crc; o.ref_low = p.ref_low; o.ref_high = p.ref_high; o.h = 0; o.s = 0;
-    o.ctrl_block = ctrl_block_cells(s_lo, s_hi);
+    o.s_lo = s_lo; o.s_hi = s_hi; o.calc_crc = calc_crc; o.ref_low = (uint8_t)p.ref_low; o.ref_high = (uint8_t)p.ref_high; o.h = 0; o.s = 0;
+    o.ctrl_block = false;                   /* not looked at here: the batch loop does ctrl_block_maybe() */
     return true;
 }
+/* the first 32 cells of the Control Block pattern: necessary for a Control Block, and a false alarm only once in 2^32 lines */
+__device__ __forceinline__ bool ctrl_block_maybe(uint64_t s_lo) { return (uint32_t)s_lo == (uint32_t)ctrl_cells_0_55(); }
 
 __device__ inline void bits_to_words(uint64_t s_lo, uint64_t s_hi, uint16_t *w)
 {
@@ -2020,7 +2022,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     FastBits fb;
                     /* only the first rung of the ladder inside the batch: a line that needs another shift stage or hysteresis
                      * depth ends the batch and takes the sequential path below (keeps this loop's control flow flat) */
-                    if (!fast_try0(lds, pre, lc, fb) || fb.ctrl_block) break;
+                    if (!fast_try0(lds, pre, lc, fb) || ctrl_block_maybe(fb.s_lo)) break;
                     bool mine = lane == j;
                     bl.d0 = mine ? (uint32_t)fb.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb.s_lo >> 32) : bl.d1;
                     bl.d2 = mine ? (uint32_t)fb.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb.s_hi >> 32) : bl.d3;
