@@ -324,6 +324,9 @@ __device__ inline void process_block(const sdv_deint_settings &st, const Lines8 
             if (!(run_res == SDV_RES_14BIT && st.en_q_code)) return;
             if ((uint16_t)(calc_q(out) ^ out.w(WORD_Q0)) == 0) return;
         }
+        /* all words passed their CRC but a syndrome does not vanish: P_CORR / the Q check mark the block broken; with a fixed
+         * resolution there is no second attempt (what a 16-bit probe of 14-bit material runs into block after block) */
+        if (st.res_mode == SDV_RES_MODE_14BIT || st.res_mode == SDV_RES_MODE_16BIT) { blk_mark_broken(out); return; }
     } else if (run_res == SDV_RES_14BIT && (bad & (bad - 1)) == 0) {
         /* Second short cut, the block next to a lost line: exactly one word failed its CRC (14-bit mode).
          *   audio word k: TASK_SELECTION -> P_CORR: fixByP(k) (FIX_DONE or FIX_NOT_NEED) -> audio state FIX_P -> Q syndrome check

@@ -1116,16 +1116,21 @@ struct Step {
          * again: it may get forced bad).  A block none of whose eight lines is such a line cannot change anything, so each
          * class only decodes the blocks that touch one: candidate bits of the queue by ballot, then per class. */
         __shared__ uint64_t s_bad[QCAP / 64];
+        bool any_bad = false;
+        uint32_t mine = 0;                      /* bit c: line c * 64 + lane is a candidate (loads first, ballots after: they pipeline) */
         for (int c = 0; c * 64 < qn; c++) {
             const int i = c * 64 + lane;
-            bool bad = false;
             if (i < qn) {
                 const SLine &l = q[i];
                 const bool forced = (l.flags & SL_FORCED_BAD) != 0, failed = forced || ((l.wcrc & 0xFF) != 0xFF);
                 const bool eligible = !crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced && l.frame != f2.frame_number;
-                bad = failed && (eligible || crc_valid(l));
+                if (failed && (eligible || crc_valid(l))) mine |= 1u << c;
             }
-            const uint64_t m = __ballot(bad);
+        }
+        any_bad = __ballot(mine != 0) != 0;
+        if (!any_bad && !cfg.ignore_crc) return false;          /* nothing in the queue can change: the common case on a clean tape */
+        for (int c = 0; c * 64 < qn; c++) {
+            const uint64_t m = __ballot((mine >> c) & 1);
             if (lane == 0) s_bad[c] = m;
         }
         __syncthreads();
@@ -1206,6 +1211,7 @@ struct Step {
     {
         if (!cfg.en_cwd) return;
         bool next = false;
+        const int qn_own = qn;                                        /* the queue without frame B's look-ahead lines */
         if (f1.outer_padding_ok && order_set(f1)) {                   /* fillNextFieldForCWD :5390-5456 */
             uint16_t last_line = f1.field_order == ORDER_TFF ? 1 : 2;
             Field p = f1.field_order == ORDER_TFF ? field(2, 0) : field(2, 1);
@@ -1216,7 +1222,10 @@ struct Step {
         }
         __syncthreads();
         for (;;) { bool more = perform_cwd(); __syncthreads(); if (!more) break; }
-        if (next) while (qn > 0 && uni(q[qn - 1].frame) == f2.frame_number) qn--;      /* removeNextFieldAfterCWD */
+        if (next) {                                                   /* removeNextFieldAfterCWD: every trailing line of frame B */
+            qn = qn_own;                                              /* the look-ahead lines are frame B's by construction ... */
+            while (qn > 0 && uni(q[qn - 1].frame) == f2.frame_number) qn--;      /* ... and so is the end-of-file flush, if any */
+        }
     }
 
     /* ---- performDeinterleave (:6675-6885) + outputSamplePair (:6525-6569) ---- */
