@@ -49,3 +49,17 @@ def test_product_does_not_reference_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liborc" not in text and "oracle/" not in text.replace("(see oracle/", ""), f
                 assert "hip_emu.h" not in text or f == "stc007_device.h" or f == "engine.inc", f
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and as C++ on its own, and the PODs must have the documented sizes."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "sdvpcm.h"\n'
+                   '#define CHECK(t, n) typedef char check_##t[(sizeof(t) == (n)) ? 1 : -1]\n'
+                   'CHECK(sdv_line_rec, 48); CHECK(sdv_frame_stats, 32); CHECK(sdv_v2d_state, 120); CHECK(sdv_deint_line, 24);\n'
+                   'CHECK(sdv_block_rec, 72); CHECK(sdv_sample_pair, 12); CHECK(sdv_frame_asm, 64); CHECK(sdv_stitch_settings, 16);\n'
+                   'int main(void) { sdv_engine *e = sdv_engine_create(0); sdv_engine_destroy(e); return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
