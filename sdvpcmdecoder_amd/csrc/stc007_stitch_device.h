@@ -425,10 +425,8 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
             } else ln = 0;
             if (r.service_type != SDV_SRV_NO && r.service_type != SDV_SRV_FILLER) ln = 0;
         }
-        /* f_max_line: over all data / filler lines */
-        for (int ofs = 32; ofs > 0; ofs >>= 1) { uint16_t o = (uint16_t)__shfl((int)ln, (lane + ofs) & 63); if (o > ln) ln = o; }
-        uint16_t mx = (uint16_t)__shfl((int)ln, 0);
-        if (mx > max_line) max_line = mx;
+        /* f_max_line and the reference-level sums: per lane here, across the lanes once after the pass */
+        if (ln > max_line) max_line = ln;
         for (int p = 0; p < 2; p++) {
             bool mine = sel && (odd == (p == 0));
             uint64_t m = __ballot(mine);
@@ -436,11 +434,15 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
             bool kept = mine && rank < BUF_FIELD;
             if (kept) a.fields[((size_t)k * 2 + (size_t)p) * BUF_FIELD + rank] = sline_from_rec(a.src.at(start + i));
             uint64_t mk = __ballot(kept), mv = __ballot(kept && ok);
-            /* sums of the reference level over kept lines / kept valid lines */
-            uint32_t ra = kept ? ref : 0, ro = (kept && ok) ? ref : 0;
-            for (int ofs = 32; ofs > 0; ofs >>= 1) { ra += (uint32_t)__shfl((int)ra, (lane + ofs) & 63); ro += (uint32_t)__shfl((int)ro, (lane + ofs) & 63); }
-            ref_all[p] += (uint32_t)__shfl((int)ra, 0); ref_ok[p] += (uint32_t)__shfl((int)ro, 0);
+            ref_all[p] += kept ? ref : 0; ref_ok[p] += (kept && ok) ? ref : 0;
             cnt[p] += (uint32_t)__popcll(mk); valid[p] += (uint32_t)__popcll(mv);
+        }
+    }
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        uint16_t o = (uint16_t)__shfl((int)max_line, (lane + ofs) & 63); if (o > max_line) max_line = o;
+        for (int p = 0; p < 2; p++) {
+            ref_all[p] += (uint32_t)__shfl((int)ref_all[p], (lane + ofs) & 63);
+            ref_ok[p] += (uint32_t)__shfl((int)ref_ok[p], (lane + ofs) & 63);
         }
     }
     int8_t ctrl[5] = { -1, -1, -1, -1, -1 };
