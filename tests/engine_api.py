@@ -73,9 +73,20 @@ def emu_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
     return rc, pairs[:npairs.value], frames[:nframes.value]
 
 
-def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1):
-    """Host-memory call (emulator build only)."""
+def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1, row_stride=None, misalign=0):
+    """Host-memory call (emulator build only).  row_stride / misalign: the same pixels in a padded, shifted buffer."""
     n, h, w = luma.shape
+    if row_stride is not None or misalign:
+        rs = row_stride or w
+        buf = np.full(n * h * rs + misalign + 64, 0x5A, dtype=np.uint8)
+        view = buf[misalign:misalign + n * h * rs].reshape(n, h, rs)
+        view[:, :, :w] = luma
+        nrec = n * (h + 3) + (1 if flags & 1 else 0) + (h + 4 if flags & 4 else 0)
+        recs = np.zeros(nrec, dtype=libs.LINE_DTYPE)
+        stats = np.zeros(n + (1 if flags & 4 else 0), dtype=STATS_DTYPE)
+        rc = lib.sdv_binarize_frames(eng, buf.ctypes.data + misalign, rs, rs * h, w, h, n, first_frame_no, flags, recs.ctypes.data,
+                                     stats.ctypes.data, None)
+        return rc, recs, stats
     nrec = n * (h + 3) + (1 if flags & 1 else 0) + (h + 4 if flags & 4 else 0)
     recs = np.zeros(nrec, dtype=libs.LINE_DTYPE)
     stats = np.zeros(n + (1 if flags & 4 else 0), dtype=STATS_DTYPE)

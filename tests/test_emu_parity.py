@@ -67,6 +67,25 @@ def test_emu_end_of_file_frame_and_next_source(emu_lib, oracle_lib):
     assert gs2.view(np.uint8).tobytes() == ws2.tobytes()
 
 
+@pytest.mark.parametrize("width,height,row_stride,misalign", [(720, 47, None, 0), (721, 40, None, 0), (712, 42, 720, 0), (720, 40, 733, 0),
+                                                             (720, 40, None, 3), (736, 38, 752, 16)])
+def test_emu_ragged_geometry(emu_lib, oracle_lib, width, height, row_stride, misalign):
+    """Odd heights, widths that are not a multiple of 16, padded rows, buffers that do not start 16-byte aligned: the vector
+    staging of the frame loop has to fall back to its byte path (or not) without changing a record."""
+    emu = emu_lib
+    even = height + (height & 1)
+    luma, _, _ = synth.stc007_frames(n_frames=3, seed=31, width=width, height=even, lines_per_field=even // 2 + 2, noise_sigma=3.0)
+    luma = np.ascontiguousarray(luma[:, :height])               # an odd height: the second field is one row shorter
+    want, want_stats = oracle_binarize(luma, mode=2)
+    eng = C.c_void_p(emu.sdv_engine_create(0))
+    emu.sdv_set_mode(eng, 2)
+    rc, got, got_stats = engine_api.emu_binarize(emu, eng, luma, row_stride=row_stride, misalign=misalign)
+    emu.sdv_engine_destroy(eng)
+    assert rc == 0
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+
+
 def test_emu_batch_path_corner_cases(emu_lib, oracle_lib):
     """Exercises the line-batch fast path: duplicated rows (dup-line rule), silent audio (almost-silent lines are
     exempt from it), a bad row in the middle of a batch, doubled-width sources, dup check switched off."""

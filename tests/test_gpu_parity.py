@@ -133,3 +133,27 @@ def test_hip_full_size_properties(torch_cuda):
     valid = (lines["flags"] & 64) != 0
     assert valid[:, 1:243].all() and valid[:, 244:].all() and not valid[:, 0].any() and not valid[:, 243].any()
     assert (body[:, 243]["service_type"] == 4).all() and (body[:, 487]["service_type"] == 4).all() and (body[:, 488]["service_type"] == 5).all()
+
+
+@pytest.mark.parametrize("width,height,pad,shift", [(720, 487, 0, 0), (721, 120, 0, 0), (712, 120, 8, 0), (720, 120, 13, 0), (720, 120, 0, 5),
+                                                     (736, 122, 16, 16)])
+def test_hip_ragged_geometry(torch_cuda, width, height, pad, shift):
+    """Odd heights, widths that are not a multiple of 16, padded rows (row_stride > width), buffers that do not start 16-byte
+    aligned: same records as the oracle (the frame loop picks its byte path or its vector path per frame)."""
+    torch = torch_cuda
+    from sdvpcmdecoder_amd import Engine, LINE_DTYPE
+    even = height + (height & 1)
+    luma, _, _ = synth.stc007_frames(n_frames=3, seed=33, width=width, height=even, lines_per_field=even // 2 + 2, noise_sigma=3.0)
+    luma = np.ascontiguousarray(luma[:, :height])
+    want, want_stats = oracle_binarize(luma, mode=2)
+    n = luma.shape[0]
+    rs = width + pad
+    buf = torch.full((n * height * rs + shift + 64,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    view = buf[shift:shift + n * height * rs].view(n, height, rs)[:, :, :width]
+    view.copy_(torch.from_numpy(luma).to("cuda:0"))
+    eng = Engine(0)
+    eng.setBinarizationMode(2)
+    lines, stats = eng.binarize_frames(view, first_frame_no=1, new_file=True)
+    got = lines.cpu().numpy().view(LINE_DTYPE).reshape(-1)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert stats.cpu().numpy().tobytes() == want_stats.tobytes()

@@ -64,6 +64,27 @@ def test_emu_streaming_calls_equal_one_call(emu, oracle_lib):
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
 
 
+def test_emu_empty_and_tiny_inputs(emu, oracle_lib):
+    """Nothing in, nothing out; a single frame has no successor yet and produces nothing until the next one arrives; a stream that
+    is only the end-of-file frame produces nothing at all."""
+    recs, st = sc.make_input("ntsc_clean", lambda luma: oracle_binarize(luma, mode=2))
+    want_p, want_f = sa.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    eng = emu.sdv_engine_create(0)
+    rc, p, f = ea.emu_stitch(emu, eng, recs[:0], st, pair_cap=16, frame_cap=4)
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    one = 1 + 489                                   # NEW_FILE + the first frame
+    rc, p, f = ea.emu_stitch(emu, eng, recs[:one], None, pair_cap=16, frame_cap=4)
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    rc, p, f = ea.emu_stitch(emu, eng, recs[one:], None)
+    assert rc == 0 and _same(p, f, want_p, want_f), _diff(p, f, want_p, want_f)
+    emu.sdv_engine_destroy(eng)
+    eng = emu.sdv_engine_create(0)
+    tail = recs[-(486 + 4):]                        # filler frame + END_FILE only
+    rc, p, f = ea.emu_stitch(emu, eng, tail, st, pair_cap=16, frame_cap=4)
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    emu.sdv_engine_destroy(eng)
+
+
 def test_emu_rejects_what_it_cannot_reproduce(emu, oracle_lib):
     recs, st = sc.make_input("ntsc_clean", lambda luma: oracle_binarize(luma, mode=2))
     bad = recs.copy()
