@@ -359,6 +359,53 @@ int sdv_saturate_stitch_stats(sdv_engine *e);
 int sdv_stitch_frames(sdv_engine *e, const sdv_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                       size_t *n_pairs, sdv_frame_asm *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* ---- PCM-1 back half: PCM1DataStitcher (pcm1datastitcher.h:94-201) ------------------------------------------------- */
+/* What PCM1DataStitcher reads of one PCM1Line (pcm1line.h:59-146, pcmline.h:137-186).  32 bytes. */
+typedef struct sdv_pcm1_line_rec {
+    uint32_t frame_number;          /* PCMLine::frame_number */
+    uint16_t line_number;           /* PCMLine::line_number */
+    uint16_t words[7];              /* PCM1Line::words: L2 R2 L4 R4 L6 R6 (13 bit) + CRCC as read */
+    uint16_t calc_crc;              /* PCMLine::getCalculatedCRC() */
+    uint8_t ref_level;              /* PCMLine::ref_level */
+    uint8_t picked_bits_left, picked_bits_right;    /* PCM1Line::picked_bits_* (Bit Picker) */
+    uint8_t service_type;           /* SDV_SRV_* (SDV_SRV_HEADER_LINE = PCM1Line::isServHeader()) */
+    uint8_t flags;                  /* SDV_LF_BW_SET, SDV_LF_FORCED_BAD */
+    uint8_t _pad[5];
+} sdv_pcm1_line_rec;
+
+/* PCM1DataStitcher slots (pcm1datastitcher.h:183-190); defaults of the constructor (pcm1datastitcher.cpp:18-31) */
+typedef struct sdv_pcm1_stitch_settings {
+    uint8_t field_order;            /* setFieldOrder: 1 = TFF (default), 2 = BFF */
+    uint8_t auto_offset;            /* setAutoLineOffset (default on) */
+    uint8_t use_ecc;                /* setFineUseECC (ignore_CRC = !use_ecc) */
+    int8_t odd_offset, even_offset; /* setOddLineOffset / setEvenLineOffset */
+    uint8_t _pad[3];
+} sdv_pcm1_stitch_settings;
+
+/* FrameAsmPCM1 (frametrimset.h:116-224) as emitted with guiUpdFrameAsm.  52 bytes. */
+typedef struct sdv_frame_asm_pcm1 {
+    uint32_t frame_number;
+    uint16_t odd_std_lines, even_std_lines, odd_data_lines, even_data_lines, odd_valid_lines, even_valid_lines;
+    uint16_t odd_top_data, odd_bottom_data, even_top_data, even_bottom_data, odd_sample_rate, even_sample_rate;
+    uint16_t blocks_total, blocks_drop, samples_drop;
+    uint16_t odd_top_padding, odd_bottom_padding, even_top_padding, even_bottom_padding, blocks_fix_bp;
+    uint8_t field_order, odd_ref, even_ref, service_type;
+    uint8_t flags;                  /* SDV_FA_ORDER_PRESET, SDV_FA_ORDER_GUESSED, SDV_FA1_ODD_EMPHASIS, SDV_FA1_EVEN_EMPHASIS */
+    uint8_t _pad[3];
+} sdv_frame_asm_pcm1;
+enum { SDV_FA1_ODD_EMPHASIS = 1 << 2, SDV_FA1_EVEN_EMPHASIS = 1 << 3 };
+
+void sdv_default_pcm1_stitch_settings(sdv_pcm1_stitch_settings *st);
+int sdv_set_pcm1_stitch_settings(sdv_engine *e, const sdv_pcm1_stitch_settings *st);
+/* PCM1DataStitcher::doFrameReassemble (pcm1datastitcher.cpp:1578-1772) over a span of the PCM-1 line stream: every complete
+ * frame (lines up to its END_FRAME) is trimmed, split into sub-lines and fields, padded to 735 sub-lines per field and
+ * deinterleaved into 8 blocks per field (PCM1Deinterleaver::processBlock, pcm1deinterleaver.cpp:69-278; PCM-1 has no error
+ * correction); 1470 PCMSamplePairs and one FrameAsmPCM1 per frame (plus the NEW_FILE / END_FILE tags).  Frames are
+ * independent of each other in this format, so there is no stream state apart from records that wait for their END_FRAME.
+ * Same conventions as sdv_stitch_frames (device pointers, counts returned, SDV_ERR_UNSUPPORTED for lines of foreign frames). */
+int sdv_pcm1_stitch_frames(sdv_engine *e, const sdv_pcm1_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
+                           size_t *n_pairs, sdv_frame_asm_pcm1 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

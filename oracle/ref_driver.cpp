@@ -463,3 +463,101 @@ extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sd
     delete ds;
     return overflow ? -1 : got;
 }
+
+/* ------------------------------------------------------------------ PCM-1 back half: the real PCM1DataStitcher */
+extern "C" uint16_t ref_pcm1_crc(const uint16_t *w6)
+{
+    PCM1Line l;
+    for (uint8_t i = 0; i < 6; i++) l.setWord(i, w6[i]);
+    l.calcCRC();
+    return l.getCalculatedCRC();
+}
+
+static void rec_to_pcm1_line(const sdv_pcm1_line_rec &r, PCM1Line &l)
+{
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    switch (r.service_type) {
+        case SDV_SRV_NEW_FILE: l.setServNewFile("synthetic.avi"); return;
+        case SDV_SRV_END_FILE: l.setServEndFile(); return;
+        case SDV_SRV_FILLER: l.setServFiller(); return;
+        case SDV_SRV_END_FIELD: l.setServEndField(); return;
+        case SDV_SRV_END_FRAME: l.setServEndFrame(); return;
+        case SDV_SRV_HEADER_LINE: l.setServHeader(); return;
+        default: break;
+    }
+    for (uint8_t i = 0; i < 6; i++) l.setWord(i, r.words[i]);
+    l.setSourceCRC(r.words[6]); l.calcCRC();
+    l.ref_level = r.ref_level; l.picked_bits_left = r.picked_bits_left; l.picked_bits_right = r.picked_bits_right;
+    l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
+    if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+}
+
+static void frasm1_to_pod(FrameAsmPCM1 &f, sdv_frame_asm_pcm1 *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->frame_number = f.frame_number;
+    o->odd_std_lines = f.odd_std_lines; o->even_std_lines = f.even_std_lines; o->odd_data_lines = f.odd_data_lines; o->even_data_lines = f.even_data_lines;
+    o->odd_valid_lines = f.odd_valid_lines; o->even_valid_lines = f.even_valid_lines;
+    o->odd_top_data = f.odd_top_data; o->odd_bottom_data = f.odd_bottom_data; o->even_top_data = f.even_top_data; o->even_bottom_data = f.even_bottom_data;
+    o->odd_sample_rate = f.odd_sample_rate; o->even_sample_rate = f.even_sample_rate;
+    o->blocks_total = f.blocks_total; o->blocks_drop = f.blocks_drop; o->samples_drop = f.samples_drop;
+    o->odd_top_padding = f.odd_top_padding; o->odd_bottom_padding = f.odd_bottom_padding; o->even_top_padding = f.even_top_padding; o->even_bottom_padding = f.even_bottom_padding;
+    o->blocks_fix_bp = f.blocks_fix_bp;
+    o->field_order = f.field_order; o->odd_ref = f.odd_ref; o->even_ref = f.even_ref;
+    o->service_type = f.isServNewFile() ? 1 : (f.isServEndFile() ? 2 : 0);
+    o->flags = (uint8_t)((f.isOrderPreset() ? SDV_FA_ORDER_PRESET : 0) | (f.isOrderGuessed() ? SDV_FA_ORDER_GUESSED : 0) |
+                         (f.odd_emphasis ? SDV_FA1_ODD_EMPHASIS : 0) | (f.even_emphasis ? SDV_FA1_EVEN_EMPHASIS : 0));
+}
+
+extern "C" long ref_pcm1_stitch_run(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                    sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames)
+{
+    PCM1DataStitcher *ds = new PCM1DataStitcher();
+    std::deque<PCM1Line> in_q;
+    std::deque<PCMSamplePair> out_q;
+    QMutex in_mtx, out_mtx, fr_mtx;
+    std::vector<FrameAsmPCM1> fr;
+    ds->setInputPointers(&in_q, &in_mtx);
+    ds->setOutputPointers(&out_q, &out_mtx);
+    QObject::connect(ds, &PCM1DataStitcher::guiUpdFrameAsm, [&](FrameAsmPCM1 d) { fr_mtx.lock(); fr.push_back(d); fr_mtx.unlock(); });
+    ds->setFieldOrder(st->field_order); ds->setAutoLineOffset(st->auto_offset != 0);
+    ds->setOddLineOffset(st->odd_offset); ds->setEvenLineOffset(st->even_offset); ds->setFineUseECC(st->use_ecc != 0);
+    std::thread th([ds]() { ds->doFrameReassemble(); });
+    size_t fed = 0; long got = 0; bool overflow = false;
+    size_t idle = 0;
+    PCM1Line l;
+    while (true) {
+        in_mtx.lock();
+        size_t qs = in_q.size();
+        while (fed < n_recs && qs < (size_t)(MAX_PCMLINE_QUEUE_SIZE - 1)) { rec_to_pcm1_line(recs[fed], l); in_q.push_back(l); fed++; qs++; }
+        in_mtx.unlock();
+        out_mtx.lock();
+        size_t drained = out_q.size();
+        while (!out_q.empty()) {
+            PCMSamplePair &p = out_q.front();
+            if ((size_t)got < out_cap) {
+                sdv_sample_pair *o = &out[got];
+                memset(o, 0, sizeof(*o));
+                for (int c = 0; c < 2; c++) {
+                    o->audio_word[c] = p.samples[c].audio_word;
+                    o->sample_flags[c] = (uint8_t)((p.samples[c].data_block_ok ? SDV_SF_BLOCK_OK : 0) | (p.samples[c].word_valid ? SDV_SF_WORD_VALID : 0) |
+                                                   (p.samples[c].word_fixed ? SDV_SF_WORD_FIXED : 0) | (p.samples[c].word_masked ? SDV_SF_WORD_MASKED : 0));
+                }
+                o->sample_rate = p.sample_rate; o->emphasis = p.emphasis; o->service_type = p.service_type;
+            } else overflow = true;
+            got++;
+            out_q.pop_front();
+        }
+        out_mtx.unlock();
+        if (fed == n_recs && drained == 0) { idle++; if (idle > 150) break; } else idle = 0;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    ds->stop();
+    th.join();
+    size_t nf = fr.size() < frames_cap ? fr.size() : frames_cap;
+    for (size_t i = 0; i < nf; i++) frasm1_to_pod(fr[i], &frames[i]);
+    if (n_frames) *n_frames = fr.size();
+    delete ds;
+    return overflow ? -1 : got;
+}

@@ -67,6 +67,12 @@ class StitchSettings(C.Structure):
                 ("top_line_fix", C.c_uint8), ("_pad", C.c_uint8), ("sample_rate_preset", C.c_uint16)]
 
 
+class Pcm1StitchSettings(C.Structure):
+    """PCM1DataStitcher settings (slots pcm1datastitcher.h:183-190)"""
+    _fields_ = [("field_order", C.c_uint8), ("auto_offset", C.c_uint8), ("use_ecc", C.c_uint8), ("odd_offset", C.c_int8),
+                ("even_offset", C.c_int8), ("_pad", C.c_uint8 * 3)]
+
+
 class StitchInfo(C.Structure):
     _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("_pad", C.c_uint32),
                 ("device_ms", C.c_float), ("_pad2", C.c_float)]
@@ -124,6 +130,11 @@ def load_library(path: str | None = None):
     lib.sdv_set_stitch_settings.argtypes = [C.c_void_p, C.POINTER(StitchSettings)]
     lib.sdv_reset_stitcher.argtypes = [C.c_void_p]
     lib.sdv_get_stitch_info.argtypes = [C.c_void_p, C.POINTER(StitchInfo)]
+    lib.sdv_default_pcm1_stitch_settings.argtypes = [C.POINTER(Pcm1StitchSettings)]
+    lib.sdv_set_pcm1_stitch_settings.argtypes = [C.c_void_p, C.POINTER(Pcm1StitchSettings)]
+    lib.sdv_pcm1_stitch_frames.restype = C.c_int
+    lib.sdv_pcm1_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     lib.sdv_stitch_frames.restype = C.c_int
     lib.sdv_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
@@ -272,6 +283,33 @@ class Engine:
         npairs, nframes = C.c_size_t(0), C.c_size_t(0)
         rc = self.lib.sdv_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
                                         C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
+        self._check(rc)
+        return out_pairs[:npairs.value], out_frames[:nframes.value]
+
+    # ---- PCM-1 back half (PCM1DataStitcher) ----
+    def default_pcm1_stitch_settings(self) -> Pcm1StitchSettings:
+        st = Pcm1StitchSettings()
+        self.lib.sdv_default_pcm1_stitch_settings(C.byref(st))
+        return st
+
+    def set_pcm1_stitch_settings(self, st: Pcm1StitchSettings):
+        self._check(self.lib.sdv_set_pcm1_stitch_settings(self._h, C.byref(st)))
+
+    def pcm1_stitch_frames(self, lines, out_pairs=None, out_frames=None, stream=None):
+        """PCM1DataStitcher::doFrameReassemble over a span of the PCM-1 line stream: `lines` is a torch.uint8 CUDA tensor
+        (n_records, 32) of sdv_pcm1_line_rec.  Returns (pairs, frames): torch.uint8 CUDA tensors (n_pairs, 12) of sdv_sample_pair
+        and (n_frames, 52) of sdv_frame_asm_pcm1."""
+        import torch
+        assert lines.is_cuda and lines.dtype == torch.uint8 and lines.dim() == 2 and lines.shape[1] == 32 and lines.is_contiguous()
+        n = lines.shape[0]
+        if out_pairs is None:
+            out_pairs = torch.empty((n * 3 + 4096, 12), dtype=torch.uint8, device=lines.device)     # 3 pairs per line + padding lines
+        if out_frames is None:
+            out_frames = torch.empty((n // 64 + 64, 52), dtype=torch.uint8, device=lines.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)
+        npairs, nframes = C.c_size_t(0), C.c_size_t(0)
+        rc = self.lib.sdv_pcm1_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
+                                             C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
 

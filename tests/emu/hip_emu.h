@@ -154,6 +154,7 @@ static inline unsigned __brev(unsigned v)
     return (v >> 16) | (v << 16);
 }
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = (T)(o + v); return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = (T)(o | v); return o; }
 template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 
 #endif

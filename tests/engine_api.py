@@ -53,6 +53,12 @@ def bind(lib):
     lib.sdv_stitch_frames.restype = C.c_int
     lib.sdv_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    import pcm1_api as p1
+    lib.sdv_default_pcm1_stitch_settings.argtypes = [C.POINTER(p1.Pcm1Settings)]
+    lib.sdv_set_pcm1_stitch_settings.argtypes = [C.c_void_p, C.POINTER(p1.Pcm1Settings)]
+    lib.sdv_pcm1_stitch_frames.restype = C.c_int
+    lib.sdv_pcm1_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     return lib
 
 
@@ -71,6 +77,24 @@ def emu_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
     rc = lib.sdv_stitch_frames(eng, recs.ctypes.data, len(recs), pairs.ctypes.data, pair_cap, C.byref(npairs),
                                frames.ctypes.data, frame_cap, C.byref(nframes), None)
     return rc, pairs[:npairs.value], frames[:nframes.value]
+
+
+def emu_pcm1_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
+    """Host-memory call (emulator build only): one sdv_pcm1_stitch_frames call over `recs`."""
+    import pcm1_api as p1
+    import stitch_api as sa
+    if settings is not None:
+        assert lib.sdv_set_pcm1_stitch_settings(eng, C.byref(settings)) == 0
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == 5).sum()) + 2
+    pair_cap = pair_cap or nfr * 1472 + 16
+    frame_cap = frame_cap or nfr + 8
+    pairs = np.zeros(pair_cap, dtype=sa.PAIR_DTYPE)
+    frames = np.zeros(frame_cap, dtype=p1.FRASM1_DTYPE)
+    npairs, nframes = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.sdv_pcm1_stitch_frames(eng, recs.ctypes.data if len(recs) else None, len(recs), pairs.ctypes.data, pair_cap, C.byref(npairs),
+                                    frames.ctypes.data, frame_cap, C.byref(nframes), None)
+    return rc, pairs[:min(npairs.value, pair_cap)], frames[:min(nframes.value, frame_cap)]
 
 
 def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1, row_stride=None, misalign=0):

@@ -1,0 +1,211 @@
+"""PCM-1 back half (PCM1DataStitcher -> PCMSamplePair).
+  oracle (oracle/pcm1.c)  vs  golden fixtures of the real reference, the reference's own CRC known answer, and - when the
+                              reference build is loadable - the real PCM1DataStitcher run live on every scenario;
+  HIP kernel source       vs  the oracle, on the SIMT emulator (CPU) and through the C-ABI on the GPU (-m gpu)."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import engine_api as ea
+import libs
+import pcm1_api as p1
+from stitch_api import PAIR_DTYPE
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _same(pairs, frames, want_p, want_f):
+    return len(pairs) == len(want_p) and pairs.tobytes() == want_p.tobytes() and len(frames) == len(want_f) and frames.tobytes() == want_f.tobytes()
+
+
+def _diff(pairs, frames, want_p, want_f):
+    out = [f"pairs {len(pairs)} vs {len(want_p)}, frames {len(frames)} vs {len(want_f)}"]
+    for i in range(min(len(frames), len(want_f))):
+        if frames[i].tobytes() != want_f[i].tobytes():
+            out.append(f" frame {i}: " + str([(n, frames[i][n], want_f[i][n]) for n in p1.FRASM1_DTYPE.names if np.any(frames[i][n] != want_f[i][n])]))
+    n = min(len(pairs), len(want_p))
+    d = np.nonzero((pairs[:n].view(np.uint8).reshape(n, 12) != want_p[:n].view(np.uint8).reshape(n, 12)).any(axis=1))[0]
+    out.append(f" {len(d)} pairs differ, first at {d[:5]}")
+    return "\n".join(out)
+
+
+def _oracle(name):
+    recs, st = p1.make_input(name)
+    pairs, frames = p1.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    return recs, st, pairs, frames
+
+
+# ---- the oracle is pinned ------------------------------------------------------------------------------------------
+def test_crc_known_answers(oracle_lib):
+    """PCM1Line::calcCRC: the reference's own test line (pcmtester.cpp:14-21 -> 0x9EB9), the silent line (CRC_SILENT) and 254
+    random lines whose CRC the real reference computed (tests/golden/pcm1_crc.npz)."""
+    oracle_lib.orc_pcm1_crc_words.restype = C.c_uint16
+    z = np.load(os.path.join(GOLD, "pcm1_crc.npz"))
+    words, crc = z["words"], z["crc"]
+    assert crc[0] == 0x9EB9 and crc[1] == 0xECBF
+    got = np.array([oracle_lib.orc_pcm1_crc_words(np.ascontiguousarray(w).ctypes.data_as(C.POINTER(C.c_uint16))) for w in words], dtype=np.uint16)
+    assert (got == crc).all()
+    assert (p1.crc_words(words) == crc).all()          # the vectorised copy the input generator uses
+
+
+@pytest.mark.parametrize("name", p1.GOLDEN)
+def test_oracle_matches_golden(name, oracle_lib):
+    z = np.load(os.path.join(GOLD, "pcm1_" + name + ".npz"))
+    recs, st, pairs, frames = _oracle(name)
+    assert hashlib.sha256(recs.tobytes()).hexdigest() == str(z["input_sha256"]), "regenerated input stream differs from the fixture's"
+    assert bytes(st) == z["settings"].tobytes()
+    want_p = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    want_f = np.ascontiguousarray(z["frames"]).view(p1.FRASM1_DTYPE).reshape(-1)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("name", list(p1.CASES))
+def test_oracle_matches_live_reference(name, oracle_lib):
+    if not libs.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available")
+    recs, st, pairs, frames = _oracle(name)
+    rp, rf = p1.run_cpu(libs.load_ref(), "ref_", recs, st)
+    assert _same(pairs, frames, rp, rf), _diff(pairs, frames, rp, rf)
+
+
+def test_clean_stream_is_a_permutation_of_the_lines(oracle_lib):
+    """Property: on a clean tape every block is valid and the pair stream holds every sub-line's words exactly once."""
+    recs, st = p1.make_input("clean")
+    pairs, frames = p1.run_cpu(oracle_lib, "orc_", recs, st)
+    assert (pairs["sample_flags"] == 3).all() and (frames["blocks_drop"] == 0).all() and len(pairs) == 3 * 1470
+
+    def sample(w):
+        w = w.astype(np.uint16)
+        coarse = (w & 0x1000) != 0
+        fine = (w << 4).astype(np.uint16)
+        c = ((w & 0x0FFF) << 2).astype(np.uint16) | np.where((w & 0x0800) != 0, 0xC000, 0).astype(np.uint16)
+        return np.where(coarse, c, fine).astype(np.uint16).view(np.int16)
+    data = recs[recs["service_type"] == 0]
+    want = sample(data["words"][:, :6].reshape(-1, 2))
+    a = np.sort(want.view(np.uint32).reshape(-1))
+    b = np.sort(np.ascontiguousarray(pairs["audio_word"]).view(np.uint32).reshape(-1))
+    assert (a == b).all()
+
+
+# ---- the kernels on the emulator -----------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emu(emu_lib):
+    return ea.bind(emu_lib)
+
+
+@pytest.mark.parametrize("name", list(p1.CASES))
+def test_emu_matches_oracle(name, emu, oracle_lib):
+    recs, st, want_p, want_f = _oracle(name)
+    eng = emu.sdv_engine_create(0)
+    rc, pairs, frames = ea.emu_pcm1_stitch(emu, eng, recs, st)
+    emu.sdv_engine_destroy(eng)
+    assert rc == 0
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def test_emu_streaming_calls_equal_one_call(emu, oracle_lib):
+    """The stream may arrive in arbitrary pieces: records wait in the engine for their END_FRAME."""
+    recs, st, want_p, want_f = _oracle("file_marks")
+    eng = emu.sdv_engine_create(0)
+    cuts = [0, 1, 2, 300, 496, 497, 1200, 1201, 2000, len(recs) - 1, len(recs)]
+    got_p, got_f = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs[a:b], st if a == 0 else None, pair_cap=8000, frame_cap=16)
+        assert rc == 0
+        got_p.append(p.copy())
+        got_f.append(f.copy())
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def test_emu_edge_inputs(emu, oracle_lib):
+    eng = emu.sdv_engine_create(0)
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, np.zeros(0, dtype=p1.LINE1_DTYPE))            # empty
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    recs, st = p1.make_input("clean")
+    end = int(np.nonzero(recs["service_type"] == p1.SRV_END_FRAME)[0][0])
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs[:end])                                  # a frame without its END_FRAME: nothing yet
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs[end:end + 1])                           # ... now it completes
+    want_p, want_f = p1.run_cpu(oracle_lib, "orc_", recs[:end + 1], st)
+    assert rc == 0 and _same(p, f, want_p, want_f)
+    lone = recs[end:end + 1].copy()                                                      # a lone END_FRAME: an all-padding frame
+    lone["frame_number"] = 9
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, lone)
+    want_p, want_f = p1.run_cpu(oracle_lib, "orc_", lone, st)
+    assert rc == 0 and len(p) == 1470 and _same(p, f, want_p, want_f)
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs, pair_cap=100, frame_cap=8)             # output buffer too small: reported, sized
+    assert rc != 0 and b"too small" in emu.sdv_last_error(eng)
+    emu.sdv_engine_destroy(eng)
+
+
+def test_emu_rejects_what_the_reference_handles_with_leftover_state(emu):
+    """Lines of a later frame queued ahead of an END_FRAME stay in the reference's queue for a later turn: not a per-frame job."""
+    recs, st = p1.make_input("clean")
+    recs = recs.copy()
+    recs["frame_number"][100] = 2
+    eng = emu.sdv_engine_create(0)
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs, st)
+    assert rc == -6 or rc != 0
+    assert b"later frame" in emu.sdv_last_error(eng)
+    emu.sdv_engine_destroy(eng)
+
+
+# ---- the product on the GPU ------------------------------------------------------------------------------------------
+def _gpu_run(eng, recs, st, torch, **kw):
+    from sdvpcmdecoder_amd import Pcm1StitchSettings
+    s = Pcm1StitchSettings.from_buffer_copy(bytes(st))
+    eng.set_pcm1_stitch_settings(s)
+    d = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), 32)).cuda()
+    p, f = eng.pcm1_stitch_frames(d, **kw)
+    return p.cpu().numpy().reshape(-1).view(PAIR_DTYPE), f.cpu().numpy().reshape(-1).view(p1.FRASM1_DTYPE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(p1.CASES))
+def test_gpu_matches_oracle(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    recs, st, want_p, want_f = _oracle(name)
+    pairs, frames = _gpu_run(Engine(0), recs, st, torch)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", p1.GOLDEN)
+def test_gpu_matches_golden_from_reference(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    z = np.load(os.path.join(GOLD, "pcm1_" + name + ".npz"))
+    recs, st = p1.make_input(name)
+    assert hashlib.sha256(recs.tobytes()).hexdigest() == str(z["input_sha256"])
+    pairs, frames = _gpu_run(Engine(0), recs, st, torch)
+    want_p = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    want_f = np.ascontiguousarray(z["frames"]).view(p1.FRASM1_DTYPE).reshape(-1)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+def test_gpu_large_batch_in_pieces():
+    """2000 frames with damage, file marks in the middle of the batch, three calls cut mid-frame: equal to the oracle's run."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    a = p1.make_stream(700, seed=41, p_bad=0.03, header=2, new_file=True, end_file=True)
+    b = p1.make_stream(1300, seed=42, p_bad=0.01, p_picked=0.02, new_file=True, first_frame=1000)
+    recs = np.concatenate([a, b])
+    st = p1.default_settings()
+    want_p, want_f = p1.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    eng = Engine(0)
+    cuts = [0, 123457, 600001, len(recs)]
+    got_p, got_f = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        p, f = _gpu_run(eng, recs[lo:hi], st, torch)
+        got_p.append(p)
+        got_f.append(f)
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
