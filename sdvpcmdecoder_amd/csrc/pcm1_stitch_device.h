@@ -28,7 +28,7 @@ enum { ORDER_TFF = 1, ORDER_BFF = 2 };
 /* per-frame marks found by the flags pass */
 enum { FF_NEW_FILE = 1, FF_END_FILE = 2, FF_FOREIGN = 4 };
 /* reasons a frame cannot be stitched statelessly (the reference would read sub-lines left over from earlier frames, or hold lines back) */
-enum { FE_FOREIGN = 1, FE_TOO_LONG = 2, FE_STALE = 4, FE_SHORT_QUEUE = 8 };
+enum { FE_FOREIGN = 1, FE_TOO_LONG = 2, FE_STALE = 4, FE_SHORT_QUEUE = 8, FE_MARKS = 16 };
 
 struct RecSrc1 {
     const sdv_pcm1_line_rec *carry; uint32_t n_carry; const sdv_pcm1_line_rec *recs;
@@ -36,52 +36,39 @@ struct RecSrc1 {
 };
 struct Cfg1 { uint8_t field_order, auto_offset, ignore_crc; int8_t odd_offset, even_offset; };
 
-/* a service line is a cleared PCM1Line that keeps frame and line number (PCMLine::setServiceLine, pcmline.cpp:490-502) */
-__device__ inline bool r_service(const sdv_pcm1_line_rec &r) { return r.service_type != SDV_SRV_NO; }
-__device__ inline bool r_crc_if(const sdv_pcm1_line_rec &r) { return !r_service(r) && r.calc_crc == r.words[6]; }   /* isCRCValidIgnoreForced */
-__device__ inline bool r_crc(const sdv_pcm1_line_rec &r) { return !(r.flags & SDV_LF_FORCED_BAD) && r_crc_if(r); }    /* isCRCValid, pcmline.cpp:360-367 */
-__device__ inline bool r_bw(const sdv_pcm1_line_rec &r) { return !r_service(r) && (r.flags & SDV_LF_BW_SET) != 0; }
-
-/* ---- segments: positions of the END_FRAME records (same two-pass scheme as the STC-007 stitch stage) ------------- */
-struct SegArgs1 { RecSrc1 src; uint32_t n_recs; uint32_t *block_count; const uint32_t *block_ofs; uint32_t *seg_end; int write; };
-enum { SEG_CHUNK1 = 4096 };
+/* ---- segments: positions of the END_FRAME records, and the file tags of every frame ------------------------------- */
+/* Pass 0 counts the END_FRAMEs of every 4096-record chunk and leaves each record's service type in a byte array (5 MB for a
+ * 10 000-frame batch instead of the 157 MB of records); after the host's prefix sum, pass 1 works from those bytes: it writes
+ * the segment ends and tags segment k (= the number of END_FRAMEs ahead of a record) with the NEW_FILE / END_FILE records in it.
+ * The frame kernel, which sees the frame numbers, confirms the tags. */
+struct SegArgs1 { RecSrc1 src; uint32_t n_recs; uint8_t *svc; uint32_t *block_count; const uint32_t *block_ofs; uint32_t *seg_end; uint32_t n_seg; uint32_t *marks; uint32_t *stat; int write; };
+#ifndef SDV_P1_SEG_CHUNK
+#define SDV_P1_SEG_CHUNK 1024
+#endif
+enum { SEG_CHUNK1 = SDV_P1_SEG_CHUNK };
 __device__ inline void seg_body(const SegArgs1 &a, uint32_t blk, int lane)
 {
     const uint32_t lo = blk * SEG_CHUNK1;
     uint32_t hi = lo + SEG_CHUNK1; if (hi > a.n_recs) hi = a.n_recs;
     uint32_t cnt = 0;
+    const uint32_t base = a.write ? a.block_ofs[blk] : 0u;
+#pragma unroll 4
     for (uint32_t c = lo; c < hi; c += 64) {
         const uint32_t i = c + (uint32_t)lane;
-        const bool ef = i < hi && a.src.at(i).service_type == SDV_SRV_END_FRAME;
-        const uint64_t m = __ballot(ef);
-        if (a.write && ef) a.seg_end[a.block_ofs[blk] + cnt + (uint32_t)__popcll(m & lanemask_lt(lane))] = i;
+        uint8_t srv = SDV_SRV_NO;
+        if (i < hi) { if (a.write) srv = a.svc[i]; else { srv = a.src.at(i).service_type; a.svc[i] = srv; } }
+        const uint64_t m = __ballot(srv == SDV_SRV_END_FRAME);
+        if (a.write) {
+            const uint32_t seg = base + cnt + (uint32_t)__popcll(m & lanemask_lt(lane));
+            if (srv == SDV_SRV_END_FRAME) a.seg_end[seg] = i;
+            else if ((srv == SDV_SRV_NEW_FILE || srv == SDV_SRV_END_FILE) && seg < a.n_seg) {
+                atomicOr(&a.marks[seg], srv == SDV_SRV_NEW_FILE ? (uint32_t)FF_NEW_FILE : (uint32_t)FF_END_FILE);
+                atomicAdd(&a.stat[2], 1u);
+            }
+        }
         cnt += (uint32_t)__popcll(m);
     }
     if (!a.write && lane == 0) a.block_count[blk] = cnt;
-}
-
-/* ---- file marks per frame: a NEW_FILE / END_FILE record belongs to the frame whose END_FRAME follows it ------------ */
-struct MarkArgs1 { RecSrc1 src; uint32_t n_recs; const uint32_t *seg_end; uint32_t n_seg; uint32_t *marks; uint32_t *stat; };
-__device__ inline void mark_body(const MarkArgs1 &a, uint32_t i)
-{
-    if (i >= a.n_recs) return;
-    const sdv_pcm1_line_rec &r = a.src.at(i);
-    const uint8_t srv = r.service_type;
-    uint32_t lo = 0, hi = a.n_seg;                     /* first segment whose END_FRAME index is >= i */
-    if (srv != SDV_SRV_NEW_FILE && srv != SDV_SRV_END_FILE && srv != SDV_SRV_END_FRAME) {
-        /* ordinary lines only need the check for lines of a later frame queued ahead of this frame's END_FRAME: rare, so look at the
-         * neighbour first and search only when the frame number changes inside a segment */
-        if (i + 1 >= a.n_recs) return;
-        const sdv_pcm1_line_rec &nx = a.src.at(i + 1);
-        if (nx.frame_number >= r.frame_number) return;
-    }
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a.seg_end[mid] < i) lo = mid + 1; else hi = mid; }
-    if (lo >= a.n_seg) return;                          /* waits for its END_FRAME in the carry */
-    const uint32_t frame = a.src.at(a.seg_end[lo]).frame_number;
-    uint32_t m = 0;
-    if (r.frame_number == frame) { if (srv == SDV_SRV_NEW_FILE) m = FF_NEW_FILE; else if (srv == SDV_SRV_END_FILE) m = FF_END_FILE; }
-    else if (r.frame_number > frame) m = FF_FOREIGN;    /* the reference would keep this line queued for a later turn */
-    if (m) { atomicOr(&a.marks[lo], m); atomicAdd(&a.stat[2], 1u); }
 }
 
 /* ---- output offsets: exclusive scan of the per-frame output counts, one workgroup --------------------------------- */
@@ -120,94 +107,198 @@ struct FrameArgs1 {
     RecSrc1 src; const uint32_t *seg_end; uint32_t n_seg; Cfg1 cfg;
     const uint32_t *marks; const uint64_t *pair_ofs; const uint32_t *frasm_ofs;
     sdv_sample_pair *out_pairs; uint64_t pairs_cap; sdv_frame_asm_pcm1 *out_frames; uint32_t frames_cap;
+    unsigned long long *timing; /* developer aid (SDV_STITCH_TIMING): 8 cycle stamps per frame */
     uint32_t *stat;             /* [0] = OR of FE_*, [1] = first frame index with an error, [2] = marks set (0: the plain layout) */
 };
 
-__device__ inline uint32_t wmin(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane ^ d); v = o < v ? o : v; } return v; }
-__device__ inline uint32_t wmax(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane ^ d); v = o > v ? o : v; } return v; }
-__device__ inline uint32_t wsum(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) v += (uint32_t)__shfl((int)v, lane ^ d); return v; }
 
 __device__ inline void frasm1_clear(sdv_frame_asm_pcm1 &f)     /* FrameAsmPCM1::clear, frametrimset.cpp:455-464, 727-744 */
 {
     f = sdv_frame_asm_pcm1();
     f.odd_bottom_data = f.even_bottom_data = 0xFFFF;
 }
-__device__ inline void service_pair(sdv_sample_pair &p, uint8_t srv)
+/* a PCMSamplePair as its three 32-bit words (layout of sdv_sample_pair): built in registers, stored as one 12-byte write */
+struct Pair3 { uint32_t a, b, c; };
+static_assert(sizeof(sdv_sample_pair) == 12 && sizeof(Pair3) == 12, "pair layout");
+__device__ inline Pair3 make_pair3(int16_t l, int16_t r, uint32_t flags, uint32_t rate, bool emphasis, uint32_t srv)
 {
-    p.audio_word[0] = p.audio_word[1] = 0; p.sample_flags[0] = p.sample_flags[1] = 0; p.sample_rate = 44056; p.emphasis = 0; p.service_type = srv; p._pad = 0;
+    Pair3 p;
+    p.a = (uint32_t)(uint16_t)l | ((uint32_t)(uint16_t)r << 16);
+    p.b = flags | (flags << 8) | (rate << 16);
+    p.c = (emphasis ? 1u : 0u) | (srv << 8);
+    return p;
 }
+__device__ inline void store_pair(sdv_sample_pair *dst, const Pair3 &p) { *(Pair3 *)dst = p; }
+__device__ inline void service_pair(sdv_sample_pair *dst, uint8_t srv) { store_pair(dst, make_pair3(0, 0, 0, 44056, false, srv)); }
 /* PCM1DataBlock::getSample (pcm1datablock.cpp:309-348) */
 __device__ inline int16_t p1_sample(uint16_t w)
 {
-    if ((w & BIT_RANGE) == 0) return (int16_t)(uint16_t)(w << 4);
-    const bool pos = (w & BIT_SIGN) == 0;
-    w = (uint16_t)((w & ~BIT_RANGE) << 2);
-    if (!pos) w |= (1 << 15) | (1 << 14);
-    return (int16_t)w;
+    /* fine range (range bit clear): the 12 bits times 16; coarse range: the 12 bits sign-extended, times 4 - i.e. the same
+     * left-aligned value shifted back arithmetically by 2 */
+    const int16_t x = (int16_t)(uint16_t)(w << 4);
+    return (int16_t)(x >> ((w >> 11) & 2));
 }
 
 #define P1_NONE 0xFFFFFFFFu
+#ifdef SDV_EMU
+#define P1_STAMP(i) ((void)0)
+#else
+#define P1_STAMP(i) do { if (a.timing && lane == 0) a.timing[(size_t)k * 8 + (i)] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+#endif
 
-/* one wave, one frame.  lds: 2 x 245 record indices (+1: relative to the segment start) */
-__device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uint16_t (*field_idx)[LINES_PF + 3])
+/* What the frame needs of one line record, 16 bytes: the frame's records are read from HBM once and kept in LDS in this form. */
+struct Line16 { uint16_t w[6]; uint16_t line; uint8_t fl; uint8_t ref; };
+enum { LF_VALID = 1,        /* isCRCValid() of a data line of this frame */
+       LF_BW = 2,           /* hasBWSet() */
+       LF_CI = 4,           /* isCRCValidIgnoreForced() */
+       LF_DATA = 8,         /* takes part in splitFrameToFields: a data line or a filler of this frame */
+       LF_HDR = 16,         /* isServHeader() */
+       LF_OK = 32,          /* what the deinterleaver takes for "valid": B/W levels when CRCs are ignored, the CRC otherwise */
+       LF_PICK = 64,        /* picked_bits_right > 0 */
+       LF_PICKL = 128 };    /* picked_bits_left > 0 */
+#ifndef SDV_P1_LDS_LINES
+#define SDV_P1_LDS_LINES 544
+#endif
+enum { LDS_LINES = SDV_P1_LDS_LINES };   /* a 525-line frame's 490 PCM lines + service tags with room to spare (16 frames per CU); longer segments are read from
+                                          * global memory in every sweep */
+
+/* an sdv_pcm1_line_rec as the two 16-byte loads it is read with:
+ *   a = { frame_number, line_number | words[0] << 16, words[1] | words[2] << 16, words[3] | words[4] << 16 }
+ *   b = { words[5] | words[6] << 16, calc_crc | ref_level << 16 | picked_bits_left << 24, picked_bits_right | service_type << 8 | flags << 16, pad } */
+struct Raw32 { uint4 a, b; };
+static_assert(sizeof(sdv_pcm1_line_rec) == 32, "record layout");
+struct LineBits { uint32_t w01, w23, w45, meta; };      /* the bytes of a Line16: meta = line | fl << 16 | ref << 24 */
+static_assert(sizeof(Line16) == 16 && sizeof(LineBits) == 16, "line layout");
+
+__device__ inline LineBits compact_raw(const uint4 &a, const uint4 &b, uint32_t frame, bool ignore_crc, uint32_t &seen)
 {
-    const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, hi = a.seg_end[k];
-    const uint32_t frame = a.src.at(hi).frame_number;
+    const uint32_t srv = (b.z >> 8) & 0xFF;
+    const bool match = a.x == frame, data = match && srv == SDV_SRV_NO;
+    if (a.x > frame) seen |= FF_FOREIGN;
+    if (match && srv == SDV_SRV_NEW_FILE) seen |= FF_NEW_FILE;
+    if (match && srv == SDV_SRV_END_FILE) seen |= FF_END_FILE;
+    const uint32_t M = (uint32_t)WORD_MASK | ((uint32_t)WORD_MASK << 16), S = (uint32_t)BIT_RANGE | ((uint32_t)BIT_RANGE << 16);   /* a service line is a cleared line */
+    LineBits l;
+    l.w01 = data ? ((uint32_t)(((((uint64_t)a.z) << 32) | a.y) >> 16) & M) : S;
+    l.w23 = data ? ((uint32_t)(((((uint64_t)a.w) << 32) | a.z) >> 16) & M) : S;
+    l.w45 = data ? ((uint32_t)(((((uint64_t)b.x) << 32) | a.w) >> 16) & M) : S;
+    const bool ci = data && (b.y & 0xFFFF) == (b.x >> 16), crc = ci && !(b.z & ((uint32_t)SDV_LF_FORCED_BAD << 16)), bw = data && (b.z & ((uint32_t)SDV_LF_BW_SET << 16)) != 0;
+    const uint32_t fl = (crc ? LF_VALID : 0u) | (bw ? LF_BW : 0u) | (ci ? LF_CI : 0u) | ((data || (match && srv == SDV_SRV_FILLER)) ? LF_DATA : 0u) |
+                        ((match && srv == SDV_SRV_HEADER_LINE) ? LF_HDR : 0u) | ((ignore_crc ? bw : crc) ? LF_OK : 0u) |
+                        ((data && (b.z & 0xFF) != 0) ? LF_PICK : 0u) | ((data && (b.y >> 24) != 0) ? LF_PICKL : 0u);
+    l.meta = (a.y & 0xFFFF) | (fl << 16) | (data ? (b.y << 8) & 0xFF000000u : 0u);
+    return l;
+}
+__device__ inline Line16 compact(const sdv_pcm1_line_rec &r, uint32_t frame, bool ignore_crc, uint32_t &seen)
+{
+    const Raw32 *src = (const Raw32 *)&r;
+    const LineBits b = compact_raw(src->a, src->b, frame, ignore_crc, seen);
+    Line16 l;
+    __builtin_memcpy(&l, &b, sizeof(l));
+    return l;
+}
+
+/* one wave, one frame.  kLds: the frame's lines are staged in `lines` (LDS) by the first sweep; otherwise later sweeps read the records again. */
+template <bool kLds>
+__device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uint32_t lo, uint32_t n, Line16 *lines, uint16_t (*field_idx)[LINES_PF + 3])
+{
+    const uint32_t frame = a.src.at(lo + n).frame_number;           /* the END_FRAME record */
     const bool plain = a.stat[2] == 0;
     const uint32_t marks = plain ? 0u : a.marks[k];
     const uint64_t pofs = plain ? (uint64_t)k * (2 * SUBLINES_PF) : a.pair_ofs[k];
     const uint32_t fofs = plain ? k : a.frasm_ofs[k];
     const Cfg1 cfg = a.cfg;
-    uint32_t err = (marks & FF_FOREIGN) ? FE_FOREIGN : 0;
-    const uint32_t n = hi - lo;
-    if (n > BUF_TRIM) err |= FE_TOO_LONG;
+    uint32_t err = n > BUF_TRIM ? FE_TOO_LONG : 0u, seen = 0;
+    auto line_at = [&](uint32_t i) -> Line16 { if (kLds) return lines[i]; uint32_t dummy = 0; return compact(a.src.at(lo + i), frame, cfg.ignore_crc != 0, dummy); };
+
+    P1_STAMP(0);
+    /* 1. findFrameTrim: every item is a first / last / count over the lines in stream order; index 0 = odd lines, 1 = even lines */
+    /* The sweep itself only loads, compacts, stores to LDS and notes which of the eight kinds of line
+     *     q = 4 * (even line) + {0: CRC valid, 1: B/W levels, 2: CRC valid ignoring "forced bad", 3: header line}
+     * occur at all (plus the count of valid lines per field).  The first and the last line of every kind that does occur is then
+     * searched from either end of the staged lines - found in the first chunk looked at on any ordinary frame.
+     * Four chunks of 64 records per turn: the eight 16-byte loads of a turn are issued back to back, so a 490-line frame costs
+     * two memory round trips instead of eight. */
+    uint32_t any8 = 0, goods = 0;                    /* goods: valid odd lines | valid even lines << 16 */
+    const uint32_t n_scan = n < BUF_TRIM ? n : (uint32_t)BUF_TRIM;      /* fillUntilFullFrame keeps BUF_SIZE_TRIM lines at most (:178-195) */
+    auto kinds = [](uint32_t meta) -> uint32_t { const uint32_t fl = meta >> 16, bits = (fl & 7u) | ((fl >> 1) & 8u); return (meta & 1u) ? bits : bits << 4; };
+    for (uint32_t c4 = 0; c4 < n_scan; c4 += 256) {
+        Raw32 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = c4 + 64u * (uint32_t)u + (uint32_t)lane;
+            const Raw32 *src = (const Raw32 *)&a.src.at(lo + (i < n_scan ? i : n_scan - 1));
+            raw[u].a = src->a; raw[u].b = src->b;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = c4 + 64u * (uint32_t)u + (uint32_t)lane;
+            const LineBits l = compact_raw(raw[u].a, raw[u].b, frame, cfg.ignore_crc != 0, seen);
+            if (i < n_scan) {
+                if (kLds) *(LineBits *)&lines[i] = l;
+                const uint32_t m8 = kinds(l.meta);
+                any8 |= m8;
+                goods += (m8 & 1u) | ((m8 & 16u) << 12);
+            }
+        }
+    }
+    for (int d = 1; d < 64; d <<= 1) goods += (uint32_t)__shfl((int)goods, lane ^ d);
+    uint32_t present = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (__ballot((any8 >> q) & 1u)) present |= 1u << q;
+    uint32_t f0 = P1_NONE, f1 = P1_NONE, f2 = P1_NONE, f3 = P1_NONE, f4 = P1_NONE, f5 = P1_NONE, f6 = P1_NONE, f7 = P1_NONE;
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;          /* index + 1, 0 = none */
+    auto kinds_at = [&](uint32_t i) -> uint32_t {
+        if (i >= n_scan) return 0u;
+        if (kLds) return kinds(((const LineBits *)&lines[i])->meta);
+        uint32_t dummy = 0; const Raw32 *src = (const Raw32 *)&a.src.at(lo + i);
+        return kinds(compact_raw(src->a, src->b, frame, cfg.ignore_crc != 0, dummy).meta);
+    };
+#define P1_FIRST(q, f) if ((pending >> (q)) & 1u) { const uint64_t m = __ballot((m8 >> (q)) & 1u); if (m) { f = c + (uint32_t)__ffsll((unsigned long long)m) - 1u; pending &= ~(1u << (q)); } }
+#define P1_LAST(q, l) if ((pending >> (q)) & 1u) { const uint64_t m = __ballot((m8 >> (q)) & 1u); if (m) { l = c + 64u - (uint32_t)__clzll((unsigned long long)m); pending &= ~(1u << (q)); } }
+    uint32_t pending = present;
+    for (uint32_t c = 0; pending != 0 && c < n_scan; c += 64) {
+        const uint32_t m8 = kinds_at(c + (uint32_t)lane);
+        P1_FIRST(0, f0) P1_FIRST(1, f1) P1_FIRST(2, f2) P1_FIRST(3, f3) P1_FIRST(4, f4) P1_FIRST(5, f5) P1_FIRST(6, f6) P1_FIRST(7, f7)
+    }
+    pending = present;
+    for (uint32_t c = n_scan ? ((n_scan - 1) / 64) * 64 : 0u; pending != 0; c -= 64) {
+        const uint32_t m8 = kinds_at(c + (uint32_t)lane);
+        P1_LAST(0, l0) P1_LAST(1, l1) P1_LAST(2, l2) P1_LAST(3, l3) P1_LAST(4, l4) P1_LAST(5, l5) P1_LAST(6, l6) P1_LAST(7, l7)
+        if (c == 0) break;
+    }
+#undef P1_FIRST
+#undef P1_LAST
+    const uint32_t good[2] = { goods & 0xFFFF, goods >> 16 };
+    const uint32_t first_valid[2] = { f0, f4 }, first_bw[2] = { f1, f5 }, first_ci[2] = { f2, f6 }, first_hdr[2] = { f3, f7 };
+    const uint32_t last_valid[2] = { l0, l4 }, last_bw[2] = { l1, l5 }, last_ci[2] = { l2, l6 }, last_hdr[2] = { l3, l7 };
+    P1_STAMP(1);
+    seen = (uint32_t)(__ballot(seen & FF_FOREIGN) ? FF_FOREIGN : 0) | (uint32_t)(__ballot(seen & FF_NEW_FILE) ? FF_NEW_FILE : 0) | (uint32_t)(__ballot(seen & FF_END_FILE) ? FF_END_FILE : 0);
+    if (seen & FF_FOREIGN) err |= FE_FOREIGN;
+    if ((seen ^ marks) & (FF_NEW_FILE | FF_END_FILE)) err |= FE_MARKS;      /* a file tag with another frame's number: the offsets were laid out for it */
 
     if (marks & FF_END_FILE) {                      /* the frame that carries the END_FILE tag only closes the file (:1721-1729) */
         if (lane == 0) {
             if (fofs < a.frames_cap) { sdv_frame_asm_pcm1 d; frasm1_clear(d); d.service_type = SDV_PAIR_SRV_END_FILE; a.out_frames[fofs] = d; }
-            if (pofs < a.pairs_cap) { sdv_sample_pair p; service_pair(p, SDV_PAIR_SRV_END_FILE); a.out_pairs[pofs] = p; }
+            if (pofs < a.pairs_cap) service_pair(&a.out_pairs[pofs], SDV_PAIR_SRV_END_FILE);
             if (err) { atomicOr(&a.stat[0], err); atomicMin(&a.stat[1], k); }
         }
         return;
     }
 
-    /* 1. findFrameTrim: per parity (index 0 = odd lines, 1 = even lines) */
-    uint32_t good[2] = { 0, 0 }, first_valid[2] = { P1_NONE, P1_NONE }, last_valid[2] = { 0, 0 }, first_hdr[2] = { P1_NONE, P1_NONE }, last_hdr[2] = { 0, 0 };
-    uint32_t first_bw[2] = { P1_NONE, P1_NONE }, last_bw[2] = { 0, 0 }, first_ci[2] = { P1_NONE, P1_NONE }, last_ci[2] = { 0, 0 };   /* last_*: index + 1, 0 = none */
-    for (uint32_t c = 0; c < n; c += 64) {
-        const uint32_t i = c + (uint32_t)lane;
-        if (i < n) {
-            const sdv_pcm1_line_rec &r = a.src.at(lo + i);
-            if (r.frame_number == frame) {
-                const int par = (r.line_number & 1) ? 0 : 1;
-                const bool v = !r_service(r) && r_crc(r), hd = r.service_type == SDV_SRV_HEADER_LINE, bw = r_bw(r), ci = r_crc_if(r);
-#pragma unroll
-                for (int p = 0; p < 2; p++) {       /* compile-time indices: the counters stay in registers */
-                    const bool m = par == p;
-                    if (m && v) { good[p]++; if (first_valid[p] == P1_NONE) first_valid[p] = i; last_valid[p] = i + 1; }
-                    if (m && hd) { if (first_hdr[p] == P1_NONE) first_hdr[p] = i; last_hdr[p] = i + 1; }
-                    if (m && bw) { if (first_bw[p] == P1_NONE) first_bw[p] = i; last_bw[p] = i + 1; }
-                    if (m && ci) { if (first_ci[p] == P1_NONE) first_ci[p] = i; last_ci[p] = i + 1; }
-                }
-            }
-        }
-    }
     bool header_present = false, emphasis_set = false;
     uint32_t top[2], bottom[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        good[p] = wsum(good[p], lane);
-        first_valid[p] = wmin(first_valid[p], lane); last_valid[p] = wmax(last_valid[p], lane);
-        first_hdr[p] = wmin(first_hdr[p], lane); last_hdr[p] = wmax(last_hdr[p], lane);
         /* a header line counts while no valid data line of its field has been seen: from the top for "header present" (:262-285),
          * from the bottom for the emphasis flag (:306-352; the backward scan stops at the second field's last valid line, which is
          * never past the own field's) */
         if (first_hdr[p] != P1_NONE && first_hdr[p] < first_valid[p]) header_present = true;
         if (last_hdr[p] > last_valid[p]) emphasis_set = true;
         const bool skip_bad = good[p] > MIN_GOOD;
-        const uint32_t fi = wmin(skip_bad ? first_ci[p] : first_bw[p], lane), la = wmax(skip_bad ? last_ci[p] : last_bw[p], lane);
-        top[p] = fi != P1_NONE ? a.src.at(lo + fi).line_number : 0u;
-        bottom[p] = la != 0 ? a.src.at(lo + la - 1).line_number : 0u;
+        const uint32_t fi = skip_bad ? first_ci[p] : first_bw[p], la = skip_bad ? last_ci[p] : last_bw[p];
+        top[p] = fi != P1_NONE ? (kLds ? lines[fi].line : a.src.at(lo + fi).line_number) : 0u;
+        bottom[p] = la != 0 ? (kLds ? lines[la - 1].line : a.src.at(lo + la - 1).line_number) : 0u;
     }
     if (!cfg.auto_offset) {                          /* :388-412 */
         top[0] = cfg.odd_offset > 0 ? (uint32_t)(2 * cfg.odd_offset + 1) : 1u;
@@ -215,49 +306,50 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
     }
     if (marks & FF_NEW_FILE) header_present = emphasis_set = false;            /* resetState after the trim search (:1688-1692, :63-76) */
 
+    P1_STAMP(2);
     /* 2. splitFrameToFields: rank the lines of either field, 245 at most */
-    uint32_t cnt[2] = { 0, 0 }, valid[2] = { 0, 0 }, ref_ok[2] = { 0, 0 }, ref_all[2] = { 0, 0 };
+    uint32_t cnt[2] = { 0, 0 }, valid[2] = { 0, 0 }, refs[2] = { 0, 0 };       /* refs: sum over valid lines << 16 | sum over all lines (245 x 255 fits) */
     const bool even_open = top[1] != bottom[1] || top[1] != 0;
-    for (uint32_t c = 0; c < n; c += 64) {
+    for (uint32_t c = 0; c < n_scan; c += 64) {
         const uint32_t i = c + (uint32_t)lane;
         bool in[2] = { false, false };
-        bool ok = false, filler = false; uint32_t ref = 0;
-        if (i < n) {
-            const sdv_pcm1_line_rec &r = a.src.at(lo + i);
-            filler = r.service_type == SDV_SRV_FILLER;
-            if (r.frame_number == frame && (!r_service(r) || filler)) {
-                const uint32_t ln = r.line_number;
+        bool ok = false; uint32_t ref = 0;
+        if (i < n_scan) {
+            const Line16 l = line_at(i);
+            if (l.fl & LF_DATA) {
+                const uint32_t ln = l.line;
                 in[0] = (ln & 1) != 0 && ln >= top[0] && ln <= bottom[0];
                 in[1] = (ln & 1) == 0 && ln >= top[1] && ln <= bottom[1] && even_open;
-                ok = r_crc(r); ref = filler ? 0u : r.ref_level;
+                ok = (l.fl & LF_VALID) != 0; ref = l.ref;
             }
         }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const uint64_t m = __ballot(in[p]);
             const uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
-            if (in[p] && rank < LINES_PF) {
-                field_idx[p][rank] = (uint16_t)(i + 1);
-                ref_all[p] += ref;
-                if (ok) { valid[p]++; ref_ok[p] += ref; }
-            }
+            const bool take = in[p] && rank < LINES_PF;
+            if (take) { field_idx[p][rank] = (uint16_t)i; refs[p] += ref + (ok ? ref << 16 : 0u); }
+            valid[p] += (uint32_t)__popcll(__ballot(take && ok));
             cnt[p] += (uint32_t)__popcll(m);
         }
     }
+    P1_STAMP(3);
     sdv_frame_asm_pcm1 f; frasm1_clear(f);
     f.frame_number = frame;
     uint32_t data[2], ref_level[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         if (cnt[p] > LINES_PF) cnt[p] = LINES_PF;
-        valid[p] = wsum(valid[p], lane); ref_ok[p] = wsum(ref_ok[p], lane); ref_all[p] = wsum(ref_all[p], lane);
+        for (int d = 1; d < 64; d <<= 1) refs[p] += (uint32_t)__shfl((int)refs[p], lane ^ d);
         data[p] = 3 * cnt[p];
-        /* the reference sums the level once per sub-line and divides by the sub-line count (:767-798) */
-        ref_level[p] = valid[p] > 0 ? ((3 * ref_ok[p]) / (3 * valid[p])) & 0xFF : (cnt[p] > 0 ? ((3 * ref_all[p]) / (3 * cnt[p])) & 0xFF : 0u);
+        /* the reference adds the level once per sub-line and divides by the sub-line count (:767-798): the same quotient.  Sums and
+         * counts are below 2^16: the float quotient is exact enough for the floor (never within 1/245 of the next integer) */
+        const uint32_t num = valid[p] > 0 ? refs[p] >> 16 : refs[p] & 0xFFFF, den = valid[p] > 0 ? valid[p] : cnt[p];
+        ref_level[p] = den > 0 ? (uint32_t)((float)num / (float)den) & 0xFF : 0u;
     }
 
     /* 3. findFramePadding (:809-923); uint16_t arithmetic as the reference's fields */
-    uint16_t top_pad[2], bot_pad[2];
+    uint32_t top_pad[2], bot_pad[2];        /* hold uint16_t values */
     if (cfg.auto_offset) {
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -268,7 +360,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int ofs = p == 0 ? cfg.odd_offset : cfg.even_offset;
-            top_pad[p] = ofs > 0 ? 0 : (uint16_t)(0 - ofs);
+            top_pad[p] = ofs > 0 ? 0u : (uint32_t)(uint16_t)(0 - ofs);
             uint16_t bp = (uint16_t)(((int)bottom[p] - (int)top[p]) / 2 + 1);
             bp = (uint16_t)(bp + top_pad[p]);
             if (bp > LINES_PF) {
@@ -279,70 +371,91 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
                 if (dl > data[p]) err |= FE_STALE;   /* the reference would output sub-lines left in its field buffer by earlier frames */
                 data[p] = dl;
             }
-            bot_pad[p] = (uint16_t)((SUBLINES_PF - (int)data[p]) / 3 - top_pad[p]);
+            bot_pad[p] = (uint32_t)(uint16_t)((SUBLINES_PF - (int)data[p]) / 3 - (int)top_pad[p]);
         }
     }
     const uint8_t order = cfg.field_order == ORDER_BFF ? ORDER_BFF : ORDER_TFF;
 
+    P1_STAMP(4);
     /* 4. the two fields in output order (:1076-1218, :1382-1453) */
     uint64_t po = pofs;
     if (marks & FF_NEW_FILE) {
         if (lane == 0) {
             if (fofs < a.frames_cap) { sdv_frame_asm_pcm1 d; frasm1_clear(d); d.service_type = SDV_PAIR_SRV_NEW_FILE; a.out_frames[fofs] = d; }
-            if (po < a.pairs_cap) { sdv_sample_pair p; service_pair(p, SDV_PAIR_SRV_NEW_FILE); a.out_pairs[po] = p; }
+            if (po < a.pairs_cap) service_pair(&a.out_pairs[po], SDV_PAIR_SRV_NEW_FILE);
         }
         po++;
     }
     uint32_t blocks_drop = 0, samples_drop = 0, blocks_fix_bp = 0;
+    /* pairs are addressed as a 32-bit byte offset from the field's (uniform) base; `lim`: how many of the field's pairs fit the buffer */
     for (int fld = 0; fld < 2; fld++) {
         const bool odd_field = (order == ORDER_TFF) == (fld == 0);
         const uint16_t *fidx = odd_field ? field_idx[0] : field_idx[1];
         const uint32_t f_top = odd_field ? top_pad[0] : top_pad[1], f_bot = odd_field ? bot_pad[0] : bot_pad[1], f_data = odd_field ? data[0] : data[1];
-        const uint32_t q_top = 3u * f_top, q_data = f_data <= SUBLINES_PF ? f_data : 0u /* addLinesFromField refuses (:960) */;
-        if ((uint64_t)q_top + q_data + 3ull * f_bot < SUBLINES_PF) err |= FE_SHORT_QUEUE;   /* DI_RET_NO_DATA: 8 cleared blocks of 92 pairs */
-        for (uint32_t blk = 0; blk < 8; blk++) {
-            const uint32_t len = blk == 7 ? 91u : 92u;         /* the last block is short (PCM1DataBlock::setShortLength) */
-            sdv_sample_pair sp[2]; uint32_t dst[2]; bool act[2];
-            uint32_t bad = 0; bool any_picked = false;
+        const uint32_t f_lines = f_data <= SUBLINES_PF ? f_data / 3 : 0u;      /* addLinesFromField refuses more than a field (:960) */
+        if ((uint64_t)f_top + f_lines + f_bot < LINES_PF) err |= FE_SHORT_QUEUE;    /* DI_RET_NO_DATA: 8 cleared blocks of 92 pairs */
+        /* The padded field is 245 lines of 3 sub-lines; a lane takes a line.  First the lines' flags as three 245-bit masks ... */
+        uint64_t okm[4], pkm[4], plm[4];
+        uint32_t li[4];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t t = (uint32_t)(h * 64 + lane);       /* sub-line of the block: [0,46) first stripe, [46,92) second */
-                act[h] = t < len;
-                const uint32_t sub = blk * 92 + t;
-                uint16_t wl = BIT_RANGE, wr = BIT_RANGE; bool ok = false, picked = false;
-                if (act[h] && sub >= q_top && sub < q_top + q_data) {
-                    const uint32_t j = sub - q_top, line = j / 3, part = j - 3 * line;
-                    const sdv_pcm1_line_rec &r = a.src.at(lo + fidx[line] - 1);
-                    if (!r_service(r)) {            /* a filler line is a cleared line: silent, invalid */
-                        wl = (uint16_t)(r.words[2 * part] & WORD_MASK); wr = (uint16_t)(r.words[2 * part + 1] & WORD_MASK);
-                        ok = cfg.ignore_crc ? r_bw(r) : r_crc(r);
-                        picked = (part == 0 && r.picked_bits_left > 0) || r.picked_bits_right > 0;
-                    }
+        for (int c = 0; c < 4; c++) {
+            const uint32_t pl = (uint32_t)(c * 64 + lane);
+            const bool is_line = pl >= f_top && pl - f_top < f_lines && pl < LINES_PF;
+            li[c] = is_line ? fidx[pl - f_top] : P1_NONE;
+            const uint32_t fl = is_line ? (kLds ? (uint32_t)lines[li[c]].fl : (uint32_t)line_at(li[c]).fl) : 0u;
+            okm[c] = __ballot((fl & LF_OK) != 0); pkm[c] = __ballot((fl & LF_PICK) != 0); plm[c] = __ballot((fl & LF_PICKL) != 0);
+        }
+        okm[3] |= ~0ull << (LINES_PF - 192);                    /* lines past the field do not exist: not "bad" */
+        if (fld == 0) P1_STAMP(5);
+        /* ... then the blocks: block b is sub-lines [92 b, 92 b + 92) (the last one: 91), i.e. whole lines plus a partial line at
+         * either end.  All ranges are compile-time constants once the loop is unrolled. */
+        uint32_t valid_blocks = 0;
+#pragma unroll
+        for (int blk = 0; blk < 8; blk++) {
+            const int s0 = 92 * blk, s1 = blk == 7 ? SUBLINES_PF : s0 + 92, l0 = s0 / 3, l1 = (s1 - 1) / 3;
+            uint32_t bad_lines = 0, any_pick = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int lo_b = l0 > 64 * w ? l0 - 64 * w : 0, hi_b = l1 < 64 * w + 63 ? l1 - 64 * w : 63;     /* bits of word w inside [l0, l1] */
+                if (lo_b <= hi_b && hi_b >= 0) {
+                    const uint64_t m = (~0ull >> (63 - hi_b)) & (~0ull << lo_b);
+                    bad_lines += (uint32_t)__popcll(~okm[w] & m);
+                    any_pick |= (pkm[w] & m) != 0 ? 1u : 0u;
+                    /* picked_bits_left belongs to the line's first sub-line only: lines whose sub-line 3 L lies inside the block */
+                    const int f0 = (s0 + 2) / 3, fl_lo = f0 > 64 * w ? f0 - 64 * w : 0;
+                    if (fl_lo <= hi_b) any_pick |= (plm[w] & (~0ull >> (63 - hi_b)) & (~0ull << fl_lo)) != 0 ? 1u : 0u;
                 }
-                bad += (uint32_t)__popcll(__ballot(act[h] && !ok));
-                any_picked = any_picked || __ballot(act[h] && picked) != 0;
-                /* setWordData (:150-278): the stripe that starts at word 2 (odd pairs) reads the first 46 sub-lines in even blocks and
-                 * the second 46 in odd blocks; the stripe that starts at word 0 the others */
-                const bool first = t < 46;
-                const uint32_t wp = first ? t : t - 46;
-                const bool odd_pair = ((blk & 1) == 0) == first;
-                dst[h] = blk * 92 + 2 * wp + (odd_pair ? 1u : 0u);
-                sp[h].audio_word[0] = p1_sample(wl); sp[h].audio_word[1] = p1_sample(wr);
-                sp[h].sample_flags[0] = sp[h].sample_flags[1] = (uint8_t)(ok ? SDV_SF_WORD_VALID : 0);
-                sp[h].sample_rate = 44100; sp[h].emphasis = emphasis_set ? 1 : 0; sp[h].service_type = 0; sp[h]._pad = 0;
             }
-            const bool valid_blk = bad == 0;
-            if (!valid_blk) { blocks_drop++; samples_drop += (2 * bad) & 0xFF; }
-            else if (any_picked) blocks_fix_bp++;
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-                if (act[h]) {
-                    if (valid_blk) { sp[h].sample_flags[0] |= SDV_SF_BLOCK_OK; sp[h].sample_flags[1] |= SDV_SF_BLOCK_OK; }
-                    if (po + dst[h] < a.pairs_cap) a.out_pairs[po + dst[h]] = sp[h];
-                }
+            const uint32_t cut0 = (uint32_t)(s0 - 3 * l0), cut1 = (uint32_t)(3 * l1 + 3 - s1);          /* sub-lines of the edge lines outside the block */
+            const uint32_t bad0 = (uint32_t)(~okm[l0 / 64] >> (l0 % 64)) & 1u, bad1 = (uint32_t)(~okm[l1 / 64] >> (l1 % 64)) & 1u;
+            const uint32_t bad = 3 * bad_lines - cut0 * bad0 - cut1 * bad1;
+            if (bad) { blocks_drop++; samples_drop += (2 * bad) & 0xFF; }
+            else { valid_blocks |= 1u << blk; if (any_pick) blocks_fix_bp++; }
+        }
+        /* ... and the pairs in output order, a lane per pair: consecutive lanes write consecutive 12-byte pairs (one 768-byte run per
+         * store instruction) and gather their sub-line from LDS.  setWordData (:150-278): the stripe that starts at word 2 (odd pairs)
+         * reads the first 46 sub-lines of the block in even blocks and the second 46 in odd blocks; the stripe that starts at word 0
+         * the others */
+        char *const base = (char *)(a.out_pairs + po);
+        const uint32_t lim = po >= a.pairs_cap ? 0u : (a.pairs_cap - po >= SUBLINES_PF ? (uint32_t)SUBLINES_PF : (uint32_t)(a.pairs_cap - po));
+        for (uint32_t c = 0; c < SUBLINES_PF; c += 64) {
+            const uint32_t o = c + (uint32_t)lane;
+            const uint32_t blk = o / 92, pr = o - 92 * blk;
+            const uint32_t sub = 92 * blk + ((((blk & 1) == 0) == ((pr & 1) != 0)) ? 0u : 46u) + (pr >> 1);
+            const uint32_t pl = sub / 3, part = sub - 3 * pl;
+            uint32_t ww = (uint32_t)BIT_RANGE | ((uint32_t)BIT_RANGE << 16); bool ok = false;
+            if (o < lim && pl >= f_top && pl - f_top < f_lines) {
+                const uint32_t li1 = fidx[pl - f_top];
+                if (kLds) { ww = ((const uint32_t *)lines[li1].w)[part]; ok = (lines[li1].fl & LF_OK) != 0; }
+                else { const Line16 l = line_at(li1); ww = part == 0 ? (l.w[0] | ((uint32_t)l.w[1] << 16)) : (part == 1 ? (l.w[2] | ((uint32_t)l.w[3] << 16)) : (l.w[4] | ((uint32_t)l.w[5] << 16))); ok = (l.fl & LF_OK) != 0; }
+            }
+            const uint32_t flags = ((valid_blocks >> blk) & 1u ? (uint32_t)SDV_SF_BLOCK_OK : 0u) | (ok ? (uint32_t)SDV_SF_WORD_VALID : 0u);
+            if (o < lim)
+                store_pair((sdv_sample_pair *)(base + o * 12u), make_pair3(p1_sample((uint16_t)(ww & 0xFFFF)), p1_sample((uint16_t)(ww >> 16)), flags, 44100, emphasis_set, 0));
         }
         po += SUBLINES_PF;
     }
+    P1_STAMP(6);
     if (lane == 0) {
         f.odd_std_lines = f.even_std_lines = LINES_PF;
         f.odd_data_lines = (uint16_t)(data[0] / 3); f.even_data_lines = (uint16_t)(data[1] / 3);
@@ -350,7 +463,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         f.odd_top_data = (uint16_t)top[0]; f.odd_bottom_data = (uint16_t)bottom[0]; f.even_top_data = (uint16_t)top[1]; f.even_bottom_data = (uint16_t)bottom[1];
         f.odd_sample_rate = f.even_sample_rate = 44100;
         f.blocks_total = 16; f.blocks_drop = (uint16_t)blocks_drop; f.samples_drop = (uint16_t)samples_drop; f.blocks_fix_bp = (uint16_t)blocks_fix_bp;
-        f.odd_top_padding = top_pad[0]; f.odd_bottom_padding = bot_pad[0]; f.even_top_padding = top_pad[1]; f.even_bottom_padding = bot_pad[1];
+        f.odd_top_padding = (uint16_t)top_pad[0]; f.odd_bottom_padding = (uint16_t)bot_pad[0]; f.even_top_padding = (uint16_t)top_pad[1]; f.even_bottom_padding = (uint16_t)bot_pad[1];
         f.field_order = order; f.odd_ref = (uint8_t)ref_level[0]; f.even_ref = (uint8_t)ref_level[1];
         f.flags = (uint8_t)(SDV_FA_ORDER_PRESET | (emphasis_set ? (SDV_FA1_ODD_EMPHASIS | SDV_FA1_EVEN_EMPHASIS) : 0));
         const uint32_t fo = fofs + ((marks & FF_NEW_FILE) ? 1u : 0u);
@@ -361,11 +474,14 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
 } // namespace sdvp1
 
 __global__ void __launch_bounds__(64) sdv_k_pcm1_segments(sdvp1::SegArgs1 a) { sdvp1::seg_body(a, blockIdx.x, (int)threadIdx.x); }
-__global__ void __launch_bounds__(64) sdv_k_pcm1_marks(sdvp1::MarkArgs1 a) { sdvp1::mark_body(a, blockIdx.x * 64u + threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_scan(sdvp1::ScanArgs1 a) { sdvp1::scan_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
 {
+    __shared__ alignas(16) sdvp1::Line16 lines[sdvp1::LDS_LINES];
     __shared__ uint16_t field_idx[2][sdvp1::LINES_PF + 3];
-    sdvp1::frame_body(a, blockIdx.x, (int)threadIdx.x, field_idx);
+    const uint32_t k = blockIdx.x;
+    const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, n = a.seg_end[k] - lo;
+    if (n <= sdvp1::LDS_LINES) sdvp1::frame_body<true>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
+    else sdvp1::frame_body<false>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
 }
 #endif

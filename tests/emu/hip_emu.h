@@ -155,6 +155,7 @@ static inline unsigned __brev(unsigned v)
 }
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = (T)(o | v); return o; }
+template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 
 #endif

@@ -72,6 +72,7 @@ CASES = {
     "file_marks": (4, dict(seed=314, p_bad=0.03, header=3, new_file=True, end_file=True), {}),
     "empty_frames": (4, dict(seed=315, p_bad=0.02, empty=(1,), one_field=(2,)), {}),
     "burst": (4, dict(seed=316, burst=(300, 200)), {}),
+    "very_long_fields": (3, dict(seed=317, lines=(345, 350), p_bad=0.02, header=2), {}),      # > 672 records: the kernel's global-memory path
 }
 GOLDEN = ("header_emph", "bad5", "noise_outside", "file_marks", "manual_offsets", "empty_frames")
 

@@ -151,8 +151,15 @@ def test_emu_rejects_what_the_reference_handles_with_leftover_state(emu):
     recs["frame_number"][100] = 2
     eng = emu.sdv_engine_create(0)
     rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs, st)
-    assert rc == -6 or rc != 0
-    assert b"later frame" in emu.sdv_last_error(eng)
+    assert rc != 0 and b"later frame" in emu.sdv_last_error(eng)
+    emu.sdv_engine_destroy(eng)
+    recs, st = p1.make_input("file_marks")          # a NEW_FILE tag that carries an older frame number: the reference skips it
+    recs = recs.copy()
+    assert recs["service_type"][0] == p1.SRV_NEW_FILE
+    recs["frame_number"][0] = 0
+    eng = emu.sdv_engine_create(0)
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs, st)
+    assert rc != 0 and b"file tag" in emu.sdv_last_error(eng)
     emu.sdv_engine_destroy(eng)
 
 

@@ -1,7 +1,8 @@
 """Timing driver of the PCM-1 back half: N synthetic PCM-1 frames (a 100-frame damaged tape tiled, frame numbers continued)
 -> sdv_pcm1_stitch_frames, `reps` timed calls.  Prints wall time per call and the algorithmic-bytes rate."""
-import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import pcm1_api as p1
 from sdvpcmdecoder_amd import Engine
