@@ -219,6 +219,29 @@ def main():
                   "note": "stitch = frame reassembly + CWD + deinterleave + P/Q ECC to PCMSamplePair (sdv_stitch_frames), wall clock per "
                           "batch incl. its host round trips; not part of `value`"}
 
+    # the other format branch built so far: the PCM-1 back half (PCM1DataStitcher -> PCMSamplePair) over a tape of the same length
+    pcm1 = None
+    if not args.no_stitch and world == 1:
+        from sdvpcmdecoder_amd import synth as _synth
+        p1_recs = _synth.pcm1_tape(n)
+        p1_dev = torch.from_numpy(p1_recs.view(np.uint8).reshape(len(p1_recs), 32)).to(dev)
+        p1p = torch.empty((n * 1470 + 64, 12), dtype=torch.uint8, device=dev)
+        p1f = torch.empty((n + 64, 52), dtype=torch.uint8, device=dev)
+        eng.pcm1_stitch_frames(p1_dev, out_pairs=p1p, out_frames=p1f, stream=stream)
+        k_steps = max(1, min(args.steps, 5))
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(k_steps):
+            pp, pf = eng.pcm1_stitch_frames(p1_dev, out_pairs=p1p, out_frames=p1f, stream=stream)
+        torch.cuda.synchronize(dev)
+        p1_ms = (time.perf_counter() - t1) * 1e3 / k_steps
+        p1_bytes = len(p1_recs) * 32 + n * (1470 * 12 + 52)
+        pcm1 = {"ms_per_step": p1_ms, "frames_per_s": n / p1_ms * 1e3, "algorithmic_gb_per_s": p1_bytes / p1_ms / 1e6,
+                "sample_pairs_per_step": int(pp.shape[0]),
+                "note": "PCM-1 frames (490 line records each) -> trim, field split, padding, deinterleave to PCMSamplePair "
+                        "(sdv_pcm1_stitch_frames), wall clock per batch incl. its host round trips; not part of `value`"}
+        p1_first = pp[:3000 * 1470].cpu().numpy().copy() if rank == 0 else None
+
     # correctness of what was timed: all lines decode to the generator's words
     recs = out_lines[1:1 + nrec].view(-1)  # device bytes
     host = out_lines[1:1 + 8 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(8, H + 3)
@@ -254,6 +277,8 @@ def main():
         }
         if stitch is not None:
             out["stitch_stage"] = stitch
+        if pcm1 is not None:
+            out["pcm1_stage"] = pcm1
         if not args.no_cpu and world == 1:
             ncpu = min(args.cpu_frames, n)
             sample = luma[:ncpu].cpu().numpy()
@@ -275,6 +300,16 @@ def main():
                 stitch["cpu_baseline"] = {"value": nst / dts, "unit": "frames/s", "cores": 1, "kind": "port",
                                           "sample": f"records of the first {nst} frames, {dts:.1f} s of CPU work",
                                           "bit_exact_vs_gpu_on_overlap": bool(cp[:kk].tobytes() == first_pairs.reshape(-1).view(sa.PAIR_DTYPE)[:kk].tobytes())}
+            if pcm1 is not None:
+                import pcm1_api as p1a
+                np1 = min(3000, n)
+                end = int(np.nonzero(p1_recs["service_type"] == 5)[0][np1 - 1])
+                t0 = time.perf_counter()
+                cp1, _ = p1a.run_cpu(libs.load_oracle(), "orc_", p1_recs[:end + 1], p1a.default_settings())
+                dt1 = time.perf_counter() - t0
+                pcm1["cpu_baseline"] = {"value": np1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+                                        "sample": f"the first {np1} frames, {dt1:.2f} s of CPU work",
+                                        "bit_exact_vs_gpu_on_overlap": bool(cp1.tobytes() == p1_first.reshape(-1).view(p1a.PAIR_DTYPE)[:len(cp1)].tobytes())}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

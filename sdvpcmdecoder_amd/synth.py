@@ -283,3 +283,125 @@ def interleave_stream_f1(audio16: np.ndarray) -> np.ndarray:
     lines[:, 7] = ((full & 3) << shifts[None, :]).sum(axis=1)
     crc = crc16_words14(lines)
     return np.concatenate([lines, crc[:, None].astype(np.uint32)], axis=1).astype(np.uint16)
+
+
+# ---- PCM-1 line streams (records of the PCM-1 back half, sdv_pcm1_line_rec) -----------------------------------------
+PCM1_LINE_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words", "<u2", (7,)), ("calc_crc", "<u2"),
+                            ("ref_level", "u1"), ("picked_bits_left", "u1"), ("picked_bits_right", "u1"), ("service_type", "u1"),
+                            ("flags", "u1"), ("_pad", "u1", (5,))])
+assert PCM1_LINE_DTYPE.itemsize == 32
+
+
+def pcm1_crc_words(words6):
+    """PCM1Line::calcCRC over rows of six 13-bit words (vectorised restatement used only to BUILD inputs; the oracle's own
+    orc_pcm1_crc_words and the reference's calcCRC are what the tests pin against each other)."""
+    w = (~np.asarray(words6, dtype=np.uint32)) & 0x1FFF
+    crc = np.full(w.shape[0], 0xFFFF, dtype=np.uint32)
+    for i in range(6):
+        for b in range(12, -1, -1):
+            bit = (w[:, i] >> b) & 1
+            top = ((crc >> 15) & 1) ^ bit
+            crc = ((crc << 1) & 0xFFFF) ^ (top * 0x1021)
+    return ((~crc) & 0xFFFF).astype(np.uint16)
+
+
+
+def pcm1_line_stream(n_frames, seed=0, lines=(245, 245), first=(1, 2), header=0, footer=0, p_bad=0.0, p_nobw=0.0, p_picked=0.0, p_forced=0.0,
+                p_filler=0.0, noise_lines=0, new_file=False, end_file=False, empty=(), one_field=(), burst=None, first_frame=1):
+    """The PCM1Line stream of a synthetic PCM-1 tape as the PCM-1 VideoToDigital branch would queue it: per frame the odd rows,
+    END_FIELD, the even rows, END_FIELD, END_FRAME (videotodigital.cpp:1189-1383); header/footer rows as HEADER service lines."""
+    rng = np.random.default_rng(seed)
+    out = []
+
+    def rec(frame, line, srv=0):
+        r = np.zeros(1, dtype=PCM1_LINE_DTYPE)
+        r["frame_number"] = frame
+        r["line_number"] = line
+        r["service_type"] = srv
+        if srv:        # a cleared line (PCM1Line::clear): silent words, CRC_SILENT against its inverse
+            r["words"][0, :6] = 1 << 12
+            r["calc_crc"] = 0xECBF
+            r["words"][0, 6] = 0xECBF ^ 0xFFFF
+        return r
+
+    for fi in range(n_frames):
+        frame = first_frame + fi
+        last_line = 0
+        if new_file and fi == 0:
+            out.append(rec(frame, 0, 1))
+        for field in (0, 1):
+            if fi in empty or (fi in one_field and field == 1):
+                cnt = 0
+            else:
+                cnt = lines[field]
+            ln = first[field]
+            for _ in range(noise_lines if fi % 2 == 0 else 0):         # garbage rows above the data: B/W found, CRC bad
+                r = rec(frame, ln)
+                r["words"][0, :6] = rng.integers(0, 1 << 13, size=6)
+                r["calc_crc"] = pcm1_crc_words(r["words"][:, :6])
+                r["words"][0, 6] = r["calc_crc"][0] ^ np.uint16(rng.integers(1, 1 << 16))
+                r["flags"] = 8
+                r["ref_level"] = rng.integers(40, 200)
+                out.append(r)
+                ln += 2
+            for _ in range(header):
+                out.append(rec(frame, ln, 6))
+                ln += 2
+            block = np.zeros(cnt, dtype=PCM1_LINE_DTYPE)
+            block["frame_number"] = frame
+            block["line_number"] = ln + 2 * np.arange(cnt)
+            block["words"][:, :6] = rng.integers(0, 1 << 13, size=(cnt, 6))
+            small = rng.random((cnt, 6)) < 0.5                          # half of the words in the fine range (range bit clear)
+            block["words"][:, :6] = np.where(small, block["words"][:, :6] & 0x0FFF, block["words"][:, :6])
+            block["calc_crc"] = pcm1_crc_words(block["words"][:, :6]) if cnt else 0
+            block["words"][:, 6] = block["calc_crc"]
+            block["flags"] = 8
+            block["ref_level"] = rng.integers(60, 180, size=cnt)
+            bad = rng.random(cnt) < p_bad
+            block["words"][bad, 6] ^= rng.integers(1, 1 << 16, size=int(bad.sum())).astype(np.uint16)
+            nobw = rng.random(cnt) < p_nobw
+            block["flags"][nobw] = 0
+            pk = rng.random(cnt) < p_picked
+            block["picked_bits_left"][pk] = rng.integers(0, 4, size=int(pk.sum()))
+            block["picked_bits_right"][pk] = rng.integers(0, 3, size=int(pk.sum()))
+            fb = rng.random(cnt) < p_forced
+            block["flags"][fb] |= 32
+            fil = rng.random(cnt) < p_filler
+            for i in np.nonzero(fil)[0]:
+                block[i] = rec(frame, block["line_number"][i], 3)[0]
+            if burst and fi == 1 and field == 0 and cnt:
+                s, length = burst
+                s = min(s, 2 * cnt) // 2
+                block["words"][s:s + length // 2, 6] ^= 0x5A5A
+            out.append(block)
+            ln += 2 * cnt
+            for _ in range(footer):
+                out.append(rec(frame, ln, 6))
+                ln += 2
+            out.append(rec(frame, ln, 4))
+            last_line = max(last_line, ln)
+        out.append(rec(frame, last_line + 2, 5))
+    if end_file:
+        frame = first_frame + n_frames
+        for field in (0, 1):
+            for ln in range(1 + field, 491, 2):
+                out.append(rec(frame, ln, 3))
+            out.append(rec(frame, 491 + field, 4))
+        out.append(rec(frame, 494, 2))
+        out.append(rec(frame, 496, 5))
+    return np.concatenate(out)
+
+
+def pcm1_tape(n_frames, seed=5, period=100, **kw):
+    """`n_frames` of PCM-1 line records for throughput runs: a `period`-frame damaged tape repeated with continuing frame numbers."""
+    kw.setdefault("p_bad", 0.02)
+    kw.setdefault("header", 2)
+    base = pcm1_line_stream(period, seed=seed, **kw)
+    tiles = []
+    for t in range((n_frames + period - 1) // period):
+        b = base.copy()
+        b["frame_number"] += period * t
+        tiles.append(b)
+    recs = np.concatenate(tiles)
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    return recs[:ends[n_frames - 1] + 1]

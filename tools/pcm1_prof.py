@@ -5,18 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import pcm1_api as p1
-from sdvpcmdecoder_amd import Engine
+from sdvpcmdecoder_amd import Engine, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-base = p1.make_stream(100, seed=5, p_bad=0.02, header=2)
-tiles = []
-for t in range((n + 99) // 100):
-    b = base.copy()
-    b["frame_number"] += 100 * t
-    tiles.append(b)
-recs = np.concatenate(tiles)
-ends = np.nonzero(recs["service_type"] == p1.SRV_END_FRAME)[0]
-recs = recs[:ends[n - 1] + 1]
+recs = synth.pcm1_tape(n)
 d = torch.from_numpy(recs.view(np.uint8).reshape(len(recs), 32)).cuda()
 eng = Engine(0)
 out_p = torch.empty((n * 1470 + 64, 12), dtype=torch.uint8, device='cuda')
