@@ -16,3 +16,10 @@ rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_IN
 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/pmc2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc2.err; echo "pmc2 rc=$?"
 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc3.err; echo "pmc3 rc=$?"
 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc4.err; echo "pmc4 rc=$?"
+# PCM-1 back half: kernel stats and PMC passes of its frame kernel
+rm -rf $R/gpurun_out/prof_pcm1 $R/gpurun_out/p1pmc1 $R/gpurun_out/p1pmc2 $R/gpurun_out/p1pmc3 $R/gpurun_out/p1pmc4
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pcm1 -- python3 $R/tools/pcm1_prof.py 10000 20 > $R/gpurun_out/prof_pcm1.log 2>&1; echo "rocprof pcm1 rc=$?"
+rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/p1pmc1 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc1.err; echo "p1pmc1 rc=$?"
+rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/p1pmc2 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc2.err; echo "p1pmc2 rc=$?"
+rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p1pmc3 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc3.err; echo "p1pmc3 rc=$?"
+rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p1pmc4 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc4.err; echo "p1pmc4 rc=$?"

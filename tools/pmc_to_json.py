@@ -4,8 +4,9 @@ per-launch counter sums of the last full-batch dispatch of the given kernel."""
 import collections, csv, glob, json, sys
 kernel = sys.argv[1] if len(sys.argv) > 1 else "sdv_k_stc007_frames_lean"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_%s.json" % kernel
+prefix = sys.argv[3] if len(sys.argv) > 3 else "pmc"          # directory prefix under gpurun_out/ (pmc1..4, p1pmc1..4)
 res = {}
-for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
+for p in tuple(prefix + str(i) for i in (1, 2, 3, 4)):
     agg = collections.OrderedDict()
     for f in glob.glob("gpurun_out/%s/**/*_counter_collection.csv" % p, recursive=True):
         for r in csv.DictReader(open(f)):
