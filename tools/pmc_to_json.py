@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc1..pmc4 (rocprofv3 --pmc passes of tools/gpu_validate.sh) -> profiles/<round>_pmc_<kernel>.json:
 per-launch counter sums of the last full-batch dispatch of the given kernel."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 kernel = sys.argv[1] if len(sys.argv) > 1 else "sdv_k_stc007_frames_lean"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_%s.json" % kernel
 prefix = sys.argv[3] if len(sys.argv) > 3 else "pmc"          # directory prefix under gpurun_out/ (pmc1..4, p1pmc1..4)
 res = {}
 for p in tuple(prefix + str(i) for i in (1, 2, 3, 4)):
     agg = collections.OrderedDict()
-    for f in glob.glob("gpurun_out/%s/**/*_counter_collection.csv" % p, recursive=True):
+    files = glob.glob("gpurun_out/%s/**/*_counter_collection.csv" % p, recursive=True)
+    files.sort(key=os.path.getmtime)
+    for f in files[-1:]:            # gpurun merges into gpurun_out/: older runs' files stay around - only the newest run counts
         for r in csv.DictReader(open(f)):
             if not r["Kernel_Name"].startswith(kernel + "("):
                 continue
