@@ -114,14 +114,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("SDV_BENCH_BACKEND", "nccl")     # nccl = RCCL; "gloo" lets the N > 1 path be exercised on a 1-GPU box
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=backend, init_method="env://")
+    # SDV_BENCH_FORCE_DIST=1: run the sharded (collective) code path with a single rank too - lets the RCCL plumbing be exercised
+    # on a 1-GPU box (torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or (os.environ.get("SDV_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before anything initialises HIP
     assert torch.cuda.is_available(), "bench.py needs a GPU (the decode engine has no CPU path)"
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if use_dist:
+        if backend == "nccl":
+            dist.init_process_group(backend=backend, init_method="env://", device_id=dev)     # one rank per GPU, bound to it
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
 
     W, H = 720, 486
     n = args.frames
@@ -138,11 +145,11 @@ def main():
     stream = torch.cuda.current_stream(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:
+    if use_dist:
         from sdvpcmdecoder_amd.sharded import ShardedBinarizeLoop, torch_all_gather
         loop = ShardedBinarizeLoop(eng, rank, world, torch_all_gather(dev if backend == "nccl" else None))
 
@@ -179,7 +186,7 @@ def main():
         general += info.frames_general
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -267,7 +274,7 @@ def main():
                                    f"Binarizer mode {args.mode}, noise sigma {args.noise}, binarize+bit-extract+CRC only",
                        "frames_per_gpu_per_step": n, "speculation_rounds_per_step": rounds / args.steps,
                        "sharding": ("one tape of %d frames per step in contiguous ranges, 120-byte state all-gather per step, %d range re-decodes"
-                                    % (n * world, loop.redo)) if world > 1 else "single GPU",
+                                    % (n * world, loop.redo)) if loop is not None else "single GPU",
                        "decoded_words_match_generator": words_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(frames_per_launch),
@@ -311,7 +318,7 @@ def main():
                                         "sample": f"the first {np1} frames, {dt1:.2f} s of CPU work",
                                         "bit_exact_vs_gpu_on_overlap": bool(cp1.tobytes() == p1_first.reshape(-1).view(p1a.PAIR_DTYPE)[:len(cp1)].tobytes())}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
