@@ -36,6 +36,19 @@ def build_hip(force=False):
     return HIP_LIB
 
 
+def build_example(force=False):
+    """examples/decode_tape: the C-ABI driven from plain C++ host code (what a maintainer's binding looks like)."""
+    src = os.path.join(ROOT, "examples", "decode_tape.cpp")
+    out = os.path.join(ROOT, "examples", "decode_tape")
+    if not force and not _newer(out, [src, os.path.join(ROOT, "include", "sdvpcm.h"), HIP_LIB]):
+        return out
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           "-I" + os.path.join(ROOT, "include"), src, "-L" + PKG, "-lsdvpcm_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                           "-Wl,-rpath,$ORIGIN/../sdvpcmdecoder_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", out])
+    return out
+
+
 def build_oracle():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
@@ -66,6 +79,7 @@ def build_emu(force=False):
 
 def build_all():
     build_hip()
+    build_example()
     build_oracle()
     build_reference()
     build_emu()

@@ -63,3 +63,45 @@ def test_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+
+
+# ---- the boundary driven from plain C++ host code (examples/decode_tape.cpp): no Python, no torch in the process that decodes ----
+def test_cpp_example_builds():
+    from sdvpcmdecoder_amd import build as b
+    assert os.path.exists(b.build_example())
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_matches_reference_golden(tmp_path):
+    """decode_tape stc007: luma file -> sdv_binarize_frames(NEW_FILE | END_FILE) -> sdv_stitch_frames, written by a C++ program that
+    links libsdvpcm_hip.so; compared with the real reference's output for the same file (tests/golden/e2e_ntsc_file.npz)."""
+    import subprocess
+    import numpy as np
+    from sdvpcmdecoder_amd import build as b
+    import test_stitch_kernel as tsk
+    exe = b.build_example()
+    luma, z, want_p, want_f = tsk._e2e_fixture()
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    out = subprocess.run([exe, "stc007", str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "pairs.out"), str(tmp_path / "frames.out")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert (tmp_path / "pairs.out").read_bytes() == want_p.tobytes()
+    assert (tmp_path / "frames.out").read_bytes() == want_f.tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_pcm1_matches_reference_golden(tmp_path):
+    import subprocess
+    import numpy as np
+    import pcm1_api as p1
+    from sdvpcmdecoder_amd import build as b
+    exe = b.build_example()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "pcm1_file_marks.npz"))
+    recs, st = p1.make_input("file_marks")
+    (tmp_path / "lines.raw").write_bytes(recs.tobytes())
+    out = subprocess.run([exe, "pcm1", str(tmp_path / "lines.raw"), str(tmp_path / "pairs.out"), str(tmp_path / "frames.out")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert (tmp_path / "pairs.out").read_bytes() == np.ascontiguousarray(z["pairs"]).tobytes()
+    assert (tmp_path / "frames.out").read_bytes() == np.ascontiguousarray(z["frames"]).tobytes()
