@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(64) sdv_k_pcm1_segments(sdvp1::SegArgs1 a) { s
 __global__ void __launch_bounds__(64) sdv_k_pcm1_scan(sdvp1::ScanArgs1 a) { sdvp1::scan_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
 {
-    __shared__ alignas(16) sdvp1::Line16 lines[sdvp1::LDS_LINES];
+    alignas(16) __shared__ sdvp1::Line16 lines[sdvp1::LDS_LINES];
     __shared__ uint16_t field_idx[2][sdvp1::LINES_PF + 3];
     const uint32_t k = blockIdx.x;
     const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, n = a.seg_end[k] - lo;
