@@ -129,11 +129,15 @@ class ShardedBinarizeLoop:
         out = eng.binarize_frames(luma, first_frame_no=first_frame_no, new_file=new_file and rank == 0, **kw)
         final = eng.get_chain_state()
         while True:
-            finals = self.all_gather(final)
-            ok = rank == 0 or assumed == finals[rank - 1]
-            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
+            # one collective per check: every rank publishes what it started from and what it ended in (2 x 120 bytes), so that
+            # all ranks see the same verdict for every rank without a second exchange
+            both = self.all_gather(bytes(assumed) + bytes(final))
+            k = len(both[0]) // 2
+            finals = [b[k:] for b in both]
+            oks = [r == 0 or both[r][:k] == finals[r - 1] for r in range(self.world)]
+            if all(oks):
                 break
-            if not ok:
+            if not oks[rank]:
                 self.redo += 1
                 assumed = finals[rank - 1]
                 eng.set_chain_state(assumed)
@@ -149,11 +153,23 @@ def torch_all_gather(device=None):
     import torch
     import torch.distributed as dist
 
+    flat_ok = [True]
+
     def gather(b: bytes):
+        world = dist.get_world_size()
         t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
         if device is not None:
             t = t.to(device)
-        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        n = t.numel()
+        if flat_ok[0]:
+            try:        # one flat output tensor, one copy back to the host
+                out = torch.empty(world * n, dtype=torch.uint8, device=t.device)
+                dist.all_gather_into_tensor(out, t)
+                host = out.cpu().numpy().tobytes()
+                return [host[r * n:(r + 1) * n] for r in range(world)]
+            except (RuntimeError, NotImplementedError):
+                flat_ok[0] = False          # a backend without the flat form: the list form below
+        outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         return [o.cpu().numpy().tobytes() for o in outs]
     return gather
