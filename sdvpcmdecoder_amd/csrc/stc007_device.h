@@ -105,7 +105,8 @@ struct FrameArgs {
     size_t frame_stride, row_stride;
     int width, height;
     uint32_t first_frame_no;        /* frame_number of frame index 0 */
-    int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch */
+    int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch ... */
+    const int *frame_list;          /* ... or, when set, the frames frame_list[0 .. grid) */
     int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
     int end_file_frame;             /* frame index of the filler frame that closes the file (no pixels: FILLER lines, END_FILE), or -1 */
     uint8_t doubled, mode, check_line_copy, coordinate_damper, m2_format;
@@ -2077,8 +2078,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
-    int f = a.frame_lo + (int)blockIdx.x;
-    if (f < a.frame_hi) sdv::frame_body<false>(a, lds, f);
+    int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
+    if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f);
 }
 #ifndef SDV_LEAN_WAVES_PER_EU
 #define SDV_LEAN_WAVES_PER_EU 5   /* 1.26 ms vs 1.46 (4), 1.28 (6), 1.45 (8) per 10 000 frames (profiles/r01_tuning_notes.md) */
@@ -2086,7 +2087,7 @@ __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv:
 __global__ void __launch_bounds__(64, SDV_LEAN_WAVES_PER_EU) sdv_k_stc007_frames_lean(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
-    int f = a.frame_lo + (int)blockIdx.x;
-    if (f < a.frame_hi) sdv::frame_body<true>(a, lds, f);
+    int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
+    if (a.frame_list || f < a.frame_hi) sdv::frame_body<true>(a, lds, f);
 }
 #endif
