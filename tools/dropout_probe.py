@@ -6,7 +6,7 @@ import numpy as np, torch
 from sdvpcmdecoder_amd import Engine, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 luma0, _ = synth.stc007_frames_torch(n, seed=3, device='cuda', noise_sigma=4.0, cyclic=True)
-for D in (0, 1, 4, 16, 64):
+for D in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,4,16,64".split(","))]:
     luma = luma0.clone()
     if D:
         rng = np.random.default_rng(D)
