@@ -243,6 +243,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         }
     }
     for (int d = 1; d < 64; d <<= 1) goods += (uint32_t)__shfl((int)goods, lane ^ d);
+    __syncthreads();            /* the staged lines are read by other lanes from here on: LDS writes of the sweep made visible */
     uint32_t present = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) if (__ballot((any8 >> q) & 1u)) present |= 1u << q;
@@ -333,6 +334,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             cnt[p] += (uint32_t)__popcll(m);
         }
     }
+    __syncthreads();            /* field_idx[] complete before the output stage gathers through it */
     P1_STAMP(3);
     sdv_frame_asm_pcm1 f; frasm1_clear(f);
     f.frame_number = frame;
