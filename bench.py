@@ -205,6 +205,7 @@ def main():
         frame_no = 1 + n
         st_ms = e2e_ms = 0.0
         st_rounds = 0
+        st_dev_ms = 0.0
         k_steps = max(1, min(args.steps, 5))
         for _ in range(k_steps):
             # the tape goes on: frame numbers keep increasing, the chain states of both stages carry over
@@ -219,10 +220,11 @@ def main():
             st_ms += (t3 - t2) * 1e3
             e2e_ms += (t3 - t1) * 1e3
             st_rounds += eng.stitch_info().rounds
+            st_dev_ms += eng.stitch_info().device_ms
             frame_no += n
         stitch = {"stitch_ms_per_step": st_ms / k_steps, "stitch_frames_per_s": n / (st_ms / k_steps) * 1e3,
                   "frames_to_pcm_ms_per_step": e2e_ms / k_steps, "frames_to_pcm_frames_per_s": n / (e2e_ms / k_steps) * 1e3,
-                  "sample_pairs_per_step": int(pairs.shape[0]), "rounds_per_step": st_rounds / k_steps,
+                  "sample_pairs_per_step": int(pairs.shape[0]), "rounds_per_step": st_rounds / k_steps, "stitch_device_ms_per_step": st_dev_ms / k_steps,
                   "note": "stitch = frame reassembly + CWD + deinterleave + P/Q ECC to PCMSamplePair (sdv_stitch_frames), wall clock per "
                           "batch incl. its host round trips; not part of `value`"}
 
