@@ -203,6 +203,10 @@ def main():
         pairs, frs = eng.stitch_frames(lines_all, out_pairs=sp, out_frames=sf, stream=stream)
         first_pairs = pairs[:4 * 1470].cpu().numpy().copy() if rank == 0 else None
         frame_no = 1 + n
+        # one untimed continuing step: the stream's steady shape (the carried frame makes every later call one frame longer)
+        eng.binarize_frames(luma, first_frame_no=frame_no, new_file=False, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+        eng.stitch_frames(out_lines[1:1 + nrec], out_pairs=sp, out_frames=sf, stream=stream)
+        frame_no += n
         st_ms = e2e_ms = 0.0
         st_rounds = 0
         st_dev_ms = 0.0
