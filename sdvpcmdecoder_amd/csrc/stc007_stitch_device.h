@@ -348,37 +348,81 @@ __device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int l
     return SRES_UNKNOWN;
 }
 
-__device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
+/* What the trim search and the field split need of one record, one word: line number | flags | reference level.  The frame's
+ * records are read from HBM once (four 64-record chunks of three 16-byte loads in flight per turn) and kept in LDS in this form;
+ * only the lines that go into a field buffer are read again (for their nine words). */
+enum { AM_G = 1 << 16,          /* data line, CRC valid, not forced bad */
+       AM_CI = 1 << 17,         /* data line, CRC valid ignoring "forced bad" */
+       AM_MK = 1 << 18,         /* data line with both markers found */
+       AM_DATA = 1 << 19, AM_FILLER = 1 << 20, AM_NEW_FILE = 1 << 21, AM_END_FILE = 1 << 22, AM_CTRL = 1 << 23,
+       ANALYZE_LDS = 1024 };    /* records staged per frame; longer segments compute the word from the record on every access */
+struct Rec48 { uint4 q0, q1, q2; };      /* an sdv_line_rec as three 16-byte loads */
+static_assert(sizeof(sdv_line_rec) == 48, "record layout");
+__device__ inline uint32_t rec_meta(const Rec48 &r, uint32_t fnum, bool &bad_number)
+{
+    const uint32_t line = r.q0.y & 0xFFFF, w8 = r.q1.y >> 16, crc = r.q1.z & 0xFFFF, srv = r.q2.z >> 24;
+    const uint32_t mst = r.q2.w & 0xFF, med = (r.q2.w >> 8) & 0xFF, flags = (r.q2.w >> 16) & 0xFF, ref = r.q2.y >> 24;
+    bad_number = r.q0.x != fnum;
+    uint32_t m = line;
+    if (srv == SDV_SRV_NO) {
+        const bool ci = crc == w8;
+        m |= AM_DATA | (ci ? AM_CI : 0u) | ((ci && !(flags & SDV_LF_FORCED_BAD)) ? AM_G : 0u) | ((mst == MST_BOT_2 && med == MED_LEN_OK) ? AM_MK : 0u) | (ref << 24);
+    } else if (srv == SDV_SRV_FILLER) m |= AM_FILLER;
+    else if (srv == SDV_SRV_NEW_FILE) m |= AM_NEW_FILE;
+    else if (srv == SDV_SRV_END_FILE) m |= AM_END_FILE;
+    else if (srv == SDV_SRV_CTRL_BLOCK) m |= AM_CTRL;
+    return m;
+}
+
+template <bool kLds>
+__device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, uint32_t *meta)
 {
     const uint32_t start = k == 0 ? 0u : a.seg_end[k - 1] + 1u, end = a.seg_end[k];      /* [start, end) + END_FRAME at end */
     const uint32_t n = end - start;
     const uint32_t fnum = a.src.at(end).frame_number;
     FrameLocal *fl = &a.fl[k];
+    auto meta_at = [&](uint32_t i) -> uint32_t {
+        if (kLds) return meta[i];
+        const Rec48 *src = (const Rec48 *)&a.src.at(start + i);
+        Rec48 r; r.q0 = src->q0; r.q1 = src->q1; r.q2 = src->q2;
+        bool bn; return rec_meta(r, fnum, bn);
+    };
     /* pass 1 (findFramesTrim, first loop :300-470): good lines per field, service flags, first Control Block */
     uint32_t good[2] = { 0, 0 }, first_good = 0xFFFFFFFFu, ctrl_pos = 0xFFFFFFFFu;
     bool new_file = false, end_file = false, bad_numbers = false;
-    for (uint32_t c = 0; c < n; c += 64) {
-        uint32_t i = c + (uint32_t)lane;
-        bool act = i < n, g = false, odd = false, nf = false, ef = false, cb = false, bn = false;
-        if (act) {
-            const sdv_line_rec &r = a.src.at(start + i);
-            bn = r.frame_number != fnum;
-            if (r.service_type == SDV_SRV_NO) { g = !(r.flags & SDV_LF_FORCED_BAD) && r.calc_crc == r.words[8]; odd = (r.line_number % 2) != 0; }
-            else if (r.service_type == SDV_SRV_NEW_FILE) nf = true;
-            else if (r.service_type == SDV_SRV_END_FILE) ef = true;
-            else if (r.service_type == SDV_SRV_CTRL_BLOCK) cb = true;
+    __syncthreads();                /* LDS of the workgroup is free again (kernels that run several frames per workgroup) */
+    for (uint32_t c4 = 0; c4 < n; c4 += 256) {
+        Rec48 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = c4 + 64u * (uint32_t)u + (uint32_t)lane;
+            const Rec48 *src = (const Rec48 *)&a.src.at(start + (i < n ? i : n - 1));
+            raw[u].q0 = src->q0; raw[u].q1 = src->q1; raw[u].q2 = src->q2;
         }
-        uint64_t mg = __ballot(g), mo = __ballot(g && odd), mc = __ballot(cb);
-        new_file = new_file || __ballot(nf) != 0; end_file = end_file || __ballot(ef) != 0; bad_numbers = bad_numbers || __ballot(bn) != 0;
-        good[0] += (uint32_t)__popcll(mo); good[1] += (uint32_t)__popcll(mg & ~mo);
-        if (mg != 0 && first_good == 0xFFFFFFFFu) first_good = c + (uint32_t)(__ffsll((unsigned long long)mg) - 1);
-        /* a Control Block counts while no good line has been seen yet: keep the last such one */
-        while (mc != 0) {
-            uint32_t pos = c + (uint32_t)(__ffsll((unsigned long long)mc) - 1);
-            mc &= mc - 1;
-            if (pos < first_good) ctrl_pos = pos;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = c4 + 64u * (uint32_t)u, i = c + (uint32_t)lane;
+            if (c >= n) break;
+            const bool act = i < n;
+            bool bn = false;
+            uint32_t m = rec_meta(raw[u], fnum, bn);
+            if (!act) { m = 0; bn = false; }
+            if (kLds && act) meta[i] = m;
+            const bool g = (m & AM_G) != 0, odd = (m & 1u) != 0;
+            uint64_t mg = __ballot(g), mo = __ballot(g && odd), mc = __ballot((m & AM_CTRL) != 0);
+            new_file = new_file || __ballot((m & AM_NEW_FILE) != 0) != 0; end_file = end_file || __ballot((m & AM_END_FILE) != 0) != 0;
+            bad_numbers = bad_numbers || __ballot(bn) != 0;
+            good[0] += (uint32_t)__popcll(mo); good[1] += (uint32_t)__popcll(mg & ~mo);
+            if (mg != 0 && first_good == 0xFFFFFFFFu) first_good = c + (uint32_t)(__ffsll((unsigned long long)mg) - 1);
+            /* a Control Block counts while no good line has been seen yet: keep the last such one */
+            while (mc != 0) {
+                uint32_t pos = c + (uint32_t)(__ffsll((unsigned long long)mc) - 1);
+                mc &= mc - 1;
+                if (pos < first_good) ctrl_pos = pos;
+            }
         }
     }
+    __syncthreads();                /* the staged words are read by other lanes from here on */
     bool skip[2] = { good[0] > MIN_GOOD_LINES_PF, good[1] > MIN_GOOD_LINES_PF };
     /* pass 2 (second loop :480-700): top / bottom data line of each field, in stream order */
     uint16_t top[2] = { 0, 0 }, bottom[2] = { 0, 0 }, max_line = 0;
@@ -388,11 +432,11 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
         bool act = i < n, q = false, odd = false;
         uint16_t ln = 0;
         if (act) {
-            const sdv_line_rec &r = a.src.at(start + i);
-            ln = r.line_number; odd = (ln % 2) != 0;
-            if (r.service_type == SDV_SRV_NO) {
-                bool crc_if = r.calc_crc == r.words[8];
-                bool markers = r.mark_st_stage == MST_BOT_2 && r.mark_ed_stage == MED_LEN_OK;
+            const uint32_t m = meta_at(i);
+            ln = (uint16_t)(m & 0xFFFF); odd = (ln % 2) != 0;
+            if (m & AM_DATA) {
+                bool crc_if = (m & AM_CI) != 0;
+                bool markers = (m & AM_MK) != 0;
                 q = skip[odd ? 0 : 1] ? crc_if : (markers || crc_if);
             }
         }
@@ -414,16 +458,15 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane)
         bool act = i < n, sel = false, odd = false, ok = false;
         uint16_t ln = 0; uint32_t ref = 0;
         if (act) {
-            const sdv_line_rec &r = a.src.at(start + i);
-            if (r.service_type == SDV_SRV_NO || r.service_type == SDV_SRV_FILLER) {
-                ln = r.line_number; odd = (ln % 2) != 0;
+            const uint32_t m = meta_at(i);
+            if (m & (AM_DATA | AM_FILLER)) {
+                ln = (uint16_t)(m & 0xFFFF); odd = (ln % 2) != 0;
                 int p = odd ? 0 : 1;
                 bool in = ln >= top[p] && ln <= bottom[p];
                 if (!odd) in = in && ((top[1] != bottom[1]) || (top[1] != 0));
                 sel = in;
-                if (r.service_type == SDV_SRV_NO) { ok = !(r.flags & SDV_LF_FORCED_BAD) && r.calc_crc == r.words[8]; ref = r.ref_level; }
-            } else ln = 0;
-            if (r.service_type != SDV_SRV_NO && r.service_type != SDV_SRV_FILLER) ln = 0;
+                if (m & AM_DATA) { ok = (m & AM_G) != 0; ref = m >> 24; }
+            }
         }
         /* f_max_line and the reference-level sums: per lane here, across the lanes once after the pass */
         if (ln > max_line) max_line = ln;
@@ -1521,7 +1564,14 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 } // namespace sdvs
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
-__global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a) { sdvs::analyze_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
+{
+    __shared__ uint32_t meta[sdvs::ANALYZE_LDS];
+    const uint32_t k = blockIdx.x;
+    const uint32_t n = a.seg_end[k] - (k == 0 ? 0u : a.seg_end[k - 1] + 1u);
+    if (n <= sdvs::ANALYZE_LDS) sdvs::analyze_body<true>(a, k, (int)threadIdx.x, meta);
+    else sdvs::analyze_body<false>(a, k, (int)threadIdx.x, meta);
+}
 #ifndef SDV_ST_WAVES
 #define SDV_ST_WAVES 4   /* 128 VGPRs + 100 B scratch: 4 096 resident waves share the turns; 1.73 ms per 10 000-frame call vs 1.83 (3 waves, no scratch) and 1.78 (5) */
 #endif
