@@ -288,6 +288,24 @@ def main():
                          "kernel": "sdv_k_stc007_frames_lean" if general == 0 else "sdv_k_stc007_frames_lean + sdv_k_stc007_frames", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_launch": bpf * frames_per_launch},
         }
+        if world == 1 and not args.no_stitch:
+            # the boundary takes device pointers; a caller that keeps its frames in host memory pays this on top (never part of `value`)
+            try:
+                hb = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+                db = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+                db.copy_(hb, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                th = time.perf_counter()
+                for _ in range(4):
+                    db.copy_(hb, non_blocking=True)
+                torch.cuda.synchronize(dev)
+                bw = 4 * (256 << 20) / (time.perf_counter() - th)
+                out["host_fed"] = {"h2d_gb_per_s": bw / 1e9, "frames_per_s_bound_by_pcie": bw / (W * H),
+                                   "note": "pinned host -> HBM copy rate measured here; 349 920 B of luma per frame have to cross it when the "
+                                           "frames start in host memory, so that path is bound by the link, not by the kernels"}
+                del hb, db
+            except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
+                out["host_fed"] = {"error": repr(ex)}
         if stitch is not None:
             out["stitch_stage"] = stitch
         if pcm1 is not None:
