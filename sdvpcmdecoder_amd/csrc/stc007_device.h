@@ -37,6 +37,10 @@
 #endif
 
 #define SDV_MAX_WIDTH 1536          /* staged scanline bytes per wave (720 px SD, 1440 px doubled) */
+#define SDV_PX_BYTES 2048           /* LDS bytes for staged scanlines: two rows at a pitch of 1024, each written by 64 lanes x 16 bytes */
+#ifndef SDV_PAIR_LINES
+#define SDV_PAIR_LINES 1            /* batch loop: two scanlines per iteration (independent decode chains interleave) */
+#endif
 #define SDV_MAX_HEIGHT 640          /* LINES_PER_FRAME_MAX, config.h:79 */
 
 namespace sdv {
@@ -91,7 +95,7 @@ __device__ __constant__ const CrcTables c_crc = make_crc_tables();
 struct SweepEnt { uint8_t result, hyst, shift, pad; uint16_t crc; int16_t start, stop; uint16_t pad2; };
 struct CrcStat { uint8_t result, hyst, shift, idx; uint16_t crc; };
 struct WaveLds {
-    alignas(16) uint8_t px[SDV_MAX_WIDTH];
+    alignas(16) uint8_t px[SDV_PX_BYTES];     /* one staged scanline, or two of up to 1024 bytes side by side (the pair loop) */
     uint32_t hist[256];
     SweepEnt sweep[256];
     CrcStat crc_stats[MAX_COLL_CRCS + 1];
@@ -1571,6 +1575,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
  * byte path at commit time. */
 struct RowPrefetch {
     uint4 v0, v1; const uint8_t *row;
+    uint4 vb; const uint8_t *row_b; bool has_b;      /* pair loop: the row after `row` in decode order, already fetched */
     bool vec;           /* every row of the frame starts 16-byte aligned: 16-byte vectors, else the byte path */
     int i0;             /* this lane's vector of a row, clamped to the last one (lanes past the row reload it: no exec juggling) */
 };
@@ -1709,9 +1714,9 @@ __device__ inline FastPre fast_pre(const FrameArgs &a, const Bin &b, Geo &g)
     p.x1 = x1 < pixel_start ? pixel_start : (x1 >= pixel_stop ? pixel_stop - 1 : x1);
     return p;
 }
-__device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const LaneConst &lc, FastBits &o)     /* needs p.ok */
+__device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const LaneConst &lc, FastBits &o, int ofs = 0)     /* needs p.ok; ofs: where the row starts in px */
 {
-    uint8_t p0 = lds.px[p.x0], p1 = lds.px[p.x1];
+    uint8_t p0 = lds.px[p.x0 + ofs], p1 = lds.px[p.x1 + ofs];
     uint64_t a_lo = __ballot(p0 > p.ref_low), b_lo = __ballot(p0 >= p.ref_high);
     uint64_t a_hi = __ballot(p1 > p.ref_low), b_hi = __ballot(p1 >= p.ref_high);
     uint64_t s_lo, s_hi;
@@ -1991,6 +1996,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
     pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
+    pf.vb = uint4{0, 0, 0, 0}; pf.row_b = frame; pf.has_b = false;
     pf.vec = ((((uintptr_t)frame) | (uintptr_t)a.row_stride) & 15) == 0 && a.width >= 16;
     { int nvec = a.width >> 4; pf.i0 = lane < nvec ? lane : (nvec > 0 ? nvec - 1 : 0); }
     row_prefetch(pf, frame, a.width);
@@ -2009,16 +2015,64 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 int nb = nl - idx; if (nb > 64) nb = 64;
                 BatchLane bl; bl.d0 = bl.d1 = bl.d2 = bl.d3 = bl.meta = 0;
                 int j = 0;
-                for (; j < nb; j++) {
+                bool redo = false;                              /* a line of a pair did not pass: stage it again for the sequential path */
+                /* row of line k of this field in decode order; past the field: the other field's rows, then any valid row */
+                auto row_in_order = [&](int k) -> const uint8_t * {
+                    if (k < nl) return frame + (size_t)(2 * k + field) * a.row_stride;
+                    if (field == 0 && (k - nl) < n_field[1]) return frame + (size_t)(2 * (k - nl) + 1) * a.row_stride;
+                    return frame;
+                };
+                if (SDV_PAIR_LINES) {
+                    /* two lines per iteration: inside a batch every line is decoded with the same inherited tuning, so the two
+                     * decode chains (LDS gather, ballots, automaton, CRC) are independent and interleave */
+                    for (; j + 1 < nb; j += 2) {
+                        if (!pf.has_b) { pf.row_b = row_in_order(idx + j + 1); pf.vb = ((const uint4 *)pf.row_b)[pf.i0]; pf.has_b = true; }
+                        __syncthreads();
+                        ((uint4 *)lds.px)[lane] = pf.v0;
+                        ((uint4 *)lds.px)[64 + lane] = pf.vb;
+                        __syncthreads();
+                        {
+                            const int ka = idx + j + 2, kb = idx + j + 3;
+                            pf.row = ka < nl ? pf.row_b + row_step : row_in_order(ka);
+                            pf.v0 = ((const uint4 *)pf.row)[pf.i0];
+                            pf.row_b = kb < nl ? pf.row + row_step : row_in_order(kb);
+                            pf.vb = ((const uint4 *)pf.row_b)[pf.i0];
+                        }
+                        FastBits fa, fb2;
+                        const bool oka = fast_try0(lds, pre, lc, fa, 0), okb = fast_try0(lds, pre, lc, fb2, 1024);
+                        if (!oka || ctrl_block_maybe(fa.s_lo)) { redo = true; break; }
+                        {
+                            bool mine = lane == j;
+                            bl.d0 = mine ? (uint32_t)fa.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fa.s_lo >> 32) : bl.d1;
+                            bl.d2 = mine ? (uint32_t)fa.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fa.s_hi >> 32) : bl.d3;
+                            bl.meta = mine ? ((uint32_t)fa.calc_crc | ((uint32_t)fa.h << 16) | ((uint32_t)fa.s << 20)) : bl.meta;
+                        }
+                        if (!okb || ctrl_block_maybe(fb2.s_lo)) { j++; redo = true; break; }
+                        {
+                            bool mine = lane == j + 1;
+                            bl.d0 = mine ? (uint32_t)fb2.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb2.s_lo >> 32) : bl.d1;
+                            bl.d2 = mine ? (uint32_t)fb2.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb2.s_hi >> 32) : bl.d3;
+                            bl.meta = mine ? ((uint32_t)fb2.calc_crc | ((uint32_t)fb2.h << 16) | ((uint32_t)fb2.s << 20)) : bl.meta;
+                        }
+                    }
+                    if (redo) {                                 /* line idx + j goes through the sequential path: fetch it again (it is in L2) */
+                        pf.has_b = false;
+                        row_prefetch(pf, row_in_order(idx + j), a.width);
+                    }
+                }
+                for (; !redo && j < nb; j++) {
                     {   /* row_commit / row_prefetch of the plain case, without their case distinctions */
                         __syncthreads();
                         ((uint4 *)lds.px)[lane] = pf.v0;
                         __syncthreads();
                         int k = idx + j + 1;                    /* next row in decode order */
-                        const uint8_t *nxt = (k < nl) ? pf.row + row_step
-                                                      : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : frame);
-                        pf.row = nxt;
-                        pf.v0 = ((const uint4 *)nxt)[pf.i0];
+                        if (pf.has_b) { pf.row = pf.row_b; pf.v0 = pf.vb; pf.has_b = false; }      /* already fetched by the pair loop */
+                        else {
+                            const uint8_t *nxt = (k < nl) ? pf.row + row_step
+                                                          : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : frame);
+                            pf.row = nxt;
+                            pf.v0 = ((const uint4 *)nxt)[pf.i0];
+                        }
                     }
                     FastBits fb;
                     /* only the first rung of the ladder inside the batch: a line that needs another shift stage or hysteresis
@@ -2034,9 +2088,10 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     rec += j; idx += j;
                 }
                 if (j == nb) continue;
-                staged = true;                                  /* line idx sits in LDS and needs the sequential path */
+                staged = !redo;                                 /* line idx sits in LDS and needs the sequential path */
             }
             if (!staged) {
+                pf.has_b = false;
                 row_commit(lds, pf, a.width);
                 int k = idx + 1;
                 const uint8_t *nxt = (k < nl) ? pf.row + row_step
