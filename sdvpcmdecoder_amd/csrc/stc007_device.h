@@ -37,10 +37,10 @@
 #endif
 
 #define SDV_MAX_WIDTH 1536          /* staged scanline bytes per wave (720 px SD, 1440 px doubled) */
-#define SDV_PX_BYTES 2048           /* LDS bytes for staged scanlines: two rows at a pitch of 1024, each written by 64 lanes x 16 bytes */
-#ifndef SDV_PAIR_LINES
-#define SDV_PAIR_LINES 1            /* batch loop: two scanlines per iteration (independent decode chains interleave) */
+#ifndef SDV_BATCH_LINES
+#define SDV_BATCH_LINES 2           /* batch loop: scanlines per iteration (their decode chains are independent and interleave); 1 = off */
 #endif
+#define SDV_PX_BYTES (1024 * (SDV_BATCH_LINES > 2 ? SDV_BATCH_LINES : 2))   /* LDS bytes for staged scanlines: rows at a pitch of 1024, each written by 64 lanes x 16 bytes */
 #define SDV_MAX_HEIGHT 640          /* LINES_PER_FRAME_MAX, config.h:79 */
 
 namespace sdv {
@@ -1575,7 +1575,8 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
  * byte path at commit time. */
 struct RowPrefetch {
     uint4 v0, v1; const uint8_t *row;
-    uint4 vb; const uint8_t *row_b; bool has_b;      /* pair loop: the row after `row` in decode order, already fetched */
+    uint4 vq[SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1]; const uint8_t *rowq[SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1];
+    int nq;             /* multi-line loop: the nq rows after `row` in decode order that are already fetched */
     bool vec;           /* every row of the frame starts 16-byte aligned: 16-byte vectors, else the byte path */
     int i0;             /* this lane's vector of a row, clamped to the last one (lanes past the row reload it: no exec juggling) */
 };
@@ -1996,7 +1997,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
     pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
-    pf.vb = uint4{0, 0, 0, 0}; pf.row_b = frame; pf.has_b = false;
+    for (int u = 0; u < (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1); u++) { pf.vq[u] = uint4{0, 0, 0, 0}; pf.rowq[u] = frame; }
+    pf.nq = 0;
     pf.vec = ((((uintptr_t)frame) | (uintptr_t)a.row_stride) & 15) == 0 && a.width >= 16;
     { int nvec = a.width >> 4; pf.i0 = lane < nvec ? lane : (nvec > 0 ? nvec - 1 : 0); }
     row_prefetch(pf, frame, a.width);
@@ -2022,41 +2024,52 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     if (field == 0 && (k - nl) < n_field[1]) return frame + (size_t)(2 * (k - nl) + 1) * a.row_stride;
                     return frame;
                 };
-                if (SDV_PAIR_LINES) {
-                    /* two lines per iteration: inside a batch every line is decoded with the same inherited tuning, so the two
+                if (SDV_BATCH_LINES > 1) {
+                    /* NL lines per iteration: inside a batch every line is decoded with the same inherited tuning, so the
                      * decode chains (LDS gather, ballots, automaton, CRC) are independent and interleave */
-                    for (; j + 1 < nb; j += 2) {
-                        if (!pf.has_b) { pf.row_b = row_in_order(idx + j + 1); pf.vb = ((const uint4 *)pf.row_b)[pf.i0]; pf.has_b = true; }
+                    constexpr int NL = SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2;
+                    for (; j + NL - 1 < nb; j += NL) {
+#pragma unroll
+                        for (int u = 0; u < NL - 1; u++)
+                            if (u >= pf.nq) { pf.rowq[u] = row_in_order(idx + j + 1 + u); pf.vq[u] = ((const uint4 *)pf.rowq[u])[pf.i0]; }
+                        pf.nq = NL - 1;
                         __syncthreads();
                         ((uint4 *)lds.px)[lane] = pf.v0;
-                        ((uint4 *)lds.px)[64 + lane] = pf.vb;
+#pragma unroll
+                        for (int u = 0; u < NL - 1; u++) ((uint4 *)lds.px)[64 * (u + 1) + lane] = pf.vq[u];
                         __syncthreads();
                         {
-                            const int ka = idx + j + 2, kb = idx + j + 3;
-                            pf.row = ka < nl ? pf.row_b + row_step : row_in_order(ka);
+                            const uint8_t *prev = pf.rowq[NL - 2];
+                            const int k0 = idx + j + NL;
+                            pf.row = k0 < nl ? prev + row_step : row_in_order(k0);
                             pf.v0 = ((const uint4 *)pf.row)[pf.i0];
-                            pf.row_b = kb < nl ? pf.row + row_step : row_in_order(kb);
-                            pf.vb = ((const uint4 *)pf.row_b)[pf.i0];
+                            prev = pf.row;
+#pragma unroll
+                            for (int u = 0; u < NL - 1; u++) {
+                                const int k = k0 + 1 + u;
+                                pf.rowq[u] = k < nl ? prev + row_step : row_in_order(k);
+                                pf.vq[u] = ((const uint4 *)pf.rowq[u])[pf.i0];
+                                prev = pf.rowq[u];
+                            }
                         }
-                        FastBits fa, fb2;
-                        const bool oka = fast_try0(lds, pre, lc, fa, 0), okb = fast_try0(lds, pre, lc, fb2, 1024);
-                        if (!oka || ctrl_block_maybe(fa.s_lo)) { redo = true; break; }
-                        {
-                            bool mine = lane == j;
-                            bl.d0 = mine ? (uint32_t)fa.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fa.s_lo >> 32) : bl.d1;
-                            bl.d2 = mine ? (uint32_t)fa.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fa.s_hi >> 32) : bl.d3;
-                            bl.meta = mine ? ((uint32_t)fa.calc_crc | ((uint32_t)fa.h << 16) | ((uint32_t)fa.s << 20)) : bl.meta;
+                        FastBits fx[NL]; bool okx[NL];
+#pragma unroll
+                        for (int u = 0; u < NL; u++) okx[u] = fast_try0(lds, pre, lc, fx[u], 1024 * u);
+                        int good = 0;
+#pragma unroll
+                        for (int u = 0; u < NL; u++) {
+                            if (good == u && okx[u] && !ctrl_block_maybe(fx[u].s_lo)) {
+                                good = u + 1;
+                                bool mine = lane == j + u;
+                                bl.d0 = mine ? (uint32_t)fx[u].s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fx[u].s_lo >> 32) : bl.d1;
+                                bl.d2 = mine ? (uint32_t)fx[u].s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fx[u].s_hi >> 32) : bl.d3;
+                                bl.meta = mine ? ((uint32_t)fx[u].calc_crc | ((uint32_t)fx[u].h << 16) | ((uint32_t)fx[u].s << 20)) : bl.meta;
+                            }
                         }
-                        if (!okb || ctrl_block_maybe(fb2.s_lo)) { j++; redo = true; break; }
-                        {
-                            bool mine = lane == j + 1;
-                            bl.d0 = mine ? (uint32_t)fb2.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb2.s_lo >> 32) : bl.d1;
-                            bl.d2 = mine ? (uint32_t)fb2.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb2.s_hi >> 32) : bl.d3;
-                            bl.meta = mine ? ((uint32_t)fb2.calc_crc | ((uint32_t)fb2.h << 16) | ((uint32_t)fb2.s << 20)) : bl.meta;
-                        }
+                        if (good < NL) { j += good; redo = true; break; }
                     }
                     if (redo) {                                 /* line idx + j goes through the sequential path: fetch it again (it is in L2) */
-                        pf.has_b = false;
+                        pf.nq = 0;
                         row_prefetch(pf, row_in_order(idx + j), a.width);
                     }
                 }
@@ -2066,7 +2079,12 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                         ((uint4 *)lds.px)[lane] = pf.v0;
                         __syncthreads();
                         int k = idx + j + 1;                    /* next row in decode order */
-                        if (pf.has_b) { pf.row = pf.row_b; pf.v0 = pf.vb; pf.has_b = false; }      /* already fetched by the pair loop */
+                        if (pf.nq > 0) {                        /* already fetched by the multi-line loop */
+                            pf.row = pf.rowq[0]; pf.v0 = pf.vq[0];
+#pragma unroll
+                            for (int u = 0; u + 1 < (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1); u++) { pf.rowq[u] = pf.rowq[u + 1]; pf.vq[u] = pf.vq[u + 1]; }
+                            pf.nq--;
+                        }
                         else {
                             const uint8_t *nxt = (k < nl) ? pf.row + row_step
                                                           : (field == 0 && n_field[1] > 0 ? frame + a.row_stride : frame);
@@ -2091,7 +2109,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 staged = !redo;                                 /* line idx sits in LDS and needs the sequential path */
             }
             if (!staged) {
-                pf.has_b = false;
+                pf.nq = 0;
                 row_commit(lds, pf, a.width);
                 int k = idx + 1;
                 const uint8_t *nxt = (k < nl) ? pf.row + row_step
