@@ -366,7 +366,7 @@ __device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_
     /* one scalar add-with-carry chain over the four 32-bit limbs (there is no 64-bit unsigned compare on the scalar unit to
      * recover the carry of a 64-bit add, and the compiler re-materialises SCC between the limbs when left to itself) */
     uint32_t y0, y1, y2, y3;
-    asm volatile("s_add_u32 %0, %4, %8\n\ts_addc_u32 %1, %5, %9\n\ts_addc_u32 %2, %6, %10\n\ts_addc_u32 %3, %7, %11"
+    asm("s_add_u32 %0, %4, %8\n\ts_addc_u32 %1, %5, %9\n\ts_addc_u32 %2, %6, %10\n\ts_addc_u32 %3, %7, %11"
                  : "=&s"(y0), "=&s"(y1), "=&s"(y2), "=&s"(y3)
                  : "s"((uint32_t)x_lo), "s"((uint32_t)(x_lo >> 32)), "s"((uint32_t)x_hi), "s"((uint32_t)(x_hi >> 32)),
                    "s"((uint32_t)u_lo), "s"((uint32_t)(u_lo >> 32)), "s"((uint32_t)u_hi), "s"((uint32_t)(u_hi >> 32))
@@ -1715,9 +1715,13 @@ __device__ inline FastPre fast_pre(const FrameArgs &a, const Bin &b, Geo &g)
     p.x1 = x1 < pixel_start ? pixel_start : (x1 >= pixel_stop ? pixel_stop - 1 : x1);
     return p;
 }
-__device__ inline bool fast_try0(const WaveLds &lds, const FastPre &p, const LaneConst &lc, FastBits &o, int ofs = 0)     /* needs p.ok; ofs: where the row starts in px */
+/* the two cells a lane owns, sampled from the row staged at px + ofs; fast_try0 below takes them (split so that the LDS reads of
+ * several rows can be issued before the first row is worked on) */
+struct FastCells { uint8_t p0, p1; };
+__device__ __forceinline__ FastCells fast_sample(const WaveLds &lds, const FastPre &p, int ofs) { FastCells c; c.p0 = lds.px[p.x0 + ofs]; c.p1 = lds.px[p.x1 + ofs]; return c; }
+__device__ inline bool fast_try0(const FastCells &cells, const FastPre &p, const LaneConst &lc, FastBits &o)     /* needs p.ok */
 {
-    uint8_t p0 = lds.px[p.x0 + ofs], p1 = lds.px[p.x1 + ofs];
+    uint8_t p0 = cells.p0, p1 = cells.p1;
     uint64_t a_lo = __ballot(p0 > p.ref_low), b_lo = __ballot(p0 >= p.ref_high);
     uint64_t a_hi = __ballot(p1 > p.ref_low), b_hi = __ballot(p1 >= p.ref_high);
     uint64_t s_lo, s_hi;
@@ -1948,9 +1952,18 @@ __device__ __attribute__((noinline)) void slow_line(SlowCtx *c, WaveLds *lds, ui
  * paths gives the frame up: it marks its outgoing state (sdv_v2d_state::_pad[0]) and the engine decodes from that frame on
  * with the full kernel. */
 enum { STATE_ABORTED = 0xA5 };
+#ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch */
+__device__ unsigned long long sdv_k1_cycles[8];
+#define K1_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define K1_ADD(i, t0, t1) do { if (lane_id() == 0) atomicAdd(&sdv_k1_cycles[i], (t1) - (t0)); } while (0)
+#else
+#define K1_T(var) do { } while (0)
+#define K1_ADD(i, t0, t1) do { } while (0)
+#endif
 template <bool kLean>
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 {
+    K1_T(t_begin);
     V2D v; Line wl;
     v2d_load_state(v, lds, &a.states_in[f], a);
     const uint32_t frame_no = a.first_frame_no + (uint32_t)f;
@@ -2014,6 +2027,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             FastPre pre; pre.ok = false;
             if (pf.vec && a.width <= 1024 && (a.width & 15) == 0 && batch_eligible(a, lds, v, geo)) pre = fast_pre(a, v.bin, geo);
             if (pre.ok) {
+                K1_T(t_batch);
                 int nb = nl - idx; if (nb > 64) nb = 64;
                 BatchLane bl; bl.d0 = bl.d1 = bl.d2 = bl.d3 = bl.meta = 0;
                 int j = 0;
@@ -2052,9 +2066,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                                 prev = pf.rowq[u];
                             }
                         }
-                        FastBits fx[NL]; bool okx[NL];
+                        FastBits fx[NL]; bool okx[NL]; FastCells cx[NL];
 #pragma unroll
-                        for (int u = 0; u < NL; u++) okx[u] = fast_try0(lds, pre, lc, fx[u], 1024 * u);
+                        for (int u = 0; u < NL; u++) cx[u] = fast_sample(lds, pre, 1024 * u);      /* all LDS reads first */
+#pragma unroll
+                        for (int u = 0; u < NL; u++) okx[u] = fast_try0(cx[u], pre, lc, fx[u]);
                         int good = 0;
 #pragma unroll
                         for (int u = 0; u < NL; u++) {
@@ -2095,14 +2111,18 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     FastBits fb;
                     /* only the first rung of the ladder inside the batch: a line that needs another shift stage or hysteresis
                      * depth ends the batch and takes the sequential path below (keeps this loop's control flow flat) */
-                    if (!fast_try0(lds, pre, lc, fb) || ctrl_block_maybe(fb.s_lo)) break;
+                    if (!fast_try0(fast_sample(lds, pre, 0), pre, lc, fb) || ctrl_block_maybe(fb.s_lo)) break;
                     bool mine = lane == j;
                     bl.d0 = mine ? (uint32_t)fb.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb.s_lo >> 32) : bl.d1;
                     bl.d2 = mine ? (uint32_t)fb.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb.s_hi >> 32) : bl.d3;
                     bl.meta = mine ? ((uint32_t)fb.calc_crc | ((uint32_t)fb.h << 16) | ((uint32_t)fb.s << 20)) : bl.meta;
                 }
+                K1_T(t_loop);
+                K1_ADD(1, t_batch, t_loop);
                 if (j > 0) {
                     batch_finish(a, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
+                    K1_T(t_fin);
+                    K1_ADD(2, t_loop, t_fin);
                     rec += j; idx += j;
                 }
                 if (j == nb) continue;
@@ -2138,9 +2158,13 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     }
     line_num = (uint16_t)(line_num + 2);
     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
+    K1_T(t_ef0);
     v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f]);
     emit_record(wl, rec++);
     v2d_store_state(v, lds, &a.states_out[f], a);
+    K1_T(t_end);
+    K1_ADD(3, t_ef0, t_end);
+    K1_ADD(0, t_begin, t_end);
 }
 
 } // namespace sdv
