@@ -2039,6 +2039,10 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     return frame;
                 };
                 if (SDV_BATCH_LINES > 1) {
+                    constexpr int NLA = SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2;
+                    const uint8_t *after[NLA];                  /* the rows that follow this field in decode order */
+#pragma unroll
+                    for (int q = 0; q < NLA; q++) after[q] = row_in_order(nl + q);
                     /* NL lines per iteration: inside a batch every line is decoded with the same inherited tuning, so the
                      * decode chains (LDS gather, ballots, automaton, CRC) are independent and interleave */
                     constexpr int NL = SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2;
@@ -2052,16 +2056,20 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 #pragma unroll
                         for (int u = 0; u < NL - 1; u++) ((uint4 *)lds.px)[64 * (u + 1) + lane] = pf.vq[u];
                         __syncthreads();
-                        {
+                        {   /* the next NL rows: one pointer step inside the field; past its end one of the NL rows looked up per field */
                             const uint8_t *prev = pf.rowq[NL - 2];
                             const int k0 = idx + j + NL;
-                            pf.row = k0 < nl ? prev + row_step : row_in_order(k0);
+                            auto beyond = [&](int d) -> const uint8_t * { const uint8_t *r = after[0];
+#pragma unroll
+                                for (int q = 1; q < NL; q++) r = d == q ? after[q] : r;
+                                return r; };
+                            pf.row = k0 < nl ? prev + row_step : beyond(k0 - nl);
                             pf.v0 = ((const uint4 *)pf.row)[pf.i0];
                             prev = pf.row;
 #pragma unroll
                             for (int u = 0; u < NL - 1; u++) {
                                 const int k = k0 + 1 + u;
-                                pf.rowq[u] = k < nl ? prev + row_step : row_in_order(k);
+                                pf.rowq[u] = k < nl ? prev + row_step : beyond(k - nl);
                                 pf.vq[u] = ((const uint4 *)pf.rowq[u])[pf.i0];
                                 prev = pf.rowq[u];
                             }
