@@ -40,6 +40,9 @@
 #ifndef SDV_BATCH_LINES
 #define SDV_BATCH_LINES 2           /* batch loop: scanlines per iteration (their decode chains are independent and interleave); 1 = off */
 #endif
+#ifndef SDV_INTERLEAVE2
+#define SDV_INTERLEAVE2 1
+#endif
 #define SDV_PX_BYTES (1024 * (SDV_BATCH_LINES > 2 ? SDV_BATCH_LINES : 2))   /* LDS bytes for staged scanlines: rows at a pitch of 1024, each written by 64 lanes x 16 bytes */
 #define SDV_MAX_HEIGHT 640          /* LINES_PER_FRAME_MAX, config.h:79 */
 
@@ -1733,6 +1736,50 @@ __device__ inline bool fast_try0(const FastCells &cells, const FastPre &p, const
     o.ctrl_block = false;                   /* not looked at here: the batch loop does ctrl_block_maybe() */
     return true;
 }
+/* fast_try0 for two rows at once, the two decode chains written step by step side by side: every step of row B is independent
+ * of the same step of row A, so the in-order issue of a wave always has a second instruction that does not wait for the first */
+#ifndef SDV_EMU
+#define SDV_CARRY_ADD(y0, y1, y2, y3, x_lo, x_hi, u_lo, u_hi) \
+    asm("s_add_u32 %0, %4, %8\n\ts_addc_u32 %1, %5, %9\n\ts_addc_u32 %2, %6, %10\n\ts_addc_u32 %3, %7, %11" \
+        : "=&s"(y0), "=&s"(y1), "=&s"(y2), "=&s"(y3) \
+        : "s"((uint32_t)(x_lo)), "s"((uint32_t)((x_lo) >> 32)), "s"((uint32_t)(x_hi)), "s"((uint32_t)((x_hi) >> 32)), \
+          "s"((uint32_t)(u_lo)), "s"((uint32_t)((u_lo) >> 32)), "s"((uint32_t)(u_hi)), "s"((uint32_t)((u_hi) >> 32)) \
+        : "scc")
+#endif
+__device__ inline void fast_try0_x2(const FastCells &ca, const FastCells &cb, const FastPre &p, const LaneConst &lc,
+                                    FastBits &oa, FastBits &ob, bool &ok_a, bool &ok_b)
+{
+    const int lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint64_t aA_lo = __ballot(ca.p0 > p.ref_low), aB_lo = __ballot(cb.p0 > p.ref_low);
+    const uint64_t bA_lo = __ballot(ca.p0 >= p.ref_high), bB_lo = __ballot(cb.p0 >= p.ref_high);
+    const uint64_t aA_hi = __ballot(ca.p1 > p.ref_low), aB_hi = __ballot(cb.p1 > p.ref_low);
+    const uint64_t bA_hi = __ballot(ca.p1 >= p.ref_high), bB_hi = __ballot(cb.p1 >= p.ref_high);
+    const uint64_t eA_lo = ~(aA_lo ^ bA_lo), eB_lo = ~(aB_lo ^ bB_lo), eA_hi = ~(aA_hi ^ bA_hi), eB_hi = ~(aB_hi ^ bB_hi);
+    const uint64_t tA_lo = aA_lo & ~bA_lo, tB_lo = aB_lo & ~bB_lo, tA_hi = aA_hi & ~bA_hi, tB_hi = aB_hi & ~bB_hi;
+    const int cA_lo = __popcll(tA_lo & lt) + (int)((tA_lo >> lane) & 1), cB_lo = __popcll(tB_lo & lt) + (int)((tB_lo >> lane) & 1);
+    const int cA_hi = __popcll(tA_lo) + __popcll(tA_hi & lt) + (int)((tA_hi >> lane) & 1);
+    const int cB_hi = __popcll(tB_lo) + __popcll(tB_hi & lt) + (int)((tB_hi >> lane) & 1);
+    const uint64_t ptA_lo = __ballot(cA_lo & 1), ptB_lo = __ballot(cB_lo & 1), ptA_hi = __ballot(cA_hi & 1), ptB_hi = __ballot(cB_hi & 1);
+    const uint64_t uA_lo = ((aA_lo & bA_lo) ^ ptA_lo) & eA_lo, uB_lo = ((aB_lo & bB_lo) ^ ptB_lo) & eB_lo;
+    const uint64_t uA_hi = ((aA_hi & bA_hi) ^ ptA_hi) & eA_hi, uB_hi = ((aB_hi & bB_hi) ^ ptB_hi) & eB_hi;
+    const uint64_t xA_lo = uA_lo | ~eA_lo, xB_lo = uB_lo | ~eB_lo, xA_hi = uA_hi | ~eA_hi, xB_hi = uB_hi | ~eB_hi;
+    uint64_t yA_lo, yA_hi, yB_lo, yB_hi;
+#ifdef SDV_EMU
+    yA_lo = xA_lo + uA_lo; yA_hi = xA_hi + uA_hi + ((yA_lo < xA_lo) ? 1ull : 0ull);
+    yB_lo = xB_lo + uB_lo; yB_hi = xB_hi + uB_hi + ((yB_lo < xB_lo) ? 1ull : 0ull);
+#else
+    { uint32_t y0, y1, y2, y3; SDV_CARRY_ADD(y0, y1, y2, y3, xA_lo, xA_hi, uA_lo, uA_hi); yA_lo = ((uint64_t)y1 << 32) | y0; yA_hi = ((uint64_t)y3 << 32) | y2; }
+    { uint32_t y0, y1, y2, y3; SDV_CARRY_ADD(y0, y1, y2, y3, xB_lo, xB_hi, uB_lo, uB_hi); yB_lo = ((uint64_t)y1 << 32) | y0; yB_hi = ((uint64_t)y3 << 32) | y2; }
+#endif
+    const uint64_t sA_lo = (((yA_lo ^ xA_lo) & ~eA_lo) | uA_lo) ^ ptA_lo, sB_lo = (((yB_lo ^ xB_lo) & ~eB_lo) | uB_lo) ^ ptB_lo;
+    const uint64_t sA_hi = (((yA_hi ^ xA_hi) & ~eA_hi) | uA_hi) ^ ptA_hi, sB_hi = (((yB_hi ^ xB_hi) & ~eB_hi) | uB_hi) ^ ptB_hi;
+    const int parA = (__popcll(sA_lo & lc.klo) + __popcll(sA_hi & lc.khi)) & 1, parB = (__popcll(sB_lo & lc.klo) + __popcll(sB_hi & lc.khi)) & 1;
+    const uint16_t crcA = (uint16_t)((uint16_t)(__ballot(parA) & 0xFFFF) ^ c_crc.init), crcB = (uint16_t)((uint16_t)(__ballot(parB) & 0xFFFF) ^ c_crc.init);
+    ok_a = crcA == rev16((uint32_t)((sA_hi >> 48) & 0xFFFF)); ok_b = crcB == rev16((uint32_t)((sB_hi >> 48) & 0xFFFF));
+    oa.s_lo = sA_lo; oa.s_hi = sA_hi; oa.calc_crc = crcA; oa.ref_low = (uint8_t)p.ref_low; oa.ref_high = (uint8_t)p.ref_high; oa.h = 0; oa.s = 0; oa.ctrl_block = false;
+    ob.s_lo = sB_lo; ob.s_hi = sB_hi; ob.calc_crc = crcB; ob.ref_low = (uint8_t)p.ref_low; ob.ref_high = (uint8_t)p.ref_high; ob.h = 0; ob.s = 0; ob.ctrl_block = false;
+}
 /* the first 32 cells of the Control Block pattern: necessary for a Control Block, and a false alarm only once in 2^32 lines */
 __device__ __forceinline__ bool ctrl_block_maybe(uint64_t s_lo) { return (uint32_t)s_lo == (uint32_t)ctrl_cells_0_55(); }
 
@@ -2077,8 +2124,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                         FastBits fx[NL]; bool okx[NL]; FastCells cx[NL];
 #pragma unroll
                         for (int u = 0; u < NL; u++) cx[u] = fast_sample(lds, pre, 1024 * u);      /* all LDS reads first */
+                        if (NL == 2 && SDV_INTERLEAVE2) fast_try0_x2(cx[0], cx[1], pre, lc, fx[0], fx[1], okx[0], okx[1]);
+                        else {
 #pragma unroll
-                        for (int u = 0; u < NL; u++) okx[u] = fast_try0(cx[u], pre, lc, fx[u]);
+                            for (int u = 0; u < NL; u++) okx[u] = fast_try0(cx[u], pre, lc, fx[u]);
+                        }
                         int good = 0;
 #pragma unroll
                         for (int u = 0; u < NL; u++) {
