@@ -43,6 +43,10 @@
 #ifndef SDV_INTERLEAVE2
 #define SDV_INTERLEAVE2 1
 #endif
+#ifndef SDV_PREFETCH_ITERS
+#define SDV_PREFETCH_ITERS 1         /* multi-line loop: iterations of rows in flight ahead of the one being decoded */
+#endif
+#define SDV_ROWQ ((SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2) * SDV_PREFETCH_ITERS - 1)   /* rows queued behind `row` */
 #define SDV_PX_BYTES (1024 * (SDV_BATCH_LINES > 2 ? SDV_BATCH_LINES : 2))   /* LDS bytes for staged scanlines: rows at a pitch of 1024, each written by 64 lanes x 16 bytes */
 #define SDV_MAX_HEIGHT 640          /* LINES_PER_FRAME_MAX, config.h:79 */
 
@@ -1578,7 +1582,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
  * byte path at commit time. */
 struct RowPrefetch {
     uint4 v0, v1; const uint8_t *row;
-    uint4 vq[SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1]; const uint8_t *rowq[SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1];
+    uint4 vq[SDV_ROWQ]; const uint8_t *rowq[SDV_ROWQ];
     int nq;             /* multi-line loop: the nq rows after `row` in decode order that are already fetched */
     bool vec;           /* every row of the frame starts 16-byte aligned: 16-byte vectors, else the byte path */
     int i0;             /* this lane's vector of a row, clamped to the last one (lanes past the row reload it: no exec juggling) */
@@ -2057,7 +2061,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
     pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
-    for (int u = 0; u < (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1); u++) { pf.vq[u] = uint4{0, 0, 0, 0}; pf.rowq[u] = frame; }
+    for (int u = 0; u < SDV_ROWQ; u++) { pf.vq[u] = uint4{0, 0, 0, 0}; pf.rowq[u] = frame; }
     pf.nq = 0;
     pf.vec = ((((uintptr_t)frame) | (uintptr_t)a.row_stride) & 15) == 0 && a.width >= 16;
     { int nvec = a.width >> 4; pf.i0 = lane < nvec ? lane : (nvec > 0 ? nvec - 1 : 0); }
@@ -2086,39 +2090,49 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     return frame;
                 };
                 if (SDV_BATCH_LINES > 1) {
-                    constexpr int NLA = SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2;
+                    constexpr int NLA = SDV_ROWQ + 1 + (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2);
                     const uint8_t *after[NLA];                  /* the rows that follow this field in decode order */
 #pragma unroll
                     for (int q = 0; q < NLA; q++) after[q] = row_in_order(nl + q);
                     /* NL lines per iteration: inside a batch every line is decoded with the same inherited tuning, so the
                      * decode chains (LDS gather, ballots, automaton, CRC) are independent and interleave */
                     constexpr int NL = SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2;
-                    for (; j + NL - 1 < nb; j += NL) {
+                    /* R[0] = pf.v0 / pf.row is the row of line idx + j, R[1 + u] = pf.vq[u] the rows behind it: NL * SDV_PREFETCH_ITERS rows in
+                     * registers or on their way */
+                    constexpr int NR = SDV_ROWQ + 1;
+                    auto beyond = [&](int d) -> const uint8_t * { const uint8_t *r = frame;
 #pragma unroll
-                        for (int u = 0; u < NL - 1; u++)
-                            if (u >= pf.nq) { pf.rowq[u] = row_in_order(idx + j + 1 + u); pf.vq[u] = ((const uint4 *)pf.rowq[u])[pf.i0]; }
-                        pf.nq = NL - 1;
+                        for (int q = 0; q < NLA; q++) r = d == q ? after[q] : r;
+                        return r; };
+                    for (; j + NL - 1 < nb; j += NL) {
+                        /* rows that are not in flight yet (start of a batch after sequential lines) */
+#pragma unroll
+                        for (int i = 1; i < NR; i++)
+                            if (i - 1 >= pf.nq) {
+                                const int k = idx + j + i;
+                                pf.rowq[i - 1] = k < nl ? row_in_order(k) : beyond(k - nl);
+                                pf.vq[i - 1] = ((const uint4 *)pf.rowq[i - 1])[pf.i0];
+                            }
+                        pf.nq = NR - 1;
                         __syncthreads();
                         ((uint4 *)lds.px)[lane] = pf.v0;
 #pragma unroll
                         for (int u = 0; u < NL - 1; u++) ((uint4 *)lds.px)[64 * (u + 1) + lane] = pf.vq[u];
                         __syncthreads();
-                        {   /* the next NL rows: one pointer step inside the field; past its end one of the NL rows looked up per field */
-                            const uint8_t *prev = pf.rowq[NL - 2];
-                            const int k0 = idx + j + NL;
-                            auto beyond = [&](int d) -> const uint8_t * { const uint8_t *r = after[0];
+                        {   /* the queue moves up by NL rows and NL new rows are requested at its end: one pointer step inside the field,
+                             * past its end one of the rows looked up per batch */
+                            const uint8_t *prev = NR > 1 ? pf.rowq[NR - 2] : pf.row;       /* the last row requested so far */
+                            if (NR > NL) { pf.row = pf.rowq[NL - 1]; pf.v0 = pf.vq[NL - 1]; }
 #pragma unroll
-                                for (int q = 1; q < NL; q++) r = d == q ? after[q] : r;
-                                return r; };
-                            pf.row = k0 < nl ? prev + row_step : beyond(k0 - nl);
-                            pf.v0 = ((const uint4 *)pf.row)[pf.i0];
-                            prev = pf.row;
+                            for (int i = 1; i + NL < NR; i++) { pf.rowq[i - 1] = pf.rowq[i - 1 + NL]; pf.vq[i - 1] = pf.vq[i - 1 + NL]; }
 #pragma unroll
-                            for (int u = 0; u < NL - 1; u++) {
-                                const int k = k0 + 1 + u;
-                                pf.rowq[u] = k < nl ? prev + row_step : beyond(k - nl);
-                                pf.vq[u] = ((const uint4 *)pf.rowq[u])[pf.i0];
-                                prev = pf.rowq[u];
+                            for (int u = 0; u < NL; u++) {
+                                const int i = NR - NL + u;                                  /* slot in R of the new row */
+                                const int k = idx + j + NL + i;                              /* its decode position */
+                                const uint8_t *r = k < nl ? prev + row_step : beyond(k - nl);
+                                const uint4 val = ((const uint4 *)r)[pf.i0];
+                                if (i == 0) { pf.row = r; pf.v0 = val; } else { pf.rowq[i - 1] = r; pf.vq[i - 1] = val; }
+                                prev = r;
                             }
                         }
                         FastBits fx[NL]; bool okx[NL]; FastCells cx[NL];
@@ -2156,7 +2170,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                         if (pf.nq > 0) {                        /* already fetched by the multi-line loop */
                             pf.row = pf.rowq[0]; pf.v0 = pf.vq[0];
 #pragma unroll
-                            for (int u = 0; u + 1 < (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES - 1 : 1); u++) { pf.rowq[u] = pf.rowq[u + 1]; pf.vq[u] = pf.vq[u + 1]; }
+                            for (int u = 0; u + 1 < SDV_ROWQ; u++) { pf.rowq[u] = pf.rowq[u + 1]; pf.vq[u] = pf.vq[u + 1]; }
                             pf.nq--;
                         }
                         else {
