@@ -111,6 +111,9 @@ struct WaveLds {
 };
 
 /* ---- launch parameters ---------------------------------------------------------------------- */
+/* the chain after a frame: 0 its successor was started from exactly what it produced, 1 a lean wave gave the frame up,
+ * 2 the successor was started from something else */
+enum { VF_OK = 0, VF_ABORTED = 1, VF_BREAK = 2 };
 struct FrameArgs {
     const uint8_t *luma;            /* frame f, row r at luma + f*frame_stride + r*row_stride */
     size_t frame_stride, row_stride;
@@ -118,6 +121,8 @@ struct FrameArgs {
     uint32_t first_frame_no;        /* frame_number of frame index 0 */
     int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch ... */
     const int *frame_list;          /* ... or, when set, the frames frame_list[0 .. grid) */
+    uint8_t *flag;                  /* [n_total] VF_*: how frame f left the chain (written by the frame itself when it is done) */
+    int n_total;                    /* frames of the call */
     int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
     int end_file_frame;             /* frame index of the filler frame that closes the file (no pixels: FILLER lines, END_FILE), or -1 */
     uint8_t doubled, mode, check_line_copy, coordinate_damper, m2_format;
@@ -1575,6 +1580,18 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
     }
     o._pad[0] = o._pad[1] = 0;
     *s = o;
+    /* the check of the chain, by the frame itself: was the next frame started from this state? */
+    const int f = (int)(s - a.states_out);
+    uint8_t fl = VF_OK;
+    if (f + 1 < a.n_total) {
+        uint32_t mine[sizeof(sdv_v2d_state) / 4];
+        __builtin_memcpy(mine, &o, sizeof(o));
+        const uint32_t *next = (const uint32_t *)&a.states_in[f + 1];
+        bool same = true;
+        for (unsigned i = 0; i < sizeof(sdv_v2d_state) / 4; i++) same = same && (mine[i] == next[i]);
+        if (!same) fl = VF_BREAK;
+    }
+    a.flag[f] = fl;
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
@@ -2211,7 +2228,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             line_num = (uint16_t)(field + 1 + 2 * idx);
             if (!fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec)) {
                 if (kLean) {
-                    if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; }
+                    if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
                     return;
                 } else {
                     SlowCtx c;
