@@ -533,7 +533,7 @@ struct StepChain {
     uint32_t _pad[3];
     SLine tail[MIN_DEINT];
 };
-enum { SI_OVERFLOW = 1, SI_STEADY = 2 };
+enum { SI_OVERFLOW = 1, SI_STEADY = 2, SI_MISS = 4 /* direct output: the turn wanted more room than was guessed */ };
 struct StepInfo { uint32_t n_pairs; uint8_t n_frasm, changed, push_order, bits; };
 struct StepArgs {
     const SLine *fields; const FrameLocal *fl; Cfg cfg;
@@ -544,6 +544,9 @@ struct StepArgs {
     const uint8_t *prob_order, *prob_res;   /* getProbableFieldOrder() before the step's own push / getProbableResolution() after its pushes */
     SLine *ws;                              /* QCAP lines per wave */
     sdv_sample_pair *pairs; sdv_frame_asm *frasm; StepInfo *info;
+    /* direct output: when every turn of the stream is known to emit guess_pairs pairs and guess_frasm descriptors (a tape that plays),
+     * the turns write straight into the caller's buffers at k * guess; NULL = per-turn slots, packed by the compact kernel */
+    sdv_sample_pair *direct_pairs; sdv_frame_asm *direct_frasm; uint32_t guess_pairs, guess_frasm;
     uint32_t first_round;
     unsigned long long *timing;             /* optional: 8 cycle stamps per step (SDV_STITCH_TIMING=1), NULL otherwise */
 };
@@ -1276,6 +1279,7 @@ struct Step {
 
     /* ---- performDeinterleave (:6675-6885) + outputSamplePair (:6525-6569) ---- */
     sdv_sample_pair *out_pairs; uint32_t n_pairs;
+    uint32_t pair_cap; bool clipped;       /* room for this turn's pairs; clipped: it wanted more */
     __device__ static inline sdv_sample_pair service_pair(uint8_t srv)
     {
         sdv_sample_pair p;
@@ -1352,7 +1356,7 @@ struct Step {
             for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
             if (act) {
                 sdv_sample_pair *o = out_pairs + n_pairs + 3u * (uint32_t)i;
-                if (n_pairs + 3u * (uint32_t)i + 3u <= PAIR_SLOT) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
+                if (n_pairs + 3u * (uint32_t)i + 3u <= pair_cap) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
             }
         }
         if (nblk > 0) {
@@ -1361,7 +1365,7 @@ struct Step {
             f1.blocks_fix_p = (uint16_t)(f1.blocks_fix_p + fix_p); f1.blocks_fix_q = (uint16_t)(f1.blocks_fix_q + fix_q); f1.blocks_fix_cwd = (uint16_t)(f1.blocks_fix_cwd + fix_cwd);
             f1.blocks_drop = (uint16_t)(f1.blocks_drop + drop); f1.samples_drop = (uint16_t)(f1.samples_drop + sdrop);
             f1.blocks_broken_field = (uint16_t)(f1.blocks_broken_field + brk_field);
-            n_pairs += 3u * (uint32_t)nblk; if (n_pairs > PAIR_SLOT) { n_pairs = PAIR_SLOT; overflow = true; }
+            n_pairs += 3u * (uint32_t)nblk; if (n_pairs > pair_cap) { n_pairs = pair_cap; clipped = true; }
         }
         broken_countdown = cd;
         /* what stays in conv_queue: the last (at most) 112 lines */
@@ -1405,7 +1409,9 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2);
     s.q = a.ws + (size_t)slot * QCAP; s.overflow = false;
     s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
-    s.out_pairs = a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
+    const bool direct = a.direct_pairs != NULL;
+    s.out_pairs = direct ? a.direct_pairs + (size_t)k * a.guess_pairs : a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
+    s.pair_cap = direct ? a.guess_pairs : (uint32_t)PAIR_SLOT; s.clipped = false;
     s.f0 = in->f0; make_uniform(s.f0);
     s.last_pad_counter = (uint8_t)uni(in->last_pad_counter); s.broken_countdown = (uint8_t)uni(in->broken_countdown);
     s.qn = (int)uni(in->tail_n);
@@ -1423,11 +1429,13 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     ST_STAMP(1);
     s.find_field_stitching();
     ST_STAMP(2);
-    sdv_frame_asm *fo = a.frasm + (size_t)k * FRASM_SLOT;
+    sdv_frame_asm *fo = direct ? a.direct_frasm + (size_t)k * a.guess_frasm : a.frasm + (size_t)k * FRASM_SLOT;
+    const uint32_t frasm_cap = direct ? a.guess_frasm : (uint32_t)FRASM_SLOT;
     uint8_t n_frasm = 0;
     if (s.file_start) {
         Frasm sd; frasm_clear(sd); sd.service_type = 1;
-        if (lane == 0) { frasm_to_pod(sd, fo[n_frasm]); s.out_pairs[0] = Step::service_pair(SDV_PAIR_SRV_NEW_FILE); }
+        if (n_frasm < frasm_cap && s.pair_cap >= 1) { if (lane == 0) { frasm_to_pod(sd, fo[n_frasm]); s.out_pairs[0] = Step::service_pair(SDV_PAIR_SRV_NEW_FILE); } }
+        else s.clipped = true;
         n_frasm++; s.n_pairs = 1;
     }
     s.fill_frame_for_output();
@@ -1437,7 +1445,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     ST_STAMP(4);
     s.perform_deinterleave();
     ST_STAMP(5);
-    if (lane == 0) frasm_to_pod(s.f1, fo[n_frasm]);
+    if (n_frasm < frasm_cap) { if (lane == 0) frasm_to_pod(s.f1, fo[n_frasm]); } else s.clipped = true;
     n_frasm++;
     s.f0 = s.f1;
     /* the next turn reads frasm_f0's geometry, order, paddings and resolutions only: keep the per-frame statistics out of
@@ -1446,7 +1454,8 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     int tail_n = s.qn - s.tail_ofs;
     if (s.file_end) {
         Frasm sd; frasm_clear(sd); sd.service_type = 2;
-        if (lane == 0) { frasm_to_pod(sd, fo[n_frasm]); if (s.n_pairs < PAIR_SLOT) s.out_pairs[s.n_pairs] = Step::service_pair(SDV_PAIR_SRV_END_FILE); }
+        if (n_frasm < frasm_cap && s.n_pairs < s.pair_cap) { if (lane == 0) { frasm_to_pod(sd, fo[n_frasm]); s.out_pairs[s.n_pairs] = Step::service_pair(SDV_PAIR_SRV_END_FILE); } }
+        else s.clipped = true;
         n_frasm++; s.n_pairs++;
         reset_state(s); tail_n = 0;
     }
@@ -1470,7 +1479,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     const bool changed = __ballot(diff) != 0;
     if (lane == 0) {
         StepInfo inf; inf.n_pairs = s.n_pairs; inf.n_frasm = n_frasm; inf.changed = changed ? 1 : 0; inf.push_order = s.push_order;
-        inf.bits = (uint8_t)((s.overflow ? SI_OVERFLOW : 0) | ((s.f0.inner_padding_ok && s.f0.outer_padding_ok && order_set(s.f0)) ? SI_STEADY : 0));
+        inf.bits = (uint8_t)(((s.overflow || (!direct && s.clipped)) ? SI_OVERFLOW : 0) | ((direct && s.clipped) ? SI_MISS : 0) | ((s.f0.inner_padding_ok && s.f0.outer_padding_ok && order_set(s.f0)) ? SI_STEADY : 0));
         a.info[k] = inf;
     }
     __syncthreads();
