@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""gpurun_out/ of the last tools/gpu_validate.sh run -> profiles/ (trimmed rocprofv3 kernel stats, bench JSON lines, PMC summaries)."""
+import csv, glob, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
+
+
+def newest(pat):
+    fs = glob.glob(pat)
+    fs.sort(key=os.path.getmtime)
+    return fs[-1]
+
+
+def trim(src, dst):
+    rows = list(csv.DictReader(open(src)))
+    keep = [r for r in rows if r['Name'].startswith('sdv_') or r['Name'].startswith('__amd_rocclr')]
+    with open(dst, 'w', newline='') as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        for r in keep:
+            w.writerow(r)
+
+
+trim(newest('gpurun_out/prof_bench/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_kernel_stats.csv')
+trim(newest('gpurun_out/prof_stitch/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_stitch_kernel_stats.csv')
+trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_pcm1_kernel_stats.csv')
+shutil.copy('gpurun_out/bench_full.json', 'profiles/r01_bench_full.json')
+shutil.copy('gpurun_out/bench_2rank_gloo.json', 'profiles/r01_bench_2rank_gloo_one_gpu.json')
+subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', 'profiles/r01_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
+subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', 'profiles/r01_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
+d = json.loads(open('gpurun_out/bench_full.json').read().strip().split('\n')[-1])
+print('value', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'launch ms', d['roofline']['avg_launch_ms'], 'traffic', d['roofline']['traffic'])
+for k in ('stitch_stage', 'pcm1_stage'):
+    print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ('note', 'cpu_baseline')})
+print('cpu', d['cpu_baseline']['value'], d['stitch_stage']['cpu_baseline']['value'], d['pcm1_stage']['cpu_baseline']['value'], d.get('host_fed', {}).get('h2d_gb_per_s'))
