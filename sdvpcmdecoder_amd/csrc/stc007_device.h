@@ -364,8 +364,9 @@ __device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_
     uint64_t t_lo = a_lo & ~b_lo, t_hi = a_hi & ~b_hi;           /* toggling cells */
     /* inclusive prefix parity of t, lane i owns cells i and i+64 */
     int lane = lane_id();
-    int c_lo = prefix_count(t_lo) + (int)((t_lo >> lane) & 1);
-    int c_hi = __popcll(t_lo) + prefix_count(t_hi) + (int)((t_hi >> lane) & 1);
+    const uint64_t le = ((1ull << lane) - 1ull) | (1ull << lane);       /* inclusive */
+    int c_lo = __popcll(t_lo & le);
+    int c_hi = __popcll(t_lo) + __popcll(t_hi & le);
     uint64_t pt_lo = __ballot(c_lo & 1);
     uint64_t pt_hi = __ballot(c_hi & 1);
     uint64_t u_lo = ((a_lo & b_lo) ^ pt_lo) & e_lo, u_hi = ((a_hi & b_hi) ^ pt_hi) & e_hi;   /* head values */
@@ -1771,16 +1772,16 @@ __device__ inline void fast_try0_x2(const FastCells &ca, const FastCells &cb, co
                                     FastBits &oa, FastBits &ob, bool &ok_a, bool &ok_b)
 {
     const int lane = lane_id();
-    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint64_t le = ((1ull << lane) - 1ull) | (1ull << lane);       /* lanes up to and including this one: inclusive prefix counts in one popcount */
     const uint64_t aA_lo = __ballot(ca.p0 > p.ref_low), aB_lo = __ballot(cb.p0 > p.ref_low);
     const uint64_t bA_lo = __ballot(ca.p0 >= p.ref_high), bB_lo = __ballot(cb.p0 >= p.ref_high);
     const uint64_t aA_hi = __ballot(ca.p1 > p.ref_low), aB_hi = __ballot(cb.p1 > p.ref_low);
     const uint64_t bA_hi = __ballot(ca.p1 >= p.ref_high), bB_hi = __ballot(cb.p1 >= p.ref_high);
     const uint64_t eA_lo = ~(aA_lo ^ bA_lo), eB_lo = ~(aB_lo ^ bB_lo), eA_hi = ~(aA_hi ^ bA_hi), eB_hi = ~(aB_hi ^ bB_hi);
     const uint64_t tA_lo = aA_lo & ~bA_lo, tB_lo = aB_lo & ~bB_lo, tA_hi = aA_hi & ~bA_hi, tB_hi = aB_hi & ~bB_hi;
-    const int cA_lo = __popcll(tA_lo & lt) + (int)((tA_lo >> lane) & 1), cB_lo = __popcll(tB_lo & lt) + (int)((tB_lo >> lane) & 1);
-    const int cA_hi = __popcll(tA_lo) + __popcll(tA_hi & lt) + (int)((tA_hi >> lane) & 1);
-    const int cB_hi = __popcll(tB_lo) + __popcll(tB_hi & lt) + (int)((tB_hi >> lane) & 1);
+    const int cA_lo = __popcll(tA_lo & le), cB_lo = __popcll(tB_lo & le);
+    const int cA_hi = __popcll(tA_lo) + __popcll(tA_hi & le);
+    const int cB_hi = __popcll(tB_lo) + __popcll(tB_hi & le);
     const uint64_t ptA_lo = __ballot(cA_lo & 1), ptB_lo = __ballot(cB_lo & 1), ptA_hi = __ballot(cA_hi & 1), ptB_hi = __ballot(cB_hi & 1);
     const uint64_t uA_lo = ((aA_lo & bA_lo) ^ ptA_lo) & eA_lo, uB_lo = ((aB_lo & bB_lo) ^ ptB_lo) & eB_lo;
     const uint64_t uA_hi = ((aA_hi & bA_hi) ^ ptA_hi) & eA_hi, uB_hi = ((aB_hi & bB_hi) ^ ptB_hi) & eB_hi;
