@@ -334,11 +334,14 @@ __device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int l
             good[m] = __ballot(g); brk[m] = __ballot(k);
         }
         int cnt = test - c * 64; if (cnt > 64) cnt = 64;
-        for (int j = 0; j < cnt; j++)
-            for (int m = 0; m < 2; m++) {
-                if ((good[m] >> j) & 1) res[m]++;
-                else if (((brk[m] >> j) & 1) && res[m] > 0) res[m]--;
-            }
+        if ((brk[0] | brk[1]) == 0) {                /* no broken block: the counters only go up (the usual case) */
+            res[0] = (uint16_t)(res[0] + __popcll(good[0])); res[1] = (uint16_t)(res[1] + __popcll(good[1]));
+        } else
+            for (int j = 0; j < cnt; j++)
+                for (int m = 0; m < 2; m++) {
+                    if ((good[m] >> j) & 1) res[m]++;
+                    else if (((brk[m] >> j) & 1) && res[m] > 0) res[m]--;
+                }
     }
     if (res[0] > (ILV * 2)) {
         uint16_t t = (uint16_t)(res[1] * 128);
@@ -639,6 +642,14 @@ struct Step {
             }
             uint64_t mv = __ballot(v), ms = __ballot(sl), mu = __ballot(u), mb = __ballot(br);
             int cnt = nblk - c * 64; if (cnt > 64) cnt = 64;
+            const uint64_t full = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+            if ((ms | mu | mb) == 0 && (mv & full) == full) {        /* a chunk of valid, checked, sounding blocks: the run goes on */
+                valid_cnt = (uint16_t)(valid_cnt + cnt);
+                if (silence_cnt > silence_max) silence_max = silence_cnt;
+                silence_cnt = 0;
+                if (uncheck_cnt > uncheck_max) uncheck_max = uncheck_cnt;
+                uncheck_cnt = 0;
+            } else
             for (int j = 0; j < cnt; j++) {
                 if ((mv >> j) & 1) valid_cnt++; else if (valid_cnt > valid_max) valid_max = valid_cnt;
                 if ((ms >> j) & 1) { silence_cnt++; if (silence_cnt >= MAX_BURST_SILENCE) valid_cnt = 0; }
@@ -1333,6 +1344,8 @@ struct Step {
             const uint64_t m_ns = __ballot(ns), m_seam = __ballot(seam), m_brk = __ballot(brk);
             uint64_t m_cd = 0;
             int cnt = nblk - c * 64; if (cnt > 64) cnt = 64;
+            /* nothing counts down and no broken block starts a countdown in this chunk: nothing to replay (the usual case) */
+            if (!(cd == 0 && (cfg.broken_mask_dur == 0 || (m_brk & m_ns & ~m_seam) == 0)))
             for (int j = 0; j < cnt; j++) {
                 if (((m_ns >> j) & 1) && !((m_seam >> j) & 1)) {
                     if (cfg.broken_mask_dur > 0 && cd == 0 && ((m_brk >> j) & 1)) cd = cfg.broken_mask_dur;
@@ -1351,9 +1364,12 @@ struct Step {
             fix_p += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_P));
             fix_q += (uint32_t)__popcll(__ballot(rep && valid && b.audio_state == SDV_AUD_FIX_Q));
             fix_cwd += (uint32_t)__popcll(__ballot(rep && valid && b.cwd_applied && b.cwd_fixed != 0));
-            drop += (uint32_t)__popcll(__ballot(rep && !valid));
-            brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
-            for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
+            const uint64_t m_drop = __ballot(rep && !valid);
+            if (m_drop) {                                   /* dropped blocks are the exception: their statistics only then */
+                drop += (uint32_t)__popcll(m_drop);
+                brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
+                for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
+            }
             if (act) {
                 sdv_sample_pair *o = out_pairs + n_pairs + 3u * (uint32_t)i;
                 if (n_pairs + 3u * (uint32_t)i + 3u <= pair_cap) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
