@@ -1412,7 +1412,7 @@ __device__ inline void reset_state(Step &s)      /* resetState :69-89 (the stati
 #else
 #define ST_STAMP(i) do { if (a.timing && lane == 0) a.timing[(size_t)k * 8 + (i)] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
 #endif
-__device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot, int lane)
+__device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot, int lane, SLine *q_lds = NULL)
 {
     const uint32_t k = work & 0x3FFFFFFFu;
     const int w_prev = (work >> 30) & 1, w_cur = (work >> 31) & 1;
@@ -1423,7 +1423,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     Step s;
     s.cfg = a.cfg; s.fields = a.fields; s.k = k; s.lane = lane;
     s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2);
-    s.q = a.ws + (size_t)slot * QCAP; s.overflow = false;
+    s.q = q_lds ? q_lds : a.ws + (size_t)slot * QCAP; s.overflow = false;
     s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     const bool direct = a.direct_pairs != NULL;
     s.out_pairs = direct ? a.direct_pairs + (size_t)k * a.guess_pairs : a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
@@ -1613,7 +1613,12 @@ __global__ void __launch_bounds__(64, SDV_ST_WAVES) sdv_k_stitch_step(sdvs::Step
         if (threadIdx.x == 0) w = atomicAdd(a.next_work, 1u);
         w = (uint32_t)__shfl((int)w, 0);
         if (w >= a.n_work) break;
+#if defined(SDV_ST_QUEUE_LDS) && !defined(SDV_EMU)
+        __shared__ sdvs::SLine q_lds[sdvs::QCAP];          /* experiment: conv_queue of the turn in LDS (32 KB per wave) */
+        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x, q_lds);
+#else
         sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x);
+#endif
     }
 }
 __global__ void __launch_bounds__(64) sdv_k_stitch_predict(sdvs::PredictStArgs a) { sdvs::predict_st_body(a, a.first + blockIdx.x, (int)threadIdx.x); }

@@ -1,6 +1,7 @@
 """Profiling driver of the stitch stage: N synthetic NTSC frames -> binarize -> stitch (3 timed calls)."""
-import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from sdvpcmdecoder_amd import Engine, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
