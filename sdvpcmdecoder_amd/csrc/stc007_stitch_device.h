@@ -294,6 +294,7 @@ struct FrameBrief { uint32_t frame_number; uint8_t flags, field_res[2], _pad; };
 struct AnalyzeArgs {
     RecSrc src; const uint32_t *seg_end; uint32_t n_seg;      /* seg_end[k] = index of the k-th END_FRAME record */
     Cfg cfg; FrameLocal *fl; FrameBrief *brief; SLine *fields;
+    unsigned long long *timing;     /* optional: 8 cycle stamps per frame (SDV_STITCH_TIMING=1), NULL otherwise */
 };
 
 __device__ inline uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
@@ -377,9 +378,15 @@ __device__ inline uint32_t rec_meta(const Rec48 &r, uint32_t fnum, bool &bad_num
     return m;
 }
 
+#ifdef SDV_EMU
+#define AN_STAMP(i) ((void)0)
+#else
+#define AN_STAMP(i) do { if (a.timing && lane == 0) a.timing[(size_t)k * 8 + (i)] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+#endif
 template <bool kLds>
 __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, uint32_t *meta)
 {
+    AN_STAMP(0);
     const uint32_t start = k == 0 ? 0u : a.seg_end[k - 1] + 1u, end = a.seg_end[k];      /* [start, end) + END_FRAME at end */
     const uint32_t n = end - start;
     const uint32_t fnum = a.src.at(end).frame_number;
@@ -426,6 +433,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
         }
     }
     __syncthreads();                /* the staged words are read by other lanes from here on */
+    AN_STAMP(1);
     bool skip[2] = { good[0] > MIN_GOOD_LINES_PF, good[1] > MIN_GOOD_LINES_PF };
     /* pass 2 (second loop :480-700): top / bottom data line of each field, in stream order */
     uint16_t top[2] = { 0, 0 }, bottom[2] = { 0, 0 }, max_line = 0;
@@ -454,6 +462,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
         }
     }
     bool trim_ok = have[0] && have[1];
+    AN_STAMP(2);
     /* pass 3 (splitFramesToFields :737-985): the field buffers, valid counts, mean reference level */
     uint32_t cnt[2] = { 0, 0 }, valid[2] = { 0, 0 }, ref_all[2] = { 0, 0 }, ref_ok[2] = { 0, 0 };
     for (uint32_t c = 0; c < n; c += 64) {
@@ -511,6 +520,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
         for (int i = 0; i < 5; i++) fl->ctrl[i] = ctrl[i];
     }
     __syncthreads();            /* the field buffers are read back through processBlock below */
+    AN_STAMP(3);
     uint8_t fres[2];
     for (int p = 0; p < 2; p++) {
         Field f; f.lines = field_lines(a.fields, k, p); f.size = (int)cnt[p];
@@ -521,6 +531,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
         FrameBrief br; br.frame_number = fnum; br.flags = fl->flags; br.field_res[0] = fres[0]; br.field_res[1] = fres[1]; br._pad = 0;
         a.brief[k] = br;
     }
+    AN_STAMP(4);
 }
 } // namespace sdvs
 
