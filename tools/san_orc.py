@@ -1,0 +1,25 @@
+import sys, os
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ctypes as C
+import libs
+libs.load_oracle = lambda: _lib
+_lib = C.CDLL(os.path.join(ROOT, 'build', 'san') + '/liborc.so')
+# bind like libs does
+orig = libs.__dict__
+try:
+    libs._bind_bin_api(_lib, "orc_")
+except Exception as e:
+    print("bind", e)
+import numpy as np
+import pcm1_api as p1, stitch_api as sa, stitch_cases as sc
+from oracle_run import oracle_binarize
+for name in list(p1.CASES):
+    recs, st = p1.make_input(name)
+    p1.run_cpu(_lib, "orc_", recs, st)
+print("pcm1 ok")
+for name in ("ntsc_bad5", "ntsc_burst300", "pal_bad5", "f1_16bit_bad5", "ntsc_ctrlblk", "ntsc_drift", "ntsc_noisy_video"):
+    recs, st = sc.make_input(name, lambda luma: oracle_binarize(luma, mode=2))
+    sa.run_cpu(_lib, "orc_", recs, st)
+print("stitch ok")
