@@ -175,3 +175,29 @@ def test_hip_ragged_geometry(torch_cuda, width, height, pad, shift):
     got = lines.cpu().numpy().view(LINE_DTYPE).reshape(-1)
     assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
     assert stats.cpu().numpy().tobytes() == want_stats.tobytes()
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_hip_dropouts_across_calls(torch_cuda, seed):
+    """Lost lines at random places of a 160-frame tape that arrives in three calls: anchors, given-up frames and the hand-over between
+    calls together reproduce the sequential decode."""
+    from sdvpcmdecoder_amd import Engine
+    rng = np.random.default_rng(seed)
+    n = 160
+    luma, _, _ = synth.stc007_frames(n, seed=seed, noise_sigma=4.0)
+    luma = luma.copy()
+    for f in rng.choice(np.arange(3, n), size=14, replace=False):
+        luma[int(f), rng.integers(20, 460, size=int(rng.integers(1, 4)))] = 16
+    want, want_stats = oracle_binarize(luma, mode=2)
+    eng = Engine(0)
+    eng.setBinarizationMode(2)
+    cuts = [0, int(rng.integers(20, 70)), int(rng.integers(80, 140)), n]
+    got, got_stats = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r, s, _ = gpu_run(torch_cuda, luma[a:b], 2, new_file=(a == 0), first=1 + a, eng=eng)
+        got.append(r)
+        got_stats.append(s)
+    eng.close()
+    got = np.concatenate(got)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert np.concatenate(got_stats).tobytes() == want_stats.tobytes()

@@ -216,3 +216,24 @@ def test_gpu_large_batch_in_pieces():
         got_f.append(f)
     pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_gpu_random_cuts(seed):
+    """A damaged PCM-1 tape with file tags handed over in pieces cut at random record positions equals the oracle's run."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    rng = np.random.default_rng(seed)
+    recs = p1.make_stream(int(rng.integers(40, 90)), seed=seed, p_bad=0.04, header=int(rng.integers(0, 4)), p_picked=0.02, new_file=True, end_file=True)
+    st = p1.default_settings(field_order=int(rng.integers(1, 3)))
+    want_p, want_f = p1.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    eng = Engine(0)
+    cuts = [0] + sorted(int(x) for x in rng.choice(np.arange(1, len(recs)), size=9, replace=False)) + [len(recs)]
+    got_p, got_f = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        p, f = _gpu_run(eng, recs[a:b], st, torch)
+        got_p.append(p.copy())
+        got_f.append(f.copy())
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)

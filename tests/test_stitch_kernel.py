@@ -261,3 +261,39 @@ def test_gpu_full_size_audio_recovery():
     real = fr[fr["service_type"] == 0]
     assert len(real) == n and (real["blocks_drop"][1:-1] == 0).all() and (real["blocks_total"][1:-1] == 490).all()
     assert ((real["flags"][1:-1] & 0x18) == 0x18).all()         # inner and outer padding found (the last frame borders the filler frame)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_gpu_random_cuts_and_two_files(seed):
+    """Two files back to back (NEW_FILE ... END_FILE, NEW_FILE ... END_FILE), a little damage, handed over in pieces cut at random
+    record positions: calls on a playing tape write their pairs straight into the caller's buffer, calls that meet file tags fall
+    back to the packed path - the concatenated output equals the oracle's sequential run whatever the cuts are.  (What shares a
+    call with an END_FILE frame is flushed with it, as the reference flushes its input queue: the files meet at a call boundary.)"""
+    import torch
+    from sdvpcmdecoder_amd import Engine, synth, LINE_DTYPE
+    rng = np.random.default_rng(seed)
+    eng = Engine(0)
+    st = sa.default_settings()
+    eng.set_stitch_settings(_settings(st))
+    eng.reset_stitcher()
+    fno = 1
+    got_p, got_f, want_p, want_f = [], [], [], []
+    for part, nfr in enumerate((int(rng.integers(30, 60)), int(rng.integers(20, 50)))):
+        luma, _ = synth.stc007_frames_torch(nfr, seed=seed * 10 + part, device="cuda", noise_sigma=3.0)
+        eng.reset_stream()
+        lines, _ = eng.binarize_frames(luma, first_frame_no=fno, new_file=True, end_file=True)
+        recs = sc.damage(lines.cpu().numpy().reshape(-1).view(LINE_DTYPE).copy(), seed + part, 0.01, burst=0)
+        fno += nfr + 1
+        wp, wf = sa.run_cpu(libs.load_oracle(), "orc_", recs, st)
+        want_p.append(wp)
+        want_f.append(wf)
+        d = torch.from_numpy(recs.view(np.uint8).reshape(len(recs), 48)).cuda()
+        cuts = [0] + sorted(int(x) for x in rng.choice(np.arange(1, len(recs)), size=5, replace=False)) + [len(recs)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            p, f = eng.stitch_frames(d[a:b].contiguous())
+            got_p.append(p.cpu().numpy().reshape(-1).view(sa.PAIR_DTYPE).copy())
+            got_f.append(f.cpu().numpy().reshape(-1).view(sa.FRASM_DTYPE).copy())
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    want_p, want_f = np.concatenate(want_p), np.concatenate(want_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
