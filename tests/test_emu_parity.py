@@ -155,6 +155,25 @@ def test_emu_misprediction_is_repaired(emu_lib, oracle_lib):
     assert info.rounds >= 3 and info.frames_launched > 6
 
 
+@pytest.mark.parametrize("seed", [61, 62, 63])
+def test_emu_random_dropouts_and_anchors(emu_lib, oracle_lib, seed):
+    """Lost lines and a moving data window at random frames of a 14-frame tape: several links of the chain break in the first round,
+    every one becomes an anchor, given-up frames go to the full kernel together - and the records equal the sequential decode."""
+    rng = np.random.default_rng(seed)
+    n = 14
+    luma, _, _ = synth.stc007_frames(n, seed=seed, height=40, noise_sigma=3.0)
+    luma = luma.copy()
+    for f in rng.choice(np.arange(1, n), size=4, replace=False):
+        luma[int(f), rng.integers(2, 38, size=int(rng.integers(1, 3)))] = 16
+    shift_at = int(rng.integers(4, n - 2))
+    luma[shift_at:] = np.roll(luma[shift_at:], int(rng.integers(3, 9)), axis=2)
+    want, want_stats = oracle_binarize(luma, mode=2)
+    got, got_stats, info = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    assert info.rounds <= 12, info.rounds
+
+
 def test_emu_bad_arguments(emu_lib):
     eng = C.c_void_p(emu_lib.sdv_engine_create(0))
     buf = np.zeros((1, 8, 200), np.uint8)
