@@ -2140,7 +2140,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                         {   /* the queue moves up by NL rows and NL new rows are requested at its end: one pointer step inside the field,
                              * past its end one of the rows looked up per batch */
                             const uint8_t *prev = NR > 1 ? pf.rowq[NR - 2] : pf.row;       /* the last row requested so far */
-                            if (NR > NL) { pf.row = pf.rowq[NL - 1]; pf.v0 = pf.vq[NL - 1]; }
+                            if (NR > NL) { constexpr int q0 = NR > NL ? NL - 1 : 0; pf.row = pf.rowq[q0]; pf.v0 = pf.vq[q0]; }
 #pragma unroll
                             for (int i = 1; i + NL < NR; i++) { pf.rowq[i - 1] = pf.rowq[i - 1 + NL]; pf.vq[i - 1] = pf.vq[i - 1 + NL]; }
 #pragma unroll
