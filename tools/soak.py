@@ -1,0 +1,51 @@
+"""Soak run on the GPU box: random geometries, noise, lost lines, window shifts and call boundaries; every byte of the line records, the
+frame statistics, the sample pairs and the frame descriptors against the CPU oracle.  Not part of the test suite (minutes of oracle time);
+prints one line per case and exits non-zero on the first difference."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ctypes as C
+import numpy as np, torch
+import libs, stitch_api as sa
+from oracle_run import oracle_binarize
+from sdvpcmdecoder_amd import Engine, synth, LINE_DTYPE, StitchSettings
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+orc = libs.load_oracle()
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    n = int(rng.integers(150, 400))
+    height = int(rng.choice([486, 486, 487, 480, 576]))
+    lpf = 294 if height == 576 else 245
+    width = int(rng.choice([720, 720, 704]))
+    sigma = float(rng.choice([0.0, 3.0, 6.0]))
+    luma, _, _ = synth.stc007_frames(n, seed=seed0 + case, width=width, height=height, lines_per_field=lpf, noise_sigma=sigma)
+    luma = luma.copy()
+    for f in rng.choice(np.arange(2, n), size=int(rng.integers(0, 12)), replace=False):
+        luma[int(f), rng.integers(10, height - 10, size=int(rng.integers(1, 4)))] = 16
+    if rng.random() < 0.5:
+        k = int(rng.integers(n // 3, n - 10))
+        luma[k:] = np.roll(luma[k:], int(rng.integers(2, 8)), axis=2)
+    t0 = time.time()
+    want, want_stats = oracle_binarize(luma, mode=2, first_frame_no=1, new_file=True, end_file=True)
+    st = sa.default_settings()
+    want_p, want_f = sa.run_cpu(orc, "orc_", want, st)
+    t_cpu = time.time() - t0
+    eng = Engine(0); eng.setBinarizationMode(2)
+    pst = StitchSettings(); C.memmove(C.byref(pst), C.byref(st), C.sizeof(pst)); eng.set_stitch_settings(pst)
+    cuts = [0] + sorted(int(x) for x in rng.choice(np.arange(5, n - 5), size=int(rng.integers(0, 4)), replace=False)) + [n]
+    recs, stats, pairs, frames, rounds = [], [], [], [], 0
+    d = torch.from_numpy(luma).cuda()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lines, stt = eng.binarize_frames(d[a:b], first_frame_no=1 + a, new_file=(a == 0), end_file=(b == n))
+        rounds += eng.run_info().rounds
+        p, f = eng.stitch_frames(lines)
+        recs.append(lines.cpu().numpy().reshape(-1).view(LINE_DTYPE).copy()); stats.append(stt.cpu().numpy().copy())
+        pairs.append(p.cpu().numpy().copy()); frames.append(f.cpu().numpy().copy())
+    recs = np.concatenate(recs); stats = np.concatenate(stats); pairs = np.concatenate(pairs); frames = np.concatenate(frames)
+    ok = recs.tobytes() == want.tobytes() and stats.tobytes() == want_stats.tobytes() and pairs.tobytes() == want_p.tobytes() and frames.tobytes() == want_f.tobytes()
+    print(f"case {case}: {n} frames {width}x{height} sigma {sigma} calls {len(cuts) - 1} binarize rounds {rounds} pairs {len(want_p)} cpu {t_cpu:.1f}s -> {'OK' if ok else 'MISMATCH'}", flush=True)
+    if not ok:
+        sys.exit(1)
+print("soak ok")
