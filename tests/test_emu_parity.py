@@ -174,6 +174,21 @@ def test_emu_random_dropouts_and_anchors(emu_lib, oracle_lib, seed):
     assert info.rounds <= 12, info.rounds
 
 
+def test_emu_window_jump_settles_in_few_rounds(emu_lib, oracle_lib):
+    """The data window moves in the middle of a 40-frame batch.  Every link behind the jump breaks (the 16-frame coordinate history
+    of the predicted states is the old window's), but only over coordinates: the frames behind the jump are predicted again from the
+    first real state behind it, not settled one per round."""
+    n = 40
+    luma, _, _ = synth.stc007_frames(n, seed=77, height=24, noise_sigma=2.0)
+    luma = luma.copy()
+    luma[9:] = np.roll(luma[9:], 6, axis=2)
+    want, want_stats = oracle_binarize(luma, mode=1)
+    got, got_stats, info = emu_run(emu_lib, luma, 1)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    assert info.rounds <= 10, info.rounds
+
+
 def test_emu_bad_arguments(emu_lib):
     eng = C.c_void_p(emu_lib.sdv_engine_create(0))
     buf = np.zeros((1, 8, 200), np.uint8)
