@@ -359,6 +359,23 @@ int sdv_saturate_stitch_stats(sdv_engine *e);
 int sdv_stitch_frames(sdv_engine *e, const sdv_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                       size_t *n_pairs, sdv_frame_asm *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* ---- PCM-1 front half: one PCM1Line as Binarizer::processLine leaves it (pcm1line.h:59-146, pcmline.h:137-186) --------- */
+/* 40 bytes.  Record of the oracle and of the reference driver today; the engine's PCM-1 binarize
+ * entry will emit the same record. */
+typedef struct sdv_pcm1_bin_rec {
+    uint32_t frame_number;
+    uint16_t line_number;
+    uint16_t words[7];              /* L2 R2 L4 R4 L6 R6 (13 bit) + CRCC as read (or as the Bit Picker completed it) */
+    uint16_t calc_crc;
+    int16_t data_start, data_stop;  /* PCMLine::coords */
+    uint8_t black_level, white_level, ref_low, ref_level, ref_high;
+    uint8_t hysteresis_depth, shift_stage;
+    uint8_t service_type;           /* SDV_SRV_* (SDV_SRV_HEADER_LINE when the header pattern was read) */
+    uint8_t picked_bits_left, picked_bits_right;
+    uint8_t flags;                  /* SDV_LF_* */
+    uint8_t _pad[3];
+} sdv_pcm1_bin_rec;
+
 /* ---- PCM-1 back half: PCM1DataStitcher (pcm1datastitcher.h:94-201) ------------------------------------------------- */
 /* What PCM1DataStitcher reads of one PCM1Line (pcm1line.h:59-146, pcmline.h:137-186).  32 bytes. */
 typedef struct sdv_pcm1_line_rec {

@@ -93,6 +93,59 @@ int orc_bin_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16
     return ret;
 }
 
+/* ------------------------------------------------------------------ PCM-1 front half (bin_pcm1.c) */
+#include "bin_pcm1.h"
+typedef struct { orc_binarizer bin; orc_video_line vl; orc_p1_line out; } orc_bin1_handle;
+
+static void p1_line_to_rec(const orc_p1_line *l, sdv_pcm1_bin_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->frame_number = l->frame_number; r->line_number = l->line_number;
+    for (int i = 0; i < 7; i++) r->words[i] = l->words[i];
+    r->calc_crc = l->calc_crc;
+    r->data_start = l->coords.data_start; r->data_stop = l->coords.data_stop;
+    r->black_level = l->black_level; r->white_level = l->white_level;
+    r->ref_low = l->ref_low; r->ref_level = l->ref_level; r->ref_high = l->ref_high;
+    r->hysteresis_depth = l->hysteresis_depth; r->shift_stage = l->shift_stage;
+    r->service_type = l->service_type;
+    r->picked_bits_left = l->picked_bits_left; r->picked_bits_right = l->picked_bits_right;
+    r->flags = (uint8_t)((l->ref_level_sweeped ? SDV_LF_REF_SWEEPED : 0) | (l->coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) |
+                         (l->data_by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l->blk_wht_set ? SDV_LF_BW_SET : 0) |
+                         (l->coords_set ? SDV_LF_COORDS_SET : 0) | (l->forced_bad ? SDV_LF_FORCED_BAD : 0) |
+                         (orc_p1_crc_valid(l) ? SDV_LF_CRC_VALID : 0) | (l->coords.from_doubled ? SDV_LF_FROM_DOUBLED : 0));
+}
+
+void *orc_bin1_new(void)
+{
+    orc_bin1_handle *h = (orc_bin1_handle *)calloc(1, sizeof(*h));
+    orc_binarizer_init(&h->bin);
+    orc_p1_clear(&h->out);
+    return h;
+}
+void orc_bin1_free(void *h) { free(h); }
+void orc_bin1_set_mode(void *h, int mode) { orc_binarizer_set_mode(&((orc_bin1_handle *)h)->bin, (uint8_t)mode); }
+void orc_bin1_set_coord_search(void *h, int on) { ((orc_bin1_handle *)h)->bin.do_coord_search = on != 0; }
+void orc_bin1_set_preset(void *hh, const sdv_bin_preset *p) { orc_bin_set_preset(hh, p); }      /* the binarizer is the first member of both handles */
+void orc_bin1_reset_good(void *h) { orc_binarizer_set_good_parameters_p1(&((orc_bin1_handle *)h)->bin, NULL); }
+void orc_bin1_set_good_from_last(void *hh) { orc_bin1_handle *h = (orc_bin1_handle *)hh; orc_binarizer_set_good_parameters_p1(&h->bin, &h->out); }
+void orc_bin1_set_state(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); }
+int orc_bin1_scan_done(void *h) { return ((orc_bin1_handle *)h)->bin.p1_scan_done ? 1 : 0; }
+int orc_bin1_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16_t line, int service, int doubled, int empty,
+                     sdv_pcm1_bin_rec *out)
+{
+    orc_bin1_handle *h = (orc_bin1_handle *)hh;
+    h->vl.frame_number = frame; h->vl.line_number = line;
+    h->vl.pixels = px; h->vl.length = (uint16_t)len;
+    h->vl.service_type = (uint8_t)service;
+    h->vl.empty = (service != SDV_SRV_NO) ? true : (empty != 0);
+    h->vl.doubled = (service == SDV_SRV_NO) ? (doubled != 0) : false;
+    h->bin.video_line = &h->vl;
+    h->bin.out_pcm_line = NULL;
+    int ret = orc_binarizer_process_line_p1(&h->bin, &h->out);
+    p1_line_to_rec(&h->out, out);
+    return ret;
+}
+
 /* ------------------------------------------------------------------ VideoToDigital level */
 #include "v2d.h"
 

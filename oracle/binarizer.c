@@ -8,6 +8,7 @@
  *   Binarizer          binarizer.cpp:48-8055 (STC-007 branches only)
  */
 #include "sdv_oracle.h"
+#include "bin_internal.h"
 #include <string.h>
 
 /* ------------------------------------------------------------------ CRC-16 CCITT-FALSE */
@@ -64,7 +65,7 @@ bool orc_coords_lt(const orc_coords *a, const orc_coords *b)   /* :63-98 */
     }
     return false;
 }
-static bool coords_ne(const orc_coords *a, const orc_coords *b)  /* :39-46 */
+bool coords_ne(const orc_coords *a, const orc_coords *b)  /* :39-46 */
 {
     return (a->data_start != b->data_start) || (a->data_stop != b->data_stop) || (a->from_doubled != b->from_doubled);
 }
@@ -266,7 +267,7 @@ void orc_bin_preset_reset(orc_bin_preset *p)    /* binarizer.cpp:48-65 */
     p->en_force_coords = false; p->en_coord_search = true; p->en_first_line_dup = true; p->en_good_no_marker = true;
 }
 
-static void reset_crc_stats(orc_crc_handler *a, uint16_t count, uint8_t *valid_cnt)   /* :1771-1786 */
+void reset_crc_stats(orc_crc_handler *a, uint16_t count, uint8_t *valid_cnt)   /* :1771-1786 */
 {
     for (uint16_t i = 0; i < count; i++) {
         a[i].result = 0; a[i].data_start = a[i].data_stop = 0; a[i].crc = 0; a[i].hyst_dph = a[i].shift_stg = 0x0f;
@@ -334,8 +335,8 @@ void orc_binarizer_set_good_parameters(orc_binarizer *b, const orc_stc_line *l) 
         orc_binarizer_set_bw_levels(b, l->black_level, l->white_level);
     }
 }
-static bool is_ref_level_preset(const orc_binarizer *b) { return b->in_def_reference >= b->digi_set.min_ref_lvl; }  /* :428-438 */
-static bool are_bw_levels_preset(const orc_binarizer *b)   /* :406-425 */
+bool is_ref_level_preset(const orc_binarizer *b) { return b->in_def_reference >= b->digi_set.min_ref_lvl; }  /* :428-438 */
+bool are_bw_levels_preset(const orc_binarizer *b)   /* :406-425 */
 {
     if ((b->in_def_white > b->digi_set.min_white_lvl) && (b->in_def_black < b->digi_set.max_black_lvl)) {
         if (is_ref_level_preset(b))
@@ -346,7 +347,7 @@ static bool are_bw_levels_preset(const orc_binarizer *b)   /* :406-425 */
 }
 
 /* ------------------------------------------------------------------ CRC statistics */
-static void update_crc_stats(orc_crc_handler *a, orc_crc_handler in, uint8_t *valid_cnt)   /* :1789-1826 */
+void update_crc_stats(orc_crc_handler *a, orc_crc_handler in, uint8_t *valid_cnt)   /* :1789-1826 */
 {
     bool found = false;
     if (*valid_cnt >= ORC_MAX_COLL_CRCS) *valid_cnt = ORC_MAX_COLL_CRCS - 1;
@@ -361,7 +362,7 @@ static void update_crc_stats(orc_crc_handler *a, orc_crc_handler in, uint8_t *va
     }
 }
 
-static void find_most_frequent_crc(orc_crc_handler *a, uint8_t *valid_cnt, bool skip_equal)   /* :1829-1928 */
+void find_most_frequent_crc(orc_crc_handler *a, uint8_t *valid_cnt, bool skip_equal)   /* :1829-1928 */
 {
     a[0].result = 0; a[0].data_start = 0; a[0].data_stop = 0; a[0].hyst_dph = 0; a[0].shift_stg = 0;
     if (*valid_cnt >= ORC_MAX_COLL_CRCS) *valid_cnt = ORC_MAX_COLL_CRCS - 1;
@@ -377,7 +378,7 @@ static void find_most_frequent_crc(orc_crc_handler *a, uint8_t *valid_cnt, bool 
     if (a[0].result == 0) *valid_cnt = 0;
 }
 
-static void invalidate_non_frequent_crcs(orc_crc_handler *a, uint8_t low_level, uint8_t high_level, uint8_t valid_cnt, uint16_t target_crc)  /* :1931-1982 */
+void invalidate_non_frequent_crcs(orc_crc_handler *a, uint8_t low_level, uint8_t high_level, uint8_t valid_cnt, uint16_t target_crc)  /* :1931-1982 */
 {
     uint8_t index = high_level;
     while (index >= low_level) {
@@ -388,7 +389,7 @@ static void invalidate_non_frequent_crcs(orc_crc_handler *a, uint8_t low_level, 
     }
 }
 
-static uint8_t pick_level_by_crc_stats(const orc_crc_handler *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+uint8_t pick_level_by_crc_stats(const orc_crc_handler *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
                                        uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :1985-2140 */
 {
     bool good_ref_det = false, range_lock = false, second_start_lock = false;
@@ -500,14 +501,14 @@ static uint8_t pick_level_by_crc_stats_opt(const orc_binarizer *b, const orc_crc
 /* ------------------------------------------------------------------ AGC: BLACK / WHITE */
 #define PIX(b, x) ((b)->video_line->pixels[(x)])
 
-static uint16_t most_frequent_brightness_count(const uint16_t *s)   /* :2450-2468 */
+uint16_t most_frequent_brightness_count(const uint16_t *s)   /* :2450-2468 */
 {
     uint16_t hf = 0;
     for (int lev = 255; lev >= 0; lev--) if (s[lev] > hf) hf = s[lev];
     return hf;
 }
 
-static uint8_t usefull_low_level(const orc_binarizer *b, const uint16_t *s)   /* :2471-2513 */
+uint8_t usefull_low_level(const orc_binarizer *b, const uint16_t *s)   /* :2471-2513 */
 {
     bool filtered_found = false;
     uint8_t brt_lev = 0, lowest_lev = 0;
@@ -524,7 +525,7 @@ static uint8_t usefull_low_level(const orc_binarizer *b, const uint16_t *s)   /*
     return lowest_lev;
 }
 
-static uint8_t usefull_high_level(const orc_binarizer *b, const uint16_t *s)  /* :2516-2557 */
+uint8_t usefull_high_level(const orc_binarizer *b, const uint16_t *s)  /* :2516-2557 */
 {
     bool filtered_found = false;      /* never set in the reference */
     uint8_t brt_lev = 255, highest_lev = 255;
@@ -541,10 +542,10 @@ static uint8_t usefull_high_level(const orc_binarizer *b, const uint16_t *s)  /*
     return highest_lev;
 }
 
-static uint8_t get_low_level(uint8_t in_lvl, uint8_t diff)  { return (in_lvl > diff) ? (uint8_t)(in_lvl - diff) : 1; }          /* :3476-3487 */
-static uint8_t get_high_level(uint8_t in_lvl, uint8_t diff) { return (in_lvl < (255 - diff)) ? (uint8_t)(in_lvl + diff) : 254; } /* :3490-3501 */
+uint8_t get_low_level(uint8_t in_lvl, uint8_t diff)  { return (in_lvl > diff) ? (uint8_t)(in_lvl - diff) : 1; }          /* :3476-3487 */
+uint8_t get_high_level(uint8_t in_lvl, uint8_t diff) { return (in_lvl < (255 - diff)) ? (uint8_t)(in_lvl + diff) : 254; } /* :3490-3501 */
 
-static uint8_t pick_center_ref_level(const orc_binarizer *b, uint8_t lvl_black, uint8_t lvl_white)   /* :3504-3548 */
+uint8_t pick_center_ref_level(const orc_binarizer *b, uint8_t lvl_black, uint8_t lvl_white)   /* :3504-3548 */
 {
     uint8_t br_delta = (uint8_t)(lvl_white - lvl_black), res_lvl;
     if (br_delta >= b->digi_set.min_contrast) {
@@ -912,7 +913,7 @@ static void read_pcm_data(orc_binarizer *b, orc_stc_line *l)   /* :7695-8055 */
 }
 
 /* ------------------------------------------------------------------ reference level sweep */
-static void calc_forced_coords(const orc_binarizer *b, orc_coords *fc)   /* :631-641, :3586-3596, :3853-3863 */
+void calc_forced_coords(const orc_binarizer *b, orc_coords *fc)   /* :631-641, :3586-3596, :3853-3863 */
 {
     orc_coords_clear(fc);
     if (b->digi_set.en_force_coords) {

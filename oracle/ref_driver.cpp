@@ -465,6 +465,88 @@ extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sd
 }
 
 /* ------------------------------------------------------------------ PCM-1 back half: the real PCM1DataStitcher */
+/* ---- PCM-1 front half: the real Binarizer with a PCM1Line as output ------------------------------------------------ */
+struct RefBin1 {
+    Binarizer bin;
+    VideoLine vline;
+    PCM1Line out;
+};
+
+static void p1_line_to_rec(PCM1Line &l, sdv_pcm1_bin_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->frame_number = l.frame_number; r->line_number = l.line_number;
+    for (int i = 0; i < 7; i++) r->words[i] = l.getWord(i);
+    r->calc_crc = l.getCalculatedCRC();
+    r->data_start = l.coords.data_start; r->data_stop = l.coords.data_stop;
+    r->black_level = l.black_level; r->white_level = l.white_level;
+    r->ref_low = l.ref_low; r->ref_level = l.ref_level; r->ref_high = l.ref_high;
+    r->hysteresis_depth = l.hysteresis_depth; r->shift_stage = l.shift_stage;
+    uint8_t st = SDV_SRV_NO;
+    if (l.isServNewFile()) st = SDV_SRV_NEW_FILE; else if (l.isServEndFile()) st = SDV_SRV_END_FILE;
+    else if (l.isServFiller()) st = SDV_SRV_FILLER; else if (l.isServEndField()) st = SDV_SRV_END_FIELD;
+    else if (l.isServEndFrame()) st = SDV_SRV_END_FRAME; else if (l.isServHeader()) st = SDV_SRV_HEADER_LINE;
+    r->service_type = st;
+    r->picked_bits_left = l.picked_bits_left; r->picked_bits_right = l.picked_bits_right;
+    r->flags = (uint8_t)((l.isDataByRefSweep() ? SDV_LF_REF_SWEEPED : 0) | (l.isDataByCoordSweep() ? SDV_LF_COORDS_SWEEPED : 0) |
+                         (l.isDataBySkip() ? SDV_LF_BY_EXT_TUNE : 0) | (l.hasBWSet() ? SDV_LF_BW_SET : 0) |
+                         (l.hasDataCoordSet() ? SDV_LF_COORDS_SET : 0) | (l.isForcedBad() ? SDV_LF_FORCED_BAD : 0) |
+                         (l.isCRCValid() ? SDV_LF_CRC_VALID : 0) | (l.isSourceDoubleWidth() ? SDV_LF_FROM_DOUBLED : 0));
+}
+
+extern "C" {
+void *ref_bin1_new(void) { return new RefBin1(); }
+void ref_bin1_free(void *h) { delete (RefBin1 *)h; }
+void ref_bin1_set_mode(void *h, int mode) { ((RefBin1 *)h)->bin.setMode((uint8_t)mode); }
+void ref_bin1_set_coord_search(void *h, int on) { ((RefBin1 *)h)->bin.setCoordinatesSearch(on != 0); }
+void ref_bin1_set_preset(void *h, const sdv_bin_preset *p)
+{
+    RefBin1 *r = (RefBin1 *)h;
+    bin_preset_t s = r->bin.getDefaultFineSettings();
+    s.max_black_lvl = p->max_black_lvl; s.min_white_lvl = p->min_white_lvl; s.min_contrast = p->min_contrast;
+    s.min_ref_lvl = p->min_ref_lvl; s.max_ref_lvl = p->max_ref_lvl; s.min_valid_crcs = p->min_valid_crcs;
+    s.mark_max_dist = p->mark_max_dist; s.left_bit_pick = p->left_bit_pick; s.right_bit_pick = p->right_bit_pick;
+    s.en_force_coords = p->en_force_coords; s.en_coord_search = p->en_coord_search;
+    s.en_first_line_dup = p->en_first_line_dup; s.en_good_no_marker = p->en_good_no_marker;
+    s.horiz_coords.data_start = p->horiz_start; s.horiz_coords.data_stop = p->horiz_stop;
+    r->bin.setFineSettings(s);
+}
+void ref_bin1_reset_good(void *h) { ((RefBin1 *)h)->bin.setGoodParameters(NULL); }
+void ref_bin1_set_good_from_last(void *h) { RefBin1 *r = (RefBin1 *)h; r->bin.setGoodParameters(&r->out); }
+void ref_bin1_set_state(void *h, const sdv_bin_state *s)
+{
+    RefBin1 *r = (RefBin1 *)h;
+    r->bin.setReferenceLevel(s->in_def_reference);
+    CoordinatePair c;
+    c.data_start = s->in_def_start; c.data_stop = s->in_def_stop; c.from_doubled = s->in_def_from_doubled != 0;
+    r->bin.setDataCoordinates(c);
+    r->bin.setBWLevels(s->in_def_black, s->in_def_white);
+}
+int ref_bin1_scan_done(void *h) { return ((RefBin1 *)h)->vline.scan_done ? 1 : 0; }
+int ref_bin1_process(void *h, const uint8_t *px, int len, uint32_t frame, uint16_t line, int service, int doubled, int empty,
+                     sdv_pcm1_bin_rec *out)
+{
+    RefBin1 *r = (RefBin1 *)h;
+    r->vline.clear();
+    r->vline.frame_number = frame;
+    r->vline.line_number = line;
+    if (service == SDV_SRV_NO) {
+        r->vline.setEmpty(empty != 0);
+        if (!empty) r->vline.pixel_data.assign(px, px + len);
+        r->vline.setDoubleWidth(doubled != 0);
+    } else if (service == SDV_SRV_NEW_FILE) r->vline.setServNewFile("synthetic");
+    else if (service == SDV_SRV_END_FILE) r->vline.setServEndFile();
+    else if (service == SDV_SRV_FILLER) r->vline.setServFiller();
+    else if (service == SDV_SRV_END_FIELD) r->vline.setServEndField();
+    else if (service == SDV_SRV_END_FRAME) r->vline.setServEndFrame();
+    r->bin.setSource(&r->vline);
+    r->bin.setOutput(&r->out);
+    int ret = r->bin.processLine();
+    p1_line_to_rec(r->out, out);
+    return ret;
+}
+} /* extern "C" */
+
 extern "C" uint16_t ref_pcm1_crc(const uint16_t *w6)
 {
     PCM1Line l;

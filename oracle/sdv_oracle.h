@@ -120,6 +120,7 @@ typedef struct {
     uint8_t proc_state, bin_mode, line_part_mode, hysteresis_depth_lim, shift_stages_lim;
     uint16_t line_length, scan_start, scan_end, mark_start_max, mark_end_min, estimated_ppb;
     bool was_BW_scanned;
+    bool p1_scan_done;                  /* VideoLine::scan_done as left by findPCM1Coordinates (binarizer.cpp:5810) */
     orc_crc_handler shift_crcs[ORC_SHIFT_STAGES_MAX + 1];
     /* hyst_crcs is [HYST_DEPTH_MAX+1]; the reference reads one element past it
      * (binarizer.cpp:8005 with hyst_cnt+1) which lands on crc_stats[0] in the class layout

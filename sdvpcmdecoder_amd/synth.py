@@ -55,9 +55,11 @@ def render_lines(bits: np.ndarray, width: int = 720, black: int = 30, white: int
                  x0: int = 12, x1: int | None = None, shift: np.ndarray | None = None,
                  noise_sigma: float = 0.0, rng: np.random.Generator | None = None,
                  blur: int = 0) -> np.ndarray:
-    """Nearest-cell rasterisation of (n, 137) bit cells into (n, width) uint8 luma.
-    Data window [x0, x1); `shift` = per-line horizontal jitter in px; `blur` = box-blur radius."""
+    """Nearest-cell rasterisation of (n, cells) bit cells (137 for STC-007, 94 for PCM-1) into (n, width) uint8 luma.
+    Data window [x0, x1) - it may reach past the picture, the cells out there are cut off; `shift` = per-line horizontal
+    jitter in px; `blur` = box-blur radius."""
     n = bits.shape[0]
+    n_cells = bits.shape[1]
     if x1 is None:
         x1 = width - 12
     span = x1 - x0
@@ -65,9 +67,9 @@ def render_lines(bits: np.ndarray, width: int = 720, black: int = 30, white: int
     if shift is None:
         shift = np.zeros(n, dtype=np.int64)
     xs = x[None, :] - shift[:, None]
-    cell = ((xs - x0) * BITS_IN_LINE) // span
+    cell = ((xs - x0) * n_cells) // span
     inside = (xs >= x0) & (xs < x1)
-    cell = np.clip(cell, 0, BITS_IN_LINE - 1)
+    cell = np.clip(cell, 0, n_cells - 1)
     b = np.take_along_axis(bits, cell, axis=1)
     b = np.where(inside, b, 0)
     img = black + b.astype(np.float32) * (white - black)
@@ -304,6 +306,35 @@ def pcm1_crc_words(words6):
             crc = ((crc << 1) & 0xFFFF) ^ (top * 0x1021)
     return ((~crc) & 0xFFFF).astype(np.uint16)
 
+
+
+def pcm1_line_bits(words7: np.ndarray) -> np.ndarray:
+    """(n, 7) PCM-1 words (6 x 13 bit + CRCC) -> (n, 94) bit cells, MSB first (PCM1Line, pcm1line.h:59-96; no markers)."""
+    w = np.asarray(words7).astype(np.uint32)
+    bits = np.zeros((w.shape[0], 94), dtype=np.uint8)
+    pos = 0
+    for k in range(6):
+        for bit in range(12, -1, -1):
+            bits[:, pos] = (w[:, k] >> bit) & 1
+            pos += 1
+    for bit in range(15, -1, -1):
+        bits[:, pos] = (w[:, 6] >> bit) & 1
+        pos += 1
+    return bits
+
+
+def pcm1_random_lines(n: int, seed: int = 0, width: int = 720, x0: int = 4, x1: int | None = None, header_every: int = 0, **kw):
+    """n independent random PCM-1 video lines.  Returns (luma (n, width) u8, words (n, 7) u16)."""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(0, 1 << 13, size=(n, 6), dtype=np.uint32)
+    if header_every:
+        words[::header_every] = np.array([0x0666, 0x0CCC, 0x1999, 0x1333, 0x0666, 0x0CCC], dtype=np.uint32)
+    crc = pcm1_crc_words(words).astype(np.uint32)
+    if header_every:
+        crc[::header_every] = 0xCCCC
+    w7 = np.concatenate([words, crc[:, None]], axis=1).astype(np.uint16)
+    luma = render_lines(pcm1_line_bits(w7), width=width, x0=x0, x1=(width - 4 if x1 is None else x1), rng=rng, **kw)
+    return luma, w7
 
 
 def pcm1_line_stream(n_frames, seed=0, lines=(245, 245), first=(1, 2), header=0, footer=0, p_bad=0.0, p_nobw=0.0, p_picked=0.0, p_forced=0.0,
