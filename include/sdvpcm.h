@@ -376,6 +376,18 @@ typedef struct sdv_pcm1_bin_rec {
     uint8_t _pad[3];
 } sdv_pcm1_bin_rec;
 
+/* Binarizer::processLine (binarizer.h:361, binarizer.cpp:443-1724) with a PCM1Line as output, for n_lines video lines in one
+ * launch: line i = luma + i*row_stride (width bytes), numbered first_line + i*line_step of frame frame_number.
+ * presets[i] is what the caller had set on its Binarizer before that line (setGoodParameters / setReferenceLevel /
+ * setDataCoordinates / setBWLevels, binarizer.cpp:240-377; all zero or presets == NULL: nothing preset); mode and fine settings are
+ * the engine's (sdv_set_mode, sdv_set_bin_preset), coord_search is Binarizer::setCoordinatesSearch; flags: SDV_FLAG_DOUBLED.
+ * Service lines and empty lines carry no pixels and are the caller's to pass through.  Returns SDV_ERR_SHORT_LINE for lines
+ * under 94 px (LB_RET_SHORT_LINE), SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE (the reference level sweep of PCM-1 is not built).
+ * Device pointers; asynchronous on `stream`. */
+int sdv_pcm1_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_stride, int width, size_t n_lines,
+                            const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
+                            unsigned flags, int coord_search, sdv_pcm1_bin_rec *out_lines, void *stream);
+
 /* ---- PCM-1 back half: PCM1DataStitcher (pcm1datastitcher.h:94-201) ------------------------------------------------- */
 /* What PCM1DataStitcher reads of one PCM1Line (pcm1line.h:59-146, pcmline.h:137-186).  32 bytes. */
 typedef struct sdv_pcm1_line_rec {

@@ -1,0 +1,578 @@
+/*
+ * pcm1_bin_device.h - PCM-1 (Sony Standard B) line binarizer: Binarizer::processLine with a PCM1Line output
+ * (front half), one wavefront per video line.
+ *
+ * Reference: binarizer.cpp:443-1724 (processLine, PCM-1 paths), :2560-2600 (findPCM1BW), :5601-5813 (findPCM1Coordinates),
+ * :4123-4511 (searchPCM1Data), :7016-7131 (fillPCM1), :6116-6596 (pickCutBitsUpPCM1), :7560-7650 (fillDataWords),
+ * :7695-8055 (readPCMdata); pcm1line.cpp, pcmline.cpp for the line object.
+ *
+ * What runs where.  The stage machine, the black/white search and every single read of the line are wave-uniform (all lanes
+ * compute the same values; the histogram is built by all lanes).  The marker-less coordinate search - 25 x 25 candidate
+ * coordinate pairs, each a full readPCMdata with the Bit Picker forced - is spread over the lanes, one candidate per lane at a
+ * time, results in LDS; the vote over them (per left coordinate, then over the left coordinates) is serial on lane 0.
+ * The reference evaluates the candidates one after the other on ONE line object, and two things survive from one candidate to
+ * the next: the forced-bad mark a Bit Picker collision leaves (every later candidate then fails), and - after the search -
+ * whatever the last candidate left in the object.  Both are reproduced: the first collision in search order is found with a wave
+ * minimum, and the last candidate is evaluated once more, wave-uniformly, into the line.
+ *
+ * The 94 cells of a line are kept as one 94-bit number (word k = bits 81-13k .. 93-13k, CRCC = the low 16 bits).
+ * Not implemented: the reference level sweep, which PCM-1 runs in MODE_INSANE only - the host entry refuses that mode.
+ */
+#pragma once
+#include "stc007_device.h"
+
+namespace sdvp1b {
+using namespace sdv;
+typedef unsigned __int128 u128;
+
+enum { P1_BITS = 94, P1_WORD_BITS = 13, P1_CRC_BITS = 16, P1_CRC_SILENT = 0xECBF };
+enum { P1_SEARCH_STEP_DIV = 4, P1_SEARCH_MAX_OFS = 12, P1_SEARCH_STEP_CNT = (P1_SEARCH_MAX_OFS + 1) * 2, P1_GRID = 2 * P1_SEARCH_MAX_OFS + 1 };   /* binarizer.h:254-256 */
+enum { P1_LEFT_BASE = 32 };         /* where the left-coordinate results sit in WaveLds::sweep (the right ones use 0..25) */
+
+struct LineArgs1 {
+    const uint8_t *luma; size_t row_stride; int width; size_t n_lines;
+    const sdv_bin_state *states;    /* what the caller has preset per line (setGoodParameters / setBWLevels ...), or NULL: nothing */
+    uint32_t frame_number; uint16_t first_line, line_step;
+    uint8_t doubled, mode, coord_search;
+    sdv_bin_preset preset;
+    sdv_pcm1_bin_rec *out;
+};
+
+struct P1Lds {
+    WaveLds w;
+    uint32_t grid[P1_GRID * P1_GRID];       /* per candidate: crc | hyst << 16 | shift << 20 | valid << 24 */
+    CrcStat lstats[MAX_COLL_CRCS + 1];      /* scan_left_crcs */
+    int32_t vote[4];                        /* found, data_start, data_stop */
+};
+
+struct L1 {                         /* PCM1Line : PCMLine (pcmline.h:137-166, pcm1line.h:59-110) */
+    uint8_t black, white, ref_low, ref_level, ref_high, hyst, shift;
+    Coords coords;
+    bool coords_sweeped, by_ext_tune, bw_set, coords_set, forced_bad;
+    uint8_t service;
+    uint16_t pixel_start, pixel_stop;
+    int16_t pso; uint32_t psm, hpsm;
+    u128 v;                         /* the 94 cells */
+    uint16_t calc_crc;
+    uint8_t picked_l, picked_r;
+};
+
+__device__ inline u128 word_at(uint16_t w, int k) { return (u128)(w & 0x1FFF) << (81 - 13 * k); }
+__device__ inline uint16_t get_word(const L1 &l, int k) { return k == 6 ? (uint16_t)(l.v & 0xFFFF) : (uint16_t)((l.v >> (81 - 13 * k)) & 0x1FFF); }
+__device__ inline void set_word0(L1 &l, uint16_t w) { l.v = (l.v & ~word_at(0x1FFF, 0)) | word_at(w, 0); }                       /* PCM1Line::setWord(WORD_L2) */
+__device__ inline void set_crcc(L1 &l, uint16_t w) { l.v = (l.v & ~(u128)0xFFFF) | (u128)w; }                                   /* PCM1Line::setWord(WORD_CRCC) */
+
+/* PCM1Line::calcCRC (pcm1line.cpp:158-171): CRC-16/CCITT over the 78 inverted data cells, result inverted */
+__device__ inline void calc_crc(L1 &l)
+{
+    uint32_t crc = 0xFFFF;
+    for (int i = 0; i < 78; i++) {
+        uint32_t bit = (uint32_t)(~(l.v >> (93 - i)) & 1);
+        uint32_t top = ((crc >> 15) & 1) ^ bit;
+        crc = ((crc << 1) & 0xFFFF) ^ (top ? 0x1021u : 0u);
+    }
+    l.calc_crc = (uint16_t)(~crc & 0xFFFF);
+}
+__device__ inline bool has_header(const L1 &l)     /* pcm1line.cpp:314-323 */
+{
+    const u128 hdr = word_at(0x0666, 0) | word_at(0x0CCC, 1) | word_at(0x1999, 2) | word_at(0x1333, 3) | word_at(0x0666, 4) | word_at(0x0CCC, 5) | (u128)0xCCCC;
+    return l.v == hdr;
+}
+__device__ inline bool crc_valid_ignore_forced(const L1 &l) { return l.calc_crc == (uint16_t)(l.v & 0xFFFF) || has_header(l); }
+__device__ inline bool crc_valid(const L1 &l) { return !l.forced_bad && crc_valid_ignore_forced(l); }
+__device__ inline void set_invalid_crc(L1 &l) { set_crcc(l, (uint16_t)~l.calc_crc); }
+__device__ inline void set_silent(L1 &l)
+{
+    l.v = (l.v & (u128)0xFFFF) | word_at(0x1000, 0) | word_at(0x1000, 1) | word_at(0x1000, 2) | word_at(0x1000, 3) | word_at(0x1000, 4) | word_at(0x1000, 5);
+    calc_crc(l);
+}
+__device__ inline void base_clear(L1 &l)           /* PCMLine::clear, pcmline.cpp:96-116 */
+{
+    l.black = l.white = l.ref_low = l.ref_level = l.ref_high = 0;
+    coords_clear(l.coords);
+    l.hyst = l.shift = 0;
+    l.coords_sweeped = l.by_ext_tune = false;
+    l.calc_crc = 0;
+    l.bw_set = l.coords_set = l.forced_bad = false;
+    l.service = SDV_SRV_NO;
+    l.pixel_start = 0; l.pixel_stop = 1; l.pso = 0; l.psm = 128; l.hpsm = 64;
+}
+__device__ inline void p1_clear(L1 &l)             /* PCM1Line::clear, pcm1line.cpp:57-77 */
+{
+    base_clear(l);
+    l.picked_l = l.picked_r = 0;
+    l.v = 0;
+    set_silent(l);
+    l.calc_crc = P1_CRC_SILENT;
+    set_invalid_crc(l);
+}
+__device__ inline void set_ppb(L1 &l, const Coords &c)     /* pcmline.cpp:506-519 with 94 cells between the coordinates */
+{
+    l.psm = (uint32_t)((int)c.stop - (int)c.start);
+    l.psm = (l.psm * 128u + P1_BITS / 2) / P1_BITS;
+    l.pso = c.start;
+    l.hpsm = (l.psm + 1) / 2;
+}
+__device__ inline uint8_t get_ppb(const L1 &l) { return (uint8_t)(l.psm / 128u); }
+/* getVideoPixeBylCalc (pcmline.cpp:249-311): both shift tables are {0, +1, -1, +2, -2}, so the shift is uniform along the line */
+__device__ inline int pixel_of(const L1 &l, int bit, int stage)
+{
+    int32_t vp = (int32_t)((uint32_t)bit * l.psm + l.hpsm);
+    vp = vp / 128 + l.pso;
+    const int sh = stage == 0 ? 0 : (stage == 1 ? 1 : (stage == 2 ? -1 : (stage == 3 ? 2 : -2)));
+    vp += sh;
+    if (vp < (int32_t)l.pixel_start) vp = l.pixel_start;
+    else if (vp >= (int32_t)l.pixel_stop) vp = (int32_t)l.pixel_stop - 1;
+    return vp;
+}
+
+/* fillPCM1 (binarizer.cpp:7016-7131): the two-level automaton over the 94 cell centres */
+__device__ inline void fill_pcm1(L1 &l, const WaveLds &lds, int stage)
+{
+    bool prev_high = false;
+    u128 v = 0;
+    for (int bit = 0; bit < P1_BITS; bit++) {
+        const uint8_t px = lds.px[pixel_of(l, bit, stage)];
+        bool one;
+        if (!prev_high) { one = px > l.ref_low; prev_high = one; }
+        else { one = px >= l.ref_high; prev_high = one; }
+        v = (v << 1) | (u128)(one ? 1 : 0);
+    }
+    l.v = v;
+    calc_crc(l);
+}
+
+struct BinCtx { sdv_bin_preset ps; uint8_t mode; uint16_t scan_start, scan_end; bool force_bit_picker; };
+
+/* pickCutBitsUpPCM1 (binarizer.cpp:6116-6596) */
+__device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
+{
+    bool patch_found = false, coll_lock = false;
+    int left_bits = 0, right_bits = 0;
+    l.picked_l = l.picked_r = 0;
+    int max_cut = c.ps.left_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+    int first = c.scan_start;
+    const int half_ppb = ((int)get_ppb(l) + 1) / 2;
+    for (int i = 0; i < max_cut; i++) {
+        const int cur = pixel_of(l, i, 0);
+        if ((cur - first) >= half_ppb) break;
+        if (i == 0) first = cur;
+        left_bits = i + 1;
+    }
+    first = c.scan_end;
+    max_cut = c.ps.right_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+    for (int i = 0; i < max_cut; i++) {
+        const int cur = pixel_of(l, P1_BITS - 1 - i, 0);
+        if ((first - cur) >= half_ppb) break;
+        if (i == 0) first = cur;
+        right_bits = i + 1;
+    }
+    if (c.force_bit_picker && crc_valid(l)) { l.picked_l = (uint8_t)left_bits; l.picked_r = (uint8_t)right_bits; return; }
+    if (left_bits == 0 && right_bits == 0) return;
+    const uint32_t left_lim = left_bits ? (1u << left_bits) : 1u, right_lim = right_bits ? (1u << right_bits) : 1u;
+    const uint16_t left_orig = get_word(l, 0), right_orig = get_word(l, 6);
+    const uint16_t left_clean = left_bits ? (uint16_t)(left_orig & (uint16_t)~((left_lim - 1) << (P1_WORD_BITS - left_bits))) : left_orig;
+    const uint16_t right_clean = right_bits ? (uint16_t)(right_orig & (uint16_t)~(right_lim - 1)) : right_orig;
+    uint16_t left_fix = 0, right_fix = 0;
+    /* every value of the cut-off bits; exactly one may give a valid CRC.  With only one side cut the other loop runs once and
+     * leaves its word alone, which is the reference's single-sided loop (:6418-6583) */
+    for (uint32_t li = 0; li < left_lim && !coll_lock; li++) {
+        for (uint32_t ri = 0; ri < right_lim; ri++) {
+            const uint16_t lp = left_bits ? (uint16_t)(li << (P1_WORD_BITS - left_bits)) : 0, rp = (uint16_t)ri;
+            if (left_bits) set_word0(l, (uint16_t)(left_clean | lp));
+            if (right_bits) set_crcc(l, (uint16_t)(right_clean | rp));
+            calc_crc(l);
+            if (crc_valid(l)) {
+                if (patch_found) { coll_lock = true; break; }
+                patch_found = true; left_fix = lp; right_fix = rp;
+            }
+        }
+    }
+    if (coll_lock || !patch_found) {
+        if (left_bits) set_word0(l, left_orig);
+        if (right_bits) set_crcc(l, right_orig);
+        calc_crc(l);
+        if (coll_lock) l.forced_bad = true;
+        return;
+    }
+    if (left_bits) set_word0(l, (uint16_t)(left_clean | left_fix));
+    if (right_bits) set_crcc(l, (uint16_t)(right_clean | right_fix));
+    calc_crc(l);
+    l.picked_l = (uint8_t)left_bits; l.picked_r = (uint8_t)right_bits;
+}
+
+/* fillDataWords (binarizer.cpp:7560-7650); false = the levels clip (STG_NO_GOOD) */
+__device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &lds, uint8_t ref_delta, uint8_t shift_stg)
+{
+    if (ref_delta > HYST_DEPTH_MAX || shift_stg > SHIFT_STAGES_MAX) return false;
+    const uint8_t low_ref = get_low_level(l.ref_level, ref_delta), high_ref = get_high_level(l.ref_level, ref_delta);
+    l.ref_low = low_ref; l.ref_high = high_ref;
+    if (low_ref <= l.black) { set_invalid_crc(l); return false; }
+    if (high_ref >= l.white) { set_invalid_crc(l); return false; }
+    l.hyst = ref_delta; l.shift = shift_stg;
+    fill_pcm1(l, lds, shift_stg);
+    if ((!crc_valid(l) && (l.ref_level > c.ps.min_white_lvl) && ((c.ps.left_bit_pick != 0) || (c.ps.right_bit_pick != 0))) || c.force_bit_picker)
+        pick_cut_bits(c, l);
+    return true;
+}
+
+/* readPCMdata (binarizer.cpp:7695-8055) for a line whose reference level was not swept: hysteresis depths from 0 up, pixel shift
+ * stages from 0 up, the first combination with a valid CRC wins (both loops of the reference stop at the first valid CRC, so its
+ * two votes are over one entry each); none: depth 0, stage 0.  Then the final fill. */
+__device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const WaveLds &lds, uint8_t hyst_lim, uint8_t shift_lim)
+{
+    set_ppb(l, l.coords);
+    if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
+    if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
+    uint8_t valid_delta = 0, valid_shift = 0;
+    bool found = false;
+    for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
+        bool invalid_hyst = false;
+        for (uint8_t s = 0; s <= shift_lim; s++) {
+            if (!fill_data_words(c, l, lds, h, s)) { invalid_hyst = true; break; }
+            if (crc_valid(l)) { found = true; valid_delta = h; valid_shift = s; break; }
+        }
+        if (invalid_hyst) break;
+    }
+    fill_data_words(c, l, lds, valid_delta, valid_shift);
+}
+
+__device__ inline void stats_reset(CrcStat *a, int count) { for (int i = 0; i < count; i++) { a[i].result = 0; a[i].crc = 0; a[i].hyst = a[i].shift = 0x0f; a[i].idx = 0; } }
+__device__ inline void stats_update(CrcStat *a, uint16_t crc, uint8_t hyst, uint8_t shift, uint8_t &valid_cnt)   /* :1789-1826 */
+{
+    bool found = false;
+    if (valid_cnt >= MAX_COLL_CRCS) valid_cnt = MAX_COLL_CRCS - 1;
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[i].crc == crc) { a[i].result++; found = true; break; }
+    if (!found) {
+        valid_cnt++;
+        if (valid_cnt < MAX_COLL_CRCS) { a[valid_cnt].crc = crc; a[valid_cnt].hyst = hyst; a[valid_cnt].shift = shift; a[valid_cnt].result++; }
+    }
+}
+__device__ inline void stats_most_frequent(CrcStat *a, uint8_t &valid_cnt)     /* :1829-1928, skip_equal */
+{
+    a[0].result = 0; a[0].idx = 0; a[0].hyst = 0; a[0].shift = 0;
+    if (valid_cnt >= MAX_COLL_CRCS) valid_cnt = MAX_COLL_CRCS - 1;
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[i].result > a[0].result) { a[0].result = a[i].result; a[0].crc = a[i].crc; a[0].hyst = a[i].hyst; a[0].shift = a[i].shift; a[0].idx = i; }
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[0].idx != i)
+            if ((int)a[0].result <= (2 * (int)a[i].result)) { a[0].result = 0; a[0].hyst = 0; a[0].shift = 0; break; }
+    if (a[0].result == 0) valid_cnt = 0;
+}
+__device__ inline SweepEnt sweep_blank() { SweepEnt z; z.result = 0; z.hyst = z.shift = 0x0f; z.pad = 0; z.crc = 0; z.start = z.stop = 0; z.pad2 = 0; return z; }
+
+/* searchPCM1Data (binarizer.cpp:4123-4511).  Returns true when coordinates were found; l is left as the reference leaves its
+ * line object (the last candidate's read, the coordinates found or the starting ones). */
+__device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords data_loc, uint8_t &hyst_lim, uint8_t &shift_lim)
+{
+    const int lane = lane_id();
+    int scan_step = 1, l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+    for (int guard = 2; guard > 0; guard--) {
+        set_ppb(l, data_loc);
+        scan_step = get_ppb(l);
+        scan_step = scan_step >= P1_SEARCH_STEP_DIV ? scan_step / P1_SEARCH_STEP_DIV : 1;
+        const int span = (uint16_t)(scan_step * P1_SEARCH_MAX_OFS);
+        l0 = (int16_t)(data_loc.start - span); l1 = (int16_t)(data_loc.start + span);
+        r0 = (int16_t)(data_loc.stop - span); r1 = (int16_t)(data_loc.stop + span);
+        const int ss = c.scan_start, se = c.scan_end;
+        if ((l0 < ss && l1 < ss) || (l0 > ss && l1 > ss) || (r0 < se && r1 < se) || (r0 > se && r1 > se)) { data_loc.start = (int16_t)ss; data_loc.stop = (int16_t)se; }
+        else break;
+    }
+    const bool bitpick_previous = c.force_bit_picker;
+    c.force_bit_picker = true;
+    hyst_lim = 0;
+    shift_lim = (c.mode == SDV_MODE_DRAFT || c.mode == SDV_MODE_FAST) ? 0 : SHIFT_STAGES_SAFE;
+    /* the reference's loops run while the offsets stay inside [l0, l1] / [r0, r1]: 25 steps each unless the step does not divide
+     * the span (it does: span = 12 steps) */
+    const int n_left = (l1 - l0) / scan_step + 1, n_right = (r1 - r0) / scan_step + 1;
+    const int nl = n_left < P1_SEARCH_STEP_CNT ? n_left : P1_SEARCH_STEP_CNT, nr = n_right < P1_SEARCH_STEP_CNT ? n_right : P1_SEARCH_STEP_CNT;
+    const int n_cand = nl * nr;
+    const bool entry_forced = l.forced_bad;
+    uint32_t first_coll = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int q = lane; q < n_cand; q += 64) {
+        const int row = q / nr, col = q - row * nr;
+        L1 t = l;
+        coords_set(t.coords, (int16_t)(l0 + row * scan_step), (int16_t)(r1 - col * scan_step));
+        read_pcm_data(c, t, lds.w, hyst_lim, shift_lim);
+        uint8_t hy = t.hyst;
+        if (t.picked_l != 0 && t.picked_r != 0) hy = 0x0E; else if (t.picked_r != 0) hy = 0x0D; else if (t.picked_l != 0) hy = 0x0C;
+        lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24);
+        if (t.forced_bad && !entry_forced && first_coll == 0xFFFFFFFFu) first_coll = (uint32_t)q;
+    }
+    first_coll = wave_min_u32(first_coll);
+    __syncthreads();
+    /* the vote: serial, on lane 0 */
+    if (lane == 0) {
+        uint8_t valid_left = 0, left_ofs = 0xFF;
+        stats_reset(lds.lstats, MAX_COLL_CRCS);
+        for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) lds.w.sweep[P1_LEFT_BASE + i] = sweep_blank();
+        for (int row = 0; row < nl; row++) {
+            uint8_t valid_right = 0, right_ofs = 0xFF;
+            for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) lds.w.sweep[i] = sweep_blank();
+            stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
+            for (int col = 0; col < nr; col++) {
+                const int q = row * nr + col;
+                const uint32_t g = lds.grid[q];
+                SweepEnt e = sweep_blank();
+                e.crc = (uint16_t)(g & 0xFFFF); e.hyst = (uint8_t)((g >> 16) & 0xF); e.shift = (uint8_t)((g >> 20) & 0xF);
+                e.start = (int16_t)(l0 + row * scan_step); e.stop = (int16_t)(r1 - col * scan_step);
+                /* behind the first Bit Picker collision the line object is forced bad: nothing reads valid any more */
+                const bool valid = ((g >> 24) & 1) != 0 && (uint32_t)q < first_coll;
+                e.result = valid ? REF_CRC_OK : REF_BAD_CRC;
+                lds.w.sweep[col] = e;
+                if (valid) stats_update(lds.w.crc_stats, e.crc, e.hyst, e.shift, valid_right);
+            }
+            if (valid_right > 0) {
+                stats_most_frequent(lds.w.crc_stats, valid_right);
+                sweep_invalidate_non_frequent(lds.w, 0, P1_SEARCH_STEP_CNT - 1, valid_right, lds.w.crc_stats[0].crc);
+                if (valid_right > 0)
+                    if (pick_level_by_crc_stats(lds.w, &right_ofs, 0, P1_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_right = 0;
+            }
+            SweepEnt le = sweep_blank();
+            if (valid_right > 0) {
+                le = lds.w.sweep[right_ofs];
+                le.result = REF_CRC_OK;
+                const CrcStat top = lds.w.crc_stats[0];
+                for (uint8_t k = 0; k < top.result; k++) stats_update(lds.lstats, top.crc, top.hyst, top.shift, valid_left);
+            } else { le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX; }
+            lds.w.sweep[P1_LEFT_BASE + row] = le;
+        }
+        if (valid_left > 0) {
+            stats_most_frequent(lds.lstats, valid_left);
+            sweep_invalidate_non_frequent(lds.w, P1_LEFT_BASE, P1_LEFT_BASE + P1_SEARCH_STEP_CNT - 1, valid_left, lds.lstats[0].crc);
+            if (valid_left > 0)
+                if (pick_level_by_crc_stats(lds.w, &left_ofs, P1_LEFT_BASE, P1_LEFT_BASE + P1_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
+        }
+        lds.vote[0] = valid_left > 0 ? 1 : 0;
+        if (valid_left > 0) { lds.vote[1] = lds.w.sweep[left_ofs].start; lds.vote[2] = lds.w.sweep[left_ofs].stop; }
+    }
+    __syncthreads();
+    const bool found = lds.vote[0] != 0;
+    const int f_start = lds.vote[1], f_stop = lds.vote[2];
+    __syncthreads();
+    /* what the last candidate leaves in the line object, forced bad if a collision happened on the way */
+    if (n_cand > 0) {
+        if (first_coll != 0xFFFFFFFFu && first_coll < (uint32_t)(n_cand - 1)) l.forced_bad = true;
+        coords_set(l.coords, (int16_t)(l0 + (nl - 1) * scan_step), (int16_t)(r1 - (nr - 1) * scan_step));
+        read_pcm_data(c, l, lds.w, hyst_lim, shift_lim);
+    }
+    c.force_bit_picker = bitpick_previous;
+    if (found) {
+        l.coords.start = (int16_t)f_start; l.coords.stop = (int16_t)f_stop;
+        l.coords_set = true; l.coords_sweeped = true;
+        return true;
+    }
+    l.coords = data_loc;
+    l.coords_sweeped = false;
+    return false;
+}
+
+/* findPCM1Coordinates (binarizer.cpp:5601-5813) */
+__device__ inline void find_pcm1_coordinates(BinCtx &c, L1 &l, P1Lds &lds, const Coords &history, uint8_t &hyst_lim, uint8_t &shift_lim)
+{
+    Coords dc; coords_clear(dc);
+    const int ss = c.scan_start, se = c.scan_end;
+    const int margin = (uint16_t)(se - ss) / 16;
+    if (coords_valid(history)) dc = history;
+    else {
+        dc.start = (int16_t)ss;
+        bool state = lds.w.px[ss] > l.ref_level;
+        for (int p = ss; p < ss + margin; p++) {
+            if (!state) { if (lds.w.px[p] > l.ref_level) { dc.start = (int16_t)(p - 1); break; } }
+            else { if (lds.w.px[p] < l.ref_level) { dc.start = (int16_t)(p - 1); break; } }
+        }
+        dc.stop = (int16_t)se;
+        state = lds.w.px[se] > l.ref_level;
+        for (int p = se; p > se - margin; p--) {
+            if (!state) { if (lds.w.px[p] > l.ref_level) { dc.stop = (int16_t)(p + 1); break; } }
+            else { if (lds.w.px[p] < l.ref_level) { dc.stop = (int16_t)(p + 1); break; } }
+        }
+    }
+    const uint8_t in_hyst = hyst_lim, in_shift = shift_lim;
+    search_pcm1_data(c, l, lds, dc, hyst_lim, shift_lim);
+    hyst_lim = in_hyst; shift_lim = in_shift;
+}
+
+/* findBlackWhite (binarizer.cpp:3116-3473) over the PCM-1 part of the line (findPCM1BW, :2560-2600) */
+__device__ inline bool find_black_white_p1(const BinCtx &c, WaveLds &lds, L1 &line, bool &was_bw_scanned)
+{
+    uint16_t pixel_limit = (uint16_t)(c.scan_end - c.scan_start);
+    const uint16_t search_end = (uint16_t)(c.scan_end - (uint16_t)(pixel_limit / 32));
+    pixel_limit = (uint16_t)(c.scan_start + (uint16_t)(pixel_limit / 8));
+    hist_clear(lds);
+    hist_add_range(lds, pixel_limit, search_end);
+
+    uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
+    uint32_t black_lvl_count, white_lvl_count, temp_calc;
+    uint16_t search_lim;
+    bool black_level_detected, white_level_detected;
+    useful_low = low_scan_limit = br_black = usefull_low_level(c.ps, lds);
+    useful_high = high_scan_limit = br_white = usefull_high_level(c.ps, lds);
+    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
+    low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
+    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
+    temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
+    temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
+    search_lim = most_frequent_brightness_count(lds);
+    search_lim = search_lim / 64;
+    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
+    while (brt_lev <= low_scan_limit) {
+        if (lds.hist[brt_lev] > black_lvl_count) {
+            black_lvl_count = lds.hist[brt_lev];
+            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
+        }
+        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
+        brt_lev++;
+    }
+    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
+    if (black_level_detected) {
+        while (brt_lev >= high_scan_limit) {
+            if ((int)brt_lev < ((int)br_black + (int)c.ps.min_contrast)) break;
+            if (lds.hist[brt_lev] > white_lvl_count) {
+                white_lvl_count = lds.hist[brt_lev];
+                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
+            }
+            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
+            brt_lev--;
+        }
+    }
+    if (black_level_detected && white_level_detected) {
+        bool invalidate = false;
+        if (br_white < br_black) invalidate = true;
+        else if (((int)br_white - (int)br_black) < (int)c.ps.min_contrast) invalidate = true;
+        else if (br_black > c.ps.max_black_lvl) invalidate = true;          /* do_ref_lvl_sweep is never set on this path */
+        else if (br_white < c.ps.min_white_lvl) invalidate = true;
+        if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
+    }
+    was_bw_scanned = true;
+    line.black = br_black; line.white = br_white;
+    line.bw_set = black_level_detected && white_level_detected;
+    return line.bw_set;
+}
+
+__device__ inline void set_service(L1 &l, uint8_t srv) { base_clear(l); l.service = srv; }      /* PCMLine::setServiceLine: base clear() only */
+
+__device__ inline void emit_rec(const L1 &l, uint32_t frame, uint16_t line_no, bool from_doubled, sdv_pcm1_bin_rec *dst)
+{
+    if (lane_id() != 0) return;
+    sdv_pcm1_bin_rec r;
+    r.frame_number = frame; r.line_number = line_no;
+    for (int k = 0; k < 7; k++) r.words[k] = get_word(l, k);
+    r.calc_crc = l.calc_crc;
+    r.data_start = l.coords.start; r.data_stop = l.coords.stop;
+    r.black_level = l.black; r.white_level = l.white; r.ref_low = l.ref_low; r.ref_level = l.ref_level; r.ref_high = l.ref_high;
+    r.hysteresis_depth = l.hyst; r.shift_stage = l.shift; r.service_type = l.service;
+    r.picked_bits_left = l.picked_l; r.picked_bits_right = l.picked_r;
+    r.flags = (uint8_t)((l.coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) | (l.by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l.bw_set ? SDV_LF_BW_SET : 0) |
+                        (l.coords_set ? SDV_LF_COORDS_SET : 0) | (l.forced_bad ? SDV_LF_FORCED_BAD : 0) | (crc_valid(l) ? SDV_LF_CRC_VALID : 0) |
+                        (from_doubled ? SDV_LF_FROM_DOUBLED : 0));
+    r._pad[0] = r._pad[1] = r._pad[2] = 0;
+    *dst = r;
+}
+
+/* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, a line with pixels (service lines and empty lines are the
+ * caller's: they carry no pixels and are not sent to the device) */
+__device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
+{
+    const int lane = lane_id();
+    const uint8_t *row = a.luma + li * a.row_stride;
+    __syncthreads();
+    for (int p = lane; p < a.width; p += 64) lds.w.px[p] = row[p];
+    __syncthreads();
+
+    BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
+    c.force_bit_picker = true;      /* the Binarizer is constructed with it set (binarizer.cpp:82) and nothing clears it */
+    Bin b;                          /* the presets, in the form the shared helpers take */
+    b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
+    if (a.states) {
+        const sdv_bin_state s = a.states[li];
+        b.in_black = s.in_def_black; b.in_white = s.in_def_white; b.in_ref = s.in_def_reference;
+        b.in_coord.start = s.in_def_start; b.in_coord.stop = s.in_def_stop; b.in_coord.doubled = s.in_def_from_doubled != 0;
+    }
+    bin_set_mode(b, a.mode);
+    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0; b.do_ref_lvl_sweep = false;
+    L1 out; p1_clear(out);
+    out.coords.doubled = a.doubled != 0;
+    if (c.scan_end > c.scan_start && P1_BITS <= (c.scan_end - c.scan_start)) { out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end; }   /* setSourcePixels */
+    coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+    Coords forced; calc_forced_coords(b, c.ps, forced);
+    if (c.ps.en_force_coords && coords_valid(forced)) { out.coords = forced; out.coords_set = true; }
+    uint8_t state = STG_REF_FIND;
+    bool was_bw_scanned = false;
+    if (are_bw_levels_preset(b, c.ps)) { out.black = b.in_black; out.white = b.in_white; out.bw_set = true; }
+    if (is_ref_level_preset(b, c.ps)) state = coords_valid(b.in_coord) ? STG_INPUT_ALL : STG_INPUT_LEVEL;
+    uint8_t hyst_lim = b.in_max_hyst, shift_lim = b.in_max_shift;
+
+    for (int stage_count = 1; ; stage_count++) {
+        if (state == STG_INPUT_ALL) {                           /* :774-931 */
+            if (!out.bw_set) find_black_white_p1(c, lds.w, out, was_bw_scanned);
+            if (!coords_valid(forced)) out.coords = b.in_coord;
+            out.ref_level = b.in_ref;
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else if (b.in_ref >= out.white || b.in_ref <= out.black) state = STG_REF_FIND;
+            else {
+                read_pcm_data(c, out, lds.w, hyst_lim, shift_lim);
+                if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; } else state = STG_REF_FIND;
+            }
+        } else if (state == STG_INPUT_LEVEL) {                  /* :932-1072 */
+            if (!was_bw_scanned) find_black_white_p1(c, lds.w, out, was_bw_scanned);
+            if (!coords_valid(forced)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+            out.ref_level = b.in_ref;
+            state = out.bw_set ? STG_REF_FIND : STG_NO_GOOD;
+        } else if (state == STG_REF_FIND) {                     /* :1073-1390 */
+            if (!was_bw_scanned) find_black_white_p1(c, lds.w, out, was_bw_scanned);
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else {
+                hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN;
+                state = STG_READ_PCM;
+                out.ref_level = pick_center_ref_level(c.ps, out.black, out.white);
+                if (coords_valid(forced)) { out.coords = forced; out.coords_set = true; }
+                else {
+                    if (!coords_valid(b.in_coord)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+                    else out.coords = b.in_coord;
+                    if (c.ps.en_coord_search && a.coord_search) find_pcm1_coordinates(c, out, lds, b.in_coord, hyst_lim, shift_lim);
+                }
+                if (!out.coords_set) { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN; }
+                else { hyst_lim = b.in_max_hyst; shift_lim = b.in_max_shift; }
+            }
+        } else if (state == STG_READ_PCM) {                     /* :1401-1533 */
+            if (coords_valid(forced)) { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN; }
+            if (out.coords_set) read_pcm_data(c, out, lds.w, hyst_lim, shift_lim);
+            if (crc_valid(out)) state = STG_DATA_OK;
+            if (state != STG_DATA_OK) {
+                if (coords_valid(b.in_coord) && !coords_valid(forced) && !out.forced_bad && !out.coords_set) {
+                    if (coords_ne(out.coords, b.in_coord)) {
+                        out.coords = b.in_coord;
+                        read_pcm_data(c, out, lds.w, hyst_lim, shift_lim);
+                        if (crc_valid(out)) state = STG_DATA_OK;
+                    }
+                }
+                if (state != STG_DATA_OK) state = STG_NO_GOOD;
+            }
+        } else if (state == STG_DATA_OK) {                      /* :1534-1621 */
+            if (out.forced_bad) state = STG_NO_GOOD;
+            else {
+                if (has_header(out)) set_service(out, SDV_SRV_HEADER_LINE);
+                break;
+            }
+        } else {                                                /* STG_NO_GOOD, :1622-1669 */
+            if (crc_valid(out)) set_invalid_crc(out);
+            break;
+        }
+        if (stage_count > STG_MAX) break;
+    }
+    emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[li]);
+}
+
+} // namespace sdvp1b
+
+#ifndef SDV_P1B_WAVES_PER_EU
+#define SDV_P1B_WAVES_PER_EU 4
+#endif
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_lines(sdvp1b::LineArgs1 a)
+{
+    __shared__ sdvp1b::P1Lds lds;
+    sdvp1b::line_body(a, lds, (size_t)blockIdx.x);
+}

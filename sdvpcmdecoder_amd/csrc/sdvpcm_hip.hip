@@ -7,6 +7,7 @@
 #include "stc007_deint_device.h"
 #include "stc007_stitch_device.h"
 #include "pcm1_stitch_device.h"
+#include "pcm1_bin_device.h"
 #include "engine.inc"
 #include "stitch_engine.inc"
 #include "pcm1_engine.inc"

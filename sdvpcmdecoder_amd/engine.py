@@ -153,6 +153,14 @@ class Engine:
     def __init__(self, device: int = 0, lib=None):
         self.lib = lib or load_library()
         self.device = device
+        # The tensors this class takes are torch's: let torch bring up the HIP runtime it ships before the library makes its first
+        # HIP call - the other way round torch finds no device any more ("No HIP GPUs are available").
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         self._h = self.lib.sdv_engine_create(device)
         if not self._h:
             raise RuntimeError("sdv_engine_create failed: " + self.lib.sdv_last_error(None).decode())
@@ -312,6 +320,28 @@ class Engine:
                                              C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
+
+    def pcm1_binarize_lines(self, luma, presets=None, frame_number: int = 1, first_line: int = 1, line_step: int = 1, doubled: bool = False,
+                            coord_search: bool = True, out_lines=None, stream=None):
+        """Binarizer::processLine with a PCM1Line output for every row of `luma` (torch.uint8 CUDA tensor (n_lines, width), rows
+        contiguous) in one launch.  `presets`: None or a torch.uint8 CUDA tensor (n_lines, 10) of sdv_bin_state - what the caller's
+        Binarizer had been given before each line.  Returns a torch.uint8 CUDA tensor (n_lines, 40) of sdv_pcm1_bin_rec."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 2 and luma.stride(1) == 1
+        n, w = luma.shape
+        if presets is not None:
+            assert presets.is_cuda and presets.dtype == torch.uint8 and presets.shape == (n, 10) and presets.is_contiguous()
+        if out_lines is None:
+            out_lines = torch.empty((n, 40), dtype=torch.uint8, device=luma.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        f = self.lib.sdv_pcm1_binarize_lines
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint, C.c_int,
+                      C.c_void_p, C.c_void_p]
+        rc = f(self._h, C.c_void_p(luma.data_ptr()), luma.stride(0), w, n, None if presets is None else C.c_void_p(presets.data_ptr()),
+               frame_number, first_line, line_step, FLAG_DOUBLED if doubled else 0, 1 if coord_search else 0, C.c_void_p(out_lines.data_ptr()), sptr)
+        self._check(rc)
+        return out_lines
 
     # ---- batch replacement of doBinarize ----
     def records_per_frame(self, height: int) -> int:

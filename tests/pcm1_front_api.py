@@ -116,3 +116,79 @@ def make_case(name):
         run["empty"] = e
     run["preset"] = _preset(**pre)
     return np.ascontiguousarray(luma), run
+
+
+def run_engine_lines(lib, eng, luma, states=None, mode=1, coord_search=True, preset=None, doubled=False, first_line=1, frame=1, line_step=1):
+    """sdv_pcm1_binarize_lines on host buffers (the emulator build); one launch for all rows, row i preset with states[i]."""
+    f = lib.sdv_pcm1_binarize_lines
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint, C.c_int,
+                  C.c_void_p, C.c_void_p]
+    lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_set_mode(eng, mode)
+    lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.c_void_p]
+    p = preset if preset is not None else libs.default_preset()
+    lib.sdv_set_bin_preset(eng, C.byref(p))
+    luma = np.ascontiguousarray(luma)
+    out = np.zeros(luma.shape[0], dtype=BIN1_DTYPE)
+    st = None if states is None else np.ascontiguousarray(states)
+    rc = f(eng, luma.ctypes.data, luma.shape[1], luma.shape[1], luma.shape[0], None if st is None else st.ctypes.data, frame, first_line, line_step,
+           2 if doubled else 0, 1 if coord_search else 0, out.ctypes.data, None)
+    return rc, out
+
+
+STATE_DTYPE = np.dtype([("black", "u1"), ("white", "u1"), ("ref", "u1"), ("_p", "u1"), ("start", "<i2"), ("stop", "<i2"), ("doubled", "u1"), ("_p2", "u1")])
+assert STATE_DTYPE.itemsize == 10
+
+
+def run_lines_with_states(lib, prefix, luma, states, mode=1, coord_search=True, preset=None, doubled=False, first_line=1, frame=1, line_step=1):
+    """The oracle / the reference, every line on a Binarizer preset with states[i] (set_state) - the per-line contract of the engine entry."""
+    f = lambda name: getattr(lib, prefix + name)
+    f("new").restype = C.c_void_p
+    h = C.c_void_p(f("new")())
+    f("set_mode").argtypes = [C.c_void_p, C.c_int]
+    f("set_coord_search").argtypes = [C.c_void_p, C.c_int]
+    f("set_preset").argtypes = [C.c_void_p, C.c_void_p]
+    f("set_state").argtypes = [C.c_void_p, C.c_void_p]
+    f("free").argtypes = [C.c_void_p]
+    proc = f("process")
+    proc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint16, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f("set_mode")(h, mode)
+    f("set_coord_search")(h, 1 if coord_search else 0)
+    if preset is not None:
+        f("set_preset")(h, C.byref(preset))
+    luma = np.ascontiguousarray(luma)
+    states = np.ascontiguousarray(states)
+    out = np.zeros(luma.shape[0], dtype=BIN1_DTYPE)
+    for i in range(luma.shape[0]):
+        f("set_state")(h, states[i:i + 1].ctypes.data)
+        proc(h, luma[i].ctypes.data, luma.shape[1], frame, first_line + i * line_step, 0, 1 if doubled else 0, 0, out[i:i + 1].ctypes.data)
+    f("free")(h)
+    return out
+
+
+def states_from_records(recs):
+    """What setGoodParameters(previous line) leaves in the Binarizer before each line (binarizer.cpp:353-377): the levels and
+    coordinates of the last line with a valid CRC (ignoring the forced-bad mark), nothing before the first one."""
+    st = np.zeros(len(recs), dtype=STATE_DTYPE)
+    cur = np.zeros(1, dtype=STATE_DTYPE)[0]
+    cur["start"], cur["stop"] = -32768, 32767
+    for i in range(len(recs)):
+        st[i] = cur
+        r = recs[i]
+        w = r["words"]
+        hdr = tuple(int(x) for x in w) == (0x0666, 0x0CCC, 0x1999, 0x1333, 0x0666, 0x0CCC, 0xCCCC)
+        if int(r["calc_crc"]) == int(w[6]) or hdr:
+            cur = cur.copy()
+            cur["ref"] = r["ref_level"]
+            s, e = int(r["data_start"]), int(r["data_stop"])
+            if s != -32768 and e != 32767 and s < e:
+                cur["start"], cur["stop"], cur["doubled"] = s, e, 1 if (int(r["flags"]) & 128) else 0
+            else:
+                cur["start"], cur["stop"], cur["doubled"] = -32768, 32767, 0
+            b, wht = int(r["black_level"]), int(r["white_level"])
+            if b < wht and b < 160 and wht > 28 and wht != 0:
+                cur["black"], cur["white"] = b, wht
+            else:
+                cur["black"], cur["white"] = 0, 0
+    return st

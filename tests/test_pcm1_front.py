@@ -89,3 +89,125 @@ def test_mode_insane_is_reported_unsupported_and_short_lines_rejected(oracle_lib
     assert (rets == pf.RET_UNSUPPORTED).all()
     _, rets, _ = pf.run_lines(oracle_lib, "orc_bin1_", luma[:, :80], mode=1, feedback="none")
     assert (rets == 3).all()            # LB_RET_SHORT_LINE
+
+
+# ---- the HIP kernel source on the CPU emulator (tests/emu) against the oracle ----------------------------------------------------
+import ctypes as C
+
+
+@pytest.fixture(scope="module")
+def emu(emu_lib):
+    emu_lib.sdv_engine_create.restype = C.c_void_p
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    yield emu_lib, eng
+    emu_lib.sdv_engine_destroy(eng)
+
+
+def _case_states(name, oracle_lib):
+    """Rows, run options and the per-line presets the sequential run of the case would have had (from the oracle's own records)."""
+    luma, run = pf.make_case(name)
+    keep = np.ones(len(luma), dtype=bool)
+    if "services" in run:
+        keep &= run["services"] == 0
+    if "empty" in run:
+        keep &= run["empty"] == 0
+    seq, _, _ = pf.run_lines(oracle_lib, "orc_bin1_", luma, **run)
+    states = pf.states_from_records(seq) if run.get("feedback") == "good" else np.zeros(len(luma), dtype=pf.STATE_DTYPE)
+    if run.get("feedback") != "good":
+        states["start"], states["stop"] = -32768, 32767
+    kw = dict(mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"], doubled=run.get("doubled", False))
+    return luma[keep], states[keep], seq[keep], kw
+
+
+@pytest.mark.parametrize("name", ["clean_fast", "cut_bits_draft", "cut_left_only", "noisy_header", "forced_coords", "no_bit_picker", "window_moves", "garbage"])
+def test_emu_matches_oracle(name, emu, oracle_lib):
+    lib, eng = emu
+    luma, states, seq, kw = _case_states(name, oracle_lib)
+    want = pf.run_lines_with_states(oracle_lib, "orc_bin1_", luma, states, **kw)
+    rc, got = pf.run_engine_lines(lib, eng, luma, states, **kw)
+    assert rc == 0
+    assert got.tobytes() == want.tobytes(), _diff(got, want, np.zeros(len(got)), np.zeros(len(got)))
+    # and the batch with per-line presets is the sequential run of the case: same line numbers as the sequential run have gaps
+    # where service lines were, so compare everything but the line number
+    a, b = got.copy(), seq.copy()
+    a["line_number"] = 0; b["line_number"] = 0
+    assert a.tobytes() == b.tobytes()
+
+
+def test_emu_argument_checks(emu):
+    lib, eng = emu
+    luma = np.zeros((2, 720), np.uint8)
+    rc, _ = pf.run_engine_lines(lib, eng, luma[:, :80])
+    assert rc == 3                      # SDV_ERR_SHORT_LINE
+    rc, _ = pf.run_engine_lines(lib, eng, luma, mode=3)
+    assert rc == -4                     # SDV_ERR_UNSUPPORTED
+
+
+# ---- the product on the GPU, through the C-ABI -------------------------------------------------------------------------------------
+def _gpu_engine():
+    """torch first: it has to bring up the HIP runtime it ships before the library's own first HIP call."""
+    import torch
+    torch.zeros(1, device="cuda:0")
+    from sdvpcmdecoder_amd import Engine
+    return Engine(0)
+
+
+def _gpu_run(eng, luma, states, mode=1, coord_search=True, preset=None, doubled=False):
+    import torch
+    from sdvpcmdecoder_amd.engine import BinPreset
+    eng.setBinarizationMode(mode)
+    eng.setFineSettings(BinPreset.from_buffer_copy(bytes(preset if preset is not None else libs.default_preset())))
+    d_luma = torch.from_numpy(np.ascontiguousarray(luma)).cuda()
+    d_st = torch.from_numpy(np.ascontiguousarray(states).view(np.uint8).reshape(len(states), 10)).cuda()
+    out = eng.pcm1_binarize_lines(d_luma, d_st, frame_number=1, first_line=1, line_step=1, doubled=doubled, coord_search=coord_search)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().reshape(-1).view(pf.BIN1_DTYPE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(pf.CASES))
+def test_gpu_matches_oracle(name, oracle_lib):
+    luma, states, seq, kw = _case_states(name, oracle_lib)
+    want = pf.run_lines_with_states(oracle_lib, "orc_bin1_", luma, states, **kw)
+    got = _gpu_run(_gpu_engine(), luma, states, **kw)
+    assert got.tobytes() == want.tobytes(), _diff(got, want, np.zeros(len(got)), np.zeros(len(got)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", pf.GOLDEN)
+def test_gpu_matches_golden_from_reference(name, oracle_lib):
+    """The fixtures hold the reference's sequential run; the per-line presets are rebuilt from the fixture's own records."""
+    luma, run = pf.make_case(name)
+    g = np.load(os.path.join(GOLD, "pcm1front_" + name + ".npz"))
+    want = g["recs"].reshape(-1).view(pf.BIN1_DTYPE)
+    keep = np.ones(len(luma), dtype=bool)
+    if "services" in run:
+        keep &= run["services"] == 0
+    if "empty" in run:
+        keep &= run["empty"] == 0
+    states = pf.states_from_records(want)
+    got = _gpu_run(_gpu_engine(), luma[keep], states[keep], mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"],
+                   doubled=run.get("doubled", False))
+    a, b = got.copy(), want[keep].copy()
+    a["line_number"] = 0; b["line_number"] = 0
+    assert a.tobytes() == b.tobytes(), _diff(a, b, np.zeros(len(a)), np.zeros(len(a)))
+
+
+@pytest.mark.gpu
+def test_gpu_field_of_lines_cold_and_warm(oracle_lib):
+    """245 lines at once: every line from scratch (the coordinate search on every line), then every line preset from a decoded
+    neighbour (the steady state of a tape that plays)."""
+    from sdvpcmdecoder_amd import synth
+    luma, words = synth.pcm1_random_lines(245, seed=11, x0=5, x1=713, noise_sigma=4.0)
+    cold = np.zeros(245, dtype=pf.STATE_DTYPE); cold["start"], cold["stop"] = -32768, 32767
+    eng = _gpu_engine()
+    got = _gpu_run(eng, luma, cold, mode=2)
+    want = pf.run_lines_with_states(oracle_lib, "orc_bin1_", luma, cold, mode=2)
+    assert got.tobytes() == want.tobytes()
+    assert ((got["flags"] & pf.LF_CRC_VALID) != 0).all() and (got["words"] == words).all()
+    warm = pf.states_from_records(np.concatenate([got[:1], got[:-1]]))
+    warm[0] = warm[1]
+    got2 = _gpu_run(eng, luma, warm, mode=2)
+    want2 = pf.run_lines_with_states(oracle_lib, "orc_bin1_", luma, warm, mode=2)
+    assert got2.tobytes() == want2.tobytes()
+    assert ((got2["flags"] & pf.LF_BY_EXT_TUNE) != 0).sum() >= 240
