@@ -66,13 +66,41 @@ __device__ inline void set_crcc(L1 &l, uint16_t w) { l.v = (l.v & ~(u128)0xFFFF)
 __device__ inline void calc_crc(L1 &l)
 {
     uint32_t crc = 0xFFFF;
-    for (int i = 0; i < 78; i++) {
-        uint32_t bit = (uint32_t)(~(l.v >> (93 - i)) & 1);
-        uint32_t top = ((crc >> 15) & 1) ^ bit;
+    uint64_t x = (uint64_t)(l.v >> 30);                 /* cells 0..63, cell 0 on top */
+    for (int i = 0; i < 64; i++) {
+        const uint32_t top = ((crc >> 15) ^ (uint32_t)(~x >> 63)) & 1;
         crc = ((crc << 1) & 0xFFFF) ^ (top ? 0x1021u : 0u);
+        x <<= 1;
+    }
+    uint32_t y = (uint32_t)(l.v >> 16) & 0x3FFF;        /* cells 64..77 */
+    for (int i = 0; i < 14; i++) {
+        const uint32_t top = ((crc >> 15) ^ (~y >> 13)) & 1;
+        crc = ((crc << 1) & 0xFFFF) ^ (top ? 0x1021u : 0u);
+        y <<= 1;
     }
     l.calc_crc = (uint16_t)(~crc & 0xFFFF);
 }
+/* the same CRC as a GF(2)-linear map of the cells (cell b = bit b of lo for b < 64, bit b-64 of hi): parity masks per CRC bit */
+struct Crc1Tables { uint64_t klo[16], khi[16]; uint16_t base; };
+constexpr Crc1Tables make_crc1_tables()
+{
+    Crc1Tables t{};
+    uint16_t c = 0xFFFF;
+    for (int i = 0; i < 78; i++) c = crc16_step(c, 1);             /* all cells 0: the CRC runs over their inverse */
+    t.base = (uint16_t)~c;
+    for (int b = 0; b < 78; b++) {
+        uint16_t v = 0;
+        for (int i = 0; i < 78; i++) v = crc16_step(v, i == b);
+        for (int j = 0; j < 16; j++)
+            if (v & (1u << j)) { if (b < 64) t.klo[j] |= (1ull << b); else t.khi[j] |= (1ull << (b - 64)); }
+    }
+    return t;
+}
+#ifdef SDV_EMU
+static const Crc1Tables c_crc1 = make_crc1_tables();
+#else
+__device__ __constant__ const Crc1Tables c_crc1 = make_crc1_tables();
+#endif
 __device__ inline bool has_header(const L1 &l)     /* pcm1line.cpp:314-323 */
 {
     const u128 hdr = word_at(0x0666, 0) | word_at(0x0CCC, 1) | word_at(0x1999, 2) | word_at(0x1333, 3) | word_at(0x0666, 4) | word_at(0x0CCC, 5) | (u128)0xCCCC;
@@ -101,8 +129,8 @@ __device__ inline void p1_clear(L1 &l)             /* PCM1Line::clear, pcm1line.
 {
     base_clear(l);
     l.picked_l = l.picked_r = 0;
-    l.v = 0;
-    set_silent(l);
+    /* setSilent() + the CRC of a silent line (CRC_SILENT, pcm1line.h:98) + setInvalidCRC(), without running the CRC */
+    l.v = word_at(0x1000, 0) | word_at(0x1000, 1) | word_at(0x1000, 2) | word_at(0x1000, 3) | word_at(0x1000, 4) | word_at(0x1000, 5);
     l.calc_crc = P1_CRC_SILENT;
     set_invalid_crc(l);
 }
@@ -140,6 +168,26 @@ __device__ inline void fill_pcm1(L1 &l, const WaveLds &lds, int stage)
     }
     l.v = v;
     calc_crc(l);
+}
+
+/* the same for the whole wave (wave-uniform callers only): lane i samples cells i and i+64, the automaton is solved on the ballots
+ * (stc007_device.h, solve_automaton), the CRC is 16 parities */
+__device__ inline void fill_pcm1_wave(L1 &l, const WaveLds &lds, int stage)
+{
+    const int lane = lane_id();
+    const uint8_t p0 = lds.px[pixel_of(l, lane, stage)];
+    const bool second = lane + 64 < P1_BITS;
+    const uint8_t p1 = lds.px[pixel_of(l, second ? lane + 64 : P1_BITS - 1, stage)];
+    const uint64_t a_lo = __ballot(p0 > l.ref_low), b_lo = __ballot(p0 >= l.ref_high);
+    const uint64_t a_hi = __ballot(second && p1 > l.ref_low), b_hi = __ballot(second && p1 >= l.ref_high);
+    uint64_t s_lo, s_hi;
+    solve_automaton(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+    s_hi &= (1ull << (P1_BITS - 64)) - 1ull;
+    l.v = ((u128)__brevll(s_lo) << 30) | (u128)(__brevll(s_hi) >> 34);
+    const uint64_t klo = (lane < 16) ? c_crc1.klo[lane & 15] : 0ull, khi = (lane < 16) ? c_crc1.khi[lane & 15] : 0ull;
+    const int par = (__popcll(s_lo & klo) + __popcll(s_hi & khi)) & 1;
+    const uint64_t cb = __ballot(par);
+    l.calc_crc = (uint16_t)((uint16_t)(cb & 0xFFFF) ^ c_crc1.base);
 }
 
 struct BinCtx { sdv_bin_preset ps; uint8_t mode; uint16_t scan_start, scan_end; bool force_bit_picker; };
@@ -202,6 +250,7 @@ __device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
 }
 
 /* fillDataWords (binarizer.cpp:7560-7650); false = the levels clip (STG_NO_GOOD) */
+template <bool kWave>
 __device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &lds, uint8_t ref_delta, uint8_t shift_stg)
 {
     if (ref_delta > HYST_DEPTH_MAX || shift_stg > SHIFT_STAGES_MAX) return false;
@@ -210,7 +259,7 @@ __device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &ld
     if (low_ref <= l.black) { set_invalid_crc(l); return false; }
     if (high_ref >= l.white) { set_invalid_crc(l); return false; }
     l.hyst = ref_delta; l.shift = shift_stg;
-    fill_pcm1(l, lds, shift_stg);
+    if (kWave) fill_pcm1_wave(l, lds, shift_stg); else fill_pcm1(l, lds, shift_stg);
     if ((!crc_valid(l) && (l.ref_level > c.ps.min_white_lvl) && ((c.ps.left_bit_pick != 0) || (c.ps.right_bit_pick != 0))) || c.force_bit_picker)
         pick_cut_bits(c, l);
     return true;
@@ -219,6 +268,7 @@ __device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &ld
 /* readPCMdata (binarizer.cpp:7695-8055) for a line whose reference level was not swept: hysteresis depths from 0 up, pixel shift
  * stages from 0 up, the first combination with a valid CRC wins (both loops of the reference stop at the first valid CRC, so its
  * two votes are over one entry each); none: depth 0, stage 0.  Then the final fill. */
+template <bool kWave>
 __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const WaveLds &lds, uint8_t hyst_lim, uint8_t shift_lim)
 {
     set_ppb(l, l.coords);
@@ -229,12 +279,12 @@ __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const WaveLds &lds,
     for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
         bool invalid_hyst = false;
         for (uint8_t s = 0; s <= shift_lim; s++) {
-            if (!fill_data_words(c, l, lds, h, s)) { invalid_hyst = true; break; }
+            if (!fill_data_words<kWave>(c, l, lds, h, s)) { invalid_hyst = true; break; }
             if (crc_valid(l)) { found = true; valid_delta = h; valid_shift = s; break; }
         }
         if (invalid_hyst) break;
     }
-    fill_data_words(c, l, lds, valid_delta, valid_shift);
+    fill_data_words<kWave>(c, l, lds, valid_delta, valid_shift);
 }
 
 __device__ inline void stats_reset(CrcStat *a, int count) { for (int i = 0; i < count; i++) { a[i].result = 0; a[i].crc = 0; a[i].hyst = a[i].shift = 0x0f; a[i].idx = 0; } }
@@ -295,7 +345,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
         const int row = q / nr, col = q - row * nr;
         L1 t = l;
         coords_set(t.coords, (int16_t)(l0 + row * scan_step), (int16_t)(r1 - col * scan_step));
-        read_pcm_data(c, t, lds.w, hyst_lim, shift_lim);
+        read_pcm_data<false>(c, t, lds.w, hyst_lim, shift_lim);
         uint8_t hy = t.hyst;
         if (t.picked_l != 0 && t.picked_r != 0) hy = 0x0E; else if (t.picked_r != 0) hy = 0x0D; else if (t.picked_l != 0) hy = 0x0C;
         lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24);
@@ -356,7 +406,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
     if (n_cand > 0) {
         if (first_coll != 0xFFFFFFFFu && first_coll < (uint32_t)(n_cand - 1)) l.forced_bad = true;
         coords_set(l.coords, (int16_t)(l0 + (nl - 1) * scan_step), (int16_t)(r1 - (nr - 1) * scan_step));
-        read_pcm_data(c, l, lds.w, hyst_lim, shift_lim);
+        read_pcm_data<true>(c, l, lds.w, hyst_lim, shift_lim);
     }
     c.force_bit_picker = bitpick_previous;
     if (found) {
@@ -479,7 +529,11 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
     const int lane = lane_id();
     const uint8_t *row = a.luma + li * a.row_stride;
     __syncthreads();
-    for (int p = lane; p < a.width; p += 64) lds.w.px[p] = row[p];
+    if (((((uintptr_t)row) | (uintptr_t)a.width) & 15) == 0) {          /* 16 bytes per lane */
+        for (int p = lane * 16; p < a.width; p += 64 * 16) *(uint4 *)&lds.w.px[p] = *(const uint4 *)(row + p);
+    } else {
+        for (int p = lane; p < a.width; p += 64) lds.w.px[p] = row[p];
+    }
     __syncthreads();
 
     BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
@@ -513,7 +567,7 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
             if (!out.bw_set) state = STG_NO_GOOD;
             else if (b.in_ref >= out.white || b.in_ref <= out.black) state = STG_REF_FIND;
             else {
-                read_pcm_data(c, out, lds.w, hyst_lim, shift_lim);
+                read_pcm_data<true>(c, out, lds.w, hyst_lim, shift_lim);
                 if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; } else state = STG_REF_FIND;
             }
         } else if (state == STG_INPUT_LEVEL) {                  /* :932-1072 */
@@ -539,13 +593,13 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
             }
         } else if (state == STG_READ_PCM) {                     /* :1401-1533 */
             if (coords_valid(forced)) { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN; }
-            if (out.coords_set) read_pcm_data(c, out, lds.w, hyst_lim, shift_lim);
+            if (out.coords_set) read_pcm_data<true>(c, out, lds.w, hyst_lim, shift_lim);
             if (crc_valid(out)) state = STG_DATA_OK;
             if (state != STG_DATA_OK) {
                 if (coords_valid(b.in_coord) && !coords_valid(forced) && !out.forced_bad && !out.coords_set) {
                     if (coords_ne(out.coords, b.in_coord)) {
                         out.coords = b.in_coord;
-                        read_pcm_data(c, out, lds.w, hyst_lim, shift_lim);
+                        read_pcm_data<true>(c, out, lds.w, hyst_lim, shift_lim);
                         if (crc_valid(out)) state = STG_DATA_OK;
                     }
                 }

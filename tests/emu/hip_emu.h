@@ -153,6 +153,7 @@ static inline unsigned __brev(unsigned v)
     v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
     return (v >> 16) | (v << 16);
 }
+static inline unsigned long long __brevll(unsigned long long v) { return ((unsigned long long)__brev((unsigned)v) << 32) | __brev((unsigned)(v >> 32)); }
 template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = (T)(o | v); return o; }
 template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
