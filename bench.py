@@ -255,6 +255,54 @@ def main():
                         "(sdv_pcm1_stitch_frames), wall clock per batch incl. its host round trips; not part of `value`"}
         p1_first = pp[:3000 * 1470].cpu().numpy().copy() if rank == 0 else None
 
+    # ... and its front half: video lines -> PCM1Line records (sdv_pcm1_binarize_lines), a tape that plays (every line preset from a
+    # decoded neighbour) and the cold case (nothing preset: the marker-less coordinate search on every line)
+    pcm1f = None
+    if not args.no_stitch and world == 1:
+        from sdvpcmdecoder_amd import synth as _synth
+        LPF = 490
+        f_frames = min(n, 2000)
+        base, base_words = _synth.pcm1_random_lines(LPF * 8, seed=21, x0=5, x1=713, noise_sigma=args.noise)
+        nl = f_frames * LPF
+        fl = torch.from_numpy(base).to(dev).repeat((nl + len(base) - 1) // len(base), 1)[:nl].contiguous()
+        gen = torch.Generator(device=dev); gen.manual_seed(5)
+        for i in range(0, nl, 1 << 18):         # every line its own pixels: +-3 on top, far inside the decision levels
+            blk = fl[i:i + (1 << 18)]
+            blk.copy_((blk.to(torch.int16) + torch.randint(-3, 4, blk.shape, generator=gen, device=dev, dtype=torch.int16)).clamp_(0, 255).to(torch.uint8))
+        eng.setBinarizationMode(args.mode)
+        cold_n = min(nl, 20 * LPF)
+        rec_dt = np.dtype([("frame", "<u4"), ("line", "<u2"), ("words", "<u2", (7,)), ("crc", "<u2"), ("start", "<i2"), ("stop", "<i2"), ("lv", "u1", (5,)),
+                           ("hs", "u1", (2,)), ("srv", "u1"), ("pk", "u1", (2,)), ("flags", "u1"), ("_p", "u1", (3,))])
+        cold = eng.pcm1_binarize_lines(fl[:cold_n], stream=stream)
+        torch.cuda.synchronize(dev)
+        cr = cold.cpu().numpy().reshape(-1).view(rec_dt)
+        k0 = int(np.flatnonzero((cr["flags"] & 64) != 0)[0])
+        st = np.zeros(nl, dtype=np.dtype([("black", "u1"), ("white", "u1"), ("ref", "u1"), ("_p", "u1"), ("start", "<i2"), ("stop", "<i2"), ("d", "u1"), ("_p2", "u1")]))
+        st["black"], st["white"], st["ref"], st["start"], st["stop"] = cr["lv"][k0][0], cr["lv"][k0][1], cr["lv"][k0][3], cr["start"][k0], cr["stop"][k0]
+        d_st = torch.from_numpy(st.view(np.uint8).reshape(nl, 10)).to(dev)
+        fo = torch.empty((nl, 40), dtype=torch.uint8, device=dev)
+        res = {}
+        k_steps = max(1, min(args.steps, 5))
+        for name, a_l, a_s, cnt in (("warm", fl, d_st, nl), ("cold", fl[:cold_n], None, cold_n)):
+            eng.pcm1_binarize_lines(a_l, a_s, out_lines=fo[:cnt], stream=stream)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(k_steps):
+                eng.pcm1_binarize_lines(a_l, a_s, out_lines=fo[:cnt], stream=stream)
+            torch.cuda.synchronize(dev)
+            res[name] = (time.perf_counter() - t1) / k_steps
+            if name == "warm":
+                warm_host = fo[:3 * LPF * 8].cpu().numpy().reshape(-1).view(rec_dt).copy()
+        words_ok1 = bool((warm_host["words"] == base_words[np.arange(len(warm_host)) % len(base)]).all()) and bool(((warm_host["flags"] & 4) != 0).all())
+        pcm1f = {"lines_per_step": nl, "ms_per_step": res["warm"] * 1e3, "lines_per_s": nl / res["warm"], "frames_per_s": nl / res["warm"] / LPF,
+                 "algorithmic_gb_per_s": nl * (720 + 10 + 40) / res["warm"] / 1e9, "decoded_words_match_generator": words_ok1,
+                 "cold_lines": cold_n, "cold_ms": res["cold"] * 1e3, "cold_lines_per_s": cold_n / res["cold"],
+                 "note": "PCM-1 video lines (720 px) -> PCM1Line records (sdv_pcm1_binarize_lines, Binarizer mode as above): `warm` = every line "
+                         "preset with the levels and coordinates of a decoded line (what the frame driver hands on while a tape plays), `cold` = "
+                         "nothing preset, every line runs the 25 x 25 coordinate search; not part of `value`"}
+        pcm1f_sample = (fl[:3 * LPF].cpu().numpy(), st[:3 * LPF].copy(), warm_host[:3 * LPF].copy(), fl[:LPF // 2].cpu().numpy(), cr[:LPF // 2].copy()) if rank == 0 else None
+        del fl, fo, d_st
+
     # correctness of what was timed: all lines decode to the generator's words
     recs = out_lines[1:1 + nrec].view(-1)  # device bytes
     host = out_lines[1:1 + 8 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(8, H + 3)
@@ -310,6 +358,8 @@ def main():
             out["stitch_stage"] = stitch
         if pcm1 is not None:
             out["pcm1_stage"] = pcm1
+        if pcm1f is not None:
+            out["pcm1_front_stage"] = pcm1f
         if not args.no_cpu and world == 1:
             ncpu = min(args.cpu_frames, n)
             sample = luma[:ncpu].cpu().numpy()
@@ -341,6 +391,22 @@ def main():
                 pcm1["cpu_baseline"] = {"value": np1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
                                         "sample": f"the first {np1} frames, {dt1:.2f} s of CPU work",
                                         "bit_exact_vs_gpu_on_overlap": bool(cp1.tobytes() == p1_first.reshape(-1).view(p1a.PAIR_DTYPE)[:len(cp1)].tobytes())}
+            if pcm1f is not None:
+                import pcm1_front_api as pfa
+                wl, wst, wgot, cl, cgot = pcm1f_sample
+                orc = libs.load_oracle()
+                t0 = time.perf_counter()
+                cw = pfa.run_lines_with_states(orc, "orc_bin1_", wl, wst.view(pfa.STATE_DTYPE), mode=args.mode)
+                dtw = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                cold_st = np.zeros(len(cl), dtype=pfa.STATE_DTYPE); cold_st["start"], cold_st["stop"] = -32768, 32767
+                cc = pfa.run_lines_with_states(orc, "orc_bin1_", cl, cold_st, mode=args.mode)
+                dtc = time.perf_counter() - t0
+                pcm1f["cpu_baseline"] = {"value": len(wl) / dtw, "unit": "lines/s", "cores": 1, "kind": "port",
+                                         "sample": f"the first {len(wl)} preset lines, {dtw:.2f} s of CPU work (incl. the ctypes call per line); "
+                                                   f"cold: {len(cl)} lines in {dtc:.2f} s = {len(cl) / dtc:.0f} lines/s",
+                                         "bit_exact_vs_gpu_on_overlap": bool(cw.tobytes() == wgot.view(pfa.BIN1_DTYPE).tobytes()
+                                                                             and cc.tobytes() == cgot.view(pfa.BIN1_DTYPE).tobytes())}
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
