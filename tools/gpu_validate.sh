@@ -23,3 +23,6 @@ rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VAL
 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/p1pmc2 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc2.err; echo "p1pmc2 rc=$?"
 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p1pmc3 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc3.err; echo "p1pmc3 rc=$?"
 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p1pmc4 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc4.err; echo "p1pmc4 rc=$?"
+# PCM-1 front half: kernel stats and PMC passes of its line kernel
+bash $R/tools/gpu_pcm1_front_pmc.sh 2>&1 | grep "rc="
+

@@ -24,12 +24,15 @@ def trim(src, dst):
 trim(newest('gpurun_out/prof_bench/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_kernel_stats.csv')
 trim(newest('gpurun_out/prof_stitch/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_stitch_kernel_stats.csv')
 trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_pcm1_kernel_stats.csv')
+if glob.glob('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'):
+    trim(newest('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_pcm1_front_kernel_stats.csv')
+    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines', 'profiles/r01_pmc_sdv_k_pcm1_lines.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
 shutil.copy('gpurun_out/bench_full.json', 'profiles/r01_bench_full.json')
 shutil.copy('gpurun_out/bench_2rank_gloo.json', 'profiles/r01_bench_2rank_gloo_one_gpu.json')
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', 'profiles/r01_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', 'profiles/r01_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
 d = json.loads(open('gpurun_out/bench_full.json').read().strip().split('\n')[-1])
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'launch ms', d['roofline']['avg_launch_ms'], 'traffic', d['roofline']['traffic'])
-for k in ('stitch_stage', 'pcm1_stage'):
-    print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ('note', 'cpu_baseline')})
+for k in ('stitch_stage', 'pcm1_stage', 'pcm1_front_stage'):
+    if k in d: print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ('note', 'cpu_baseline')})
 print('cpu', d['cpu_baseline']['value'], d['stitch_stage']['cpu_baseline']['value'], d['pcm1_stage']['cpu_baseline']['value'], d.get('host_fed', {}).get('h2d_gb_per_s'))
