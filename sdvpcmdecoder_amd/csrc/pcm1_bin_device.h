@@ -36,6 +36,8 @@ struct LineArgs1 {
     uint8_t doubled, mode, coord_search;
     sdv_bin_preset preset;
     sdv_pcm1_bin_rec *out;
+    int *list;                      /* lines the lean kernel handed on (it appends; the full kernel works the list off), or NULL: all lines */
+    int *counters;                  /* [0] entries in list, [1] next entry to take */
 };
 
 struct P1Lds {
@@ -155,12 +157,12 @@ __device__ inline int pixel_of(const L1 &l, int bit, int stage)
 }
 
 /* fillPCM1 (binarizer.cpp:7016-7131): the two-level automaton over the 94 cell centres */
-__device__ inline void fill_pcm1(L1 &l, const WaveLds &lds, int stage)
+__device__ inline void fill_pcm1(L1 &l, const uint8_t *px_row, int stage)
 {
     bool prev_high = false;
     u128 v = 0;
     for (int bit = 0; bit < P1_BITS; bit++) {
-        const uint8_t px = lds.px[pixel_of(l, bit, stage)];
+        const uint8_t px = px_row[pixel_of(l, bit, stage)];
         bool one;
         if (!prev_high) { one = px > l.ref_low; prev_high = one; }
         else { one = px >= l.ref_high; prev_high = one; }
@@ -172,12 +174,12 @@ __device__ inline void fill_pcm1(L1 &l, const WaveLds &lds, int stage)
 
 /* the same for the whole wave (wave-uniform callers only): lane i samples cells i and i+64, the automaton is solved on the ballots
  * (stc007_device.h, solve_automaton), the CRC is 16 parities */
-__device__ inline void fill_pcm1_wave(L1 &l, const WaveLds &lds, int stage)
+__device__ inline void fill_pcm1_wave(L1 &l, const uint8_t *px_row, int stage)
 {
     const int lane = lane_id();
-    const uint8_t p0 = lds.px[pixel_of(l, lane, stage)];
+    const uint8_t p0 = px_row[pixel_of(l, lane, stage)];
     const bool second = lane + 64 < P1_BITS;
-    const uint8_t p1 = lds.px[pixel_of(l, second ? lane + 64 : P1_BITS - 1, stage)];
+    const uint8_t p1 = px_row[pixel_of(l, second ? lane + 64 : P1_BITS - 1, stage)];
     const uint64_t a_lo = __ballot(p0 > l.ref_low), b_lo = __ballot(p0 >= l.ref_high);
     const uint64_t a_hi = __ballot(second && p1 > l.ref_low), b_hi = __ballot(second && p1 >= l.ref_high);
     uint64_t s_lo, s_hi;
@@ -251,7 +253,7 @@ __device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
 
 /* fillDataWords (binarizer.cpp:7560-7650); false = the levels clip (STG_NO_GOOD) */
 template <bool kWave>
-__device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &lds, uint8_t ref_delta, uint8_t shift_stg)
+__device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const uint8_t *px_row, uint8_t ref_delta, uint8_t shift_stg)
 {
     if (ref_delta > HYST_DEPTH_MAX || shift_stg > SHIFT_STAGES_MAX) return false;
     const uint8_t low_ref = get_low_level(l.ref_level, ref_delta), high_ref = get_high_level(l.ref_level, ref_delta);
@@ -259,7 +261,7 @@ __device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &ld
     if (low_ref <= l.black) { set_invalid_crc(l); return false; }
     if (high_ref >= l.white) { set_invalid_crc(l); return false; }
     l.hyst = ref_delta; l.shift = shift_stg;
-    if (kWave) fill_pcm1_wave(l, lds, shift_stg); else fill_pcm1(l, lds, shift_stg);
+    if (kWave) fill_pcm1_wave(l, px_row, shift_stg); else fill_pcm1(l, px_row, shift_stg);
     if ((!crc_valid(l) && (l.ref_level > c.ps.min_white_lvl) && ((c.ps.left_bit_pick != 0) || (c.ps.right_bit_pick != 0))) || c.force_bit_picker)
         pick_cut_bits(c, l);
     return true;
@@ -269,7 +271,7 @@ __device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const WaveLds &ld
  * stages from 0 up, the first combination with a valid CRC wins (both loops of the reference stop at the first valid CRC, so its
  * two votes are over one entry each); none: depth 0, stage 0.  Then the final fill. */
 template <bool kWave>
-__device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const WaveLds &lds, uint8_t hyst_lim, uint8_t shift_lim)
+__device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const uint8_t *px_row, uint8_t hyst_lim, uint8_t shift_lim)
 {
     set_ppb(l, l.coords);
     if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
@@ -279,12 +281,12 @@ __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const WaveLds &lds,
     for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
         bool invalid_hyst = false;
         for (uint8_t s = 0; s <= shift_lim; s++) {
-            if (!fill_data_words<kWave>(c, l, lds, h, s)) { invalid_hyst = true; break; }
+            if (!fill_data_words<kWave>(c, l, px_row, h, s)) { invalid_hyst = true; break; }
             if (crc_valid(l)) { found = true; valid_delta = h; valid_shift = s; break; }
         }
         if (invalid_hyst) break;
     }
-    fill_data_words<kWave>(c, l, lds, valid_delta, valid_shift);
+    fill_data_words<kWave>(c, l, px_row, valid_delta, valid_shift);
 }
 
 __device__ inline void stats_reset(CrcStat *a, int count) { for (int i = 0; i < count; i++) { a[i].result = 0; a[i].crc = 0; a[i].hyst = a[i].shift = 0x0f; a[i].idx = 0; } }
@@ -345,7 +347,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
         const int row = q / nr, col = q - row * nr;
         L1 t = l;
         coords_set(t.coords, (int16_t)(l0 + row * scan_step), (int16_t)(r1 - col * scan_step));
-        read_pcm_data<false>(c, t, lds.w, hyst_lim, shift_lim);
+        read_pcm_data<false>(c, t, lds.w.px, hyst_lim, shift_lim);
         uint8_t hy = t.hyst;
         if (t.picked_l != 0 && t.picked_r != 0) hy = 0x0E; else if (t.picked_r != 0) hy = 0x0D; else if (t.picked_l != 0) hy = 0x0C;
         lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24);
@@ -406,7 +408,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
     if (n_cand > 0) {
         if (first_coll != 0xFFFFFFFFu && first_coll < (uint32_t)(n_cand - 1)) l.forced_bad = true;
         coords_set(l.coords, (int16_t)(l0 + (nl - 1) * scan_step), (int16_t)(r1 - (nr - 1) * scan_step));
-        read_pcm_data<true>(c, l, lds.w, hyst_lim, shift_lim);
+        read_pcm_data<true>(c, l, lds.w.px, hyst_lim, shift_lim);
     }
     c.force_bit_picker = bitpick_previous;
     if (found) {
@@ -522,19 +524,24 @@ __device__ inline void emit_rec(const L1 &l, uint32_t frame, uint16_t line_no, b
     *dst = r;
 }
 
+__device__ inline void stage_row(uint8_t *px, const uint8_t *row, int width)
+{
+    const int lane = lane_id();
+    __syncthreads();
+    if (((((uintptr_t)row) | (uintptr_t)width) & 15) == 0) {            /* 16 bytes per lane */
+        for (int p = lane * 16; p < width; p += 64 * 16) *(uint4 *)&px[p] = *(const uint4 *)(row + p);
+    } else {
+        for (int p = lane; p < width; p += 64) px[p] = row[p];
+    }
+    __syncthreads();
+}
+
 /* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, a line with pixels (service lines and empty lines are the
  * caller's: they carry no pixels and are not sent to the device) */
 __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
 {
     const int lane = lane_id();
-    const uint8_t *row = a.luma + li * a.row_stride;
-    __syncthreads();
-    if (((((uintptr_t)row) | (uintptr_t)a.width) & 15) == 0) {          /* 16 bytes per lane */
-        for (int p = lane * 16; p < a.width; p += 64 * 16) *(uint4 *)&lds.w.px[p] = *(const uint4 *)(row + p);
-    } else {
-        for (int p = lane; p < a.width; p += 64) lds.w.px[p] = row[p];
-    }
-    __syncthreads();
+    stage_row(lds.w.px, a.luma + li * a.row_stride, a.width);
 
     BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
     c.force_bit_picker = true;      /* the Binarizer is constructed with it set (binarizer.cpp:82) and nothing clears it */
@@ -567,7 +574,7 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
             if (!out.bw_set) state = STG_NO_GOOD;
             else if (b.in_ref >= out.white || b.in_ref <= out.black) state = STG_REF_FIND;
             else {
-                read_pcm_data<true>(c, out, lds.w, hyst_lim, shift_lim);
+                read_pcm_data<true>(c, out, lds.w.px, hyst_lim, shift_lim);
                 if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; } else state = STG_REF_FIND;
             }
         } else if (state == STG_INPUT_LEVEL) {                  /* :932-1072 */
@@ -593,13 +600,13 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
             }
         } else if (state == STG_READ_PCM) {                     /* :1401-1533 */
             if (coords_valid(forced)) { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN; }
-            if (out.coords_set) read_pcm_data<true>(c, out, lds.w, hyst_lim, shift_lim);
+            if (out.coords_set) read_pcm_data<true>(c, out, lds.w.px, hyst_lim, shift_lim);
             if (crc_valid(out)) state = STG_DATA_OK;
             if (state != STG_DATA_OK) {
                 if (coords_valid(b.in_coord) && !coords_valid(forced) && !out.forced_bad && !out.coords_set) {
                     if (coords_ne(out.coords, b.in_coord)) {
                         out.coords = b.in_coord;
-                        read_pcm_data<true>(c, out, lds.w, hyst_lim, shift_lim);
+                        read_pcm_data<true>(c, out, lds.w.px, hyst_lim, shift_lim);
                         if (crc_valid(out)) state = STG_DATA_OK;
                     }
                 }
@@ -620,13 +627,66 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
     emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[li]);
 }
 
+/* The lean build of the line (the pattern of the STC-007 frame kernel): a line whose caller preset levels, reference level and
+ * coordinates is read with them - stage STG_INPUT_ALL of processLine and nothing else, which needs a fraction of the registers - and
+ * a line that does not come out of that with a valid CRC (or has no complete presets, or forced coordinates) is put on the list of
+ * the full kernel, which decodes it from the start. */
+__device__ inline void lean_body(const LineArgs1 &a, uint8_t *px, size_t li)
+{
+    bool done = false;
+    const sdv_bin_state s = a.states[li];
+    BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1); c.force_bit_picker = true;
+    Bin b;
+    b.in_black = s.in_def_black; b.in_white = s.in_def_white; b.in_ref = s.in_def_reference;
+    b.in_coord.start = s.in_def_start; b.in_coord.stop = s.in_def_stop; b.in_coord.doubled = s.in_def_from_doubled != 0;
+    bin_set_mode(b, a.mode);
+    if (!c.ps.en_force_coords && are_bw_levels_preset(b, c.ps) && is_ref_level_preset(b, c.ps) && coords_valid(b.in_coord)
+        && b.in_ref < b.in_white && b.in_ref > b.in_black) {
+        stage_row(px, a.luma + li * a.row_stride, a.width);
+        L1 out; p1_clear(out);
+        if (c.scan_end > c.scan_start && P1_BITS <= (c.scan_end - c.scan_start)) { out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end; }
+        out.black = b.in_black; out.white = b.in_white; out.bw_set = true;
+        out.coords = b.in_coord;
+        out.ref_level = b.in_ref;
+        read_pcm_data<true>(c, out, px, b.in_max_hyst, b.in_max_shift);
+        if (crc_valid(out)) {
+            out.by_ext_tune = true;
+            if (has_header(out)) set_service(out, SDV_SRV_HEADER_LINE);
+            emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[li]);
+            done = true;
+        }
+    }
+    if (!done && lane_id() == 0) a.list[atomicAdd(&a.counters[0], 1)] = (int)li;
+}
+
 } // namespace sdvp1b
 
 #ifndef SDV_P1B_WAVES_PER_EU
 #define SDV_P1B_WAVES_PER_EU 4
 #endif
+#ifndef SDV_P1B_LEAN_WAVES_PER_EU
+#define SDV_P1B_LEAN_WAVES_PER_EU 8
+#endif
+/* the full line: over all lines (grid-stride), or over the list the lean kernel left */
 __global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_lines(sdvp1b::LineArgs1 a)
 {
     __shared__ sdvp1b::P1Lds lds;
-    sdvp1b::line_body(a, lds, (size_t)blockIdx.x);
+    if (a.list) {
+        const int n = a.counters[0];
+        for (;;) {
+            __syncthreads();
+            if (sdv::lane_id() == 0) lds.vote[3] = atomicAdd(&a.counters[1], 1);
+            __syncthreads();
+            const int i = lds.vote[3];
+            if (i >= n) break;
+            sdvp1b::line_body(a, lds, (size_t)a.list[i]);
+        }
+    } else {
+        for (size_t li = blockIdx.x; li < a.n_lines; li += gridDim.x) sdvp1b::line_body(a, lds, li);
+    }
+}
+__global__ void __launch_bounds__(64, SDV_P1B_LEAN_WAVES_PER_EU) sdv_k_pcm1_lines_lean(sdvp1b::LineArgs1 a)
+{
+    __shared__ alignas(16) uint8_t px[SDV_PX_BYTES];
+    sdvp1b::lean_body(a, px, (size_t)blockIdx.x);
 }
