@@ -286,7 +286,9 @@ __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const uint8_t *px_r
         }
         if (invalid_hyst) break;
     }
-    fill_data_words<kWave>(c, l, px_row, valid_delta, valid_shift);
+    /* the final fill of the reference repeats the fill that was found, on the same inputs, and leaves the line as that fill left
+     * it - it only has to be run when nothing was found */
+    if (!found) fill_data_words<kWave>(c, l, px_row, valid_delta, valid_shift);
 }
 
 __device__ inline void stats_reset(CrcStat *a, int count) { for (int i = 0; i < count; i++) { a[i].result = 0; a[i].crc = 0; a[i].hyst = a[i].shift = 0x0f; a[i].idx = 0; } }

@@ -21,10 +21,11 @@ for d in ('p1fpmc1', 'p1fpmc2', 'p1fpmc3', 'p1fpmc4'):
     if not fs: continue
     rows = list(csv.DictReader(open(fs[-1])))
     # the big launch (the warm one): most workgroups
-    big = max(int(r['Grid_Size']) for r in rows)
+    # the lean kernel's big launch (the warm one): per dispatch sums, the last one
     acc = {}
     for r in rows:
-        if int(r['Grid_Size']) == big:
-            acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-    print(d, {k: round(sum(v) / len(v)) for k, v in acc.items()})
+        if r['Kernel_Name'].startswith('sdv_k_pcm1_lines_lean('):
+            acc.setdefault(int(r['Dispatch_Id']), {}).setdefault(r['Counter_Name'], 0.0)
+            acc[int(r['Dispatch_Id'])][r['Counter_Name']] += float(r['Counter_Value'])
+    if acc: print(d, {k: round(v) for k, v in acc[max(acc)].items()})
 PY

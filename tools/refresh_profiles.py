@@ -27,6 +27,7 @@ trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3
 if glob.glob('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'):
     trim(newest('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_pcm1_front_kernel_stats.csv')
     subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines', 'profiles/r01_pmc_sdv_k_pcm1_lines.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines_lean', 'profiles/r01_pmc_sdv_k_pcm1_lines_lean.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
 shutil.copy('gpurun_out/bench_full.json', 'profiles/r01_bench_full.json')
 shutil.copy('gpurun_out/bench_2rank_gloo.json', 'profiles/r01_bench_2rank_gloo_one_gpu.json')
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', 'profiles/r01_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
