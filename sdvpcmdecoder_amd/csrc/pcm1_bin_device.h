@@ -674,14 +674,15 @@ __global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_lines(sdv
 {
     __shared__ sdvp1b::P1Lds lds;
     if (a.list) {
+        /* entry blockIdx.x first, then whatever is next behind the grid: no atomic at all while the list is shorter than the grid */
         const int n = a.counters[0];
-        for (;;) {
-            __syncthreads();
-            if (sdv::lane_id() == 0) lds.vote[3] = atomicAdd(&a.counters[1], 1);
-            __syncthreads();
-            const int i = lds.vote[3];
-            if (i >= n) break;
+        int i = (int)blockIdx.x;
+        while (i < n) {
             sdvp1b::line_body(a, lds, (size_t)a.list[i]);
+            __syncthreads();
+            if (sdv::lane_id() == 0) lds.vote[3] = (int)gridDim.x + atomicAdd(&a.counters[1], 1);
+            __syncthreads();
+            i = lds.vote[3];
         }
     } else {
         for (size_t li = blockIdx.x; li < a.n_lines; li += gridDim.x) sdvp1b::line_body(a, lds, li);

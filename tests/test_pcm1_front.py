@@ -211,3 +211,26 @@ def test_gpu_field_of_lines_cold_and_warm(oracle_lib):
     want2 = pf.run_lines_with_states(oracle_lib, "orc_bin1_", luma, warm, mode=2)
     assert got2.tobytes() == want2.tobytes()
     assert ((got2["flags"] & pf.LF_BY_EXT_TUNE) != 0).sum() >= 240
+
+
+@pytest.mark.gpu
+def test_gpu_long_hand_over_list(oracle_lib):
+    """More lines than the full kernel has workgroups, none of them decodable from its presets: the lean kernel hands all of them on,
+    the full kernel works the list off (its entries behind the grid through the shared counter) - same records as with no presets at
+    all, and as the oracle's on a sample."""
+    import torch
+    from sdvpcmdecoder_amd import synth
+    luma, _ = synth.pcm1_random_lines(245, seed=12, x0=5, x1=713, noise_sigma=4.0)
+    big = np.tile(luma, (41, 1))                        # 10 045 lines
+    wrong = np.zeros(len(big), dtype=pf.STATE_DTYPE)
+    wrong["black"], wrong["white"], wrong["ref"], wrong["start"], wrong["stop"] = 30, 200, 115, 60, 650       # presets that read nothing
+    eng = _gpu_engine()
+    eng.setBinarizationMode(1)
+    d_luma = torch.from_numpy(big).cuda()
+    a = eng.pcm1_binarize_lines(d_luma, torch.from_numpy(wrong.view(np.uint8).reshape(len(wrong), 10)).cuda()).cpu().numpy().reshape(-1).view(pf.BIN1_DTYPE)
+    want = pf.run_lines_with_states(oracle_lib, "orc_bin1_", big[:300], wrong[:300], mode=1)
+    assert a[:300].tobytes() == want.tobytes()
+    assert ((a["flags"] & pf.LF_CRC_VALID) != 0).all() and ((a["flags"] & pf.LF_BY_EXT_TUNE) == 0).all()
+    rest = a[245:].copy(); first = np.tile(a[:245], 40)
+    rest["line_number"] = 0; first["line_number"] = 0
+    assert rest.tobytes() == first.tobytes()
