@@ -32,3 +32,17 @@ lib.sdv_set_mode(eng, 2)
 rc, recs, stats = ea.emu_binarize(lib, eng, luma)
 assert rc == 0 and recs.tobytes() == want.tobytes()
 print("binarize emu ok")
+import ctypes as C
+import pcm1_front_api as pf
+lib.sdv_engine_create.restype = C.c_void_p
+for name in ("clean_fast", "cut_bits_draft", "noisy_header", "window_moves", "garbage", "forced_coords"):
+    luma1, run = pf.make_case(name)
+    seq, _, _ = pf.run_lines(orc, "orc_bin1_", luma1, **run)
+    states = pf.states_from_records(seq)
+    keep = np.ones(len(luma1), dtype=bool)
+    want1 = pf.run_lines_with_states(orc, "orc_bin1_", luma1[keep], states[keep], mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"])
+    eng = C.c_void_p(lib.sdv_engine_create(0))
+    rc, got1 = pf.run_engine_lines(lib, eng, luma1[keep], states[keep], mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"])
+    assert rc == 0 and got1.tobytes() == want1.tobytes(), name
+    lib.sdv_engine_destroy(eng)
+print("pcm1 front emu ok")

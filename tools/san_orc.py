@@ -23,3 +23,9 @@ for name in ("ntsc_bad5", "ntsc_burst300", "pal_bad5", "f1_16bit_bad5", "ntsc_ct
     recs, st = sc.make_input(name, lambda luma: oracle_binarize(luma, mode=2))
     sa.run_cpu(_lib, "orc_", recs, st)
 print("stitch ok")
+
+import pcm1_front_api as pf
+for name in sorted(pf.CASES):
+    luma, run = pf.make_case(name)
+    pf.run_lines(_lib, "orc_bin1_", luma, **run)
+print("pcm1 front ok")
