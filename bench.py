@@ -34,19 +34,29 @@ def algorithmic_bytes_per_frame(width, height):
     return width * height + (height + 3) * 48 + 32
 
 
-def measured_hbm_traffic(frames_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
-    this same command, profiles/r01_pmc_sdv_k_stc007_frames_lean.json, made by tools/pmc_to_json.py): FETCH_SIZE is in KB
-    and, on gfx950, reports half of a wide coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE in KB.
-    Scaled per frame."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sdv_k_stc007_frames_lean.json")
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_sdv_k_stc007_frames_lean.json")
+
+
+def measured_hbm_traffic(frames_per_launch, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    command, made by tools/pmc_to_json.py): FETCH_SIZE is in KB and, on gfx950, reports half of a wide coalesced stream
+    (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE in KB.  Scaled per frame.  The profile names the sources and the
+    workload it was measured on: returns (traffic, None) when they are this run's, else (None, what the profile holds) - a
+    counter from another build or workload is reported as such, never as this run's traffic."""
+    path = os.path.join(ROOT, PMC_PROFILE)
     try:
+        from sdvpcmdecoder_amd.build import source_hash
         d = json.load(open(path))
         fetch = float(d["pmc3"]["FETCH_SIZE"]) * 1024.0 * 2.0
         write = float(d["pmc4"]["WRITE_SIZE"]) * 1024.0
-        return (fetch + write) / (float(d["pmc3"].get("grid_size", 640000)) / 64.0) * frames_per_launch
-    except Exception:
-        return None
+        per_launch = (fetch + write) / (float(d["pmc3"].get("grid_size", 640000)) / 64.0) * frames_per_launch
+        same = d.get("source_sha16") == source_hash() and d.get("workload") == workload and not os.environ.get("SDVPCM_LIB")
+        if same:
+            return per_launch, None
+        return None, {"bytes_per_launch": per_launch, "profile": PMC_PROFILE, "profile_source_sha16": d.get("source_sha16"),
+                      "profile_workload": d.get("workload"), "this_source_sha16": source_hash(), "this_workload": workload}
+    except Exception as ex:      # noqa: BLE001
+        return None, {"error": repr(ex), "profile": PMC_PROFILE}
 
 
 def cpu_baseline(luma_sample, mode):
@@ -105,6 +115,16 @@ def main():
     ap.add_argument("--no-stitch", action="store_true", help="skip the extra stitch-stage measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves - as fresh child processes, before this process
+        # has touched torch or the GPU - and pass rank 0's JSON line through
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -113,6 +133,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" in os.environ and world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): the two must agree")
     backend = os.environ.get("SDV_BENCH_BACKEND", "nccl")     # nccl = RCCL; "gloo" lets the N > 1 path be exercised on a 1-GPU box
     # SDV_BENCH_FORCE_DIST=1: run the sharded (collective) code path with a single rank too - lets the RCCL plumbing be exercised
     # on a 1-GPU box (torch.distributed.run --nproc-per-node 1)
@@ -319,6 +341,7 @@ def main():
         avg_launch_ms = kernel_ms / max(rounds, 1)
         frames_per_launch = launched / max(rounds, 1)
         achieved = (bpf * frames_per_launch) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic, stale = measured_hbm_traffic(frames_per_launch, f"frames={n},mode={args.mode},noise={args.noise},width={W},height={H}")
         out = {
             "metric": "decoded video frames/sec (720x486 STC-007), binarize+bit-extract+CRC, bit-exact vs CPU",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -331,11 +354,13 @@ def main():
                                     % (n * world, loop.redo)) if loop is not None else "single GPU",
                        "decoded_words_match_generator": words_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(frames_per_launch),
-                         "traffic_unit": "bytes per launch, from the rocprofv3 PMC passes committed under profiles/",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch, from the rocprofv3 PMC passes committed under profiles/ (same sources, same workload)",
                          "kernel": "sdv_k_stc007_frames_lean" if general == 0 else "sdv_k_stc007_frames_lean + sdv_k_stc007_frames", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_launch": bpf * frames_per_launch},
         }
+        if stale is not None:
+            out["roofline"]["traffic_from_committed_profile"] = stale
         if world == 1 and not args.no_stitch:
             # the boundary takes device pointers; a caller that keeps its frames in host memory pays this on top (never part of `value`)
             try:

@@ -62,7 +62,7 @@ int main(int argc, char **argv)
         if (!read_file(argv[2], in) || in.size() != (size_t)width * height * n) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
         uint8_t *d_luma = NULL; sdv_line_rec *d_lines = NULL; sdv_frame_stats *d_stats = NULL; sdv_frame_asm *d_frames = NULL;
         /* one file from its first to its last frame: NEW_FILE tag ahead, filler frame + END_FILE tag behind */
-        const size_t n_lines = (size_t)n * sdv_records_per_frame(height) + 1 + (size_t)height + 4;
+        const size_t n_lines = sdv_binarize_records(height, n, SDV_FLAG_NEW_FILE | SDV_FLAG_END_FILE);
         const size_t pairs_cap = n_lines * 4 + 8192, frames_cap = (size_t)n + 16;
         HIP_OK(hipMalloc((void **)&d_luma, in.size()));
         HIP_OK(hipMalloc((void **)&d_lines, n_lines * sizeof(sdv_line_rec)));
@@ -72,7 +72,7 @@ int main(int argc, char **argv)
         HIP_OK(hipMemcpy(d_luma, in.data(), in.size(), hipMemcpyHostToDevice));
         SDV_OKAY(sdv_set_mode(eng, SDV_MODE_NORMAL));
         SDV_OKAY(sdv_binarize_frames(eng, d_luma, (size_t)width, (size_t)width * height, width, height, n, 1,
-                                     SDV_FLAG_NEW_FILE | SDV_FLAG_END_FILE, d_lines, d_stats, NULL));
+                                     SDV_FLAG_NEW_FILE | SDV_FLAG_END_FILE, d_lines, n_lines, d_stats, (size_t)n + 1, NULL));
         sdv_stitch_settings st; sdv_default_stitch_settings(&st);
         SDV_OKAY(sdv_set_stitch_settings(eng, &st));
         SDV_OKAY(sdv_stitch_frames(eng, d_lines, n_lines, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_frames, NULL));

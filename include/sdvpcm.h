@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDV_ABI_VERSION 1
+#define SDV_ABI_VERSION 2   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines */
 
 /* ---- status codes ---------------------------------------------------------------------------
  * 0..4 mirror Binarizer::LB_RET_* (binarizer.h:268-275); 16.. mirror STC007Deinterleaver::DI_RET_*
@@ -227,7 +227,10 @@ typedef struct sdv_engine sdv_engine;
 /* ---- engine lifetime ------------------------------------------------------------------------ */
 /* Creates an engine bound to HIP device `device` (one engine per GPU / per process rank).
  * Replaces: construction of VideoToDigital + its member Binarizer (videotodigital.h:114,
- * videotodigital.cpp:3-25).  Returns NULL on failure; sdv_last_error(NULL) then holds the reason. */
+ * videotodigital.cpp:3-25).  Returns NULL on failure; sdv_last_error(NULL) then holds the reason
+ * (per calling thread).  Every entry point switches to its engine's device for the duration of the call and
+ * restores the caller's current device before it returns.  An engine is used by one thread at a time, like the
+ * reference's workers. */
 sdv_engine *sdv_engine_create(int device);
 void sdv_engine_destroy(sdv_engine *e);
 const char *sdv_last_error(const sdv_engine *e);
@@ -275,6 +278,8 @@ int sdv_set_profiling(sdv_engine *e, int on);
 
 /* records emitted per frame: `height` scanlines + 2 END_FIELD + 1 END_FRAME service lines */
 size_t sdv_records_per_frame(int height);
+/* records one sdv_binarize_frames call emits: n_frames * (height + 3), + 1 with SDV_FLAG_NEW_FILE, + height + 4 with SDV_FLAG_END_FILE */
+size_t sdv_binarize_records(int height, int n_frames, unsigned flags);
 
 /* ---- hot path: binarize + bit-extract + CRC for a batch of whole frames ------------------------
  * Replaces the body of VideoToDigital::doBinarize (videotodigital.cpp:698-1815) including every call
@@ -286,21 +291,23 @@ size_t sdv_records_per_frame(int height);
  *  luma         device pointer; frame f, row r at luma + f*frame_stride + r*row_stride, `width` bytes
  *               of 8-bit luma per row (the pixel_data of the reference's VideoLine, videoline.h:37-88).
  *               Rows should be 16-byte aligned for full-rate loads (any alignment is accepted).
- *  out_lines    device pointer, (height+3)*n_frames records (+1 leading NEW_FILE record with
+ *  out_lines    device pointer to lines_cap records; the call writes sdv_binarize_records(height, n_frames, flags) of them and
+ *               refuses (SDV_ERR_BAD_ARG, nothing written) when lines_cap is less: (height+3)*n_frames records (+1 leading NEW_FILE record with
  *               SDV_FLAG_NEW_FILE), in exactly the order VideoToDigital pushes STC007Line objects
  *               into its output queue: odd-field rows (line numbers 1,3,..), END_FIELD, even-field
  *               rows (2,4,..), END_FIELD, END_FRAME (vin_ffmpeg.cpp:281-350).  With SDV_FLAG_END_FILE height+4 more:
  *               the filler frame (frame number first_frame_no + n_frames): FILLER lines in the same field order, END_FIELD
  *               twice, END_FILE, END_FRAME.
- *  out_stats    device pointer, one FrameBinDescriptor per frame (signal guiUpdFrameBin); one more row with
+ *  out_stats    device pointer to stats_cap rows, one FrameBinDescriptor per frame (signal guiUpdFrameBin); one more row with
  *               SDV_FLAG_END_FILE (the worker reports the filler frame too).
+ *  frame_stride at least (height-1)*row_stride + width when n_frames > 1 (frames do not overlap), else SDV_ERR_BAD_ARG.
  *  stream       hipStream_t (NULL = default stream).  The call returns after the device work of the
  *               batch has been validated (it synchronises `stream` at least once).
  * Returns SDV_OK or an SDV_ERR_* code; invalid input is refused up front like the reference's early
  * returns (binarizer.cpp:465-478, 582-589). */
 int sdv_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
                         int n_frames, uint32_t first_frame_no, unsigned flags,
-                        sdv_line_rec *out_lines, sdv_frame_stats *out_stats, void *stream);
+                        sdv_line_rec *out_lines, size_t lines_cap, sdv_frame_stats *out_stats, size_t stats_cap, void *stream);
 
 /* ---- hot path: deinterleave + P/Q error correction for a batch of data blocks -------------------
  * Replaces STC007Deinterleaver::processBlock(line_shift) (stc007deinterleaver.cpp:286-1123) called for
@@ -382,11 +389,11 @@ typedef struct sdv_pcm1_bin_rec {
  * setDataCoordinates / setBWLevels, binarizer.cpp:240-377; all zero or presets == NULL: nothing preset); mode and fine settings are
  * the engine's (sdv_set_mode, sdv_set_bin_preset), coord_search is Binarizer::setCoordinatesSearch; flags: SDV_FLAG_DOUBLED.
  * Service lines and empty lines carry no pixels and are the caller's to pass through.  Returns SDV_ERR_SHORT_LINE for lines
- * under 94 px (LB_RET_SHORT_LINE), SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE (the reference level sweep of PCM-1 is not built).
+ * under 94 px (LB_RET_SHORT_LINE), SDV_ERR_BAD_ARG when out_lines (lines_cap records) cannot take n_lines, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE (the reference level sweep of PCM-1 is not built).
  * Device pointers; asynchronous on `stream`. */
 int sdv_pcm1_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_stride, int width, size_t n_lines,
                             const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
-                            unsigned flags, int coord_search, sdv_pcm1_bin_rec *out_lines, void *stream);
+                            unsigned flags, int coord_search, sdv_pcm1_bin_rec *out_lines, size_t lines_cap, void *stream);
 
 /* ---- PCM-1 back half: PCM1DataStitcher (pcm1datastitcher.h:94-201) ------------------------------------------------- */
 /* What PCM1DataStitcher reads of one PCM1Line (pcm1line.h:59-146, pcmline.h:137-186).  32 bytes. */
@@ -431,7 +438,9 @@ int sdv_set_pcm1_stitch_settings(sdv_engine *e, const sdv_pcm1_stitch_settings *
  * deinterleaved into 8 blocks per field (PCM1Deinterleaver::processBlock, pcm1deinterleaver.cpp:69-278; PCM-1 has no error
  * correction); 1470 PCMSamplePairs and one FrameAsmPCM1 per frame (plus the NEW_FILE / END_FILE tags).  Frames are
  * independent of each other in this format, so there is no stream state apart from records that wait for their END_FRAME.
- * Same conventions as sdv_stitch_frames (device pointers, counts returned, SDV_ERR_UNSUPPORTED for lines of foreign frames). */
+ * Same conventions as sdv_stitch_frames (device pointers, counts returned, SDV_ERR_UNSUPPORTED for lines of foreign frames).
+ * A call that fails leaves the stream untouched - the lines of the call are not taken, lines that waited still wait - so it
+ * can be repeated with the buffer sizes *n_pairs / *n_frames report. */
 int sdv_pcm1_stitch_frames(sdv_engine *e, const sdv_pcm1_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                            size_t *n_pairs, sdv_frame_asm_pcm1 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 

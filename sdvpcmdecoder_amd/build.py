@@ -15,6 +15,19 @@ ROOT = os.path.dirname(PKG)
 HIP_LIB = os.path.join(PKG, "libsdvpcm_hip.so")
 
 
+def source_hash():
+    """Identity of the HIP library's sources (csrc/ + the C-ABI header): profiles/ records it next to the counters they hold, and
+    bench.py only quotes a committed profile for the build that it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "sdvpcm.h")]:
+        path = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if os.path.isfile(path) and path.endswith((".h", ".hip", ".inc")):
+            h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, sources):
     if not os.path.exists(target):
         return True

@@ -91,6 +91,13 @@ class RunInfo(C.Structure):
 _lib = None
 
 
+def _check_out(t, rec_bytes, device, name):
+    """Caller-supplied output tensors: (n, rec_bytes) uint8, contiguous, on the frames' device."""
+    import torch
+    if not (t.is_cuda and t.device == device and t.dtype == torch.uint8 and t.dim() == 2 and t.shape[1] == rec_bytes and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous torch.uint8 CUDA tensor of shape (n, {rec_bytes}) on {device}")
+
+
 def load_library(path: str | None = None):
     """Loads libsdvpcm_hip.so. Raises (never falls back) when the HIP extension is not built."""
     global _lib
@@ -121,7 +128,12 @@ def load_library(path: str | None = None):
     lib.sdv_records_per_frame.argtypes = [C.c_int]
     lib.sdv_binarize_frames.restype = C.c_int
     lib.sdv_binarize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
-                                        C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+                                        C.c_uint32, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.sdv_binarize_records.restype = C.c_size_t
+    lib.sdv_binarize_records.argtypes = [C.c_int, C.c_int, C.c_uint]
+    lib.sdv_pcm1_binarize_lines.restype = C.c_int
+    lib.sdv_pcm1_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16,
+                                            C.c_uint16, C.c_uint, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_default_deint_settings.argtypes = [C.POINTER(DeintSettings)]
     lib.sdv_deinterleave_blocks.restype = C.c_int
     lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DeintSettings), C.c_void_p, C.c_size_t,
@@ -333,15 +345,14 @@ class Engine:
             assert presets.is_cuda and presets.dtype == torch.uint8 and presets.shape == (n, 10) and presets.is_contiguous()
         if out_lines is None:
             out_lines = torch.empty((n, 40), dtype=torch.uint8, device=luma.device)
+        _check_out(out_lines, 40, luma.device, "out_lines")
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
-        f = self.lib.sdv_pcm1_binarize_lines
-        f.restype = C.c_int
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint, C.c_int,
-                      C.c_void_p, C.c_void_p]
-        rc = f(self._h, C.c_void_p(luma.data_ptr()), luma.stride(0), w, n, None if presets is None else C.c_void_p(presets.data_ptr()),
-               frame_number, first_line, line_step, FLAG_DOUBLED if doubled else 0, 1 if coord_search else 0, C.c_void_p(out_lines.data_ptr()), sptr)
+        rc = self.lib.sdv_pcm1_binarize_lines(self._h, C.c_void_p(luma.data_ptr()), luma.stride(0), w, n,
+                                              None if presets is None else C.c_void_p(presets.data_ptr()), frame_number, first_line, line_step,
+                                              FLAG_DOUBLED if doubled else 0, 1 if coord_search else 0, C.c_void_p(out_lines.data_ptr()),
+                                              out_lines.shape[0], sptr)
         self._check(rc)
-        return out_lines
+        return out_lines[:n]
 
     # ---- batch replacement of doBinarize ----
     def records_per_frame(self, height: int) -> int:
@@ -357,12 +368,16 @@ class Engine:
         nrec = n * (h + 3) + (1 if new_file else 0) + (h + 4 if end_file else 0)      # end_file: the filler frame that closes a source
         if out_lines is None:
             out_lines = torch.empty((nrec, 48), dtype=torch.uint8, device=luma.device)
+        nst = n + (1 if end_file else 0)
         if out_stats is None:
-            out_stats = torch.empty((n + (1 if end_file else 0), 32), dtype=torch.uint8, device=luma.device)
+            out_stats = torch.empty((nst, 32), dtype=torch.uint8, device=luma.device)
+        _check_out(out_lines, 48, luma.device, "out_lines")
+        _check_out(out_stats, 32, luma.device, "out_stats")
         flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0) | (FLAG_END_FILE if end_file else 0)
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        # the library checks the capacities against what the call will write (SDV_ERR_BAD_ARG when a buffer is too small)
         rc = self.lib.sdv_binarize_frames(self._h, C.c_void_p(luma.data_ptr()), luma.stride(1), luma.stride(0), w, h, n,
-                                          first_frame_no, flags, C.c_void_p(out_lines.data_ptr()),
-                                          C.c_void_p(out_stats.data_ptr()), sptr)
+                                          first_frame_no, flags, C.c_void_p(out_lines.data_ptr()), out_lines.shape[0],
+                                          C.c_void_p(out_stats.data_ptr()), out_stats.shape[0], sptr)
         self._check(rc)
-        return out_lines, out_stats
+        return out_lines[:nrec], out_stats[:nst]

@@ -41,7 +41,7 @@ def bind(lib):
     lib.sdv_records_per_frame.argtypes = [C.c_int]
     lib.sdv_binarize_frames.restype = C.c_int
     lib.sdv_binarize_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
-                                        C.c_uint32, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+                                        C.c_uint32, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     import deint_api as da
     lib.sdv_deinterleave_blocks.restype = C.c_int
     lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(da.DeintSettings), C.c_void_p, C.c_size_t, C.c_void_p]
@@ -108,13 +108,13 @@ def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1, row_stride=None, mis
         nrec = n * (h + 3) + (1 if flags & 1 else 0) + (h + 4 if flags & 4 else 0)
         recs = np.zeros(nrec, dtype=libs.LINE_DTYPE)
         stats = np.zeros(n + (1 if flags & 4 else 0), dtype=STATS_DTYPE)
-        rc = lib.sdv_binarize_frames(eng, buf.ctypes.data + misalign, rs, rs * h, w, h, n, first_frame_no, flags, recs.ctypes.data,
-                                     stats.ctypes.data, None)
+        rc = lib.sdv_binarize_frames(eng, buf.ctypes.data + misalign, rs, rs * h, w, h, n, first_frame_no, flags, recs.ctypes.data, len(recs),
+                                     stats.ctypes.data, len(stats), None)
         return rc, recs, stats
     nrec = n * (h + 3) + (1 if flags & 1 else 0) + (h + 4 if flags & 4 else 0)
     recs = np.zeros(nrec, dtype=libs.LINE_DTYPE)
     stats = np.zeros(n + (1 if flags & 4 else 0), dtype=STATS_DTYPE)
     luma = np.ascontiguousarray(luma)
-    rc = lib.sdv_binarize_frames(eng, luma.ctypes.data, w, w * h, w, h, n, first_frame_no, flags, recs.ctypes.data,
-                                 stats.ctypes.data, None)
+    rc = lib.sdv_binarize_frames(eng, luma.ctypes.data, w, w * h, w, h, n, first_frame_no, flags, recs.ctypes.data, len(recs),
+                                 stats.ctypes.data, len(stats), None)
     return rc, recs, stats

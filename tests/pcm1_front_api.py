@@ -123,7 +123,7 @@ def run_engine_lines(lib, eng, luma, states=None, mode=1, coord_search=True, pre
     f = lib.sdv_pcm1_binarize_lines
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint, C.c_int,
-                  C.c_void_p, C.c_void_p]
+                  C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_set_mode(eng, mode)
     lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.c_void_p]
@@ -133,7 +133,7 @@ def run_engine_lines(lib, eng, luma, states=None, mode=1, coord_search=True, pre
     out = np.zeros(luma.shape[0], dtype=BIN1_DTYPE)
     st = None if states is None else np.ascontiguousarray(states)
     rc = f(eng, luma.ctypes.data, luma.shape[1], luma.shape[1], luma.shape[0], None if st is None else st.ctypes.data, frame, first_line, line_step,
-           2 if doubled else 0, 1 if coord_search else 0, out.ctypes.data, None)
+           2 if doubled else 0, 1 if coord_search else 0, out.ctypes.data, len(out), None)
     return rc, out
 
 

@@ -28,7 +28,8 @@ def test_product_library_exports_all_symbols():
     for s in declared_symbols():
         assert hasattr(lib, s), f"libsdvpcm_hip.so does not export {s}"
     lib.sdv_abi_version.restype = C.c_int
-    assert lib.sdv_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "sdvpcm.h")).read()
+    assert lib.sdv_abi_version() == int(re.search(r"#define SDV_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_no_cpu_fallback_without_gpu():

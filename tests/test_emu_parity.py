@@ -195,8 +195,16 @@ def test_emu_bad_arguments(emu_lib):
     recs = np.zeros(11, dtype=libs.LINE_DTYPE)
     st = np.zeros(32, np.uint8)
     f = emu_lib.sdv_binarize_frames
-    assert f(eng, None, 200, 1600, 200, 8, 1, 1, 0, recs.ctypes.data, st.ctypes.data, None) == 1      # SDV_ERR_NULL_VIDEO
-    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 1, 1, 0, None, st.ctypes.data, None) == 2         # SDV_ERR_NULL_PCM
-    assert f(eng, buf.ctypes.data, 100, 800, 100, 8, 1, 1, 0, recs.ctypes.data, st.ctypes.data, None) == 3  # SHORT_LINE
-    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 0, 1, 0, recs.ctypes.data, st.ctypes.data, None) == -1  # BAD_ARG
+    assert f(eng, None, 200, 1600, 200, 8, 1, 1, 0, recs.ctypes.data, 11, st.ctypes.data, 1, None) == 1      # SDV_ERR_NULL_VIDEO
+    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 1, 1, 0, None, 11, st.ctypes.data, 1, None) == 2         # SDV_ERR_NULL_PCM
+    assert f(eng, buf.ctypes.data, 100, 800, 100, 8, 1, 1, 0, recs.ctypes.data, 11, st.ctypes.data, 1, None) == 3  # SHORT_LINE
+    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 0, 1, 0, recs.ctypes.data, 11, st.ctypes.data, 1, None) == -1  # BAD_ARG
+    # the output capacities are checked against what the call will write (NEW_FILE: one more record)
+    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 1, 1, 1, recs.ctypes.data, 11, st.ctypes.data, 1, None) == -1
+    assert b"12 line records" in emu_lib.sdv_last_error(eng)
+    assert f(eng, buf.ctypes.data, 200, 1600, 200, 8, 1, 1, 0, recs.ctypes.data, 11, st.ctypes.data, 0, None) == -1
+    # frames of a batch must not overlap
+    buf2 = np.zeros((2, 8, 200), np.uint8); recs2 = np.zeros(22, dtype=libs.LINE_DTYPE); st2 = np.zeros(64, np.uint8)
+    assert f(eng, buf2.ctypes.data, 200, 1000, 200, 8, 2, 1, 0, recs2.ctypes.data, 22, st2.ctypes.data, 2, None) == -1
+    assert b"frame_stride" in emu_lib.sdv_last_error(eng)
     emu_lib.sdv_engine_destroy(eng)

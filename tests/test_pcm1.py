@@ -144,6 +144,23 @@ def test_emu_edge_inputs(emu, oracle_lib):
     emu.sdv_engine_destroy(eng)
 
 
+def test_emu_failed_call_leaves_the_stream_untouched(emu, oracle_lib):
+    """A call that is refused (buffers too small) takes nothing: lines that waited for their END_FRAME still wait and the same
+    lines can be handed over again."""
+    recs, st, want_p, want_f = _oracle("file_marks")
+    eng = emu.sdv_engine_create(0)
+    cut = 700                                                                            # inside the second frame
+    rc, p0, f0 = ea.emu_pcm1_stitch(emu, eng, recs[:cut], st, pair_cap=8000, frame_cap=16)
+    assert rc == 0 and len(f0) >= 1
+    rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs[cut:], None, pair_cap=100, frame_cap=16)
+    assert rc != 0 and b"too small" in emu.sdv_last_error(eng)
+    rc, p1_, f1 = ea.emu_pcm1_stitch(emu, eng, recs[cut:], None, pair_cap=8000, frame_cap=16)   # the same lines again
+    assert rc == 0
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate([p0, p1_]), np.concatenate([f0, f1])
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
 def test_emu_rejects_what_the_reference_handles_with_leftover_state(emu):
     """Lines of a later frame queued ahead of an END_FRAME stay in the reference's queue for a later turn: not a per-frame job."""
     recs, st = p1.make_input("clean")
