@@ -97,7 +97,7 @@ int orc_bin_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16
 #include "bin_pcm1.h"
 typedef struct { orc_binarizer bin; orc_video_line vl; orc_p1_line out; } orc_bin1_handle;
 
-static void p1_line_to_rec(const orc_p1_line *l, sdv_pcm1_bin_rec *r)
+void orc_p1_line_to_rec(const orc_p1_line *l, sdv_pcm1_bin_rec *r)
 {
     memset(r, 0, sizeof(*r));
     r->frame_number = l->frame_number; r->line_number = l->line_number;
@@ -142,7 +142,7 @@ int orc_bin1_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint1
     h->bin.video_line = &h->vl;
     h->bin.out_pcm_line = NULL;
     int ret = orc_binarizer_process_line_p1(&h->bin, &h->out);
-    p1_line_to_rec(&h->out, out);
+    orc_p1_line_to_rec(&h->out, out);
     return ret;
 }
 
@@ -226,6 +226,44 @@ void orc_v2d_get_state(void *vv, sdv_v2d_state *s)
         if (v->long_valid_coords.v[i].from_doubled) m |= (uint16_t)(1u << i);
     }
     s->long_valid_doubled_mask = m;
+}
+
+/* ------------------------------------------------------------------ VideoToDigital level, PCM-1 (v2d_p1.c) */
+#include "v2d_p1.h"
+void *orc_v2d1_new(void) { orc_v2d1 *v = (orc_v2d1 *)malloc(sizeof(orc_v2d1)); orc_v2d1_init(v); return v; }
+void orc_v2d1_delete(void *v) { orc_v2d1_free((orc_v2d1 *)v); free(v); }
+void orc_v2d1_set_mode(void *v, int mode) { if (mode >= 0 && mode < 4) ((orc_v2d1 *)v)->binarization_mode = (uint8_t)mode; }
+void orc_v2d1_set_check_line_dup(void *v, int on) { ((orc_v2d1 *)v)->check_line_copy = on != 0; }
+void orc_v2d1_set_preset(void *vv, const sdv_bin_preset *p)
+{
+    orc_bin_preset s; orc_bin_preset_reset(&s);
+    s.max_black_lvl = p->max_black_lvl; s.min_white_lvl = p->min_white_lvl; s.min_contrast = p->min_contrast;
+    s.min_ref_lvl = p->min_ref_lvl; s.max_ref_lvl = p->max_ref_lvl; s.min_valid_crcs = p->min_valid_crcs;
+    s.mark_max_dist = p->mark_max_dist; s.left_bit_pick = p->left_bit_pick; s.right_bit_pick = p->right_bit_pick;
+    s.en_force_coords = p->en_force_coords; s.en_coord_search = p->en_coord_search;
+    s.en_first_line_dup = p->en_first_line_dup; s.en_good_no_marker = p->en_good_no_marker;
+    s.horiz_coords.data_start = p->horiz_start; s.horiz_coords.data_stop = p->horiz_stop;
+    orc_v2d1_set_fine_settings((orc_v2d1 *)vv, &s);
+}
+/* n_frames consecutive PCM-1 frames through the worker; new_file bit 0: NEW_FILE line first, bit 1: the filler frame + END_FILE
+ * follow (height + 4 more records, one more stats row).  Returns the records written. */
+long orc_v2d1_run(void *vv, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                  int new_file, int doubled, sdv_pcm1_bin_rec *out, sdv_frame_stats *stats)
+{
+    orc_v2d1 *v = (orc_v2d1 *)vv;
+    long n = 0;
+    for (int f = 0; f < n_frames; f++) {
+        orc_frame_stats q;
+        n += orc_v2d1_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
+                            (new_file & 1) && f == 0, doubled != 0, false, out + n, &q);
+        if (stats) stats_to_pod(&q, &stats[f]);
+    }
+    if (new_file & 2) {
+        orc_frame_stats q;
+        n += orc_v2d1_frame(v, NULL, 0, width, height, first_frame_no + (uint32_t)n_frames, false, false, true, out + n, &q);
+        if (stats) stats_to_pod(&q, &stats[n_frames]);
+    }
+    return n;
 }
 
 /* ------------------------------------------------------------------ deinterleaver level */

@@ -146,17 +146,18 @@ int ref_bin_process(void *h, const uint8_t *px, int len, uint32_t frame, uint16_
 #include <QObject>
 #include "videotodigital.h"
 
-struct RefV2D {
+template <class LineT> struct RefV2DT {
     VideoToDigital v2d;
     std::deque<VideoLine> in_q;
-    std::deque<STC007Line> out_q;
+    std::deque<LineT> out_q;
     QMutex in_mtx, out_mtx;
     std::deque<FrameBinDescriptor> stats_q;
     QMutex stats_mtx;
     std::thread th;
     bool started;
-    RefV2D() : started(false) {}
+    RefV2DT() : started(false) {}
 };
+typedef RefV2DT<STC007Line> RefV2D;
 
 static void stats_to_pod(FrameBinDescriptor &q, sdv_frame_stats *s)
 {
@@ -192,9 +193,11 @@ void ref_v2d_delete(void *h)
 void ref_v2d_set_mode(void *h, int mode) { ((RefV2D *)h)->v2d.setBinarizationMode((uint8_t)mode); }
 void ref_v2d_set_check_line_dup(void *h, int on) { ((RefV2D *)h)->v2d.setCheckLineDup(on != 0); }
 void ref_v2d_set_m2(void *h, int on) { ((RefV2D *)h)->v2d.setPCMType(on ? VideoToDigital::TYPE_M2 : VideoToDigital::TYPE_STC007); }
-void ref_v2d_set_preset(void *h, const sdv_bin_preset *p)
+static bin_preset_t to_bin_preset(const sdv_bin_preset *p);
+void ref_v2d_set_preset(void *h, const sdv_bin_preset *p) { ((RefV2D *)h)->v2d.setFineSettings(to_bin_preset(p)); }
+}
+static bin_preset_t to_bin_preset(const sdv_bin_preset *p)
 {
-    RefV2D *r = (RefV2D *)h;
     bin_preset_t s;
     s.max_black_lvl = p->max_black_lvl; s.min_white_lvl = p->min_white_lvl; s.min_contrast = p->min_contrast;
     s.min_ref_lvl = p->min_ref_lvl; s.max_ref_lvl = p->max_ref_lvl; s.min_valid_crcs = p->min_valid_crcs;
@@ -202,8 +205,9 @@ void ref_v2d_set_preset(void *h, const sdv_bin_preset *p)
     s.en_force_coords = p->en_force_coords; s.en_coord_search = p->en_coord_search;
     s.en_first_line_dup = p->en_first_line_dup; s.en_good_no_marker = p->en_good_no_marker;
     s.horiz_coords.data_start = p->horiz_start; s.horiz_coords.data_stop = p->horiz_stop;
-    r->v2d.setFineSettings(s);
+    return s;
 }
+extern "C" {
 
 static void push_service(std::deque<VideoLine> &q, int kind, uint32_t frame, uint16_t line)
 {
@@ -217,18 +221,20 @@ static void push_service(std::deque<VideoLine> &q, int kind, uint32_t frame, uin
     q.push_back(s);
 }
 
+} /* extern "C" */
+
 /* Feeds n_frames frames in VideoInFFMPEG::spliceFrame order (vin_ffmpeg.cpp:213-364) through the REAL
  * VideoToDigital worker loop and collects its STC007Line output and FrameBinDescriptor emissions. */
-long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
-                 int new_file, int doubled, sdv_line_rec *out, sdv_frame_stats *stats)
+template <class LineT, class RecT>
+static long v2d_run_t(RefV2DT<LineT> *r, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                      int new_file, int doubled, RecT *out, sdv_frame_stats *stats, void (*to_rec)(LineT &, RecT *), int recs_per_line)
 {
-    RefV2D *r = (RefV2D *)h;
     if (!r->started) { r->started = true; r->th = std::thread([r]() { r->v2d.doBinarize(); }); }
     const bool end_file = (new_file & 2) != 0;       /* bit 1: append VideoInFFMPEG::insertDummyFrame(true, false) */
     new_file &= 1;
     const int n_real = n_frames;
     if (end_file) n_frames++;
-    long expect = (long)n_real * (height + 3) + (new_file ? 1 : 0) + (end_file ? height + 4 : 0);
+    long expect = (long)n_real * ((long)height * recs_per_line + 3) + (new_file ? 1 : 0) + (end_file ? height + 4 : 0);
     long got = 0; int fed = 0; int nstats = 0;
     while (got < expect || nstats < n_frames) {
         /* keep a few frames queued */
@@ -286,7 +292,7 @@ long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int hei
         }
         /* drain */
         r->out_mtx.lock();
-        while (!r->out_q.empty() && got < expect) { line_to_rec(r->out_q.front(), &out[got++]); r->out_q.pop_front(); }
+        while (!r->out_q.empty() && got < expect) { to_rec(r->out_q.front(), &out[got++]); r->out_q.pop_front(); }
         r->out_mtx.unlock();
         r->stats_mtx.lock();
         while (!r->stats_q.empty() && nstats < n_frames) { if (stats) stats_to_pod(r->stats_q.front(), &stats[nstats]); nstats++; r->stats_q.pop_front(); }
@@ -296,7 +302,12 @@ long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int hei
     return got;
 }
 
-} /* extern "C" */
+extern "C" long ref_v2d_run(void *h, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                            int new_file, int doubled, sdv_line_rec *out, sdv_frame_stats *stats)
+{
+    return v2d_run_t<STC007Line, sdv_line_rec>((RefV2D *)h, luma, stride, width, height, n_frames, first_frame_no, new_file, doubled, out, stats, line_to_rec, 1);
+}
+
 
 /* ------------------------------------------------------------------ deinterleaver level */
 static void block_to_rec(STC007DataBlock &b, sdv_block_rec *r)
@@ -642,4 +653,34 @@ extern "C" long ref_pcm1_stitch_run(const sdv_pcm1_line_rec *recs, size_t n_recs
     if (n_frames) *n_frames = fr.size();
     delete ds;
     return overflow ? -1 : got;
+}
+
+/* ---- PCM-1 frames through the real VideoToDigital worker (setPCMType(TYPE_PCM1)), PCM1Line queue drained ------------------- */
+typedef RefV2DT<PCM1Line> RefV2D1;
+extern "C" {
+void *ref_v2d1_new(void)
+{
+    RefV2D1 *r = new RefV2D1();
+    r->v2d.setInputPointers(&r->in_q, &r->in_mtx);
+    r->v2d.setOutPCM1Pointers(&r->out_q, &r->out_mtx);
+    r->v2d.setPCMType(VideoToDigital::TYPE_PCM1);
+    QObject::connect(&r->v2d, &VideoToDigital::guiUpdFrameBin, [r](FrameBinDescriptor d) {
+        r->stats_mtx.lock(); r->stats_q.push_back(d); r->stats_mtx.unlock();
+    });
+    return r;
+}
+void ref_v2d1_delete(void *h)
+{
+    RefV2D1 *r = (RefV2D1 *)h;
+    if (r->started) { r->v2d.stop(); r->th.join(); }
+    delete r;
+}
+void ref_v2d1_set_mode(void *h, int mode) { ((RefV2D1 *)h)->v2d.setBinarizationMode((uint8_t)mode); }
+void ref_v2d1_set_check_line_dup(void *h, int on) { ((RefV2D1 *)h)->v2d.setCheckLineDup(on != 0); }
+void ref_v2d1_set_preset(void *h, const sdv_bin_preset *p) { ((RefV2D1 *)h)->v2d.setFineSettings(to_bin_preset(p)); }
+long ref_v2d1_run(void *h, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                  int new_file, int doubled, sdv_pcm1_bin_rec *out, sdv_frame_stats *stats)
+{
+    return v2d_run_t<PCM1Line, sdv_pcm1_bin_rec>((RefV2D1 *)h, luma, stride, width, height, n_frames, first_frame_no, new_file, doubled, out, stats, p1_line_to_rec, 1);
+}
 }

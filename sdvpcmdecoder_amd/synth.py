@@ -436,3 +436,38 @@ def pcm1_tape(n_frames, seed=5, period=100, **kw):
     recs = np.concatenate(tiles)
     ends = np.nonzero(recs["service_type"] == 5)[0]
     return recs[:ends[n_frames - 1] + 1]
+
+
+def pcm1_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 486, x0: int = 4, x1: int | None = None,
+                header: int = 1, top_blank: int = 0, jitter: int = 0, p_dropout: float = 0.0, dup_every: int = 0,
+                silent_from: int | None = None, **kw):
+    """Synthetic PCM-1 video frames: every row of a field is one PCM-1 line (random 13-bit words, CRCC), the first `header`
+    PCM rows of a field carry the Header pattern (pcm1line.cpp:314-323), `top_blank` rows above them are black.
+    `jitter` = per-line horizontal shift of up to +-jitter px, `p_dropout` = share of rows replaced by black,
+    `dup_every` = every that-many-th row repeats the row above it in its field (a dropout compensator at work),
+    `silent_from` = frames from that index on carry silence.  Further keywords go to render_lines (black, white, noise_sigma,
+    blur).  Returns (luma (n_frames, height, width) u8, words (n_frames * height, 7) u16 in row order)."""
+    rng = np.random.default_rng(seed)
+    n = n_frames * height
+    words = rng.integers(0, 1 << 13, size=(n, 6), dtype=np.uint32)
+    if silent_from is not None:
+        words[silent_from * height:] = 0
+    crc = pcm1_crc_words(words).astype(np.uint32)
+    row = np.arange(n) % height
+    in_field = row // 2                                      # position of the row in its field
+    is_header = (in_field >= top_blank) & (in_field < top_blank + header)
+    words[is_header] = np.array([0x0666, 0x0CCC, 0x1999, 0x1333, 0x0666, 0x0CCC], dtype=np.uint32)
+    crc[is_header] = 0xCCCC
+    if dup_every:
+        src = np.arange(n)
+        dup = (in_field % dup_every == dup_every - 1) & (in_field >= top_blank + header + 1)
+        src[dup] -= 2
+        words, crc = words[src], crc[src]
+    w7 = np.concatenate([words, crc[:, None]], axis=1).astype(np.uint16)
+    shift = rng.integers(-jitter, jitter + 1, size=n) if jitter else None
+    luma = render_lines(pcm1_line_bits(w7), width=width, x0=x0, x1=(width - 4 if x1 is None else x1), shift=shift, rng=rng, **kw)
+    black = kw.get("black", 30)
+    luma[in_field < top_blank] = black
+    if p_dropout > 0:
+        luma[rng.random(n) < p_dropout] = black
+    return luma.reshape(n_frames, height, width), w7
