@@ -395,6 +395,17 @@ int sdv_pcm1_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_strid
                             const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
                             unsigned flags, int coord_search, sdv_pcm1_bin_rec *out_lines, size_t lines_cap, void *stream);
 
+/* VideoToDigital::doBinarize (videotodigital.cpp:698-1815) with setPCMType(TYPE_PCM1) for a batch of whole frames: the frame prescan
+ * of the data coordinates (prescanCoordinates, :148-345; every mode but DRAFT), every line through Binarizer::processLine with
+ * what the lines before it left preset, the coordinate-search switch of the real-time modes (:853-884), Header lines, duplicate-line
+ * detection, coordinate damper and frame statistics.  Arguments, record order (one sdv_pcm1_bin_rec per video line and service line),
+ * flags, capacities, stream state (sdv_reset_stream / sdv_get_chain_state / sdv_set_chain_state) and error codes as for
+ * sdv_binarize_frames; SDV_ERR_SHORT_LINE under 94 px, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE.  out_lines is what the worker pushes
+ * into the deque<PCM1Line> that PCM1DataStitcher reads (sdv_pcm1_lines_from_bin converts it into sdv_pcm1_stitch_frames' input). */
+int sdv_pcm1_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
+                             int n_frames, uint32_t first_frame_no, unsigned flags,
+                             sdv_pcm1_bin_rec *out_lines, size_t lines_cap, sdv_frame_stats *out_stats, size_t stats_cap, void *stream);
+
 /* ---- PCM-1 back half: PCM1DataStitcher (pcm1datastitcher.h:94-201) ------------------------------------------------- */
 /* What PCM1DataStitcher reads of one PCM1Line (pcm1line.h:59-146, pcmline.h:137-186).  32 bytes. */
 typedef struct sdv_pcm1_line_rec {

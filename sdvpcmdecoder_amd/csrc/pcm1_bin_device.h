@@ -538,26 +538,13 @@ __device__ inline void stage_row(uint8_t *px, const uint8_t *row, int width)
     __syncthreads();
 }
 
-/* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, a line with pixels (service lines and empty lines are the
- * caller's: they carry no pixels and are not sent to the device) */
-__device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
+/* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, for the video line staged in lds.w.px: the stage machine from
+ * what the caller has preset on its Binarizer (`b`: in_black / in_white / in_ref / in_coord, limits by mode) to the finished line.
+ * A pure function of the pixels, the presets, the mode and the fine settings. */
+__device__ inline void process_line_p1(BinCtx &c, const Bin &b, bool coord_search, P1Lds &lds, L1 &out, bool vl_doubled)
 {
-    const int lane = lane_id();
-    stage_row(lds.w.px, a.luma + li * a.row_stride, a.width);
-
-    BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
-    c.force_bit_picker = true;      /* the Binarizer is constructed with it set (binarizer.cpp:82) and nothing clears it */
-    Bin b;                          /* the presets, in the form the shared helpers take */
-    b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
-    if (a.states) {
-        const sdv_bin_state s = a.states[li];
-        b.in_black = s.in_def_black; b.in_white = s.in_def_white; b.in_ref = s.in_def_reference;
-        b.in_coord.start = s.in_def_start; b.in_coord.stop = s.in_def_stop; b.in_coord.doubled = s.in_def_from_doubled != 0;
-    }
-    bin_set_mode(b, a.mode);
-    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0; b.do_ref_lvl_sweep = false;
-    L1 out; p1_clear(out);
-    out.coords.doubled = a.doubled != 0;
+    p1_clear(out);
+    out.coords.doubled = vl_doubled;
     if (c.scan_end > c.scan_start && P1_BITS <= (c.scan_end - c.scan_start)) { out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end; }   /* setSourcePixels */
     coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
     Coords forced; calc_forced_coords(b, c.ps, forced);
@@ -595,7 +582,7 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
                 else {
                     if (!coords_valid(b.in_coord)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
                     else out.coords = b.in_coord;
-                    if (c.ps.en_coord_search && a.coord_search) find_pcm1_coordinates(c, out, lds, b.in_coord, hyst_lim, shift_lim);
+                    if (c.ps.en_coord_search && coord_search) find_pcm1_coordinates(c, out, lds, b.in_coord, hyst_lim, shift_lim);
                 }
                 if (!out.coords_set) { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN; }
                 else { hyst_lim = b.in_max_hyst; shift_lim = b.in_max_shift; }
@@ -626,6 +613,27 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
         }
         if (stage_count > STG_MAX) break;
     }
+}
+
+/* one line of sdv_pcm1_binarize_lines (service lines and empty lines are the caller's: they carry no pixels and are not sent to the
+ * device) */
+__device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
+{
+    stage_row(lds.w.px, a.luma + li * a.row_stride, a.width);
+
+    BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
+    c.force_bit_picker = true;      /* the Binarizer is constructed with it set (binarizer.cpp:82) and nothing clears it */
+    Bin b;                          /* the presets, in the form the shared helpers take */
+    b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
+    if (a.states) {
+        const sdv_bin_state s = a.states[li];
+        b.in_black = s.in_def_black; b.in_white = s.in_def_white; b.in_ref = s.in_def_reference;
+        b.in_coord.start = s.in_def_start; b.in_coord.stop = s.in_def_stop; b.in_coord.doubled = s.in_def_from_doubled != 0;
+    }
+    bin_set_mode(b, a.mode);
+    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0; b.do_ref_lvl_sweep = false;
+    L1 out;
+    process_line_p1(c, b, a.coord_search != 0, lds, out, a.doubled != 0);
     emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[li]);
 }
 

@@ -1,0 +1,483 @@
+/*
+ * pcm1_frames_device.h - PCM-1 frame driver: the PCM-1 branch of VideoToDigital::doBinarize (videotodigital.cpp:698-1815) and
+ * VideoToDigital::prescanCoordinates (:148-345) around the PCM-1 line binarizer of pcm1_bin_device.h (SURVEY.md section 8 row
+ * a11 for PCM-1).
+ *
+ * Two kernels per round:
+ *   sdv_k_pcm1_prescan   one wave per (frame, prescan line): the four lines the worker decodes from scratch before every frame
+ *                        (all modes but DRAFT) to find the frame's data coordinates and reference level.  The worker resets its
+ *                        Binarizer first, so the result is a pure function of the pixels - all frames of a batch at once.
+ *   sdv_k_pcm1_frames    one wave per frame, the pattern of the STC-007 frame kernel: the lines of a frame one after the other
+ *                        in VideoInFFMPEG::spliceFrame order, every line decoded from what the lines before it left preset on the
+ *                        Binarizer (setGoodParameters / setDataCoordinates / setBWLevels), with the per-line bookkeeping of the
+ *                        worker (Header lines, duplicate-line detection, coordinate damper, statistics).  Frames run in parallel
+ *                        from predicted incoming states; every frame checks the link to its successor itself (stc007_device.h,
+ *                        v2d_store_state) and the host repeats the frames behind broken links (pcm1_frames_engine.inc).
+ */
+#pragma once
+#include "pcm1_bin_device.h"
+
+namespace sdvp1f {
+using namespace sdv;
+using namespace sdvp1b;
+
+enum { COORD_CHECK_LINES = 4, COORD_CHECK_PARTS = COORD_CHECK_LINES + 2 };      /* videotodigital.h:101-102 */
+enum { P1_LINES_PF = 245 };                                                     /* PCM1DataStitcher::LINES_PF, pcm1datastitcher.h:103 */
+
+struct PrescanRes { int16_t start, stop; uint8_t ref, valid, pad[2]; };         /* one prescan line: the coordinates and level it read valid with */
+
+struct FrameArgs1 {
+    FrameArgs f;                    /* geometry, flags, states, stats, scratch as for STC-007 (f.recs unused) */
+    sdv_pcm1_bin_rec *recs1;        /* frame k: recs1 + k*(height+3) (+1 behind the NEW_FILE frame) */
+    PrescanRes *prescan;            /* [n_total][COORD_CHECK_LINES] */
+};
+
+/* sdv_v2d_state::_pad[1] carries prescan_ref (videotodigital.cpp:703, 730: a local of the worker, 128 at its start) as its distance
+ * from 128, so that an all-zero pad is the fresh worker for every format */
+__device__ __forceinline__ uint8_t prescan_ref_of(const sdv_v2d_state &s) { return (uint8_t)(s._pad[1] ^ 128); }
+
+/* lines in the frame buffer of frame f (waitForOneFrame, :84-145): the rows, END_FIELD twice, END_FRAME, the NEW_FILE line in
+ * front of a file's first frame, END_FILE in the filler frame behind its last */
+__device__ __forceinline__ int frame_buf_lines(const FrameArgs &a, int f) { return a.height + 3 + (f == a.new_file_frame ? 1 : 0) + (f == a.end_file_frame ? 1 : 0); }
+/* does the worker prescan frame f? (prescanCoordinates :171-200, called in every mode but DRAFT, :796-801) */
+__device__ __forceinline__ bool prescan_runs(const FrameArgs &a, int f)
+{
+    return !a.preset.en_force_coords && a.mode != SDV_MODE_DRAFT && frame_buf_lines(a, f) > COORD_CHECK_PARTS;
+}
+/* row of the picture at index i of frame f's buffer, or -1 for a service line */
+__device__ inline int frame_buf_row(const FrameArgs &a, int f, int i)
+{
+    if (f == a.end_file_frame) return -1;                   /* FILLER lines carry no pixels */
+    if (f == a.new_file_frame) { if (i == 0) return -1; i--; }
+    const int n0 = (a.height + 1) / 2, n1 = a.height / 2;
+    if (i < n0) return 2 * i;
+    i -= n0 + 1;
+    if (i >= 0 && i < n1) return 2 * i + 1;
+    return -1;
+}
+
+__device__ inline void ctx_for_line(const FrameArgs &a, BinCtx &c, Bin &b)
+{
+    c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
+    c.force_bit_picker = true;      /* binarizer.cpp:82 */
+    bin_set_mode(b, a.mode);
+    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0; b.do_ref_lvl_sweep = false;
+}
+
+/* ---- prescan: block = (frame, k) ------------------------------------------------------------------------------------------ */
+__device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int k)
+{
+    const FrameArgs &a = a1.f;
+    PrescanRes r; r.start = r.stop = 0; r.ref = 0; r.valid = 0; r.pad[0] = r.pad[1] = 0;
+    if (prescan_runs(a, f)) {
+        const int gap = frame_buf_lines(a, f) / (COORD_CHECK_PARTS - 1);
+        const int row = frame_buf_row(a, f, (k + 1) * gap);
+        if (row >= 0) {
+            stage_row(lds.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
+            BinCtx c; Bin b;
+            b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);           /* setGoodParameters() (:221) */
+            ctx_for_line(a, c, b);
+            L1 out;
+            process_line_p1(c, b, true, lds, out, a.doubled != 0);
+            if (crc_valid(out)) { r.start = out.coords.start; r.stop = out.coords.stop; r.ref = out.ref_level; r.valid = 1; }
+        }
+    }
+    if (lane_id() == 0) a1.prescan[(size_t)f * COORD_CHECK_LINES + k] = r;
+}
+
+/* ---- state of a PCM-1 frame wave ------------------------------------------------------------------------------------------ */
+struct V2D1 {
+    V2D v;                          /* the part shared with STC-007 (last_words: the six data words of last_pcm1_line) */
+    uint8_t prescan_ref;
+};
+
+__device__ inline void v2d1_load_state(V2D1 &w, WaveLds &lds, const sdv_v2d_state *s, const FrameArgs &a)
+{
+    v2d_load_state(w.v, lds, s, a);
+    w.prescan_ref = (uint8_t)uni(prescan_ref_of(*s));
+}
+
+/* Was frame f+1 started from what frame f handed on?  Like for STC-007 (byte for byte), with one difference: when the worker
+ * prescans frame f+1 it resets its Binarizer first (prescanCoordinates :221), so what frame f left preset there does not reach
+ * frame f+1 and does not count. */
+__device__ inline bool link_holds1(const FrameArgs &a, int f, const sdv_v2d_state &out, sdv_v2d_state next_in)
+{
+    if (prescan_runs(a, f + 1)) next_in.bin = out.bin;
+    uint32_t x[sizeof(sdv_v2d_state) / 4], y[sizeof(sdv_v2d_state) / 4];
+    __builtin_memcpy(x, &out, sizeof(out));
+    __builtin_memcpy(y, &next_in, sizeof(next_in));
+    bool same = true;
+    for (unsigned i = 0; i < sizeof(sdv_v2d_state) / 4; i++) same = same && (x[i] == y[i]);
+    return same;
+}
+
+/* The chain after frame f; the link to frame f+1 is checked by the frame itself: when the worker prescans frame
+ * f+1 it resets its Binarizer first (prescanCoordinates :221), so what frame f left preset there does not reach frame f+1 and does
+ * not count. */
+__device__ inline void v2d1_store_state(const V2D1 &w, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a)
+{
+    if (lane_id() != 0) return;
+    const V2D &v = w.v;
+    sdv_v2d_state o;
+    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin._pad = 0;
+    o.bin.in_def_start = v.bin.in_coord.start; o.bin.in_def_stop = v.bin.in_coord.stop;
+    o.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.bin._pad2 = 0;
+    o.do_ref_lvl_sweep = 0; o.reset_stats = v.reset_stats ? 1 : 0;
+    o.n_last_valid = (uint8_t)v.n_last; o.n_long_valid = (uint8_t)v.n_long;
+    const uint16_t lm = a.doubled ? (uint16_t)((1u << v.n_last) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
+    o.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); o.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+    o.long_valid_doubled_mask = gm;
+    for (int i = 0; i < COORD_HISTORY_DEPTH; i++) {
+        if (i < v.n_last) { o.last_valid[i].data_start = key_start(lds.lv_keys[i]); o.last_valid[i].data_stop = key_stop(lds.lv_keys[i]); }
+        else { o.last_valid[i].data_start = 0; o.last_valid[i].data_stop = 0; }
+    }
+    for (int i = 0; i < COORD_LONG_HISTORY; i++) {
+        if (i < v.n_long) { o.long_valid[i].data_start = key_start(lds.long_keys[i]); o.long_valid[i].data_stop = key_stop(lds.long_keys[i]); }
+        else { o.long_valid[i].data_start = 0; o.long_valid[i].data_stop = 0; }
+    }
+    o._pad[0] = 0; o._pad[1] = (uint8_t)(w.prescan_ref ^ 128);
+    *s = o;
+    const int f = (int)(s - a.states_out);
+    a.flag[f] = (f + 1 < a.n_total && !link_holds1(a, f, o, a.states_in[f + 1])) ? VF_BREAK : VF_OK;
+}
+
+/* :772-822 start-of-frame work, with the prescan results of this frame */
+__device__ inline void v2d1_begin_frame(V2D1 &w, const FrameArgs1 &a1, WaveLds &lds, int f)
+{
+    const FrameArgs &a = a1.f;
+    V2D &v = w.v;
+    v.field_state = FIELD_NEW;
+    v.good_coords_in_field = v.pcm_lines_in_field = 0;
+    if (v.reset_stats) {
+        v.reset_stats = false;
+        v.n_last = v.nfv = v.nfi = v.n_long = 0;
+        coords_clear(v.frame_avg);
+        bin_set_good_parameters_reset(v.bin, a.preset);
+    }
+    coords_clear(v.frame_avg);
+    if (!a.preset.en_force_coords) {
+        if (prescan_runs(a, f)) {
+            bin_set_good_parameters_reset(v.bin, a.preset);                             /* :221 */
+            /* the lines that read valid, sorted like std::sort under CoordinatePair::operator< / by level; the middle ones (:322-336) */
+            uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
+            for (int k = 0; k < COORD_CHECK_LINES; k++) {
+                const PrescanRes r = a1.prescan[(size_t)f * COORD_CHECK_LINES + k];
+                if (uni(r.valid)) { keys[n] = uniu(coords_key(r.start, r.stop)); refs[n] = (uint8_t)uni(r.ref); n++; }
+            }
+            for (int i = 1; i < n; i++)
+                for (int j = i; j > 0; j--) {
+                    if (keys[j - 1] > keys[j]) { const uint32_t t = keys[j]; keys[j] = keys[j - 1]; keys[j - 1] = t; }
+                    if (refs[j - 1] > refs[j]) { const uint8_t t = refs[j]; refs[j] = refs[j - 1]; refs[j - 1] = t; }
+                }
+            if (n > 0) { v.frame_avg = key_to_coords(keys[n / 2], a.doubled != 0); w.prescan_ref = refs[n / 2]; }
+        }
+        if (!coords_valid(v.frame_avg)) { uint32_t k; if (median_keys(lds.long_keys, v.n_long, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0); }
+        else v.bin.in_ref = w.prescan_ref;                                              /* setReferenceLevel(prescan_ref) */
+        if (coords_valid(v.frame_avg)) bin_set_data_coordinates2(v.bin, v.frame_avg.start, v.frame_avg.stop);
+    }
+}
+
+__device__ inline void set_good_parameters_p1(Bin &b, const sdv_bin_preset &ps, const L1 &l)   /* binarizer.cpp:353-377 */
+{
+    if (crc_valid_ignore_forced(l)) { b.in_ref = l.ref_level; bin_set_data_coordinates(b, l.coords); bin_set_bw_levels(b, ps, l.black, l.white); }
+}
+
+/* service lines: Binarizer::processLine :539-568 + VideoToDigital :1006-1114 */
+__device__ inline void v2d1_service_line(V2D1 &w, const FrameArgs &a, L1 &wl, uint8_t srv)
+{
+    V2D &v = w.v;
+    p1_clear(wl);
+    set_service(wl, srv);
+    if (srv == SDV_SRV_NEW_FILE || srv == SDV_SRV_END_FILE) {
+        v.line_in_field_cnt = 0;
+        v.n_last = v.nfv = v.nfi = v.n_long = 0;
+        if (srv == SDV_SRV_END_FILE || !coords_valid(v.frame_avg)) bin_set_good_parameters_reset(v.bin, a.preset);
+    } else if (srv == SDV_SRV_END_FIELD) {
+        v.field_state = FIELD_NEW;
+        v.line_in_field_cnt = 0;
+        v.good_coords_in_field = 0; v.pcm_lines_in_field = 0;
+        for (int i = 0; i < 8; i++) v.last_words[i] = 0;           /* last_pcm1_line.clear(): the data words are zero */
+    }
+}
+
+__device__ inline int16_t p1_get_sample(uint16_t w)     /* pcm1line.cpp:188-222 */
+{
+    if ((w & (1 << 12)) == 0) w = (uint16_t)(w << 4);
+    else {
+        const bool pos = (w & (1 << 11)) == 0;
+        w = (uint16_t)(w & ~(1 << 12));
+        w = (uint16_t)(w << 2);
+        if (!pos) w |= (1 << 15) | (1 << 14);
+    }
+    return (int16_t)w;
+}
+
+/* regular line, after Binarizer::processLine: VideoToDigital :1115-1634 (PCM-1 branches) */
+__device__ inline void v2d1_post_line(V2D1 &w, const FrameArgs &a, WaveLds &lds, L1 &wl, uint32_t *fv_keys, uint32_t *fi_keys, bool even_line)
+{
+    V2D &v = w.v;
+    const sdv_bin_preset &ps = a.preset;
+    if (wl.service != SDV_SRV_NO) {
+        if (wl.service == SDV_SRV_HEADER_LINE && v.field_state == FIELD_NEW) v.field_state = FIELD_SAFE;     /* :1064-1088 */
+        return;
+    }
+    const bool count_has_data = wl.bw_set;
+    const bool count_has_pcm = crc_valid(wl) || count_has_data;
+    if (count_has_pcm && v.field_state == FIELD_NEW) v.field_state = FIELD_UNSAFE;
+    if (crc_valid(wl)) {
+        v.good_coords_in_field++;
+        v.q_line_length = (uint16_t)a.width;
+        if (a.check_line_copy) {
+            if (v.field_state == FIELD_UNSAFE) {
+                set_good_parameters_p1(v.bin, ps, wl);
+                if (ps.en_first_line_dup) wl.forced_bad = true;
+            } else {
+                int diff = 0, silent = 0;
+                for (int i = 0; i < 6; i++) {
+                    const uint16_t wd = get_word(wl, i);
+                    diff += __popc((uint32_t)(uint8_t)(wd ^ v.last_words[i]));          /* the XOR is truncated to uint8_t (pcm1line.cpp:236-263) */
+                    const int16_t smp = p1_get_sample(wd);
+                    if (!(smp >= 8) && !(smp < -8)) silent++;
+                }
+                if (!(silent >= 2) && diff <= (P1_BITS / BIT_DIFF_THRES_DIV)) { wl.forced_bad = true; if (!even_line) v.q_dup_odd++; else v.q_dup_even++; }
+            }
+        }
+        if (crc_valid_ignore_forced(wl)) {
+            const uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
+            __syncthreads();
+            if (lane_id() == 0) {
+                if (v.n_last == COORD_HISTORY_DEPTH) for (int i = 0; i < COORD_HISTORY_DEPTH - 1; i++) lds.lv_keys[i] = lds.lv_keys[i + 1];
+                lds.lv_keys[v.n_last == COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
+            }
+            if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
+            __syncthreads();
+            fv_keys[v.nfv++] = key;
+            if (a.coordinate_damper && !ps.en_force_coords && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
+                Coords target; coords_clear(target);
+                uint32_t k;
+                if (median_keys(lds.lv_keys, v.n_last, &k)) target = key_to_coords(k, false);
+                if (!coords_valid(target)) target = v.frame_avg;
+                if (coords_valid(target)) {
+                    const int16_t ds = (int16_t)(wl.coords.start - target.start), de = (int16_t)(wl.coords.stop - target.stop);
+                    const uint8_t in_delta = (uint8_t)(get_ppb(wl) * 3);
+                    if (((int)ds <= -(int)in_delta) || ((int)ds >= (int)in_delta) || ((int)de <= -(int)in_delta) || ((int)de >= (int)in_delta)) wl.forced_bad = true;
+                }
+            }
+        }
+        if (crc_valid(wl)) set_good_parameters_p1(v.bin, ps, wl);
+        else { if (!even_line) v.q_bad_odd++; else v.q_bad_even++; }
+        v.field_state = FIELD_INIT;
+    } else {
+        if (v.q_line_length == 0) v.q_line_length = (uint16_t)a.width;
+        if (coords_valid(wl.coords)) fi_keys[v.nfi++] = coords_key(wl.coords.start, wl.coords.stop);
+        if (count_has_data) {
+            Coords preset_coords; coords_clear(preset_coords);
+            if (!even_line) v.q_bad_odd++; else v.q_bad_even++;
+            if (!ps.en_force_coords) {
+                uint32_t k;
+                if (median_keys(lds.lv_keys, v.n_last, &k)) preset_coords = key_to_coords(k, a.doubled != 0);
+                if (!coords_valid(preset_coords)) preset_coords = v.frame_avg;
+            }
+            v.field_state = FIELD_INIT;
+            bin_set_data_coordinates(v.bin, preset_coords);
+            bin_set_bw_levels(v.bin, ps, 0, 0);
+        } else {
+            bin_set_bw_levels(v.bin, ps, 0, 0);
+        }
+    }
+    if (!even_line) v.q_odd++; else v.q_even++;
+    if (count_has_pcm) {
+        if (!even_line) v.q_pcm_odd++; else v.q_pcm_even++;
+        v.pcm_lines_in_field++;
+        for (int i = 0; i < 6; i++) v.last_words[i] = get_word(wl, i);
+    }
+    v.line_in_field_cnt++;
+}
+
+/* one frame */
+__device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
+{
+    const FrameArgs &a = a1.f;
+    V2D1 w; L1 wl;
+    v2d1_load_state(w, lds.w, &a.states_in[f], a);
+    V2D &v = w.v;
+    const uint32_t frame_no = a.first_frame_no + (uint32_t)f;
+    const uint8_t *frame = a.luma + (size_t)f * a.frame_stride;
+    uint32_t *fv_keys = a.scratch + (size_t)f * 2u * (size_t)a.height;
+    uint32_t *fi_keys = fv_keys + a.height;
+    size_t rec_base = (size_t)f * (size_t)(a.height + 3);
+    if (a.new_file_frame >= 0 && f > a.new_file_frame) rec_base += 1;
+    sdv_pcm1_bin_rec *rec = a1.recs1 + rec_base;
+    const bool doubled = a.doubled != 0;
+
+    v2d1_begin_frame(w, a1, lds.w, f);
+    const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
+    uint16_t line_num = 0;
+    if (f == a.new_file_frame) { v2d1_service_line(w, a, wl, SDV_SRV_NEW_FILE); emit_rec(wl, frame_no, 0, false, rec++); }
+    for (int field = 0; field < 2; field++) {
+        const int nl = n_field[field];
+        for (int idx = 0; idx < nl; idx++) {
+            line_num = (uint16_t)(field + 1 + 2 * idx);
+            if (f == a.end_file_frame) {            /* VideoInFFMPEG::insertDummyFrame(true, false): FILLER lines (vin_ffmpeg.cpp:367-523) */
+                v2d1_service_line(w, a, wl, SDV_SRV_FILLER);
+                emit_rec(wl, frame_no, line_num, false, rec++);
+                continue;
+            }
+            stage_row(lds.w.px, frame + (size_t)(2 * idx + field) * a.row_stride, a.width);
+            BinCtx c;
+            ctx_for_line(a, c, v.bin);
+            /* :853-884: the real-time modes stop searching once a field has produced enough good lines */
+            bool coord_search = true;
+            if (a.mode == SDV_MODE_DRAFT || a.mode == SDV_MODE_FAST) coord_search = !(v.good_coords_in_field > 2 || v.pcm_lines_in_field > 2);
+            process_line_p1(c, v.bin, coord_search, lds, wl, doubled);
+            v2d1_post_line(w, a, lds.w, wl, fv_keys, fi_keys, (line_num % 2) == 0);
+            emit_rec(wl, frame_no, line_num, doubled, rec++);
+        }
+        line_num = (uint16_t)(field + 1 + 2 * nl);
+        v2d1_service_line(w, a, wl, SDV_SRV_END_FIELD);
+        emit_rec(wl, frame_no, line_num, false, rec++);
+    }
+    if (f == a.end_file_frame) {
+        line_num = (uint16_t)(line_num + 2);
+        v2d1_service_line(w, a, wl, SDV_SRV_END_FILE);
+        emit_rec(wl, frame_no, line_num, false, rec++);
+    }
+    line_num = (uint16_t)(line_num + 2);
+    v2d1_service_line(w, a, wl, SDV_SRV_END_FRAME);
+    v.q_odd = v.q_even = P1_LINES_PF;                               /* :1638-1642 */
+    v2d_end_frame(v, a, lds.w, frame_no, fv_keys, fi_keys, &a.stats[f]);
+    emit_rec(wl, frame_no, line_num, false, rec++);
+    v2d1_store_state(w, lds.w, &a.states_out[f], a);
+}
+
+/* ---- prediction of the incoming states ------------------------------------------------------------------------------------ */
+/* states[k] for the frames behind an anchor (first_of as for STC-007, engine.inc): what the worker carries from frame to frame is the
+ * coordinate history - the last nine valid lines, the medians of the last sixteen frames - and prescan_ref.  On a tape that plays
+ * every line of a frame reads with the coordinates its prescan found, so all of that follows from the prescan results, which are
+ * known before any frame is decoded.  DRAFT mode has no prescan: there the state is handed on as it is, like for STC-007. */
+struct PredictArgs1 { sdv_v2d_state *states; const PrescanRes *prescan; int first, hi; const int *first_of; FrameArgs f; };
+
+__device__ inline sdv_v2d_state predict_state1(const PredictArgs1 &a, int k, int base)
+{
+    const sdv_v2d_state s0 = a.states[base];
+    sdv_v2d_state p = s0;
+    const uint8_t dbl = a.f.doubled;
+    int n_long = s0.reset_stats ? 0 : s0.n_long_valid;       /* a worker that starts over clears its histories first (:778-790) */
+    sdv_coord lg[COORD_LONG_HISTORY];
+    for (int i = 0; i < COORD_LONG_HISTORY; i++) lg[i] = s0.long_valid[i];
+    bool touched = false;
+    sdv_coord last; last.data_start = 0; last.data_stop = 0;
+    uint8_t pref = prescan_ref_of(s0);
+    /* only the last sixteen frames in between can still be seen in the history */
+    int j0 = base; if (k - j0 > COORD_LONG_HISTORY + 1) j0 = k - (COORD_LONG_HISTORY + 1);
+    for (int j = j0; j < k; j++) {
+        if (!prescan_runs(a.f, j)) continue;
+        uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
+        for (int q = 0; q < COORD_CHECK_LINES; q++) { const PrescanRes r = a.prescan[(size_t)j * COORD_CHECK_LINES + q]; if (r.valid) { keys[n] = coords_key(r.start, r.stop); refs[n] = r.ref; n++; } }
+        if (n == 0) continue;
+        for (int i = 1; i < n; i++)
+            for (int q = i; q > 0; q--) {
+                if (keys[q - 1] > keys[q]) { const uint32_t t = keys[q]; keys[q] = keys[q - 1]; keys[q - 1] = t; }
+                if (refs[q - 1] > refs[q]) { const uint8_t t = refs[q]; refs[q] = refs[q - 1]; refs[q - 1] = t; }
+            }
+        last.data_start = key_start(keys[n / 2]); last.data_stop = key_stop(keys[n / 2]);
+        pref = refs[n / 2];
+        touched = true;
+        if (n_long == COORD_LONG_HISTORY) { for (int i = 0; i + 1 < COORD_LONG_HISTORY; i++) lg[i] = lg[i + 1]; n_long--; }
+        lg[n_long++] = last;
+    }
+    if (touched) {
+        p.reset_stats = 0;
+        p.n_last_valid = COORD_HISTORY_DEPTH;
+        for (int i = 0; i < COORD_HISTORY_DEPTH; i++) p.last_valid[i] = last;
+        p.n_long_valid = (uint8_t)n_long;
+        for (int i = 0; i < COORD_LONG_HISTORY; i++) { if (i < n_long) p.long_valid[i] = lg[i]; else { p.long_valid[i].data_start = 0; p.long_valid[i].data_stop = 0; } }
+        const uint16_t lm = dbl ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : 0, gm = dbl ? (uint16_t)((1u << n_long) - 1u) : 0;
+        p.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); p.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+        p.long_valid_doubled_mask = gm;
+        p._pad[1] = (uint8_t)(pref ^ 128);
+        p.bin.in_def_start = last.data_start; p.bin.in_def_stop = last.data_stop; p.bin.in_def_from_doubled = dbl;
+    } else if (!touched && !s0.reset_stats && a.f.mode == SDV_MODE_DRAFT) {
+        /* DRAFT: the tuning is handed on; a frame that plays fills the histories with the pair it inherited (the STC-007 model) */
+        const int16_t cs = s0.bin.in_def_start, ce = s0.bin.in_def_stop;
+        if (s0.bin.in_def_reference >= a.f.preset.min_ref_lvl && (cs != NO_COORD_LEFT && ce != NO_COORD_RIGHT && cs < ce)) {
+            const int m = k - base;
+            p.bin.in_def_from_doubled = dbl;
+            p.n_last_valid = COORD_HISTORY_DEPTH;
+            for (int i = 0; i < COORD_HISTORY_DEPTH; i++) { p.last_valid[i].data_start = cs; p.last_valid[i].data_stop = ce; }
+            const int total = (int)s0.n_long_valid + m;
+            const int keep = total > COORD_LONG_HISTORY ? COORD_LONG_HISTORY : total, drop = total - keep;
+            for (int i = 0; i < COORD_LONG_HISTORY; i++) {
+                const int src = i + drop;
+                if (i >= keep) { p.long_valid[i].data_start = 0; p.long_valid[i].data_stop = 0; }
+                else if (src < (int)s0.n_long_valid) p.long_valid[i] = s0.long_valid[src];
+                else { p.long_valid[i].data_start = cs; p.long_valid[i].data_stop = ce; }
+            }
+            p.n_long_valid = (uint8_t)keep;
+            const uint16_t lm = dbl ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : 0, gm = dbl ? (uint16_t)((1u << keep) - 1u) : 0;
+            p.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); p.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+            p.long_valid_doubled_mask = gm;
+        }
+    }
+    return p;
+}
+__device__ inline void predict_body1(const PredictArgs1 &a, int k)
+{
+    const int base = a.first_of ? a.first_of[k - a.first] : a.first;
+    if (base != k) a.states[k] = predict_state1(a, k, base);
+}
+
+/* Repair of a run of broken links (pcm1_frames_engine.inc): the frame behind the first link of the run has been given what its
+ * predecessor really handed on (sdv_k_anchor); frame list[i] further into the run is predicted again from that frame, head[i] - and
+ * when that tells nothing new (the model has no better idea than before), it takes its own predecessor's outcome instead. */
+struct RepairArgs1 { PredictArgs1 p; const sdv_v2d_state *states_out; const int *list, *head; int n; };
+__device__ inline void repair_body1(const RepairArgs1 &a, int i)
+{
+    const int k = a.list[i];
+    sdv_v2d_state p = predict_state1(a.p, k, a.head[i]);
+    const sdv_v2d_state cur = a.p.states[k];
+    uint32_t x[sizeof(sdv_v2d_state) / 4], y[sizeof(sdv_v2d_state) / 4];
+    __builtin_memcpy(x, &p, sizeof(p));
+    __builtin_memcpy(y, &cur, sizeof(cur));
+    bool same = true;
+    for (unsigned q = 0; q < sizeof(sdv_v2d_state) / 4; q++) same = same && (x[q] == y[q]);
+    a.p.states[k] = same ? a.states_out[k - 1] : p;
+}
+/* the links of the chain after a round: flag[k] for k in [0, n - 1) */
+struct VerifyArgs1 { FrameArgs f; };
+__device__ inline void verify_body1(const VerifyArgs1 &a, int k)
+{
+    a.f.flag[k] = link_holds1(a.f, k, a.f.states_out[k], a.f.states_in[k + 1]) ? VF_OK : VF_BREAK;
+}
+
+} // namespace sdvp1f
+
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_prescan(sdvp1f::FrameArgs1 a)
+{
+    __shared__ sdvp1b::P1Lds lds;
+    const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp1f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp1f::COORD_CHECK_LINES;
+    sdvp1f::prescan_body(a, lds, f, i % sdvp1f::COORD_CHECK_LINES);
+}
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_frames_bin(sdvp1f::FrameArgs1 a)
+{
+    __shared__ sdvp1b::P1Lds lds;
+    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x;
+    sdvp1f::frame_body1(a, lds, f);
+}
+#ifndef SDV_EMU
+__global__ void sdv_k_pcm1_predict(sdvp1f::PredictArgs1 a)
+{
+    const int k = a.first + (a.first_of ? 0 : 1) + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < a.hi) sdvp1f::predict_body1(a, k);
+}
+__global__ void sdv_k_pcm1_repair(sdvp1f::RepairArgs1 a)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < a.n) sdvp1f::repair_body1(a, i);
+}
+__global__ void sdv_k_pcm1_verify(sdvp1f::VerifyArgs1 a)
+{
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k + 1 < a.f.n_total) sdvp1f::verify_body1(a, k);
+}
+#endif

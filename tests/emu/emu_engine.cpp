@@ -12,6 +12,8 @@ struct uint4 { uint32_t x, y, z, w; };
 #include "../../sdvpcmdecoder_amd/csrc/stc007_stitch_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_stitch_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_bin_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/pcm1_frames_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/stitch_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_engine.inc"
+#include "../../sdvpcmdecoder_amd/csrc/pcm1_frames_engine.inc"
