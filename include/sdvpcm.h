@@ -395,6 +395,27 @@ int sdv_pcm1_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_strid
                             const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
                             unsigned flags, int coord_search, sdv_pcm1_bin_rec *out_lines, size_t lines_cap, void *stream);
 
+/* ---- PCM-16x0 front half: one PCM16X0SubLine as Binarizer::processLine leaves it (pcm16x0subline.h:113-125, pcmline.h:137-186) ---
+ * A PCM-16x0 video line carries three sub-lines of 3 x 16 bit + CRCC (and one control bit between the second and the third); the
+ * reference runs its Binarizer three times over a line, once per third (Binarizer::setLinePartMode, videotodigital.cpp:902-925), and
+ * queues one PCM16X0SubLine per pass - three records per video line here, one for a service line.  36 bytes. */
+typedef struct sdv_pcm16x0_bin_rec {
+    uint32_t frame_number;
+    uint16_t line_number;
+    uint16_t words[4];              /* R1/P1/L1, L2/P2/R2, R3/P3/L3 (16 bit) + CRCC as read (or as the Bit Picker completed it) */
+    uint16_t calc_crc;
+    int16_t data_start, data_stop;  /* PCMLine::coords */
+    uint16_t queue_order;           /* PCM16X0SubLine::queue_order: position of the video line in its field (videotodigital.cpp:1141) */
+    uint8_t black_level, white_level, ref_low, ref_level, ref_high;
+    uint8_t hysteresis_depth, shift_stage;
+    uint8_t service_type;           /* SDV_SRV_* */
+    uint8_t picked_bits_left, picked_bits_right;
+    uint8_t flags;                  /* SDV_LF_* */
+    uint8_t line_part;              /* PCM16X0SubLine::PART_LEFT / PART_MIDDLE / PART_RIGHT = 0 / 1 / 2 */
+    uint8_t control_bit;            /* PCM16X0SubLine::control_bit */
+    uint8_t _pad;
+} sdv_pcm16x0_bin_rec;
+
 /* VideoToDigital::doBinarize (videotodigital.cpp:698-1815) with setPCMType(TYPE_PCM1) for a batch of whole frames: the frame prescan
  * of the data coordinates (prescanCoordinates, :148-345; every mode but DRAFT), every line through Binarizer::processLine with
  * what the lines before it left preset, the coordinate-search switch of the real-time modes (:853-884), Header lines, duplicate-line

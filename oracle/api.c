@@ -146,6 +146,66 @@ int orc_bin1_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint1
     return ret;
 }
 
+/* ------------------------------------------------------------------ PCM-16x0 front half (bin_pcm16.c) */
+#include "bin_pcm16.h"
+typedef struct { orc_binarizer bin; orc_video_line vl; orc_p16_line out; } orc_bin16_handle;
+
+void orc_p16_line_to_rec(const orc_p16_line *l, sdv_pcm16x0_bin_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->frame_number = l->frame_number; r->line_number = l->line_number;
+    for (int i = 0; i < 4; i++) r->words[i] = l->words[i];
+    r->calc_crc = l->calc_crc;
+    r->data_start = l->coords.data_start; r->data_stop = l->coords.data_stop;
+    r->queue_order = l->queue_order;
+    r->black_level = l->black_level; r->white_level = l->white_level;
+    r->ref_low = l->ref_low; r->ref_level = l->ref_level; r->ref_high = l->ref_high;
+    r->hysteresis_depth = l->hysteresis_depth; r->shift_stage = l->shift_stage;
+    r->service_type = l->service_type;
+    r->picked_bits_left = l->picked_bits_left; r->picked_bits_right = l->picked_bits_right;
+    r->flags = (uint8_t)((l->ref_level_sweeped ? SDV_LF_REF_SWEEPED : 0) | (l->coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) |
+                         (l->data_by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l->blk_wht_set ? SDV_LF_BW_SET : 0) |
+                         (l->coords_set ? SDV_LF_COORDS_SET : 0) | (l->forced_bad ? SDV_LF_FORCED_BAD : 0) |
+                         (orc_p16_crc_valid(l) ? SDV_LF_CRC_VALID : 0) | (l->coords.from_doubled ? SDV_LF_FROM_DOUBLED : 0));
+    r->line_part = l->line_part; r->control_bit = l->control_bit ? 1 : 0;
+}
+
+void *orc_bin16_new(void)
+{
+    orc_bin16_handle *h = (orc_bin16_handle *)calloc(1, sizeof(*h));
+    orc_binarizer_init(&h->bin);
+    orc_p16_clear(&h->out);
+    return h;
+}
+void orc_bin16_free(void *h) { free(h); }
+void orc_bin16_set_mode(void *h, int mode) { orc_binarizer_set_mode(&((orc_bin16_handle *)h)->bin, (uint8_t)mode); }
+void orc_bin16_set_coord_search(void *h, int on) { ((orc_bin16_handle *)h)->bin.do_coord_search = on != 0; }
+void orc_bin16_set_preset(void *hh, const sdv_bin_preset *p) { orc_bin_set_preset(hh, p); }
+void orc_bin16_reset_good(void *h) { orc_binarizer_set_good_parameters_p16(&((orc_bin16_handle *)h)->bin, NULL); }
+void orc_bin16_set_good_from_last(void *hh) { orc_bin16_handle *h = (orc_bin16_handle *)hh; orc_binarizer_set_good_parameters_p16(&h->bin, &h->out); }
+void orc_bin16_set_state(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); }
+int orc_bin16_scan_done(void *h) { return ((orc_bin16_handle *)h)->vl.scan_done ? 1 : 0; }
+/* one pass over a video line: part = Binarizer::PART_PCM16X0_LEFT / _MIDDLE / _RIGHT (1 / 2 / 3; 0 = FULL_LINE); new_line: the
+ * VideoLine is a fresh one (scan_done cleared), else the same line as in the pass before */
+int orc_bin16_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16_t line, int service, int doubled, int empty,
+                      int part, int new_line, sdv_pcm16x0_bin_rec *out)
+{
+    orc_bin16_handle *h = (orc_bin16_handle *)hh;
+    if (new_line) h->vl.scan_done = false;
+    h->vl.frame_number = frame; h->vl.line_number = line;
+    h->vl.pixels = px; h->vl.length = (uint16_t)len;
+    h->vl.service_type = (uint8_t)service;
+    h->vl.empty = (service != SDV_SRV_NO) ? true : (empty != 0);
+    h->vl.doubled = (service == SDV_SRV_NO) ? (doubled != 0) : false;
+    h->bin.video_line = &h->vl;
+    h->bin.out_pcm_line = NULL;
+    h->bin.line_part_mode = (uint8_t)part;
+    int ret = orc_binarizer_process_line_p16(&h->bin, &h->out);
+    orc_p16_line_to_rec(&h->out, out);
+    return ret;
+}
+uint16_t orc_pcm16x0_crc(const uint16_t *w3) { return orc_p16_crc_words(w3); }
+
 /* ------------------------------------------------------------------ VideoToDigital level */
 #include "v2d.h"
 

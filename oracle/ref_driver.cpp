@@ -684,3 +684,85 @@ long ref_v2d1_run(void *h, const uint8_t *luma, size_t stride, int width, int he
     return v2d_run_t<PCM1Line, sdv_pcm1_bin_rec>((RefV2D1 *)h, luma, stride, width, height, n_frames, first_frame_no, new_file, doubled, out, stats, p1_line_to_rec, 1);
 }
 }
+
+/* ---- PCM-16x0 front half: the real Binarizer with a PCM16X0SubLine as output, one pass per line part ----------------------- */
+#include "pcm16x0subline.h"
+struct RefBin16 {
+    Binarizer bin;
+    VideoLine vline;
+    PCM16X0SubLine out;
+};
+static void p16_line_to_rec(PCM16X0SubLine &l, sdv_pcm16x0_bin_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->frame_number = l.frame_number; r->line_number = l.line_number;
+    for (int i = 0; i < 4; i++) r->words[i] = l.getWord(i);
+    r->calc_crc = l.getCalculatedCRC();
+    r->data_start = l.coords.data_start; r->data_stop = l.coords.data_stop;
+    r->queue_order = l.queue_order;
+    r->black_level = l.black_level; r->white_level = l.white_level;
+    r->ref_low = l.ref_low; r->ref_level = l.ref_level; r->ref_high = l.ref_high;
+    r->hysteresis_depth = l.hysteresis_depth; r->shift_stage = l.shift_stage;
+    uint8_t st = SDV_SRV_NO;
+    if (l.isServNewFile()) st = SDV_SRV_NEW_FILE; else if (l.isServEndFile()) st = SDV_SRV_END_FILE;
+    else if (l.isServFiller()) st = SDV_SRV_FILLER; else if (l.isServEndField()) st = SDV_SRV_END_FIELD;
+    else if (l.isServEndFrame()) st = SDV_SRV_END_FRAME;
+    r->service_type = st;
+    r->picked_bits_left = l.picked_bits_left; r->picked_bits_right = l.picked_bits_right;
+    r->flags = (uint8_t)((l.isDataByRefSweep() ? SDV_LF_REF_SWEEPED : 0) | (l.isDataByCoordSweep() ? SDV_LF_COORDS_SWEEPED : 0) |
+                         (l.isDataBySkip() ? SDV_LF_BY_EXT_TUNE : 0) | (l.hasBWSet() ? SDV_LF_BW_SET : 0) |
+                         (l.hasDataCoordSet() ? SDV_LF_COORDS_SET : 0) | (l.isForcedBad() ? SDV_LF_FORCED_BAD : 0) |
+                         (l.isCRCValid() ? SDV_LF_CRC_VALID : 0) | (l.isSourceDoubleWidth() ? SDV_LF_FROM_DOUBLED : 0));
+    r->line_part = l.line_part; r->control_bit = l.control_bit ? 1 : 0;
+}
+extern "C" {
+void *ref_bin16_new(void) { return new RefBin16(); }
+void ref_bin16_free(void *h) { delete (RefBin16 *)h; }
+void ref_bin16_set_mode(void *h, int mode) { ((RefBin16 *)h)->bin.setMode((uint8_t)mode); }
+void ref_bin16_set_coord_search(void *h, int on) { ((RefBin16 *)h)->bin.setCoordinatesSearch(on != 0); }
+void ref_bin16_set_preset(void *h, const sdv_bin_preset *p) { ((RefBin16 *)h)->bin.setFineSettings(to_bin_preset(p)); }
+void ref_bin16_reset_good(void *h) { ((RefBin16 *)h)->bin.setGoodParameters(NULL); }
+void ref_bin16_set_good_from_last(void *h) { RefBin16 *r = (RefBin16 *)h; r->bin.setGoodParameters(&r->out); }
+void ref_bin16_set_state(void *h, const sdv_bin_state *s)
+{
+    RefBin16 *r = (RefBin16 *)h;
+    r->bin.setReferenceLevel(s->in_def_reference);
+    CoordinatePair c;
+    c.data_start = s->in_def_start; c.data_stop = s->in_def_stop; c.from_doubled = s->in_def_from_doubled != 0;
+    r->bin.setDataCoordinates(c);
+    r->bin.setBWLevels(s->in_def_black, s->in_def_white);
+}
+int ref_bin16_scan_done(void *h) { return ((RefBin16 *)h)->vline.scan_done ? 1 : 0; }
+int ref_bin16_process(void *h, const uint8_t *px, int len, uint32_t frame, uint16_t line, int service, int doubled, int empty,
+                      int part, int new_line, sdv_pcm16x0_bin_rec *out)
+{
+    RefBin16 *r = (RefBin16 *)h;
+    if (new_line) {
+        r->vline.clear();
+        r->vline.frame_number = frame;
+        r->vline.line_number = line;
+        if (service == SDV_SRV_NO) {
+            r->vline.setEmpty(empty != 0);
+            if (!empty) r->vline.pixel_data.assign(px, px + len);
+            r->vline.setDoubleWidth(doubled != 0);
+        } else if (service == SDV_SRV_NEW_FILE) r->vline.setServNewFile("synthetic");
+        else if (service == SDV_SRV_END_FILE) r->vline.setServEndFile();
+        else if (service == SDV_SRV_FILLER) r->vline.setServFiller();
+        else if (service == SDV_SRV_END_FIELD) r->vline.setServEndField();
+        else if (service == SDV_SRV_END_FRAME) r->vline.setServEndFrame();
+    }
+    r->bin.setSource(&r->vline);
+    r->bin.setOutput(&r->out);
+    r->bin.setLinePartMode((uint8_t)part);
+    int ret = r->bin.processLine();
+    p16_line_to_rec(r->out, out);
+    return ret;
+}
+uint16_t ref_pcm16x0_crc(const uint16_t *w3)
+{
+    PCM16X0SubLine l;
+    for (int i = 0; i < 3; i++) l.setWord(i, w3[i]);
+    l.calcCRC();
+    return l.getCalculatedCRC();
+}
+}

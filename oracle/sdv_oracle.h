@@ -69,6 +69,7 @@ typedef struct {
     uint16_t length;
     bool empty, doubled;
     uint8_t service_type;
+    bool scan_done;             /* VideoLine::scan_done (videoline.h:58): set by the PCM-16x0 coordinate search, which then runs once per video line */
 } orc_video_line;
 
 /* ---- STC007Line : PCMLine (pcmline.h:137-166, stc007line.h:153-165) ---- */
@@ -111,7 +112,7 @@ typedef struct {
 /* ---- Binarizer (binarizer.h:306-337) ---- */
 typedef struct {
     orc_bin_preset digi_set;
-    const orc_video_line *video_line;
+    const orc_video_line *video_line;   /* scan_done is written through it by the PCM-16x0 path (bin_pcm16.c) */
     orc_stc_line *out_pcm_line;
     uint8_t in_def_black, in_def_white, in_def_reference;
     orc_coords in_def_coord;

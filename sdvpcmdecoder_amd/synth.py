@@ -471,3 +471,55 @@ def pcm1_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 48
     if p_dropout > 0:
         luma[rng.random(n) < p_dropout] = black
     return luma.reshape(n_frames, height, width), w7
+
+
+# ---- PCM-16x0 (Sony PCM-1610/1620/1630): 193 bit cells per line = 3 sub-lines of 3 x 16 bit + CRCC, one control bit ----------
+PCM16X0_BIN_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words", "<u2", (4,)), ("calc_crc", "<u2"),
+                              ("data_start", "<i2"), ("data_stop", "<i2"), ("queue_order", "<u2"),
+                              ("black_level", "u1"), ("white_level", "u1"), ("ref_low", "u1"), ("ref_level", "u1"), ("ref_high", "u1"),
+                              ("hysteresis_depth", "u1"), ("shift_stage", "u1"), ("service_type", "u1"),
+                              ("picked_bits_left", "u1"), ("picked_bits_right", "u1"), ("flags", "u1"), ("line_part", "u1"),
+                              ("control_bit", "u1"), ("_pad", "u1")])
+assert PCM16X0_BIN_DTYPE.itemsize == 36
+
+
+def pcm16x0_crc_words(words3):
+    """PCM16X0SubLine::calcCRC (pcm16x0subline.cpp:158-170): CRC-16/CCITT-FALSE over three 16-bit words, MSB first
+    (vectorised restatement used only to BUILD inputs)."""
+    w = np.asarray(words3, dtype=np.uint32)
+    crc = np.full(w.shape[:-1], 0xFFFF, dtype=np.uint32)
+    for i in range(3):
+        for b in range(15, -1, -1):
+            bit = (w[..., i] >> b) & 1
+            top = ((crc >> 15) & 1) ^ bit
+            crc = ((crc << 1) & 0xFFFF) ^ (top * 0x1021)
+    return crc.astype(np.uint16)
+
+
+def pcm16x0_line_bits(words: np.ndarray, control: np.ndarray | None = None) -> np.ndarray:
+    """(n, 3, 4) sub-line words (3 x 16 bit + CRCC per sub-line) -> (n, 193) bit cells: sub-lines 0 and 1, the control bit (cell
+    128), sub-line 2 (pcm16x0subline.h:90-100, binarizer.cpp:7151-7198)."""
+    w = np.asarray(words).astype(np.uint32)
+    n = w.shape[0]
+    bits = np.zeros((n, 193), dtype=np.uint8)
+    for part in range(3):
+        pos = part * 64 + (1 if part == 2 else 0)
+        for k in range(4):
+            for bit in range(15, -1, -1):
+                bits[:, pos] = (w[:, part, k] >> bit) & 1
+                pos += 1
+    bits[:, 128] = 1 if control is None else np.asarray(control).astype(np.uint8)
+    return bits
+
+
+def pcm16x0_random_lines(n: int, seed: int = 0, width: int = 720, x0: int = 4, x1: int | None = None, control=None, silent: bool = False, **kw):
+    """n independent random PCM-16x0 video lines.  Returns (luma (n, width) u8, words (n, 3, 4) u16)."""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(0, 1 << 16, size=(n, 3, 3), dtype=np.uint32)
+    if silent:
+        words[:] = 0
+    crc = pcm16x0_crc_words(words).astype(np.uint32)
+    w4 = np.concatenate([words, crc[..., None]], axis=2).astype(np.uint16)
+    ctl = None if control is None else (rng.integers(0, 2, size=n) if control == "random" else np.full(n, control))
+    luma = render_lines(pcm16x0_line_bits(w4, ctl), width=width, x0=x0, x1=(width - 4 if x1 is None else x1), rng=rng, **kw)
+    return luma, w4

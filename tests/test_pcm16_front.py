@@ -1,0 +1,103 @@
+"""PCM-16x0 front half: the oracle's restatement of Binarizer::processLine with a PCM16X0SubLine output
+(oracle/bin_pcm16.c: black/white search over the three thirds, marker-less coordinate search over the 21 x 21 grid with the three
+parts read at every pair and voted on, Bit Picker on the outer parts, control bit) against the real reference - live when
+oracle/_ref is built, and through the committed fixtures (tests/golden/pcm16front_*.npz, made by make_golden_pcm16_front.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import libs
+import pcm16_front_api as pf
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _diff(a, b, ra, rb):
+    for i in range(min(len(a), len(b))):
+        if a[i].tobytes() != b[i].tobytes() or ra[i] != rb[i]:
+            return f"sub-line {i}:\n  got  {a[i]} ret {ra[i]}\n  want {b[i]} ret {rb[i]}"
+    return f"lengths {len(a)} / {len(b)}"
+
+
+def test_crc_known_answers(oracle_lib):
+    """PCM16X0SubLine::calcCRC: CRC-16/CCITT-FALSE over 3 x 16 bit; the silent line's CRC is the constant the reference holds
+    (pcm16x0subline.h:104, CRC_SILENT = 0x0E10); check value of the algorithm (pcmline.h:88-97)."""
+    import ctypes as C
+    f = oracle_lib.orc_pcm16x0_crc
+    f.restype = C.c_uint16
+    f.argtypes = [C.POINTER(C.c_uint16)]
+    assert f((C.c_uint16 * 3)(0, 0, 0)) == 0x0E10
+    from sdvpcmdecoder_amd import synth
+    rng = np.random.default_rng(1)
+    w = rng.integers(0, 1 << 16, size=(64, 3), dtype=np.uint32)
+    want = synth.pcm16x0_crc_words(w)
+    got = [f((C.c_uint16 * 3)(*[int(x) for x in row])) for row in w]
+    assert (np.array(got, dtype=np.uint16) == want).all()
+    if libs.ref_available():
+        g = libs.load_ref().ref_pcm16x0_crc
+        g.restype = C.c_uint16
+        g.argtypes = [C.POINTER(C.c_uint16)]
+        assert [g((C.c_uint16 * 3)(*[int(x) for x in row])) for row in w] == got
+
+
+@pytest.mark.parametrize("name", pf.GOLDEN)
+def test_oracle_matches_golden(name, oracle_lib):
+    luma, run = pf.make_case(name)
+    g = np.load(os.path.join(GOLD, "pcm16front_" + name + ".npz"))
+    assert hashlib.sha256(luma.tobytes()).hexdigest() == str(g["input_sha256"]), "the seeded input changed: regenerate the fixtures"
+    want = g["recs"].reshape(-1).view(pf.BIN16_DTYPE)
+    got, rets, scans = pf.run_lines(oracle_lib, "orc_bin16_", luma, **run)
+    assert got.tobytes() == want.tobytes() and (rets == g["rets"]).all(), _diff(got, want, rets, g["rets"])
+    assert (scans == g["scans"]).all()
+
+
+@pytest.mark.skipif(not libs.ref_available(), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("name", sorted(pf.CASES))
+def test_oracle_matches_live_reference(name, oracle_lib):
+    ref = libs.load_ref()
+    luma, run = pf.make_case(name)
+    want, wrets, wscans = pf.run_lines(ref, "ref_bin16_", luma, **run)
+    got, rets, scans = pf.run_lines(oracle_lib, "orc_bin16_", luma, **run)
+    assert got.tobytes() == want.tobytes() and (rets == wrets).all(), _diff(got, want, rets, wrets)
+    assert (scans == wscans).all()
+
+
+@pytest.mark.skipif(not libs.ref_available(), reason="reference build (oracle/_ref) not present")
+@pytest.mark.parametrize("seed", range(6))
+def test_oracle_matches_live_reference_random(seed, oracle_lib):
+    """Random geometry, levels, noise and cut-off; every mode but MODE_INSANE (whose reference level sweep is not restated)."""
+    from sdvpcmdecoder_amd import synth
+    ref = libs.load_ref()
+    rng = np.random.default_rng(950 + seed)
+    width = int(rng.choice([640, 704, 720, 768]))
+    x0 = int(rng.integers(-6, 9)); x1 = width - int(rng.integers(-6, 9))
+    black = int(rng.integers(10, 70)); white = black + int(rng.integers(40, 170))
+    luma, _ = synth.pcm16x0_random_lines(6, seed=seed, width=width, x0=x0, x1=x1, black=black, white=min(white, 250),
+                                         noise_sigma=float(rng.integers(0, 12)), blur=int(rng.integers(0, 2)), control="random")
+    for mode in (0, 1, 2):
+        for fb in ("good", "reset"):
+            want, wrets, wscans = pf.run_lines(ref, "ref_bin16_", luma, mode=mode, feedback=fb)
+            got, rets, scans = pf.run_lines(oracle_lib, "orc_bin16_", luma, mode=mode, feedback=fb)
+            assert got.tobytes() == want.tobytes() and (rets == wrets).all(), (mode, fb, _diff(got, want, rets, wrets))
+            assert (scans == wscans).all()
+
+
+def test_clean_lines_decode_to_what_was_rendered(oracle_lib):
+    from sdvpcmdecoder_amd import synth
+    luma, words = synth.pcm16x0_random_lines(8, seed=5, noise_sigma=2.0, control="random")
+    got, rets, _ = pf.run_lines(oracle_lib, "orc_bin16_", luma, mode=1, feedback="good")
+    assert (rets == 0).all() and ((got["flags"] & pf.LF_CRC_VALID) != 0).all()
+    assert (got["words"].reshape(8, 3, 4) == words).all()
+    assert (got["line_part"].reshape(8, 3) == np.arange(3)).all()
+
+
+def test_short_line_and_insane_mode(oracle_lib):
+    luma = np.zeros((1, 150), np.uint8)
+    got, rets, _ = pf.run_lines(oracle_lib, "orc_bin16_", luma, mode=1)
+    assert (rets == 3).all()                                    # LB_RET_SHORT_LINE: under 193 px
+    from sdvpcmdecoder_amd import synth
+    luma, _ = synth.pcm16x0_random_lines(1, seed=9)
+    got, rets, _ = pf.run_lines(oracle_lib, "orc_bin16_", luma, mode=3)
+    assert (rets == 100).all()                                  # the reference level sweep is not restated
