@@ -326,6 +326,44 @@ long orc_v2d1_run(void *vv, const uint8_t *luma, size_t stride, int width, int h
     return n;
 }
 
+/* ------------------------------------------------------------------ VideoToDigital level, PCM-16x0 (v2d_p16.c) */
+#include "v2d_p16.h"
+void *orc_v2d16_new(void) { orc_v2d16 *v = (orc_v2d16 *)malloc(sizeof(orc_v2d16)); orc_v2d16_init(v); return v; }
+void orc_v2d16_delete(void *v) { orc_v2d16_free((orc_v2d16 *)v); free(v); }
+void orc_v2d16_set_mode(void *v, int mode) { if (mode >= 0 && mode < 4) ((orc_v2d16 *)v)->binarization_mode = (uint8_t)mode; }
+void orc_v2d16_set_check_line_dup(void *v, int on) { ((orc_v2d16 *)v)->check_line_copy = on != 0; }
+void orc_v2d16_set_preset(void *vv, const sdv_bin_preset *p)
+{
+    orc_bin_preset s; orc_bin_preset_reset(&s);
+    s.max_black_lvl = p->max_black_lvl; s.min_white_lvl = p->min_white_lvl; s.min_contrast = p->min_contrast;
+    s.min_ref_lvl = p->min_ref_lvl; s.max_ref_lvl = p->max_ref_lvl; s.min_valid_crcs = p->min_valid_crcs;
+    s.mark_max_dist = p->mark_max_dist; s.left_bit_pick = p->left_bit_pick; s.right_bit_pick = p->right_bit_pick;
+    s.en_force_coords = p->en_force_coords; s.en_coord_search = p->en_coord_search;
+    s.en_first_line_dup = p->en_first_line_dup; s.en_good_no_marker = p->en_good_no_marker;
+    s.horiz_coords.data_start = p->horiz_start; s.horiz_coords.data_stop = p->horiz_stop;
+    orc_v2d16_set_fine_settings((orc_v2d16 *)vv, &s);
+}
+/* n_frames consecutive PCM-16x0 frames through the worker (flags as orc_v2d1_run).  Returns the records written:
+ * per frame 3 * height + 3, + 1 for NEW_FILE, + height + 4 for the filler frame. */
+long orc_v2d16_run(void *vv, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                   int new_file, int doubled, sdv_pcm16x0_bin_rec *out, sdv_frame_stats *stats)
+{
+    orc_v2d16 *v = (orc_v2d16 *)vv;
+    long n = 0;
+    for (int f = 0; f < n_frames; f++) {
+        orc_frame_stats q;
+        n += orc_v2d16_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
+                             (new_file & 1) && f == 0, doubled != 0, false, out + n, &q);
+        if (stats) stats_to_pod(&q, &stats[f]);
+    }
+    if (new_file & 2) {
+        orc_frame_stats q;
+        n += orc_v2d16_frame(v, NULL, 0, width, height, first_frame_no + (uint32_t)n_frames, false, false, true, out + n, &q);
+        if (stats) stats_to_pod(&q, &stats[n_frames]);
+    }
+    return n;
+}
+
 /* ------------------------------------------------------------------ deinterleaver level */
 #include "deint.h"
 

@@ -766,3 +766,33 @@ uint16_t ref_pcm16x0_crc(const uint16_t *w3)
     return l.getCalculatedCRC();
 }
 }
+
+/* ---- PCM-16x0 frames through the real VideoToDigital worker (setPCMType(TYPE_PCM16X0)), PCM16X0SubLine queue drained -------- */
+typedef RefV2DT<PCM16X0SubLine> RefV2D16;
+extern "C" {
+void *ref_v2d16_new(void)
+{
+    RefV2D16 *r = new RefV2D16();
+    r->v2d.setInputPointers(&r->in_q, &r->in_mtx);
+    r->v2d.setOutPCM16X0Pointers(&r->out_q, &r->out_mtx);
+    r->v2d.setPCMType(VideoToDigital::TYPE_PCM16X0);
+    QObject::connect(&r->v2d, &VideoToDigital::guiUpdFrameBin, [r](FrameBinDescriptor d) {
+        r->stats_mtx.lock(); r->stats_q.push_back(d); r->stats_mtx.unlock();
+    });
+    return r;
+}
+void ref_v2d16_delete(void *h)
+{
+    RefV2D16 *r = (RefV2D16 *)h;
+    if (r->started) { r->v2d.stop(); r->th.join(); }
+    delete r;
+}
+void ref_v2d16_set_mode(void *h, int mode) { ((RefV2D16 *)h)->v2d.setBinarizationMode((uint8_t)mode); }
+void ref_v2d16_set_check_line_dup(void *h, int on) { ((RefV2D16 *)h)->v2d.setCheckLineDup(on != 0); }
+void ref_v2d16_set_preset(void *h, const sdv_bin_preset *p) { ((RefV2D16 *)h)->v2d.setFineSettings(to_bin_preset(p)); }
+long ref_v2d16_run(void *h, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
+                   int new_file, int doubled, sdv_pcm16x0_bin_rec *out, sdv_frame_stats *stats)
+{
+    return v2d_run_t<PCM16X0SubLine, sdv_pcm16x0_bin_rec>((RefV2D16 *)h, luma, stride, width, height, n_frames, first_frame_no, new_file, doubled, out, stats, p16_line_to_rec, 3);
+}
+}

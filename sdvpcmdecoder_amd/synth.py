@@ -523,3 +523,38 @@ def pcm16x0_random_lines(n: int, seed: int = 0, width: int = 720, x0: int = 4, x
     ctl = None if control is None else (rng.integers(0, 2, size=n) if control == "random" else np.full(n, control))
     luma = render_lines(pcm16x0_line_bits(w4, ctl), width=width, x0=x0, x1=(width - 4 if x1 is None else x1), rng=rng, **kw)
     return luma, w4
+
+
+def pcm16x0_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 486, x0: int = 4, x1: int | None = None,
+                   top_blank: int = 0, jitter: int = 0, p_dropout: float = 0.0, dup_every: int = 0, silent_from: int | None = None,
+                   control=None, smear: tuple | None = None, **kw):
+    """Synthetic PCM-16x0 video frames: every row of a field is one PCM-16x0 line (three sub-lines of random 16-bit words + CRCC),
+    `top_blank` rows at the top of a field are black.  `jitter` = per-line horizontal shift of up to +-jitter px, `p_dropout` = share
+    of rows replaced by black, `dup_every` = every that-many-th row repeats the row above it in its field, `silent_from` = frames from
+    that index on carry silence, `control` = None (bit set) / 0 / 1 / "random", `smear` = (every, x_from, x_to): a stretch of every
+    that-many-th row wiped out.  Further keywords go to render_lines.  Returns (luma (n_frames, height, width) u8, words
+    (n_frames * height, 3, 4) u16 in row order)."""
+    rng = np.random.default_rng(seed)
+    n = n_frames * height
+    words = rng.integers(0, 1 << 16, size=(n, 3, 3), dtype=np.uint32)
+    if silent_from is not None:
+        words[silent_from * height:] = 0
+    row = np.arange(n) % height
+    in_field = row // 2
+    if dup_every:
+        src = np.arange(n)
+        dup = (in_field % dup_every == dup_every - 1) & (in_field >= top_blank + 1)
+        src[dup] -= 2
+        words = words[src]
+    crc = pcm16x0_crc_words(words).astype(np.uint32)
+    w4 = np.concatenate([words, crc[..., None]], axis=2).astype(np.uint16)
+    ctl = None if control is None else (rng.integers(0, 2, size=n) if control == "random" else np.full(n, control))
+    shift = rng.integers(-jitter, jitter + 1, size=n) if jitter else None
+    luma = render_lines(pcm16x0_line_bits(w4, ctl), width=width, x0=x0, x1=(width - 4 if x1 is None else x1), shift=shift, rng=rng, **kw)
+    black = kw.get("black", 30)
+    luma[in_field < top_blank] = black
+    if smear is not None:
+        luma[(in_field % smear[0]) == smear[0] - 1, smear[1]:smear[2]] = 110
+    if p_dropout > 0:
+        luma[rng.random(n) < p_dropout] = black
+    return luma.reshape(n_frames, height, width), w4
