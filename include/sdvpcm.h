@@ -416,13 +416,25 @@ typedef struct sdv_pcm16x0_bin_rec {
     uint8_t _pad;
 } sdv_pcm16x0_bin_rec;
 
+/* VideoToDigital::doBinarize (videotodigital.cpp:698-1815) with setPCMType(TYPE_PCM16X0) for a batch of whole frames: the frame
+ * prescan (prescanCoordinates, :148-345: the right third of four lines, every mode but DRAFT), three Binarizer passes per video line
+ * with the hand-over between the parts of a line (:1455-1511) and from line to line, forced-bad propagation inside a line
+ * (:1168-1180), duplicate-line detection per part, coordinate damper and frame statistics.  out_lines takes
+ * sdv_pcm16x0_binarize_records(height, n_frames, flags) records: three per video line, one per service line - what the worker pushes
+ * into the deque<PCM16X0SubLine> that PCM16X0DataStitcher reads.  Everything else as for sdv_binarize_frames; SDV_ERR_SHORT_LINE under
+ * 193 px, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE. */
+size_t sdv_pcm16x0_binarize_records(int height, int n_frames, unsigned flags);
+int sdv_pcm16x0_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
+                                int n_frames, uint32_t first_frame_no, unsigned flags,
+                                sdv_pcm16x0_bin_rec *out_lines, size_t lines_cap, sdv_frame_stats *out_stats, size_t stats_cap, void *stream);
+
 /* VideoToDigital::doBinarize (videotodigital.cpp:698-1815) with setPCMType(TYPE_PCM1) for a batch of whole frames: the frame prescan
  * of the data coordinates (prescanCoordinates, :148-345; every mode but DRAFT), every line through Binarizer::processLine with
  * what the lines before it left preset, the coordinate-search switch of the real-time modes (:853-884), Header lines, duplicate-line
  * detection, coordinate damper and frame statistics.  Arguments, record order (one sdv_pcm1_bin_rec per video line and service line),
  * flags, capacities, stream state (sdv_reset_stream / sdv_get_chain_state / sdv_set_chain_state) and error codes as for
  * sdv_binarize_frames; SDV_ERR_SHORT_LINE under 94 px, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE.  out_lines is what the worker pushes
- * into the deque<PCM1Line> that PCM1DataStitcher reads (sdv_pcm1_lines_from_bin converts it into sdv_pcm1_stitch_frames' input). */
+ * into the deque<PCM1Line> that PCM1DataStitcher reads. */
 int sdv_pcm1_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
                              int n_frames, uint32_t first_frame_no, unsigned flags,
                              sdv_pcm1_bin_rec *out_lines, size_t lines_cap, sdv_frame_stats *out_stats, size_t stats_cap, void *stream);

@@ -1,0 +1,627 @@
+/*
+ * pcm16_bin_device.h - PCM-16x0 (Sony PCM-1610/1620/1630) line binarizer: Binarizer::processLine with a PCM16X0SubLine output
+ * (SURVEY.md section 8 row a9), one pass per third of a video line, the line staged once in LDS by its wavefront.
+ *
+ * Reference: binarizer.cpp:443-1724 (processLine, PCM-16x0 paths), :2603-2681 (findPCM16X0BW), :5819-6042 (findPCM16X0Coordinates),
+ * :4514-5271 (searchPCM16X0Data), :7134-7319 (fillPCM16X0), :6599-7013 (pickCutBitsUpPCM16X0), :7560-7691 (fillDataWords),
+ * :7695-8055 (readPCMdata); pcm16x0subline.cpp, pcmline.cpp for the line object.
+ *
+ * A sub-line is 64 bit cells (3 x 16 bit + CRCC): exactly one cell per lane, so a read is one LDS byte per lane, two ballots, the
+ * two-level automaton solved on them (stc007_device.h, solve_automaton) and the CRC as 16 parities.  The 193 cells of the whole
+ * line (three sub-lines and the control bit between the second and the third) share one set of data coordinates.
+ *
+ * The marker-less coordinate search - 21 x 21 coordinate pairs, all three parts read at each with the Bit Picker forced - is spread
+ * over the lanes, one read per lane at a time, results in LDS.  The reference walks the grid in order and what it does depends on
+ * what it has seen: it stops sweeping the right coordinate behind the window where all three parts read, stops sweeping the left one
+ * where fewer than two still do, and a Bit Picker collision marks the one line object forced bad for every read that follows.  All of
+ * that is replayed serially, over the lane-parallel results, by lane 0; the line object is then left as the last read the reference
+ * would have made leaves it.
+ * Not implemented: the reference level sweep, which PCM-16x0 runs in MODE_INSANE only - the host entry refuses that mode.
+ */
+#pragma once
+#include "pcm1_bin_device.h"
+
+namespace sdvp16 {
+using namespace sdv;
+using sdvp1b::BinCtx;
+using sdvp1b::stats_reset;
+using sdvp1b::stats_update;
+using sdvp1b::sweep_blank;
+
+enum { P16_BITS = 193, P16_DATA = 64, P16_WORD_BITS = 16, P16_CRC_SILENT = 0x0E10, P16_SUBLINES = 3 };
+enum { P16_SEARCH_STEP_DIV = 2, P16_SEARCH_MAX_OFS = 10, P16_SEARCH_STEP_CNT = (P16_SEARCH_MAX_OFS + 1) * 2 };     /* binarizer.h:262-264 */
+enum { PART_FULL = 0, PART_LEFT = 1, PART_MIDDLE = 2, PART_RIGHT = 3 };        /* Binarizer::FULL_LINE, PART_PCM16X0_* (binarizer.h:217-224) */
+/* where the per-part, combined and left-coordinate result rows sit in WaveLds::sweep */
+enum { SW_P0 = 0, SW_P1 = 32, SW_P2 = 64, SW_RIGHT = 96, SW_LEFT = 128 };
+
+struct P16Lds {
+    WaveLds w;
+    uint32_t grid[P16_SEARCH_STEP_CNT * P16_SEARCH_STEP_CNT * P16_SUBLINES];   /* per read: crc | hyst << 16 | shift << 20 | valid << 24 | collision << 25 | picked << 26 */
+    CrcStat pstats[3][MAX_COLL_CRCS + 1];   /* scan_right_p0/p1/p2_crcs */
+    CrcStat lstats[MAX_COLL_CRCS + 1];      /* scan_left_crcs (scan_right_crcs: w.crc_stats) */
+    int32_t vote[8];
+};
+
+struct L16 {                        /* PCM16X0SubLine : PCMLine (pcmline.h:137-166, pcm16x0subline.h:113-125) */
+    uint8_t black, white, ref_low, ref_level, ref_high, hyst, shift;
+    Coords coords;
+    bool coords_sweeped, by_ext_tune, bw_set, coords_set, forced_bad, control_bit;
+    uint8_t service, line_part;
+    uint16_t pixel_start, pixel_stop;
+    int16_t pso; uint32_t psm, hpsm;
+    uint64_t v;                     /* the 64 cells: word k = bits 48-16k .. 63-16k, CRCC = the low 16 bits */
+    uint16_t calc_crc, queue_order;
+    uint8_t picked_l, picked_r;
+};
+
+__device__ __forceinline__ uint16_t get_word(const L16 &l, int k) { return (uint16_t)(l.v >> (48 - 16 * k)); }
+
+/* PCM16X0SubLine::calcCRC (pcm16x0subline.cpp:158-170): CRC-16/CCITT-FALSE over the 48 data cells, as a GF(2)-linear map of them */
+struct Crc16Tables { uint64_t k[16]; uint16_t base; };
+constexpr Crc16Tables make_crc16_tables()
+{
+    Crc16Tables t{};
+    uint16_t c = 0xFFFF;
+    for (int i = 0; i < 48; i++) c = crc16_step(c, 0);
+    t.base = c;
+    for (int b = 0; b < 48; b++) {          /* data cell b (0 = first = MSB of word 0) sits at bit 63 - b of v */
+        uint16_t v = 0;
+        for (int i = 0; i < 48; i++) v = crc16_step(v, i == b);
+        for (int j = 0; j < 16; j++) if (v & (1u << j)) t.k[j] |= (1ull << (63 - b));
+    }
+    return t;
+}
+#ifdef SDV_EMU
+static const Crc16Tables c_crc16 = make_crc16_tables();
+#else
+__device__ __constant__ const Crc16Tables c_crc16 = make_crc16_tables();
+#endif
+__device__ inline void calc_crc(L16 &l)             /* one lane on its own */
+{
+    uint32_t crc = 0;
+    for (int j = 0; j < 16; j++) crc |= (uint32_t)(__popcll(l.v & c_crc16.k[j]) & 1) << j;
+    l.calc_crc = (uint16_t)(crc ^ c_crc16.base);
+}
+__device__ inline bool crc_valid_ignore_forced(const L16 &l) { return l.calc_crc == (uint16_t)(l.v & 0xFFFF); }
+__device__ inline bool crc_valid(const L16 &l) { return !l.forced_bad && crc_valid_ignore_forced(l); }
+__device__ inline void set_invalid_crc(L16 &l) { l.v = (l.v & ~0xFFFFull) | (uint64_t)(uint16_t)~l.calc_crc; }
+__device__ inline void base_clear(L16 &l)           /* PCMLine::clear, pcmline.cpp:96-116 */
+{
+    l.black = l.white = l.ref_low = l.ref_level = l.ref_high = 0;
+    coords_clear(l.coords);
+    l.hyst = l.shift = 0;
+    l.coords_sweeped = l.by_ext_tune = false;
+    l.calc_crc = 0;
+    l.bw_set = l.coords_set = l.forced_bad = false;
+    l.service = SDV_SRV_NO;
+    l.pixel_start = 0; l.pixel_stop = 1; l.pso = 0; l.psm = 128; l.hpsm = 64;
+}
+__device__ inline void p16_clear(L16 &l)            /* PCM16X0SubLine::clear, pcm16x0subline.cpp:59-79 */
+{
+    base_clear(l);
+    l.control_bit = true; l.line_part = 0; l.picked_l = l.picked_r = 0; l.queue_order = 0;
+    l.v = 0; l.calc_crc = P16_CRC_SILENT;
+    set_invalid_crc(l);
+}
+__device__ inline void set_service(L16 &l, uint8_t srv) { base_clear(l); l.service = srv; }     /* PCMLine::setServiceLine: base clear() only */
+__device__ inline void set_ppb(L16 &l, const Coords &c)     /* pcmline.cpp:506-519 with 193 cells between the coordinates */
+{
+    l.psm = (uint32_t)((int)c.stop - (int)c.start);
+    l.psm = (l.psm * 128u + P16_BITS / 2) / P16_BITS;
+    l.pso = c.start;
+    l.hpsm = (l.psm + 1) / 2;
+}
+__device__ inline uint8_t get_ppb(const L16 &l) { return (uint8_t)(l.psm / 128u); }
+/* getVideoPixeBylCalc (pcmline.cpp:249-311): both shift tables are {0, +1, -1, +2, -2}, so the shift is uniform along the line */
+__device__ inline int pixel_of(const L16 &l, int bit, int stage)
+{
+    int32_t vp = (int32_t)((uint32_t)bit * l.psm + l.hpsm);
+    vp = vp / 128 + l.pso;
+    const int sh = stage == 0 ? 0 : (stage == 1 ? 1 : (stage == 2 ? -1 : (stage == 3 ? 2 : -2)));
+    vp += sh;
+    if (vp < (int32_t)l.pixel_start) vp = l.pixel_start;
+    else if (vp >= (int32_t)l.pixel_stop) vp = (int32_t)l.pixel_stop - 1;
+    return vp;
+}
+__device__ __forceinline__ int part_start_bit(uint8_t part) { return part == PART_LEFT ? 0 : (part == PART_MIDDLE ? P16_DATA : 2 * P16_DATA + 1); }
+
+/* fillPCM16X0 (binarizer.cpp:7134-7319), one lane on its own: the two-level automaton over the 64 cell centres of the part */
+__device__ inline void fill_pcm16(L16 &l, const uint8_t *px_row, uint8_t part, int stage)
+{
+    const int b0 = part_start_bit(part);
+    bool prev_high = false;
+    uint64_t v = 0;
+    for (int i = 0; i < P16_DATA; i++) {
+        const uint8_t px = px_row[pixel_of(l, b0 + i, stage)];
+        bool one;
+        if (!prev_high) { one = px > l.ref_low; prev_high = one; }
+        else { one = px >= l.ref_high; prev_high = one; }
+        v = (v << 1) | (uint64_t)(one ? 1 : 0);
+    }
+    l.v = v;
+    calc_crc(l);
+    l.control_bit = true;
+    if (crc_valid(l)) if (px_row[pixel_of(l, 2 * P16_DATA, stage)] < l.ref_level) l.control_bit = false;
+}
+/* the same for the whole wave (wave-uniform callers only): lane i samples cell i of the part */
+__device__ inline void fill_pcm16_wave(L16 &l, const uint8_t *px_row, uint8_t part, int stage)
+{
+    const int lane = lane_id();
+    const uint8_t p0 = px_row[pixel_of(l, part_start_bit(part) + lane, stage)];
+    const uint64_t a_lo = __ballot(p0 > l.ref_low), b_lo = __ballot(p0 >= l.ref_high);
+    uint64_t s_lo, s_hi;
+    solve_automaton(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
+    l.v = __brevll(s_lo);
+    const int par = __popcll(l.v & c_crc16.k[lane & 15]) & 1;
+    const uint64_t cb = __ballot(par);
+    l.calc_crc = (uint16_t)((uint16_t)(cb & 0xFFFF) ^ c_crc16.base);
+    l.control_bit = true;
+    if (crc_valid(l)) if (px_row[pixel_of(l, 2 * P16_DATA, stage)] < l.ref_level) l.control_bit = false;
+}
+
+/* pickCutBitsUpPCM16X0 (binarizer.cpp:6599-7013): the left bits of the left part's first word, the right bits of the right part's CRCC */
+__device__ inline void pick_cut_bits(const BinCtx &c, L16 &l, uint8_t part)
+{
+    l.picked_l = l.picked_r = 0;
+    if (part != PART_LEFT && part != PART_RIGHT) return;
+    const bool left = part == PART_LEFT;
+    int max_cut = left ? c.ps.left_bit_pick : c.ps.right_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+    int first = left ? c.scan_start : c.scan_end, bits = 0;
+    const int half_ppb = ((int)get_ppb(l) + 1) / 2;
+    for (int i = 0; i < max_cut; i++) {
+        const int cur = pixel_of(l, left ? i : P16_BITS - 1 - i, 0);
+        if ((left ? (cur - first) : (first - cur)) >= half_ppb) break;
+        if (i == 0) first = cur;
+        bits = i + 1;
+    }
+    if (c.force_bit_picker && crc_valid(l)) { if (left) l.picked_l = (uint8_t)bits; else l.picked_r = (uint8_t)bits; return; }
+    if (bits == 0) return;
+    const uint64_t orig = l.v;
+    const uint32_t lim = 1u << bits;
+    const int sh = left ? 64 - bits : 0;                    /* where the cut-off bits sit in the cells */
+    const uint64_t clean = orig & ~((uint64_t)(lim - 1) << sh);
+    bool patch_found = false, coll_lock = false;
+    uint64_t fix = 0;
+    for (uint32_t i = 0; i < lim; i++) {
+        l.v = clean | ((uint64_t)i << sh);
+        calc_crc(l);
+        if (crc_valid(l)) {
+            if (patch_found) { coll_lock = true; break; }
+            patch_found = true; fix = (uint64_t)i << sh;
+        }
+    }
+    if (coll_lock || !patch_found) { l.v = orig; calc_crc(l); if (coll_lock) l.forced_bad = true; return; }
+    l.v = clean | fix;
+    calc_crc(l);
+    if (left) l.picked_l = (uint8_t)bits; else l.picked_r = (uint8_t)bits;
+}
+
+/* fillDataWords (binarizer.cpp:7560-7670); false = the levels clip (STG_NO_GOOD) */
+template <bool kWave>
+__device__ inline bool fill_data_words(const BinCtx &c, L16 &l, const uint8_t *px_row, uint8_t part, uint8_t ref_delta, uint8_t shift_stg)
+{
+    if (ref_delta > HYST_DEPTH_MAX || shift_stg > SHIFT_STAGES_MAX) return false;
+    const uint8_t low_ref = get_low_level(l.ref_level, ref_delta), high_ref = get_high_level(l.ref_level, ref_delta);
+    l.ref_low = low_ref; l.ref_high = high_ref;
+    if (low_ref <= l.black) { set_invalid_crc(l); return false; }
+    if (high_ref >= l.white) { set_invalid_crc(l); return false; }
+    l.hyst = ref_delta; l.shift = shift_stg;
+    if (part == PART_FULL) return false;                    /* fillPCM16X0 answers STG_NO_GOOD outside the three parts (:7199-7203) */
+    if (kWave) fill_pcm16_wave(l, px_row, part, shift_stg); else fill_pcm16(l, px_row, part, shift_stg);
+    if ((!crc_valid(l) && (l.ref_level > c.ps.min_white_lvl) && ((c.ps.left_bit_pick != 0) || (c.ps.right_bit_pick != 0))) || c.force_bit_picker)
+        pick_cut_bits(c, l, part);
+    return true;
+}
+
+/* readPCMdata (binarizer.cpp:7695-8055) for a line whose reference level was not swept (see pcm1_bin_device.h, read_pcm_data) */
+template <bool kWave>
+__device__ inline void read_pcm_data(const BinCtx &c, L16 &l, const uint8_t *px_row, uint8_t part, uint8_t hyst_lim, uint8_t shift_lim)
+{
+    set_ppb(l, l.coords);
+    if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
+    if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
+    bool found = false;
+    for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
+        bool invalid_hyst = false;
+        for (uint8_t s = 0; s <= shift_lim; s++) {
+            if (!fill_data_words<kWave>(c, l, px_row, part, h, s)) { invalid_hyst = true; break; }
+            if (crc_valid(l)) { found = true; break; }
+        }
+        if (invalid_hyst) break;
+    }
+    if (!found) fill_data_words<kWave>(c, l, px_row, part, 0, 0);
+}
+
+/* ---- searchPCM16X0Data (binarizer.cpp:4514-5271) ---------------------------------------------------------------------------- */
+__device__ inline SweepEnt grid_entry(uint32_t g, bool valid, int16_t start, int16_t stop)
+{
+    SweepEnt e = sweep_blank();
+    e.crc = (uint16_t)(g & 0xFFFF); e.hyst = (uint8_t)((g >> 16) & 0xF); e.shift = (uint8_t)((g >> 20) & 0xF);
+    e.start = start; e.stop = stop;
+    e.result = valid ? REF_CRC_OK : REF_BAD_CRC;
+    return e;
+}
+/* findMostFrequentCRC without skip_equal (:1829-1928): the most frequent entry wins whatever the runner-up's count */
+__device__ inline void stats_most_frequent_noskip(CrcStat *a, uint8_t &valid_cnt)
+{
+    a[0].result = 0; a[0].idx = 0; a[0].hyst = 0; a[0].shift = 0;
+    if (valid_cnt >= MAX_COLL_CRCS) valid_cnt = MAX_COLL_CRCS - 1;
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[i].result > a[0].result) { a[0].result = a[i].result; a[0].crc = a[i].crc; a[0].hyst = a[i].hyst; a[0].shift = a[i].shift; a[0].idx = i; }
+    if (a[0].result == 0) valid_cnt = 0;
+}
+__device__ __forceinline__ uint8_t sat_f(int v) { return (uint8_t)(v > 0x0F ? 0x0F : v); }
+
+/* Returns true when coordinates were found; l is left as the reference leaves its line object. */
+__device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords data_loc, uint8_t &hyst_lim, uint8_t &shift_lim)
+{
+    const int lane = lane_id();
+    int scan_step = 1, l0 = 0, l1 = 0, r0 = 0, r1 = 0;
+    for (int guard = 2; guard > 0; guard--) {
+        set_ppb(l, data_loc);
+        scan_step = get_ppb(l);
+        scan_step = scan_step >= P16_SEARCH_STEP_DIV ? scan_step / P16_SEARCH_STEP_DIV : 1;
+        const int span = (uint16_t)(scan_step * P16_SEARCH_MAX_OFS);
+        l0 = (int16_t)(data_loc.start - span); l1 = (int16_t)(data_loc.start + span);
+        r0 = (int16_t)(data_loc.stop - span); r1 = (int16_t)(data_loc.stop + span);
+        const int ss = c.scan_start, se = c.scan_end;
+        if ((l0 < ss && l1 < ss) || (l0 > ss && l1 > ss) || (r0 < se && r1 < se) || (r0 > se && r1 > se)) { data_loc.start = (int16_t)ss; data_loc.stop = (int16_t)se; }
+        else break;
+    }
+    const bool bitpick_previous = c.force_bit_picker;
+    c.force_bit_picker = true;
+    hyst_lim = 0;
+    shift_lim = (c.mode == SDV_MODE_DRAFT || c.mode == SDV_MODE_FAST) ? 0 : SHIFT_STAGES_SAFE;
+    const int n_left = (l1 - l0) / scan_step + 1, n_right = (r1 - r0) / scan_step + 1;
+    const int nl = n_left < P16_SEARCH_STEP_CNT ? n_left : P16_SEARCH_STEP_CNT, nr = n_right < P16_SEARCH_STEP_CNT ? n_right : P16_SEARCH_STEP_CNT;
+    const int n_reads = nl * nr * P16_SUBLINES;
+    const bool entry_forced = l.forced_bad;
+    /* every read of the grid, as if the line object came to it clean: (row, col, part) in the reference's order */
+    __syncthreads();
+    for (int q = lane; q < n_reads; q += 64) {
+        const int pair = q / P16_SUBLINES, part = q - pair * P16_SUBLINES, row = pair / nr, col = pair - row * nr;
+        L16 t = l;
+        coords_set(t.coords, (int16_t)(l0 + row * scan_step), (int16_t)(r1 - col * scan_step));
+        read_pcm_data<false>(c, t, lds.w.px, (uint8_t)(PART_LEFT + part), hyst_lim, shift_lim);
+        int hy = t.hyst;
+        const bool picked = (part == 0 && t.picked_l != 0) || (part == 2 && t.picked_r != 0);
+        if (part == 0 && t.picked_l != 0) hy = sat_f(hy + 0x02);
+        if (part == 2 && t.picked_r != 0) hy = sat_f(hy + 0x03);
+        lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24)
+                      | ((uint32_t)((t.forced_bad && !entry_forced) ? 1 : 0) << 25) | ((uint32_t)(picked ? 1 : 0) << 26);
+    }
+    __syncthreads();
+    /* the walk over the grid and the votes: serial, on lane 0 */
+    if (lane == 0) {
+        SweepEnt *sw = lds.w.sweep;
+        uint8_t valid_left = 0, left_ofs = 0xFF;
+        bool forced = entry_forced, lock_left = false;
+        int last_read = -1, coll_read = -1;
+        stats_reset(lds.lstats, MAX_COLL_CRCS);
+        for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[SW_LEFT + i] = sweep_blank();
+        for (int row = 0; row < nl; row++) {
+            uint8_t valid_right = 0, valid_p[3] = { 0, 0, 0 }, right_ofs = 0xFF;
+            for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) { sw[SW_P0 + i] = sw[SW_P1 + i] = sw[SW_P2 + i] = sw[SW_RIGHT + i] = sweep_blank(); }
+            stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
+            for (int p = 0; p < 3; p++) stats_reset(lds.pstats[p], MAX_COLL_CRCS);
+            bool lock_right = false, lock_min = false;
+            int step_min = 0, step_max = P16_SEARCH_STEP_CNT;
+            const int16_t start_ofs = (int16_t)(l0 + row * scan_step);
+            for (int col = 0; col < nr; col++) {
+                const int16_t stop_ofs = (int16_t)(r1 - col * scan_step);
+                bool ok[3];
+                for (int p = 0; p < 3; p++) {
+                    const int q = (row * nr + col) * P16_SUBLINES + p;
+                    const uint32_t g = lds.grid[q];
+                    /* a line object that is forced bad reads nothing valid; the Bit Picker then tries to patch and puts the words back */
+                    ok[p] = !forced && ((g >> 24) & 1) != 0;
+                    uint32_t ge = g;
+                    if (forced) ge = (g & 0xFFFFu) | (g & (0xFu << 20));           /* CRCC as read stays; no picked-bits penalty; depth 0 */
+                    sw[(p == 0 ? SW_P0 : (p == 1 ? SW_P1 : SW_P2)) + col] = grid_entry(ge, ok[p], start_ofs, stop_ofs);
+                    if (ok[p]) {
+                        const SweepEnt &e = sw[(p == 0 ? SW_P0 : (p == 1 ? SW_P1 : SW_P2)) + col];
+                        stats_update(lds.pstats[p], e.crc, e.hyst, e.shift, valid_p[p]);
+                        if (!lock_min) { step_min = col; lock_min = true; }
+                        step_max = col;
+                    }
+                    if (!forced && ((g >> 25) & 1) != 0) { forced = true; if (coll_read < 0) coll_read = q; }
+                    last_read = q;
+                }
+                if (lock_right && !ok[0] && !ok[1] && !ok[2]) break;
+                if (!lock_right && ok[0] && ok[1] && ok[2]) lock_right = true;
+            }
+            for (int p = 0; p < 3; p++)
+                if (valid_p[p] > 0) {
+                    sdvp1b::stats_most_frequent(lds.pstats[p], valid_p[p]);
+                    const int base = p == 0 ? SW_P0 : (p == 1 ? SW_P1 : SW_P2);
+                    /* invalidateNonFrequentCRCs (:1931-1982) on this part's row */
+                    for (int i = 0; i < P16_SEARCH_STEP_CNT; i++)
+                        if (sw[base + i].result == REF_CRC_OK) { if (valid_p[p] == 0 || sw[base + i].crc != lds.pstats[p][0].crc) sw[base + i].result = REF_CRC_COLL; }
+                }
+            if (step_max >= P16_SEARCH_STEP_CNT) step_max = P16_SEARCH_STEP_CNT - 1;
+            uint8_t valid_crcs = 0;
+            for (int i = step_min; i <= step_max; i++) {
+                SweepEnt &r = sw[SW_RIGHT + i];
+                const SweepEnt p0 = sw[SW_P0 + i], p1 = sw[SW_P1 + i], p2 = sw[SW_P2 + i];
+                valid_crcs = 0;
+                if (p1.result == REF_CRC_OK) {
+                    valid_crcs++;
+                    r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.shift = p1.shift; r.start = p1.start; r.stop = p1.stop;
+                    int hy = p1.hyst;
+                    if (p2.result == REF_CRC_OK) { valid_crcs++; hy = (uint8_t)(hy + p2.hyst); if (p2.shift > r.shift) r.shift = p2.shift; } else hy = (uint8_t)(hy + HYST_DEPTH_SAFE);
+                    if (p0.result == REF_CRC_OK) { valid_crcs++; hy = (uint8_t)(hy + p0.hyst); if (p0.shift > r.shift) r.shift = p0.shift; } else hy = (uint8_t)(hy + HYST_DEPTH_SAFE);
+                    r.hyst = sat_f(hy);
+                    stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                } else if (p0.result == REF_CRC_OK && p2.result == REF_CRC_OK) {
+                    valid_crcs = 2;
+                    r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.hyst = p2.hyst; r.shift = p2.shift; r.start = p2.start; r.stop = p2.stop;
+                    if (p0.hyst > r.hyst) { r.hyst = p0.hyst; r.shift = p0.shift; }
+                    else if (p0.hyst == r.hyst) { if (p0.shift > r.shift) r.shift = p0.shift; }
+                    r.hyst = sat_f((uint8_t)(r.hyst + HYST_DEPTH_SAFE));
+                    stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                } else r.result = REF_BAD_CRC;
+                if (valid_crcs == P16_SUBLINES) lock_left = true;
+            }
+            /* pickLevelByCRCStats works on WaveLds::sweep from index 0: the combined row is copied there for the call */
+            auto pick_right = [&](uint8_t &ofs) -> bool {
+                SweepEnt keep[P16_SEARCH_STEP_CNT];
+                for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) { keep[i] = sw[i]; sw[i] = sw[SW_RIGHT + i]; }
+                const bool ok = pick_level_by_crc_stats(lds.w, &ofs, (uint8_t)step_min, (uint8_t)step_max, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) == SPAN_OK;
+                for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[i] = keep[i];
+                return ok;
+            };
+            if (valid_right > 0) if (!pick_right(right_ofs)) valid_right = 0;
+            if (valid_right == 0) {
+                for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[SW_RIGHT + i] = sweep_blank();
+                stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
+                for (int i = step_min; i <= step_max; i++) {
+                    SweepEnt &r = sw[SW_RIGHT + i];
+                    const SweepEnt p0 = sw[SW_P0 + i], p2 = sw[SW_P2 + i];
+                    if (p2.result == REF_CRC_OK) {
+                        r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.shift = p2.shift; r.start = p2.start; r.stop = p2.stop;
+                        r.hyst = sat_f((uint8_t)(p2.hyst + HYST_DEPTH_MAX));
+                        stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                    } else if (p0.result == REF_CRC_OK) {
+                        r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.shift = p0.shift; r.start = p0.start; r.stop = p0.stop;
+                        r.hyst = sat_f((uint8_t)(p0.hyst + 2 * HYST_DEPTH_SAFE));
+                        stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                    } else r.result = REF_BAD_CRC;
+                }
+                if (valid_right > 0) if (!pick_right(right_ofs)) valid_right = 0;
+            }
+            if (valid_right > 0) {
+                SweepEnt le = sw[SW_RIGHT + right_ofs];
+                le.result = REF_CRC_OK;
+                sw[SW_LEFT + row] = le;
+                stats_update(lds.lstats, le.crc, le.hyst, le.shift, valid_left);
+                if (lock_left) {
+                    int nv = 0;
+                    if (sw[SW_P0 + right_ofs].result == REF_CRC_OK) nv++;
+                    if (sw[SW_P1 + right_ofs].result == REF_CRC_OK) nv++;
+                    if (sw[SW_P2 + right_ofs].result == REF_CRC_OK) nv++;
+                    if (nv < 2) break;
+                }
+            }
+        }
+        if (valid_left > 0) {
+            stats_most_frequent_noskip(lds.lstats, valid_left);
+            for (int i = 0; i < P16_SEARCH_STEP_CNT; i++)
+                if (sw[SW_LEFT + i].result == REF_CRC_OK) { if (valid_left == 0 || sw[SW_LEFT + i].crc != lds.lstats[0].crc) sw[SW_LEFT + i].result = REF_CRC_COLL; }
+        }
+        if (valid_left > 0) {
+            for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[i] = sw[SW_LEFT + i];
+            if (pick_level_by_crc_stats(lds.w, &left_ofs, 0, P16_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
+        }
+        lds.vote[0] = valid_left > 0 ? 1 : 0;
+        if (valid_left > 0) { lds.vote[1] = sw[left_ofs].start; lds.vote[2] = sw[left_ofs].stop; }
+        lds.vote[3] = last_read; lds.vote[4] = coll_read;
+    }
+    __syncthreads();
+    const bool found = lds.vote[0] != 0;
+    const int f_start = lds.vote[1], f_stop = lds.vote[2], last_read = lds.vote[3], coll_read = lds.vote[4];
+    __syncthreads();
+    /* what the last read the reference made leaves in the line object: forced bad if a collision happened before it */
+    if (last_read >= 0) {
+        const int pair = last_read / P16_SUBLINES, part = last_read - pair * P16_SUBLINES, row = pair / nr, col = pair - row * nr;
+        if (coll_read >= 0 && coll_read < last_read) l.forced_bad = true;
+        coords_set(l.coords, (int16_t)(l0 + row * scan_step), (int16_t)(r1 - col * scan_step));
+        read_pcm_data<true>(c, l, lds.w.px, (uint8_t)(PART_LEFT + part), hyst_lim, shift_lim);
+    }
+    c.force_bit_picker = bitpick_previous;
+    if (found) {
+        l.coords.start = (int16_t)f_start; l.coords.stop = (int16_t)f_stop;
+        l.coords_set = true; l.coords_sweeped = true;
+        return true;
+    }
+    l.coords = data_loc;
+    l.coords_sweeped = false;
+    return false;
+}
+
+/* findPCM16X0Coordinates (binarizer.cpp:5819-6042); scan_done = VideoLine::scan_done of the line being read */
+__device__ inline void find_pcm16_coordinates(BinCtx &c, L16 &l, P16Lds &lds, const Coords &history, bool &scan_done, uint8_t &hyst_lim, uint8_t &shift_lim)
+{
+    if (scan_done) return;
+    Coords dc; coords_clear(dc);
+    const int ss = c.scan_start, se = c.scan_end;
+    const int margin = (uint16_t)(se - ss) / 40;
+    if (coords_valid(history)) dc = history;
+    else {
+        dc.start = (int16_t)ss;
+        bool state = lds.w.px[ss] > l.ref_level;
+        for (int p = ss; p < ss + margin; p++) {
+            if (!state) { if (lds.w.px[p] > l.ref_level) { dc.start = (int16_t)(p - 1); break; } }
+            else { if (lds.w.px[p] < l.ref_level) { dc.start = (int16_t)(p - 1); break; } }
+        }
+        dc.stop = (int16_t)se;
+        state = lds.w.px[se] > l.ref_level;
+        for (int p = se; p > se - margin; p--) {
+            if (!state) { if (lds.w.px[p] > l.ref_level) { dc.stop = (int16_t)(p + 1); break; } }
+            else { if (lds.w.px[p] < l.ref_level) { dc.stop = (int16_t)(p + 1); break; } }
+        }
+    }
+    const uint8_t in_hyst = hyst_lim, in_shift = shift_lim;
+    search_pcm16_data(c, l, lds, dc, hyst_lim, shift_lim);
+    hyst_lim = in_hyst; shift_lim = in_shift;
+    scan_done = true;
+}
+
+/* findBlackWhite (binarizer.cpp:3116-3473) over the PCM-16x0 windows of the line (findPCM16X0BW, :2603-2681: one in each third) */
+__device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &line, bool &was_bw_scanned)
+{
+    uint16_t pixel_limit = (uint16_t)(c.scan_end - c.scan_start);
+    const uint16_t eighth = (uint16_t)(pixel_limit / 8);
+    hist_clear(lds);
+    uint16_t from = (uint16_t)(pixel_limit / 5);
+    hist_add_range(lds, from, (uint16_t)(from + eighth));
+    from = (uint16_t)((uint16_t)(eighth * 4) + eighth / 2);
+    hist_add_range(lds, from, (uint16_t)(from + eighth));
+    const uint16_t to = (uint16_t)(c.scan_end - pixel_limit / 64);
+    hist_add_range(lds, (uint16_t)(to - eighth), to);
+
+    uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
+    uint32_t black_lvl_count, white_lvl_count, temp_calc;
+    uint16_t search_lim;
+    bool black_level_detected, white_level_detected;
+    useful_low = low_scan_limit = br_black = usefull_low_level(c.ps, lds);
+    useful_high = high_scan_limit = br_white = usefull_high_level(c.ps, lds);
+    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
+    low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
+    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
+    temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
+    temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
+    search_lim = most_frequent_brightness_count(lds);
+    search_lim = search_lim / 64;
+    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
+    while (brt_lev <= low_scan_limit) {
+        if (lds.hist[brt_lev] > black_lvl_count) {
+            black_lvl_count = lds.hist[brt_lev];
+            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
+        }
+        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
+        brt_lev++;
+    }
+    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
+    if (black_level_detected) {
+        while (brt_lev >= high_scan_limit) {
+            if ((int)brt_lev < ((int)br_black + (int)c.ps.min_contrast)) break;
+            if (lds.hist[brt_lev] > white_lvl_count) {
+                white_lvl_count = lds.hist[brt_lev];
+                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
+            }
+            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
+            brt_lev--;
+        }
+    }
+    if (black_level_detected && white_level_detected) {
+        bool invalidate = false;
+        if (br_white < br_black) invalidate = true;
+        else if (((int)br_white - (int)br_black) < (int)c.ps.min_contrast) invalidate = true;
+        else if (br_black > c.ps.max_black_lvl) invalidate = true;          /* do_ref_lvl_sweep is never set on this path */
+        else if (br_white < c.ps.min_white_lvl) invalidate = true;
+        if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
+    }
+    was_bw_scanned = true;
+    line.black = br_black; line.white = br_white;
+    line.bw_set = black_level_detected && white_level_detected;
+    return line.bw_set;
+}
+
+/* Binarizer::processLine (binarizer.cpp:443-1724), PCM16X0SubLine output, one part of the video line staged in lds.w.px */
+__device__ inline void process_line_p16(BinCtx &c, const Bin &b, bool coord_search, uint8_t part, bool &scan_done, P16Lds &lds, L16 &out, bool vl_doubled)
+{
+    p16_clear(out);
+    out.line_part = part == PART_MIDDLE ? 1 : (part == PART_RIGHT ? 2 : 0);
+    out.coords.doubled = vl_doubled;
+    if (c.scan_end > c.scan_start && P16_BITS <= (c.scan_end - c.scan_start)) { out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end; }
+    coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+    Coords forced; calc_forced_coords(b, c.ps, forced);
+    if (c.ps.en_force_coords && coords_valid(forced)) { out.coords = forced; out.coords_set = true; }
+    uint8_t state = STG_REF_FIND;
+    bool was_bw_scanned = false;
+    if (are_bw_levels_preset(b, c.ps)) { out.black = b.in_black; out.white = b.in_white; out.bw_set = true; }
+    if (is_ref_level_preset(b, c.ps)) state = coords_valid(b.in_coord) ? STG_INPUT_ALL : STG_INPUT_LEVEL;
+    uint8_t hyst_lim = b.in_max_hyst, shift_lim = b.in_max_shift;
+
+    for (int stage_count = 1; ; stage_count++) {
+        if (state == STG_INPUT_ALL) {                           /* :774-931 */
+            if (!out.bw_set) find_black_white_p16(c, lds.w, out, was_bw_scanned);
+            if (!coords_valid(forced)) out.coords = b.in_coord;
+            out.ref_level = b.in_ref;
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else if (b.in_ref >= out.white || b.in_ref <= out.black) state = STG_REF_FIND;
+            else {
+                read_pcm_data<true>(c, out, lds.w.px, part, hyst_lim, shift_lim);
+                if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; } else state = STG_REF_FIND;
+            }
+        } else if (state == STG_INPUT_LEVEL) {                  /* :932-1072 */
+            if (!was_bw_scanned) find_black_white_p16(c, lds.w, out, was_bw_scanned);
+            if (!coords_valid(forced)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+            out.ref_level = b.in_ref;
+            state = out.bw_set ? STG_REF_FIND : STG_NO_GOOD;
+        } else if (state == STG_REF_FIND) {                     /* :1073-1390 */
+            if (!was_bw_scanned) find_black_white_p16(c, lds.w, out, was_bw_scanned);
+            if (!out.bw_set) state = STG_NO_GOOD;
+            else {
+                hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN;
+                state = STG_READ_PCM;
+                out.ref_level = pick_center_ref_level(c.ps, out.black, out.white);
+                if (coords_valid(forced)) { out.coords = forced; out.coords_set = true; }
+                else {
+                    if (!coords_valid(b.in_coord)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+                    else out.coords = b.in_coord;
+                    if (c.ps.en_coord_search && coord_search) {
+                        /* the search reads all three parts through the one line object and leaves the part mode as it found it */
+                        find_pcm16_coordinates(c, out, lds, b.in_coord, scan_done, hyst_lim, shift_lim);
+                    }
+                }
+                if (!out.coords_set) {                          /* :1301-1320 */
+                    if (c.mode == SDV_MODE_DRAFT) { hyst_lim = 2; shift_lim = SHIFT_STAGES_MIN; }
+                    else { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_SAFE; }
+                } else { hyst_lim = b.in_max_hyst; shift_lim = SHIFT_STAGES_SAFE; }
+            }
+        } else if (state == STG_READ_PCM) {                     /* :1401-1533 */
+            if (coords_valid(forced)) { hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN; }
+            if (out.coords_set) read_pcm_data<true>(c, out, lds.w.px, part, hyst_lim, shift_lim);
+            if (crc_valid(out)) state = STG_DATA_OK;
+            if (state != STG_DATA_OK) {
+                if (coords_valid(b.in_coord) && !coords_valid(forced) && !out.forced_bad && !out.coords_set) {
+                    if (coords_ne(out.coords, b.in_coord)) {
+                        out.coords = b.in_coord;
+                        read_pcm_data<true>(c, out, lds.w.px, part, hyst_lim, shift_lim);
+                        if (crc_valid(out)) state = STG_DATA_OK;
+                    }
+                }
+                if (state != STG_DATA_OK) state = STG_NO_GOOD;
+            }
+        } else if (state == STG_DATA_OK) {                      /* :1534-1621 */
+            if (out.forced_bad) state = STG_NO_GOOD;
+            else { out.coords_set = true; break; }              /* :1568-1574 */
+        } else {                                                /* STG_NO_GOOD, :1622-1669 */
+            if (crc_valid(out)) set_invalid_crc(out);
+            break;
+        }
+        if (stage_count > STG_MAX) break;
+    }
+}
+
+__device__ inline void emit_rec(const L16 &l, uint32_t frame, uint16_t line_no, bool from_doubled, sdv_pcm16x0_bin_rec *dst)
+{
+    if (lane_id() != 0) return;
+    sdv_pcm16x0_bin_rec r;
+    r.frame_number = frame; r.line_number = line_no;
+    for (int k = 0; k < 4; k++) r.words[k] = get_word(l, k);
+    r.calc_crc = l.calc_crc;
+    r.data_start = l.coords.start; r.data_stop = l.coords.stop;
+    r.queue_order = l.queue_order;
+    r.black_level = l.black; r.white_level = l.white; r.ref_low = l.ref_low; r.ref_level = l.ref_level; r.ref_high = l.ref_high;
+    r.hysteresis_depth = l.hyst; r.shift_stage = l.shift; r.service_type = l.service;
+    r.picked_bits_left = l.picked_l; r.picked_bits_right = l.picked_r;
+    r.flags = (uint8_t)((l.coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) | (l.by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l.bw_set ? SDV_LF_BW_SET : 0) |
+                        (l.coords_set ? SDV_LF_COORDS_SET : 0) | (l.forced_bad ? SDV_LF_FORCED_BAD : 0) | (crc_valid(l) ? SDV_LF_CRC_VALID : 0) |
+                        (from_doubled ? SDV_LF_FROM_DOUBLED : 0));
+    r.line_part = l.line_part; r.control_bit = l.control_bit ? 1 : 0; r._pad = 0;
+    *dst = r;
+}
+
+} // namespace sdvp16

@@ -1,0 +1,502 @@
+/*
+ * pcm16_frames_device.h - PCM-16x0 frame driver: the PCM-16x0 branch of VideoToDigital::doBinarize (videotodigital.cpp:698-1815)
+ * and VideoToDigital::prescanCoordinates (:148-345) around the line binarizer of pcm16_bin_device.h (SURVEY.md section 8 row a11
+ * for PCM-16x0).  Same two kernels per round and the same scheduling as PCM-1 (pcm1_frames_device.h); what differs:
+ *   - a video line is read three times (left, middle, right third, :902-925) and queued as three PCM16X0SubLines; the parts of a
+ *     line hand levels and coordinates to each other (:1455-1511) and a part forced bad takes the parts behind it along (:1168-1180);
+ *   - the prescan reads the right third of its four lines (:253-259) and leaves VideoLine::scan_done set on them, so the main pass
+ *     does not search those lines again (binarizer.cpp:5846);
+ *   - the window of the last valid coordinates holds 27 entries (9 lines x 3 parts, :1265-1273), so the chain state is longer.
+ */
+#pragma once
+#include "pcm16_bin_device.h"
+#include "pcm1_frames_device.h"
+
+namespace sdvp16f {
+using namespace sdv;
+using namespace sdvp16;
+using sdvp1f::PrescanRes;
+using sdvp1f::prescan_ref_of;
+using sdvp1f::frame_buf_lines;
+using sdvp1f::frame_buf_row;
+using sdvp1f::prescan_runs;
+using sdvp1f::ctx_for_line;
+using sdvp1f::COORD_CHECK_LINES;
+using sdvp1f::COORD_CHECK_PARTS;
+
+enum { P16_LINES_PF = 245 };                                    /* PCM16X0DataStitcher::LINES_PF, pcm16x0datastitcher.h:124 */
+enum { LV16 = COORD_HISTORY_DEPTH * P16_SUBLINES };             /* 27 */
+
+/* the chain state of a PCM-16x0 stream: sdv_v2d_state with a last-valid window of 27 (entries 9.. in `more`) */
+struct State16 { sdv_v2d_state s; sdv_coord more[LV16 - COORD_HISTORY_DEPTH]; };
+
+struct FrameArgs16 {
+    FrameArgs f;                    /* geometry, flags, stats, scratch as for STC-007 (f.recs, f.states_in/out unused) */
+    const State16 *states_in; State16 *states_out;
+    sdv_pcm16x0_bin_rec *recs16;    /* frame k: recs16 + k*(3*height+3) (+1 behind the NEW_FILE frame) */
+    PrescanRes *prescan;            /* [n_total][COORD_CHECK_LINES]; pad[0] = VideoLine::scan_done after the prescan read */
+    uint2 *frame_med;               /* [n_total] what frame f pushed into the multi-frame history: {coordinate key, 1} or {0, 0} (nothing) */
+};
+struct Lds16 { P16Lds p; uint32_t lv_keys16[LV16]; };
+
+/* ---- prescan: block = (frame, k) ------------------------------------------------------------------------------------------ */
+__device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, int k)
+{
+    const FrameArgs &a = a16.f;
+    PrescanRes r; r.start = r.stop = 0; r.ref = 0; r.valid = 0; r.pad[0] = r.pad[1] = 0;
+    if (prescan_runs(a, f)) {
+        const int gap = frame_buf_lines(a, f) / (COORD_CHECK_PARTS - 1);
+        const int row = frame_buf_row(a, f, (k + 1) * gap);
+        if (row >= 0) {
+            sdvp1b::stage_row(lds.p.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
+            BinCtx c; Bin b;
+            b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
+            ctx_for_line(a, c, b);
+            L16 out;
+            bool scan_done = false;
+            process_line_p16(c, b, true, PART_RIGHT, scan_done, lds.p, out, a.doubled != 0);
+            if (crc_valid(out)) { r.start = out.coords.start; r.stop = out.coords.stop; r.ref = out.ref_level; r.valid = 1; }
+            r.pad[0] = scan_done ? 1 : 0;
+        }
+    }
+    if (lane_id() == 0) a16.prescan[(size_t)f * COORD_CHECK_LINES + k] = r;
+}
+
+/* ---- state of a PCM-16x0 frame wave --------------------------------------------------------------------------------------- */
+struct V2D16 {
+    V2D v;                          /* the part shared with STC-007; last_words unused */
+    uint8_t prescan_ref;
+    uint16_t last_w[3][3];          /* the data words of last_pcm16x0_p0/p1/p2_line */
+};
+
+__device__ inline void load_state16(V2D16 &w, Lds16 &lds, const State16 *s, const FrameArgs &a)
+{
+    v2d_load_state(w.v, lds.p.w, &s->s, a);
+    w.prescan_ref = (uint8_t)uni(prescan_ref_of(s->s));
+    for (int i = 0; i < LV16; i++) {
+        const sdv_coord cc = i < COORD_HISTORY_DEPTH ? s->s.last_valid[i] : s->more[i - COORD_HISTORY_DEPTH];
+        lds.lv_keys16[i] = coords_key(cc.data_start, cc.data_stop);
+    }
+    for (int p = 0; p < 3; p++) for (int k = 0; k < 3; k++) w.last_w[p][k] = 0;
+}
+
+__device__ inline bool link_holds16(const FrameArgs &a, int f, const State16 &out, State16 next_in)
+{
+    if (prescan_runs(a, f + 1)) next_in.s.bin = out.s.bin;             /* reset before it is read (prescanCoordinates :221) */
+    uint32_t x[sizeof(State16) / 4], y[sizeof(State16) / 4];
+    __builtin_memcpy(x, &out, sizeof(out));
+    __builtin_memcpy(y, &next_in, sizeof(next_in));
+    bool same = true;
+    for (unsigned i = 0; i < sizeof(State16) / 4; i++) same = same && (x[i] == y[i]);
+    return same;
+}
+
+__device__ inline void store_state16(const V2D16 &w, const Lds16 &lds, const FrameArgs16 &a16, int f)
+{
+    if (lane_id() != 0) return;
+    const FrameArgs &a = a16.f;
+    const V2D &v = w.v;
+    State16 o;
+    o.s.bin.in_def_black = v.bin.in_black; o.s.bin.in_def_white = v.bin.in_white; o.s.bin.in_def_reference = v.bin.in_ref; o.s.bin._pad = 0;
+    o.s.bin.in_def_start = v.bin.in_coord.start; o.s.bin.in_def_stop = v.bin.in_coord.stop;
+    o.s.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.s.bin._pad2 = 0;
+    o.s.do_ref_lvl_sweep = 0; o.s.reset_stats = v.reset_stats ? 1 : 0;
+    o.s.n_last_valid = (uint8_t)v.n_last; o.s.n_long_valid = (uint8_t)v.n_long;
+    const int n9 = v.n_last < COORD_HISTORY_DEPTH ? v.n_last : COORD_HISTORY_DEPTH;
+    const uint16_t lm = a.doubled ? (uint16_t)((1u << n9) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
+    o.s.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); o.s.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+    o.s.long_valid_doubled_mask = gm;
+    for (int i = 0; i < LV16; i++) {
+        sdv_coord cc; cc.data_start = 0; cc.data_stop = 0;
+        if (i < v.n_last) { cc.data_start = key_start(lds.lv_keys16[i]); cc.data_stop = key_stop(lds.lv_keys16[i]); }
+        if (i < COORD_HISTORY_DEPTH) o.s.last_valid[i] = cc; else o.more[i - COORD_HISTORY_DEPTH] = cc;
+    }
+    for (int i = 0; i < COORD_LONG_HISTORY; i++) {
+        if (i < v.n_long) { o.s.long_valid[i].data_start = key_start(lds.p.w.long_keys[i]); o.s.long_valid[i].data_stop = key_stop(lds.p.w.long_keys[i]); }
+        else { o.s.long_valid[i].data_start = 0; o.s.long_valid[i].data_stop = 0; }
+    }
+    o.s._pad[0] = 0; o.s._pad[1] = (uint8_t)(w.prescan_ref ^ 128);
+    a16.states_out[f] = o;
+    a.flag[f] = (f + 1 < a.n_total && !link_holds16(a, f, o, a16.states_in[f + 1])) ? VF_BREAK : VF_OK;
+}
+
+__device__ inline void begin_frame16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, int f)   /* :772-822 */
+{
+    const FrameArgs &a = a16.f;
+    V2D &v = w.v;
+    v.field_state = FIELD_NEW;
+    v.good_coords_in_field = v.pcm_lines_in_field = 0;
+    if (v.reset_stats) {
+        v.reset_stats = false;
+        v.n_last = v.nfv = v.nfi = v.n_long = 0;
+        coords_clear(v.frame_avg);
+        bin_set_good_parameters_reset(v.bin, a.preset);
+    }
+    coords_clear(v.frame_avg);
+    if (!a.preset.en_force_coords) {
+        if (prescan_runs(a, f)) {
+            bin_set_good_parameters_reset(v.bin, a.preset);
+            uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
+            for (int k = 0; k < COORD_CHECK_LINES; k++) {
+                const PrescanRes r = a16.prescan[(size_t)f * COORD_CHECK_LINES + k];
+                if (uni(r.valid)) { keys[n] = uniu(coords_key(r.start, r.stop)); refs[n] = (uint8_t)uni(r.ref); n++; }
+            }
+            for (int i = 1; i < n; i++)
+                for (int j = i; j > 0; j--) {
+                    if (keys[j - 1] > keys[j]) { const uint32_t t = keys[j]; keys[j] = keys[j - 1]; keys[j - 1] = t; }
+                    if (refs[j - 1] > refs[j]) { const uint8_t t = refs[j]; refs[j] = refs[j - 1]; refs[j - 1] = t; }
+                }
+            if (n > 0) { v.frame_avg = key_to_coords(keys[n / 2], a.doubled != 0); w.prescan_ref = refs[n / 2]; }
+        }
+        if (!coords_valid(v.frame_avg)) { uint32_t k; if (median_keys(lds.p.w.long_keys, v.n_long, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0); }
+        else v.bin.in_ref = w.prescan_ref;
+        if (coords_valid(v.frame_avg)) bin_set_data_coordinates2(v.bin, v.frame_avg.start, v.frame_avg.stop);
+    }
+}
+
+__device__ inline void set_good_parameters_p16(Bin &b, const sdv_bin_preset &ps, const L16 &l)   /* binarizer.cpp:353-377 */
+{
+    if (crc_valid_ignore_forced(l)) { b.in_ref = l.ref_level; bin_set_data_coordinates(b, l.coords); bin_set_bw_levels(b, ps, l.black, l.white); }
+}
+
+__device__ inline void service_line16(V2D16 &w, const FrameArgs &a, L16 &wl, uint8_t srv)       /* :1006-1114 */
+{
+    V2D &v = w.v;
+    p16_clear(wl);
+    set_service(wl, srv);
+    if (srv == SDV_SRV_NEW_FILE || srv == SDV_SRV_END_FILE) {
+        v.line_in_field_cnt = 0;
+        v.n_last = v.nfv = v.nfi = v.n_long = 0;
+        if (srv == SDV_SRV_END_FILE || !coords_valid(v.frame_avg)) bin_set_good_parameters_reset(v.bin, a.preset);
+    } else if (srv == SDV_SRV_END_FIELD) {
+        v.field_state = FIELD_NEW;
+        v.line_in_field_cnt = 0;
+        v.good_coords_in_field = 0; v.pcm_lines_in_field = 0;
+        for (int p = 0; p < 3; p++) for (int k = 0; k < 3; k++) w.last_w[p][k] = 0;
+    }
+}
+
+/* one part of a regular line, after Binarizer::processLine: VideoToDigital :1115-1634 (PCM-16x0 branches) */
+__device__ inline void post_part16(V2D16 &w, const FrameArgs &a, Lds16 &lds, L16 &wl, uint32_t *fv_keys, uint32_t *fi_keys, bool even_line,
+                                   bool &force_bad_line, bool scan_done)
+{
+    V2D &v = w.v;
+    const sdv_bin_preset &ps = a.preset;
+    const bool count_has_data = wl.bw_set;
+    const bool count_has_pcm = crc_valid(wl) || count_has_data;
+    const int part = wl.line_part;
+    wl.queue_order = v.line_in_field_cnt;                               /* :1141 */
+    if (count_has_pcm && v.field_state == FIELD_NEW) v.field_state = FIELD_UNSAFE;
+    if (crc_valid(wl) && force_bad_line) wl.forced_bad = true;          /* :1168-1180 */
+    if (crc_valid(wl)) {
+        v.good_coords_in_field++;
+        v.q_line_length = (uint16_t)a.width;
+        if (a.check_line_copy) {
+            if (v.field_state == FIELD_UNSAFE) {
+                set_good_parameters_p16(v.bin, ps, wl);
+                if (ps.en_first_line_dup) { wl.forced_bad = true; force_bad_line = true; }
+            } else {
+                int diff = 0;
+                for (int k = 0; k < 3; k++) diff += __popc((uint32_t)(uint8_t)(get_word(wl, k) ^ w.last_w[part][k]));   /* the XOR is truncated to uint8_t */
+                const int16_t s0 = (int16_t)get_word(wl, 0), s2 = (int16_t)get_word(wl, 2);
+                const bool almost_silent = (!(s0 >= 4) && !(s0 < -4)) || (!(s2 >= 4) && !(s2 < -4));                      /* pcm16x0subline.cpp:291-318 */
+                if (!almost_silent && diff <= (P16_DATA / BIT_DIFF_THRES_DIV)) { wl.forced_bad = true; if (!even_line) v.q_dup_odd++; else v.q_dup_even++; }
+            }
+        }
+        if (crc_valid_ignore_forced(wl)) {
+            const uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
+            __syncthreads();
+            if (lane_id() == 0) {
+                if (v.n_last == LV16) for (int i = 0; i < LV16 - 1; i++) lds.lv_keys16[i] = lds.lv_keys16[i + 1];
+                lds.lv_keys16[v.n_last == LV16 ? LV16 - 1 : v.n_last] = key;
+            }
+            if (v.n_last < LV16) v.n_last++;
+            __syncthreads();
+            fv_keys[v.nfv++] = key;
+            if (a.coordinate_damper && !ps.en_force_coords && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
+                Coords target; coords_clear(target);
+                uint32_t k;
+                if (median_keys(lds.lv_keys16, v.n_last, &k)) target = key_to_coords(k, false);
+                if (!coords_valid(target)) target = v.frame_avg;
+                if (coords_valid(target)) {
+                    const int16_t ds = (int16_t)(wl.coords.start - target.start), de = (int16_t)(wl.coords.stop - target.stop);
+                    const uint8_t in_delta = (uint8_t)(get_ppb(wl) * 3);
+                    if (((int)ds <= -(int)in_delta) || ((int)ds >= (int)in_delta) || ((int)de <= -(int)in_delta) || ((int)de >= (int)in_delta)) { wl.forced_bad = true; force_bad_line = true; }
+                }
+            }
+        }
+        if (crc_valid(wl)) set_good_parameters_p16(v.bin, ps, wl);
+        else { if (!even_line) v.q_bad_odd++; else v.q_bad_even++; }
+        if (part == 2) v.field_state = FIELD_INIT;
+    } else {
+        if (v.q_line_length == 0) v.q_line_length = (uint16_t)a.width;
+        if (coords_valid(wl.coords)) fi_keys[v.nfi++] = coords_key(wl.coords.start, wl.coords.stop);
+        if (count_has_data) {
+            Coords preset_coords; coords_clear(preset_coords);
+            if (!even_line) v.q_bad_odd++; else v.q_bad_even++;
+            if (!ps.en_force_coords) {
+                uint32_t k;
+                if (median_keys(lds.lv_keys16, v.n_last, &k)) preset_coords = key_to_coords(k, a.doubled != 0);
+                if (!coords_valid(preset_coords)) preset_coords = v.frame_avg;
+            }
+            if (part == 2) {
+                v.field_state = FIELD_INIT;
+                bin_set_data_coordinates(v.bin, preset_coords);
+                bin_set_bw_levels(v.bin, ps, 0, 0);
+            } else {                                                    /* :1455-1511: the next part of the same line */
+                v.bin.in_ref = wl.ref_level;
+                bin_set_bw_levels(v.bin, ps, wl.black, wl.white);
+                if (scan_done) bin_set_data_coordinates(v.bin, wl.coords);
+                else bin_set_data_coordinates(v.bin, preset_coords);
+            }
+        } else {
+            bin_set_bw_levels(v.bin, ps, 0, 0);
+        }
+    }
+    if (!even_line) v.q_odd++; else v.q_even++;
+    if (count_has_pcm) {
+        if (!even_line) v.q_pcm_odd++; else v.q_pcm_even++;
+        v.pcm_lines_in_field++;
+        for (int k = 0; k < 3; k++) w.last_w[part][k] = get_word(wl, k);
+    }
+    v.line_in_field_cnt++;
+}
+
+__device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
+{
+    const FrameArgs &a = a16.f;
+    V2D16 w; L16 wl;
+    load_state16(w, lds, &a16.states_in[f], a);
+    V2D &v = w.v;
+    const uint32_t frame_no = a.first_frame_no + (uint32_t)f;
+    const uint8_t *frame = a.luma + (size_t)f * a.frame_stride;
+    uint32_t *fv_keys = a.scratch + (size_t)f * 6u * (size_t)a.height;         /* three sub-lines per line, valid + invalid lists */
+    uint32_t *fi_keys = fv_keys + 3 * a.height;
+    size_t rec_base = (size_t)f * (size_t)(3 * a.height + 3);
+    if (a.new_file_frame >= 0 && f > a.new_file_frame) rec_base += 1;
+    sdv_pcm16x0_bin_rec *rec = a16.recs16 + rec_base;
+    const bool doubled = a.doubled != 0;
+
+    begin_frame16(w, a16, lds, f);
+    /* the rows the prescan has read: their VideoLine carries scan_done into the main pass */
+    int pre_row[COORD_CHECK_LINES]; bool pre_done[COORD_CHECK_LINES];
+    for (int k = 0; k < COORD_CHECK_LINES; k++) { pre_row[k] = -1; pre_done[k] = false; }
+    if (prescan_runs(a, f)) {
+        const int gap = frame_buf_lines(a, f) / (COORD_CHECK_PARTS - 1);
+        for (int k = 0; k < COORD_CHECK_LINES; k++) { pre_row[k] = frame_buf_row(a, f, (k + 1) * gap); pre_done[k] = uni(a16.prescan[(size_t)f * COORD_CHECK_LINES + k].pad[0]) != 0; }
+    }
+    const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
+    uint16_t line_num = 0;
+    if (f == a.new_file_frame) { service_line16(w, a, wl, SDV_SRV_NEW_FILE); emit_rec(wl, frame_no, 0, false, rec++); }
+    for (int field = 0; field < 2; field++) {
+        const int nl = n_field[field];
+        for (int idx = 0; idx < nl; idx++) {
+            line_num = (uint16_t)(field + 1 + 2 * idx);
+            if (f == a.end_file_frame) {
+                service_line16(w, a, wl, SDV_SRV_FILLER);
+                emit_rec(wl, frame_no, line_num, false, rec++);
+                continue;
+            }
+            const int row = 2 * idx + field;
+            sdvp1b::stage_row(lds.p.w.px, frame + (size_t)row * a.row_stride, a.width);
+            bool scan_done = false;
+            for (int k = 0; k < COORD_CHECK_LINES; k++) if (pre_row[k] == row && pre_done[k]) scan_done = true;
+            bool force_bad_line = false;
+            for (int sub = 0; sub < P16_SUBLINES; sub++) {
+                BinCtx c;
+                ctx_for_line(a, c, v.bin);
+                bool coord_search = true;                               /* :927-950 */
+                if (a.mode == SDV_MODE_DRAFT || a.mode == SDV_MODE_FAST) coord_search = !(v.good_coords_in_field > 9 || v.pcm_lines_in_field > 15);
+                process_line_p16(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
+                post_part16(w, a, lds, wl, fv_keys, fi_keys, (line_num % 2) == 0, force_bad_line, scan_done);
+                emit_rec(wl, frame_no, line_num, doubled, rec++);
+            }
+        }
+        line_num = (uint16_t)(field + 1 + 2 * nl);
+        service_line16(w, a, wl, SDV_SRV_END_FIELD);
+        emit_rec(wl, frame_no, line_num, false, rec++);
+    }
+    if (f == a.end_file_frame) {
+        line_num = (uint16_t)(line_num + 2);
+        service_line16(w, a, wl, SDV_SRV_END_FILE);
+        emit_rec(wl, frame_no, line_num, false, rec++);
+    }
+    line_num = (uint16_t)(line_num + 2);
+    service_line16(w, a, wl, SDV_SRV_END_FRAME);
+    v.q_odd = v.q_even = P16_LINES_PF;                                  /* :1643-1652 */
+    v.q_pcm_odd = (uint16_t)(v.q_pcm_odd / P16_SUBLINES); v.q_pcm_even = (uint16_t)(v.q_pcm_even / P16_SUBLINES);
+    v.q_bad_odd = (uint16_t)(v.q_bad_odd / P16_SUBLINES); v.q_bad_even = (uint16_t)(v.q_bad_even / P16_SUBLINES);
+    {   /* the median of the frame's valid coordinates is what v2d_end_frame pushes into long_valid_coords (:1668-1682) */
+        uint32_t mk = 0; bool pushed = median_keys(fv_keys, v.nfv, &mk);
+        if (pushed) { const Coords mc = key_to_coords(mk, false); pushed = coords_valid(mc); }
+        if (lane_id() == 0) { uint2 m; m.x = pushed ? mk : 0u; m.y = pushed ? 1u : 0u; a16.frame_med[f] = m; }
+    }
+    v2d_end_frame(v, a, lds.p.w, frame_no, fv_keys, fi_keys, &a.stats[f]);
+    emit_rec(wl, frame_no, line_num, false, rec++);
+    store_state16(w, lds, a16, f);
+}
+
+/* ---- prediction of the incoming states (the PCM-1 model, pcm1_frames_device.h, with the longer window) ------------------------ */
+struct PredictArgs16 { State16 *states; const PrescanRes *prescan; int first, hi; FrameArgs f; };
+
+/* the median of a state's window of last valid coordinates (videotodigital.cpp:348-371), or false when it is empty */
+__device__ inline bool last_valid_median16(const State16 &s0, sdv_coord *out)
+{
+    const int n = s0.s.n_last_valid > LV16 ? LV16 : s0.s.n_last_valid;
+    if (n == 0 || s0.s.reset_stats) return false;
+    uint32_t keys[LV16];
+    for (int i = 0; i < n; i++) { const sdv_coord cc = i < COORD_HISTORY_DEPTH ? s0.s.last_valid[i] : s0.more[i - COORD_HISTORY_DEPTH]; keys[i] = coords_key(cc.data_start, cc.data_stop); }
+    for (int i = 1; i < n; i++) { const uint32_t x = keys[i]; int j = i; while (j > 0 && keys[j - 1] > x) { keys[j] = keys[j - 1]; j--; } keys[j] = x; }
+    out->data_start = key_start(keys[n / 2]); out->data_stop = key_stop(keys[n / 2]);
+    return true;
+}
+/* sticky = the frames in between are taken to decode with the coordinates the stream already carries (the median of the window of
+ * last valid coordinates) instead of the ones their own prescan finds: what happens when the first line of a field is marked bad
+ * (no Header in this format, :1193-1211) and the worker falls back on its history for the lines behind it (:1431-1451) */
+__device__ inline State16 predict_state16(const PredictArgs16 &a, int k, int base, bool sticky = false)
+{
+    const State16 s0 = a.states[base];
+    State16 p = s0;
+    sdv_coord carried; carried.data_start = 0; carried.data_stop = 0;
+    const bool use_carried = sticky && last_valid_median16(s0, &carried);
+    const uint8_t dbl = a.f.doubled;
+    int n_long = s0.s.reset_stats ? 0 : s0.s.n_long_valid;
+    sdv_coord lg[COORD_LONG_HISTORY];
+    for (int i = 0; i < COORD_LONG_HISTORY; i++) lg[i] = s0.s.long_valid[i];
+    bool touched = false;
+    sdv_coord last; last.data_start = 0; last.data_stop = 0;
+    uint8_t pref = prescan_ref_of(s0.s);
+    int j0 = base; if (k - j0 > COORD_LONG_HISTORY + 1) j0 = k - (COORD_LONG_HISTORY + 1);
+    for (int j = j0; j < k; j++) {
+        if (!prescan_runs(a.f, j)) continue;
+        uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
+        for (int q = 0; q < COORD_CHECK_LINES; q++) { const PrescanRes r = a.prescan[(size_t)j * COORD_CHECK_LINES + q]; if (r.valid) { keys[n] = coords_key(r.start, r.stop); refs[n] = r.ref; n++; } }
+        if (n == 0) continue;
+        for (int i = 1; i < n; i++)
+            for (int q = i; q > 0; q--) {
+                if (keys[q - 1] > keys[q]) { const uint32_t t = keys[q]; keys[q] = keys[q - 1]; keys[q - 1] = t; }
+                if (refs[q - 1] > refs[q]) { const uint8_t t = refs[q]; refs[q] = refs[q - 1]; refs[q - 1] = t; }
+            }
+        last.data_start = key_start(keys[n / 2]); last.data_stop = key_stop(keys[n / 2]);
+        if (use_carried) last = carried;
+        pref = refs[n / 2];
+        touched = true;
+        if (n_long == COORD_LONG_HISTORY) { for (int i = 0; i + 1 < COORD_LONG_HISTORY; i++) lg[i] = lg[i + 1]; n_long--; }
+        lg[n_long++] = last;
+    }
+    if (touched) {
+        p.s.reset_stats = 0;
+        p.s.n_last_valid = LV16;
+        for (int i = 0; i < COORD_HISTORY_DEPTH; i++) p.s.last_valid[i] = last;
+        for (int i = 0; i < LV16 - COORD_HISTORY_DEPTH; i++) p.more[i] = last;
+        p.s.n_long_valid = (uint8_t)n_long;
+        for (int i = 0; i < COORD_LONG_HISTORY; i++) { if (i < n_long) p.s.long_valid[i] = lg[i]; else { p.s.long_valid[i].data_start = 0; p.s.long_valid[i].data_stop = 0; } }
+        const uint16_t lm = dbl ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : 0, gm = dbl ? (uint16_t)((1u << n_long) - 1u) : 0;
+        p.s.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); p.s.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+        p.s.long_valid_doubled_mask = gm;
+        p.s._pad[1] = (uint8_t)(pref ^ 128);
+        p.s.bin.in_def_start = last.data_start; p.s.bin.in_def_stop = last.data_stop; p.s.bin.in_def_from_doubled = dbl;
+    } else if (!s0.s.reset_stats && a.f.mode == SDV_MODE_DRAFT) {
+        const int16_t cs = s0.s.bin.in_def_start, ce = s0.s.bin.in_def_stop;
+        if (s0.s.bin.in_def_reference >= a.f.preset.min_ref_lvl && (cs != NO_COORD_LEFT && ce != NO_COORD_RIGHT && cs < ce)) {
+            const int m = k - base;
+            p.s.bin.in_def_from_doubled = dbl;
+            p.s.n_last_valid = LV16;
+            for (int i = 0; i < COORD_HISTORY_DEPTH; i++) { p.s.last_valid[i].data_start = cs; p.s.last_valid[i].data_stop = ce; }
+            for (int i = 0; i < LV16 - COORD_HISTORY_DEPTH; i++) { p.more[i].data_start = cs; p.more[i].data_stop = ce; }
+            const int total = (int)s0.s.n_long_valid + m;
+            const int keep = total > COORD_LONG_HISTORY ? COORD_LONG_HISTORY : total, drop = total - keep;
+            for (int i = 0; i < COORD_LONG_HISTORY; i++) {
+                const int src = i + drop;
+                if (i >= keep) { p.s.long_valid[i].data_start = 0; p.s.long_valid[i].data_stop = 0; }
+                else if (src < (int)s0.s.n_long_valid) p.s.long_valid[i] = s0.s.long_valid[src];
+                else { p.s.long_valid[i].data_start = cs; p.s.long_valid[i].data_stop = ce; }
+            }
+            p.s.n_long_valid = (uint8_t)keep;
+            const uint16_t lm = dbl ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : 0, gm = dbl ? (uint16_t)((1u << keep) - 1u) : 0;
+            p.s.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); p.s.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+            p.s.long_valid_doubled_mask = gm;
+        }
+    }
+    return p;
+}
+struct RepairArgs16 { PredictArgs16 p; const State16 *states_out; const int *list, *head; const uint8_t *sticky; int n; const uint2 *frame_med; };
+/* Repair of a run of broken links (pcm16_frames_engine.inc).  Heads (head[i] == list[i]) take their predecessor's real outcome; they
+ * come first in the list and are written by an earlier launch than the others read them.  A frame further into the run:
+ *   DRAFT mode (the whole tuning is handed on): predicted again from its run's head - or, when that tells nothing new, its own
+ *   predecessor's outcome;
+ *   the other modes, first attempt (sticky[i]): predicted again from the head with the coordinates the stream carries (predict_state16);
+ *   later attempts: its own predecessor's outcome (what a frame hands on depends little on what it was handed), except for the
+ *   multi-frame history, which only passes through the frames - that is rebuilt from the head's true state and what the frames
+ *   since then have pushed themselves, so that one wrong median does not need sixteen rounds to leave the chain. */
+__device__ inline void repair_body16(const RepairArgs16 &a, int i)
+{
+    const int k = a.list[i], h = a.head[i];
+    if (h == k) { a.p.states[k] = a.states_out[k - 1]; return; }
+    if (a.p.f.mode == SDV_MODE_DRAFT || a.sticky[i]) {
+        State16 p = predict_state16(a.p, k, h, a.p.f.mode != SDV_MODE_DRAFT);
+        const State16 cur = a.p.states[k];
+        uint32_t x[sizeof(State16) / 4], y[sizeof(State16) / 4];
+        __builtin_memcpy(x, &p, sizeof(p));
+        __builtin_memcpy(y, &cur, sizeof(cur));
+        bool same = true;
+        for (unsigned q = 0; q < sizeof(State16) / 4; q++) same = same && (x[q] == y[q]);
+        a.p.states[k] = same ? a.states_out[k - 1] : p;
+        return;
+    }
+    State16 p = a.states_out[k - 1];
+    const State16 h_in = a.p.states[h];
+    int n_long = h_in.s.reset_stats ? 0 : h_in.s.n_long_valid;
+    sdv_coord lg[COORD_LONG_HISTORY];
+    for (int q = 0; q < COORD_LONG_HISTORY; q++) lg[q] = h_in.s.long_valid[q];
+    for (int j = h; j < k; j++) {
+        const uint2 m = a.frame_med[j];
+        if (!m.y) continue;
+        if (n_long == COORD_LONG_HISTORY) { for (int q = 0; q + 1 < COORD_LONG_HISTORY; q++) lg[q] = lg[q + 1]; n_long--; }
+        lg[n_long].data_start = key_start(m.x); lg[n_long].data_stop = key_stop(m.x); n_long++;
+    }
+    p.s.n_long_valid = (uint8_t)n_long;
+    for (int q = 0; q < COORD_LONG_HISTORY; q++) { if (q < n_long) p.s.long_valid[q] = lg[q]; else { p.s.long_valid[q].data_start = 0; p.s.long_valid[q].data_stop = 0; } }
+    p.s.long_valid_doubled_mask = a.p.f.doubled ? (uint16_t)((1u << n_long) - 1u) : 0;
+    a.p.states[k] = p;
+}
+struct VerifyArgs16 { FrameArgs f; const State16 *states_in, *states_out; };
+__device__ inline void verify_body16(const VerifyArgs16 &a, int k)
+{
+    a.f.flag[k] = link_holds16(a.f, k, a.states_out[k], a.states_in[k + 1]) ? VF_OK : VF_BREAK;
+}
+
+} // namespace sdvp16f
+
+#ifndef SDV_P16_WAVES_PER_EU
+#define SDV_P16_WAVES_PER_EU 3
+#endif
+__global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_prescan(sdvp16f::FrameArgs16 a)
+{
+    __shared__ sdvp16f::Lds16 lds;
+    const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp16f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp16f::COORD_CHECK_LINES;
+    sdvp16f::prescan_body(a, lds, f, i % sdvp16f::COORD_CHECK_LINES);
+}
+__global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_frames_bin(sdvp16f::FrameArgs16 a)
+{
+    __shared__ sdvp16f::Lds16 lds;
+    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x;
+    sdvp16f::frame_body16(a, lds, f);
+}
+#ifndef SDV_EMU
+__global__ void sdv_k_pcm16_predict(sdvp16f::PredictArgs16 a)
+{
+    const int k = a.first + 1 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k < a.hi) a.states[k] = sdvp16f::predict_state16(a, k, a.first, true);
+}
+__global__ void sdv_k_pcm16_repair(sdvp16f::RepairArgs16 a, int lo, int hi)
+{
+    const int i = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < hi) sdvp16f::repair_body16(a, i);
+}
+__global__ void sdv_k_pcm16_verify(sdvp16f::VerifyArgs16 a)
+{
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k + 1 < a.f.n_total) sdvp16f::verify_body16(a, k);
+}
+#endif

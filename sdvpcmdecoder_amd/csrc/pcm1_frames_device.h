@@ -30,6 +30,7 @@ struct FrameArgs1 {
     FrameArgs f;                    /* geometry, flags, states, stats, scratch as for STC-007 (f.recs unused) */
     sdv_pcm1_bin_rec *recs1;        /* frame k: recs1 + k*(height+3) (+1 behind the NEW_FILE frame) */
     PrescanRes *prescan;            /* [n_total][COORD_CHECK_LINES] */
+    uint2 *frame_med;               /* [n_total] what frame f pushed into the multi-frame history: {coordinate key, 1} or {0, 0} (nothing) */
 };
 
 /* sdv_v2d_state::_pad[1] carries prescan_ref (videotodigital.cpp:703, 730: a local of the worker, 128 at its start) as its distance
@@ -345,6 +346,11 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
     line_num = (uint16_t)(line_num + 2);
     v2d1_service_line(w, a, wl, SDV_SRV_END_FRAME);
     v.q_odd = v.q_even = P1_LINES_PF;                               /* :1638-1642 */
+    {   /* the median of the frame's valid coordinates is what v2d_end_frame pushes into long_valid_coords (:1668-1682) */
+        uint32_t mk = 0; bool pushed = median_keys(fv_keys, v.nfv, &mk);
+        if (pushed) { const Coords mc = key_to_coords(mk, false); pushed = coords_valid(mc); }
+        if (lane_id() == 0) { uint2 m; m.x = pushed ? mk : 0u; m.y = pushed ? 1u : 0u; a1.frame_med[f] = m; }
+    }
     v2d_end_frame(v, a, lds.w, frame_no, fv_keys, fi_keys, &a.stats[f]);
     emit_rec(wl, frame_no, line_num, false, rec++);
     v2d1_store_state(w, lds.w, &a.states_out[f], a);
@@ -357,10 +363,26 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
  * known before any frame is decoded.  DRAFT mode has no prescan: there the state is handed on as it is, like for STC-007. */
 struct PredictArgs1 { sdv_v2d_state *states; const PrescanRes *prescan; int first, hi; const int *first_of; FrameArgs f; };
 
-__device__ inline sdv_v2d_state predict_state1(const PredictArgs1 &a, int k, int base)
+/* the median of a state's window of last valid coordinates (videotodigital.cpp:348-371), or false when it is empty */
+__device__ inline bool last_valid_median1(const sdv_v2d_state &s0, sdv_coord *out)
+{
+    const int n = s0.n_last_valid > COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH : s0.n_last_valid;
+    if (n == 0 || s0.reset_stats) return false;
+    uint32_t keys[COORD_HISTORY_DEPTH];
+    for (int i = 0; i < n; i++) keys[i] = coords_key(s0.last_valid[i].data_start, s0.last_valid[i].data_stop);
+    for (int i = 1; i < n; i++) { const uint32_t x = keys[i]; int j = i; while (j > 0 && keys[j - 1] > x) { keys[j] = keys[j - 1]; j--; } keys[j] = x; }
+    out->data_start = key_start(keys[n / 2]); out->data_stop = key_stop(keys[n / 2]);
+    return true;
+}
+/* sticky = the frames in between are taken to decode with the coordinates the stream already carries (the median of the window of
+ * last valid coordinates) instead of the ones their own prescan finds: what happens on a tape without Header lines, where the first
+ * line of a field is marked bad (:1193-1211) and the worker falls back on its history for the lines behind it (:1431-1451) */
+__device__ inline sdv_v2d_state predict_state1(const PredictArgs1 &a, int k, int base, bool sticky = false)
 {
     const sdv_v2d_state s0 = a.states[base];
     sdv_v2d_state p = s0;
+    sdv_coord carried; carried.data_start = 0; carried.data_stop = 0;
+    const bool use_carried = sticky && last_valid_median1(s0, &carried);
     const uint8_t dbl = a.f.doubled;
     int n_long = s0.reset_stats ? 0 : s0.n_long_valid;       /* a worker that starts over clears its histories first (:778-790) */
     sdv_coord lg[COORD_LONG_HISTORY];
@@ -381,6 +403,7 @@ __device__ inline sdv_v2d_state predict_state1(const PredictArgs1 &a, int k, int
                 if (refs[q - 1] > refs[q]) { const uint8_t t = refs[q]; refs[q] = refs[q - 1]; refs[q - 1] = t; }
             }
         last.data_start = key_start(keys[n / 2]); last.data_stop = key_stop(keys[n / 2]);
+        if (use_carried) last = carried;
         pref = refs[n / 2];
         touched = true;
         if (n_long == COORD_LONG_HISTORY) { for (int i = 0; i + 1 < COORD_LONG_HISTORY; i++) lg[i] = lg[i + 1]; n_long--; }
@@ -428,20 +451,43 @@ __device__ inline void predict_body1(const PredictArgs1 &a, int k)
 }
 
 /* Repair of a run of broken links (pcm1_frames_engine.inc): the frame behind the first link of the run has been given what its
- * predecessor really handed on (sdv_k_anchor); frame list[i] further into the run is predicted again from that frame, head[i] - and
- * when that tells nothing new (the model has no better idea than before), it takes its own predecessor's outcome instead. */
-struct RepairArgs1 { PredictArgs1 p; const sdv_v2d_state *states_out; const int *list, *head; int n; };
+ * predecessor really handed on (sdv_k_anchor).  A frame list[i] further into the run, whose run starts at frame head[i]:
+ *   DRAFT mode (the whole tuning is handed on): predicted again from its run's head - or, when that tells nothing new, its own
+ *   predecessor's outcome;
+ *   the other modes, first attempt (sticky[i]): predicted again from the head with the coordinates the stream carries (predict_state1);
+ *   later attempts: its own predecessor's outcome (what a frame hands on depends little on what it was handed), except for the
+ *   multi-frame history, which only passes through the frames - that is rebuilt from the head's true state and what the frames
+ *   since then have pushed themselves, so that one wrong median does not need sixteen rounds to leave the chain. */
+struct RepairArgs1 { PredictArgs1 p; const sdv_v2d_state *states_out; const int *list, *head; const uint8_t *sticky; int n; const uint2 *frame_med; };
 __device__ inline void repair_body1(const RepairArgs1 &a, int i)
 {
-    const int k = a.list[i];
-    sdv_v2d_state p = predict_state1(a.p, k, a.head[i]);
-    const sdv_v2d_state cur = a.p.states[k];
-    uint32_t x[sizeof(sdv_v2d_state) / 4], y[sizeof(sdv_v2d_state) / 4];
-    __builtin_memcpy(x, &p, sizeof(p));
-    __builtin_memcpy(y, &cur, sizeof(cur));
-    bool same = true;
-    for (unsigned q = 0; q < sizeof(sdv_v2d_state) / 4; q++) same = same && (x[q] == y[q]);
-    a.p.states[k] = same ? a.states_out[k - 1] : p;
+    const int k = a.list[i], h = a.head[i];
+    if (a.p.f.mode == SDV_MODE_DRAFT || a.sticky[i]) {
+        sdv_v2d_state p = predict_state1(a.p, k, h, a.p.f.mode != SDV_MODE_DRAFT);
+        const sdv_v2d_state cur = a.p.states[k];
+        uint32_t x[sizeof(sdv_v2d_state) / 4], y[sizeof(sdv_v2d_state) / 4];
+        __builtin_memcpy(x, &p, sizeof(p));
+        __builtin_memcpy(y, &cur, sizeof(cur));
+        bool same = true;
+        for (unsigned q = 0; q < sizeof(sdv_v2d_state) / 4; q++) same = same && (x[q] == y[q]);
+        a.p.states[k] = same ? a.states_out[k - 1] : p;
+        return;
+    }
+    sdv_v2d_state p = a.states_out[k - 1];
+    const sdv_v2d_state h_in = a.p.states[h];
+    int n_long = h_in.reset_stats ? 0 : h_in.n_long_valid;
+    sdv_coord lg[COORD_LONG_HISTORY];
+    for (int q = 0; q < COORD_LONG_HISTORY; q++) lg[q] = h_in.long_valid[q];
+    for (int j = h; j < k; j++) {
+        const uint2 m = a.frame_med[j];
+        if (!m.y) continue;
+        if (n_long == COORD_LONG_HISTORY) { for (int q = 0; q + 1 < COORD_LONG_HISTORY; q++) lg[q] = lg[q + 1]; n_long--; }
+        lg[n_long].data_start = key_start(m.x); lg[n_long].data_stop = key_stop(m.x); n_long++;
+    }
+    p.n_long_valid = (uint8_t)n_long;
+    for (int q = 0; q < COORD_LONG_HISTORY; q++) { if (q < n_long) p.long_valid[q] = lg[q]; else { p.long_valid[q].data_start = 0; p.long_valid[q].data_stop = 0; } }
+    p.long_valid_doubled_mask = a.p.f.doubled ? (uint16_t)((1u << n_long) - 1u) : 0;
+    a.p.states[k] = p;
 }
 /* the links of the chain after a round: flag[k] for k in [0, n - 1) */
 struct VerifyArgs1 { FrameArgs f; };

@@ -9,7 +9,11 @@
 #include "pcm1_stitch_device.h"
 #include "pcm1_bin_device.h"
 #include "pcm1_frames_device.h"
+#include "pcm16_bin_device.h"
+#include "pcm16_frames_device.h"
 #include "engine.inc"
 #include "stitch_engine.inc"
 #include "pcm1_engine.inc"
 #include "pcm1_frames_engine.inc"
+#include "pcm16_frames_engine.inc"
+#include "pcm16_engine.inc"

@@ -133,6 +133,10 @@ def load_library(path: str | None = None):
     lib.sdv_binarize_records.argtypes = [C.c_int, C.c_int, C.c_uint]
     lib.sdv_pcm1_binarize_frames.restype = C.c_int
     lib.sdv_pcm1_binarize_frames.argtypes = lib.sdv_binarize_frames.argtypes
+    lib.sdv_pcm16x0_binarize_frames.restype = C.c_int
+    lib.sdv_pcm16x0_binarize_frames.argtypes = lib.sdv_binarize_frames.argtypes
+    lib.sdv_pcm16x0_binarize_records.restype = C.c_size_t
+    lib.sdv_pcm16x0_binarize_records.argtypes = [C.c_int, C.c_int, C.c_uint]
     lib.sdv_pcm1_binarize_lines.restype = C.c_int
     lib.sdv_pcm1_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16,
                                             C.c_uint16, C.c_uint, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -377,6 +381,30 @@ class Engine:
         rc = self.lib.sdv_pcm1_binarize_frames(self._h, C.c_void_p(luma.data_ptr()), luma.stride(1), luma.stride(0), w, h, n,
                                                first_frame_no, flags, C.c_void_p(out_lines.data_ptr()), out_lines.shape[0],
                                                C.c_void_p(out_stats.data_ptr()), out_stats.shape[0], sptr)
+        self._check(rc)
+        return out_lines[:nrec], out_stats[:nst]
+
+    def pcm16x0_binarize_frames(self, luma, first_frame_no: int = 1, new_file: bool = False, doubled: bool = False,
+                                out_lines=None, out_stats=None, stream=None, end_file: bool = False):
+        """VideoToDigital::doBinarize with setPCMType(TYPE_PCM16X0) over whole frames: luma is a torch.uint8 CUDA tensor
+        (n_frames, height, width).  Returns (lines, stats): torch.uint8 CUDA tensors (n_records, 36) of sdv_pcm16x0_bin_rec - three
+        per video line, one per service line - and (n_frames, 32) of sdv_frame_stats."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 3 and luma.stride(2) == 1
+        n, h, w = luma.shape
+        flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0) | (FLAG_END_FILE if end_file else 0)
+        nrec = int(self.lib.sdv_pcm16x0_binarize_records(h, n, flags))
+        nst = n + (1 if end_file else 0)
+        if out_lines is None:
+            out_lines = torch.empty((nrec, 36), dtype=torch.uint8, device=luma.device)
+        if out_stats is None:
+            out_stats = torch.empty((nst, 32), dtype=torch.uint8, device=luma.device)
+        _check_out(out_lines, 36, luma.device, "out_lines")
+        _check_out(out_stats, 32, luma.device, "out_stats")
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        rc = self.lib.sdv_pcm16x0_binarize_frames(self._h, C.c_void_p(luma.data_ptr()), luma.stride(1), luma.stride(0), w, h, n,
+                                                  first_frame_no, flags, C.c_void_p(out_lines.data_ptr()), out_lines.shape[0],
+                                                  C.c_void_p(out_stats.data_ptr()), out_stats.shape[0], sptr)
         self._check(rc)
         return out_lines[:nrec], out_stats[:nst]
 

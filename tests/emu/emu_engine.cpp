@@ -7,13 +7,18 @@
 #define SDV_EMU 1
 #include "hip_emu.h"
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 #include "../../sdvpcmdecoder_amd/csrc/stc007_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/stc007_deint_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/stc007_stitch_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_stitch_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_bin_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_frames_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/pcm16_bin_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/pcm16_frames_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/stitch_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_frames_engine.inc"
+#include "../../sdvpcmdecoder_amd/csrc/pcm16_frames_engine.inc"
+#include "../../sdvpcmdecoder_amd/csrc/pcm16_engine.inc"

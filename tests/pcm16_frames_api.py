@@ -91,3 +91,25 @@ def run_cpu(lib, prefix, luma, mode, st, first_frame_no=1, handle=None, keep=Fal
         return recs, stats, h
     g("delete")(h)
     return recs, stats
+
+
+def run_engine(lib, eng, luma, mode, st, first_frame_no=1, configure=True):
+    """sdv_pcm16x0_binarize_frames on host buffers (the emulator build): one call for all frames."""
+    f = lib.sdv_pcm16x0_binarize_frames
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint, C.c_void_p, C.c_size_t,
+                  C.c_void_p, C.c_size_t, C.c_void_p]
+    if configure:
+        lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
+        lib.sdv_set_mode(eng, mode)
+        lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.c_void_p]
+        lib.sdv_set_bin_preset(eng, C.byref(_preset(st)))
+        lib.sdv_set_check_line_dup.argtypes = [C.c_void_p, C.c_int]
+        lib.sdv_set_check_line_dup(eng, st.get("check_line_dup", 1))
+    luma = np.ascontiguousarray(luma)
+    n, h, w = luma.shape
+    recs = np.zeros(n_records(n, h, st), dtype=BIN16_DTYPE)
+    stats = np.zeros(n + (1 if st.get("end_file") else 0), dtype=STATS_DTYPE)
+    flags = (1 if st.get("new_file") else 0) | (2 if st.get("doubled") else 0) | (4 if st.get("end_file") else 0)
+    rc = f(eng, luma.ctypes.data, w, w * h, w, h, n, first_frame_no, flags, recs.ctypes.data, len(recs), stats.ctypes.data, len(stats), None)
+    return rc, recs, stats
