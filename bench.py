@@ -325,6 +325,39 @@ def main():
         pcm1f_sample = (fl[:3 * LPF].cpu().numpy(), st[:3 * LPF].copy(), warm_host[:3 * LPF].copy(), fl[:LPF // 2].cpu().numpy(), cr[:LPF // 2].copy()) if rank == 0 else None
         del fl, fo, d_st
 
+    # ... and the frame drivers of the two marker-less formats (VideoToDigital::doBinarize with TYPE_PCM1 / TYPE_PCM16X0): whole frames in,
+    # line records out, with the reference's per-frame coordinate prescan - BASELINE configs[3], the format dispatch
+    fmt_stages = {}
+    if not args.no_stitch and world == 1:
+        from sdvpcmdecoder_amd import synth as _synth
+        nf = min(n, 2000)
+        for key, gen, call, rec_bytes, per_frame in (("pcm1_frames_stage", _synth.pcm1_frames, eng.pcm1_binarize_frames, 40, H + 3),
+                                                     ("pcm16x0_frames_stage", _synth.pcm16x0_frames, eng.pcm16x0_binarize_frames, 36, 3 * H + 3)):
+            base, _w = gen(8, seed=530, height=H, width=W, noise_sigma=args.noise)
+            fl = torch.from_numpy(np.tile(base, ((nf + 7) // 8, 1, 1))[:nf]).to(dev)
+            ol = torch.empty((nf * per_frame + 1, rec_bytes), dtype=torch.uint8, device=dev)
+            osx = torch.empty((nf, 32), dtype=torch.uint8, device=dev)
+            eng.setBinarizationMode(args.mode)
+            eng.reset_stream()
+            call(fl, first_frame_no=1, new_file=True, out_lines=ol, out_stats=osx, stream=stream)          # the start of the tape
+            first = ol[:1 + 2 * per_frame].cpu().numpy().copy()
+            call(fl, first_frame_no=1 + nf, out_lines=ol[1:], out_stats=osx, stream=stream)
+            k_steps = max(1, min(args.steps, 3))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter(); rnd = 0
+            for r in range(k_steps):
+                call(fl, first_frame_no=1 + (r + 2) * nf, out_lines=ol[1:], out_stats=osx, stream=stream)
+                rnd += eng.run_info().rounds
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t1) * 1e3 / k_steps
+            fmt_stages[key] = ({"frames_per_step": nf, "ms_per_step": ms, "frames_per_s": nf / ms * 1e3, "rounds_per_step": rnd / k_steps,
+                                "algorithmic_gb_per_s": nf * (W * H + per_frame * rec_bytes + 32) / ms / 1e6,
+                                "note": "synthetic %s frames (720x486, every row a PCM line) -> line records incl. the per-frame coordinate prescan, "
+                                        "Binarizer mode as above, continuing tape, wall clock per batch; not part of `value`" % key.split("_")[0].upper()},
+                               base.copy(), first)
+            del fl, ol, osx
+        eng.reset_stream()
+
     # correctness of what was timed: all lines decode to the generator's words
     recs = out_lines[1:1 + nrec].view(-1)  # device bytes
     host = out_lines[1:1 + 8 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(8, H + 3)
@@ -385,6 +418,25 @@ def main():
             out["pcm1_stage"] = pcm1
         if pcm1f is not None:
             out["pcm1_front_stage"] = pcm1f
+        for key, (stage, _b, _f) in fmt_stages.items():
+            out[key] = stage
+        if not args.no_cpu and world == 1:
+            # the frame drivers of PCM-1 / PCM-16x0 on the CPU: the real reference's worker (or the oracle port) on the first eight frames
+            import libs as _libs
+            for key, (stage, base2, first) in fmt_stages.items():
+                api = __import__("pcm1_frames_api" if key.startswith("pcm1_") else "pcm16_frames_api")
+                use_ref = _libs.ref_available()
+                lib = _libs.load_ref() if use_ref else _libs.load_oracle()
+                fd = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)       # the worker logs to stderr
+                try:
+                    t0 = time.perf_counter()
+                    cr, _cs = api.run_cpu(lib, "ref_" if use_ref else "orc_", base2, args.mode, dict(new_file=True))
+                    dtc = time.perf_counter() - t0
+                finally:
+                    os.dup2(fd, 2); os.close(devnull); os.close(fd)
+                stage["cpu_baseline"] = {"value": len(base2) / dtc, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                                         "sample": f"the first {len(base2)} frames of the tape, {dtc:.2f} s of CPU work",
+                                         "bit_exact_vs_gpu_on_overlap": bool(cr.tobytes()[:first.nbytes] == first.tobytes())}
         if not args.no_cpu and world == 1:
             ncpu = min(args.cpu_frames, n)
             sample = luma[:ncpu].cpu().numpy()
