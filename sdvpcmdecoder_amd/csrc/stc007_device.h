@@ -43,6 +43,9 @@
 #ifndef SDV_INTERLEAVE2
 #define SDV_INTERLEAVE2 1
 #endif
+#ifndef SDV_CAPTURE
+#define SDV_CAPTURE 1               /* whole-frame capture in the lean kernel (capture_solve); 0 = the round-1 row-staging loop only */
+#endif
 #ifndef SDV_PREFETCH_ITERS
 #define SDV_PREFETCH_ITERS 1         /* multi-line loop: iterations of rows in flight ahead of the one being decoded */
 #endif
@@ -1896,6 +1899,53 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
     return true;
 }
 
+struct BatchLaneOut { uint64_t s_lo, s_hi; uint16_t crc; };
+/* ---------------------------------------------------------------------------------------------
+ * Whole-frame capture (round 2).  On a tape that plays every line of a frame is read with the tuning the frame inherits, so what a
+ * line contributes is only the four comparison masks of its 128 bit cells.  The capture loop takes the rows of BOTH fields together -
+ * rows 2k and 2k+1 are neighbours in memory, so the frame is streamed through once, front to back, and the 128-byte lines two rows
+ * share are fetched once - and per line does nothing but the cell gather, four compares and parking the masks in "its" lane
+ * (v_writelane).  Every 64 row pairs the lanes solve the hysteresis automaton and the CRC of their own line (capture_solve), the
+ * field-0 lines go through the per-line bookkeeping at once (batch_finish), the field-1 lines wait in LDS until field 0 has ended.
+ * A line that does not read on the first rung ends the capture: what was decoded up to it stays, the frame loop below takes over
+ * from that line with the row-staging paths of round 1.
+ * --------------------------------------------------------------------------------------------- */
+#ifdef SDV_EMU
+__device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t val, int lane) { return lane_id() == lane ? val : old; }
+#else
+/* clang has no builtin for v_writelane_b32; the LLVM intrinsic is reachable by its name */
+extern "C" __device__ uint32_t sdv_llvm_writelane(uint32_t val, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t val, int lane) { return sdv_llvm_writelane(val, (uint32_t)lane, old); }
+#endif
+struct CaptureRaw { uint32_t a0, a1, a2, a3, b0, b1, b2, b3; };     /* of "my" line: A = px > low (cells 0..127), B = px >= high */
+__device__ __forceinline__ void capture_park(CaptureRaw &r, uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, int j)
+{
+    r.a0 = write_lane(r.a0, (uint32_t)a_lo, j); r.a1 = write_lane(r.a1, (uint32_t)(a_lo >> 32), j);
+    r.a2 = write_lane(r.a2, (uint32_t)a_hi, j); r.a3 = write_lane(r.a3, (uint32_t)(a_hi >> 32), j);
+    r.b0 = write_lane(r.b0, (uint32_t)b_lo, j); r.b1 = write_lane(r.b1, (uint32_t)(b_lo >> 32), j);
+    r.b2 = write_lane(r.b2, (uint32_t)b_hi, j); r.b3 = write_lane(r.b3, (uint32_t)(b_hi >> 32), j);
+}
+__device__ __forceinline__ uint64_t prefix_xor64(uint64_t x) { x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32; return x; }
+/* solve_automaton + the CRC of fill_stc007 for one line per LANE (every lane its own masks): returns the cells and whether the line
+ * reads (CRC as read == CRC calculated, and not the start of a Control Block) */
+__device__ inline bool capture_solve(const CaptureRaw &r, BatchLaneOut &o)
+{
+    const uint64_t a_lo = (uint64_t)r.a0 | ((uint64_t)r.a1 << 32), a_hi = (uint64_t)r.a2 | ((uint64_t)r.a3 << 32);
+    const uint64_t b_lo = (uint64_t)r.b0 | ((uint64_t)r.b1 << 32), b_hi = (uint64_t)r.b2 | ((uint64_t)r.b3 << 32);
+    const uint64_t e_lo = ~(a_lo ^ b_lo), e_hi = ~(a_hi ^ b_hi), t_lo = a_lo & ~b_lo, t_hi = a_hi & ~b_hi;
+    const uint64_t pt_lo = prefix_xor64(t_lo), pt_hi = prefix_xor64(t_hi) ^ ((__popcll(t_lo) & 1) ? ~0ull : 0ull);
+    const uint64_t u_lo = ((a_lo & b_lo) ^ pt_lo) & e_lo, u_hi = ((a_hi & b_hi) ^ pt_hi) & e_hi;
+    const uint64_t x_lo = u_lo | ~e_lo, x_hi = u_hi | ~e_hi;
+    const uint64_t y_lo = x_lo + u_lo, y_hi = x_hi + u_hi + ((y_lo < x_lo) ? 1ull : 0ull);
+    const uint64_t s_lo = ((((y_lo ^ x_lo) & ~e_lo) | u_lo) ^ pt_lo), s_hi = ((((y_hi ^ x_hi) & ~e_hi) | u_hi) ^ pt_hi);
+    uint32_t crc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) crc |= (uint32_t)((__popcll(s_lo & c_crc.klo[j]) + __popcll(s_hi & c_crc.khi[j])) & 1) << j;
+    crc ^= c_crc.init;
+    o.s_lo = s_lo; o.s_hi = s_hi; o.crc = (uint16_t)crc;
+    return (uint16_t)crc == rev16((uint32_t)((s_hi >> 48) & 0xFFFF)) && !ctrl_block_maybe(s_lo);
+}
+
 /* ---------------------------------------------------------------------------------------------
  * Line-batch fast path.  In the steady state the tuning does not change from line to line, so up to
  * 64 consecutive lines of a field are decoded one after another by the whole wave (phase A), each
@@ -2086,9 +2136,107 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     row_prefetch(pf, frame, a.width);
     const size_t row_step = 2 * a.row_stride;                  /* the next row of a field */
     uint16_t line_num = 0;
-    for (int field = 0; field < 2; field++) {
+    int start_field = 0, start_idx = 0;
+#if SDV_CAPTURE
+    /* whole-frame capture (see capture_solve): only in the lean build, on the geometry the batch loop takes */
+    if (kLean && pf.vec && a.width <= 1024 && (a.width & 15) == 0 && n_field[1] > 0 && batch_eligible(a, lds, v, geo)) {
+        const FastPre pre = fast_pre(a, v.bin, geo);
+        if (pre.ok) {
+            K1_T(t_cap);
+            const int n0 = n_field[0], n1 = n_field[1];
+            const int n_chunks = (n0 + 63) / 64;
+            uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][5 words][lane], over px + hist + sweep */
+            uint32_t ok1_packed = 0;                            /* lines of field 1 that read, per chunk (7 bits each) */
+            const uint8_t *pair = frame;                        /* rows 2k, 2k+1 */
+            const size_t rs = a.row_stride;
+            const uint32_t lo = pre.ref_low, hi = pre.ref_high;
+            constexpr int D = 4;                                /* row pairs in flight */
+            uint8_t q[D][4];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int k = d < n0 ? d : n0 - 1;
+                const uint8_t *ra = frame + (size_t)(2 * k) * rs, *rb = k < n1 ? ra + rs : ra;
+                q[d][0] = ra[pre.x0]; q[d][1] = ra[pre.x1]; q[d][2] = rb[pre.x0]; q[d][3] = rb[pre.x1];
+            }
+            bool whole = true;
+            for (int c = 0; c < n_chunks && whole; c++) {
+                const int cn0 = n0 - 64 * c < 64 ? n0 - 64 * c : 64, cn1 = n1 - 64 * c < 64 ? (n1 - 64 * c > 0 ? n1 - 64 * c : 0) : 64;
+                CaptureRaw r0, r1;
+                r0.a0 = r0.a1 = r0.a2 = r0.a3 = r0.b0 = r0.b1 = r0.b2 = r0.b3 = 0;
+                r1 = r0;
+                for (int j0 = 0; j0 < cn0; j0 += D) {
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        const int j = j0 + d;
+                        if (j < cn0) {
+                            const uint8_t p0 = q[d][0], p1 = q[d][1], p2 = q[d][2], p3 = q[d][3];
+                            {   /* the pair D places ahead (the chunks follow each other without a gap: j0 is a multiple of D) */
+                                const int kn = 64 * c + j + D;
+                                const int k = kn < n0 ? kn : n0 - 1;
+                                const uint8_t *ra = frame + (size_t)(2 * k) * rs, *rb = k < n1 ? ra + rs : ra;
+                                q[d][0] = ra[pre.x0]; q[d][1] = ra[pre.x1]; q[d][2] = rb[pre.x0]; q[d][3] = rb[pre.x1];
+                            }
+                            const uint64_t aA_lo = __ballot(p0 > lo), bA_lo = __ballot(p0 >= hi), aA_hi = __ballot(p1 > lo), bA_hi = __ballot(p1 >= hi);
+                            const uint64_t aB_lo = __ballot(p2 > lo), bB_lo = __ballot(p2 >= hi), aB_hi = __ballot(p3 > lo), bB_hi = __ballot(p3 >= hi);
+                            capture_park(r0, aA_lo, aA_hi, bA_lo, bA_hi, j);
+                            capture_park(r1, aB_lo, aB_hi, bB_lo, bB_hi, j);
+                        }
+                    }
+                }
+                (void)pair;
+                /* every lane its own line: automaton + CRC */
+                BatchLaneOut o0, o1;
+                const bool ok0 = capture_solve(r0, o0), ok1 = capture_solve(r1, o1);
+                const uint64_t okm0 = __ballot(ok0 || lane >= cn0), okm1 = __ballot(ok1 || lane >= cn1);
+                const int n_ok0 = okm0 == ~0ull ? cn0 : (__ffsll((unsigned long long)~okm0) - 1);
+                const int n_ok1 = okm1 == ~0ull ? cn1 : (__ffsll((unsigned long long)~okm1) - 1);
+                ok1_packed |= (uint32_t)n_ok1 << (7 * c);
+                /* field 1 waits for the end of field 0 */
+                park[(c * 5 + 0) * 64 + lane] = (uint32_t)o1.s_lo; park[(c * 5 + 1) * 64 + lane] = (uint32_t)(o1.s_lo >> 32);
+                park[(c * 5 + 2) * 64 + lane] = (uint32_t)o1.s_hi; park[(c * 5 + 3) * 64 + lane] = (uint32_t)(o1.s_hi >> 32);
+                park[(c * 5 + 4) * 64 + lane] = (uint32_t)o1.crc;
+                /* field 0 goes through the per-line bookkeeping now */
+                BatchLane bl;
+                bl.d0 = (uint32_t)o0.s_lo; bl.d1 = (uint32_t)(o0.s_lo >> 32); bl.d2 = (uint32_t)o0.s_hi; bl.d3 = (uint32_t)(o0.s_hi >> 32); bl.meta = (uint32_t)o0.crc;
+                if (n_ok0 > 0) { batch_finish(a, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec); rec += n_ok0; }
+                if (n_ok0 < cn0) { whole = false; start_field = 0; start_idx = 64 * c + n_ok0; }
+            }
+            if (whole) {
+                line_num = (uint16_t)(1 + 2 * n0);
+                v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
+                emit_record(wl, rec++);
+                start_field = 1; start_idx = 0;
+                __syncthreads();
+                for (int c = 0; c < n_chunks && whole; c++) {
+                    const int cn1 = n1 - 64 * c < 64 ? (n1 - 64 * c > 0 ? n1 - 64 * c : 0) : 64;
+                    if (cn1 <= 0) break;
+                    const int n_ok1 = (int)((ok1_packed >> (7 * c)) & 0x7F);
+                    BatchLane bl;
+                    bl.d0 = park[(c * 5 + 0) * 64 + lane]; bl.d1 = park[(c * 5 + 1) * 64 + lane]; bl.d2 = park[(c * 5 + 2) * 64 + lane];
+                    bl.d3 = park[(c * 5 + 3) * 64 + lane]; bl.meta = park[(c * 5 + 4) * 64 + lane];
+                    if (n_ok1 > 0) { batch_finish(a, v, bl, n_ok1, frame_no, (uint16_t)(2 + 2 * (64 * c)), fv_keys, rec); rec += n_ok1; }
+                    if (n_ok1 < cn1) { whole = false; start_idx = 64 * c + n_ok1; }
+                }
+                __syncthreads();
+                if (whole) {
+                    line_num = (uint16_t)(2 + 2 * n1);
+                    v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
+                    emit_record(wl, rec++);
+                    start_field = 2;
+                }
+            }
+            if (start_field < 2) {      /* the row-staging loop below takes over: its first row */
+                pf.nq = 0;
+                row_prefetch(pf, frame + (size_t)(2 * start_idx + start_field) * a.row_stride, a.width);
+            }
+            K1_T(t_cap1);
+            K1_ADD(4, t_cap, t_cap1);
+        }
+    }
+#endif
+    for (int field = start_field; field < 2; field++) {
         const int nl = n_field[field];
-        int idx = 0;
+        int idx = field == start_field ? start_idx : 0;
         while (idx < nl) {
             bool staged = false;
             /* the batch loop is the 16-byte-vector, single-vector-per-lane case (rows aligned, width a multiple of 16 up to 1024:

@@ -1,5 +1,5 @@
 """Experiment driver: steady-state timing of an alternative build of the library whose frame kernel has no general path
-(build/variants/lean_*.so): the stream is started by the product library, its chain state is handed to the variant."""
+(build/variants/lib_*.so): the stream is started by the product library, its chain state is handed to the variant."""
 import sys, time, glob
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -12,7 +12,7 @@ base = Engine(0)
 base.binarize_frames(luma, first_frame_no=1, new_file=True, out_lines=out, out_stats=st)
 state = base.get_chain_state()
 ref = None
-for path in [None] + sorted(glob.glob('build/variants/lean_*.so')):
+for path in [None] + sorted(glob.glob('build/variants/lib_*.so')):
     eng = Engine(0, lib=load_library(path)) if path else Engine(0)
     eng.set_chain_state(state)
     eng.set_profiling(True)
