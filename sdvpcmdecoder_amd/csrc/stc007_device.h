@@ -46,6 +46,9 @@
 #ifndef SDV_CAPTURE
 #define SDV_CAPTURE 1               /* whole-frame capture in the lean kernel (capture_solve); 0 = the round-1 row-staging loop only */
 #endif
+#ifndef SDV_CAPTURE_D
+#define SDV_CAPTURE_D 4             /* capture loop: row pairs in flight */
+#endif
 #ifndef SDV_PREFETCH_ITERS
 #define SDV_PREFETCH_ITERS 1         /* multi-line loop: iterations of rows in flight ahead of the one being decoded */
 #endif
@@ -1479,7 +1482,9 @@ __device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, L
 }
 
 /* END_FRAME bookkeeping (videotodigital.cpp:1636-1714) */
-__device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, uint32_t frame_no, const uint32_t *fv_keys, const uint32_t *fi_keys, sdv_frame_stats *out)
+/* uniform_key: every entry of fv_keys is known to hold this key (a frame that was captured whole) - its median without reading them */
+__device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, uint32_t frame_no, const uint32_t *fv_keys, const uint32_t *fi_keys, sdv_frame_stats *out,
+                                  const uint32_t *uniform_key = nullptr)
 {
     if (v.q_pcm_odd > v.q_odd) v.q_pcm_odd = v.q_odd;
     if (v.q_pcm_even > v.q_even) v.q_pcm_even = v.q_even;
@@ -1488,7 +1493,8 @@ __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, u
     bool not_sure = false;
     uint32_t k;
     coords_clear(v.frame_avg);
-    if (median_keys(fv_keys, v.nfv, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
+    if (uniform_key && v.nfv > 0) v.frame_avg = key_to_coords(*uniform_key, a.doubled != 0);
+    else if (median_keys(fv_keys, v.nfv, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
     if (coords_valid(v.frame_avg)) {
         __syncthreads();
         if (lane_id() == 0) {
@@ -1912,7 +1918,15 @@ struct BatchLaneOut { uint64_t s_lo, s_hi; uint16_t crc; };
  * --------------------------------------------------------------------------------------------- */
 #ifdef SDV_EMU
 __device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t val, int lane) { return lane_id() == lane ? val : old; }
+__device__ __forceinline__ uint8_t stream_load_u8(const uint8_t *p) { return *p; }
+#define SDV_ISSUE_AFTER8(oa, ob, m0, m1, m2, m3, m4, m5, m6, m7) ((void)0)
 #else
+/* a byte that is read once: the load does not allocate in the caches on its way */
+__device__ __forceinline__ uint8_t stream_load_u8(const uint8_t *p) { return __builtin_nontemporal_load(p); }
+/* the uniform offsets oa, ob become known only once the eight uniform masks are: loads addressed through them are issued after the
+ * compares that produce the masks (no instruction is emitted) */
+#define SDV_ISSUE_AFTER8(oa, ob, m0, m1, m2, m3, m4, m5, m6, m7) \
+    asm volatile("" : "+s"(oa), "+s"(ob) : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(m5), "s"(m6), "s"(m7))
 /* clang has no builtin for v_writelane_b32; the LLVM intrinsic is reachable by its name */
 extern "C" __device__ uint32_t sdv_llvm_writelane(uint32_t val, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
 __device__ __forceinline__ uint32_t write_lane(uint32_t old, uint32_t val, int lane) { return sdv_llvm_writelane(val, (uint32_t)lane, old); }
@@ -2137,9 +2151,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const size_t row_step = 2 * a.row_stride;                  /* the next row of a field */
     uint16_t line_num = 0;
     int start_field = 0, start_idx = 0;
+    bool all_captured = false; uint32_t captured_key = 0;
 #if SDV_CAPTURE
     /* whole-frame capture (see capture_solve): only in the lean build, on the geometry the batch loop takes */
-    if (kLean && pf.vec && a.width <= 1024 && (a.width & 15) == 0 && n_field[1] > 0 && batch_eligible(a, lds, v, geo)) {
+    if (kLean && pf.vec && a.width <= 1024 && (a.width & 15) == 0 && n_field[1] > 0 && (uint64_t)a.row_stride * (uint64_t)a.height < (1ull << 31) &&
+        batch_eligible(a, lds, v, geo)) {
         const FastPre pre = fast_pre(a, v.bin, geo);
         if (pre.ok) {
             K1_T(t_cap);
@@ -2147,16 +2163,22 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             const int n_chunks = (n0 + 63) / 64;
             uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][5 words][lane], over px + hist + sweep */
             uint32_t ok1_packed = 0;                            /* lines of field 1 that read, per chunk (7 bits each) */
-            const uint8_t *pair = frame;                        /* rows 2k, 2k+1 */
-            const size_t rs = a.row_stride;
+            const uint32_t rs = (uint32_t)a.row_stride;         /* offsets inside a frame fit 32 bits (checked above) */
             const uint32_t lo = pre.ref_low, hi = pre.ref_high;
-            constexpr int D = 4;                                /* row pairs in flight */
+            const uint32_t x0 = (uint32_t)pre.x0, x1 = (uint32_t)pre.x1;
+            constexpr int D = SDV_CAPTURE_D;                    /* row pairs in flight */
+            static_assert(64 % D == 0, "the prefetch queue must stay aligned with the 64-line chunks");
+            /* rows 2k, 2k+1 of the frame; the luma is read once and never again: non-temporal, so that it does not push the
+             * record buffer out of the last-level cache (profiles/r02_probe_capture_ceiling.txt) */
+            auto pair_offsets = [&](int kn, uint32_t &oa, uint32_t &ob) {
+                const uint32_t k = (uint32_t)(kn < n0 ? kn : n0 - 1);
+                oa = 2u * k * rs; ob = (int)k < n1 ? oa + rs : oa; };
             uint8_t q[D][4];
 #pragma unroll
             for (int d = 0; d < D; d++) {
-                const int k = d < n0 ? d : n0 - 1;
-                const uint8_t *ra = frame + (size_t)(2 * k) * rs, *rb = k < n1 ? ra + rs : ra;
-                q[d][0] = ra[pre.x0]; q[d][1] = ra[pre.x1]; q[d][2] = rb[pre.x0]; q[d][3] = rb[pre.x1];
+                uint32_t oa, ob; pair_offsets(d, oa, ob);
+                q[d][0] = stream_load_u8(frame + (oa + x0)); q[d][1] = stream_load_u8(frame + (oa + x1));
+                q[d][2] = stream_load_u8(frame + (ob + x0)); q[d][3] = stream_load_u8(frame + (ob + x1));
             }
             bool whole = true;
             for (int c = 0; c < n_chunks && whole; c++) {
@@ -2164,33 +2186,35 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 CaptureRaw r0, r1;
                 r0.a0 = r0.a1 = r0.a2 = r0.a3 = r0.b0 = r0.b1 = r0.b2 = r0.b3 = 0;
                 r1 = r0;
+                /* the body runs for whole groups of D pairs: past the end of the last chunk it parks clamped rows in lanes nobody reads */
                 for (int j0 = 0; j0 < cn0; j0 += D) {
 #pragma unroll
                     for (int d = 0; d < D; d++) {
                         const int j = j0 + d;
-                        if (j < cn0) {
-                            const uint8_t p0 = q[d][0], p1 = q[d][1], p2 = q[d][2], p3 = q[d][3];
-                            {   /* the pair D places ahead (the chunks follow each other without a gap: j0 is a multiple of D) */
-                                const int kn = 64 * c + j + D;
-                                const int k = kn < n0 ? kn : n0 - 1;
-                                const uint8_t *ra = frame + (size_t)(2 * k) * rs, *rb = k < n1 ? ra + rs : ra;
-                                q[d][0] = ra[pre.x0]; q[d][1] = ra[pre.x1]; q[d][2] = rb[pre.x0]; q[d][3] = rb[pre.x1];
-                            }
-                            const uint64_t aA_lo = __ballot(p0 > lo), bA_lo = __ballot(p0 >= hi), aA_hi = __ballot(p1 > lo), bA_hi = __ballot(p1 >= hi);
-                            const uint64_t aB_lo = __ballot(p2 > lo), bB_lo = __ballot(p2 >= hi), aB_hi = __ballot(p3 > lo), bB_hi = __ballot(p3 >= hi);
-                            capture_park(r0, aA_lo, aA_hi, bA_lo, bA_hi, j);
-                            capture_park(r1, aB_lo, aB_hi, bB_lo, bB_hi, j);
+                        const uint8_t p0 = q[d][0], p1 = q[d][1], p2 = q[d][2], p3 = q[d][3];
+                        const uint64_t aA_lo = __ballot(p0 > lo), bA_lo = __ballot(p0 >= hi), aA_hi = __ballot(p1 > lo), bA_hi = __ballot(p1 >= hi);
+                        const uint64_t aB_lo = __ballot(p2 > lo), bB_lo = __ballot(p2 >= hi), aB_hi = __ballot(p3 > lo), bB_hi = __ballot(p3 >= hi);
+                        {   /* the pair D places ahead (the chunks follow each other without a gap: j0 is a multiple of D). Its
+                             * request waits for the compares above, so that the bytes land in the registers those just freed */
+                            uint32_t oa, ob; pair_offsets(64 * c + j + D, oa, ob);
+                            SDV_ISSUE_AFTER8(oa, ob, aA_lo, bA_lo, aA_hi, bA_hi, aB_lo, bB_lo, aB_hi, bB_hi);
+                            q[d][0] = stream_load_u8(frame + (oa + x0)); q[d][1] = stream_load_u8(frame + (oa + x1));
+                            q[d][2] = stream_load_u8(frame + (ob + x0)); q[d][3] = stream_load_u8(frame + (ob + x1));
                         }
+                        capture_park(r0, aA_lo, aA_hi, bA_lo, bA_hi, j);
+                        capture_park(r1, aB_lo, aB_hi, bB_lo, bB_hi, j);
                     }
                 }
-                (void)pair;
                 /* every lane its own line: automaton + CRC */
+                K1_T(t_s0);
                 BatchLaneOut o0, o1;
                 const bool ok0 = capture_solve(r0, o0), ok1 = capture_solve(r1, o1);
                 const uint64_t okm0 = __ballot(ok0 || lane >= cn0), okm1 = __ballot(ok1 || lane >= cn1);
                 const int n_ok0 = okm0 == ~0ull ? cn0 : (__ffsll((unsigned long long)~okm0) - 1);
                 const int n_ok1 = okm1 == ~0ull ? cn1 : (__ffsll((unsigned long long)~okm1) - 1);
                 ok1_packed |= (uint32_t)n_ok1 << (7 * c);
+                K1_T(t_s1);
+                K1_ADD(5, t_s0, t_s1);
                 /* field 1 waits for the end of field 0 */
                 park[(c * 5 + 0) * 64 + lane] = (uint32_t)o1.s_lo; park[(c * 5 + 1) * 64 + lane] = (uint32_t)(o1.s_lo >> 32);
                 park[(c * 5 + 2) * 64 + lane] = (uint32_t)o1.s_hi; park[(c * 5 + 3) * 64 + lane] = (uint32_t)(o1.s_hi >> 32);
@@ -2199,6 +2223,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 BatchLane bl;
                 bl.d0 = (uint32_t)o0.s_lo; bl.d1 = (uint32_t)(o0.s_lo >> 32); bl.d2 = (uint32_t)o0.s_hi; bl.d3 = (uint32_t)(o0.s_hi >> 32); bl.meta = (uint32_t)o0.crc;
                 if (n_ok0 > 0) { batch_finish(a, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec); rec += n_ok0; }
+                K1_T(t_s2);
+                K1_ADD(6, t_s1, t_s2);
                 if (n_ok0 < cn0) { whole = false; start_field = 0; start_idx = 64 * c + n_ok0; }
             }
             if (whole) {
@@ -2223,6 +2249,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
                     emit_record(wl, rec++);
                     start_field = 2;
+                    all_captured = true; captured_key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
                 }
             }
             if (start_field < 2) {      /* the row-staging loop below takes over: its first row */
@@ -2397,7 +2424,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     line_num = (uint16_t)(line_num + 2);
     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
     K1_T(t_ef0);
-    v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f]);
+    v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f], all_captured ? &captured_key : nullptr);
     emit_record(wl, rec++);
     v2d_store_state(v, lds, &a.states_out[f], a);
     K1_T(t_end);

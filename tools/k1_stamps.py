@@ -14,4 +14,5 @@ eng.binarize_frames(luma, first_frame_no=1 + n, new_file=False)
 torch.cuda.synchronize()
 eng.lib.sdv_debug_k1_cycles(out, 0)
 v = [x / n for x in out]
-print(f"cycles per frame: total {v[0]:.0f}  batch loops {v[1]:.0f}  batch_finish {v[2]:.0f}  end of frame {v[3]:.0f}  rest {v[0]-v[1]-v[2]-v[3]:.0f}")
+print(f"cycles per frame: total {v[0]:.0f}  batch loops {v[1]:.0f}  batch_finish {v[2]:.0f}  end of frame {v[3]:.0f}  "
+      f"capture (all) {v[4]:.0f} of which solve {v[5]:.0f}, field-0 batch_finish {v[6]:.0f}, gather loop + field 1 {v[4]-v[5]-v[6]:.0f}  rest {v[0]-v[1]-v[2]-v[3]-v[4]:.0f}")

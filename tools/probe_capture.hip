@@ -36,10 +36,11 @@ __global__ void __launch_bounds__(64, WPE) k_stream(Args a)
 }
 
 // per row: two byte gathers (cells lane and lane+64), four compares, 8 writelanes into the batch registers of "its" lane
-template <int D, bool DUAL, int WPE>
+template <int D, bool DUAL, int WPE, bool NT_LD = false>
 __global__ void __launch_bounds__(64, WPE) k_capture(Args a)
 {
     const int f = blockIdx.x, lane = threadIdx.x;
+    auto LDB = [](const uint8_t *p) -> uint8_t { return NT_LD ? __builtin_nontemporal_load(p) : *p; };
     const uint8_t *frame = a.luma + (size_t)f * W * H;
     // cell centres: 132 cells between px 12 and 708, data cell b at cell b+3
     const uint32_t psm = ((708 - 12) * 128 + 66) / 132, hpsm = (psm + 1) / 2;
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(64, WPE) k_capture(Args a)
     auto rowB = [&](int k) -> const uint8_t * { if (DUAL) return frame + (size_t)(2 * k + 1) * W; int fld = k >= (NP + 1) / 2 ? 1 : 0; int kk = fld ? k - (NP + 1) / 2 : k; int r = 4 * kk + 2 + fld; if (r >= H) r = H - 1; return frame + (size_t)r * W; };
     uint8_t q[D][4];
 #pragma unroll
-    for (int d = 0; d < D; d++) { const uint8_t *ra = rowA(d), *rb = rowB(d); q[d][0] = ra[x0]; q[d][1] = ra[x1]; q[d][2] = rb[x0]; q[d][3] = rb[x1]; }
+    for (int d = 0; d < D; d++) { const uint8_t *ra = rowA(d), *rb = rowB(d); q[d][0] = LDB(ra + x0); q[d][1] = LDB(ra + x1); q[d][2] = LDB(rb + x0); q[d][3] = LDB(rb + x1); }
     for (int k0 = 0; k0 < NP; k0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(64, WPE) k_capture(Args a)
             if (k < NP) {
                 const uint8_t p0 = q[d][0], p1 = q[d][1], p2 = q[d][2], p3 = q[d][3];
                 const int kn = k + D < NP ? k + D : NP - 1;
-                { const uint8_t *ra = rowA(kn), *rb = rowB(kn); q[d][0] = ra[x0]; q[d][1] = ra[x1]; q[d][2] = rb[x0]; q[d][3] = rb[x1]; }
+                { const uint8_t *ra = rowA(kn), *rb = rowB(kn); q[d][0] = LDB(ra + x0); q[d][1] = LDB(ra + x1); q[d][2] = LDB(rb + x0); q[d][3] = LDB(rb + x1); }
                 const uint64_t aA_lo = __ballot(p0 > a.lo), bA_lo = __ballot(p0 >= a.hi), aA_hi = __ballot(p1 > a.lo), bA_hi = __ballot(p1 >= a.hi);
                 const uint64_t aB_lo = __ballot(p2 > a.lo), bB_lo = __ballot(p2 >= a.hi), aB_hi = __ballot(p3 > a.lo), bB_hi = __ballot(p3 >= a.hi);
                 const int j = k & 63;
@@ -190,6 +191,10 @@ int main(int argc, char **argv)
     RUN("write only 24 KB per frame", k_write_only);
     RUN("stream, 8 waves/SIMD", (k_stream<8>));
     RUN("stream, 5 waves/SIMD", (k_stream<5>));
+    RUN("capture dual  D=4 w5 plain loads", (k_capture<4, true, 5, false>));
+    RUN("capture dual  D=4 w5 NT loads", (k_capture<4, true, 5, true>));
+    RUN("capture dual  D=4 w5 plain loads", (k_capture<4, true, 5, false>));
+    RUN("capture dual  D=4 w5 NT loads", (k_capture<4, true, 5, true>));
     RUN("capture dual  D=2 w8", (k_capture<2, true, 8>));
     RUN("capture dual  D=4 w8", (k_capture<4, true, 8>));
     RUN("capture dual  D=8 w8", (k_capture<8, true, 8>));
