@@ -34,7 +34,8 @@ def algorithmic_bytes_per_frame(width, height):
     return width * height + (height + 3) * 48 + 32
 
 
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_sdv_k_stc007_frames_lean.json")
+HOT_KERNEL = "sdv_k_stc007_frames_lean"
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_%s.json" % HOT_KERNEL)
 
 
 def measured_hbm_traffic(frames_per_launch, workload):
@@ -50,11 +51,11 @@ def measured_hbm_traffic(frames_per_launch, workload):
         fetch = float(d["pmc3"]["FETCH_SIZE"]) * 1024.0 * 2.0
         write = float(d["pmc4"]["WRITE_SIZE"]) * 1024.0
         per_launch = (fetch + write) / (float(d["pmc3"].get("grid_size", 640000)) / 64.0) * frames_per_launch
-        same = d.get("source_sha16") == source_hash() and d.get("workload") == workload and not os.environ.get("SDVPCM_LIB")
+        same = d.get("source_sha16") == source_hash(HOT_KERNEL) and d.get("workload") == workload and not os.environ.get("SDVPCM_LIB")
         if same:
             return per_launch, None
         return None, {"bytes_per_launch": per_launch, "profile": PMC_PROFILE, "profile_source_sha16": d.get("source_sha16"),
-                      "profile_workload": d.get("workload"), "this_source_sha16": source_hash(), "this_workload": workload}
+                      "profile_workload": d.get("workload"), "this_source_sha16": source_hash(HOT_KERNEL), "this_workload": workload}
     except Exception as ex:      # noqa: BLE001
         return None, {"error": repr(ex), "profile": PMC_PROFILE}
 

@@ -15,13 +15,29 @@ ROOT = os.path.dirname(PKG)
 HIP_LIB = os.path.join(PKG, "libsdvpcm_hip.so")
 
 
-def source_hash():
-    """Identity of the HIP library's sources (csrc/ + the C-ABI header): profiles/ records it next to the counters they hold, and
-    bench.py only quotes a committed profile for the build that it was measured on."""
+# the sources a kernel is compiled from and launched by (its device header, the engine that configures the launch, the C-ABI)
+KERNEL_SOURCES = {
+    "sdv_k_stc007_frames": ("stc007_device.h", "engine.inc"),
+    "sdv_k_pcm1_lines": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_engine.inc"),
+    "sdv_k_pcm1_frames": ("pcm1_stitch_device.h", "pcm1_engine.inc"),
+    "sdv_k_pcm1_frames_bin": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_frames_device.h", "pcm1_frames_engine.inc"),
+    "sdv_k_pcm16_frames_bin": ("stc007_device.h", "pcm1_bin_device.h", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc"),
+}
+
+
+def source_hash(kernel=None):
+    """Identity of the HIP library's sources (csrc/ + the C-ABI header), or of the sources one kernel depends on (KERNEL_SOURCES,
+    longest matching prefix of its name): profiles/ records it next to the counters they hold, and bench.py only quotes a committed
+    profile for the build that it was measured on."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(PKG, "csrc")
-    for f in sorted(os.listdir(csrc)) + [os.path.join(ROOT, "include", "sdvpcm.h")]:
+    names = sorted(os.listdir(csrc))
+    if kernel:
+        keys = [k for k in KERNEL_SOURCES if kernel.startswith(k)]
+        if keys:
+            names = sorted(KERNEL_SOURCES[max(keys, key=len)])
+    for f in names + [os.path.join(ROOT, "include", "sdvpcm.h")]:
         path = f if os.path.isabs(f) else os.path.join(csrc, f)
         if os.path.isfile(path) and path.endswith((".h", ".hip", ".inc")):
             h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())

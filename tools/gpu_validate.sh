@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/bench_full.json
 SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --frames 4000 --no-cpu 2> gpurun_out/bench_2rank.err | tail -1 > gpurun_out/bench_2rank_gloo.json; echo "2-rank rc=$?"
 cd /tmp && export TMPDIR=/tmp
@@ -26,3 +26,5 @@ rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc WRITE_SIZE --output-f
 # PCM-1 front half: kernel stats and PMC passes of its line kernel
 bash $R/tools/gpu_pcm1_front_pmc.sh 2>&1 | grep "rc="
 
+# PCM-1 and PCM-16x0 frame drivers: kernel stats
+bash $R/tools/gpu_frames_prof.sh 2>&1 | grep "rc="

@@ -27,7 +27,7 @@ for p in tuple(prefix + str(i) for i in (1, 2, 3, 4)):
 # what was measured: the sources of the library (run this right after the passes, on the tree that was sent to the GPU box) and the
 # workload of the profiled command (argv[4], e.g. "frames=10000,mode=2,noise=4.0,width=720,height=486") - bench.py quotes the
 # counters only for the same build and workload
-res["source_sha16"] = source_hash()
+res["source_sha16"] = source_hash(kernel)
 res["workload"] = sys.argv[4] if len(sys.argv) > 4 else "frames=10000,mode=2,noise=4.0,width=720,height=486"
 json.dump(res, open(out, "w"), indent=1)
 print(out, {p: {k: v for k, v in d.items() if k.isupper()} for p, d in res.items() if isinstance(d, dict)})

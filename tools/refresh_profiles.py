@@ -3,6 +3,7 @@
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r02'      # the round the summaries are named for
 
 
 def newest(pat):
@@ -21,17 +22,20 @@ def trim(src, dst):
             w.writerow(r)
 
 
-trim(newest('gpurun_out/prof_bench/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_kernel_stats.csv')
-trim(newest('gpurun_out/prof_stitch/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_stitch_kernel_stats.csv')
-trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_pcm1_kernel_stats.csv')
+trim(newest('gpurun_out/prof_bench/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_kernel_stats.csv')
+trim(newest('gpurun_out/prof_stitch/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_stitch_kernel_stats.csv')
+trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_pcm1_kernel_stats.csv')
+for d, name in (('prof_p1f', 'pcm1_frames'), ('prof_p16f', 'pcm16x0_frames')):
+    if glob.glob(f'gpurun_out/{d}/*/*kernel_stats.csv'):
+        trim(newest(f'gpurun_out/{d}/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_{name}_kernel_stats.csv')
 if glob.glob('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'):
-    trim(newest('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'), 'profiles/r01_rocprofv3_pcm1_front_kernel_stats.csv')
-    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines', 'profiles/r01_pmc_sdv_k_pcm1_lines.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
-    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines_lean', 'profiles/r01_pmc_sdv_k_pcm1_lines_lean.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
-shutil.copy('gpurun_out/bench_full.json', 'profiles/r01_bench_full.json')
-shutil.copy('gpurun_out/bench_2rank_gloo.json', 'profiles/r01_bench_2rank_gloo_one_gpu.json')
-subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', 'profiles/r01_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
-subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', 'profiles/r01_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
+    trim(newest('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_pcm1_front_kernel_stats.csv')
+    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines', f'profiles/{RND}_pmc_sdv_k_pcm1_lines.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines_lean', f'profiles/{RND}_pmc_sdv_k_pcm1_lines_lean.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
+shutil.copy('gpurun_out/bench_full.json', f'profiles/{RND}_bench_full.json')
+shutil.copy('gpurun_out/bench_2rank_gloo.json', f'profiles/{RND}_bench_2rank_gloo_one_gpu.json')
+subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', f'profiles/{RND}_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
+subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', f'profiles/{RND}_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
 d = json.loads(open('gpurun_out/bench_full.json').read().strip().split('\n')[-1])
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'launch ms', d['roofline']['avg_launch_ms'], 'traffic', d['roofline']['traffic'])
 for k in ('stitch_stage', 'pcm1_stage', 'pcm1_front_stage'):
