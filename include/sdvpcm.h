@@ -488,6 +488,49 @@ int sdv_set_pcm1_stitch_settings(sdv_engine *e, const sdv_pcm1_stitch_settings *
 int sdv_pcm1_stitch_frames(sdv_engine *e, const sdv_pcm1_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                            size_t *n_pairs, sdv_frame_asm_pcm1 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* ---- PCM-16x0 back half: PCM16X0DataStitcher (pcm16x0datastitcher.h:100-327) ------------------------------------------- */
+/* PCM16X0DataStitcher slots (pcm16x0datastitcher.h:304-314); defaults of the constructor and of setDefaultFineSettings
+ * (pcm16x0datastitcher.cpp:3-33, 5636-5641) */
+enum { SDV_P16_FORMAT_AUTO = 0, SDV_P16_FORMAT_SI = 1, SDV_P16_FORMAT_EI = 2 };     /* PCM16X0Deinterleaver::FORMAT_* (AUTO is handled as SI, :5784) */
+typedef struct sdv_pcm16x0_stitch_settings {
+    uint8_t format;                 /* setFormat: SDV_P16_FORMAT_* (default SI) */
+    uint8_t field_order;            /* setFieldOrder: 1 = TFF (default), 2 = BFF */
+    uint8_t p_correction;           /* setPCorrection (default on) */
+    uint8_t use_ecc;                /* setFineUseECC (ignore_CRC = !use_ecc; default on) */
+    uint8_t mask_seams;             /* setFineMaskSeams (default on) */
+    uint8_t broke_mask;             /* setFineBrokeMask: blocks masked after a BROKEN one (default 81) */
+    uint16_t sample_rate_preset;    /* setSampleRatePreset (1 = auto, 44056, 44100) */
+} sdv_pcm16x0_stitch_settings;
+
+/* FrameAsmPCM16x0 (frametrimset.h:116-249) as emitted with guiUpdFrameAsm.  56 bytes. */
+typedef struct sdv_frame_asm_pcm16x0 {
+    uint32_t frame_number;
+    uint16_t odd_std_lines, even_std_lines, odd_data_lines, even_data_lines, odd_valid_lines, even_valid_lines;
+    uint16_t odd_top_data, odd_bottom_data, even_top_data, even_bottom_data, odd_sample_rate, even_sample_rate;
+    uint16_t blocks_total, blocks_drop, samples_drop;
+    uint16_t odd_top_padding, odd_bottom_padding, even_top_padding, even_bottom_padding;
+    uint16_t blocks_broken, blocks_fix_bp, blocks_fix_p, blocks_fix_cwd;
+    uint8_t field_order, odd_ref, even_ref, service_type;
+    uint8_t flags;                  /* SDV_FA_ORDER_PRESET, SDV_FA_ORDER_GUESSED, SDV_FA1_*_EMPHASIS, SDV_FA16_* */
+    uint8_t _pad;
+} sdv_frame_asm_pcm16x0;
+enum { SDV_FA16_SILENCE = 1 << 4, SDV_FA16_PADDING_OK = 1 << 5, SDV_FA16_EI_FORMAT = 1 << 6 };
+
+void sdv_default_pcm16x0_stitch_settings(sdv_pcm16x0_stitch_settings *st);
+/* Applies the settings and starts a fresh PCM16X0DataStitcher (statistics and queued lines are dropped). */
+int sdv_set_pcm16x0_stitch_settings(sdv_engine *e, const sdv_pcm16x0_stitch_settings *st);
+/* PCM16X0DataStitcher::doFrameReassemble (pcm16x0datastitcher.cpp:5652-5856) over a span of the PCM-16x0 sub-line stream
+ * (sdv_pcm16x0_binarize_frames' out_lines, service lines included): every complete frame (records up to its END_FRAME) is trimmed
+ * (findFrameTrim :213), split into fields (:566), scanned for false-positive CRCs of the Bit Picker (:753), aligned - SI format:
+ * per-field padding sweep with P-code checks and Control Bit positions (findSIPadding :1557); EI format: the padding between the
+ * fields of the frame (findEIFrameStitching :3588) - , assembled with padding (fillFrameForOutput :4594) and deinterleaved with
+ * P-code correction (PCM16X0Deinterleaver::processBlock, pcm16x0deinterleaver.cpp:128-708; performDeinterleave :5165) into three
+ * PCMSamplePairs per data block: 1470 per frame, plus the NEW_FILE / END_FILE tags; one FrameAsmPCM16x0 per frame.  Stream state
+ * (the padding and Control Bit histories, sub-lines that wait for their END_FRAME or for the rest of their interleave block)
+ * lives in the engine.  Same conventions as sdv_pcm1_stitch_frames. */
+int sdv_pcm16x0_stitch_frames(sdv_engine *e, const sdv_pcm16x0_bin_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
+                              size_t *n_pairs, sdv_frame_asm_pcm16x0 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -796,3 +796,124 @@ long ref_v2d16_run(void *h, const uint8_t *luma, size_t stride, int width, int h
     return v2d_run_t<PCM16X0SubLine, sdv_pcm16x0_bin_rec>((RefV2D16 *)h, luma, stride, width, height, n_frames, first_frame_no, new_file, doubled, out, stats, p16_line_to_rec, 3);
 }
 }
+
+/* ---- PCM-16x0 back half: the real PCM16X0Deinterleaver and PCM16X0DataStitcher ------------------------------------------------ */
+#include "pcm16.h"
+static void rec_to_p16_line(const sdv_pcm16x0_bin_rec &r, PCM16X0SubLine &l)
+{
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    switch (r.service_type) {
+        case SDV_SRV_NEW_FILE: l.setServNewFile("synthetic.avi"); return;
+        case SDV_SRV_END_FILE: l.setServEndFile(); return;
+        case SDV_SRV_FILLER: l.setServFiller(); return;
+        case SDV_SRV_END_FIELD: l.setServEndField(); return;
+        case SDV_SRV_END_FRAME: l.setServEndFrame(); return;
+        default: break;
+    }
+    for (uint8_t i = 0; i < 3; i++) l.setWord(i, r.words[i]);
+    l.setSourceCRC(r.words[3]); l.calcCRC();
+    l.coords.data_start = r.data_start; l.coords.data_stop = r.data_stop;
+    l.ref_level = r.ref_level; l.picked_bits_left = r.picked_bits_left; l.picked_bits_right = r.picked_bits_right;
+    l.control_bit = r.control_bit != 0; l.line_part = r.line_part; l.queue_order = r.queue_order;
+    l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
+    if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+}
+
+extern "C" void ref_pcm16x0_deint_blocks(const sdv_pcm16x0_bin_rec *lines, size_t n_lines, int ei_format, int force_check, int p_code, int ignore_crc,
+                                         int first_shift, int first_even, orc_p16_block_rec *out, size_t n_blocks)
+{
+    std::vector<PCM16X0SubLine> q(n_lines);
+    for (size_t i = 0; i < n_lines; i++) rec_to_p16_line(lines[i], q[i]);
+    PCM16X0Deinterleaver di;
+    PCM16X0DataBlock b;
+    di.setInput(&q); di.setOutput(&b);
+    di.setForcedErrorCheck(force_check != 0); di.setPCorrection(p_code != 0); di.setIgnoreCRC(ignore_crc != 0);
+    if (ei_format) di.setEIFormat(); else di.setSIFormat();
+    bool even = first_even != 0;
+    for (size_t k = 0; k < n_blocks; k++) {
+        b.clear();
+        uint8_t ret = di.processBlock((uint16_t)(first_shift + (int)k), even);
+        orc_p16_block_rec *o = &out[k];
+        memset(o, 0, sizeof(*o));
+        o->frame_number = b.frame_number; o->start_line = b.start_line; o->stop_line = b.stop_line; o->queue_order = b.queue_order;
+        o->start_part = b.start_part; o->stop_part = b.stop_part;
+        for (uint8_t i = 0; i < 3; i++) {
+            for (uint8_t w = 0; w < 3; w++) { o->words[i][w] = b.getWord(i, w); o->word_crc[i][w] = b.isWordCRCOk(i, w); o->word_valid[i][w] = b.isWordValid(i, w); }
+            o->picked_left[i] = b.hasPickedLeft(i); o->picked_crc[i] = b.hasPickedCRC(i); o->audio_state[i] = b.getAudioState(i);
+        }
+        o->order_even = b.isOrderEven(); o->ret = ret;
+        even = !even;
+    }
+}
+
+static void frasm16_to_pod(FrameAsmPCM16x0 &f, sdv_frame_asm_pcm16x0 *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->frame_number = f.frame_number;
+    o->odd_std_lines = f.odd_std_lines; o->even_std_lines = f.even_std_lines; o->odd_data_lines = f.odd_data_lines; o->even_data_lines = f.even_data_lines;
+    o->odd_valid_lines = f.odd_valid_lines; o->even_valid_lines = f.even_valid_lines;
+    o->odd_top_data = f.odd_top_data; o->odd_bottom_data = f.odd_bottom_data; o->even_top_data = f.even_top_data; o->even_bottom_data = f.even_bottom_data;
+    o->odd_sample_rate = f.odd_sample_rate; o->even_sample_rate = f.even_sample_rate;
+    o->blocks_total = f.blocks_total; o->blocks_drop = f.blocks_drop; o->samples_drop = f.samples_drop;
+    o->odd_top_padding = f.odd_top_padding; o->odd_bottom_padding = f.odd_bottom_padding; o->even_top_padding = f.even_top_padding; o->even_bottom_padding = f.even_bottom_padding;
+    o->blocks_broken = f.blocks_broken; o->blocks_fix_bp = f.blocks_fix_bp; o->blocks_fix_p = f.blocks_fix_p; o->blocks_fix_cwd = f.blocks_fix_cwd;
+    o->field_order = f.field_order; o->odd_ref = f.odd_ref; o->even_ref = f.even_ref;
+    o->service_type = f.isServNewFile() ? 1 : (f.isServEndFile() ? 2 : 0);
+    o->flags = (uint8_t)((f.isOrderPreset() ? SDV_FA_ORDER_PRESET : 0) | (f.isOrderGuessed() ? SDV_FA_ORDER_GUESSED : 0) |
+                         (f.odd_emphasis ? SDV_FA1_ODD_EMPHASIS : 0) | (f.even_emphasis ? SDV_FA1_EVEN_EMPHASIS : 0) |
+                         (f.silence ? SDV_FA16_SILENCE : 0) | (f.padding_ok ? SDV_FA16_PADDING_OK : 0) | (f.ei_format ? SDV_FA16_EI_FORMAT : 0));
+}
+
+extern "C" long ref_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                       sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames)
+{
+    PCM16X0DataStitcher *ds = new PCM16X0DataStitcher();
+    std::deque<PCM16X0SubLine> in_q;
+    std::deque<PCMSamplePair> out_q;
+    QMutex in_mtx, out_mtx, fr_mtx;
+    std::vector<FrameAsmPCM16x0> fr;
+    ds->setInputPointers(&in_q, &in_mtx);
+    ds->setOutputPointers(&out_q, &out_mtx);
+    QObject::connect(ds, &PCM16X0DataStitcher::guiUpdFrameAsm, [&](FrameAsmPCM16x0 d) { fr_mtx.lock(); fr.push_back(d); fr_mtx.unlock(); });
+    ds->setFormat(st->format); ds->setFieldOrder(st->field_order); ds->setPCorrection(st->p_correction != 0);
+    ds->setSampleRatePreset(st->sample_rate_preset);
+    ds->setFineUseECC(st->use_ecc != 0); ds->setFineMaskSeams(st->mask_seams != 0); ds->setFineBrokeMask(st->broke_mask);
+    std::thread th([ds]() { ds->doFrameReassemble(); });
+    size_t fed = 0; long got = 0; bool overflow = false;
+    size_t idle = 0;
+    PCM16X0SubLine l;
+    while (true) {
+        in_mtx.lock();
+        size_t qs = in_q.size();
+        while (fed < n_recs && qs < (size_t)(MAX_PCMLINE_QUEUE_SIZE * 3 - 1)) { rec_to_p16_line(recs[fed], l); in_q.push_back(l); fed++; qs++; }
+        in_mtx.unlock();
+        out_mtx.lock();
+        size_t drained = out_q.size();
+        while (!out_q.empty()) {
+            PCMSamplePair &p = out_q.front();
+            if ((size_t)got < out_cap) {
+                sdv_sample_pair *o = &out[got];
+                memset(o, 0, sizeof(*o));
+                for (int c = 0; c < 2; c++) {
+                    o->audio_word[c] = p.samples[c].audio_word;
+                    o->sample_flags[c] = (uint8_t)((p.samples[c].data_block_ok ? SDV_SF_BLOCK_OK : 0) | (p.samples[c].word_valid ? SDV_SF_WORD_VALID : 0) |
+                                                   (p.samples[c].word_fixed ? SDV_SF_WORD_FIXED : 0) | (p.samples[c].word_masked ? SDV_SF_WORD_MASKED : 0));
+                }
+                o->sample_rate = p.sample_rate; o->emphasis = p.emphasis; o->service_type = p.service_type;
+            } else overflow = true;
+            got++;
+            out_q.pop_front();
+        }
+        out_mtx.unlock();
+        if (fed == n_recs && drained == 0) { idle++; if (idle > 150) break; } else idle = 0;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+    ds->stop();
+    th.join();
+    size_t nf = fr.size() < frames_cap ? fr.size() : frames_cap;
+    for (size_t i = 0; i < nf; i++) frasm16_to_pod(fr[i], &frames[i]);
+    if (n_frames) *n_frames = fr.size();
+    delete ds;
+    return overflow ? -1 : got;
+}

@@ -558,3 +558,141 @@ def pcm16x0_frames(n_frames: int, seed: int = 0, width: int = 720, height: int =
     if p_dropout > 0:
         luma[rng.random(n) < p_dropout] = black
     return luma.reshape(n_frames, height, width), w4
+
+
+# ---- PCM-16x0 sub-line streams (records of the PCM-16x0 back half, sdv_pcm16x0_bin_rec) ---------------------------------
+def pcm16x0_encode_fields(audio: np.ndarray, ei: bool = False) -> np.ndarray:
+    """Audio sample pairs (n_frames * 1470, 2) i16 -> sub-line words (n_frames, 2, 735, 3) u16 of the two fields of every frame in
+    playback order.  A data block holds three sub-blocks (L, R, P = L ^ R) and sits on the sub-lines s, s + 35, s + 70 of a
+    105-sub-line interleave block (SI) or s, s + 490, s + 980 of the frame (EI) (pcm16x0datablock.h:38-91); which of L / R sits on
+    the first line alternates with the sub-block and with the block (PCM16X0DataBlock::getWordToLine, pcm16x0datablock.cpp:1029-1155)."""
+    a = np.asarray(audio).astype(np.int64) & 0xFFFF
+    n_frames = a.shape[0] // 1470
+    a = a[:n_frames * 1470].reshape(n_frames, 490, 3, 2)              # [frame][block][sub-block][L, R]
+    out = np.zeros((n_frames, 1470, 3), dtype=np.uint16)
+    blk = np.arange(490)
+    if ei:
+        s1 = blk; step = 490; even = (blk % 2) == 1
+    else:
+        s1 = (blk // 35) * 105 + blk % 35; step = 35; even = ((blk % 35) % 2) == 1
+    for k in range(3):
+        l_first = ((k & 1) != 0) != even                              # L on LINE_1
+        lw, rw = a[:, :, k, 0], a[:, :, k, 1]
+        out[:, s1, k] = np.where(l_first[None, :], lw, rw)
+        out[:, s1 + 2 * step, k] = np.where(l_first[None, :], rw, lw)
+        out[:, s1 + step, k] = lw ^ rw
+    return out.reshape(n_frames, 2, 735, 3)
+
+
+def pcm16x0_sub_stream(n_frames, seed=0, ei=False, first=(1, 2), cut=(0, 0), tail_cut=(0, 0), lead=(0, 0), trail=(0, 0), bff=False,
+                       emphasis=False, rate_44100=False, code=False, ei_bit=None, silent=(), quiet=(), p_bad=0.0, p_nobw=0.0, p_picked=0.0, p_forced=0.0,
+                       burst=None, wander=None, new_file=False, end_file=False, empty=(), one_field=(), first_frame=1, amplitude=1 << 15):
+    """The PCM16X0SubLine stream of a synthetic PCM-1630 tape as the PCM-16x0 VideoToDigital branch queues it: per frame the odd
+    rows (three sub-lines each), END_FIELD, the even rows, END_FIELD, END_FRAME.  `cut` / `tail_cut` = PCM lines the capture lost at
+    the top / bottom of the (odd, even) field, `lead` / `trail` = rows of noise (levels found, CRC bad) above / below the data,
+    `wander` = (period, amount): the top cut of both fields moves by up to `amount` lines every `period` frames, `silent` = frames
+    of digital silence, `quiet` = frames of near-silence (+-3), p_* = share of sub-lines damaged / without levels / completed by the Bit
+    Picker / forced bad, `burst` = (frame, field, first_line, lines): a dropout.  Returns (records, audio (n_frames * 1470, 2) i16)."""
+    rng = np.random.default_rng(seed)
+    audio = rng.integers(-amplitude, amplitude, size=(n_frames * 1470, 2)).astype(np.int16)
+    for fi in silent:
+        audio[fi * 1470:(fi + 1) * 1470] = 0
+    for fi in quiet:
+        audio[fi * 1470:(fi + 1) * 1470] = rng.integers(-3, 4, size=(1470, 2))
+    words = pcm16x0_encode_fields(audio, ei=ei)                        # [frame][field in playback order][735][3]
+    ctrl = np.ones((735,), dtype=np.uint8)
+    for b in range(7):
+        base = b * 105 + 1
+        if emphasis: ctrl[base + 0] = 0
+        if rate_44100: ctrl[base + 3] = 0
+        if (ei if ei_bit is None else ei_bit): ctrl[base + 6] = 0
+        if code: ctrl[base + 9] = 0
+    out = []
+
+    def srv(frame, line, st):
+        r = np.zeros(1, dtype=PCM16X0_BIN_DTYPE)
+        r["frame_number"] = frame; r["line_number"] = line; r["service_type"] = st
+        r["words"][0, 3] = 0x0E10 ^ 0xFFFF; r["control_bit"] = 1
+        return r
+
+    def noise_rows(frame, ln, cnt):
+        blk = np.zeros(cnt * 3, dtype=PCM16X0_BIN_DTYPE)
+        if cnt == 0:
+            return blk, ln
+        blk["frame_number"] = frame
+        blk["line_number"] = np.repeat(ln + 2 * np.arange(cnt), 3)
+        blk["line_part"] = np.tile(np.arange(3), cnt)
+        blk["words"][:, :3] = rng.integers(0, 1 << 16, size=(cnt * 3, 3))
+        blk["calc_crc"] = pcm16x0_crc_words(blk["words"][:, :3])
+        blk["words"][:, 3] = blk["calc_crc"] ^ rng.integers(1, 1 << 16, size=cnt * 3).astype(np.uint16)
+        blk["control_bit"] = rng.integers(0, 2, size=cnt * 3)
+        blk["flags"] = 8 | 16
+        blk["data_start"] = 12; blk["data_stop"] = 700
+        blk["black_level"] = 30; blk["white_level"] = 200; blk["ref_level"] = rng.integers(60, 180, size=cnt * 3)
+        return blk, ln + 2 * cnt
+
+    for fi in range(n_frames):
+        frame = first_frame + fi
+        if new_file and fi == 0:
+            out.append(srv(frame, 0, 1))
+        last_line = 0
+        shift = 0
+        if wander:
+            shift = int(rng.integers(0, wander[1] + 1)) if (fi // wander[0]) % 2 else 0
+        for parity in (0, 1):                                          # odd rows first, as the video decoder delivers them
+            play = parity if not bff else 1 - parity                   # which field of the frame (in playback order) these rows carry
+            ln = first[parity]
+            if fi in empty or (fi in one_field and parity == 1):
+                out.append(srv(frame, ln, 4)); last_line = max(last_line, ln)
+                continue
+            nb, ln = noise_rows(frame, ln, lead[parity]); out.append(nb)
+            lo = (cut[parity] + shift) * 3
+            hi = 735 - tail_cut[parity] * 3
+            cnt = hi - lo
+            blk = np.zeros(cnt, dtype=PCM16X0_BIN_DTYPE)
+            blk["frame_number"] = frame
+            blk["line_number"] = ln + 2 * (np.arange(cnt) // 3)
+            blk["line_part"] = np.arange(lo, hi) % 3
+            blk["queue_order"] = np.arange(cnt) // 3
+            blk["words"][:, :3] = words[fi, play, lo:hi]
+            blk["calc_crc"] = pcm16x0_crc_words(blk["words"][:, :3])
+            blk["words"][:, 3] = blk["calc_crc"]
+            blk["control_bit"] = ctrl[lo:hi]
+            blk["flags"] = 8 | 16
+            blk["data_start"] = 12; blk["data_stop"] = 700
+            blk["black_level"] = 30; blk["white_level"] = 200; blk["ref_low"] = 100; blk["ref_high"] = 130
+            blk["ref_level"] = rng.integers(60, 180, size=cnt)
+            bad = rng.random(cnt) < p_bad
+            if burst and burst[0] == fi and burst[1] == parity:
+                bad[max(0, burst[2] * 3 - lo):max(0, (burst[2] + burst[3]) * 3 - lo)] = True
+            blk["words"][bad, :3] ^= rng.integers(0, 1 << 16, size=(int(bad.sum()), 3)).astype(np.uint16) & rng.integers(0, 1 << 16, size=(int(bad.sum()), 3)).astype(np.uint16)
+            blk["calc_crc"][bad] = pcm16x0_crc_words(blk["words"][bad, :3])
+            same = bad & (blk["calc_crc"] == blk["words"][:, 3])
+            blk["words"][same, 3] ^= 0x0101
+            nobw = rng.random(cnt) < p_nobw
+            blk["flags"][nobw] &= 0xFF ^ 8
+            pk = rng.random(cnt) < p_picked
+            blk["picked_bits_left"][pk & (blk["line_part"] == 0)] = rng.integers(1, 4, size=int((pk & (blk["line_part"] == 0)).sum()))
+            blk["picked_bits_right"][pk & (blk["line_part"] == 2)] = rng.integers(1, 3, size=int((pk & (blk["line_part"] == 2)).sum()))
+            # a completed line is one that read wrong and was "repaired": some of them wrongly (data still off, CRC made to fit)
+            wrong = pk & (rng.random(cnt) < 0.5) & (blk["picked_bits_left"] + blk["picked_bits_right"] > 0)
+            blk["words"][wrong, 0] ^= (rng.integers(1, 8, size=int(wrong.sum())) << 13).astype(np.uint16)
+            blk["calc_crc"][wrong] = pcm16x0_crc_words(blk["words"][wrong, :3])
+            blk["words"][wrong, 3] = blk["calc_crc"][wrong]
+            fb = rng.random(cnt) < p_forced
+            blk["flags"][fb] |= 32
+            out.append(blk)
+            ln += 2 * (cnt // 3)
+            nb, ln = noise_rows(frame, ln, trail[parity]); out.append(nb)
+            out.append(srv(frame, ln, 4))
+            last_line = max(last_line, ln)
+        out.append(srv(frame, last_line + 2, 5))
+    if end_file:
+        frame = first_frame + n_frames
+        for field in (0, 1):
+            for ln in range(1 + field, 491, 2):
+                out.append(srv(frame, ln, 3))
+            out.append(srv(frame, 491 + field, 4))
+        out.append(srv(frame, 494, 2))
+        out.append(srv(frame, 496, 5))
+    return np.concatenate(out), audio

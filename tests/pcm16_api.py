@@ -1,0 +1,135 @@
+"""PCM-16x0 back half (PCM16X0Deinterleaver, PCM16X0DataStitcher): PODs, seeded sub-line streams and runners shared by the
+oracle-vs-reference test, the golden fixture generator (tests/golden/make_golden_pcm16.py) and the product parity tests."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+import libs
+from sdvpcmdecoder_amd import synth
+from stitch_api import PAIR_DTYPE
+
+SUB_DTYPE = synth.PCM16X0_BIN_DTYPE
+FRASM16_DTYPE = np.dtype([("frame_number", "<u4"),
+                          ("odd_std_lines", "<u2"), ("even_std_lines", "<u2"), ("odd_data_lines", "<u2"), ("even_data_lines", "<u2"),
+                          ("odd_valid_lines", "<u2"), ("even_valid_lines", "<u2"),
+                          ("odd_top_data", "<u2"), ("odd_bottom_data", "<u2"), ("even_top_data", "<u2"), ("even_bottom_data", "<u2"),
+                          ("odd_sample_rate", "<u2"), ("even_sample_rate", "<u2"),
+                          ("blocks_total", "<u2"), ("blocks_drop", "<u2"), ("samples_drop", "<u2"),
+                          ("odd_top_padding", "<u2"), ("odd_bottom_padding", "<u2"), ("even_top_padding", "<u2"), ("even_bottom_padding", "<u2"),
+                          ("blocks_broken", "<u2"), ("blocks_fix_bp", "<u2"), ("blocks_fix_p", "<u2"), ("blocks_fix_cwd", "<u2"),
+                          ("field_order", "u1"), ("odd_ref", "u1"), ("even_ref", "u1"), ("service_type", "u1"), ("flags", "u1"), ("_pad", "u1")])
+BLOCK16_DTYPE = np.dtype([("frame_number", "<u4"), ("start_line", "<u2"), ("stop_line", "<u2"), ("queue_order", "<u2"),
+                          ("start_part", "u1"), ("stop_part", "u1"), ("words", "<u2", (3, 3)), ("word_crc", "u1", (3, 3)), ("word_valid", "u1", (3, 3)),
+                          ("picked_left", "u1", (3,)), ("picked_crc", "u1", (3,)), ("audio_state", "u1", (3,)), ("order_even", "u1"), ("ret", "u1"), ("_pad", "u1")])
+assert SUB_DTYPE.itemsize == 36 and FRASM16_DTYPE.itemsize == 56 and BLOCK16_DTYPE.itemsize == 60, (FRASM16_DTYPE.itemsize, BLOCK16_DTYPE.itemsize)
+
+SRV_NEW_FILE, SRV_END_FILE, SRV_FILLER, SRV_END_FIELD, SRV_END_FRAME = 1, 2, 3, 4, 5
+FORMAT_SI, FORMAT_EI = 1, 2
+FA16_SILENCE, FA16_PADDING_OK, FA16_EI = 16, 32, 64
+
+
+class Pcm16Settings(C.Structure):
+    _fields_ = [("format", C.c_uint8), ("field_order", C.c_uint8), ("p_correction", C.c_uint8), ("use_ecc", C.c_uint8),
+                ("mask_seams", C.c_uint8), ("broke_mask", C.c_uint8), ("sample_rate_preset", C.c_uint16)]
+
+
+assert C.sizeof(Pcm16Settings) == 8
+
+
+def default_settings(**kw):
+    st = Pcm16Settings(FORMAT_SI, 1, 1, 1, 1, 81, 1)
+    for k, v in kw.items():
+        setattr(st, k, v)
+    return st
+
+
+make_stream = synth.pcm16x0_sub_stream
+
+# name: (frames, generator kwargs, settings overrides)
+CASES = {
+    "si_clean": (4, dict(seed=401), {}),
+    "si_cut_top": (5, dict(seed=402, cut=(6, 9), p_bad=0.01), {}),
+    "si_cut_both": (5, dict(seed=403, cut=(12, 3), tail_cut=(4, 10), p_bad=0.02), {}),
+    "si_rate_emph": (5, dict(seed=404, cut=(5, 5), rate_44100=True, emphasis=True, p_bad=0.02), {}),
+    "si_code": (4, dict(seed=405, cut=(3, 8), code=True, rate_44100=True), {}),
+    "si_bad10": (5, dict(seed=406, cut=(7, 7), p_bad=0.10, rate_44100=True), {}),
+    "si_bad35": (4, dict(seed=407, cut=(2, 4), p_bad=0.35), {}),
+    "si_noise_rows": (5, dict(seed=408, cut=(8, 6), lead=(3, 2), trail=(2, 4), p_bad=0.03, rate_44100=True), {}),
+    "si_picked_forced": (5, dict(seed=409, cut=(4, 4), p_bad=0.04, p_picked=0.10, p_forced=0.03, rate_44100=True), {}),
+    "si_silence": (6, dict(seed=410, cut=(6, 6), silent=(1, 2), quiet=(4,), p_bad=0.01), {}),
+    "si_wander": (8, dict(seed=411, cut=(4, 6), wander=(2, 5), p_bad=0.02, rate_44100=True), {}),
+    "si_burst": (5, dict(seed=412, cut=(5, 5), burst=(2, 0, 60, 50), rate_44100=True), {}),
+    "si_bff": (4, dict(seed=413, cut=(5, 7), bff=True, p_bad=0.02), dict(field_order=2)),
+    "si_no_p": (4, dict(seed=414, cut=(5, 7), p_bad=0.05), dict(p_correction=0)),
+    "si_no_ecc": (4, dict(seed=415, cut=(5, 7), p_bad=0.05, p_nobw=0.05), dict(use_ecc=0)),
+    "si_no_mask": (4, dict(seed=416, cut=(9, 2), p_bad=0.30), dict(mask_seams=0, broke_mask=0)),
+    "si_rate_preset": (3, dict(seed=417, cut=(5, 5), rate_44100=True), dict(sample_rate_preset=44056)),
+    "si_file_marks": (5, dict(seed=418, cut=(5, 7), p_bad=0.03, new_file=True, end_file=True, rate_44100=True), {}),
+    "si_empty_frames": (6, dict(seed=419, cut=(5, 7), p_bad=0.02, empty=(1,), one_field=(3,)), {}),
+    "si_short_fields": (4, dict(seed=420, cut=(100, 150), tail_cut=(120, 70), p_bad=0.02), {}),
+    "si_long_lead": (4, dict(seed=421, cut=(0, 0), lead=(20, 25), p_bad=0.02), {}),
+    "ei_clean": (4, dict(seed=431, ei=True), dict(format=FORMAT_EI)),
+    "ei_cut": (5, dict(seed=432, ei=True, cut=(6, 9), tail_cut=(3, 2), p_bad=0.01, rate_44100=True), dict(format=FORMAT_EI)),
+    "ei_bad10": (5, dict(seed=433, ei=True, cut=(7, 5), tail_cut=(4, 6), p_bad=0.10, rate_44100=True), dict(format=FORMAT_EI)),
+    "ei_wander": (8, dict(seed=434, ei=True, cut=(4, 6), tail_cut=(5, 5), wander=(2, 4), p_bad=0.02), dict(format=FORMAT_EI)),
+    "ei_silence": (6, dict(seed=435, ei=True, cut=(6, 6), tail_cut=(3, 3), silent=(1, 2), p_bad=0.01), dict(format=FORMAT_EI)),
+    "ei_bff": (4, dict(seed=436, ei=True, cut=(5, 7), tail_cut=(2, 2), bff=True, p_bad=0.02), dict(format=FORMAT_EI, field_order=2)),
+    "ei_noise_short": (5, dict(seed=437, ei=True, cut=(40, 30), tail_cut=(160, 150), lead=(2, 2), p_bad=0.05), dict(format=FORMAT_EI)),
+    "ei_file_marks": (5, dict(seed=438, ei=True, cut=(5, 7), tail_cut=(3, 3), p_bad=0.03, new_file=True, end_file=True, emphasis=True), dict(format=FORMAT_EI)),
+    "ei_picked": (5, dict(seed=439, ei=True, cut=(4, 4), tail_cut=(4, 4), p_bad=0.04, p_picked=0.10, p_forced=0.03), dict(format=FORMAT_EI)),
+    "si_tape_as_ei": (4, dict(seed=440, cut=(5, 5), tail_cut=(3, 3), p_bad=0.02), dict(format=FORMAT_EI)),
+    "ei_tape_as_si": (4, dict(seed=441, ei=True, cut=(5, 5), p_bad=0.02), {}),
+}
+GOLDEN = ("si_cut_both", "si_bad10", "si_picked_forced", "si_wander", "si_file_marks", "ei_cut", "ei_bad10", "ei_noise_short")
+
+
+def make_input(name):
+    n, kw, st_kw = CASES[name]
+    recs, _ = make_stream(n, **kw)
+    return recs, default_settings(**st_kw)
+
+
+def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
+    f = getattr(lib, prefix + "pcm16x0_stitch_run")
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm16Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == SRV_END_FRAME).sum()) + 2
+    pair_cap = pair_cap or nfr * 1500 + 16
+    frame_cap = frame_cap or nfr + 8
+    pairs = np.zeros(pair_cap, dtype=PAIR_DTYPE)
+    frames = np.zeros(frame_cap, dtype=FRASM16_DTYPE)
+    nf = C.c_size_t(0)
+    n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, pair_cap, frames.ctypes.data, frame_cap, C.byref(nf))
+    assert n >= 0, "pair buffer too small"
+    return pairs[:n], frames[:min(nf.value, frame_cap)]
+
+
+def run_blocks(lib, prefix, recs, n_blocks, ei=False, force=True, p_code=True, ignore_crc=False, first_shift=0, first_even=False):
+    f = getattr(lib, prefix + "pcm16x0_deint_blocks")
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    recs = np.ascontiguousarray(recs)
+    out = np.zeros(n_blocks, dtype=BLOCK16_DTYPE)
+    f(recs.ctypes.data, len(recs), int(ei), int(force), int(p_code), int(ignore_crc), first_shift, int(first_even), out.ctypes.data, n_blocks)
+    return out
+
+
+def digest(pairs, frames):
+    return hashlib.sha256(pairs.tobytes() + frames.tobytes()).hexdigest()
+
+
+def block_inputs():
+    """name -> (queue of data sub-lines, run_blocks keywords): damaged SI and EI queues under every switch combination."""
+    out = {}
+    tapes = [dict(p_bad=0.3, p_picked=0.2, p_forced=0.05), dict(p_bad=0.15, p_picked=0.4, p_nobw=0.1)]
+    for t, kw in enumerate(tapes):
+        for ei in (False, True):
+            recs, _ = make_stream(1, seed=900 + t, ei=ei, **kw)
+            data = recs[recs["service_type"] == 0]
+            for sw in range(8):
+                force, p_code, ign = sw & 1, (sw >> 1) & 1, (sw >> 2) & 1
+                out[f"t{t}_{'ei' if ei else 'si'}_{sw}"] = (data, dict(n_blocks=160, ei=ei, force=force, p_code=p_code, ignore_crc=ign,
+                                                                    first_shift=0, first_even=bool(t & 1)))
+    return out
