@@ -11,6 +11,7 @@
 #include "pcm1_frames_device.h"
 #include "pcm16_bin_device.h"
 #include "pcm16_frames_device.h"
+#include "pcm16_stitch_device.h"
 #include "engine.inc"
 #include "stitch_engine.inc"
 #include "pcm1_engine.inc"

@@ -73,6 +73,12 @@ class Pcm1StitchSettings(C.Structure):
                 ("even_offset", C.c_int8), ("_pad", C.c_uint8 * 3)]
 
 
+class Pcm16x0StitchSettings(C.Structure):
+    """PCM16X0DataStitcher settings (slots pcm16x0datastitcher.h:304-314)"""
+    _fields_ = [("format", C.c_uint8), ("field_order", C.c_uint8), ("p_correction", C.c_uint8), ("use_ecc", C.c_uint8),
+                ("mask_seams", C.c_uint8), ("broke_mask", C.c_uint8), ("sample_rate_preset", C.c_uint16)]
+
+
 class StitchInfo(C.Structure):
     _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("_pad", C.c_uint32),
                 ("device_ms", C.c_float), ("_pad2", C.c_float)]
@@ -153,6 +159,11 @@ def load_library(path: str | None = None):
     lib.sdv_pcm1_stitch_frames.restype = C.c_int
     lib.sdv_pcm1_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                            C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    lib.sdv_default_pcm16x0_stitch_settings.argtypes = [C.POINTER(Pcm16x0StitchSettings)]
+    lib.sdv_set_pcm16x0_stitch_settings.argtypes = [C.c_void_p, C.POINTER(Pcm16x0StitchSettings)]
+    lib.sdv_pcm16x0_stitch_frames.restype = C.c_int
+    lib.sdv_pcm16x0_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                              C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     lib.sdv_stitch_frames.restype = C.c_int
     lib.sdv_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
@@ -336,6 +347,47 @@ class Engine:
         npairs, nframes = C.c_size_t(0), C.c_size_t(0)
         rc = self.lib.sdv_pcm1_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
                                              C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
+        self._check(rc)
+        return out_pairs[:npairs.value], out_frames[:nframes.value]
+
+    def default_pcm16x0_stitch_settings(self) -> Pcm16x0StitchSettings:
+        st = Pcm16x0StitchSettings()
+        self.lib.sdv_default_pcm16x0_stitch_settings(C.byref(st))
+        return st
+
+    def set_pcm16x0_stitch_settings(self, st: Pcm16x0StitchSettings):
+        """Applies the settings and starts a fresh PCM16X0DataStitcher (histories and waiting sub-lines are dropped)."""
+        self._check(self.lib.sdv_set_pcm16x0_stitch_settings(self._h, C.byref(st)))
+
+    def pcm16x0_stitch_frames(self, lines, out_pairs=None, out_frames=None, stream=None):
+        """PCM16X0DataStitcher::doFrameReassemble over a span of the PCM-16x0 sub-line stream: `lines` is a torch.uint8 CUDA tensor
+        (n_records, 36) of sdv_pcm16x0_bin_rec (what pcm16x0_binarize_frames returns).  Returns (pairs, frames): torch.uint8 CUDA tensors
+        (n_pairs, 12) of sdv_sample_pair and (n_frames, 56) of sdv_frame_asm_pcm16x0."""
+        import torch
+        assert lines.is_cuda and lines.dtype == torch.uint8 and lines.dim() == 2 and lines.shape[1] == 36 and lines.is_contiguous()
+        n = lines.shape[0]
+        own_pairs, own_frames = out_pairs is None, out_frames is None
+        if out_pairs is None:
+            out_pairs = torch.empty((n + n // 8 + 4096, 12), dtype=torch.uint8, device=lines.device)     # a pair per sub-line + padding
+        if out_frames is None:
+            out_frames = torch.empty((n // 64 + 64, 56), dtype=torch.uint8, device=lines.device)
+        _check_out(out_pairs, 12, lines.device, "out_pairs")
+        _check_out(out_frames, 56, lines.device, "out_frames")
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)
+        npairs, nframes = C.c_size_t(0), C.c_size_t(0)
+        for attempt in (0, 1):
+            rc = self.lib.sdv_pcm16x0_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
+                                                    C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
+            # buffers of our own guess were too small (short fields still decode to 1470 pairs a frame): the refused call took
+            # nothing and reported the sizes - once more with those
+            if rc == -1 and attempt == 0 and (npairs.value > out_pairs.shape[0] or nframes.value > out_frames.shape[0]) and \
+                    (own_pairs or npairs.value <= out_pairs.shape[0]) and (own_frames or nframes.value <= out_frames.shape[0]):
+                if npairs.value > out_pairs.shape[0]:
+                    out_pairs = torch.empty((npairs.value, 12), dtype=torch.uint8, device=lines.device)
+                if nframes.value > out_frames.shape[0]:
+                    out_frames = torch.empty((nframes.value, 56), dtype=torch.uint8, device=lines.device)
+                continue
+            break
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
 

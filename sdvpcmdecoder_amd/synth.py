@@ -696,3 +696,20 @@ def pcm16x0_sub_stream(n_frames, seed=0, ei=False, first=(1, 2), cut=(0, 0), tai
         out.append(srv(frame, 494, 2))
         out.append(srv(frame, 496, 5))
     return np.concatenate(out), audio
+
+
+def pcm16x0_tape(n_frames, seed=5, period=50, **kw):
+    """`n_frames` of PCM-16x0 sub-line records for throughput runs: a `period`-frame damaged tape repeated with continuing frame numbers."""
+    kw.setdefault("p_bad", 0.02)
+    kw.setdefault("cut", (6, 9))
+    kw.setdefault("tail_cut", (3, 4))
+    kw.setdefault("rate_44100", True)
+    base, _ = pcm16x0_sub_stream(period, seed=seed, **kw)
+    tiles = []
+    for t in range((n_frames + period - 1) // period):
+        b = base.copy()
+        b["frame_number"] += period * t
+        tiles.append(b)
+    recs = np.concatenate(tiles)
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    return recs[:ends[n_frames - 1] + 1]

@@ -97,6 +97,27 @@ def emu_pcm1_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None
     return rc, pairs[:min(npairs.value, pair_cap)], frames[:min(nframes.value, frame_cap)]
 
 
+def emu_pcm16_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
+    """Host-memory call (emulator build only): one sdv_pcm16x0_stitch_frames call over `recs`."""
+    import pcm16_api as p16
+    import stitch_api as sa
+    lib.sdv_set_pcm16x0_stitch_settings.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sdv_pcm16x0_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_size_t), C.c_void_p]
+    if settings is not None:
+        assert lib.sdv_set_pcm16x0_stitch_settings(eng, C.byref(settings)) == 0
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == 5).sum()) + 2
+    pair_cap = pair_cap or nfr * 1472 + 16
+    frame_cap = frame_cap or nfr + 8
+    pairs = np.zeros(pair_cap, dtype=sa.PAIR_DTYPE)
+    frames = np.zeros(frame_cap, dtype=p16.FRASM16_DTYPE)
+    npairs, nframes = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.sdv_pcm16x0_stitch_frames(eng, recs.ctypes.data if len(recs) else None, len(recs), pairs.ctypes.data, pair_cap, C.byref(npairs),
+                                       frames.ctypes.data, frame_cap, C.byref(nframes), None)
+    return rc, pairs[:min(npairs.value, pair_cap)], frames[:min(nframes.value, frame_cap)]
+
+
 def emu_binarize(lib, eng, luma, first_frame_no=1, flags=1, row_stride=None, misalign=0):
     """Host-memory call (emulator build only).  row_stride / misalign: the same pixels in a padded, shifted buffer."""
     n, h, w = luma.shape

@@ -106,3 +106,230 @@ def test_clean_tape_decodes_to_its_audio(ei, oracle_lib):
     assert (pairs["audio_word"][ok] == audio[ok]).all()
     assert ((pairs["sample_flags"][ok] & 3) == 3).all()
     assert (pairs["sample_rate"] == 44100).all()
+
+
+# ---- the kernels on the emulator -----------------------------------------------------------------------------------
+import engine_api as ea  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu(emu_lib):
+    return ea.bind(emu_lib)
+
+
+@pytest.mark.parametrize("name", list(p16.CASES))
+def test_emu_matches_oracle(name, emu, oracle_lib):
+    recs, st, want_p, want_f = _oracle(name)
+    eng = emu.sdv_engine_create(0)
+    rc, pairs, frames = ea.emu_pcm16_stitch(emu, eng, recs, st)
+    emu.sdv_engine_destroy(eng)
+    assert rc == 0
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.parametrize("name", ["si_file_marks", "ei_wander"])
+def test_emu_streaming_calls_equal_one_call(name, emu, oracle_lib):
+    """The stream may arrive in arbitrary pieces: sub-lines wait in the engine for their END_FRAME, the padding and Control Bit
+    histories carry over from call to call."""
+    recs, st, want_p, want_f = _oracle(name)
+    eng = emu.sdv_engine_create(0)
+    cuts = [0, 1, 2, 700, 1473, 1474, 3000, 3001, 6000, len(recs) - 1, len(recs)]
+    got_p, got_f = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs[a:b], st if a == 0 else None, pair_cap=9000, frame_cap=16)
+        assert rc == 0
+        got_p.append(p.copy())
+        got_f.append(f.copy())
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def test_emu_edge_inputs(emu, oracle_lib):
+    eng = emu.sdv_engine_create(0)
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, np.zeros(0, dtype=p16.SUB_DTYPE))            # empty
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    recs, st = p16.make_input("si_clean")
+    end = int(np.nonzero(recs["service_type"] == p16.SRV_END_FRAME)[0][0])
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs[:end], st)                             # a frame without its END_FRAME: nothing yet
+    assert rc == 0 and len(p) == 0 and len(f) == 0
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs[end:end + 1])                          # ... now it completes
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", recs[:end + 1], st)
+    assert rc == 0 and _same(p, f, want_p, want_f)
+    emu.sdv_engine_destroy(eng)
+    eng = emu.sdv_engine_create(0)
+    lone = recs[end:end + 1].copy()                                                      # a lone END_FRAME: an all-padding frame
+    lone["frame_number"] = 9
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, lone, st)
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", lone, st)
+    assert rc == 0 and len(p) == 1470 and _same(p, f, want_p, want_f)
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs, pair_cap=100, frame_cap=8)            # output buffer too small: reported, sized
+    assert rc != 0 and b"too small" in emu.sdv_last_error(eng)
+    emu.sdv_engine_destroy(eng)
+
+
+def test_emu_failed_call_leaves_the_stream_untouched(emu, oracle_lib):
+    """A call that is refused takes nothing: waiting sub-lines still wait, the histories are as before, and the same records can be
+    handed over again."""
+    recs, st, want_p, want_f = _oracle("si_wander")
+    eng = emu.sdv_engine_create(0)
+    cut = 4000                                                                           # inside the third frame
+    rc, p0, f0 = ea.emu_pcm16_stitch(emu, eng, recs[:cut], st, pair_cap=20000, frame_cap=16)
+    assert rc == 0 and len(f0) == 2
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs[cut:], None, pair_cap=100, frame_cap=16)
+    assert rc != 0 and b"too small" in emu.sdv_last_error(eng)
+    rc, p1_, f1 = ea.emu_pcm16_stitch(emu, eng, recs[cut:], None, pair_cap=20000, frame_cap=16)   # the same records again
+    assert rc == 0
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate([p0, p1_]), np.concatenate([f0, f1])
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def test_emu_rejects_foreign_lines(emu):
+    """Sub-lines of another frame queued ahead of an END_FRAME stay in the reference's queue for a later turn: not a per-frame job."""
+    recs, st = p16.make_input("si_clean")
+    recs = recs.copy()
+    recs["frame_number"][100] = 2
+    eng = emu.sdv_engine_create(0)
+    rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs, st)
+    assert rc != 0 and b"another frame" in emu.sdv_last_error(eng)
+    emu.sdv_engine_destroy(eng)
+
+
+def test_emu_long_frame_takes_the_global_memory_path(emu, oracle_lib):
+    """More sub-lines in a frame than the LDS staging holds (1536): the same result, read from global memory."""
+    recs, _ = synth.pcm16x0_sub_stream(3, seed=88, cut=(4, 6), lead=(30, 30), trail=(20, 25), p_bad=0.03, p_picked=0.05, rate_44100=True)
+    assert max(np.diff(np.nonzero(recs["service_type"] == p16.SRV_END_FRAME)[0])) > 1536
+    st = p16.default_settings()
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", recs, st)
+    eng = emu.sdv_engine_create(0)
+    rc, pairs, frames = ea.emu_pcm16_stitch(emu, eng, recs, st)
+    emu.sdv_engine_destroy(eng)
+    assert rc == 0 and _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+# ---- the product on the GPU ------------------------------------------------------------------------------------------
+def _gpu_run(eng, recs, st, torch, configure=True, **kw):
+    from sdvpcmdecoder_amd import Pcm16x0StitchSettings
+    if configure:
+        eng.set_pcm16x0_stitch_settings(Pcm16x0StitchSettings.from_buffer_copy(bytes(st)))
+    d = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), 36)).cuda()
+    p, f = eng.pcm16x0_stitch_frames(d, **kw)
+    return p.cpu().numpy().reshape(-1).view(PAIR_DTYPE), f.cpu().numpy().reshape(-1).view(p16.FRASM16_DTYPE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(p16.CASES))
+def test_gpu_matches_oracle(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    recs, st, want_p, want_f = _oracle(name)
+    pairs, frames = _gpu_run(Engine(0), recs, st, torch)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", p16.GOLDEN)
+def test_gpu_matches_golden_from_reference(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    z = np.load(os.path.join(GOLD, "pcm16_" + name + ".npz"))
+    recs, st = p16.make_input(name)
+    assert hashlib.sha256(recs.tobytes()).hexdigest() == str(z["input_sha256"])
+    pairs, frames = _gpu_run(Engine(0), recs, st, torch)
+    want_p = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    want_f = np.ascontiguousarray(z["frames"]).view(p16.FRASM16_DTYPE).reshape(-1)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ei", [False, True])
+def test_gpu_large_batch_in_pieces(ei):
+    """600 frames with damage, a wandering picture and file marks in the middle, handed over in three calls cut mid-frame (more
+    frames than one internal batch would take with SDV_P16_STITCH_BATCH lowered): equal to the oracle's run."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    a, _ = p16.make_stream(250, seed=41, ei=ei, cut=(5, 7), tail_cut=(3, 3), p_bad=0.03, wander=(7, 4), rate_44100=True, new_file=True, end_file=True)
+    b, _ = p16.make_stream(350, seed=42, ei=ei, cut=(9, 4), tail_cut=(2, 5), p_bad=0.01, p_picked=0.02, silent=(40, 41, 42), new_file=True, first_frame=1000)
+    recs = np.concatenate([a, b])
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    want_p, want_f = p16.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    eng = Engine(0)
+    cuts = [0, 123457, 600001, len(recs)]
+    got_p, got_f = [], []
+    for i, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        p, f = _gpu_run(eng, recs[lo:hi], st, torch, configure=i == 0)
+        got_p.append(p)
+        got_f.append(f)
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_gpu_random_cuts(seed):
+    """A damaged PCM-1630 tape with file tags handed over in pieces cut at random record positions equals the oracle's run."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    rng = np.random.default_rng(seed)
+    ei = bool(seed & 1)
+    recs, _ = p16.make_stream(int(rng.integers(30, 60)), seed=seed, ei=ei, cut=(int(rng.integers(0, 12)), int(rng.integers(0, 12))), tail_cut=(3, 4),
+                              p_bad=0.04, p_picked=0.02, wander=(5, 3), rate_44100=bool(seed & 2), new_file=True, end_file=True)
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    want_p, want_f = p16.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    eng = Engine(0)
+    cuts = [0] + sorted(int(x) for x in rng.choice(np.arange(1, len(recs)), size=9, replace=False)) + [len(recs)]
+    got_p, got_f = [], []
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        p, f = _gpu_run(eng, recs[a:b], st, torch, configure=i == 0)
+        got_p.append(p.copy())
+        got_f.append(f.copy())
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ei", [False, True])
+def test_gpu_full_size_round_trip(ei):
+    """BASELINE-size property: 4000 clean frames (5.9 M sub-lines) with rows lost at the top and bottom of both fields decode to the
+    audio that was encoded, every block whose three lines survived valid; the call's device time is reported."""
+    import time
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    n, period = 4000, 50
+    cut, tail = (6, 9), (3, 4)
+    base, audio = p16.make_stream(period, seed=70 + ei, ei=ei, cut=cut, tail_cut=tail, rate_44100=True)
+    tiles = []
+    for t in range(n // period):
+        b = base.copy()
+        b["frame_number"] += period * t
+        tiles.append(b)
+    recs = np.concatenate(tiles)
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    eng = Engine(0)
+    from sdvpcmdecoder_amd import Pcm16x0StitchSettings
+    eng.set_pcm16x0_stitch_settings(Pcm16x0StitchSettings.from_buffer_copy(bytes(st)))
+    d = torch.from_numpy(recs.view(np.uint8).reshape(len(recs), 36)).cuda()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    p, f = eng.pcm16x0_stitch_frames(d)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    pairs = p.cpu().numpy().reshape(-1).view(PAIR_DTYPE)
+    frames = f.cpu().numpy().reshape(-1).view(p16.FRASM16_DTYPE)
+    print(f"\n[pcm16x0 stitch, {'EI' if ei else 'SI'}] {n} frames in {dt * 1e3:.1f} ms: {n / dt:,.0f} frames/s")
+    assert len(pairs) == n * 1470 and len(frames) == n
+    assert (frames["flags"] & p16.FA16_PADDING_OK).all()
+    lost = np.zeros((2, 735), dtype=bool)
+    for fl in (0, 1):
+        lost[fl, :cut[fl] * 3] = True
+        lost[fl, 735 - tail[fl] * 3:] = True
+    lost = lost.reshape(1470)
+    blk = np.arange(490)
+    s1 = blk if ei else (blk // 35) * 105 + blk % 35
+    step = 490 if ei else 35
+    whole = np.repeat(~(lost[s1] | lost[s1 + step] | lost[s1 + 2 * step]), 3)
+    got = pairs["audio_word"].reshape(n // period, period, 1470, 2)
+    want = audio.reshape(period, 1470, 2)
+    assert (got[:, :, whole] == want[None, :, whole]).all()
+    assert ((pairs["sample_flags"].reshape(n, 1470, 2)[:, whole] & 3) == 3).all()
