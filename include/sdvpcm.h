@@ -488,6 +488,11 @@ int sdv_set_pcm1_stitch_settings(sdv_engine *e, const sdv_pcm1_stitch_settings *
 int sdv_pcm1_stitch_frames(sdv_engine *e, const sdv_pcm1_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                            size_t *n_pairs, sdv_frame_asm_pcm1 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* The PCM1Line queue between the two halves: sdv_pcm1_binarize_frames writes sdv_pcm1_bin_rec (everything Binarizer::processLine leaves in a
+ * PCM1Line), sdv_pcm1_stitch_frames reads sdv_pcm1_line_rec (what PCM1DataStitcher looks at).  Record i of `in` -> record i of `out`; device
+ * pointers, asynchronous on `stream`. */
+int sdv_pcm1_bin_to_line_recs(sdv_engine *e, const sdv_pcm1_bin_rec *in, size_t n, sdv_pcm1_line_rec *out, void *stream);
+
 /* ---- PCM-16x0 back half: PCM16X0DataStitcher (pcm16x0datastitcher.h:100-327) ------------------------------------------- */
 /* PCM16X0DataStitcher slots (pcm16x0datastitcher.h:304-314); defaults of the constructor and of setDefaultFineSettings
  * (pcm16x0datastitcher.cpp:3-33, 5636-5641) */

@@ -473,8 +473,22 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         if (err) { atomicOr(&a.stat[0], err); atomicMin(&a.stat[1], k); }
     }
 }
+/* ---- front half -> back half: what PCM1DataStitcher reads of a PCM1Line (sdv_pcm1_line_rec) out of the record the frame driver writes ---- */
+struct ConvArgs1 { const sdv_pcm1_bin_rec *in; sdv_pcm1_line_rec *out; size_t n; };
+__device__ inline void conv_body(const ConvArgs1 &a, size_t i)
+{
+    if (i >= a.n) return;
+    const sdv_pcm1_bin_rec r = a.in[i];
+    sdv_pcm1_line_rec o = sdv_pcm1_line_rec();
+    o.frame_number = r.frame_number; o.line_number = r.line_number;
+    for (int w = 0; w < 7; w++) o.words[w] = r.words[w];
+    o.calc_crc = r.calc_crc; o.ref_level = r.ref_level; o.picked_bits_left = r.picked_bits_left; o.picked_bits_right = r.picked_bits_right;
+    o.service_type = r.service_type; o.flags = (uint8_t)(r.flags & (SDV_LF_BW_SET | SDV_LF_FORCED_BAD));
+    a.out[i] = o;
+}
 } // namespace sdvp1
 
+__global__ void __launch_bounds__(64) sdv_k_pcm1_bin_to_line(sdvp1::ConvArgs1 a) { sdvp1::conv_body(a, (size_t)blockIdx.x * 64u + threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_segments(sdvp1::SegArgs1 a) { sdvp1::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_scan(sdvp1::ScanArgs1 a) { sdvp1::scan_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)

@@ -159,6 +159,8 @@ def load_library(path: str | None = None):
     lib.sdv_pcm1_stitch_frames.restype = C.c_int
     lib.sdv_pcm1_stitch_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                            C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    lib.sdv_pcm1_bin_to_line_recs.restype = C.c_int
+    lib.sdv_pcm1_bin_to_line_recs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.sdv_default_pcm16x0_stitch_settings.argtypes = [C.POINTER(Pcm16x0StitchSettings)]
     lib.sdv_set_pcm16x0_stitch_settings.argtypes = [C.c_void_p, C.POINTER(Pcm16x0StitchSettings)]
     lib.sdv_pcm16x0_stitch_frames.restype = C.c_int
@@ -349,6 +351,18 @@ class Engine:
                                              C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
+
+    def pcm1_bin_to_line_recs(self, bin_recs, out=None, stream=None):
+        """The records pcm1_binarize_frames returns ((n, 40) sdv_pcm1_bin_rec) as the records pcm1_stitch_frames takes ((n, 32) sdv_pcm1_line_rec)."""
+        import torch
+        _check_out(bin_recs, 40, bin_recs.device, "bin_recs")
+        n = bin_recs.shape[0]
+        if out is None:
+            out = torch.empty((n, 32), dtype=torch.uint8, device=bin_recs.device)
+        _check_out(out, 32, bin_recs.device, "out")
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(bin_recs.device).cuda_stream)
+        self._check(self.lib.sdv_pcm1_bin_to_line_recs(self._h, C.c_void_p(bin_recs.data_ptr()), n, C.c_void_p(out.data_ptr()), sptr))
+        return out[:n]
 
     def default_pcm16x0_stitch_settings(self) -> Pcm16x0StitchSettings:
         st = Pcm16x0StitchSettings()

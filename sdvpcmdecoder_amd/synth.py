@@ -713,3 +713,45 @@ def pcm16x0_tape(n_frames, seed=5, period=50, **kw):
     recs = np.concatenate(tiles)
     ends = np.nonzero(recs["service_type"] == 5)[0]
     return recs[:ends[n_frames - 1] + 1]
+
+
+def pcm16x0_tape_frames(n_frames: int, seed: int = 0, ei: bool = False, width: int = 720, height: int = 486, first_pcm_line=(0, 0), bff: bool = False,
+                        rate_44100: bool = True, emphasis: bool = False, code: bool = False, x0: int = 4, x1: int | None = None, p_dropout: float = 0.0,
+                        amplitude: int = 1 << 15, **kw):
+    """Video of a PCM-1630 tape: audio -> data blocks -> interleave (SI or EI) -> 245 PCM lines per field with their Control Bits ->
+    luma.  Row r of a frame belongs to field r % 2 (odd rows of the reference = even r) and shows PCM line first_pcm_line[field] + r // 2 of that
+    field: a 486-row capture sees 243 of the 245 lines of either field.  Returns (luma (n_frames, height, width) u8, audio
+    (n_frames * 1470, 2) i16, seen (2, 735) bool: the sub-lines of a [odd rows, even rows] field that are in the picture)."""
+    rng = np.random.default_rng(seed)
+    audio = rng.integers(-amplitude, amplitude, size=(n_frames * 1470, 2)).astype(np.int16)
+    words = pcm16x0_encode_fields(audio, ei=ei)                        # [frame][field in playback order][735][3]
+    crc = pcm16x0_crc_words(words.reshape(-1, 3)).reshape(n_frames, 2, 735)
+    w4 = np.concatenate([words, crc[..., None]], axis=3).reshape(n_frames, 2, 245, 3, 4)
+    ctrl = np.ones((245,), dtype=np.uint8)                            # the Control Bit sits between the second and the third sub-line of a line
+    for b in range(7):
+        line = b * 35
+        if emphasis: ctrl[line + 0] = 0
+        if rate_44100: ctrl[line + 1] = 0
+        if ei: ctrl[line + 2] = 0
+        if code: ctrl[line + 3] = 0
+    rows_w = np.zeros((n_frames, height, 3, 4), dtype=np.uint16)
+    rows_c = np.ones((n_frames, height), dtype=np.uint8)
+    blank = np.ones((height,), dtype=bool)
+    seen = np.zeros((2, 735), dtype=bool)
+    for r in range(height):
+        parity = r % 2
+        play = parity if not bff else 1 - parity
+        pl = first_pcm_line[parity] + r // 2
+        if 0 <= pl < 245:
+            rows_w[:, r] = w4[:, play, pl]
+            rows_c[:, r] = ctrl[pl]
+            blank[r] = False
+            seen[parity, 3 * pl:3 * pl + 3] = True
+    n = n_frames * height
+    luma = render_lines(pcm16x0_line_bits(rows_w.reshape(n, 3, 4), rows_c.reshape(n)), width=width, x0=x0, x1=(width - 4 if x1 is None else x1), rng=rng, **kw)
+    luma = luma.reshape(n_frames, height, width)
+    black = kw.get("black", 30)
+    luma[:, blank] = black
+    if p_dropout > 0:
+        luma[rng.random((n_frames, height)) < p_dropout] = black
+    return luma, audio, seen

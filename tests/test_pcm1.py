@@ -254,3 +254,39 @@ def test_gpu_random_cuts(seed):
         got_f.append(f.copy())
     pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def bin_to_line_recs(bin_recs):
+    """sdv_pcm1_bin_rec -> sdv_pcm1_line_rec in numpy: what sdv_pcm1_bin_to_line_recs does on the device."""
+    out = np.zeros(len(bin_recs), dtype=p1.LINE1_DTYPE)
+    for nm in ("frame_number", "line_number", "words", "calc_crc", "ref_level", "picked_bits_left", "picked_bits_right", "service_type"):
+        out[nm] = bin_recs[nm]
+    out["flags"] = bin_recs["flags"] & (p1.LF_BW_SET | p1.LF_FORCED_BAD)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gpu_video_to_audio(mode):
+    """The whole PCM-1 path on the device - video frames -> sdv_pcm1_binarize_frames -> sdv_pcm1_bin_to_line_recs ->
+    sdv_pcm1_stitch_frames - against the oracle's two halves chained on the CPU."""
+    import torch
+    import pcm1_frames_api as fa
+    from sdvpcmdecoder_amd import Engine, synth
+    luma, _ = synth.pcm1_frames(5, seed=91 + mode, height=486, noise_sigma=4.0)
+    orc = libs.load_oracle()
+    want_recs, _ = fa.run_cpu(orc, "orc_", luma, mode, {})
+    st = p1.default_settings()
+    want_p, want_f = p1.run_cpu(orc, "orc_", bin_to_line_recs(want_recs), st)
+    eng = Engine(0)
+    eng.setPCMType(0)              # PCM_PCM1
+    eng.setBinarizationMode(mode)
+    lines, _ = eng.pcm1_binarize_frames(torch.from_numpy(luma).cuda())
+    assert lines.cpu().numpy().tobytes() == want_recs.tobytes()
+    conv = eng.pcm1_bin_to_line_recs(lines)
+    assert conv.cpu().numpy().tobytes() == bin_to_line_recs(want_recs).tobytes()
+    p, f = eng.pcm1_stitch_frames(conv)
+    pairs = p.cpu().numpy().reshape(-1).view(PAIR_DTYPE)
+    frames = f.cpu().numpy().reshape(-1).view(p1.FRASM1_DTYPE)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+    assert len(pairs) == 5 * 1470 and (pairs["sample_flags"] & 2).mean() > 0.95

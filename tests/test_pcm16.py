@@ -333,3 +333,32 @@ def test_gpu_full_size_round_trip(ei):
     want = audio.reshape(period, 1470, 2)
     assert (got[:, :, whole] == want[None, :, whole]).all()
     assert ((pairs["sample_flags"].reshape(n, 1470, 2)[:, whole] & 3) == 3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ei", [False, True])
+def test_gpu_video_to_audio(ei):
+    """The whole PCM-16x0 path on the device - video frames -> sdv_pcm16x0_binarize_frames -> sdv_pcm16x0_stitch_frames - against the
+    oracle's two halves chained on the CPU, and against the audio the tape was made from: a 486-row capture shows 243 of the 245 PCM
+    lines of a field, the blocks that lost one line come back through their P-code."""
+    import torch
+    import pcm16_frames_api as fa
+    from sdvpcmdecoder_amd import Engine, Pcm16x0StitchSettings
+    n = 6
+    luma, audio, seen = synth.pcm16x0_tape_frames(n, seed=5 + ei, ei=ei, noise_sigma=4.0)
+    orc = libs.load_oracle()
+    want_recs, _ = fa.run_cpu(orc, "orc_", luma, 2, {})
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    want_p, want_f = p16.run_cpu(orc, "orc_", want_recs, st)
+    eng = Engine(0)
+    eng.setPCMType(1)              # PCM_PCM16X0
+    eng.setBinarizationMode(2)     # MODE_NORMAL
+    eng.set_pcm16x0_stitch_settings(Pcm16x0StitchSettings.from_buffer_copy(bytes(st)))
+    lines, _ = eng.pcm16x0_binarize_frames(torch.from_numpy(luma).cuda())
+    p, f = eng.pcm16x0_stitch_frames(lines)
+    pairs = p.cpu().numpy().reshape(-1).view(PAIR_DTYPE)
+    frames = f.cpu().numpy().reshape(-1).view(p16.FRASM16_DTYPE)
+    assert lines.cpu().numpy().tobytes() == want_recs.tobytes()
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+    assert (frames["flags"] & p16.FA16_PADDING_OK).all() and (frames["odd_sample_rate"] == 44100).all()
+    assert (pairs["audio_word"] == audio).all() and ((pairs["sample_flags"] & 3) == 3).all()
