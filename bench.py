@@ -278,6 +278,37 @@ def main():
                         "(sdv_pcm1_stitch_frames), wall clock per batch incl. its host round trips; not part of `value`"}
         p1_first = pp[:3000 * 1470].cpu().numpy().copy() if rank == 0 else None
 
+    # ... the PCM-16x0 back half (PCM16X0DataStitcher): sub-line records -> sample pairs, both interleave formats
+    pcm16 = None
+    if not args.no_stitch and world == 1:
+        from sdvpcmdecoder_amd import synth as _synth
+        pcm16 = {"note": "PCM-1630 frames (1470 sub-line records each, damaged tape with rows lost at the top and bottom of the fields) -> trim, "
+                         "field split, padding detection by P-code checks over every candidate padding, deinterleave + P-code correction to "
+                         "PCMSamplePair (sdv_pcm16x0_stitch_frames), wall clock per batch incl. its host round trips; not part of `value`"}
+        p16_keep = {}
+        for fmt, ei in (("si", False), ("ei", True)):
+            recs16 = _synth.pcm16x0_tape(n, ei=ei)
+            d16 = torch.from_numpy(recs16.view(np.uint8).reshape(len(recs16), 36)).to(dev)
+            st16 = eng.default_pcm16x0_stitch_settings(); st16.format = 2 if ei else 1
+            o16p = torch.empty((n * 1470 + 64, 12), dtype=torch.uint8, device=dev)
+            o16f = torch.empty((n + 64, 56), dtype=torch.uint8, device=dev)
+            eng.set_pcm16x0_stitch_settings(st16)
+            eng.pcm16x0_stitch_frames(d16, out_pairs=o16p, out_frames=o16f, stream=stream)
+            k_steps = max(1, min(args.steps, 5))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(k_steps):
+                eng.set_pcm16x0_stitch_settings(st16)          # a fresh stitcher: every step decodes the same tape from its start
+                pp16, pf16 = eng.pcm16x0_stitch_frames(d16, out_pairs=o16p, out_frames=o16f, stream=stream)
+            torch.cuda.synchronize(dev)
+            ms16 = (time.perf_counter() - t1) * 1e3 / k_steps
+            b16 = len(recs16) * 36 + n * (1470 * 12 + 56)
+            pcm16[fmt] = {"ms_per_step": ms16, "frames_per_s": n / ms16 * 1e3, "algorithmic_gb_per_s": b16 / ms16 / 1e6, "sample_pairs_per_step": int(pp16.shape[0]),
+                          "frames_with_padding_found": int((pf16[:, 54] & 32).ne(0).sum().item())}
+            if rank == 0:
+                p16_keep[fmt] = (recs16, pp16[:200 * 1470].cpu().numpy().copy())
+            del d16, o16p, o16f
+
     # ... and its front half: video lines -> PCM1Line records (sdv_pcm1_binarize_lines), a tape that plays (every line preset from a
     # decoded neighbour) and the cold case (nothing preset: the marker-less coordinate search on every line)
     pcm1f = None
@@ -419,6 +450,8 @@ def main():
             out["pcm1_stage"] = pcm1
         if pcm1f is not None:
             out["pcm1_front_stage"] = pcm1f
+        if pcm16 is not None:
+            out["pcm16x0_stage"] = pcm16
         for key, (stage, _b, _f) in fmt_stages.items():
             out[key] = stage
         if not args.no_cpu and world == 1:
@@ -469,6 +502,25 @@ def main():
                 pcm1["cpu_baseline"] = {"value": np1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
                                         "sample": f"the first {np1} frames, {dt1:.2f} s of CPU work",
                                         "bit_exact_vs_gpu_on_overlap": bool(cp1.tobytes() == p1_first.reshape(-1).view(p1a.PAIR_DTYPE)[:len(cp1)].tobytes())}
+            if pcm16 is not None:
+                # the PCM-16x0 back half on the CPU: the real reference's stitcher thread (or the oracle port) on the first 200 frames
+                import pcm16_api as p16a
+                use_ref = libs.ref_available()
+                lib16 = libs.load_ref() if use_ref else libs.load_oracle()
+                for fmt, (recs16, got16) in p16_keep.items():
+                    n16 = min(200, n)
+                    end = int(np.nonzero(recs16["service_type"] == 5)[0][n16 - 1])
+                    st = p16a.default_settings(format=2 if fmt == "ei" else 1)
+                    fd = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)       # the stitcher logs to stderr
+                    try:
+                        t0 = time.perf_counter()
+                        cp16, _ = p16a.run_cpu(lib16, "ref_" if use_ref else "orc_", recs16[:end + 1], st)
+                        dt16 = time.perf_counter() - t0
+                    finally:
+                        os.dup2(fd, 2); os.close(devnull); os.close(fd)
+                    pcm16[fmt]["cpu_baseline"] = {"value": n16 / dt16, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                                                  "sample": f"the first {n16} frames, {dt16:.2f} s of CPU work" + (" (incl. ~0.3 s the driver waits for the stitcher thread to go idle)" if use_ref else ""),
+                                                  "bit_exact_vs_gpu_on_overlap": bool(cp16.tobytes() == got16.reshape(-1).view(p16a.PAIR_DTYPE)[:len(cp16)].tobytes())}
             if pcm1f is not None:
                 import pcm1_front_api as pfa
                 wl, wst, wgot, cl, cgot = pcm1f_sample

@@ -28,3 +28,5 @@ bash $R/tools/gpu_pcm1_front_pmc.sh 2>&1 | grep "rc="
 
 # PCM-1 and PCM-16x0 frame drivers: kernel stats
 bash $R/tools/gpu_frames_prof.sh 2>&1 | grep "rc="
+# PCM-16x0 back half: kernel stats
+bash $R/tools/gpu_pcm16_prof.sh 10000 2>&1 | grep "rc=\|frames/s"
