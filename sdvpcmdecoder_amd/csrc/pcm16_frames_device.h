@@ -9,6 +9,25 @@
  *   - the window of the last valid coordinates holds 27 entries (9 lines x 3 parts, :1265-1273), so the chain state is longer.
  */
 #pragma once
+#ifndef SDV_P16_STAMPS
+#define SDV_P16_STAMPS 0         /* developer aid: the frame's statistics row is overwritten with four cycle sums (rows staged, parts decoded, per-part bookkeeping, records stored) */
+#endif
+#if SDV_P16_STAMPS && !defined(SDV_EMU)
+#define P16_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define P16_ADD(i, t0, t1) (p16_stamp[i] += (t1) - (t0))
+#else
+#define P16_T(x) ((void)0)
+#define P16_ADD(i, t0, t1) ((void)0)
+#endif
+#ifndef SDV_P16_BATCH
+#define SDV_P16_BATCH 1          /* runs of lines that read from one tuning take batch16 */
+#endif
+#ifndef SDV_P16_LEAN
+#define SDV_P16_LEAN 1           /* parts that read from their presets take lean_part16 */
+#endif
+#ifndef SDV_P16_ABLATE
+#define SDV_P16_ABLATE 0        /* developer aid: 1 no line decode, 2 no per-part bookkeeping, 3 no record store (outputs are wrong) */
+#endif
 #include "pcm16_bin_device.h"
 #include "pcm1_frames_device.h"
 
@@ -66,7 +85,7 @@ __device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, i
 struct V2D16 {
     V2D v;                          /* the part shared with STC-007; last_words unused */
     uint8_t prescan_ref;
-    uint16_t last_w[3][3];          /* the data words of last_pcm16x0_p0/p1/p2_line */
+    uint64_t lw0, lw1, lw2;         /* the data words of last_pcm16x0_p0/p1/p2_line (the 48 data cells; named members: an indexed array would put the whole state into scratch) */
 };
 
 __device__ inline void load_state16(V2D16 &w, Lds16 &lds, const State16 *s, const FrameArgs &a)
@@ -77,7 +96,7 @@ __device__ inline void load_state16(V2D16 &w, Lds16 &lds, const State16 *s, cons
         const sdv_coord cc = i < COORD_HISTORY_DEPTH ? s->s.last_valid[i] : s->more[i - COORD_HISTORY_DEPTH];
         lds.lv_keys16[i] = coords_key(cc.data_start, cc.data_stop);
     }
-    for (int p = 0; p < 3; p++) for (int k = 0; k < 3; k++) w.last_w[p][k] = 0;
+    w.lw0 = w.lw1 = w.lw2 = 0;
 }
 
 __device__ inline bool link_holds16(const FrameArgs &a, int f, const State16 &out, State16 next_in)
@@ -172,7 +191,7 @@ __device__ inline void service_line16(V2D16 &w, const FrameArgs &a, L16 &wl, uin
         v.field_state = FIELD_NEW;
         v.line_in_field_cnt = 0;
         v.good_coords_in_field = 0; v.pcm_lines_in_field = 0;
-        for (int p = 0; p < 3; p++) for (int k = 0; k < 3; k++) w.last_w[p][k] = 0;
+        w.lw0 = w.lw1 = w.lw2 = 0;
     }
 }
 
@@ -196,8 +215,8 @@ __device__ inline void post_part16(V2D16 &w, const FrameArgs &a, Lds16 &lds, L16
                 set_good_parameters_p16(v.bin, ps, wl);
                 if (ps.en_first_line_dup) { wl.forced_bad = true; force_bad_line = true; }
             } else {
-                int diff = 0;
-                for (int k = 0; k < 3; k++) diff += __popc((uint32_t)(uint8_t)(get_word(wl, k) ^ w.last_w[part][k]));   /* the XOR is truncated to uint8_t */
+                const uint64_t lw = part == 0 ? w.lw0 : (part == 1 ? w.lw1 : w.lw2);
+                const int diff = __popcll(((wl.v >> 16) ^ lw) & 0x00FF00FF00FFull);     /* per word the XOR is truncated to uint8_t */
                 const int16_t s0 = (int16_t)get_word(wl, 0), s2 = (int16_t)get_word(wl, 2);
                 const bool almost_silent = (!(s0 >= 4) && !(s0 < -4)) || (!(s2 >= 4) && !(s2 < -4));                      /* pcm16x0subline.cpp:291-318 */
                 if (!almost_silent && diff <= (P16_DATA / BIT_DIFF_THRES_DIV)) { wl.forced_bad = true; if (!even_line) v.q_dup_odd++; else v.q_dup_even++; }
@@ -206,9 +225,13 @@ __device__ inline void post_part16(V2D16 &w, const FrameArgs &a, Lds16 &lds, L16
         if (crc_valid_ignore_forced(wl)) {
             const uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
             __syncthreads();
-            if (lane_id() == 0) {
-                if (v.n_last == LV16) for (int i = 0; i < LV16 - 1; i++) lds.lv_keys16[i] = lds.lv_keys16[i + 1];
-                lds.lv_keys16[v.n_last == LV16 ? LV16 - 1 : v.n_last] = key;
+            {   /* the window moves up by one when it is full: every lane carries one entry (no serial chain through LDS) */
+                const int ln = lane_id();
+                const bool full = v.n_last == LV16;
+                const uint32_t moved = (full && ln < LV16 - 1) ? lds.lv_keys16[ln + 1] : 0u;
+                __syncthreads();
+                if (full && ln < LV16 - 1) lds.lv_keys16[ln] = moved;
+                if (ln == 0) lds.lv_keys16[full ? LV16 - 1 : v.n_last] = key;
             }
             if (v.n_last < LV16) v.n_last++;
             __syncthreads();
@@ -257,9 +280,212 @@ __device__ inline void post_part16(V2D16 &w, const FrameArgs &a, Lds16 &lds, L16
     if (count_has_pcm) {
         if (!even_line) v.q_pcm_odd++; else v.q_pcm_even++;
         v.pcm_lines_in_field++;
-        for (int k = 0; k < 3; k++) w.last_w[part][k] = get_word(wl, k);
+        const uint64_t nw = wl.v >> 16;
+        w.lw0 = part == 0 ? nw : w.lw0; w.lw1 = part == 1 ? nw : w.lw1; w.lw2 = part == 2 ? nw : w.lw2;
     }
     v.line_in_field_cnt++;
+}
+
+#ifdef SDV_EMU
+__device__ inline uint32_t lane_read32(uint32_t x, uint32_t idx) { return (uint32_t)__shfl((int)x, (int)idx); }
+#else
+__device__ inline uint32_t lane_read32(uint32_t x, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)uniu(idx)); }
+#endif
+/* ---- the tape plays: a part that reads from what its predecessor left preset ------------------------------------------------------- */
+/* Binarizer::processLine for a part whose levels, reference level and coordinates are preset and that reads valid on the first rung of
+ * the ladder (hysteresis 0, shift 0) is stage STG_INPUT_ALL and nothing else (binarizer.cpp:774-931): one LDS byte per lane, two ballots,
+ * the automaton, the CRC, the Control Bit, the Bit Picker's count of cut-off cells.  What depends on the tuning only - the pixel every
+ * lane samples in each of the three parts, the levels with their clipping test, the cut-off counts - is kept while the tuning stays the
+ * same (on a tape that plays: for the whole frame).  Anything else - no complete presets, forced coordinates, a part that does not read
+ * at once - goes through process_line_p16 from the start. */
+struct Lean16 {
+    uint32_t key_coords, key_levels;        /* what `x` etc. were computed for; key_levels = 0xFFFFFFFF: nothing yet */
+    uint16_t x[3], x_ctrl;                  /* lane's pixel in the left / middle / right part; the Control Bit's pixel */
+    uint8_t low, high, bits_l, bits_r;
+    bool usable;
+    uint32_t psm, hpsm; int16_t pso;
+};
+__device__ inline void lean16_reset(Lean16 &n) { n.key_levels = 0xFFFFFFFFu; n.key_coords = 0; n.usable = false; }
+/* true when parts can be read the lean way under the tuning in b (and n describes that tuning) */
+__device__ inline bool lean16_prepare(Lean16 &n, const BinCtx &c, const Bin &b)
+{
+    if (c.ps.en_force_coords) return false;
+    if (!(are_bw_levels_preset(b, c.ps) && is_ref_level_preset(b, c.ps) && coords_valid(b.in_coord))) return false;
+    if (!(b.in_ref < b.in_white && b.in_ref > b.in_black)) return false;
+    if (!(c.scan_end > c.scan_start && P16_BITS <= (c.scan_end - c.scan_start))) return false;
+    const uint32_t kc = coords_key(b.in_coord.start, b.in_coord.stop) , kl = (uint32_t)b.in_black | ((uint32_t)b.in_white << 8) | ((uint32_t)b.in_ref << 16) | ((uint32_t)(b.in_coord.doubled ? 1 : 0) << 24);
+    if (kc != n.key_coords || kl != n.key_levels) {
+        n.key_coords = kc; n.key_levels = kl;
+        L16 t; p16_clear(t);
+        t.pixel_start = c.scan_start; t.pixel_stop = c.scan_end;
+        t.coords = b.in_coord;
+        set_ppb(t, t.coords);
+        n.psm = t.psm; n.hpsm = t.hpsm; n.pso = t.pso;
+        const int lane = lane_id();
+        for (int q = 0; q < 3; q++) n.x[q] = (uint16_t)pixel_of(t, part_start_bit((uint8_t)(PART_LEFT + q)) + lane, 0);
+        n.x_ctrl = (uint16_t)pixel_of(t, 2 * P16_DATA, 0);
+        n.low = get_low_level(b.in_ref, 0); n.high = get_high_level(b.in_ref, 0);
+        n.usable = !(n.low <= b.in_black) && !(n.high >= b.in_white);
+        /* pickCutBitsUpPCM16X0 (binarizer.cpp:6599-7013): how many cells the picture cuts off at either end */
+        t.black = b.in_black; t.white = b.in_white; t.ref_level = b.in_ref;
+        for (int side = 0; side < 2; side++) {
+            const bool left = side == 0;
+            int max_cut = left ? c.ps.left_bit_pick : c.ps.right_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+            int first = left ? c.scan_start : c.scan_end, bits = 0;
+            const int half_ppb = ((int)get_ppb(t) + 1) / 2;
+            for (int i = 0; i < max_cut; i++) {
+                const int cur = pixel_of(t, left ? i : P16_BITS - 1 - i, 0);
+                if ((left ? (cur - first) : (first - cur)) >= half_ppb) break;
+                if (i == 0) first = cur;
+                bits = i + 1;
+            }
+            if (left) n.bits_l = (uint8_t)bits; else n.bits_r = (uint8_t)bits;
+        }
+    }
+    return n.usable && c.force_bit_picker;
+}
+__device__ inline bool lean_part16(Lean16 &n, const BinCtx &c, const Bin &b, uint8_t part, const uint8_t *px_row, L16 &out)
+{
+    if (!lean16_prepare(n, c, b)) return false;
+    const int lane = lane_id();
+    const int q = part == PART_LEFT ? 0 : (part == PART_MIDDLE ? 1 : 2);
+    const uint8_t p0 = px_row[q == 0 ? n.x[0] : (q == 1 ? n.x[1] : n.x[2])];
+    const uint64_t a_lo = __ballot(p0 > n.low), b_lo = __ballot(p0 >= n.high);
+    uint64_t s_lo, s_hi;
+    solve_automaton(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
+    const uint64_t v = __brevll(s_lo);
+    const int par = __popcll(v & c_crc16.k[lane & 15]) & 1;
+    const uint16_t crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc16.base);
+    if (crc != (uint16_t)(v & 0xFFFF)) return false;
+    /* the line as processLine leaves it (STG_INPUT_ALL -> STG_DATA_OK) */
+    p16_clear(out);
+    out.line_part = (uint8_t)q;
+    out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end;
+    out.coords = b.in_coord;
+    out.black = b.in_black; out.white = b.in_white; out.bw_set = true;
+    out.ref_level = b.in_ref; out.ref_low = n.low; out.ref_high = n.high;
+    out.hyst = 0; out.shift = 0;
+    out.psm = n.psm; out.hpsm = n.hpsm; out.pso = n.pso;
+    out.v = v; out.calc_crc = crc;
+    out.control_bit = !(px_row[n.x_ctrl] < b.in_ref);
+    out.picked_l = q == 0 ? n.bits_l : 0; out.picked_r = q == 2 ? n.bits_r : 0;
+    out.by_ext_tune = true; out.coords_set = true;
+    return true;
+}
+
+/* ---- a run of lines that all read from the same presets: 21 video lines = 63 parts at a time -------------------------------------- */
+/* While a tape plays every part is decoded with the tuning its predecessor was decoded with and hands that same tuning on, so the parts
+ * of a run of lines do not depend on each other: phase A reads them - per line four byte gathers straight from the frame (the three
+ * cells a lane owns and the Control Bit's pixel; no LDS staging, no barrier), two ballots, the automaton and the CRC per part - and parks
+ * each part's 64 cells in the lane that owns it; phase B does VideoToDigital's per-part bookkeeping (:1115-1634) for all parts at once, a
+ * lane per part: duplicate-line test against the same part of the line above, the record, the counters as sums.  Preconditions:
+ * the field is past its first valid part, the window of last valid coordinates holds nothing but the preset coordinates (so the
+ * coordinate damper sees a delta of zero).  The first line with a part that does not read, or that repeats the line above, ends the run:
+ * it and what follows take the part-by-part path.  Returns the number of video lines taken. */
+enum { BATCH16_LINES = 21 };
+__device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, const Lean16 &n, const uint8_t *frame, int field, int idx, int nl,
+                              uint32_t frame_no, sdv_pcm16x0_bin_rec *rec, uint32_t *fv_keys, L16 &wl)
+{
+    const FrameArgs &a = a16.f;
+    V2D &v = w.v;
+    const int lane = lane_id();
+    if (v.field_state != FIELD_INIT) return 0;
+    const uint32_t key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
+    if (__ballot(lane < v.n_last && lds.lv_keys16[lane < LV16 ? lane : 0] != key) != 0ull) return 0;
+    int n_lines = nl - idx; if (n_lines > BATCH16_LINES) n_lines = BATCH16_LINES;
+    const uint8_t low = n.low, high = n.high, ref = v.bin.in_ref;
+    /* phase A */
+    uint32_t v_lo = 0, v_hi = 0, cb = 0;
+    int n_ok = 0;
+    for (int l = 0; l < n_lines; l++) {
+        const uint8_t *rowp = frame + (size_t)(2 * (idx + l) + field) * a.row_stride;
+        const uint8_t p0 = rowp[n.x[0]], p1 = rowp[n.x[1]], p2 = rowp[n.x[2]], pc = rowp[n.x_ctrl];
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const uint8_t px = q == 0 ? p0 : (q == 1 ? p1 : p2);
+            const uint64_t a_lo = __ballot(px > low), b_lo = __ballot(px >= high);
+            uint64_t s_lo, s_hi;
+            solve_automaton(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
+            const uint64_t cells = __brevll(s_lo);
+            const int par = __popcll(cells & c_crc16.k[lane & 15]) & 1;
+            const uint16_t crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc16.base);
+            ok = ok && crc == (uint16_t)(cells & 0xFFFF);
+            const int j = 3 * l + q;
+            v_lo = write_lane(v_lo, (uint32_t)cells, j); v_hi = write_lane(v_hi, (uint32_t)(cells >> 32), j);
+            cb = write_lane(cb, pc < ref ? 0u : 1u, j);
+        }
+        if (!ok) break;
+        n_ok = l + 1;
+    }
+    if (n_ok == 0) return 0;
+    /* phase B: lane j = part j % 3 of line j / 3 */
+    const int part = lane % 3, line_in = lane / 3;
+    const uint64_t mine = ((uint64_t)v_hi << 32) | v_lo;
+    const uint64_t words = mine >> 16;
+    if (a.check_line_copy) {
+        const int src = lane >= 3 ? lane - 3 : lane;
+        uint64_t above = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(words >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)words, src);
+        if (lane < 3) above = lane == 0 ? w.lw0 : (lane == 1 ? w.lw1 : w.lw2);
+        const int diff = __popcll((words ^ above) & 0x00FF00FF00FFull);
+        const int16_t s0 = (int16_t)(uint16_t)(mine >> 48), s2 = (int16_t)(uint16_t)(mine >> 16);
+        const bool almost_silent = (!(s0 >= 4) && !(s0 < -4)) || (!(s2 >= 4) && !(s2 < -4));
+        const uint64_t dup = __ballot(lane < 3 * n_ok && !almost_silent && diff <= (P16_DATA / BIT_DIFF_THRES_DIV));
+        if (dup) { n_ok = (__ffsll((unsigned long long)dup) - 1) / 3; if (n_ok == 0) return 0; }
+    }
+    const int n_sub = 3 * n_ok;
+    const bool even_line = field == 1;
+    const uint16_t q0 = v.line_in_field_cnt;
+    if (lane < n_sub) {
+        sdv_pcm16x0_bin_rec r;
+        r.frame_number = frame_no; r.line_number = (uint16_t)(field + 1 + 2 * (idx + line_in));
+        r.words[0] = (uint16_t)(mine >> 48); r.words[1] = (uint16_t)(mine >> 32); r.words[2] = (uint16_t)(mine >> 16); r.words[3] = (uint16_t)mine;
+        r.calc_crc = (uint16_t)mine;
+        r.data_start = v.bin.in_coord.start; r.data_stop = v.bin.in_coord.stop;
+        r.queue_order = (uint16_t)(q0 + lane);
+        r.black_level = v.bin.in_black; r.white_level = v.bin.in_white; r.ref_low = low; r.ref_level = ref; r.ref_high = high;
+        r.hysteresis_depth = 0; r.shift_stage = 0; r.service_type = SDV_SRV_NO;
+        r.picked_bits_left = part == 0 ? n.bits_l : 0; r.picked_bits_right = part == 2 ? n.bits_r : 0;
+        r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | SDV_LF_COORDS_SET | SDV_LF_CRC_VALID | (a.doubled ? SDV_LF_FROM_DOUBLED : 0));
+        r.line_part = (uint8_t)part; r.control_bit = (uint8_t)cb; r._pad = 0;
+        rec[lane] = r;
+        fv_keys[v.nfv + lane] = key;
+    }
+    /* the counters of n_sub parts that read (post_part16 with a valid CRC, field state FIELD_INIT) */
+    v.good_coords_in_field = (uint16_t)(v.good_coords_in_field + n_sub);
+    v.q_line_length = (uint16_t)a.width;
+    if (!even_line) { v.q_odd = (uint16_t)(v.q_odd + n_sub); v.q_pcm_odd = (uint16_t)(v.q_pcm_odd + n_sub); }
+    else { v.q_even = (uint16_t)(v.q_even + n_sub); v.q_pcm_even = (uint16_t)(v.q_pcm_even + n_sub); }
+    v.pcm_lines_in_field = (uint16_t)(v.pcm_lines_in_field + n_sub);
+    v.line_in_field_cnt = (uint16_t)(v.line_in_field_cnt + n_sub);
+    v.nfv += n_sub;
+    {   /* the window of last valid coordinates: n_sub more entries of the same key */
+        int fill_to = v.n_last + n_sub; if (fill_to > LV16) fill_to = LV16;
+        __syncthreads();
+        if (lane >= v.n_last && lane < fill_to) lds.lv_keys16[lane] = key;
+        __syncthreads();
+        v.n_last = fill_to;
+    }
+    {   /* what the last line leaves behind: its words for the duplicate test, and the line object of its last part */
+        const uint32_t h0 = lane_read32((uint32_t)(words >> 32), (uint32_t)(n_sub - 3)), l0 = lane_read32((uint32_t)words, (uint32_t)(n_sub - 3));
+        const uint32_t h1 = lane_read32((uint32_t)(words >> 32), (uint32_t)(n_sub - 2)), l1 = lane_read32((uint32_t)words, (uint32_t)(n_sub - 2));
+        const uint32_t h2 = lane_read32((uint32_t)(words >> 32), (uint32_t)(n_sub - 1)), l2 = lane_read32((uint32_t)words, (uint32_t)(n_sub - 1));
+        w.lw0 = ((uint64_t)h0 << 32) | l0; w.lw1 = ((uint64_t)h1 << 32) | l1; w.lw2 = ((uint64_t)h2 << 32) | l2;
+        const uint64_t last = ((uint64_t)lane_read32(v_hi, (uint32_t)(n_sub - 1)) << 32) | lane_read32(v_lo, (uint32_t)(n_sub - 1));
+        p16_clear(wl);
+        wl.line_part = 2;
+        wl.pixel_start = 0; wl.pixel_stop = (uint16_t)(a.width - 1);
+        wl.coords = v.bin.in_coord;
+        wl.black = v.bin.in_black; wl.white = v.bin.in_white; wl.bw_set = true;
+        wl.ref_level = ref; wl.ref_low = low; wl.ref_high = high;
+        wl.psm = n.psm; wl.hpsm = n.hpsm; wl.pso = n.pso;
+        wl.v = last; wl.calc_crc = (uint16_t)last;
+        wl.control_bit = lane_read32(cb, (uint32_t)(n_sub - 1)) != 0;
+        wl.picked_r = n.bits_r;
+        wl.by_ext_tune = true; wl.coords_set = true;
+        wl.queue_order = (uint16_t)(q0 + n_sub - 1);
+    }
+    return n_ok;
 }
 
 __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
@@ -287,6 +513,10 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
     }
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     uint16_t line_num = 0;
+    Lean16 lean; lean16_reset(lean);
+#if SDV_P16_STAMPS && !defined(SDV_EMU)
+    unsigned long long p16_stamp[4] = { 0, 0, 0, 0 };
+#endif
     if (f == a.new_file_frame) { service_line16(w, a, wl, SDV_SRV_NEW_FILE); emit_rec(wl, frame_no, 0, false, rec++); }
     for (int field = 0; field < 2; field++) {
         const int nl = n_field[field];
@@ -297,8 +527,22 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
                 emit_rec(wl, frame_no, line_num, false, rec++);
                 continue;
             }
+#if SDV_P16_BATCH
+            {
+                BinCtx cb0;
+                ctx_for_line(a, cb0, v.bin);
+                P16_T(t_g);
+                if (lean16_prepare(lean, cb0, v.bin)) {
+                    const int took = batch16(w, a16, lds, lean, frame, field, idx, nl, frame_no, rec, fv_keys, wl);
+                    P16_T(t_h); P16_ADD(1, t_g, t_h);
+                    if (took > 0) { rec += 3 * took; idx += took - 1; continue; }
+                }
+            }
+#endif
             const int row = 2 * idx + field;
+            P16_T(t_a);
             sdvp1b::stage_row(lds.p.w.px, frame + (size_t)row * a.row_stride, a.width);
+            P16_T(t_b); P16_ADD(0, t_a, t_b);
             bool scan_done = false;
             for (int k = 0; k < COORD_CHECK_LINES; k++) if (pre_row[k] == row && pre_done[k]) scan_done = true;
             bool force_bad_line = false;
@@ -307,9 +551,24 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
                 ctx_for_line(a, c, v.bin);
                 bool coord_search = true;                               /* :927-950 */
                 if (a.mode == SDV_MODE_DRAFT || a.mode == SDV_MODE_FAST) coord_search = !(v.good_coords_in_field > 9 || v.pcm_lines_in_field > 15);
-                process_line_p16(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
+                P16_T(t_c);
+#if SDV_P16_ABLATE == 1
+                p16_clear(wl);
+#else
+                if (!(SDV_P16_LEAN && lean_part16(lean, c, v.bin, (uint8_t)(PART_LEFT + sub), lds.p.w.px, wl)))
+                    process_line_p16(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
+#endif
+                P16_T(t_d); P16_ADD(1, t_c, t_d);
+#if SDV_P16_ABLATE != 2
                 post_part16(w, a, lds, wl, fv_keys, fi_keys, (line_num % 2) == 0, force_bad_line, scan_done);
+#endif
+                P16_T(t_e); P16_ADD(2, t_d, t_e);
+#if SDV_P16_ABLATE != 3
                 emit_rec(wl, frame_no, line_num, doubled, rec++);
+#else
+                rec++;
+#endif
+                P16_T(t_f); P16_ADD(3, t_e, t_f);
             }
         }
         line_num = (uint16_t)(field + 1 + 2 * nl);
@@ -334,6 +593,9 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
     v2d_end_frame(v, a, lds.p.w, frame_no, fv_keys, fi_keys, &a.stats[f]);
     emit_rec(wl, frame_no, line_num, false, rec++);
     store_state16(w, lds, a16, f);
+#if SDV_P16_STAMPS && !defined(SDV_EMU)
+    if (lane_id() == 0) { unsigned long long *dst = (unsigned long long *)&a.stats[f]; for (int i = 0; i < 4; i++) dst[i] = p16_stamp[i]; }
+#endif
 }
 
 /* ---- prediction of the incoming states (the PCM-1 model, pcm1_frames_device.h, with the longer window) ------------------------ */

@@ -246,9 +246,13 @@ __device__ inline void v2d1_post_line(V2D1 &w, const FrameArgs &a, WaveLds &lds,
         if (crc_valid_ignore_forced(wl)) {
             const uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
             __syncthreads();
-            if (lane_id() == 0) {
-                if (v.n_last == COORD_HISTORY_DEPTH) for (int i = 0; i < COORD_HISTORY_DEPTH - 1; i++) lds.lv_keys[i] = lds.lv_keys[i + 1];
-                lds.lv_keys[v.n_last == COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
+            {   /* the window moves up by one when it is full: every lane carries one entry (no serial chain through LDS) */
+                const int ln = lane_id();
+                const bool full = v.n_last == COORD_HISTORY_DEPTH;
+                const uint32_t moved = (full && ln < COORD_HISTORY_DEPTH - 1) ? lds.lv_keys[ln + 1] : 0u;
+                __syncthreads();
+                if (full && ln < COORD_HISTORY_DEPTH - 1) lds.lv_keys[ln] = moved;
+                if (ln == 0) lds.lv_keys[full ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
             }
             if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
             __syncthreads();
