@@ -299,6 +299,189 @@ __device__ inline void v2d1_post_line(V2D1 &w, const FrameArgs &a, WaveLds &lds,
     v.line_in_field_cnt++;
 }
 
+/* ---- the tape plays: lines that read from what their predecessor left preset ----------------------------------------------------------- */
+#ifndef SDV_P1_BATCH
+#define SDV_P1_BATCH 1              /* runs of lines that read from one tuning take batch1, single ones lean_line1 */
+#endif
+#ifdef SDV_EMU
+__device__ inline uint32_t lane_read32(uint32_t x, uint32_t idx) { return (uint32_t)__shfl((int)x, (int)idx); }
+#else
+__device__ inline uint32_t lane_read32(uint32_t x, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)uniu(idx)); }
+extern "C" __device__ uint32_t sdv_llvm_writelane1(uint32_t val, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+#endif
+__device__ __forceinline__ uint32_t park_lane(uint32_t old, uint32_t val, int lane)
+{
+#ifdef SDV_EMU
+    return lane_id() == lane ? val : old;
+#else
+    return sdv_llvm_writelane1(val, (uint32_t)lane, old);
+#endif
+}
+/* What depends on the tuning only: the pixels a lane samples (cells lane and lane + 64), the levels with their clipping test, the cells
+ * the picture cuts off at either end (pickCutBitsUpPCM1, binarizer.cpp:6116-6596).  Kept while the tuning stays the same. */
+struct Lean1 {
+    uint32_t key_coords, key_levels;
+    uint16_t x0, x1;
+    uint8_t low, high, bits_l, bits_r;
+    bool usable;
+    uint32_t psm, hpsm; int16_t pso;
+};
+__device__ inline void lean1_reset(Lean1 &n) { n.key_levels = 0xFFFFFFFFu; n.key_coords = 0; n.usable = false; }
+__device__ inline bool lean1_prepare(Lean1 &n, const BinCtx &c, const Bin &b)
+{
+    if (c.ps.en_force_coords) return false;
+    if (!(are_bw_levels_preset(b, c.ps) && is_ref_level_preset(b, c.ps) && coords_valid(b.in_coord))) return false;
+    if (!(b.in_ref < b.in_white && b.in_ref > b.in_black)) return false;
+    if (!(c.scan_end > c.scan_start && P1_BITS <= (c.scan_end - c.scan_start))) return false;
+    const uint32_t kc = coords_key(b.in_coord.start, b.in_coord.stop), kl = (uint32_t)b.in_black | ((uint32_t)b.in_white << 8) | ((uint32_t)b.in_ref << 16) | ((uint32_t)(b.in_coord.doubled ? 1 : 0) << 24);
+    if (kc != n.key_coords || kl != n.key_levels) {
+        n.key_coords = kc; n.key_levels = kl;
+        L1 t; p1_clear(t);
+        t.pixel_start = c.scan_start; t.pixel_stop = c.scan_end;
+        t.coords = b.in_coord;
+        set_ppb(t, t.coords);
+        n.psm = t.psm; n.hpsm = t.hpsm; n.pso = t.pso;
+        const int lane = lane_id();
+        n.x0 = (uint16_t)pixel_of(t, lane, 0);
+        n.x1 = (uint16_t)pixel_of(t, lane + 64 < P1_BITS ? lane + 64 : P1_BITS - 1, 0);
+        n.low = get_low_level(b.in_ref, 0); n.high = get_high_level(b.in_ref, 0);
+        n.usable = !(n.low <= b.in_black) && !(n.high >= b.in_white);
+        int max_cut = c.ps.left_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+        int first = c.scan_start, left_bits = 0, right_bits = 0;
+        const int half_ppb = ((int)get_ppb(t) + 1) / 2;
+        for (int i = 0; i < max_cut; i++) { const int cur = pixel_of(t, i, 0); if ((cur - first) >= half_ppb) break; if (i == 0) first = cur; left_bits = i + 1; }
+        first = c.scan_end;
+        max_cut = c.ps.right_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+        for (int i = 0; i < max_cut; i++) { const int cur = pixel_of(t, P1_BITS - 1 - i, 0); if ((first - cur) >= half_ppb) break; if (i == 0) first = cur; right_bits = i + 1; }
+        n.bits_l = (uint8_t)left_bits; n.bits_r = (uint8_t)right_bits;
+    }
+    return n.usable && c.force_bit_picker;
+}
+/* one read of a line under the tuning in n: the cells as two masks (cell b = bit b), the CRC over them; false when the CRC does not match
+ * or the line is a Header */
+__device__ inline bool lean_read1(const Lean1 &n, uint8_t p0, uint8_t p1, uint64_t &s_lo, uint64_t &s_hi, u128 &cells, uint16_t &crc)
+{
+    const int lane = lane_id();
+    const bool second = lane + 64 < P1_BITS;
+    const uint64_t a_lo = __ballot(p0 > n.low), b_lo = __ballot(p0 >= n.high);
+    const uint64_t a_hi = __ballot(second && p1 > n.low), b_hi = __ballot(second && p1 >= n.high);
+    solve_automaton(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+    s_hi &= (1ull << (P1_BITS - 64)) - 1ull;
+    cells = ((u128)__brevll(s_lo) << 30) | (u128)(__brevll(s_hi) >> 34);
+    const uint64_t klo = (lane < 16) ? c_crc1.klo[lane & 15] : 0ull, khi = (lane < 16) ? c_crc1.khi[lane & 15] : 0ull;
+    const int par = (__popcll(s_lo & klo) + __popcll(s_hi & khi)) & 1;
+    crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc1.base);
+    if (crc != (uint16_t)(cells & 0xFFFF)) return false;
+    L1 t; t.v = cells;
+    return !has_header(t);
+}
+__device__ inline void lean_fill_line1(const Lean1 &n, const FrameArgs &a, const Bin &b, u128 cells, uint16_t crc, L1 &out)
+{
+    p1_clear(out);
+    out.pixel_start = 0; out.pixel_stop = (uint16_t)(a.width - 1);
+    out.coords = b.in_coord;
+    out.black = b.in_black; out.white = b.in_white; out.bw_set = true;
+    out.ref_level = b.in_ref; out.ref_low = n.low; out.ref_high = n.high;
+    out.hyst = 0; out.shift = 0;
+    out.psm = n.psm; out.hpsm = n.hpsm; out.pso = n.pso;
+    out.v = cells; out.calc_crc = crc;
+    out.picked_l = n.bits_l; out.picked_r = n.bits_r;
+    out.by_ext_tune = true;
+}
+/* Binarizer::processLine for a line that reads from its presets on the first rung of the ladder: stage STG_INPUT_ALL and nothing else */
+__device__ inline bool lean_line1(Lean1 &n, const BinCtx &c, const FrameArgs &a, const Bin &b, const uint8_t *px_row, L1 &out)
+{
+    if (!lean1_prepare(n, c, b)) return false;
+    uint64_t s_lo, s_hi; u128 cells; uint16_t crc;
+    if (!lean_read1(n, px_row[n.x0], px_row[n.x1], s_lo, s_hi, cells, crc)) return false;
+    lean_fill_line1(n, a, b, cells, crc, out);
+    return true;
+}
+/* A run of up to 64 lines that all read from the same presets (the pattern of batch16, pcm16_frames_device.h): phase A reads them - two
+ * byte gathers per lane straight from the frame, four ballots, the automaton, the CRC - and parks each line's cells in the lane that
+ * owns it; phase B does VideoToDigital's per-line bookkeeping (:1115-1634) a lane per line.  Returns the number of lines taken. */
+__device__ inline int batch1(V2D1 &w, const FrameArgs &a, WaveLds &lds, const Lean1 &n, const uint8_t *frame, int field, int idx, int nl,
+                             uint32_t frame_no, sdv_pcm1_bin_rec *rec, uint32_t *fv_keys, L1 &wl)
+{
+    V2D &v = w.v;
+    const int lane = lane_id();
+    if (v.field_state != FIELD_INIT) return 0;
+    const uint32_t key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
+    if (__ballot(lane < v.n_last && lds.lv_keys[lane < COORD_HISTORY_DEPTH ? lane : 0] != key) != 0ull) return 0;
+    int n_lines = nl - idx; if (n_lines > 64) n_lines = 64;
+    uint32_t m0 = 0, m1 = 0, m2 = 0;
+    int n_ok = 0;
+    for (int l = 0; l < n_lines; l++) {
+        const uint8_t *rowp = frame + (size_t)(2 * (idx + l) + field) * a.row_stride;
+        uint64_t s_lo, s_hi; u128 cells; uint16_t crc;
+        if (!lean_read1(n, rowp[n.x0], rowp[n.x1], s_lo, s_hi, cells, crc)) break;
+        m0 = park_lane(m0, (uint32_t)s_lo, l); m1 = park_lane(m1, (uint32_t)(s_lo >> 32), l); m2 = park_lane(m2, (uint32_t)s_hi, l);
+        n_ok = l + 1;
+    }
+    if (n_ok == 0) return 0;
+    /* phase B: lane j = line j of the run */
+    const uint64_t my_lo = ((uint64_t)m1 << 32) | m0, my_hi = m2;
+    const u128 mine = ((u128)__brevll(my_lo) << 30) | (u128)(__brevll(my_hi) >> 34);
+    L1 t; t.v = mine;
+    uint16_t wd[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) wd[k] = get_word(t, k);
+    if (a.check_line_copy) {
+        const int src = lane >= 1 ? lane - 1 : 0;
+        const uint32_t p0 = (uint32_t)__shfl((int)m0, src), p1 = (uint32_t)__shfl((int)m1, src), p2 = (uint32_t)__shfl((int)m2, src);
+        L1 ab; ab.v = ((u128)__brevll(((uint64_t)p1 << 32) | p0) << 30) | (u128)(__brevll((uint64_t)p2) >> 34);
+        int diff = 0, silent = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint16_t above = lane == 0 ? v.last_words[k] : get_word(ab, k);
+            diff += __popc((uint32_t)(uint8_t)(wd[k] ^ above));
+            const int16_t smp = p1_get_sample(wd[k]);
+            if (!(smp >= 8) && !(smp < -8)) silent++;
+        }
+        const uint64_t dup = __ballot(lane < n_ok && !(silent >= 2) && diff <= (P1_BITS / BIT_DIFF_THRES_DIV));
+        if (dup) { n_ok = __ffsll((unsigned long long)dup) - 1; if (n_ok == 0) return 0; }
+    }
+    const bool even_line = field == 1;
+    const uint8_t ref = v.bin.in_ref;
+    if (lane < n_ok) {
+        sdv_pcm1_bin_rec r;
+        r.frame_number = frame_no; r.line_number = (uint16_t)(field + 1 + 2 * (idx + lane));
+#pragma unroll
+        for (int k = 0; k < 6; k++) r.words[k] = wd[k];
+        r.words[6] = (uint16_t)(mine & 0xFFFF);
+        r.calc_crc = (uint16_t)(mine & 0xFFFF);
+        r.data_start = v.bin.in_coord.start; r.data_stop = v.bin.in_coord.stop;
+        r.black_level = v.bin.in_black; r.white_level = v.bin.in_white; r.ref_low = n.low; r.ref_level = ref; r.ref_high = n.high;
+        r.hysteresis_depth = 0; r.shift_stage = 0; r.service_type = SDV_SRV_NO;
+        r.picked_bits_left = n.bits_l; r.picked_bits_right = n.bits_r;
+        r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | SDV_LF_CRC_VALID | (a.doubled ? SDV_LF_FROM_DOUBLED : 0));
+        r._pad[0] = r._pad[1] = r._pad[2] = 0;
+        rec[lane] = r;
+        fv_keys[v.nfv + lane] = key;
+    }
+    v.good_coords_in_field = (uint16_t)(v.good_coords_in_field + n_ok);
+    v.q_line_length = (uint16_t)a.width;
+    if (!even_line) { v.q_odd = (uint16_t)(v.q_odd + n_ok); v.q_pcm_odd = (uint16_t)(v.q_pcm_odd + n_ok); }
+    else { v.q_even = (uint16_t)(v.q_even + n_ok); v.q_pcm_even = (uint16_t)(v.q_pcm_even + n_ok); }
+    v.pcm_lines_in_field = (uint16_t)(v.pcm_lines_in_field + n_ok);
+    v.line_in_field_cnt = (uint16_t)(v.line_in_field_cnt + n_ok);
+    v.nfv += n_ok;
+    {
+        int fill_to = v.n_last + n_ok; if (fill_to > COORD_HISTORY_DEPTH) fill_to = COORD_HISTORY_DEPTH;
+        __syncthreads();
+        if (lane >= v.n_last && lane < fill_to) lds.lv_keys[lane] = key;
+        __syncthreads();
+        v.n_last = fill_to;
+    }
+    {   /* what the last line leaves behind */
+        const uint64_t l_lo = ((uint64_t)lane_read32(m1, (uint32_t)(n_ok - 1)) << 32) | lane_read32(m0, (uint32_t)(n_ok - 1)), l_hi = lane_read32(m2, (uint32_t)(n_ok - 1));
+        const u128 last = ((u128)__brevll(l_lo) << 30) | (u128)(__brevll(l_hi) >> 34);
+        lean_fill_line1(n, a, v.bin, last, (uint16_t)(last & 0xFFFF), wl);
+        for (int k = 0; k < 6; k++) v.last_words[k] = get_word(wl, k);
+    }
+    return n_ok;
+}
+
 /* one frame */
 __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
 {
@@ -316,6 +499,7 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
     const bool doubled = a.doubled != 0;
 
     v2d1_begin_frame(w, a1, lds.w, f);
+    Lean1 lean; lean1_reset(lean);
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     uint16_t line_num = 0;
     if (f == a.new_file_frame) { v2d1_service_line(w, a, wl, SDV_SRV_NEW_FILE); emit_rec(wl, frame_no, 0, false, rec++); }
@@ -328,13 +512,19 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
                 emit_rec(wl, frame_no, line_num, false, rec++);
                 continue;
             }
-            stage_row(lds.w.px, frame + (size_t)(2 * idx + field) * a.row_stride, a.width);
             BinCtx c;
             ctx_for_line(a, c, v.bin);
+#if SDV_P1_BATCH
+            if (lean1_prepare(lean, c, v.bin)) {
+                const int took = batch1(w, a, lds.w, lean, frame, field, idx, nl, frame_no, rec, fv_keys, wl);
+                if (took > 0) { rec += took; idx += took - 1; continue; }
+            }
+#endif
+            stage_row(lds.w.px, frame + (size_t)(2 * idx + field) * a.row_stride, a.width);
             /* :853-884: the real-time modes stop searching once a field has produced enough good lines */
             bool coord_search = true;
             if (a.mode == SDV_MODE_DRAFT || a.mode == SDV_MODE_FAST) coord_search = !(v.good_coords_in_field > 2 || v.pcm_lines_in_field > 2);
-            process_line_p1(c, v.bin, coord_search, lds, wl, doubled);
+            if (!(SDV_P1_BATCH && lean_line1(lean, c, a, v.bin, lds.w.px, wl))) process_line_p1(c, v.bin, coord_search, lds, wl, doubled);
             v2d1_post_line(w, a, lds.w, wl, fv_keys, fi_keys, (line_num % 2) == 0);
             emit_rec(wl, frame_no, line_num, doubled, rec++);
         }
