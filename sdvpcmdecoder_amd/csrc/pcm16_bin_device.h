@@ -125,20 +125,19 @@ __device__ inline int pixel_of(const L16 &l, int bit, int stage)
 }
 __device__ __forceinline__ int part_start_bit(uint8_t part) { return part == PART_LEFT ? 0 : (part == PART_MIDDLE ? P16_DATA : 2 * P16_DATA + 1); }
 
-/* fillPCM16X0 (binarizer.cpp:7134-7319), one lane on its own: the two-level automaton over the 64 cell centres of the part */
+/* fillPCM16X0 (binarizer.cpp:7134-7319), one lane on its own: the two comparisons of the part's 64 cell centres are collected as masks, the
+ * two-level automaton is solved on them (solve_automaton_lane) */
 __device__ inline void fill_pcm16(L16 &l, const uint8_t *px_row, uint8_t part, int stage)
 {
     const int b0 = part_start_bit(part);
-    bool prev_high = false;
-    uint64_t v = 0;
+    uint64_t a_lo = 0, b_lo = 0;
     for (int i = 0; i < P16_DATA; i++) {
         const uint8_t px = px_row[pixel_of(l, b0 + i, stage)];
-        bool one;
-        if (!prev_high) { one = px > l.ref_low; prev_high = one; }
-        else { one = px >= l.ref_high; prev_high = one; }
-        v = (v << 1) | (uint64_t)(one ? 1 : 0);
+        a_lo |= (uint64_t)(px > l.ref_low ? 1 : 0) << i; b_lo |= (uint64_t)(px >= l.ref_high ? 1 : 0) << i;
     }
-    l.v = v;
+    uint64_t s_lo, s_hi;
+    solve_automaton_lane(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
+    l.v = __brevll(s_lo);
     calc_crc(l);
     l.control_bit = true;
     if (crc_valid(l)) if (px_row[pixel_of(l, 2 * P16_DATA, stage)] < l.ref_level) l.control_bit = false;
@@ -176,24 +175,34 @@ __device__ inline void pick_cut_bits(const BinCtx &c, L16 &l, uint8_t part)
     }
     if (c.force_bit_picker && crc_valid(l)) { if (left) l.picked_l = (uint8_t)bits; else l.picked_r = (uint8_t)bits; return; }
     if (bits == 0) return;
-    const uint64_t orig = l.v;
+    if (l.forced_bad) return;           /* nothing reads valid on a line that is forced bad: the search would put everything back */
+    /* Every value of the cut-off bits; exactly one may give a valid CRC (:6760-6990).  The CRC is linear in the cells: each of the left
+     * part's first cells flips a fixed pattern of CRC bits; the right part's cut-off bits are the low bits of the CRCC as read, so there
+     * at most one value fits. */
     const uint32_t lim = 1u << bits;
-    const int sh = left ? 64 - bits : 0;                    /* where the cut-off bits sit in the cells */
-    const uint64_t clean = orig & ~((uint64_t)(lim - 1) << sh);
-    bool patch_found = false, coll_lock = false;
-    uint64_t fix = 0;
-    for (uint32_t i = 0; i < lim; i++) {
-        l.v = clean | ((uint64_t)i << sh);
-        calc_crc(l);
-        if (crc_valid(l)) {
-            if (patch_found) { coll_lock = true; break; }
-            patch_found = true; fix = (uint64_t)i << sh;
+    if (left) {
+        const int sh = 64 - bits;
+        const uint64_t clean = l.v & ~((uint64_t)(lim - 1) << sh);
+        uint32_t base = 0;
+        for (int j = 0; j < 16; j++) base |= (uint32_t)(__popcll(clean & c_crc16.k[j]) & 1) << j;
+        base ^= c_crc16.base;
+        const uint16_t crcc = (uint16_t)(l.v & 0xFFFF);
+        int found = 0; uint32_t fix = 0; uint16_t crc_fix = 0;
+        for (uint32_t i = 0; i < lim; i++) {
+            uint32_t crc = base;
+            for (int t = 0; t < bits; t++) if ((i >> t) & 1u) { uint32_t col = 0; for (int j = 0; j < 16; j++) col |= (uint32_t)((c_crc16.k[j] >> (sh + t)) & 1ull) << j; crc ^= col; }
+            if ((uint16_t)crc == crcc) { if (found) { found = 2; break; } found = 1; fix = i; crc_fix = (uint16_t)crc; }
         }
+        if (found == 2) { l.forced_bad = true; return; }
+        if (found == 0) return;
+        l.v = clean | ((uint64_t)fix << sh); l.calc_crc = crc_fix;
+        l.picked_l = (uint8_t)bits;
+    } else {
+        const uint16_t mask = (uint16_t)(lim - 1), crcc_clean = (uint16_t)((uint16_t)(l.v & 0xFFFF) & ~mask);
+        if ((uint16_t)(l.calc_crc & ~mask) != crcc_clean) return;       /* the data cells are not touched: calc_crc stands */
+        l.v = (l.v & ~(uint64_t)0xFFFF) | (uint64_t)(uint16_t)(crcc_clean | (l.calc_crc & mask));
+        l.picked_r = (uint8_t)bits;
     }
-    if (coll_lock || !patch_found) { l.v = orig; calc_crc(l); if (coll_lock) l.forced_bad = true; return; }
-    l.v = clean | fix;
-    calc_crc(l);
-    if (left) l.picked_l = (uint8_t)bits; else l.picked_r = (uint8_t)bits;
 }
 
 /* fillDataWords (binarizer.cpp:7560-7670); false = the levels clip (STG_NO_GOOD) */

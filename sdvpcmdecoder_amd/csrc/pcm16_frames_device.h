@@ -390,6 +390,7 @@ __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, cons
     V2D &v = w.v;
     const int lane = lane_id();
     if (v.field_state != FIELD_INIT) return 0;
+    if ((uint8_t)((uint8_t)(n.psm / 128u) * 3) == 0) return 0;         /* in_delta = getPPB() * 3 as uint8_t: at 0 the damper flags a delta of zero */
     const uint32_t key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
     if (__ballot(lane < v.n_last && lds.lv_keys16[lane < LV16 ? lane : 0] != key) != 0ull) return 0;
     int n_lines = nl - idx; if (n_lines > BATCH16_LINES) n_lines = BATCH16_LINES;

@@ -64,24 +64,6 @@ __device__ inline uint16_t get_word(const L1 &l, int k) { return k == 6 ? (uint1
 __device__ inline void set_word0(L1 &l, uint16_t w) { l.v = (l.v & ~word_at(0x1FFF, 0)) | word_at(w, 0); }                       /* PCM1Line::setWord(WORD_L2) */
 __device__ inline void set_crcc(L1 &l, uint16_t w) { l.v = (l.v & ~(u128)0xFFFF) | (u128)w; }                                   /* PCM1Line::setWord(WORD_CRCC) */
 
-/* PCM1Line::calcCRC (pcm1line.cpp:158-171): CRC-16/CCITT over the 78 inverted data cells, result inverted */
-__device__ inline void calc_crc(L1 &l)
-{
-    uint32_t crc = 0xFFFF;
-    uint64_t x = (uint64_t)(l.v >> 30);                 /* cells 0..63, cell 0 on top */
-    for (int i = 0; i < 64; i++) {
-        const uint32_t top = ((crc >> 15) ^ (uint32_t)(~x >> 63)) & 1;
-        crc = ((crc << 1) & 0xFFFF) ^ (top ? 0x1021u : 0u);
-        x <<= 1;
-    }
-    uint32_t y = (uint32_t)(l.v >> 16) & 0x3FFF;        /* cells 64..77 */
-    for (int i = 0; i < 14; i++) {
-        const uint32_t top = ((crc >> 15) ^ (~y >> 13)) & 1;
-        crc = ((crc << 1) & 0xFFFF) ^ (top ? 0x1021u : 0u);
-        y <<= 1;
-    }
-    l.calc_crc = (uint16_t)(~crc & 0xFFFF);
-}
 /* the same CRC as a GF(2)-linear map of the cells (cell b = bit b of lo for b < 64, bit b-64 of hi): parity masks per CRC bit */
 struct Crc1Tables { uint64_t klo[16], khi[16]; uint16_t base; };
 constexpr Crc1Tables make_crc1_tables()
@@ -103,6 +85,26 @@ static const Crc1Tables c_crc1 = make_crc1_tables();
 #else
 __device__ __constant__ const Crc1Tables c_crc1 = make_crc1_tables();
 #endif
+/* PCM1Line::calcCRC (pcm1line.cpp:158-171): CRC-16/CCITT over the 78 inverted data cells, result inverted - computed through the
+ * parity masks above (one lane on its own) */
+__device__ inline void cell_masks(u128 v, uint64_t &s_lo, uint64_t &s_hi)       /* cell b = bit b of s_lo (b < 64) / bit b - 64 of s_hi */
+{
+    s_lo = __brevll((uint64_t)(v >> 30));
+    s_hi = __brevll((uint64_t)(v & (u128)0x3FFFFFFFull) << 34);
+}
+__device__ inline uint16_t crc_of_masks(uint64_t s_lo, uint64_t s_hi)
+{
+    uint32_t crc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) crc |= (uint32_t)((__popcll(s_lo & c_crc1.klo[j]) + __popcll(s_hi & c_crc1.khi[j])) & 1) << j;
+    return (uint16_t)(crc ^ c_crc1.base);
+}
+__device__ inline void calc_crc(L1 &l)
+{
+    uint64_t s_lo, s_hi;
+    cell_masks(l.v, s_lo, s_hi);
+    l.calc_crc = crc_of_masks(s_lo, s_hi);
+}
 __device__ inline bool has_header(const L1 &l)     /* pcm1line.cpp:314-323 */
 {
     const u128 hdr = word_at(0x0666, 0) | word_at(0x0CCC, 1) | word_at(0x1999, 2) | word_at(0x1333, 3) | word_at(0x0666, 4) | word_at(0x0CCC, 5) | (u128)0xCCCC;
@@ -156,20 +158,24 @@ __device__ inline int pixel_of(const L1 &l, int bit, int stage)
     return vp;
 }
 
-/* fillPCM1 (binarizer.cpp:7016-7131): the two-level automaton over the 94 cell centres */
+/* fillPCM1 (binarizer.cpp:7016-7131): the two-level automaton over the 94 cell centres, one lane on its own: the two comparisons of every
+ * cell are collected as masks and the automaton is solved on them (solve_automaton), the CRC comes from the parity masks */
 __device__ inline void fill_pcm1(L1 &l, const uint8_t *px_row, int stage)
 {
-    bool prev_high = false;
-    u128 v = 0;
-    for (int bit = 0; bit < P1_BITS; bit++) {
+    uint64_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+    for (int bit = 0; bit < 64; bit++) {
         const uint8_t px = px_row[pixel_of(l, bit, stage)];
-        bool one;
-        if (!prev_high) { one = px > l.ref_low; prev_high = one; }
-        else { one = px >= l.ref_high; prev_high = one; }
-        v = (v << 1) | (u128)(one ? 1 : 0);
+        a_lo |= (uint64_t)(px > l.ref_low ? 1 : 0) << bit; b_lo |= (uint64_t)(px >= l.ref_high ? 1 : 0) << bit;
     }
-    l.v = v;
-    calc_crc(l);
+    for (int bit = 64; bit < P1_BITS; bit++) {
+        const uint8_t px = px_row[pixel_of(l, bit, stage)];
+        a_hi |= (uint64_t)(px > l.ref_low ? 1 : 0) << (bit - 64); b_hi |= (uint64_t)(px >= l.ref_high ? 1 : 0) << (bit - 64);
+    }
+    uint64_t s_lo, s_hi;
+    solve_automaton_lane(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+    s_hi &= (1ull << (P1_BITS - 64)) - 1ull;
+    l.v = ((u128)__brevll(s_lo) << 30) | (u128)(__brevll(s_hi) >> 34);
+    l.calc_crc = crc_of_masks(s_lo, s_hi);
 }
 
 /* the same for the whole wave (wave-uniform callers only): lane i samples cells i and i+64, the automaton is solved on the ballots
@@ -194,31 +200,11 @@ __device__ inline void fill_pcm1_wave(L1 &l, const uint8_t *px_row, int stage)
 
 struct BinCtx { sdv_bin_preset ps; uint8_t mode; uint16_t scan_start, scan_end; bool force_bit_picker; };
 
-/* pickCutBitsUpPCM1 (binarizer.cpp:6116-6596) */
-__device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
+/* the Bit Picker's search as the reference runs it (binarizer.cpp:6418-6583): every combination of the cut-off bits in turn.  Only taken
+ * when a Header line is among the combinations (its words are valid whatever the CRC says); pick_cut_bits below does the rest by linearity */
+__device__ inline void pick_cut_bits_by_trial(L1 &l, int left_bits, int right_bits)
 {
     bool patch_found = false, coll_lock = false;
-    int left_bits = 0, right_bits = 0;
-    l.picked_l = l.picked_r = 0;
-    int max_cut = c.ps.left_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
-    int first = c.scan_start;
-    const int half_ppb = ((int)get_ppb(l) + 1) / 2;
-    for (int i = 0; i < max_cut; i++) {
-        const int cur = pixel_of(l, i, 0);
-        if ((cur - first) >= half_ppb) break;
-        if (i == 0) first = cur;
-        left_bits = i + 1;
-    }
-    first = c.scan_end;
-    max_cut = c.ps.right_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
-    for (int i = 0; i < max_cut; i++) {
-        const int cur = pixel_of(l, P1_BITS - 1 - i, 0);
-        if ((first - cur) >= half_ppb) break;
-        if (i == 0) first = cur;
-        right_bits = i + 1;
-    }
-    if (c.force_bit_picker && crc_valid(l)) { l.picked_l = (uint8_t)left_bits; l.picked_r = (uint8_t)right_bits; return; }
-    if (left_bits == 0 && right_bits == 0) return;
     const uint32_t left_lim = left_bits ? (1u << left_bits) : 1u, right_lim = right_bits ? (1u << right_bits) : 1u;
     const uint16_t left_orig = get_word(l, 0), right_orig = get_word(l, 6);
     const uint16_t left_clean = left_bits ? (uint16_t)(left_orig & (uint16_t)~((left_lim - 1) << (P1_WORD_BITS - left_bits))) : left_orig;
@@ -248,6 +234,61 @@ __device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
     if (left_bits) set_word0(l, (uint16_t)(left_clean | left_fix));
     if (right_bits) set_crcc(l, (uint16_t)(right_clean | right_fix));
     calc_crc(l);
+    l.picked_l = (uint8_t)left_bits; l.picked_r = (uint8_t)right_bits;
+}
+
+/* pickCutBitsUpPCM1 (binarizer.cpp:6116-6596) */
+__device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
+{
+    int left_bits = 0, right_bits = 0;
+    l.picked_l = l.picked_r = 0;
+    int max_cut = c.ps.left_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+    int first = c.scan_start;
+    const int half_ppb = ((int)get_ppb(l) + 1) / 2;
+    for (int i = 0; i < max_cut; i++) {
+        const int cur = pixel_of(l, i, 0);
+        if ((cur - first) >= half_ppb) break;
+        if (i == 0) first = cur;
+        left_bits = i + 1;
+    }
+    first = c.scan_end;
+    max_cut = c.ps.right_bit_pick; if (c.mode == SDV_MODE_DRAFT) max_cut /= 2;
+    for (int i = 0; i < max_cut; i++) {
+        const int cur = pixel_of(l, P1_BITS - 1 - i, 0);
+        if ((first - cur) >= half_ppb) break;
+        if (i == 0) first = cur;
+        right_bits = i + 1;
+    }
+    if (c.force_bit_picker && crc_valid(l)) { l.picked_l = (uint8_t)left_bits; l.picked_r = (uint8_t)right_bits; return; }
+    if (left_bits == 0 && right_bits == 0) return;
+    if (l.forced_bad) return;           /* nothing reads valid on a line that is forced bad: the search would put everything back */
+    /* Every value of the cut-off bits; exactly one may give a valid CRC (:6418-6583).  The CRC is linear in the cells: the left bits
+     * (the first cells of the line) each flip a fixed pattern of CRC bits, the right bits are the low bits of the CRCC as read - so a
+     * left value fits iff the CRC it gives agrees with the CRCC outside the cut-off bits, and then with exactly one right value. */
+    const u128 hdr = word_at(0x0666, 0) | word_at(0x0CCC, 1) | word_at(0x1999, 2) | word_at(0x1333, 3) | word_at(0x0666, 4) | word_at(0x0CCC, 5) | (u128)0xCCCC;
+    const u128 cut = (left_bits ? (((u128)((1u << left_bits) - 1)) << (P1_BITS - left_bits)) : (u128)0) | (u128)(right_bits ? ((1u << right_bits) - 1) : 0);
+    if (((l.v ^ hdr) & ~cut) == 0) { pick_cut_bits_by_trial(l, left_bits, right_bits); return; }      /* a Header in reach: valid whatever its CRC */
+    const uint16_t right_orig = get_word(l, 6), right_mask = right_bits ? (uint16_t)((1u << right_bits) - 1) : 0, right_clean = (uint16_t)(right_orig & ~right_mask);
+    const u128 data_clean = l.v & ~(cut & ~(u128)0xFFFF);
+    uint64_t s_lo, s_hi;
+    cell_masks(data_clean, s_lo, s_hi);
+    const uint16_t base = crc_of_masks(s_lo, s_hi);
+    uint16_t col[4] = { 0, 0, 0, 0 };       /* what cell i of the line flips in the CRC */
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (i < left_bits) { uint32_t x = 0; for (int j = 0; j < 16; j++) x |= (uint32_t)((c_crc1.klo[j] >> i) & 1ull) << j; col[i] = (uint16_t)x; }
+    const uint32_t left_lim = left_bits ? (1u << left_bits) : 1u;
+    int found = 0; uint32_t li_fix = 0; uint16_t crc_fix = 0;
+    for (uint32_t li = 0; li < left_lim; li++) {
+        uint16_t crc = base;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i < left_bits && ((li >> (left_bits - 1 - i)) & 1u)) crc ^= col[i];       /* the top bit of the value is the first cell */
+        if ((uint16_t)(crc & ~right_mask) == right_clean) { if (found) { found = 2; break; } found = 1; li_fix = li; crc_fix = crc; }
+    }
+    if (found == 2) { l.forced_bad = true; return; }        /* two values fit: the line is put back as it was and marked */
+    if (found == 0) return;
+    l.v = data_clean | (left_bits ? ((u128)li_fix << (P1_BITS - left_bits)) : (u128)0);
+    set_crcc(l, (uint16_t)(right_clean | (crc_fix & right_mask)));
+    l.calc_crc = crc_fix;
     l.picked_l = (uint8_t)left_bits; l.picked_r = (uint8_t)right_bits;
 }
 

@@ -397,6 +397,18 @@ __device__ inline void solve_automaton(uint64_t a_lo, uint64_t a_hi, uint64_t b_
     s_lo = d_lo ^ pt_lo;
     s_hi = d_hi ^ pt_hi;
 }
+/* the same for one LANE on its own masks (no collectives): the prefix parity by doubling shifts */
+__device__ __forceinline__ uint64_t prefix_xor64(uint64_t x) { x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32; return x; }
+__device__ inline void solve_automaton_lane(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, uint64_t &s_lo, uint64_t &s_hi)
+{
+    const uint64_t e_lo = ~(a_lo ^ b_lo), e_hi = ~(a_hi ^ b_hi), t_lo = a_lo & ~b_lo, t_hi = a_hi & ~b_hi;
+    const uint64_t pt_lo = prefix_xor64(t_lo), pt_hi = prefix_xor64(t_hi) ^ ((__popcll(t_lo) & 1) ? ~0ull : 0ull);
+    const uint64_t u_lo = ((a_lo & b_lo) ^ pt_lo) & e_lo, u_hi = ((a_hi & b_hi) ^ pt_hi) & e_hi;
+    const uint64_t x_lo = u_lo | ~e_lo, x_hi = u_hi | ~e_hi;
+    const uint64_t y_lo = x_lo + u_lo, y_hi = x_hi + u_hi + ((y_lo < x_lo) ? 1ull : 0ull);
+    s_lo = (((y_lo ^ x_lo) & ~e_lo) | u_lo) ^ pt_lo;
+    s_hi = (((y_hi ^ x_hi) & ~e_hi) | u_hi) ^ pt_hi;
+}
 
 __device__ __forceinline__ uint16_t rev14(uint32_t v) { return (uint16_t)(__brev(v) >> 18); }
 __device__ __forceinline__ uint16_t rev16(uint32_t v) { return (uint16_t)(__brev(v) >> 16); }
@@ -1939,7 +1951,6 @@ __device__ __forceinline__ void capture_park(CaptureRaw &r, uint64_t a_lo, uint6
     r.b0 = write_lane(r.b0, (uint32_t)b_lo, j); r.b1 = write_lane(r.b1, (uint32_t)(b_lo >> 32), j);
     r.b2 = write_lane(r.b2, (uint32_t)b_hi, j); r.b3 = write_lane(r.b3, (uint32_t)(b_hi >> 32), j);
 }
-__device__ __forceinline__ uint64_t prefix_xor64(uint64_t x) { x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32; return x; }
 /* solve_automaton + the CRC of fill_stc007 for one line per LANE (every lane its own masks): returns the cells and whether the line
  * reads (CRC as read == CRC calculated, and not the start of a Control Block) */
 __device__ inline bool capture_solve(const CaptureRaw &r, BatchLaneOut &o)

@@ -100,7 +100,7 @@ def run_engine(lib, eng, luma, mode, st, first_frame_no=1, configure=True):
     if configure:
         lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
         lib.sdv_set_mode(eng, mode)
-        lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.c_void_p]
+        lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.POINTER(libs.BinPreset)]
         lib.sdv_set_bin_preset(eng, C.byref(_preset(st)))
         lib.sdv_set_check_line_dup.argtypes = [C.c_void_p, C.c_int]
         lib.sdv_set_check_line_dup(eng, st.get("check_line_dup", 1))

@@ -126,7 +126,7 @@ def run_engine_lines(lib, eng, luma, states=None, mode=1, coord_search=True, pre
                   C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_set_mode(eng, mode)
-    lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.POINTER(libs.BinPreset)]
     p = preset if preset is not None else libs.default_preset()
     lib.sdv_set_bin_preset(eng, C.byref(p))
     luma = np.ascontiguousarray(luma)

@@ -61,16 +61,12 @@ def test_clean_frames_decode_to_what_was_rendered(oracle_lib):
 
 
 # ---- the kernels on the emulator -----------------------------------------------------------------------------------
-class _RunInfo(__import__("ctypes").Structure):
-    import ctypes as _C
-    _fields_ = [("frames", _C.c_uint32), ("rounds", _C.c_uint32), ("frames_launched", _C.c_uint32), ("frames_general", _C.c_uint32),
-                ("kernel_ms", _C.c_float), ("_p", _C.c_float)]
-
-
 def _info(lib, eng):
+    """sdv_get_run_info through the shared binding (one argtypes declaration per library: engine_api.bind)."""
     import ctypes as C
-    lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(_RunInfo)]
-    i = _RunInfo()
+    import engine_api
+    lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(engine_api.RunInfo)]
+    i = engine_api.RunInfo()
     lib.sdv_get_run_info(eng, C.byref(i))
     return i
 
