@@ -300,6 +300,14 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
                       | ((uint32_t)((t.forced_bad && !entry_forced) ? 1 : 0) << 25) | ((uint32_t)(picked ? 1 : 0) << 26);
     }
     __syncthreads();
+    /* rows of the grid in which something happens: a read that is valid, or a Bit Picker collision (the walk below leaves every other row
+     * as it finds it, apart from noting its last read) */
+    uint64_t rows_live;
+    {
+        bool live = false;
+        if (lane < nl) for (int i = 0; i < nr * P16_SUBLINES; i++) live = live || ((lds.grid[lane * nr * P16_SUBLINES + i] >> 24) & 3u) != 0;
+        rows_live = __ballot(live);
+    }
     /* the walk over the grid and the votes: serial, on lane 0 */
     if (lane == 0) {
         SweepEnt *sw = lds.w.sweep;
@@ -309,6 +317,7 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
         stats_reset(lds.lstats, MAX_COLL_CRCS);
         for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[SW_LEFT + i] = sweep_blank();
         for (int row = 0; row < nl; row++) {
+            if (forced || !((rows_live >> row) & 1ull)) { last_read = (row * nr + nr - 1) * P16_SUBLINES + 2; continue; }      /* nothing reads in this row: it changes nothing */
             uint8_t valid_right = 0, valid_p[3] = { 0, 0, 0 }, right_ofs = 0xFF;
             for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) { sw[SW_P0 + i] = sw[SW_P1 + i] = sw[SW_P2 + i] = sw[SW_RIGHT + i] = sweep_blank(); }
             stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);

@@ -398,12 +398,24 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
     }
     first_coll = wave_min_u32(first_coll);
     __syncthreads();
+    /* rows of the grid with a read that is valid (behind the first collision nothing is) */
+    uint64_t rows_live;
+    {
+        bool live = false;
+        if (lane < nl) for (int i = 0; i < nr; i++) { const int q = lane * nr + i; live = live || (((lds.grid[q] >> 24) & 1u) != 0 && (uint32_t)q < first_coll); }
+        rows_live = __ballot(live);
+    }
     /* the vote: serial, on lane 0 */
     if (lane == 0) {
         uint8_t valid_left = 0, left_ofs = 0xFF;
         stats_reset(lds.lstats, MAX_COLL_CRCS);
         for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) lds.w.sweep[P1_LEFT_BASE + i] = sweep_blank();
         for (int row = 0; row < nl; row++) {
+            if (!((rows_live >> row) & 1ull)) {      /* nothing reads in this row: its entry in the left sweep is the "bad" one */
+                SweepEnt le = sweep_blank(); le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX;
+                lds.w.sweep[P1_LEFT_BASE + row] = le;
+                continue;
+            }
             uint8_t valid_right = 0, right_ofs = 0xFF;
             for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) lds.w.sweep[i] = sweep_blank();
             stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
