@@ -7,6 +7,9 @@
  *       (the VideoToDigital worker's body) -> sdv_stitch_frames (the STC007DataStitcher worker's body) -> PCMSamplePair records
  *   decode_tape pcm1 <lines.raw> <pairs.out> <frames.out>
  *       sdv_pcm1_line_rec records (the PCM1DataStitcher worker's input deque) -> sdv_pcm1_stitch_frames
+ *   decode_tape pcm16x0 <luma.raw> <width> <height> <n_frames> <si|ei> <pairs.out> <frames.out>
+ *       8-bit luma frames of a PCM-1600/1610/1630 tape -> sdv_pcm16x0_binarize_frames (VideoToDigital with TYPE_PCM16X0) ->
+ *       sdv_pcm16x0_stitch_frames (the PCM16X0DataStitcher worker's body); the sub-line records never leave the device
  *
  * Build (host code only, any C++ compiler): g++ -std=c++17 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/decode_tape.cpp
  *        -Lsdvpcmdecoder_amd -lsdvpcm_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../sdvpcmdecoder_amd' (build.py: build_example).
@@ -97,6 +100,33 @@ int main(int argc, char **argv)
         rc = download(d_pairs, n_pairs, argv[3]); if (!rc) rc = download(d_frames, n_frames, argv[4]);
         printf("pcm1: %zu line records -> %zu sample pairs, %zu frame descriptors\n", n_lines, n_pairs, n_frames);
         (void)hipFree(d_lines); (void)hipFree(d_frames);
+    } else if (mode == "pcm16x0" && argc == 9) {
+        const int width = atoi(argv[3]), height = atoi(argv[4]), n = atoi(argv[5]);
+        const bool ei = std::string(argv[6]) == "ei";
+        if (!read_file(argv[2], in) || in.size() != (size_t)width * height * n) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
+        uint8_t *d_luma = NULL; sdv_pcm16x0_bin_rec *d_lines = NULL; sdv_frame_stats *d_stats = NULL; sdv_frame_asm_pcm16x0 *d_frames = NULL;
+        const unsigned flags = SDV_FLAG_NEW_FILE | SDV_FLAG_END_FILE;
+        const size_t n_lines = sdv_pcm16x0_binarize_records(height, n, flags);
+        const size_t pairs_cap = (size_t)(n + 1) * 1470 + 16, frames_cap = (size_t)n + 16;
+        HIP_OK(hipMalloc((void **)&d_luma, in.size()));
+        HIP_OK(hipMalloc((void **)&d_lines, n_lines * sizeof(sdv_pcm16x0_bin_rec)));
+        HIP_OK(hipMalloc((void **)&d_stats, ((size_t)n + 1) * sizeof(sdv_frame_stats)));
+        HIP_OK(hipMalloc((void **)&d_pairs, pairs_cap * sizeof(sdv_sample_pair)));
+        HIP_OK(hipMalloc((void **)&d_frames, frames_cap * sizeof(sdv_frame_asm_pcm16x0)));
+        HIP_OK(hipMemcpy(d_luma, in.data(), in.size(), hipMemcpyHostToDevice));
+        SDV_OKAY(sdv_set_pcm_type(eng, SDV_PCM_PCM16X0, 0));
+        SDV_OKAY(sdv_set_mode(eng, SDV_MODE_NORMAL));
+        SDV_OKAY(sdv_pcm16x0_binarize_frames(eng, d_luma, (size_t)width, (size_t)width * height, width, height, n, 1, flags, d_lines, n_lines,
+                                             d_stats, (size_t)n + 1, NULL));
+        sdv_pcm16x0_stitch_settings st; sdv_default_pcm16x0_stitch_settings(&st);
+        st.format = ei ? SDV_P16_FORMAT_EI : SDV_P16_FORMAT_SI;
+        SDV_OKAY(sdv_set_pcm16x0_stitch_settings(eng, &st));
+        SDV_OKAY(sdv_pcm16x0_stitch_frames(eng, d_lines, n_lines, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_frames, NULL));
+        HIP_OK(hipDeviceSynchronize());
+        rc = download(d_pairs, n_pairs, argv[7]); if (!rc) rc = download(d_frames, n_frames, argv[8]);
+        sdv_run_info info; sdv_get_run_info(eng, &info);
+        printf("pcm16x0 (%s): %d frames -> %zu sub-line records -> %zu sample pairs, %zu frame descriptors (binarize rounds %u)\n", ei ? "EI" : "SI", n, n_lines, n_pairs, n_frames, info.rounds);
+        (void)hipFree(d_luma); (void)hipFree(d_lines); (void)hipFree(d_stats); (void)hipFree(d_frames);
     } else { fprintf(stderr, "usage: see the header of examples/decode_tape.cpp\n"); rc = 1; }
     if (d_pairs) (void)hipFree(d_pairs);
     sdv_engine_destroy(eng);

@@ -33,3 +33,25 @@ if __name__ == "__main__":
         np.savez_compressed(path, input_sha256=hashlib.sha256(recs.tobytes()).hexdigest(), settings=np.frombuffer(bytes(st), dtype=np.uint8),
                             pairs=pairs.view(np.uint8).reshape(len(pairs), 12), frames=frames.view(np.uint8).reshape(len(frames), 56))
         print(f"{name}: {len(recs)} records -> {len(pairs)} sample pairs, {len(frames)} frames, {os.path.getsize(path)} bytes")
+
+# the whole PCM-16x0 path - video through the real VideoToDigital worker (TYPE_PCM16X0), its sub-lines through the real
+# PCM16X0DataStitcher - for one file from NEW_FILE to END_FILE in either interleave format: e2e_pcm16x0_<si|ei>.npz holds what the
+# luma (regenerated from the seed by the test) has to decode to
+def make_e2e_luma(ei):
+    from sdvpcmdecoder_amd import synth
+    luma, audio, _ = synth.pcm16x0_tape_frames(5, seed=61 + int(ei), ei=ei, noise_sigma=4.0)
+    return luma, audio
+
+
+if __name__ == "__main__":
+    import pcm16_frames_api as fa
+    for ei in (False, True):
+        luma, audio = make_e2e_luma(ei)
+        recs, stats = fa.run_cpu(ref, "ref_", luma, 2, dict(new_file=True, end_file=True))
+        st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+        pairs, frames = p16.run_cpu(ref, "ref_", recs, st)
+        path = os.path.join(HERE, "e2e_pcm16x0_%s.npz" % ("ei" if ei else "si"))
+        np.savez_compressed(path, luma_sha256=hashlib.sha256(luma.tobytes()).hexdigest(), recs_sha256=hashlib.sha256(recs.tobytes()).hexdigest(),
+                            pairs=pairs.view(np.uint8).reshape(len(pairs), 12), frames=frames.view(np.uint8).reshape(len(frames), 56))
+        print(f"e2e {'EI' if ei else 'SI'}: {len(recs)} records -> {len(pairs)} pairs, {len(frames)} frames, audio recovered:",
+              bool((pairs['audio_word'][pairs['service_type'] == 0] == audio).all()), os.path.getsize(path), "bytes")

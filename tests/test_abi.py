@@ -106,3 +106,23 @@ def test_cpp_host_program_pcm1_matches_reference_golden(tmp_path):
     assert out.returncode == 0, out.stderr + out.stdout
     assert (tmp_path / "pairs.out").read_bytes() == np.ascontiguousarray(z["pairs"]).tobytes()
     assert (tmp_path / "frames.out").read_bytes() == np.ascontiguousarray(z["frames"]).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["si", "ei"])
+def test_cpp_host_program_pcm16x0_matches_reference_golden(fmt, tmp_path):
+    """decode_tape pcm16x0: luma file -> sdv_pcm16x0_binarize_frames(NEW_FILE | END_FILE) -> sdv_pcm16x0_stitch_frames from plain C++;
+    compared with the real reference's two workers on the same file (tests/golden/e2e_pcm16x0_*.npz)."""
+    import subprocess
+    import numpy as np
+    from sdvpcmdecoder_amd import build as b
+    import test_pcm16 as t16
+    exe = b.build_example()
+    luma, audio, z, want_p, want_f = t16._e2e_fixture(fmt == "ei")
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    out = subprocess.run([exe, "pcm16x0", str(tmp_path / "luma.raw"), str(w), str(h), str(n), fmt, str(tmp_path / "pairs.out"), str(tmp_path / "frames.out")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert (tmp_path / "pairs.out").read_bytes() == want_p.tobytes()
+    assert (tmp_path / "frames.out").read_bytes() == want_f.tobytes()

@@ -362,3 +362,53 @@ def test_gpu_video_to_audio(ei):
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
     assert (frames["flags"] & p16.FA16_PADDING_OK).all() and (frames["odd_sample_rate"] == 44100).all()
     assert (pairs["audio_word"] == audio).all() and ((pairs["sample_flags"] & 3) == 3).all()
+
+
+# ---- one file through both halves, against the real reference's two workers --------------------------------------------
+def _e2e_fixture(ei):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_pcm16", os.path.join(GOLD, "make_golden_pcm16.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    z = np.load(os.path.join(GOLD, "e2e_pcm16x0_%s.npz" % ("ei" if ei else "si")))
+    luma, audio = mg.make_e2e_luma(ei)
+    assert hashlib.sha256(luma.tobytes()).hexdigest() == str(z["luma_sha256"]), "regenerated video differs from the fixture's"
+    want_p = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    want_f = np.ascontiguousarray(z["frames"]).view(p16.FRASM16_DTYPE).reshape(-1)
+    return luma, audio, z, want_p, want_f
+
+
+@pytest.mark.parametrize("ei", [False, True])
+def test_oracle_whole_file_matches_reference_golden(ei, oracle_lib):
+    """video -> oracle VideoToDigital (TYPE_PCM16X0, NEW_FILE .. filler frame + END_FILE) -> oracle stitcher == both real reference workers,
+    and the audio the tape was made from"""
+    import pcm16_frames_api as fa
+    luma, audio, z, want_p, want_f = _e2e_fixture(ei)
+    recs, _ = fa.run_cpu(oracle_lib, "orc_", luma, 2, dict(new_file=True, end_file=True))
+    assert hashlib.sha256(recs.tobytes()).hexdigest() == str(z["recs_sha256"])
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    pairs, frames = p16.run_cpu(oracle_lib, "orc_", recs, st)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+    assert (pairs["service_type"] == 1).sum() == 1 and pairs["service_type"][-1] == 2
+    assert (pairs["audio_word"][pairs["service_type"] == 0] == audio).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ei", [False, True])
+def test_gpu_whole_file_matches_reference_golden(ei):
+    """The drop-in path end to end on the GPU: sdv_pcm16x0_binarize_frames(NEW_FILE | END_FILE) -> sdv_pcm16x0_stitch_frames, device buffers
+    handed from one stage to the next, against the output of the real reference's two workers."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, Pcm16x0StitchSettings
+    luma, audio, z, want_p, want_f = _e2e_fixture(ei)
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    eng = Engine(0)
+    eng.setPCMType(1)
+    eng.setBinarizationMode(2)
+    eng.set_pcm16x0_stitch_settings(Pcm16x0StitchSettings.from_buffer_copy(bytes(st)))
+    lines, _ = eng.pcm16x0_binarize_frames(torch.from_numpy(luma).cuda(), new_file=True, end_file=True)
+    assert hashlib.sha256(lines.cpu().numpy().tobytes()).hexdigest() == str(z["recs_sha256"])
+    p, f = eng.pcm16x0_stitch_frames(lines)
+    pairs = p.cpu().numpy().reshape(-1).view(PAIR_DTYPE)
+    frames = f.cpu().numpy().reshape(-1).view(p16.FRASM16_DTYPE)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
