@@ -94,7 +94,11 @@ typedef struct sdv_bin_preset {
 /* Preset incoming "good parameters" of a Binarizer (Binarizer::setGoodParameters, binarizer.cpp:353-377):
  * all-zero = nothing preset. */
 typedef struct sdv_bin_state {
-    uint8_t in_def_black, in_def_white, in_def_reference, _pad;
+    uint8_t in_def_black, in_def_white, in_def_reference;
+    uint8_t do_ref_lvl_sweep;               /* Binarizer::do_ref_lvl_sweep as the previous line left it (sticky, binarizer.cpp:1104-1128): read by
+                                             * the level detection of the next line (:3409).  Only the per-line entries take it from here (for
+                                             * PCM-1 it is set by a line that is not SDV_LF_BY_EXT_TUNE and has SDV_LF_BW_SET, to "the mode is
+                                             * MODE_INSANE"); inside sdv_v2d_state the flag has its own field and this byte is 0 */
     int16_t in_def_start, in_def_stop;      /* CoordinatePair::NO_COORD_LEFT/RIGHT when unset */
     uint8_t in_def_from_doubled, _pad2;
 } sdv_bin_state;
@@ -389,7 +393,8 @@ typedef struct sdv_pcm1_bin_rec {
  * setDataCoordinates / setBWLevels, binarizer.cpp:240-377; all zero or presets == NULL: nothing preset); mode and fine settings are
  * the engine's (sdv_set_mode, sdv_set_bin_preset), coord_search is Binarizer::setCoordinatesSearch; flags: SDV_FLAG_DOUBLED.
  * Service lines and empty lines carry no pixels and are the caller's to pass through.  Returns SDV_ERR_SHORT_LINE for lines
- * under 94 px (LB_RET_SHORT_LINE), SDV_ERR_BAD_ARG when out_lines (lines_cap records) cannot take n_lines, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE (the reference level sweep of PCM-1 is not built).
+ * under 94 px (LB_RET_SHORT_LINE), SDV_ERR_BAD_ARG when out_lines (lines_cap records) cannot take n_lines.  SDV_MODE_INSANE adds the reference level sweep
+ * (sweepRefLevel / calcRefLevelBySweep, binarizer.cpp:3551-4120) to every line that does not read from its presets: a coordinate search per level.
  * Device pointers; asynchronous on `stream`. */
 int sdv_pcm1_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_stride, int width, size_t n_lines,
                             const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
@@ -422,7 +427,7 @@ typedef struct sdv_pcm16x0_bin_rec {
  * (:1168-1180), duplicate-line detection per part, coordinate damper and frame statistics.  out_lines takes
  * sdv_pcm16x0_binarize_records(height, n_frames, flags) records: three per video line, one per service line - what the worker pushes
  * into the deque<PCM16X0SubLine> that PCM16X0DataStitcher reads.  Everything else as for sdv_binarize_frames; SDV_ERR_SHORT_LINE under
- * 193 px, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE. */
+ * 193 px.  SDV_MODE_INSANE: the reference level sweep for every pass that does not read from what was handed on (binarizer.cpp:1113-1120). */
 size_t sdv_pcm16x0_binarize_records(int height, int n_frames, unsigned flags);
 int sdv_pcm16x0_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
                                 int n_frames, uint32_t first_frame_no, unsigned flags,
@@ -433,7 +438,8 @@ int sdv_pcm16x0_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_s
  * what the lines before it left preset, the coordinate-search switch of the real-time modes (:853-884), Header lines, duplicate-line
  * detection, coordinate damper and frame statistics.  Arguments, record order (one sdv_pcm1_bin_rec per video line and service line),
  * flags, capacities, stream state (sdv_reset_stream / sdv_get_chain_state / sdv_set_chain_state) and error codes as for
- * sdv_binarize_frames; SDV_ERR_SHORT_LINE under 94 px, SDV_ERR_UNSUPPORTED in SDV_MODE_INSANE.  out_lines is what the worker pushes
+ * sdv_binarize_frames; SDV_ERR_SHORT_LINE under 94 px.  SDV_MODE_INSANE: the reference level sweep for every line that does not read
+ * from what was handed on (binarizer.cpp:1105-1112).  out_lines is what the worker pushes
  * into the deque<PCM1Line> that PCM1DataStitcher reads. */
 int sdv_pcm1_binarize_frames(sdv_engine *e, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
                              int n_frames, uint32_t first_frame_no, unsigned flags,

@@ -128,7 +128,8 @@ void orc_bin1_set_coord_search(void *h, int on) { ((orc_bin1_handle *)h)->bin.do
 void orc_bin1_set_preset(void *hh, const sdv_bin_preset *p) { orc_bin_set_preset(hh, p); }      /* the binarizer is the first member of both handles */
 void orc_bin1_reset_good(void *h) { orc_binarizer_set_good_parameters_p1(&((orc_bin1_handle *)h)->bin, NULL); }
 void orc_bin1_set_good_from_last(void *hh) { orc_bin1_handle *h = (orc_bin1_handle *)hh; orc_binarizer_set_good_parameters_p1(&h->bin, &h->out); }
-void orc_bin1_set_state(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); }
+/* the flag has no setter in the reference (the member stays as the last line left it); the per-line entry of the engine takes it from the state */
+void orc_bin1_set_state(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); ((orc_bin1_handle *)hh)->bin.do_ref_lvl_sweep = s->do_ref_lvl_sweep != 0; }
 int orc_bin1_scan_done(void *h) { return ((orc_bin1_handle *)h)->bin.p1_scan_done ? 1 : 0; }
 int orc_bin1_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16_t line, int service, int doubled, int empty,
                      sdv_pcm1_bin_rec *out)
@@ -183,7 +184,7 @@ void orc_bin16_set_coord_search(void *h, int on) { ((orc_bin16_handle *)h)->bin.
 void orc_bin16_set_preset(void *hh, const sdv_bin_preset *p) { orc_bin_set_preset(hh, p); }
 void orc_bin16_reset_good(void *h) { orc_binarizer_set_good_parameters_p16(&((orc_bin16_handle *)h)->bin, NULL); }
 void orc_bin16_set_good_from_last(void *hh) { orc_bin16_handle *h = (orc_bin16_handle *)hh; orc_binarizer_set_good_parameters_p16(&h->bin, &h->out); }
-void orc_bin16_set_state(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); }
+void orc_bin16_set_state(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); ((orc_bin16_handle *)hh)->bin.do_ref_lvl_sweep = s->do_ref_lvl_sweep != 0; }
 int orc_bin16_scan_done(void *h) { return ((orc_bin16_handle *)h)->vl.scan_done ? 1 : 0; }
 /* one pass over a video line: part = Binarizer::PART_PCM16X0_LEFT / _MIDDLE / _RIGHT (1 / 2 / 3; 0 = FULL_LINE); new_line: the
  * VideoLine is a fresh one (scan_done cleared), else the same line as in the pass before */

@@ -10,6 +10,8 @@ void find_most_frequent_crc(orc_crc_handler *a, uint8_t *valid_cnt, bool skip_eq
 void invalidate_non_frequent_crcs(orc_crc_handler *a, uint8_t low_level, uint8_t high_level, uint8_t valid_cnt, uint16_t target_crc);
 uint8_t pick_level_by_crc_stats(const orc_crc_handler *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
                                 uint8_t target_result, uint8_t max_hyst, uint8_t max_shift);
+uint8_t pick_level_by_crc_stats_opt(const orc_binarizer *b, const orc_crc_handler *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+                                    uint8_t target_result, uint8_t max_hyst, uint8_t max_shift);
 uint16_t most_frequent_brightness_count(const uint16_t *s);
 uint8_t usefull_low_level(const orc_binarizer *b, const uint16_t *s);
 uint8_t usefull_high_level(const orc_binarizer *b, const uint16_t *s);

@@ -565,6 +565,109 @@ static bool find_pcm1_coordinates(orc_binarizer *b, orc_p1_line *l, orc_coords c
     return search_state;
 }
 
+/* ------------------------------------------------------------------ reference level sweep (MODE_INSANE only for this format, :1105-1112) */
+/* Binarizer::sweepRefLevel (:3551-3817) with a PCM1Line as the trial line.  The first-try read from the preset coordinates never
+ * runs for this format (skip_bin stays false, :3647-3679): every level runs the whole coordinate search.  clear() through the
+ * PCMLine pointer is the base clear() (it is not virtual): words and picked bits of the trial line persist from level to level. */
+static void sweep_ref_level_p1(orc_binarizer *b, orc_p1_line *pcm_line, orc_crc_handler *crc_res)
+{
+    uint8_t low_lvl, high_lvl, read_result;
+    uint16_t ref_index;
+    orc_p1_line t;
+    orc_coords forced_coords;
+
+    orc_p1_clear(&t);                       /* PCM1Line temp_pcm1 (constructor) */
+    calc_forced_coords(b, &forced_coords);
+    low_lvl = (uint8_t)(pcm_line->black_level + 1); high_lvl = (uint8_t)(pcm_line->white_level - 1);
+    if (b->digi_set.min_ref_lvl > low_lvl) low_lvl = b->digi_set.min_ref_lvl;
+    if (b->digi_set.max_ref_lvl < high_lvl) high_lvl = b->digi_set.max_ref_lvl;
+    ref_index = high_lvl;
+    while (ref_index >= low_lvl) {
+        p1_base_clear(&t);
+        p1_set_source_pixels(&t, 0, (uint16_t)(b->video_line->length - 1));
+        t.coords.from_doubled = b->video_line->doubled;
+        t.black_level = low_lvl; t.white_level = high_lvl;
+        t.ref_level = (uint8_t)ref_index;
+        if (!orc_p1_crc_valid(&t)) {
+            if (!orc_coords_valid(&forced_coords)) find_pcm1_coordinates(b, &t, b->in_def_coord);
+            else { t.coords = forced_coords; t.coords_set = true; }
+            if (t.coords_set) read_pcm_data(b, &t);
+        }
+        if (t.picked_bits_left != 0 && t.picked_bits_right != 0) t.hysteresis_depth = (uint8_t)(t.hysteresis_depth + ORC_HYST_DEPTH_MAX + 3);   /* :3735-3752 */
+        else if (t.picked_bits_right != 0) t.hysteresis_depth = (uint8_t)(t.hysteresis_depth + ORC_HYST_DEPTH_MAX + 2);
+        else if (t.picked_bits_left != 0) t.hysteresis_depth = (uint8_t)(t.hysteresis_depth + ORC_HYST_DEPTH_MAX + 1);
+        if (t.hysteresis_depth > 0x0F) t.hysteresis_depth = 0x0F;
+        read_result = ORC_REF_NO_PCM;
+        if (orc_p1_crc_valid(&t) && orc_coords_valid(&t.coords)) read_result = ORC_REF_CRC_OK;
+        else if (t.coords_set) read_result = ORC_REF_BAD_CRC;
+        if (read_result != ORC_REF_NO_PCM) {
+            crc_res[ref_index].result = read_result;
+            crc_res[ref_index].data_start = t.coords.data_start;
+            crc_res[ref_index].data_stop = t.coords.data_stop;
+            crc_res[ref_index].hyst_dph = t.hysteresis_depth;
+            crc_res[ref_index].shift_stg = t.shift_stage;
+            crc_res[ref_index].crc = t.calc_crc;
+        }
+        if (ref_index == 0) break;          /* (the reference's uint16_t counter would wrap; min_ref_lvl > 0 in every preset) */
+        ref_index--;
+    }
+}
+
+/* Binarizer::calcRefLevelBySweep (:3821-4120), the branches a line without markers takes */
+static void calc_ref_level_by_sweep_p1(orc_binarizer *b, orc_p1_line *pcm_line)
+{
+    uint8_t fast_ref, bin_level, valid_crc_cnt, span_res;
+    orc_crc_handler scan_sweep_crcs[256];
+    const uint8_t blk1 = (uint8_t)(pcm_line->black_level + 1), wht1 = (uint8_t)(pcm_line->white_level - 1);
+
+    fast_ref = pick_center_ref_level(b, pcm_line->black_level, pcm_line->white_level);
+    b->hysteresis_depth_lim = 0;
+    b->shift_stages_lim = ORC_SHIFT_STAGES_SAFE;
+    reset_crc_stats(scan_sweep_crcs, 256, NULL);
+    sweep_ref_level_p1(b, pcm_line, scan_sweep_crcs);
+    span_res = ORC_SPAN_NOT_FOUND;
+    reset_crc_stats(b->crc_stats, ORC_MAX_COLL_CRCS + 1, &valid_crc_cnt);
+    b->crc_stats[0].hyst_dph = 0; b->crc_stats[0].shift_stg = 0;
+    for (bin_level = wht1; bin_level > pcm_line->black_level; bin_level--)
+        if (scan_sweep_crcs[bin_level].result == ORC_REF_CRC_OK) update_crc_stats(b->crc_stats, scan_sweep_crcs[bin_level], &valid_crc_cnt);
+    if (valid_crc_cnt > 0) {
+        find_most_frequent_crc(b->crc_stats, &valid_crc_cnt, true);
+        invalidate_non_frequent_crcs(scan_sweep_crcs, blk1, wht1, valid_crc_cnt, b->crc_stats[0].crc);
+        if (valid_crc_cnt > 0) {
+            if (b->crc_stats[0].result < b->digi_set.min_valid_crcs) span_res = ORC_SPAN_TOO_NARROW;
+            else span_res = pick_level_by_crc_stats(scan_sweep_crcs, &pcm_line->ref_level, blk1, wht1, ORC_REF_CRC_OK, 0x0F, ORC_SHIFT_STAGES_MAX);
+        }
+    }
+    if (span_res == ORC_SPAN_OK) {
+        orc_crc_handler t = scan_sweep_crcs[pcm_line->ref_level];
+        pcm_line->ref_level_sweeped = true;
+        orc_coords_set(&pcm_line->coords, t.data_start, t.data_stop);
+        pcm_line->coords_set = true;
+        b->hysteresis_depth_lim = t.hyst_dph;
+        if (b->hysteresis_depth_lim > ORC_HYST_DEPTH_MAX) b->hysteresis_depth_lim = ORC_HYST_DEPTH_MAX;
+        b->shift_stages_lim = t.shift_stg;
+    } else {
+        if (span_res == ORC_SPAN_TOO_NARROW) {
+            span_res = pick_level_by_crc_stats_opt(b, scan_sweep_crcs, &pcm_line->ref_level, blk1, wht1, ORC_REF_CRC_OK, b->hysteresis_depth_lim, b->shift_stages_lim);
+            pcm_line->forced_bad = true;
+        } else span_res = pick_level_by_crc_stats(scan_sweep_crcs, &pcm_line->ref_level, blk1, wht1, ORC_REF_NO_PCM, 0xFF, 0xFF);   /* canUseMarkers() == false */
+        if (span_res == ORC_SPAN_OK) {
+            orc_crc_handler t = scan_sweep_crcs[pcm_line->ref_level];
+            orc_coords_set(&pcm_line->coords, t.data_start, t.data_stop);
+            pcm_line->coords_set = true;
+        } else if (is_ref_level_preset(b)) {
+            pcm_line->ref_level = b->in_def_reference;
+            if (orc_coords_valid(&b->in_def_coord)) pcm_line->coords = b->in_def_coord;
+        } else {
+            pcm_line->ref_level = fast_ref;
+            if (!orc_coords_valid(&b->in_def_coord)) orc_coords_set(&pcm_line->coords, (int16_t)b->scan_start, (int16_t)b->scan_end);
+            else pcm_line->coords = b->in_def_coord;
+        }
+        b->hysteresis_depth_lim = ORC_HYST_DEPTH_MIN;
+        b->shift_stages_lim = ORC_SHIFT_STAGES_MIN;
+    }
+}
+
 /* ------------------------------------------------------------------ Binarizer::processLine, PCM1Line output */
 void orc_binarizer_set_good_parameters_p1(orc_binarizer *b, const orc_p1_line *l)   /* :353-377 */
 {
@@ -645,21 +748,26 @@ uint8_t orc_binarizer_process_line_p1(orc_binarizer *b, orc_p1_line *out)   /* :
                 if (!b->was_BW_scanned) find_black_white(b, out);
                 if (!out->blk_wht_set) b->proc_state = ORC_STG_NO_GOOD;
                 else {
-                    b->do_ref_lvl_sweep = false;
-                    if (b->bin_mode == ORC_MODE_INSANE) return ORC_LB_RET_UNSUPPORTED;     /* reference level sweep: not restated */
-                    b->hysteresis_depth_lim = ORC_HYST_DEPTH_SAFE;
-                    b->shift_stages_lim = ORC_SHIFT_STAGES_MIN;
-                    b->proc_state = ORC_STG_READ_PCM;
-                    out->ref_level = pick_center_ref_level(b, out->black_level, out->white_level);
-                    if (orc_coords_valid(&forced_coords)) { out->coords = forced_coords; out->coords_set = true; }
+                    b->do_ref_lvl_sweep = (b->bin_mode == ORC_MODE_INSANE);          /* :1104-1112 */
+                    if (b->do_ref_lvl_sweep) b->proc_state = ORC_STG_REF_SWEEP_RUN;
                     else {
-                        if (!orc_coords_valid(&b->in_def_coord)) orc_coords_set(&out->coords, (int16_t)b->scan_start, (int16_t)b->scan_end);
-                        else out->coords = b->in_def_coord;
-                        if (b->digi_set.en_coord_search && b->do_coord_search) find_pcm1_coordinates(b, out, b->in_def_coord);
+                        b->hysteresis_depth_lim = ORC_HYST_DEPTH_SAFE;
+                        b->shift_stages_lim = ORC_SHIFT_STAGES_MIN;
+                        b->proc_state = ORC_STG_READ_PCM;
+                        out->ref_level = pick_center_ref_level(b, out->black_level, out->white_level);
+                        if (orc_coords_valid(&forced_coords)) { out->coords = forced_coords; out->coords_set = true; }
+                        else {
+                            if (!orc_coords_valid(&b->in_def_coord)) orc_coords_set(&out->coords, (int16_t)b->scan_start, (int16_t)b->scan_end);
+                            else out->coords = b->in_def_coord;
+                            if (b->digi_set.en_coord_search && b->do_coord_search) find_pcm1_coordinates(b, out, b->in_def_coord);
+                        }
+                        if (!out->coords_set) { b->hysteresis_depth_lim = ORC_HYST_DEPTH_SAFE; b->shift_stages_lim = ORC_SHIFT_STAGES_MIN; }
+                        else { b->hysteresis_depth_lim = b->in_max_hysteresis_depth; b->shift_stages_lim = b->in_max_shift_stages; }
                     }
-                    if (!out->coords_set) { b->hysteresis_depth_lim = ORC_HYST_DEPTH_SAFE; b->shift_stages_lim = ORC_SHIFT_STAGES_MIN; }
-                    else { b->hysteresis_depth_lim = b->in_max_hysteresis_depth; b->shift_stages_lim = b->in_max_shift_stages; }
                 }
+            } else if (b->proc_state == ORC_STG_REF_SWEEP_RUN) {        /* :1391-1400 */
+                calc_ref_level_by_sweep_p1(b, out);
+                b->proc_state = ORC_STG_READ_PCM;
             } else if (b->proc_state == ORC_STG_READ_PCM) {                 /* :1401-1533 */
                 if (orc_coords_valid(&forced_coords)) { b->hysteresis_depth_lim = ORC_HYST_DEPTH_SAFE; b->shift_stages_lim = ORC_SHIFT_STAGES_MIN; }
                 if (out->coords_set) read_pcm_data(b, out);

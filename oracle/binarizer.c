@@ -433,7 +433,7 @@ uint8_t pick_level_by_crc_stats(const orc_crc_handler *crcs, uint8_t *ref_result
     return ORC_SPAN_OK;
 }
 
-static uint8_t pick_level_by_crc_stats_opt(const orc_binarizer *b, const orc_crc_handler *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+uint8_t pick_level_by_crc_stats_opt(const orc_binarizer *b, const orc_crc_handler *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
                                            uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :2143-2383 */
 {
     bool range_lock = false, good_ref_det = false;

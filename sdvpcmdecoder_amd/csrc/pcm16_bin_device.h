@@ -16,7 +16,6 @@
  * where fewer than two still do, and a Bit Picker collision marks the one line object forced bad for every read that follows.  All of
  * that is replayed serially, over the lane-parallel results, by lane 0; the line object is then left as the last read the reference
  * would have made leaves it.
- * Not implemented: the reference level sweep, which PCM-16x0 runs in MODE_INSANE only - the host entry refuses that mode.
  */
 #pragma once
 #include "pcm1_bin_device.h"
@@ -27,6 +26,8 @@ using sdvp1b::BinCtx;
 using sdvp1b::stats_reset;
 using sdvp1b::stats_update;
 using sdvp1b::sweep_blank;
+using sdvp1b::rs_store;
+using sdvp1b::rs_unpack;
 
 enum { P16_BITS = 193, P16_DATA = 64, P16_WORD_BITS = 16, P16_CRC_SILENT = 0x0E10, P16_SUBLINES = 3 };
 enum { P16_SEARCH_STEP_DIV = 2, P16_SEARCH_MAX_OFS = 10, P16_SEARCH_STEP_CNT = (P16_SEARCH_MAX_OFS + 1) * 2 };     /* binarizer.h:262-264 */
@@ -45,7 +46,7 @@ struct P16Lds {
 struct L16 {                        /* PCM16X0SubLine : PCMLine (pcmline.h:137-166, pcm16x0subline.h:113-125) */
     uint8_t black, white, ref_low, ref_level, ref_high, hyst, shift;
     Coords coords;
-    bool coords_sweeped, by_ext_tune, bw_set, coords_set, forced_bad, control_bit;
+    bool ref_sweeped, coords_sweeped, by_ext_tune, bw_set, coords_set, forced_bad, control_bit;
     uint8_t service, line_part;
     uint16_t pixel_start, pixel_stop;
     int16_t pso; uint32_t psm, hpsm;
@@ -90,7 +91,7 @@ __device__ inline void base_clear(L16 &l)           /* PCMLine::clear, pcmline.c
     l.black = l.white = l.ref_low = l.ref_level = l.ref_high = 0;
     coords_clear(l.coords);
     l.hyst = l.shift = 0;
-    l.coords_sweeped = l.by_ext_tune = false;
+    l.ref_sweeped = l.coords_sweeped = l.by_ext_tune = false;
     l.calc_crc = 0;
     l.bw_set = l.coords_set = l.forced_bad = false;
     l.service = SDV_SRV_NO;
@@ -222,13 +223,14 @@ __device__ inline bool fill_data_words(const BinCtx &c, L16 &l, const uint8_t *p
     return true;
 }
 
-/* readPCMdata (binarizer.cpp:7695-8055) for a line whose reference level was not swept (see pcm1_bin_device.h, read_pcm_data) */
+/* readPCMdata (binarizer.cpp:7695-8055) (see pcm1_bin_device.h, read_pcm_data) */
 template <bool kWave>
 __device__ inline void read_pcm_data(const BinCtx &c, L16 &l, const uint8_t *px_row, uint8_t part, uint8_t hyst_lim, uint8_t shift_lim)
 {
     set_ppb(l, l.coords);
     if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
     if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
+    if (l.ref_sweeped) { fill_data_words<kWave>(c, l, px_row, part, hyst_lim, shift_lim); return; }     /* isDataByRefSweep(), :7741 */
     bool found = false;
     for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
         bool invalid_hyst = false;
@@ -484,8 +486,105 @@ __device__ inline void find_pcm16_coordinates(BinCtx &c, L16 &l, P16Lds &lds, co
     scan_done = true;
 }
 
+/* ---- reference level sweep (MODE_INSANE only for this format, binarizer.cpp:1113-1120) -------------------------------------------
+ * Binarizer::sweepRefLevel (:3551-3817) with a PCM16X0SubLine as the trial line: every level runs the whole coordinate search over the
+ * three parts of the video line (scan_done is reset per level, :3704) and then reads the part the pass is for; the early return of
+ * :3570 never fires (a fresh sub-line is PART_LEFT).  clear() through the PCMLine pointer is the base clear(): cells, picked bits and
+ * Control Bit of the trial line persist from level to level.  The table of the sweep: see pcm1_bin_device.h (rs_store). */
+__device__ inline void sweep_ref_level_p16(BinCtx &c, const Bin &b, uint8_t part, bool &scan_done, P16Lds &lds, const L16 &pcm_line, bool vl_doubled)
+{
+    Coords forced; calc_forced_coords(b, c.ps, forced);
+    uint8_t low_lvl = (uint8_t)(pcm_line.black + 1), high_lvl = (uint8_t)(pcm_line.white - 1);
+    if (c.ps.min_ref_lvl > low_lvl) low_lvl = c.ps.min_ref_lvl;
+    if (c.ps.max_ref_lvl < high_lvl) high_lvl = c.ps.max_ref_lvl;
+    L16 t; p16_clear(t);
+    for (int lvl = (int)high_lvl; lvl >= (int)low_lvl; lvl--) {
+        base_clear(t);
+        if (c.scan_end > 0 && P16_BITS <= c.scan_end) { t.pixel_start = 0; t.pixel_stop = c.scan_end; }    /* setSourcePixels(0, size - 1) */
+        t.coords.doubled = vl_doubled;
+        t.black = low_lvl; t.white = high_lvl; t.ref_level = (uint8_t)lvl;
+        uint8_t hyst_lim = 0, shift_lim = SHIFT_STAGES_SAFE;        /* calcRefLevelBySweep, :3847-3851 */
+        if (!crc_valid(t)) {
+            if (!coords_valid(forced)) { scan_done = false; find_pcm16_coordinates(c, t, lds, b.in_coord, scan_done, hyst_lim, shift_lim); }
+            else { t.coords = forced; t.coords_set = true; }
+            if (t.coords_set) read_pcm_data<true>(c, t, lds.w.px, part, hyst_lim, shift_lim);
+        }
+        if (t.picked_r != 0) t.hyst = (uint8_t)(t.hyst + HYST_DEPTH_MAX + 2);                            /* :3753-3765 */
+        else if (t.picked_l != 0) t.hyst = (uint8_t)(t.hyst + HYST_DEPTH_MAX + 1);
+        if (t.hyst > 0x0F) t.hyst = 0x0F;
+        SweepEnt e = sweep_blank();
+        e.result = REF_NO_PCM;
+        if (crc_valid(t) && coords_valid(t.coords)) e.result = REF_CRC_OK;
+        else if (t.coords_set) e.result = REF_BAD_CRC;
+        if (e.result != REF_NO_PCM) {
+            e.start = t.coords.start; e.stop = t.coords.stop; e.hyst = t.hyst; e.shift = t.shift; e.crc = t.calc_crc;
+            if (lane_id() == 0) rs_store(lds.w, lvl, e);
+        }
+    }
+}
+
+/* Binarizer::calcRefLevelBySweep (binarizer.cpp:3821-4120), the branches a line without markers takes */
+__device__ inline void calc_ref_level_by_sweep_p16(BinCtx &c, const Bin &b, uint8_t part, bool &scan_done, P16Lds &lds, L16 &l, bool vl_doubled,
+                                                   uint8_t &hyst_lim, uint8_t &shift_lim)
+{
+    const int lane = lane_id();
+    const uint8_t fast_ref = pick_center_ref_level(c.ps, l.black, l.white);
+    const uint8_t blk1 = (uint8_t)(l.black + 1), wht1 = (uint8_t)(l.white - 1);
+    hyst_lim = 0; shift_lim = SHIFT_STAGES_SAFE;
+    __syncthreads();
+    { const SweepEnt z = sweep_blank(); for (int i = lane; i < 256; i += 64) rs_store(lds.w, i, z); }
+    __syncthreads();
+    sweep_ref_level_p16(c, b, part, scan_done, lds, l, vl_doubled);
+    rs_unpack(lds.w);
+    uint8_t span_res = SPAN_NOT_FOUND, valid_crc_cnt = 0;
+    if (lane == 0) {
+        crc_stats_reset(lds.w, MAX_COLL_CRCS + 1); lds.w.crc_stats[0].hyst = 0; lds.w.crc_stats[0].shift = 0;
+        for (uint8_t lv = wht1; lv > l.black; lv--)
+            if (lds.w.sweep[lv].result == REF_CRC_OK) crc_stats_update(lds.w, lds.w.sweep[lv].crc, lds.w.sweep[lv].hyst, lds.w.sweep[lv].shift, valid_crc_cnt);
+        const uint8_t first_cnt = valid_crc_cnt;
+        if (valid_crc_cnt > 0) {
+            crc_stats_most_frequent(lds.w, valid_crc_cnt);
+            sweep_invalidate_non_frequent(lds.w, blk1, wht1, valid_crc_cnt, lds.w.crc_stats[0].crc);
+        }
+        lds.w.crc_stats[0].idx = (uint8_t)((first_cnt > 0 ? 1 : 0) | (valid_crc_cnt > 0 ? 2 : 0));
+    }
+    __syncthreads();
+    const bool had_any = (lds.w.crc_stats[0].idx & 1) != 0, still_valid = (lds.w.crc_stats[0].idx & 2) != 0;
+    if (had_any && still_valid) {
+        if (lds.w.crc_stats[0].result < c.ps.min_valid_crcs) span_res = SPAN_TOO_NARROW;
+        else span_res = pick_level_by_crc_stats(lds.w, &l.ref_level, blk1, wht1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX);
+    }
+    if (span_res == SPAN_OK) {
+        const SweepEnt t = lds.w.sweep[l.ref_level];
+        l.ref_sweeped = true;
+        coords_set(l.coords, t.start, t.stop);
+        l.coords_set = true;
+        hyst_lim = t.hyst > HYST_DEPTH_MAX ? (uint8_t)HYST_DEPTH_MAX : t.hyst;
+        shift_lim = t.shift;
+    } else {
+        if (span_res == SPAN_TOO_NARROW) {
+            span_res = pick_level_by_crc_stats_opt(c.ps, lds.w, &l.ref_level, blk1, wht1, REF_CRC_OK, hyst_lim, shift_lim);
+            l.forced_bad = true;
+        } else span_res = pick_level_by_crc_stats(lds.w, &l.ref_level, blk1, wht1, REF_NO_PCM, 0xFF, 0xFF);      /* canUseMarkers() == false */
+        if (span_res == SPAN_OK) {
+            const SweepEnt t = lds.w.sweep[l.ref_level];
+            coords_set(l.coords, t.start, t.stop);
+            l.coords_set = true;
+        } else if (is_ref_level_preset(b, c.ps)) {
+            l.ref_level = b.in_ref;
+            if (coords_valid(b.in_coord)) l.coords = b.in_coord;
+        } else {
+            l.ref_level = fast_ref;
+            if (!coords_valid(b.in_coord)) coords_set(l.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+            else l.coords = b.in_coord;
+        }
+        hyst_lim = 0; shift_lim = SHIFT_STAGES_MIN;            /* HYST_DEPTH_MIN */
+    }
+    __syncthreads();
+}
+
 /* findBlackWhite (binarizer.cpp:3116-3473) over the PCM-16x0 windows of the line (findPCM16X0BW, :2603-2681: one in each third) */
-__device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &line, bool &was_bw_scanned)
+__device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &line, bool &was_bw_scanned, bool sweep_flag)
 {
     uint16_t pixel_limit = (uint16_t)(c.scan_end - c.scan_start);
     const uint16_t eighth = (uint16_t)(pixel_limit / 8);
@@ -535,7 +634,8 @@ __device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &
         bool invalidate = false;
         if (br_white < br_black) invalidate = true;
         else if (((int)br_white - (int)br_black) < (int)c.ps.min_contrast) invalidate = true;
-        else if (br_black > c.ps.max_black_lvl) invalidate = true;          /* do_ref_lvl_sweep is never set on this path */
+        else if (sweep_flag && (((int)br_white - (int)br_black) < (int)c.ps.min_valid_crcs)) invalidate = true;       /* Binarizer::do_ref_lvl_sweep: left by the last line that got as far as :1104 */
+        else if (br_black > c.ps.max_black_lvl) invalidate = true;
         else if (br_white < c.ps.min_white_lvl) invalidate = true;
         if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
     }
@@ -546,7 +646,8 @@ __device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &
 }
 
 /* Binarizer::processLine (binarizer.cpp:443-1724), PCM16X0SubLine output, one part of the video line staged in lds.w.px */
-__device__ inline void process_line_p16(BinCtx &c, const Bin &b, bool coord_search, uint8_t part, bool &scan_done, P16Lds &lds, L16 &out, bool vl_doubled)
+template <bool kInsane>          /* the build for MODE_INSANE: see process_line_p1 */
+__device__ inline void process_line_p16(BinCtx &c, Bin &b, bool coord_search, uint8_t part, bool &scan_done, P16Lds &lds, L16 &out, bool vl_doubled)
 {
     p16_clear(out);
     out.line_part = part == PART_MIDDLE ? 1 : (part == PART_RIGHT ? 2 : 0);
@@ -563,7 +664,7 @@ __device__ inline void process_line_p16(BinCtx &c, const Bin &b, bool coord_sear
 
     for (int stage_count = 1; ; stage_count++) {
         if (state == STG_INPUT_ALL) {                           /* :774-931 */
-            if (!out.bw_set) find_black_white_p16(c, lds.w, out, was_bw_scanned);
+            if (!out.bw_set) find_black_white_p16(c, lds.w, out, was_bw_scanned, b.do_ref_lvl_sweep);
             if (!coords_valid(forced)) out.coords = b.in_coord;
             out.ref_level = b.in_ref;
             if (!out.bw_set) state = STG_NO_GOOD;
@@ -573,14 +674,17 @@ __device__ inline void process_line_p16(BinCtx &c, const Bin &b, bool coord_sear
                 if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; } else state = STG_REF_FIND;
             }
         } else if (state == STG_INPUT_LEVEL) {                  /* :932-1072 */
-            if (!was_bw_scanned) find_black_white_p16(c, lds.w, out, was_bw_scanned);
+            if (!was_bw_scanned) find_black_white_p16(c, lds.w, out, was_bw_scanned, b.do_ref_lvl_sweep);
             if (!coords_valid(forced)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
             out.ref_level = b.in_ref;
             state = out.bw_set ? STG_REF_FIND : STG_NO_GOOD;
         } else if (state == STG_REF_FIND) {                     /* :1073-1390 */
-            if (!was_bw_scanned) find_black_white_p16(c, lds.w, out, was_bw_scanned);
+            if (!was_bw_scanned) find_black_white_p16(c, lds.w, out, was_bw_scanned, b.do_ref_lvl_sweep);
             if (!out.bw_set) state = STG_NO_GOOD;
-            else {
+            else if ((b.do_ref_lvl_sweep = kInsane)) {          /* = (mode == MODE_INSANE), :1113-1133: the member keeps this until the next line gets here; STG_REF_SWEEP_RUN, :1391-1400 */
+                if (kInsane) calc_ref_level_by_sweep_p16(c, b, part, scan_done, lds, out, vl_doubled, hyst_lim, shift_lim);
+                state = STG_READ_PCM;
+            } else {
                 hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN;
                 state = STG_READ_PCM;
                 out.ref_level = pick_center_ref_level(c.ps, out.black, out.white);
@@ -603,7 +707,7 @@ __device__ inline void process_line_p16(BinCtx &c, const Bin &b, bool coord_sear
             if (out.coords_set) read_pcm_data<true>(c, out, lds.w.px, part, hyst_lim, shift_lim);
             if (crc_valid(out)) state = STG_DATA_OK;
             if (state != STG_DATA_OK) {
-                if (coords_valid(b.in_coord) && !coords_valid(forced) && !out.forced_bad && !out.coords_set) {
+                if (coords_valid(b.in_coord) && !coords_valid(forced) && !b.do_ref_lvl_sweep && !out.forced_bad && !out.coords_set) {
                     if (coords_ne(out.coords, b.in_coord)) {
                         out.coords = b.in_coord;
                         read_pcm_data<true>(c, out, lds.w.px, part, hyst_lim, shift_lim);
@@ -635,7 +739,7 @@ __device__ inline void emit_rec(const L16 &l, uint32_t frame, uint16_t line_no, 
     r.black_level = l.black; r.white_level = l.white; r.ref_low = l.ref_low; r.ref_level = l.ref_level; r.ref_high = l.ref_high;
     r.hysteresis_depth = l.hyst; r.shift_stage = l.shift; r.service_type = l.service;
     r.picked_bits_left = l.picked_l; r.picked_bits_right = l.picked_r;
-    r.flags = (uint8_t)((l.coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) | (l.by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l.bw_set ? SDV_LF_BW_SET : 0) |
+    r.flags = (uint8_t)((l.ref_sweeped ? SDV_LF_REF_SWEEPED : 0) | (l.coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) | (l.by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l.bw_set ? SDV_LF_BW_SET : 0) |
                         (l.coords_set ? SDV_LF_COORDS_SET : 0) | (l.forced_bad ? SDV_LF_FORCED_BAD : 0) | (crc_valid(l) ? SDV_LF_CRC_VALID : 0) |
                         (from_doubled ? SDV_LF_FROM_DOUBLED : 0));
     r.line_part = l.line_part; r.control_bit = l.control_bit ? 1 : 0; r._pad = 0;

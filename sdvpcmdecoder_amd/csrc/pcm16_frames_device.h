@@ -42,6 +42,7 @@ using sdvp1f::prescan_runs;
 using sdvp1f::ctx_for_line;
 using sdvp1f::COORD_CHECK_LINES;
 using sdvp1f::COORD_CHECK_PARTS;
+using sdvp1f::sweep_flag_matters;
 
 enum { P16_LINES_PF = 245 };                                    /* PCM16X0DataStitcher::LINES_PF, pcm16x0datastitcher.h:124 */
 enum { LV16 = COORD_HISTORY_DEPTH * P16_SUBLINES };             /* 27 */
@@ -59,6 +60,7 @@ struct FrameArgs16 {
 struct Lds16 { P16Lds p; uint32_t lv_keys16[LV16]; };
 
 /* ---- prescan: block = (frame, k) ------------------------------------------------------------------------------------------ */
+template <bool kInsane>
 __device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, int k)
 {
     const FrameArgs &a = a16.f;
@@ -68,23 +70,36 @@ __device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, i
         const int row = frame_buf_row(a, f, (k + 1) * gap);
         if (row >= 0) {
             sdvp1b::stage_row(lds.p.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
-            BinCtx c; Bin b;
-            b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
-            ctx_for_line(a, c, b);
-            L16 out;
-            bool scan_done = false;
-            process_line_p16(c, b, true, PART_RIGHT, scan_done, lds.p, out, a.doubled != 0);
-            if (crc_valid(out)) { r.start = out.coords.start; r.stop = out.coords.stop; r.ref = out.ref_level; r.valid = 1; }
-            r.pad[0] = scan_done ? 1 : 0;
+            /* both values of the Binarizer's sticky sweep flag where it matters (pcm1_frames_device.h, PrescanRes) */
+            for (int variant = 0; variant < (sweep_flag_matters(a.preset) ? 2 : 1); variant++) {
+                BinCtx c; Bin b;
+                b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
+                ctx_for_line(a, c, b);
+                b.do_ref_lvl_sweep = variant != 0;
+                L16 out;
+                bool scan_done = false;
+                process_line_p16<kInsane>(c, b, true, PART_RIGHT, scan_done, lds.p, out, a.doubled != 0);
+                PrescanRes q = r;
+                if (crc_valid(out)) { q.start = out.coords.start; q.stop = out.coords.stop; q.ref = out.ref_level; q.valid = 1; }
+                q.pad[0] = scan_done ? 1 : 0;
+                q.pad[1] = out.bw_set ? 1 : 0;
+                if (lane_id() == 0) a16.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k] = q;
+                __syncthreads();
+            }
+            return;
         }
     }
-    if (lane_id() == 0) a16.prescan[(size_t)f * COORD_CHECK_LINES + k] = r;
+    if (lane_id() == 0) {
+        a16.prescan[(size_t)f * COORD_CHECK_LINES + k] = r;
+        if (sweep_flag_matters(a.preset)) a16.prescan[((size_t)a.n_total + f) * COORD_CHECK_LINES + k] = r;
+    }
 }
 
 /* ---- state of a PCM-16x0 frame wave --------------------------------------------------------------------------------------- */
 struct V2D16 {
     V2D v;                          /* the part shared with STC-007; last_words unused */
     uint8_t prescan_ref;
+    uint8_t pre_variant;            /* bit k: prescan line k of this frame was taken from the second variant */
     uint64_t lw0, lw1, lw2;         /* the data words of last_pcm16x0_p0/p1/p2_line (the 48 data cells; named members: an indexed array would put the whole state into scratch) */
 };
 
@@ -116,10 +131,10 @@ __device__ inline void store_state16(const V2D16 &w, const Lds16 &lds, const Fra
     const FrameArgs &a = a16.f;
     const V2D &v = w.v;
     State16 o;
-    o.s.bin.in_def_black = v.bin.in_black; o.s.bin.in_def_white = v.bin.in_white; o.s.bin.in_def_reference = v.bin.in_ref; o.s.bin._pad = 0;
+    o.s.bin.in_def_black = v.bin.in_black; o.s.bin.in_def_white = v.bin.in_white; o.s.bin.in_def_reference = v.bin.in_ref; o.s.bin.do_ref_lvl_sweep = 0;
     o.s.bin.in_def_start = v.bin.in_coord.start; o.s.bin.in_def_stop = v.bin.in_coord.stop;
     o.s.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.s.bin._pad2 = 0;
-    o.s.do_ref_lvl_sweep = 0; o.s.reset_stats = v.reset_stats ? 1 : 0;
+    o.s.do_ref_lvl_sweep = v.bin.do_ref_lvl_sweep ? 1 : 0; o.s.reset_stats = v.reset_stats ? 1 : 0;
     o.s.n_last_valid = (uint8_t)v.n_last; o.s.n_long_valid = (uint8_t)v.n_long;
     const int n9 = v.n_last < COORD_HISTORY_DEPTH ? v.n_last : COORD_HISTORY_DEPTH;
     const uint16_t lm = a.doubled ? (uint16_t)((1u << n9) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
@@ -143,6 +158,7 @@ __device__ inline void begin_frame16(V2D16 &w, const FrameArgs16 &a16, Lds16 &ld
 {
     const FrameArgs &a = a16.f;
     V2D &v = w.v;
+    w.pre_variant = 0;
     v.field_state = FIELD_NEW;
     v.good_coords_in_field = v.pcm_lines_in_field = 0;
     if (v.reset_stats) {
@@ -157,8 +173,11 @@ __device__ inline void begin_frame16(V2D16 &w, const FrameArgs16 &a16, Lds16 &ld
             bin_set_good_parameters_reset(v.bin, a.preset);
             uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
             for (int k = 0; k < COORD_CHECK_LINES; k++) {
-                const PrescanRes r = a16.prescan[(size_t)f * COORD_CHECK_LINES + k];
+                const int variant = (sweep_flag_matters(a.preset) && v.bin.do_ref_lvl_sweep) ? 1 : 0;
+                w.pre_variant = (uint8_t)(w.pre_variant | (variant << k));
+                const PrescanRes r = a16.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k];
                 if (uni(r.valid)) { keys[n] = uniu(coords_key(r.start, r.stop)); refs[n] = (uint8_t)uni(r.ref); n++; }
+                if (uni(r.pad[1])) v.bin.do_ref_lvl_sweep = a.mode == SDV_MODE_INSANE;
             }
             for (int i = 1; i < n; i++)
                 for (int j = i; j > 0; j--) {
@@ -489,6 +508,7 @@ __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, cons
     return n_ok;
 }
 
+template <bool kInsane>
 __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
 {
     const FrameArgs &a = a16.f;
@@ -510,7 +530,7 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
     for (int k = 0; k < COORD_CHECK_LINES; k++) { pre_row[k] = -1; pre_done[k] = false; }
     if (prescan_runs(a, f)) {
         const int gap = frame_buf_lines(a, f) / (COORD_CHECK_PARTS - 1);
-        for (int k = 0; k < COORD_CHECK_LINES; k++) { pre_row[k] = frame_buf_row(a, f, (k + 1) * gap); pre_done[k] = uni(a16.prescan[(size_t)f * COORD_CHECK_LINES + k].pad[0]) != 0; }
+        for (int k = 0; k < COORD_CHECK_LINES; k++) { pre_row[k] = frame_buf_row(a, f, (k + 1) * gap); pre_done[k] = uni(a16.prescan[((size_t)((w.pre_variant >> k) & 1) * a.n_total + f) * COORD_CHECK_LINES + k].pad[0]) != 0; }
     }
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     uint16_t line_num = 0;
@@ -557,7 +577,7 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
                 p16_clear(wl);
 #else
                 if (!(SDV_P16_LEAN && lean_part16(lean, c, v.bin, (uint8_t)(PART_LEFT + sub), lds.p.w.px, wl)))
-                    process_line_p16(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
+                    process_line_p16<kInsane>(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
 #endif
                 P16_T(t_d); P16_ADD(1, t_c, t_d);
 #if SDV_P16_ABLATE != 2
@@ -633,7 +653,11 @@ __device__ inline State16 predict_state16(const PredictArgs16 &a, int k, int bas
     for (int j = j0; j < k; j++) {
         if (!prescan_runs(a.f, j)) continue;
         uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
-        for (int q = 0; q < COORD_CHECK_LINES; q++) { const PrescanRes r = a.prescan[(size_t)j * COORD_CHECK_LINES + q]; if (r.valid) { keys[n] = coords_key(r.start, r.stop); refs[n] = r.ref; n++; } }
+        for (int q = 0; q < COORD_CHECK_LINES; q++) {
+            const PrescanRes r = a.prescan[(size_t)j * COORD_CHECK_LINES + q];
+            if (r.valid) { keys[n] = coords_key(r.start, r.stop); refs[n] = r.ref; n++; }
+            if (r.pad[1]) p.s.do_ref_lvl_sweep = a.f.mode == SDV_MODE_INSANE ? 1 : 0;
+        }
         if (n == 0) continue;
         for (int i = 1; i < n; i++)
             for (int q = i; q > 0; q--) {
@@ -734,18 +758,22 @@ __device__ inline void verify_body16(const VerifyArgs16 &a, int k)
 #ifndef SDV_P16_WAVES_PER_EU
 #define SDV_P16_WAVES_PER_EU 3
 #endif
-__global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_prescan(sdvp16f::FrameArgs16 a)
-{
-    __shared__ sdvp16f::Lds16 lds;
-    const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp16f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp16f::COORD_CHECK_LINES;
-    sdvp16f::prescan_body(a, lds, f, i % sdvp16f::COORD_CHECK_LINES);
+/* two builds of the two kernels: MODE_INSANE (with the reference level sweep) and every other mode (process_line_p1) */
+#define SDV_P16F_KERNELS(SUFFIX, INSANE) \
+__global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_prescan##SUFFIX(sdvp16f::FrameArgs16 a) \
+{ \
+    __shared__ sdvp16f::Lds16 lds; \
+    const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp16f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp16f::COORD_CHECK_LINES; \
+    sdvp16f::prescan_body<INSANE>(a, lds, f, i % sdvp16f::COORD_CHECK_LINES); \
+} \
+__global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_frames_bin##SUFFIX(sdvp16f::FrameArgs16 a) \
+{ \
+    __shared__ sdvp16f::Lds16 lds; \
+    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x; \
+    sdvp16f::frame_body16<INSANE>(a, lds, f); \
 }
-__global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_frames_bin(sdvp16f::FrameArgs16 a)
-{
-    __shared__ sdvp16f::Lds16 lds;
-    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x;
-    sdvp16f::frame_body16(a, lds, f);
-}
+SDV_P16F_KERNELS(, false)
+SDV_P16F_KERNELS(_insane, true)
 #ifndef SDV_EMU
 __global__ void sdv_k_pcm16_predict(sdvp16f::PredictArgs16 a)
 {

@@ -16,7 +16,6 @@
  * minimum, and the last candidate is evaluated once more, wave-uniformly, into the line.
  *
  * The 94 cells of a line are kept as one 94-bit number (word k = bits 81-13k .. 93-13k, CRCC = the low 16 bits).
- * Not implemented: the reference level sweep, which PCM-1 runs in MODE_INSANE only - the host entry refuses that mode.
  */
 #pragma once
 #include "stc007_device.h"
@@ -50,7 +49,7 @@ struct P1Lds {
 struct L1 {                         /* PCM1Line : PCMLine (pcmline.h:137-166, pcm1line.h:59-110) */
     uint8_t black, white, ref_low, ref_level, ref_high, hyst, shift;
     Coords coords;
-    bool coords_sweeped, by_ext_tune, bw_set, coords_set, forced_bad;
+    bool ref_sweeped, coords_sweeped, by_ext_tune, bw_set, coords_set, forced_bad;
     uint8_t service;
     uint16_t pixel_start, pixel_stop;
     int16_t pso; uint32_t psm, hpsm;
@@ -123,7 +122,7 @@ __device__ inline void base_clear(L1 &l)           /* PCMLine::clear, pcmline.cp
     l.black = l.white = l.ref_low = l.ref_level = l.ref_high = 0;
     coords_clear(l.coords);
     l.hyst = l.shift = 0;
-    l.coords_sweeped = l.by_ext_tune = false;
+    l.ref_sweeped = l.coords_sweeped = l.by_ext_tune = false;
     l.calc_crc = 0;
     l.bw_set = l.coords_set = l.forced_bad = false;
     l.service = SDV_SRV_NO;
@@ -308,7 +307,7 @@ __device__ inline bool fill_data_words(const BinCtx &c, L1 &l, const uint8_t *px
     return true;
 }
 
-/* readPCMdata (binarizer.cpp:7695-8055) for a line whose reference level was not swept: hysteresis depths from 0 up, pixel shift
+/* readPCMdata (binarizer.cpp:7695-8055).  A line whose reference level was not swept: hysteresis depths from 0 up, pixel shift
  * stages from 0 up, the first combination with a valid CRC wins (both loops of the reference stop at the first valid CRC, so its
  * two votes are over one entry each); none: depth 0, stage 0.  Then the final fill. */
 template <bool kWave>
@@ -317,6 +316,7 @@ __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const uint8_t *px_r
     set_ppb(l, l.coords);
     if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
     if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
+    if (l.ref_sweeped) { fill_data_words<kWave>(c, l, px_row, hyst_lim, shift_lim); return; }     /* isDataByRefSweep(): the sweep has picked depth and stage (:7741) */
     uint8_t valid_delta = 0, valid_shift = 0;
     bool found = false;
     for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
@@ -502,8 +502,133 @@ __device__ inline void find_pcm1_coordinates(BinCtx &c, L1 &l, P1Lds &lds, const
     hyst_lim = in_hyst; shift_lim = in_shift;
 }
 
+/* ---- reference level sweep (MODE_INSANE only for this format, binarizer.cpp:1105-1112) -------------------------------------------
+ * The sweep's table (one entry per level) has to outlive the coordinate searches that run inside it, and those use the first 58
+ * (PCM-1) / 150 (PCM-16x0) entries of WaveLds::sweep.  While the sweep runs the table is kept packed in two words per level: one in
+ * the brightness histogram (not in use at that point), one behind entry 160 of the sweep array; it is unpacked in place when the
+ * sweep is done. */
+enum { RS_BASE = 160 };
+static_assert(sizeof(SweepEnt) * (256 - RS_BASE) >= 256 * 4, "the second words of the packed table fit behind the search's entries");
+__device__ inline uint32_t *rs_words(WaveLds &w) { return reinterpret_cast<uint32_t *>(&w.sweep[RS_BASE]); }
+__device__ inline void rs_store(WaveLds &w, int lvl, const SweepEnt &e)
+{
+    w.hist[lvl] = (uint32_t)e.crc | ((uint32_t)(e.hyst & 0xF) << 16) | ((uint32_t)(e.shift & 0xF) << 20) | ((uint32_t)e.result << 24);
+    rs_words(w)[lvl] = (uint32_t)(uint16_t)e.start | ((uint32_t)(uint16_t)e.stop << 16);
+}
+__device__ inline void rs_unpack(WaveLds &w)
+{
+    const int lane = lane_id();
+    uint32_t a[4], b[4];
+    __syncthreads();
+    for (int k = 0; k < 4; k++) { a[k] = w.hist[lane + 64 * k]; b[k] = rs_words(w)[lane + 64 * k]; }
+    __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        SweepEnt e = sweep_blank();
+        e.crc = (uint16_t)(a[k] & 0xFFFF); e.hyst = (uint8_t)((a[k] >> 16) & 0xF); e.shift = (uint8_t)((a[k] >> 20) & 0xF); e.result = (uint8_t)(a[k] >> 24);
+        e.start = (int16_t)(b[k] & 0xFFFF); e.stop = (int16_t)(b[k] >> 16);
+        w.sweep[lane + 64 * k] = e;
+    }
+    __syncthreads();
+}
+
+/* Binarizer::sweepRefLevel (binarizer.cpp:3551-3817) with a PCM1Line as the trial line.  The first-try read from the preset
+ * coordinates never runs for this format (skip_bin stays false, :3647-3679): every level runs the whole coordinate search, levels one
+ * after the other (the search itself is spread over the lanes).  clear() through the PCMLine pointer is the base clear(): cells and
+ * picked bits of the trial line persist from level to level. */
+__device__ inline void sweep_ref_level_p1(BinCtx &c, const Bin &b, P1Lds &lds, const L1 &pcm_line, bool vl_doubled)
+{
+    Coords forced; calc_forced_coords(b, c.ps, forced);
+    uint8_t low_lvl = (uint8_t)(pcm_line.black + 1), high_lvl = (uint8_t)(pcm_line.white - 1);
+    if (c.ps.min_ref_lvl > low_lvl) low_lvl = c.ps.min_ref_lvl;
+    if (c.ps.max_ref_lvl < high_lvl) high_lvl = c.ps.max_ref_lvl;
+    L1 t; p1_clear(t);
+    for (int lvl = (int)high_lvl; lvl >= (int)low_lvl; lvl--) {
+        base_clear(t);
+        if (c.scan_end > 0 && P1_BITS <= c.scan_end) { t.pixel_start = 0; t.pixel_stop = c.scan_end; }     /* setSourcePixels(0, size - 1) */
+        t.coords.doubled = vl_doubled;
+        t.black = low_lvl; t.white = high_lvl; t.ref_level = (uint8_t)lvl;
+        uint8_t hyst_lim = 0, shift_lim = SHIFT_STAGES_SAFE;        /* calcRefLevelBySweep, :3847-3851 */
+        if (!crc_valid(t)) {
+            if (!coords_valid(forced)) find_pcm1_coordinates(c, t, lds, b.in_coord, hyst_lim, shift_lim);
+            else { t.coords = forced; t.coords_set = true; }
+            if (t.coords_set) read_pcm_data<true>(c, t, lds.w.px, hyst_lim, shift_lim);
+        }
+        if (t.picked_l != 0 && t.picked_r != 0) t.hyst = (uint8_t)(t.hyst + HYST_DEPTH_MAX + 3);         /* :3735-3752 */
+        else if (t.picked_r != 0) t.hyst = (uint8_t)(t.hyst + HYST_DEPTH_MAX + 2);
+        else if (t.picked_l != 0) t.hyst = (uint8_t)(t.hyst + HYST_DEPTH_MAX + 1);
+        if (t.hyst > 0x0F) t.hyst = 0x0F;
+        SweepEnt e = sweep_blank();
+        e.result = REF_NO_PCM;
+        if (crc_valid(t) && coords_valid(t.coords)) e.result = REF_CRC_OK;
+        else if (t.coords_set) e.result = REF_BAD_CRC;
+        if (e.result != REF_NO_PCM) {
+            e.start = t.coords.start; e.stop = t.coords.stop; e.hyst = t.hyst; e.shift = t.shift; e.crc = t.calc_crc;
+            if (lane_id() == 0) rs_store(lds.w, lvl, e);
+        }
+    }
+}
+
+/* Binarizer::calcRefLevelBySweep (binarizer.cpp:3821-4120), the branches a line without markers takes */
+__device__ inline void calc_ref_level_by_sweep_p1(BinCtx &c, const Bin &b, P1Lds &lds, L1 &l, bool vl_doubled, uint8_t &hyst_lim, uint8_t &shift_lim)
+{
+    const int lane = lane_id();
+    const uint8_t fast_ref = pick_center_ref_level(c.ps, l.black, l.white);
+    const uint8_t blk1 = (uint8_t)(l.black + 1), wht1 = (uint8_t)(l.white - 1);
+    hyst_lim = 0; shift_lim = SHIFT_STAGES_SAFE;
+    __syncthreads();
+    { const SweepEnt z = sweep_blank(); for (int i = lane; i < 256; i += 64) rs_store(lds.w, i, z); }
+    __syncthreads();
+    sweep_ref_level_p1(c, b, lds, l, vl_doubled);
+    rs_unpack(lds.w);
+    uint8_t span_res = SPAN_NOT_FOUND, valid_crc_cnt = 0;
+    if (lane == 0) {
+        crc_stats_reset(lds.w, MAX_COLL_CRCS + 1); lds.w.crc_stats[0].hyst = 0; lds.w.crc_stats[0].shift = 0;
+        for (uint8_t lv = wht1; lv > l.black; lv--)
+            if (lds.w.sweep[lv].result == REF_CRC_OK) crc_stats_update(lds.w, lds.w.sweep[lv].crc, lds.w.sweep[lv].hyst, lds.w.sweep[lv].shift, valid_crc_cnt);
+        const uint8_t first_cnt = valid_crc_cnt;
+        if (valid_crc_cnt > 0) {
+            crc_stats_most_frequent(lds.w, valid_crc_cnt);
+            sweep_invalidate_non_frequent(lds.w, blk1, wht1, valid_crc_cnt, lds.w.crc_stats[0].crc);
+        }
+        lds.w.crc_stats[0].idx = (uint8_t)((first_cnt > 0 ? 1 : 0) | (valid_crc_cnt > 0 ? 2 : 0));
+    }
+    __syncthreads();
+    const bool had_any = (lds.w.crc_stats[0].idx & 1) != 0, still_valid = (lds.w.crc_stats[0].idx & 2) != 0;
+    if (had_any && still_valid) {
+        if (lds.w.crc_stats[0].result < c.ps.min_valid_crcs) span_res = SPAN_TOO_NARROW;
+        else span_res = pick_level_by_crc_stats(lds.w, &l.ref_level, blk1, wht1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX);
+    }
+    if (span_res == SPAN_OK) {
+        const SweepEnt t = lds.w.sweep[l.ref_level];
+        l.ref_sweeped = true;
+        coords_set(l.coords, t.start, t.stop);
+        l.coords_set = true;
+        hyst_lim = t.hyst > HYST_DEPTH_MAX ? (uint8_t)HYST_DEPTH_MAX : t.hyst;
+        shift_lim = t.shift;
+    } else {
+        if (span_res == SPAN_TOO_NARROW) {
+            span_res = pick_level_by_crc_stats_opt(c.ps, lds.w, &l.ref_level, blk1, wht1, REF_CRC_OK, hyst_lim, shift_lim);
+            l.forced_bad = true;
+        } else span_res = pick_level_by_crc_stats(lds.w, &l.ref_level, blk1, wht1, REF_NO_PCM, 0xFF, 0xFF);      /* canUseMarkers() == false */
+        if (span_res == SPAN_OK) {
+            const SweepEnt t = lds.w.sweep[l.ref_level];
+            coords_set(l.coords, t.start, t.stop);
+            l.coords_set = true;
+        } else if (is_ref_level_preset(b, c.ps)) {
+            l.ref_level = b.in_ref;
+            if (coords_valid(b.in_coord)) l.coords = b.in_coord;
+        } else {
+            l.ref_level = fast_ref;
+            if (!coords_valid(b.in_coord)) coords_set(l.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
+            else l.coords = b.in_coord;
+        }
+        hyst_lim = 0; shift_lim = SHIFT_STAGES_MIN;            /* HYST_DEPTH_MIN */
+    }
+    __syncthreads();
+}
+
 /* findBlackWhite (binarizer.cpp:3116-3473) over the PCM-1 part of the line (findPCM1BW, :2560-2600) */
-__device__ inline bool find_black_white_p1(const BinCtx &c, WaveLds &lds, L1 &line, bool &was_bw_scanned)
+__device__ inline bool find_black_white_p1(const BinCtx &c, WaveLds &lds, L1 &line, bool &was_bw_scanned, bool sweep_flag)
 {
     uint16_t pixel_limit = (uint16_t)(c.scan_end - c.scan_start);
     const uint16_t search_end = (uint16_t)(c.scan_end - (uint16_t)(pixel_limit / 32));
@@ -549,7 +674,8 @@ __device__ inline bool find_black_white_p1(const BinCtx &c, WaveLds &lds, L1 &li
         bool invalidate = false;
         if (br_white < br_black) invalidate = true;
         else if (((int)br_white - (int)br_black) < (int)c.ps.min_contrast) invalidate = true;
-        else if (br_black > c.ps.max_black_lvl) invalidate = true;          /* do_ref_lvl_sweep is never set on this path */
+        else if (sweep_flag && (((int)br_white - (int)br_black) < (int)c.ps.min_valid_crcs)) invalidate = true;       /* Binarizer::do_ref_lvl_sweep: left by the last line that got as far as :1104 */
+        else if (br_black > c.ps.max_black_lvl) invalidate = true;
         else if (br_white < c.ps.min_white_lvl) invalidate = true;
         if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
     }
@@ -572,7 +698,7 @@ __device__ inline void emit_rec(const L1 &l, uint32_t frame, uint16_t line_no, b
     r.black_level = l.black; r.white_level = l.white; r.ref_low = l.ref_low; r.ref_level = l.ref_level; r.ref_high = l.ref_high;
     r.hysteresis_depth = l.hyst; r.shift_stage = l.shift; r.service_type = l.service;
     r.picked_bits_left = l.picked_l; r.picked_bits_right = l.picked_r;
-    r.flags = (uint8_t)((l.coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) | (l.by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l.bw_set ? SDV_LF_BW_SET : 0) |
+    r.flags = (uint8_t)((l.ref_sweeped ? SDV_LF_REF_SWEEPED : 0) | (l.coords_sweeped ? SDV_LF_COORDS_SWEEPED : 0) | (l.by_ext_tune ? SDV_LF_BY_EXT_TUNE : 0) | (l.bw_set ? SDV_LF_BW_SET : 0) |
                         (l.coords_set ? SDV_LF_COORDS_SET : 0) | (l.forced_bad ? SDV_LF_FORCED_BAD : 0) | (crc_valid(l) ? SDV_LF_CRC_VALID : 0) |
                         (from_doubled ? SDV_LF_FROM_DOUBLED : 0));
     r._pad[0] = r._pad[1] = r._pad[2] = 0;
@@ -594,7 +720,11 @@ __device__ inline void stage_row(uint8_t *px, const uint8_t *row, int width)
 /* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, for the video line staged in lds.w.px: the stage machine from
  * what the caller has preset on its Binarizer (`b`: in_black / in_white / in_ref / in_coord, limits by mode) to the finished line.
  * A pure function of the pixels, the presets, the mode and the fine settings. */
-__device__ inline void process_line_p1(BinCtx &c, const Bin &b, bool coord_search, P1Lds &lds, L1 &out, bool vl_doubled)
+/* kInsane: the build for MODE_INSANE, the only one that holds the reference level sweep (kept out of the kernels of the other modes:
+ * with it in the same function their register allocation and their rates suffer - measured 736 k -> 574-648 k frames/s for the PCM-1
+ * frame driver, 372 k -> 240 k for the PCM-16x0 one) */
+template <bool kInsane>
+__device__ inline void process_line_p1(BinCtx &c, Bin &b, bool coord_search, P1Lds &lds, L1 &out, bool vl_doubled)
 {
     p1_clear(out);
     out.coords.doubled = vl_doubled;
@@ -610,7 +740,7 @@ __device__ inline void process_line_p1(BinCtx &c, const Bin &b, bool coord_searc
 
     for (int stage_count = 1; ; stage_count++) {
         if (state == STG_INPUT_ALL) {                           /* :774-931 */
-            if (!out.bw_set) find_black_white_p1(c, lds.w, out, was_bw_scanned);
+            if (!out.bw_set) find_black_white_p1(c, lds.w, out, was_bw_scanned, b.do_ref_lvl_sweep);
             if (!coords_valid(forced)) out.coords = b.in_coord;
             out.ref_level = b.in_ref;
             if (!out.bw_set) state = STG_NO_GOOD;
@@ -620,14 +750,17 @@ __device__ inline void process_line_p1(BinCtx &c, const Bin &b, bool coord_searc
                 if (crc_valid(out)) { out.by_ext_tune = true; state = STG_DATA_OK; } else state = STG_REF_FIND;
             }
         } else if (state == STG_INPUT_LEVEL) {                  /* :932-1072 */
-            if (!was_bw_scanned) find_black_white_p1(c, lds.w, out, was_bw_scanned);
+            if (!was_bw_scanned) find_black_white_p1(c, lds.w, out, was_bw_scanned, b.do_ref_lvl_sweep);
             if (!coords_valid(forced)) coords_set(out.coords, (int16_t)c.scan_start, (int16_t)c.scan_end);
             out.ref_level = b.in_ref;
             state = out.bw_set ? STG_REF_FIND : STG_NO_GOOD;
         } else if (state == STG_REF_FIND) {                     /* :1073-1390 */
-            if (!was_bw_scanned) find_black_white_p1(c, lds.w, out, was_bw_scanned);
+            if (!was_bw_scanned) find_black_white_p1(c, lds.w, out, was_bw_scanned, b.do_ref_lvl_sweep);
             if (!out.bw_set) state = STG_NO_GOOD;
-            else {
+            else if ((b.do_ref_lvl_sweep = kInsane)) {          /* = (mode == MODE_INSANE), :1104-1133: the member keeps this until the next line gets here; STG_REF_SWEEP_RUN, :1391-1400 */
+                if (kInsane) calc_ref_level_by_sweep_p1(c, b, lds, out, vl_doubled, hyst_lim, shift_lim);
+                state = STG_READ_PCM;
+            } else {
                 hyst_lim = HYST_DEPTH_SAFE; shift_lim = SHIFT_STAGES_MIN;
                 state = STG_READ_PCM;
                 out.ref_level = pick_center_ref_level(c.ps, out.black, out.white);
@@ -645,7 +778,7 @@ __device__ inline void process_line_p1(BinCtx &c, const Bin &b, bool coord_searc
             if (out.coords_set) read_pcm_data<true>(c, out, lds.w.px, hyst_lim, shift_lim);
             if (crc_valid(out)) state = STG_DATA_OK;
             if (state != STG_DATA_OK) {
-                if (coords_valid(b.in_coord) && !coords_valid(forced) && !out.forced_bad && !out.coords_set) {
+                if (coords_valid(b.in_coord) && !coords_valid(forced) && !b.do_ref_lvl_sweep && !out.forced_bad && !out.coords_set) {
                     if (coords_ne(out.coords, b.in_coord)) {
                         out.coords = b.in_coord;
                         read_pcm_data<true>(c, out, lds.w.px, hyst_lim, shift_lim);
@@ -670,6 +803,7 @@ __device__ inline void process_line_p1(BinCtx &c, const Bin &b, bool coord_searc
 
 /* one line of sdv_pcm1_binarize_lines (service lines and empty lines are the caller's: they carry no pixels and are not sent to the
  * device) */
+template <bool kInsane>
 __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
 {
     stage_row(lds.w.px, a.luma + li * a.row_stride, a.width);
@@ -684,9 +818,10 @@ __device__ inline void line_body(const LineArgs1 &a, P1Lds &lds, size_t li)
         b.in_coord.start = s.in_def_start; b.in_coord.stop = s.in_def_stop; b.in_coord.doubled = s.in_def_from_doubled != 0;
     }
     bin_set_mode(b, a.mode);
-    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0; b.do_ref_lvl_sweep = false;
+    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0;
+    b.do_ref_lvl_sweep = a.states ? a.states[li].do_ref_lvl_sweep != 0 : false;
     L1 out;
-    process_line_p1(c, b, a.coord_search != 0, lds, out, a.doubled != 0);
+    process_line_p1<kInsane>(c, b, a.coord_search != 0, lds, out, a.doubled != 0);
     emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[li]);
 }
 
@@ -731,23 +866,33 @@ __device__ inline void lean_body(const LineArgs1 &a, uint8_t *px, size_t li)
 #define SDV_P1B_LEAN_WAVES_PER_EU 8
 #endif
 /* the full line: over all lines (grid-stride), or over the list the lean kernel left */
-__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_lines(sdvp1b::LineArgs1 a)
+template <bool kInsane>
+__device__ inline void lines_kernel_body(const sdvp1b::LineArgs1 &a, sdvp1b::P1Lds &lds)
 {
-    __shared__ sdvp1b::P1Lds lds;
     if (a.list) {
         /* entry blockIdx.x first, then whatever is next behind the grid: no atomic at all while the list is shorter than the grid */
         const int n = a.counters[0];
         int i = (int)blockIdx.x;
         while (i < n) {
-            sdvp1b::line_body(a, lds, (size_t)a.list[i]);
+            sdvp1b::line_body<kInsane>(a, lds, (size_t)a.list[i]);
             __syncthreads();
             if (sdv::lane_id() == 0) lds.vote[3] = (int)gridDim.x + atomicAdd(&a.counters[1], 1);
             __syncthreads();
             i = lds.vote[3];
         }
     } else {
-        for (size_t li = blockIdx.x; li < a.n_lines; li += gridDim.x) sdvp1b::line_body(a, lds, li);
+        for (size_t li = blockIdx.x; li < a.n_lines; li += gridDim.x) sdvp1b::line_body<kInsane>(a, lds, li);
     }
+}
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_lines(sdvp1b::LineArgs1 a)
+{
+    __shared__ sdvp1b::P1Lds lds;
+    lines_kernel_body<false>(a, lds);
+}
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_lines_insane(sdvp1b::LineArgs1 a)      /* MODE_INSANE */
+{
+    __shared__ sdvp1b::P1Lds lds;
+    lines_kernel_body<true>(a, lds);
 }
 __global__ void __launch_bounds__(64, SDV_P1B_LEAN_WAVES_PER_EU) sdv_k_pcm1_lines_lean(sdvp1b::LineArgs1 a)
 {

@@ -25,6 +25,11 @@ enum { COORD_CHECK_LINES = 4, COORD_CHECK_PARTS = COORD_CHECK_LINES + 2 };      
 enum { P1_LINES_PF = 245 };                                                     /* PCM1DataStitcher::LINES_PF, pcm1datastitcher.h:103 */
 
 struct PrescanRes { int16_t start, stop; uint8_t ref, valid, pad[2]; };         /* one prescan line: the coordinates and level it read valid with */
+/* pad[1]: the line found levels, i.e. it went through binarizer.cpp:1104 and left Binarizer::do_ref_lvl_sweep at "the mode is MODE_INSANE".
+ * That member is the one thing a prescan line takes over from whatever the Binarizer did before (it enters the level validation, :3409),
+ * and it only matters when min_valid_crcs > min_contrast: then every prescan line is decoded for both values of it (second half of the
+ * array) and the frame picks, line after line, the variant its own flag calls for. */
+__device__ __forceinline__ bool sweep_flag_matters(const sdv_bin_preset &ps) { return ps.min_valid_crcs > ps.min_contrast; }
 
 struct FrameArgs1 {
     FrameArgs f;                    /* geometry, flags, states, stats, scratch as for STC-007 (f.recs unused) */
@@ -62,10 +67,11 @@ __device__ inline void ctx_for_line(const FrameArgs &a, BinCtx &c, Bin &b)
     c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
     c.force_bit_picker = true;      /* binarizer.cpp:82 */
     bin_set_mode(b, a.mode);
-    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0; b.do_ref_lvl_sweep = false;
+    b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0;
 }
 
 /* ---- prescan: block = (frame, k) ------------------------------------------------------------------------------------------ */
+template <bool kInsane>
 __device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int k)
 {
     const FrameArgs &a = a1.f;
@@ -75,15 +81,26 @@ __device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int
         const int row = frame_buf_row(a, f, (k + 1) * gap);
         if (row >= 0) {
             stage_row(lds.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
-            BinCtx c; Bin b;
-            b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);           /* setGoodParameters() (:221) */
-            ctx_for_line(a, c, b);
-            L1 out;
-            process_line_p1(c, b, true, lds, out, a.doubled != 0);
-            if (crc_valid(out)) { r.start = out.coords.start; r.stop = out.coords.stop; r.ref = out.ref_level; r.valid = 1; }
+            for (int variant = 0; variant < (sweep_flag_matters(a.preset) ? 2 : 1); variant++) {
+                BinCtx c; Bin b;
+                b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);       /* setGoodParameters() (:221) */
+                ctx_for_line(a, c, b);
+                b.do_ref_lvl_sweep = variant != 0;
+                L1 out;
+                process_line_p1<kInsane>(c, b, true, lds, out, a.doubled != 0);
+                PrescanRes q = r;
+                if (crc_valid(out)) { q.start = out.coords.start; q.stop = out.coords.stop; q.ref = out.ref_level; q.valid = 1; }
+                q.pad[1] = out.bw_set || out.service == SDV_SRV_HEADER_LINE ? 1 : 0;      /* (a Header line is only recognised behind the levels) */
+                if (lane_id() == 0) a1.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k] = q;
+                __syncthreads();
+            }
+            return;
         }
     }
-    if (lane_id() == 0) a1.prescan[(size_t)f * COORD_CHECK_LINES + k] = r;
+    if (lane_id() == 0) {
+        a1.prescan[(size_t)f * COORD_CHECK_LINES + k] = r;
+        if (sweep_flag_matters(a.preset)) a1.prescan[((size_t)a.n_total + f) * COORD_CHECK_LINES + k] = r;
+    }
 }
 
 /* ---- state of a PCM-1 frame wave ------------------------------------------------------------------------------------------ */
@@ -120,10 +137,10 @@ __device__ inline void v2d1_store_state(const V2D1 &w, const WaveLds &lds, sdv_v
     if (lane_id() != 0) return;
     const V2D &v = w.v;
     sdv_v2d_state o;
-    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin._pad = 0;
+    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin.do_ref_lvl_sweep = 0;
     o.bin.in_def_start = v.bin.in_coord.start; o.bin.in_def_stop = v.bin.in_coord.stop;
     o.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.bin._pad2 = 0;
-    o.do_ref_lvl_sweep = 0; o.reset_stats = v.reset_stats ? 1 : 0;
+    o.do_ref_lvl_sweep = v.bin.do_ref_lvl_sweep ? 1 : 0; o.reset_stats = v.reset_stats ? 1 : 0;
     o.n_last_valid = (uint8_t)v.n_last; o.n_long_valid = (uint8_t)v.n_long;
     const uint16_t lm = a.doubled ? (uint16_t)((1u << v.n_last) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
     o.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); o.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
@@ -162,8 +179,10 @@ __device__ inline void v2d1_begin_frame(V2D1 &w, const FrameArgs1 &a1, WaveLds &
             /* the lines that read valid, sorted like std::sort under CoordinatePair::operator< / by level; the middle ones (:322-336) */
             uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
             for (int k = 0; k < COORD_CHECK_LINES; k++) {
-                const PrescanRes r = a1.prescan[(size_t)f * COORD_CHECK_LINES + k];
+                const int variant = (sweep_flag_matters(a.preset) && v.bin.do_ref_lvl_sweep) ? 1 : 0;
+                const PrescanRes r = a1.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k];
                 if (uni(r.valid)) { keys[n] = uniu(coords_key(r.start, r.stop)); refs[n] = (uint8_t)uni(r.ref); n++; }
+                if (uni(r.pad[1])) v.bin.do_ref_lvl_sweep = a.mode == SDV_MODE_INSANE;
             }
             for (int i = 1; i < n; i++)
                 for (int j = i; j > 0; j--) {
@@ -484,6 +503,7 @@ __device__ inline int batch1(V2D1 &w, const FrameArgs &a, WaveLds &lds, const Le
 }
 
 /* one frame */
+template <bool kInsane>
 __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
 {
     const FrameArgs &a = a1.f;
@@ -525,7 +545,7 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
             /* :853-884: the real-time modes stop searching once a field has produced enough good lines */
             bool coord_search = true;
             if (a.mode == SDV_MODE_DRAFT || a.mode == SDV_MODE_FAST) coord_search = !(v.good_coords_in_field > 2 || v.pcm_lines_in_field > 2);
-            if (!(SDV_P1_BATCH && lean_line1(lean, c, a, v.bin, lds.w.px, wl))) process_line_p1(c, v.bin, coord_search, lds, wl, doubled);
+            if (!(SDV_P1_BATCH && lean_line1(lean, c, a, v.bin, lds.w.px, wl))) process_line_p1<kInsane>(c, v.bin, coord_search, lds, wl, doubled);
             v2d1_post_line(w, a, lds.w, wl, fv_keys, fi_keys, (line_num % 2) == 0);
             emit_rec(wl, frame_no, line_num, doubled, rec++);
         }
@@ -590,7 +610,11 @@ __device__ inline sdv_v2d_state predict_state1(const PredictArgs1 &a, int k, int
     for (int j = j0; j < k; j++) {
         if (!prescan_runs(a.f, j)) continue;
         uint32_t keys[COORD_CHECK_LINES]; uint8_t refs[COORD_CHECK_LINES]; int n = 0;
-        for (int q = 0; q < COORD_CHECK_LINES; q++) { const PrescanRes r = a.prescan[(size_t)j * COORD_CHECK_LINES + q]; if (r.valid) { keys[n] = coords_key(r.start, r.stop); refs[n] = r.ref; n++; } }
+        for (int q = 0; q < COORD_CHECK_LINES; q++) {
+            const PrescanRes r = a.prescan[(size_t)j * COORD_CHECK_LINES + q];
+            if (r.valid) { keys[n] = coords_key(r.start, r.stop); refs[n] = r.ref; n++; }
+            if (r.pad[1]) p.do_ref_lvl_sweep = a.f.mode == SDV_MODE_INSANE ? 1 : 0;
+        }
         if (n == 0) continue;
         for (int i = 1; i < n; i++)
             for (int q = i; q > 0; q--) {
@@ -693,18 +717,22 @@ __device__ inline void verify_body1(const VerifyArgs1 &a, int k)
 
 } // namespace sdvp1f
 
-__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_prescan(sdvp1f::FrameArgs1 a)
-{
-    __shared__ sdvp1b::P1Lds lds;
-    const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp1f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp1f::COORD_CHECK_LINES;
-    sdvp1f::prescan_body(a, lds, f, i % sdvp1f::COORD_CHECK_LINES);
+/* two builds of the two kernels: MODE_INSANE (with the reference level sweep) and every other mode (process_line_p1) */
+#define SDV_P1F_KERNELS(SUFFIX, INSANE) \
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_prescan##SUFFIX(sdvp1f::FrameArgs1 a) \
+{ \
+    __shared__ sdvp1b::P1Lds lds; \
+    const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp1f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp1f::COORD_CHECK_LINES; \
+    sdvp1f::prescan_body<INSANE>(a, lds, f, i % sdvp1f::COORD_CHECK_LINES); \
+} \
+__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_frames_bin##SUFFIX(sdvp1f::FrameArgs1 a) \
+{ \
+    __shared__ sdvp1b::P1Lds lds; \
+    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x; \
+    sdvp1f::frame_body1<INSANE>(a, lds, f); \
 }
-__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_frames_bin(sdvp1f::FrameArgs1 a)
-{
-    __shared__ sdvp1b::P1Lds lds;
-    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x;
-    sdvp1f::frame_body1(a, lds, f);
-}
+SDV_P1F_KERNELS(, false)
+SDV_P1F_KERNELS(_insane, true)
 #ifndef SDV_EMU
 __global__ void sdv_k_pcm1_predict(sdvp1f::PredictArgs1 a)
 {

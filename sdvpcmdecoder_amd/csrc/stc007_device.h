@@ -1584,7 +1584,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
 {
     if (lane_id() != 0) return;
     sdv_v2d_state o;
-    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin._pad = 0;
+    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin.do_ref_lvl_sweep = 0;
     o.bin.in_def_start = v.bin.in_coord.start; o.bin.in_def_stop = v.bin.in_coord.stop;
     o.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.bin._pad2 = 0;
     o.do_ref_lvl_sweep = v.bin.do_ref_lvl_sweep ? 1 : 0; o.reset_stats = v.reset_stats ? 1 : 0;

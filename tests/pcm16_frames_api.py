@@ -36,8 +36,14 @@ CASES = {
     "smeared_parts_fast": (3, 48, dict(seed=723, smear=(2, 500, 600), noise_sigma=3.0), 1, {}),
     "smeared_parts_draft": (3, 48, dict(seed=724, smear=(4, 20, 120), noise_sigma=3.0), 0, {}),
     "ntsc_full": (2, 486, dict(seed=725, noise_sigma=4.0), 2, {}),
+    # MODE_INSANE: passes that do not read from what was handed on run the reference level sweep
+    "insane_smeared": (2, 16, dict(seed=732, smear=(3, 250, 330), black=50, white=100, noise_sigma=3.0), 3, {}),
+    "insane_jitter": (2, 16, dict(seed=734, jitter=2, black=40, white=90, noise_sigma=4.0), 3, {}),
+    # min_valid_crcs above min_contrast: the Binarizer's sticky sweep flag then decides whether levels 50 apart count as levels
+    "insane_flag_matters": (3, 12, dict(seed=736, black=50, white=100, noise_sigma=4.0, smear=(3, 250, 330)), 3, dict(preset=dict(min_valid_crcs=60))),
+    "insane_flag_matters_wide": (2, 12, dict(seed=737, black=40, white=120, noise_sigma=4.0, smear=(3, 250, 330)), 3, dict(preset=dict(min_valid_crcs=60))),
 }
-GOLDEN = ("noisy_normal", "jitter_draft", "dropouts_fast", "dup_lines", "file_marks", "cut_bits_normal", "smeared_parts_normal", "control_bits")
+GOLDEN = ("noisy_normal", "jitter_draft", "dropouts_fast", "dup_lines", "file_marks", "cut_bits_normal", "smeared_parts_normal", "control_bits", "insane_smeared")
 
 
 def make_input(name):
@@ -53,6 +59,8 @@ def _preset(st):
         p.horiz_start, p.horiz_stop = st["force"]
     if "first_line_dup" in st:
         p.en_first_line_dup = st["first_line_dup"]
+    for k, v in st.get("preset", {}).items():
+        setattr(p, k, v)
     return p
 
 
@@ -74,7 +82,7 @@ def run_cpu(lib, prefix, luma, mode, st, first_frame_no=1, handle=None, keep=Fal
     g("run").argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     h = handle or C.c_void_p(g("new")())
     if handle is None:
-        if "force" in st or "first_line_dup" in st:
+        if "force" in st or "first_line_dup" in st or "preset" in st:
             g("set_preset")(h, C.byref(_preset(st)))
         g("set_mode")(h, mode)
         if "check_line_dup" in st:

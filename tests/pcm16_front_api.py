@@ -86,8 +86,19 @@ CASES = {
     "silent": (dict(n=6, seed=621, silent=True, noise_sigma=2.0), dict(mode=1, feedback="good"), {}),
     "window_moves": (dict(n=12, seed=622, noise_sigma=3.0, jump_at=6, jump_to=(9, 708)), dict(mode=1, feedback="good"), {}),
     "one_bad_part": (dict(n=8, seed=623, noise_sigma=2.0, smear=(250, 330)), dict(mode=2, feedback="reset"), {}),
+    # MODE_INSANE: every pass that does not read from what was handed on runs the reference level sweep (a coordinate search per level)
+    "insane_scratch": (dict(n=2, seed=631, noise_sigma=2.0, black=40, white=110), dict(mode=3, feedback="none"), {}),
+    "insane_cut_left": (dict(n=2, seed=632, x0=-5, x1=712, noise_sigma=2.0, black=40, white=100), dict(mode=3, feedback="reset"), {}),
+    "insane_cut_right": (dict(n=2, seed=633, x0=6, x1=724, noise_sigma=2.0, black=40, white=100), dict(mode=3, feedback="reset"), {}),
+    "insane_noisy": (dict(n=8, seed=634, x0=5, x1=713, noise_sigma=9.0, blur=1), dict(mode=3, feedback="good"), {}),
+    "insane_one_bad_part": (dict(n=3, seed=635, noise_sigma=2.0, smear=(250, 330), black=50, white=100), dict(mode=3, feedback="reset"), {}),
+    "insane_level_range": (dict(n=3, seed=636, noise_sigma=4.0), dict(mode=3, feedback="none"), dict(min_ref_lvl=96, max_ref_lvl=112)),
+    "insane_forced_coords": (dict(n=3, seed=637, x0=6, x1=712), dict(mode=3, feedback="none"), dict(en_force_coords=1, horiz_start=6, horiz_stop=8)),
+    "insane_garbage": (dict(n=1, seed=638, garbage=True), dict(mode=3, feedback="good"), {}),
+    "insane_few_valid": (dict(n=2, seed=639, black=50, white=100, noise_sigma=2.0), dict(mode=3, feedback="none"), dict(min_valid_crcs=60)),
 }
-GOLDEN = ("clean_fast", "cut_bits_normal", "noisy", "heavy_noise", "control_bits", "flat_and_services", "window_moves", "one_bad_part")
+GOLDEN = ("clean_fast", "cut_bits_normal", "noisy", "heavy_noise", "control_bits", "flat_and_services", "window_moves", "one_bad_part",
+          "insane_scratch", "insane_cut_left", "insane_one_bad_part", "insane_few_valid")
 
 
 def make_case(name):

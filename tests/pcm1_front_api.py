@@ -13,7 +13,6 @@ BIN1_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words"
                        ("picked_bits_left", "u1"), ("picked_bits_right", "u1"), ("flags", "u1"), ("_pad", "u1", (3,))])
 assert BIN1_DTYPE.itemsize == 40
 LF_COORDS_SWEEPED, LF_BY_EXT_TUNE, LF_BW_SET, LF_COORDS_SET, LF_FORCED_BAD, LF_CRC_VALID = 2, 4, 8, 16, 32, 64
-RET_UNSUPPORTED = 100
 
 
 def run_lines(lib, prefix, luma, mode=1, coord_search=True, preset=None, feedback="good", services=None, doubled=False, empty=None,
@@ -83,8 +82,20 @@ CASES = {
     "garbage": (dict(n=10, seed=418, garbage=True), dict(mode=1, feedback="good"), {}),
     "flat_and_services": (dict(n=12, seed=419, flat=(2, 7), noise_sigma=2.0), dict(mode=1, feedback="good", services={4: 4, 5: 5, 9: 3}, empty=(10,)), {}),
     "window_moves": (dict(n=16, seed=420, noise_sigma=3.0, jump_at=8, jump_to=(15, 700)), dict(mode=1, feedback="good"), {}),
+    # MODE_INSANE: every line that does not read from what was handed on runs the reference level sweep (a coordinate search per level)
+    "insane_scratch": (dict(n=5, seed=431, noise_sigma=2.0), dict(mode=3, feedback="none"), {}),
+    "insane_cut_right": (dict(n=4, seed=432, x0=10, x1=728, noise_sigma=2.0), dict(mode=3, feedback="reset"), {}),
+    "insane_cut_left": (dict(n=4, seed=433, x0=-12, x1=700, noise_sigma=2.0), dict(mode=3, feedback="reset"), {}),
+    "insane_noisy_header": (dict(n=12, seed=434, x0=7, x1=709, noise_sigma=8.0, blur=1, header_every=5), dict(mode=3, feedback="good"), {}),
+    "insane_low_contrast": (dict(n=6, seed=435, black=60, white=95, noise_sigma=2.0), dict(mode=3, feedback="none"), {}),
+    "insane_level_range": (dict(n=6, seed=436, noise_sigma=4.0), dict(mode=3, feedback="none"), dict(min_ref_lvl=96, max_ref_lvl=112)),
+    "insane_forced_coords": (dict(n=5, seed=437, x0=6, x1=712), dict(mode=3, feedback="none"), dict(en_force_coords=1, horiz_start=6, horiz_stop=8)),
+    "insane_garbage": (dict(n=4, seed=438, garbage=True), dict(mode=3, feedback="good"), {}),
+    "insane_window_moves": (dict(n=10, seed=439, noise_sigma=3.0, jump_at=5, jump_to=(15, 700)), dict(mode=3, feedback="good"), {}),
+    "insane_few_valid": (dict(n=3, seed=440, black=50, white=100, noise_sigma=2.0), dict(mode=3, feedback="none"), dict(min_valid_crcs=60)),
 }
-GOLDEN = ("clean_fast", "cut_bits_normal", "noisy_header", "heavy_noise", "forced_coords", "flat_and_services", "window_moves")
+GOLDEN = ("clean_fast", "cut_bits_normal", "noisy_header", "heavy_noise", "forced_coords", "flat_and_services", "window_moves",
+          "insane_scratch", "insane_cut_left", "insane_noisy_header", "insane_few_valid")
 
 
 def make_case(name):
@@ -137,7 +148,7 @@ def run_engine_lines(lib, eng, luma, states=None, mode=1, coord_search=True, pre
     return rc, out
 
 
-STATE_DTYPE = np.dtype([("black", "u1"), ("white", "u1"), ("ref", "u1"), ("_p", "u1"), ("start", "<i2"), ("stop", "<i2"), ("doubled", "u1"), ("_p2", "u1")])
+STATE_DTYPE = np.dtype([("black", "u1"), ("white", "u1"), ("ref", "u1"), ("sweep_flag", "u1"), ("start", "<i2"), ("stop", "<i2"), ("doubled", "u1"), ("_p2", "u1")])
 assert STATE_DTYPE.itemsize == 10
 
 
@@ -167,9 +178,11 @@ def run_lines_with_states(lib, prefix, luma, states, mode=1, coord_search=True, 
     return out
 
 
-def states_from_records(recs):
+def states_from_records(recs, mode=1):
     """What setGoodParameters(previous line) leaves in the Binarizer before each line (binarizer.cpp:353-377): the levels and
-    coordinates of the last line with a valid CRC (ignoring the forced-bad mark), nothing before the first one."""
+    coordinates of the last line with a valid CRC (ignoring the forced-bad mark), nothing before the first one.  And the sticky
+    do_ref_lvl_sweep member: a line that found levels and was not read with the preset tuning went through :1104 and left it at
+    "the mode is MODE_INSANE"."""
     st = np.zeros(len(recs), dtype=STATE_DTYPE)
     cur = np.zeros(1, dtype=STATE_DTYPE)[0]
     cur["start"], cur["stop"] = -32768, 32767
@@ -177,6 +190,9 @@ def states_from_records(recs):
         st[i] = cur
         r = recs[i]
         w = r["words"]
+        if (int(r["flags"]) & LF_BW_SET) and not (int(r["flags"]) & LF_BY_EXT_TUNE):
+            cur = cur.copy()
+            cur["sweep_flag"] = 1 if mode == 3 else 0
         hdr = tuple(int(x) for x in w) == (0x0666, 0x0CCC, 0x1999, 0x1333, 0x0666, 0x0CCC, 0xCCCC)
         if int(r["calc_crc"]) == int(w[6]) or hdr:
             cur = cur.copy()
@@ -191,4 +207,14 @@ def states_from_records(recs):
                 cur["black"], cur["white"] = b, wht
             else:
                 cur["black"], cur["white"] = 0, 0
+    return st
+
+
+def states_for_run(recs, run):
+    """Per-line presets equivalent to the sequential run `run` that produced `recs`: everything for feedback "good", only the
+    sticky sweep flag (which no feedback mode touches) for "none" / "reset"."""
+    st = states_from_records(recs, run["mode"])
+    if run.get("feedback") != "good":
+        st["black"] = st["white"] = st["ref"] = 0
+        st["start"], st["stop"], st["doubled"] = -32768, 32767, 0
     return st

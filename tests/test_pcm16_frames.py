@@ -114,8 +114,6 @@ def test_emu_bad_arguments(emu_lib):
     luma = np.zeros((1, 8, 200), np.uint8)
     rc, _, _ = pf.run_engine(emu_lib, eng, luma[:, :, :180], 1, {})
     assert rc == 3                                              # SDV_ERR_SHORT_LINE: under 193 px
-    rc, _, _ = pf.run_engine(emu_lib, eng, luma, 3, {})
-    assert rc == -4 and b"INSANE" in emu_lib.sdv_last_error(eng)    # SDV_ERR_UNSUPPORTED
     f = emu_lib.sdv_pcm16x0_binarize_frames
     recs = np.zeros(27, dtype=pf.BIN16_DTYPE); st = np.zeros(1, dtype=pf.STATS_DTYPE)
     emu_lib.sdv_set_mode(eng, 1)
@@ -134,6 +132,8 @@ def _gpu_run(eng, luma, mode, st, torch, first_frame_no=1, configure=True):
             p.horiz_start, p.horiz_stop = st["force"]
         if "first_line_dup" in st:
             p.en_first_line_dup = st["first_line_dup"]
+        for k, v in st.get("preset", {}).items():
+            setattr(p, k, v)
         eng.setFineSettings(p)
         eng.setCheckLineDup(bool(st.get("check_line_dup", 1)))
     d = torch.from_numpy(np.ascontiguousarray(luma)).to("cuda:0")

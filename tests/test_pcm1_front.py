@@ -46,7 +46,7 @@ def test_oracle_matches_live_reference(name, oracle_lib):
 @pytest.mark.skipif(not libs.ref_available(), reason="reference build (oracle/_ref) not present")
 @pytest.mark.parametrize("seed", range(6))
 def test_oracle_matches_live_reference_random(seed, oracle_lib):
-    """Random geometry, levels, noise and cut-off; every mode but MODE_INSANE (whose reference level sweep is not restated)."""
+    """Random geometry, levels, noise and cut-off; every mode but MODE_INSANE (its sweep is covered by the insane_* scenarios; too slow for random runs)."""
     from sdvpcmdecoder_amd import synth
     ref = libs.load_ref()
     rng = np.random.default_rng(900 + seed)
@@ -82,13 +82,20 @@ def test_cut_off_bits_are_picked(oracle_lib):
     assert (got["words"] == words).all()
 
 
-def test_mode_insane_is_reported_unsupported_and_short_lines_rejected(oracle_lib):
+def test_short_lines_rejected(oracle_lib):
     from sdvpcmdecoder_amd import synth
     luma, _ = synth.pcm1_random_lines(2, seed=7)
-    _, rets, _ = pf.run_lines(oracle_lib, "orc_bin1_", luma, mode=3, feedback="none")
-    assert (rets == pf.RET_UNSUPPORTED).all()
     _, rets, _ = pf.run_lines(oracle_lib, "orc_bin1_", luma[:, :80], mode=1, feedback="none")
     assert (rets == 3).all()            # LB_RET_SHORT_LINE
+
+
+def test_mode_insane_sweeps_the_reference_level(oracle_lib):
+    """MODE_INSANE: a line that starts from nothing gets its reference level from the sweep (and reads with it)."""
+    from sdvpcmdecoder_amd import synth
+    luma, words = synth.pcm1_random_lines(2, seed=7, black=50, white=100)
+    got, rets, _ = pf.run_lines(oracle_lib, "orc_bin1_", luma, mode=3, feedback="none")
+    assert (rets == 0).all() and ((got["flags"] & 1) != 0).all() and ((got["flags"] & pf.LF_CRC_VALID) != 0).all()
+    assert (got["words"][:, :6] == words[:, :6]).all()
 
 
 # ---- the HIP kernel source on the CPU emulator (tests/emu) against the oracle ----------------------------------------------------
@@ -112,14 +119,13 @@ def _case_states(name, oracle_lib):
     if "empty" in run:
         keep &= run["empty"] == 0
     seq, _, _ = pf.run_lines(oracle_lib, "orc_bin1_", luma, **run)
-    states = pf.states_from_records(seq) if run.get("feedback") == "good" else np.zeros(len(luma), dtype=pf.STATE_DTYPE)
-    if run.get("feedback") != "good":
-        states["start"], states["stop"] = -32768, 32767
+    states = pf.states_for_run(seq, run)
     kw = dict(mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"], doubled=run.get("doubled", False))
     return luma[keep], states[keep], seq[keep], kw
 
 
-@pytest.mark.parametrize("name", ["clean_fast", "cut_bits_draft", "cut_left_only", "noisy_header", "forced_coords", "no_bit_picker", "window_moves", "garbage"])
+@pytest.mark.parametrize("name", ["clean_fast", "cut_bits_draft", "cut_left_only", "noisy_header", "forced_coords", "no_bit_picker", "window_moves", "garbage"]
+                         + sorted(n for n in pf.CASES if n.startswith("insane")))
 def test_emu_matches_oracle(name, emu, oracle_lib):
     lib, eng = emu
     luma, states, seq, kw = _case_states(name, oracle_lib)
@@ -139,8 +145,6 @@ def test_emu_argument_checks(emu):
     luma = np.zeros((2, 720), np.uint8)
     rc, _ = pf.run_engine_lines(lib, eng, luma[:, :80])
     assert rc == 3                      # SDV_ERR_SHORT_LINE
-    rc, _ = pf.run_engine_lines(lib, eng, luma, mode=3)
-    assert rc == -4                     # SDV_ERR_UNSUPPORTED
 
 
 # ---- the product on the GPU, through the C-ABI -------------------------------------------------------------------------------------
@@ -185,7 +189,7 @@ def test_gpu_matches_golden_from_reference(name, oracle_lib):
         keep &= run["services"] == 0
     if "empty" in run:
         keep &= run["empty"] == 0
-    states = pf.states_from_records(want)
+    states = pf.states_for_run(want, run)
     got = _gpu_run(_gpu_engine(), luma[keep], states[keep], mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"],
                    doubled=run.get("doubled", False))
     a, b = got.copy(), want[keep].copy()
