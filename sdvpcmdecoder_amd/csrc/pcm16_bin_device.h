@@ -58,7 +58,7 @@ struct L16 {                        /* PCM16X0SubLine : PCMLine (pcmline.h:137-1
 __device__ __forceinline__ uint16_t get_word(const L16 &l, int k) { return (uint16_t)(l.v >> (48 - 16 * k)); }
 
 /* PCM16X0SubLine::calcCRC (pcm16x0subline.cpp:158-170): CRC-16/CCITT-FALSE over the 48 data cells, as a GF(2)-linear map of them */
-struct Crc16Tables { uint64_t k[16]; uint16_t base; };
+struct Crc16Tables { uint64_t k[16]; uint16_t base; uint16_t col[4]; };      /* col[c]: what data cell c flips in the CRC (the Bit Picker's left bits) */
 constexpr Crc16Tables make_crc16_tables()
 {
     Crc16Tables t{};
@@ -69,6 +69,7 @@ constexpr Crc16Tables make_crc16_tables()
         uint16_t v = 0;
         for (int i = 0; i < 48; i++) v = crc16_step(v, i == b);
         for (int j = 0; j < 16; j++) if (v & (1u << j)) t.k[j] |= (1ull << (63 - b));
+        if (b < 4) t.col[b] = v;
     }
     return t;
 }
@@ -131,11 +132,12 @@ __device__ __forceinline__ int part_start_bit(uint8_t part) { return part == PAR
 __device__ inline void fill_pcm16(L16 &l, const uint8_t *px_row, uint8_t part, int stage)
 {
     const int b0 = part_start_bit(part);
-    uint64_t a_lo = 0, b_lo = 0;
-    for (int i = 0; i < P16_DATA; i++) {
-        const uint8_t px = px_row[pixel_of(l, b0 + i, stage)];
-        a_lo |= (uint64_t)(px > l.ref_low ? 1 : 0) << i; b_lo |= (uint64_t)(px >= l.ref_high ? 1 : 0) << i;
-    }
+    int32_t acc = (int32_t)((uint32_t)b0 * l.psm + l.hpsm) + (((int32_t)l.pso + shift_of_stage(stage)) << 7);
+    const int32_t lo = l.pixel_start, hi = (int32_t)l.pixel_stop - 1;
+    uint32_t a0, a1, c0, c1;
+    compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a0, c0);
+    compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a1, c1);
+    const uint64_t a_lo = (uint64_t)a0 | ((uint64_t)a1 << 32), b_lo = (uint64_t)c0 | ((uint64_t)c1 << 32);
     uint64_t s_lo, s_hi;
     solve_automaton_lane(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
     l.v = __brevll(s_lo);
@@ -191,7 +193,7 @@ __device__ inline void pick_cut_bits(const BinCtx &c, L16 &l, uint8_t part)
         int found = 0; uint32_t fix = 0; uint16_t crc_fix = 0;
         for (uint32_t i = 0; i < lim; i++) {
             uint32_t crc = base;
-            for (int t = 0; t < bits; t++) if ((i >> t) & 1u) { uint32_t col = 0; for (int j = 0; j < 16; j++) col |= (uint32_t)((c_crc16.k[j] >> (sh + t)) & 1ull) << j; crc ^= col; }
+            for (int t = 0; t < bits; t++) if ((i >> t) & 1u) crc ^= c_crc16.col[bits - 1 - t];       /* bit t of the value sits at bit sh + t of v = data cell bits - 1 - t */
             if ((uint16_t)crc == crcc) { if (found) { found = 2; break; } found = 1; fix = i; crc_fix = (uint16_t)crc; }
         }
         if (found == 2) { l.forced_bad = true; return; }

@@ -64,7 +64,7 @@ __device__ inline void set_word0(L1 &l, uint16_t w) { l.v = (l.v & ~word_at(0x1F
 __device__ inline void set_crcc(L1 &l, uint16_t w) { l.v = (l.v & ~(u128)0xFFFF) | (u128)w; }                                   /* PCM1Line::setWord(WORD_CRCC) */
 
 /* the same CRC as a GF(2)-linear map of the cells (cell b = bit b of lo for b < 64, bit b-64 of hi): parity masks per CRC bit */
-struct Crc1Tables { uint64_t klo[16], khi[16]; uint16_t base; };
+struct Crc1Tables { uint64_t klo[16], khi[16]; uint16_t base; uint16_t col[4]; };      /* col[i]: what cell i of the line flips in the CRC (the Bit Picker's left bits) */
 constexpr Crc1Tables make_crc1_tables()
 {
     Crc1Tables t{};
@@ -76,6 +76,7 @@ constexpr Crc1Tables make_crc1_tables()
         for (int i = 0; i < 78; i++) v = crc16_step(v, i == b);
         for (int j = 0; j < 16; j++)
             if (v & (1u << j)) { if (b < 64) t.klo[j] |= (1ull << b); else t.khi[j] |= (1ull << (b - 64)); }
+        if (b < 4) t.col[b] = v;
     }
     return t;
 }
@@ -161,17 +162,14 @@ __device__ inline int pixel_of(const L1 &l, int bit, int stage)
  * cell are collected as masks and the automaton is solved on them (solve_automaton), the CRC comes from the parity masks */
 __device__ inline void fill_pcm1(L1 &l, const uint8_t *px_row, int stage)
 {
-    uint64_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
-    for (int bit = 0; bit < 64; bit++) {
-        const uint8_t px = px_row[pixel_of(l, bit, stage)];
-        a_lo |= (uint64_t)(px > l.ref_low ? 1 : 0) << bit; b_lo |= (uint64_t)(px >= l.ref_high ? 1 : 0) << bit;
-    }
-    for (int bit = 64; bit < P1_BITS; bit++) {
-        const uint8_t px = px_row[pixel_of(l, bit, stage)];
-        a_hi |= (uint64_t)(px > l.ref_low ? 1 : 0) << (bit - 64); b_hi |= (uint64_t)(px >= l.ref_high ? 1 : 0) << (bit - 64);
-    }
+    int32_t acc = (int32_t)l.hpsm + (((int32_t)l.pso + shift_of_stage(stage)) << 7);
+    const int32_t lo = l.pixel_start, hi = (int32_t)l.pixel_stop - 1;
+    uint32_t a0, a1, a2, b0, b1, b2;
+    compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a0, b0);
+    compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a1, b1);
+    compare_cells32<P1_BITS - 64>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a2, b2);
     uint64_t s_lo, s_hi;
-    solve_automaton_lane(a_lo, a_hi, b_lo, b_hi, s_lo, s_hi);
+    solve_automaton_lane((uint64_t)a0 | ((uint64_t)a1 << 32), (uint64_t)a2, (uint64_t)b0 | ((uint64_t)b1 << 32), (uint64_t)b2, s_lo, s_hi);
     s_hi &= (1ull << (P1_BITS - 64)) - 1ull;
     l.v = ((u128)__brevll(s_lo) << 30) | (u128)(__brevll(s_hi) >> 34);
     l.calc_crc = crc_of_masks(s_lo, s_hi);
@@ -272,15 +270,12 @@ __device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
     uint64_t s_lo, s_hi;
     cell_masks(data_clean, s_lo, s_hi);
     const uint16_t base = crc_of_masks(s_lo, s_hi);
-    uint16_t col[4] = { 0, 0, 0, 0 };       /* what cell i of the line flips in the CRC */
-#pragma unroll
-    for (int i = 0; i < 4; i++) if (i < left_bits) { uint32_t x = 0; for (int j = 0; j < 16; j++) x |= (uint32_t)((c_crc1.klo[j] >> i) & 1ull) << j; col[i] = (uint16_t)x; }
     const uint32_t left_lim = left_bits ? (1u << left_bits) : 1u;
     int found = 0; uint32_t li_fix = 0; uint16_t crc_fix = 0;
     for (uint32_t li = 0; li < left_lim; li++) {
         uint16_t crc = base;
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (i < left_bits && ((li >> (left_bits - 1 - i)) & 1u)) crc ^= col[i];       /* the top bit of the value is the first cell */
+        for (int i = 0; i < 4; i++) if (i < left_bits && ((li >> (left_bits - 1 - i)) & 1u)) crc ^= c_crc1.col[i];       /* the top bit of the value is the first cell */
         if ((uint16_t)(crc & ~right_mask) == right_clean) { if (found) { found = 2; break; } found = 1; li_fix = li; crc_fix = crc; }
     }
     if (found == 2) { l.forced_bad = true; return; }        /* two values fit: the line is put back as it was and marked */

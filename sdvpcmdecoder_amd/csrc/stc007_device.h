@@ -410,6 +410,50 @@ __device__ inline void solve_automaton_lane(uint64_t a_lo, uint64_t a_hi, uint64
     s_hi = (((y_hi ^ x_hi) & ~e_hi) | u_hi) ^ pt_hi;
 }
 
+/* The two comparison masks (px > low, px >= high) of kCount <= 32 consecutive cells for ONE lane on its own (the candidate reads of the
+ * marker-less coordinate searches): cell k is sampled at pixel (acc >> 7) clamped to [lo, hi], acc advancing by psm per cell (acc holds
+ * cell * psm + psm / 2 + 128 * (data start + pixel shift): the cell centre of getVideoPixeBylCalc, pcmline.cpp:249-311, in 1/128 pixel).
+ * Written for the issue rate: the bytes are fetched eight at a time before they are used, a comparison is one subtraction whose sign is
+ * shifted into the mask (v_alignbit), no 64-bit shifts.  First cell in bit 0. */
+__device__ __forceinline__ uint32_t shl1_sign(uint32_t m, int32_t t)
+{
+#ifdef SDV_EMU
+    return (m << 1) | ((uint32_t)t >> 31);
+#else
+    return __builtin_amdgcn_alignbit(m, (uint32_t)t, 31);
+#endif
+}
+template <int kN>
+__device__ __forceinline__ void compare_cells_block(const uint8_t *px_row, int32_t &acc, int32_t psm, int32_t lo, int32_t hi, int32_t ref_low, int32_t rh1,
+                                                    uint32_t &am, uint32_t &bm)
+{
+    int32_t px[kN];
+#pragma unroll
+    for (int j = 0; j < kN; j++) {
+        int32_t vp = acc >> 7; acc += psm;
+        vp = vp < lo ? lo : (vp > hi ? hi : vp);
+        px[j] = px_row[vp];
+    }
+#pragma unroll
+    for (int j = 0; j < kN; j++) { am = shl1_sign(am, ref_low - px[j]); bm = shl1_sign(bm, rh1 - px[j]); }
+}
+#ifndef SDV_CELLS_UNROLL
+#define SDV_CELLS_UNROLL 4          /* blocks of eight cells unrolled per mask (4 = all; 1 = a loop: 1-3 % slower on the PCM frame drivers, measured) */
+#endif
+template <int kCount>
+__device__ __forceinline__ void compare_cells32(const uint8_t *px_row, int32_t &acc, int32_t psm, int32_t lo, int32_t hi, int32_t ref_low, int32_t ref_high,
+                                                uint32_t &a, uint32_t &b)
+{
+    static_assert(kCount > 0 && kCount <= 32, "one 32-bit mask");
+    uint32_t am = 0, bm = 0;
+    const int32_t rh1 = ref_high - 1;           /* px >= high  <=>  high - 1 - px < 0 */
+#pragma unroll SDV_CELLS_UNROLL
+    for (int blk = 0; blk < kCount / 8; blk++) compare_cells_block<8>(px_row, acc, psm, lo, hi, ref_low, rh1, am, bm);
+    if (kCount % 8) compare_cells_block<(kCount % 8) ? (kCount % 8) : 1>(px_row, acc, psm, lo, hi, ref_low, rh1, am, bm);
+    a = __brev(am) >> (32 - kCount); b = __brev(bm) >> (32 - kCount);
+}
+__device__ __forceinline__ int32_t shift_of_stage(int stage) { return stage == 0 ? 0 : (stage == 1 ? 1 : (stage == 2 ? -1 : (stage == 3 ? 2 : -2))); }
+
 __device__ __forceinline__ uint16_t rev14(uint32_t v) { return (uint16_t)(__brev(v) >> 18); }
 __device__ __forceinline__ uint16_t rev16(uint32_t v) { return (uint16_t)(__brev(v) >> 16); }
 
