@@ -25,6 +25,7 @@ using namespace sdv;
 using sdvp1b::BinCtx;
 using sdvp1b::stats_reset;
 using sdvp1b::stats_update;
+using sdvp1b::stats_update_fresh;
 using sdvp1b::sweep_blank;
 using sdvp1b::rs_store;
 using sdvp1b::rs_unpack;
@@ -322,12 +323,11 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
         for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[SW_LEFT + i] = sweep_blank();
         for (int row = 0; row < nl; row++) {
             if (forced || !((rows_live >> row) & 1ull)) { last_read = (row * nr + nr - 1) * P16_SUBLINES + 2; continue; }      /* nothing reads in this row: it changes nothing */
+            /* the row's tables are not cleared: everything below reads only the entries this row has written (the columns it visited, the
+             * span between its first and last valid column) and the statistics start over by count */
             uint8_t valid_right = 0, valid_p[3] = { 0, 0, 0 }, right_ofs = 0xFF;
-            for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) { sw[SW_P0 + i] = sw[SW_P1 + i] = sw[SW_P2 + i] = sw[SW_RIGHT + i] = sweep_blank(); }
-            stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
-            for (int p = 0; p < 3; p++) stats_reset(lds.pstats[p], MAX_COLL_CRCS);
             bool lock_right = false, lock_min = false;
-            int step_min = 0, step_max = P16_SEARCH_STEP_CNT;
+            int step_min = 0, step_max = P16_SEARCH_STEP_CNT, n_vis = 0;
             const int16_t start_ofs = (int16_t)(l0 + row * scan_step);
             for (int col = 0; col < nr; col++) {
                 const int16_t stop_ofs = (int16_t)(r1 - col * scan_step);
@@ -342,22 +342,24 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
                     sw[(p == 0 ? SW_P0 : (p == 1 ? SW_P1 : SW_P2)) + col] = grid_entry(ge, ok[p], start_ofs, stop_ofs);
                     if (ok[p]) {
                         const SweepEnt &e = sw[(p == 0 ? SW_P0 : (p == 1 ? SW_P1 : SW_P2)) + col];
-                        stats_update(lds.pstats[p], e.crc, e.hyst, e.shift, valid_p[p]);
+                        stats_update_fresh(lds.pstats[p], e.crc, e.hyst, e.shift, valid_p[p]);
                         if (!lock_min) { step_min = col; lock_min = true; }
                         step_max = col;
                     }
                     if (!forced && ((g >> 25) & 1) != 0) { forced = true; if (coll_read < 0) coll_read = q; }
                     last_read = q;
                 }
+                n_vis = col + 1;
                 if (lock_right && !ok[0] && !ok[1] && !ok[2]) break;
                 if (!lock_right && ok[0] && ok[1] && ok[2]) lock_right = true;
             }
+            if (!lock_min) continue;        /* nothing read valid in this row (a collision made it live): no vote, nothing to hand up */
             for (int p = 0; p < 3; p++)
                 if (valid_p[p] > 0) {
                     sdvp1b::stats_most_frequent(lds.pstats[p], valid_p[p]);
                     const int base = p == 0 ? SW_P0 : (p == 1 ? SW_P1 : SW_P2);
                     /* invalidateNonFrequentCRCs (:1931-1982) on this part's row */
-                    for (int i = 0; i < P16_SEARCH_STEP_CNT; i++)
+                    for (int i = 0; i < n_vis; i++)
                         if (sw[base + i].result == REF_CRC_OK) { if (valid_p[p] == 0 || sw[base + i].crc != lds.pstats[p][0].crc) sw[base + i].result = REF_CRC_COLL; }
                 }
             if (step_max >= P16_SEARCH_STEP_CNT) step_max = P16_SEARCH_STEP_CNT - 1;
@@ -373,40 +375,33 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
                     if (p2.result == REF_CRC_OK) { valid_crcs++; hy = (uint8_t)(hy + p2.hyst); if (p2.shift > r.shift) r.shift = p2.shift; } else hy = (uint8_t)(hy + HYST_DEPTH_SAFE);
                     if (p0.result == REF_CRC_OK) { valid_crcs++; hy = (uint8_t)(hy + p0.hyst); if (p0.shift > r.shift) r.shift = p0.shift; } else hy = (uint8_t)(hy + HYST_DEPTH_SAFE);
                     r.hyst = sat_f(hy);
-                    stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                    stats_update_fresh(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
                 } else if (p0.result == REF_CRC_OK && p2.result == REF_CRC_OK) {
                     valid_crcs = 2;
                     r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.hyst = p2.hyst; r.shift = p2.shift; r.start = p2.start; r.stop = p2.stop;
                     if (p0.hyst > r.hyst) { r.hyst = p0.hyst; r.shift = p0.shift; }
                     else if (p0.hyst == r.hyst) { if (p0.shift > r.shift) r.shift = p0.shift; }
                     r.hyst = sat_f((uint8_t)(r.hyst + HYST_DEPTH_SAFE));
-                    stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                    stats_update_fresh(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
                 } else r.result = REF_BAD_CRC;
                 if (valid_crcs == P16_SUBLINES) lock_left = true;
             }
-            /* pickLevelByCRCStats works on WaveLds::sweep from index 0: the combined row is copied there for the call */
             auto pick_right = [&](uint8_t &ofs) -> bool {
-                SweepEnt keep[P16_SEARCH_STEP_CNT];
-                for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) { keep[i] = sw[i]; sw[i] = sw[SW_RIGHT + i]; }
-                const bool ok = pick_level_by_crc_stats(lds.w, &ofs, (uint8_t)step_min, (uint8_t)step_max, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) == SPAN_OK;
-                for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[i] = keep[i];
-                return ok;
+                return pick_level_by_crc_stats_at(sw + SW_RIGHT, &ofs, (uint8_t)step_min, (uint8_t)step_max, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) == SPAN_OK;
             };
             if (valid_right > 0) if (!pick_right(right_ofs)) valid_right = 0;
             if (valid_right == 0) {
-                for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[SW_RIGHT + i] = sweep_blank();
-                stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
                 for (int i = step_min; i <= step_max; i++) {
                     SweepEnt &r = sw[SW_RIGHT + i];
                     const SweepEnt p0 = sw[SW_P0 + i], p2 = sw[SW_P2 + i];
                     if (p2.result == REF_CRC_OK) {
                         r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.shift = p2.shift; r.start = p2.start; r.stop = p2.stop;
                         r.hyst = sat_f((uint8_t)(p2.hyst + HYST_DEPTH_MAX));
-                        stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                        stats_update_fresh(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
                     } else if (p0.result == REF_CRC_OK) {
                         r.result = REF_CRC_OK; r.crc = P16_CRC_SILENT; r.shift = p0.shift; r.start = p0.start; r.stop = p0.stop;
                         r.hyst = sat_f((uint8_t)(p0.hyst + 2 * HYST_DEPTH_SAFE));
-                        stats_update(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
+                        stats_update_fresh(lds.w.crc_stats, r.crc, r.hyst, r.shift, valid_right);
                     } else r.result = REF_BAD_CRC;
                 }
                 if (valid_right > 0) if (!pick_right(right_ofs)) valid_right = 0;
@@ -430,12 +425,10 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
             for (int i = 0; i < P16_SEARCH_STEP_CNT; i++)
                 if (sw[SW_LEFT + i].result == REF_CRC_OK) { if (valid_left == 0 || sw[SW_LEFT + i].crc != lds.lstats[0].crc) sw[SW_LEFT + i].result = REF_CRC_COLL; }
         }
-        if (valid_left > 0) {
-            for (int i = 0; i < P16_SEARCH_STEP_CNT; i++) sw[i] = sw[SW_LEFT + i];
-            if (pick_level_by_crc_stats(lds.w, &left_ofs, 0, P16_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
-        }
+        if (valid_left > 0)
+            if (pick_level_by_crc_stats_at(sw + SW_LEFT, &left_ofs, 0, P16_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
         lds.vote[0] = valid_left > 0 ? 1 : 0;
-        if (valid_left > 0) { lds.vote[1] = sw[left_ofs].start; lds.vote[2] = sw[left_ofs].stop; }
+        if (valid_left > 0) { lds.vote[1] = sw[SW_LEFT + left_ofs].start; lds.vote[2] = sw[SW_LEFT + left_ofs].stop; }
         lds.vote[3] = last_read; lds.vote[4] = coll_read;
     }
     __syncthreads();

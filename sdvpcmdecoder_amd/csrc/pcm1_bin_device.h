@@ -339,6 +339,16 @@ __device__ inline void stats_update(CrcStat *a, uint16_t crc, uint8_t hyst, uint
         if (valid_cnt < MAX_COLL_CRCS) { a[valid_cnt].crc = crc; a[valid_cnt].hyst = hyst; a[valid_cnt].shift = shift; a[valid_cnt].result++; }
     }
 }
+/* the same on a table that was not cleared: a new entry starts its count at one (never more entries than the table holds here: one per
+ * candidate of a grid row) */
+__device__ inline void stats_update_fresh(CrcStat *a, uint16_t crc, uint8_t hyst, uint8_t shift, uint8_t &valid_cnt)
+{
+    for (uint8_t i = 1; i <= valid_cnt; i++)
+        if (a[i].crc == crc) { a[i].result++; return; }
+    valid_cnt++;
+    a[valid_cnt].crc = crc; a[valid_cnt].hyst = hyst; a[valid_cnt].shift = shift; a[valid_cnt].result = 1;
+}
+static_assert(P1_SEARCH_STEP_CNT < MAX_COLL_CRCS, "a row of the PCM-1 grid fits the statistics table");
 __device__ inline void stats_most_frequent(CrcStat *a, uint8_t &valid_cnt)     /* :1829-1928, skip_equal */
 {
     a[0].result = 0; a[0].idx = 0; a[0].hyst = 0; a[0].shift = 0;
@@ -404,16 +414,14 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
     if (lane == 0) {
         uint8_t valid_left = 0, left_ofs = 0xFF;
         stats_reset(lds.lstats, MAX_COLL_CRCS);
-        for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) lds.w.sweep[P1_LEFT_BASE + i] = sweep_blank();
+        for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) { lds.w.sweep[P1_LEFT_BASE + i] = sweep_blank(); lds.w.sweep[i] = sweep_blank(); }
         for (int row = 0; row < nl; row++) {
             if (!((rows_live >> row) & 1ull)) {      /* nothing reads in this row: its entry in the left sweep is the "bad" one */
                 SweepEnt le = sweep_blank(); le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX;
                 lds.w.sweep[P1_LEFT_BASE + row] = le;
                 continue;
             }
-            uint8_t valid_right = 0, right_ofs = 0xFF;
-            for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) lds.w.sweep[i] = sweep_blank();
-            stats_reset(lds.w.crc_stats, MAX_COLL_CRCS);
+            uint8_t valid_right = 0, right_ofs = 0xFF;         /* (every row writes the same nr entries of the right sweep, the rest stay blank; the statistics start over by count) */
             for (int col = 0; col < nr; col++) {
                 const int q = row * nr + col;
                 const uint32_t g = lds.grid[q];
@@ -424,7 +432,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
                 const bool valid = ((g >> 24) & 1) != 0 && (uint32_t)q < first_coll;
                 e.result = valid ? REF_CRC_OK : REF_BAD_CRC;
                 lds.w.sweep[col] = e;
-                if (valid) stats_update(lds.w.crc_stats, e.crc, e.hyst, e.shift, valid_right);
+                if (valid) stats_update_fresh(lds.w.crc_stats, e.crc, e.hyst, e.shift, valid_right);
             }
             if (valid_right > 0) {
                 stats_most_frequent(lds.w.crc_stats, valid_right);

@@ -946,10 +946,10 @@ __device__ inline void sweep_invalidate_non_frequent(WaveLds &lds, uint8_t low_l
         index--;
     }
 }
-__device__ inline uint8_t pick_level_by_crc_stats(const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
-                                                  uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :1985-2140 */
+/* crcs: the table the indices count from (WaveLds::sweep, or a row inside it) */
+__device__ inline uint8_t pick_level_by_crc_stats_at(const SweepEnt *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+                                                     uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :1985-2140 */
 {
-    const SweepEnt *crcs = lds.sweep;
     bool good_ref_det = false, range_lock = false, second_start_lock = false;
     uint8_t index, low_depth = 0xFF, low_shift = 0xFF, low_ref = 0, high_ref = 0, tst_low_ref = 0, tst_high_ref = 0, picked_ref;
     index = high_lvl;
@@ -983,6 +983,11 @@ __device__ inline uint8_t pick_level_by_crc_stats(const WaveLds &lds, uint8_t *r
     picked_ref = (uint8_t)(low_ref + picked_ref);
     *ref_result = picked_ref;
     return SPAN_OK;
+}
+__device__ inline uint8_t pick_level_by_crc_stats(const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+                                                  uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)
+{
+    return pick_level_by_crc_stats_at(lds.sweep, ref_result, low_lvl, high_lvl, target_result, max_hyst, max_shift);
 }
 __device__ inline uint8_t pick_level_by_crc_stats_opt(const sdv_bin_preset &ps, const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
                                                       uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :2143-2383 */
