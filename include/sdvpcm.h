@@ -257,6 +257,11 @@ int sdv_reset_stream(sdv_engine *e);
 /* The feedback state after the last frame decoded so far (and a way to resume from a saved one). */
 int sdv_get_chain_state(const sdv_engine *e, sdv_v2d_state *out);
 int sdv_set_chain_state(sdv_engine *e, const sdv_v2d_state *in);
+/* The same for a PCM-16x0 stream, whose window of last valid coordinates holds 27 entries (three sub-lines per video line): an opaque
+ * blob of sdv_pcm16x0_chain_state_size() bytes (192).  PCM-1 streams use sdv_get/set_chain_state. */
+size_t sdv_pcm16x0_chain_state_size(void);
+int sdv_get_pcm16x0_chain_state(const sdv_engine *e, void *out, size_t cap);
+int sdv_set_pcm16x0_chain_state(sdv_engine *e, const void *in, size_t n);
 
 /* flags of sdv_binarize_frames */
 enum {
@@ -530,6 +535,15 @@ enum { SDV_FA16_SILENCE = 1 << 4, SDV_FA16_PADDING_OK = 1 << 5, SDV_FA16_EI_FORM
 void sdv_default_pcm16x0_stitch_settings(sdv_pcm16x0_stitch_settings *st);
 /* Applies the settings and starts a fresh PCM16X0DataStitcher (statistics and queued lines are dropped). */
 int sdv_set_pcm16x0_stitch_settings(sdv_engine *e, const sdv_pcm16x0_stitch_settings *st);
+/* PCM16X0DataStitcher's stream state as an opaque blob (the padding and Control Bit statistics rings, oldest entry first, and the
+ * Control Bit values of the last frame): checkpoints, and the hand-over to the engine of the next GPU of a sharded tape (DESIGN.md
+ * section 7).  sdv_set_pcm16x0_stitch_state drops sub-lines of an unfinished frame.  sdv_saturate_pcm16x0_stitch_stats fills every ring
+ * with its most frequent entry (an engine that joined the stream after a short warm-up, about to compare its state with the true one). */
+size_t sdv_pcm16x0_stitch_state_size(void);
+int sdv_get_pcm16x0_stitch_state(sdv_engine *e, void *out, size_t cap);
+int sdv_set_pcm16x0_stitch_state(sdv_engine *e, const void *in, size_t n);
+int sdv_saturate_pcm16x0_stitch_stats(sdv_engine *e);
+
 /* PCM16X0DataStitcher::doFrameReassemble (pcm16x0datastitcher.cpp:5652-5856) over a span of the PCM-16x0 sub-line stream
  * (sdv_pcm16x0_binarize_frames' out_lines, service lines included): every complete frame (records up to its END_FRAME) is trimmed
  * (findFrameTrim :213), split into fields (:566), scanned for false-positive CRCs of the Bit Picker (:753), aligned - SI format:

@@ -173,6 +173,13 @@ def load_library(path: str | None = None):
     lib.sdv_get_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_set_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_saturate_stitch_stats.argtypes = [C.c_void_p]
+    lib.sdv_pcm16x0_chain_state_size.restype = C.c_size_t
+    lib.sdv_get_pcm16x0_chain_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_set_pcm16x0_chain_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_pcm16x0_stitch_state_size.restype = C.c_size_t
+    lib.sdv_get_pcm16x0_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_set_pcm16x0_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_saturate_pcm16x0_stitch_stats.argtypes = [C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -260,6 +267,27 @@ class Engine:
 
     def saturate_stitch_stats(self):
         self._check(self.lib.sdv_saturate_stitch_stats(self._h))
+
+    def get_pcm16x0_chain_state(self) -> bytes:
+        n = self.lib.sdv_pcm16x0_chain_state_size()
+        buf = C.create_string_buffer(n)
+        self._check(self.lib.sdv_get_pcm16x0_chain_state(self._h, buf, n))
+        return buf.raw
+
+    def set_pcm16x0_chain_state(self, state: bytes):
+        self._check(self.lib.sdv_set_pcm16x0_chain_state(self._h, C.create_string_buffer(state, len(state)), len(state)))
+
+    def get_pcm16x0_stitch_state(self) -> bytes:
+        n = self.lib.sdv_pcm16x0_stitch_state_size()
+        buf = C.create_string_buffer(n)
+        self._check(self.lib.sdv_get_pcm16x0_stitch_state(self._h, buf, n))
+        return buf.raw
+
+    def set_pcm16x0_stitch_state(self, state: bytes):
+        self._check(self.lib.sdv_set_pcm16x0_stitch_state(self._h, C.create_string_buffer(state, len(state)), len(state)))
+
+    def saturate_pcm16x0_stitch_stats(self):
+        self._check(self.lib.sdv_saturate_pcm16x0_stitch_stats(self._h))
 
     def set_profiling(self, on: bool = True):
         self._check(self.lib.sdv_set_profiling(self._h, int(on)))

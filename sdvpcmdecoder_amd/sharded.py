@@ -108,6 +108,98 @@ class ShardedDecoder:
         return pairs, frames
 
 
+class ShardedPcmDecoder:
+    """The same for a PCM-1 or PCM-16x0 tape (`fmt` "pcm1" / "pcm16x0").  These formats need no successor frame (a frame is stitched
+    from its own lines) and PCM-1's stitcher carries nothing from frame to frame, so what crosses a range boundary is the frame
+    driver's chain state (120 / 192 bytes) and, for PCM-16x0, the stitcher's statistics rings (sdv_get_pcm16x0_stitch_state).
+    `eng`: the methods of sdvpcmdecoder_amd.Engine for the format (pcm1_binarize_frames, pcm1_bin_to_line_recs, pcm1_stitch_frames,
+    get/set_chain_state; pcm16x0_binarize_frames, pcm16x0_stitch_frames, get/set_pcm16x0_chain_state, get/set_pcm16x0_stitch_state,
+    saturate_pcm16x0_stitch_stats, set_pcm16x0_stitch_settings); `stitch_settings`: the format's stitch settings (applied where the
+    stitcher has to start afresh)."""
+
+    def __init__(self, eng, rank: int, world: int, all_gather, height: int, fmt: str, stitch_settings, warmup: int = 20, stitch_warmup: int = 4):
+        assert fmt in ("pcm1", "pcm16x0")
+        self.eng, self.rank, self.world, self.all_gather, self.fmt = eng, rank, world, all_gather, fmt
+        self.height, self.warmup, self.stitch_warmup, self.stitch_settings = height, warmup, stitch_warmup, stitch_settings
+        self.rpf = height + 3 if fmt == "pcm1" else 3 * height + 3
+        self.stats = {"binarize_redo": 0, "stitch_redo": 0, "gathers": 0}
+
+    def frames_needed(self, n_frames: int):
+        lo, hi = shard_bounds(n_frames, self.rank, self.world)
+        return lo - min(self.warmup, lo), hi
+
+    def _binarize(self, luma, **kw):
+        f = self.eng.pcm1_binarize_frames if self.fmt == "pcm1" else self.eng.pcm16x0_binarize_frames
+        return f(luma, **kw)[0]
+
+    def _chain(self, state=None):
+        if self.fmt == "pcm1":
+            return self.eng.get_chain_state() if state is None else self.eng.set_chain_state(state)
+        return self.eng.get_pcm16x0_chain_state() if state is None else self.eng.set_pcm16x0_chain_state(state)
+
+    def _stitch(self, recs):
+        if self.fmt == "pcm1":
+            return self.eng.pcm1_stitch_frames(self.eng.pcm1_bin_to_line_recs(recs))
+        return self.eng.pcm16x0_stitch_frames(recs)
+
+    def decode(self, luma, n_frames: int, first_frame_no: int = 1):
+        """luma: frames frames_needed(n_frames) of the tape.  Returns (pairs, frame descriptors) of frames lo..hi-1; concatenated over the
+        ranks: the output of one engine decoding the whole tape (NEW_FILE ... END_FILE)."""
+        eng, rank, world, rpf = self.eng, self.rank, self.world, self.rpf
+        lo, hi = shard_bounds(n_frames, rank, world)
+        f0, _ = self.frames_needed(n_frames)
+        lead, n_own, last = lo - f0, hi - lo, rank == world - 1
+        assert luma.shape[0] == hi - f0 and n_own > 0
+        # ---- binarize stage: as ShardedDecoder ------------------------------------------------------------------------
+        eng.reset_stream()
+        predicted, warm = None, None
+        if lead:
+            warm = self._binarize(luma[:lead], first_frame_no=first_frame_no + f0, new_file=False)
+            predicted = self._chain()
+
+        def run_range():
+            own = self._binarize(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
+            return own, self._chain()
+        own, final = run_range()
+        while True:
+            finals = self.all_gather(final)
+            self.stats["gathers"] += 1
+            ok = rank == 0 or predicted == finals[rank - 1]
+            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
+                break
+            if not ok:
+                self.stats["binarize_redo"] += 1
+                predicted = finals[rank - 1]
+                self._chain(predicted)
+                own, final = run_range()
+        # ---- stitch stage ---------------------------------------------------------------------------------------------
+        if self.fmt == "pcm1":
+            eng.set_pcm1_stitch_settings(self.stitch_settings)
+            return self._stitch(own)              # nothing is carried from frame to frame
+        eng.set_pcm16x0_stitch_settings(self.stitch_settings)          # a fresh stitcher
+        s_pred = None
+        s_lead = min(self.stitch_warmup, lead)
+        if s_lead:
+            self._stitch(warm[(lead - s_lead) * rpf:])              # output discarded
+            eng.saturate_pcm16x0_stitch_stats()
+            s_pred = eng.get_pcm16x0_stitch_state()
+        pairs, frames = self._stitch(own)
+        s_final = eng.get_pcm16x0_stitch_state()
+        while True:
+            finals = self.all_gather(s_final)
+            self.stats["gathers"] += 1
+            ok = rank == 0 or s_pred == finals[rank - 1]
+            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
+                break
+            if not ok:
+                self.stats["stitch_redo"] += 1
+                s_pred = finals[rank - 1]
+                eng.set_pcm16x0_stitch_state(s_pred)
+                pairs, frames = self._stitch(own)
+                s_final = eng.get_pcm16x0_stitch_state()
+        return pairs, frames
+
+
 class ShardedBinarizeLoop:
     """The binarize stage of a tape that keeps coming, batch after batch, each batch split over the ranks (what `bench.py --gpus N`
     times): batch s = frames [s*B, (s+1)*B) of the tape, rank r owns its r-th part.  Rank r's incoming state for batch s is rank

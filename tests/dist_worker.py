@@ -21,6 +21,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     if warmup < 0:
         return loop_main(out_dir, n_frames, rank, world)
+    if len(sys.argv) > 5:
+        return pcm_main(out_dir, n_frames, warmup, s_warm, sys.argv[5], rank, world)
     luma, _, _ = synth.stc007_frames(n_frames, seed=41, noise_sigma=3.0)          # every rank renders the same tape ...
     eng = EmuEngine(C.CDLL(os.path.join(HERE, "emu", "libsdvpcm_emu.so")))
     eng.set_stitch_settings(sa.default_settings())
@@ -29,6 +31,38 @@ def main():
     pairs, frames = dec.decode(luma[f0:f1], n_frames, first_frame_no=1)           # ... and is only given its part of it
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pairs=pairs.view(np.uint8).reshape(len(pairs), 12),
              frames=frames.view(np.uint8).reshape(len(frames), 64), redo=np.array([dec.stats["binarize_redo"], dec.stats["stitch_redo"], dec.stats["gathers"]]))
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def pcm_tape(fmt, n_frames):
+    """The tape of the PCM-1 / PCM-16x0 sharding tests (every rank renders the same one)."""
+    from sdvpcmdecoder_amd import synth
+    if fmt == "pcm1":
+        return synth.pcm1_frames(n_frames, seed=43, height=486, noise_sigma=3.0)[0]
+    return synth.pcm16x0_tape_frames(n_frames, seed=44, ei=(fmt == "pcm16x0_ei"))[0]
+
+
+def pcm_main(out_dir, n_frames, warmup, s_warm, fmt, rank, world):
+    """ShardedPcmDecoder: one PCM-1 / PCM-16x0 tape over the ranks."""
+    import ctypes as C
+    import torch.distributed as dist
+    from sdvpcmdecoder_amd.sharded import ShardedPcmDecoder, torch_all_gather
+    from emu_engine_adapter import EmuEngine
+    import pcm1_api as p1
+    import pcm16_api as p16
+    luma = pcm_tape(fmt, n_frames)
+    eng = EmuEngine(C.CDLL(os.path.join(HERE, "emu", "libsdvpcm_emu.so")))
+    eng.lib.sdv_set_pcm_type.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    st = p1.default_settings() if fmt == "pcm1" else p16.default_settings(format=1 if fmt == "pcm16x0_ei" else 0)
+    dec = ShardedPcmDecoder(eng, rank, world, torch_all_gather(None), height=luma.shape[1], fmt="pcm1" if fmt == "pcm1" else "pcm16x0", stitch_settings=st,
+                            warmup=warmup, stitch_warmup=s_warm)
+    f0, f1 = dec.frames_needed(n_frames)
+    pairs, frames = dec.decode(luma[f0:f1], n_frames, first_frame_no=1)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pairs=pairs.view(np.uint8).reshape(len(pairs), 12),
+             frames=frames.view(np.uint8).reshape(len(frames), frames.dtype.itemsize),
+             redo=np.array([dec.stats["binarize_redo"], dec.stats["stitch_redo"], dec.stats["gathers"]]))
     eng.close()
     dist.barrier()
     dist.destroy_process_group()

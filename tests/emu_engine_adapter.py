@@ -61,3 +61,73 @@ class EmuEngine:
 
     def saturate_stitch_stats(self):
         assert self.lib.sdv_saturate_stitch_stats(self.h) == 0
+
+    # ---- PCM-1 / PCM-16x0 (ShardedPcmDecoder) ----------------------------------------------------------------------------------
+    def _frames(self, pf, luma, first_frame_no, new_file, end_file):
+        st = {}
+        if new_file:
+            st["new_file"] = True
+        if end_file:
+            st["end_file"] = True
+        rc, recs, stats = pf.run_engine(self.lib, self.h, np.ascontiguousarray(luma), None, st, first_frame_no=first_frame_no, configure=False)
+        assert rc == 0, self.lib.sdv_last_error(self.h)
+        return recs, stats
+
+    def pcm1_binarize_frames(self, luma, first_frame_no=1, new_file=False, end_file=False):
+        import pcm1_frames_api as pf
+        return self._frames(pf, luma, first_frame_no, new_file, end_file)
+
+    def pcm16x0_binarize_frames(self, luma, first_frame_no=1, new_file=False, end_file=False):
+        import pcm16_frames_api as pf
+        return self._frames(pf, luma, first_frame_no, new_file, end_file)
+
+    def pcm1_bin_to_line_recs(self, recs):
+        import pcm1_api as p1
+        recs = np.ascontiguousarray(recs)
+        out = np.zeros(len(recs), dtype=p1.LINE1_DTYPE)
+        self.lib.sdv_pcm1_bin_to_line_recs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        assert self.lib.sdv_pcm1_bin_to_line_recs(self.h, recs.ctypes.data, len(recs), out.ctypes.data, None) == 0
+        return out
+
+    def set_pcm1_stitch_settings(self, st):
+        assert self.lib.sdv_set_pcm1_stitch_settings(self.h, C.byref(st)) == 0
+
+    def pcm1_stitch_frames(self, recs):
+        rc, pairs, frames = ea.emu_pcm1_stitch(self.lib, self.h, recs)
+        assert rc == 0, self.lib.sdv_last_error(self.h)
+        return pairs.copy(), frames.copy()
+
+    def set_pcm16x0_stitch_settings(self, st):
+        self.lib.sdv_set_pcm16x0_stitch_settings.argtypes = [C.c_void_p, C.c_void_p]
+        assert self.lib.sdv_set_pcm16x0_stitch_settings(self.h, C.byref(st)) == 0
+
+    def pcm16x0_stitch_frames(self, recs):
+        rc, pairs, frames = ea.emu_pcm16_stitch(self.lib, self.h, recs)
+        assert rc == 0, self.lib.sdv_last_error(self.h)
+        return pairs.copy(), frames.copy()
+
+    def _blob(self, size_fn, get_fn):
+        size_fn.restype = C.c_size_t
+        n = size_fn()
+        buf = C.create_string_buffer(n)
+        get_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        assert get_fn(self.h, buf, n) == 0
+        return buf.raw
+
+    def get_pcm16x0_chain_state(self):
+        return self._blob(self.lib.sdv_pcm16x0_chain_state_size, self.lib.sdv_get_pcm16x0_chain_state)
+
+    def set_pcm16x0_chain_state(self, b):
+        self.lib.sdv_set_pcm16x0_chain_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        assert self.lib.sdv_set_pcm16x0_chain_state(self.h, C.create_string_buffer(b, len(b)), len(b)) == 0
+
+    def get_pcm16x0_stitch_state(self):
+        return self._blob(self.lib.sdv_pcm16x0_stitch_state_size, self.lib.sdv_get_pcm16x0_stitch_state)
+
+    def set_pcm16x0_stitch_state(self, b):
+        self.lib.sdv_set_pcm16x0_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        assert self.lib.sdv_set_pcm16x0_stitch_state(self.h, C.create_string_buffer(b, len(b)), len(b)) == 0
+
+    def saturate_pcm16x0_stitch_stats(self):
+        self.lib.sdv_saturate_pcm16x0_stitch_stats.argtypes = [C.c_void_p]
+        assert self.lib.sdv_saturate_pcm16x0_stitch_stats(self.h) == 0

@@ -66,3 +66,36 @@ def test_two_ranks_binarize_loop(tmp_path, emu_lib, oracle_lib):
         got = np.concatenate([np.ascontiguousarray(z[f"b{batch}"]).view(libs.LINE_DTYPE).reshape(-1) for z in parts])
         assert got.tobytes() == want.tobytes(), f"batch {batch}"
     assert int(parts[1]["redo"]) >= 1
+
+
+@pytest.mark.parametrize("fmt,n_frames,warmup,s_warm", [("pcm1", 6, 2, 2), ("pcm16x0", 6, 2, 2), ("pcm16x0_ei", 5, 1, 1)])
+def test_two_ranks_one_pcm_tape(tmp_path, emu_lib, oracle_lib, fmt, n_frames, warmup, s_warm):
+    """ShardedPcmDecoder: a PCM-1 / PCM-16x0 tape over two ranks equals the sequential decode by the oracle's two workers."""
+    import dist_worker
+    import pcm1_api as p1
+    import pcm16_api as p16
+    import pcm1_frames_api as p1f
+    import pcm16_frames_api as p16f
+    from test_pcm1 import bin_to_line_recs
+    world = 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33500 + os.getpid() % 2000), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(tmp_path), str(n_frames), str(warmup), str(s_warm), fmt],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    luma = dist_worker.pcm_tape(fmt, n_frames)
+    orc = libs.load_oracle()
+    if fmt == "pcm1":
+        recs, _ = p1f.run_cpu(orc, "orc_", luma, 2, dict(new_file=True, end_file=True))
+        want_p, want_f = p1.run_cpu(orc, "orc_", bin_to_line_recs(recs), p1.default_settings())
+        fdt = p1.FRASM1_DTYPE
+    else:
+        recs, _ = p16f.run_cpu(orc, "orc_", luma, 2, dict(new_file=True, end_file=True))
+        want_p, want_f = p16.run_cpu(orc, "orc_", recs, p16.default_settings(format=1 if fmt == "pcm16x0_ei" else 0))
+        fdt = p16.FRASM16_DTYPE
+    parts = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    pairs = np.concatenate([np.ascontiguousarray(z["pairs"]).view(sa.PAIR_DTYPE).reshape(-1) for z in parts])
+    frames = np.concatenate([np.ascontiguousarray(z["frames"]).view(fdt).reshape(-1) for z in parts])
+    assert len(pairs) == len(want_p) and pairs.tobytes() == want_p.tobytes()
+    assert len(frames) == len(want_f) and frames.tobytes() == want_f.tobytes()
+    assert all(int(z["redo"][2]) >= 1 for z in parts)
