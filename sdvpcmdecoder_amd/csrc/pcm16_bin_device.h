@@ -266,6 +266,143 @@ __device__ inline void stats_most_frequent_noskip(CrcStat *a, uint8_t &valid_cnt
 }
 __device__ __forceinline__ uint8_t sat_f(int v) { return (uint8_t)(v > 0x0F ? 0x0F : v); }
 
+/* pickLevelByCRCStats (binarizer.cpp:1985-2140) over one row of the grid held by the lanes (lane = column): ok = the entry has the
+ * target result, hyst / shift = its depth and stage.  Same two passes: the lowest (depth, stage) and the highest column that has it,
+ * then the longest run of that pair below it (with the reference's rule that a run still open at the low end is never compared). */
+__device__ inline bool pick_in_row(bool ok, uint32_t hyst, uint32_t shift, int low, int high, uint8_t &picked)
+{
+    const int lane = lane_id();
+    const bool cand = ok && lane >= low && lane <= high && hyst <= 0x0Fu && shift <= (uint32_t)SHIFT_STAGES_MAX;
+    const uint32_t key = cand ? ((hyst << 4) | shift) : 0xFFFFu;
+    const uint32_t best = wave_min_u32(key);
+    if (best == 0xFFFFu) return false;
+    const uint32_t M = (uint32_t)__ballot(cand && key == best);
+    int high_ref = 31 - __clz((int)M), low_ref = 0, tst_low = 0, tst_high = 0;
+    bool range_lock = false, second = false;
+    for (int index = high_ref; ; index--) {
+        if ((M >> index) & 1u) {
+            if (!range_lock) low_ref = index;
+            else { if (!second) { tst_high = index; second = true; } tst_low = index; }
+        } else {
+            range_lock = true;
+            if (second) { second = false; if ((tst_high - tst_low) >= (high_ref - low_ref)) { low_ref = tst_low; high_ref = tst_high; } }
+        }
+        if (index == low) break;
+    }
+    picked = (uint8_t)(low_ref + (uint8_t)(high_ref - low_ref) / 2);
+    return true;
+}
+__device__ __forceinline__ uint32_t row_read(uint32_t x, int idx) { return (uint32_t)__shfl((int)x, idx); }
+
+/* The walk of searchPCM16X0Data over a grid without collisions: row after row, the columns of a row on the lanes.  What the serial walk
+ * keeps in tables is here a handful of masks: which columns read valid per part, which of those survive the part's vote, which columns
+ * combine to a valid line.  Leaves lds.vote as the serial walk does. */
+__device__ inline void walk_rows_parallel(P16Lds &lds, int nl, int nr, int l0, int r1, int scan_step, uint64_t rows_live)
+{
+    const int lane = lane_id();
+    SweepEnt *sw = lds.w.sweep;
+    uint8_t valid_left = 0;             /* lane 0's */
+    bool lock_left = false;
+    int last_read = -1;
+    if (lane == 0) stats_reset(lds.lstats, MAX_COLL_CRCS);
+    if (lane < P16_SEARCH_STEP_CNT) sw[SW_LEFT + lane] = sweep_blank();
+    __syncthreads();
+    const uint32_t colmask = nr >= 32 ? 0xFFFFFFFFu : ((1u << nr) - 1u);
+    for (int row = 0; row < nl; row++) {
+        if (!((rows_live >> row) & 1ull)) { last_read = (row * nr + nr - 1) * P16_SUBLINES + 2; continue; }
+        uint32_t g0 = 0, g1 = 0, g2 = 0;
+        if (lane < nr) { const uint32_t *gp = &lds.grid[(row * nr + lane) * P16_SUBLINES]; g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; }
+        uint32_t m0 = (uint32_t)__ballot(lane < nr && ((g0 >> 24) & 1u)), m1 = (uint32_t)__ballot(lane < nr && ((g1 >> 24) & 1u)), m2 = (uint32_t)__ballot(lane < nr && ((g2 >> 24) & 1u));
+        /* the columns the walk visits: it stops behind the window in which all three parts read, at the first column where none does */
+        int n_vis = nr;
+        {
+            const uint32_t all3 = m0 & m1 & m2, none = ~(m0 | m1 | m2) & colmask;
+            if (all3) { const int c0 = __ffs((int)all3) - 1; const uint32_t stop = c0 >= 31 ? 0u : (none & ~((2u << c0) - 1u)); if (stop) n_vis = __ffs((int)stop); }
+        }
+        const uint32_t vis = n_vis >= 32 ? 0xFFFFFFFFu : ((1u << n_vis) - 1u);
+        m0 &= vis; m1 &= vis; m2 &= vis;
+        last_read = (row * nr + n_vis - 1) * P16_SUBLINES + 2;
+        const uint32_t any = m0 | m1 | m2;
+        if (!any) continue;
+        const int step_min = __ffs((int)any) - 1, step_max = 31 - __clz((int)any);
+        /* per part: the most frequent CRC among the columns that read (first seen wins a tie; a rival with half its count or more voids
+         * the vote, findMostFrequentCRC :1829-1928), the others are marked as collisions (invalidateNonFrequentCRCs) */
+        uint32_t ok0 = 0, ok1 = 0, ok2 = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const uint32_t m = p == 0 ? m0 : (p == 1 ? m1 : m2), g = p == 0 ? g0 : (p == 1 ? g1 : g2);
+            if (!m) continue;
+            const uint32_t crc = g & 0xFFFFu;
+            const bool mine = (m >> lane) & 1u;
+            uint32_t eq = 0;
+            for (int j = step_min; j <= step_max; j++) if ((m >> j) & 1u) { const uint32_t cj = row_read(crc, j); eq |= (cj == crc ? 1u : 0u) << j; }
+            const uint32_t cnt = (uint32_t)__popc(eq), first = (uint32_t)(__ffs((int)eq) - 1);
+            const uint32_t top = wave_max_u32(mine ? ((cnt << 8) | (31u - first)) : 0u);
+            const uint32_t tcnt = top >> 8, tfirst = 31u - (top & 0xFFu);
+            const uint32_t tcrc = row_read(crc, (int)tfirst);
+            const bool rival = __ballot(mine && crc != tcrc && 2u * cnt >= tcnt) != 0ull;
+            const uint32_t okp = rival ? 0u : row_read(eq, (int)tfirst);
+            if (p == 0) ok0 = okp; else if (p == 1) ok1 = okp; else ok2 = okp;
+        }
+        /* the line a column combines to (:4893-5050) */
+        const bool o0 = (ok0 >> lane) & 1u, o1 = (ok1 >> lane) & 1u, o2 = (ok2 >> lane) & 1u;
+        const uint32_t h0 = (g0 >> 16) & 0xFu, h1 = (g1 >> 16) & 0xFu, h2 = (g2 >> 16) & 0xFu, s0 = (g0 >> 20) & 0xFu, s1 = (g1 >> 20) & 0xFu, s2 = (g2 >> 20) & 0xFu;
+        const bool in_range = lane >= step_min && lane <= step_max;
+        bool r_ok = false; uint32_t r_hyst = 0, r_shift = 0; int n3 = 0;
+        if (o1) {
+            n3 = 1; r_ok = true; r_shift = s1;
+            uint32_t hy = h1;
+            if (o2) { n3++; hy = (uint8_t)(hy + h2); if (s2 > r_shift) r_shift = s2; } else hy = (uint8_t)(hy + HYST_DEPTH_SAFE);
+            if (o0) { n3++; hy = (uint8_t)(hy + h0); if (s0 > r_shift) r_shift = s0; } else hy = (uint8_t)(hy + HYST_DEPTH_SAFE);
+            r_hyst = sat_f((int)hy);
+        } else if (o0 && o2) {
+            n3 = 2; r_ok = true; r_hyst = h2; r_shift = s2;
+            if (h0 > r_hyst) { r_hyst = h0; r_shift = s0; }
+            else if (h0 == r_hyst) { if (s0 > r_shift) r_shift = s0; }
+            r_hyst = sat_f((int)(uint8_t)(r_hyst + HYST_DEPTH_SAFE));
+        }
+        if (__ballot(in_range && n3 == P16_SUBLINES) != 0ull) lock_left = true;
+        uint8_t right_ofs = 0xFF;
+        bool valid_right = __ballot(in_range && r_ok) != 0ull;
+        if (valid_right) valid_right = pick_in_row(r_ok, r_hyst, r_shift, step_min, step_max, right_ofs);
+        if (!valid_right) {             /* the fallback: the right part alone, else the left one (:5080-5140) */
+            r_ok = false;
+            if (o2) { r_ok = true; r_shift = s2; r_hyst = sat_f((int)(uint8_t)(h2 + HYST_DEPTH_MAX)); }
+            else if (o0) { r_ok = true; r_shift = s0; r_hyst = sat_f((int)(uint8_t)(h0 + 2 * HYST_DEPTH_SAFE)); }
+            valid_right = __ballot(in_range && r_ok) != 0ull;
+            if (valid_right) valid_right = pick_in_row(r_ok, r_hyst, r_shift, step_min, step_max, right_ofs);
+        }
+        if (valid_right) {
+            const uint32_t le_h = row_read(r_hyst, right_ofs), le_s = row_read(r_shift, right_ofs);
+            if (lane == 0) {
+                SweepEnt le = sweep_blank();
+                le.result = REF_CRC_OK; le.crc = P16_CRC_SILENT; le.hyst = (uint8_t)le_h; le.shift = (uint8_t)le_s;
+                le.start = (int16_t)(l0 + row * scan_step); le.stop = (int16_t)(r1 - (int)right_ofs * scan_step);
+                sw[SW_LEFT + row] = le;
+                stats_update(lds.lstats, le.crc, le.hyst, le.shift, valid_left);
+            }
+            if (lock_left) {
+                const int nv = (int)((ok0 >> right_ofs) & 1u) + (int)((ok1 >> right_ofs) & 1u) + (int)((ok2 >> right_ofs) & 1u);
+                if (nv < 2) break;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint8_t left_ofs = 0xFF;
+        if (valid_left > 0) {
+            stats_most_frequent_noskip(lds.lstats, valid_left);
+            for (int i = 0; i < P16_SEARCH_STEP_CNT; i++)
+                if (sw[SW_LEFT + i].result == REF_CRC_OK) { if (valid_left == 0 || sw[SW_LEFT + i].crc != lds.lstats[0].crc) sw[SW_LEFT + i].result = REF_CRC_COLL; }
+        }
+        if (valid_left > 0)
+            if (pick_level_by_crc_stats_at(sw + SW_LEFT, &left_ofs, 0, P16_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
+        lds.vote[0] = valid_left > 0 ? 1 : 0;
+        if (valid_left > 0) { lds.vote[1] = sw[SW_LEFT + left_ofs].start; lds.vote[2] = sw[SW_LEFT + left_ofs].stop; }
+        lds.vote[3] = last_read; lds.vote[4] = -1;
+    }
+}
+
 /* Returns true when coordinates were found; l is left as the reference leaves its line object. */
 __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords data_loc, uint8_t &hyst_lim, uint8_t &shift_lim)
 {
@@ -308,13 +445,18 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
     /* rows of the grid in which something happens: a read that is valid, or a Bit Picker collision (the walk below leaves every other row
      * as it finds it, apart from noting its last read) */
     uint64_t rows_live;
+    bool any_coll;
     {
-        bool live = false;
-        if (lane < nl) for (int i = 0; i < nr * P16_SUBLINES; i++) live = live || ((lds.grid[lane * nr * P16_SUBLINES + i] >> 24) & 3u) != 0;
+        bool live = false, coll = false;
+        if (lane < nl) for (int i = 0; i < nr * P16_SUBLINES; i++) { const uint32_t g = lds.grid[lane * nr * P16_SUBLINES + i]; live = live || ((g >> 24) & 3u) != 0; coll = coll || ((g >> 25) & 1u) != 0; }
         rows_live = __ballot(live);
+        any_coll = __ballot(coll) != 0ull;
     }
-    /* the walk over the grid and the votes: serial, on lane 0 */
-    if (lane == 0) {
+    /* The walk over the grid and the votes.  Without a Bit Picker collision anywhere (and a line object that is not forced bad to begin
+     * with) the rows do not influence each other's reads and a row is worked on by the whole wave (walk_rows_parallel); otherwise the
+     * walk is replayed cell by cell on lane 0. */
+    if (!any_coll && !entry_forced && nr <= 32) walk_rows_parallel(lds, nl, nr, l0, r1, scan_step, rows_live);
+    else if (lane == 0) {
         SweepEnt *sw = lds.w.sweep;
         uint8_t valid_left = 0, left_ofs = 0xFF;
         bool forced = entry_forced, lock_left = false;

@@ -145,6 +145,7 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned __brev(unsigned v)
 {
     v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
