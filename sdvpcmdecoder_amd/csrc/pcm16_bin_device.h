@@ -28,6 +28,9 @@ using sdvp1b::stats_update;
 using sdvp1b::stats_update_fresh;
 using sdvp1b::sweep_blank;
 using sdvp1b::rs_store;
+using sdvp1b::pick_in_row;
+using sdvp1b::row_read;
+using sdvp1b::row_vote;
 using sdvp1b::rs_unpack;
 
 enum { P16_BITS = 193, P16_DATA = 64, P16_WORD_BITS = 16, P16_CRC_SILENT = 0x0E10, P16_SUBLINES = 3 };
@@ -266,34 +269,6 @@ __device__ inline void stats_most_frequent_noskip(CrcStat *a, uint8_t &valid_cnt
 }
 __device__ __forceinline__ uint8_t sat_f(int v) { return (uint8_t)(v > 0x0F ? 0x0F : v); }
 
-/* pickLevelByCRCStats (binarizer.cpp:1985-2140) over one row of the grid held by the lanes (lane = column): ok = the entry has the
- * target result, hyst / shift = its depth and stage.  Same two passes: the lowest (depth, stage) and the highest column that has it,
- * then the longest run of that pair below it (with the reference's rule that a run still open at the low end is never compared). */
-__device__ inline bool pick_in_row(bool ok, uint32_t hyst, uint32_t shift, int low, int high, uint8_t &picked)
-{
-    const int lane = lane_id();
-    const bool cand = ok && lane >= low && lane <= high && hyst <= 0x0Fu && shift <= (uint32_t)SHIFT_STAGES_MAX;
-    const uint32_t key = cand ? ((hyst << 4) | shift) : 0xFFFFu;
-    const uint32_t best = wave_min_u32(key);
-    if (best == 0xFFFFu) return false;
-    const uint32_t M = (uint32_t)__ballot(cand && key == best);
-    int high_ref = 31 - __clz((int)M), low_ref = 0, tst_low = 0, tst_high = 0;
-    bool range_lock = false, second = false;
-    for (int index = high_ref; ; index--) {
-        if ((M >> index) & 1u) {
-            if (!range_lock) low_ref = index;
-            else { if (!second) { tst_high = index; second = true; } tst_low = index; }
-        } else {
-            range_lock = true;
-            if (second) { second = false; if ((tst_high - tst_low) >= (high_ref - low_ref)) { low_ref = tst_low; high_ref = tst_high; } }
-        }
-        if (index == low) break;
-    }
-    picked = (uint8_t)(low_ref + (uint8_t)(high_ref - low_ref) / 2);
-    return true;
-}
-__device__ __forceinline__ uint32_t row_read(uint32_t x, int idx) { return (uint32_t)__shfl((int)x, idx); }
-
 /* The walk of searchPCM16X0Data over a grid without collisions: row after row, the columns of a row on the lanes.  What the serial walk
  * keeps in tables is here a handful of masks: which columns read valid per part, which of those survive the part's vote, which columns
  * combine to a valid line.  Leaves lds.vote as the serial walk does. */
@@ -332,16 +307,8 @@ __device__ inline void walk_rows_parallel(P16Lds &lds, int nl, int nr, int l0, i
         for (int p = 0; p < 3; p++) {
             const uint32_t m = p == 0 ? m0 : (p == 1 ? m1 : m2), g = p == 0 ? g0 : (p == 1 ? g1 : g2);
             if (!m) continue;
-            const uint32_t crc = g & 0xFFFFu;
-            const bool mine = (m >> lane) & 1u;
-            uint32_t eq = 0;
-            for (int j = step_min; j <= step_max; j++) if ((m >> j) & 1u) { const uint32_t cj = row_read(crc, j); eq |= (cj == crc ? 1u : 0u) << j; }
-            const uint32_t cnt = (uint32_t)__popc(eq), first = (uint32_t)(__ffs((int)eq) - 1);
-            const uint32_t top = wave_max_u32(mine ? ((cnt << 8) | (31u - first)) : 0u);
-            const uint32_t tcnt = top >> 8, tfirst = 31u - (top & 0xFFu);
-            const uint32_t tcrc = row_read(crc, (int)tfirst);
-            const bool rival = __ballot(mine && crc != tcrc && 2u * cnt >= tcnt) != 0ull;
-            const uint32_t okp = rival ? 0u : row_read(eq, (int)tfirst);
+            uint32_t tcnt, tfirst;
+            const uint32_t okp = row_vote(m, g & 0xFFFFu, step_min, step_max, tcnt, tfirst);
             if (p == 0) ok0 = okp; else if (p == 1) ok1 = okp; else ok2 = okp;
         }
         /* the line a column combines to (:4893-5050) */

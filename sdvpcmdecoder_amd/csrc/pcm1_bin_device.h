@@ -362,6 +362,52 @@ __device__ inline void stats_most_frequent(CrcStat *a, uint8_t &valid_cnt)     /
 }
 __device__ inline SweepEnt sweep_blank() { SweepEnt z; z.result = 0; z.hyst = z.shift = 0x0f; z.pad = 0; z.crc = 0; z.start = z.stop = 0; z.pad2 = 0; return z; }
 
+__device__ __forceinline__ uint32_t row_read(uint32_t x, int idx) { return (uint32_t)__shfl((int)x, idx); }
+/* pickLevelByCRCStats (binarizer.cpp:1985-2140) over one row of the grid held by the lanes (lane = column): ok = the entry has the
+ * target result, hyst / shift = its depth and stage.  Same two passes: the lowest (depth, stage) and the highest column that has it,
+ * then the longest run of that pair below it (with the reference's rule that a run still open at the low end is never compared). */
+__device__ inline bool pick_in_row(bool ok, uint32_t hyst, uint32_t shift, int low, int high, uint8_t &picked)
+{
+    const int lane = lane_id();
+    const bool cand = ok && lane >= low && lane <= high && hyst <= 0x0Fu && shift <= (uint32_t)SHIFT_STAGES_MAX;
+    const uint32_t key = cand ? ((hyst << 4) | shift) : 0xFFFFu;
+    const uint32_t best = wave_min_u32(key);
+    if (best == 0xFFFFu) return false;
+    const uint32_t M = (uint32_t)__ballot(cand && key == best);
+    int high_ref = 31 - __clz((int)M), low_ref = 0, tst_low = 0, tst_high = 0;
+    bool range_lock = false, second = false;
+    for (int index = high_ref; ; index--) {
+        if ((M >> index) & 1u) {
+            if (!range_lock) low_ref = index;
+            else { if (!second) { tst_high = index; second = true; } tst_low = index; }
+        } else {
+            range_lock = true;
+            if (second) { second = false; if ((tst_high - tst_low) >= (high_ref - low_ref)) { low_ref = tst_low; high_ref = tst_high; } }
+        }
+        if (index == low) break;
+    }
+    picked = (uint8_t)(low_ref + (uint8_t)(high_ref - low_ref) / 2);
+    return true;
+}
+
+/* The vote over one row of the grid held by the lanes (lane = column), findMostFrequentCRC with skip_equal (binarizer.cpp:1829-1928) +
+ * invalidateNonFrequentCRCs: m = the columns that read valid (all inside [lo, hi]), crc = the lane's CRC.  The most frequent CRC wins,
+ * the one seen first on a tie; a rival with half its count or more voids the vote.  Returns the columns that carry the winner (0: void),
+ * its count and the column it was first seen in. */
+__device__ inline uint32_t row_vote(uint32_t m, uint32_t crc, int lo, int hi, uint32_t &tcnt, uint32_t &tfirst)
+{
+    const int lane = lane_id();
+    const bool mine = lane < 32 && ((m >> (lane & 31)) & 1u);
+    uint32_t eq = 0;
+    for (int j = lo; j <= hi; j++) if ((m >> j) & 1u) { const uint32_t cj = row_read(crc, j); eq |= (cj == crc ? 1u : 0u) << j; }
+    const uint32_t cnt = (uint32_t)__popc(eq), first = (uint32_t)(__ffs((int)eq) - 1);
+    const uint32_t top = wave_max_u32(mine ? ((cnt << 8) | (31u - first)) : 0u);
+    tcnt = top >> 8; tfirst = 31u - (top & 0xFFu);
+    const uint32_t tcrc = row_read(crc, (int)tfirst);
+    const bool rival = __ballot(mine && crc != tcrc && 2u * cnt >= tcnt) != 0ull;
+    return rival ? 0u : row_read(eq, (int)tfirst);
+}
+
 /* searchPCM1Data (binarizer.cpp:4123-4511).  Returns true when coordinates were found; l is left as the reference leaves its
  * line object (the last candidate's read, the coordinates found or the starting ones). */
 __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords data_loc, uint8_t &hyst_lim, uint8_t &shift_lim)
@@ -410,53 +456,49 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
         if (lane < nl) for (int i = 0; i < nr; i++) { const int q = lane * nr + i; live = live || (((lds.grid[q] >> 24) & 1u) != 0 && (uint32_t)q < first_coll); }
         rows_live = __ballot(live);
     }
-    /* the vote: serial, on lane 0 */
-    if (lane == 0) {
-        uint8_t valid_left = 0, left_ofs = 0xFF;
-        stats_reset(lds.lstats, MAX_COLL_CRCS);
-        for (int i = 0; i < P1_SEARCH_STEP_CNT; i++) { lds.w.sweep[P1_LEFT_BASE + i] = sweep_blank(); lds.w.sweep[i] = sweep_blank(); }
+    /* the votes: row after row, the columns of a row on the lanes (row_vote, pick_in_row); the vote over the rows on lane 0 */
+    {
+        uint8_t valid_left = 0;         /* lane 0's */
+        if (lane == 0) stats_reset(lds.lstats, MAX_COLL_CRCS);
+        if (lane < P1_SEARCH_STEP_CNT) lds.w.sweep[P1_LEFT_BASE + lane] = sweep_blank();
+        __syncthreads();
         for (int row = 0; row < nl; row++) {
-            if (!((rows_live >> row) & 1ull)) {      /* nothing reads in this row: its entry in the left sweep is the "bad" one */
-                SweepEnt le = sweep_blank(); le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX;
-                lds.w.sweep[P1_LEFT_BASE + row] = le;
-                continue;
-            }
-            uint8_t valid_right = 0, right_ofs = 0xFF;         /* (every row writes the same nr entries of the right sweep, the rest stay blank; the statistics start over by count) */
-            for (int col = 0; col < nr; col++) {
-                const int q = row * nr + col;
-                const uint32_t g = lds.grid[q];
-                SweepEnt e = sweep_blank();
-                e.crc = (uint16_t)(g & 0xFFFF); e.hyst = (uint8_t)((g >> 16) & 0xF); e.shift = (uint8_t)((g >> 20) & 0xF);
-                e.start = (int16_t)(l0 + row * scan_step); e.stop = (int16_t)(r1 - col * scan_step);
+            SweepEnt le = sweep_blank(); le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX;     /* nothing reads in this row, or its vote is void */
+            if ((rows_live >> row) & 1ull) {
+                const int q = row * nr + lane;
+                const uint32_t g = lane < nr ? lds.grid[q] : 0u;
                 /* behind the first Bit Picker collision the line object is forced bad: nothing reads valid any more */
-                const bool valid = ((g >> 24) & 1) != 0 && (uint32_t)q < first_coll;
-                e.result = valid ? REF_CRC_OK : REF_BAD_CRC;
-                lds.w.sweep[col] = e;
-                if (valid) stats_update_fresh(lds.w.crc_stats, e.crc, e.hyst, e.shift, valid_right);
+                const uint32_t m = (uint32_t)__ballot(lane < nr && ((g >> 24) & 1u) != 0 && (uint32_t)q < first_coll);
+                const uint32_t crc = g & 0xFFFFu, hy = (g >> 16) & 0xFu, sh = (g >> 20) & 0xFu;
+                uint32_t tcnt = 0, tfirst = 0;
+                const uint32_t okm = m ? row_vote(m, crc, __ffs((int)m) - 1, 31 - __clz((int)m), tcnt, tfirst) : 0u;
+                uint8_t right_ofs = 0xFF;
+                if (okm && pick_in_row(lane < 32 && ((okm >> (lane & 31)) & 1u), hy, sh, 0, P1_SEARCH_STEP_CNT - 1, right_ofs)) {
+                    le.result = REF_CRC_OK; le.crc = (uint16_t)row_read(crc, right_ofs); le.hyst = (uint8_t)row_read(hy, right_ofs); le.shift = (uint8_t)row_read(sh, right_ofs);
+                    le.start = (int16_t)(l0 + row * scan_step); le.stop = (int16_t)(r1 - (int)right_ofs * scan_step);
+                    /* the row's winner enters the statistics of the left coordinate once per column that carried it */
+                    const uint16_t top_crc = (uint16_t)row_read(crc, (int)tfirst); const uint8_t top_h = (uint8_t)row_read(hy, (int)tfirst), top_s = (uint8_t)row_read(sh, (int)tfirst);
+                    if (lane == 0) {
+                        bool found_it = false;
+                        for (uint8_t i = 1; i <= valid_left; i++) if (lds.lstats[i].crc == top_crc) { lds.lstats[i].result = (uint8_t)(lds.lstats[i].result + tcnt); found_it = true; break; }
+                        if (!found_it) { valid_left++; lds.lstats[valid_left].crc = top_crc; lds.lstats[valid_left].hyst = top_h; lds.lstats[valid_left].shift = top_s; lds.lstats[valid_left].result = (uint8_t)tcnt; }
+                    }
+                }
             }
-            if (valid_right > 0) {
-                stats_most_frequent(lds.w.crc_stats, valid_right);
-                sweep_invalidate_non_frequent(lds.w, 0, P1_SEARCH_STEP_CNT - 1, valid_right, lds.w.crc_stats[0].crc);
-                if (valid_right > 0)
-                    if (pick_level_by_crc_stats(lds.w, &right_ofs, 0, P1_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_right = 0;
+            if (lane == 0) lds.w.sweep[P1_LEFT_BASE + row] = le;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            uint8_t left_ofs = 0xFF;
+            if (valid_left > 0) {
+                stats_most_frequent(lds.lstats, valid_left);
+                sweep_invalidate_non_frequent(lds.w, P1_LEFT_BASE, P1_LEFT_BASE + P1_SEARCH_STEP_CNT - 1, valid_left, lds.lstats[0].crc);
+                if (valid_left > 0)
+                    if (pick_level_by_crc_stats(lds.w, &left_ofs, P1_LEFT_BASE, P1_LEFT_BASE + P1_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
             }
-            SweepEnt le = sweep_blank();
-            if (valid_right > 0) {
-                le = lds.w.sweep[right_ofs];
-                le.result = REF_CRC_OK;
-                const CrcStat top = lds.w.crc_stats[0];
-                for (uint8_t k = 0; k < top.result; k++) stats_update(lds.lstats, top.crc, top.hyst, top.shift, valid_left);
-            } else { le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX; }
-            lds.w.sweep[P1_LEFT_BASE + row] = le;
+            lds.vote[0] = valid_left > 0 ? 1 : 0;
+            if (valid_left > 0) { lds.vote[1] = lds.w.sweep[left_ofs].start; lds.vote[2] = lds.w.sweep[left_ofs].stop; }
         }
-        if (valid_left > 0) {
-            stats_most_frequent(lds.lstats, valid_left);
-            sweep_invalidate_non_frequent(lds.w, P1_LEFT_BASE, P1_LEFT_BASE + P1_SEARCH_STEP_CNT - 1, valid_left, lds.lstats[0].crc);
-            if (valid_left > 0)
-                if (pick_level_by_crc_stats(lds.w, &left_ofs, P1_LEFT_BASE, P1_LEFT_BASE + P1_SEARCH_STEP_CNT - 1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX) != SPAN_OK) valid_left = 0;
-        }
-        lds.vote[0] = valid_left > 0 ? 1 : 0;
-        if (valid_left > 0) { lds.vote[1] = lds.w.sweep[left_ofs].start; lds.vote[2] = lds.w.sweep[left_ofs].stop; }
     }
     __syncthreads();
     const bool found = lds.vote[0] != 0;
