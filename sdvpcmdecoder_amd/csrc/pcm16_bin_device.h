@@ -238,15 +238,23 @@ __device__ inline void read_pcm_data(const BinCtx &c, L16 &l, const uint8_t *px_
     if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
     if (l.ref_sweeped) { fill_data_words<kWave>(c, l, px_row, part, hyst_lim, shift_lim); return; }     /* isDataByRefSweep(), :7741 */
     bool found = false;
+    /* the first fill (depth 0, stage 0) is kept: the reference's final fill repeats it when nothing reads valid (pcm1_bin_device.h) */
+    const bool entry_forced = l.forced_bad;
+    bool kept = false;
+    uint64_t k_v = 0; uint16_t k_crc = 0; uint8_t k_pl = 0, k_pr = 0, k_lo = 0, k_hi = 0; bool k_cb = true;
     for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
         bool invalid_hyst = false;
         for (uint8_t s = 0; s <= shift_lim; s++) {
             if (!fill_data_words<kWave>(c, l, px_row, part, h, s)) { invalid_hyst = true; break; }
             if (crc_valid(l)) { found = true; break; }
+            if (h == 0 && s == 0 && c.force_bit_picker) { kept = true; k_v = l.v; k_crc = l.calc_crc; k_pl = l.picked_l; k_pr = l.picked_r; k_lo = l.ref_low; k_hi = l.ref_high; k_cb = l.control_bit; }
         }
         if (invalid_hyst) break;
     }
-    if (!found) fill_data_words<kWave>(c, l, px_row, part, 0, 0);
+    if (!found) {
+        if (kept && l.forced_bad == entry_forced) { l.v = k_v; l.calc_crc = k_crc; l.picked_l = k_pl; l.picked_r = k_pr; l.ref_low = k_lo; l.ref_high = k_hi; l.hyst = 0; l.shift = 0; l.control_bit = k_cb; }
+        else fill_data_words<kWave>(c, l, px_row, part, 0, 0);
+    }
 }
 
 /* ---- searchPCM16X0Data (binarizer.cpp:4514-5271) ---------------------------------------------------------------------------- */

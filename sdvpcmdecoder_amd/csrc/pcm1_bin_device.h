@@ -312,19 +312,27 @@ __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const uint8_t *px_r
     if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
     if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
     if (l.ref_sweeped) { fill_data_words<kWave>(c, l, px_row, hyst_lim, shift_lim); return; }     /* isDataByRefSweep(): the sweep has picked depth and stage (:7741) */
-    uint8_t valid_delta = 0, valid_shift = 0;
     bool found = false;
+    /* what the very first fill (depth 0, stage 0) leaves: when nothing reads valid the reference's final fill is that fill again, and it
+     * comes out the same unless the forced-bad mark changed in between (the Bit Picker looks at it) - then it is run again */
+    const bool entry_forced = l.forced_bad;
+    bool kept = false;
+    u128 k_v = 0; uint16_t k_crc = 0; uint8_t k_pl = 0, k_pr = 0, k_lo = 0, k_hi = 0;
     for (uint8_t h = 0; h <= hyst_lim && !found; h++) {
         bool invalid_hyst = false;
         for (uint8_t s = 0; s <= shift_lim; s++) {
             if (!fill_data_words<kWave>(c, l, px_row, h, s)) { invalid_hyst = true; break; }
-            if (crc_valid(l)) { found = true; valid_delta = h; valid_shift = s; break; }
+            if (crc_valid(l)) { found = true; break; }
+            if (h == 0 && s == 0 && c.force_bit_picker) { kept = true; k_v = l.v; k_crc = l.calc_crc; k_pl = l.picked_l; k_pr = l.picked_r; k_lo = l.ref_low; k_hi = l.ref_high; }
         }
         if (invalid_hyst) break;
     }
     /* the final fill of the reference repeats the fill that was found, on the same inputs, and leaves the line as that fill left
-     * it - it only has to be run when nothing was found */
-    if (!found) fill_data_words<kWave>(c, l, px_row, valid_delta, valid_shift);
+     * it - it only has to be reproduced when nothing was found */
+    if (!found) {
+        if (kept && l.forced_bad == entry_forced) { l.v = k_v; l.calc_crc = k_crc; l.picked_l = k_pl; l.picked_r = k_pr; l.ref_low = k_lo; l.ref_high = k_hi; l.hyst = 0; l.shift = 0; }
+        else fill_data_words<kWave>(c, l, px_row, 0, 0);
+    }
 }
 
 __device__ inline void stats_reset(CrcStat *a, int count) { for (int i = 0; i < count; i++) { a[i].result = 0; a[i].crc = 0; a[i].hyst = a[i].shift = 0x0f; a[i].idx = 0; } }
