@@ -362,7 +362,7 @@ def main():
     fmt_stages = {}
     if not args.no_stitch and world == 1:
         from sdvpcmdecoder_amd import synth as _synth
-        nf = min(n, 2000)
+        nf = min(n, 10000)         # BASELINE's batch (the frame kernels want more frames than the GPU has SIMDs: 2 000 frames leave half of them idle)
         for key, gen, call, rec_bytes, per_frame in (("pcm1_frames_stage", _synth.pcm1_frames, eng.pcm1_binarize_frames, 40, H + 3),
                                                      ("pcm16x0_frames_stage", _synth.pcm16x0_frames, eng.pcm16x0_binarize_frames, 36, 3 * H + 3)):
             base, _w = gen(8, seed=530, height=H, width=W, noise_sigma=args.noise)
