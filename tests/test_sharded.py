@@ -68,7 +68,7 @@ def test_two_ranks_binarize_loop(tmp_path, emu_lib, oracle_lib):
     assert int(parts[1]["redo"]) >= 1
 
 
-@pytest.mark.parametrize("fmt,n_frames,warmup,s_warm", [("pcm1", 6, 2, 2), ("pcm16x0", 6, 2, 2), ("pcm16x0_ei", 5, 1, 1)])
+@pytest.mark.parametrize("fmt,n_frames,warmup,s_warm", [("pcm1", 6, 2, 2), ("pcm16x0", 6, 2, 2), ("pcm16x0_ei", 5, 1, 1), ("pcm1", 4, 0, 0), ("pcm16x0", 4, 0, 0)])
 def test_two_ranks_one_pcm_tape(tmp_path, emu_lib, oracle_lib, fmt, n_frames, warmup, s_warm):
     """ShardedPcmDecoder: a PCM-1 / PCM-16x0 tape over two ranks equals the sequential decode by the oracle's two workers."""
     import dist_worker
@@ -99,3 +99,5 @@ def test_two_ranks_one_pcm_tape(tmp_path, emu_lib, oracle_lib, fmt, n_frames, wa
     assert len(pairs) == len(want_p) and pairs.tobytes() == want_p.tobytes()
     assert len(frames) == len(want_f) and frames.tobytes() == want_f.tobytes()
     assert all(int(z["redo"][2]) >= 1 for z in parts)
+    if warmup == 0:         # no warm-up, no prediction: the second rank has to take its predecessor's real state and decode again
+        assert int(parts[1]["redo"][0]) >= 1 and (fmt == "pcm1" or int(parts[1]["redo"][1]) >= 1), parts[1]["redo"]
