@@ -136,7 +136,7 @@ __device__ __forceinline__ int part_start_bit(uint8_t part) { return part == PAR
 __device__ inline void fill_pcm16(L16 &l, const uint8_t *px_row, uint8_t part, int stage)
 {
     const int b0 = part_start_bit(part);
-    int32_t acc = (int32_t)((uint32_t)b0 * l.psm + l.hpsm) + (((int32_t)l.pso + shift_of_stage(stage)) << 7);
+    int32_t acc = (int32_t)((uint32_t)b0 * l.psm + l.hpsm) + ((int32_t)l.pso + shift_of_stage(stage)) * 128;
     const int32_t lo = l.pixel_start, hi = (int32_t)l.pixel_stop - 1;
     uint32_t a0, a1, c0, c1;
     compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a0, c0);
@@ -320,7 +320,8 @@ __device__ inline void walk_rows_parallel(P16Lds &lds, int nl, int nr, int l0, i
             if (p == 0) ok0 = okp; else if (p == 1) ok1 = okp; else ok2 = okp;
         }
         /* the line a column combines to (:4893-5050) */
-        const bool o0 = (ok0 >> lane) & 1u, o1 = (ok1 >> lane) & 1u, o2 = (ok2 >> lane) & 1u;
+        const int col = lane & 31;           /* (the masks are 32 columns wide; lanes behind them are never in range) */
+        const bool o0 = lane < 32 && ((ok0 >> col) & 1u), o1 = lane < 32 && ((ok1 >> col) & 1u), o2 = lane < 32 && ((ok2 >> col) & 1u);
         const uint32_t h0 = (g0 >> 16) & 0xFu, h1 = (g1 >> 16) & 0xFu, h2 = (g2 >> 16) & 0xFu, s0 = (g0 >> 20) & 0xFu, s1 = (g1 >> 20) & 0xFu, s2 = (g2 >> 20) & 0xFu;
         const bool in_range = lane >= step_min && lane <= step_max;
         bool r_ok = false; uint32_t r_hyst = 0, r_shift = 0; int n3 = 0;

@@ -162,7 +162,7 @@ __device__ inline int pixel_of(const L1 &l, int bit, int stage)
  * cell are collected as masks and the automaton is solved on them (solve_automaton), the CRC comes from the parity masks */
 __device__ inline void fill_pcm1(L1 &l, const uint8_t *px_row, int stage)
 {
-    int32_t acc = (int32_t)l.hpsm + (((int32_t)l.pso + shift_of_stage(stage)) << 7);
+    int32_t acc = (int32_t)l.hpsm + ((int32_t)l.pso + shift_of_stage(stage)) * 128;
     const int32_t lo = l.pixel_start, hi = (int32_t)l.pixel_stop - 1;
     uint32_t a0, a1, a2, b0, b1, b2;
     compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, l.ref_low, l.ref_high, a0, b0);

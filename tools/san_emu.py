@@ -46,3 +46,23 @@ for name in ("clean_fast", "cut_bits_draft", "noisy_header", "window_moves", "ga
     assert rc == 0 and got1.tobytes() == want1.tobytes(), name
     lib.sdv_engine_destroy(eng)
 print("pcm1 front emu ok")
+
+# round 2: the frame drivers (MODE_INSANE and the parallel walk included) and the PCM-16x0 back half on the emulator
+import pcm1_frames_api as f1, pcm16_frames_api as f16, pcm16_api as p16
+for pf in (f1, f16):
+    for name in ("clean_normal", "cut_bits_normal", "dropouts_fast", "jitter_draft", "garbage", "insane_jitter", "insane_flag_matters"):
+        luma2, mode, st = pf.make_input(name)
+        want2, wst2 = pf.run_cpu(orc, "orc_", luma2, mode, st)
+        eng = C.c_void_p(lib.sdv_engine_create(0))
+        rc, got2, st2 = pf.run_engine(lib, eng, luma2, mode, st)
+        assert rc == 0 and got2.tobytes() == want2.tobytes() and st2.tobytes() == wst2.tobytes(), name
+        lib.sdv_engine_destroy(eng)
+print("frame drivers emu ok")
+for name in ("si_clean", "si_bad10", "si_picked_forced"):
+    recs, st = p16.make_input(name)
+    wp, wf = p16.run_cpu(orc, "orc_", recs, st)
+    eng = C.c_void_p(lib.sdv_engine_create(0))
+    rc, p, f = ea.emu_pcm16_stitch(lib, eng, recs, st)
+    assert rc == 0 and p.tobytes() == wp.tobytes() and f.tobytes() == wf.tobytes(), name
+    lib.sdv_engine_destroy(eng)
+print("pcm16x0 stitch emu ok")

@@ -29,3 +29,23 @@ for name in sorted(pf.CASES):
     luma, run = pf.make_case(name)
     pf.run_lines(_lib, "orc_bin1_", luma, **run)
 print("pcm1 front ok")
+
+# round 2: PCM-16x0 lines, both frame drivers (MODE_INSANE included), the PCM-16x0 back half
+import pcm16_front_api as p16f
+for name in sorted(p16f.CASES):
+    luma, run = p16f.make_case(name)
+    p16f.run_lines(_lib, "orc_bin16_", luma, **run)
+print("pcm16x0 front ok")
+import pcm1_frames_api as f1, pcm16_frames_api as f16
+for pf in (f1, f16):
+    for name in sorted(pf.CASES):
+        if name == "ntsc_full":
+            continue
+        luma, mode, st = pf.make_input(name)
+        pf.run_cpu(_lib, "orc_", luma, mode, st)
+print("frame drivers ok")
+import pcm16_api as p16
+for name in sorted(p16.CASES):
+    recs, st = p16.make_input(name)
+    p16.run_cpu(_lib, "orc_", recs, st)
+print("pcm16x0 stitch ok")
