@@ -316,7 +316,7 @@ __device__ inline void walk_rows_parallel(P16Lds &lds, int nl, int nr, int l0, i
             const uint32_t m = p == 0 ? m0 : (p == 1 ? m1 : m2), g = p == 0 ? g0 : (p == 1 ? g1 : g2);
             if (!m) continue;
             uint32_t tcnt, tfirst;
-            const uint32_t okp = row_vote(m, g & 0xFFFFu, step_min, step_max, tcnt, tfirst);
+            const uint32_t okp = row_vote(m, g & 0xFFFFu, &lds.grid[row * nr * P16_SUBLINES + p], P16_SUBLINES, step_min, step_max, tcnt, tfirst);
             if (p == 0) ok0 = okp; else if (p == 1) ok1 = okp; else ok2 = okp;
         }
         /* the line a column combines to (:4893-5050) */

@@ -399,15 +399,15 @@ __device__ inline bool pick_in_row(bool ok, uint32_t hyst, uint32_t shift, int l
 }
 
 /* The vote over one row of the grid held by the lanes (lane = column), findMostFrequentCRC with skip_equal (binarizer.cpp:1829-1928) +
- * invalidateNonFrequentCRCs: m = the columns that read valid (all inside [lo, hi]), crc = the lane's CRC.  The most frequent CRC wins,
+ * invalidateNonFrequentCRCs: m = the columns that read valid (all inside [lo, hi]), crc = the lane's CRC (= grid_row[lane * stride]).  The most frequent CRC wins,
  * the one seen first on a tie; a rival with half its count or more voids the vote.  Returns the columns that carry the winner (0: void),
  * its count and the column it was first seen in. */
-__device__ inline uint32_t row_vote(uint32_t m, uint32_t crc, int lo, int hi, uint32_t &tcnt, uint32_t &tfirst)
+__device__ inline uint32_t row_vote(uint32_t m, uint32_t crc, const uint32_t *grid_row, int stride, int lo, int hi, uint32_t &tcnt, uint32_t &tfirst)
 {
     const int lane = lane_id();
     const bool mine = lane < 32 && ((m >> (lane & 31)) & 1u);
-    uint32_t eq = 0;
-    for (int j = lo; j <= hi; j++) if ((m >> j) & 1u) { const uint32_t cj = row_read(crc, j); eq |= (cj == crc ? 1u : 0u) << j; }
+    uint32_t eq = 0;        /* the other columns' CRCs are read where the candidate reads left them (grid_row[j * stride], low 16 bits) */
+    for (int j = lo; j <= hi; j++) if ((m >> j) & 1u) { const uint32_t cj = grid_row[j * stride] & 0xFFFFu; eq |= (cj == crc ? 1u : 0u) << j; }
     const uint32_t cnt = (uint32_t)__popc(eq), first = (uint32_t)(__ffs((int)eq) - 1);
     const uint32_t top = wave_max_u32(mine ? ((cnt << 8) | (31u - first)) : 0u);
     tcnt = top >> 8; tfirst = 31u - (top & 0xFFu);
@@ -479,7 +479,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
                 const uint32_t m = (uint32_t)__ballot(lane < nr && ((g >> 24) & 1u) != 0 && (uint32_t)q < first_coll);
                 const uint32_t crc = g & 0xFFFFu, hy = (g >> 16) & 0xFu, sh = (g >> 20) & 0xFu;
                 uint32_t tcnt = 0, tfirst = 0;
-                const uint32_t okm = m ? row_vote(m, crc, __ffs((int)m) - 1, 31 - __clz((int)m), tcnt, tfirst) : 0u;
+                const uint32_t okm = m ? row_vote(m, crc, &lds.grid[row * nr], 1, __ffs((int)m) - 1, 31 - __clz((int)m), tcnt, tfirst) : 0u;
                 uint8_t right_ofs = 0xFF;
                 if (okm && pick_in_row(lane < 32 && ((okm >> (lane & 31)) & 1u), hy, sh, 0, P1_SEARCH_STEP_CNT - 1, right_ofs)) {
                     le.result = REF_CRC_OK; le.crc = (uint16_t)row_read(crc, right_ofs); le.hyst = (uint8_t)row_read(hy, right_ofs); le.shift = (uint8_t)row_read(sh, right_ofs);

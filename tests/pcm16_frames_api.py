@@ -37,11 +37,11 @@ CASES = {
     "smeared_parts_draft": (3, 48, dict(seed=724, smear=(4, 20, 120), noise_sigma=3.0), 0, {}),
     "ntsc_full": (2, 486, dict(seed=725, noise_sigma=4.0), 2, {}),
     # MODE_INSANE: passes that do not read from what was handed on run the reference level sweep
-    "insane_smeared": (2, 16, dict(seed=732, smear=(3, 250, 330), black=50, white=100, noise_sigma=3.0), 3, {}),
+    "insane_smeared": (2, 10, dict(seed=732, smear=(3, 250, 330), black=50, white=100, noise_sigma=3.0), 3, {}),
     "insane_jitter": (2, 16, dict(seed=734, jitter=2, black=40, white=90, noise_sigma=4.0), 3, {}),
     # min_valid_crcs above min_contrast: the Binarizer's sticky sweep flag then decides whether levels 50 apart count as levels
     "insane_flag_matters": (3, 12, dict(seed=736, black=50, white=100, noise_sigma=4.0, smear=(3, 250, 330)), 3, dict(preset=dict(min_valid_crcs=60))),
-    "insane_flag_matters_wide": (2, 12, dict(seed=737, black=40, white=120, noise_sigma=4.0, smear=(3, 250, 330)), 3, dict(preset=dict(min_valid_crcs=60))),
+    "insane_flag_matters_wide": (1, 10, dict(seed=737, black=40, white=100, noise_sigma=4.0, smear=(3, 250, 330)), 3, dict(preset=dict(min_valid_crcs=50))),
 }
 GOLDEN = ("noisy_normal", "jitter_draft", "dropouts_fast", "dup_lines", "file_marks", "cut_bits_normal", "smeared_parts_normal", "control_bits", "insane_smeared")
 

@@ -38,7 +38,7 @@ CASES = {
     "insane_jitter": (2, 16, dict(seed=734, jitter=2, black=40, white=90, noise_sigma=4.0), 3, {}),
     # min_valid_crcs above min_contrast: the Binarizer's sticky sweep flag then decides whether levels 50 apart count as levels
     "insane_flag_matters": (3, 16, dict(seed=736, black=50, white=100, noise_sigma=8.0, blur=1, p_dropout=0.1), 3, dict(preset=dict(min_valid_crcs=60))),
-    "insane_flag_matters_wide": (2, 16, dict(seed=737, black=40, white=120, noise_sigma=8.0, blur=1), 3, dict(preset=dict(min_valid_crcs=60))),
+    "insane_flag_matters_wide": (1, 12, dict(seed=737, black=40, white=100, noise_sigma=8.0, blur=1), 3, dict(preset=dict(min_valid_crcs=50))),
 }
 GOLDEN = ("noisy_normal", "jitter_draft", "dropouts_fast", "dup_lines", "file_marks", "cut_bits_normal", "insane_noisy")
 

@@ -83,7 +83,7 @@ CASES = {
     "flat_and_services": (dict(n=12, seed=419, flat=(2, 7), noise_sigma=2.0), dict(mode=1, feedback="good", services={4: 4, 5: 5, 9: 3}, empty=(10,)), {}),
     "window_moves": (dict(n=16, seed=420, noise_sigma=3.0, jump_at=8, jump_to=(15, 700)), dict(mode=1, feedback="good"), {}),
     # MODE_INSANE: every line that does not read from what was handed on runs the reference level sweep (a coordinate search per level)
-    "insane_scratch": (dict(n=5, seed=431, noise_sigma=2.0), dict(mode=3, feedback="none"), {}),
+    "insane_scratch": (dict(n=3, seed=431, noise_sigma=2.0, black=40, white=120), dict(mode=3, feedback="none"), {}),
     "insane_cut_right": (dict(n=4, seed=432, x0=10, x1=728, noise_sigma=2.0), dict(mode=3, feedback="reset"), {}),
     "insane_cut_left": (dict(n=4, seed=433, x0=-12, x1=700, noise_sigma=2.0), dict(mode=3, feedback="reset"), {}),
     "insane_noisy_header": (dict(n=12, seed=434, x0=7, x1=709, noise_sigma=8.0, blur=1, header_every=5), dict(mode=3, feedback="good"), {}),
