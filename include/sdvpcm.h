@@ -556,6 +556,69 @@ int sdv_saturate_pcm16x0_stitch_stats(sdv_engine *e);
 int sdv_pcm16x0_stitch_frames(sdv_engine *e, const sdv_pcm16x0_bin_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                               size_t *n_pairs, sdv_frame_asm_pcm16x0 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* ---- AudioProcessor: dropout masking on the PCMSamplePair stream ---------------------------- */
+/* AudioProcessor::DROP_* (audioprocessor.h:83-93), set with setMasking (audioprocessor.cpp:1532-1574) */
+enum { SDV_DROP_IGNORE = 0, SDV_DROP_MUTE_BLOCK = 1, SDV_DROP_MUTE_WORD = 2, SDV_DROP_HOLD_BLOCK = 3, SDV_DROP_HOLD_WORD = 4,
+       SDV_DROP_INTER_LIN_BLOCK = 5, SDV_DROP_INTER_LIN_WORD = 6, SDV_DROP_MAX = 7 };
+/* The window constants of the class (audioprocessor.h:62-71): BUF_SIZE, MIN_VALID_BEFORE, MAX_RAMP_DOWN, MAX_RAMP_UP */
+enum { SDV_AP_BUF_SIZE = 512, SDV_AP_MIN_VALID_BEFORE = 3, SDV_AP_MAX_RAMP_DOWN = 192, SDV_AP_MAX_RAMP_UP = 32 };
+
+/* One purgePipeline() of the worker (audioprocessor.cpp:1716-1745: the output file is released, newSource is emitted and the
+ * sample index starts over).  first_pair = how many pairs of this call's output had been put out when it happened: the pairs
+ * from there up to the next event (or the end of the output) carry PCMSample::index 0, 1, 2, ... and, when the event is a
+ * NEW_FILE tag, go into that source's WAV file.  16 bytes. */
+enum { SDV_AP_PURGE_NEW_FILE = 1,   /* the NEW_FILE tag (:120-137): what waited in the window is put out as it is */
+       SDV_AP_PURGE_END_FILE = 2,   /* the file ended (:138-152, :1338-1342) after the last window was scanned with the end-of-file rule */
+       SDV_AP_PURGE_STOP = 3        /* stop() (:1655-1660) */ };
+typedef struct sdv_audio_purge {
+    uint64_t first_pair;
+    uint32_t tag_index;             /* the position of the tag in this call's `pairs` (n_pairs for SDV_AP_PURGE_STOP) */
+    uint8_t kind;                   /* SDV_AP_PURGE_* */
+    uint8_t _pad[3];
+} sdv_audio_purge;
+
+/* setMasking(mode).  Like the slot it takes effect with the next window; it does not touch what waits in the window. */
+int sdv_set_audio_masking(sdv_engine *e, int drop_mode);
+/* A freshly constructed AudioProcessor (audioprocessor.cpp:3-36): empty window, sample index 0, masking as set. */
+int sdv_reset_audio(sdv_engine *e);
+/* How many pairs wait in the worker's window (prebuffer.size()), i.e. have been taken but not put out yet. */
+size_t sdv_audio_pending(const sdv_engine *e);
+
+/* AudioProcessor::processAudio (audioprocessor.cpp:1621-1713) over a burst of the PCMSamplePair stream, i.e. what one of the
+ * stitch entry points wrote (NEW_FILE / END_FILE tags included): the worker's loop of fillUntilBufferFull (:70-200: the window of
+ * 512 pairs is topped up, pairs get their index, word validity is replaced by block validity in the *_BLOCK modes),
+ * scanBuffer / fixBadSamples per channel (:740-1178: invalid regions found back to front; ramps of 192 / 32 samples into and out
+ * of a mute for long ones, one region for short ones, filled by rangeMute / rangeLevelHold / rangeLinearInterpolation
+ * :511-737; the end-of-file rule :1122-1172) and outputAudio (:1287-1357: pairs leave from the front while the first four are
+ * valid or masked, three stay as look-behind), with purgePipeline at the tags.
+ *
+ * Feed schedule.  The reference polls its queue, so what it writes depends on how much the queue held at each turn.  This entry
+ * fixes the schedule to the one a decoder faster than real time produces: the burst is in the queue before the worker's next
+ * turn and the queue runs dry at the end of the call - every turn fills the window completely except the last one of the call,
+ * which takes what is left (and, as in the reference, is scanned only when the window holds 227 pairs or the file ended).
+ * A call with `stop` != 0 ends with stop(): the window is purged as it is (its last pair is dropped, dumpBuffer :1423-1434).
+ *
+ * out_pairs receives the pairs in the order of outputWordPair (:1265-1284) - service_type 0, flags as the worker left them
+ * (SDV_SF_WORD_VALID set on everything a scan has seen, SDV_SF_WORD_MASKED on what was altered); out_purges the purge events in
+ * order; *n_masked the sum of the guiAddMask reports.  out_cap must be at least n_pairs + sdv_audio_pending() + the number of
+ * tags in the burst (n_pairs + 513 + tags is always enough) because pairs are worked on in place; *n_out is the count put out.
+ * Not supported (SDV_ERR_UNSUPPORTED, the stream state is left untouched): an END_FILE that finds fewer than three pairs in the
+ * window (the reference then neither purges nor starts a new source, :1302-1306), a window whose first pairs can never leave
+ * (a stream that starts with invalid samples and no NEW_FILE tag: the reference's worker stops taking input for good), and more
+ * than 65 536 tags in one burst.
+ * All buffers are device pointers; the call returns when the outputs are complete. */
+int sdv_audio_process(sdv_engine *e, const sdv_sample_pair *pairs, size_t n_pairs, int stop, sdv_sample_pair *out_pairs, size_t out_cap,
+                      size_t *n_out, sdv_audio_purge *out_purges, size_t purges_cap, size_t *n_purges, uint64_t *n_masked, void *stream);
+
+/* ---- SamplesToWAV: the file the GUI writes -------------------------------------------------- */
+/* SamplesToWAV::saveAudio (samples2wav.cpp:306-323) for n pairs: left and right audio_word, little-endian, 4 bytes per pair, to
+ * `pcm` (device pointers; asynchronous on `stream`). */
+int sdv_wav_pack(sdv_engine *e, const sdv_sample_pair *pairs, size_t n, int16_t *pcm, void *stream);
+/* The 44-byte RIFF header as SamplesToWAV leaves it (default_header :4-21, updateHeader :111-206) on a file that holds n_pairs
+ * pairs whose last one had sample_rate `last_sample_rate` (setSampleRate :257-289: 44056 stays, anything else reads 44100).
+ * Host memory. */
+void sdv_wav_header(uint8_t hdr[44], uint64_t n_pairs, uint16_t last_sample_rate);
+
 #ifdef __cplusplus
 }
 #endif
