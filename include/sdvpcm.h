@@ -583,6 +583,8 @@ int sdv_set_audio_masking(sdv_engine *e, int drop_mode);
 int sdv_reset_audio(sdv_engine *e);
 /* How many pairs wait in the worker's window (prebuffer.size()), i.e. have been taken but not put out yet. */
 size_t sdv_audio_pending(const sdv_engine *e);
+/* PCMSample::index of the next pair that will be put out (it counts from 0 behind every purge and runs on across calls). */
+uint64_t sdv_audio_next_index(const sdv_engine *e);
 
 /* AudioProcessor::processAudio (audioprocessor.cpp:1621-1713) over a burst of the PCMSamplePair stream, i.e. what one of the
  * stitch entry points wrote (NEW_FILE / END_FILE tags included): the worker's loop of fillUntilBufferFull (:70-200: the window of
@@ -600,8 +602,9 @@ size_t sdv_audio_pending(const sdv_engine *e);
  *
  * out_pairs receives the pairs in the order of outputWordPair (:1265-1284) - service_type 0, flags as the worker left them
  * (SDV_SF_WORD_VALID set on everything a scan has seen, SDV_SF_WORD_MASKED on what was altered); out_purges the purge events in
- * order; *n_masked the sum of the guiAddMask reports.  out_cap must be at least n_pairs + sdv_audio_pending() + the number of
- * tags in the burst (n_pairs + 513 + tags is always enough) because pairs are worked on in place; *n_out is the count put out.
+ * order; *n_masked the sum of the guiAddMask reports.  *n_out / *n_purges receive the counts; when out_cap / purges_cap are too
+ * small the call fails with SDV_ERR_BAD_ARG, the counts say what is needed (n_pairs + 512 + tags is always enough) and the
+ * stream state is untouched, so the call can be repeated.
  * Not supported (SDV_ERR_UNSUPPORTED, the stream state is left untouched): an END_FILE that finds fewer than three pairs in the
  * window (the reference then neither purges nor starts a new source, :1302-1306), a window whose first pairs can never leave
  * (a stream that starts with invalid samples and no NEW_FILE tag: the reference's worker stops taking input for good), and more

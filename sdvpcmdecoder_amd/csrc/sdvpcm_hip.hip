@@ -12,9 +12,11 @@
 #include "pcm16_bin_device.h"
 #include "pcm16_frames_device.h"
 #include "pcm16_stitch_device.h"
+#include "audio_device.h"
 #include "engine.inc"
 #include "stitch_engine.inc"
 #include "pcm1_engine.inc"
 #include "pcm1_frames_engine.inc"
 #include "pcm16_frames_engine.inc"
 #include "pcm16_engine.inc"
+#include "audio_engine.inc"

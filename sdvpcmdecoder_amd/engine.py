@@ -180,25 +180,41 @@ def load_library(path: str | None = None):
     lib.sdv_get_pcm16x0_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_set_pcm16x0_stitch_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_saturate_pcm16x0_stitch_stats.argtypes = [C.c_void_p]
+    lib.sdv_set_audio_masking.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_reset_audio.argtypes = [C.c_void_p]
+    lib.sdv_audio_pending.restype = C.c_size_t
+    lib.sdv_audio_pending.argtypes = [C.c_void_p]
+    lib.sdv_audio_next_index.restype = C.c_uint64
+    lib.sdv_audio_next_index.argtypes = [C.c_void_p]
+    lib.sdv_audio_process.restype = C.c_int
+    lib.sdv_audio_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.sdv_wav_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.sdv_wav_header.argtypes = [C.c_void_p, C.c_uint64, C.c_uint16]
+    lib.sdv_wav_header.restype = None
     if path is None:
         _lib = lib
     return lib
+
+
+AUDIO_PURGE_DTYPE = __import__("numpy").dtype([("first_pair", "<u8"), ("tag_index", "<u4"), ("kind", "u1"), ("_pad", "u1", (3,))])
 
 
 class Engine:
     """One decode engine per GPU (per process rank)."""
 
     def __init__(self, device: int = 0, lib=None):
-        self.lib = lib or load_library()
-        self.device = device
-        # The tensors this class takes are torch's: let torch bring up the HIP runtime it ships before the library makes its first
-        # HIP call - the other way round torch finds no device any more ("No HIP GPUs are available").
+        # The tensors this class takes are torch's: let torch load and bring up the HIP runtime it ships before the library is loaded
+        # and makes its first HIP call - the other way round two runtimes end up in the process and one of them finds no device
+        # ("No HIP GPUs are available" / "no HIP device available").
         try:
             import torch
             if torch.cuda.is_available():
                 torch.cuda.init()
         except ImportError:
             pass
+        self.lib = lib or load_library()
+        self.device = device
         self._h = self.lib.sdv_engine_create(device)
         if not self._h:
             raise RuntimeError("sdv_engine_create failed: " + self.lib.sdv_last_error(None).decode())
@@ -529,3 +545,84 @@ class Engine:
                                           C.c_void_p(out_stats.data_ptr()), out_stats.shape[0], sptr)
         self._check(rc)
         return out_lines[:nrec], out_stats[:nst]
+
+    # ---- AudioProcessor / SamplesToWAV -----------------------------------------------------------
+    def set_audio_masking(self, drop_mode: int):
+        """AudioProcessor::setMasking (audioprocessor.cpp:1532-1574): SDV_DROP_* 0..6."""
+        self._check(self.lib.sdv_set_audio_masking(self._h, int(drop_mode)))
+
+    def reset_audio(self):
+        """A freshly constructed AudioProcessor: nothing waits, the sample index is 0; the masking mode stays."""
+        self._check(self.lib.sdv_reset_audio(self._h))
+
+    def audio_pending(self) -> int:
+        return int(self.lib.sdv_audio_pending(self._h))
+
+    def audio_next_index(self) -> int:
+        return int(self.lib.sdv_audio_next_index(self._h))
+
+    def audio_process(self, pairs, stop=False, out_pairs=None, out_purges=None, stream=None):
+        """AudioProcessor::processAudio over one burst of the PCMSamplePair stream: `pairs` is a torch.uint8 CUDA tensor (n, 12) of
+        sdv_sample_pair (what the stitch entry points return, tags included).  Returns (out, purges, masked): torch.uint8 CUDA tensors
+        (n_out, 12) of sdv_sample_pair and (n_purges, 16) of sdv_audio_purge, and the sum of the guiAddMask reports."""
+        import torch
+        _check_out(pairs, 12, pairs.device, "pairs")
+        n = pairs.shape[0]
+        if out_pairs is None:
+            out_pairs = torch.empty((n + 1024, 12), dtype=torch.uint8, device=pairs.device)
+        if out_purges is None:
+            out_purges = torch.empty((256, 16), dtype=torch.uint8, device=pairs.device)
+        _check_out(out_pairs, 12, pairs.device, "out_pairs")
+        _check_out(out_purges, 16, pairs.device, "out_purges")
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(pairs.device).cuda_stream)
+        n_out, n_pur, masked = C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+        for attempt in range(2):
+            rc = self.lib.sdv_audio_process(self._h, C.c_void_p(pairs.data_ptr()) if n else None, n, 1 if stop else 0, C.c_void_p(out_pairs.data_ptr()),
+                                            out_pairs.shape[0], C.byref(n_out), C.c_void_p(out_purges.data_ptr()), out_purges.shape[0], C.byref(n_pur),
+                                            C.byref(masked), sptr)
+            if rc == -1 and attempt == 0 and (n_out.value > out_pairs.shape[0] or n_pur.value > out_purges.shape[0]):
+                # a refused call takes nothing: come again with the sizes it reported
+                if n_out.value > out_pairs.shape[0]:
+                    out_pairs = torch.empty((n_out.value, 12), dtype=torch.uint8, device=pairs.device)
+                if n_pur.value > out_purges.shape[0]:
+                    out_purges = torch.empty((n_pur.value, 16), dtype=torch.uint8, device=pairs.device)
+                continue
+            break
+        self._check(rc)
+        return out_pairs[:n_out.value], out_purges[:n_pur.value], int(masked.value)
+
+    def wav_pack(self, pairs, out=None, stream=None):
+        """SamplesToWAV::saveAudio for every pair: (n, 12) sdv_sample_pair -> (n, 2) int16 on the device."""
+        import torch
+        _check_out(pairs, 12, pairs.device, "pairs")
+        n = pairs.shape[0]
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.int16, device=pairs.device)
+        assert out.is_cuda and out.dtype == torch.int16 and out.is_contiguous() and out.numel() >= 2 * n
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(pairs.device).cuda_stream)
+        self._check(self.lib.sdv_wav_pack(self._h, C.c_void_p(pairs.data_ptr()) if n else None, n, C.c_void_p(out.data_ptr()), sptr))
+        return out[:n]
+
+    def wav_header(self, n_pairs: int, last_sample_rate: int) -> bytes:
+        hdr = C.create_string_buffer(44)
+        self.lib.sdv_wav_header(hdr, int(n_pairs), int(last_sample_rate))
+        return hdr.raw
+
+    def wav_files(self, out_pairs, purges):
+        """The files SamplesToWAV leaves for an output stream of audio_process (one per NEW_FILE purge that is followed by at least one
+        pair): {number of the NEW_FILE tag: bytes}.  `purges` as a numpy array of sdv_audio_purge records (or the uint8 tensor)."""
+        import numpy as np
+        if hasattr(purges, "cpu"):
+            purges = purges.cpu().numpy().view(AUDIO_PURGE_DTYPE).reshape(-1)
+        files, k, n = {}, 0, out_pairs.shape[0]
+        for i, p in enumerate(purges):
+            if p["kind"] != 1:
+                continue
+            a = int(p["first_pair"])
+            b = int(purges[i + 1]["first_pair"]) if i + 1 < len(purges) else n
+            if b > a:
+                pcm = self.wav_pack(out_pairs[a:b])
+                rate = int(out_pairs[b - 1].cpu().numpy().view(PAIR_DTYPE)["sample_rate"][0])
+                files[k] = self.wav_header(b - a, rate) + pcm.cpu().numpy().tobytes()
+            k += 1
+        return files

@@ -166,6 +166,11 @@ def _c_long_tape():
     return tape(["N", audio(40000, 27, p_bad=0.001, runs=[(9000, 400, 2), (20000, 3000, 0), (30000, 20, 1)]), "E"])
 
 
+def _c_worn_tape():
+    # an invalid word in almost every window: the windows are 509 pairs apart until one ends on an invalid pair
+    return tape(["N", audio(70000, 33, p_bad=0.01, runs=[(30000, 3, 2), (50897, 5, 0)]), "E"])
+
+
 def _c_no_first_tag():
     # a stream that starts without NEW_FILE: no silent pair in front, the index starts at 0
     return tape([audio(1500, 31, runs=[(300, 40, 2)]), "E", "N", audio(800, 32), "E"])
@@ -208,6 +213,8 @@ CASES = {
     "extreme_levels": (_c_extreme_levels, DROP_INTER_LIN_WORD, None, 1),
     "input_masked_flag": (_c_input_masked_flag, DROP_INTER_LIN_WORD, None, 1),
     "long_tape": (_c_long_tape, DROP_INTER_LIN_WORD, None, 1),
+    "worn_tape": (_c_worn_tape, DROP_INTER_LIN_WORD, None, 1),
+    "worn_tape_hold_bursts": (_c_worn_tape, DROP_HOLD_WORD, (0.3, 0.31, 0.77, 1.0), 1),
     # the queue runs dry in between: bursts
     "bursts_long_runs": (_c_long_runs, DROP_INTER_LIN_WORD, (0.13, 0.5, 0.51, 0.9, 1.0), 1),
     "bursts_two_files": (_c_two_files, DROP_HOLD_WORD, (0.2, 0.4, 0.6, 1.0), 0),
@@ -285,3 +292,53 @@ def wav_files(lib, prefix, out, purges):
 
 def digest(out, purges, masked):
     return hashlib.sha256(out.tobytes() + np.ascontiguousarray(purges).tobytes() + str(masked).encode()).hexdigest()
+
+
+def bind_product(lib):
+    """argtypes of the audio entry points of the C-ABI (product library or its emulator build)."""
+    lib.sdv_set_audio_masking.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_reset_audio.argtypes = [C.c_void_p]
+    lib.sdv_audio_pending.restype = C.c_size_t
+    lib.sdv_audio_pending.argtypes = [C.c_void_p]
+    lib.sdv_audio_next_index.restype = C.c_uint64
+    lib.sdv_audio_next_index.argtypes = [C.c_void_p]
+    lib.sdv_audio_process.restype = C.c_int
+    lib.sdv_audio_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.sdv_wav_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.sdv_wav_header.argtypes = [C.c_void_p, C.c_uint64, C.c_uint16]
+    lib.sdv_wav_header.restype = None
+    return lib
+
+
+def emu_audio(lib, eng, pairs, stop, out_cap=None, purges_cap=None):
+    """Host-memory call (emulator build only): one sdv_audio_process call over `pairs` -> (rc, out, purges, masked)."""
+    pairs = np.ascontiguousarray(pairs)
+    out_cap = len(pairs) + 1024 if out_cap is None else out_cap
+    purges_cap = int((pairs["service_type"] != 0).sum()) + 2 if purges_cap is None else purges_cap
+    out = np.zeros(max(out_cap, 1), dtype=PAIR_DTYPE)
+    pur = np.zeros(max(purges_cap, 1), dtype=PURGE_DTYPE)
+    n_out, n_pur, nm = C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+    rc = lib.sdv_audio_process(eng, pairs.ctypes.data if len(pairs) else None, len(pairs), stop, out.ctypes.data, out_cap, C.byref(n_out),
+                               pur.ctypes.data, purges_cap, C.byref(n_pur), C.byref(nm), None)
+    return rc, out[:min(n_out.value, out_cap)], pur[:min(n_pur.value, purges_cap)], nm.value, n_out.value, n_pur.value
+
+
+def emu_run(lib, pairs, mode, ends, stop):
+    """The bursts of a case through a fresh engine of the emulator build, like run_cpu: -> (out, purges, masked)."""
+    eng = lib.sdv_engine_create(0)
+    assert lib.sdv_set_audio_masking(eng, mode) == 0
+    outs, purs, masked, a, got = [], [], 0, 0, 0
+    try:
+        for k, b in enumerate(ends):
+            b = int(b)
+            rc, o, p, m, _, _ = emu_audio(lib, eng, pairs[a:b], 1 if (stop and k + 1 == len(ends)) else 0)
+            assert rc == 0, lib.sdv_last_error(eng)
+            p = p.copy()
+            p["first_pair"] += got
+            p["tag_index"] += a
+            outs.append(o.copy()); purs.append(p); masked += m
+            got += len(o); a = b
+    finally:
+        lib.sdv_engine_destroy(eng)
+    return np.concatenate(outs), np.concatenate(purs), masked

@@ -17,9 +17,11 @@ struct uint2 { uint32_t x, y; };
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_bin_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_frames_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_stitch_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/audio_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/stitch_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_frames_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_frames_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_engine.inc"
+#include "../../sdvpcmdecoder_amd/csrc/audio_engine.inc"

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Generates the AudioProcessor golden fixtures (audio_<case>.npz) by running the REAL reference (oracle/_ref/libsdvref.so: the
+AudioProcessor's own processAudio loop on its own thread, fed in the bursts of the case; SamplesToWAV writing its files into a
+temporary directory) on the seeded scenarios of tests/audio_api.py.  Build container only (needs /root/reference).
+
+Each fixture: sha256 of the input PCMSamplePair stream (regenerated from the seeds by the test), the mode, the burst ends and the
+stop flag, and what the reference put out: the pairs, PCMSample::index of each, the positions of its newSource signals, the sum of
+its guiAddMask reports, and the bytes of the WAV files it wrote."""
+import hashlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import libs  # noqa: E402
+import audio_api as A  # noqa: E402
+
+
+def read_wavs(d):
+    files = {}
+    for f in sorted(os.listdir(d)):
+        assert f.startswith("src") and f.endswith("_v0.99.7.wav"), f
+        files[int(f[3:].split("_")[0])] = np.frombuffer(open(os.path.join(d, f), "rb").read(), dtype=np.uint8)
+    return files
+
+
+if __name__ == "__main__":
+    ref = libs.load_ref()
+    for name in A.GOLDEN:
+        pairs, mode, ends, stop = A.make_input(name)
+        with tempfile.TemporaryDirectory() as d:
+            out, idx, pur, masked, _ = A.run_cpu(ref, "ref_", pairs, mode, ends, stop, wav_dir=d)
+            wavs = read_wavs(d)
+        path = os.path.join(HERE, "audio_" + name + ".npz")
+        extra = {"wav%d" % k: v for k, v in wavs.items()}
+        np.savez_compressed(path, input_sha256=hashlib.sha256(pairs.tobytes()).hexdigest(), mode=mode, ends=ends, stop=stop,
+                            pairs=out.view(np.uint8).reshape(len(out), 12), index=idx, purges=pur, masked=masked, **extra)
+        print(f"{name}: {len(pairs)} pairs in -> {len(out)} out, {len(pur)} purges, {masked} masked, wav files {sorted(wavs)}, {os.path.getsize(path)} bytes")
