@@ -309,6 +309,50 @@ def main():
                 p16_keep[fmt] = (recs16, pp16[:200 * 1470].cpu().numpy().copy())
             del d16, o16p, o16f
 
+    # the consumer of every PCMSamplePair stream: AudioProcessor (dropout masking) on the pair stream of a tape of the same length,
+    # in three states of wear; the output of each is packed to WAV bytes (SamplesToWAV, 8f-2)
+    audio = None
+    if not args.no_stitch and world == 1:
+        import audio_api as _A
+        audio = {"note": "PCMSamplePair stream of n frames (1470 pairs each, NEW_FILE .. END_FILE) -> AudioProcessor window automaton in linear-interpolation "
+                         "mode (sdv_audio_process) -> 16-bit stereo PCM of the WAV file (sdv_wav_pack); wall clock per tape incl. the host round trips; "
+                         "algorithmic bytes = 12 B read + 12 B written per pair (+ 12 + 4 for the WAV packing); not part of `value`"}
+        npairs = n * 1470
+        rng = np.random.default_rng(9)
+        starts = np.sort(rng.integers(1000, npairs - 5000, max(1, n // 25)))
+        tapes = (("clean", dict()),
+                 ("dropout_every_25_frames", dict(runs=[(int(s_), int(rng.integers(1, 700)), int(rng.integers(0, 3))) for s_ in starts])),
+                 ("invalid_word_in_every_window", dict(p_bad=0.01)))
+        a_out = torch.empty((npairs + 1024, 12), dtype=torch.uint8, device=dev)
+        a_pur = torch.empty((16, 16), dtype=torch.uint8, device=dev)
+        a_pcm = torch.empty((npairs + 1024, 2), dtype=torch.int16, device=dev)
+        eng.set_audio_masking(_A.DROP_INTER_LIN_WORD)
+        audio_keep = {}
+        for name, kw in tapes:
+            tape = _A.tape(["N", _A.audio(npairs, 3, tone=False, **kw), "E"])
+            d_t = torch.from_numpy(tape.view(np.uint8).reshape(len(tape), 12)).to(dev)
+            eng.reset_audio(); eng.audio_process(d_t, stop=True, out_pairs=a_out, out_purges=a_pur, stream=stream)
+            k_steps = max(1, min(args.steps, 5))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(k_steps):
+                eng.reset_audio()
+                ao, apu, am = eng.audio_process(d_t, stop=True, out_pairs=a_out, out_purges=a_pur, stream=stream)
+            torch.cuda.synchronize(dev)
+            a_ms = (time.perf_counter() - t1) * 1e3 / k_steps
+            t1 = time.perf_counter()
+            for _ in range(k_steps):
+                eng.wav_pack(ao, out=a_pcm, stream=stream)
+            torch.cuda.synchronize(dev)
+            w_ms = (time.perf_counter() - t1) * 1e3 / k_steps
+            audio[name] = {"ms_per_step": a_ms, "frames_per_s": n / a_ms * 1e3, "pairs_per_s": npairs / a_ms * 1e3, "algorithmic_gb_per_s": 24 * npairs / a_ms / 1e6,
+                           "masked_samples": int(am), "wav_pack_ms_per_step": w_ms, "wav_pack_gb_per_s": 16 * npairs / w_ms / 1e6}
+            if rank == 0:
+                k = min(n, 2000) * 1470
+                audio_keep[name] = (tape[:k + 1], ao[:k - 600].cpu().numpy().copy())
+            del d_t
+        del a_out, a_pcm
+
     # ... and its front half: video lines -> PCM1Line records (sdv_pcm1_binarize_lines), a tape that plays (every line preset from a
     # decoded neighbour) and the cold case (nothing preset: the marker-less coordinate search on every line)
     pcm1f = None
@@ -452,6 +496,28 @@ def main():
             out["pcm1_front_stage"] = pcm1f
         if pcm16 is not None:
             out["pcm16x0_stage"] = pcm16
+        if audio is not None:
+            out["audio_stage"] = audio
+            if not args.no_cpu:
+                # the real AudioProcessor (its own processAudio loop on a thread, oracle/_ref) or the oracle port on the head of each tape
+                import libs as _libs
+                import audio_api as _A
+                use_ref = _libs.ref_available()
+                lib = _libs.load_ref() if use_ref else _libs.load_oracle()
+                for name, (head, first) in audio_keep.items():
+                    sample = _A.tape([head, "E"])
+                    fd = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)       # the worker logs to stderr
+                    try:
+                        t0 = time.perf_counter()
+                        cr = _A.run_cpu(lib, "ref_" if use_ref else "orc_", sample, _A.DROP_INTER_LIN_WORD, np.array([len(sample)], dtype=np.uint64), 1)
+                        dtc = time.perf_counter() - t0
+                    finally:
+                        os.dup2(fd, 2); os.close(devnull); os.close(fd)
+                    idle = 0.14 if use_ref else 0.0         # the driver's wait for the worker to go idle after the queue ran dry
+                    nf = (len(sample) - 2) / 1470
+                    audio[name]["cpu_baseline"] = {"value": nf / max(dtc - idle, 1e-6), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                                                   "sample": f"the first {nf:.0f} frames of the tape, {dtc - idle:.2f} s of CPU work",
+                                                   "bit_exact_vs_gpu_on_overlap": bool(cr[0][:len(first)].view(np.uint8).tobytes() == first.tobytes())}
         for key, (stage, _b, _f) in fmt_stages.items():
             out[key] = stage
         if not args.no_cpu and world == 1:

@@ -41,3 +41,17 @@ if __name__ == "__main__":
         np.savez_compressed(path, input_sha256=hashlib.sha256(pairs.tobytes()).hexdigest(), mode=mode, ends=ends, stop=stop,
                             pairs=out.view(np.uint8).reshape(len(out), 12), index=idx, purges=pur, masked=masked, **extra)
         print(f"{name}: {len(pairs)} pairs in -> {len(out)} out, {len(pur)} purges, {masked} masked, wav files {sorted(wavs)}, {os.path.getsize(path)} bytes")
+
+    # end to end: the PCMSamplePair stream the real VideoToDigital + STC007DataStitcher made of the synthetic NTSC file (e2e_ntsc_file.npz,
+    # tests/golden/make_golden_stitch.py) through the real AudioProcessor and into the real SamplesToWAV
+    from stitch_api import PAIR_DTYPE
+    z = np.load(os.path.join(HERE, "e2e_ntsc_file.npz"))
+    pairs = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    ends = np.array([len(pairs)], dtype=np.uint64)
+    with tempfile.TemporaryDirectory() as d:
+        out, idx, pur, masked, _ = A.run_cpu(ref, "ref_", pairs, A.DROP_INTER_LIN_WORD, ends, 1, wav_dir=d)
+        wavs = read_wavs(d)
+    path = os.path.join(HERE, "e2e_ntsc_file_audio.npz")
+    np.savez_compressed(path, input_sha256=hashlib.sha256(pairs.tobytes()).hexdigest(), pairs=out.view(np.uint8).reshape(len(out), 12), purges=pur, masked=masked,
+                        **{"wav%d" % k: v for k, v in wavs.items()})
+    print(f"e2e_ntsc_file: {len(pairs)} pairs in -> {len(out)} out, {masked} masked, wav files {sorted(wavs)}, {os.path.getsize(path)} bytes")

@@ -67,6 +67,24 @@ def test_oracle_matches_live_reference(name, oracle_lib):
         assert dict(A.wav_files(oracle_lib, "orc_", out, pur)) == ref_files
 
 
+def _e2e_audio_fixture():
+    z = np.load(os.path.join(GOLD, "e2e_ntsc_file_audio.npz"))
+    want = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    return z, want, {int(k[3:]): z[k].tobytes() for k in z.files if k.startswith("wav")}
+
+
+def test_oracle_whole_file_to_wav_matches_reference_golden(oracle_lib):
+    """The pair stream of the end-to-end fixture (video -> both real workers, e2e_ntsc_file.npz) -> oracle AudioProcessor -> WAV bytes ==
+    what the real AudioProcessor put out and the real SamplesToWAV wrote for it."""
+    z, want, wavs = _e2e_audio_fixture()
+    pairs = np.ascontiguousarray(np.load(os.path.join(GOLD, "e2e_ntsc_file.npz"))["pairs"]).view(PAIR_DTYPE).reshape(-1)
+    assert hashlib.sha256(pairs.tobytes()).hexdigest() == str(z["input_sha256"])
+    out, idx, pur, masked, hit = A.run_cpu(oracle_lib, "orc_", pairs, A.DROP_INTER_LIN_WORD, np.array([len(pairs)], dtype=np.uint64), 1)
+    assert out.tobytes() == want.tobytes(), _diff(out, want)
+    assert np.array_equal(pur["first_pair"], z["purges"]) and masked == int(z["masked"]) and masked > 0
+    assert dict(A.wav_files(oracle_lib, "orc_", out, pur)) == wavs and len(wavs) == 1
+
+
 def test_clean_stream_passes_unchanged(oracle_lib):
     """Property: a stream without invalid samples leaves as it came, behind one silent pair per file and without each file's last pair."""
     pairs, mode, ends, stop, out, idx, pur, masked, hit = _oracle("clean")
@@ -237,6 +255,28 @@ def test_gpu_matches_golden(name):
     d_out = torch.from_numpy(out.view(np.uint8).reshape(len(out), 12)).to("cuda:0")
     files = eng.wav_files(d_out, pur)
     assert files == {int(k[3:]): z[k].tobytes() for k in z.files if k.startswith("wav")}
+
+
+@pytest.mark.gpu
+def test_gpu_video_to_wav_matches_reference_golden():
+    """The whole chain on the device, buffers handed from stage to stage: video -> sdv_binarize_frames -> sdv_stitch_frames ->
+    sdv_audio_process -> sdv_wav_pack, against the file the real reference's four stages (VideoToDigital, STC007DataStitcher,
+    AudioProcessor, SamplesToWAV) wrote for the same video."""
+    import torch
+    import test_stitch_kernel as tsk
+    from sdvpcmdecoder_amd import Engine
+    luma, _, _, _ = tsk._e2e_fixture()
+    z, want, wavs = _e2e_audio_fixture()
+    eng = Engine(0)
+    lines, _ = eng.binarize_frames(torch.from_numpy(luma).cuda(), first_frame_no=1, new_file=True, end_file=True)
+    eng.set_stitch_settings(tsk._settings(tsk.sa.default_settings()))
+    pairs, _ = eng.stitch_frames(lines)
+    eng.set_audio_masking(A.DROP_INTER_LIN_WORD)
+    out, pur, masked = eng.audio_process(pairs, stop=True)
+    got = out.cpu().numpy().view(PAIR_DTYPE).reshape(-1)
+    assert got.tobytes() == want.tobytes(), _diff(got, want)
+    assert masked == int(z["masked"])
+    assert eng.wav_files(out, pur) == wavs
 
 
 @pytest.mark.gpu

@@ -30,3 +30,7 @@ bash $R/tools/gpu_pcm1_front_pmc.sh 2>&1 | grep "rc="
 bash $R/tools/gpu_frames_prof.sh 2>&1 | grep "rc="
 # PCM-16x0 back half: kernel stats
 bash $R/tools/gpu_pcm16_prof.sh 10000 2>&1 | grep "rc=\|frames/s"
+# AudioProcessor stage: kernel stats over the three tapes of tools/audio_prof.py
+rm -rf $R/gpurun_out/prof_audio
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_audio -- python3 $R/tools/audio_prof.py 10000 5 > $R/gpurun_out/prof_audio.log 2>&1; echo "rocprof audio rc=$?"
+grep "it=4" $R/gpurun_out/prof_audio.log

@@ -25,7 +25,7 @@ def trim(src, dst):
 trim(newest('gpurun_out/prof_bench/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_kernel_stats.csv')
 trim(newest('gpurun_out/prof_stitch/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_stitch_kernel_stats.csv')
 trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_pcm1_kernel_stats.csv')
-for d, name in (('prof_p1f', 'pcm1_frames'), ('prof_p16f', 'pcm16x0_frames'), ('prof_p16s', 'pcm16x0_stitch')):
+for d, name in (('prof_p1f', 'pcm1_frames'), ('prof_p16f', 'pcm16x0_frames'), ('prof_p16s', 'pcm16x0_stitch'), ('prof_audio', 'audio')):
     if glob.glob(f'gpurun_out/{d}/*/*kernel_stats.csv'):
         trim(newest(f'gpurun_out/{d}/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_{name}_kernel_stats.csv')
 if glob.glob('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'):
@@ -37,7 +37,9 @@ shutil.copy('gpurun_out/bench_2rank_gloo.json', f'profiles/{RND}_bench_2rank_glo
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', f'profiles/{RND}_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', f'profiles/{RND}_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
 d = json.loads(open('gpurun_out/bench_full.json').read().strip().split('\n')[-1])
+if os.path.exists('gpurun_out/prof_audio.log'):
+    shutil.copy('gpurun_out/prof_audio.log', f'profiles/{RND}_audio_prof.log')
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'launch ms', d['roofline']['avg_launch_ms'], 'traffic', d['roofline']['traffic'])
-for k in ('stitch_stage', 'pcm1_stage', 'pcm1_front_stage', 'pcm16x0_stage'):
+for k in ('stitch_stage', 'pcm1_stage', 'pcm1_front_stage', 'pcm16x0_stage', 'audio_stage'):
     if k in d: print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ('note', 'cpu_baseline')})
 print('cpu', d['cpu_baseline']['value'], d['stitch_stage']['cpu_baseline']['value'], d['pcm1_stage']['cpu_baseline']['value'], d.get('host_fed', {}).get('h2d_gb_per_s'))
