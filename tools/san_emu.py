@@ -66,3 +66,15 @@ for name in ("si_clean", "si_bad10", "si_picked_forced"):
     assert rc == 0 and p.tobytes() == wp.tobytes() and f.tobytes() == wf.tobytes(), name
     lib.sdv_engine_destroy(eng)
 print("pcm16x0 stitch emu ok")
+# round 2, SURVEY 8f: AudioProcessor on the emulator (plan with leaps, window chains, emit, WAV packing)
+import audio_api as au
+au.bind_product(lib)
+for name in sorted(au.CASES):
+    if name in au.UNSUPPORTED:
+        continue
+    pairs, mode, ends, stop = au.make_input(name)
+    want = au.run_cpu(orc, "orc_", pairs, mode, ends, stop)
+    out, pur, masked = au.emu_run(lib, pairs, mode, ends, stop)
+    assert out.tobytes() == want[0].tobytes() and pur.tobytes() == want[2].tobytes() and masked == want[3], name
+    au.wav_files(lib, "sdv_", out, pur)
+print("audio emu ok")

@@ -49,3 +49,10 @@ for name in sorted(p16.CASES):
     recs, st = p16.make_input(name)
     p16.run_cpu(_lib, "orc_", recs, st)
 print("pcm16x0 stitch ok")
+# round 2, SURVEY 8f: AudioProcessor / SamplesToWAV
+import audio_api as au
+for name in sorted(au.CASES):
+    pairs, mode, ends, stop = au.make_input(name)
+    out, idx, pur, masked, hit = au.run_cpu(_lib, "orc_", pairs, mode, ends, stop)
+    au.wav_files(_lib, "orc_", out, pur)
+print("audio ok")
