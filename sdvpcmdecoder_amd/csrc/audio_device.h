@@ -44,6 +44,11 @@ struct StretchResult { uint32_t popped, scanned_upto, flags, left; uint64_t mask
 
 __device__ __forceinline__ int a_lane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint32_t a_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
+__device__ __forceinline__ uint64_t lane_read64(uint64_t v, int src)      /* the value lane `src` (the same for every lane) holds */
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
 
 /* ---- tags: positions of the service pairs of the input ------------------------------------------------------------- */
 struct TagArgs { const sdv_sample_pair *pairs; uint32_t n; uint32_t *count; uint64_t *list; /* (position << 8) | service_type, in no particular order */ };
@@ -59,7 +64,7 @@ __device__ inline void tags_body(const TagArgs &a, uint32_t blk, int lane)
 /* ---- prepare: W and the bitmap ---------------------------------------------------------------------------------- */
 struct PrepArgs {
     const sdv_sample_pair *pairs; const sdv_sample_pair *carry; const Stretch *st; uint32_t n_st; uint32_t total_w;
-    sdv_sample_pair *w; uint64_t *bad1, *bad2, *bad3;
+    sdv_sample_pair *w; uint64_t *bad1; uint8_t *bad2; uint64_t *bad3;   /* one bit per pair; one byte per 64 pairs (zeroed up to a multiple of 64 bytes); one bit per 4096 pairs */
     uint64_t *v0, *v1, *m0, *m1;        /* per channel: word_valid, word_masked of every pair of W (a set bit past the end of W in v0 / v1) */
     uint32_t *has_mi;                   /* set when some sample is masked without being valid (only foreign input can be) */
     uint8_t by_block, ignore;
@@ -102,38 +107,53 @@ __device__ inline void prep_body(const PrepArgs &a, uint32_t blk, int lane)
         const uint64_t m = __ballot(bad), b0 = __ballot(ok0), b1 = __ballot(ok1), c0 = __ballot(mk0), c1 = __ballot(mk1);
         if (lane == 0 && (p >> 6) < ((a.total_w + 63u) >> 6)) {
             a.bad1[p >> 6] = m; a.v0[p >> 6] = b0; a.v1[p >> 6] = b1; a.m0[p >> 6] = c0; a.m1[p >> 6] = c1;
-            if ((c0 & ~b0) | (c1 & ~b1)) atomicOr(a.has_mi, 1u);
-            if (m) {
-                atomicOr((unsigned long long *)&a.bad2[p >> 12], 1ull << ((p >> 6) & 63u));
-                atomicOr((unsigned long long *)&a.bad3[p >> 18], 1ull << ((p >> 12) & 63u));
-            }
+            if (((c0 & ~b0) | (c1 & ~b1)) && !*a.has_mi) atomicOr(a.has_mi, 1u);
+            a.bad2[p >> 6] = m ? 1 : 0;
         }
     }
 }
 
-/* The first position >= p with its bit set, `limit` if there is none below it. */
-__device__ inline uint32_t next_bad(const uint64_t *bad1, const uint64_t *bad2, const uint64_t *bad3, uint32_t p, uint32_t limit)
+/* the top level from the middle one: a lane per block of 64 bytes (no atomics anywhere: on a worn tape every wave of the prepare
+ * pass has something to report, and thousands of atomics on a handful of words cost more than the pass itself) */
+struct SummArgs { const uint8_t *bad2; uint32_t n_blocks; uint64_t *bad3; };
+__device__ inline void summ_body(const SummArgs &a, uint32_t blk, int lane)
+{
+    const uint32_t g = blk * 64u + (uint32_t)lane;
+    uint64_t acc = 0;
+    if (g < a.n_blocks) for (int k = 0; k < 8; k++) acc |= ((const uint64_t *)a.bad2)[g * 8u + (uint32_t)k];
+    const uint64_t m = __ballot(acc != 0);
+    if (lane == 0) a.bad3[blk] = m;
+}
+
+/* The first position >= p with its bit set, `limit` if there is none below it.  A wave collective (lanes 0..7 read the eight
+ * 64-bit words of a 64-byte block of the middle level). */
+__device__ inline uint32_t next_bad(const uint64_t *bad1, const uint8_t *bad2, const uint64_t *bad3, uint32_t p, uint32_t limit, int lane)
 {
     if (p >= limit) return limit;
-    const uint32_t w = p >> 6, g = w >> 6, h = g >> 6;
-    uint64_t x = bad1[w] & (~0ull << (p & 63u));
-    uint32_t w1 = w;
-    if (!x) {
-        uint64_t y = bad2[g] & ((w & 63u) == 63u ? 0ull : (~0ull << ((w & 63u) + 1u)));
-        uint32_t g1 = g;
-        if (!y) {
-            uint64_t z = bad3[h] & ((g & 63u) == 63u ? 0ull : (~0ull << ((g & 63u) + 1u)));
-            uint32_t h1 = h;
-            const uint32_t h_end = ((limit - 1u) >> 18) + 1u;
-            while (!z) { h1++; if (h1 >= h_end) return limit; z = bad3[h1]; }
-            g1 = h1 * 64u + (uint32_t)__ffsll((unsigned long long)z) - 1u;
-            y = bad2[g1];
+    const uint32_t w = p >> 6;
+    const uint64_t x = bad1[w] & (~0ull << (p & 63u));
+    if (x) { const uint32_t q = w * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u; return q < limit ? q : limit; }
+    uint32_t g = w >> 6, skip = (w & 63u) + 1u;          /* the block of 64 words, and how many of its bytes lie at or before w */
+    for (;;) {
+        uint64_t y = lane < 8 ? ((const uint64_t *)bad2)[g * 8u + (uint32_t)lane] : 0ull;
+        const uint32_t first = (uint32_t)lane * 8u;     /* byte index of this lane's first byte in the block */
+        if (skip > first) y &= skip - first >= 8u ? 0ull : (~0ull << ((skip - first) * 8u));
+        const uint64_t m = __ballot(y != 0);
+        if (m) {
+            const int f = __ffsll((unsigned long long)m) - 1;
+            const uint64_t yf = lane_read64(y, f);
+            const uint32_t w1 = g * 64u + (uint32_t)f * 8u + (((uint32_t)__ffsll((unsigned long long)yf) - 1u) >> 3);
+            const uint32_t q = w1 * 64u + (uint32_t)__ffsll((unsigned long long)bad1[w1]) - 1u;
+            return q < limit ? q : limit;
         }
-        w1 = g1 * 64u + (uint32_t)__ffsll((unsigned long long)y) - 1u;
-        x = bad1[w1];
+        /* nothing more in this block: the next block that holds something */
+        uint32_t h = g >> 6;
+        uint64_t z = bad3[h] & ((g & 63u) == 63u ? 0ull : (~0ull << ((g & 63u) + 1u)));
+        const uint32_t h_end = ((limit - 1u) >> 18) + 1u;
+        while (!z) { h++; if (h >= h_end) return limit; z = bad3[h]; }
+        g = h * 64u + (uint32_t)__ffsll((unsigned long long)z) - 1u; skip = 0;
+        if (g * 4096u >= limit) return limit;
     }
-    const uint32_t q = w1 * 64u + (uint32_t)__ffsll((unsigned long long)x) - 1u;
-    return q < limit ? q : limit;
 }
 
 /* ---- one window ------------------------------------------------------------------------------------------------- */
@@ -274,7 +294,7 @@ __device__ inline uint32_t window_body(sdv_sample_pair *w, int n, bool file_end,
 enum { CHUNK_WORDS = 3072, CHUNK_PAD = 16, LEAP_WORDS = (STRIDE * 63 + WIN + 127) / 64 + 1 };
 struct PlanLds { uint64_t bm[2][CHUNK_WORDS + CHUNK_PAD]; };    /* word_valid of the two channels, staged */
 struct WinRec { uint32_t w_pos; uint32_t pops; uint16_t n; uint8_t file_end, head; };
-struct PlanArgs { const Stretch *st; uint32_t n_st; const uint64_t *v0, *v1, *m0, *m1, *bad1, *bad2, *bad3; const uint32_t *has_mi; uint32_t n_words;
+struct PlanArgs { const Stretch *st; uint32_t n_st; const uint64_t *v0, *v1, *m0, *m1, *bad1; const uint8_t *bad2; const uint64_t *bad3; const uint32_t *has_mi; uint32_t n_words;
                   WinRec *wins; const uint32_t *win_base; StretchResult *res; };
 
 __device__ __forceinline__ uint64_t word_range(int j, int a, int b)      /* the bits a..b (inclusive) that fall into word j */
@@ -283,53 +303,66 @@ __device__ __forceinline__ uint64_t word_range(int j, int a, int b)      /* the 
     if (lo > hi) return 0ull;
     return (~0ull >> (63 - (hi - lo))) << (lo - 64 * j);
 }
+/* A 512-bit mask spread over the wave: lane j < 8 holds bits 64j .. 64j+63, the other lanes hold 0.  One vector instruction then
+ * works on all eight words, the questions about the whole mask are a ballot plus one lane read.  Every member is a wave collective:
+ * call them from wave-uniform control flow only. */
+__device__ __forceinline__ uint64_t lane_pull64(uint64_t v, int src)      /* the value lane `src` (own choice of every lane) holds */
+{
+    const uint32_t lo = a_shfl((uint32_t)v, src), hi = a_shfl((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
 struct Bits512 {
-    uint64_t w[8];
-    __device__ __forceinline__ void set_all(uint64_t v) { for (int j = 0; j < 8; j++) w[j] = v; }
-    __device__ __forceinline__ void keep_below(int n) { for (int j = 0; j < 8; j++) w[j] &= n > 0 ? word_range(j, 0, n - 1) : 0ull; }
-    __device__ __forceinline__ void set_range(int a, int b) { if (a <= b) for (int j = 0; j < 8; j++) w[j] |= word_range(j, a, b); }
-    __device__ __forceinline__ bool any() const { uint64_t x = 0; for (int j = 0; j < 8; j++) x |= w[j]; return x != 0; }
-    __device__ __forceinline__ int lowest() const { int r = -1; for (int j = 7; j >= 0; j--) if (w[j]) r = 64 * j + __ffsll((unsigned long long)w[j]) - 1; return r; }
-    __device__ __forceinline__ int highest() const { int r = -1; for (int j = 0; j < 8; j++) if (w[j]) r = 64 * j + 63 - __clzll((unsigned long long)w[j]); return r; }
-    __device__ __forceinline__ bool bit(int i) const { uint64_t x = 0; for (int j = 0; j < 8; j++) x = (i >> 6) == j ? w[j] : x; return (x >> (i & 63)) & 1ull; }
-    __device__ __forceinline__ void shift_down(int k)       /* bit i <- bit i + k; whole words in three stages so that no index is a run-time value */
+    uint64_t w;
+    __device__ __forceinline__ static uint64_t range(int lane, int a, int b) { return lane < 8 ? word_range(lane, a, b) : 0ull; }
+    __device__ __forceinline__ void keep_below(int n, int lane) { w &= n > 0 ? range(lane, 0, n - 1) : 0ull; }
+    __device__ __forceinline__ void set_range(int a, int b, int lane) { if (a <= b) w |= range(lane, a, b); }
+    __device__ __forceinline__ bool any() const { return __ballot(w != 0) != 0; }
+    __device__ __forceinline__ int lowest() const
+    {
+        const uint64_t m = __ballot(w != 0);
+        const int j = m ? __ffsll((unsigned long long)m) - 1 : 0;
+        const uint64_t x = lane_read64(w, j);
+        return m ? 64 * j + __ffsll((unsigned long long)x) - 1 : -1;
+    }
+    __device__ __forceinline__ int highest() const
+    {
+        const uint64_t m = __ballot(w != 0);
+        const int j = m ? 63 - __clzll((unsigned long long)m) : 0;
+        const uint64_t x = lane_read64(w, j);
+        return m ? 64 * j + 63 - __clzll((unsigned long long)x) : -1;
+    }
+    __device__ __forceinline__ bool bit(int i) const { return (lane_read64(w, i >> 6) >> (i & 63)) & 1ull; }
+    __device__ __forceinline__ void shift_down(int k, int lane)      /* bit i <- bit i + k */
     {
         const int q = k >> 6, r = k & 63;
-        if (q & 4) { for (int j = 0; j < 4; j++) { w[j] = w[j + 4]; w[j + 4] = 0; } }
-        if (q & 2) { for (int j = 0; j < 6; j++) w[j] = w[j + 2]; w[6] = w[7] = 0; }
-        if (q & 1) { for (int j = 0; j < 7; j++) w[j] = w[j + 1]; w[7] = 0; }
-        if (r) { for (int j = 0; j < 7; j++) w[j] = (w[j] >> r) | (w[j + 1] << (64 - r)); w[7] >>= r; }
+        const int s0 = lane + q < 63 ? lane + q : 63, s1 = lane + q + 1 < 63 ? lane + q + 1 : 63;      /* lane 63 holds 0 */
+        const uint64_t lo = lane_pull64(w, s0), hi = lane_pull64(w, s1);
+        w = r ? (lo >> r) | (hi << (64 - r)) : lo;
     }
 };
 /* 512 bits of a staged bitmap from bit position `rel` on */
-/* every lane holds the same word: say so, and the 512-bit arithmetic of the plan runs on the scalar unit */
-__device__ __forceinline__ uint64_t uniform64(uint64_t x)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ void take512(const uint64_t *bm, uint32_t rel, Bits512 &o)
+__device__ __forceinline__ void take512(const uint64_t *bm, uint32_t rel, Bits512 &o, int lane)
 {
     const uint32_t q = rel >> 6, r = rel & 63u;
-    uint64_t x[9];
-    for (int j = 0; j < 9; j++) x[j] = uniform64(bm[q + j]);
-    for (int j = 0; j < 8; j++) o.w[j] = r ? (x[j] >> r) | (x[j + 1] << (64u - r)) : x[j];
+    const uint64_t x = lane < 9 ? bm[q + (uint32_t)lane] : 0ull;
+    const uint64_t nx = lane_pull64(x, lane < 63 ? lane + 1 : 63);
+    o.w = lane < 8 ? (r ? (x >> r) | (nx << (64u - r)) : x) : 0ull;
 }
 
 /* the validity of one channel after a scan of the window (n pairs) */
-__device__ inline void scan_validity(Bits512 &v, int n, bool file_end)
+__device__ inline void scan_validity(Bits512 &v, int n, bool file_end, int lane)
 {
     const int fv = v.lowest(), lv = v.highest();
     if (fv >= 0) {
-        Bits512 o; o.set_all(0);
-        o.set_range(fv, lv);                                /* the runs between valid samples are repaired */
-        if (lv < n - (RAMP_DOWN + RAMP_UP + 1)) o.set_range(lv + 1, lv + RAMP_DOWN + 1);       /* ramp down + its forced zero */
+        Bits512 o; o.w = 0;
+        o.set_range(fv, lv, lane);                          /* the runs between valid samples are repaired */
+        if (lv < n - (RAMP_DOWN + RAMP_UP + 1)) o.set_range(lv + 1, lv + RAMP_DOWN + 1, lane);      /* ramp down + its forced zero */
         v = o;
     }
     if (file_end && n >= 2 && !v.bit(n - 1)) {
-        Bits512 x = v; x.w[0] &= ~1ull;
-        const int a = x.highest() < 0 ? 0 : x.highest();
-        v.set_range(a + 1, n - 1);
+        Bits512 x = v; if (lane == 0) x.w &= ~1ull;
+        const int h = x.highest();
+        v.set_range((h < 0 ? 0 : h) + 1, n - 1, lane);
     }
 }
 
@@ -343,7 +376,7 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
     uint32_t chunk = 0xFFFFFFFFu;                           /* the first bitmap word staged in LDS */
     Bits512 ev0, ev1; bool have_ev = false, std_left = false;  /* std_left: they are all valid */                 /* validity of the pairs that stayed behind, as the scans left it */
     bool prev_adjacent = false;
-    ev0.set_all(0); ev1.set_all(0);
+    ev0.w = 0; ev1.w = 0;
     for (;;) {
         if (L >= (uint32_t)WIN) { flags |= RES_STALLED; break; }       /* a full window nothing can leave: the worker takes no more input */
         const uint32_t avail = total - (S + L);
@@ -357,9 +390,20 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
         if (chunk == 0xFFFFFFFFu || gw < chunk || gw + (uint32_t)LEAP_WORDS > chunk + (uint32_t)CHUNK_WORDS) {
             __syncthreads();
             chunk = gw;
-            for (uint32_t i = (uint32_t)lane; i < (uint32_t)(CHUNK_WORDS + CHUNK_PAD); i += 64u) {
-                const uint32_t wi = chunk + i; const bool in = wi < a.n_words;
-                lds.bm[0][i] = in ? a.v0[wi] : ~0ull; lds.bm[1][i] = in ? a.v1[wi] : ~0ull;
+            /* (CHUNK_WORDS + CHUNK_PAD) / 64 = 48.25 rounds: eight rounds of loads in flight at a time */
+            for (uint32_t base = 0; base < (uint32_t)(CHUNK_WORDS + CHUNK_PAD); base += 512u) {
+                uint64_t x0[8], x1[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = base + (uint32_t)u * 64u + (uint32_t)lane, wi = chunk + i;
+                    const bool in = i < (uint32_t)(CHUNK_WORDS + CHUNK_PAD) && wi < a.n_words;
+                    x0[u] = in ? a.v0[wi] : ~0ull; x1[u] = in ? a.v1[wi] : ~0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = base + (uint32_t)u * 64u + (uint32_t)lane;
+                    if (i < (uint32_t)(CHUNK_WORDS + CHUNK_PAD)) { lds.bm[0][i] = x0[u]; lds.bm[1][i] = x1[u]; }
+                }
             }
             __syncthreads();
         }
@@ -399,18 +443,15 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
         }
         const uint32_t rel = gpos - chunk * 64u;
         Bits512 o0, o1, c0, c1;
-        take512(lds.bm[0], rel, o0); take512(lds.bm[1], rel, o1);
-        o0.keep_below((int)n); o1.keep_below((int)n);
+        take512(lds.bm[0], rel, o0, lane); take512(lds.bm[1], rel, o1, lane);
+        o0.keep_below((int)n, lane); o1.keep_below((int)n, lane);
         c0 = o0; c1 = o1;
-        if (have_ev) for (int j = 0; j < 8; j++) {
-            const uint64_t keep = word_range(j, 0, (int)L - 1);
-            c0.w[j] = (o0.w[j] & ~keep) | (ev0.w[j] & keep); c1.w[j] = (o1.w[j] & ~keep) | (ev1.w[j] & keep);
-        }
-        Bits512 inv; for (int j = 0; j < 8; j++) inv.w[j] = ~(c0.w[j] & c1.w[j]);
-        inv.keep_below((int)n);
+        const uint64_t behind = Bits512::range(lane, 0, (int)L - 1);      /* the pairs that stayed behind */
+        if (have_ev) { c0.w = (o0.w & ~behind) | (ev0.w & behind); c1.w = (o1.w & ~behind) | (ev1.w & behind); }
+        Bits512 inv; inv.w = ~(c0.w & c1.w);
+        inv.keep_below((int)n, lane);
         /* does this window read what the one before it writes?  (the pairs that stayed behind, where they were invalid in the input) */
-        bool dep_now = false;
-        for (int j = 0; j < 8; j++) dep_now = dep_now || ((~(o0.w[j] & o1.w[j]) & word_range(j, 0, (int)L - 1)) != 0);
+        const bool dep_now = __ballot((~(o0.w & o1.w) & behind) != 0) != 0;
         const bool scan = file_end ? n > 0 : n >= (uint32_t)SCAN_MIN;
         const uint32_t play_min = file_end ? (uint32_t)KEEP : (uint32_t)PLAY_MIN;
         uint32_t pops = 0;
@@ -418,7 +459,7 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
             /* no invalid sample in reach: nothing changes, everything but the look-behind leaves; full windows in a row are skipped at once */
             prev_adjacent = false;
             if (!at_end) {
-                const uint32_t q = next_bad(a.bad1, a.bad2, a.bad3, gpos + L, limit) - t.w_base;
+                const uint32_t q = next_bad(a.bad1, a.bad2, a.bad3, gpos + L, limit, lane) - t.w_base;
                 const uint32_t end = q < total ? q : total;
                 const uint32_t m = (end - S - (uint32_t)WIN) / (uint32_t)STRIDE + 1u;
                 S += m * (uint32_t)STRIDE; L = KEEP;
@@ -431,12 +472,13 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
         } else if (scan) {
             scanned = S + n;
             Bits512 r0 = c0, r1 = c1;
-            scan_validity(r0, (int)n, file_end); scan_validity(r1, (int)n, file_end);
+            scan_validity(r0, (int)n, file_end, lane); scan_validity(r1, (int)n, file_end, lane);
             Bits512 wait;       /* pairs that cannot leave: a channel neither valid nor masked (PCMSamplePair::isReadyForOutput) */
-            if (has_mi) { Bits512 k0, k1; take512(a.m0 + (gpos >> 6), gpos & 63u, k0); take512(a.m1 + (gpos >> 6), gpos & 63u, k1); for (int j = 0; j < 8; j++) wait.w[j] = ~((r0.w[j] | k0.w[j]) & (r1.w[j] | k1.w[j])); }
-            else for (int j = 0; j < 8; j++) wait.w[j] = ~(r0.w[j] & r1.w[j]);
-            wait.keep_below((int)n);
-            const int first_wait = wait.any() ? wait.lowest() : (int)n;
+            if (has_mi) { Bits512 k0, k1; take512(a.m0 + (gpos >> 6), gpos & 63u, k0, lane); take512(a.m1 + (gpos >> 6), gpos & 63u, k1, lane); wait.w = ~((r0.w | k0.w) & (r1.w | k1.w)); }
+            else wait.w = ~(r0.w & r1.w);
+            wait.keep_below((int)n, lane);
+            const int lw = wait.lowest();
+            const int first_wait = lw >= 0 ? lw : (int)n;
             if (n >= play_min) {
                 int pp = first_wait - KEEP; if (pp < 0) pp = 0;
                 if (pp > (int)n - KEEP) pp = (int)n - KEEP;
@@ -451,10 +493,10 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
             prev_adjacent = true;
             ev0 = r0; ev1 = r1;
         } else { ev0 = c0; ev1 = c1; prev_adjacent = false; }
-        if (pops) { ev0.shift_down((int)pops); ev1.shift_down((int)pops); }
+        if (pops) { ev0.shift_down((int)pops, lane); ev1.shift_down((int)pops, lane); }
         have_ev = true;
         S += pops; L = n - pops;
-        { Bits512 z; for (int j = 0; j < 8; j++) z.w[j] = ~(ev0.w[j] & ev1.w[j]); z.keep_below((int)L); std_left = !z.any(); }
+        { Bits512 z; z.w = ~(ev0.w & ev1.w); z.keep_below((int)L, lane); std_left = !z.any(); }
         if (at_end) break;
     }
     if (lane == 0) {
@@ -517,6 +559,7 @@ __device__ inline void wav_body(const WavArgs &a, size_t i)
 
 __global__ void __launch_bounds__(64) sdv_k_ap_tags(sdva::TagArgs a) { sdva::tags_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_ap_prepare(sdva::PrepArgs a) { sdva::prep_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_ap_summary(sdva::SummArgs a) { sdva::summ_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_ap_plan(sdva::PlanArgs a)
 {
     __shared__ sdva::PlanLds lds;

@@ -138,6 +138,7 @@ inline Idx3 gdim() { return Idx3{ st().grid_dim.x, 1, 1 }; }
 #define __ballot(p) emu::collective(emu::OP_BALLOT, __LINE__, (uint64_t)((p) ? 1 : 0))
 #define __shfl(v, src) ((int)(uint32_t)emu::collective(emu::OP_SHFL, __LINE__, (uint64_t)(uint32_t)(v), (uint64_t)(src)))
 #define __syncthreads() ((void)emu::collective(emu::OP_SYNC, __LINE__, 0))
+#define __builtin_amdgcn_readlane(v, l) ((int)(uint32_t)emu::collective(emu::OP_SHFL, __LINE__, (uint64_t)(uint32_t)(v), (uint64_t)(l)))
 #define __builtin_amdgcn_readfirstlane(v) ((int)(uint32_t)emu::collective(emu::OP_FIRST, __LINE__, (uint64_t)(uint32_t)(v)))
 
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
