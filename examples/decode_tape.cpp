@@ -11,6 +11,11 @@
  *       8-bit luma frames of a PCM-1600/1610/1630 tape -> sdv_pcm16x0_binarize_frames (VideoToDigital with TYPE_PCM16X0) ->
  *       sdv_pcm16x0_stitch_frames (the PCM16X0DataStitcher worker's body); the sub-line records never leave the device
  *
+ *   decode_tape wav <luma.raw> <width> <height> <n_frames> <out.wav> [<mask mode 0..6>]
+ *       the whole chain of the application for an STC-007 file: sdv_binarize_frames -> sdv_stitch_frames -> sdv_audio_process (the
+ *       AudioProcessor worker's loop, linear interpolation of dropouts by default) -> sdv_wav_pack + sdv_wav_header: the file SamplesToWAV
+ *       writes, byte for byte; nothing but the luma goes to the device and nothing but the 16-bit PCM comes back
+ *
  * Build (host code only, any C++ compiler): g++ -std=c++17 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/decode_tape.cpp
  *        -Lsdvpcmdecoder_amd -lsdvpcm_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN/../sdvpcmdecoder_amd' (build.py: build_example).
  */
@@ -84,6 +89,52 @@ int main(int argc, char **argv)
         sdv_run_info info; sdv_get_run_info(eng, &info);
         printf("stc007: %d frames -> %zu line records -> %zu sample pairs, %zu frame descriptors (binarize rounds %u)\n", n, n_lines, n_pairs, n_frames, info.rounds);
         (void)hipFree(d_luma); (void)hipFree(d_lines); (void)hipFree(d_stats); (void)hipFree(d_frames);
+    } else if (mode == "wav" && (argc == 7 || argc == 8)) {
+        const int width = atoi(argv[3]), height = atoi(argv[4]), n = atoi(argv[5]);
+        const int mask_mode = argc == 8 ? atoi(argv[7]) : SDV_DROP_INTER_LIN_WORD;
+        if (!read_file(argv[2], in) || in.size() != (size_t)width * height * n) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
+        uint8_t *d_luma = NULL; sdv_line_rec *d_lines = NULL; sdv_frame_stats *d_stats = NULL; sdv_frame_asm *d_frames = NULL;
+        sdv_sample_pair *d_audio = NULL; sdv_audio_purge *d_purges = NULL; int16_t *d_pcm = NULL;
+        const size_t n_lines = sdv_binarize_records(height, n, SDV_FLAG_NEW_FILE | SDV_FLAG_END_FILE);
+        const size_t pairs_cap = n_lines * 4 + 8192, frames_cap = (size_t)n + 16, purges_cap = 8;
+        HIP_OK(hipMalloc((void **)&d_luma, in.size()));
+        HIP_OK(hipMalloc((void **)&d_lines, n_lines * sizeof(sdv_line_rec)));
+        HIP_OK(hipMalloc((void **)&d_stats, ((size_t)n + 1) * sizeof(sdv_frame_stats)));
+        HIP_OK(hipMalloc((void **)&d_pairs, pairs_cap * sizeof(sdv_sample_pair)));
+        HIP_OK(hipMalloc((void **)&d_frames, frames_cap * sizeof(sdv_frame_asm)));
+        HIP_OK(hipMalloc((void **)&d_audio, (pairs_cap + 1024) * sizeof(sdv_sample_pair)));
+        HIP_OK(hipMalloc((void **)&d_purges, purges_cap * sizeof(sdv_audio_purge)));
+        HIP_OK(hipMalloc((void **)&d_pcm, (pairs_cap + 1024) * 2 * sizeof(int16_t)));
+        HIP_OK(hipMemcpy(d_luma, in.data(), in.size(), hipMemcpyHostToDevice));
+        SDV_OKAY(sdv_set_mode(eng, SDV_MODE_NORMAL));
+        SDV_OKAY(sdv_binarize_frames(eng, d_luma, (size_t)width, (size_t)width * height, width, height, n, 1,
+                                     SDV_FLAG_NEW_FILE | SDV_FLAG_END_FILE, d_lines, n_lines, d_stats, (size_t)n + 1, NULL));
+        sdv_stitch_settings st; sdv_default_stitch_settings(&st);
+        SDV_OKAY(sdv_set_stitch_settings(eng, &st));
+        SDV_OKAY(sdv_stitch_frames(eng, d_lines, n_lines, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_frames, NULL));
+        /* the pair stream (NEW_FILE ... END_FILE) stays on the device and goes straight into the audio stage; stop = the application closing */
+        size_t n_audio = 0, n_purges = 0; uint64_t n_masked = 0;
+        SDV_OKAY(sdv_set_audio_masking(eng, mask_mode));
+        SDV_OKAY(sdv_audio_process(eng, d_pairs, n_pairs, 1, d_audio, pairs_cap + 1024, &n_audio, d_purges, purges_cap, &n_purges, &n_masked, NULL));
+        std::vector<sdv_audio_purge> purges(n_purges);
+        if (n_purges) HIP_OK(hipMemcpy(purges.data(), d_purges, n_purges * sizeof(sdv_audio_purge), hipMemcpyDeviceToHost));
+        /* the file of the first source: the pairs between its NEW_FILE purge and the next purge */
+        size_t a = 0, b = 0; bool found = false;
+        for (size_t k = 0; k < n_purges && !found; k++) if (purges[k].kind == SDV_AP_PURGE_NEW_FILE) { a = (size_t)purges[k].first_pair; b = k + 1 < n_purges ? (size_t)purges[k + 1].first_pair : n_audio; found = true; }
+        if (!found || b <= a) { fprintf(stderr, "no audio came out\n"); rc = 5; }
+        else {
+            SDV_OKAY(sdv_wav_pack(eng, d_audio + a, b - a, d_pcm, NULL));
+            HIP_OK(hipDeviceSynchronize());
+            sdv_sample_pair last;
+            HIP_OK(hipMemcpy(&last, d_audio + (b - 1), sizeof(last), hipMemcpyDeviceToHost));
+            std::vector<uint8_t> file(44 + 4 * (b - a));
+            sdv_wav_header(file.data(), b - a, last.sample_rate);
+            HIP_OK(hipMemcpy(file.data() + 44, d_pcm, 4 * (b - a), hipMemcpyDeviceToHost));
+            rc = write_file(argv[6], file.data(), file.size()) ? 0 : 4;
+            printf("wav: %d frames -> %zu sample pairs -> %zu after the audio stage (%llu samples masked, %zu purges) -> %zu bytes at %u Hz\n", n, n_pairs, n_audio,
+                   (unsigned long long)n_masked, n_purges, file.size(), last.sample_rate == 44056 ? 44056u : 44100u);
+        }
+        (void)hipFree(d_luma); (void)hipFree(d_lines); (void)hipFree(d_stats); (void)hipFree(d_frames); (void)hipFree(d_audio); (void)hipFree(d_purges); (void)hipFree(d_pcm);
     } else if (mode == "pcm1" && argc == 5) {
         if (!read_file(argv[2], in) || in.size() % sizeof(sdv_pcm1_line_rec)) { fprintf(stderr, "cannot read %s\n", argv[2]); return 1; }
         const size_t n_lines = in.size() / sizeof(sdv_pcm1_line_rec);

@@ -84,17 +84,32 @@ __device__ inline sdv_sample_pair silent_pair()
 }
 __device__ inline void prep_body(const PrepArgs &a, uint32_t blk, int lane)
 {
+    /* the stretch the wave's first pair lies in - almost always the stretch of all 256: looked up once, on the scalar unit */
+    const uint32_t p_first = blk * 256u;
+    const uint32_t s_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)find_stretch(a.st, a.n_st, p_first < a.total_w ? p_first : a.total_w - 1u));
+    const Stretch t_first = a.st[s_first];
+    const bool one = p_first + 256u <= t_first.w_base + t_first.v_len || s_first + 1u == a.n_st;
+    /* all four loads of the wave first, then the work: four times the bytes in flight */
+    sdv_sample_pair qs[4]; bool is_data[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t p = (blk * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
+        qs[r] = silent_pair(); is_data[r] = false;
+        if (p < a.total_w) {
+            Stretch t = t_first;
+            if (!one) t = a.st[find_stretch(a.st, a.n_st, p)];
+            const uint32_t k = p - t.w_base;
+            if (k >= t.head) { qs[r] = a.pairs[t.in_start + (k - t.head)]; is_data[r] = true; }
+            else if (t.head_is_carry) qs[r] = a.carry[k];
+        }
+    }
+#pragma unroll
     for (int r = 0; r < 4; r++) {
         const uint32_t p = (blk * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
         bool bad = false, ok0 = true, ok1 = true, mk0 = false, mk1 = false;
         if (p < a.total_w) {
-            const uint32_t s = find_stretch(a.st, a.n_st, p);
-            const Stretch t = a.st[s];
-            const uint32_t k = p - t.w_base;
-            sdv_sample_pair q;
-            if (k < t.head) q = t.head_is_carry ? a.carry[k] : silent_pair();
-            else {
-                q = a.pairs[t.in_start + (k - t.head)];
+            sdv_sample_pair q = qs[r];
+            if (is_data[r]) {
                 q._pad = 0;
                 if (a.by_block) for (int ch = 0; ch < 2; ch++)      /* setValidityByBlock (:166-169) */
                     q.sample_flags[ch] = (uint8_t)((q.sample_flags[ch] & ~SDV_SF_WORD_VALID) | ((q.sample_flags[ch] & SDV_SF_BLOCK_OK) ? SDV_SF_WORD_VALID : 0));
@@ -533,16 +548,28 @@ struct EmitArgs { const Stretch *st; uint32_t n_st; const StretchResult *res; co
                   sdv_sample_pair *carry_out; uint8_t ignore; };
 __device__ inline void emit_body(const EmitArgs &a, uint32_t blk, int lane)
 {
+    const uint32_t p_first = blk * 256u;
+    const uint32_t s_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)find_stretch(a.st, a.n_st, p_first < a.total_w ? p_first : a.total_w - 1u));
+    const Stretch t_first = a.st[s_first];
+    const StretchResult r_first = a.res[s_first];
+    const bool one = p_first + 256u <= t_first.w_base + t_first.v_len || s_first + 1u == a.n_st;
+    sdv_sample_pair qs[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t p = (blk * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
+        if (p < a.total_w) qs[r] = a.w[p];
+    }
+#pragma unroll
     for (int r = 0; r < 4; r++) {
         const uint32_t p = (blk * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
         if (p >= a.total_w) continue;
-        const uint32_t s = find_stretch(a.st, a.n_st, p);
-        const Stretch t = a.st[s];
+        Stretch t = t_first; uint32_t popped = r_first.popped, scanned = r_first.scanned_upto;
+        if (!one) { const uint32_t s = find_stretch(a.st, a.n_st, p); t = a.st[s]; popped = a.res[s].popped; scanned = a.res[s].scanned_upto; }
         const uint32_t k = p - t.w_base;
         const bool closed = t.end_kind != END_OPEN || t.stop;
-        const uint32_t n_out = closed ? (t.v_len > 0 ? t.v_len - 1u : 0u) : a.res[s].popped;     /* a purge drops the last pair (:1423-1434) */
-        sdv_sample_pair q = a.w[p];
-        if (a.ignore && k < a.res[s].scanned_upto) { q.sample_flags[0] |= SDV_SF_WORD_VALID; q.sample_flags[1] |= SDV_SF_WORD_VALID; }   /* clearInvalids (:1404-1409) */
+        const uint32_t n_out = closed ? (t.v_len > 0 ? t.v_len - 1u : 0u) : popped;     /* a purge drops the last pair (:1423-1434) */
+        sdv_sample_pair q = qs[r];
+        if (a.ignore && k < scanned) { q.sample_flags[0] |= SDV_SF_WORD_VALID; q.sample_flags[1] |= SDV_SF_WORD_VALID; }   /* clearInvalids (:1404-1409) */
         if (k < n_out) { const uint64_t o = t.out_base + k; if (o < a.out_cap) a.out[o] = q; }
         else if (!closed) a.carry_out[k - n_out] = q;
     }

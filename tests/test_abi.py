@@ -126,3 +126,22 @@ def test_cpp_host_program_pcm16x0_matches_reference_golden(fmt, tmp_path):
     assert out.returncode == 0, out.stderr + out.stdout
     assert (tmp_path / "pairs.out").read_bytes() == want_p.tobytes()
     assert (tmp_path / "frames.out").read_bytes() == want_f.tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_writes_the_reference_wav(tmp_path):
+    """decode_tape wav: luma file -> binarize -> stitch -> sdv_audio_process -> sdv_wav_pack / sdv_wav_header from plain C++; the file equals the
+    one the real reference's SamplesToWAV wrote at the end of its own chain (tests/golden/e2e_ntsc_file_audio.npz)."""
+    import subprocess
+    import numpy as np
+    from sdvpcmdecoder_amd import build as b
+    import test_stitch_kernel as tsk
+    import test_audio as ta
+    exe = b.build_example()
+    luma, _, _, _ = tsk._e2e_fixture()
+    z, _, wavs = ta._e2e_audio_fixture()
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    out = subprocess.run([exe, "wav", str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "out.wav")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert (tmp_path / "out.wav").read_bytes() == wavs[0]
