@@ -622,6 +622,28 @@ int sdv_wav_pack(sdv_engine *e, const sdv_sample_pair *pairs, size_t n, int16_t 
  * Host memory. */
 void sdv_wav_header(uint8_t hdr[44], uint64_t n_pairs, uint16_t last_sample_rate);
 
+/* ---- the workers back to back: video frames -> PCMSamplePair (-> masked PCMSamplePair) in one call ------------------- */
+/* SURVEY 8b's "sdv_decode_frames": the format's VideoToDigital worker, its data stitcher and - on request - the AudioProcessor, one
+ * after the other on `stream`, with the line records (and the raw pair stream) in buffers the engine owns, so that only the luma
+ * goes in and only the sample pairs come out.  pcm_type selects the chain (what setPCMType selects in the application):
+ *   SDV_PCM_STC007   sdv_binarize_frames          -> sdv_stitch_frames           out_frames: sdv_frame_asm[]         (64 B)
+ *   SDV_PCM_PCM1     sdv_pcm1_binarize_frames     -> sdv_pcm1_bin_to_line_recs -> sdv_pcm1_stitch_frames
+ *                                                                                out_frames: sdv_frame_asm_pcm1[]    (52 B)
+ *   SDV_PCM_PCM16X0  sdv_pcm16x0_binarize_frames  -> sdv_pcm16x0_stitch_frames   out_frames: sdv_frame_asm_pcm16x0[] (56 B)
+ * Arguments up to `flags` as for sdv_binarize_frames (SDV_FLAG_NEW_FILE / SDV_FLAG_END_FILE put the file tags into the stream);
+ * every setting comes from the same setters as for the separate calls (sdv_set_mode, sdv_set_bin_preset, sdv_set_stitch_settings,
+ * sdv_set_pcm1_stitch_settings, sdv_set_pcm16x0_stitch_settings, sdv_set_audio_masking), and the stream state of every stage lives on
+ * in the engine exactly as if the separate entry points had been called.  out_stats (n_frames records, + 1 with SDV_FLAG_END_FILE) may
+ * be NULL.  with_audio != 0: the pair stream goes through sdv_audio_process (stop = audio_stop) before it is handed out; out_purges /
+ * n_purges / n_masked then receive what that call reports (NULL otherwise).  The result is what the separate calls give - the parity
+ * tests compare the two.  A failure of a later stage leaves the earlier stages' stream state advanced (the frames were binarized):
+ * after an error other than SDV_ERR_BAD_ARG for a too small buffer of the last stage, reset the streams. */
+int sdv_decode_frames(sdv_engine *e, int pcm_type, const uint8_t *luma, size_t row_stride, size_t frame_stride, int width, int height,
+                      int n_frames, uint32_t first_frame_no, unsigned flags,
+                      sdv_sample_pair *out_pairs, size_t pairs_cap, size_t *n_pairs, void *out_frames, size_t frames_cap, size_t *n_frames_out,
+                      sdv_frame_stats *out_stats, size_t stats_cap,
+                      int with_audio, int audio_stop, sdv_audio_purge *out_purges, size_t purges_cap, size_t *n_purges, uint64_t *n_masked, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,6 +192,10 @@ def load_library(path: str | None = None):
     lib.sdv_wav_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.sdv_wav_header.argtypes = [C.c_void_p, C.c_uint64, C.c_uint16]
     lib.sdv_wav_header.restype = None
+    lib.sdv_decode_frames.restype = C.c_int
+    lib.sdv_decode_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint,
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_void_p]
     if path is None:
         _lib = lib
     return lib
@@ -626,3 +630,30 @@ class Engine:
                 files[k] = self.wav_header(b - a, rate) + pcm.cpu().numpy().tobytes()
             k += 1
         return files
+
+    # ---- the workers back to back (sdv_decode_frames) ---------------------------------------------
+    def decode_frames(self, pcm_type: int, luma, first_frame_no: int = 1, new_file: bool = False, doubled: bool = False, end_file: bool = False,
+                      with_audio: bool = False, audio_stop: bool = False, stream=None):
+        """Video frames -> PCMSamplePair in one call: the format's VideoToDigital worker, its data stitcher and - with_audio - the AudioProcessor;
+        the line records (and the raw pair stream) stay inside the engine.  luma: torch.uint8 CUDA tensor (n_frames, height, width).
+        Returns (pairs (n, 12), frame descriptors (n, 64 / 52 / 56), frame stats (n, 32)) and, with_audio, also (purges (n, 16), masked)."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 3 and luma.stride(2) == 1
+        n, h, w = luma.shape
+        flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0) | (FLAG_END_FILE if end_file else 0)
+        fr_bytes = {PCM_STC007: 64, 0: 52, 1: 56}[pcm_type]
+        nst = n + (1 if end_file else 0)
+        out_pairs = torch.empty(((n + 2) * 1800 + 8192, 12), dtype=torch.uint8, device=luma.device)
+        out_frames = torch.empty((n + 16, fr_bytes), dtype=torch.uint8, device=luma.device)
+        out_stats = torch.empty((nst, 32), dtype=torch.uint8, device=luma.device)
+        out_purges = torch.empty((16, 16), dtype=torch.uint8, device=luma.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        n_pairs, n_fr, n_pur, masked = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+        rc = self.lib.sdv_decode_frames(self._h, pcm_type, C.c_void_p(luma.data_ptr()), luma.stride(1), luma.stride(0), w, h, n, first_frame_no, flags,
+                                        C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0], C.byref(n_pairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0],
+                                        C.byref(n_fr), C.c_void_p(out_stats.data_ptr()), out_stats.shape[0], 1 if with_audio else 0, 1 if audio_stop else 0,
+                                        C.c_void_p(out_purges.data_ptr()), out_purges.shape[0], C.byref(n_pur), C.byref(masked), sptr)
+        self._check(rc)
+        if with_audio:
+            return out_pairs[:n_pairs.value], out_frames[:n_fr.value], out_stats[:nst], out_purges[:n_pur.value], int(masked.value)
+        return out_pairs[:n_pairs.value], out_frames[:n_fr.value], out_stats[:nst]

@@ -1,0 +1,141 @@
+"""sdv_decode_frames (the workers back to back, chain selected by the PCM type): the fused call gives what the separate
+entry points give - line records and the raw pair stream never leave the engine - for the three formats, with and without the audio stage;
+on the SIMT emulator (CPU) and through the C-ABI on the GPU (-m gpu).  The separate entry points are themselves pinned against the oracle
+and the real reference by their own test files."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import audio_api as A
+import dist_worker
+import engine_api as ea
+import pcm1_api as p1
+import pcm16_api as p16
+import stitch_api as sa
+from emu_engine_adapter import EmuEngine
+from stitch_api import PAIR_DTYPE
+
+PCM1, PCM16X0, STC007 = 0, 1, 2
+FRASM = {STC007: sa.FRASM_DTYPE, PCM1: p1.FRASM1_DTYPE, PCM16X0: p16.FRASM16_DTYPE}
+
+
+def _bind(lib):
+    lib.sdv_decode_frames.restype = C.c_int
+    lib.sdv_decode_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint,
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.sdv_set_pcm_type.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    return lib
+
+
+def _tape(fmt, n):
+    from sdvpcmdecoder_amd import synth
+    if fmt == STC007:
+        luma = synth.stc007_frames(n, seed=12, noise_sigma=4.0)[0].copy()
+        luma[:, 77::61] = 16        # lost lines: the error correction and, where it gives up, the dropout masking have something to do
+        return luma
+    return dist_worker.pcm_tape("pcm1" if fmt == PCM1 else "pcm16x0", n)
+
+
+def _separate(eng, fmt, luma):
+    """The chain stage by stage through the separate entry points -> (pairs, frame descriptors, frame stats)."""
+    if fmt == STC007:
+        recs, stats = eng.binarize_frames(luma, first_frame_no=1, new_file=True, end_file=True)
+        pairs, frames = eng.stitch_frames(recs)
+    elif fmt == PCM1:
+        recs, stats = eng.pcm1_binarize_frames(luma, first_frame_no=1, new_file=True, end_file=True)
+        pairs, frames = eng.pcm1_stitch_frames(eng.pcm1_bin_to_line_recs(recs))
+    else:
+        recs, stats = eng.pcm16x0_binarize_frames(luma, first_frame_no=1, new_file=True, end_file=True)
+        pairs, frames = eng.pcm16x0_stitch_frames(recs)
+    return pairs, frames, stats
+
+
+def _fused_host(lib, h, fmt, luma, with_audio, stop=1, give_stats=True):
+    luma = np.ascontiguousarray(luma)
+    n, hgt, w = luma.shape
+    cap = (n + 2) * 1800 + 8192
+    pairs = np.zeros(cap, dtype=PAIR_DTYPE)
+    frames = np.zeros(n + 16, dtype=FRASM[fmt])
+    stats = np.zeros(n + 1, dtype=ea.STATS_DTYPE)
+    pur = np.zeros(8, dtype=A.PURGE_DTYPE)
+    npairs, nfr, npur, nm = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+    rc = lib.sdv_decode_frames(h, fmt, luma.ctypes.data, w, w * hgt, w, hgt, n, 1, 1 | 4, pairs.ctypes.data, cap, C.byref(npairs), frames.ctypes.data, len(frames),
+                               C.byref(nfr), stats.ctypes.data if give_stats else None, len(stats) if give_stats else 0, 1 if with_audio else 0, stop,
+                               pur.ctypes.data, len(pur), C.byref(npur), C.byref(nm), None)
+    assert rc == 0, lib.sdv_last_error(h)
+    return pairs[:npairs.value], frames[:nfr.value], stats, pur[:npur.value], nm.value
+
+
+@pytest.mark.parametrize("fmt", [STC007, PCM1, PCM16X0])
+def test_emu_fused_equals_separate_calls(fmt, emu_lib, oracle_lib):
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    luma = _tape(fmt, 3)
+    a = EmuEngine(lib)
+    lib.sdv_set_pcm_type(a.h, fmt, 0)
+    want_p, want_f, want_s = _separate(a, fmt, luma)
+    assert len(want_p) > 3 * 1400 and want_p["service_type"][0] == 1 and want_p["service_type"][-1] == 2
+    a.close()
+    b = EmuEngine(lib)
+    lib.sdv_set_pcm_type(b.h, fmt, 0)
+    got_p, got_f, got_s, _, _ = _fused_host(lib, b.h, fmt, luma, with_audio=False)
+    assert got_p.tobytes() == want_p.tobytes() and got_f.tobytes() == want_f.tobytes() and got_s.tobytes() == want_s.tobytes()
+    b.close()
+    # ... and with the audio stage behind it: the oracle's AudioProcessor on the separate calls' pair stream
+    c = EmuEngine(lib)
+    lib.sdv_set_pcm_type(c.h, fmt, 0)
+    lib.sdv_set_audio_masking(c.h, A.DROP_INTER_LIN_WORD)
+    got_a, got_f2, _, pur, masked = _fused_host(lib, c.h, fmt, luma, with_audio=True, give_stats=False)
+    w_out, _, w_pur, w_masked, hit = A.run_cpu(oracle_lib, "orc_", want_p, A.DROP_INTER_LIN_WORD, np.array([len(want_p)], dtype=np.uint64), 1)
+    assert hit == 0 and got_a.tobytes() == w_out.tobytes() and pur.tobytes() == w_pur.tobytes() and masked == w_masked and got_f2.tobytes() == want_f.tobytes()
+    if fmt == STC007:
+        assert masked > 0       # the lost lines left samples the error correction could not restore
+    c.close()
+
+
+def test_emu_fused_refuses_bad_arguments(emu_lib):
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    e = EmuEngine(lib)
+    luma = np.zeros((1, 16, 720), dtype=np.uint8)
+    n1, n2 = C.c_size_t(0), C.c_size_t(0)
+    buf = np.zeros(4096, dtype=PAIR_DTYPE)
+    args = (luma.ctypes.data, 720, 720 * 16, 720, 16, 1, 1, 0, buf.ctypes.data, len(buf), C.byref(n1), buf.ctypes.data, 8, C.byref(n2), None, 0)
+    assert lib.sdv_decode_frames(e.h, 5, *args, 0, 0, None, 0, None, None, None) == -1 and b"unknown PCM type" in lib.sdv_last_error(e.h)
+    assert lib.sdv_decode_frames(e.h, STC007, *args, 1, 0, None, 0, None, None, None) == -1 and b"with_audio" in lib.sdv_last_error(e.h)
+    assert lib.sdv_decode_frames(e.h, STC007, None, *args[1:], 0, 0, None, 0, None, None, None) == 1      # LB_RET_NULL_VIDEO
+    e.close()
+
+
+# ---- the product on the GPU ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [STC007, PCM1, PCM16X0])
+def test_gpu_fused_equals_separate_calls(fmt, oracle_lib):
+    import torch
+    from sdvpcmdecoder_amd import Engine, Pcm16x0StitchSettings
+    luma = _tape(fmt, 6)
+    d = torch.from_numpy(np.ascontiguousarray(luma)).cuda()
+    eng = Engine(0)
+    eng.setPCMType(fmt)
+    if fmt == STC007:
+        lines, stats = eng.binarize_frames(d, first_frame_no=1, new_file=True, end_file=True)
+        p, f = eng.stitch_frames(lines)
+    elif fmt == PCM1:
+        lines, stats = eng.pcm1_binarize_frames(d, first_frame_no=1, new_file=True, end_file=True)
+        p, f = eng.pcm1_stitch_frames(eng.pcm1_bin_to_line_recs(lines))
+    else:
+        lines, stats = eng.pcm16x0_binarize_frames(d, first_frame_no=1, new_file=True, end_file=True)
+        p, f = eng.pcm16x0_stitch_frames(lines)
+    want_p, want_f, want_s = p.cpu().numpy().copy(), f.cpu().numpy().copy(), stats.cpu().numpy().copy()
+    eng2 = Engine(0)
+    eng2.setPCMType(fmt)
+    gp, gf, gs = eng2.decode_frames(fmt, d, first_frame_no=1, new_file=True, end_file=True)
+    assert gp.cpu().numpy().tobytes() == want_p.tobytes() and gf.cpu().numpy().tobytes() == want_f.tobytes() and gs.cpu().numpy().tobytes() == want_s.tobytes()
+    eng3 = Engine(0)
+    eng3.setPCMType(fmt)
+    eng3.set_audio_masking(A.DROP_INTER_LIN_WORD)
+    ga, gf3, _, pur, masked = eng3.decode_frames(fmt, d, first_frame_no=1, new_file=True, end_file=True, with_audio=True, audio_stop=True)
+    wp = want_p.view(PAIR_DTYPE).reshape(-1)
+    w_out, _, w_pur, w_masked, hit = A.run_cpu(oracle_lib, "orc_", wp, A.DROP_INTER_LIN_WORD, np.array([len(wp)], dtype=np.uint64), 1)
+    assert hit == 0 and ga.cpu().numpy().tobytes() == w_out.tobytes() and pur.cpu().numpy().tobytes() == w_pur.tobytes() and masked == w_masked
+    assert gf3.cpu().numpy().tobytes() == want_f.tobytes()
