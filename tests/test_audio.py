@@ -181,6 +181,30 @@ def test_emu_edge_inputs(emu, oracle_lib):
     emu.sdv_engine_destroy(eng)
 
 
+def test_emu_in_place_and_staged_paths_agree(emu, oracle_lib):
+    """With room for the whole burst the pairs are worked on in place in the caller's buffer; with exactly the room the output needs they go through
+    a buffer of the engine.  Same result, burst by burst."""
+    for name in ("short_runs_lin", "window_edges", "bursts_long_runs", "worn_tape", "no_first_tag"):
+        pairs, mode, ends, stop, want, idx, want_pur, want_masked, hit = _oracle(name)
+        eng = emu.sdv_engine_create(0)
+        emu.sdv_set_audio_masking(eng, mode)
+        outs, a = [], 0
+        for k, b in enumerate(ends):
+            b = int(b)
+            st = 1 if (stop and k + 1 == len(ends)) else 0
+            rc, o, _, _, n_out, n_pur = A.emu_audio(emu, eng, pairs[a:b], st, out_cap=0)          # refused: tells the size, takes nothing
+            if rc == 0:                 # ... unless the burst puts nothing out
+                assert n_out == 0
+            else:
+                assert rc == -1 and n_out > 0
+                rc, o, p, m, n_out2, _ = A.emu_audio(emu, eng, pairs[a:b], st, out_cap=n_out, purges_cap=max(n_pur, 1))
+                assert rc == 0 and n_out2 == n_out
+            outs.append(o.copy()); a = b
+        emu.sdv_engine_destroy(eng)
+        out = np.concatenate(outs)
+        assert out.tobytes() == want.tobytes(), name + ": " + _diff(out, want)
+
+
 def test_emu_many_files_in_one_call(emu, oracle_lib):
     """The stretches between tags are independent: 40 short files in one burst, one wave each."""
     rng = np.random.default_rng(5)
