@@ -34,3 +34,7 @@ bash $R/tools/gpu_pcm16_prof.sh 10000 2>&1 | grep "rc=\|frames/s"
 rm -rf $R/gpurun_out/prof_audio
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_audio -- python3 $R/tools/audio_prof.py 10000 5 > $R/gpurun_out/prof_audio.log 2>&1; echo "rocprof audio rc=$?"
 grep "it=4" $R/gpurun_out/prof_audio.log
+# ... and the HBM traffic of its streaming pass (sdv_k_ap_prepare: input -> the caller's buffer + bitmaps), PMC passes on the clean tape
+rm -rf $R/gpurun_out/apmc3 $R/gpurun_out/apmc4
+rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/apmc3 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc3.err; echo "apmc3 rc=$?"
+rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/apmc4 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc4.err; echo "apmc4 rc=$?"

@@ -36,6 +36,8 @@ shutil.copy('gpurun_out/bench_full.json', f'profiles/{RND}_bench_full.json')
 shutil.copy('gpurun_out/bench_2rank_gloo.json', f'profiles/{RND}_bench_2rank_gloo_one_gpu.json')
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', f'profiles/{RND}_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', f'profiles/{RND}_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
+if glob.glob('gpurun_out/apmc3/**/*_counter_collection.csv', recursive=True):
+    subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_ap_prepare', f'profiles/{RND}_pmc_sdv_k_ap_prepare.json', 'apmc', 'tools/audio_prof.py 10000 1: 14.7 M sample pairs per launch, 176.4 MB read + 176.4 MB written algorithmic'], stdout=subprocess.DEVNULL)
 d = json.loads(open('gpurun_out/bench_full.json').read().strip().split('\n')[-1])
 if os.path.exists('gpurun_out/prof_audio.log'):
     shutil.copy('gpurun_out/prof_audio.log', f'profiles/{RND}_audio_prof.log')
