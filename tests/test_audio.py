@@ -205,6 +205,18 @@ def test_emu_in_place_and_staged_paths_agree(emu, oracle_lib):
         assert out.tobytes() == want.tobytes(), name + ": " + _diff(out, want)
 
 
+def test_emu_random_tapes(emu, oracle_lib):
+    """Differential fuzz (tools/audio_fuzz.py): 60 random tapes - files of random length, dropout runs of random place / length / channel, random
+    invalid words and blocks, tags in random order, random bursts, every masking mode - the kernels against the oracle.  (The same generator
+    ran 150 tapes through the real AudioProcessor against the oracle, and 400 through the emulator, when this was written.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audio_fuzz", os.path.join(os.path.dirname(GOLD), "..", "tools", "audio_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    res = [fz.check(emu, oracle_lib, seed) for seed in range(5000, 5060)]
+    assert res.count("ok") >= 55
+
+
 def test_emu_many_files_in_one_call(emu, oracle_lib):
     """The stretches between tags are independent: 40 short files in one burst, one wave each."""
     rng = np.random.default_rng(5)
@@ -301,6 +313,27 @@ def test_gpu_video_to_wav_matches_reference_golden():
     assert got.tobytes() == want.tobytes(), _diff(got, want)
     assert masked == int(z["masked"])
     assert eng.wav_files(out, pur) == wavs
+
+
+@pytest.mark.gpu
+def test_gpu_random_tapes(oracle_lib):
+    """The differential fuzz of tools/audio_fuzz.py on the GPU: 300 random tapes against the oracle."""
+    import importlib.util
+    from sdvpcmdecoder_amd import Engine
+    spec = importlib.util.spec_from_file_location("audio_fuzz", os.path.join(os.path.dirname(GOLD), "..", "tools", "audio_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    eng = Engine(0)
+    n_ok = 0
+    for seed in range(7000, 7300):
+        pairs, mode, ends, stop = fz.random_case(seed)
+        want = A.run_cpu(oracle_lib, "orc_", pairs, mode, ends, stop)
+        if want[4]:
+            continue
+        out, pur, masked = _gpu_run(eng, pairs, mode, ends, stop)
+        assert out.tobytes() == want[0].tobytes() and pur.tobytes() == want[2].tobytes() and masked == want[3], (seed, mode, list(ends), stop)
+        n_ok += 1
+    assert n_ok >= 280
 
 
 @pytest.mark.gpu
