@@ -217,6 +217,24 @@ def test_emu_random_tapes(emu, oracle_lib):
     assert res.count("ok") >= 55
 
 
+def test_emu_next_index_runs_on_across_calls(emu, oracle_lib):
+    """sdv_audio_next_index before a call = PCMSample::index of the first pair that call puts out (the reference's own index, from the oracle run)."""
+    for name in ("bursts_long_runs", "bursts_two_files", "bursts_small"):
+        pairs, mode, ends, stop, want, idx, want_pur, want_masked, hit = _oracle(name)
+        eng = emu.sdv_engine_create(0)
+        emu.sdv_set_audio_masking(eng, mode)
+        a = got = 0
+        for k, b in enumerate(ends):
+            b = int(b)
+            before = emu.sdv_audio_next_index(eng)
+            rc, o, p, m, _, _ = A.emu_audio(emu, eng, pairs[a:b], 1 if (stop and k + 1 == len(ends)) else 0)
+            assert rc == 0
+            if len(o) and (len(p) == 0 or p[0]["first_pair"] > 0):
+                assert before == idx[got], (name, k)
+            got += len(o); a = b
+        emu.sdv_engine_destroy(eng)
+
+
 def test_emu_many_files_in_one_call(emu, oracle_lib):
     """The stretches between tags are independent: 40 short files in one burst, one wave each."""
     rng = np.random.default_rng(5)
@@ -313,6 +331,19 @@ def test_gpu_video_to_wav_matches_reference_golden():
     assert got.tobytes() == want.tobytes(), _diff(got, want)
     assert masked == int(z["masked"])
     assert eng.wav_files(out, pur) == wavs
+
+
+@pytest.mark.gpu
+def test_gpu_output_buffer_grows_on_demand(oracle_lib):
+    """Engine.audio_process with a buffer that is too small: the refused call takes nothing, the wrapper comes again with the sizes it was told."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    pairs, mode, ends, stop, want, idx, want_pur, want_masked, hit = _oracle("two_files")
+    eng = Engine(0)
+    eng.set_audio_masking(mode)
+    d = torch.from_numpy(np.ascontiguousarray(pairs).view(np.uint8).reshape(len(pairs), 12)).to("cuda:0")
+    o, p, m = eng.audio_process(d, stop=True, out_pairs=torch.empty((10, 12), dtype=torch.uint8, device="cuda:0"), out_purges=torch.empty((1, 16), dtype=torch.uint8, device="cuda:0"))
+    assert o.cpu().numpy().tobytes() == want.tobytes() and p.cpu().numpy().tobytes() == want_pur.tobytes() and m == want_masked
 
 
 @pytest.mark.gpu
