@@ -1032,7 +1032,80 @@ __device__ inline void choose_body(const FrameArgs16s &a, int lane)
         uint4 q0 = { 0, 0, 0, 0 }, q1 = { 0, 0, 0, 0 };                /* ok[0], ok[1] | best_pad, sweep_lock, elig, marks */
         if ((uint32_t)lane < nc) { const uint4 *src = (const uint4 *)&a.pick[c0 + lane]; q0 = src[0]; q1 = src[1]; }
         uint32_t mine = 0;                      /* the Choice16 of frame c0 + lane, as a word */
+        /* A tape that plays: the history holds one padding, 65 times over, and every frame's checks pass on it.  Then nothing of what the
+         * frames do depends on their order - each locks on that padding (mode 1) and pushes it where it already is - and the 64 frames
+         * of the chunk are decided at once, a lane each; anything else (a file tag, a field whose check fails on it, a history that is not
+         * saturated) goes through the in-order loop below. */
+        {
+            const uint64_t s0 = __ballot(st.hist0 == (uint32_t)STATS_DEPTH), s1 = __ballot(st.hist1 == (uint32_t)STATS_DEPTH);
+            const bool saturated = st.nvalid == STATS_DEPTH && ((s0 != 0) != (s1 != 0));
+            const uint32_t P = s0 ? (uint32_t)__ffsll((unsigned long long)s0) - 1u : 64u + (uint32_t)(s1 ? __ffsll((unsigned long long)s1) - 1 : 0);
+            const uint32_t marks_l = (q1.y >> 16) & 0xFF;
+            bool fits = saturated && P < (ei ? (uint32_t)MAX_PAD_EI : (uint32_t)MAX_PAD_SI) && !(marks_l & (FF_NEW_FILE | FF_END_FILE));
+            uint32_t word = 0, pushes = 0;
+            const int n_fields = ei ? 1 : 2;
+            for (int p = 0; p < n_fields; p++) {
+                const uint32_t elig = (q1.y >> (8 * p)) & 0xFF;
+                if (ei || elig) {
+                    const uint32_t wi = ei ? (P >> 5) : (uint32_t)(2 * p) + (P >> 5);
+                    const uint32_t w = wi == 0 ? q0.x : (wi == 1 ? q0.y : (wi == 2 ? q0.z : q0.w));
+                    fits = fits && ((w >> (P & 31)) & 1u);
+                    word |= (1u << (8 * p)) | (P << (16 + 8 * p));
+                    pushes++;
+                }
+            }
+            if (__ballot((uint32_t)lane < nc && !fits) == 0 && saturated) {
+                uint32_t total = (uint32_t)lane < nc ? pushes : 0u;
+                for (int d = 1; d < 64; d <<= 1) total += (uint32_t)__shfl((int)total, lane ^ d);
+                st.pos = (int)(((uint32_t)st.pos + total) % (uint32_t)STATS_DEPTH);
+                if ((uint32_t)lane < nc) *(uint32_t *)&a.choice[c0 + lane] = word;
+                continue;
+            }
+        }
+        /* SI with different paddings in the two fields: the history holds the two values A (field 0) and B (field 1) in turn.  As long as
+         * every frame pushes A, then B - its field either passes on the probable padding when that is its own, or fails on the other one and
+         * locks on the sweep's winner, which is its own - the counts of the two values before every push follow from the ring alone (one A
+         * or B goes in, what sat 65 pushes back comes out), so the probable padding at each of the 64 pushes of 32 frames is known up
+         * front, a lane checks its frame against it, and if all agree the 32 frames are decided at once. */
+        bool sub_done[2] = { false, false };
+        if (!ei) for (int sub = 0; sub < 2; sub++) {
+            const uint32_t base = 32u * (uint32_t)sub;
+            if (base >= nc) { sub_done[sub] = true; continue; }
+            const uint32_t m = nc - base < 32u ? nc - base : 32u;
+            const int pm2 = (st.pos + STATS_DEPTH - 2) % STATS_DEPTH, pm1 = (st.pos + STATS_DEPTH - 1) % STATS_DEPTH;
+            const uint32_t A = pm2 < 64 ? lane_read(st.ring_lo, (uint32_t)pm2) : st.ring64, B = pm1 < 64 ? lane_read(st.ring_lo, (uint32_t)pm1) : st.ring64;
+            const uint64_t mA_lo = __ballot(st.ring_lo == A), mAB_lo = __ballot(st.ring_lo == A || st.ring_lo == B);
+            const bool mA_hi = st.ring64 == A, only_two = mAB_lo == ~0ull && (st.ring64 == A || st.ring64 == B);
+            const uint32_t cA0 = (uint32_t)__popcll((unsigned long long)mA_lo) + (mA_hi ? 1u : 0u);
+            const unsigned __int128 M = (unsigned __int128)mA_lo | ((unsigned __int128)(mA_hi ? 1u : 0u) << 64);
+            const uint64_t R = (uint64_t)((M >> st.pos) | (M << (STATS_DEPTH - st.pos)));       /* bit t: the entry that push t of this run evicts is an A */
+            const bool in = (uint32_t)lane >= base && (uint32_t)lane < base + m;
+            const uint32_t i = (uint32_t)lane - base;
+            auto low = [](uint32_t t) -> uint64_t { return t >= 64u ? ~0ull : ((1ull << t) - 1ull); };
+            const uint32_t cA_t0 = cA0 + i - (uint32_t)__popcll((unsigned long long)(R & low(2u * i)));
+            const uint32_t cA_t1 = cA0 + i + 1u - (uint32_t)__popcll((unsigned long long)(R & low(2u * i + 1u)));
+            const bool r0A = cA_t0 * 2u > (uint32_t)STATS_DEPTH, r1A = cA_t1 * 2u > (uint32_t)STATS_DEPTH;    /* the probable padding is A (else B) */
+            const uint64_t ok0 = (uint64_t)q0.x | ((uint64_t)q0.y << 32), ok1 = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+            const uint32_t best0 = q1.x & 0xFF, best1 = (q1.x >> 8) & 0xFF, lock0 = (q1.x >> 16) & 0xFF, lock1 = (q1.x >> 24) & 0xFF;
+            const uint32_t elig0 = q1.y & 0xFF, elig1 = (q1.y >> 8) & 0xFF, marks_l = (q1.y >> 16) & 0xFF;
+            const bool f0 = r0A ? ((ok0 >> (A & 63u)) & 1ull) : (!((ok0 >> (B & 63u)) & 1ull) && lock0 && best0 == A);
+            const bool f1 = !r1A ? ((ok1 >> (B & 63u)) & 1ull) : (!((ok1 >> (A & 63u)) & 1ull) && lock1 && best1 == B);
+            const bool fits = f0 && f1 && elig0 && elig1 && !(marks_l & (FF_NEW_FILE | FF_END_FILE));
+            const bool all = st.nvalid == STATS_DEPTH && only_two && A != B && A < (uint32_t)MAX_PAD_SI && B < (uint32_t)MAX_PAD_SI && __ballot(in && !fits) == 0;
+            if (!all) break;            /* the rest of the chunk goes through the loop below, in order */
+            if (in) mine = (r0A ? 1u : 2u) | ((r1A ? 2u : 1u) << 8) | (A << 16) | (B << 24);
+            /* the history after 2m pushes of A, B, A, B, ... */
+            const int dl = (lane - st.pos + STATS_DEPTH) % STATS_DEPTH, d64 = (64 - st.pos + STATS_DEPTH) % STATS_DEPTH;
+            if ((uint32_t)dl < 2u * m) st.ring_lo = (dl & 1) ? B : A;
+            if ((uint32_t)d64 < 2u * m) st.ring64 = (d64 & 1) ? B : A;
+            const uint32_t cA = cA0 + m - (uint32_t)__popcll((unsigned long long)(R & low(2u * m))), cB = (uint32_t)STATS_DEPTH - cA;
+            st.hist0 = ((uint32_t)lane == A ? cA : 0u) + ((uint32_t)lane == B ? cB : 0u);
+            st.hist1 = ((uint32_t)lane + 64u == A ? cA : 0u) + ((uint32_t)lane + 64u == B ? cB : 0u);
+            st.pos = (int)(((uint32_t)st.pos + 2u * m) % (uint32_t)STATS_DEPTH);
+            sub_done[sub] = true;
+        }
         for (uint32_t j = 0; j < nc; j++) {
+            if (sub_done[j >> 5]) continue;
             const uint32_t meta = lane_read(q1.x, j), meta2 = lane_read(q1.y, j);      /* best_pad[2] sweep_lock[2] | elig[2] marks */
             const uint32_t marks = (meta2 >> 16) & 0xFF;
             uint32_t word = 0;

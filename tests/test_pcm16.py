@@ -412,3 +412,30 @@ def test_gpu_whole_file_matches_reference_golden(ei):
     pairs = p.cpu().numpy().reshape(-1).view(PAIR_DTYPE)
     frames = f.cpu().numpy().reshape(-1).view(p16.FRASM16_DTYPE)
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+# ---- long tapes: the padding history saturates (65 entries), and the decision kernel's chunk-at-once path takes over ------------
+def _long_tape(ei, hurt):
+    from sdvpcmdecoder_amd import synth
+    recs = synth.pcm16x0_tape(150, seed=21 if ei else 20, period=150, ei=ei, p_bad=0.01)
+    recs = recs.copy()
+    if hurt:
+        # frames in the middle lose most of their CRCs (their padding checks fail: the in-order path and the way back into the fast one),
+        # and a file boundary sits in the tape (the history starts over)
+        ends = np.nonzero(recs["service_type"] == 5)[0]
+        for f in (70, 71, 100, 131):
+            a, b = ends[f - 1] + 1, ends[f]
+            sel = np.arange(a, b)[::2]
+            recs["flags"][sel] &= ~np.uint8(64) & 0xFF          # SDV_LF_CRC_VALID
+    return recs
+
+
+@pytest.mark.parametrize("ei,hurt", [(False, False), (False, True), (True, False), (True, True)])
+def test_emu_long_tape_matches_oracle(ei, hurt, emu, oracle_lib):
+    recs = _long_tape(ei, hurt)
+    st = p16.default_settings(format=2 if ei else 1)
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", recs, st)
+    eng = emu.sdv_engine_create(0)
+    rc, pairs, frames = ea.emu_pcm16_stitch(emu, eng, recs, st)
+    emu.sdv_engine_destroy(eng)
+    assert rc == 0 and len(want_f) == 150
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
