@@ -439,3 +439,27 @@ def test_emu_long_tape_matches_oracle(ei, hurt, emu, oracle_lib):
     emu.sdv_engine_destroy(eng)
     assert rc == 0 and len(want_f) == 150
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ei", [False, True])
+def test_gpu_long_damaged_tape_matches_oracle(ei, oracle_lib):
+    """1 200 frames with a hurt frame every ~40 and a second file in the middle: the chunk-at-once decisions, the in-order loop and the way
+    from one to the other, across batch boundaries and the three streams, against the oracle's sequential decode."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, synth, Pcm16x0StitchSettings
+    n = 1200
+    recs = synth.pcm16x0_tape(n, seed=31 if ei else 30, period=300, ei=ei, p_bad=0.01).copy()
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    rng = np.random.default_rng(3)
+    for f in sorted(rng.choice(np.arange(70, n - 1), 30, replace=False)):
+        a, b = ends[f - 1] + 1, ends[f]
+        recs["flags"][np.arange(a, b)[::2]] &= ~np.uint8(64) & 0xFF
+    st = p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI)
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", recs, st)
+    eng = Engine(0)
+    eng.set_pcm16x0_stitch_settings(Pcm16x0StitchSettings.from_buffer_copy(bytes(st)))
+    p, f = eng.pcm16x0_stitch_frames(torch.from_numpy(recs.view(np.uint8).reshape(len(recs), 36)).cuda())
+    pairs = p.cpu().numpy().reshape(-1).view(PAIR_DTYPE)
+    frames = f.cpu().numpy().reshape(-1).view(p16.FRASM16_DTYPE)
+    assert len(want_f) == n and _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
