@@ -43,9 +43,20 @@ for case in range(n_cases):
         p, f = eng.stitch_frames(lines)
         recs.append(lines.cpu().numpy().reshape(-1).view(LINE_DTYPE).copy()); stats.append(stt.cpu().numpy().copy())
         pairs.append(p.cpu().numpy().copy()); frames.append(f.cpu().numpy().copy())
+    pairs_calls = list(pairs)
     recs = np.concatenate(recs); stats = np.concatenate(stats); pairs = np.concatenate(pairs); frames = np.concatenate(frames)
     ok = recs.tobytes() == want.tobytes() and stats.tobytes() == want_stats.tobytes() and pairs.tobytes() == want_p.tobytes() and frames.tobytes() == want_f.tobytes()
-    print(f"case {case}: {n} frames {width}x{height} sigma {sigma} calls {len(cuts) - 1} binarize rounds {rounds} pairs {len(want_p)} cpu {t_cpu:.1f}s -> {'OK' if ok else 'MISMATCH'}", flush=True)
+    # ... and on through the audio stage, burst by burst as the stitch calls delivered them, in a random masking mode
+    import audio_api as au
+    a_mode = int(rng.integers(0, 7))
+    eng.set_audio_masking(a_mode)
+    a_out, ends, got = [], [], 0
+    for k, p_ in enumerate(pairs_calls):
+        o, pu, m_ = eng.audio_process(torch.from_numpy(p_).cuda(), stop=(k + 1 == len(pairs_calls)))
+        a_out.append(o.cpu().numpy().copy()); got += len(p_); ends.append(got)
+    w_out = au.run_cpu(orc, "orc_", want_p, a_mode, np.array(ends, dtype=np.uint64), 1)
+    ok = ok and (w_out[4] != 0 or np.concatenate(a_out).tobytes() == w_out[0].tobytes())
+    print(f"case {case}: {n} frames {width}x{height} sigma {sigma} audio mode {a_mode} calls {len(cuts) - 1} binarize rounds {rounds} pairs {len(want_p)} cpu {t_cpu:.1f}s -> {'OK' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
 print("soak ok")
