@@ -172,12 +172,12 @@ def stc007_frames(n_frames: int, seed: int = 0, width: int = 720, height: int = 
     first = f * 2 * lines_per_field + ct[:, 0:1] + r
     second = f * 2 * lines_per_field + lines_per_field + ct[:, 1:2] + r
     odd, even = (second, first) if bff else (first, second)
-    idx = np.empty((n_frames, height), dtype=np.int64)
+    idx = np.zeros((n_frames, height), dtype=np.int64)         # (a row behind the last full pair of an odd height stays blanking)
     idx[:, 0:2 * vis:2] = odd
     idx[:, 1:2 * vis:2] = even
     flat = idx.reshape(-1)
     # rows that fall outside their field's PCM lines (vertical offset too large) are blanking: no PCM there
-    blank = np.empty((n_frames, height), dtype=bool)
+    blank = np.ones((n_frames, height), dtype=bool)
     blank[:, 0:2 * vis:2] = ((ct[:, 1:2] if bff else ct[:, 0:1]) + r) >= lines_per_field
     blank[:, 1:2 * vis:2] = ((ct[:, 0:1] if bff else ct[:, 1:2]) + r) >= lines_per_field
     blank = blank.reshape(-1)
