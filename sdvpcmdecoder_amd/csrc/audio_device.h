@@ -14,7 +14,8 @@
  *   - the stretches between the NEW_FILE / END_FILE tags start from a purged window and are independent: one wave each.
  * Layout: the pairs of a call are laid out in a work array W, stretch after stretch, each stretch headed by what the window
  * held when it began (the silent pair purgePipeline leaves, or what waited from the call before); windows are worked on in
- * place in W; the emit pass copies W to the caller's buffer without the pair every purge drops and keeps what still waits.
+ * place in W.  W is the caller's output buffer where no purge shifts what follows it (a burst that continues or holds one file);
+ * otherwise a buffer of the engine, and the emit pass copies it to the caller's without the pair every purge drops.
  */
 #pragma once
 #include <stdint.h>
@@ -42,7 +43,6 @@ struct Stretch {
 };
 struct StretchResult { uint32_t popped, scanned_upto, flags, left; uint64_t masked; uint32_t n_win, _pad; };
 
-__device__ __forceinline__ int a_lane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint32_t a_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
 __device__ __forceinline__ uint64_t lane_read64(uint64_t v, int src)      /* the value lane `src` (the same for every lane) holds */
 {
