@@ -103,6 +103,8 @@ __device__ inline void prep_body(const PrepArgs &a, uint32_t blk, int lane)
             else if (t.head_is_carry) qs[r] = a.carry[k];
         }
     }
+    /* the four bitmap words of the wave go out together: lanes 0..3 store word 0..3 of each bitmap (one 32-byte store per bitmap) */
+    uint64_t w_bad = 0, w_v0 = 0, w_v1 = 0, w_m0 = 0, w_m1 = 0; uint32_t any_mi = 0, bytes = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const uint32_t p = (blk * 4u + (uint32_t)r) * 64u + (uint32_t)lane;
@@ -120,11 +122,16 @@ __device__ inline void prep_body(const PrepArgs &a, uint32_t blk, int lane)
             bad = !(ok0 && ok1);
         }
         const uint64_t m = __ballot(bad), b0 = __ballot(ok0), b1 = __ballot(ok1), c0 = __ballot(mk0), c1 = __ballot(mk1);
-        if (lane == 0 && (p >> 6) < ((a.total_w + 63u) >> 6)) {
-            a.bad1[p >> 6] = m; a.v0[p >> 6] = b0; a.v1[p >> 6] = b1; a.m0[p >> 6] = c0; a.m1[p >> 6] = c1;
-            if (((c0 & ~b0) | (c1 & ~b1)) && !*a.has_mi) atomicOr(a.has_mi, 1u);
-            a.bad2[p >> 6] = m ? 1 : 0;
-        }
+        if (lane == r) { w_bad = m; w_v0 = b0; w_v1 = b1; w_m0 = c0; w_m1 = c1; }
+        if ((c0 & ~b0) | (c1 & ~b1)) any_mi = 1;
+        bytes |= (m ? 1u : 0u) << (8 * r);
+    }
+    const uint32_t wi = blk * 4u + (uint32_t)lane, n_words = (a.total_w + 63u) >> 6;
+    if (lane < 4 && wi < n_words) { a.bad1[wi] = w_bad; a.v0[wi] = w_v0; a.v1[wi] = w_v1; a.m0[wi] = w_m0; a.m1[wi] = w_m1; }
+    if (lane == 0) {
+        /* the middle level: a byte per word (the array is zeroed up to a multiple of 64 bytes, whole groups of four lie inside it) */
+        *(uint32_t *)&a.bad2[blk * 4u] = bytes;
+        if (any_mi && !*a.has_mi) atomicOr(a.has_mi, 1u);
     }
 }
 
