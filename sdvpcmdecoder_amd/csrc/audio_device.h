@@ -21,6 +21,10 @@
 #include <stdint.h>
 #include "../../include/sdvpcm.h"
 
+#ifndef SDV_AP_NT_STORES
+#define SDV_AP_NT_STORES 1
+#endif
+
 namespace sdva {
 
 enum { WIN = SDV_AP_BUF_SIZE, KEEP = SDV_AP_MIN_VALID_BEFORE, RAMP_DOWN = SDV_AP_MAX_RAMP_DOWN, RAMP_UP = SDV_AP_MAX_RAMP_UP,
@@ -75,6 +79,16 @@ __device__ inline uint32_t find_stretch(const Stretch *st, uint32_t n_st, uint32
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (st[mid].w_base <= p) lo = mid; else hi = mid; }
     return lo;
 }
+/* a pair that is written once and read (if at all) by a later kernel */
+__device__ __forceinline__ void store_pair_streaming(sdv_sample_pair *dst, const sdv_sample_pair &q)
+{
+#if defined(SDV_EMU) || !SDV_AP_NT_STORES
+    *dst = q;
+#else
+    const uint32_t *src = (const uint32_t *)&q; uint32_t *d = (uint32_t *)dst;
+    __builtin_nontemporal_store(src[0], d); __builtin_nontemporal_store(src[1], d + 1); __builtin_nontemporal_store(src[2], d + 2);
+#endif
+}
 __device__ inline sdv_sample_pair silent_pair()
 {
     sdv_sample_pair q;                  /* purgePipeline's setSamplePair(0, 0, true x4, false x2) on a cleared pair (:1734-1743) */
@@ -116,7 +130,7 @@ __device__ inline void prep_body(const PrepArgs &a, uint32_t blk, int lane)
                 if (a.by_block) for (int ch = 0; ch < 2; ch++)      /* setValidityByBlock (:166-169) */
                     q.sample_flags[ch] = (uint8_t)((q.sample_flags[ch] & ~SDV_SF_WORD_VALID) | ((q.sample_flags[ch] & SDV_SF_BLOCK_OK) ? SDV_SF_WORD_VALID : 0));
             }
-            a.w[p] = q;
+            store_pair_streaming(&a.w[p], q);
             ok0 = a.ignore || (q.sample_flags[0] & SDV_SF_WORD_VALID); ok1 = a.ignore || (q.sample_flags[1] & SDV_SF_WORD_VALID);
             mk0 = (q.sample_flags[0] & SDV_SF_WORD_MASKED) != 0; mk1 = (q.sample_flags[1] & SDV_SF_WORD_MASKED) != 0;
             bad = !(ok0 && ok1);
@@ -577,7 +591,7 @@ __device__ inline void emit_body(const EmitArgs &a, uint32_t blk, int lane)
         const uint32_t n_out = closed ? (t.v_len > 0 ? t.v_len - 1u : 0u) : popped;     /* a purge drops the last pair (:1423-1434) */
         sdv_sample_pair q = qs[r];
         if (a.ignore && k < scanned) { q.sample_flags[0] |= SDV_SF_WORD_VALID; q.sample_flags[1] |= SDV_SF_WORD_VALID; }   /* clearInvalids (:1404-1409) */
-        if (k < n_out) { const uint64_t o = t.out_base + k; if (o < a.out_cap) a.out[o] = q; }
+        if (k < n_out) { const uint64_t o = t.out_base + k; if (o < a.out_cap) store_pair_streaming(&a.out[o], q); }
         else if (!closed) a.carry_out[k - n_out] = q;
     }
 }
