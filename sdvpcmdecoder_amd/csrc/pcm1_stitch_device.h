@@ -128,7 +128,19 @@ __device__ inline Pair3 make_pair3(int16_t l, int16_t r, uint32_t flags, uint32_
     p.c = (emphasis ? 1u : 0u) | (srv << 8);
     return p;
 }
-__device__ inline void store_pair(sdv_sample_pair *dst, const Pair3 &p) { *(Pair3 *)dst = p; }
+#ifndef SDV_PAIR_NT_STORES
+#define SDV_PAIR_NT_STORES 1
+#endif
+/* the sample pairs are written once and read by a later stage (or by the host): streaming stores in the product build */
+__device__ inline void store_pair(sdv_sample_pair *dst, const Pair3 &p)
+{
+#if defined(SDV_EMU) || !SDV_PAIR_NT_STORES
+    *(Pair3 *)dst = p;
+#else
+    uint32_t *d = (uint32_t *)dst;
+    __builtin_nontemporal_store(p.a, d); __builtin_nontemporal_store(p.b, d + 1); __builtin_nontemporal_store(p.c, d + 2);
+#endif
+}
 __device__ inline void service_pair(sdv_sample_pair *dst, uint8_t srv) { store_pair(dst, make_pair3(0, 0, 0, 44056, false, srv)); }
 /* PCM1DataBlock::getSample (pcm1datablock.cpp:309-348) */
 __device__ inline int16_t p1_sample(uint16_t w)
