@@ -604,8 +604,9 @@ uint64_t sdv_audio_next_index(const sdv_engine *e);
  * (SDV_SF_WORD_VALID set on everything a scan has seen, SDV_SF_WORD_MASKED on what was altered); out_purges the purge events in
  * order; *n_masked the sum of the guiAddMask reports.  *n_out / *n_purges receive the counts; when out_cap / purges_cap are too
  * small the call fails with SDV_ERR_BAD_ARG, the counts say what is needed (n_pairs + 512 + tags is always enough) and the
- * stream state is untouched, so the call can be repeated.  out_pairs must not overlap `pairs`; with room for n_pairs + 512 + tags pairs
- * the pairs are worked on in place there (what lies behind *n_out is scratch then) and cross HBM once in each direction.
+ * stream state is untouched, so the call can be repeated.  With room for n_pairs + 512 + tags pairs in out_pairs the pairs are worked on
+ * there (what lies behind *n_out is scratch then) and cross HBM once in each direction; out_pairs may be `pairs` itself (or overlap it):
+ * the burst then goes through a buffer of the engine first.
  * Not supported (SDV_ERR_UNSUPPORTED, the stream state is left untouched): an END_FILE that finds fewer than three pairs in the
  * window (the reference then neither purges nor starts a new source, :1302-1306), a window whose first pairs can never leave
  * (a stream that starts with invalid samples and no NEW_FILE tag: the reference's worker stops taking input for good), and more

@@ -235,6 +235,20 @@ def test_emu_next_index_runs_on_across_calls(emu, oracle_lib):
         emu.sdv_engine_destroy(eng)
 
 
+def test_emu_call_in_place(emu, oracle_lib):
+    """out_pairs == pairs: the output overwrites the input."""
+    for name in ("short_runs_lin", "two_files", "worn_tape"):
+        pairs, mode, ends, stop, want, idx, want_pur, want_masked, hit = _oracle(name)
+        eng = emu.sdv_engine_create(0)
+        emu.sdv_set_audio_masking(eng, mode)
+        buf = np.concatenate([pairs, np.zeros(1024, dtype=PAIR_DTYPE)])
+        pur = np.zeros(16, dtype=A.PURGE_DTYPE)
+        n_out, n_pur, nm = C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+        rc = emu.sdv_audio_process(eng, buf.ctypes.data, len(pairs), 1, buf.ctypes.data, len(buf), C.byref(n_out), pur.ctypes.data, 16, C.byref(n_pur), C.byref(nm), None)
+        emu.sdv_engine_destroy(eng)
+        assert rc == 0 and buf[:n_out.value].tobytes() == want.tobytes() and nm.value == want_masked, name
+
+
 def test_emu_many_files_in_one_call(emu, oracle_lib):
     """The stretches between tags are independent: 40 short files in one burst, one wave each."""
     rng = np.random.default_rng(5)
