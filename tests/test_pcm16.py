@@ -429,7 +429,7 @@ def _long_tape(ei, hurt):
     return recs
 
 
-@pytest.mark.parametrize("ei,hurt", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("ei,hurt", [(False, True), (True, True)])       # (the clean tapes are the first 70 frames of these)
 def test_emu_long_tape_matches_oracle(ei, hurt, emu, oracle_lib):
     recs = _long_tape(ei, hurt)
     st = p16.default_settings(format=2 if ei else 1)
