@@ -91,7 +91,9 @@ extern "C" long ref_audio_run(const sdv_sample_pair *pairs, size_t n, const uint
             if (qs == last) { if (++same > 40) break; } else { same = 0; last = qs; }
             std::this_thread::sleep_for(std::chrono::milliseconds(5));
         }
-        std::this_thread::sleep_for(std::chrono::milliseconds(130));
+        /* the worker sleeps 50 ms when it finds the queue empty and a turn takes well under a millisecond: a quarter of a second of margin for a loaded machine
+         * (only the scenarios with several bursts pay it more than once) */
+        std::this_thread::sleep_for(std::chrono::milliseconds(b + 1 < n_bursts ? 250 : 130));
     }
     const size_t before_stop = got.size(), pur_before = pur.size();
     const uint64_t masked_before = masked.load();
