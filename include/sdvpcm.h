@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define SDV_ABI_VERSION 2   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines */
+#define SDV_ABI_VERSION 3   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only) */
 
 /* ---- status codes ---------------------------------------------------------------------------
  * 0..4 mirror Binarizer::LB_RET_* (binarizer.h:268-275); 16.. mirror STC007Deinterleaver::DI_RET_*
