@@ -535,8 +535,8 @@ enum { SDV_FA16_SILENCE = 1 << 4, SDV_FA16_PADDING_OK = 1 << 5, SDV_FA16_EI_FORM
 void sdv_default_pcm16x0_stitch_settings(sdv_pcm16x0_stitch_settings *st);
 /* Applies the settings and starts a fresh PCM16X0DataStitcher (statistics and queued lines are dropped). */
 int sdv_set_pcm16x0_stitch_settings(sdv_engine *e, const sdv_pcm16x0_stitch_settings *st);
-/* PCM16X0DataStitcher's stream state as an opaque blob (the padding and Control Bit statistics rings, oldest entry first, and the
- * Control Bit values of the last frame): checkpoints, and the hand-over to the engine of the next GPU of a sharded tape (DESIGN.md
+/* PCM16X0DataStitcher's stream state as an opaque blob (the padding and Control Bit statistics rings, oldest entry first, the
+ * Control Bit values of the last frame and what is left in conv_queue): checkpoints, and the hand-over to the engine of the next GPU of a sharded tape (DESIGN.md
  * section 7).  sdv_set_pcm16x0_stitch_state drops sub-lines of an unfinished frame.  sdv_saturate_pcm16x0_stitch_stats fills every ring
  * with its most frequent entry (an engine that joined the stream after a short warm-up, about to compare its state with the true one). */
 size_t sdv_pcm16x0_stitch_state_size(void);
@@ -552,7 +552,12 @@ int sdv_saturate_pcm16x0_stitch_stats(sdv_engine *e);
  * P-code correction (PCM16X0Deinterleaver::processBlock, pcm16x0deinterleaver.cpp:128-708; performDeinterleave :5165) into three
  * PCMSamplePairs per data block: 1470 per frame, plus the NEW_FILE / END_FILE tags; one FrameAsmPCM16x0 per frame.  Stream state
  * (the padding and Control Bit histories, sub-lines that wait for their END_FRAME or for the rest of their interleave block)
- * lives in the engine.  Same conventions as sdv_pcm1_stitch_frames. */
+ * lives in the engine.  Same conventions as sdv_pcm1_stitch_frames.
+ * A frame whose lines arrive with sub-lines missing or doubled is queued with the reference's "WRONG COUNT" (:4699-4703): its fields
+ * do not add up to 1470 sub-lines, performDeinterleave takes whole interleave rounds (105 sub-lines SI, 1470 EI; :5216) and the rest
+ * stays in conv_queue, in front of the next frame - from there on every frame's blocks start in its predecessor, and a frame puts out
+ * an extra round (105 / 1470 pairs more) whenever the rest has grown to one.  Reproduced as is; size `pairs_cap` for it (a call that does
+ * not fit is refused with the needed sizes in *n_pairs / *n_frames and takes nothing). */
 int sdv_pcm16x0_stitch_frames(sdv_engine *e, const sdv_pcm16x0_bin_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                               size_t *n_pairs, sdv_frame_asm_pcm16x0 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 

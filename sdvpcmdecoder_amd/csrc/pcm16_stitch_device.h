@@ -18,8 +18,11 @@
  *   K-D  sdv_k_pcm16_flags     one wave, the frames in order: Control Bit history -> sample rate / emphasis / code of every frame.
  *   K-E  sdv_k_pcm16_emit      one wave per frame: 490 data blocks through processBlock (a lane per block), seam and BROKEN masking
  *        as scans over the blocks (performDeinterleave :5165), 1470 PCMSamplePairs and the FrameAsmPCM16x0.
- * A frame whose padded size is not 1470 sub-lines (only the reference's own "logic error" paths produce that; the remainder would
- * wait in conv_queue for the next frame) is reported as SDV_ERR_UNSUPPORTED.
+ *   K-B' sdv_k_pcm16_carry     one wave, the frames in order: a frame whose padded size is not 1470 sub-lines (sub-lines missing or
+ *        doubled in a line: the reference's "WRONG COUNT" path, :4664-4703) leaves a remainder in conv_queue that the next frame's
+ *        blocks start in (performDeinterleave pops whole interleave blocks only, :5216, :5431-5443).  What every frame finds in the queue
+ *        and how many blocks it puts out is a segmented prefix sum over the frame sizes; the remainder itself is always the tail of the
+ *        frame before, so K-C / K-E read it from there.
  * Algorithmic bytes per frame: 36 B per sub-line record in (1470: 52.9 KB) + 1470 x 12 B pairs + 56 B descriptor out.
  */
 #ifndef SDV_PCM16_STITCH_DEVICE_H
@@ -43,7 +46,7 @@ enum { DS_NO_DATA, DS_SILENCE, DS_BROKE, DS_NO_PAD, DS_OK };
 enum { ORDER_TFF = 1, ORDER_BFF = 2 };
 enum { FF_NEW_FILE = 1, FF_END_FILE = 2 };
 /* reasons a frame cannot be stitched by this engine */
-enum { FE_FOREIGN = 1, FE_TOO_LONG = 2, FE_SIZE = 4, FE_MARKS = 16 };
+enum { FE_FOREIGN = 1, FE_TOO_LONG = 2, FE_MARKS = 16 };
 
 
 /* ---- a sub-line as the stitcher needs it, 12 bytes ---------------------------------------------------------------- */
@@ -119,33 +122,6 @@ __device__ inline void seg_body(const SegArgs16 &a, uint32_t blk, int lane)
     }
     if (!a.write && lane == 0) a.block_count[blk] = cnt;
 }
-__device__ inline void frame_counts(uint32_t marks, uint32_t &pairs, uint32_t &frasm)
-{
-    if (marks & FF_END_FILE) { pairs = 1; frasm = 1; }                          /* outputFileStop only (:5822-5828) */
-    else { pairs = FRAME_SUBS + ((marks & FF_NEW_FILE) ? 1 : 0); frasm = 1 + ((marks & FF_NEW_FILE) ? 1 : 0); }
-}
-struct ScanArgs16 { const uint32_t *marks; uint32_t n_seg; uint64_t *pair_ofs; uint32_t *frasm_ofs; const uint32_t *stat; };
-__device__ inline void scan_body(const ScanArgs16 &a, int lane)
-{
-    if (a.stat[2] == 0) {
-        if (lane == 0) { a.pair_ofs[a.n_seg] = (uint64_t)a.n_seg * FRAME_SUBS; a.frasm_ofs[a.n_seg] = a.n_seg; }
-        return;
-    }
-    const uint32_t run = (a.n_seg + 63) / 64, k0 = (uint32_t)lane * run;
-    uint32_t k1 = k0 + run; if (k1 > a.n_seg) k1 = a.n_seg;
-    uint64_t psum = 0; uint32_t fsum = 0;
-    for (uint32_t k = k0; k < k1; k++) { uint32_t p, f; frame_counts(a.marks[k], p, f); psum += p; fsum += f; }
-    uint64_t ps = psum; uint32_t fs = fsum;
-    for (int d = 1; d < 64; d <<= 1) {
-        const int src = lane >= d ? lane - d : lane;
-        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)ps, src), hi = (uint32_t)__shfl((int)(uint32_t)(ps >> 32), src), of = (uint32_t)__shfl((int)fs, src);
-        if (lane >= d) { ps += ((uint64_t)hi << 32) | lo; fs += of; }
-    }
-    uint64_t pb = ps - psum; uint32_t fb = fs - fsum;
-    for (uint32_t k = k0; k < k1; k++) { uint32_t p, f; frame_counts(a.marks[k], p, f); a.pair_ofs[k] = pb; a.frasm_ofs[k] = fb; pb += p; fb += f; }
-    if (lane == 63) { a.pair_ofs[a.n_seg] = ps; a.frasm_ofs[a.n_seg] = fs; }
-}
-
 /* ---- PCM16X0DataBlock + PCM16X0Deinterleaver::processBlock on three sub-lines ----------------------------------------------- */
 enum { L1 = 0, L2 = 1, L3 = 2, W_L = 0, W_R = 1, W_P = 2 };
 enum { AUD_ORIG, AUD_FIX_P, AUD_BROKEN };
@@ -337,6 +313,8 @@ struct Dec16 {
     uint16_t extra[2];                      /* lines of last-resort padding behind the [odd, even] field */
     uint8_t field_order, padding_ok, silence, err;
     uint16_t srate; uint8_t emph, code;     /* filled by K-D */
+    uint32_t total;                         /* sub-lines fillFrameForOutput queues for this frame (1470 unless lines came with sub-lines missing or doubled) */
+    uint16_t rem_in, n_it;                  /* filled by K-B': sub-lines already waiting in conv_queue, interleave-block rounds of performDeinterleave */
 };
 /* what the in-order part of K-B needs of a frame (written by K-A), 32 bytes, and what it decides */
 struct Pick16 {
@@ -354,15 +332,17 @@ struct State16 {
     uint8_t pad_ring[STATS_DEPTH]; uint8_t emph_ring[STATS_DEPTH], code_ring[STATS_DEPTH]; uint16_t srate_ring[STATS_DEPTH];
     int32_t pad_pos, ctrl_pos;              /* slot the next push() overwrites */
     uint16_t f1_srate; uint8_t f1_emph, f1_code;
+    uint32_t rem_n;                         /* sub-lines left in conv_queue behind the last frame (their content: the engine's remainder buffer) */
 };
 
 struct FrameArgs16s {
     RecSrc16 src; const uint32_t *seg_end; uint32_t n_seg, seg_base, n_batch; Cfg16 cfg;
-    const uint32_t *marks; const uint64_t *pair_ofs; const uint32_t *frasm_ofs;
+    const uint32_t *marks; uint64_t *pair_ofs; uint32_t *frasm_ofs;      /* offsets: [k] written by K-B' of the batch that holds frame k, [k + 1] the running total */
+    const Sub *rem_in; Sub *rem_out;        /* conv_queue's remainder in front of the batch's first frame / behind its last one (FRAME_SUBS entries each) */
     Ana16 *ana; Pick16 *pick; Choice16 *choice; Dec16 *dec; Ctrl16 *ctrl; Sub *fields;          /* per frame of the batch; fields: [frame][2][735] */
     State16 *state;
     sdv_sample_pair *out_pairs; uint64_t pairs_cap; sdv_frame_asm_pcm16x0 *out_frames; uint32_t frames_cap;
-    uint32_t *stat;             /* [0] = OR of FE_*, [1] = first frame index with an error, [2] = marks set (0: the plain layout) */
+    uint32_t *stat;             /* [0] = OR of FE_*, [1] = first frame index with an error, [2] = file tags seen */
 };
 
 #ifndef SDV_P16_LDS_SUBS
@@ -1017,7 +997,7 @@ __device__ inline void finish_frame(const Choice16 &ch, const Cfg16 &cfg, const 
     d.top_pad[0] = top_pad[0]; d.top_pad[1] = top_pad[1]; d.bot_pad[0] = bot_pad[0]; d.bot_pad[1] = bot_pad[1];
     d.data[0] = data[0]; d.data[1] = data[1]; d.cut[0] = cut[0]; d.cut[1] = cut[1];
     d.field_order = order; d.padding_ok = padding_ok; d.silence = silence;
-    d.err = total != FRAME_SUBS ? (uint8_t)FE_SIZE : 0;
+    d.err = 0; d.total = total; d.rem_in = 0; d.n_it = 0;
 }
 
 /* K-B, in order: which padding every frame locks on.  One wave; lane j holds the Pick16 of frame c0 + j in registers and the loop
@@ -1147,7 +1127,7 @@ __device__ inline void finish_body(const FrameArgs16s &a, uint32_t kb)
     d.srate = 0; d.emph = d.code = 0;
     if (an.marks & FF_END_FILE) {
         d.top_pad[0] = d.top_pad[1] = d.bot_pad[0] = d.bot_pad[1] = d.data[0] = d.data[1] = d.cut[0] = d.cut[1] = d.extra[0] = d.extra[1] = 0;
-        d.field_order = 0; d.padding_ok = d.silence = 0; d.err = 0;
+        d.field_order = 0; d.padding_ok = d.silence = 0; d.err = 0; d.total = 0; d.rem_in = 0; d.n_it = 0;
     } else if (a.cfg.field_order == ORDER_BFF) finish_frame<1>(a.choice[kb], a.cfg, an, d);
     else finish_frame<0>(a.choice[kb], a.cfg, an, d);
     a.dec[kb] = d;
@@ -1170,16 +1150,80 @@ __device__ inline Sub conv_at(const Dec16 &d, const Sub *fields, uint32_t pos)
     return sub_empty();
 }
 
+/* conv_queue as frame kb finds it after fillFrameForOutput: what the frames before left behind (always a tail of the previous frame's
+ * padded sub-lines - less than one interleave round of it stays, and every frame queues at least 1470), then its own padded sub-lines */
+struct Queue16 {
+    Dec16 d, dprev; const Sub *fields, *fields_prev, *rem; uint32_t rem_n, prev_from;
+    __device__ inline Sub at(uint32_t q) const
+    {
+        if (q >= rem_n) return conv_at(d, fields, q - rem_n);
+        return fields_prev ? conv_at(dprev, fields_prev, prev_from + q) : rem[q];
+    }
+};
+__device__ inline Queue16 queue_of(const FrameArgs16s &a, uint32_t kb, const Dec16 &d)
+{
+    Queue16 q;
+    q.d = d; q.fields = a.fields + (size_t)kb * (2 * SUBLINES_PF); q.rem_n = d.rem_in; q.fields_prev = NULL; q.rem = a.rem_in; q.prev_from = 0; q.dprev = d;
+    if (d.rem_in != 0 && kb > 0) { q.dprev = a.dec[kb - 1]; q.fields_prev = q.fields - 2 * SUBLINES_PF; q.prev_from = q.dprev.total - d.rem_in; }
+    return q;
+}
+
+/* ---- K-B': what waits in conv_queue (performDeinterleave :5216-5446 pops whole rounds - 105 sub-lines SI, 1470 EI - and leaves the rest) ------ */
+__device__ inline void carry_body(const FrameArgs16s &a, int lane)
+{
+    const bool ei = a.cfg.format == SDV_P16_FORMAT_EI;
+    const uint32_t lim = ei ? (uint32_t)FRAME_SUBS : (uint32_t)SI_TRUE, blk_it = ei ? (uint32_t)EI_OFS : (uint32_t)SI_OFS;
+    uint32_t R = a.state->rem_n;
+    uint64_t pbase = a.pair_ofs[a.seg_base]; uint32_t fbase = a.frasm_ofs[a.seg_base];
+    for (uint32_t c0 = 0; c0 < a.n_batch; c0 += 64) {
+        const uint32_t kb = c0 + (uint32_t)lane; const bool act = kb < a.n_batch;
+        const uint32_t marks = act ? a.marks[a.seg_base + kb] : 0u, S = act ? a.dec[kb].total : 0u;
+        const bool endf = (marks & FF_END_FILE) != 0, newf = (marks & FF_NEW_FILE) != 0;       /* both empty the queue (resetState :72), END_FILE queues nothing */
+        uint32_t f = (act && (endf || newf)) ? 1u : 0u, x = (!act || endf) ? 0u : S % lim;
+        for (int d = 1; d < 64; d <<= 1) {              /* segmented sum of the frame sizes modulo a round */
+            const int src = lane >= d ? lane - d : lane;
+            const uint32_t xf = (uint32_t)__shfl((int)f, src), xv = (uint32_t)__shfl((int)x, src);
+            if (lane >= d) { if (!f) x = (x + xv) % lim; f |= xf; }
+        }
+        const uint32_t r_out = f ? x : (x + R) % lim;
+        const uint32_t r_prev = (uint32_t)__shfl((int)r_out, lane > 0 ? lane - 1 : 0);
+        const uint32_t r_in = (newf || endf) ? 0u : (lane == 0 ? R : r_prev);
+        const uint32_t n_it = endf ? 0u : (r_in + S) / lim;
+        const uint32_t pairs = !act ? 0u : (endf ? 1u : 3u * blk_it * n_it + (newf ? 1u : 0u)), frasm = !act ? 0u : (endf ? 1u : 1u + (newf ? 1u : 0u));
+        uint64_t ps = pairs; uint32_t fs = frasm;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int src = lane >= d ? lane - d : lane;
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)ps, src), hi = (uint32_t)__shfl((int)(uint32_t)(ps >> 32), src), of = (uint32_t)__shfl((int)fs, src);
+            if (lane >= d) { ps += ((uint64_t)hi << 32) | lo; fs += of; }
+        }
+        if (act) {
+            a.dec[kb].rem_in = (uint16_t)r_in; a.dec[kb].n_it = (uint16_t)n_it;
+            a.pair_ofs[a.seg_base + kb] = pbase + ps - pairs; a.frasm_ofs[a.seg_base + kb] = fbase + fs - frasm;
+        }
+        const uint32_t last = (a.n_batch - c0 < 64u ? a.n_batch - c0 : 64u) - 1u;
+        R = (uint32_t)__shfl((int)r_out, (int)last);
+        pbase += ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ps >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)ps, 63);
+        fbase += (uint32_t)__shfl((int)fs, 63);
+    }
+    if (lane == 0) { a.pair_ofs[a.seg_base + a.n_batch] = pbase; a.frasm_ofs[a.seg_base + a.n_batch] = fbase; a.state->rem_n = R; }
+    if (R != 0) {               /* the batch's last frame leaves sub-lines behind: a copy for the frame that follows it (next batch or next call) */
+        const uint32_t kb = a.n_batch - 1;
+        const Dec16 d = a.dec[kb];
+        const Sub *fields = a.fields + (size_t)kb * (2 * SUBLINES_PF);
+        for (uint32_t i = (uint32_t)lane; i < R; i += 64) a.rem_out[i] = conv_at(d, fields, d.total - R + i);
+    }
+}
+
 /* ---- K-C: collectCtrlBitStats (:4745-4912) ------------------------------------------------------------------------------------ */
 __device__ inline void ctrl_body(const FrameArgs16s &a, uint32_t kb, int lane)
 {
     const Dec16 d = a.dec[kb];
-    const Sub *fields = a.fields + (size_t)kb * (2 * SUBLINES_PF);
+    const Queue16 queue = queue_of(a, kb, d);
     const int iblk = lane / 3, which = lane % 3;
     bool ok = false, zero = false;
     if (lane < 3 * 2 * IBLK_PF && !d.err && !(a.ana[kb].marks & FF_END_FILE)) {
         const uint32_t pos = (uint32_t)iblk * SI_TRUE + 1u + (which == 0 ? (uint32_t)BIT_EMPH : (which == 1 ? (uint32_t)BIT_RATE : (uint32_t)BIT_CODE));
-        const Sub s = conv_at(d, fields, pos);
+        const Sub s = queue.at(pos);            /* from the front of the queue, whatever waits there (:4752-4792) */
         ok = (s.fl & SF_CRC) != 0; zero = ok && !(s.fl & SF_CTRL);
     }
     const uint64_t okm = __ballot(ok), zm = __ballot(zero);
@@ -1258,17 +1302,16 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
     const Ana16 &an = a.ana[kb];
     const Dec16 d = a.dec[kb];
     const Cfg16 cfg = a.cfg;
-    const bool plain = a.stat[2] == 0;
-    const uint32_t marks = plain ? 0u : a.marks[k];
-    const uint64_t pofs = plain ? (uint64_t)k * FRAME_SUBS : a.pair_ofs[k];
-    const uint32_t fofs = plain ? k : a.frasm_ofs[k];
+    const uint32_t marks = a.marks[k];
+    const uint64_t pofs = a.pair_ofs[k];
+    const uint32_t fofs = a.frasm_ofs[k];
     uint32_t err = an.err | d.err;
     if ((an.marks ^ marks) & (FF_NEW_FILE | FF_END_FILE)) err |= FE_MARKS;
     if (marks & FF_END_FILE) {
         if (lane == 0) {
             if (fofs < a.frames_cap) { sdv_frame_asm_pcm16x0 s; frasm16_clear(s); s.service_type = SDV_PAIR_SRV_END_FILE; a.out_frames[fofs] = s; }
             if (pofs < a.pairs_cap) sdvp1::service_pair(&a.out_pairs[pofs], SDV_PAIR_SRV_END_FILE);
-            if (err & ~(uint32_t)FE_SIZE) { atomicOr(&a.stat[0], err & ~(uint32_t)FE_SIZE); atomicMin(&a.stat[1], k); }
+            if (err) { atomicOr(&a.stat[0], err); atomicMin(&a.stat[1], k); }
         }
         return;
     }
@@ -1281,8 +1324,10 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
         }
         po++;
     }
-    const Sub *fields = a.fields + (size_t)kb * (2 * SUBLINES_PF);
+    const Queue16 queue = queue_of(a, kb, d);
     const bool ei = cfg.format == SDV_P16_FORMAT_EI;
+    const uint32_t lim = ei ? (uint32_t)FRAME_SUBS : (uint32_t)SI_TRUE, blk_it = ei ? (uint32_t)EI_OFS : (uint32_t)SI_OFS;
+    const uint32_t n_blocks = blk_it * d.n_it;          /* 490, unless the queue holds more or less than a frame (:5216) */
     const DiCfg di = { !cfg.ignore_crc, cfg.p_correction != 0, cfg.ignore_crc != 0 };
     const uint16_t rate = (cfg.sample_rate_preset == 44100 || cfg.sample_rate_preset == 44056) ? cfg.sample_rate_preset : d.srate;   /* setBlockSampleRate (:4915-4928) */
     const bool seam_mask = cfg.mask_seams && !d.padding_ok && !d.silence;
@@ -1290,14 +1335,14 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
     uint32_t drop = 0, broken = 0, fix_p = 0, fix_bp = 0, samples_drop = 0;
     char *const base = (char *)(a.out_pairs + po);
     const uint64_t room = po >= a.pairs_cap ? 0 : a.pairs_cap - po;
-    for (uint32_t c = 0; c < EI_TRUE; c += 64) {
+    for (uint32_t c = 0; c < n_blocks; c += 64) {
         const uint32_t t = c + (uint32_t)lane;
-        const bool act = t < EI_TRUE;
+        const bool act = t < n_blocks;
         Blk b;
         {
             const uint32_t tt = act ? t : 0u;
-            const uint32_t i = ei ? tt : tt % SI_OFS, p0 = ei ? tt : (tt / SI_OFS) * SI_TRUE + i, step = ei ? (uint32_t)EI_OFS : (uint32_t)SI_OFS;
-            process_block(di, conv_at(d, fields, p0), conv_at(d, fields, p0 + step), conv_at(d, fields, p0 + 2 * step), (i & 1u) != 0, b);
+            const uint32_t i = tt % blk_it, p0 = (tt / blk_it) * lim + i;
+            process_block(di, queue.at(p0), queue.at(p0 + blk_it), queue.at(p0 + 2 * blk_it), (i & 1u) != 0, b);
         }
         const bool nonsilent = act && !b_silent(b);
         /* seam masking: the first blocks of the frame, until three have checked out (:5256-5284) */
@@ -1355,7 +1400,7 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
         f.odd_valid_lines = (uint16_t)(an.valid[0] / 3); f.even_valid_lines = (uint16_t)(an.valid[1] / 3);
         f.odd_top_data = an.top[0]; f.odd_bottom_data = an.bottom[0]; f.even_top_data = an.top[1]; f.even_bottom_data = an.bottom[1];
         f.odd_sample_rate = f.even_sample_rate = rate;
-        f.blocks_total = 3 * EI_TRUE; f.blocks_drop = (uint16_t)drop; f.samples_drop = (uint16_t)samples_drop;
+        f.blocks_total = (uint16_t)(3u * n_blocks); f.blocks_drop = (uint16_t)drop; f.samples_drop = (uint16_t)samples_drop;
         f.odd_top_padding = d.top_pad[0]; f.odd_bottom_padding = d.bot_pad[0]; f.even_top_padding = d.top_pad[1]; f.even_bottom_padding = d.bot_pad[1];
         f.blocks_broken = (uint16_t)broken; f.blocks_fix_bp = (uint16_t)fix_bp; f.blocks_fix_p = (uint16_t)fix_p; f.blocks_fix_cwd = 0;
         f.field_order = d.field_order; f.odd_ref = an.ref[0]; f.even_ref = an.ref[1];
@@ -1368,7 +1413,6 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
 } // namespace sdvp16
 
 __global__ void __launch_bounds__(64) sdv_k_pcm16_segments(sdvp16::SegArgs16 a) { sdvp16::seg_body(a, blockIdx.x, (int)threadIdx.x); }
-__global__ void __launch_bounds__(64) sdv_k_pcm16_scan(sdvp16::ScanArgs16 a) { sdvp16::scan_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm16_analyse(sdvp16::FrameArgs16s a)
 {
     __shared__ sdvp16::AnaLds lds;
@@ -1379,6 +1423,7 @@ __global__ void __launch_bounds__(64) sdv_k_pcm16_analyse(sdvp16::FrameArgs16s a
 }
 __global__ void __launch_bounds__(64) sdv_k_pcm16_choose(sdvp16::FrameArgs16s a) { sdvp16::choose_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm16_finish(sdvp16::FrameArgs16s a) { sdvp16::finish_body(a, blockIdx.x * 64u + threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_pcm16_carry(sdvp16::FrameArgs16s a) { sdvp16::carry_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm16_ctrl(sdvp16::FrameArgs16s a) { sdvp16::ctrl_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm16_flags(sdvp16::FrameArgs16s a)
 {

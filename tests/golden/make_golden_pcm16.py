@@ -19,14 +19,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import libs  # noqa: E402
 import pcm16_api as p16  # noqa: E402
 
+ONLY = sys.argv[1:]            # names of the scenarios to (re)generate; none: everything
+
 if __name__ == "__main__":
     ref = libs.load_ref()
     blocks = {}
     for key, (recs, kw) in p16.block_inputs().items():
         blocks[key] = p16.run_blocks(ref, "ref_", recs, **kw).view(np.uint8)
-    np.savez_compressed(os.path.join(HERE, "pcm16_blocks.npz"), **blocks)
+    if not ONLY:
+        np.savez_compressed(os.path.join(HERE, "pcm16_blocks.npz"), **blocks)
     print("blocks:", len(blocks), "runs,", os.path.getsize(os.path.join(HERE, "pcm16_blocks.npz")), "bytes")
     for name in p16.GOLDEN:
+        if ONLY and name not in ONLY:
+            continue
         recs, st = p16.make_input(name)
         pairs, frames = p16.run_cpu(ref, "ref_", recs, st)
         path = os.path.join(HERE, "pcm16_" + name + ".npz")
@@ -43,7 +48,7 @@ def make_e2e_luma(ei):
     return luma, audio
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not ONLY:
     import pcm16_frames_api as fa
     for ei in (False, True):
         luma, audio = make_e2e_luma(ei)

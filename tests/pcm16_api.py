@@ -80,13 +80,45 @@ CASES = {
     "ei_picked": (5, dict(seed=439, ei=True, cut=(4, 4), tail_cut=(4, 4), p_bad=0.04, p_picked=0.10, p_forced=0.03), dict(format=FORMAT_EI)),
     "si_tape_as_ei": (4, dict(seed=440, cut=(5, 5), tail_cut=(3, 3), p_bad=0.02), dict(format=FORMAT_EI)),
     "ei_tape_as_si": (4, dict(seed=441, ei=True, cut=(5, 5), p_bad=0.02), {}),
+    # lines that reach the stitcher with a sub-line missing or doubled: a field no longer adds up to 735 sub-lines, the frame is queued with
+    # the "WRONG COUNT" (pcm16x0datastitcher.cpp:4699-4703) and what does not fill an interleave round waits in conv_queue for the next frame
+    "si_lost_sublines": (8, dict(seed=451, cut=(5, 7), tail_cut=(3, 3), p_bad=0.02, rate_44100=True), {}, dict(seed=1, drop=3)),
+    "si_doubled_sublines": (8, dict(seed=452, cut=(6, 4), tail_cut=(2, 5), p_bad=0.02), {}, dict(seed=2, dup=4)),
+    "si_lost_many": (9, dict(seed=453, cut=(4, 4), tail_cut=(3, 3), p_bad=0.05, emphasis=True), {}, dict(seed=3, drop=40, dup=10)),
+    "si_lost_file_marks": (9, dict(seed=454, cut=(5, 7), p_bad=0.03, new_file=True, end_file=True), {}, dict(seed=4, drop=5, dup=3)),
+    "ei_lost_sublines": (8, dict(seed=455, ei=True, cut=(5, 7), tail_cut=(3, 3), p_bad=0.02, rate_44100=True), dict(format=FORMAT_EI), dict(seed=5, drop=3)),
+    "ei_doubled_sublines": (8, dict(seed=456, ei=True, cut=(6, 4), tail_cut=(2, 5), p_bad=0.02), dict(format=FORMAT_EI), dict(seed=6, dup=4)),
+    "ei_lost_many": (9, dict(seed=457, ei=True, cut=(4, 4), tail_cut=(3, 3), p_bad=0.05), dict(format=FORMAT_EI), dict(seed=7, drop=300, dup=10)),
+    "ei_lost_file_marks": (9, dict(seed=458, ei=True, cut=(5, 7), tail_cut=(2, 2), p_bad=0.03, new_file=True, end_file=True), dict(format=FORMAT_EI), dict(seed=8, drop=6, dup=2)),
+    "ei_lost_bff_no_p": (7, dict(seed=459, ei=True, cut=(5, 7), tail_cut=(2, 2), bff=True, p_bad=0.1), dict(format=FORMAT_EI, field_order=2, p_correction=0), dict(seed=9, drop=7)),
+    # long enough for the remainder to grow into a whole extra interleave round: a frame that puts out 525 (SI) / 980 (EI) data blocks
+    "si_lost_long": (30, dict(seed=460, cut=(5, 7), tail_cut=(3, 3), p_bad=0.02), {}, dict(seed=10, drop=400)),
+    "ei_lost_every_field": (372, dict(seed=462, ei=True, cut=(5, 7), tail_cut=(3, 3)), dict(format=FORMAT_EI), dict(every_field=True)),
 }
-GOLDEN = ("si_cut_both", "si_bad10", "si_picked_forced", "si_wander", "si_file_marks", "ei_cut", "ei_bad10", "ei_noise_short")
+WRONG_COUNT = tuple(n for n, c in CASES.items() if len(c) > 3)
+GOLDEN = ("si_cut_both", "si_bad10", "si_picked_forced", "si_wander", "si_file_marks", "ei_cut", "ei_bad10", "ei_noise_short",
+          "si_lost_sublines", "si_lost_file_marks", "ei_doubled_sublines", "ei_lost_many", "si_lost_long")
+
+
+def mangle(recs, seed=0, drop=0, dup=0, every_field=False):
+    """Sub-line records lost / delivered twice at random places of the stream (service records stay); every_field: the middle
+    sub-line of one line of every field is lost."""
+    if every_field:
+        return recs[~((recs["service_type"] == 0) & (recs["line_number"] >= 200) & (recs["line_number"] <= 201) & (recs["line_part"] == 1))]
+    rng = np.random.default_rng(seed)
+    data = np.nonzero(recs["service_type"] == 0)[0]
+    sel = rng.choice(data, size=drop + dup, replace=False)
+    times = np.ones(len(recs), dtype=np.int64)
+    times[sel[:drop]] = 0
+    times[sel[drop:]] = 2
+    return np.repeat(recs, times)
 
 
 def make_input(name):
-    n, kw, st_kw = CASES[name]
+    n, kw, st_kw = CASES[name][:3]
     recs, _ = make_stream(n, **kw)
+    if len(CASES[name]) > 3:
+        recs = mangle(recs, **CASES[name][3])
     return recs, default_settings(**st_kw)
 
 
@@ -96,7 +128,7 @@ def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
     f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm16Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     recs = np.ascontiguousarray(recs)
     nfr = int((recs["service_type"] == SRV_END_FRAME).sum()) + 2
-    pair_cap = pair_cap or nfr * 1500 + 16
+    pair_cap = pair_cap or nfr * 2400 + 16
     frame_cap = frame_cap or nfr + 8
     pairs = np.zeros(pair_cap, dtype=PAIR_DTYPE)
     frames = np.zeros(frame_cap, dtype=FRASM16_DTYPE)
