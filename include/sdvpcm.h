@@ -588,6 +588,8 @@ int sdv_set_audio_masking(sdv_engine *e, int drop_mode);
 int sdv_reset_audio(sdv_engine *e);
 /* How many pairs wait in the worker's window (prebuffer.size()), i.e. have been taken but not put out yet. */
 size_t sdv_audio_pending(const sdv_engine *e);
+/* 1 while the worker takes no more input: its window is full and the first pairs can never leave (fillUntilBufferFull :108). */
+int sdv_audio_stalled(const sdv_engine *e);
 /* PCMSample::index of the next pair that will be put out (it counts from 0 behind every purge and runs on across calls). */
 uint64_t sdv_audio_next_index(const sdv_engine *e);
 
@@ -612,10 +614,14 @@ uint64_t sdv_audio_next_index(const sdv_engine *e);
  * stream state is untouched, so the call can be repeated.  With room for n_pairs + 512 + tags pairs in out_pairs the pairs are worked on
  * there (what lies behind *n_out is scratch then) and cross HBM once in each direction; out_pairs may be `pairs` itself (or overlap it):
  * the burst then goes through a buffer of the engine first.
- * Not supported (SDV_ERR_UNSUPPORTED, the stream state is left untouched): an END_FILE that finds fewer than three pairs in the
- * window (the reference then neither purges nor starts a new source, :1302-1306), a window whose first pairs can never leave
- * (a stream that starts with invalid samples and no NEW_FILE tag: the reference's worker stops taking input for good), and more
- * than 65 536 tags in one burst.
+ * The two dead ends of the worker are reproduced as they are: an END_FILE that finds fewer than three pairs in the window neither
+ * purges nor starts a new source (outputAudio returns early, :1298-1301) - the one or two pairs are scanned as the end of a file, stay
+ * in the window and the stream goes on behind them; a full window whose first pairs can never leave (a stream that starts with invalid
+ * samples and no NEW_FILE tag) makes the worker stop taking input for good (:108) - the call still succeeds, everything behind that
+ * window - pairs and tags, of this call and of every later one - is dropped unread as the reference's queue would keep it forever,
+ * sdv_audio_stalled() says so, and only stop() (the window is purged as it is) or sdv_reset_audio() get the stream going again.
+ * Not supported (SDV_ERR_UNSUPPORTED, the stream state is left untouched): service tags other than NEW_FILE / END_FILE (PCMSamplePair has
+ * no others, pcmsamplepair.h:99-104) and more than 65 536 tags in one burst.
  * All buffers are device pointers; the call returns when the outputs are complete. */
 int sdv_audio_process(sdv_engine *e, const sdv_sample_pair *pairs, size_t n_pairs, int stop, sdv_sample_pair *out_pairs, size_t out_cap,
                       size_t *n_out, sdv_audio_purge *out_purges, size_t purges_cap, size_t *n_purges, uint64_t *n_masked, void *stream);

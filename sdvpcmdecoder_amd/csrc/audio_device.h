@@ -592,7 +592,7 @@ __device__ inline void emit_body(const EmitArgs &a, uint32_t blk, int lane)
         sdv_sample_pair q = qs[r];
         if (a.ignore && k < scanned) { q.sample_flags[0] |= SDV_SF_WORD_VALID; q.sample_flags[1] |= SDV_SF_WORD_VALID; }   /* clearInvalids (:1404-1409) */
         if (k < n_out) { const uint64_t o = t.out_base + k; if (o < a.out_cap) store_pair_streaming(&a.out[o], q); }
-        else if (!closed) a.carry_out[k - n_out] = q;
+        else if (!closed && k - n_out < (uint32_t)WIN) a.carry_out[k - n_out] = q;      /* (a stalled window holds WIN pairs; what lies behind it was never taken) */
     }
 }
 

@@ -184,6 +184,8 @@ def load_library(path: str | None = None):
     lib.sdv_reset_audio.argtypes = [C.c_void_p]
     lib.sdv_audio_pending.restype = C.c_size_t
     lib.sdv_audio_pending.argtypes = [C.c_void_p]
+    lib.sdv_audio_stalled.restype = C.c_int
+    lib.sdv_audio_stalled.argtypes = [C.c_void_p]
     lib.sdv_audio_next_index.restype = C.c_uint64
     lib.sdv_audio_next_index.argtypes = [C.c_void_p]
     lib.sdv_audio_process.restype = C.c_int
@@ -561,6 +563,10 @@ class Engine:
 
     def audio_pending(self) -> int:
         return int(self.lib.sdv_audio_pending(self._h))
+
+    def audio_stalled(self) -> bool:
+        """The worker takes no more input: its window is full and the first pairs can never leave (audioprocessor.cpp:108)."""
+        return bool(self.lib.sdv_audio_stalled(self._h))
 
     def audio_next_index(self) -> int:
         return int(self.lib.sdv_audio_next_index(self._h))

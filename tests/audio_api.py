@@ -126,6 +126,23 @@ def _c_tiny_files():
                  "N", "E", "N", audio(1, 28), "E", "N", audio(700, 29, runs=[(300, 30, 1)]), "E"])
 
 
+def _c_tiny_files_bad():
+    # END_FILE tags that find one or two pairs in the window (no purge: the pairs are scanned as the end of a file and stay), with invalid words among them,
+    # the very first pairs of a stream without a tag included
+    return tape([audio(2, 40, runs=[(1, 1, 2)]), "E", audio(1, 41, runs=[(0, 1, 0)]), "E", audio(300, 42, runs=[(100, 20, 2)]), "E",
+                 "N", audio(1, 43, runs=[(0, 1, 1)]), "E", "E", audio(1, 44), "E", audio(400, 45, runs=[(0, 3, 2), (200, 230, 0)]), "E", "N", audio(1, 46, runs=[(0, 1, 2)]), "E"])
+
+
+def _c_stalled_start():
+    # a stream that starts with invalid samples and no NEW_FILE tag: the window fills up, nothing can ever leave, the worker stops taking input
+    return tape([audio(2000, 77, runs=[(0, 5, 2)]), "E", "N", audio(500, 78), "E"])
+
+
+def _c_tiny_then_long():
+    # ... the same behind an END_FILE that did not purge (one pair in the window, invalid in one channel)
+    return tape(["N", audio(900, 79, runs=[(300, 40, 2)]), "E", "N", audio(1, 80, runs=[(0, 1, 1)]), "E", audio(1, 83, runs=[(0, 1, 1)]), audio(1500, 81, runs=[(0, 2, 1), (700, 10, 2)]), "N", audio(100, 82), "E"])
+
+
 def _c_small_files():
     return tape(["N", audio(3, 16), "E", "N", audio(2, 17, runs=[(1, 1, 0)]), "E", "N", audio(230, 18, runs=[(100, 20, 2)]), "E", "N", audio(226, 19, runs=[(5, 200, 2)]), "E",
                  "N", audio(9, 30, runs=[(3, 6, 2)]), "E", "N", audio(700, 29, runs=[(300, 30, 1)]), "E"])
@@ -206,6 +223,13 @@ CASES = {
     "no_first_tag": (_c_no_first_tag, DROP_INTER_LIN_WORD, None, 1),
     "tiny_files": (_c_tiny_files, DROP_INTER_LIN_WORD, None, 1),
     "small_files": (_c_small_files, DROP_INTER_LIN_WORD, None, 1),
+    "tiny_files_bad": (_c_tiny_files_bad, DROP_INTER_LIN_WORD, None, 1),
+    "tiny_files_bad_ignore": (_c_tiny_files_bad, DROP_IGNORE, None, 0),
+    "tiny_files_bad_block_bursts": (_c_tiny_files_bad, DROP_HOLD_BLOCK, (0.001, 0.003, 0.4, 0.43, 1.0), 1),
+    "stalled_start": (_c_stalled_start, DROP_INTER_LIN_WORD, None, 1),
+    "stalled_start_open": (_c_stalled_start, DROP_MUTE_WORD, None, 0),
+    "stalled_start_bursts": (_c_stalled_start, DROP_INTER_LIN_WORD, (0.1, 0.2, 0.5, 0.9, 1.0), 1),
+    "tiny_then_long": (_c_tiny_then_long, DROP_INTER_LIN_WORD, None, 1),
     "exact_windows": (_c_exact_windows, DROP_INTER_LIN_WORD, None, 1),
     "masked_zero_start": (_c_masked_zero_start, DROP_INTER_LIN_WORD, None, 1),
     "masked_zero_start_hold": (_c_masked_zero_start, DROP_HOLD_WORD, None, 1),
@@ -220,8 +244,10 @@ CASES = {
     "bursts_two_files": (_c_two_files, DROP_HOLD_WORD, (0.2, 0.4, 0.6, 1.0), 0),
     "bursts_small": (_c_short_runs, DROP_INTER_LIN_WORD, (0.02, 0.05, 0.1, 0.16, 0.3, 1.0), 1),
 }
-GOLDEN = ("short_runs_lin", "long_runs_hold", "window_edges", "blocks_by_block", "two_files", "no_end_tag_stop", "masked_zero_start", "bursts_long_runs", "ignore")
-UNSUPPORTED = ("tiny_files",)      # the product refuses these (the oracle and the reference still agree on them)
+GOLDEN = ("short_runs_lin", "long_runs_hold", "window_edges", "blocks_by_block", "two_files", "no_end_tag_stop", "masked_zero_start", "bursts_long_runs", "ignore",
+          "tiny_files", "tiny_files_bad", "stalled_start", "tiny_then_long")
+DEAD_ENDS = ("tiny_files", "tiny_files_bad", "tiny_files_bad_ignore", "tiny_files_bad_block_bursts", "stalled_start", "stalled_start_open", "stalled_start_bursts",
+             "tiny_then_long")      # the worker's two dead ends (an END_FILE that does not purge, a window nothing can leave): reproduced as they are
 
 
 def make_input(name):

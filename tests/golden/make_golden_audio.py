@@ -29,9 +29,13 @@ def read_wavs(d):
     return files
 
 
+ONLY = sys.argv[1:]            # names of the scenarios to (re)generate; none: everything
+
 if __name__ == "__main__":
     ref = libs.load_ref()
     for name in A.GOLDEN:
+        if ONLY and name not in ONLY:
+            continue
         pairs, mode, ends, stop = A.make_input(name)
         with tempfile.TemporaryDirectory() as d:
             out, idx, pur, masked, _ = A.run_cpu(ref, "ref_", pairs, mode, ends, stop, wav_dir=d)
@@ -42,6 +46,8 @@ if __name__ == "__main__":
                             pairs=out.view(np.uint8).reshape(len(out), 12), index=idx, purges=pur, masked=masked, **extra)
         print(f"{name}: {len(pairs)} pairs in -> {len(out)} out, {len(pur)} purges, {masked} masked, wav files {sorted(wavs)}, {os.path.getsize(path)} bytes")
 
+    if ONLY:
+        sys.exit(0)
     # end to end: the PCMSamplePair stream the real VideoToDigital + STC007DataStitcher made of the synthetic NTSC file (e2e_ntsc_file.npz,
     # tests/golden/make_golden_stitch.py) through the real AudioProcessor and into the real SamplesToWAV
     from stitch_api import PAIR_DTYPE

@@ -17,7 +17,7 @@ import libs
 from stitch_api import PAIR_DTYPE
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SUPPORTED = [n for n in A.CASES if n not in A.UNSUPPORTED]
+SUPPORTED = list(A.CASES)        # (round 3: the worker's two dead ends are reproduced, nothing is refused any more)
 
 
 def _diff(out, want):
@@ -40,11 +40,12 @@ def test_oracle_matches_golden(name, oracle_lib):
     assert mode == int(z["mode"]) and stop == int(z["stop"]) and np.array_equal(ends, z["ends"])
     want = np.ascontiguousarray(z["pairs"]).view(PAIR_DTYPE).reshape(-1)
     assert out.tobytes() == want.tobytes(), _diff(out, want)
-    assert np.array_equal(idx, z["index"]) and np.array_equal(pur["first_pair"], z["purges"]) and masked == int(z["masked"]) and hit == 0
+    assert np.array_equal(idx, z["index"]) and np.array_equal(pur["first_pair"], z["purges"]) and masked == int(z["masked"]) and hit == (1 if name in A.DEAD_ENDS else 0)
     # the index is implied by the purge positions (what the C-ABI relies on), and the kinds / tag positions are consistent
     assert np.array_equal(idx, A.expected_index(len(out), pur["first_pair"]))
     tags = np.nonzero(pairs["service_type"])[0]
-    assert np.array_equal(pur["tag_index"][pur["kind"] != A.PURGE_STOP], tags) and np.array_equal(pur["kind"][pur["kind"] != A.PURGE_STOP], pairs["service_type"][tags])
+    if name not in A.DEAD_ENDS:         # (there a tag may pass without a purge, or never be read)
+        assert np.array_equal(pur["tag_index"][pur["kind"] != A.PURGE_STOP], tags) and np.array_equal(pur["kind"][pur["kind"] != A.PURGE_STOP], pairs["service_type"][tags])
     # the WAV files the reference wrote
     files = dict(A.wav_files(oracle_lib, "orc_", out, pur))
     ref_files = {int(k[3:]): z[k].tobytes() for k in z.files if k.startswith("wav")}
@@ -62,7 +63,7 @@ def test_oracle_matches_live_reference(name, oracle_lib):
         ref_files = {int(f[3:].split("_")[0]): open(os.path.join(d, f), "rb").read() for f in os.listdir(d)}
     assert out.tobytes() == r_out.tobytes(), _diff(out, r_out)
     assert np.array_equal(idx, r_idx) and np.array_equal(pur["first_pair"], r_pur) and masked == r_masked
-    assert hit == (1 if name in A.UNSUPPORTED else 0)
+    assert hit == (1 if name in A.DEAD_ENDS else 0)
     if stop:        # (without it the driver still has to stop the worker to end the run: the files then hold what stop() flushed as well)
         assert dict(A.wav_files(oracle_lib, "orc_", out, pur)) == ref_files
 
@@ -123,30 +124,44 @@ def emu(emu_lib):
 @pytest.mark.parametrize("name", SUPPORTED)
 def test_emu_matches_oracle(name, emu, oracle_lib):
     pairs, mode, ends, stop, want, idx, want_pur, want_masked, hit = _oracle(name)
-    assert hit == 0
     out, pur, masked = A.emu_run(emu, pairs, mode, ends, stop)
     assert out.tobytes() == want.tobytes(), _diff(out, want)
     assert pur.tobytes() == want_pur.tobytes() and masked == want_masked
 
 
-def test_emu_refuses_what_the_reference_mishandles(emu, oracle_lib):
+def test_emu_follows_the_reference_into_its_dead_ends(emu, oracle_lib):
+    emu.sdv_audio_stalled.argtypes = [C.c_void_p]
     eng = emu.sdv_engine_create(0)
     emu.sdv_set_audio_masking(eng, A.DROP_INTER_LIN_WORD)
-    pairs, mode, ends, stop = A.make_input("tiny_files")
-    rc, out, pur, masked, n_out, n_pur = A.emu_audio(emu, eng, pairs, 1)
-    assert rc == -4 and b"fewer than three pairs" in emu.sdv_last_error(eng) and emu.sdv_audio_pending(eng) == 0
     # a stream that starts with invalid samples and no NEW_FILE tag: the reference's window fills up and nothing can ever leave
     bad = A.audio(2000, 77, runs=[(0, 5, 2)])
     rc, out, pur, masked, n_out, n_pur = A.emu_audio(emu, eng, bad, 0)
-    assert rc == -4 and b"never leave" in emu.sdv_last_error(eng) and emu.sdv_audio_pending(eng) == 0
-    _, _, _, _, hit = A.run_cpu(oracle_lib, "orc_", bad, A.DROP_INTER_LIN_WORD, np.array([len(bad)], dtype=np.uint64), 0)
-    assert hit == 1
-    # a tag that is neither NEW_FILE nor END_FILE
+    assert rc == 0 and n_out == 0 and n_pur == 0 and emu.sdv_audio_pending(eng) == 512 and emu.sdv_audio_stalled(eng) == 1
+    want = A.run_cpu(oracle_lib, "orc_", bad, A.DROP_INTER_LIN_WORD, np.array([len(bad)], dtype=np.uint64), 0)
+    assert want[4] == 1 and len(want[0]) == 0
+    # ... nothing is taken any more, tags included
+    rc, out, pur, masked, n_out, n_pur = A.emu_audio(emu, eng, A.tape(["N", A.audio(700, 3), "E"]), 0)
+    assert rc == 0 and n_out == 0 and n_pur == 0 and emu.sdv_audio_pending(eng) == 512 and emu.sdv_audio_stalled(eng) == 1
+    # ... until stop() purges the window as it is
+    rc, out, pur, masked, n_out, n_pur = A.emu_audio(emu, eng, A.audio(10, 4), 1)
+    want = A.run_cpu(oracle_lib, "orc_", bad, A.DROP_INTER_LIN_WORD, np.array([len(bad)], dtype=np.uint64), 1)
+    assert rc == 0 and out.tobytes() == want[0].tobytes() and n_out == 511 and n_pur == 1 and pur[0]["kind"] == A.PURGE_STOP and pur[0]["first_pair"] == 511
+    assert emu.sdv_audio_stalled(eng) == 0 and emu.sdv_audio_pending(eng) == 1
+    # a failed call takes nothing, also when an END_FILE that does not purge has split it into spans
+    pairs, mode, ends, stop = A.make_input("tiny_files_bad")
+    emu.sdv_reset_audio(eng)
+    rc, out, pur, masked, n_out, n_pur = A.emu_audio(emu, eng, pairs, 1, out_cap=300)
+    assert rc == -1 and b"too small" in emu.sdv_last_error(eng) and emu.sdv_audio_pending(eng) == 0 and emu.sdv_audio_next_index(eng) == 0
+    rc, out, pur, masked, n_out, n_pur = A.emu_audio(emu, eng, pairs, 1)
+    want = A.run_cpu(oracle_lib, "orc_", pairs, mode, ends, stop)
+    assert rc == 0 and out.tobytes() == want[0].tobytes() and pur.tobytes() == want[2].tobytes() and masked == want[3]
+    # a tag that is neither NEW_FILE nor END_FILE (PCMSamplePair has no such type)
     odd = A.tape(["N", A.audio(100, 78), A.tag(7), A.audio(100, 79)])
     rc = A.emu_audio(emu, eng, odd, 0)[0]
     assert rc == -4 and b"neither NEW_FILE nor END_FILE" in emu.sdv_last_error(eng)
     # the engine is still usable
     pairs, mode, ends, stop = A.make_input("short_runs_lin")
+    emu.sdv_reset_audio(eng)
     rc, out, pur, masked, _, _ = A.emu_audio(emu, eng, pairs, 1)
     want = A.run_cpu(oracle_lib, "orc_", pairs, mode, ends, stop)
     assert rc == 0 and out.tobytes() == want[0].tobytes()
