@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define SDV_ABI_VERSION 3   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only) */
+#define SDV_ABI_VERSION 4   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only);
+                             * 4: sdv_pcm16x0_binarize_lines, sdv_audio_stalled (additions); the calls that used to refuse PCM-16x0 frames of the wrong size and the
+                             * AudioProcessor's dead ends now follow the reference; the PCM-16x0 stitch state blob grew by conv_queue's remainder */
 
 /* ---- status codes ---------------------------------------------------------------------------
  * 0..4 mirror Binarizer::LB_RET_* (binarizer.h:268-275); 16.. mirror STC007Deinterleaver::DI_RET_*
@@ -425,6 +427,19 @@ typedef struct sdv_pcm16x0_bin_rec {
     uint8_t control_bit;            /* PCM16X0SubLine::control_bit */
     uint8_t _pad;
 } sdv_pcm16x0_bin_rec;
+
+/* Binarizer::processLine (binarizer.h:361, binarizer.cpp:443-1724) with a PCM16X0SubLine as output, for n_lines video lines in one launch:
+ * the three passes the reference makes over one VideoLine (setLinePartMode PART_PCM16X0_LEFT / _MIDDLE / _RIGHT, videotodigital.cpp:902-925),
+ * in that order, on line i = luma + i*row_stride (width bytes), numbered first_line + i*line_step of frame frame_number.  presets[3 i + part]
+ * is what the caller had set on its Binarizer before that pass (setGoodParameters / setReferenceLevel / setDataCoordinates / setBWLevels,
+ * binarizer.cpp:240-377, and the sticky do_ref_lvl_sweep member; presets == NULL: nothing preset); the passes of a line share the line's
+ * VideoLine::scan_done mark like in the reference (a line whose coordinate search has run is not searched again, binarizer.cpp:5819-6042),
+ * which starts cleared.  out_lines takes three records per line (lines_cap >= 3 n_lines), out_scan_done (or NULL) the mark behind each pass.
+ * Mode, fine settings, coord_search, flags, service / empty lines, SDV_MODE_INSANE and errors as for sdv_pcm1_binarize_lines;
+ * SDV_ERR_SHORT_LINE under 193 px.  The twin of sdv_pcm1_binarize_lines for callers that keep VideoToDigital's frame loop. */
+int sdv_pcm16x0_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_stride, int width, size_t n_lines,
+                               const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
+                               unsigned flags, int coord_search, sdv_pcm16x0_bin_rec *out_lines, size_t lines_cap, uint8_t *out_scan_done, void *stream);
 
 /* VideoToDigital::doBinarize (videotodigital.cpp:698-1815) with setPCMType(TYPE_PCM16X0) for a batch of whole frames: the frame
  * prescan (prescanCoordinates, :148-345: the right third of four lines, every mode but DRAFT), three Binarizer passes per video line

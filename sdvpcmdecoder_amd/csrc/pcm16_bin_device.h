@@ -859,4 +859,57 @@ __device__ inline void emit_rec(const L16 &l, uint32_t frame, uint16_t line_no, 
     *dst = r;
 }
 
+/* ---- sdv_pcm16x0_binarize_lines: the three passes over a video line, one wave per line ------------------------------------------------ */
+struct LineArgs16 {
+    const uint8_t *luma; size_t row_stride; int width; size_t n_lines;
+    const sdv_bin_state *states;    /* [3 * n_lines]: what the caller has preset before each pass (setGoodParameters / setBWLevels ...), or NULL: nothing */
+    uint32_t frame_number; uint16_t first_line, line_step;
+    uint8_t doubled, mode, coord_search;
+    sdv_bin_preset preset;
+    sdv_pcm16x0_bin_rec *out;       /* [3 * n_lines] */
+    uint8_t *scan_done;             /* [3 * n_lines] VideoLine::scan_done behind each pass, or NULL */
+};
+/* The reference runs its Binarizer three times over one VideoLine object (setLinePartMode, videotodigital.cpp:902-925); what the
+ * passes share is the line's scan_done mark (binarizer.cpp:5819-6042: a line whose coordinate search has run is not searched again). */
+template <bool kInsane>
+__device__ inline void line16_body(const LineArgs16 &a, P16Lds &lds, size_t li)
+{
+    sdvp1b::stage_row(lds.w.px, a.luma + li * a.row_stride, a.width);
+    bool scan_done = false;
+    for (int sub = 0; sub < P16_SUBLINES; sub++) {
+        BinCtx c; c.ps = a.preset; c.mode = a.mode; c.scan_start = 0; c.scan_end = (uint16_t)(a.width - 1);
+        c.force_bit_picker = true;      /* binarizer.cpp:82 */
+        Bin b;
+        b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);
+        b.do_ref_lvl_sweep = false;
+        if (a.states) {
+            const sdv_bin_state s = a.states[3 * li + (size_t)sub];
+            b.in_black = s.in_def_black; b.in_white = s.in_def_white; b.in_ref = s.in_def_reference;
+            b.in_coord.start = s.in_def_start; b.in_coord.stop = s.in_def_stop; b.in_coord.doubled = s.in_def_from_doubled != 0;
+            b.do_ref_lvl_sweep = s.do_ref_lvl_sweep != 0;
+        }
+        bin_set_mode(b, a.mode);
+        b.scan_start = c.scan_start; b.scan_end = c.scan_end; b.vl_doubled = a.doubled != 0;
+        L16 out;
+        process_line_p16<kInsane>(c, b, a.coord_search != 0, (uint8_t)(PART_LEFT + sub), scan_done, lds, out, a.doubled != 0);
+        emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[3 * li + (size_t)sub]);
+        if (a.scan_done && lane_id() == 0) a.scan_done[3 * li + (size_t)sub] = scan_done ? 1 : 0;
+        __syncthreads();
+    }
+}
+
 } // namespace sdvp16
+
+#ifndef SDV_P16B_WAVES_PER_EU
+#define SDV_P16B_WAVES_PER_EU 4
+#endif
+__global__ void __launch_bounds__(64, SDV_P16B_WAVES_PER_EU) sdv_k_pcm16_lines(sdvp16::LineArgs16 a)
+{
+    __shared__ sdvp16::P16Lds lds;
+    for (size_t li = blockIdx.x; li < a.n_lines; li += gridDim.x) sdvp16::line16_body<false>(a, lds, li);
+}
+__global__ void __launch_bounds__(64, SDV_P16B_WAVES_PER_EU) sdv_k_pcm16_lines_insane(sdvp16::LineArgs16 a)      /* MODE_INSANE */
+{
+    __shared__ sdvp16::P16Lds lds;
+    for (size_t li = blockIdx.x; li < a.n_lines; li += gridDim.x) sdvp16::line16_body<true>(a, lds, li);
+}

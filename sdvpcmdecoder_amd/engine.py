@@ -146,6 +146,9 @@ def load_library(path: str | None = None):
     lib.sdv_pcm1_binarize_lines.restype = C.c_int
     lib.sdv_pcm1_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16,
                                             C.c_uint16, C.c_uint, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.sdv_pcm16x0_binarize_lines.restype = C.c_int
+    lib.sdv_pcm16x0_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16,
+                                               C.c_uint16, C.c_uint, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.sdv_default_deint_settings.argtypes = [C.POINTER(DeintSettings)]
     lib.sdv_deinterleave_blocks.restype = C.c_int
     lib.sdv_deinterleave_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(DeintSettings), C.c_void_p, C.c_size_t,
@@ -475,6 +478,29 @@ class Engine:
                                               out_lines.shape[0], sptr)
         self._check(rc)
         return out_lines[:n]
+
+    def pcm16x0_binarize_lines(self, luma, presets=None, frame_number: int = 1, first_line: int = 1, line_step: int = 1, doubled: bool = False,
+                               coord_search: bool = True, out_lines=None, with_scan_done: bool = False, stream=None):
+        """Binarizer::processLine with a PCM16X0SubLine output, the three passes over every row of `luma` (torch.uint8 CUDA tensor
+        (n_lines, width), rows contiguous) in one launch.  `presets`: None or a torch.uint8 CUDA tensor (3 * n_lines, 10) of sdv_bin_state -
+        what the caller's Binarizer had been given before each pass.  Returns a torch.uint8 CUDA tensor (3 * n_lines, 36) of
+        sdv_pcm16x0_bin_rec (and, with_scan_done, a uint8 tensor of VideoLine::scan_done behind each pass)."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 2 and luma.stride(1) == 1
+        n, w = luma.shape
+        if presets is not None:
+            assert presets.is_cuda and presets.dtype == torch.uint8 and presets.shape == (3 * n, 10) and presets.is_contiguous()
+        if out_lines is None:
+            out_lines = torch.empty((3 * n, 36), dtype=torch.uint8, device=luma.device)
+        _check_out(out_lines, 36, luma.device, "out_lines")
+        scans = torch.zeros((3 * n,), dtype=torch.uint8, device=luma.device) if with_scan_done else None
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        rc = self.lib.sdv_pcm16x0_binarize_lines(self._h, C.c_void_p(luma.data_ptr()), luma.stride(0), w, n,
+                                                 None if presets is None else C.c_void_p(presets.data_ptr()), frame_number, first_line, line_step,
+                                                 FLAG_DOUBLED if doubled else 0, 1 if coord_search else 0, C.c_void_p(out_lines.data_ptr()),
+                                                 out_lines.shape[0], None if scans is None else C.c_void_p(scans.data_ptr()), sptr)
+        self._check(rc)
+        return (out_lines[:3 * n], scans) if with_scan_done else out_lines[:3 * n]
 
     def pcm1_binarize_frames(self, luma, first_frame_no: int = 1, new_file: bool = False, doubled: bool = False,
                              out_lines=None, out_stats=None, stream=None, end_file: bool = False):

@@ -132,3 +132,130 @@ def make_case(name):
         run["empty"] = e
     run["preset"] = _preset(**pre)
     return np.ascontiguousarray(luma), run
+
+
+# ---- the per-pass contract of sdv_pcm16x0_binarize_lines ---------------------------------------------------------------------------
+STATE_DTYPE = np.dtype([("black", "u1"), ("white", "u1"), ("ref", "u1"), ("sweep_flag", "u1"), ("start", "<i2"), ("stop", "<i2"), ("doubled", "u1"), ("_pad", "u1")])
+assert STATE_DTYPE.itemsize == 10
+
+
+def run_lines_with_states(lib, prefix, luma, states, mode=1, coord_search=True, preset=None, doubled=False, first_line=1, frame=1):
+    """The oracle / the reference, three passes per row, every pass on a Binarizer preset with states[3 i + part] (set_state): the
+    per-pass contract of the engine entry.  -> (records, scan_done behind each pass)"""
+    f = lambda name: getattr(lib, prefix + name)
+    f("new").restype = C.c_void_p
+    h = C.c_void_p(f("new")())
+    f("set_mode").argtypes = [C.c_void_p, C.c_int]
+    f("set_coord_search").argtypes = [C.c_void_p, C.c_int]
+    f("set_preset").argtypes = [C.c_void_p, C.c_void_p]
+    f("set_state").argtypes = [C.c_void_p, C.c_void_p]
+    f("scan_done").argtypes = [C.c_void_p]
+    f("free").argtypes = [C.c_void_p]
+    proc = f("process")
+    proc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint16, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f("set_mode")(h, mode)
+    f("set_coord_search")(h, 1 if coord_search else 0)
+    if preset is not None:
+        f("set_preset")(h, C.byref(preset))
+    luma = np.ascontiguousarray(luma)
+    states = np.ascontiguousarray(states)
+    n = luma.shape[0]
+    out = np.zeros(3 * n, dtype=BIN16_DTYPE)
+    scans = np.zeros(3 * n, dtype=np.uint8)
+    for i in range(n):
+        for j, part in enumerate(PARTS):
+            k = 3 * i + j
+            f("set_state")(h, states[k:k + 1].ctypes.data)
+            proc(h, luma[i].ctypes.data, luma.shape[1], frame, first_line + i, 0, 1 if doubled else 0, 0, part, 1 if j == 0 else 0, out[k:k + 1].ctypes.data)
+            scans[k] = f("scan_done")(h)
+    f("free")(h)
+    return out, scans
+
+
+def states_from_records(recs, mode=1):
+    """What setGoodParameters(previous sub-line) leaves in the Binarizer before each pass (binarizer.cpp:353-377): the levels and
+    coordinates of the last sub-line whose CRC is valid (ignoring the forced-bad mark), nothing before the first one; and the sticky
+    do_ref_lvl_sweep member (a pass that found levels and was not read with the preset tuning went through :1104 and left it at "the mode
+    is MODE_INSANE")."""
+    st = np.zeros(len(recs), dtype=STATE_DTYPE)
+    cur = np.zeros(1, dtype=STATE_DTYPE)[0]
+    cur["start"], cur["stop"] = -32768, 32767
+    for i in range(len(recs)):
+        st[i] = cur
+        r = recs[i]
+        if (int(r["flags"]) & LF_BW_SET) and not (int(r["flags"]) & LF_BY_EXT_TUNE):
+            cur = cur.copy()
+            cur["sweep_flag"] = 1 if mode == 3 else 0
+        if int(r["service_type"]) == 0 and int(r["calc_crc"]) == int(r["words"][3]):
+            cur = cur.copy()
+            cur["ref"] = r["ref_level"]
+            s, e = int(r["data_start"]), int(r["data_stop"])
+            if s != -32768 and e != 32767 and s < e:
+                cur["start"], cur["stop"], cur["doubled"] = s, e, 1 if (int(r["flags"]) & 128) else 0
+            else:
+                cur["start"], cur["stop"], cur["doubled"] = -32768, 32767, 0
+            b, wht = int(r["black_level"]), int(r["white_level"])
+            if b < wht and b < 160 and wht > 28 and wht != 0:
+                cur["black"], cur["white"] = b, wht
+            else:
+                cur["black"], cur["white"] = 0, 0
+    return st
+
+
+def states_for_run(recs, run):
+    """Per-pass presets equivalent to the sequential run `run` that produced `recs` (one record per pass, one per service line):
+    everything for feedback "good", only the sticky sweep flag (which no feedback mode touches) for "none" / "reset"."""
+    st = states_from_records(recs, run.get("mode", 1))
+    if run.get("feedback", "good") != "good":
+        st["black"] = st["white"] = st["ref"] = 0
+        st["start"], st["stop"], st["doubled"] = -32768, 32767, 0
+    return st
+
+
+def data_rows(n, run):
+    """Rows of a case that are decoded from pixels (service and empty lines are the caller's to pass through) and, per row, where its
+    three records sit in the sequential record stream."""
+    services = run.get("services"); empty = run.get("empty")
+    rows, at, k = [], [], 0
+    for i in range(n):
+        srv = 0 if services is None else int(services[i])
+        emp = 0 if empty is None else int(empty[i])
+        if srv == 0 and emp == 0:
+            rows.append(i); at.append(k)
+        k += 3 if srv == 0 else 1
+    return np.array(rows, dtype=np.int64), np.array(at, dtype=np.int64)
+
+
+def run_engine_lines(lib, eng, luma, states=None, mode=1, coord_search=True, preset=None, doubled=False, first_line=1, frame=1, line_step=1):
+    """sdv_pcm16x0_binarize_lines on host buffers (the emulator build); one launch for all rows, pass `part` of row i preset with
+    states[3 i + part].  -> (rc, records, scan_done behind each pass)"""
+    f = lib.sdv_pcm16x0_binarize_lines
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16, C.c_uint, C.c_int,
+                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.sdv_set_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.sdv_set_mode(eng, mode)
+    lib.sdv_set_bin_preset.argtypes = [C.c_void_p, C.POINTER(libs.BinPreset)]
+    p = preset if preset is not None else libs.default_preset()
+    lib.sdv_set_bin_preset(eng, C.byref(p))
+    luma = np.ascontiguousarray(luma)
+    out = np.zeros(3 * luma.shape[0], dtype=BIN16_DTYPE)
+    scans = np.zeros(3 * luma.shape[0], dtype=np.uint8)
+    st = None if states is None else np.ascontiguousarray(states)
+    rc = f(eng, luma.ctypes.data, luma.shape[1], luma.shape[1], luma.shape[0], None if st is None else st.ctypes.data, frame, first_line, line_step,
+           2 if doubled else 0, 1 if coord_search else 0, out.ctypes.data, len(out), scans.ctypes.data, None)
+    return rc, out, scans
+
+
+def case_states(name, recs=None, lib=None, prefix="orc_bin16_"):
+    """Rows of a case that go to the per-pass entry, the presets every pass of the sequential run had (from `recs`: the records of that
+    run - the oracle's when not given), the sequential records and scan_done marks of those passes, the engine keywords."""
+    luma, run = make_case(name)
+    scans = None
+    if recs is None:
+        recs, _, scans = run_lines(lib, prefix, luma, **run)
+    rows, at = data_rows(len(luma), run)
+    idx = (at[:, None] + np.arange(3)[None, :]).reshape(-1)
+    states = states_for_run(recs, run)[idx]
+    kw = dict(mode=run["mode"], coord_search=run.get("coord_search", True), preset=run["preset"], doubled=run.get("doubled", False))
+    return luma[rows], states, recs[idx], (None if scans is None else scans[idx]), kw

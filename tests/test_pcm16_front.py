@@ -102,3 +102,110 @@ def test_short_line_and_insane_mode(oracle_lib):
     got, rets, _ = pf.run_lines(oracle_lib, "orc_bin16_", luma, mode=3, feedback="none")
     # MODE_INSANE: each of the three passes gets its reference level from the sweep and reads with it
     assert (rets == 0).all() and ((got["flags"] & 1) != 0).all() and ((got["flags"] & 64) != 0).all()
+
+
+# ---- the per-pass entry (sdv_pcm16x0_binarize_lines): the contract, the kernel source on the emulator, the product on the GPU --------------
+import ctypes as C  # noqa: E402
+
+
+def _same_but_line_number(a, b):
+    """the sequential run numbers its lines with gaps where service lines were: everything but the line number"""
+    a, b = a.copy(), b.copy()
+    a["line_number"] = 0; b["line_number"] = 0
+    return a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("name", sorted(pf.CASES))
+def test_states_reproduce_the_sequential_run(name, oracle_lib):
+    """What a pass depends on is its pixels, the mode and settings, the line's scan_done mark and what was preset on the Binarizer: preset
+    pass by pass with what the sequential run had handed on, every pass comes out as in that run."""
+    luma, states, seq, seq_scans, kw = pf.case_states(name, lib=oracle_lib)
+    got, scans = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, states, **kw)
+    assert _same_but_line_number(got, seq), _diff(got, seq, scans, seq_scans)
+    assert (scans == seq_scans).all()
+
+
+@pytest.fixture(scope="module")
+def emu(emu_lib):
+    emu_lib.sdv_engine_create.restype = C.c_void_p
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    yield emu_lib, eng
+    emu_lib.sdv_engine_destroy(eng)
+
+
+@pytest.mark.parametrize("name", ["clean_fast", "cut_bits_normal", "cut_left_only", "noisy", "control_bits", "forced_coords", "no_bit_picker", "window_moves", "one_bad_part", "garbage",
+                                  "flat_and_services", "wide_1440_doubled", "insane_scratch", "insane_one_bad_part", "insane_few_valid"])
+def test_emu_lines_match_oracle(name, emu, oracle_lib):
+    lib, eng = emu
+    luma, states, seq, seq_scans, kw = pf.case_states(name, lib=oracle_lib)
+    rc, got, scans = pf.run_engine_lines(lib, eng, luma, states, **kw)
+    assert rc == 0
+    assert _same_but_line_number(got, seq), _diff(got, seq, scans, seq_scans)
+    assert (scans == seq_scans).all()
+
+
+def test_emu_lines_argument_checks(emu):
+    lib, eng = emu
+    luma = np.zeros((2, 720), np.uint8)
+    assert pf.run_engine_lines(lib, eng, luma[:, :150])[0] == 3          # SDV_ERR_SHORT_LINE: under 193 px
+    rc, got, _ = pf.run_engine_lines(lib, eng, luma)                     # nothing preset, nothing to read
+    assert rc == 0 and ((got["flags"] & pf.LF_CRC_VALID) == 0).all() and (got["line_part"].reshape(2, 3) == np.arange(3)).all()
+
+
+def _gpu_lines(luma, states, mode=1, coord_search=True, preset=None, doubled=False):
+    import torch
+    torch.zeros(1, device="cuda:0")
+    from sdvpcmdecoder_amd import Engine
+    from sdvpcmdecoder_amd.engine import BinPreset
+    eng = Engine(0)
+    eng.setBinarizationMode(mode)
+    eng.setFineSettings(BinPreset.from_buffer_copy(bytes(preset if preset is not None else libs.default_preset())))
+    d_luma = torch.from_numpy(np.ascontiguousarray(luma)).cuda()
+    d_st = torch.from_numpy(np.ascontiguousarray(states).view(np.uint8).reshape(len(states), 10)).cuda()
+    out, scans = eng.pcm16x0_binarize_lines(d_luma, d_st, frame_number=1, first_line=1, line_step=1, doubled=doubled, coord_search=coord_search, with_scan_done=True)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().reshape(-1).view(pf.BIN16_DTYPE), scans.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(pf.CASES))
+def test_gpu_lines_match_oracle(name, oracle_lib):
+    luma, states, seq, seq_scans, kw = pf.case_states(name, lib=oracle_lib)
+    got, scans = _gpu_lines(luma, states, **kw)
+    assert _same_but_line_number(got, seq), _diff(got, seq, scans, seq_scans)
+    assert (scans == seq_scans).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", pf.GOLDEN)
+def test_gpu_lines_match_golden_from_reference(name):
+    """The fixtures hold the real Binarizer's sequential run (three passes per line on one object); the presets of every pass are rebuilt
+    from the fixture's own records - no oracle in between."""
+    g = np.load(os.path.join(GOLD, "pcm16front_" + name + ".npz"))
+    want = g["recs"].reshape(-1).view(pf.BIN16_DTYPE)
+    luma, states, seq, _, kw = pf.case_states(name, recs=want)
+    assert hashlib.sha256(pf.make_case(name)[0].tobytes()).hexdigest() == str(g["input_sha256"])
+    got, scans = _gpu_lines(luma, states, **kw)
+    assert _same_but_line_number(got, seq), _diff(got, seq, scans, scans)
+    rows, at = pf.data_rows(len(pf.make_case(name)[0]), pf.make_case(name)[1])
+    idx = (at[:, None] + np.arange(3)[None, :]).reshape(-1)
+    assert (scans == g["scans"][idx]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_field_of_lines_three_passes(oracle_lib):
+    """245 lines at once: every pass from scratch (the coordinate search on the first pass of every line), then every pass preset from a
+    decoded neighbour (a tape that plays)."""
+    from sdvpcmdecoder_amd import synth
+    luma, words = synth.pcm16x0_random_lines(245, seed=21, x0=5, x1=713, noise_sigma=4.0, control="random")
+    cold = np.zeros(3 * 245, dtype=pf.STATE_DTYPE); cold["start"], cold["stop"] = -32768, 32767
+    got, scans = _gpu_lines(luma, cold, mode=2)
+    want, wscans = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, cold, mode=2)
+    assert got.tobytes() == want.tobytes() and (scans == wscans).all()
+    assert ((got["flags"] & pf.LF_CRC_VALID) != 0).all() and (got["words"].reshape(245, 3, 4) == words).all()
+    warm = pf.states_from_records(np.concatenate([got[:1], got[:-1]]), mode=2)
+    warm[0] = warm[1]
+    got2, scans2 = _gpu_lines(luma, warm, mode=2)
+    want2, wscans2 = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, warm, mode=2)
+    assert got2.tobytes() == want2.tobytes() and (scans2 == wscans2).all()
+    assert ((got2["flags"] & pf.LF_BY_EXT_TUNE) != 0).sum() >= 3 * 240
