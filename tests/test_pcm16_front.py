@@ -202,10 +202,11 @@ def test_gpu_field_of_lines_three_passes(oracle_lib):
     got, scans = _gpu_lines(luma, cold, mode=2)
     want, wscans = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, cold, mode=2)
     assert got.tobytes() == want.tobytes() and (scans == wscans).all()
-    assert ((got["flags"] & pf.LF_CRC_VALID) != 0).all() and (got["words"].reshape(245, 3, 4) == words).all()
+    # nothing handed on: the first pass searches the coordinates and reads; the line's search has run then, the other passes have nothing to read with
+    assert ((got["flags"][0::3] & pf.LF_CRC_VALID) != 0).all() and (got["words"].reshape(245, 3, 4)[:, 0] == words[:, 0]).all() and (scans == 1).all()
     warm = pf.states_from_records(np.concatenate([got[:1], got[:-1]]), mode=2)
     warm[0] = warm[1]
     got2, scans2 = _gpu_lines(luma, warm, mode=2)
     want2, wscans2 = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, warm, mode=2)
     assert got2.tobytes() == want2.tobytes() and (scans2 == wscans2).all()
-    assert ((got2["flags"] & pf.LF_BY_EXT_TUNE) != 0).sum() >= 3 * 240
+    assert ((got2["flags"] & pf.LF_BY_EXT_TUNE) != 0).sum() >= 3 * 240 and (got2["words"].reshape(245, 3, 4) == words).all()
