@@ -98,12 +98,91 @@ def cpu_baseline(luma_sample, mode):
         t0 = time.perf_counter()
         recs, _ = oracle_binarize(luma_sample, mode=mode)
         dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": kind,
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "host_cores": os.cpu_count(), "kind": kind,
             "sample": f"first {n} frames of the same synthetic batch, {dt:.1f} s of CPU work, single worker thread "
                       f"(the reference runs the path on one thread per stage)"}, recs
 
 
+def cpu_worker(sample_path, mode, ready_path, go_path):
+    """One worker of the all-core CPU baseline (a fresh process, no torch, no GPU): the real reference's VideoToDigital worker (or the
+    oracle port) over the frames in `sample_path`, started when `go_path` appears.  Prints one JSON line."""
+    import numpy as np
+    import libs
+    luma = np.load(sample_path, mmap_mode="r")
+    kind = "port"
+    run = None
+    try:
+        if libs.ref_available():
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+            mg = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mg)
+            libs.load_ref()
+            run = lambda: mg.run_ref(luma, mode)        # noqa: E731
+            kind = "reference"
+    except Exception:
+        run = None
+    if run is None:
+        from oracle_run import oracle_binarize
+        libs.load_oracle()
+        run = lambda: oracle_binarize(np.ascontiguousarray(luma), mode=mode)      # noqa: E731
+    luma = np.ascontiguousarray(luma)                   # every worker its own copy of the pixels, as every core would have its own frames
+    open(ready_path, "w").close()
+    while not os.path.exists(go_path):
+        time.sleep(0.002)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 2)                                 # the reference logs to stderr
+    t0 = time.time()
+    recs, _ = run()
+    t1 = time.time()
+    import hashlib
+    print(json.dumps({"kind": kind, "frames": int(luma.shape[0]), "t0": t0, "t1": t1, "sha": hashlib.sha256(recs.tobytes()).hexdigest()}), flush=True)
+
+
+def cpu_baseline_all_cores(luma_sample, mode):
+    """the CPU path on every core of this host - os.cpu_count() fresh child processes, one reference worker each
+    (the reference itself runs the path on a single thread per stage; this is what a host-side shard over all cores would reach)."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    cores = os.cpu_count() or 1
+    d = tempfile.mkdtemp(prefix="sdv_cpu_")
+    try:
+        sample = os.path.join(d, "sample.npy")
+        np.save(sample, luma_sample)
+        go = os.path.join(d, "go")
+        env = dict(os.environ)
+        env.pop("ROCR_VISIBLE_DEVICES", None)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", sample, str(mode), os.path.join(d, "ready%d" % i), go],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(cores)]
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(d, "ready%d" % i)) for i in range(cores)) < cores and time.time() - t_wait < 180 and all(p.poll() is None for p in procs):
+            time.sleep(0.01)
+        open(go, "w").close()
+        res = []
+        for p_ in procs:
+            out, _ = p_.communicate(timeout=600)
+            lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+            if p_.returncode == 0 and lines:
+                res.append(json.loads(lines[-1]))
+        if not res:
+            return {"error": "no worker finished", "cores": cores}
+        wall = max(r["t1"] for r in res) - min(r["t0"] for r in res)
+        frames = sum(r["frames"] for r in res)
+        return {"value": frames / wall, "unit": "frames/s", "cores": cores, "workers_finished": len(res), "kind": res[0]["kind"],
+                "per_worker_frames_per_s": frames / len(res) / (sum(r["t1"] - r["t0"] for r in res) / len(res)),
+                "all_workers_decoded_the_same_records": len(set(r["sha"] for r in res)) == 1,
+                "sample": f"{len(res)} worker processes (os.cpu_count() = {cores}), each the first {res[0]['frames']} frames of the same synthetic batch, "
+                          f"{wall:.1f} s of wall time from the first start to the last finish"}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -112,6 +191,7 @@ def main():
     ap.add_argument("--mode", type=int, default=2, help="Binarizer mode (2 = NORMAL, the reference default)")
     ap.add_argument("--noise", type=float, default=4.0)
     ap.add_argument("--cpu-frames", type=int, default=3000)
+    ap.add_argument("--cpu-frames-all-cores", type=int, default=600, help="frames per worker of the all-core CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stitch", action="store_true", help="skip the extra stitch-stage measurement")
     args = ap.parse_args()
@@ -259,12 +339,124 @@ def main():
             torch.cuda.synchronize(dev)
             full_ms += (time.perf_counter() - t1) * 1e3
             frame_no += n
+        # frames -> PCMSamplePair through the fused entry (sdv_decode_frames without the audio stage): the path north_star names, on SURVEY 8d's bytes
+        fused_ms = 0.0
+        for _ in range(k_steps):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            eng.decode_frames(2, luma, first_frame_no=frame_no, with_audio=False, stream=stream)
+            torch.cuda.synchronize(dev)
+            fused_ms += (time.perf_counter() - t1) * 1e3
+            frame_no += n
+        e2e_best_ms = min(e2e_ms, fused_ms) / k_steps
+        E2E_BYTES = W * H + H * 32 + 1470 * 8           # 349 920 B luma + 486 x 32 B line records + 1470 x 8 B sample pairs = 377 232 B per NTSC frame
+        end_to_end = {"workload": f"{n}-frame NTSC STC-007 batch resident in HBM, frames -> PCMSamplePair (binarize + stitch + deinterleave + P/Q ECC), continuing tape",
+                      "ms_per_step": e2e_best_ms, "frames_per_s": n / e2e_best_ms * 1e3,
+                      "two_calls_ms_per_step": e2e_ms / k_steps, "fused_entry_ms_per_step": fused_ms / k_steps,
+                      "roofline": {"bound": "hbm", "achieved": n * E2E_BYTES / e2e_best_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": n * E2E_BYTES / e2e_best_ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": E2E_BYTES,
+                                   "note": "wall clock of the whole chain (several kernels and their host round trips), not one kernel's launch time"}}
         stitch = {"frames_to_masked_pcm_ms_per_step": full_ms / k_steps, "frames_to_masked_pcm_frames_per_s": n / (full_ms / k_steps) * 1e3,
                   "stitch_ms_per_step": st_ms / k_steps, "stitch_frames_per_s": n / (st_ms / k_steps) * 1e3,
                   "frames_to_pcm_ms_per_step": e2e_ms / k_steps, "frames_to_pcm_frames_per_s": n / (e2e_ms / k_steps) * 1e3,
                   "sample_pairs_per_step": int(pairs.shape[0]), "rounds_per_step": st_rounds / k_steps, "stitch_device_ms_per_step": st_dev_ms / k_steps,
                   "note": "stitch = frame reassembly + CWD + deinterleave + P/Q ECC to PCMSamplePair (sdv_stitch_frames), wall clock per "
                           "batch incl. its host round trips; not part of `value`"}
+
+    # BASELINE configs[2]: STC-007 PAL 720x576, Deinterleaver + P/Q error correction on - a clean tape, and the tape of SURVEY 8d C3 (every 97th
+    # line of a frame lost, a bit cell inverted on one line in 53: P and Q corrections, BROKEN blocks, seam masking at work)
+    pal = None
+    if not args.no_stitch and world == 1:
+        HP = 576
+        PAL_BYTES = W * HP + HP * 32 + 1764 * 8         # 414 720 + 18 432 + 14 112 = 447 264 B per PAL frame
+        npal = n
+        pal = {"note": "configs[2]: synthetic STC-007 PAL 720x576 frames (294 lines per field, 288 visible) resident in HBM -> sdv_binarize_frames -> sdv_stitch_frames "
+                       "with P, Q and CWD corrections on, continuing tape, wall clock per batch incl. host round trips; roofline on SURVEY 8d's 447 264 B per frame; "
+                       "not part of `value`"}
+        luma_p, _w = synth.stc007_frames_torch(npal, seed=7, device=dev, width=W, height=HP, lines_per_field=294, noise_sigma=args.noise, cyclic=True)
+        nrec_p = npal * (HP + 3)
+        ol_p = torch.empty((nrec_p + 1, 48), dtype=torch.uint8, device=dev)
+        os_p = torch.empty((npal, 32), dtype=torch.uint8, device=dev)
+        sp_p = torch.empty((npal * 1764 + 65536, 12), dtype=torch.uint8, device=dev)
+        sf_p = torch.empty((npal + 64, 64), dtype=torch.uint8, device=dev)
+        for tape_name in ("clean", "lost_lines_and_flipped_cells"):
+            if tape_name != "clean":
+                luma_p[:, 96::97, :] = 16
+                flat = luma_p.view(-1, W)
+                gsel = torch.Generator(device=dev); gsel.manual_seed(53)
+                rows = torch.arange(0, flat.shape[0], 53, device=dev)
+                xs = 12 + (torch.randint(4, 132, rows.shape, generator=gsel, device=dev) * (W - 24)) // 137
+                for dx in range(5):
+                    flat[rows, xs + dx] = (230 - flat[rows, xs + dx].to(torch.int16)).clamp_(0, 255).to(torch.uint8)
+            eng.setBinarizationMode(args.mode)
+            eng.reset_stream(); eng.reset_stitcher()
+            eng.binarize_frames(luma_p, first_frame_no=1, new_file=True, out_lines=ol_p, out_stats=os_p, stream=stream)
+            eng.stitch_frames(ol_p[:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
+            fno = 1 + npal
+            eng.binarize_frames(luma_p, first_frame_no=fno, out_lines=ol_p[1:], out_stats=os_p, stream=stream)
+            eng.stitch_frames(ol_p[1:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
+            fno += npal
+            k_steps = max(1, min(args.steps, 3))
+            b_ms = s_ms = 0.0; b_rounds = s_rounds = b_general = 0
+            for _ in range(k_steps):
+                torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                eng.binarize_frames(luma_p, first_frame_no=fno, out_lines=ol_p[1:], out_stats=os_p, stream=stream)
+                torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                pp_, ff_ = eng.stitch_frames(ol_p[1:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
+                torch.cuda.synchronize(dev); t3 = time.perf_counter()
+                b_ms += (t2 - t1) * 1e3; s_ms += (t3 - t2) * 1e3
+                b_rounds += eng.run_info().rounds; b_general += eng.run_info().frames_general; s_rounds += eng.stitch_info().rounds
+                fno += npal
+            tot = (b_ms + s_ms) / k_steps
+            pr = pp_[:, :].cpu().numpy().reshape(-1).view(np.dtype([("w", "<i2", (2,)), ("fl", "u1", (2,)), ("rate", "<u2"), ("e", "u1"), ("srv", "u1"), ("_p", "<u2")]))
+            pal[tape_name] = {"frames_per_step": npal, "binarize_ms_per_step": b_ms / k_steps, "stitch_ms_per_step": s_ms / k_steps, "ms_per_step": tot,
+                              "frames_per_s": npal / tot * 1e3, "binarize_rounds_per_step": b_rounds / k_steps, "frames_by_full_kernel_per_step": b_general / k_steps,
+                              "stitch_rounds_per_step": s_rounds / k_steps, "sample_pairs_per_step": int(pp_.shape[0]), "sample_rate": int(pr["rate"][len(pr) // 2]),
+                              "samples_valid_share": float(((pr["fl"] & 2) != 0).mean()),
+                              "roofline": {"bound": "hbm", "achieved": npal * PAL_BYTES / tot / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": npal * PAL_BYTES / tot / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": PAL_BYTES}}
+        del luma_p, ol_p, os_p, sp_p, sf_p
+        eng.reset_stream(); eng.reset_stitcher()
+
+    # damaged tapes in the binarize stage (the speculation across frames has to repair what it predicted wrong): 16 lost lines and 16 jumps of
+    # the data window per 10 000 frames - the workloads of tools/dropout_probe.py / tools/jump_probe.py, on the tape `value` was measured on
+    damaged = None
+    if not args.no_stitch and world == 1:
+        damaged = {"note": "sdv_binarize_frames over the benchmark's tape with damage, continuing stream, wall clock per batch; rounds = launches of the frame kernels "
+                           "until every frame was decoded from its predecessor's real state; frames_launched counts re-decodes; frames_by_full_kernel those that "
+                           "needed the kernel with the general path; compare with `value` (clean tape, 1 round); not part of `value`"}
+        per = max(1, n // 625)                          # 16 per 10 000 frames
+        rng_d = np.random.default_rng(16)
+        for kind in ("lost_lines", "window_jumps"):
+            lum = luma.clone()
+            if kind == "lost_lines":
+                for f_ in sorted(rng_d.choice(np.arange(50, n - 50), size=per, replace=False)):
+                    lum[int(f_), int(rng_d.integers(40, 440))] = 16
+            else:
+                at = 0
+                for f_ in sorted(rng_d.choice(np.arange(50, n - 50), size=per, replace=False)):
+                    to = at
+                    while to == at:
+                        to = int(rng_d.integers(-8, 9))
+                    lum[int(f_):] = torch.roll(luma[int(f_):], to, dims=2); at = to
+            eng.setBinarizationMode(args.mode)
+            eng.reset_stream()
+            eng.binarize_frames(luma, first_frame_no=1, new_file=True, out_lines=out_lines, out_stats=out_stats, stream=stream)
+            k_steps = max(1, min(args.steps, 3))
+            d_ms = 0.0; d_kms = 0.0; d_rounds = d_launched = d_general = 0
+            for r_ in range(k_steps):
+                # (the jumps leave the window displaced at the end of the batch: every step starts from the clean tape's state again)
+                eng.binarize_frames(luma, first_frame_no=1 + (2 * r_ + 1) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+                torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                eng.binarize_frames(lum, first_frame_no=1 + (2 * r_ + 2) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+                torch.cuda.synchronize(dev); d_ms += (time.perf_counter() - t1) * 1e3
+                i_ = eng.run_info()
+                d_kms += i_.kernel_ms; d_rounds += i_.rounds; d_launched += i_.frames_launched; d_general += i_.frames_general
+            damaged[kind] = {"events_per_step": per, "frames_per_step": n, "ms_per_step": d_ms / k_steps, "frames_per_s": n / (d_ms / k_steps) * 1e3,
+                             "kernel_ms_per_step": d_kms / k_steps, "rounds_per_step": d_rounds / k_steps, "frames_launched_per_step": d_launched / k_steps,
+                             "frames_by_full_kernel_per_step": d_general / k_steps}
+            del lum
+        eng.reset_stream()
 
     # the other format branch built so far: the PCM-1 back half (PCM1DataStitcher -> PCMSamplePair) over a tape of the same length
     pcm1 = None
@@ -501,6 +693,11 @@ def main():
                 out["host_fed"] = {"error": repr(ex)}
         if stitch is not None:
             out["stitch_stage"] = stitch
+            out["end_to_end"] = end_to_end
+        if pal is not None:
+            out["pal_stage"] = pal
+        if damaged is not None:
+            out["damaged_tape"] = damaged
         if pcm1 is not None:
             out["pcm1_stage"] = pcm1
         if pcm1f is not None:
@@ -556,6 +753,10 @@ def main():
             k = min(len(first_recs), len(cpu_recs))
             cb["bit_exact_vs_gpu_on_overlap"] = bool(first_recs[:k].tobytes() == cpu_recs[:k].tobytes())
             out["cpu_baseline"] = cb
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sample[:min(args.cpu_frames_all_cores, ncpu)], args.mode)
+            except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
+                out["cpu_baseline_all_cores"] = {"error": repr(ex), "cores": os.cpu_count()}
             if stitch is not None:
                 # the stitch stage on the CPU: the oracle port of STC007DataStitcher over the records of the first 1000 frames
                 import libs
