@@ -275,6 +275,76 @@ __device__ inline void bursts_end(Bursts &u)
     if (u.uc > u.um) u.um = u.uc;
     if (u.bc > u.bm) u.bm = u.bc;
 }
+/* The same bookkeeping for up to 64 blocks at once: bit i of V / S / U / B = what bursts_block would see of block i (valid_all && !silent && can /
+ * silent / !can || fixed / broken), n = how many blocks the words hold.  Equivalent to n calls of bursts_block in bit order - the counters carry
+ * from word to word - so a run of blocks is judged with a handful of mask operations instead of one pass through processBlock's bookkeeping per block.
+ * Works on wave-uniform words (the EI sweep: a lane per block, the words are ballots) and on per-lane words (the SI sweep: a lane per padding) alike. */
+struct BurstsW { uint32_t vc, sc, uc, bc, vm, sm, um, bm; };
+__device__ inline uint64_t low_mask64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+__device__ inline uint32_t longest_run64(uint64_t x) { uint32_t n = 0; while (x) { x &= x << 1; n++; } return n; }
+__device__ inline uint64_t runs_ge64(uint64_t w, uint32_t k)        /* the positions where a run of at least k ones (all of it inside the word) ends */
+{
+    if (k == 0) return ~0ull;
+    if (k > 64u) return 0ull;
+    uint64_t res = ~0ull, p = w; uint32_t len = 0, plen = 1;
+    while (k) {
+        if (k & 1u) { res &= len ? (p << len) : p; len += plen; }
+        k >>= 1;
+        if (k) { p &= p << plen; plen <<= 1; }
+    }
+    return res;
+}
+/* one of the run counters (silent / unchecked / broken) over a word: c = the run that reaches into the word from below, m = the longest run that has
+ * ended so far; returns the positions at which the run (with what it brought along) is at least k long */
+__device__ inline uint64_t bursts_run_word(uint32_t &c, uint32_t &m, uint64_t w, uint64_t mask_n, uint32_t n, uint32_t k)
+{
+    w &= mask_n;
+    if (w == mask_n) {
+        const uint64_t t = (c + n >= k) ? (mask_n & ~low_mask64(k > c ? k - c - 1u : 0u)) : 0ull;
+        c += n;
+        return t;
+    }
+    const uint64_t zeros = ~w & mask_n;
+    const uint32_t lo = (uint32_t)__ffsll((unsigned long long)zeros) - 1u;          /* ones from bit 0 up */
+    const uint32_t z = 63u - (uint32_t)__clzll((unsigned long long)zeros);          /* the highest zero */
+    uint64_t t = (c + lo >= k) ? (low_mask64(lo) & ~low_mask64(k > c ? k - c - 1u : 0u)) : 0ull;
+    if (c + lo > m) m = c + lo;
+    const uint64_t rest = w & ~low_mask64(lo);
+    const uint32_t inner = longest_run64(rest & low_mask64(z));
+    if (inner > m) m = inner;
+    t |= runs_ge64(rest, k) & mask_n;
+    c = n - 1u - z;
+    return t;
+}
+__device__ inline void bursts_word(BurstsW &u, uint64_t V, uint64_t S, uint64_t U, uint64_t B, uint32_t n, uint32_t max_sil, uint32_t max_unch)
+{
+    if (n == 0) return;
+    const uint64_t mask_n = low_mask64(n);
+    V &= mask_n;
+    /* where the count of valid blocks starts over: a silent run of max_sil, an unchecked run past max_unch, any BROKEN block (MAX_BROKEN = 1) */
+    uint64_t R = bursts_run_word(u.sc, u.sm, S, mask_n, n, max_sil);
+    R |= bursts_run_word(u.uc, u.um, U, mask_n, n, max_unch + 1u);
+    R |= bursts_run_word(u.bc, u.bm, B, mask_n, n, (uint32_t)MAX_BROKEN);
+    /* the valid count is only looked at by a block that is not valid itself - before that block's own resets - and at the very end */
+    if (V == 0) { if (u.vc > u.vm) u.vm = u.vc; if (R) u.vc = 0; return; }
+    uint32_t pos = 0;
+    while (R) {
+        const uint32_t r = (uint32_t)__ffsll((unsigned long long)R) - 1u;
+        const uint64_t seg = low_mask64(r + 1u) & ~low_mask64(pos), nv = ~V & seg;
+        if (nv) { const uint32_t j = 63u - (uint32_t)__clzll((unsigned long long)nv), c = u.vc + (uint32_t)__popcll((unsigned long long)(V & seg & low_mask64(j))); if (c > u.vm) u.vm = c; }
+        u.vc = 0; pos = r + 1u; R &= R - 1ull;
+    }
+    const uint64_t seg = mask_n & ~low_mask64(pos), nv = ~V & seg;
+    if (nv) { const uint32_t j = 63u - (uint32_t)__clzll((unsigned long long)nv), c = u.vc + (uint32_t)__popcll((unsigned long long)(V & seg & low_mask64(j))); if (c > u.vm) u.vm = c; }
+    u.vc += (uint32_t)__popcll((unsigned long long)(V & seg));
+}
+__device__ inline void bursts_end_w(BurstsW &u)
+{
+    if (u.vc > u.vm) u.vm = u.vc;
+    if (u.sc > u.sm) u.sm = u.sc;
+    if (u.uc > u.um) u.um = u.uc;
+    if (u.bc > u.bm) u.bm = u.bc;
+}
 struct Stats { uint16_t valid, silent, unchecked, broken; };        /* FieldStitchStats without its index: the table slot is the index */
 __device__ inline bool stats_less(const Stats &a, uint32_t ia, const Stats &b, uint32_t ib)      /* frametrimset.cpp:312-370 */
 {
@@ -349,12 +419,57 @@ struct FrameArgs16s {
 #define SDV_P16_LDS_SUBS 1536
 #endif
 enum { LDS_SUBS = SDV_P16_LDS_SUBS };       /* a 525-line frame: 1470 sub-lines + service tags; longer segments are read from global memory */
+enum { CLS_WORDS = 10,                      /* SI: block classes over the field positions 0..639 */
+       EI_WORDS = 12,                       /* EI: up to 732 blocks per padding */
+       SLOW_CAP = 64 * EI_WORDS };
 struct AnaLds {
-    Sub lines[LDS_SUBS];
-    uint16_t fidx[2][SUBLINES_PF + 1];      /* record index of every sub-line of the [odd, even] field buffer */
+    Sub lines[LDS_SUBS];                    /* the frame's sub-lines in stream order; behind the field split: the two field buffers, [0..735) odd, [735..1470) even */
+    uint64_t cls[2][4][CLS_WORDS];          /* SI: [order of the block's first word: odd / even][valid, silent, unchecked, broken] one bit per field position the block starts at */
+    uint64_t eim[4][EI_WORDS];              /* EI: the same four questions for the blocks of the padding at hand */
+    uint16_t slow[SLOW_CAP]; uint32_t n_slow;       /* EI: blocks that hold a sub-line the Bit Picker touched: decoded by processBlock itself */
     Stats tab[MAX_PAD_SI][5];               /* SI: per padding, interleave blocks 1..5 */
     int32_t uni[16];
 };
+
+/* What trySIPadding / tryEIPadding ask of a block (forced P-code check, :1203-1215 / :2456-2468) when none of its three sub-lines was touched by the Bit
+ * Picker, in closed form (processBlock :128-708 with force_ecc_check and en_p_code, no picked bits): with all three lines good the block is BROKEN when a
+ * P-code check fails and valid when none does; with one bad line that line is restored from the other two (or, the parity line, left alone) and the block
+ * counts as unchecked; with more it is left as it is, unchecked as well.  Bits: 1 valid, 2 silent, 4 unchecked, 8 broken; 16: picked bits - ask processBlock. */
+enum { CL_V = 1, CL_S = 2, CL_U = 4, CL_B = 8, CL_SLOW = 16 };
+__device__ inline uint32_t classify_block(bool ignore_crc, const Sub &l1, const Sub &l2, const Sub &l3)
+{
+    if ((l1.pickl | l2.pickl | l3.pickl) != 0 || ((l1.fl | l2.fl | l3.fl) & SF_PICKR)) return CL_SLOW;
+    const uint32_t okf = ignore_crc ? (uint32_t)SF_OKIGN : (uint32_t)SF_CRC;
+    const bool ok1 = (l1.fl & okf) != 0, ok2 = (l2.fl & okf) != 0, ok3 = (l3.fl & okf) != 0;
+    const uint32_t a = (uint32_t)(l1.w[0] | l1.w[1] | l1.w[2]), m = (uint32_t)(l2.w[0] | l2.w[1] | l2.w[2]), c = (uint32_t)(l3.w[0] | l3.w[1] | l3.w[2]);
+    const int nb = (ok1 ? 0 : 1) + (ok2 ? 0 : 1) + (ok3 ? 0 : 1);
+    if (nb == 0) {
+        const bool brk = ((l1.w[0] ^ l2.w[0] ^ l3.w[0]) | (l1.w[1] ^ l2.w[1] ^ l3.w[1]) | (l1.w[2] ^ l2.w[2] ^ l3.w[2])) != 0, sil = (a | c) == 0;
+        return (brk ? (uint32_t)(CL_U | CL_B) : (sil ? 0u : (uint32_t)CL_V)) | (sil ? (uint32_t)CL_S : 0u);
+    }
+    /* the audio words as they stand afterwards: a restored word is the XOR of the other two */
+    bool sil;
+    if (nb == 1 && !ok1) sil = (m | c) == 0;
+    else if (nb == 1 && !ok3) sil = (a | m) == 0;
+    else sil = (a | c) == 0;
+    return (uint32_t)CL_U | (sil ? (uint32_t)CL_S : 0u);
+}
+__device__ inline uint32_t classify_slow(const DiCfg &d, const Sub &l1, const Sub &l2, const Sub &l3, bool even_order)
+{
+    Blk b;
+    process_block(d, l1, l2, l3, even_order, b);
+    const bool silent = b_silent(b), can = b_can_force(b);
+    return ((b_valid_all(b) && !silent && can) ? (uint32_t)CL_V : 0u) | (silent ? (uint32_t)CL_S : 0u) | ((!can || b_fixed_any(b)) ? (uint32_t)CL_U : 0u) |
+           (b_broken_any(b) ? (uint32_t)CL_B : 0u);
+}
+/* 35 bits of a bitmap from position q on */
+__device__ inline uint64_t bits_from(const uint64_t *w, uint32_t q)
+{
+    const uint32_t i = q >> 6, sh = q & 63u;
+    uint64_t x = w[i] >> sh;
+    if (sh > 64u - SI_OFS && i + 1 < (uint32_t)CLS_WORDS) x |= w[i + 1] << (64u - sh);
+    return x & ((1ull << SI_OFS) - 1ull);
+}
 
 /* findZeroControlBitOffset (:868-1055) over a field: lane 0 */
 template <typename F>
@@ -491,18 +606,20 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
     __syncthreads();
     const uint32_t top[2] = { (uint32_t)lds.uni[0], (uint32_t)lds.uni[1] }, bottom[2] = { (uint32_t)lds.uni[2], (uint32_t)lds.uni[3] };
     /* 3. splitFrameToFields (:566-750): rank the sub-lines of either field, 735 at most */
+    Sub *const fout = a.fields + (size_t)kb * (2 * SUBLINES_PF);
     uint32_t cnt[2] = { 0, 0 }, valid[2] = { 0, 0 }, refs_all[2] = { 0, 0 }, refs_ok[2] = { 0, 0 };
     const bool even_open = top[1] != bottom[1] || top[1] != 0;
     for (uint32_t c = 0; c < n_scan; c += 64) {
         const uint32_t i = c + (uint32_t)lane;
         bool in[2] = { false, false }; bool ok = false; uint32_t ref = 0;
+        Sub sl = sub_empty();
         if (i < n_scan) {
-            const Sub s = line_at(i);
-            if ((s.fl & SF_MATCH) && !(s.fl & SF_SKIP)) {
-                const uint32_t ln = s.line;
+            sl = line_at(i);
+            if ((sl.fl & SF_MATCH) && !(sl.fl & SF_SKIP)) {
+                const uint32_t ln = sl.line;
                 in[0] = (ln & 1) != 0 && ln >= top[0] && ln <= bottom[0];
                 in[1] = (ln & 1) == 0 && ln >= top[1] && ln <= bottom[1] && even_open;
-                ok = (s.fl & SF_CRC) != 0; ref = s.ref;
+                ok = (sl.fl & SF_CRC) != 0; ref = sl.ref;
             }
         }
 #pragma unroll
@@ -510,7 +627,7 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
             const uint64_t m = __ballot(in[p]);
             const uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
             const bool take = in[p] && rank < SUBLINES_PF;
-            if (take) { lds.fidx[p][rank] = (uint16_t)i; refs_all[p] += ref; if (ok) refs_ok[p] += ref; }
+            if (take) { fout[p * SUBLINES_PF + rank] = sl; refs_all[p] += ref; if (ok) refs_ok[p] += ref; }     /* the field buffers (global: K-B' .. K-E read them) */
             valid[p] += (uint32_t)__popcll(__ballot(take && ok));
             cnt[p] += (uint32_t)__popcll(m);
         }
@@ -524,16 +641,15 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
         ref_level[p] = valid[p] > 0 ? (refs_ok[p] / valid[p]) & 0xFF : (cnt[p] > 0 ? (refs_all[p] / cnt[p]) & 0xFF : 0u);
     }
     __syncthreads();
-    /* 4. prescanForFalsePosCRCs (:753-833): whole video lines whose only valid sub-line is one the Bit Picker completed.  The field
-     * buffers live in global memory for K-C and K-E; with the frame staged in LDS the marks are made there first */
-    Sub *const fout = a.fields + (size_t)kb * (2 * SUBLINES_PF);
-    if (!kLds) {
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-            for (uint32_t c = 0; c < data[p]; c += 64) { const uint32_t u = c + (uint32_t)lane; if (u < data[p]) fout[p * SUBLINES_PF + u] = line_at(lds.fidx[p][u]); }
-        __syncthreads();
+    /* From here on only the field buffers are looked at: they take the place of the staged records in LDS (read back from global memory:
+     * __syncthreads orders the wave's own stores before the loads) */
+    for (uint32_t c = 0; c < 2 * SUBLINES_PF; c += 64) {
+        const uint32_t u = c + (uint32_t)lane;
+        if (u < 2 * SUBLINES_PF) { const uint32_t p = u >= SUBLINES_PF ? 1u : 0u; if (u - p * SUBLINES_PF < data[p]) lds.lines[u] = fout[u]; }
     }
-    auto fld_ref = [&](int p, uint32_t u) -> Sub & { return kLds ? lds.lines[lds.fidx[p][u]] : fout[p * SUBLINES_PF + u]; };
+    __syncthreads();
+    auto fld_ref = [&](int p, uint32_t u) -> Sub & { return lds.lines[p * SUBLINES_PF + u]; };
+    /* 4. prescanForFalsePosCRCs (:753-833): whole video lines whose only valid sub-line is one the Bit Picker completed */
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const uint32_t n_tri = data[p] / 3;
@@ -552,16 +668,13 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
                 const bool c0 = (s0.fl & SF_CRC) != 0, c1 = (s1.fl & SF_CRC) != 0, c2 = (s2.fl & SF_CRC) != 0;
                 if ((c0 && !c1 && !c2 && s0.pickl != 0) || (!c0 && !c1 && c2 && (s2.fl & SF_PICKR))) {
                     s0.fl &= (uint8_t)~SF_CRC; s1.fl &= (uint8_t)~SF_CRC; s2.fl &= (uint8_t)~SF_CRC;
+                    Sub *g = fout + p * SUBLINES_PF + 3 * t;
+                    g[0].fl = s0.fl; g[1].fl = s1.fl; g[2].fl = s2.fl;
                 }
             }
         }
     }
     __syncthreads();
-    if (kLds) {
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-            for (uint32_t c = 0; c < data[p]; c += 64) { const uint32_t u = c + (uint32_t)lane; if (u < data[p]) fout[p * SUBLINES_PF + u] = lds.lines[lds.fidx[p][u]]; }
-    }
     auto field_at = [&](int p, int u) -> Sub { return (u >= 0 && u < (int)data[p]) ? fld_ref(p, (uint32_t)u) : sub_empty(); };
     Ana16 *const out = &a.ana[kb];
     /* 5. the padding tables */
@@ -569,23 +682,36 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
     if (!ei) {
 #pragma unroll 1
         for (int p = 0; p < 2; p++) {
-            /* padding_queue under padding `pad`: pad lines of nothing, the field, nothing up to 735 sub-lines (:1613-1646, :1825-1833) */
+            /* padding_queue under padding `pad`: pad lines of nothing, the field, nothing up to 735 sub-lines (:1613-1646, :1825-1833); the data block
+             * of line li of interleave block iblk starts at field position q = li + 105 iblk - 3 pad - whatever the padding, a block that starts at
+             * q is the sub-lines q, q + 35, q + 70, so every block the sweep looks at (35 paddings x 5 interleave blocks x 35 lines) is one of the
+             * 640 x 2 (the order of its words alternates with li) that are judged here once, a lane each */
+            for (int w = 0; w < CLS_WORDS; w++) {
+                const int q = 64 * w + lane;
+                const Sub l1 = field_at(p, q), l2 = field_at(p, q + SI_OFS), l3 = field_at(p, q + 2 * SI_OFS);
+                uint32_t c0 = classify_block(pad_cfg.ignore_crc, l1, l2, l3), c1 = c0;
+                if (c0 & CL_SLOW) { c0 = classify_slow(pad_cfg, l1, l2, l3, false); c1 = classify_slow(pad_cfg, l1, l2, l3, true); }
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    const uint64_t m0 = __ballot((c0 >> f) & 1u), m1 = __ballot((c1 >> f) & 1u);
+                    if (lane == 0) { lds.cls[0][f][w] = m0; lds.cls[1][f][w] = m1; }
+                }
+            }
+            __syncthreads();
             for (int task0 = 0; task0 < MAX_PAD_SI * 5; task0 += 64) {
                 const int task = task0 + lane;
                 if (task < MAX_PAD_SI * 5) {
                     const int pad = task / 5, iblk = 1 + task % 5;
-                    Bursts u = { 0, 0, 0, 0, 0, 0, 0, 0 };
-                    bool even_block = false;
-                    for (int li = 0; li < SI_OFS; li++) {
-                        const int q = li + iblk * SI_TRUE - 3 * pad;
-                        Blk b;
-                        process_block(pad_cfg, field_at(p, q), field_at(p, q + SI_OFS), field_at(p, q + 2 * SI_OFS), even_block, b);
-                        bursts_block(u, b, MAX_SIL_SI, MAX_UNCH_SI);
-                        even_block = !even_block;
-                    }
-                    bursts_end(u);
-                    Stats s; s.valid = u.vm; s.silent = u.sm; s.unchecked = u.um; s.broken = u.bm;
-                    lds.tab[pad][iblk - 1] = s;
+                    const uint32_t q0 = (uint32_t)(iblk * SI_TRUE - 3 * pad);
+                    const uint64_t ev = 0x5555555555555555ull, od = ~ev;         /* line li of an interleave block: even_order = li odd */
+                    uint64_t m[4];
+#pragma unroll
+                    for (int f = 0; f < 4; f++) m[f] = (bits_from(lds.cls[0][f], q0) & ev) | (bits_from(lds.cls[1][f], q0) & od);
+                    BurstsW u = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                    bursts_word(u, m[0], m[1], m[2], m[3], SI_OFS, MAX_SIL_SI, MAX_UNCH_SI);
+                    bursts_end_w(u);
+                    Stats st; st.valid = (uint16_t)u.vm; st.silent = (uint16_t)u.sm; st.unchecked = (uint16_t)u.um; st.broken = (uint16_t)u.bm;
+                    lds.tab[pad][iblk - 1] = st;
                 }
             }
             __syncthreads();
@@ -604,31 +730,49 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
             }
         }
     } else {
-        /* padding_queue = first field, `pad` lines of nothing, second field (:2708-2765); block i = lines i, i + 490, i + 980 */
+        /* padding_queue = first field, `pad` lines of nothing, second field (:2708-2765); block i = lines i, i + 490, i + 980: a lane per block, 64 blocks
+         * at a time, the four questions as ballots, the burst counters on the ballots */
         const int p1 = cfg.field_order == ORDER_BFF ? 1 : 0, p2 = 1 - p1;
         const int c1 = (int)data[p1], c2 = (int)data[p2];
-        for (int pad0 = 0; pad0 < MAX_PAD_EI; pad0 += 64) {
-            const int pad = pad0 + lane;
-            if (pad < MAX_PAD_EI) {
-                const int size = c1 + 3 * pad + c2;
-                auto q_at = [&](int i) -> Sub { return i < c1 ? field_at(p1, i) : (i < c1 + 3 * pad ? sub_empty() : field_at(p2, i - c1 - 3 * pad)); };
-                Bursts u = { 0, 0, 0, 0, 0, 0, 0, 0 };
-                bool even_block = false, ran = false;
-                if (size >= EI_TRUE)
-                    for (int i = 0; (2 * EI_OFS) + i + 1 < size; i++) {
-                        Blk b;
-                        process_block(pad_cfg, q_at(i), q_at(i + EI_OFS), q_at(i + 2 * EI_OFS), even_block, b);
-                        ran = true;
-                        bursts_block(u, b, MAX_SIL_EI, MAX_UNCH_EI);
-                        even_block = !even_block;
-                    }
-                bursts_end(u);
-                Stats s; s.valid = u.vm; s.silent = u.sm; s.unchecked = u.um; s.broken = u.bm;
-                if (!ran) { s.valid = 0; s.silent = s.unchecked = s.broken = 0xFF; }
-                out->st[pad] = s;
+#pragma unroll 1
+        for (int pad = 0; pad < MAX_PAD_EI; pad++) {
+            const int size = c1 + 3 * pad + c2, n_blk = size >= EI_TRUE ? size - 2 * EI_OFS - 1 : 0;
+            auto q_at = [&](int i) -> Sub { return i < c1 ? field_at(p1, i) : (i < c1 + 3 * pad ? sub_empty() : field_at(p2, i - c1 - 3 * pad)); };
+            uint32_t n_slow = 0;
+            for (int i0 = 0; i0 < n_blk; i0 += 64) {
+                const int i = i0 + lane;
+                uint32_t c = 0;
+                if (i < n_blk) c = classify_block(pad_cfg.ignore_crc, q_at(i), q_at(i + EI_OFS), q_at(i + 2 * EI_OFS));
+                const uint64_t sm = __ballot((c & CL_SLOW) != 0);
+                if (c & CL_SLOW) lds.slow[n_slow + (uint32_t)__popcll(sm & lanemask_lt(lane))] = (uint16_t)i;
+                n_slow += (uint32_t)__popcll(sm);
+#pragma unroll
+                for (int f = 0; f < 4; f++) { const uint64_t m = __ballot((c >> f) & 1u); if (lane == 0) lds.eim[f][i0 >> 6] = m; }
             }
+            __syncthreads();
+            for (uint32_t k0 = 0; k0 < n_slow; k0 += 64) {          /* the blocks with picked bits, side by side */
+                const uint32_t k = k0 + (uint32_t)lane;
+                if (k < n_slow) {
+                    const int i = (int)lds.slow[k];
+                    const uint32_t c = classify_slow(pad_cfg, q_at(i), q_at(i + EI_OFS), q_at(i + 2 * EI_OFS), (i & 1) != 0);
+#pragma unroll
+                    for (int f = 0; f < 4; f++) if ((c >> f) & 1u) atomicOr((unsigned long long *)&lds.eim[f][i >> 6], 1ull << (i & 63));
+                }
+            }
+            __syncthreads();
+            BurstsW u = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int i0 = 0; i0 < n_blk; i0 += 64) {
+                const int w = i0 >> 6;
+                bursts_word(u, lds.eim[0][w], lds.eim[1][w], lds.eim[2][w], lds.eim[3][w], (uint32_t)(n_blk - i0 < 64 ? n_blk - i0 : 64), MAX_SIL_EI, MAX_UNCH_EI);
+            }
+            bursts_end_w(u);
+            if (lane == 0) {
+                Stats st; st.valid = (uint16_t)u.vm; st.silent = (uint16_t)u.sm; st.unchecked = (uint16_t)u.um; st.broken = (uint16_t)u.bm;
+                if (n_blk <= 0) { st.valid = 0; st.silent = st.unchecked = st.broken = 0xFF; }
+                out->st[pad] = st;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         {
             Stats m; m.valid = m.silent = m.unchecked = m.broken = 0; uint32_t mi = 0; uint16_t mb = 0;
             const bool found = best_padding(out->st, MAX_PAD_EI, lane, m, mi, mb);

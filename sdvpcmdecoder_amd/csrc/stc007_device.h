@@ -114,6 +114,7 @@ struct WaveLds {
     alignas(16) uint8_t px[SDV_PX_BYTES];     /* one staged scanline, or two of up to 1024 bytes side by side (the pair loop) */
     uint32_t hist[256];
     SweepEnt sweep[256];
+    uint8_t park_room[256];                  /* (the whole-frame capture parks the second field's lines over px .. here: five chunks of 64 lines for a 640-line frame) */
     CrcStat crc_stats[MAX_COLL_CRCS + 1];
     uint32_t lv_keys[COORD_HISTORY_DEPTH];   /* last_valid_coord_list as sort keys (videotodigital.cpp:707) */
     uint32_t long_keys[COORD_LONG_HISTORY];  /* long_valid_coords (videotodigital.cpp:710) */
@@ -2232,7 +2233,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             K1_T(t_cap);
             const int n0 = n_field[0], n1 = n_field[1];
             const int n_chunks = (n0 + 63) / 64;
-            uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][5 words][lane], over px + hist + sweep */
+            uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][5 words][lane], over px + hist + sweep + park_room */
+            static_assert(offsetof(WaveLds, crc_stats) >= ((SDV_MAX_HEIGHT / 2 + 63) / 64) * 5 * 64 * sizeof(uint32_t), "the parked lines of a field of SDV_MAX_HEIGHT / 2 lines must fit in front of the histories");
             uint32_t ok1_packed = 0;                            /* lines of field 1 that read, per chunk (7 bits each) */
             const uint32_t rs = (uint32_t)a.row_stride;         /* offsets inside a frame fit 32 bits (checked above) */
             const uint32_t lo = pre.ref_low, hi = pre.ref_high;

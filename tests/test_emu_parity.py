@@ -208,3 +208,27 @@ def test_emu_bad_arguments(emu_lib):
     assert f(eng, buf2.ctypes.data, 200, 1000, 200, 8, 2, 1, 0, recs2.ctypes.data, 22, st2.ctypes.data, 2, None) == -1
     assert b"frame_stride" in emu_lib.sdv_last_error(eng)
     emu_lib.sdv_engine_destroy(eng)
+
+
+@pytest.mark.parametrize("height,lpf", [(576, 294), (640, 320)])
+def test_emu_tall_frames_keep_their_histories(emu_lib, oracle_lib, height, lpf):
+    """PAL-size frames (more than 256 lines per field: five 64-line chunks of parked lines in the whole-frame capture) with a data window
+    that moves half way: the 16-frame coordinate history decides what the frames behind the jump start from - records and frame
+    descriptors equal the oracle's, and a tape that plays is decoded in one round per call."""
+    n = 8
+    luma, _, _ = synth.stc007_frames(n_frames=n, seed=41, height=height, lines_per_field=lpf, noise_sigma=3.0)
+    moved, _, _ = synth.stc007_frames(n_frames=n, seed=41, height=height, lines_per_field=lpf, noise_sigma=3.0, x0=17, x1=713)
+    tape = np.concatenate([luma[:5], moved[5:], luma[:4]])
+    want, want_stats = oracle_binarize(tape, mode=2)
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    emu_lib.sdv_set_mode(eng, 2)
+    got, got_stats, info = emu_run(emu_lib, tape, 2, eng=eng)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    # a tape that plays, continued: every frame is predicted right
+    steady, _, _ = synth.stc007_frames(n_frames=6, seed=42, height=height, lines_per_field=lpf, noise_sigma=3.0)
+    emu_lib.sdv_reset_stream(eng)
+    emu_run(emu_lib, steady, 2, eng=eng)
+    _, _, info = emu_run(emu_lib, steady, 2, flags=0, first=7, eng=eng)
+    emu_lib.sdv_engine_destroy(eng)
+    assert info.rounds == 1 and info.frames_general == 0
