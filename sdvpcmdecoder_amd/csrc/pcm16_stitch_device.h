@@ -420,14 +420,19 @@ struct FrameArgs16s {
 #endif
 enum { LDS_SUBS = SDV_P16_LDS_SUBS };       /* a 525-line frame: 1470 sub-lines + service tags; longer segments are read from global memory */
 enum { CLS_WORDS = 10,                      /* SI: block classes over the field positions 0..639 */
-       EI_WORDS = 12,                       /* EI: up to 732 blocks per padding */
-       SLOW_CAP = 64 * EI_WORDS };
+       SLOW_CAP = 512 };
 struct AnaLds {
     Sub lines[LDS_SUBS];                    /* the frame's sub-lines in stream order; behind the field split: the two field buffers, [0..735) odd, [735..1470) even */
-    uint64_t cls[2][4][CLS_WORDS];          /* SI: [order of the block's first word: odd / even][valid, silent, unchecked, broken] one bit per field position the block starts at */
-    uint64_t eim[4][EI_WORDS];              /* EI: the same four questions for the blocks of the padding at hand */
-    uint16_t slow[SLOW_CAP]; uint32_t n_slow;       /* EI: blocks that hold a sub-line the Bit Picker touched: decoded by processBlock itself */
-    Stats tab[MAX_PAD_SI][5];               /* SI: per padding, interleave blocks 1..5 */
+    union {
+        struct {
+            uint64_t cls[2][4][CLS_WORDS];  /* SI: [order of the block's first word: odd / even][valid, silent, unchecked, broken] one bit per field position the block starts at */
+            Stats tab[MAX_PAD_SI][5];       /* SI: per padding, interleave blocks 1..5 */
+        } si;
+        struct {
+            uint64_t m[MAX_PAD_EI][4];      /* EI: the same four questions for 64 consecutive blocks, under every padding */
+            uint32_t slow[SLOW_CAP];        /* EI: (padding << 16 | block) of blocks that hold a sub-line the Bit Picker touched: decoded by processBlock itself */
+        } ei;
+    };
     int32_t uni[16];
 };
 
@@ -471,6 +476,7 @@ __device__ inline uint64_t bits_from(const uint64_t *w, uint32_t q)
     return x & ((1ull << SI_OFS) - 1ull);
 }
 
+__device__ inline uint32_t wave_max_u32(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl((int)v, lane ^ d); v = o > v ? o : v; } return v; }
 /* findZeroControlBitOffset (:868-1055) over a field: lane 0 */
 template <typename F>
 __device__ inline int16_t find_zero_ctrl(F field, uint16_t f_size, bool from_top)
@@ -511,6 +517,33 @@ __device__ inline int16_t find_zero_ctrl(F field, uint16_t f_size, bool from_top
     }
     return best_cnt > 0 ? best_ofs : (int16_t)-1;
 }
+/* the same search with a lane per starting position (the reference tries at most 53 of them, three sub-lines apart, and keeps the first one with the
+ * most cleared Control Bits) */
+template <typename F>
+__device__ inline int16_t find_zero_ctrl_wave(F field, uint16_t f_size, bool from_top, int lane)
+{
+    const int t = lane;
+    int start; bool exists;
+    if (!from_top) { exists = (int)f_size + 1 - 3 * t >= 3; start = (int)f_size + 1 - 3 * (t + 1); }
+    else { exists = 1 + 3 * t < (int)f_size - 3; start = 1 + 3 * (t + 1); }
+    exists = exists && t <= (SI_OFS * 3 / 2);
+    uint32_t zero_cnt = 0;
+    if (exists) {
+        for (int iblk = 0; iblk < IBLK_PF; iblk++) {
+            const int so = from_top ? start + iblk * SI_TRUE : start - iblk * SI_TRUE;
+            if (from_top ? so >= (int)f_size : so < 0) break;
+            const Sub s = field((uint16_t)so);
+            if (sub_part(s) != 1) { zero_cnt = 0; break; }
+            if ((s.fl & SF_CRC) && !(s.fl & SF_CTRL)) zero_cnt++;
+        }
+    }
+    const uint32_t key = exists ? ((zero_cnt << 8) | (uint32_t)(63 - t)) : 0u;
+    const uint32_t best = wave_max_u32(key, lane);
+    if ((best >> 8) == 0) return (int16_t)-1;
+    const int bt = 63 - (int)(best & 0xFF);
+    const int bstart = from_top ? 1 + 3 * (bt + 1) : (int)f_size + 1 - 3 * (bt + 1);
+    return (int16_t)(bstart - 1);
+}
 template <typename F>
 __device__ inline uint8_t estimate_block_number(F field, uint16_t f_size, int16_t zero_ofs)    /* :1058-1126 */
 {
@@ -525,7 +558,6 @@ __device__ inline uint8_t estimate_block_number(F field, uint16_t f_size, int16_
     return out;
 }
 
-__device__ inline uint32_t wave_max_u32(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl((int)v, lane ^ d); v = o > v ? o : v; } return v; }
 __device__ inline uint32_t wave_min_u32(uint32_t v, int lane) { for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl((int)v, lane ^ d); v = o < v ? o : v; } return v; }
 /* the front of std::sort over the paddings that share the fewest BROKEN blocks and checked anything at all (:1869-1896, :2799-2826):
  * tab[0..n) with FieldStitchStats::operator<.  Returns false when there is no such padding. */
@@ -567,8 +599,67 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
     }
     seen = (uint32_t)(__ballot(seen & FF_NEW_FILE) ? FF_NEW_FILE : 0) | (uint32_t)(__ballot(seen & FF_END_FILE) ? FF_END_FILE : 0) | (uint32_t)(__ballot(seen >> 8) ? (FE_FOREIGN << 8) : 0);
     __syncthreads();
-    /* 2. findFrameTrim (:213-563): the reference's walk over the records, lane 0 */
-    if (lane == 0) {
+    /* 2. findFrameTrim (:213-563).  The reference walks the records with a step that depends on what it finds (three sub-lines on from a line that
+     * counted, else one).  On a stream of whole lines - every record either a service line or one of three consecutive sub-lines with parts
+     * 0, 1, 2 - that walk looks at every line's first sub-line and nowhere else does anything, whatever it steps by; then its counts and its
+     * first / last lines are ballots over the records.  Anything else (a sub-line missing or doubled, filler lines) takes the walk itself. */
+    bool whole_lines = kLds;
+    uint32_t good_par[2] = { 0, 0 };
+    if (kLds) {
+        bool bad = false;
+        for (uint32_t c = 0; c < n_scan; c += 64) {
+            const uint32_t i = c + (uint32_t)lane;
+            bool counts = false; uint32_t par = 0;
+            if (i < n_scan) {
+                const Sub s0 = lds.lines[i];
+                if (!(s0.fl & SF_SKIP)) {
+                    const uint32_t part = s0.part;          /* (a filler carries PART_FILLER: not 0, 1 or 2) */
+                    auto plain = [&](uint32_t j, uint32_t want) -> bool { if (j >= n_scan) return false; const Sub t = lds.lines[j]; return !(t.fl & SF_SKIP) && t.part == want; };
+                    if (part == 0) bad = bad || !(plain(i + 1, 1) && plain(i + 2, 2));
+                    else if (part == 1) bad = bad || !(i >= 1 && plain(i - 1, 0) && plain(i + 1, 2));
+                    else if (part == 2) bad = bad || !(i >= 2 && plain(i - 2, 0) && plain(i - 1, 1));
+                    else bad = true;
+                    if (part == 0 && !bad && (s0.fl & SF_MATCH)) {
+                        counts = ((s0.fl | lds.lines[i + 1].fl | lds.lines[i + 2].fl) & SF_CRC) != 0;
+                        par = (s0.line % 2) == 0 ? 1u : 0u;
+                    }
+                }
+            }
+            good_par[0] += 3u * (uint32_t)__popcll(__ballot(counts && par == 0));
+            good_par[1] += 3u * (uint32_t)__popcll(__ballot(counts && par == 1));
+        }
+        whole_lines = __ballot(bad) == 0;
+    }
+    if (whole_lines) {
+        const bool skip_par[2] = { good_par[0] > (uint32_t)MIN_GOOD_SUB, good_par[1] > (uint32_t)MIN_GOOD_SUB };
+        uint32_t first_i[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, last_i[2] = { 0, 0 };      /* record index of the first line that counts; index + 1 of the last one */
+        for (uint32_t c = 0; c < n_scan; c += 64) {
+            const uint32_t i = c + (uint32_t)lane;
+            bool hv = false; uint32_t par = 0;
+            if (i < n_scan) {
+                const Sub s0 = lds.lines[i];
+                if (!(s0.fl & SF_SKIP) && s0.part == 0 && (s0.fl & SF_MATCH)) {
+                    par = (s0.line % 2) == 0 ? 1u : 0u;
+                    const uint8_t any = (uint8_t)(s0.fl | lds.lines[i + 1].fl | lds.lines[i + 2].fl);
+                    hv = (any & (skip_par[par] ? SF_CI : SF_BW)) != 0;
+                }
+            }
+#pragma unroll
+            for (uint32_t p = 0; p < 2; p++) {
+                const uint64_t m = __ballot(hv && par == p);
+                if (m) {
+                    if (first_i[p] == 0xFFFFFFFFu) first_i[p] = c + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                    last_i[p] = c + 64u - (uint32_t)__clzll((unsigned long long)m);
+                }
+            }
+        }
+        if (lane == 0) {
+            for (int p = 0; p < 2; p++) {
+                lds.uni[p] = first_i[p] != 0xFFFFFFFFu ? (int32_t)lds.lines[first_i[p]].line : 0;
+                lds.uni[2 + p] = (first_i[p] != 0xFFFFFFFFu && last_i[p] - 1u > first_i[p]) ? (int32_t)lds.lines[last_i[p] - 1u].line : 0;      /* the line that set the top does not set the bottom */
+            }
+        }
+    } else if (lane == 0) {
         uint32_t i = 0, o_good = 0, e_good = 0;
         bool o_skip = false, e_skip = false, o_top = false, e_top = false;
         uint16_t top[2] = { 0, 0 }, bottom[2] = { 0, 0 };
@@ -694,7 +785,7 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
 #pragma unroll
                 for (int f = 0; f < 4; f++) {
                     const uint64_t m0 = __ballot((c0 >> f) & 1u), m1 = __ballot((c1 >> f) & 1u);
-                    if (lane == 0) { lds.cls[0][f][w] = m0; lds.cls[1][f][w] = m1; }
+                    if (lane == 0) { lds.si.cls[0][f][w] = m0; lds.si.cls[1][f][w] = m1; }
                 }
             }
             __syncthreads();
@@ -706,20 +797,20 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
                     const uint64_t ev = 0x5555555555555555ull, od = ~ev;         /* line li of an interleave block: even_order = li odd */
                     uint64_t m[4];
 #pragma unroll
-                    for (int f = 0; f < 4; f++) m[f] = (bits_from(lds.cls[0][f], q0) & ev) | (bits_from(lds.cls[1][f], q0) & od);
+                    for (int f = 0; f < 4; f++) m[f] = (bits_from(lds.si.cls[0][f], q0) & ev) | (bits_from(lds.si.cls[1][f], q0) & od);
                     BurstsW u = { 0, 0, 0, 0, 0, 0, 0, 0 };
                     bursts_word(u, m[0], m[1], m[2], m[3], SI_OFS, MAX_SIL_SI, MAX_UNCH_SI);
                     bursts_end_w(u);
                     Stats st; st.valid = (uint16_t)u.vm; st.silent = (uint16_t)u.sm; st.unchecked = (uint16_t)u.um; st.broken = (uint16_t)u.bm;
-                    lds.tab[pad][iblk - 1] = st;
+                    lds.si.tab[pad][iblk - 1] = st;
                 }
             }
             __syncthreads();
             if (lane < MAX_PAD_SI) {       /* interleave blocks 1..5 share the worst BROKEN burst; the best of them stands for the padding (:1456-1514) */
                 uint16_t top_broken = 0;
-                for (int i = 0; i < 5; i++) if (lds.tab[lane][i].broken > top_broken) top_broken = lds.tab[lane][i].broken;
-                Stats m = lds.tab[lane][0]; m.broken = top_broken; uint32_t mi = 1;
-                for (int i = 1; i < 5; i++) { Stats c = lds.tab[lane][i]; c.broken = top_broken; if (stats_less(c, (uint32_t)(i + 1), m, mi)) { m = c; mi = (uint32_t)(i + 1); } }
+                for (int i = 0; i < 5; i++) if (lds.si.tab[lane][i].broken > top_broken) top_broken = lds.si.tab[lane][i].broken;
+                Stats m = lds.si.tab[lane][0]; m.broken = top_broken; uint32_t mi = 1;
+                for (int i = 1; i < 5; i++) { Stats c = lds.si.tab[lane][i]; c.broken = top_broken; if (stats_less(c, (uint32_t)(i + 1), m, mi)) { m = c; mi = (uint32_t)(i + 1); } }
                 out->st[MAX_PAD_SI * p + lane] = m;
             }
             __syncthreads();
@@ -730,49 +821,72 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
             }
         }
     } else {
-        /* padding_queue = first field, `pad` lines of nothing, second field (:2708-2765); block i = lines i, i + 490, i + 980: a lane per block, 64 blocks
-         * at a time, the four questions as ballots, the burst counters on the ballots */
+        /* padding_queue = first field, `pad` lines of nothing, second field (:2708-2765); block i = lines i, i + 490, i + 980.  64 consecutive blocks
+         * at a time, a lane per block: under every padding the four questions as ballots (a block's first line, and its second one while that
+         * still lies in the first field, do not depend on the padding: fetched once per 64 blocks); then a lane per padding takes its counters
+         * over the 64 blocks on the ballots. */
         const int p1 = cfg.field_order == ORDER_BFF ? 1 : 0, p2 = 1 - p1;
         const int c1 = (int)data[p1], c2 = (int)data[p2];
-#pragma unroll 1
-        for (int pad = 0; pad < MAX_PAD_EI; pad++) {
-            const int size = c1 + 3 * pad + c2, n_blk = size >= EI_TRUE ? size - 2 * EI_OFS - 1 : 0;
-            auto q_at = [&](int i) -> Sub { return i < c1 ? field_at(p1, i) : (i < c1 + 3 * pad ? sub_empty() : field_at(p2, i - c1 - 3 * pad)); };
+        auto n_blocks_of = [&](int pad) -> int { const int size = c1 + 3 * pad + c2; return size >= EI_TRUE ? size - 2 * EI_OFS - 1 : 0; };
+        auto q_at = [&](int pad, int i) -> Sub { return i < c1 ? field_at(p1, i) : (i < c1 + 3 * pad ? sub_empty() : field_at(p2, i - c1 - 3 * pad)); };
+        const int n_max = n_blocks_of(MAX_PAD_EI - 1);
+        BurstsW u0 = { 0, 0, 0, 0, 0, 0, 0, 0 }, u1 = u0;      /* the counters of padding `lane` and padding `lane + 64` */
+        for (int i0 = 0; i0 < n_max; i0 += 64) {
+            const int i = i0 + lane;
+            const bool fix1 = i < c1, fix2 = i + EI_OFS < c1;
+            const Sub f1 = fix1 ? field_at(p1, i) : sub_empty(), f2 = fix2 ? field_at(p1, i + EI_OFS) : sub_empty();
             uint32_t n_slow = 0;
-            for (int i0 = 0; i0 < n_blk; i0 += 64) {
-                const int i = i0 + lane;
-                uint32_t c = 0;
-                if (i < n_blk) c = classify_block(pad_cfg.ignore_crc, q_at(i), q_at(i + EI_OFS), q_at(i + 2 * EI_OFS));
-                const uint64_t sm = __ballot((c & CL_SLOW) != 0);
-                if (c & CL_SLOW) lds.slow[n_slow + (uint32_t)__popcll(sm & lanemask_lt(lane))] = (uint16_t)i;
-                n_slow += (uint32_t)__popcll(sm);
+            auto flush_slow = [&]() {               /* the blocks with picked bits, side by side */
+                __syncthreads();
+                for (uint32_t k0 = 0; k0 < n_slow; k0 += 64) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    if (k < n_slow) {
+                        const uint32_t e = lds.ei.slow[k]; const int pad = (int)(e >> 16), bi = (int)(e & 0xFFFF);
+                        const uint32_t c = classify_slow(pad_cfg, q_at(pad, bi), q_at(pad, bi + EI_OFS), q_at(pad, bi + 2 * EI_OFS), (bi & 1) != 0);
 #pragma unroll
-                for (int f = 0; f < 4; f++) { const uint64_t m = __ballot((c >> f) & 1u); if (lane == 0) lds.eim[f][i0 >> 6] = m; }
-            }
-            __syncthreads();
-            for (uint32_t k0 = 0; k0 < n_slow; k0 += 64) {          /* the blocks with picked bits, side by side */
-                const uint32_t k = k0 + (uint32_t)lane;
-                if (k < n_slow) {
-                    const int i = (int)lds.slow[k];
-                    const uint32_t c = classify_slow(pad_cfg, q_at(i), q_at(i + EI_OFS), q_at(i + 2 * EI_OFS), (i & 1) != 0);
-#pragma unroll
-                    for (int f = 0; f < 4; f++) if ((c >> f) & 1u) atomicOr((unsigned long long *)&lds.eim[f][i >> 6], 1ull << (i & 63));
+                        for (int f = 0; f < 4; f++) if ((c >> f) & 1u) atomicOr((unsigned long long *)&lds.ei.m[pad][f], 1ull << (bi & 63));
+                    }
                 }
+                __syncthreads();
+                n_slow = 0;
+            };
+#pragma unroll 1
+            for (int pad = 0; pad < MAX_PAD_EI; pad++) {
+                const int nb = n_blocks_of(pad);
+                uint32_t c = 0;
+                if (i < nb) {
+                    const Sub l1 = fix1 ? f1 : q_at(pad, i), l2 = fix2 ? f2 : q_at(pad, i + EI_OFS), l3 = q_at(pad, i + 2 * EI_OFS);
+                    c = classify_block(pad_cfg.ignore_crc, l1, l2, l3);
+                }
+                const uint64_t sm = __ballot((c & CL_SLOW) != 0);
+                if (sm) {
+                    if (n_slow + 64u > (uint32_t)SLOW_CAP) flush_slow();
+                    if (c & CL_SLOW) lds.ei.slow[n_slow + (uint32_t)__popcll(sm & lanemask_lt(lane))] = ((uint32_t)pad << 16) | (uint32_t)i;
+                    n_slow += (uint32_t)__popcll(sm);
+                }
+#pragma unroll
+                for (int f = 0; f < 4; f++) { const uint64_t m = __ballot((c >> f) & 1u); if (lane == 0) lds.ei.m[pad][f] = m; }
             }
-            __syncthreads();
-            BurstsW u = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            for (int i0 = 0; i0 < n_blk; i0 += 64) {
-                const int w = i0 >> 6;
-                bursts_word(u, lds.eim[0][w], lds.eim[1][w], lds.eim[2][w], lds.eim[3][w], (uint32_t)(n_blk - i0 < 64 ? n_blk - i0 : 64), MAX_SIL_EI, MAX_UNCH_EI);
-            }
-            bursts_end_w(u);
-            if (lane == 0) {
-                Stats st; st.valid = (uint16_t)u.vm; st.silent = (uint16_t)u.sm; st.unchecked = (uint16_t)u.um; st.broken = (uint16_t)u.bm;
-                if (n_blk <= 0) { st.valid = 0; st.silent = st.unchecked = st.broken = 0xFF; }
-                out->st[pad] = st;
+            flush_slow();
+            {
+                const int nb0 = n_blocks_of(lane) - i0, nb1 = lane + 64 < MAX_PAD_EI ? n_blocks_of(lane + 64) - i0 : 0;
+                if (nb0 > 0) bursts_word(u0, lds.ei.m[lane][0], lds.ei.m[lane][1], lds.ei.m[lane][2], lds.ei.m[lane][3], (uint32_t)(nb0 < 64 ? nb0 : 64), MAX_SIL_EI, MAX_UNCH_EI);
+                if (nb1 > 0) { const int pd = lane + 64; bursts_word(u1, lds.ei.m[pd][0], lds.ei.m[pd][1], lds.ei.m[pd][2], lds.ei.m[pd][3], (uint32_t)(nb1 < 64 ? nb1 : 64), MAX_SIL_EI, MAX_UNCH_EI); }
             }
             __syncthreads();
         }
+        bursts_end_w(u0); bursts_end_w(u1);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int pad = lane + 64 * half;
+            if (pad < MAX_PAD_EI) {
+                const BurstsW &u = half ? u1 : u0;
+                Stats st; st.valid = (uint16_t)u.vm; st.silent = (uint16_t)u.sm; st.unchecked = (uint16_t)u.um; st.broken = (uint16_t)u.bm;
+                if (n_blocks_of(pad) <= 0) { st.valid = 0; st.silent = st.unchecked = st.broken = 0xFF; }
+                out->st[pad] = st;
+            }
+        }
+        __syncthreads();
         {
             Stats m; m.valid = m.silent = m.unchecked = m.broken = 0; uint32_t mi = 0; uint16_t mb = 0;
             const bool found = best_padding(out->st, MAX_PAD_EI, lane, m, mi, mb);
@@ -804,17 +918,24 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
         }
         if (lane == 0) a.pick[kb] = pk;
     }
-    /* 6. Control Bit offsets, lane 0 */
+    /* 6. Control Bit offsets: the searches a lane per starting position, the rest on lane 0 */
+    int16_t z_top[2], z_bot[2];
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+        auto fld = [&](uint16_t u) -> Sub { return field_at(p, (int)u); };
+        z_top[p] = find_zero_ctrl_wave(fld, (uint16_t)data[p], true, lane);
+        z_bot[p] = find_zero_ctrl_wave(fld, (uint16_t)data[p], false, lane);
+    }
     if (lane == 0) {
         out->frame = frame; out->err = seen >> 8; out->marks = (uint8_t)(seen & 3u);
 #pragma unroll 1
         for (int p = 0; p < 2; p++) {
             auto fld = [&](uint16_t u) -> Sub { return field_at(p, (int)u); };
             const uint16_t cntp = (uint16_t)data[p];
-            int16_t z = find_zero_ctrl(fld, cntp, true);
+            int16_t z = z_top[p];
             if (z >= 0 && (z + 3 + 1) < (int)cntp) { const Sub s = fld((uint16_t)(z + 4)); if ((s.fl & SF_CRC) && !(s.fl & SF_CTRL)) z = (int16_t)(z + 3); }
             out->zero_top[p] = z; out->iblk_top[p] = estimate_block_number(fld, cntp, z);
-            const int16_t zb = find_zero_ctrl(fld, cntp, false);
+            const int16_t zb = z_bot[p];
             out->zero_bot[p] = zb; out->iblk_bot[p] = estimate_block_number(fld, cntp, zb);
             out->top[p] = (uint16_t)top[p]; out->bottom[p] = (uint16_t)bottom[p]; out->data[p] = cntp; out->valid[p] = (uint16_t)valid[p]; out->ref[p] = (uint8_t)ref_level[p];
         }
@@ -1400,7 +1521,24 @@ __device__ inline void flags_body(const FrameArgs16s &a, int lane, FlagLds &lds)
     for (uint32_t c0 = 0; c0 < a.n_batch; c0 += FLAG_CHUNK) {
         const uint32_t nc = a.n_batch - c0 < FLAG_CHUNK ? a.n_batch - c0 : (uint32_t)FLAG_CHUNK;
         __syncthreads();
-        if ((uint32_t)lane < nc) { lds.c[lane] = a.ctrl[c0 + lane]; lds.marks[lane] = a.ana[c0 + lane].marks; }
+        Ctrl16 mine; mine.even_order = 0; mine.emph = mine.code = mine._pad = 0; mine.rate = 0; mine._pad2 = 0;
+        uint32_t my_marks = 0;
+        if ((uint32_t)lane < nc) { mine = a.ctrl[c0 + lane]; my_marks = a.ana[c0 + lane].marks; lds.c[lane] = mine; lds.marks[lane] = (uint8_t)my_marks; }
+        /* A tape that plays: the Control Bits of every frame of the chunk read, no file tag among them.  Then no frame looks at the history - each takes
+         * its own bits (:4716-4721) - and all the history sees is one push per frame: the chunk is decided at once, a lane per frame. */
+        if (__ballot((uint32_t)lane < nc && (!mine.even_order || (my_marks & (FF_NEW_FILE | FF_END_FILE)))) == 0) {
+            const uint32_t entry = ctrl_pack(mine.emph ? 2u : 1u, mine.code ? 2u : 1u, mine.rate == 44100 ? 2u : 1u);
+            if ((uint32_t)lane < nc) { Dec16 &d = a.dec[c0 + lane]; d.srate = mine.rate; d.emph = mine.emph; d.code = mine.code; }
+            /* slot s of the ring takes the push of frame (s - pos) mod 65 */
+            const uint32_t j_lo = (uint32_t)((lane - pos + STATS_DEPTH) % STATS_DEPTH), j_64 = (uint32_t)((64 - pos + STATS_DEPTH) % STATS_DEPTH);
+            const uint32_t e_lo = (uint32_t)__shfl((int)entry, (int)(j_lo < 64u ? j_lo : 0u)), e_64 = (uint32_t)__shfl((int)entry, (int)(j_64 < 64u ? j_64 : 0u));
+            if (j_lo < nc) ring_lo = e_lo;
+            if (j_64 < nc) ring64 = e_64;
+            pos = (int)(((uint32_t)pos + nc) % (uint32_t)STATS_DEPTH);
+            const uint32_t last = nc - 1u;
+            f1_srate = (uint32_t)__shfl((int)(uint32_t)mine.rate, (int)last); f1_emph = (uint32_t)__shfl((int)(uint32_t)mine.emph, (int)last); f1_code = (uint32_t)__shfl((int)(uint32_t)mine.code, (int)last);
+            continue;
+        }
         __syncthreads();
         for (uint32_t j = 0; j < nc; j++) {
             const uint32_t marks = lds.marks[j];
