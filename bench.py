@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--mode", type=int, default=2, help="Binarizer mode (2 = NORMAL, the reference default)")
     ap.add_argument("--noise", type=float, default=4.0)
     ap.add_argument("--cpu-frames", type=int, default=3000)
-    ap.add_argument("--cpu-frames-all-cores", type=int, default=600, help="frames per worker of the all-core CPU baseline")
+    ap.add_argument("--cpu-frames-all-cores", type=int, default=150, help="frames per worker of the all-core CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stitch", action="store_true", help="skip the extra stitch-stage measurement")
     args = ap.parse_args()
@@ -381,6 +381,11 @@ def main():
         sf_p = torch.empty((npal + 64, 64), dtype=torch.uint8, device=dev)
         for tape_name in ("clean", "lost_lines_and_flipped_cells"):
             if tape_name != "clean":
+                # every frame damaged, ~11 lines per frame that read at no reference level: in NORMAL mode each of them costs the reference's full level
+                # sweep (170 levels x 24 marker searches + ladder: 1.3 ms per line on a CPU core) and the speculation needs tens of rounds - a fifth of
+                # the batch keeps the default run within its minutes
+                npal = max(1, n // 5)
+                luma_p = luma_p[:npal]; nrec_p = npal * (HP + 3)
                 luma_p[:, 96::97, :] = 16
                 flat = luma_p.view(-1, W)
                 gsel = torch.Generator(device=dev); gsel.manual_seed(53)
@@ -396,7 +401,7 @@ def main():
             eng.binarize_frames(luma_p, first_frame_no=fno, out_lines=ol_p[1:], out_stats=os_p, stream=stream)
             eng.stitch_frames(ol_p[1:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
             fno += npal
-            k_steps = max(1, min(args.steps, 3))
+            k_steps = max(1, min(args.steps, 3)) if tape_name == "clean" else 1
             b_ms = s_ms = 0.0; b_rounds = s_rounds = b_general = 0
             for _ in range(k_steps):
                 torch.cuda.synchronize(dev); t1 = time.perf_counter()

@@ -123,7 +123,10 @@ struct WaveLds {
 /* ---- launch parameters ---------------------------------------------------------------------- */
 /* the chain after a frame: 0 its successor was started from exactly what it produced, 1 a lean wave gave the frame up,
  * 2 the successor was started from something else */
-enum { VF_OK = 0, VF_ABORTED = 1, VF_BREAK = 2 };
+enum { VF_OK = 0, VF_ABORTED = 1, VF_BREAK = 2,
+       VF_KIND = 0x0F,
+       VF_MOVED = 0x40,             /* the frame leaves the chain with other coordinates / histories than the model makes of what it was started from */
+       VF_RETUNED = 0x80 };         /* ... with other black / white / reference levels */
 struct FrameArgs {
     const uint8_t *luma;            /* frame f, row r at luma + f*frame_stride + r*row_stride */
     size_t frame_stride, row_stride;
@@ -617,19 +620,19 @@ __device__ inline void apply_markers(Line &l, const Markers &m)
  * reference sweep where every lane owns a different reference level). */
 __device__ inline void find_coordinates_serial(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, Line &l)
 {
-    uint8_t best_hyst = 0;
     bool have = false; uint32_t best_key = 0;
     uint8_t carried_ed = l.mark_ed;      /* temp_line keeps mark_ed_stage between iterations when START is missing */
+    Markers best;                        /* the reference searches once more with the level it picked (level 0 when none qualified): the same search, the same result */
     for (uint8_t h = 0; h < 24; h++) {
         Markers m = search_markers(b, ps, lds, l.ref_level, h);
+        if (h == 0) best = m;
         if (m.has_start) carried_ed = m.ed_stage;
         if (m.has_start && carried_ed == MARK_ED_LEN_OK) {
             uint32_t k = coords_key((int16_t)m.st1e, (int16_t)m.ed_start);
-            if (!have || k < best_key) { best_key = k; best_hyst = h; have = true; }   /* ties keep the lower hysteresis */
+            if (!have || k < best_key) { best_key = k; best = m; have = true; }   /* ties keep the lower hysteresis */
         }
     }
-    Markers m = search_markers(b, ps, lds, l.ref_level, best_hyst);
-    apply_markers(l, m);
+    apply_markers(l, best);
 }
 
 /* wave-parallel version: lanes 0..23 each try one hysteresis level */
@@ -1067,19 +1070,21 @@ __device__ inline SweepEnt sweep_one_level(const Bin &b, const sdv_bin_preset &p
     set_source_pixels(t, 0, (uint16_t)(b.line_length - 1));
     t.coords.doubled = b.vl_doubled;
     t.black = low_lvl; t.white = high_lvl; t.ref_level = ref_index;
-    bool read = false;
+    bool read = false, searched = false;
     if (!coords_valid(forced_coords)) {
         if (coords_valid(b.in_coord)) {
             bool skip_bin = false;
             if (ps.en_good_no_marker) {
                 find_coordinates_serial(b, ps, lds, t);
-                if (!has_markers(t)) skip_bin = true;
+                if (!has_markers(t)) skip_bin = true; else searched = true;
             }
             if (skip_bin) { t.coords = b.in_coord; read_pcm_data_serial(b.hyst_lim, b.shift_lim, t, lds); read = true; }
         }
     }
     if (!crc_valid(t)) {
-        if (!coords_valid(forced_coords)) find_coordinates_serial(b, ps, lds, t);
+        /* (a line whose markers were found above is searched again by the reference, with the same pixels and the same level: nothing has touched the line
+         * in between, the search leaves what it left - not repeated) */
+        if (!coords_valid(forced_coords)) { if (!searched) find_coordinates_serial(b, ps, lds, t); }
         else { t.coords = forced_coords; t.coords_set = true; }
         if (t.coords_set) { read_pcm_data_serial(b.hyst_lim, b.shift_lim, t, lds); read = true; }
     }
@@ -1611,6 +1616,39 @@ __device__ inline void v2d_make_uniform(V2D &v)
     v.q_bad_even = (uint16_t)uni(v.q_bad_even); v.q_dup_odd = (uint16_t)uni(v.q_dup_odd); v.q_dup_even = (uint16_t)uni(v.q_dup_even);
 }
 
+/* The model of the chain (engine.inc, chain speculation): the state `m` frames behind s0 when every line of those frames decodes with the inherited
+ * tuning - presets unchanged, the 9-entry window saturated with the one coordinate pair, one entry of it per frame pushed into the 16-frame history. */
+__device__ inline bool pod_coords_valid(int16_t s, int16_t e) { return s != NO_COORD_LEFT && e != NO_COORD_RIGHT && s < e; }
+__device__ inline sdv_v2d_state predict_state(const sdv_v2d_state &s0, int m, bool doubled, uint8_t min_ref_lvl)
+{
+    sdv_v2d_state p = s0;
+    /* What the frames in between will measure: what the last frame measured - the newest entry of the multi-frame history (on a
+     * tape that plays every entry is the same; after a jump of the data window the history is a mix for 16 frames, and a frame
+     * leaves the binarizer tuned to what it saw, not to the median it was started with, videotodigital.cpp:808-821, :1369) */
+    int16_t cs = s0.bin.in_def_start, ce = s0.bin.in_def_stop;
+    if (s0.n_long_valid > 0) { cs = s0.long_valid[s0.n_long_valid - 1].data_start; ce = s0.long_valid[s0.n_long_valid - 1].data_stop; }
+    const bool steady = (s0.bin.in_def_reference >= min_ref_lvl) && pod_coords_valid(cs, ce) && !s0.reset_stats;
+    if (steady) {
+        p.bin.in_def_start = cs; p.bin.in_def_stop = ce; p.bin.in_def_from_doubled = doubled ? 1 : 0;
+        p.n_last_valid = COORD_HISTORY_DEPTH;
+        for (int i = 0; i < COORD_HISTORY_DEPTH; i++) { p.last_valid[i].data_start = cs; p.last_valid[i].data_stop = ce; }
+        const int total = (int)s0.n_long_valid + m;
+        const int keep = total > COORD_LONG_HISTORY ? COORD_LONG_HISTORY : total;
+        const int drop = total - keep;             /* oldest entries that fell out of the window */
+        for (int i = 0; i < COORD_LONG_HISTORY; i++) {
+            const int src = i + drop;
+            if (i >= keep) { p.long_valid[i].data_start = 0; p.long_valid[i].data_stop = 0; }
+            else if (src < (int)s0.n_long_valid) p.long_valid[i] = s0.long_valid[src];
+            else { p.long_valid[i].data_start = cs; p.long_valid[i].data_stop = ce; }
+        }
+        p.n_long_valid = (uint8_t)keep;
+        const uint16_t lm = doubled ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : 0, gm = doubled ? (uint16_t)((1u << keep) - 1u) : 0;
+        p.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); p.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
+        p.long_valid_doubled_mask = gm;
+    }
+    return p;
+}
+
 /* ---- chain state <-> registers ---------------------------------------------------------------- */
 __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state *s, const FrameArgs &a)
 {
@@ -1655,16 +1693,28 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
     }
     o._pad[0] = o._pad[1] = 0;
     *s = o;
-    /* the check of the chain, by the frame itself: was the next frame started from this state? */
+    /* the check of the chain, by the frame itself: was the next frame started from this state?  (and: is it the state the frame itself was started
+     * from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
     const int f = (int)(s - a.states_out);
     uint8_t fl = VF_OK;
+    uint32_t mine[sizeof(sdv_v2d_state) / 4];
+    __builtin_memcpy(mine, &o, sizeof(o));
     if (f + 1 < a.n_total) {
-        uint32_t mine[sizeof(sdv_v2d_state) / 4];
-        __builtin_memcpy(mine, &o, sizeof(o));
         const uint32_t *next = (const uint32_t *)&a.states_in[f + 1];
         bool same = true;
         for (unsigned i = 0; i < sizeof(sdv_v2d_state) / 4; i++) same = same && (mine[i] == next[i]);
         if (!same) fl = VF_BREAK;
+    }
+    {
+        /* ... "what it was started from" as the model sees it: one frame on, with the inherited tuning */
+        const sdv_v2d_state exp = predict_state(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl);
+        uint32_t own[sizeof(sdv_v2d_state) / 4];
+        __builtin_memcpy(own, &exp, sizeof(exp));
+        /* dword 0: in_def_black, in_def_white, in_def_reference (+ a pad byte); dword 2, byte 2: do_ref_lvl_sweep - the rest are coordinates and histories */
+        bool same = true;
+        for (unsigned i = 1; i < sizeof(sdv_v2d_state) / 4; i++) same = same && ((i == 2 ? (mine[i] ^ own[i]) & 0xFF00FFFFu : mine[i] ^ own[i]) == 0);
+        if (!same) fl |= VF_MOVED;
+        if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
     a.flag[f] = fl;
 }
