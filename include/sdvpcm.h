@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define SDV_ABI_VERSION 4   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only);
-                             * 4: sdv_pcm16x0_binarize_lines, sdv_audio_stalled (additions); the calls that used to refuse PCM-16x0 frames of the wrong size and the
+                             * 4: sdv_pcm16x0_binarize_lines, sdv_audio_stalled, sdv_set_frame_flags, sdv_double_width (additions); the calls that used to refuse PCM-16x0 frames of the wrong size and the
                              * AudioProcessor's dead ends now follow the reference; the PCM-16x0 stitch state blob grew by conv_queue's remainder */
 
 /* ---- status codes ---------------------------------------------------------------------------
@@ -288,6 +288,24 @@ int sdv_get_run_info(const sdv_engine *e, sdv_run_info *out);
 int sdv_set_profiling(sdv_engine *e, int on);
 
 /* records emitted per frame: `height` scanlines + 2 END_FIELD + 1 END_FRAME service lines */
+/* Per-frame marks of the caller for the NEXT frame entry call on this engine (sdv_binarize_frames, sdv_pcm1_binarize_frames,
+ * sdv_pcm16x0_binarize_frames, sdv_decode_frames): flags[i] belongs to frame i of that call, the call consumes them (whether it succeeds or not).
+ * SDV_FRAME_EMPTY: the frame was dropped by the video input - VideoInFFMPEG::insertDummyFrame(false, true) (vin_ffmpeg.cpp:367-522) sends its lines as
+ * empty VideoLines, Binarizer::processLine answers each with a silent line of invalid CRC (binarizer.cpp:569-570, :1689-1700) and the worker books them
+ * as lines that did not read; the pixels of such a frame are not looked at.  flags is a HOST array of n bytes (n == 0: no marks). */
+enum { SDV_FRAME_EMPTY = 1 };
+int sdv_set_frame_flags(sdv_engine *e, const uint8_t *flags, size_t n);
+
+/* The 2x width doubling the input plugin applies to narrow sources before the lines reach the Binarizer (FFMPEGWrapper::needsDoubleWidth /
+ * getFinalWidth, ffmpegwrapper.cpp:179-197: widths between MIN_DBL_WIDTH 10 and MAX_DBL_WIDTH 959), as an integer pixel replication on the device:
+ * dst[r][2 x] = dst[r][2 x + 1] = src[r][x] for `rows` rows of `width` pixels (row strides in bytes; dst rows are 2 * width pixels).  The frames it
+ * makes go to the frame entries with SDV_FLAG_DOUBLED.  NOT the reference's pixels: the reference lets libswscale resize with SWS_GAUSS
+ * (ffmpegwrapper.cpp:236-241), which is outside the rebuilt path and not reproducible without that library (parity unpinned there);
+ * this is the integer doubler SURVEY section 8f-3 names.  sdv_needs_double_width is the reference's rule for when to apply it.
+ * Device pointers; asynchronous on `stream`; src and dst must not overlap. */
+int sdv_needs_double_width(int width);
+int sdv_double_width(sdv_engine *e, const uint8_t *src, size_t src_row_stride, int width, size_t rows, uint8_t *dst, size_t dst_row_stride, void *stream);
+
 size_t sdv_records_per_frame(int height);
 /* records one sdv_binarize_frames call emits: n_frames * (height + 3), + 1 with SDV_FLAG_NEW_FILE, + height + 4 with SDV_FLAG_END_FILE */
 size_t sdv_binarize_records(int height, int n_frames, unsigned flags);

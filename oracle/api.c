@@ -239,6 +239,16 @@ void orc_v2d_set_preset(void *vv, const sdv_bin_preset *p)
     orc_v2d_set_fine_settings((orc_v2d *)vv, &s);
 }
 
+/* dropped frames of the next *_run call: mask[f] != 0 = frame f of that call is a frame of empty lines (consumed by the call) */
+int orc_g_empty_frame = 0;
+static uint8_t *g_empty_mask = NULL; static size_t g_empty_n = 0;
+void orc_set_empty_frames(const uint8_t *mask, size_t n)
+{
+    free(g_empty_mask); g_empty_mask = NULL; g_empty_n = 0;
+    if (mask && n) { g_empty_mask = (uint8_t *)malloc(n); memcpy(g_empty_mask, mask, n); g_empty_n = n; }
+}
+static int empty_frame_at(int f) { return (size_t)f < g_empty_n && g_empty_mask[f] != 0; }
+
 /* Runs n_frames consecutive frames (frame numbers first_frame_no..). Records: per frame height+3
  * (+1 NEW_FILE before the first frame when new_file). Returns total records written. */
 long orc_v2d_run(void *vv, const uint8_t *luma, size_t stride, int width, int height, int n_frames, uint32_t first_frame_no,
@@ -248,10 +258,12 @@ long orc_v2d_run(void *vv, const uint8_t *luma, size_t stride, int width, int he
     long n = 0;
     for (int f = 0; f < n_frames; f++) {
         orc_frame_stats q;
+        orc_g_empty_frame = empty_frame_at(f);
         n += orc_v2d_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
                            (new_file & 1) && f == 0, doubled != 0, out + n, &q);
         if (stats) stats_to_pod(&q, &stats[f]);
     }
+    orc_g_empty_frame = 0; orc_set_empty_frames(NULL, 0);
     if (new_file & 2) {     /* bit 1: the file ends here (out needs height + 4 more records, stats one more row) */
         orc_frame_stats q;
         n += orc_v2d_end_file_frame(v, height, first_frame_no + (uint32_t)n_frames, out + n, &q);
@@ -315,10 +327,12 @@ long orc_v2d1_run(void *vv, const uint8_t *luma, size_t stride, int width, int h
     long n = 0;
     for (int f = 0; f < n_frames; f++) {
         orc_frame_stats q;
+        orc_g_empty_frame = empty_frame_at(f);
         n += orc_v2d1_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
                             (new_file & 1) && f == 0, doubled != 0, false, out + n, &q);
         if (stats) stats_to_pod(&q, &stats[f]);
     }
+    orc_g_empty_frame = 0; orc_set_empty_frames(NULL, 0);
     if (new_file & 2) {
         orc_frame_stats q;
         n += orc_v2d1_frame(v, NULL, 0, width, height, first_frame_no + (uint32_t)n_frames, false, false, true, out + n, &q);
@@ -353,10 +367,12 @@ long orc_v2d16_run(void *vv, const uint8_t *luma, size_t stride, int width, int 
     long n = 0;
     for (int f = 0; f < n_frames; f++) {
         orc_frame_stats q;
+        orc_g_empty_frame = empty_frame_at(f);
         n += orc_v2d16_frame(v, luma + (size_t)f * stride * (size_t)height, stride, width, height, first_frame_no + (uint32_t)f,
                              (new_file & 1) && f == 0, doubled != 0, false, out + n, &q);
         if (stats) stats_to_pod(&q, &stats[f]);
     }
+    orc_g_empty_frame = 0; orc_set_empty_frames(NULL, 0);
     if (new_file & 2) {
         orc_frame_stats q;
         n += orc_v2d16_frame(v, NULL, 0, width, height, first_frame_no + (uint32_t)n_frames, false, false, true, out + n, &q);

@@ -223,6 +223,11 @@ static void push_service(std::deque<VideoLine> &q, int kind, uint32_t frame, uin
 
 } /* extern "C" */
 
+/* dropped frames of the next *_run call: mask[f] != 0 = frame f of that call arrives as VideoInFFMPEG::insertDummyFrame(false, true) makes it
+ * (vin_ffmpeg.cpp:367-522): lines without a service tag, of the length of a line, marked empty.  Consumed by the call. */
+static std::vector<uint8_t> g_empty_frames;
+extern "C" void ref_set_empty_frames(const uint8_t *mask, size_t n) { g_empty_frames.assign(mask, mask + (mask ? n : 0)); }
+
 /* Feeds n_frames frames in VideoInFFMPEG::spliceFrame order (vin_ffmpeg.cpp:213-364) through the REAL
  * VideoToDigital worker loop and collects its STC007Line output and FrameBinDescriptor emissions. */
 template <class LineT, class RecT>
@@ -274,7 +279,8 @@ static long v2d_run_t(RefV2DT<LineT> *r, const uint8_t *luma, size_t stride, int
                     VideoLine v;
                     v.frame_number = fno; v.line_number = line_num;
                     v.setDoubleWidth(doubled != 0);
-                    v.pixel_data.assign(fr + (size_t)line_offset * stride, fr + (size_t)line_offset * stride + width);
+                    if ((size_t)fed < g_empty_frames.size() && g_empty_frames[(size_t)fed]) { v.setServNo(); v.setLength((uint16_t)width); v.setEmpty(true); }     /* dummy_line of a dropped frame */
+                    else v.pixel_data.assign(fr + (size_t)line_offset * stride, fr + (size_t)line_offset * stride + width);
                     tmp.push_back(v);
                     if (line_offset < (height - 2)) line_offset += 2;
                     else { line_num += 2; break; }
@@ -299,6 +305,7 @@ static long v2d_run_t(RefV2DT<LineT> *r, const uint8_t *luma, size_t stride, int
         r->stats_mtx.unlock();
         if (got < expect || nstats < n_frames) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
+    g_empty_frames.clear();
     return got;
 }
 

@@ -173,4 +173,9 @@ uint8_t orc_binarizer_process_line(orc_binarizer *b);
 #ifdef __cplusplus
 }
 #endif
+/* A dropped frame (VideoInFFMPEG::insertDummyFrame(false, true), vin_ffmpeg.cpp:367-522): the frame's lines arrive as VideoLines marked empty
+ * (no service tag, the length of a line, no pixels looked at).  Set by the *_run loops for the frame they are about to feed (orc_set_empty_frames). */
+extern int orc_g_empty_frame;
+void orc_set_empty_frames(const uint8_t *mask, size_t n);
+
 #endif

@@ -268,6 +268,7 @@ int orc_v2d_frame(orc_v2d *v, const uint8_t *luma, size_t stride, int width, int
         for (;;) {
             vl.line_number = line_num; vl.service_type = ORC_SRV_NO; vl.empty = false; vl.doubled = doubled;
             vl.pixels = luma + (size_t)line_offset * stride; vl.length = (uint16_t)width;
+            if (orc_g_empty_frame) { vl.empty = true; vl.pixels = NULL; vl.length = 0; }       /* a dropped frame: dummy_line.setLength(); setDoubleWidth(); setEmpty(true) (vin_ffmpeg.cpp:372-374, :428) */
             orc_v2d_line(v, &vl, &out[n++], out_stats);
             if (line_offset < (height - 2)) line_offset += 2;
             else { line_num = (uint16_t)(line_num + 2); break; }

@@ -300,7 +300,8 @@ static int build_frame_buf(orc_video_line *buf, const uint8_t *luma, size_t stri
         for (;;) {
             vl.line_number = line_num;
             if (filler) { vl.service_type = ORC_SRV_FILLER; vl.empty = true; vl.doubled = false; vl.pixels = NULL; vl.length = 0; }
-            else { vl.service_type = ORC_SRV_NO; vl.empty = false; vl.doubled = doubled; vl.pixels = luma + (size_t)line_offset * stride; vl.length = (uint16_t)width; }
+            else { vl.service_type = ORC_SRV_NO; vl.empty = false; vl.doubled = doubled; vl.pixels = luma + (size_t)line_offset * stride; vl.length = (uint16_t)width;
+                   if (orc_g_empty_frame) { vl.empty = true; vl.pixels = NULL; vl.length = 0; } }      /* a dropped frame (vin_ffmpeg.cpp:372-374, :428) */
             buf[n++] = vl;
             if (line_offset < (height - 2)) line_offset += 2;
             else { line_num = (uint16_t)(line_num + 2); break; }

@@ -535,6 +535,7 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     uint16_t line_num = 0;
     Lean16 lean; lean16_reset(lean);
+    const bool empty_frame = frame_is_empty(a, f);
 #if SDV_P16_STAMPS && !defined(SDV_EMU)
     unsigned long long p16_stamp[4] = { 0, 0, 0, 0 };
 #endif
@@ -561,6 +562,17 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
             }
 #endif
             const int row = 2 * idx + field;
+            if (empty_frame) {                      /* a dropped frame: three passes over an empty VideoLine, each a cleared sub-line (binarizer.cpp:1689-1700) */
+                bool scan_done_e = false, force_bad_e = false;
+                for (int sub = 0; sub < P16_SUBLINES; sub++) {
+                    p16_clear(wl); wl.line_part = (uint8_t)sub;
+                    const uint16_t ql = v.q_line_length;
+                    post_part16(w, a, lds, wl, fv_keys, fi_keys, (line_num % 2) == 0, force_bad_e, scan_done_e);
+                    v.q_line_length = ql;
+                    emit_rec(wl, frame_no, line_num, false, rec++);
+                }
+                continue;
+            }
             P16_T(t_a);
             sdvp1b::stage_row(lds.p.w.px, frame + (size_t)row * a.row_stride, a.width);
             P16_T(t_b); P16_ADD(0, t_a, t_b);

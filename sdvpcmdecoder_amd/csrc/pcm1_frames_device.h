@@ -54,6 +54,7 @@ __device__ __forceinline__ bool prescan_runs(const FrameArgs &a, int f)
 __device__ inline int frame_buf_row(const FrameArgs &a, int f, int i)
 {
     if (f == a.end_file_frame) return -1;                   /* FILLER lines carry no pixels */
+    if (frame_is_empty(a, f)) return -1;                    /* nor do the lines of a dropped frame */
     if (f == a.new_file_frame) { if (i == 0) return -1; i--; }
     const int n0 = (a.height + 1) / 2, n1 = a.height / 2;
     if (i < n0) return 2 * i;
@@ -520,6 +521,7 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
     const bool doubled = a.doubled != 0;
 
     v2d1_begin_frame(w, a1, lds.w, f);
+    const bool empty_frame = frame_is_empty(a, f);
     Lean1 lean; lean1_reset(lean);
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     uint16_t line_num = 0;
@@ -530,6 +532,14 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
             line_num = (uint16_t)(field + 1 + 2 * idx);
             if (f == a.end_file_frame) {            /* VideoInFFMPEG::insertDummyFrame(true, false): FILLER lines (vin_ffmpeg.cpp:367-523) */
                 v2d1_service_line(w, a, wl, SDV_SRV_FILLER);
+                emit_rec(wl, frame_no, line_num, false, rec++);
+                continue;
+            }
+            if (empty_frame) {                      /* a dropped frame: an empty VideoLine comes back as a cleared line (binarizer.cpp:1689-1700), its length counts as 0 */
+                p1_clear(wl);
+                const uint16_t ql = v.q_line_length;
+                v2d1_post_line(w, a, lds.w, wl, fv_keys, fi_keys, (line_num % 2) == 0);
+                v.q_line_length = ql;
                 emit_rec(wl, frame_no, line_num, false, rec++);
                 continue;
             }

@@ -145,7 +145,10 @@ struct FrameArgs {
     sdv_line_rec *recs;             /* frame f: recs + f*(height+3) (+1 for every frame after new_file_frame...) */
     sdv_frame_stats *stats;         /* [n frames] */
     uint32_t *scratch;              /* per frame 2*height u32 (frame_valid / frame_invalid coordinate keys) */
+    const uint8_t *frame_flags;     /* [n frames] SDV_FRAME_* of the caller (sdv_set_frame_flags), or NULL */
 };
+/* a dropped frame: VideoInFFMPEG::insertDummyFrame(false, true) sends its lines as empty VideoLines (vin_ffmpeg.cpp:367-522) */
+__device__ __forceinline__ bool frame_is_empty(const FrameArgs &a, int f) { return a.frame_flags && f < a.n_total && f != a.end_file_frame && (a.frame_flags[f] & SDV_FRAME_EMPTY); }
 
 /* ---- uniform per-wave state (kept in registers; identical in all lanes) ---------------------- */
 struct Coords { int16_t start, stop; bool doubled; };
@@ -2201,6 +2204,20 @@ __device__ __attribute__((noinline)) void slow_line(SlowCtx *c, WaveLds *lds, ui
     emit_record(c->wl, rec);
 }
 
+/* A line of a dropped frame: Binarizer::processLine answers an empty VideoLine with a cleared line - silent words, CRC invalid
+ * (binarizer.cpp:569-570, :1689-1700) - and the worker books it like any line that did not read (the line's length counts as 0:
+ * VideoLine::setEmpty drops the pixels, videoline.cpp:71-75). */
+__device__ __attribute__((noinline)) void empty_line(SlowCtx *c, WaveLds *lds, uint32_t frame_no, uint16_t line_num,
+                                                     uint32_t *fv_keys, uint32_t *fi_keys, sdv_line_rec *rec)
+{
+    stc_clear(c->wl);
+    c->wl.frame_number = frame_no; c->wl.line_number = line_num;
+    const uint16_t ql = c->v.q_line_length;
+    v2d_post_line(c->v, c->a, *lds, c->wl, fv_keys, fi_keys, (line_num % 2) == 0);
+    c->v.q_line_length = ql;
+    emit_record(c->wl, rec);
+}
+
 /* kLean: the build of the frame loop without the general path.  The general path (reference sweep, marker searches at 24
  * hysteresis levels) is rare on a tape that plays, but as a callee its registers count for the whole kernel and hold the
  * occupancy at 3 waves per SIMD; without it the loop fits 5.  A lean wave that meets a line it cannot take through the fast
@@ -2235,6 +2252,35 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     const int lane = lane_id();
 
     v2d_begin_frame(v, a, lds);
+    if (frame_is_empty(a, f)) {
+        if (kLean) {            /* to the full kernel: the bookkeeping of lines that do not read lives there */
+            if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
+            return;
+        } else {
+            uint16_t ln = 0;
+            if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
+            for (int field = 0; field < 2; field++) {
+                const int nl = field == 0 ? (a.height + 1) / 2 : a.height / 2;
+                for (int i = 0; i < nl; i++) {
+                    ln = (uint16_t)(field + 1 + 2 * i);
+                    SlowCtx c;
+                    c.a = a; c.v = v;
+                    empty_line(&c, &lds, frame_no, ln, fv_keys, fi_keys, rec++);
+                    v = c.v;
+                    v2d_make_uniform(v);
+                }
+                ln = (uint16_t)(ln + 2);
+                v2d_service_line(v, a, lds, wl, frame_no, ln, SDV_SRV_END_FIELD);
+                emit_record(wl, rec++);
+            }
+            ln = (uint16_t)(ln + 2);
+            v2d_service_line(v, a, lds, wl, frame_no, ln, SDV_SRV_END_FRAME);
+            v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f]);
+            emit_record(wl, rec++);
+            v2d_store_state(v, lds, &a.states_out[f], a);
+            return;
+        }
+    }
     if (f == a.end_file_frame) {
         /* VideoInFFMPEG::insertDummyFrame(true, false) (vin_ffmpeg.cpp:367-523) through the worker: FILLER lines in field order,
          * END_FIELD after each field, END_FILE, END_FRAME */

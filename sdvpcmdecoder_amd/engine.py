@@ -34,6 +34,7 @@ PCM_PCM1, PCM_PCM16X0, PCM_STC007 = 0, 1, 2
 TYPE_M2 = 3                      # VideoToDigital::TYPE_M2 (videotodigital.h:77)
 MODE_DRAFT, MODE_FAST, MODE_NORMAL, MODE_INSANE = 0, 1, 2, 3
 FLAG_NEW_FILE, FLAG_DOUBLED, FLAG_END_FILE = 1, 2, 4
+FRAME_EMPTY = 1                 # sdv_set_frame_flags: SDV_FRAME_EMPTY
 
 
 class BinPreset(C.Structure):
@@ -126,6 +127,9 @@ def load_library(path: str | None = None):
     lib.sdv_set_check_line_dup.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_set_pcm_type.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.sdv_reset_stream.argtypes = [C.c_void_p]
+    lib.sdv_set_frame_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_needs_double_width.argtypes = [C.c_int]
+    lib.sdv_double_width.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
     lib.sdv_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -270,6 +274,27 @@ class Engine:
 
     def reset_stream(self):
         self._check(self.lib.sdv_reset_stream(self._h))
+
+    def set_frame_flags(self, flags):
+        """Per-frame marks for the next frame entry call (binarize_frames / pcm1_binarize_frames / pcm16x0_binarize_frames / decode_frames):
+        flags[i] & FRAME_EMPTY = frame i of that call was dropped by the video input (VideoInFFMPEG::insertDummyFrame(false, true))."""
+        import numpy as np
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(self.lib.sdv_set_frame_flags(self._h, fl.ctypes.data if len(fl) else None, len(fl)))
+
+    def needs_double_width(self, width: int) -> bool:
+        return bool(self.lib.sdv_needs_double_width(width))
+
+    def double_width(self, luma, stream=None):
+        """The integer 2x width doubler (sdv_double_width): luma (..., width) uint8 CUDA tensor with contiguous rows -> (..., 2 * width)."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.stride(-1) == 1 and luma.is_contiguous()
+        w = luma.shape[-1]
+        rows = luma.numel() // w
+        out = torch.empty(luma.shape[:-1] + (2 * w,), dtype=torch.uint8, device=luma.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        self._check(self.lib.sdv_double_width(self._h, C.c_void_p(luma.data_ptr()), w, w, rows, C.c_void_p(out.data_ptr()), 2 * w, sptr))
+        return out
 
     # ---- stream state as bytes (checkpoints, hand-over between the GPUs of a sharded stream) ----
     def get_chain_state(self) -> bytes:
