@@ -1,0 +1,273 @@
+/*
+ * decode_tape_sharded.cpp - one STC-007 tape decoded by several GPUs of a node from plain C++ host code: one process per GPU, contiguous frame
+ * ranges per rank, the luma never leaves its GPU, and the only thing that crosses between the ranks is what the reference's two workers carry from
+ * frame to frame, all-gathered with RCCL (ncclAllGather over xGMI):
+ *     VideoToDigital        sdv_v2d_state, 120 bytes                              (sdv_get_chain_state / sdv_set_chain_state)
+ *     STC007DataStitcher    previous descriptor, statistics rings and the 112 assembled lines of conv_queue - the field seam -, 3.8 KB
+ *                           (sdv_get_stitch_state / sdv_set_stitch_state)
+ * The gathered states are used to VERIFY a guess, the same speculation the engine runs inside a batch, one level up (DESIGN.md section 7;
+ * the Python harness of the same loop: sdvpcmdecoder_amd/sharded.py):
+ *   1. rank r > 0 decodes a short warm-up just before its range from a reset engine and keeps the state it ends in - its prediction of what rank
+ *      r - 1 will hand over;
+ *   2. every rank decodes its range from that state, then all ranks all-gather their final states;
+ *   3. a rank whose prediction differs from what its predecessor really ended in decodes its range again from the true state; repeated until every
+ *      rank started from exactly its predecessor's final state.  The result is the sequential decode of the whole tape, whatever the guesses were.
+ *
+ *   RANK=r WORLD_SIZE=n [LOCAL_RANK=d] decode_tape_sharded <luma.raw> <width> <height> <n_frames> <out prefix> [rccl | file:<dir>] [warm-up frames [stitcher warm-up turns]]
+ *       writes <out prefix>.rank<r>.pairs / .frames: the PCMSamplePair records and FrameAsmSTC007 descriptors of this rank's frames; concatenated in
+ *       rank order they are what `decode_tape stc007` writes for the same file.
+ *   Collective back ends: `rccl` (default; rank 0 publishes the ncclUniqueId in <out prefix>.ncclid) and `file:<dir>` (the all-gather through files
+ *   of a shared directory: for debugging and for the CPU test of this loop, which links the test-only emulator build of the engine and has no RCCL).
+ *
+ * Build: build.py build_example_sharded (g++, -lsdvpcm_hip -lamdhip64 -lrccl); the CPU test build: -DSDV_EXAMPLE_HOST_MEMORY against
+ * tests/emu/libsdvpcm_emu.so (the same C-ABI on host pointers).
+ */
+#ifndef SDV_EXAMPLE_HOST_MEMORY
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "sdvpcm.h"
+
+/* ---- buffers: device memory (product) or host memory (the emulator build of the CPU test) ------------------------------------------------ */
+#ifndef SDV_EXAMPLE_HOST_MEMORY
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+static void *dev_alloc(size_t n) { void *p = NULL; HIP_OK(hipMalloc(&p, n ? n : 1)); return p; }
+static void dev_free(void *p) { if (p) (void)hipFree(p); }
+static void h2d(void *d, const void *h, size_t n) { if (n) HIP_OK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }
+static void d2h(void *h, const void *d, size_t n) { if (n) HIP_OK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }
+static void d2d(void *d, const void *s, size_t n) { if (n) HIP_OK(hipMemcpy(d, s, n, hipMemcpyDeviceToDevice)); }
+static void dev_sync() { HIP_OK(hipDeviceSynchronize()); }
+#else
+static void *dev_alloc(size_t n) { return malloc(n ? n : 1); }
+static void dev_free(void *p) { free(p); }
+static void h2d(void *d, const void *h, size_t n) { memcpy(d, h, n); }
+static void d2h(void *h, const void *d, size_t n) { memcpy(h, d, n); }
+static void d2d(void *d, const void *s, size_t n) { memcpy(d, s, n); }
+static void dev_sync() {}
+#endif
+#define SDV_OKAY(x) do { int r_ = (x); if (r_ != SDV_OK) { fprintf(stderr, "rank %d: %s = %d: %s\n", g_rank, #x, r_, sdv_last_error(eng)); exit(3); } } while (0)
+static int g_rank = 0;
+
+/* ---- the collective: every rank contributes `bytes`, every rank receives all contributions in rank order ----------------------------------- */
+struct Comm {
+    int rank, world;
+    virtual ~Comm() {}
+    virtual void all_gather(const void *send, void *recv, size_t bytes) = 0;
+};
+#ifndef SDV_EXAMPLE_HOST_MEMORY
+#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); exit(4); } } while (0)
+struct RcclComm : Comm {
+    ncclComm_t comm; hipStream_t stream; uint8_t *d_send, *d_recv; size_t cap;
+    RcclComm(int r, int w, const std::string &id_file) : comm(NULL), stream(NULL), d_send(NULL), d_recv(NULL), cap(0)
+    {
+        rank = r; world = w;
+        ncclUniqueId id;
+        if (rank == 0) {
+            NCCL_OK(ncclGetUniqueId(&id));
+            const std::string tmp = id_file + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); exit(4); }
+            fclose(f);
+            rename(tmp.c_str(), id_file.c_str());
+        } else {
+            for (int tries = 0;; tries++) {
+                FILE *f = fopen(id_file.c_str(), "rb");
+                if (f) { const bool ok = fread(&id, sizeof(id), 1, f) == 1; fclose(f); if (ok) break; }
+                if (tries > 6000) { fprintf(stderr, "rank %d: no ncclUniqueId in %s\n", rank, id_file.c_str()); exit(4); }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        }
+        HIP_OK(hipStreamCreate(&stream));
+        NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+    }
+    ~RcclComm() { if (comm) ncclCommDestroy(comm); dev_free(d_send); dev_free(d_recv); if (stream) (void)hipStreamDestroy(stream); }
+    void all_gather(const void *send, void *recv, size_t bytes) override
+    {
+        if (bytes > cap) { dev_free(d_send); dev_free(d_recv); d_send = (uint8_t *)dev_alloc(bytes); d_recv = (uint8_t *)dev_alloc(bytes * (size_t)world); cap = bytes; }
+        HIP_OK(hipMemcpyAsync(d_send, send, bytes, hipMemcpyHostToDevice, stream));
+        NCCL_OK(ncclAllGather(d_send, d_recv, bytes, ncclChar, comm, stream));       /* latency-bound: a few KB per rank over xGMI */
+        HIP_OK(hipMemcpyAsync(recv, d_recv, bytes * (size_t)world, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    }
+};
+#endif
+struct FileComm : Comm {
+    std::string dir; unsigned seq;
+    FileComm(int r, int w, const std::string &d) : dir(d), seq(0) { rank = r; world = w; }
+    void all_gather(const void *send, void *recv, size_t bytes) override
+    {
+        const std::string mine = dir + "/g" + std::to_string(seq) + ".r" + std::to_string(rank);
+        FILE *f = fopen((mine + ".tmp").c_str(), "wb");
+        if (!f || fwrite(send, 1, bytes, f) != bytes) { fprintf(stderr, "rank %d: cannot write %s\n", rank, mine.c_str()); exit(4); }
+        fclose(f);
+        rename((mine + ".tmp").c_str(), mine.c_str());
+        for (int r = 0; r < world; r++) {
+            const std::string theirs = dir + "/g" + std::to_string(seq) + ".r" + std::to_string(r);
+            for (int tries = 0;; tries++) {
+                FILE *g = fopen(theirs.c_str(), "rb");
+                if (g) { const bool ok = fread((uint8_t *)recv + (size_t)r * bytes, 1, bytes, g) == bytes; fclose(g); if (ok) break; }
+                if (tries > 60000) { fprintf(stderr, "rank %d: rank %d never wrote %s\n", rank, r, theirs.c_str()); exit(4); }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        seq++;
+    }
+};
+
+/* every rank reached the same verdict?  (one more tiny gather: a rank that has to decode again keeps everybody in the loop) */
+static bool all_ok(Comm &c, bool ok)
+{
+    std::vector<uint8_t> all((size_t)c.world);
+    const uint8_t mine = ok ? 1 : 0;
+    c.all_gather(&mine, all.data(), 1);
+    for (uint8_t v : all) if (!v) return false;
+    return true;
+}
+
+static bool write_file(const std::string &path, const void *p, size_t n)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(p, 1, n, f) == n;
+    fclose(f);
+    return ok;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: see the header of examples/decode_tape_sharded.cpp\n"); return 1; }
+    const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0, world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
+    const int local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
+    g_rank = rank;
+    const char *luma_path = argv[1];
+    const int width = atoi(argv[2]), height = atoi(argv[3]), n_frames = atoi(argv[4]);
+    const std::string prefix = argv[5], comm_arg = argc > 6 ? argv[6] : "rccl";
+    const int warmup = argc > 7 ? atoi(argv[7]) : 20, stitch_warmup = argc > 8 ? atoi(argv[8]) : 4;
+    if (rank < 0 || rank >= world || n_frames < world || width <= 0 || height <= 0) { fprintf(stderr, "bad arguments\n"); return 1; }
+#ifndef SDV_EXAMPLE_HOST_MEMORY
+    HIP_OK(hipSetDevice(local));
+#endif
+    sdv_engine *eng = sdv_engine_create(local);
+    if (!eng) { fprintf(stderr, "sdv_engine_create: %s\n", sdv_last_error(NULL)); return 2; }
+    Comm *comm = NULL;
+    if (comm_arg.rfind("file:", 0) == 0) comm = new FileComm(rank, world, comm_arg.substr(5));
+#ifndef SDV_EXAMPLE_HOST_MEMORY
+    else comm = new RcclComm(rank, world, prefix + ".ncclid");
+#else
+    else { fprintf(stderr, "this build has the file back end only\n"); return 1; }
+#endif
+
+    /* ---- this rank's part of the tape: `lead` warm-up frames, its own range [lo, hi), one successor frame for the last stitcher turn ---------- */
+    const int lo = (int)((long long)n_frames * rank / world), hi = (int)((long long)n_frames * (rank + 1) / world);
+    const int lead = warmup < lo ? warmup : lo, look = hi < n_frames ? 1 : 0, n_own = hi - lo;
+    const bool last = rank == world - 1;
+    const size_t frame_bytes = (size_t)width * (size_t)height, n_in = (size_t)(lead + n_own + look);
+    std::vector<uint8_t> host(n_in * frame_bytes);
+    {
+        FILE *f = fopen(luma_path, "rb");
+        if (!f || fseek(f, (long)((size_t)(lo - lead) * frame_bytes), SEEK_SET) != 0 || fread(host.data(), 1, host.size(), f) != host.size()) { fprintf(stderr, "rank %d: cannot read %s\n", rank, luma_path); return 1; }
+        fclose(f);
+    }
+    uint8_t *d_luma = (uint8_t *)dev_alloc(host.size());
+    h2d(d_luma, host.data(), host.size());
+    const size_t rpf = sdv_records_per_frame(height);
+    const unsigned own_flags = (rank == 0 ? SDV_FLAG_NEW_FILE : 0u) | (last ? SDV_FLAG_END_FILE : 0u);
+    const size_t n_warm = (size_t)lead * rpf, n_own_recs = sdv_binarize_records(height, n_own, own_flags), n_extra = (size_t)look * rpf;
+    sdv_line_rec *d_warm = (sdv_line_rec *)dev_alloc(n_warm * sizeof(sdv_line_rec));
+    sdv_line_rec *d_whole = (sdv_line_rec *)dev_alloc((n_own_recs + n_extra) * sizeof(sdv_line_rec));       /* own range, then the successor frame */
+    sdv_frame_stats *d_stats = (sdv_frame_stats *)dev_alloc((n_in + 2) * sizeof(sdv_frame_stats));
+    SDV_OKAY(sdv_set_mode(eng, SDV_MODE_NORMAL));
+
+    /* ---- binarize stage (the VideoToDigital worker) ------------------------------------------------------------------------------------------- */
+    unsigned gathers = 0, binarize_redo = 0, stitch_redo = 0;
+    SDV_OKAY(sdv_reset_stream(eng));
+    sdv_v2d_state predicted, fin;
+    memset(&predicted, 0, sizeof(predicted));
+    if (lead) {
+        SDV_OKAY(sdv_binarize_frames(eng, d_luma, (size_t)width, frame_bytes, width, height, lead, (uint32_t)(1 + lo - lead), 0, d_warm, n_warm, d_stats, n_in + 2, NULL));
+        SDV_OKAY(sdv_get_chain_state(eng, &predicted));
+    }
+    auto run_range = [&]() {
+        SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)lead * frame_bytes, (size_t)width, frame_bytes, width, height, n_own, (uint32_t)(1 + lo), own_flags,
+                                     d_whole, n_own_recs, d_stats, n_in + 2, NULL));
+        SDV_OKAY(sdv_get_chain_state(eng, &fin));
+        if (look)       /* the successor of this range's last stitcher turn (rank r + 1 decodes it again, as its first frame) */
+            SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)(lead + n_own) * frame_bytes, (size_t)width, frame_bytes, width, height, 1, (uint32_t)(1 + hi), 0,
+                                         d_whole + n_own_recs, n_extra, d_stats, n_in + 2, NULL));
+    };
+    run_range();
+    std::vector<sdv_v2d_state> finals((size_t)world);
+    for (;;) {
+        comm->all_gather(&fin, finals.data(), sizeof(sdv_v2d_state));
+        gathers++;
+        const bool ok = rank == 0 || memcmp(&predicted, &finals[(size_t)rank - 1], sizeof(predicted)) == 0;
+        if (all_ok(*comm, ok)) break;
+        if (!ok) {
+            binarize_redo++;
+            predicted = finals[(size_t)rank - 1];
+            SDV_OKAY(sdv_set_chain_state(eng, &predicted));
+            run_range();
+        }
+    }
+
+    /* ---- stitch stage (the STC007DataStitcher worker) ----------------------------------------------------------------------------------------- */
+    const size_t n_whole = n_own_recs + n_extra;
+    const size_t pairs_cap = n_whole * 4 + 8192, frames_cap = (size_t)n_own + 16, state_n = sdv_stitch_state_size();
+    sdv_sample_pair *d_pairs = (sdv_sample_pair *)dev_alloc(pairs_cap * sizeof(sdv_sample_pair));
+    sdv_frame_asm *d_frames = (sdv_frame_asm *)dev_alloc(frames_cap * sizeof(sdv_frame_asm));
+    sdv_stitch_settings st; sdv_default_stitch_settings(&st);
+    SDV_OKAY(sdv_set_stitch_settings(eng, &st));
+    SDV_OKAY(sdv_reset_stitcher(eng));
+    std::vector<uint8_t> s_pred(state_n, 0), s_final(state_n, 0), s_all(state_n * (size_t)world);
+    size_t n_pairs = 0, n_fr = 0;
+    const int s_lead = stitch_warmup < lead ? stitch_warmup : lead;
+    if (s_lead) {
+        /* warm-up turns lo - s_lead .. lo - 1 (output discarded); frame lo then waits inside the engine for its successor */
+        const size_t n_cat = (size_t)(s_lead + 1) * rpf;
+        sdv_line_rec *d_cat = (sdv_line_rec *)dev_alloc(n_cat * sizeof(sdv_line_rec));
+        d2d(d_cat, d_warm + (size_t)(lead - s_lead) * rpf, (size_t)s_lead * rpf * sizeof(sdv_line_rec));
+        d2d(d_cat + (size_t)s_lead * rpf, d_whole, rpf * sizeof(sdv_line_rec));
+        size_t np = 0, nf = 0;
+        SDV_OKAY(sdv_stitch_frames(eng, d_cat, n_cat, d_pairs, pairs_cap, &np, d_frames, frames_cap, &nf, NULL));
+        SDV_OKAY(sdv_saturate_stitch_stats(eng));
+        SDV_OKAY(sdv_get_stitch_state(eng, s_pred.data(), state_n));
+        SDV_OKAY(sdv_stitch_frames(eng, d_whole + rpf, n_whole - rpf, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+        dev_free(d_cat);
+    } else {
+        SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+    }
+    SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
+    for (;;) {
+        comm->all_gather(s_final.data(), s_all.data(), state_n);
+        gathers++;
+        const bool ok = rank == 0 || memcmp(s_pred.data(), s_all.data() + (size_t)(rank - 1) * state_n, state_n) == 0;
+        if (all_ok(*comm, ok)) break;
+        if (!ok) {
+            stitch_redo++;
+            memcpy(s_pred.data(), s_all.data() + (size_t)(rank - 1) * state_n, state_n);
+            SDV_OKAY(sdv_set_stitch_state(eng, s_pred.data(), state_n));        /* drops the waiting frame: the whole range is fed again */
+            SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+            SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
+        }
+    }
+    dev_sync();
+
+    std::vector<sdv_sample_pair> h_pairs(n_pairs); std::vector<sdv_frame_asm> h_frames(n_fr);
+    d2h(h_pairs.data(), d_pairs, n_pairs * sizeof(sdv_sample_pair));
+    d2h(h_frames.data(), d_frames, n_fr * sizeof(sdv_frame_asm));
+    const std::string base = prefix + ".rank" + std::to_string(rank);
+    if (!write_file(base + ".pairs", h_pairs.data(), n_pairs * sizeof(sdv_sample_pair)) || !write_file(base + ".frames", h_frames.data(), n_fr * sizeof(sdv_frame_asm))) { fprintf(stderr, "cannot write %s.*\n", base.c_str()); return 4; }
+    printf("rank %d of %d: frames [%d, %d) (+ %d warm-up, + %d successor) -> %zu sample pairs, %zu frame descriptors; %u all-gathers, ranges decoded again: binarize %u, stitch %u\n",
+           rank, world, lo, hi, lead, look, n_pairs, n_fr, gathers, binarize_redo, stitch_redo);
+    delete comm;
+    dev_free(d_luma); dev_free(d_warm); dev_free(d_whole); dev_free(d_stats); dev_free(d_pairs); dev_free(d_frames);
+    sdv_engine_destroy(eng);
+    return 0;
+}

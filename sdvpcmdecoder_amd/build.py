@@ -79,6 +79,32 @@ def build_example(force=False):
     return out
 
 
+def build_example_sharded(force=False):
+    """examples/decode_tape_sharded: one tape over several GPUs from plain C++ host code (RCCL all-gather of the hand-over states)."""
+    src = os.path.join(ROOT, "examples", "decode_tape_sharded.cpp")
+    out = os.path.join(ROOT, "examples", "decode_tape_sharded")
+    if not force and not _newer(out, [src, os.path.join(ROOT, "include", "sdvpcm.h"), HIP_LIB]):
+        return out
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           "-I" + os.path.join(ROOT, "include"), src, "-L" + PKG, "-lsdvpcm_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl", "-lpthread",
+                           "-Wl,-rpath,$ORIGIN/../sdvpcmdecoder_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", out])
+    return out
+
+
+def build_example_sharded_emu(force=False):
+    """TEST ONLY: the same host program against the emulator build of the engine (host pointers, the file back end of the collective), so
+    that the loop - warm-up, all-gather, verify, repair - can be run by two processes in the GPU-less container."""
+    src = os.path.join(ROOT, "examples", "decode_tape_sharded.cpp")
+    emu = build_emu()
+    out = os.path.join(ROOT, "tests", "emu", "decode_tape_sharded_emu")
+    if not force and not _newer(out, [src, os.path.join(ROOT, "include", "sdvpcm.h"), emu]):
+        return out
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-DSDV_EXAMPLE_HOST_MEMORY", "-I" + os.path.join(ROOT, "include"), src,
+                           "-L" + os.path.join(ROOT, "tests", "emu"), "-lsdvpcm_emu", "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", out])
+    return out
+
+
 def build_oracle():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
@@ -110,6 +136,7 @@ def build_emu(force=False):
 def build_all():
     build_hip()
     build_example()
+    build_example_sharded()
     build_oracle()
     build_reference()
     build_emu()

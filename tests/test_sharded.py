@@ -101,3 +101,70 @@ def test_two_ranks_one_pcm_tape(tmp_path, emu_lib, oracle_lib, fmt, n_frames, wa
     assert all(int(z["redo"][2]) >= 1 for z in parts)
     if warmup == 0:         # no warm-up, no prediction: the second rank has to take its predecessor's real state and decode again
         assert int(parts[1]["redo"][0]) >= 1 and (fmt == "pcm1" or int(parts[1]["redo"][1]) >= 1), parts[1]["redo"]
+
+
+# ---- the same loop in C++ (examples/decode_tape_sharded.cpp) ---------------------------------------------------------------------------------
+def _sequential_truth(luma):
+    recs, _ = oracle_binarize(luma, mode=2, new_file=True, end_file=True)
+    return sa.run_cpu(libs.load_oracle(), "orc_", recs, sa.default_settings())
+
+
+@pytest.mark.parametrize("n_frames,warmup,s_warm,expect_redo", [(6, 3, 2, False), (10, 3, 2, True)])
+def test_cpp_host_program_two_ranks_one_tape(tmp_path, emu_lib, oracle_lib, n_frames, warmup, s_warm, expect_redo):
+    """The C++ host program of the sharded decode, built against the emulator build of the engine, two processes, the all-gather through
+    files: warm-up, all-gather of the 120-byte / 3.8 KB states through sdv_get_/set_*_state, verification and repair - the concatenated
+    output is the oracle's sequential decode of the whole file, and the same as the Python harness gives (test_two_ranks_one_tape)."""
+    from sdvpcmdecoder_amd import build as b
+    exe = b.build_example_sharded_emu()
+    luma, _, _ = synth.stc007_frames(n_frames, seed=41, noise_sigma=3.0)
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    os.makedirs(tmp_path / "comm")
+    world = 2
+    procs = [subprocess.Popen([exe, str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "out"), "file:" + str(tmp_path / "comm"), str(warmup), str(s_warm)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world)), stdout=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    want_p, want_f = _sequential_truth(luma)
+    pairs = b"".join((tmp_path / f"out.rank{r}.pairs").read_bytes() for r in range(world))
+    frames = b"".join((tmp_path / f"out.rank{r}.frames").read_bytes() for r in range(world))
+    assert pairs == want_p.tobytes() and frames == want_f.tobytes()
+    # a warm-up shorter than the predecessor's history cannot reproduce its coordinate history: the repair of the binarize stage has to run
+    assert ("binarize 0," not in outs[1]) == expect_redo, outs[1]
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_sharded_rccl_one_rank(tmp_path):
+    """The product build on the GPU with one rank: ncclCommInitRank / ncclAllGather of the state blobs (the RCCL plumbing; more ranks need
+    the multi-GPU node), output equal to the reference's for the file (tests/golden/e2e_ntsc_file.npz)."""
+    from sdvpcmdecoder_amd import build as b
+    import test_stitch_kernel as tsk
+    exe = b.build_example_sharded()
+    luma, z, want_p, want_f = tsk._e2e_fixture()
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    out = subprocess.run([exe, str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "out"), "rccl"],
+                         env=dict(os.environ, RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "1 all-gathers" in out.stdout or "2 all-gathers" in out.stdout
+    assert (tmp_path / "out.rank0.pairs").read_bytes() == want_p.tobytes()
+    assert (tmp_path / "out.rank0.frames").read_bytes() == want_f.tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_sharded_two_ranks_one_gpu(tmp_path):
+    """Two ranks of the product build sharing the one GPU of the test box, the all-gather through files (RCCL wants a GPU per rank): the
+    device-side loop with real hand-over between the ranks."""
+    from sdvpcmdecoder_amd import build as b
+    import test_stitch_kernel as tsk
+    exe = b.build_example_sharded()
+    luma, z, want_p, want_f = tsk._e2e_fixture()
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    os.makedirs(tmp_path / "comm")
+    procs = [subprocess.Popen([exe, str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "out"), "file:" + str(tmp_path / "comm")],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0"), stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert b"".join((tmp_path / f"out.rank{r}.pairs").read_bytes() for r in range(2)) == want_p.tobytes()
+    assert b"".join((tmp_path / f"out.rank{r}.frames").read_bytes() for r in range(2)) == want_f.tobytes()
