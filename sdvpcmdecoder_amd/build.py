@@ -62,6 +62,8 @@ def build_hip(force=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
            "-o", HIP_LIB, os.path.join(csrc, "sdvpcm_hip.hip")]
+    if os.environ.get("SDVPCM_DEV_AIDS") == "1":        # a developer build: the scheduler trace etc. can be switched on through the environment
+        cmd.insert(1, "-DSDV_DEV_AIDS")
     subprocess.check_call(cmd, cwd=csrc)
     return HIP_LIB
 

@@ -5,6 +5,7 @@
  * container.  Produces tests/emu/libsdvpcm_emu.so; never loaded by the product package.
  */
 #define SDV_EMU 1
+#define SDV_DEV_AIDS 1
 #define SDV_P16_STITCH_BATCH 3         /* small batches: the hand-over between the batches of a call (histories, conv_queue's remainder) is exercised by every tape */
 #include "hip_emu.h"
 struct uint4 { uint32_t x, y, z, w; };
