@@ -8,7 +8,7 @@
 #include <string.h>
 
 enum { P1_BIT_RANGE = 1 << 12, P1_BIT_SIGN = 1 << 11, P1_WORD_MASK = (1 << 13) - 1, P1_CRC_SILENT = 0xECBF };
-enum { P1_LINES_PF = 245, P1_SUBLINES_PF = 245 * 3, P1_MIN_GOOD = 245 * 4 / 5, P1_BUF_TRIM = 3 * 640 * 3 };
+enum { P1_LINES_PF = 245, P1_SUBLINES_PF = 245 * 3, P1_MIN_GOOD = 245 * 4 / 5, P1_BUF_TRIM = 3 * 640 /* MAX_VLINE_QUEUE_SIZE, config.h:83 */ };
 enum { P1_INT_BLK = 8, P1_MIN_DEINT = 735, P1_STRIPE_TWO = 46, P1_STRIPE_LEN = 46, P1_STRIPE_SHORT = 45, P1_WORD_CNT = 184, P1_WORD_CNT_SHORT = 182 };
 enum { P1_ORDER_UNK = 0, P1_ORDER_TFF, P1_ORDER_BFF };
 
@@ -207,8 +207,12 @@ static void stitch_frame(p1_stitcher *s, const sdv_pcm1_line_rec *recs, size_t l
 {
     p1_frasm *f = &s->f1;
     const sdv_pcm1_stitch_settings *st = &s->st;
-    size_t n = hi - lo; if (n > P1_BUF_TRIM) n = P1_BUF_TRIM;
+    size_t n = hi - lo;
     const sdv_pcm1_line_rec *t = recs + lo;
+    if (n > P1_BUF_TRIM) {      /* fillUntilFullFrame (:150-196) keeps the first BUF_SIZE_TRIM lines that carry the frame's number; the rest is popped unseen */
+        size_t kept = 0;
+        for (size_t i = 0; i < n; i++) if (t[i].frame_number == frame && ++kept == P1_BUF_TRIM) { n = i + 1; break; }
+    }
     f->frame_number = frame;
     /* findFrameTrim (:202-568) */
     uint16_t o_good = 0, e_good = 0;

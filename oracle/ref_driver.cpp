@@ -470,6 +470,8 @@ extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sd
         out_mtx.unlock();
         /* done when everything is fed and the stitcher has stopped making progress (it keeps < 2 frames queued) */
         in_mtx.lock(); qs = in_q.size(); in_mtx.unlock();
+        fr_mtx.lock(); if (fr.size() > frames_cap + 64) overflow = true; fr_mtx.unlock();      /* ... or reports frames without end */
+        if (overflow) break;        /* a stitcher that never lets go of a frame (a queue head it cannot pop) fills any buffer: report -1 instead of hanging */
         if (fed == n_recs && drained == 0) { idle++; if (idle > 150) break; } else idle = 0;
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
     }
@@ -650,6 +652,8 @@ extern "C" long ref_pcm1_stitch_run(const sdv_pcm1_line_rec *recs, size_t n_recs
             out_q.pop_front();
         }
         out_mtx.unlock();
+        fr_mtx.lock(); if (fr.size() > frames_cap + 64) overflow = true; fr_mtx.unlock();      /* ... or reports frames without end */
+        if (overflow) break;        /* a stitcher that never lets go of a frame (a queue head it cannot pop) fills any buffer: report -1 instead of hanging */
         if (fed == n_recs && drained == 0) { idle++; if (idle > 150) break; } else idle = 0;
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
     }
@@ -913,6 +917,8 @@ extern "C" long ref_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n
             out_q.pop_front();
         }
         out_mtx.unlock();
+        fr_mtx.lock(); if (fr.size() > frames_cap + 64) overflow = true; fr_mtx.unlock();      /* ... or reports frames without end */
+        if (overflow) break;        /* a stitcher that never lets go of a frame (a queue head it cannot pop) fills any buffer: report -1 instead of hanging */
         if (fed == n_recs && drained == 0) { idle++; if (idle > 150) break; } else idle = 0;
         std::this_thread::sleep_for(std::chrono::milliseconds(2));
     }

@@ -1442,7 +1442,7 @@ __device__ inline void carry_body(const FrameArgs16s &a, int lane)
     uint64_t pbase = a.pair_ofs[a.seg_base]; uint32_t fbase = a.frasm_ofs[a.seg_base];
     for (uint32_t c0 = 0; c0 < a.n_batch; c0 += 64) {
         const uint32_t kb = c0 + (uint32_t)lane; const bool act = kb < a.n_batch;
-        const uint32_t marks = act ? a.marks[a.seg_base + kb] : 0u, S = act ? a.dec[kb].total : 0u;
+        const uint32_t marks = act ? a.ana[kb].marks : 0u, S = act ? a.dec[kb].total : 0u;      /* the tags that carry the frame's own number: what its trim search saw (:300-330) */
         const bool endf = (marks & FF_END_FILE) != 0, newf = (marks & FF_NEW_FILE) != 0;       /* both empty the queue (resetState :72), END_FILE queues nothing */
         uint32_t f = (act && (endf || newf)) ? 1u : 0u, x = (!act || endf) ? 0u : S % lim;
         for (int d = 1; d < 64; d <<= 1) {              /* segmented sum of the frame sizes modulo a round */
@@ -1584,11 +1584,10 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
     const Ana16 &an = a.ana[kb];
     const Dec16 d = a.dec[kb];
     const Cfg16 cfg = a.cfg;
-    const uint32_t marks = a.marks[k];
+    const uint32_t marks = an.marks;
     const uint64_t pofs = a.pair_ofs[k];
     const uint32_t fofs = a.frasm_ofs[k];
     uint32_t err = an.err | d.err;
-    if ((an.marks ^ marks) & (FF_NEW_FILE | FF_END_FILE)) err |= FE_MARKS;
     if (marks & FF_END_FILE) {
         if (lane == 0) {
             if (fofs < a.frames_cap) { sdv_frame_asm_pcm16x0 s; frasm16_clear(s); s.service_type = SDV_PAIR_SRV_END_FILE; a.out_frames[fofs] = s; }

@@ -72,7 +72,16 @@ __device__ inline void seg_body(const SegArgs1 &a, uint32_t blk, int lane)
 }
 
 /* ---- output offsets: exclusive scan of the per-frame output counts, one workgroup --------------------------------- */
-struct ScanArgs1 { const uint32_t *marks; uint32_t n_seg; uint64_t *pair_ofs; uint32_t *frasm_ofs; const uint32_t *stat; };   /* n_seg + 1 entries each */
+struct ScanArgs1 { uint32_t *marks; uint32_t n_seg; uint64_t *pair_ofs; uint32_t *frasm_ofs; const uint32_t *stat; RecSrc1 src; const uint32_t *seg_end; };   /* n_seg + 1 entries each */
+/* how many records of the segment [lo, lo + n) fillUntilFullFrame keeps: the lines that carry the frame's number, BUF_SIZE_TRIM of them at most (:150-196) -
+ * the index behind the last one kept.  One lane. */
+__device__ inline uint32_t kept_records(const RecSrc1 &src, uint32_t lo, uint32_t n, uint32_t frame)
+{
+    if (n <= (uint32_t)BUF_TRIM) return n;
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < n; i++) if (src.at(lo + i).frame_number == frame) { if (++kept == (uint32_t)BUF_TRIM) return i + 1; }
+    return n;
+}
 __device__ inline void frame_counts(uint32_t marks, uint32_t &pairs, uint32_t &frasm)
 {
     if (marks & FF_END_FILE) { pairs = 1; frasm = 1; }                         /* outputFileStop only (:1723-1729) */
@@ -89,6 +98,20 @@ __device__ inline void scan_body(const ScanArgs1 &a, int lane)
     }
     const uint32_t run = (a.n_seg + 63) / 64, k0 = (uint32_t)lane * run;
     uint32_t k1 = k0 + run; if (k1 > a.n_seg) k1 = a.n_seg;
+    /* The segments pass marked every frame in whose records a file tag lies.  What the reference's frame sees is less: the tags that carry the
+     * frame's own number, among the lines it keeps (a tag with an older number is popped with the frame and never looked at, :1617-1637) -
+     * the few marked frames are read once more for that */
+    for (uint32_t k = k0; k < k1; k++)
+        if (a.marks[k]) {
+            const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, n = a.seg_end[k] - lo, frame = a.src.at(lo + n).frame_number;
+            const uint32_t keep = kept_records(a.src, lo, n, frame);
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < keep; i++) {
+                const sdv_pcm1_line_rec &r = a.src.at(lo + i);
+                if (r.frame_number == frame) m |= r.service_type == SDV_SRV_NEW_FILE ? (uint32_t)FF_NEW_FILE : (r.service_type == SDV_SRV_END_FILE ? (uint32_t)FF_END_FILE : 0u);
+            }
+            a.marks[k] = m;
+        }
     uint64_t psum = 0; uint32_t fsum = 0;
     for (uint32_t k = k0; k < k1; k++) { uint32_t p, f; frame_counts(a.marks[k], p, f); psum += p; fsum += f; }
     uint64_t ps = psum; uint32_t fs = fsum;                     /* inclusive wave scan */
@@ -220,7 +243,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
     const uint64_t pofs = plain ? (uint64_t)k * (2 * SUBLINES_PF) : a.pair_ofs[k];
     const uint32_t fofs = plain ? k : a.frasm_ofs[k];
     const Cfg1 cfg = a.cfg;
-    uint32_t err = n > BUF_TRIM ? FE_TOO_LONG : 0u, seen = 0;
+    uint32_t err = 0u, seen = 0;
     auto line_at = [&](uint32_t i) -> Line16 { if (kLds) return lines[i]; uint32_t dummy = 0; return compact(a.src.at(lo + i), frame, cfg.ignore_crc != 0, dummy); };
 
     P1_STAMP(0);
@@ -232,7 +255,9 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
      * Four chunks of 64 records per turn: the eight 16-byte loads of a turn are issued back to back, so a 490-line frame costs
      * two memory round trips instead of eight. */
     uint32_t any8 = 0, goods = 0;                    /* goods: valid odd lines | valid even lines << 16 */
-    const uint32_t n_scan = n < BUF_TRIM ? n : (uint32_t)BUF_TRIM;      /* fillUntilFullFrame keeps BUF_SIZE_TRIM lines at most (:178-195) */
+    /* fillUntilFullFrame keeps BUF_SIZE_TRIM of the frame's lines at most (:178-195): what lies behind the last one kept is not looked at */
+    uint32_t n_scan = n;
+    if (n > (uint32_t)BUF_TRIM) { if (lane == 0) n_scan = kept_records(a.src, lo, n, frame); n_scan = (uint32_t)__shfl((int)n_scan, 0); }
     auto kinds = [](uint32_t meta) -> uint32_t { const uint32_t fl = meta >> 16, bits = (fl & 7u) | ((fl >> 1) & 8u); return (meta & 1u) ? bits : bits << 4; };
     for (uint32_t c4 = 0; c4 < n_scan; c4 += 256) {
         Raw32 raw[4];

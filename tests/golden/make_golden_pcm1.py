@@ -29,7 +29,10 @@ if __name__ == "__main__":
     crc = np.array([ref.ref_pcm1_crc(np.ascontiguousarray(w).ctypes.data_as(C.POINTER(C.c_uint16))) for w in words], dtype=np.uint16)
     assert crc[0] == 0x9EB9 and crc[1] == 0xECBF
     np.savez_compressed(os.path.join(HERE, "pcm1_crc.npz"), words=words, crc=crc)
+    only = sys.argv[1:]                                               # names to (re)generate; all when none is given
     for name in p1.GOLDEN:
+        if only and name not in only:
+            continue
         recs, st = p1.make_input(name)
         pairs, frames = p1.run_cpu(ref, "ref_", recs, st)
         path = os.path.join(HERE, "pcm1_" + name + ".npz")

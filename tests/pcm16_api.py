@@ -95,14 +95,38 @@ CASES = {
     "si_lost_long": (30, dict(seed=460, cut=(5, 7), tail_cut=(3, 3), p_bad=0.02), {}, dict(seed=10, drop=400)),
     "ei_lost_every_field": (372, dict(seed=462, ei=True, cut=(5, 7), tail_cut=(3, 3)), dict(format=FORMAT_EI), dict(every_field=True)),
 }
+# records that carry the number of a frame already gone, in the middle of later frames: the reference pops its queue only while the head
+# carries the frame's own number (pcm16x0datastitcher.cpp:5711-5732), stops at the stranger and assembles what is left of the same frame
+# again and again - it never ends.  The product refuses such a stream.
+LIVELOCK = {
+    "si_stale_tags": (6, dict(seed=463, cut=(5, 7), tail_cut=(3, 3), p_bad=0.03, new_file=True, end_file=True), {}, dict(stale_tags=True)),
+    "ei_stale_tags": (6, dict(seed=464, ei=True, cut=(5, 7), tail_cut=(3, 3), p_bad=0.03, new_file=True, end_file=True), dict(format=FORMAT_EI), dict(stale_tags=True)),
+}
 WRONG_COUNT = tuple(n for n, c in CASES.items() if len(c) > 3)
 GOLDEN = ("si_cut_both", "si_bad10", "si_picked_forced", "si_wander", "si_file_marks", "ei_cut", "ei_bad10", "ei_noise_short",
           "si_lost_sublines", "si_lost_file_marks", "ei_doubled_sublines", "ei_lost_many", "si_lost_long")
 
 
-def mangle(recs, seed=0, drop=0, dup=0, every_field=False):
+def mangle(recs, seed=0, drop=0, dup=0, every_field=False, stale_tags=False):
     """Sub-line records lost / delivered twice at random places of the stream (service records stay); every_field: the middle
-    sub-line of one line of every field is lost."""
+    sub-line of one line of every field is lost; stale_tags: the NEW_FILE tag of the stream numbered one frame early, and an END_FILE
+    and a NEW_FILE tag numbered one frame early in the middle of frames 2 and 3, a NEW_FILE tag of its own in the middle of frame 4."""
+    if stale_tags:
+        recs = recs.copy()
+        recs["frame_number"][np.nonzero(recs["service_type"] == SRV_NEW_FILE)[0][0]] -= 1
+        ends = np.nonzero(recs["service_type"] == SRV_END_FRAME)[0]
+        parts, last = [], 0
+        for at, srv, d in ((ends[0] + 500, SRV_END_FILE, -1), (ends[1] + 900, SRV_NEW_FILE, -1), (ends[2] + 700, SRV_NEW_FILE, 0)):
+            tag = recs[at:at + 1].copy()
+            for nm in tag.dtype.names:
+                if nm not in ("frame_number", "line_number"):
+                    tag[nm] = 0
+            tag["service_type"] = srv
+            tag["frame_number"] = int(recs["frame_number"][at]) + d
+            parts += [recs[last:at], tag]
+            last = at
+        parts.append(recs[last:])
+        return np.concatenate(parts)
     if every_field:
         return recs[~((recs["service_type"] == 0) & (recs["line_number"] >= 200) & (recs["line_number"] <= 201) & (recs["line_part"] == 1))]
     rng = np.random.default_rng(seed)
@@ -115,14 +139,15 @@ def mangle(recs, seed=0, drop=0, dup=0, every_field=False):
 
 
 def make_input(name):
-    n, kw, st_kw = CASES[name][:3]
+    case = CASES[name] if name in CASES else LIVELOCK[name]
+    n, kw, st_kw = case[:3]
     recs, _ = make_stream(n, **kw)
-    if len(CASES[name]) > 3:
-        recs = mangle(recs, **CASES[name][3])
+    if len(case) > 3:
+        recs = mangle(recs, **case[3])
     return recs, default_settings(**st_kw)
 
 
-def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
+def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None, overflow_ok=False):
     f = getattr(lib, prefix + "pcm16x0_stitch_run")
     f.restype = C.c_long
     f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm16Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -134,6 +159,8 @@ def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
     frames = np.zeros(frame_cap, dtype=FRASM16_DTYPE)
     nf = C.c_size_t(0)
     n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, pair_cap, frames.ctypes.data, frame_cap, C.byref(nf))
+    if n < 0 and overflow_ok:
+        return None, nf.value
     assert n >= 0, "pair buffer too small"
     return pairs[:n], frames[:min(nf.value, frame_cap)]
 

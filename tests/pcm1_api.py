@@ -63,16 +63,56 @@ CASES = {
     "empty_frames": (4, dict(seed=315, p_bad=0.02, empty=(1,), one_field=(2,)), {}),
     "burst": (4, dict(seed=316, burst=(300, 200)), {}),
     "very_long_fields": (3, dict(seed=317, lines=(345, 350), p_bad=0.02, header=2), {}),      # > 672 records: the kernel's global-memory path
+    # what the reference's per-frame queue walk (pcm1datastitcher.cpp:1392-1473) drops or cuts: see MANGLE
+    "stale_new_file": (4, dict(seed=318, p_bad=0.03, header=3, new_file=True, end_file=True), {}),
+    "stale_end_file": (4, dict(seed=319, p_bad=0.03, new_file=True, end_file=True), {}),
+    "stale_tag_inside": (4, dict(seed=320, p_bad=0.03, header=2), {}),
+    "overlong_frame": (3, dict(seed=321, lines=(990, 985), p_bad=0.02), {}),
+    "overlong_frame_tagged": (3, dict(seed=322, lines=(990, 985), p_bad=0.02, new_file=True, end_file=True), {}),
 }
-GOLDEN = ("header_emph", "bad5", "noise_outside", "file_marks", "manual_offsets", "empty_frames")
+GOLDEN = ("header_emph", "bad5", "noise_outside", "file_marks", "manual_offsets", "empty_frames", "stale_tag_inside", "overlong_frame_tagged")
+
+
+def _older_number(recs, srv, which=0):
+    at = np.nonzero(recs["service_type"] == srv)[0][which]
+    recs["frame_number"][at] -= 1
+    return recs
+
+
+def _tag_inside(recs):
+    """A NEW_FILE and an END_FILE tag of the frame before in the middle of frame 2, and a NEW_FILE of its own in frame 3."""
+    ends = np.nonzero(recs["service_type"] == SRV_END_FRAME)[0]
+    out = []
+    for at, srv, d in ((ends[0] + 40, SRV_NEW_FILE, -1), (ends[0] + 300, SRV_END_FILE, -1), (ends[1] + 120, SRV_NEW_FILE, 0)):
+        r = recs[at:at + 1].copy()
+        r["service_type"] = srv
+        r["frame_number"] = int(recs["frame_number"][at]) + d
+        out.append((at, r))
+    parts, last = [], 0
+    for at, r in out:
+        parts += [recs[last:at], r]
+        last = at
+    parts.append(recs[last:])
+    return np.concatenate(parts)
+
+
+# name: what is done to the generated stream
+MANGLE = {
+    "stale_new_file": lambda r: _older_number(r, SRV_NEW_FILE),
+    "stale_end_file": lambda r: _older_number(r, SRV_END_FILE),
+    "stale_tag_inside": _tag_inside,
+}
 
 
 def make_input(name):
     n, kw, st_kw = CASES[name]
-    return make_stream(n, **kw), default_settings(**st_kw)
+    recs = make_stream(n, **kw)
+    if name in MANGLE:
+        recs = MANGLE[name](recs.copy())
+    return recs, default_settings(**st_kw)
 
 
-def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
+def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None, overflow_ok=False):
     f = getattr(lib, prefix + "pcm1_stitch_run")
     f.restype = C.c_long
     f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm1Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -84,6 +124,8 @@ def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
     frames = np.zeros(frame_cap, dtype=FRASM1_DTYPE)
     nf = C.c_size_t(0)
     n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, pair_cap, frames.ctypes.data, frame_cap, C.byref(nf))
+    if n < 0 and overflow_ok:
+        return None, nf.value
     assert n >= 0, "pair buffer too small"
     return pairs[:n], frames[:min(nf.value, frame_cap)]
 

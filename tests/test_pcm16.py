@@ -185,11 +185,23 @@ def test_emu_failed_call_leaves_the_stream_untouched(emu, oracle_lib):
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
 
 
-def test_emu_rejects_foreign_lines(emu):
-    """Sub-lines of another frame queued ahead of an END_FRAME stay in the reference's queue for a later turn: not a per-frame job."""
+def _strangers():
     recs, st = p16.make_input("si_clean")
     recs = recs.copy()
     recs["frame_number"][100] = 2
+    yield "later_number", recs, st
+    for name in p16.LIVELOCK:
+        yield (name,) + p16.make_input(name)
+
+
+@pytest.mark.parametrize("name,recs,st", list(_strangers()), ids=lambda v: v if isinstance(v, str) else "")
+def test_emu_refuses_what_the_reference_never_finishes(name, recs, st, emu):
+    """A record numbered for another frame ahead of an END_FRAME: the reference pops its queue up to the stranger
+    (pcm16x0datastitcher.cpp:5711-5732), finds the same END_FRAME again and assembles what is left of the frame without end (shown on
+    the real reference: more frame reports than the stream has frames, until the driver's buffers are full).  The product refuses."""
+    if libs.ref_available():
+        pairs, n_frames = p16.run_cpu(libs.load_ref(), "ref_", recs, st, overflow_ok=True)
+        assert pairs is None and n_frames > int((recs["service_type"] == p16.SRV_END_FRAME).sum())
     eng = emu.sdv_engine_create(0)
     rc, p, f = ea.emu_pcm16_stitch(emu, eng, recs, st)
     assert rc != 0 and b"another frame" in emu.sdv_last_error(eng)
