@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define SDV_ABI_VERSION 4   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only);
-                             * 4: sdv_pcm16x0_binarize_lines, sdv_audio_stalled, sdv_set_frame_flags, sdv_double_width (additions); the calls that used to refuse PCM-16x0 frames of the wrong size and the
+                             * 4: sdv_pcm16x0_binarize_lines, sdv_audio_stalled, sdv_set_frame_flags, sdv_double_width, sdv_vis_render_lines (additions); the calls that used to refuse PCM-16x0 frames of the wrong size and the
                              * AudioProcessor's dead ends now follow the reference; the PCM-16x0 stitch state blob grew by conv_queue's remainder */
 
 /* ---- status codes ---------------------------------------------------------------------------
@@ -689,6 +689,29 @@ int sdv_decode_frames(sdv_engine *e, int pcm_type, const uint8_t *luma, size_t r
                       sdv_sample_pair *out_pairs, size_t pairs_cap, size_t *n_pairs, void *out_frames, size_t frames_cap, size_t *n_frames_out,
                       sdv_frame_stats *out_stats, size_t stats_cap,
                       int with_audio, int audio_stop, sdv_audio_purge *out_purges, size_t purges_cap, size_t *n_purges, uint64_t *n_masked, void *stream);
+
+/* ---- visualiser feed: the canvases of RenderPCM's "binarized lines" window ---------------------------------------------------
+ * Replaces RenderPCM::renderNewLine(STC007Line / PCM1Line / PCM16X0SubLine) (renderpcm.cpp:939-1169, 489-624, 743-936) as MainWindow drives it
+ * for its binarized-lines visualiser (mainwindow.cpp:1949-1990): every line VideoToDigital queues that is no service line, fillers
+ * included (videotodigital.cpp:398-402, 452-456, 507-511), is drawn on the next row of one canvas, bit by bit in the colours of
+ * renderpcm.h:52-65 (5 / 8 / 4 pixels per bit); at every binarized frame (an END_FRAME record here) the canvas is handed out and the
+ * next frame starts at row 0 again (prepareNewFrame, renderpcm.cpp:176-186) - on the same canvas, which is never cleared.
+ *   kind                     records (device)          canvas (sdv_vis_canvas_size)
+ *   SDV_VIS_STC007_LINES     sdv_line_rec              685 x 650   (startSTC007NTSCFrame + setLineCount(VID_UNKNOWN))
+ *   SDV_VIS_PCM1_LINES       sdv_pcm1_bin_rec          752 x 490   (startPCM1Frame)
+ *   SDV_VIS_PCM16X0_LINES    sdv_pcm16x0_bin_rec       772 x 490   (startPCM1600Frame; three sub-lines and the control bit per row)
+ * - the record streams the frame entries (sdv_binarize_frames, sdv_pcm1_binarize_frames, sdv_pcm16x0_binarize_frames) put out.  One call
+ * draws all frames that end in `recs`: out_canvases[f] is frame f's canvas (height x width pixels of 32 bit, QImage::Format_RGB32 as the
+ * reference fills it: 0xFFRRGGBB, and the value 2 where the reference writes its VIS_BIT0_BLK, which is the enumerator Qt::black).  The engine
+ * keeps the last canvas per kind for the next call like RenderPCM keeps its QImage; a canvas nothing was drawn on yet is 0xFF000000 (the
+ * reference leaves those rows uninitialised).  Records behind the last END_FRAME are not drawn: pass whole frames.  *n_frames = frames in
+ * `recs`; more than canvases_cap: SDV_ERR_BAD_ARG, nothing drawn.  Device pointers; the call reads one small array back (the frame count)
+ * and leaves the drawing running on `stream`.  sdv_vis_reset: a new canvas (RenderPCM::startNewFrame).
+ * The block canvases (renderNewBlock) and the assembled-lines canvas are not rebuilt. */
+enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2 };
+int sdv_vis_canvas_size(int kind, uint32_t *width, uint32_t *height);
+int sdv_vis_reset(sdv_engine *e, int kind, void *stream);
+int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_recs, uint32_t *out_canvases, size_t canvases_cap, size_t *n_frames, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,99 @@
+/*
+ * ref_render_driver.cpp - thin C-ABI shim around the REAL RenderPCM (renderpcm.cpp, compiled from /root/reference by oracle/Makefile.ref
+ * into oracle/_ref/libsdvref.so).  TEST INFRASTRUCTURE ONLY.  Our own code: it only calls the reference's public slots the way
+ * MainWindow wires its "binarized" visualiser (mainwindow.cpp:1949-1990): start<format>Frame, a renderNewLine per line that is not a service
+ * line (fillers are drawn), prepareNewFrame per frame; frames leave through the renderedFrame(QImage) signal.
+ */
+#include <cstring>
+#include <cstdint>
+#include <vector>
+#include <QCoreApplication>
+#include <QImage>
+#include "renderpcm.h"
+#include "frametrimset.h"
+#include "../include/sdvpcm.h"
+
+static int q_argc = 1;
+static char q_arg0[] = "sdvref";
+static char *q_argv[] = { q_arg0, NULL };
+
+static void service_of(PCMLine &l, uint8_t st)
+{
+    if (st == SDV_SRV_FILLER) l.setServFiller();
+}
+
+static void to_line(const sdv_line_rec &r, STC007Line &l)
+{
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    if (r.service_type == SDV_SRV_FILLER) { l.setServFiller(); return; }
+    for (uint8_t i = 0; i < 8; i++) l.setWord(i, r.words[i]);
+    l.setSourceCRC(r.words[8]); l.calcCRC();
+    l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
+    l.setDataCoordinatesState((r.flags & SDV_LF_COORDS_SET) != 0);
+    l.mark_st_stage = r.mark_st_stage; l.mark_ed_stage = r.mark_ed_stage;
+    if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+    l.applyCRCStatePerWord();
+}
+
+static void to_line(const sdv_pcm1_bin_rec &r, PCM1Line &l)
+{
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    if (r.service_type == SDV_SRV_FILLER) { l.setServFiller(); return; }
+    for (uint8_t i = 0; i < 6; i++) l.setWord(i, r.words[i]);
+    l.setSourceCRC(r.words[6]); l.calcCRC();
+    l.picked_bits_left = r.picked_bits_left; l.picked_bits_right = r.picked_bits_right;
+    l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
+    l.setDataCoordinatesState((r.flags & SDV_LF_COORDS_SET) != 0);
+    if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+}
+
+static void to_line(const sdv_pcm16x0_bin_rec &r, PCM16X0SubLine &l)
+{
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    if (r.service_type == SDV_SRV_FILLER) { l.setServFiller(); return; }
+    for (uint8_t i = 0; i < 3; i++) l.setWord(i, r.words[i]);
+    l.setSourceCRC(r.words[3]); l.calcCRC();
+    l.picked_bits_left = r.picked_bits_left; l.picked_bits_right = r.picked_bits_right;
+    l.control_bit = r.control_bit != 0; l.line_part = r.line_part; l.queue_order = r.queue_order;
+    l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
+    l.setDataCoordinatesState((r.flags & SDV_LF_COORDS_SET) != 0);
+    if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+}
+
+/* kind: 0 STC-007 (sdv_line_rec), 1 PCM-1 (sdv_pcm1_bin_rec), 2 PCM-16x0 (sdv_pcm16x0_bin_rec).  The canvas of every frame (at its END_FRAME
+ * record) goes to out[frame] as width*height 32-bit pixels; rows no frame has reached yet are whatever `new QImage` left there.  Returns frames. */
+extern "C" long ref_vis_render_lines(int kind, const void *recs, size_t n_recs, uint32_t *out, size_t out_cap, uint32_t *width, uint32_t *height)
+{
+    if (!QCoreApplication::instance()) new QCoreApplication(q_argc, q_argv);
+    RenderPCM ren;
+    long frames = 0;
+    uint32_t w = 0, h = 0;
+    QObject::connect(&ren, &RenderPCM::renderedFrame, [&](QImage img) {
+        w = (uint32_t)img.width(); h = (uint32_t)img.height();
+        if ((size_t)frames < out_cap)
+            for (uint32_t y = 0; y < h; y++) memcpy(out + ((size_t)frames * h + y) * w, img.constScanLine((int)y), (size_t)w * 4);
+        frames++;
+    });
+    ren.setLivePlay(false);
+    if (kind == 0) { ren.startSTC007NTSCFrame(); ren.setLineCount(FrameAsmDescriptor::VID_UNKNOWN); }
+    else if (kind == 1) ren.startPCM1Frame();
+    else ren.startPCM1600Frame();
+    STC007Line l0; PCM1Line l1; PCM16X0SubLine l2;
+    for (size_t i = 0; i < n_recs; i++) {
+        uint8_t srv; uint32_t frame;
+        if (kind == 0) { const sdv_line_rec &r = ((const sdv_line_rec *)recs)[i]; srv = r.service_type; frame = r.frame_number; }
+        else if (kind == 1) { const sdv_pcm1_bin_rec &r = ((const sdv_pcm1_bin_rec *)recs)[i]; srv = r.service_type; frame = r.frame_number; }
+        else { const sdv_pcm16x0_bin_rec &r = ((const sdv_pcm16x0_bin_rec *)recs)[i]; srv = r.service_type; frame = r.frame_number; }
+        if (srv == SDV_SRV_END_FRAME) { ren.prepareNewFrame(frame); ren.displayIsReady(); continue; }
+        if (srv != SDV_SRV_NO && srv != SDV_SRV_FILLER) continue;          /* videotodigital.cpp:398-402, 452-456, 507-511 */
+        if (kind == 0) { to_line(((const sdv_line_rec *)recs)[i], l0); ren.renderNewLine(l0); }
+        else if (kind == 1) { to_line(((const sdv_pcm1_bin_rec *)recs)[i], l1); ren.renderNewLine(l1); }
+        else { to_line(((const sdv_pcm16x0_bin_rec *)recs)[i], l2); ren.renderNewLine(l2); }
+    }
+    if (width) *width = w;
+    if (height) *height = h;
+    return frames;
+}

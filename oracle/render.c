@@ -1,0 +1,160 @@
+/*
+ * render.c - CPU restatement of RenderPCM's canvases of binarized lines (renderpcm.cpp).  TEST INFRASTRUCTURE ONLY: used by tests/,
+ * __graft_entry__.smoke() and nothing else; pinned against the real RenderPCM (oracle/ref_render_driver.cpp) and the fixtures it made.
+ *
+ * The "binarized" visualiser of the reference (mainwindow.cpp:1949-1990) is one RenderPCM object that is handed every line VideoToDigital
+ * queues, except service lines other than fillers (videotodigital.cpp:398-402, 452-456, 507-511), and a prepareNewFrame() per binarized frame
+ * (:176-186): the canvas (a QImage::Format_RGB32) is copied out and the fill row goes back to 0 - the canvas itself is NOT cleared, rows a
+ * frame does not reach keep what earlier frames drew.
+ *
+ *   STC-007   renderNewLine(STC007Line)     :939-1169    5 px per bit, 137 bits (START 1010, 128 data bits, STOP 01111), 685 x 650
+ *   PCM-1     renderNewLine(PCM1Line)       :489-624     8 px per bit, 94 bits, 752 x 490
+ *   PCM-16x0  renderNewLine(PCM16X0SubLine) :743-936     4 px per bit, three sub-lines of 64 bits and the control bit, 772 x 490
+ *
+ * VIS_BIT0_BLK is Qt::black - the GlobalColor enumerator (2), not a QRgb: the reference stores the value 2 in those pixels.
+ */
+#include <string.h>
+#include "render.h"
+
+enum { PX_BLK = 2u,                                           /* (QRgb)Qt::black */
+       B0_GRY = 0xFF2D2D2Du, B1_GRY = 0xFF969696u, B0_YEL = 0xFF7F6E00u, B1_YEL = 0xFFFFDC00u, B0_GRN = 0xFF005F1Eu, B1_GRN = 0xFF00E146u,
+       B0_RED = 0xFF8C0000u, B1_RED = 0xFFFF462Bu, B0_BLU = 0xFF005F7Fu, B1_BLU = 0xFF00BFFFu, B0_MGN = 0xFF8C008Cu, B1_MGN = 0xFFFF00FFu,
+       B1_MARK = 0xFFFFFFFFu };
+
+void orc_vis_canvas_size(int kind, uint32_t *w, uint32_t *h)
+{
+    switch (kind) {
+        case ORC_VIS_STC007: *w = 5 * 137; *h = 650; break;      /* startSTC007NTSCFrame + setLineCount(VID_UNKNOWN), mainwindow.cpp:1985-1986 */
+        case ORC_VIS_PCM1: *w = 8 * 94; *h = 490; break;         /* startPCM1Frame :128-131 */
+        case ORC_VIS_PCM16X0: *w = 4 * 193; *h = 490; break;     /* startPCM1600Frame :140-143 */
+        default: *w = *h = 0;
+    }
+}
+
+static bool drawn(uint8_t service_type) { return service_type == SDV_SRV_NO || service_type == SDV_SRV_FILLER; }
+
+/* :939-1169 */
+static void stc_line(const sdv_line_rec *r, uint32_t *px)
+{
+    uint16_t words[9];
+    bool crc_valid, markers, forced, word_crc, word_valid;
+    if (r->service_type == SDV_SRV_FILLER) {     /* a cleared line (STC007Line::clear): silent words, the read CRC is the inverse of CRC_SILENT */
+        memset(words, 0, sizeof(words)); words[8] = (uint16_t)~0xA96A;
+        crc_valid = markers = forced = word_crc = word_valid = false;
+    } else {
+        memcpy(words, r->words, sizeof(words));
+        crc_valid = (r->flags & SDV_LF_CRC_VALID) != 0; forced = (r->flags & SDV_LF_FORCED_BAD) != 0;
+        markers = r->mark_st_stage == 4 /* MARK_ST_BOT_2, stc007line.h:130 */ && r->mark_ed_stage == 3 /* MARK_ED_LEN_OK, :139 */;
+        word_crc = (r->word_state & SDV_WS_WORD_CRC) != 0; word_valid = (r->word_state & SDV_WS_WORD_VALID) != 0;
+    }
+    for (int i = 0; i < 4; i++) {
+        const bool one = (i % 2) == 0;
+        const uint32_t c = (crc_valid || markers) ? (one ? B1_GRY : B0_GRY) : PX_BLK;
+        for (int j = 0; j < 5; j++) *px++ = c;
+    }
+    for (int w = 0; w < 9; w++) {
+        const int bits = w == 8 ? 16 : 14;
+        for (int b = bits - 1; b >= 0; b--) {
+            const bool one = ((words[w] >> b) & 1) != 0;
+            uint32_t c;
+            if (forced) c = one ? B1_MGN : B0_MGN;
+            else if (word_crc) c = one ? B1_GRY : B0_GRY;
+            else if (word_valid) c = one ? B1_GRN : B0_GRN;
+            else if (markers) c = one ? B1_YEL : B0_YEL;
+            else c = one ? B1_RED : B0_RED;
+            for (int j = 0; j < 5; j++) *px++ = c;
+        }
+    }
+    for (int i = 0; i < 5; i++) {
+        uint32_t c = PX_BLK;
+        if (i == 0) { if (crc_valid || markers) c = B0_GRY; }
+        else if (crc_valid) c = B1_MARK;
+        else if (markers) c = B1_GRY;
+        for (int j = 0; j < 5; j++) *px++ = c;
+    }
+}
+
+/* the colour of one data bit of a PCM-1 line / PCM-16x0 sub-line (:536-607, :803-876) */
+static uint32_t bit_colour(bool one, bool crc_valid, bool forced, bool bw, bool picked)
+{
+    if (crc_valid) return picked ? (one ? B1_BLU : B0_BLU) : (one ? B1_GRY : PX_BLK);
+    if (forced) return one ? B1_MGN : B0_MGN;
+    if (bw) return one ? B1_YEL : B0_YEL;
+    return one ? B1_RED : B0_RED;
+}
+
+/* :489-624 */
+static void pcm1_line(const sdv_pcm1_bin_rec *r, uint32_t *px)
+{
+    uint16_t words[7];
+    bool crc_valid = false, forced = false, bw = false;
+    int pl = 0, pr = 0;
+    if (r->service_type == SDV_SRV_FILLER) { for (int i = 0; i < 6; i++) words[i] = 1 << 12; words[6] = (uint16_t)~0xECBF; }
+    else {
+        memcpy(words, r->words, sizeof(words));
+        crc_valid = (r->flags & SDV_LF_CRC_VALID) != 0; forced = (r->flags & SDV_LF_FORCED_BAD) != 0; bw = (r->flags & SDV_LF_BW_SET) != 0;
+        pl = r->picked_bits_left; pr = r->picked_bits_right;
+    }
+    int line_bit = 0;
+    for (int w = 0; w < 7; w++)
+        for (int b = (w == 6 ? 16 : 13) - 1; b >= 0; b--, line_bit++) {
+            const bool picked = line_bit < pl || line_bit > 94 - pr - 1;
+            const uint32_t c = bit_colour(((words[w] >> b) & 1) != 0, crc_valid, forced, bw, picked);
+            for (int j = 0; j < 8; j++) *px++ = c;
+        }
+}
+
+/* :743-936; returns true when the row is finished (PART_RIGHT) */
+static bool pcm16_subline(const sdv_pcm16x0_bin_rec *r, uint32_t *row)
+{
+    uint16_t words[4];
+    bool crc_valid = false, forced = false, bw = false, coords = false, control = true;
+    int pl = 0, pr = 0, part = 0;
+    if (r->service_type == SDV_SRV_FILLER) { words[0] = words[1] = words[2] = 0; words[3] = (uint16_t)~0x0E10; }   /* PCM16X0SubLine::clear: PART_LEFT, control bit set */
+    else {
+        memcpy(words, r->words, sizeof(words));
+        crc_valid = (r->flags & SDV_LF_CRC_VALID) != 0; forced = (r->flags & SDV_LF_FORCED_BAD) != 0; bw = (r->flags & SDV_LF_BW_SET) != 0;
+        coords = (r->flags & SDV_LF_COORDS_SET) != 0; control = r->control_bit != 0;
+        pl = r->picked_bits_left; pr = r->picked_bits_right; part = r->line_part;
+    }
+    int ofs = part > 2 ? 0 : part * 64;
+    if (part == 2) ofs++;
+    uint32_t *px = row + 4 * ofs;
+    int line_bit = 0;
+    for (int w = 0; w < 4; w++)
+        for (int b = 15; b >= 0; b--, line_bit++) {
+            const bool picked = line_bit < pl || line_bit > 64 - pr - 1;
+            const uint32_t c = bit_colour(((words[w] >> b) & 1) != 0, crc_valid, forced, bw, picked);
+            for (int j = 0; j < 4; j++) *px++ = c;
+        }
+    if (part == 1) {
+        const uint32_t c = (!coords || !crc_valid) ? (control ? B1_RED : B0_RED) : (control ? B1_GRY : PX_BLK);
+        for (int j = 0; j < 4; j++) *px++ = c;
+    }
+    return part == 2;
+}
+
+long orc_vis_render_lines(int kind, const void *recs, size_t n_recs, uint32_t *canvas, uint32_t *out, size_t out_cap)
+{
+    uint32_t w, h, fill = 0;
+    long frames = 0;
+    orc_vis_canvas_size(kind, &w, &h);
+    if (!w) return -1;
+    for (size_t i = 0; i < n_recs; i++) {
+        uint8_t srv;
+        if (kind == ORC_VIS_STC007) srv = ((const sdv_line_rec *)recs)[i].service_type;
+        else if (kind == ORC_VIS_PCM1) srv = ((const sdv_pcm1_bin_rec *)recs)[i].service_type;
+        else srv = ((const sdv_pcm16x0_bin_rec *)recs)[i].service_type;
+        if (srv == SDV_SRV_END_FRAME) {          /* newFrameBinarized -> prepareNewFrame (:176-186): the canvas goes out, the fill row back to 0 */
+            if ((size_t)frames < out_cap) memcpy(out + (size_t)frames * w * h, canvas, (size_t)w * h * 4);
+            frames++; fill = 0;
+            continue;
+        }
+        if (!drawn(srv) || fill >= h) continue;
+        uint32_t *row = canvas + (size_t)fill * w;
+        if (kind == ORC_VIS_STC007) { stc_line(&((const sdv_line_rec *)recs)[i], row); fill++; }
+        else if (kind == ORC_VIS_PCM1) { pcm1_line(&((const sdv_pcm1_bin_rec *)recs)[i], row); fill++; }
+        else if (pcm16_subline(&((const sdv_pcm16x0_bin_rec *)recs)[i], row)) fill++;
+    }
+    return frames;
+}

@@ -55,7 +55,7 @@ def _newer(target, sources):
 def build_hip(force=False):
     csrc = os.path.join(PKG, "csrc")
     srcs = [os.path.join(csrc, f) for f in ("sdvpcm_hip.hip", "stc007_device.h", "stc007_deint_device.h", "stc007_stitch_device.h", "engine.inc",
-                                              "stitch_engine.inc", "pcm1_stitch_device.h", "pcm1_bin_device.h", "pcm1_engine.inc", "pcm1_frames_device.h", "pcm1_frames_engine.inc", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc", "pcm16_engine.inc", "pcm16_stitch_device.h", "audio_device.h", "audio_engine.inc")] + \
+                                              "stitch_engine.inc", "pcm1_stitch_device.h", "pcm1_bin_device.h", "pcm1_engine.inc", "pcm1_frames_device.h", "pcm1_frames_engine.inc", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc", "pcm16_engine.inc", "pcm16_stitch_device.h", "audio_device.h", "audio_engine.inc", "vis_device.h", "vis_engine.inc")] + \
            [os.path.join(ROOT, "include", "sdvpcm.h")]
     if not force and not _newer(HIP_LIB, srcs):
         return HIP_LIB
@@ -127,7 +127,7 @@ def build_emu(force=False):
             os.path.join(PKG, "csrc", "engine.inc"), os.path.join(PKG, "csrc", "stc007_stitch_device.h"),
             os.path.join(PKG, "csrc", "stitch_engine.inc"),
             os.path.join(PKG, "csrc", "pcm1_stitch_device.h"), os.path.join(PKG, "csrc", "pcm1_bin_device.h"), os.path.join(PKG, "csrc", "pcm1_engine.inc"), os.path.join(PKG, "csrc", "pcm1_frames_device.h"), os.path.join(PKG, "csrc", "pcm1_frames_engine.inc"), os.path.join(PKG, "csrc", "pcm16_bin_device.h"), os.path.join(PKG, "csrc", "pcm16_frames_device.h"), os.path.join(PKG, "csrc", "pcm16_frames_engine.inc"), os.path.join(PKG, "csrc", "pcm16_engine.inc"), os.path.join(PKG, "csrc", "pcm16_stitch_device.h"), os.path.join(PKG, "csrc", "audio_device.h"), os.path.join(PKG, "csrc", "audio_engine.inc"),
-            os.path.join(ROOT, "include", "sdvpcm.h")]
+            os.path.join(PKG, "csrc", "vis_device.h"), os.path.join(PKG, "csrc", "vis_engine.inc"), os.path.join(ROOT, "include", "sdvpcm.h")]
     if not force and not _newer(out, srcs):
         return out
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", out,

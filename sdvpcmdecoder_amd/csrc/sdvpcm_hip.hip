@@ -13,6 +13,7 @@
 #include "pcm16_frames_device.h"
 #include "pcm16_stitch_device.h"
 #include "audio_device.h"
+#include "vis_device.h"
 #include "engine.inc"
 #include "stitch_engine.inc"
 #include "pcm1_engine.inc"
@@ -20,3 +21,4 @@
 #include "pcm16_frames_engine.inc"
 #include "pcm16_engine.inc"
 #include "audio_engine.inc"
+#include "vis_engine.inc"

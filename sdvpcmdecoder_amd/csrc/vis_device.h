@@ -1,0 +1,303 @@
+/*
+ * vis_device.h - the canvases of RenderPCM's "binarized lines" visualiser, drawn from device-resident line records.
+ *
+ * Reference: RenderPCM::renderNewLine(STC007Line / PCM1Line / PCM16X0SubLine) (renderpcm.cpp:939-1169, 489-624, 743-936), fed with every
+ * line VideoToDigital queues that is no service line or is a filler (videotodigital.cpp:398-402, 452-456, 507-511), and
+ * prepareNewFrame() per binarized frame (renderpcm.cpp:176-186; wiring mainwindow.cpp:1949-1990).  The reference draws one line at a
+ * time into one QImage that is never cleared: a frame's canvas is what the frame drew over what the frames before it left there.
+ *
+ * Here all frames of a batch are drawn at once - a record's row is its rank among the drawn records of its frame (PCM-16x0: among the
+ * right-hand sub-lines, the row advances with those) - into one canvas per frame, and a second pass carries what earlier frames (or
+ * the canvas kept from the call before) left in the places a frame did not draw.  Both passes are plain streaming writes: 4 bytes per
+ * pixel leave, 36-40 bytes per record come in; the bound is HBM write bandwidth.
+ *
+ * A place ("cell") is a row of the canvas; for PCM-16x0 a third of a row (the middle one with the control bit).  Where two records of
+ * a frame land in the same cell (sub-lines whose right-hand part was lost), the later one wins like in the reference's sequential
+ * drawing: the earlier one is not drawn at all.
+ */
+#pragma once
+#include <stdint.h>
+#include "../../include/sdvpcm.h"
+#include "stc007_stitch_device.h"
+
+namespace sdvvis {
+using sdvs::lanemask_lt;
+
+enum { PX_BLK = 2u,                  /* VIS_BIT0_BLK is Qt::black, the GlobalColor enumerator: the reference stores its value, 2 (renderpcm.h:52) */
+       B0_GRY = 0xFF2D2D2Du, B1_GRY = 0xFF969696u, B0_YEL = 0xFF7F6E00u, B1_YEL = 0xFFFFDC00u, B0_GRN = 0xFF005F1Eu, B1_GRN = 0xFF00E146u,
+       B0_RED = 0xFF8C0000u, B1_RED = 0xFFFF462Bu, B0_BLU = 0xFF005F7Fu, B1_BLU = 0xFF00BFFFu, B0_MGN = 0xFF8C008Cu, B1_MGN = 0xFFFF00FFu,
+       B1_MARK = 0xFFFFFFFFu,        /* renderpcm.h:53-65 */
+       BLANK = 0xFF000000u };        /* a canvas nothing was drawn on: QImage::fill(Qt::black) */
+
+struct Geometry { uint32_t w, h, cells_per_row; };
+__host__ __device__ inline Geometry geometry(int kind)
+{
+    Geometry g = { 0, 0, 0 };
+    if (kind == SDV_VIS_STC007_LINES) { g.w = 5 * 137; g.h = 650; g.cells_per_row = 1; }        /* startSTC007NTSCFrame + setLineCount(VID_UNKNOWN) */
+    else if (kind == SDV_VIS_PCM1_LINES) { g.w = 8 * 94; g.h = 490; g.cells_per_row = 1; }      /* startPCM1Frame */
+    else if (kind == SDV_VIS_PCM16X0_LINES) { g.w = 4 * 193; g.h = 490; g.cells_per_row = 3; }  /* startPCM1600Frame */
+    return g;
+}
+/* pixels [x0, x1) of a cell */
+__host__ __device__ inline void cell_span(int kind, uint32_t part, uint32_t &x0, uint32_t &x1)
+{
+    if (kind != SDV_VIS_PCM16X0_LINES) { x0 = 0; x1 = geometry(kind).w; return; }
+    x0 = part == 0 ? 0u : part == 1 ? 4u * 64u : 4u * 129u;
+    x1 = part == 0 ? 4u * 64u : part == 1 ? 4u * 129u : 4u * 193u;
+}
+
+struct VisArgs {
+    const void *recs; uint32_t n_recs; int kind;
+    uint32_t *cnt;                  /* per 64 records: END_FRAME records | records that end a row << 16 */
+    const uint32_t *base_end, *base_adv;    /* per 64 records: how many of either came before */
+    uint32_t *frame_adv0;           /* per frame: rows ended before the frame began */
+    uint32_t n_frames;
+    uint32_t *out;                  /* n_frames canvases */
+    uint32_t *wmask; uint32_t wmask_stride;     /* per frame: one bit per cell the frame drew */
+    const uint32_t *canvas;         /* what the frames before this call left */
+    int32_t *last_drawn; uint32_t n_cells;      /* per frame and cell: the last frame up to this one that drew the cell (-1: none in this call) */
+};
+
+/* what the passes need to know of record i: END_FRAME?, drawn?, the third of the row it lands in, does the row end with it */
+struct Rec { bool end, drawn, adv; uint32_t part; };
+template <class R> __device__ inline Rec classify(const R *recs, uint32_t i, uint32_t n, int kind)
+{
+    Rec c; c.end = c.drawn = c.adv = false; c.part = 0;
+    if (i >= n) return c;
+    const uint8_t srv = recs[i].service_type;
+    c.end = srv == SDV_SRV_END_FRAME;
+    c.drawn = srv == SDV_SRV_NO || srv == SDV_SRV_FILLER;
+    c.adv = c.drawn;
+    return c;
+}
+template <> __device__ inline Rec classify<sdv_pcm16x0_bin_rec>(const sdv_pcm16x0_bin_rec *recs, uint32_t i, uint32_t n, int kind)
+{
+    Rec c; c.end = c.drawn = c.adv = false; c.part = 0;
+    if (i >= n) return c;
+    const uint8_t srv = recs[i].service_type;
+    c.end = srv == SDV_SRV_END_FRAME;
+    c.drawn = srv == SDV_SRV_NO || srv == SDV_SRV_FILLER;
+    const uint32_t part = srv == SDV_SRV_NO ? recs[i].line_part : 0u;      /* a filler is a cleared sub-line: PART_LEFT (pcm16x0subline.cpp:63-86) */
+    c.adv = c.drawn && part == 2;                                           /* the row ends with a PART_RIGHT sub-line (renderpcm.cpp:929-935) */
+    c.part = part > 2 ? 0u : part;                                          /* :771-773 */
+    return c;
+}
+
+template <class R> __device__ inline void count_body(const VisArgs &a, uint32_t chunk, int lane)
+{
+    const Rec c = classify((const R *)a.recs, chunk * 64u + (uint32_t)lane, a.n_recs, a.kind);
+    const uint64_t em = __ballot(c.end), am = __ballot(c.adv);
+    if (lane == 0) a.cnt[chunk] = (uint32_t)__popcll(em) | ((uint32_t)__popcll(am) << 16);
+}
+
+template <class R> __device__ inline void index_body(const VisArgs &a, uint32_t chunk, int lane)
+{
+    const uint32_t i = chunk * 64u + (uint32_t)lane;
+    const Rec c = classify((const R *)a.recs, i, a.n_recs, a.kind);
+    const uint64_t em = __ballot(c.end), am = __ballot(c.adv);
+    const uint32_t f = a.base_end[chunk] + (uint32_t)__popcll(em & lanemask_lt(lane)), adv = a.base_adv[chunk] + (uint32_t)__popcll(am & lanemask_lt(lane));
+    if (c.end && f + 1 < a.n_frames) a.frame_adv0[f + 1] = adv;
+    if (i == 0) a.frame_adv0[0] = 0;
+}
+
+/* ---- the lines ------------------------------------------------------------------------------------------------------------- */
+/* What the pixels of one record depend on: the bits of the line MSB first (up to 128) and a handful of colours. */
+struct Look {
+    uint32_t hi_h, hi_l, lo_h, lo_l;    /* bits 0..63 in hi, 64..127 in lo, bit b at position 63 - (b % 64) */
+    uint32_t c0, c1;                    /* a data bit that is 0 / 1 */
+    uint32_t p0, p1;                    /* the same under the Bit Picker's mark (PCM-1, PCM-16x0) */
+    uint32_t aux;                       /* STC-007: bit 0 = CRC valid, bit 1 = CRC valid or markers, bit 2 = markers; PCM-16x0: the control bit's colour */
+    uint32_t pick;                      /* picked_bits_left | picked_bits_right << 8 */
+};
+__device__ inline uint64_t push(uint64_t acc, uint32_t word, int bits) { return (acc << bits) | (uint64_t)(word & ((1u << bits) - 1u)); }
+
+__device__ inline Look look_of(const sdv_line_rec &r)     /* renderpcm.cpp:939-1169 */
+{
+    Look k; k.p0 = k.p1 = k.pick = 0;
+    const bool filler = r.service_type == SDV_SRV_FILLER;   /* a cleared line (stc007line.cpp:69-98): silent words, the read CRC the inverse of CRC_SILENT, no flag set */
+    uint64_t hi = 0, lo = 0;
+    if (!filler) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) hi = push(hi, r.words[w], 14);
+        hi = push(hi, (uint32_t)r.words[4] >> 6, 8);                           /* 4 x 14 + 8 = 64 */
+        lo = push(lo, r.words[4], 6);
+#pragma unroll
+        for (int w = 5; w < 8; w++) lo = push(lo, r.words[w], 14);
+        lo = push(lo, r.words[8], 16);                                         /* 6 + 3 x 14 + 16 = 64 */
+    } else lo = (uint16_t)~0xA96Au;
+    const bool crc = !filler && (r.flags & SDV_LF_CRC_VALID), forced = !filler && (r.flags & SDV_LF_FORCED_BAD);
+    const bool markers = !filler && r.mark_st_stage == 4 /* MARK_ST_BOT_2 */ && r.mark_ed_stage == 3 /* MARK_ED_LEN_OK */;
+    const bool wcrc = !filler && (r.word_state & SDV_WS_WORD_CRC), wvalid = !filler && (r.word_state & SDV_WS_WORD_VALID);
+    if (forced) { k.c0 = B0_MGN; k.c1 = B1_MGN; }
+    else if (wcrc) { k.c0 = B0_GRY; k.c1 = B1_GRY; }
+    else if (wvalid) { k.c0 = B0_GRN; k.c1 = B1_GRN; }
+    else if (markers) { k.c0 = B0_YEL; k.c1 = B1_YEL; }
+    else { k.c0 = B0_RED; k.c1 = B1_RED; }
+    k.aux = (crc ? 1u : 0u) | ((crc || markers) ? 2u : 0u) | (markers ? 4u : 0u);
+    k.hi_h = (uint32_t)(hi >> 32); k.hi_l = (uint32_t)hi; k.lo_h = (uint32_t)(lo >> 32); k.lo_l = (uint32_t)lo;
+    return k;
+}
+/* the colours of a PCM-1 line / PCM-16x0 sub-line (renderpcm.cpp:536-607, 803-876) */
+__device__ inline void colours(Look &k, bool crc, bool forced, bool bw)
+{
+    if (crc) { k.c0 = PX_BLK; k.c1 = B1_GRY; k.p0 = B0_BLU; k.p1 = B1_BLU; }
+    else if (forced) { k.c0 = k.p0 = B0_MGN; k.c1 = k.p1 = B1_MGN; }
+    else if (bw) { k.c0 = k.p0 = B0_YEL; k.c1 = k.p1 = B1_YEL; }
+    else { k.c0 = k.p0 = B0_RED; k.c1 = k.p1 = B1_RED; }
+}
+__device__ inline Look look_of(const sdv_pcm1_bin_rec &r)   /* :489-624 */
+{
+    Look k; k.aux = 0;
+    const bool filler = r.service_type == SDV_SRV_FILLER;   /* pcm1line.cpp:57-77 */
+    uint64_t hi = 0, lo = 0;                                /* 94 bits: 64 + 30 */
+    uint16_t w[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) w[i] = filler ? (i < 6 ? (uint16_t)(1u << 12) : (uint16_t)~0xECBFu) : r.words[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) hi = push(hi, w[i], 13);
+    hi = push(hi, (uint32_t)w[4] >> 1, 12);                 /* 4 x 13 + 12 = 64 */
+    lo = push(lo, w[4], 1); lo = push(lo, w[5], 13); lo = push(lo, w[6], 16);
+    lo <<= 34;                                              /* 30 bits, left-aligned */
+    colours(k, !filler && (r.flags & SDV_LF_CRC_VALID), !filler && (r.flags & SDV_LF_FORCED_BAD), !filler && (r.flags & SDV_LF_BW_SET));
+    k.pick = filler ? 0u : (uint32_t)r.picked_bits_left | ((uint32_t)r.picked_bits_right << 8);
+    k.hi_h = (uint32_t)(hi >> 32); k.hi_l = (uint32_t)hi; k.lo_h = (uint32_t)(lo >> 32); k.lo_l = (uint32_t)lo;
+    return k;
+}
+__device__ inline Look look_of(const sdv_pcm16x0_bin_rec &r)    /* :743-936 */
+{
+    Look k;
+    const bool filler = r.service_type == SDV_SRV_FILLER;   /* pcm16x0subline.cpp:63-86: silent words, control bit set */
+    uint64_t hi = 0;
+    if (!filler) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) hi = push(hi, r.words[i], 16);
+    } else hi = (uint16_t)~0x0E10u;
+    const bool crc = !filler && (r.flags & SDV_LF_CRC_VALID), coords = !filler && (r.flags & SDV_LF_COORDS_SET), control = filler || r.control_bit != 0;
+    colours(k, crc, !filler && (r.flags & SDV_LF_FORCED_BAD), !filler && (r.flags & SDV_LF_BW_SET));
+    k.aux = (!coords || !crc) ? (control ? B1_RED : B0_RED) : (control ? B1_GRY : (uint32_t)PX_BLK);        /* :878-912 */
+    k.pick = filler ? 0u : (uint32_t)r.picked_bits_left | ((uint32_t)r.picked_bits_right << 8);
+    k.hi_h = (uint32_t)(hi >> 32); k.hi_l = (uint32_t)hi; k.lo_h = k.lo_l = 0;
+    return k;
+}
+__device__ inline uint32_t bit_of(const Look &k, uint32_t b)
+{
+    const uint32_t w = b < 32 ? k.hi_h : b < 64 ? k.hi_l : b < 96 ? k.lo_h : k.lo_l;
+    return (w >> (31u - (b & 31u))) & 1u;
+}
+/* the pixel at x of the line / of the sub-line's part of the row (x counted from the part's first pixel) */
+template <class R> __device__ inline uint32_t pixel(const Look &k, uint32_t x, uint32_t part);
+template <> __device__ inline uint32_t pixel<sdv_line_rec>(const Look &k, uint32_t x, uint32_t)
+{
+    const uint32_t b = x / 5u;
+    if (b < 4) return (k.aux & 2u) ? ((b & 1u) ? (uint32_t)B0_GRY : (uint32_t)B1_GRY) : (uint32_t)PX_BLK;       /* START: 1010 */
+    if (b < 132) return bit_of(k, b - 4) ? k.c1 : k.c0;
+    if (b == 132) return (k.aux & 2u) ? (uint32_t)B0_GRY : (uint32_t)PX_BLK;                                    /* STOP: 0 1111 */
+    return (k.aux & 1u) ? (uint32_t)B1_MARK : (k.aux & 4u) ? (uint32_t)B1_GRY : (uint32_t)PX_BLK;
+}
+template <> __device__ inline uint32_t pixel<sdv_pcm1_bin_rec>(const Look &k, uint32_t x, uint32_t)
+{
+    const uint32_t b = x / 8u, pl = k.pick & 0xFFu, pr = k.pick >> 8;
+    const bool picked = b < pl || (int)b > 94 - (int)pr - 1;
+    const uint32_t v = bit_of(k, b);
+    return picked ? (v ? k.p1 : k.p0) : (v ? k.c1 : k.c0);
+}
+template <> __device__ inline uint32_t pixel<sdv_pcm16x0_bin_rec>(const Look &k, uint32_t x, uint32_t part)
+{
+    const uint32_t b = x / 4u, pl = k.pick & 0xFFu, pr = k.pick >> 8;
+    if (b >= 64) return k.aux;                      /* the control bit behind the middle sub-line */
+    const bool picked = b < pl || (int)b > 64 - (int)pr - 1;
+    const uint32_t v = bit_of(k, b);
+    return picked ? (v ? k.p1 : k.p0) : (v ? k.c1 : k.c0);
+}
+
+template <class R> __device__ inline void draw_body(const VisArgs &a, uint32_t chunk, int lane)
+{
+    const R *recs = (const R *)a.recs;
+    const Geometry g = geometry(a.kind);
+    const uint32_t i = chunk * 64u + (uint32_t)lane;
+    const Rec c = classify(recs, i, a.n_recs, a.kind);
+    const uint64_t em = __ballot(c.end), am = __ballot(c.adv);
+    const uint32_t f = a.base_end[chunk] + (uint32_t)__popcll(em & lanemask_lt(lane)), adv = a.base_adv[chunk] + (uint32_t)__popcll(am & lanemask_lt(lane));
+    bool live = c.drawn && f < a.n_frames;          /* records behind the last END_FRAME belong to a frame that has not ended */
+    uint32_t row = 0;
+    if (live) { row = adv - a.frame_adv0[f]; live = row < g.h; }       /* "line overflow": the canvas is full (renderpcm.cpp:955-961) */
+    if (live && g.cells_per_row > 1 && !c.adv) {
+        /* a left or middle sub-line is drawn over by the next one of its kind that comes before the row ends */
+        for (uint32_t j = i + 1; j < a.n_recs; j++) {
+            const Rec n = classify(recs, j, a.n_recs, a.kind);
+            if (n.end || n.adv) break;
+            if (n.drawn && n.part == c.part) { live = false; break; }
+        }
+    }
+    Look k = Look();
+    if (live) {
+        k = look_of(recs[i]);
+        const uint32_t cell = row * g.cells_per_row + c.part;
+        atomicOr(&a.wmask[(size_t)f * a.wmask_stride + cell / 32u], 1u << (cell % 32u));
+    }
+    const uint64_t lm = __ballot(live);
+    for (int j = 0; j < 64; j++) {
+        if (!((lm >> j) & 1ull)) continue;
+        Look kj;
+        kj.hi_h = (uint32_t)__shfl((int)k.hi_h, j); kj.hi_l = (uint32_t)__shfl((int)k.hi_l, j); kj.lo_h = (uint32_t)__shfl((int)k.lo_h, j); kj.lo_l = (uint32_t)__shfl((int)k.lo_l, j);
+        kj.c0 = (uint32_t)__shfl((int)k.c0, j); kj.c1 = (uint32_t)__shfl((int)k.c1, j); kj.p0 = (uint32_t)__shfl((int)k.p0, j); kj.p1 = (uint32_t)__shfl((int)k.p1, j);
+        kj.aux = (uint32_t)__shfl((int)k.aux, j); kj.pick = (uint32_t)__shfl((int)k.pick, j);
+        const uint32_t fj = (uint32_t)__shfl((int)f, j), rowj = (uint32_t)__shfl((int)row, j), partj = (uint32_t)__shfl((int)c.part, j);
+        uint32_t x0, x1;
+        cell_span(a.kind, partj, x0, x1);
+        uint32_t *dst = a.out + ((size_t)fj * g.h + rowj) * g.w + x0;
+        for (uint32_t x = (uint32_t)lane; x < x1 - x0; x += 64u) dst[x] = pixel<R>(kj, x, partj);
+    }
+}
+
+/* ---- what a frame did not draw stays as it was ---------------------------------------------------------------------------------- */
+/* A cell a frame did not draw shows what the last frame before it that drew the cell put there (or the canvas kept from before the
+ * call): always pixels the line pass wrote, never pixels of this pass, so every (frame, cell) is on its own once it knows that frame.
+ * last_body finds it for every frame of a cell (one wave per cell walking the frames' bitmaps, 64 frames a step); fill_body copies,
+ * one wave per frame and 64 cells - a frame's rows are neighbours in memory, the source rows are few and stay in L2. */
+__device__ inline void last_body(const VisArgs &a, uint32_t cell, int lane)
+{
+    int32_t last = -1;              /* -1: the canvas kept from before */
+    for (uint32_t f0 = 0; f0 < a.n_frames; f0 += 64u) {
+        const uint32_t f = f0 + (uint32_t)lane;
+        const uint64_t wm = __ballot(f < a.n_frames && ((a.wmask[(size_t)f * a.wmask_stride + cell / 32u] >> (cell % 32u)) & 1u));
+        const uint64_t upto = wm & (lanemask_lt(lane) | (1ull << lane));
+        if (f < a.n_frames) a.last_drawn[(size_t)f * a.n_cells + cell] = upto ? (int32_t)f0 + 63 - (int32_t)__clzll((long long)upto) : last;
+        if (wm) last = (int32_t)f0 + 63 - (int32_t)__clzll((long long)wm);
+    }
+}
+__device__ inline void fill_body(const VisArgs &a, uint32_t block, int lane)
+{
+    const Geometry g = geometry(a.kind);
+    const uint32_t chunks = (a.n_cells + 63u) / 64u, f = block / chunks, cell = (block % chunks) * 64u + (uint32_t)lane;
+    const int32_t from = cell < a.n_cells ? a.last_drawn[(size_t)f * a.n_cells + cell] : (int32_t)f;
+    uint64_t todo = __ballot(from != (int32_t)f);
+    const size_t frame_px = (size_t)g.w * g.h;
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int32_t fj = __shfl(from, j);
+        const uint32_t cj = (block % chunks) * 64u + (uint32_t)j, row = cj / g.cells_per_row;
+        uint32_t x0, x1;
+        cell_span(a.kind, cj % g.cells_per_row, x0, x1);
+        const size_t at = (size_t)row * g.w + x0;
+        const uint32_t *src = fj < 0 ? a.canvas + at : a.out + (size_t)fj * frame_px + at;
+        uint32_t *dst = a.out + (size_t)f * frame_px + at;
+        for (uint32_t x = (uint32_t)lane; x < x1 - x0; x += 64u) dst[x] = src[x];
+    }
+}
+
+struct BlankArgs { uint32_t *canvas; uint32_t n_px; };
+__device__ inline void blank_body(const BlankArgs &a, uint32_t i) { if (i < a.n_px) a.canvas[i] = BLANK; }
+} // namespace sdvvis
+
+#define SDV_VIS_KERNELS(R, tag) \
+    __global__ void __launch_bounds__(64) sdv_k_vis_count_##tag(sdvvis::VisArgs a) { sdvvis::count_body<R>(a, blockIdx.x, (int)threadIdx.x); } \
+    __global__ void __launch_bounds__(64) sdv_k_vis_index_##tag(sdvvis::VisArgs a) { sdvvis::index_body<R>(a, blockIdx.x, (int)threadIdx.x); } \
+    __global__ void __launch_bounds__(64) sdv_k_vis_draw_##tag(sdvvis::VisArgs a) { sdvvis::draw_body<R>(a, blockIdx.x, (int)threadIdx.x); }
+SDV_VIS_KERNELS(sdv_line_rec, stc007)
+SDV_VIS_KERNELS(sdv_pcm1_bin_rec, pcm1)
+SDV_VIS_KERNELS(sdv_pcm16x0_bin_rec, pcm16x0)
+__global__ void __launch_bounds__(64) sdv_k_vis_last(sdvvis::VisArgs a) { sdvvis::last_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_vis_fill(sdvvis::VisArgs a) { sdvvis::fill_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_vis_blank(sdvvis::BlankArgs a) { sdvvis::blank_body(a, blockIdx.x * 64u + threadIdx.x); }

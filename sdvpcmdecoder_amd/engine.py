@@ -35,6 +35,7 @@ TYPE_M2 = 3                      # VideoToDigital::TYPE_M2 (videotodigital.h:77)
 MODE_DRAFT, MODE_FAST, MODE_NORMAL, MODE_INSANE = 0, 1, 2, 3
 FLAG_NEW_FILE, FLAG_DOUBLED, FLAG_END_FILE = 1, 2, 4
 FRAME_EMPTY = 1                 # sdv_set_frame_flags: SDV_FRAME_EMPTY
+VIS_STC007_LINES, VIS_PCM1_LINES, VIS_PCM16X0_LINES = 0, 1, 2       # sdv_vis_render_lines: SDV_VIS_*
 
 
 class BinPreset(C.Structure):
@@ -130,6 +131,9 @@ def load_library(path: str | None = None):
     lib.sdv_set_frame_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_needs_double_width.argtypes = [C.c_int]
     lib.sdv_double_width.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.sdv_vis_canvas_size.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.sdv_vis_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.sdv_vis_render_lines.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
     lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
     lib.sdv_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -295,6 +299,30 @@ class Engine:
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
         self._check(self.lib.sdv_double_width(self._h, C.c_void_p(luma.data_ptr()), w, w, rows, C.c_void_p(out.data_ptr()), 2 * w, sptr))
         return out
+
+    # ---- visualiser feed (RenderPCM's canvas of binarized lines) ----
+    def vis_canvas_size(self, kind: int):
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        self._check(self.lib.sdv_vis_canvas_size(kind, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def vis_reset(self, kind: int, stream=None):
+        import torch
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self.lib.sdv_vis_reset(self._h, kind, sptr))
+
+    def vis_render_lines(self, kind: int, recs, n_frames: int, stream=None):
+        """sdv_vis_render_lines: `recs` = (n, record size) uint8 CUDA tensor of the kind's line records holding `n_frames` whole frames
+        -> (n_frames, height, width) int32 CUDA tensor of 32-bit pixels (view it as uint32 on the host)."""
+        import torch
+        assert recs.is_cuda and recs.dtype == torch.uint8 and recs.is_contiguous()
+        w, h = self.vis_canvas_size(kind)
+        out = torch.empty((max(n_frames, 1), h, w), dtype=torch.int32, device=recs.device)
+        got = C.c_size_t(0)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(recs.device).cuda_stream)
+        self._check(self.lib.sdv_vis_render_lines(self._h, kind, C.c_void_p(recs.data_ptr()), recs.shape[0], C.c_void_p(out.data_ptr()), n_frames,
+                                                  C.byref(got), sptr))
+        return out[:got.value]
 
     # ---- stream state as bytes (checkpoints, hand-over between the GPUs of a sharded stream) ----
     def get_chain_state(self) -> bytes:

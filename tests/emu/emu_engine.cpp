@@ -20,6 +20,7 @@ struct uint2 { uint32_t x, y; };
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_frames_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_stitch_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/audio_device.h"
+#include "../../sdvpcmdecoder_amd/csrc/vis_device.h"
 #include "../../sdvpcmdecoder_amd/csrc/engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/stitch_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm1_engine.inc"
@@ -27,6 +28,7 @@ struct uint2 { uint32_t x, y; };
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_frames_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/pcm16_engine.inc"
 #include "../../sdvpcmdecoder_amd/csrc/audio_engine.inc"
+#include "../../sdvpcmdecoder_amd/csrc/vis_engine.inc"
 
 /* ---- test hooks (emulator build only) -------------------------------------------------------------------------------------------- */
 /* bursts_word (64 blocks per call, mask arithmetic) against bursts_block (one block per call) on random flag sequences: returns the number of

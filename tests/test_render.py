@@ -1,0 +1,179 @@
+"""The canvases of RenderPCM's binarized-lines visualiser (sdv_vis_render_lines).
+  -m "not gpu": the oracle (oracle/render.c) against the real RenderPCM (when the reference build is loadable) and against the fixtures
+                the real RenderPCM made; the product's kernels in the SIMT emulator against the oracle.
+  -m gpu:       the product on the GPU against the oracle and the fixtures."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import libs
+import render_api as ra
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _masked(canvases, mask):
+    return np.where(mask, canvases, 0)
+
+
+def _diff(got, want, mask):
+    d = np.argwhere(mask & (got != want))
+    return f"{len(d)} pixels differ, first (frame, row, x) {d[:4].tolist()}: got {[hex(got[tuple(x)]) for x in d[:4]]} want {[hex(want[tuple(x)]) for x in d[:4]]}"
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("name", list(ra.CASES))
+def test_oracle_matches_live_reference(name, oracle_lib):
+    """Every pixel some frame has drawn so far equals the real RenderPCM's (the rest of its canvas is uninitialised memory)."""
+    if not libs.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available")
+    kind, recs = ra.make_input(name)
+    out, _ = ra.run_oracle(kind, recs)
+    ref = ra.run_ref(kind, recs)
+    mask = ra.written(kind, recs)
+    assert (_masked(out, mask) == _masked(ref, mask)).all(), _diff(out, ref, mask)
+    assert (out[~mask] == ra.BLANK).all()
+
+
+@pytest.mark.parametrize("name", ra.GOLDEN)
+def test_oracle_matches_golden(name, oracle_lib):
+    z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
+    kind, recs = ra.make_input(name)
+    assert ra.hashlib.sha256(recs.tobytes()).hexdigest() == str(z["input_sha256"]), "regenerated record stream differs from the fixture's"
+    out, _ = ra.run_oracle(kind, recs)
+    mask = ra.written(kind, recs)
+    assert ra.digest(out, mask) == str(z["canvases_sha256"])
+    last = z["last_canvas"]                      # the real RenderPCM's last canvas, drawn pixels only
+    assert (_masked(out[-1], mask[-1]) == last).all(), _diff(out[-1:], last[None], mask[-1:])
+
+
+def test_canvas_is_kept_between_calls(oracle_lib):
+    """Frame by frame on one canvas = all frames in one go."""
+    kind, recs = ra.make_input("pcm16_shrinking")
+    whole, _ = ra.run_oracle(kind, recs)
+    ends = np.nonzero(recs["service_type"] == ra.SRV_END_FRAME)[0]
+    canvas, lo, parts = None, 0, []
+    for e in ends:
+        out, canvas = ra.run_oracle(kind, recs[lo:e + 1], canvas)
+        parts.append(out)
+        lo = e + 1
+    assert (np.concatenate(parts) == whole).all()
+
+
+# ---- the product's kernels in the SIMT emulator ------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emu(emu_lib):
+    lib = emu_lib
+    lib.sdv_engine_create.restype = C.c_void_p
+    lib.sdv_engine_destroy.argtypes = [C.c_void_p]
+    lib.sdv_last_error.restype = C.c_char_p
+    lib.sdv_last_error.argtypes = [C.c_void_p]
+    lib.sdv_vis_render_lines.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    lib.sdv_vis_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.sdv_vis_canvas_size.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    return lib
+
+
+def _emu_run(emu, eng, kind, recs, cap=None):
+    w, h = ra.SIZE[kind]
+    n = ra.n_frames(recs) if cap is None else cap
+    out = np.zeros((max(n, 1), h, w), dtype=np.uint32)
+    got = C.c_size_t(0)
+    recs = np.ascontiguousarray(recs)
+    rc = emu.sdv_vis_render_lines(eng, kind, recs.ctypes.data, len(recs), out.ctypes.data, n, C.byref(got), None)
+    return rc, out[:min(got.value, n)], got.value
+
+
+@pytest.mark.parametrize("name", list(ra.CASES))
+def test_emu_matches_oracle(name, emu):
+    kind, recs = ra.make_input(name)
+    want, _ = ra.run_oracle(kind, recs)
+    eng = emu.sdv_engine_create(0)
+    rc, out, n = _emu_run(emu, eng, kind, recs)
+    emu.sdv_engine_destroy(eng)
+    assert rc == 0 and n == len(want)
+    assert (out == want).all(), _diff(out, want, np.ones_like(want, dtype=bool))
+
+
+def test_emu_calls_continue_on_the_kept_canvas(emu):
+    """Two calls = one call; a reset in between starts from a blank canvas; a buffer that is too small is refused with the count."""
+    kind, recs = ra.make_input("stc_shrinking")
+    want, _ = ra.run_oracle(kind, recs)
+    ends = np.nonzero(recs["service_type"] == ra.SRV_END_FRAME)[0]
+    cut = ends[0] + 1
+    eng = emu.sdv_engine_create(0)
+    rc, a, _ = _emu_run(emu, eng, kind, recs[:cut])
+    assert rc == 0
+    rc, b, n = _emu_run(emu, eng, kind, recs[cut:], cap=1)
+    assert rc != 0 and n == 3 and b"3 canvases" in emu.sdv_last_error(eng)
+    rc, b, _ = _emu_run(emu, eng, kind, recs[cut:])
+    assert rc == 0 and (np.concatenate([a, b]) == want).all()
+    assert emu.sdv_vis_reset(eng, kind, None) == 0
+    rc, c, _ = _emu_run(emu, eng, kind, recs[cut:])
+    fresh, _ = ra.run_oracle(kind, recs[cut:])
+    assert rc == 0 and (c == fresh).all()
+    rc, d, n = _emu_run(emu, eng, kind, recs[cut:ends[1]])         # no frame ends in these records: nothing is handed out
+    assert rc == 0 and n == 0
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    assert emu.sdv_vis_canvas_size(kind, C.byref(w), C.byref(h)) == 0 and (w.value, h.value) == ra.SIZE[kind]
+    assert emu.sdv_vis_canvas_size(7, C.byref(w), C.byref(h)) != 0
+    emu.sdv_engine_destroy(eng)
+
+
+# ---- the product on the GPU --------------------------------------------------------------------------------------------------------
+def _gpu_run(eng, kind, recs, torch):
+    d = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), recs.dtype.itemsize)).cuda()
+    out = eng.vis_render_lines(kind, d, ra.n_frames(recs))
+    return out.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ra.CASES))
+def test_gpu_matches_oracle(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    kind, recs = ra.make_input(name)
+    want, _ = ra.run_oracle(kind, recs)
+    out = _gpu_run(Engine(0), kind, recs, torch)
+    assert out.shape == want.shape and (out == want).all(), _diff(out, want, np.ones_like(want, dtype=bool))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ra.GOLDEN)
+def test_gpu_matches_golden_from_reference(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
+    kind, recs = ra.make_input(name)
+    assert ra.hashlib.sha256(recs.tobytes()).hexdigest() == str(z["input_sha256"])
+    out = _gpu_run(Engine(0), kind, recs, torch)
+    mask = ra.written(kind, recs)
+    assert ra.digest(out, mask) == str(z["canvases_sha256"])
+    assert (_masked(out[-1], mask[-1]) == z["last_canvas"]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_frames_entry_to_canvas_in_batches():
+    """The records of the frame entry drawn in two calls = in one call = the oracle on the oracle's records (200 frames: the pass that
+    carries undrawn rows over walks several groups of 64 frames)."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, synth
+    import oracle_run
+    luma = synth.stc007_frames(200, seed=77, height=24, noise_sigma=5.0)[0]
+    luma[::7, ::5] = 16                                   # some rows lost
+    want_recs = oracle_run.oracle_binarize(luma, mode=2)[0]
+    want, _ = ra.run_oracle(ra.STC007, want_recs)
+    eng = Engine(0)
+    recs, _ = eng.binarize_frames(torch.from_numpy(luma).cuda(), new_file=True)
+    n_rec = recs.shape[0]
+    assert bytes(recs.cpu().numpy().tobytes()) == want_recs.tobytes()
+    one = eng.vis_render_lines(ra.STC007, recs, 200).cpu().numpy().view(np.uint32)
+    assert (one == want).all()
+    eng.vis_reset(ra.STC007)
+    ends = np.nonzero(want_recs["service_type"] == ra.SRV_END_FRAME)[0]
+    cut = int(ends[130]) + 1
+    a = eng.vis_render_lines(ra.STC007, recs[:cut].contiguous(), 131).cpu().numpy().view(np.uint32)
+    b = eng.vis_render_lines(ra.STC007, recs[cut:n_rec].contiguous(), 69).cpu().numpy().view(np.uint32)
+    assert (np.concatenate([a, b]) == want).all()
