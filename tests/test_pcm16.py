@@ -2,6 +2,7 @@
   oracle (oracle/pcm16.c)  vs  golden fixtures of the real reference and - when the reference build is loadable - the real
                                PCM16X0Deinterleaver / PCM16X0DataStitcher run live on every scenario;
   HIP kernel source        vs  the oracle, on the SIMT emulator (CPU) and through the C-ABI on the GPU (-m gpu)."""
+import ctypes as C
 import hashlib
 import os
 
@@ -183,6 +184,14 @@ def test_emu_failed_call_leaves_the_stream_untouched(emu, oracle_lib):
     emu.sdv_engine_destroy(eng)
     pairs, frames = np.concatenate([p0, p1_]), np.concatenate([f0, f1])
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def test_emu_burst_counters_as_mask_arithmetic(emu):
+    """bursts_word (the analysis' burst counters on 64 blocks at once, pcm16_stitch_device.h) = the block-by-block counters of the reference's
+    sweep (pcm16x0datastitcher.cpp:1380-1462) on 100 000 random flag sequences, SI and EI limits, words cut at random places."""
+    emu.sdv_emu_selftest_bursts.restype = C.c_int
+    emu.sdv_emu_selftest_bursts.argtypes = [C.c_uint64, C.c_int]
+    assert emu.sdv_emu_selftest_bursts(20261002, 100000) == 0
 
 
 def _strangers():
