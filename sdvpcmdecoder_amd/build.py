@@ -64,6 +64,8 @@ def build_hip(force=False):
            "-o", HIP_LIB, os.path.join(csrc, "sdvpcm_hip.hip")]
     if os.environ.get("SDVPCM_DEV_AIDS") == "1":        # a developer build: the scheduler trace etc. can be switched on through the environment
         cmd.insert(1, "-DSDV_DEV_AIDS")
+        for d in os.environ.get("SDVPCM_DEV_DEFINES", "").split():       # experiments: extra -D switches of a developer build
+            cmd.insert(1, "-D" + d)
     subprocess.check_call(cmd, cwd=csrc)
     return HIP_LIB
 

@@ -286,6 +286,21 @@ struct WsSrc {
     const SLine *q;
     __device__ inline sdv_deint_line line(size_t i) const { return view(q[i]); }
 };
+/* A window of the queue in LDS for the loops that decode block i from lines i, i + 16, ..., i + 112, 64 blocks a step: the 176
+ * lines of a step as sdv_deint_line (24 B) in a ring of 256, so that the 64 lines of the next step can arrive while this one is
+ * decoded.  One round trip to the queue (L2 / Infinity Cache) per step instead of eight gathers per lane. */
+enum { RING = 256, RING_SPAN = 64 + MIN_DEINT };
+/* The lanes of the one wave of a workgroup exchange data through LDS: the hardware runs a wave's LDS operations in order, all that is
+ * needed is that the compiler keeps them in order too.  (__syncthreads would also wait for every load in flight - the prefetch.) */
+#ifdef SDV_EMU
+#define SDV_LDS_WAVE_SYNC() __syncthreads()
+#else
+#define SDV_LDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+struct RingSrc {
+    const sdv_deint_line *ring;
+    __device__ inline const sdv_deint_line &line(size_t i) const { return ring[i & (RING - 1)]; }
+};
 
 /* ================================================================================================================== */
 /* sdv_k_stitch_analyze: one wave per frame segment                                                                    */
@@ -594,6 +609,7 @@ struct Step {
     uint8_t last_pad_counter, broken_countdown, prob_order, prob_res, push_order;
     bool file_start, file_end;
     SLine *q; int qn;                       /* conv_queue */
+    sdv_deint_line *ring;                   /* LDS, RING entries (RingSrc) */
     int lane;
 
     __device__ inline Field field(int frame, int parity) const
@@ -638,12 +654,19 @@ struct Step {
         const sdv_deint_settings ds = deint_cfg(mode, cfg.ignore_crc, true, cfg.en_p, cfg.en_q, false);
         const int nblk = n - MIN_DEINT;
         uint16_t valid_cnt = 0, silence_cnt = 0, uncheck_cnt = 0, broken_count = 0, valid_max = 0, silence_max = 0, uncheck_max = 0;
+        RingSrc rs; rs.ring = ring;
+        SDV_LDS_WAVE_SYNC();                                          /* whoever used the ring before is done with it */
+        for (int i = lane; i < RING_SPAN && i < n; i += 64) ring[i] = pq.line((size_t)i);
         for (int c = 0; c * 64 < nblk; c++) {
             int i = c * 64 + lane;
             bool v = false, sl = false, u = false, br = false;
+            const int nx = c * 64 + RING_SPAN + lane;                 /* the next step's new lines: asked for now, stored behind this step's decodes */
+            const bool has_nx = nx < n && (c + 1) * 64 < nblk;
+            sdv_deint_line nxl; if (has_nx) nxl = pq.line((size_t)nx);
+            SDV_LDS_WAVE_SYNC();
             if (i < nblk) {
                 Block b; sdvd::Lines8 l8;
-                sdvd::gather8(pq, (size_t)i, l8);
+                sdvd::gather8(rs, (size_t)i, l8);
                 sdvd::process_block(ds, l8, 0, b);
                 bool silent = blk_silent(b, cfg.m2), force = can_force_check(b);
                 v = blk_valid(b) && !silent && force;
@@ -669,6 +692,7 @@ struct Step {
                 else { if (uncheck_cnt > uncheck_max) uncheck_max = uncheck_cnt; uncheck_cnt = 0; }
                 if ((mb >> j) & 1) { broken_count++; if (broken_count >= MAX_BURST_BROKEN) valid_cnt = 0; }
             }
+            if (has_nx) ring[nx & (RING - 1)] = nxl;
         }
         if (valid_cnt > valid_max) valid_max = valid_cnt;
         if (silence_cnt > silence_max) silence_max = silence_cnt;
@@ -1308,6 +1332,13 @@ struct Step {
         p.audio_word[0] = p.audio_word[1] = 0; p.sample_flags[0] = p.sample_flags[1] = 0; p.sample_rate = 44056; p.emphasis = 0; p.service_type = srv; p._pad = 0;
         return p;
     }
+    uint32_t *pairbuf;                      /* LDS: 64 x 3 pairs as dwords */
+    __device__ static inline void pack_pair(const sdv_sample_pair &p, uint32_t *o)
+    {
+        o[0] = (uint32_t)(uint16_t)p.audio_word[0] | ((uint32_t)(uint16_t)p.audio_word[1] << 16);
+        o[1] = (uint32_t)p.sample_flags[0] | ((uint32_t)p.sample_flags[1] << 8) | ((uint32_t)p.sample_rate << 16);
+        o[2] = (uint32_t)p.emphasis | ((uint32_t)p.service_type << 8) | ((uint32_t)p._pad << 16);
+    }
     __device__ inline sdv_sample_pair make_pair(const Block &b, int il, int ir, uint16_t rate) const
     {
         sdv_sample_pair p = service_pair(SDV_PAIR_SRV_NO);
@@ -1326,7 +1357,9 @@ struct Step {
     __device__ inline void perform_deinterleave()
     {
         const int nblk = qn > MIN_DEINT ? qn - MIN_DEINT : 0;
-        WsSrc src; src.q = q;
+        RingSrc src; src.ring = ring;
+        __syncthreads();                                              /* whoever used the ring before is done with it */
+        for (int i = lane; i < RING_SPAN && i < qn; i += 64) ring[i] = view(q[i]);
         uint16_t rate = (cfg.preset_sample_rate == 44100 || cfg.preset_sample_rate == 44056) ? cfg.preset_sample_rate
                         : (f1.video_standard == VID_NTSC ? (uint16_t)44056 : (uint16_t)44100);        /* setBlockSampleRate :6455-6480 */
         uint8_t cd = broken_countdown;
@@ -1334,6 +1367,11 @@ struct Step {
         for (int c = 0; c * 64 < nblk; c++) {
             const int i = c * 64 + lane;
             const bool act = i < nblk;
+            /* the next step's new lines: asked for now, stored behind this step's decodes */
+            const int nx = c * 64 + RING_SPAN + lane;
+            const bool has_nx = nx < qn && (c + 1) * 64 < nblk;
+            SLine nxl; if (has_nx) nxl = q[nx];
+            SDV_LDS_WAVE_SYNC();
             Block b; sdvd::blk_clear(b);
             bool ns = false, seam = false, brk = false;
             if (act) {
@@ -1381,10 +1419,19 @@ struct Step {
                 brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
                 for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
             }
+            /* the 64 blocks' 192 pairs are one stretch of 2 304 bytes: through LDS, then whole dwords side by side */
             if (act) {
-                sdv_sample_pair *o = out_pairs + n_pairs + 3u * (uint32_t)i;
-                if (n_pairs + 3u * (uint32_t)i + 3u <= pair_cap) { o[0] = make_pair(b, 0, 1, rate); o[1] = make_pair(b, 2, 3, rate); o[2] = make_pair(b, 4, 5, rate); }
+                uint32_t *pb = pairbuf + 9 * lane;
+                pack_pair(make_pair(b, 0, 1, rate), pb); pack_pair(make_pair(b, 2, 3, rate), pb + 3); pack_pair(make_pair(b, 4, 5, rate), pb + 6);
             }
+            SDV_LDS_WAVE_SYNC();
+            {
+                const uint32_t first = n_pairs + 192u * (uint32_t)c;
+                uint32_t *o32 = (uint32_t *)out_pairs + 3u * (size_t)first;
+                for (uint32_t d = (uint32_t)lane; d < 9u * (uint32_t)cnt; d += 64u)
+                    if (first + 3u * (d / 9u) + 3u <= pair_cap) o32[d] = pairbuf[d];          /* a block's three pairs fit or none of them is written */
+            }
+            if (has_nx) ring[nx & (RING - 1)] = view(nxl);             /* slots of lines this step no longer reads */
         }
         if (nblk > 0) {
             f1.blocks_total = (uint16_t)(f1.blocks_total + nblk);
@@ -1423,7 +1470,7 @@ __device__ inline void reset_state(Step &s)      /* resetState :69-89 (the stati
 #else
 #define ST_STAMP(i) do { if (a.timing && lane == 0) a.timing[(size_t)k * 8 + (i)] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
 #endif
-__device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot, int lane, SLine *q_lds = NULL)
+__device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot, int lane, sdv_deint_line *ring, uint32_t *pairbuf, SLine *q_lds = NULL)
 {
     const uint32_t k = work & 0x3FFFFFFFu;
     const int w_prev = (work >> 30) & 1, w_cur = (work >> 31) & 1;
@@ -1434,7 +1481,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     Step s;
     s.cfg = a.cfg; s.fields = a.fields; s.k = k; s.lane = lane;
     s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2);
-    s.q = q_lds ? q_lds : a.ws + (size_t)slot * QCAP; s.overflow = false;
+    s.q = q_lds ? q_lds : a.ws + (size_t)slot * QCAP; s.overflow = false; s.ring = ring; s.pairbuf = pairbuf;
     s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     const bool direct = a.direct_pairs != NULL;
     s.out_pairs = direct ? a.direct_pairs + (size_t)k * a.guess_pairs : a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
@@ -1619,6 +1666,8 @@ __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 #endif
 __global__ void __launch_bounds__(64, SDV_ST_WAVES) sdv_k_stitch_step(sdvs::StepArgs a)
 {
+    __shared__ sdv_deint_line ring[sdvs::RING];
+    __shared__ uint32_t pairbuf[64 * 9];
     for (;;) {
         uint32_t w = 0;
         if (threadIdx.x == 0) w = atomicAdd(a.next_work, 1u);
@@ -1626,9 +1675,9 @@ __global__ void __launch_bounds__(64, SDV_ST_WAVES) sdv_k_stitch_step(sdvs::Step
         if (w >= a.n_work) break;
 #if defined(SDV_ST_QUEUE_LDS) && !defined(SDV_EMU)
         __shared__ sdvs::SLine q_lds[sdvs::QCAP];          /* experiment: conv_queue of the turn in LDS (32 KB per wave) */
-        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x, q_lds);
+        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x, ring, pairbuf, q_lds);
 #else
-        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x);
+        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x, ring, pairbuf);
 #endif
     }
 }
