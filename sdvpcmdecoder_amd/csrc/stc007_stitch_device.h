@@ -286,21 +286,6 @@ struct WsSrc {
     const SLine *q;
     __device__ inline sdv_deint_line line(size_t i) const { return view(q[i]); }
 };
-/* A window of the queue in LDS for the loops that decode block i from lines i, i + 16, ..., i + 112, 64 blocks a step: the 176
- * lines of a step as sdv_deint_line (24 B) in a ring of 256, so that the 64 lines of the next step can arrive while this one is
- * decoded.  One round trip to the queue (L2 / Infinity Cache) per step instead of eight gathers per lane. */
-enum { RING = 256, RING_SPAN = 64 + MIN_DEINT };
-/* The lanes of the one wave of a workgroup exchange data through LDS: the hardware runs a wave's LDS operations in order, all that is
- * needed is that the compiler keeps them in order too.  (__syncthreads would also wait for every load in flight - the prefetch.) */
-#ifdef SDV_EMU
-#define SDV_LDS_WAVE_SYNC() __syncthreads()
-#else
-#define SDV_LDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#endif
-struct RingSrc {
-    const sdv_deint_line *ring;
-    __device__ inline const sdv_deint_line &line(size_t i) const { return ring[i & (RING - 1)]; }
-};
 
 /* ================================================================================================================== */
 /* sdv_k_stitch_analyze: one wave per frame segment                                                                    */
@@ -324,21 +309,46 @@ template <class T> __device__ inline void make_uniform(T &x)
     __builtin_memcpy(&x, w, sizeof(T));
 }
 
+/* A window of the queue in LDS for the loops that decode block i from lines i, i + 16, ..., i + 112, 64 blocks a step: the 176
+ * lines of a step as sdv_deint_line (24 B) in a ring of 256, so that the 64 lines of the next step can arrive while this one is
+ * decoded.  One round trip to the queue (L2 / Infinity Cache) per step instead of eight gathers per lane. */
+enum { RING = 256, RING_SPAN = 64 + MIN_DEINT, RING_SMALL = 192 };    /* RING_SMALL: the analysis kernel's, in the LDS its first phases used */
+/* The lanes of the one wave of a workgroup exchange data through LDS: the hardware runs a wave's LDS operations in order, all that is
+ * needed is that the compiler keeps them in order too.  (__syncthreads would also wait for every load in flight - the prefetch.) */
+#ifdef SDV_EMU
+#define SDV_LDS_WAVE_SYNC() __syncthreads()
+#else
+#define SDV_LDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+
+template <int N> struct RingSrcN {
+    const sdv_deint_line *ring;
+    __device__ inline const sdv_deint_line &line(size_t i) const { return ring[(uint32_t)i % (uint32_t)N]; }
+};
+typedef RingSrcN<RING> RingSrc;
+
 /* STC007DataStitcher::getFieldResolution (stc007datastitcher.cpp:996-1211) for one field buffer, blocks split over the lanes */
-__device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int lane)
+__device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int lane, sdv_deint_line *ring)
 {
     if (cfg.preset_audio_res == SRES_14BIT) return SRES_14BIT;
     if (cfg.preset_audio_res == SRES_16BIT) return SRES_16BIT;
     if (f.size > BUF_FIELD || f.size <= MIN_DEINT) return SRES_UNKNOWN;
     int test = f.size - MIN_DEINT;
     FieldSrc src; src.f = f;
+    RingSrcN<RING_SMALL> rs; rs.ring = ring;
     uint16_t res[2] = { 0, 0 };
+    SDV_LDS_WAVE_SYNC();                                              /* whoever used the ring before is done with it */
+    for (int i = lane; i < RING_SPAN && i < f.size; i += 64) ring[i] = src.line((size_t)i);
     for (int c = 0; c * 64 < test; c++) {
         int i = c * 64 + lane;
         bool act = i < test;
         uint64_t good[2], brk[2];
+        const int nx = c * 64 + RING_SPAN + lane;                     /* the next step's new lines: asked for now, stored behind this step's decodes */
+        const bool has_nx = nx < f.size && (c + 1) * 64 < test;
+        sdv_deint_line nxl; if (has_nx) nxl = src.line((size_t)nx);
+        SDV_LDS_WAVE_SYNC();
         sdvd::Lines8 l8;
-        if (act) sdvd::gather8(src, (size_t)i, l8);
+        if (act) sdvd::gather8(rs, (size_t)i, l8);
         for (int m = 0; m < 2; m++) {
             bool g = false, k = false;
             if (act) {
@@ -358,6 +368,7 @@ __device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int l
                     if ((good[m] >> j) & 1) res[m]++;
                     else if (((brk[m] >> j) & 1) && res[m] > 0) res[m]--;
                 }
+        if (has_nx) ring[(uint32_t)nx % (uint32_t)RING_SMALL] = nxl;  /* slots of lines the next step no longer reads */
     }
     if (res[0] > (ILV * 2)) {
         uint16_t t = (uint16_t)(res[1] * 128);
@@ -374,7 +385,8 @@ enum { AM_G = 1 << 16,          /* data line, CRC valid, not forced bad */
        AM_CI = 1 << 17,         /* data line, CRC valid ignoring "forced bad" */
        AM_MK = 1 << 18,         /* data line with both markers found */
        AM_DATA = 1 << 19, AM_FILLER = 1 << 20, AM_NEW_FILE = 1 << 21, AM_END_FILE = 1 << 22, AM_CTRL = 1 << 23,
-       ANALYZE_LDS = 1024 };    /* records staged per frame; longer segments compute the word from the record on every access */
+       ANALYZE_LDS = 1024,      /* records staged per frame; longer segments compute the word from the record on every access */
+       ANALYZE_LDS_WORDS = 1152 };    /* ... and the same LDS holds the RING_SMALL lines of the resolution trials afterwards */
 struct Rec48 { uint4 q0, q1, q2; };      /* an sdv_line_rec as three 16-byte loads */
 static_assert(sizeof(sdv_line_rec) == 48, "record layout");
 __device__ inline uint32_t rec_meta(const Rec48 &r, uint32_t fnum, bool &bad_number)
@@ -539,7 +551,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
     uint8_t fres[2];
     for (int p = 0; p < 2; p++) {
         Field f; f.lines = field_lines(a.fields, k, p); f.size = (int)cnt[p];
-        fres[p] = field_resolution(a.cfg, f, lane);
+        fres[p] = field_resolution(a.cfg, f, lane, (sdv_deint_line *)meta);
     }
     if (lane == 0) {
         fl->field_res[0] = fres[0]; fl->field_res[1] = fres[1];
@@ -1013,10 +1025,18 @@ struct Step {
     }
 
     /* ---- conv_queue writers (addLinesFromField :4452-4518, addFieldPadding :4521-4571) ---- */
+    /* could performCWD change this line or be changed by it: a word that failed its CRC on a line that is still unrepaired and eligible,
+     * or repaired already (perform_cwd's `mine`, without its frame test).  No such line in the queue (padding lines are none): nothing to scan. */
+    bool cwd_cand;
+    __device__ static inline bool cwd_candidate(const SLine &l)
+    {
+        const bool forced = (l.flags & SL_FORCED_BAD) != 0, failed = forced || ((l.wcrc & 0xFF) != 0xFF);
+        return failed && ((!crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced) || crc_valid(l));
+    }
     __device__ inline uint16_t add_lines(const Field &f, uint16_t start, uint16_t count, uint16_t &last_line)
     {
         if (!(BUF_FIELD >= (int)start && BUF_FIELD >= (int)start + (int)count)) return 0;
-        for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) q[qn + i] = f.get(start + i);
+        for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) { const SLine l = f.get(start + i); cwd_cand |= cwd_candidate(l); q[qn + i] = l; }
         if (count > 0) last_line = (uint16_t)uni((uint32_t)(f.get(start + count - 1).line + 2));
         qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; }
         return count;
@@ -1212,6 +1232,7 @@ struct Step {
          * class only decodes the blocks that touch one: candidate bits of the queue by ballot, then per class. */
         __shared__ uint64_t s_bad[QCAP / 64];
         bool any_bad = false;
+        if (!cfg.ignore_crc && !__ballot(cwd_cand)) return false;     /* no line that entered the queue is a candidate: the common case on a clean tape */
         uint32_t mine = 0;                      /* bit c: line c * 64 + lane is a candidate (loads first, ballots after: they pipeline) */
         for (int c = 0; c * 64 < qn; c++) {
             const int i = c * 64 + lane;
@@ -1489,7 +1510,8 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     s.f0 = in->f0; make_uniform(s.f0);
     s.last_pad_counter = (uint8_t)uni(in->last_pad_counter); s.broken_countdown = (uint8_t)uni(in->broken_countdown);
     s.qn = (int)uni(in->tail_n);
-    for (int i = lane; i < s.qn; i += 64) s.q[i] = in->tail[i];
+    s.cwd_cand = false;
+    for (int i = lane; i < s.qn; i += 64) { const SLine l = in->tail[i]; s.cwd_cand |= Step::cwd_candidate(l); s.q[i] = l; }
     /* waitForTwoFrames / findFramesTrim / splitFramesToFields results come from the analysis pass */
     frasm_clear(s.f1); frasm_clear(s.f2);
     s.f1.frame_number = s.l1.frame_number; s.f2.frame_number = s.l2.frame_number;
@@ -1655,7 +1677,8 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 {
-    __shared__ uint32_t meta[sdvs::ANALYZE_LDS];
+    __shared__ uint32_t meta[sdvs::ANALYZE_LDS_WORDS];
+    static_assert(sizeof(meta) >= sdvs::RING_SMALL * sizeof(sdv_deint_line), "the ring of the resolution trials lives in the staging area");
     const uint32_t k = blockIdx.x;
     const uint32_t n = a.seg_end[k] - (k == 0 ? 0u : a.seg_end[k - 1] + 1u);
     if (n <= sdvs::ANALYZE_LDS) sdvs::analyze_body<true>(a, k, (int)threadIdx.x, meta);
