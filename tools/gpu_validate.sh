@@ -38,3 +38,9 @@ grep "it=4" $R/gpurun_out/prof_audio.log
 rm -rf $R/gpurun_out/apmc3 $R/gpurun_out/apmc4
 rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/apmc3 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc3.err; echo "apmc3 rc=$?"
 rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/apmc4 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc4.err; echo "apmc4 rc=$?"
+# visualiser canvases: kernel stats
+rm -rf $R/gpurun_out/prof_vis
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vis -- python3 $R/tools/vis_prof.py 2000 4 > $R/gpurun_out/prof_vis.log 2>&1; echo "rocprof vis rc=$?"
+tail -1 $R/gpurun_out/prof_vis.log
+# PMC passes of the stitch kernels, the PCM-16x0 analysis, the prescans and the audio plan
+bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="

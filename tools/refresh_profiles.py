@@ -3,7 +3,7 @@
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r02'      # the round the summaries are named for
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r03'      # the round the summaries are named for
 
 
 def newest(pat):
@@ -38,6 +38,20 @@ subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_fra
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', f'profiles/{RND}_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
 if glob.glob('gpurun_out/apmc3/**/*_counter_collection.csv', recursive=True):
     subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_ap_prepare', f'profiles/{RND}_pmc_sdv_k_ap_prepare.json', 'apmc', 'tools/audio_prof.py 10000 1: 14.7 M sample pairs per launch, 176.4 MB read + 176.4 MB written algorithmic'], stdout=subprocess.DEVNULL)
+# the PMC sets of tools/gpu_pmc_round3.sh (kernels the round-2 verdict asked counters for) and the visualiser's kernel stats
+for kern, prefix, name, workload in (
+        ('sdv_k_stitch_step', 'stpmc', 'sdv_k_stitch_step', 'tools/stitch_prof.py 10000 2 cont: 10 000-frame NTSC continuing tape, 4096 resident waves work 10 000 turns off a queue'),
+        ('sdv_k_stitch_analyze', 'stpmc', 'sdv_k_stitch_analyze', 'tools/stitch_prof.py 10000 2 cont: 10 001 frames per launch'),
+        ('sdv_k_pcm16_analyse', 'p16spmc', 'sdv_k_pcm16_analyse_si', 'tools/pcm16_prof.py 10000 1 si: 1024 frames per launch (one batch)'),
+        ('sdv_k_pcm16_analyse', 'p16epmc', 'sdv_k_pcm16_analyse_ei', 'tools/pcm16_prof.py 10000 1 ei: 3072 frames per launch (three batches)'),
+        ('sdv_k_pcm1_prescan', 'p1fpre', 'sdv_k_pcm1_prescan', 'tools/pcm1_frames_prof.py 10000 1: 10 000 frames, four prescan lines per frame, last mode of the run (NORMAL)'),
+        ('sdv_k_pcm16_prescan', 'p16fpre', 'sdv_k_pcm16_prescan', 'tools/pcm16_frames_prof.py 10000 1: 10 000 frames, four prescan lines per frame, last mode of the run (NORMAL)'),
+        ('sdv_k_pcm16_frames_bin', 'p16fpre', 'sdv_k_pcm16_frames_bin', 'tools/pcm16_frames_prof.py 10000 1: 10 000 frames per launch, last mode of the run (NORMAL)'),
+        ('sdv_k_ap_plan', 'applan', 'sdv_k_ap_plan', 'tools/audio_prof.py 10000 1: last tape of the run (an invalid word in every window)')):
+    if glob.glob(f'gpurun_out/{prefix}1/**/*_counter_collection.csv', recursive=True):
+        subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', kern, f'profiles/{RND}_pmc_{name}.json', prefix, workload], stdout=subprocess.DEVNULL)
+if glob.glob('gpurun_out/prof_vis/*/*kernel_stats.csv'):
+    trim(newest('gpurun_out/prof_vis/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_vis_kernel_stats.csv')
 d = json.loads(open('gpurun_out/bench_full.json').read().strip().split('\n')[-1])
 if os.path.exists('gpurun_out/prof_audio.log'):
     shutil.copy('gpurun_out/prof_audio.log', f'profiles/{RND}_audio_prof.log')
