@@ -690,6 +690,14 @@ int sdv_decode_frames(sdv_engine *e, int pcm_type, const uint8_t *luma, size_t r
                       sdv_frame_stats *out_stats, size_t stats_cap,
                       int with_audio, int audio_stop, sdv_audio_purge *out_purges, size_t purges_cap, size_t *n_purges, uint64_t *n_masked, void *stream);
 
+/* The data blocks of the stitch stage, for the visualiser: STC007DataStitcher::outputDataBlock hands every block it has turned into three sample
+ * pairs to `newBlockProcessed(STC007DataBlock)` (stc007datastitcher.cpp:6626).  With a block buffer set (device memory, blocks_cap records; NULL:
+ * off, the default), every sdv_stitch_frames call also writes those blocks - as it leaves them: seam / BROKEN masking applied, sample rate set -
+ * in stream order: block j belongs to the sample pairs 3 j .. 3 j + 2 of the call, file-tag pairs not counted.  sdv_stitch_block_count: how many the
+ * last call wrote (or needed, when it failed with SDV_ERR_BAD_ARG for lack of room).  Costs one more launch of the turn kernel per call. */
+int sdv_set_stitch_block_output(sdv_engine *e, sdv_block_rec *out_blocks, size_t blocks_cap);
+size_t sdv_stitch_block_count(sdv_engine *e);
+
 /* ---- visualiser feed: the canvases of RenderPCM's "binarized lines" window ---------------------------------------------------
  * Replaces RenderPCM::renderNewLine(STC007Line / PCM1Line / PCM16X0SubLine) (renderpcm.cpp:939-1169, 489-624, 743-936) as MainWindow drives it
  * for its binarized-lines visualiser (mainwindow.cpp:1949-1990): every line VideoToDigital queues that is no service line, fillers
@@ -707,11 +715,21 @@ int sdv_decode_frames(sdv_engine *e, int pcm_type, const uint8_t *luma, size_t r
  * reference leaves those rows uninitialised).  Records behind the last END_FRAME are not drawn: pass whole frames.  *n_frames = frames in
  * `recs`; more than canvases_cap: SDV_ERR_BAD_ARG, nothing drawn.  Device pointers; the call reads one small array back (the frame count)
  * and leaves the drawing running on `stream`.  sdv_vis_reset: a new canvas (RenderPCM::startNewFrame).
- * The block canvases (renderNewBlock) and the assembled-lines canvas are not rebuilt. */
-enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2 };
+ * The block canvas of STC-007 follows below; those of PCM-1 / PCM-16x0 and the assembled-lines canvas are not rebuilt. */
+enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2, SDV_VIS_STC007_BLOCKS_NTSC = 3, SDV_VIS_STC007_BLOCKS_PAL = 4 };
 int sdv_vis_canvas_size(int kind, uint32_t *width, uint32_t *height);
 int sdv_vis_reset(sdv_engine *e, int kind, void *stream);
 int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_recs, uint32_t *out_canvases, size_t canvases_cap, size_t *n_frames, void *stream);
+/* The data blocks window: RenderPCM::renderNewBlock(STC007DataBlock) (renderpcm.cpp:1770-2051) as MainWindow drives it (mainwindow.cpp:2070-2113):
+ * one row per block - six status bits (P / Q / CWD corrections, block validity, near silence), the six 16-bit samples with every bit in the colour
+ * of its word's state, seven tail bits (seam, emphasis, BROKEN), 6 pixels per bit - and a prepareNewFrame per assembled frame.  kind:
+ * SDV_VIS_STC007_BLOCKS_NTSC (654 x 490) or _PAL (654 x 588; the canvas follows the video standard, setLineCount).  blocks: the device
+ * buffer sdv_set_stitch_block_output filled; frame_blocks: HOST array, how many of them belong to each of the n_frames frames
+ * (sdv_frame_asm::blocks_total of the descriptors that are no file tags); blocks past the canvas' rows are dropped like in the reference.
+ * out_canvases[f] = the canvas after frame f; the engine keeps the last one per kind.  Not covered: M2 sample format (getSample's other branch),
+ * emphasis (the reference never sets it for STC-007, stc007datastitcher.cpp:6719).  Device pointers but frame_blocks; asynchronous on `stream`. */
+int sdv_vis_render_blocks(sdv_engine *e, int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
+                          uint32_t *out_canvases, size_t canvases_cap, void *stream);
 
 #ifdef __cplusplus
 }

@@ -495,11 +495,25 @@ void orc_default_stitch_settings(sdv_stitch_settings *st)
 
 /* feeds all records, runs the stitcher until the queue holds less than two frames; returns number of pairs
  * (<0: output buffer too small) */
+static long stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                       sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks);
 long orc_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                     sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames)
 {
+    return stitch_run(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL, 0, NULL);
+}
+/* ... and the data blocks the stitcher hands to the visualiser (newBlockProcessed), one per three sample pairs */
+long orc_stitch_run_blocks(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                           sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
+{
+    return stitch_run(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, blocks, blocks_cap, n_blocks);
+}
+static long stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                       sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
+{
     orc_stitcher *s = (orc_stitcher *)malloc(sizeof(orc_stitcher));
     orc_stitcher_init(s);
+    s->keep_blocks = blocks != NULL;
     if (st->video_standard < ORC_VID_MAX) s->preset_video_mode = st->video_standard;
     if (st->field_order < ORC_ORDER_MAX) s->preset_field_order = st->field_order;
     s->enable_P_code = st->enable_p; s->enable_Q_code = st->enable_q; s->enable_CWD = st->enable_cwd; s->mode_m2 = st->m2_format;
@@ -526,6 +540,8 @@ long orc_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_se
     size_t nf = s->frames_n < frames_cap ? s->frames_n : frames_cap;
     for (size_t i = 0; i < nf; i++) frasm_to_pod(&s->frames[i], &frames[i]);
     if (n_frames) *n_frames = s->frames_n;
+    if (blocks) { for (size_t i = 0; i < s->blocks_n && i < blocks_cap; i++) block_to_rec(&s->blocks[i], &blocks[i]); }
+    if (n_blocks) *n_blocks = s->blocks_n;
     orc_stitcher_free(s);
     free(s);
     return n;

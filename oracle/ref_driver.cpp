@@ -424,8 +424,8 @@ static void frasm_to_pod(FrameAsmSTC007 &f, sdv_frame_asm *o)
     o->ctrl_index = f.ctrl_index; o->ctrl_hour = f.ctrl_hour; o->ctrl_minute = f.ctrl_minute; o->ctrl_second = f.ctrl_second; o->ctrl_field = f.ctrl_field;
 }
 
-extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
-                               sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames)
+static long ref_stitch_worker(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                               sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
 {
     STC007DataStitcher *ds = new STC007DataStitcher();
     std::deque<STC007Line> in_q;
@@ -435,6 +435,8 @@ extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sd
     ds->setInputPointers(&in_q, &in_mtx);
     ds->setOutputPointers(&out_q, &out_mtx);
     QObject::connect(ds, &STC007DataStitcher::guiUpdFrameAsm, [&](FrameAsmSTC007 d) { fr_mtx.lock(); fr.push_back(d); fr_mtx.unlock(); });
+    size_t blocks_seen = 0;           /* newBlockProcessed: the block as outputDataBlock hands it to the visualiser (:6626), on the stitcher's thread */
+    if (blocks) QObject::connect(ds, &STC007DataStitcher::newBlockProcessed, [&](STC007DataBlock b) { if (blocks_seen < blocks_cap) block_to_rec(b, &blocks[blocks_seen]); blocks_seen++; });
     ds->setVideoStandard(st->video_standard); ds->setFieldOrder(st->field_order);
     ds->setPCorrection(st->enable_p); ds->setQCorrection(st->enable_q); ds->setCWDCorrection(st->enable_cwd);
     ds->setM2SampleFormat(st->m2_format); ds->setResolutionPreset(st->resolution_preset); ds->setSampleRatePreset(st->sample_rate_preset);
@@ -480,8 +482,20 @@ extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sd
     size_t nf = fr.size() < frames_cap ? fr.size() : frames_cap;
     for (size_t i = 0; i < nf; i++) frasm_to_pod(fr[i], &frames[i]);
     if (n_frames) *n_frames = fr.size();
+    if (n_blocks) *n_blocks = blocks_seen;
     delete ds;
     return overflow ? -1 : got;
+}
+
+extern "C" long ref_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                               sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames)
+{
+    return ref_stitch_worker(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL, 0, NULL);
+}
+extern "C" long ref_stitch_run_blocks(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                      sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
+{
+    return ref_stitch_worker(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, blocks, blocks_cap, n_blocks);
 }
 
 /* ------------------------------------------------------------------ PCM-1 back half: the real PCM1DataStitcher */

@@ -97,3 +97,56 @@ extern "C" long ref_vis_render_lines(int kind, const void *recs, size_t n_recs, 
     if (height) *height = h;
     return frames;
 }
+
+/* ---- the data blocks window: renderNewBlock(STC007DataBlock) as MainWindow wires it (mainwindow.cpp:2070-2113): startSTC007DBFrame, setLineCount
+ * with the video standard, a renderNewBlock per block the stitcher put out, prepareNewFrame per assembled frame. ----------------------------- */
+#include "stc007datablock.h"
+/* an sdv_block_rec back into the reference's object through its public interface; returns false for a record the interface cannot express
+ * (a word whose line passed its CRC but that is not valid) */
+static bool to_block(const sdv_block_rec &r, STC007DataBlock &b)
+{
+    bool ok = true;
+    b.clear();
+    b.setResolution(r.resolution);
+    for (uint8_t i = 0; i < 8; i++) {
+        const bool crc = (r.line_crc >> i) & 1, cwd = (r.cwd_fixed >> i) & 1, valid = (r.word_valid >> i) & 1;
+        b.setWord(i, r.words[i], crc, cwd);             /* word_valid = line_crc */
+        if (valid && !crc) b.setFixed(i);
+        if (!valid && crc) ok = false;
+        b.setSource(i, r.w_frame[i], r.w_line[i]);
+    }
+    b.setAudioState(r.audio_state);
+    b.cwd_applied = r.cwd_applied != 0; b.sample_rate = r.sample_rate;
+    return ok;
+}
+
+/* kind: 3 NTSC (490 rows), 4 PAL (588 rows).  frame_blocks[f] blocks belong to frame f.  Returns the frames, -2 if a record cannot be expressed. */
+extern "C" long ref_vis_render_blocks(int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
+                                      uint32_t *out, size_t out_cap, uint32_t *width, uint32_t *height)
+{
+    if (!QCoreApplication::instance()) new QCoreApplication(q_argc, q_argv);
+    RenderPCM ren;
+    long frames = 0;
+    uint32_t w = 0, h = 0;
+    QObject::connect(&ren, &RenderPCM::renderedFrame, [&](QImage img) {
+        w = (uint32_t)img.width(); h = (uint32_t)img.height();
+        if ((size_t)frames < out_cap)
+            for (uint32_t y = 0; y < h; y++) memcpy(out + ((size_t)frames * h + y) * w, img.constScanLine((int)y), (size_t)w * 4);
+        frames++;
+    });
+    ren.setLivePlay(false);
+    ren.startSTC007DBFrame();
+    ren.setLineCount(kind == 4 ? FrameAsmDescriptor::VID_PAL : FrameAsmDescriptor::VID_NTSC);
+    STC007DataBlock b;
+    size_t at = 0;
+    for (size_t f = 0; f < n_frames; f++) {
+        for (uint32_t i = 0; i < frame_blocks[f] && at < n_blocks; i++, at++) {
+            if (!to_block(blocks[at], b)) return -2;
+            ren.renderNewBlock(b);
+        }
+        ren.prepareNewFrame((uint32_t)f); ren.displayIsReady();
+    }
+    if (width) *width = w;
+    if (height) *height = h;
+    return frames;
+}

@@ -19,7 +19,7 @@
 enum { PX_BLK = 2u,                                           /* (QRgb)Qt::black */
        B0_GRY = 0xFF2D2D2Du, B1_GRY = 0xFF969696u, B0_YEL = 0xFF7F6E00u, B1_YEL = 0xFFFFDC00u, B0_GRN = 0xFF005F1Eu, B1_GRN = 0xFF00E146u,
        B0_RED = 0xFF8C0000u, B1_RED = 0xFFFF462Bu, B0_BLU = 0xFF005F7Fu, B1_BLU = 0xFF00BFFFu, B0_MGN = 0xFF8C008Cu, B1_MGN = 0xFFFF00FFu,
-       B1_MARK = 0xFFFFFFFFu };
+       B1_MARK = 0xFFFFFFFFu, LIM_OK = 0xFFFFFFFFu, LIM_MARK = 0xFFE0AAAAu };
 
 void orc_vis_canvas_size(int kind, uint32_t *w, uint32_t *h)
 {
@@ -27,6 +27,8 @@ void orc_vis_canvas_size(int kind, uint32_t *w, uint32_t *h)
         case ORC_VIS_STC007: *w = 5 * 137; *h = 650; break;      /* startSTC007NTSCFrame + setLineCount(VID_UNKNOWN), mainwindow.cpp:1985-1986 */
         case ORC_VIS_PCM1: *w = 8 * 94; *h = 490; break;         /* startPCM1Frame :128-131 */
         case ORC_VIS_PCM16X0: *w = 4 * 193; *h = 490; break;     /* startPCM1600Frame :140-143 */
+        case ORC_VIS_STC007_BLOCKS_NTSC: *w = 6 * (6 + 16 * 6 + 7); *h = 490; break;     /* startSTC007DBFrame :170-173 (+ setLineCount(VID_NTSC)) */
+        case ORC_VIS_STC007_BLOCKS_PAL: *w = 6 * (6 + 16 * 6 + 7); *h = 588; break;      /* ... + setLineCount(VID_PAL), mainwindow.cpp:2093 */
         default: *w = *h = 0;
     }
 }
@@ -157,4 +159,65 @@ long orc_vis_render_lines(int kind, const void *recs, size_t n_recs, uint32_t *c
         else if (pcm16_subline(&((const sdv_pcm16x0_bin_rec *)recs)[i], row)) fill++;
     }
     return frames;
+}
+
+/* ---- the data blocks window (renderNewBlock(STC007DataBlock), renderpcm.cpp:1770-2051) ------------------------------------------------ */
+static int16_t blk_sample(const sdv_block_rec *b, int w) { return b->resolution == SDV_RES_16BIT ? (int16_t)b->words[w] : (int16_t)(b->words[w] << 2); }  /* getSample, not M2 */
+static bool blk_near_silence(const sdv_block_rec *b, int w)     /* isNearSilence :417-446 */
+{
+    const int16_t v = blk_sample(b, w), lim = b->resolution == SDV_RES_16BIT ? 4 : 16;
+    return v < lim && v >= -lim;
+}
+static void stc_block(const sdv_block_rec *b, uint32_t *px)
+{
+    const bool fix_p = b->audio_state == SDV_AUD_FIX_P, fix_q = b->audio_state == SDV_AUD_FIX_Q, broken = b->audio_state == SDV_AUD_BROKEN;
+    const bool valid = (b->word_valid & 0x3F) == 0x3F;                                 /* isBlockValid: no audio word left invalid */
+    const bool cwd_audio = (b->cwd_fixed & 0x3F) != 0;                                  /* isAudioAlteredByCWD */
+    const bool almost_silent = (blk_near_silence(b, 0) || blk_near_silence(b, 2) || blk_near_silence(b, 4)) &&
+                               (blk_near_silence(b, 1) || blk_near_silence(b, 3) || blk_near_silence(b, 5));
+    const bool on_seam = b->w_line[0] > b->w_line[7];                                   /* getStartLine() > getStopLine() */
+    for (int i = 0; i < 6; i++) {                                                        /* the status bar :1793-1861 */
+        uint32_t c = PX_BLK;
+        if (i == 0) { if (fix_p) c = B1_GRN; }
+        else if (i == 1) { if (fix_q) c = B1_YEL; }
+        else if (i == 2) { if (cwd_audio) c = valid ? B1_BLU : B0_BLU; }
+        else if (i == 3) { if (!valid) c = B1_RED; }
+        else if (i == 5) c = almost_silent ? LIM_MARK : LIM_OK;
+        for (int j = 0; j < 6; j++) *px++ = c;
+    }
+    for (int w = 0; w < 6; w++) {                                                        /* the six samples, 16 bits each :1862-1993 */
+        const uint16_t v = (uint16_t)blk_sample(b, w);
+        const bool crc = (b->line_crc >> w) & 1, cwd = (b->cwd_fixed >> w) & 1, wv = (b->word_valid >> w) & 1;
+        for (int bit = 15; bit >= 0; bit--) {
+            const bool one = (v >> bit) & 1;
+            uint32_t c = one ? B1_GRY : PX_BLK;
+            if (broken) { if (!crc) c = one ? B1_MGN : B0_MGN; }
+            else if (fix_q) { if (cwd) c = one ? B1_BLU : B0_BLU; else if (!crc) c = one ? B1_YEL : B0_YEL; }
+            else if (fix_p) { if (cwd) c = one ? B1_BLU : B0_BLU; else if (!crc) c = one ? B1_GRN : B0_GRN; }
+            else if (cwd) c = one ? B1_BLU : B0_BLU;
+            else if (!wv) c = one ? B1_RED : B0_RED;
+            for (int j = 0; j < 6; j++) *px++ = c;
+        }
+    }
+    for (int i = 0; i < 7; i++) {                                                        /* seam, emphasis (never set for STC-007, stc007datastitcher.cpp:6719), BROKEN :1995-2045 */
+        uint32_t c = PX_BLK;
+        if (i == 0) c = on_seam ? LIM_MARK : LIM_OK;
+        else if (i == 4 || i == 5) { if (broken) c = B1_MGN; }
+        for (int j = 0; j < 6; j++) *px++ = c;
+    }
+}
+
+long orc_vis_render_blocks(int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames, uint32_t *canvas,
+                           uint32_t *out, size_t out_cap)
+{
+    uint32_t w, h;
+    orc_vis_canvas_size(kind, &w, &h);
+    if (kind != ORC_VIS_STC007_BLOCKS_NTSC && kind != ORC_VIS_STC007_BLOCKS_PAL) return -1;
+    size_t at = 0;
+    for (size_t f = 0; f < n_frames; f++) {          /* newFrameAssembled -> prepareNewFrame: the canvas goes out, the fill row back to 0 */
+        for (uint32_t i = 0; i < frame_blocks[f] && at < n_blocks; i++, at++)
+            if (i < h) stc_block(&blocks[at], canvas + (size_t)i * w);
+        if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
+    }
+    return (long)n_frames;
 }

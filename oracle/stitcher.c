@@ -122,7 +122,7 @@ void orc_stitcher_init(orc_stitcher *s)   /* :3-38, :7228-7236 */
 void orc_stitcher_free(orc_stitcher *s)
 {
     free(s->trim_buf); free(s->frame1_even); free(s->frame1_odd); free(s->frame2_even); free(s->frame2_odd);
-    free(s->in_lines.v); free(s->padding_queue.v); free(s->conv_queue.v); free(s->out); free(s->frames);
+    free(s->in_lines.v); free(s->padding_queue.v); free(s->conv_queue.v); free(s->out); free(s->frames); free(s->blocks);
     memset(s, 0, sizeof(*s));
 }
 void orc_stitcher_push_line(orc_stitcher *s, const orc_stc_line *l) { dq_push_back(&s->in_lines, l); }
@@ -1116,6 +1116,10 @@ static void perform_deinterleave(orc_stitcher *s)
         }
         if (s->broken_countdown > 0) s->broken_countdown--;
         output_sample_pair(s, &b, 0, 1); output_sample_pair(s, &b, 2, 3); output_sample_pair(s, &b, 4, 5);
+        if (s->keep_blocks) {                                          /* emit newBlockProcessed(*in_block), :6626 */
+            if (s->blocks_n == s->blocks_cap) { s->blocks_cap = s->blocks_cap ? s->blocks_cap * 2 : 1024; s->blocks = (orc_stc_block *)realloc(s->blocks, s->blocks_cap * sizeof(b)); }
+            s->blocks[s->blocks_n++] = b;
+        }
     }
 }
 

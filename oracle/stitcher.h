@@ -58,6 +58,8 @@ typedef struct {
     /* outputs */
     orc_sample_pair *out; size_t out_n, out_cap;
     orc_frasm *frames; size_t frames_n, frames_cap;        /* guiUpdFrameAsm emissions */
+    orc_stc_block *blocks; size_t blocks_n, blocks_cap;    /* newBlockProcessed emissions (outputDataBlock :6626), kept when keep_blocks is set */
+    bool keep_blocks;
 } orc_stitcher;
 
 void orc_stitcher_init(orc_stitcher *s);

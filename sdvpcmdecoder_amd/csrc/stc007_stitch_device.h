@@ -590,6 +590,7 @@ struct StepArgs {
     sdv_sample_pair *direct_pairs; sdv_frame_asm *direct_frasm; uint32_t guess_pairs, guess_frasm;
     uint32_t first_round;
     unsigned long long *timing;             /* optional: 8 cycle stamps per step (SDV_STITCH_TIMING=1), NULL otherwise */
+    sdv_block_rec *blocks; const uint32_t *block_ofs;   /* optional (the visualiser's feed): turn k's data blocks go to blocks[block_ofs[k] ..], newBlockProcessed :6626 */
 };
 
 struct FieldStitchStats { uint16_t index, valid, silent, unchecked, broken; };    /* frametrimset.h:278-300 */
@@ -1354,6 +1355,7 @@ struct Step {
         return p;
     }
     uint32_t *pairbuf;                      /* LDS: 64 x 3 pairs as dwords */
+    sdv_block_rec *blocks_out;              /* this turn's place in the block stream, or NULL */
     __device__ static inline void pack_pair(const sdv_sample_pair &p, uint32_t *o)
     {
         o[0] = (uint32_t)(uint16_t)p.audio_word[0] | ((uint32_t)(uint16_t)p.audio_word[1] << 16);
@@ -1440,6 +1442,14 @@ struct Step {
                 brk_field += (uint32_t)__popcll(__ballot(rep && !valid && b.audio_state == SDV_AUD_BROKEN));
                 for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
             }
+            if (blocks_out && act) {                /* the block as outputDataBlock hands it to the visualiser (newBlockProcessed, :6626) */
+                sdv_block_rec r;
+#pragma unroll
+                for (int w = 0; w < 8; w++) { r.w_frame[w] = b.w_frame[w]; r.w_line[w] = b.w_line[w]; r.words[w] = b.w(w); }
+                r.line_crc = b.line_crc; r.cwd_fixed = b.cwd_fixed; r.word_valid = b.word_valid; r.resolution = b.resolution;
+                r.audio_state = b.audio_state; r.cwd_applied = b.cwd_applied ? 1 : 0; r.sample_rate = rate;
+                blocks_out[i] = r;
+            }
             /* the 64 blocks' 192 pairs are one stretch of 2 304 bytes: through LDS, then whole dwords side by side */
             if (act) {
                 uint32_t *pb = pairbuf + 9 * lane;
@@ -1503,6 +1513,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     s.cfg = a.cfg; s.fields = a.fields; s.k = k; s.lane = lane;
     s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2);
     s.q = q_lds ? q_lds : a.ws + (size_t)slot * QCAP; s.overflow = false; s.ring = ring; s.pairbuf = pairbuf;
+    s.blocks_out = a.blocks ? a.blocks + a.block_ofs[k] : NULL;
     s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     const bool direct = a.direct_pairs != NULL;
     s.out_pairs = direct ? a.direct_pairs + (size_t)k * a.guess_pairs : a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;

@@ -27,6 +27,7 @@ enum { PX_BLK = 2u,                  /* VIS_BIT0_BLK is Qt::black, the GlobalCol
        B0_GRY = 0xFF2D2D2Du, B1_GRY = 0xFF969696u, B0_YEL = 0xFF7F6E00u, B1_YEL = 0xFFFFDC00u, B0_GRN = 0xFF005F1Eu, B1_GRN = 0xFF00E146u,
        B0_RED = 0xFF8C0000u, B1_RED = 0xFFFF462Bu, B0_BLU = 0xFF005F7Fu, B1_BLU = 0xFF00BFFFu, B0_MGN = 0xFF8C008Cu, B1_MGN = 0xFFFF00FFu,
        B1_MARK = 0xFFFFFFFFu,        /* renderpcm.h:53-65 */
+       LIM_OK = 0xFFFFFFFFu, LIM_MARK = 0xFFE0AAAAu,      /* VIS_LIM_OK, VIS_LIM_MARK :66-67 */
        BLANK = 0xFF000000u };        /* a canvas nothing was drawn on: QImage::fill(Qt::black) */
 
 struct Geometry { uint32_t w, h, cells_per_row; };
@@ -36,6 +37,8 @@ __host__ __device__ inline Geometry geometry(int kind)
     if (kind == SDV_VIS_STC007_LINES) { g.w = 5 * 137; g.h = 650; g.cells_per_row = 1; }        /* startSTC007NTSCFrame + setLineCount(VID_UNKNOWN) */
     else if (kind == SDV_VIS_PCM1_LINES) { g.w = 8 * 94; g.h = 490; g.cells_per_row = 1; }      /* startPCM1Frame */
     else if (kind == SDV_VIS_PCM16X0_LINES) { g.w = 4 * 193; g.h = 490; g.cells_per_row = 3; }  /* startPCM1600Frame */
+    else if (kind == SDV_VIS_STC007_BLOCKS_NTSC) { g.w = 6 * 109; g.h = 490; g.cells_per_row = 1; }     /* startSTC007DBFrame, setLineCount(VID_NTSC) */
+    else if (kind == SDV_VIS_STC007_BLOCKS_PAL) { g.w = 6 * 109; g.h = 588; g.cells_per_row = 1; }      /* ... setLineCount(VID_PAL) */
     return g;
 }
 /* pixels [x0, x1) of a cell */
@@ -287,6 +290,82 @@ __device__ inline void fill_body(const VisArgs &a, uint32_t block, int lane)
     }
 }
 
+/* ---- the data blocks window: renderNewBlock(STC007DataBlock), renderpcm.cpp:1770-2051 --------------------------------------------- */
+/* Frame f's blocks are blocks[frame_ofs[f] .. frame_ofs[f + 1]); block i of a frame is row i (rows past the canvas are dropped, :1781-1787).
+ * A wave takes 64 rows of one frame: a lane packs its block (six 16-bit samples, the per-word marks, seven block-level bits), the wave
+ * then writes one row after the other, 64 consecutive pixels per store - 6 pixels per bit, 6 status bits + 96 sample bits + 7 tail bits. */
+struct BlkArgs {
+    const sdv_block_rec *blocks; const uint32_t *frame_ofs; uint32_t n_frames; int kind;
+    uint32_t *out; uint32_t *wmask; uint32_t wmask_stride;
+};
+enum { BK_FIX_P = 1u << 18, BK_FIX_Q = 1u << 19, BK_BROKEN = 1u << 20, BK_VALID = 1u << 21, BK_CWD_AUDIO = 1u << 22, BK_SILENT = 1u << 23, BK_SEAM = 1u << 24 };
+__device__ inline int16_t blk_sample(const sdv_block_rec &b, int w) { return b.resolution == SDV_RES_16BIT ? (int16_t)b.words[w] : (int16_t)(b.words[w] << 2); }   /* getSample (not M2) */
+__device__ inline bool blk_near_silence(const sdv_block_rec &b, int w)      /* isNearSilence, stc007datablock.cpp:417-446 */
+{
+    const int v = blk_sample(b, w), lim = b.resolution == SDV_RES_16BIT ? 4 : 16;
+    return v < lim && v >= -lim;
+}
+__device__ inline uint32_t block_pixel(uint32_t s01, uint32_t s23, uint32_t s45, uint32_t fl, uint32_t x)
+{
+    const uint32_t b = x / 6u;
+    if (b < 6u) {                                           /* the status bar :1793-1861 */
+        if (b == 0) return (fl & BK_FIX_P) ? (uint32_t)B1_GRN : (uint32_t)PX_BLK;
+        if (b == 1) return (fl & BK_FIX_Q) ? (uint32_t)B1_YEL : (uint32_t)PX_BLK;
+        if (b == 2) return (fl & BK_CWD_AUDIO) ? ((fl & BK_VALID) ? (uint32_t)B1_BLU : (uint32_t)B0_BLU) : (uint32_t)PX_BLK;
+        if (b == 3) return (fl & BK_VALID) ? (uint32_t)PX_BLK : (uint32_t)B1_RED;
+        if (b == 5) return (fl & BK_SILENT) ? (uint32_t)LIM_MARK : (uint32_t)LIM_OK;
+        return PX_BLK;
+    }
+    if (b < 102u) {                                         /* the samples :1862-1993 */
+        const uint32_t w = (b - 6u) / 16u, bit = 15u - ((b - 6u) % 16u);
+        const uint32_t pair = w < 2 ? s01 : w < 4 ? s23 : s45, v = (w & 1u) ? pair >> 16 : pair & 0xFFFFu;
+        const bool one = (v >> bit) & 1u, crc = (fl >> w) & 1u, cwd = (fl >> (6u + w)) & 1u, wv = (fl >> (12u + w)) & 1u;
+        if (fl & BK_BROKEN) return crc ? (one ? (uint32_t)B1_GRY : (uint32_t)PX_BLK) : (one ? (uint32_t)B1_MGN : (uint32_t)B0_MGN);
+        if (fl & (BK_FIX_Q | BK_FIX_P)) {
+            if (cwd) return one ? (uint32_t)B1_BLU : (uint32_t)B0_BLU;
+            if (!crc) return (fl & BK_FIX_Q) ? (one ? (uint32_t)B1_YEL : (uint32_t)B0_YEL) : (one ? (uint32_t)B1_GRN : (uint32_t)B0_GRN);
+            return one ? (uint32_t)B1_GRY : (uint32_t)PX_BLK;
+        }
+        if (cwd) return one ? (uint32_t)B1_BLU : (uint32_t)B0_BLU;
+        if (!wv) return one ? (uint32_t)B1_RED : (uint32_t)B0_RED;
+        return one ? (uint32_t)B1_GRY : (uint32_t)PX_BLK;
+    }
+    const uint32_t i = b - 102u;                            /* seam, emphasis (never set for STC-007), BROKEN :1995-2045 */
+    if (i == 0) return (fl & BK_SEAM) ? (uint32_t)LIM_MARK : (uint32_t)LIM_OK;
+    if (i == 4 || i == 5) return (fl & BK_BROKEN) ? (uint32_t)B1_MGN : (uint32_t)PX_BLK;
+    return PX_BLK;
+}
+__device__ inline void draw_blocks_body(const BlkArgs &a, uint32_t block, int lane)
+{
+    const Geometry g = geometry(a.kind);
+    const uint32_t chunks = (g.h + 63u) / 64u, f = block / chunks, c = block % chunks;
+    const uint32_t lo = a.frame_ofs[f], n = a.frame_ofs[f + 1] - lo, rows = n < g.h ? n : g.h;
+    if (lane < 2) {                                         /* the frame's rows 64 c .. 64 c + 63 as two words of the drawn-cells bitmap */
+        const uint32_t first = 64u * c + 32u * (uint32_t)lane, word = 2u * c + (uint32_t)lane;
+        if (word < a.wmask_stride) a.wmask[(size_t)f * a.wmask_stride + word] = rows <= first ? 0u : rows - first >= 32u ? 0xFFFFFFFFu : (1u << (rows - first)) - 1u;
+    }
+    const uint32_t row = 64u * c + (uint32_t)lane;
+    const bool live = row < rows;
+    uint32_t s01 = 0, s23 = 0, s45 = 0, fl = 0;
+    if (live) {
+        const sdv_block_rec b = a.blocks[lo + row];
+        s01 = (uint32_t)(uint16_t)blk_sample(b, 0) | ((uint32_t)(uint16_t)blk_sample(b, 1) << 16);
+        s23 = (uint32_t)(uint16_t)blk_sample(b, 2) | ((uint32_t)(uint16_t)blk_sample(b, 3) << 16);
+        s45 = (uint32_t)(uint16_t)blk_sample(b, 4) | ((uint32_t)(uint16_t)blk_sample(b, 5) << 16);
+        const bool silent = (blk_near_silence(b, 0) || blk_near_silence(b, 2) || blk_near_silence(b, 4)) && (blk_near_silence(b, 1) || blk_near_silence(b, 3) || blk_near_silence(b, 5));
+        fl = (uint32_t)(b.line_crc & 0x3F) | ((uint32_t)(b.cwd_fixed & 0x3F) << 6) | ((uint32_t)(b.word_valid & 0x3F) << 12) |
+             (b.audio_state == SDV_AUD_FIX_P ? BK_FIX_P : 0u) | (b.audio_state == SDV_AUD_FIX_Q ? BK_FIX_Q : 0u) | (b.audio_state == SDV_AUD_BROKEN ? BK_BROKEN : 0u) |
+             ((b.word_valid & 0x3F) == 0x3F ? BK_VALID : 0u) | ((b.cwd_fixed & 0x3F) ? BK_CWD_AUDIO : 0u) | (silent ? BK_SILENT : 0u) | (b.w_line[0] > b.w_line[7] ? BK_SEAM : 0u);
+    }
+    const uint64_t lm = __ballot(live);
+    for (int j = 0; j < 64; j++) {
+        if (!((lm >> j) & 1ull)) continue;
+        const uint32_t j01 = (uint32_t)__shfl((int)s01, j), j23 = (uint32_t)__shfl((int)s23, j), j45 = (uint32_t)__shfl((int)s45, j), jfl = (uint32_t)__shfl((int)fl, j);
+        uint32_t *dst = a.out + ((size_t)f * g.h + 64u * c + (uint32_t)j) * g.w;
+        for (uint32_t x = (uint32_t)lane; x < g.w; x += 64u) dst[x] = block_pixel(j01, j23, j45, jfl, x);
+    }
+}
+
 struct BlankArgs { uint32_t *canvas; uint32_t n_px; };
 __device__ inline void blank_body(const BlankArgs &a, uint32_t i) { if (i < a.n_px) a.canvas[i] = BLANK; }
 } // namespace sdvvis
@@ -298,6 +377,7 @@ __device__ inline void blank_body(const BlankArgs &a, uint32_t i) { if (i < a.n_
 SDV_VIS_KERNELS(sdv_line_rec, stc007)
 SDV_VIS_KERNELS(sdv_pcm1_bin_rec, pcm1)
 SDV_VIS_KERNELS(sdv_pcm16x0_bin_rec, pcm16x0)
+__global__ void __launch_bounds__(64) sdv_k_vis_draw_blocks(sdvvis::BlkArgs a) { sdvvis::draw_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_last(sdvvis::VisArgs a) { sdvvis::last_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_fill(sdvvis::VisArgs a) { sdvvis::fill_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_blank(sdvvis::BlankArgs a) { sdvvis::blank_body(a, blockIdx.x * 64u + threadIdx.x); }

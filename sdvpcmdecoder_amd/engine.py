@@ -35,7 +35,7 @@ TYPE_M2 = 3                      # VideoToDigital::TYPE_M2 (videotodigital.h:77)
 MODE_DRAFT, MODE_FAST, MODE_NORMAL, MODE_INSANE = 0, 1, 2, 3
 FLAG_NEW_FILE, FLAG_DOUBLED, FLAG_END_FILE = 1, 2, 4
 FRAME_EMPTY = 1                 # sdv_set_frame_flags: SDV_FRAME_EMPTY
-VIS_STC007_LINES, VIS_PCM1_LINES, VIS_PCM16X0_LINES = 0, 1, 2       # sdv_vis_render_lines: SDV_VIS_*
+VIS_STC007_LINES, VIS_PCM1_LINES, VIS_PCM16X0_LINES, VIS_STC007_BLOCKS_NTSC, VIS_STC007_BLOCKS_PAL = 0, 1, 2, 3, 4       # SDV_VIS_*
 
 
 class BinPreset(C.Structure):
@@ -134,6 +134,10 @@ def load_library(path: str | None = None):
     lib.sdv_vis_canvas_size.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.sdv_vis_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.sdv_vis_render_lines.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    lib.sdv_vis_render_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_stitch_block_count.restype = C.c_size_t
+    lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
     lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
     lib.sdv_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -323,6 +327,33 @@ class Engine:
         self._check(self.lib.sdv_vis_render_lines(self._h, kind, C.c_void_p(recs.data_ptr()), recs.shape[0], C.c_void_p(out.data_ptr()), n_frames,
                                                   C.byref(got), sptr))
         return out[:got.value]
+
+    def set_stitch_block_output(self, blocks):
+        """sdv_set_stitch_block_output: `blocks` = (cap, 72) uint8 CUDA tensor that the following stitch_frames calls fill with their data
+        blocks (None: off).  The tensor must stay alive while it is set."""
+        self._block_out = blocks
+        if blocks is None:
+            self._check(self.lib.sdv_set_stitch_block_output(self._h, None, 0))
+        else:
+            assert blocks.is_cuda and blocks.is_contiguous() and blocks.shape[1] == 72
+            self._check(self.lib.sdv_set_stitch_block_output(self._h, C.c_void_p(blocks.data_ptr()), blocks.shape[0]))
+
+    def stitch_block_count(self) -> int:
+        return int(self.lib.sdv_stitch_block_count(self._h))
+
+    def vis_render_blocks(self, kind: int, blocks, frame_blocks, stream=None):
+        """sdv_vis_render_blocks: `blocks` = (n, 72) uint8 CUDA tensor of sdv_block_rec, frame_blocks = blocks per frame (host sequence)
+        -> (n_frames, height, width) int32 CUDA tensor."""
+        import numpy as np
+        import torch
+        assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+        per = np.ascontiguousarray(np.asarray(frame_blocks, dtype=np.uint32))
+        w, h = self.vis_canvas_size(kind)
+        out = torch.empty((max(len(per), 1), h, w), dtype=torch.int32, device=blocks.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(blocks.device).cuda_stream)
+        self._check(self.lib.sdv_vis_render_blocks(self._h, kind, C.c_void_p(blocks.data_ptr()), blocks.shape[0], per.ctypes.data, len(per),
+                                                   C.c_void_p(out.data_ptr()), len(per), sptr))
+        return out[:len(per)]
 
     # ---- stream state as bytes (checkpoints, hand-over between the GPUs of a sharded stream) ----
     def get_chain_state(self) -> bytes:

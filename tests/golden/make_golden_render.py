@@ -29,3 +29,20 @@ if __name__ == "__main__":
         np.savez_compressed(path, input_sha256=hashlib.sha256(recs.tobytes()).hexdigest(), canvases_sha256=ra.digest(ref, mask),
                             last_canvas=np.where(mask[-1], ref[-1], 0).astype(np.uint32))
         print(f"{name}: {len(recs)} records -> {len(ref)} canvases of {ref.shape[2]} x {ref.shape[1]}, {os.path.getsize(path)} bytes")
+    for name in ra.BLOCK_GOLDEN:          # the data blocks window: the real stitcher's blocks on the real RenderPCM
+        if only and name not in only:
+            continue
+        import libs
+        import oracle_run
+        import stitch_api as sa
+        import stitch_cases as sc
+        kind, case = ra.BLOCK_CASES[name]
+        recs, st = sc.make_input(case, lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+        pairs, frames, blocks = sa.run_cpu_blocks(libs.load_ref(), "ref_", recs, st)
+        per = np.ascontiguousarray(frames["blocks_total"][frames["service_type"] == 0].astype(np.uint32))
+        ref = ra.run_ref_blocks(kind, np.ascontiguousarray(blocks), per)
+        mask = ra.written_blocks(kind, per)
+        path = os.path.join(HERE, "render_" + name + ".npz")
+        np.savez_compressed(path, blocks_sha256=hashlib.sha256(blocks.tobytes()).hexdigest(), canvases_sha256=ra.digest(ref, mask),
+                            last_canvas=np.where(mask[-1], ref[-1], 0).astype(np.uint32))
+        print(f"{name}: {len(blocks)} blocks -> {len(ref)} canvases of {ref.shape[2]} x {ref.shape[1]}, {os.path.getsize(path)} bytes")

@@ -11,8 +11,8 @@ import pcm1_frames_api as p1f
 import pcm16_frames_api as p16f
 from sdvpcmdecoder_amd import synth
 
-STC007, PCM1, PCM16X0 = 0, 1, 2
-SIZE = {STC007: (685, 650), PCM1: (752, 490), PCM16X0: (772, 490)}          # width, height of the canvas
+STC007, PCM1, PCM16X0, STC007_BLOCKS_NTSC, STC007_BLOCKS_PAL = 0, 1, 2, 3, 4
+SIZE = {STC007: (685, 650), PCM1: (752, 490), PCM16X0: (772, 490), STC007_BLOCKS_NTSC: (654, 490), STC007_BLOCKS_PAL: (654, 588)}   # width, height of the canvas
 BLANK = 0xFF000000                                                          # a canvas nothing was drawn on yet (QImage::fill(Qt::black))
 SRV_FILLER, SRV_END_FRAME = 3, 5
 LF_BW_SET, LF_COORDS_SET, LF_FORCED_BAD, LF_CRC_VALID = 8, 16, 32, 64
@@ -143,3 +143,63 @@ def run_ref(kind, recs):
 
 def digest(canvases, mask):
     return hashlib.sha256(np.where(mask, canvases, 0).astype(np.uint32).tobytes()).hexdigest()
+
+
+# ---- the data blocks window (sdv_vis_render_blocks; RenderPCM::renderNewBlock(STC007DataBlock), renderpcm.cpp:1770-2051) ---------------------------
+# name: (canvas, scenario of tests/stitch_cases.py whose blocks are drawn)
+BLOCK_CASES = {
+    "blk_clean": (STC007_BLOCKS_NTSC, "ntsc_clean"),
+    "blk_bad5": (STC007_BLOCKS_NTSC, "ntsc_bad5"),                      # P and Q corrections
+    "blk_bad10_no_q_cwd": (STC007_BLOCKS_NTSC, "ntsc_bad10_no_q_cwd"),  # CWD marks, blocks left invalid
+    "blk_burst": (STC007_BLOCKS_NTSC, "ntsc_burst300"),                 # BROKEN blocks, the mask behind them
+    "blk_pal": (STC007_BLOCKS_PAL, "pal_bad5"),
+    "blk_16bit": (STC007_BLOCKS_NTSC, "f1_16bit_bad5"),
+    "blk_silent": (STC007_BLOCKS_NTSC, "ntsc_silent_bad"),
+    "blk_drift": (STC007_BLOCKS_NTSC, "ntsc_drift"),                    # seams that do not fit: blocks marked on the seam
+    "blk_pal_on_ntsc_canvas": (STC007_BLOCKS_NTSC, "pal_bad5"),         # more blocks per frame than the canvas has rows
+}
+BLOCK_GOLDEN = ("blk_bad5", "blk_burst", "blk_pal", "blk_16bit")
+
+
+def make_block_input(name):
+    """(canvas kind, blocks (sdv_block_rec), blocks per frame) of a scenario: what the oracle's stitcher puts out for it."""
+    import stitch_api as sa
+    import stitch_cases as sc
+    kind, case = BLOCK_CASES[name]
+    recs, st = sc.make_input(case, lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    pairs, frames, blocks = sa.run_cpu_blocks(libs.load_oracle(), "orc_", recs, st)
+    per_frame = frames["blocks_total"][frames["service_type"] == 0].astype(np.uint32)
+    assert int(per_frame.sum()) == len(blocks)
+    return kind, np.ascontiguousarray(blocks), np.ascontiguousarray(per_frame)
+
+
+def written_blocks(kind, per_frame):
+    w, h = SIZE[kind]
+    rows = np.minimum(np.maximum.accumulate(per_frame.astype(np.int64)), h)
+    return (np.arange(h)[None, :, None] < rows[:, None, None]) & np.ones((1, 1, w), dtype=bool)
+
+
+def run_oracle_blocks(kind, blocks, per_frame, canvas=None):
+    lib = libs.load_oracle()
+    w, h = SIZE[kind]
+    n = len(per_frame)
+    out = np.zeros((n, h, w), dtype=np.uint32)
+    if canvas is None:
+        canvas = np.full((h, w), BLANK, dtype=np.uint32)
+    lib.orc_vis_render_blocks.restype = C.c_long
+    lib.orc_vis_render_blocks.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+    assert lib.orc_vis_render_blocks(kind, blocks.ctypes.data, len(blocks), per_frame.ctypes.data, n, canvas.ctypes.data, out.ctypes.data, n) == n
+    return out, canvas
+
+
+def run_ref_blocks(kind, blocks, per_frame):
+    lib = libs.load_ref()
+    w, h = SIZE[kind]
+    n = len(per_frame)
+    out = np.zeros((n, h, w), dtype=np.uint32)
+    lib.ref_vis_render_blocks.restype = C.c_long
+    lib.ref_vis_render_blocks.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rw, rh = C.c_uint32(0), C.c_uint32(0)
+    got = lib.ref_vis_render_blocks(kind, blocks.ctypes.data, len(blocks), per_frame.ctypes.data, n, out.ctypes.data, n, C.byref(rw), C.byref(rh))
+    assert got == n and (rw.value, rh.value) == (w, h), (got, n, rw.value, rh.value)
+    return out

@@ -85,3 +85,25 @@ def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None):
     n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, pair_cap, frames.ctypes.data, frame_cap, C.byref(nf))
     assert n >= 0, "pair buffer too small"
     return pairs[:n], frames[:min(nf.value, frame_cap)]
+
+
+BLOCK_DTYPE = np.dtype([("w_frame", "<u4", (8,)), ("w_line", "<u2", (8,)), ("words", "<u2", (8,)), ("line_crc", "u1"), ("cwd_fixed", "u1"), ("word_valid", "u1"),
+                        ("resolution", "u1"), ("audio_state", "u1"), ("cwd_applied", "u1"), ("sample_rate", "<u2")])     # sdv_block_rec, 72 bytes
+
+
+def run_cpu_blocks(lib, prefix, recs, st):
+    """... and the data blocks the stitcher hands to the visualiser (newBlockProcessed): (pairs, frames, blocks)."""
+    f = getattr(lib, prefix + "stitch_run_blocks")
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(StitchSettings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    recs = np.ascontiguousarray(recs)
+    nfr = int(recs["frame_number"].max() - recs["frame_number"].min()) + 4
+    pair_cap, frame_cap = nfr * 2100 + 4096, nfr + 8
+    pairs = np.zeros(pair_cap, dtype=PAIR_DTYPE)
+    frames = np.zeros(frame_cap, dtype=FRASM_DTYPE)
+    blocks = np.zeros(pair_cap // 3 + 1, dtype=BLOCK_DTYPE)
+    nf, nb = C.c_size_t(0), C.c_size_t(0)
+    n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, pair_cap, frames.ctypes.data, frame_cap, C.byref(nf), blocks.ctypes.data, len(blocks), C.byref(nb))
+    assert n >= 0 and nb.value <= len(blocks)
+    return pairs[:n], frames[:min(nf.value, frame_cap)], blocks[:nb.value]

@@ -177,3 +177,131 @@ def test_gpu_frames_entry_to_canvas_in_batches():
     a = eng.vis_render_lines(ra.STC007, recs[:cut].contiguous(), 131).cpu().numpy().view(np.uint32)
     b = eng.vis_render_lines(ra.STC007, recs[cut:n_rec].contiguous(), 69).cpu().numpy().view(np.uint32)
     assert (np.concatenate([a, b]) == want).all()
+
+
+# ---- the data blocks window: sdv_set_stitch_block_output + sdv_vis_render_blocks (renderNewBlock(STC007DataBlock)) -------------------------------------
+@pytest.mark.ref
+@pytest.mark.parametrize("name", list(ra.BLOCK_CASES))
+def test_oracle_block_canvases_match_live_reference(name, oracle_lib):
+    """The oracle's stitcher blocks equal the real stitcher's newBlockProcessed blocks, and their canvases the real RenderPCM's."""
+    if not libs.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available")
+    import stitch_api as sa
+    import stitch_cases as sc
+    import oracle_run
+    kind, blocks, per = ra.make_block_input(name)
+    recs, st = sc.make_input(ra.BLOCK_CASES[name][1], lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    ref_blocks = sa.run_cpu_blocks(libs.load_ref(), "ref_", recs, st)[2]
+    assert blocks.tobytes() == ref_blocks.tobytes()
+    out, _ = ra.run_oracle_blocks(kind, blocks, per)
+    ref = ra.run_ref_blocks(kind, blocks, per)
+    mask = ra.written_blocks(kind, per)
+    assert (_masked(out, mask) == _masked(ref, mask)).all(), _diff(out, ref, mask)
+
+
+@pytest.mark.parametrize("name", ra.BLOCK_GOLDEN)
+def test_oracle_block_canvases_match_golden(name, oracle_lib):
+    z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
+    kind, blocks, per = ra.make_block_input(name)
+    assert ra.hashlib.sha256(blocks.tobytes()).hexdigest() == str(z["blocks_sha256"]), "the stitcher's blocks differ from the real stitcher's"
+    out, _ = ra.run_oracle_blocks(kind, blocks, per)
+    mask = ra.written_blocks(kind, per)
+    assert ra.digest(out, mask) == str(z["canvases_sha256"])
+    assert (_masked(out[-1], mask[-1]) == z["last_canvas"]).all()
+
+
+def _emu_blocks(emu, name, two_calls=False):
+    """The product's path in the emulator: records -> sdv_stitch_frames with a block buffer set -> sdv_vis_render_blocks."""
+    import engine_api as ea
+    import stitch_cases as sc
+    import stitch_api as sa
+    import oracle_run
+    kind, want_blocks, per = ra.make_block_input(name)
+    recs, st = sc.make_input(ra.BLOCK_CASES[name][1], lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    lib = ea.bind(emu)
+    lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_stitch_block_count.restype = C.c_size_t
+    lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
+    lib.sdv_vis_render_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    eng = lib.sdv_engine_create(0)
+    buf = np.zeros(len(want_blocks) + 8, dtype=sa.BLOCK_DTYPE)
+    assert lib.sdv_set_stitch_block_output(eng, buf.ctypes.data, len(buf)) == 0
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    cuts = [0, int(ends[len(ends) // 2]) + 1, len(recs)] if two_calls else [0, len(recs)]
+    w, h = ra.SIZE[kind]
+    canv, got_blocks, frames = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, p, f = ea.emu_stitch(lib, eng, recs[a:b], st if a == 0 else None)
+        assert rc == 0
+        nb = lib.sdv_stitch_block_count(eng)
+        got_blocks.append(buf[:nb].copy())
+        per_call = np.ascontiguousarray(f["blocks_total"][f["service_type"] == 0].astype(np.uint32))
+        assert int(per_call.sum()) == nb
+        out = np.zeros((max(len(per_call), 1), h, w), dtype=np.uint32)
+        assert lib.sdv_vis_render_blocks(eng, kind, buf.ctypes.data, nb, per_call.ctypes.data, len(per_call), out.ctypes.data, len(per_call), None) == 0
+        canv.append(out[:len(per_call)])
+    lib.sdv_engine_destroy(eng)
+    return kind, want_blocks, per, np.concatenate(got_blocks), np.concatenate(canv)
+
+
+@pytest.mark.parametrize("name", list(ra.BLOCK_CASES))
+def test_emu_blocks_and_their_canvases_match_oracle(name, emu):
+    kind, want_blocks, per, blocks, canvases = _emu_blocks(emu, name)
+    assert blocks.tobytes() == want_blocks.tobytes()
+    want, _ = ra.run_oracle_blocks(kind, want_blocks, per)
+    assert (canvases == want).all(), _diff(canvases, want, np.ones_like(want, dtype=bool))
+
+
+def test_emu_blocks_in_two_calls(emu):
+    kind, want_blocks, per, blocks, canvases = _emu_blocks(emu, "blk_burst", two_calls=True)
+    assert blocks.tobytes() == want_blocks.tobytes()
+    want, _ = ra.run_oracle_blocks(kind, want_blocks, per)
+    assert (canvases == want).all()
+
+
+def test_emu_block_buffer_too_small_is_refused_with_the_count(emu):
+    import engine_api as ea
+    import stitch_cases as sc
+    import stitch_api as sa
+    import oracle_run
+    recs, st = sc.make_input("ntsc_clean", lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    lib = ea.bind(emu)
+    lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_stitch_block_count.restype = C.c_size_t
+    lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
+    eng = lib.sdv_engine_create(0)
+    buf = np.zeros(100, dtype=sa.BLOCK_DTYPE)
+    assert lib.sdv_set_stitch_block_output(eng, buf.ctypes.data, len(buf)) == 0
+    rc, p, f = ea.emu_stitch(lib, eng, recs, st)
+    assert rc != 0 and b"data blocks are needed" in lib.sdv_last_error(eng) and lib.sdv_stitch_block_count(eng) == 2530
+    lib.sdv_engine_destroy(eng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ra.BLOCK_CASES))
+def test_gpu_blocks_and_their_canvases_match_oracle(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine, StitchSettings
+    import stitch_cases as sc
+    import stitch_api as sa
+    import oracle_run
+    kind, want_blocks, per = ra.make_block_input(name)
+    recs, st = sc.make_input(ra.BLOCK_CASES[name][1], lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    eng = Engine(0)
+    eng.set_stitch_settings(StitchSettings.from_buffer_copy(bytes(st)))
+    buf = torch.zeros((len(want_blocks) + 8, 72), dtype=torch.uint8, device="cuda")
+    eng.set_stitch_block_output(buf)
+    d = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), 48)).cuda()
+    pairs, frames = eng.stitch_frames(d)
+    nb = eng.stitch_block_count()
+    got = buf[:nb].cpu().numpy().reshape(-1).view(sa.BLOCK_DTYPE)
+    assert got.tobytes() == want_blocks.tobytes()
+    fr = frames.cpu().numpy().reshape(-1).view(sa.FRASM_DTYPE)
+    per_gpu = fr["blocks_total"][fr["service_type"] == 0].astype(np.uint32)
+    assert (per_gpu == per).all()
+    canvases = eng.vis_render_blocks(kind, buf[:nb].contiguous(), per_gpu).cpu().numpy().view(np.uint32)
+    want, _ = ra.run_oracle_blocks(kind, want_blocks, per)
+    assert (canvases == want).all(), _diff(canvases, want, np.ones_like(want, dtype=bool))
+    if name in ra.BLOCK_GOLDEN:
+        z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
+        assert ra.digest(canvases, ra.written_blocks(kind, per)) == str(z["canvases_sha256"])
