@@ -1443,12 +1443,19 @@ struct Step {
                 for (int e = 1; e <= 6; e++) sdrop += (uint32_t)e * (uint32_t)__popcll(__ballot(rep && !valid && errs == e));
             }
             if (blocks_out && act) {                /* the block as outputDataBlock hands it to the visualiser (newBlockProcessed, :6626) */
-                sdv_block_rec r;
+                uint32_t r[18];                     /* an sdv_block_rec as 18 dwords: nine 8-byte stores instead of 28 narrow ones */
 #pragma unroll
-                for (int w = 0; w < 8; w++) { r.w_frame[w] = b.w_frame[w]; r.w_line[w] = b.w_line[w]; r.words[w] = b.w(w); }
-                r.line_crc = b.line_crc; r.cwd_fixed = b.cwd_fixed; r.word_valid = b.word_valid; r.resolution = b.resolution;
-                r.audio_state = b.audio_state; r.cwd_applied = b.cwd_applied ? 1 : 0; r.sample_rate = rate;
-                blocks_out[i] = r;
+                for (int w = 0; w < 8; w++) r[w] = b.w_frame[w];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    r[8 + w] = (uint32_t)b.w_line[2 * w] | ((uint32_t)b.w_line[2 * w + 1] << 16);
+                    r[12 + w] = (uint32_t)b.w(2 * w) | ((uint32_t)b.w(2 * w + 1) << 16);
+                }
+                r[16] = (uint32_t)b.line_crc | ((uint32_t)b.cwd_fixed << 8) | ((uint32_t)b.word_valid << 16) | ((uint32_t)b.resolution << 24);
+                r[17] = (uint32_t)b.audio_state | ((b.cwd_applied ? 1u : 0u) << 8) | ((uint32_t)rate << 16);
+                uint2 *o2 = (uint2 *)(blocks_out + i);
+#pragma unroll
+                for (int w = 0; w < 9; w++) { uint2 v; v.x = r[2 * w]; v.y = r[2 * w + 1]; o2[w] = v; }
             }
             /* the 64 blocks' 192 pairs are one stretch of 2 304 bytes: through LDS, then whole dwords side by side */
             if (act) {

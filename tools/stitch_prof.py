@@ -15,6 +15,8 @@ eng.set_profiling(True)
 out_p = torch.empty((n * 1470 + 20000, 12), dtype=torch.uint8, device='cuda')
 out_f = torch.empty((n + 64, 64), dtype=torch.uint8, device='cuda')
 fn = 1 + n
+if len(sys.argv) > 4 and sys.argv[4] == "blocks":        # with the visualiser's block output on
+    blk = torch.empty((n * 490 + 4096, 72), dtype=torch.uint8, device='cuda'); eng.set_stitch_block_output(blk)
 for it in range(reps):
     if cont and it > 0:
         lines2, _ = eng.binarize_frames(luma, first_frame_no=fn, new_file=False)
