@@ -763,27 +763,37 @@ def main():
             except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
                 out["cpu_baseline_all_cores"] = {"error": repr(ex), "cores": os.cpu_count()}
             if stitch is not None:
-                # the stitch stage on the CPU: the oracle port of STC007DataStitcher over the records of the first 1000 frames
+                # the stitch stage on the CPU: the real STC007DataStitcher on its own thread (or the oracle port of it) over the records of the first 1000 frames
                 import libs
                 import stitch_api as sa
                 nst = min(1000, ncpu)
                 srecs = np.ascontiguousarray(cpu_recs[:1 + nst * (H + 3)])
-                t0 = time.perf_counter()
-                cp, _ = sa.run_cpu(libs.load_oracle(), "orc_", srecs, sa.default_settings())
-                dts = time.perf_counter() - t0
+                use_ref_st = libs.ref_available()
+                fd = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)       # the stitcher logs to stderr
+                try:
+                    t0 = time.perf_counter()
+                    cp, _ = sa.run_cpu(libs.load_ref() if use_ref_st else libs.load_oracle(), "ref_" if use_ref_st else "orc_", srecs, sa.default_settings())
+                    dts = time.perf_counter() - t0
+                finally:
+                    os.dup2(fd, 2); os.close(devnull); os.close(fd)
                 kk = min(len(cp), len(first_pairs))
-                stitch["cpu_baseline"] = {"value": nst / dts, "unit": "frames/s", "cores": 1, "kind": "port",
-                                          "sample": f"records of the first {nst} frames, {dts:.1f} s of CPU work",
+                stitch["cpu_baseline"] = {"value": nst / dts, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref_st else "port",
+                                          "sample": f"records of the first {nst} frames, {dts:.1f} s of CPU work" + (" (incl. ~0.3 s the driver waits for the stitcher thread to go idle)" if use_ref_st else ""),
                                           "bit_exact_vs_gpu_on_overlap": bool(cp[:kk].tobytes() == first_pairs.reshape(-1).view(sa.PAIR_DTYPE)[:kk].tobytes())}
             if pcm1 is not None:
                 import pcm1_api as p1a
                 np1 = min(3000, n)
                 end = int(np.nonzero(p1_recs["service_type"] == 5)[0][np1 - 1])
-                t0 = time.perf_counter()
-                cp1, _ = p1a.run_cpu(libs.load_oracle(), "orc_", p1_recs[:end + 1], p1a.default_settings())
-                dt1 = time.perf_counter() - t0
-                pcm1["cpu_baseline"] = {"value": np1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
-                                        "sample": f"the first {np1} frames, {dt1:.2f} s of CPU work",
+                use_ref_p1 = libs.ref_available()
+                fd = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)
+                try:
+                    t0 = time.perf_counter()
+                    cp1, _ = p1a.run_cpu(libs.load_ref() if use_ref_p1 else libs.load_oracle(), "ref_" if use_ref_p1 else "orc_", p1_recs[:end + 1], p1a.default_settings())
+                    dt1 = time.perf_counter() - t0
+                finally:
+                    os.dup2(fd, 2); os.close(devnull); os.close(fd)
+                pcm1["cpu_baseline"] = {"value": np1 / dt1, "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref_p1 else "port",
+                                        "sample": f"the first {np1} frames, {dt1:.2f} s of CPU work" + (" (incl. ~0.3 s the driver waits for the stitcher thread to go idle)" if use_ref_p1 else ""),
                                         "bit_exact_vs_gpu_on_overlap": bool(cp1.tobytes() == p1_first.reshape(-1).view(p1a.PAIR_DTYPE)[:len(cp1)].tobytes())}
             if pcm16 is not None:
                 # the PCM-16x0 back half on the CPU: the real reference's stitcher thread (or the oracle port) on the first 200 frames
