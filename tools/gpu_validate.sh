@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/bench_full.json
+SDV_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu 2> gpurun_out/bench_nccl1.err | tail -1 > gpurun_out/bench_nccl_1rank.json; echo "nccl 1-rank rc=$?"
 SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --frames 4000 --no-cpu 2> gpurun_out/bench_2rank.err | tail -1 > gpurun_out/bench_2rank_gloo.json; echo "2-rank rc=$?"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_bench $R/gpurun_out/prof_stitch $R/gpurun_out/pmc1 $R/gpurun_out/pmc2 $R/gpurun_out/pmc3 $R/gpurun_out/pmc4

@@ -34,6 +34,8 @@ if glob.glob('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'):
     subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines_lean', f'profiles/{RND}_pmc_sdv_k_pcm1_lines_lean.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
 shutil.copy('gpurun_out/bench_full.json', f'profiles/{RND}_bench_full.json')
 shutil.copy('gpurun_out/bench_2rank_gloo.json', f'profiles/{RND}_bench_2rank_gloo_one_gpu.json')
+if os.path.exists('gpurun_out/bench_nccl_1rank.json') and os.path.getsize('gpurun_out/bench_nccl_1rank.json') > 100:
+    shutil.copy('gpurun_out/bench_nccl_1rank.json', f'profiles/{RND}_bench_nccl_1rank.json')
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_stc007_frames_lean', f'profiles/{RND}_pmc_sdv_k_stc007_frames_lean.json', 'pmc'], stdout=subprocess.DEVNULL)
 subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_frames', f'profiles/{RND}_pmc_sdv_k_pcm1_frames.json', 'p1pmc'], stdout=subprocess.DEVNULL)
 if glob.glob('gpurun_out/apmc3/**/*_counter_collection.csv', recursive=True):
