@@ -132,6 +132,13 @@ struct FrameArgs1 {
     sdv_sample_pair *out_pairs; uint64_t pairs_cap; sdv_frame_asm_pcm1 *out_frames; uint32_t frames_cap;
     unsigned long long *timing; /* developer aid (SDV_STITCH_TIMING): 8 cycle stamps per frame */
     uint32_t *stat;             /* [0] = OR of FE_*, [1] = first frame index with an error, [2] = marks set (0: the plain layout) */
+    /* The reference's field buffers outlive a frame (frame1_odd / frame1_even, pcm1datastitcher.h): with manual line offsets a field can be told
+     * to hold more lines than the frame delivered, and then puts out what earlier frames left at those places (:896-909 -> addLinesFromField).
+     * Manual mode therefore runs the kernel twice: the first pass (cnt_out set) stops behind the field split and leaves every frame's line counts
+     * and the records its fields were made of; the second pass (cnt_in set) looks the missing places up - the last earlier frame whose field
+     * reached that far, or `hist`, the buffers as the calls before left them. */
+    uint32_t *cnt_out, *kept_out;               /* per frame: odd | even << 16 lines split; per frame 2 x 245 record indices */
+    const uint32_t *cnt_in, *kept_in; const void *hist;     /* hist: 2 x 245 Line16 */
 };
 
 
@@ -316,6 +323,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
     if ((seen ^ marks) & (FF_NEW_FILE | FF_END_FILE)) err |= FE_MARKS;      /* a file tag with another frame's number: the offsets were laid out for it */
 
     if (marks & FF_END_FILE) {                      /* the frame that carries the END_FILE tag only closes the file (:1721-1729) */
+        if (a.cnt_out) { if (lane == 0) a.cnt_out[k] = 0; return; }    /* ... and does not touch the field buffers */
         if (lane == 0) {
             if (fofs < a.frames_cap) { sdv_frame_asm_pcm1 d; frasm1_clear(d); d.service_type = SDV_PAIR_SRV_END_FILE; a.out_frames[fofs] = d; }
             if (pofs < a.pairs_cap) service_pair(&a.out_pairs[pofs], SDV_PAIR_SRV_END_FILE);
@@ -372,6 +380,13 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         }
     }
     __syncthreads();            /* field_idx[] complete before the output stage gathers through it */
+    if (a.cnt_out) {            /* first pass of manual mode: what this frame writes into the field buffers */
+        const uint32_t c0 = cnt[0] > LINES_PF ? (uint32_t)LINES_PF : cnt[0], c1 = cnt[1] > LINES_PF ? (uint32_t)LINES_PF : cnt[1];
+        if (lane == 0) a.cnt_out[k] = c0 | (c1 << 16);
+        for (uint32_t q = (uint32_t)lane; q < c0; q += 64) a.kept_out[(size_t)k * (2 * LINES_PF) + q] = lo + field_idx[0][q];
+        for (uint32_t q = (uint32_t)lane; q < c1; q += 64) a.kept_out[(size_t)k * (2 * LINES_PF) + LINES_PF + q] = lo + field_idx[1][q];
+        return;
+    }
     P1_STAMP(3);
     sdv_frame_asm_pcm1 f; frasm1_clear(f);
     f.frame_number = frame;
@@ -389,6 +404,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
 
     /* 3. findFramePadding (:809-923); uint16_t arithmetic as the reference's fields */
     uint32_t top_pad[2], bot_pad[2];        /* hold uint16_t values */
+    uint32_t stale_to[2] = { 0, 0 };        /* field positions [cnt, stale_to) come from earlier frames */
     if (cfg.auto_offset) {
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -407,11 +423,35 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
                 bottom[p] = (uint16_t)(bottom[p] - bp * 2);
                 uint16_t dl = (uint16_t)(((int)bottom[p] - (int)top[p]) / 2 + 1);
                 dl = (uint16_t)(dl * 3);
-                if (dl > data[p]) err |= FE_STALE;   /* the reference would output sub-lines left in its field buffer by earlier frames */
+                if (dl > data[p]) stale_to[p] = dl / 3u;     /* the field buffer is read past what this frame wrote: earlier frames' lines */
                 data[p] = dl;
             }
             bot_pad[p] = (uint32_t)(uint16_t)((SUBLINES_PF - (int)data[p]) / 3 - (int)top_pad[p]);
         }
+    }
+    if (stale_to[0] | stale_to[1]) {
+        /* the lines earlier frames left at those places join the frame's staged lines (behind its own records) */
+        const uint32_t s0 = stale_to[0] > cnt[0] ? stale_to[0] - cnt[0] : 0u, s1 = stale_to[1] > cnt[1] ? stale_to[1] - cnt[1] : 0u;
+        if (!kLds || !a.cnt_in || n_scan + s0 + s1 > (uint32_t)LDS_LINES || stale_to[0] > LINES_PF || stale_to[1] > LINES_PF) err |= FE_STALE;
+        else {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint32_t base = n_scan + (p ? s0 : 0u);
+                for (uint32_t q = cnt[p] + (uint32_t)lane; q < stale_to[p]; q += 64) {
+                    Line16 l;
+                    uint32_t j = k;
+                    while (j > 0 && ((a.cnt_in[j - 1] >> (16 * p)) & 0xFFFFu) <= q) j--;
+                    if (j > 0) {
+                        const sdv_pcm1_line_rec &r = a.src.at(a.kept_in[(size_t)(j - 1) * (2 * LINES_PF) + (size_t)p * LINES_PF + q]);
+                        uint32_t dummy = 0;
+                        l = compact(r, r.frame_number, cfg.ignore_crc != 0, dummy);
+                    } else l = ((const Line16 *)a.hist)[p * LINES_PF + q];
+                    lines[base + q - cnt[p]] = l;
+                    field_idx[p][q] = (uint16_t)(base + q - cnt[p]);
+                }
+            }
+        }
+        __syncthreads();
     }
     const uint8_t order = cfg.field_order == ORDER_BFF ? ORDER_BFF : ORDER_TFF;
 
@@ -510,6 +550,29 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         if (err) { atomicOr(&a.stat[0], err); atomicMin(&a.stat[1], k); }
     }
 }
+/* the field buffers as this call leaves them: place q of field p holds the line of the last frame whose field reached that far */
+struct HistArgs1 { RecSrc1 src; const uint32_t *cnt, *kept; uint32_t n_seg; uint8_t ignore_crc; void *hist; };
+__device__ inline void hist_body(const HistArgs1 &a, int lane)
+{
+    for (uint32_t i = (uint32_t)lane; i < 2 * LINES_PF; i += 64) {
+        const uint32_t p = i / LINES_PF, q = i % LINES_PF;
+        uint32_t j = a.n_seg;
+        while (j > 0 && ((a.cnt[j - 1] >> (16 * p)) & 0xFFFFu) <= q) j--;
+        if (j > 0) {
+            const sdv_pcm1_line_rec &r = a.src.at(a.kept[(size_t)(j - 1) * (2 * LINES_PF) + (size_t)p * LINES_PF + q]);
+            uint32_t dummy = 0;
+            ((Line16 *)a.hist)[i] = compact(r, r.frame_number, a.ignore_crc != 0, dummy);
+        }
+    }
+}
+/* a fresh stitcher's field buffers: default-constructed PCM1SubLines (silent words, nothing valid; pcm1subline.cpp:47-64) */
+__device__ inline void hist_clear_body(void *hist, int lane)
+{
+    for (uint32_t i = (uint32_t)lane; i < 2 * LINES_PF; i += 64) {
+        Line16 l; for (int w = 0; w < 6; w++) l.w[w] = BIT_RANGE; l.line = 0; l.fl = 0; l.ref = 0;
+        ((Line16 *)hist)[i] = l;
+    }
+}
 /* ---- front half -> back half: what PCM1DataStitcher reads of a PCM1Line (sdv_pcm1_line_rec) out of the record the frame driver writes ---- */
 struct ConvArgs1 { const sdv_pcm1_bin_rec *in; sdv_pcm1_line_rec *out; size_t n; };
 __device__ inline void conv_body(const ConvArgs1 &a, size_t i)
@@ -528,6 +591,9 @@ __device__ inline void conv_body(const ConvArgs1 &a, size_t i)
 __global__ void __launch_bounds__(64) sdv_k_pcm1_bin_to_line(sdvp1::ConvArgs1 a) { sdvp1::conv_body(a, (size_t)blockIdx.x * 64u + threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_segments(sdvp1::SegArgs1 a) { sdvp1::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_scan(sdvp1::ScanArgs1 a) { sdvp1::scan_body(a, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_pcm1_hist(sdvp1::HistArgs1 a) { sdvp1::hist_body(a, (int)threadIdx.x); }
+struct sdv_p1_hist_clear_args { void *hist; };
+__global__ void __launch_bounds__(64) sdv_k_pcm1_hist_clear(sdv_p1_hist_clear_args a) { sdvp1::hist_clear_body(a.hist, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
 {
     alignas(16) __shared__ sdvp1::Line16 lines[sdvp1::LDS_LINES];

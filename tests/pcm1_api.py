@@ -67,10 +67,17 @@ CASES = {
     "stale_new_file": (4, dict(seed=318, p_bad=0.03, header=3, new_file=True, end_file=True), {}),
     "stale_end_file": (4, dict(seed=319, p_bad=0.03, new_file=True, end_file=True), {}),
     "stale_tag_inside": (4, dict(seed=320, p_bad=0.03, header=2), {}),
+    # manual line offsets over fields that are longer than 245 lines by their numbers and have lost lines: the stitcher is told to read its field
+    # buffers past what the frame wrote and puts out what earlier frames left there (pcm1datastitcher.cpp:896-909, :952-1016)
+    "manual_lost_lines": (6, dict(seed=323, p_bad=0.03, lines=(252, 250)), dict(auto_offset=0, odd_offset=-2, even_offset=1)),
+    "manual_lost_many": (8, dict(seed=324, p_bad=0.05, lines=(258, 261), header=2), dict(auto_offset=0, odd_offset=3, even_offset=-5)),
+    "manual_lost_first_frame": (5, dict(seed=325, p_bad=0.02, lines=(250, 255)), dict(auto_offset=0, odd_offset=0, even_offset=0)),
+    "manual_lost_file_marks": (7, dict(seed=326, p_bad=0.03, lines=(251, 249), new_file=True, end_file=True), dict(auto_offset=0, odd_offset=-1, even_offset=2, use_ecc=0)),
     "overlong_frame": (3, dict(seed=321, lines=(990, 985), p_bad=0.02), {}),
     "overlong_frame_tagged": (3, dict(seed=322, lines=(990, 985), p_bad=0.02, new_file=True, end_file=True), {}),
 }
-GOLDEN = ("header_emph", "bad5", "noise_outside", "file_marks", "manual_offsets", "empty_frames", "stale_tag_inside", "overlong_frame_tagged")
+GOLDEN = ("header_emph", "bad5", "noise_outside", "file_marks", "manual_offsets", "empty_frames", "stale_tag_inside", "overlong_frame_tagged",
+          "manual_lost_many", "manual_lost_first_frame")
 
 
 def _older_number(recs, srv, which=0):
@@ -96,8 +103,23 @@ def _tag_inside(recs):
     return np.concatenate(parts)
 
 
+def _lose_lines(share, seed, first_frame_share=None):
+    """Data lines lost on the way (the records are simply not there); first_frame_share: another share for the first frame."""
+    def f(recs):
+        rng = np.random.default_rng(seed)
+        p = np.full(len(recs), share)
+        if first_frame_share is not None:
+            p[recs["frame_number"] == recs["frame_number"][0]] = first_frame_share
+        return recs[~((recs["service_type"] == 0) & (rng.random(len(recs)) < p))]
+    return f
+
+
 # name: what is done to the generated stream
 MANGLE = {
+    "manual_lost_lines": _lose_lines(0.04, 1),
+    "manual_lost_many": _lose_lines(0.15, 2),
+    "manual_lost_first_frame": _lose_lines(0.03, 3, first_frame_share=0.5),      # places no frame has written yet: default-constructed sub-lines
+    "manual_lost_file_marks": _lose_lines(0.08, 4),
     "stale_new_file": lambda r: _older_number(r, SRV_NEW_FILE),
     "stale_end_file": lambda r: _older_number(r, SRV_END_FILE),
     "stale_tag_inside": _tag_inside,

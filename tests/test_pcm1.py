@@ -161,6 +161,24 @@ def test_emu_failed_call_leaves_the_stream_untouched(emu, oracle_lib):
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
 
 
+@pytest.mark.parametrize("name", ["manual_lost_many", "manual_lost_file_marks"])
+def test_emu_field_buffers_outlive_calls(name, emu):
+    """Manual line offsets over damaged fields, the stream cut into calls at every frame end and in the middle of frames: the lines earlier
+    frames left in the field buffers are found whether those frames came with this call or with one before."""
+    recs, st, want_p, want_f = _oracle(name)
+    ends = np.nonzero(recs["service_type"] == p1.SRV_END_FRAME)[0]
+    cuts = sorted(set([0, int(ends[0]) + 1, int(ends[1]) + 200, int(ends[3]) + 1, len(recs)]))
+    eng = emu.sdv_engine_create(0)
+    pairs, frames = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, p, f = ea.emu_pcm1_stitch(emu, eng, recs[a:b], st if a == 0 else None, pair_cap=20000, frame_cap=32)
+        assert rc == 0, emu.sdv_last_error(eng)
+        pairs.append(p); frames.append(f)
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate(pairs), np.concatenate(frames)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
 def test_emu_refuses_what_the_reference_never_finishes(emu):
     """A line of a later frame queued ahead of an END_FRAME: the reference pops its queue up to that line (pcm1datastitcher.cpp:1634-1660),
     finds the same END_FRAME again and assembles what is left of the frame without end (shown on the real reference: more frame reports
