@@ -524,9 +524,11 @@ int sdv_set_pcm1_stitch_settings(sdv_engine *e, const sdv_pcm1_stitch_settings *
 /* PCM1DataStitcher::doFrameReassemble (pcm1datastitcher.cpp:1578-1772) over a span of the PCM-1 line stream: every complete
  * frame (lines up to its END_FRAME) is trimmed, split into sub-lines and fields, padded to 735 sub-lines per field and
  * deinterleaved into 8 blocks per field (PCM1Deinterleaver::processBlock, pcm1deinterleaver.cpp:69-278; PCM-1 has no error
- * correction); 1470 PCMSamplePairs and one FrameAsmPCM1 per frame (plus the NEW_FILE / END_FILE tags).  Frames are
- * independent of each other in this format, so there is no stream state apart from records that wait for their END_FRAME.
- * Same conventions as sdv_stitch_frames (device pointers, counts returned, SDV_ERR_UNSUPPORTED for lines of foreign frames).
+ * correction); 1470 PCMSamplePairs and one FrameAsmPCM1 per frame (plus the NEW_FILE / END_FILE tags).  With automatic line
+ * offsets frames are independent of each other, and there is no stream state apart from records that wait for their END_FRAME; with manual
+ * offsets the stitcher's field buffers (what earlier frames left in them, pcm1datastitcher.cpp:896-909, 952-1016) live in the engine between
+ * calls; sdv_set_pcm1_stitch_settings starts a fresh stitcher.
+ * Same conventions as sdv_stitch_frames (device pointers, counts returned, SDV_ERR_UNSUPPORTED for lines of a later frame ahead of an END_FRAME).
  * A call that fails leaves the stream untouched - the lines of the call are not taken, lines that waited still wait - so it
  * can be repeated with the buffer sizes *n_pairs / *n_frames report. */
 int sdv_pcm1_stitch_frames(sdv_engine *e, const sdv_pcm1_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
