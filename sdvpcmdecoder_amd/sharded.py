@@ -110,7 +110,7 @@ class ShardedDecoder:
 
 class ShardedPcmDecoder:
     """The same for a PCM-1 or PCM-16x0 tape (`fmt` "pcm1" / "pcm16x0").  These formats need no successor frame (a frame is stitched
-    from its own lines) and PCM-1's stitcher carries nothing from frame to frame, so what crosses a range boundary is the frame
+    from its own lines) and PCM-1's stitcher carries nothing from frame to frame (with automatic line offsets; manual offsets are refused), so what crosses a range boundary is the frame
     driver's chain state (120 / 192 bytes) and, for PCM-16x0, the stitcher's statistics rings (sdv_get_pcm16x0_stitch_state).
     `eng`: the methods of sdvpcmdecoder_amd.Engine for the format (pcm1_binarize_frames, pcm1_bin_to_line_recs, pcm1_stitch_frames,
     get/set_chain_state; pcm16x0_binarize_frames, pcm16x0_stitch_frames, get/set_pcm16x0_chain_state, get/set_pcm16x0_stitch_state,
@@ -119,6 +119,10 @@ class ShardedPcmDecoder:
 
     def __init__(self, eng, rank: int, world: int, all_gather, height: int, fmt: str, stitch_settings, warmup: int = 20, stitch_warmup: int = 4):
         assert fmt in ("pcm1", "pcm16x0")
+        if fmt == "pcm1" and stitch_settings is not None and not getattr(stitch_settings, "auto_offset", 1):
+            # with manual line offsets PCM1DataStitcher's field buffers are stream state (what earlier frames left in them can be put out again):
+            # nothing here hands them from rank to rank
+            raise ValueError("ShardedPcmDecoder: a PCM-1 tape with manual line offsets does not shard (the stitcher's field buffers carry over from frame to frame)")
         self.eng, self.rank, self.world, self.all_gather, self.fmt = eng, rank, world, all_gather, fmt
         self.height, self.warmup, self.stitch_warmup, self.stitch_settings = height, warmup, stitch_warmup, stitch_settings
         self.rpf = height + 3 if fmt == "pcm1" else 3 * height + 3
