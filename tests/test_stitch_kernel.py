@@ -86,9 +86,19 @@ def test_emu_empty_and_tiny_inputs(emu, oracle_lib):
 
 
 def test_emu_rejects_what_it_cannot_reproduce(emu, oracle_lib):
+    """A line numbered for a later frame in the middle of a frame: the real stitcher pops its queue up to that line and never gets past it
+    (more frame reports than the stream has frames until the driver's buffers are full).  The product refuses the stream."""
     recs, st = sc.make_input("ntsc_clean", lambda luma: oracle_binarize(luma, mode=2))
     bad = recs.copy()
     bad["frame_number"][700] += 7                  # a line that claims another frame
+    if libs.ref_available():
+        import ctypes as C
+        f = libs.load_ref().ref_stitch_run
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(sa.StitchSettings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        pairs, frames, nf = np.zeros(40000, dtype=sa.PAIR_DTYPE), np.zeros(40, dtype=sa.FRASM_DTYPE), C.c_size_t(0)
+        assert f(bad.ctypes.data, len(bad), C.byref(st), pairs.ctypes.data, len(pairs), frames.ctypes.data, len(frames), C.byref(nf)) == -1
+        assert nf.value > int((bad["service_type"] == 5).sum()) + 2
     eng = emu.sdv_engine_create(0)
     rc, _, _ = ea.emu_stitch(emu, eng, bad, st)
     assert rc == -4 and b"frame" in emu.sdv_last_error(eng)      # SDV_ERR_UNSUPPORTED, loudly
