@@ -7,7 +7,8 @@
  *                           (sdv_get_stitch_state / sdv_set_stitch_state)
  * The gathered states are used to VERIFY a guess, the same speculation the engine runs inside a batch, one level up (DESIGN.md section 7;
  * the Python harness of the same loop: sdvpcmdecoder_amd/sharded.py):
- *   1. rank r > 0 decodes a short warm-up just before its range from a reset engine and keeps the state it ends in - its prediction of what rank
+ *   0. rank 0 decodes the first frames of its range and publishes its state (the binarizer's sticky levels), the others start their warm-up from it;
+ *   1. rank r > 0 decodes a short warm-up just before its range and keeps the state it ends in - its prediction of what rank
  *      r - 1 will hand over;
  *   2. every rank decodes its range from that state, then all ranks all-gather their final states;
  *   3. a rank whose prediction differs from what its predecessor really ended in decodes its range again from the true state; repeated until every
@@ -190,11 +191,35 @@ int main(int argc, char **argv)
     SDV_OKAY(sdv_reset_stream(eng));
     sdv_v2d_state predicted, fin;
     memset(&predicted, 0, sizeof(predicted));
+    /* The binarizer's levels are sticky - a line that reads from the levels it inherits does not measure them again - so on a tape that plays they are
+     * what the first lines of the TAPE measured, which no warm-up further down can find out.  Rank 0 decodes the first frames of its range first and
+     * publishes the state it has then; the other ranks start their warm-up from it (a warm-up of 20 frames refills the histories either way). */
+    int k0 = 0; size_t head_recs = 0;
+    if (world > 1) {
+        sdv_v2d_state early;
+        memset(&early, 0, sizeof(early));
+        if (rank == 0) {
+            k0 = warmup > 0 ? warmup : 1; if (k0 > n_own) k0 = n_own;
+            const unsigned fl = SDV_FLAG_NEW_FILE | ((last && k0 == n_own) ? SDV_FLAG_END_FILE : 0u);
+            head_recs = sdv_binarize_records(height, k0, fl);
+            SDV_OKAY(sdv_binarize_frames(eng, d_luma, (size_t)width, frame_bytes, width, height, k0, 1u, fl, d_whole, head_recs, d_stats, n_in + 2, NULL));
+            SDV_OKAY(sdv_get_chain_state(eng, &early));
+        }
+        std::vector<sdv_v2d_state> earlies((size_t)world);
+        comm->all_gather(&early, earlies.data(), sizeof(early));
+        gathers++;
+        if (rank > 0 && lo - lead > 0) SDV_OKAY(sdv_set_chain_state(eng, &earlies[0]));     /* (a warm-up that begins with the tape is the tape's own start) */
+    }
     if (lead) {
         SDV_OKAY(sdv_binarize_frames(eng, d_luma, (size_t)width, frame_bytes, width, height, lead, (uint32_t)(1 + lo - lead), 0, d_warm, n_warm, d_stats, n_in + 2, NULL));
         SDV_OKAY(sdv_get_chain_state(eng, &predicted));
     }
     auto run_range = [&]() {
+        if (k0 > 0) {       /* rank 0: the frames behind the ones it decoded first (it never has to decode anything again) */
+            if (k0 < n_own)
+                SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)k0 * frame_bytes, (size_t)width, frame_bytes, width, height, n_own - k0, (uint32_t)(1 + k0),
+                                             last ? SDV_FLAG_END_FILE : 0u, d_whole + head_recs, n_own_recs - head_recs, d_stats, n_in + 2, NULL));
+        } else
         SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)lead * frame_bytes, (size_t)width, frame_bytes, width, height, n_own, (uint32_t)(1 + lo), own_flags,
                                      d_whole, n_own_recs, d_stats, n_in + 2, NULL));
         SDV_OKAY(sdv_get_chain_state(eng, &fin));

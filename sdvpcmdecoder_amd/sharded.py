@@ -5,7 +5,10 @@ binarizer tuning and coordinate histories, 120 bytes; STC007DataStitcher: previo
 112 assembled lines that wait in conv_queue for the next frame's blocks - the "field seam").  Sharding therefore speculates once
 more, at rank granularity, with the same scheme the engine uses inside a batch:
 
-  1. rank r > 0 first decodes a short warm-up (the frames just before its range) from a freshly reset engine, discards the
+  0. rank 0 decodes the first frames of its range and all-gathers the state it has then: the binarizer's levels are sticky
+     (a line that reads from inherited levels does not measure them again), on a tape that plays they are what the tape's
+     first lines measured - the one thing a warm-up further down the tape cannot find out by itself;
+  1. rank r > 0 then decodes a short warm-up (the frames just before its range) from that state, discards the
      output and keeps the state it ends in - its *prediction* of the state rank r-1 will hand over;
   2. every rank decodes its own range from that state and all-gathers its final state (the only collective: 120 bytes
      per rank for the binarize stage, ~4 KB per rank - the seam lines - for the stitch stage; RCCL over xGMI on the GPU box);
@@ -54,12 +57,35 @@ class ShardedDecoder:
         # ---- binarize stage ------------------------------------------------------------------------------------------
         eng.reset_stream()
         predicted, warm = None, None
+        # The binarizer's levels are sticky: a line that reads from the levels it inherits does not measure them again, so on a tape that plays
+        # they are what the first lines of the TAPE measured - nothing a warm-up at frame lo - 20 can find out.  Rank 0 therefore decodes the first
+        # frames of its range first and publishes the state it has then; the other ranks start their warm-up from that state instead of from a
+        # reset engine: a warm-up without a failing line keeps those levels (right on a tape that plays), one with failing lines measures its own
+        # (right wherever the true chain did so at the same lines); its histories are filled by the warm-up's own frames either way.
+        head = None
+        if world > 1:
+            early = bytes(len(eng.get_chain_state()))       # (every rank contributes a buffer of the same size)
+            if rank == 0:
+                k0 = min(max(self.warmup, 1), n_own)
+                head, _ = eng.binarize_frames(luma[:k0], first_frame_no=first_frame_no, new_file=True, end_file=(last and k0 == n_own))
+                early = eng.get_chain_state()
+            early = self.all_gather(early)[0]
+            self.stats["gathers"] += 1
+            if rank > 0 and f0 > 0:     # (a warm-up that begins with the tape is the tape's own start: nothing to inherit)
+                eng.set_chain_state(early)
         if lead:
             warm, _ = eng.binarize_frames(luma[:lead], first_frame_no=first_frame_no + f0, new_file=False)
             predicted = eng.get_chain_state()
 
         def run_range():
-            own, _ = eng.binarize_frames(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
+            if head is not None:            # rank 0: the frames behind the ones it decoded first (it never has to decode anything again)
+                k0 = head.shape[0] // rpf
+                own = head
+                if k0 < n_own:
+                    rest, _ = eng.binarize_frames(luma[k0:n_own], first_frame_no=first_frame_no + k0, new_file=False, end_file=last)
+                    own = _cat(head, rest)
+            else:
+                own, _ = eng.binarize_frames(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
             final = eng.get_chain_state()
             extra = None
             if look:        # the successor frame of this range's last stitcher turn (rank r+1 decodes it again as its first frame)
@@ -157,11 +183,28 @@ class ShardedPcmDecoder:
         # ---- binarize stage: as ShardedDecoder ------------------------------------------------------------------------
         eng.reset_stream()
         predicted, warm = None, None
+        head = None                         # rank 0 decodes the first frames first and publishes its state: the levels are sticky (ShardedDecoder)
+        if world > 1:
+            early = bytes(len(self._chain()))
+            if rank == 0:
+                k0 = min(max(self.warmup, 1), n_own)
+                head = self._binarize(luma[:k0], first_frame_no=first_frame_no, new_file=True, end_file=(last and k0 == n_own))
+                early = self._chain()
+            early = self.all_gather(early)[0]
+            self.stats["gathers"] += 1
+            if rank > 0 and f0 > 0:
+                self._chain(early)
         if lead:
             warm = self._binarize(luma[:lead], first_frame_no=first_frame_no + f0, new_file=False)
             predicted = self._chain()
 
         def run_range():
+            if head is not None:
+                k0 = head.shape[0] // rpf
+                own = head
+                if k0 < n_own:
+                    own = _cat(head, self._binarize(luma[k0:n_own], first_frame_no=first_frame_no + k0, new_file=False, end_file=last))
+                return own, self._chain()
             own = self._binarize(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
             return own, self._chain()
         own, final = run_range()
