@@ -478,14 +478,26 @@ class Engine:
         import torch
         assert lines.is_cuda and lines.dtype == torch.uint8 and lines.dim() == 2 and lines.shape[1] == 32 and lines.is_contiguous()
         n = lines.shape[0]
+        own_pairs, own_frames = out_pairs is None, out_frames is None
         if out_pairs is None:
             out_pairs = torch.empty((n * 3 + 4096, 12), dtype=torch.uint8, device=lines.device)     # 3 pairs per line + padding lines
         if out_frames is None:
             out_frames = torch.empty((n // 64 + 64, 52), dtype=torch.uint8, device=lines.device)
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)
         npairs, nframes = C.c_size_t(0), C.c_size_t(0)
-        rc = self.lib.sdv_pcm1_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
-                                             C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
+        for attempt in (0, 1):
+            rc = self.lib.sdv_pcm1_stitch_frames(self._h, C.c_void_p(lines.data_ptr()), n, C.c_void_p(out_pairs.data_ptr()), out_pairs.shape[0],
+                                                 C.byref(npairs), C.c_void_p(out_frames.data_ptr()), out_frames.shape[0], C.byref(nframes), sptr)
+            # buffers of our own guess were too small (a frame that lost most of its lines still decodes to 1470 pairs; lines that waited in the engine
+            # complete frames): the refused call took nothing and reported the sizes - once more with those
+            if rc == -1 and attempt == 0 and (npairs.value > out_pairs.shape[0] or nframes.value > out_frames.shape[0]) and \
+                    (own_pairs or npairs.value <= out_pairs.shape[0]) and (own_frames or nframes.value <= out_frames.shape[0]):
+                if own_pairs and npairs.value > out_pairs.shape[0]:
+                    out_pairs = torch.empty((npairs.value, 12), dtype=torch.uint8, device=lines.device)
+                if own_frames and nframes.value > out_frames.shape[0]:
+                    out_frames = torch.empty((nframes.value, 52), dtype=torch.uint8, device=lines.device)
+                continue
+            break
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
 
