@@ -242,7 +242,7 @@ __device__ inline Line16 compact(const sdv_pcm1_line_rec &r, uint32_t frame, boo
 
 /* one wave, one frame.  kLds: the frame's lines are staged in `lines` (LDS) by the first sweep; otherwise later sweeps read the records again. */
 template <bool kLds>
-__device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uint32_t lo, uint32_t n, Line16 *lines, uint16_t (*field_idx)[LINES_PF + 3])
+__device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uint32_t lo, uint32_t n, Line16 *lines, uint16_t (*field_idx)[LINES_PF + 3])
 {
     const uint32_t frame = a.src.at(lo + n).frame_number;           /* the END_FRAME record */
     const bool plain = a.stat[2] == 0;
@@ -251,7 +251,13 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
     const uint32_t fofs = plain ? k : a.frasm_ofs[k];
     const Cfg1 cfg = a.cfg;
     uint32_t err = 0u, seen = 0;
-    auto line_at = [&](uint32_t i) -> Line16 { if (kLds) return lines[i]; uint32_t dummy = 0; return compact(a.src.at(lo + i), frame, cfg.ignore_crc != 0, dummy); };
+    /* (a frame too long for the LDS staging reads its records again on every access; `lines` is then free and holds the lines earlier frames left in
+     * the field buffers, if the frame is told to put any out: field_idx entries with bit 15 set point there) */
+    auto line_at = [&](uint32_t i) -> Line16 {
+        if (kLds) return lines[i];
+        if (i & 0x8000u) return lines[i & 0x7FFFu];
+        uint32_t dummy = 0; return compact(a.src.at(lo + i), frame, cfg.ignore_crc != 0, dummy);
+    };
 
     P1_STAMP(0);
     /* 1. findFrameTrim: every item is a first / last / count over the lines in stream order; index 0 = odd lines, 1 = even lines */
@@ -323,13 +329,13 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
     if ((seen ^ marks) & (FF_NEW_FILE | FF_END_FILE)) err |= FE_MARKS;      /* a file tag with another frame's number: the offsets were laid out for it */
 
     if (marks & FF_END_FILE) {                      /* the frame that carries the END_FILE tag only closes the file (:1721-1729) */
-        if (a.cnt_out) { if (lane == 0) a.cnt_out[k] = 0; return; }    /* ... and does not touch the field buffers */
+        if (a.cnt_out) { if (lane == 0) a.cnt_out[k] = 0; return false; }    /* ... and does not touch the field buffers */
         if (lane == 0) {
             if (fofs < a.frames_cap) { sdv_frame_asm_pcm1 d; frasm1_clear(d); d.service_type = SDV_PAIR_SRV_END_FILE; a.out_frames[fofs] = d; }
             if (pofs < a.pairs_cap) service_pair(&a.out_pairs[pofs], SDV_PAIR_SRV_END_FILE);
             if (err) { atomicOr(&a.stat[0], err); atomicMin(&a.stat[1], k); }
         }
-        return;
+        return false;
     }
 
     bool header_present = false, emphasis_set = false;
@@ -385,7 +391,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         if (lane == 0) a.cnt_out[k] = c0 | (c1 << 16);
         for (uint32_t q = (uint32_t)lane; q < c0; q += 64) a.kept_out[(size_t)k * (2 * LINES_PF) + q] = lo + field_idx[0][q];
         for (uint32_t q = (uint32_t)lane; q < c1; q += 64) a.kept_out[(size_t)k * (2 * LINES_PF) + LINES_PF + q] = lo + field_idx[1][q];
-        return;
+        return false;
     }
     P1_STAMP(3);
     sdv_frame_asm_pcm1 f; frasm1_clear(f);
@@ -432,11 +438,13 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
     if (stale_to[0] | stale_to[1]) {
         /* the lines earlier frames left at those places join the frame's staged lines (behind its own records) */
         const uint32_t s0 = stale_to[0] > cnt[0] ? stale_to[0] - cnt[0] : 0u, s1 = stale_to[1] > cnt[1] ? stale_to[1] - cnt[1] : 0u;
-        if (!kLds || !a.cnt_in || n_scan + s0 + s1 > (uint32_t)LDS_LINES || stale_to[0] > LINES_PF || stale_to[1] > LINES_PF) err |= FE_STALE;
+        const uint32_t room_from = kLds ? n_scan : 0u;      /* where `lines` is free */
+        if (kLds && a.cnt_in && room_from + s0 + s1 > (uint32_t)LDS_LINES) return true;        /* no room behind the frame's own lines: once more on the path that leaves `lines` free (nothing was written yet) */
+        if (!a.cnt_in || room_from + s0 + s1 > (uint32_t)LDS_LINES || stale_to[0] > LINES_PF || stale_to[1] > LINES_PF) err |= FE_STALE;
         else {
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const uint32_t base = n_scan + (p ? s0 : 0u);
+                const uint32_t base = room_from + (p ? s0 : 0u);
                 for (uint32_t q = cnt[p] + (uint32_t)lane; q < stale_to[p]; q += 64) {
                     Line16 l;
                     uint32_t j = k;
@@ -447,7 +455,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
                         l = compact(r, r.frame_number, cfg.ignore_crc != 0, dummy);
                     } else l = ((const Line16 *)a.hist)[p * LINES_PF + q];
                     lines[base + q - cnt[p]] = l;
-                    field_idx[p][q] = (uint16_t)(base + q - cnt[p]);
+                    field_idx[p][q] = (uint16_t)((base + q - cnt[p]) | (kLds ? 0u : 0x8000u));
                 }
             }
         }
@@ -549,6 +557,7 @@ __device__ inline void frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         if (fo < a.frames_cap) a.out_frames[fo] = f;
         if (err) { atomicOr(&a.stat[0], err); atomicMin(&a.stat[1], k); }
     }
+    return false;
 }
 /* the field buffers as this call leaves them: place q of field p holds the line of the last frame whose field reached that far */
 struct HistArgs1 { RecSrc1 src; const uint32_t *cnt, *kept; uint32_t n_seg; uint8_t ignore_crc; void *hist; };
@@ -600,7 +609,8 @@ __global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
     __shared__ uint16_t field_idx[2][sdvp1::LINES_PF + 3];
     const uint32_t k = blockIdx.x;
     const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, n = a.seg_end[k] - lo;
-    if (n <= sdvp1::LDS_LINES) sdvp1::frame_body<true>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
-    else sdvp1::frame_body<false>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
+    bool again = true;
+    if (n <= sdvp1::LDS_LINES) again = sdvp1::frame_body<true>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
+    if (again) { __syncthreads(); (void)sdvp1::frame_body<false>(a, k, (int)threadIdx.x, lo, n, lines, field_idx); }
 }
 #endif

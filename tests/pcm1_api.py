@@ -73,6 +73,7 @@ CASES = {
     "manual_lost_many": (8, dict(seed=324, p_bad=0.05, lines=(258, 261), header=2), dict(auto_offset=0, odd_offset=3, even_offset=-5)),
     "manual_lost_first_frame": (5, dict(seed=325, p_bad=0.02, lines=(250, 255)), dict(auto_offset=0, odd_offset=0, even_offset=0)),
     "manual_lost_file_marks": (7, dict(seed=326, p_bad=0.03, lines=(251, 249), new_file=True, end_file=True), dict(auto_offset=0, odd_offset=-1, even_offset=2, use_ecc=0)),
+    "manual_lost_long_frame": (6, dict(seed=327, p_bad=0.03, lines=(300, 296), header=1), dict(auto_offset=0, odd_offset=-3, even_offset=2)),     # > 544 records: the global-memory path
     "overlong_frame": (3, dict(seed=321, lines=(990, 985), p_bad=0.02), {}),
     "overlong_frame_tagged": (3, dict(seed=322, lines=(990, 985), p_bad=0.02, new_file=True, end_file=True), {}),
 }
@@ -120,6 +121,7 @@ MANGLE = {
     "manual_lost_many": _lose_lines(0.15, 2),
     "manual_lost_first_frame": _lose_lines(0.03, 3, first_frame_share=0.5),      # places no frame has written yet: default-constructed sub-lines
     "manual_lost_file_marks": _lose_lines(0.08, 4),
+    "manual_lost_long_frame": _lose_lines(0.06, 5),
     "stale_new_file": lambda r: _older_number(r, SRV_NEW_FILE),
     "stale_end_file": lambda r: _older_number(r, SRV_END_FILE),
     "stale_tag_inside": _tag_inside,

@@ -12,7 +12,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
 orc = libs.load_oracle()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
-    lines = (int(rng.integers(236, 275)), int(rng.integers(236, 275)))
+    lines = (int(rng.integers(236, 330)), int(rng.integers(236, 330)))
     nf = int(rng.integers(3, 40))
     recs = p1.make_stream(nf, seed=seed0 + case, lines=lines, p_bad=0.03, header=int(rng.integers(0, 3)), new_file=bool(case % 3 == 0), end_file=bool(case % 3 == 0),
                           noise_lines=int(rng.choice([0, 0, 4])))
