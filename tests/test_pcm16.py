@@ -118,7 +118,8 @@ def emu(emu_lib):
     return ea.bind(emu_lib)
 
 
-@pytest.mark.parametrize("name", list(p16.CASES))
+# (the 372-frame tape takes the emulator most of a minute: it is left to the GPU test and to the comparison of the oracle with the real reference)
+@pytest.mark.parametrize("name", [n for n in p16.CASES if n != "ei_lost_every_field"])
 def test_emu_matches_oracle(name, emu, oracle_lib):
     recs, st, want_p, want_f = _oracle(name)
     eng = emu.sdv_engine_create(0)
