@@ -692,6 +692,22 @@ int sdv_decode_frames(sdv_engine *e, int pcm_type, const uint8_t *luma, size_t r
                       sdv_frame_stats *out_stats, size_t stats_cap,
                       int with_audio, int audio_stop, sdv_audio_purge *out_purges, size_t purges_cap, size_t *n_purges, uint64_t *n_masked, void *stream);
 
+/* One assembled STC007Line as STC007DataStitcher hands it to the visualiser (newLineProcessed, stc007datastitcher.cpp:6689-6704): a line of conv_queue
+ * after padding and CWD, with the per-word states the window colours by.  32 bytes. */
+enum { SDV_AL_FORCED_BAD = 1 << 0,      /* STC007Line::isForcedBad() */
+       SDV_AL_MARKERS = 1 << 1,         /* hasMarkers() */
+       SDV_AL_CRC_VALID = 1 << 2 };     /* isCRCValid() */
+typedef struct sdv_asm_line_rec {
+    uint32_t frame_number;
+    uint16_t line_number;
+    uint16_t words[9];              /* getWord(0..8) */
+    uint16_t calc_crc;
+    uint16_t word_crc_ok;           /* bit i = isWordCRCOk(i), i = 0..8 (all clear on a line that is forced bad) */
+    uint16_t word_valid;            /* bit i = isWordValid(i) */
+    uint8_t flags;                  /* SDV_AL_* */
+    uint8_t _pad;
+} sdv_asm_line_rec;
+
 /* The data blocks of the stitch stage, for the visualiser: STC007DataStitcher::outputDataBlock hands every block it has turned into three sample
  * pairs to `newBlockProcessed(STC007DataBlock)` (stc007datastitcher.cpp:6626).  With a block buffer set (device memory, blocks_cap records; NULL:
  * off, the default), every sdv_stitch_frames call also writes those blocks - as it leaves them: seam / BROKEN masking applied, sample rate set -
@@ -699,6 +715,14 @@ int sdv_decode_frames(sdv_engine *e, int pcm_type, const uint8_t *luma, size_t r
  * last call wrote (or needed, when it failed with SDV_ERR_BAD_ARG for lack of room).  Costs one more launch of the turn kernel per call. */
 int sdv_set_stitch_block_output(sdv_engine *e, sdv_block_rec *out_blocks, size_t blocks_cap);
 size_t sdv_stitch_block_count(sdv_engine *e);
+/* ... and the assembled lines the stitcher hands to the visualiser at the start of every turn's deinterleave (newLineProcessed: the lines of conv_queue that
+ * belong to the turn's two frames, after padding and CWD; 490 per NTSC turn on a tape that plays): with a line buffer set every sdv_stitch_frames call also
+ * writes them, turn after turn.  sdv_stitch_line_count: how many the last call wrote (or needed); sdv_stitch_line_counts: how many each turn of the last
+ * call made (a host array of `cap` entries is filled; returns the number of turns) - one turn per frame descriptor that is no file tag.  Costs two more
+ * launches of the turn kernel per call. */
+int sdv_set_stitch_line_output(sdv_engine *e, sdv_asm_line_rec *out_lines, size_t lines_cap);
+size_t sdv_stitch_line_count(sdv_engine *e);
+size_t sdv_stitch_line_counts(sdv_engine *e, uint32_t *per_turn, size_t cap);
 
 /* ---- visualiser feed: the canvases of RenderPCM's "binarized lines" window ---------------------------------------------------
  * Replaces RenderPCM::renderNewLine(STC007Line / PCM1Line / PCM16X0SubLine) (renderpcm.cpp:939-1169, 489-624, 743-936) as MainWindow drives it
@@ -717,8 +741,9 @@ size_t sdv_stitch_block_count(sdv_engine *e);
  * reference leaves those rows uninitialised).  Records behind the last END_FRAME are not drawn: pass whole frames.  *n_frames = frames in
  * `recs`; more than canvases_cap: SDV_ERR_BAD_ARG, nothing drawn.  Device pointers; the call reads one small array back (the frame count)
  * and leaves the drawing running on `stream`.  sdv_vis_reset: a new canvas (RenderPCM::startNewFrame).
- * The block canvas of STC-007 follows below; those of PCM-1 / PCM-16x0 and the assembled-lines canvas are not rebuilt. */
-enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2, SDV_VIS_STC007_BLOCKS_NTSC = 3, SDV_VIS_STC007_BLOCKS_PAL = 4 };
+ * The block canvas and the assembled-lines canvas of STC-007 follow below; those of PCM-1 / PCM-16x0 are not rebuilt. */
+enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2, SDV_VIS_STC007_BLOCKS_NTSC = 3, SDV_VIS_STC007_BLOCKS_PAL = 4,
+       SDV_VIS_STC007_ASM_NTSC = 5, SDV_VIS_STC007_ASM_PAL = 6 };
 int sdv_vis_canvas_size(int kind, uint32_t *width, uint32_t *height);
 int sdv_vis_reset(sdv_engine *e, int kind, void *stream);
 int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_recs, uint32_t *out_canvases, size_t canvases_cap, size_t *n_frames, void *stream);
@@ -732,6 +757,12 @@ int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_rec
  * emphasis (the reference never sets it for STC-007, stc007datastitcher.cpp:6719).  Device pointers but frame_blocks; asynchronous on `stream`. */
 int sdv_vis_render_blocks(sdv_engine *e, int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
                           uint32_t *out_canvases, size_t canvases_cap, void *stream);
+/* The assembled-lines window (renderAssembled, mainwindow.cpp:2000-2052): RenderPCM::renderNewLine(STC007Line) on the lines the stitcher hands over -
+ * the line buffer sdv_set_stitch_line_output filled - where every word has its own state after the CWD pass (grey: read, green: repaired, yellow / red:
+ * failed with / without markers, magenta: line forced bad).  kind: SDV_VIS_STC007_ASM_NTSC (685 x 490) / _PAL (685 x 588); frame_lines: HOST array,
+ * lines per frame (sdv_stitch_line_counts).  Otherwise as sdv_vis_render_blocks. */
+int sdv_vis_render_asm_lines(sdv_engine *e, int kind, const sdv_asm_line_rec *lines, size_t n_lines, const uint32_t *frame_lines, size_t n_frames,
+                             uint32_t *out_canvases, size_t canvases_cap, void *stream);
 
 #ifdef __cplusplus
 }

@@ -502,6 +502,27 @@ long orc_stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_se
 {
     return stitch_run(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL, 0, NULL);
 }
+/* ... the assembled lines the stitcher hands to the visualiser (newLineProcessed) of the last orc_stitch_run_blocks call: kept here until asked for */
+static sdv_asm_line_rec *g_asm; static size_t g_asm_n; static uint32_t *g_asm_frames; static size_t g_asm_frames_n;
+static void asm_to_rec(const orc_stc_line *l, sdv_asm_line_rec *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->frame_number = l->frame_number; r->line_number = l->line_number; r->calc_crc = l->calc_crc;
+    for (int i = 0; i < 9; i++) {
+        r->words[i] = l->words[i];
+        if (!l->forced_bad && l->word_crc[i]) r->word_crc_ok |= (uint16_t)(1u << i);        /* isWordCRCOk / isWordValid: false on a forced-bad line */
+        if (!l->forced_bad && l->word_valid[i]) r->word_valid |= (uint16_t)(1u << i);
+    }
+    r->flags = (uint8_t)((l->forced_bad ? SDV_AL_FORCED_BAD : 0) | (orc_stc_has_markers(l) ? SDV_AL_MARKERS : 0) | (orc_stc_crc_valid(l) ? SDV_AL_CRC_VALID : 0));
+}
+/* the lines (n_lines of them, up to cap copied) and how many each stitcher turn made (n_turns entries, up to turns_cap copied) */
+void orc_stitch_last_asm_lines(sdv_asm_line_rec *out, size_t cap, size_t *n_lines, uint32_t *per_turn, size_t turns_cap, size_t *n_turns)
+{
+    for (size_t i = 0; i < g_asm_n && i < cap; i++) out[i] = g_asm[i];
+    for (size_t i = 0; i < g_asm_frames_n && i < turns_cap; i++) per_turn[i] = g_asm_frames[i];
+    if (n_lines) *n_lines = g_asm_n;
+    if (n_turns) *n_turns = g_asm_frames_n;
+}
 /* ... and the data blocks the stitcher hands to the visualiser (newBlockProcessed), one per three sample pairs */
 long orc_stitch_run_blocks(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                            sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
@@ -540,7 +561,14 @@ static long stitch_run(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch
     size_t nf = s->frames_n < frames_cap ? s->frames_n : frames_cap;
     for (size_t i = 0; i < nf; i++) frasm_to_pod(&s->frames[i], &frames[i]);
     if (n_frames) *n_frames = s->frames_n;
-    if (blocks) { for (size_t i = 0; i < s->blocks_n && i < blocks_cap; i++) block_to_rec(&s->blocks[i], &blocks[i]); }
+    if (blocks) {
+        for (size_t i = 0; i < s->blocks_n && i < blocks_cap; i++) block_to_rec(&s->blocks[i], &blocks[i]);
+        free(g_asm); free(g_asm_frames);
+        g_asm = (sdv_asm_line_rec *)malloc((s->asm_n + 1) * sizeof(*g_asm)); g_asm_n = s->asm_n;
+        for (size_t i = 0; i < s->asm_n; i++) asm_to_rec(&s->asm_lines[i], &g_asm[i]);
+        g_asm_frames = (uint32_t *)malloc((s->asm_frames + 1) * sizeof(uint32_t)); g_asm_frames_n = s->asm_frames;
+        for (size_t i = 0; i < s->asm_frames; i++) g_asm_frames[i] = (uint32_t)s->asm_frame_n[i];
+    }
     if (n_blocks) *n_blocks = s->blocks_n;
     orc_stitcher_free(s);
     free(s);

@@ -424,6 +424,14 @@ static void frasm_to_pod(FrameAsmSTC007 &f, sdv_frame_asm *o)
     o->ctrl_index = f.ctrl_index; o->ctrl_hour = f.ctrl_hour; o->ctrl_minute = f.ctrl_minute; o->ctrl_second = f.ctrl_second; o->ctrl_field = f.ctrl_field;
 }
 
+static std::vector<sdv_asm_line_rec> g_asm; static std::vector<uint32_t> g_asm_turns; static uint32_t g_asm_in_turn;
+extern "C" void ref_stitch_last_asm_lines(sdv_asm_line_rec *out, size_t cap, size_t *n_lines, uint32_t *per_turn, size_t turns_cap, size_t *n_turns)
+{
+    for (size_t i = 0; i < g_asm.size() && i < cap; i++) out[i] = g_asm[i];
+    for (size_t i = 0; i < g_asm_turns.size() && i < turns_cap; i++) per_turn[i] = g_asm_turns[i];
+    if (n_lines) *n_lines = g_asm.size();
+    if (n_turns) *n_turns = g_asm_turns.size();
+}
 static long ref_stitch_worker(const sdv_line_rec *recs, size_t n_recs, const sdv_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                sdv_frame_asm *frames, size_t frames_cap, size_t *n_frames, sdv_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
 {
@@ -437,6 +445,17 @@ static long ref_stitch_worker(const sdv_line_rec *recs, size_t n_recs, const sdv
     QObject::connect(ds, &STC007DataStitcher::guiUpdFrameAsm, [&](FrameAsmSTC007 d) { fr_mtx.lock(); fr.push_back(d); fr_mtx.unlock(); });
     size_t blocks_seen = 0;           /* newBlockProcessed: the block as outputDataBlock hands it to the visualiser (:6626), on the stitcher's thread */
     if (blocks) QObject::connect(ds, &STC007DataStitcher::newBlockProcessed, [&](STC007DataBlock b) { if (blocks_seen < blocks_cap) block_to_rec(b, &blocks[blocks_seen]); blocks_seen++; });
+    if (blocks) {       /* ... and the assembled lines (newLineProcessed, :6696), kept for ref_stitch_last_asm_lines; a turn ends with its guiUpdFrameAsm */
+        g_asm.clear(); g_asm_turns.clear(); g_asm_in_turn = 0;
+        QObject::connect(ds, &STC007DataStitcher::newLineProcessed, [&](STC007Line l) {
+            sdv_asm_line_rec r; memset(&r, 0, sizeof(r));
+            r.frame_number = l.frame_number; r.line_number = l.line_number; r.calc_crc = l.getCalculatedCRC();
+            for (int i = 0; i < 9; i++) { r.words[i] = l.getWord(i); if (l.isWordCRCOk(i)) r.word_crc_ok |= (uint16_t)(1u << i); if (l.isWordValid(i)) r.word_valid |= (uint16_t)(1u << i); }
+            r.flags = (uint8_t)((l.isForcedBad() ? SDV_AL_FORCED_BAD : 0) | (l.hasMarkers() ? SDV_AL_MARKERS : 0) | (l.isCRCValid() ? SDV_AL_CRC_VALID : 0));
+            g_asm.push_back(r); g_asm_in_turn++;
+        });
+        QObject::connect(ds, &STC007DataStitcher::guiUpdFrameAsm, [&](FrameAsmSTC007 d) { if (!d.isServNewFile() && !d.isServEndFile()) { g_asm_turns.push_back(g_asm_in_turn); g_asm_in_turn = 0; } });
+    }
     ds->setVideoStandard(st->video_standard); ds->setFieldOrder(st->field_order);
     ds->setPCorrection(st->enable_p); ds->setQCorrection(st->enable_q); ds->setCWDCorrection(st->enable_cwd);
     ds->setM2SampleFormat(st->m2_format); ds->setResolutionPreset(st->resolution_preset); ds->setSampleRatePreset(st->sample_rate_preset);

@@ -150,3 +150,56 @@ extern "C" long ref_vis_render_blocks(int kind, const sdv_block_rec *blocks, siz
     if (height) *height = h;
     return frames;
 }
+
+
+/* ---- the assembled-lines window: renderNewLine(STC007Line) on the stitcher's lines, as MainWindow wires renderAssembled (mainwindow.cpp:2000-2052) -- */
+static bool to_asm_line(const sdv_asm_line_rec &r, STC007Line &l)
+{
+    bool ok = true;
+    l.clear();
+    l.frame_number = r.frame_number; l.line_number = r.line_number;
+    for (uint8_t i = 0; i < 9; i++) {
+        const bool crc = (r.word_crc_ok >> i) & 1, valid = (r.word_valid >> i) & 1;
+        l.setWord(i, r.words[i], crc);                  /* word_crc = word_valid = crc */
+        if (valid && !crc) l.setFixed(i);
+        if (!valid && crc) ok = false;
+    }
+    l.calcCRC();
+    if (r.flags & SDV_AL_MARKERS) l.forceMarkersOk();
+    if (r.flags & SDV_AL_FORCED_BAD) {
+        l.setForcedBad();
+        if (r.word_crc_ok | r.word_valid) ok = false;
+    }
+    if (((r.flags & SDV_AL_CRC_VALID) != 0) != l.isCRCValid()) ok = false;
+    return ok;
+}
+/* kind: 5 NTSC (490 rows), 6 PAL (588 rows).  Returns the frames; -2: a record the line object cannot express, -3: its CRC state differs. */
+extern "C" long ref_vis_render_asm_lines(int kind, const sdv_asm_line_rec *lines, size_t n_lines, const uint32_t *frame_lines, size_t n_frames,
+                                         uint32_t *out, size_t out_cap, uint32_t *width, uint32_t *height)
+{
+    if (!QCoreApplication::instance()) new QCoreApplication(q_argc, q_argv);
+    RenderPCM ren;
+    long frames = 0;
+    uint32_t w = 0, h = 0;
+    QObject::connect(&ren, &RenderPCM::renderedFrame, [&](QImage img) {
+        w = (uint32_t)img.width(); h = (uint32_t)img.height();
+        if ((size_t)frames < out_cap)
+            for (uint32_t y = 0; y < h; y++) memcpy(out + ((size_t)frames * h + y) * w, img.constScanLine((int)y), (size_t)w * 4);
+        frames++;
+    });
+    ren.setLivePlay(false);
+    ren.startSTC007NTSCFrame();
+    ren.setLineCount(kind == 6 ? FrameAsmDescriptor::VID_PAL : FrameAsmDescriptor::VID_NTSC);
+    STC007Line l;
+    size_t at = 0;
+    for (size_t f = 0; f < n_frames; f++) {
+        for (uint32_t i = 0; i < frame_lines[f] && at < n_lines; i++, at++) {
+            if (!to_asm_line(lines[at], l)) return -2;
+            ren.renderNewLine(l);
+        }
+        ren.prepareNewFrame((uint32_t)f); ren.displayIsReady();
+    }
+    if (width) *width = w;
+    if (height) *height = h;
+    return frames;
+}

@@ -29,6 +29,8 @@ void orc_vis_canvas_size(int kind, uint32_t *w, uint32_t *h)
         case ORC_VIS_PCM16X0: *w = 4 * 193; *h = 490; break;     /* startPCM1600Frame :140-143 */
         case ORC_VIS_STC007_BLOCKS_NTSC: *w = 6 * (6 + 16 * 6 + 7); *h = 490; break;     /* startSTC007DBFrame :170-173 (+ setLineCount(VID_NTSC)) */
         case ORC_VIS_STC007_BLOCKS_PAL: *w = 6 * (6 + 16 * 6 + 7); *h = 588; break;      /* ... + setLineCount(VID_PAL), mainwindow.cpp:2093 */
+        case ORC_VIS_STC007_ASM_NTSC: *w = 5 * 137; *h = 490; break;                     /* startSTC007NTSCFrame (+ setLineCount(VID_NTSC)), mainwindow.cpp:2032, 2046 */
+        case ORC_VIS_STC007_ASM_PAL: *w = 5 * 137; *h = 588; break;
         default: *w = *h = 0;
     }
 }
@@ -217,6 +219,52 @@ long orc_vis_render_blocks(int kind, const sdv_block_rec *blocks, size_t n_block
     for (size_t f = 0; f < n_frames; f++) {          /* newFrameAssembled -> prepareNewFrame: the canvas goes out, the fill row back to 0 */
         for (uint32_t i = 0; i < frame_blocks[f] && at < n_blocks; i++, at++)
             if (i < h) stc_block(&blocks[at], canvas + (size_t)i * w);
+        if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
+    }
+    return (long)n_frames;
+}
+
+/* ---- the assembled-lines window: renderNewLine(STC007Line) (:939-1169) on the lines STC007DataStitcher hands over (newLineProcessed), whose words
+ * carry their own states after the CWD pass ------------------------------------------------------------------------------------------------- */
+static void stc_asm_line(const sdv_asm_line_rec *r, uint32_t *px)
+{
+    const bool crc_valid = (r->flags & SDV_AL_CRC_VALID) != 0, markers = (r->flags & SDV_AL_MARKERS) != 0, forced = (r->flags & SDV_AL_FORCED_BAD) != 0;
+    for (int i = 0; i < 4; i++) {
+        const bool one = (i % 2) == 0;
+        const uint32_t c = (crc_valid || markers) ? (one ? B1_GRY : B0_GRY) : PX_BLK;
+        for (int j = 0; j < 5; j++) *px++ = c;
+    }
+    for (int w = 0; w < 9; w++) {
+        const bool wc = (r->word_crc_ok >> w) & 1, wv = (r->word_valid >> w) & 1;
+        for (int b = (w == 8 ? 16 : 14) - 1; b >= 0; b--) {
+            const bool one = ((r->words[w] >> b) & 1) != 0;
+            uint32_t c;
+            if (forced) c = one ? B1_MGN : B0_MGN;
+            else if (wc) c = one ? B1_GRY : B0_GRY;
+            else if (wv) c = one ? B1_GRN : B0_GRN;
+            else if (markers) c = one ? B1_YEL : B0_YEL;
+            else c = one ? B1_RED : B0_RED;
+            for (int j = 0; j < 5; j++) *px++ = c;
+        }
+    }
+    for (int i = 0; i < 5; i++) {
+        uint32_t c = PX_BLK;
+        if (i == 0) { if (crc_valid || markers) c = B0_GRY; }
+        else if (crc_valid) c = B1_MARK;
+        else if (markers) c = B1_GRY;
+        for (int j = 0; j < 5; j++) *px++ = c;
+    }
+}
+long orc_vis_render_asm_lines(int kind, const sdv_asm_line_rec *lines, size_t n_lines, const uint32_t *frame_lines, size_t n_frames, uint32_t *canvas,
+                              uint32_t *out, size_t out_cap)
+{
+    uint32_t w, h;
+    orc_vis_canvas_size(kind, &w, &h);
+    if (kind != ORC_VIS_STC007_ASM_NTSC && kind != ORC_VIS_STC007_ASM_PAL) return -1;
+    size_t at = 0;
+    for (size_t f = 0; f < n_frames; f++) {
+        for (uint32_t i = 0; i < frame_lines[f] && at < n_lines; i++, at++)
+            if (i < h) stc_asm_line(&lines[at], canvas + (size_t)i * w);
         if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
     }
     return (long)n_frames;

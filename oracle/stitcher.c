@@ -122,7 +122,7 @@ void orc_stitcher_init(orc_stitcher *s)   /* :3-38, :7228-7236 */
 void orc_stitcher_free(orc_stitcher *s)
 {
     free(s->trim_buf); free(s->frame1_even); free(s->frame1_odd); free(s->frame2_even); free(s->frame2_odd);
-    free(s->in_lines.v); free(s->padding_queue.v); free(s->conv_queue.v); free(s->out); free(s->frames); free(s->blocks);
+    free(s->in_lines.v); free(s->padding_queue.v); free(s->conv_queue.v); free(s->out); free(s->frames); free(s->blocks); free(s->asm_lines); free(s->asm_frame_n);
     memset(s, 0, sizeof(*s));
 }
 void orc_stitcher_push_line(orc_stitcher *s, const orc_stc_line *l) { dq_push_back(&s->in_lines, l); }
@@ -1078,6 +1078,17 @@ static void perform_deinterleave(orc_stitcher *s)
     orc_frasm *f0 = &s->frasm_f0, *f1 = &s->frasm_f1;
     d->ignore_crc = s->ignore_CRC; d->force_ecc_check = !s->ignore_CRC;
     orc_deint_set_p(d, s->enable_P_code); orc_deint_set_q(d, s->enable_Q_code); d->en_cwd = s->enable_CWD;
+    if (s->keep_blocks) {       /* "dump the whole line buffer out (for visualization)", :6689-6704: the lines of frame A and frame B */
+        size_t made = 0;
+        for (size_t i = 0; i < s->conv_queue.n; i++) {
+            const orc_stc_line *l = dq_at(&s->conv_queue, i);
+            if (l->frame_number != f1->frame_number && l->frame_number != s->frasm_f2.frame_number) continue;
+            if (s->asm_n == s->asm_cap) { s->asm_cap = s->asm_cap ? s->asm_cap * 2 : 2048; s->asm_lines = (orc_stc_line *)realloc(s->asm_lines, s->asm_cap * sizeof(*l)); }
+            s->asm_lines[s->asm_n++] = *l; made++;
+        }
+        if (s->asm_frames == s->asm_frames_cap) { s->asm_frames_cap = s->asm_frames_cap ? s->asm_frames_cap * 2 : 64; s->asm_frame_n = (size_t *)realloc(s->asm_frame_n, s->asm_frames_cap * sizeof(size_t)); }
+        s->asm_frame_n[s->asm_frames++] = made;
+    }
     while (s->conv_queue.n > ORC_MIN_DEINT_DATA) {
         bool already_unsafe = false;
         orc_block_clear(&b);

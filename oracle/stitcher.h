@@ -60,6 +60,7 @@ typedef struct {
     orc_frasm *frames; size_t frames_n, frames_cap;        /* guiUpdFrameAsm emissions */
     orc_stc_block *blocks; size_t blocks_n, blocks_cap;    /* newBlockProcessed emissions (outputDataBlock :6626), kept when keep_blocks is set */
     bool keep_blocks;
+    orc_stc_line *asm_lines; size_t asm_n, asm_cap; size_t *asm_frame_n; size_t asm_frames, asm_frames_cap;   /* newLineProcessed emissions and how many each turn made */
 } orc_stitcher;
 
 void orc_stitcher_init(orc_stitcher *s);

@@ -41,7 +41,7 @@ enum { MST_BOT_2 = 4, MED_LEN_OK = 3 };      /* STC007Line::MARK_ST_BOT_2 / MARK
 enum { NO_COORD_L = -32768, NO_COORD_R = 32767 };
 
 /* ---- a line as the stitcher needs it (STC007Line minus the pixel side). 32 bytes. ----------------------------- */
-enum { SL_FORCED_BAD = 1, SL_COORDS_VALID = 2, SL_BW_SET = 4 };
+enum { SL_FORCED_BAD = 1, SL_COORDS_VALID = 2, SL_BW_SET = 4, SL_MARKERS = 8 /* hasMarkers(): only the visualiser's feed looks at it */ };
 struct alignas(16) SLine {
     uint32_t frame; uint16_t line; uint16_t words[9]; uint16_t calc_crc;
     uint16_t wcrc, wvalid;          /* bit i = word_crc[i] / word_valid[i], i = 0..8 */
@@ -87,7 +87,8 @@ __device__ inline SLine sline_from_rec(const sdv_line_rec &r)
     l.calc_crc = r.calc_crc;
     bool forced = (r.flags & SDV_LF_FORCED_BAD) != 0;
     bool cv = r.data_start != NO_COORD_L && r.data_stop != NO_COORD_R && r.data_start < r.data_stop;
-    l.flags = (uint8_t)((forced ? SL_FORCED_BAD : 0) | (cv ? SL_COORDS_VALID : 0) | ((r.flags & SDV_LF_BW_SET) ? SL_BW_SET : 0));
+    l.flags = (uint8_t)((forced ? SL_FORCED_BAD : 0) | (cv ? SL_COORDS_VALID : 0) | ((r.flags & SDV_LF_BW_SET) ? SL_BW_SET : 0) |
+                        ((r.mark_st_stage == MST_BOT_2 && r.mark_ed_stage == MED_LEN_OK) ? SL_MARKERS : 0));
     bool v = !forced && l.calc_crc == l.words[8];
     l.wcrc = l.wvalid = v ? 0x1FF : 0;
     l.ref_level = r.ref_level;
@@ -591,6 +592,7 @@ struct StepArgs {
     uint32_t first_round;
     unsigned long long *timing;             /* optional: 8 cycle stamps per step (SDV_STITCH_TIMING=1), NULL otherwise */
     sdv_block_rec *blocks; const uint32_t *block_ofs;   /* optional (the visualiser's feed): turn k's data blocks go to blocks[block_ofs[k] ..], newBlockProcessed :6626 */
+    uint32_t *asm_cnt; sdv_asm_line_rec *asm_lines; const uint32_t *asm_ofs;   /* optional: how many assembled lines turn k hands to the visualiser (newLineProcessed :6696) / where they go */
 };
 
 struct FieldStitchStats { uint16_t index, valid, silent, unchecked, broken; };    /* frametrimset.h:278-300 */
@@ -1356,6 +1358,7 @@ struct Step {
     }
     uint32_t *pairbuf;                      /* LDS: 64 x 3 pairs as dwords */
     sdv_block_rec *blocks_out;              /* this turn's place in the block stream, or NULL */
+    uint32_t *asm_cnt_out; sdv_asm_line_rec *asm_out;      /* the same for the assembled lines: a count to leave, or a place to write to */
     __device__ static inline void pack_pair(const sdv_sample_pair &p, uint32_t *o)
     {
         o[0] = (uint32_t)(uint16_t)p.audio_word[0] | ((uint32_t)(uint16_t)p.audio_word[1] << 16);
@@ -1380,6 +1383,30 @@ struct Step {
     __device__ inline void perform_deinterleave()
     {
         const int nblk = qn > MIN_DEINT ? qn - MIN_DEINT : 0;
+        if (asm_cnt_out || asm_out) {
+            /* "dump the whole line buffer out (for visualization)" (:6689-6704): the lines of frame A and frame B as they stand behind the CWD pass */
+            uint32_t made = 0;
+            for (int c = 0; c * 64 < qn; c++) {
+                const int i = c * 64 + lane;
+                SLine l; bool mine = false;
+                if (i < qn) { l = q[i]; mine = l.frame == f1.frame_number || l.frame == f2.frame_number; }
+                const uint64_t mm = __ballot(mine);
+                if (asm_out && mine) {
+                    sdv_asm_line_rec r;
+                    const bool forced = (l.flags & SL_FORCED_BAD) != 0;
+                    r.frame_number = l.frame; r.line_number = l.line;
+#pragma unroll
+                    for (int w = 0; w < 9; w++) r.words[w] = l.words[w];
+                    r.calc_crc = l.calc_crc;
+                    r.word_crc_ok = forced ? (uint16_t)0 : (uint16_t)(l.wcrc & 0x1FF); r.word_valid = forced ? (uint16_t)0 : (uint16_t)(l.wvalid & 0x1FF);
+                    r.flags = (uint8_t)((forced ? SDV_AL_FORCED_BAD : 0) | ((l.flags & SL_MARKERS) ? SDV_AL_MARKERS : 0) | (crc_valid(l) ? SDV_AL_CRC_VALID : 0));
+                    r._pad = 0;
+                    asm_out[made + (uint32_t)__popcll(mm & lanemask_lt(lane))] = r;
+                }
+                made += (uint32_t)__popcll(mm);
+            }
+            if (asm_cnt_out && lane == 0) *asm_cnt_out = made;
+        }
         RingSrc src; src.ring = ring;
         __syncthreads();                                              /* whoever used the ring before is done with it */
         for (int i = lane; i < RING_SPAN && i < qn; i += 64) ring[i] = view(q[i]);
@@ -1521,6 +1548,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     s.l1 = a.fl[k]; s.l2 = a.fl[k + 1]; make_uniform(s.l1); make_uniform(s.l2);
     s.q = q_lds ? q_lds : a.ws + (size_t)slot * QCAP; s.overflow = false; s.ring = ring; s.pairbuf = pairbuf;
     s.blocks_out = a.blocks ? a.blocks + a.block_ofs[k] : NULL;
+    s.asm_cnt_out = a.asm_cnt ? a.asm_cnt + k : NULL; s.asm_out = a.asm_lines ? a.asm_lines + a.asm_ofs[k] : NULL;
     s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     const bool direct = a.direct_pairs != NULL;
     s.out_pairs = direct ? a.direct_pairs + (size_t)k * a.guess_pairs : a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;

@@ -39,6 +39,8 @@ __host__ __device__ inline Geometry geometry(int kind)
     else if (kind == SDV_VIS_PCM16X0_LINES) { g.w = 4 * 193; g.h = 490; g.cells_per_row = 3; }  /* startPCM1600Frame */
     else if (kind == SDV_VIS_STC007_BLOCKS_NTSC) { g.w = 6 * 109; g.h = 490; g.cells_per_row = 1; }     /* startSTC007DBFrame, setLineCount(VID_NTSC) */
     else if (kind == SDV_VIS_STC007_BLOCKS_PAL) { g.w = 6 * 109; g.h = 588; g.cells_per_row = 1; }      /* ... setLineCount(VID_PAL) */
+    else if (kind == SDV_VIS_STC007_ASM_NTSC) { g.w = 5 * 137; g.h = 490; g.cells_per_row = 1; }         /* startSTC007NTSCFrame, setLineCount(VID_NTSC): the assembled lines */
+    else if (kind == SDV_VIS_STC007_ASM_PAL) { g.w = 5 * 137; g.h = 588; g.cells_per_row = 1; }
     return g;
 }
 /* pixels [x0, x1) of a cell */
@@ -366,6 +368,64 @@ __device__ inline void draw_blocks_body(const BlkArgs &a, uint32_t block, int la
     }
 }
 
+/* ---- the assembled-lines window: renderNewLine(STC007Line) on the stitcher's lines (sdv_asm_line_rec): every word in the colour of its own state ---- */
+struct AsmArgs {
+    const sdv_asm_line_rec *lines; const uint32_t *frame_ofs; uint32_t n_frames; int kind;
+    uint32_t *out; uint32_t *wmask; uint32_t wmask_stride;
+};
+__device__ inline uint32_t asm_pixel(const Look &k, uint32_t st, uint32_t x)   /* st: word_crc_ok | word_valid << 9 | SDV_AL_* << 18 */
+{
+    const uint32_t b = x / 5u, fl = st >> 18;
+    const bool crc = (fl & SDV_AL_CRC_VALID) != 0, markers = (fl & SDV_AL_MARKERS) != 0, forced = (fl & SDV_AL_FORCED_BAD) != 0;
+    if (b < 4) return (crc || markers) ? ((b & 1u) ? (uint32_t)B0_GRY : (uint32_t)B1_GRY) : (uint32_t)PX_BLK;
+    if (b < 132) {
+        const uint32_t d = b - 4u, w = d < 112u ? d / 14u : 8u;
+        const bool one = bit_of(k, d) != 0, wc = (st >> w) & 1u, wv = (st >> (9u + w)) & 1u;
+        if (forced) return one ? (uint32_t)B1_MGN : (uint32_t)B0_MGN;
+        if (wc) return one ? (uint32_t)B1_GRY : (uint32_t)B0_GRY;
+        if (wv) return one ? (uint32_t)B1_GRN : (uint32_t)B0_GRN;
+        if (markers) return one ? (uint32_t)B1_YEL : (uint32_t)B0_YEL;
+        return one ? (uint32_t)B1_RED : (uint32_t)B0_RED;
+    }
+    if (b == 132) return (crc || markers) ? (uint32_t)B0_GRY : (uint32_t)PX_BLK;
+    return crc ? (uint32_t)B1_MARK : markers ? (uint32_t)B1_GRY : (uint32_t)PX_BLK;
+}
+__device__ inline void draw_asm_body(const AsmArgs &a, uint32_t block, int lane)
+{
+    const Geometry g = geometry(a.kind);
+    const uint32_t chunks = (g.h + 63u) / 64u, f = block / chunks, c = block % chunks;
+    const uint32_t lo = a.frame_ofs[f], n = a.frame_ofs[f + 1] - lo, rows = n < g.h ? n : g.h;
+    if (lane < 2) {
+        const uint32_t first = 64u * c + 32u * (uint32_t)lane, word = 2u * c + (uint32_t)lane;
+        if (word < a.wmask_stride) a.wmask[(size_t)f * a.wmask_stride + word] = rows <= first ? 0u : rows - first >= 32u ? 0xFFFFFFFFu : (1u << (rows - first)) - 1u;
+    }
+    const uint32_t row = 64u * c + (uint32_t)lane;
+    const bool live = row < rows;
+    Look k = Look(); uint32_t st = 0;
+    if (live) {
+        const sdv_asm_line_rec r = a.lines[lo + row];
+        uint64_t hi = 0, lw = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) hi = push(hi, r.words[w], 14);
+        hi = push(hi, (uint32_t)r.words[4] >> 6, 8);
+        lw = push(lw, r.words[4], 6);
+#pragma unroll
+        for (int w = 5; w < 8; w++) lw = push(lw, r.words[w], 14);
+        lw = push(lw, r.words[8], 16);
+        k.hi_h = (uint32_t)(hi >> 32); k.hi_l = (uint32_t)hi; k.lo_h = (uint32_t)(lw >> 32); k.lo_l = (uint32_t)lw;
+        st = (uint32_t)(r.word_crc_ok & 0x1FF) | ((uint32_t)(r.word_valid & 0x1FF) << 9) | ((uint32_t)r.flags << 18);
+    }
+    const uint64_t lm = __ballot(live);
+    for (int j = 0; j < 64; j++) {
+        if (!((lm >> j) & 1ull)) continue;
+        Look kj = Look();
+        kj.hi_h = (uint32_t)__shfl((int)k.hi_h, j); kj.hi_l = (uint32_t)__shfl((int)k.hi_l, j); kj.lo_h = (uint32_t)__shfl((int)k.lo_h, j); kj.lo_l = (uint32_t)__shfl((int)k.lo_l, j);
+        const uint32_t sj = (uint32_t)__shfl((int)st, j);
+        uint32_t *dst = a.out + ((size_t)f * g.h + 64u * c + (uint32_t)j) * g.w;
+        for (uint32_t x = (uint32_t)lane; x < g.w; x += 64u) dst[x] = asm_pixel(kj, sj, x);
+    }
+}
+
 struct BlankArgs { uint32_t *canvas; uint32_t n_px; };
 __device__ inline void blank_body(const BlankArgs &a, uint32_t i) { if (i < a.n_px) a.canvas[i] = BLANK; }
 } // namespace sdvvis
@@ -378,6 +438,7 @@ SDV_VIS_KERNELS(sdv_line_rec, stc007)
 SDV_VIS_KERNELS(sdv_pcm1_bin_rec, pcm1)
 SDV_VIS_KERNELS(sdv_pcm16x0_bin_rec, pcm16x0)
 __global__ void __launch_bounds__(64) sdv_k_vis_draw_blocks(sdvvis::BlkArgs a) { sdvvis::draw_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_vis_draw_asm(sdvvis::AsmArgs a) { sdvvis::draw_asm_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_last(sdvvis::VisArgs a) { sdvvis::last_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_fill(sdvvis::VisArgs a) { sdvvis::fill_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_blank(sdvvis::BlankArgs a) { sdvvis::blank_body(a, blockIdx.x * 64u + threadIdx.x); }

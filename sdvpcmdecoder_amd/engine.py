@@ -35,7 +35,7 @@ TYPE_M2 = 3                      # VideoToDigital::TYPE_M2 (videotodigital.h:77)
 MODE_DRAFT, MODE_FAST, MODE_NORMAL, MODE_INSANE = 0, 1, 2, 3
 FLAG_NEW_FILE, FLAG_DOUBLED, FLAG_END_FILE = 1, 2, 4
 FRAME_EMPTY = 1                 # sdv_set_frame_flags: SDV_FRAME_EMPTY
-VIS_STC007_LINES, VIS_PCM1_LINES, VIS_PCM16X0_LINES, VIS_STC007_BLOCKS_NTSC, VIS_STC007_BLOCKS_PAL = 0, 1, 2, 3, 4       # SDV_VIS_*
+VIS_STC007_LINES, VIS_PCM1_LINES, VIS_PCM16X0_LINES, VIS_STC007_BLOCKS_NTSC, VIS_STC007_BLOCKS_PAL, VIS_STC007_ASM_NTSC, VIS_STC007_ASM_PAL = 0, 1, 2, 3, 4, 5, 6   # SDV_VIS_*
 
 
 class BinPreset(C.Structure):
@@ -138,6 +138,12 @@ def load_library(path: str | None = None):
     lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_stitch_block_count.restype = C.c_size_t
     lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
+    lib.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_stitch_line_count.restype = C.c_size_t
+    lib.sdv_stitch_line_count.argtypes = [C.c_void_p]
+    lib.sdv_stitch_line_counts.restype = C.c_size_t
+    lib.sdv_stitch_line_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_vis_render_asm_lines.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_get_run_info.argtypes = [C.c_void_p, C.POINTER(RunInfo)]
     lib.sdv_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.sdv_get_chain_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -340,6 +346,41 @@ class Engine:
 
     def stitch_block_count(self) -> int:
         return int(self.lib.sdv_stitch_block_count(self._h))
+
+    def set_stitch_line_output(self, lines):
+        """sdv_set_stitch_line_output: `lines` = (cap, 32) uint8 CUDA tensor that the following stitch_frames calls fill with the assembled lines
+        they hand to the visualiser (None: off).  The tensor must stay alive while it is set."""
+        self._line_out = lines
+        if lines is None:
+            self._check(self.lib.sdv_set_stitch_line_output(self._h, None, 0))
+        else:
+            assert lines.is_cuda and lines.is_contiguous() and lines.shape[1] == 32
+            self._check(self.lib.sdv_set_stitch_line_output(self._h, C.c_void_p(lines.data_ptr()), lines.shape[0]))
+
+    def stitch_line_count(self) -> int:
+        return int(self.lib.sdv_stitch_line_count(self._h))
+
+    def stitch_line_counts(self):
+        """Lines per stitcher turn of the last stitch_frames call (numpy uint32)."""
+        import numpy as np
+        n = int(self.lib.sdv_stitch_line_counts(self._h, None, 0))
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        self.lib.sdv_stitch_line_counts(self._h, out.ctypes.data, n)
+        return out[:n]
+
+    def vis_render_asm_lines(self, kind: int, lines, frame_lines, stream=None):
+        """sdv_vis_render_asm_lines: `lines` = (n, 32) uint8 CUDA tensor of sdv_asm_line_rec, frame_lines = lines per frame (host sequence)
+        -> (n_frames, height, width) int32 CUDA tensor."""
+        import numpy as np
+        import torch
+        assert lines.is_cuda and lines.dtype == torch.uint8 and lines.is_contiguous()
+        per = np.ascontiguousarray(np.asarray(frame_lines, dtype=np.uint32))
+        w, h = self.vis_canvas_size(kind)
+        out = torch.empty((max(len(per), 1), h, w), dtype=torch.int32, device=lines.device)
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(lines.device).cuda_stream)
+        self._check(self.lib.sdv_vis_render_asm_lines(self._h, kind, C.c_void_p(lines.data_ptr()), lines.shape[0], per.ctypes.data, len(per),
+                                                      C.c_void_p(out.data_ptr()), len(per), sptr))
+        return out[:len(per)]
 
     def vis_render_blocks(self, kind: int, blocks, frame_blocks, stream=None):
         """sdv_vis_render_blocks: `blocks` = (n, 72) uint8 CUDA tensor of sdv_block_rec, frame_blocks = blocks per frame (host sequence)

@@ -46,3 +46,20 @@ if __name__ == "__main__":
         np.savez_compressed(path, blocks_sha256=hashlib.sha256(blocks.tobytes()).hexdigest(), canvases_sha256=ra.digest(ref, mask),
                             last_canvas=np.where(mask[-1], ref[-1], 0).astype(np.uint32))
         print(f"{name}: {len(blocks)} blocks -> {len(ref)} canvases of {ref.shape[2]} x {ref.shape[1]}, {os.path.getsize(path)} bytes")
+    for name in ra.ASM_GOLDEN:            # the assembled-lines window: the real stitcher's lines on the real RenderPCM
+        if only and name not in only:
+            continue
+        import libs
+        import oracle_run
+        import stitch_api as sa
+        import stitch_cases as sc
+        kind, case = ra.ASM_CASES[name]
+        recs, st = sc.make_input(case, lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+        sa.run_cpu_blocks(libs.load_ref(), "ref_", recs, st)
+        lines, per = sa.last_asm_lines(libs.load_ref(), "ref_")
+        ref = ra.run_ref_asm(kind, np.ascontiguousarray(lines), np.ascontiguousarray(per))
+        mask = ra.written_blocks(kind, per)
+        path = os.path.join(HERE, "render_" + name + ".npz")
+        np.savez_compressed(path, lines_sha256=hashlib.sha256(lines.tobytes()).hexdigest(), canvases_sha256=ra.digest(ref, mask),
+                            last_canvas=np.where(mask[-1], ref[-1], 0).astype(np.uint32))
+        print(f"{name}: {len(lines)} lines -> {len(ref)} canvases of {ref.shape[2]} x {ref.shape[1]}, {os.path.getsize(path)} bytes")

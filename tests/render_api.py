@@ -11,8 +11,9 @@ import pcm1_frames_api as p1f
 import pcm16_frames_api as p16f
 from sdvpcmdecoder_amd import synth
 
-STC007, PCM1, PCM16X0, STC007_BLOCKS_NTSC, STC007_BLOCKS_PAL = 0, 1, 2, 3, 4
-SIZE = {STC007: (685, 650), PCM1: (752, 490), PCM16X0: (772, 490), STC007_BLOCKS_NTSC: (654, 490), STC007_BLOCKS_PAL: (654, 588)}   # width, height of the canvas
+STC007, PCM1, PCM16X0, STC007_BLOCKS_NTSC, STC007_BLOCKS_PAL, STC007_ASM_NTSC, STC007_ASM_PAL = 0, 1, 2, 3, 4, 5, 6
+SIZE = {STC007: (685, 650), PCM1: (752, 490), PCM16X0: (772, 490), STC007_BLOCKS_NTSC: (654, 490), STC007_BLOCKS_PAL: (654, 588),
+        STC007_ASM_NTSC: (685, 490), STC007_ASM_PAL: (685, 588)}   # width, height of the canvas
 BLANK = 0xFF000000                                                          # a canvas nothing was drawn on yet (QImage::fill(Qt::black))
 SRV_FILLER, SRV_END_FRAME = 3, 5
 LF_BW_SET, LF_COORDS_SET, LF_FORCED_BAD, LF_CRC_VALID = 8, 16, 32, 64
@@ -203,3 +204,55 @@ def run_ref_blocks(kind, blocks, per_frame):
     got = lib.ref_vis_render_blocks(kind, blocks.ctypes.data, len(blocks), per_frame.ctypes.data, n, out.ctypes.data, n, C.byref(rw), C.byref(rh))
     assert got == n and (rw.value, rh.value) == (w, h), (got, n, rw.value, rh.value)
     return out
+
+
+# ---- the assembled-lines window (sdv_set_stitch_line_output + sdv_vis_render_asm_lines; renderNewLine(STC007Line) on the stitcher's lines) ----------------
+ASM_CASES = {
+    "asm_clean": (STC007_ASM_NTSC, "ntsc_clean"),
+    "asm_bad10_cwd": (STC007_ASM_NTSC, "ntsc_bad10_no_pq"),             # CWD at work: words repaired (green), lines forced bad (magenta)
+    "asm_burst": (STC007_ASM_NTSC, "ntsc_burst300"),
+    "asm_pal": (STC007_ASM_PAL, "pal_bad5"),
+    "asm_16bit": (STC007_ASM_NTSC, "f1_16bit_bad5"),
+    "asm_noisy": (STC007_ASM_NTSC, "ntsc_noisy_video"),
+    "asm_pal_on_ntsc_canvas": (STC007_ASM_NTSC, "pal_bad5"),
+}
+ASM_GOLDEN = ("asm_bad10_cwd", "asm_pal", "asm_noisy")
+
+
+def make_asm_input(name):
+    """(canvas kind, assembled lines (sdv_asm_line_rec), lines per stitcher turn) of a scenario: what the oracle's stitcher hands over."""
+    import stitch_api as sa
+    import stitch_cases as sc
+    kind, case = ASM_CASES[name]
+    recs, st = sc.make_input(case, lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    sa.run_cpu_blocks(libs.load_oracle(), "orc_", recs, st)
+    lines, per = sa.last_asm_lines(libs.load_oracle(), "orc_")
+    return kind, np.ascontiguousarray(lines), np.ascontiguousarray(per)
+
+
+def _run_asm(lib, fn, kind, lines, per, canvas):
+    w, h = SIZE[kind]
+    n = len(per)
+    out = np.zeros((n, h, w), dtype=np.uint32)
+    f = getattr(lib, fn)
+    f.restype = C.c_long
+    if canvas is not None:
+        f.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        assert f(kind, lines.ctypes.data, len(lines), per.ctypes.data, n, canvas.ctypes.data, out.ctypes.data, n) == n
+    else:
+        f.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        rw, rh = C.c_uint32(0), C.c_uint32(0)
+        got = f(kind, lines.ctypes.data, len(lines), per.ctypes.data, n, out.ctypes.data, n, C.byref(rw), C.byref(rh))
+        assert got == n and (rw.value, rh.value) == (w, h), (got, n, rw.value, rh.value)
+    return out
+
+
+def run_oracle_asm(kind, lines, per, canvas=None):
+    w, h = SIZE[kind]
+    if canvas is None:
+        canvas = np.full((h, w), BLANK, dtype=np.uint32)
+    return _run_asm(libs.load_oracle(), "orc_vis_render_asm_lines", kind, lines, per, canvas), canvas
+
+
+def run_ref_asm(kind, lines, per):
+    return _run_asm(libs.load_ref(), "ref_vis_render_asm_lines", kind, lines, per, None)

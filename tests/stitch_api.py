@@ -107,3 +107,19 @@ def run_cpu_blocks(lib, prefix, recs, st):
     n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, pair_cap, frames.ctypes.data, frame_cap, C.byref(nf), blocks.ctypes.data, len(blocks), C.byref(nb))
     assert n >= 0 and nb.value <= len(blocks)
     return pairs[:n], frames[:min(nf.value, frame_cap)], blocks[:nb.value]
+
+
+ASM_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words", "<u2", (9,)), ("calc_crc", "<u2"), ("word_crc_ok", "<u2"), ("word_valid", "<u2"),
+                      ("flags", "u1"), ("_pad", "u1")])       # sdv_asm_line_rec, 32 bytes
+
+
+def last_asm_lines(lib, prefix):
+    """The assembled lines (newLineProcessed) of the last run_cpu_blocks call on that library: (lines, lines per stitcher turn)."""
+    f = getattr(lib, prefix + "stitch_last_asm_lines")
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    nl, nt = C.c_size_t(0), C.c_size_t(0)
+    f(None, 0, C.byref(nl), None, 0, C.byref(nt))
+    lines, per = np.zeros(nl.value, dtype=ASM_DTYPE), np.zeros(nt.value, dtype=np.uint32)
+    f(lines.ctypes.data, len(lines), C.byref(nl), per.ctypes.data, len(per), C.byref(nt))
+    return lines, per

@@ -305,3 +305,110 @@ def test_gpu_blocks_and_their_canvases_match_oracle(name):
     if name in ra.BLOCK_GOLDEN:
         z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
         assert ra.digest(canvases, ra.written_blocks(kind, per)) == str(z["canvases_sha256"])
+
+
+# ---- the assembled-lines window: sdv_set_stitch_line_output + sdv_vis_render_asm_lines (renderNewLine(STC007Line) on the stitcher's lines) ---------------
+@pytest.mark.ref
+@pytest.mark.parametrize("name", list(ra.ASM_CASES))
+def test_oracle_asm_canvases_match_live_reference(name, oracle_lib):
+    """The oracle's assembled lines equal the real stitcher's newLineProcessed lines, and their canvases the real RenderPCM's."""
+    if not libs.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available")
+    import stitch_api as sa
+    import stitch_cases as sc
+    import oracle_run
+    kind, lines, per = ra.make_asm_input(name)
+    recs, st = sc.make_input(ra.ASM_CASES[name][1], lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    sa.run_cpu_blocks(libs.load_ref(), "ref_", recs, st)
+    ref_lines, ref_per = sa.last_asm_lines(libs.load_ref(), "ref_")
+    assert lines.tobytes() == ref_lines.tobytes() and per.tolist() == ref_per.tolist()
+    out, _ = ra.run_oracle_asm(kind, lines, per)
+    ref = ra.run_ref_asm(kind, lines, per)
+    mask = ra.written_blocks(kind, per)
+    assert (_masked(out, mask) == _masked(ref, mask)).all(), _diff(out, ref, mask)
+
+
+@pytest.mark.parametrize("name", ra.ASM_GOLDEN)
+def test_oracle_asm_canvases_match_golden(name, oracle_lib):
+    z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
+    kind, lines, per = ra.make_asm_input(name)
+    assert ra.hashlib.sha256(lines.tobytes()).hexdigest() == str(z["lines_sha256"]), "the stitcher's assembled lines differ from the real stitcher's"
+    out, _ = ra.run_oracle_asm(kind, lines, per)
+    mask = ra.written_blocks(kind, per)
+    assert ra.digest(out, mask) == str(z["canvases_sha256"])
+    assert (_masked(out[-1], mask[-1]) == z["last_canvas"]).all()
+
+
+@pytest.mark.parametrize("name", list(ra.ASM_CASES))
+def test_emu_asm_lines_and_their_canvases_match_oracle(name, emu):
+    """Records -> sdv_stitch_frames with a line buffer set (two calls) -> sdv_vis_render_asm_lines, in the emulator."""
+    import engine_api as ea
+    import stitch_cases as sc
+    import stitch_api as sa
+    import oracle_run
+    kind, want_lines, want_per = ra.make_asm_input(name)
+    recs, st = sc.make_input(ra.ASM_CASES[name][1], lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    lib = ea.bind(emu)
+    lib.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_stitch_line_count.restype = C.c_size_t
+    lib.sdv_stitch_line_count.argtypes = [C.c_void_p]
+    lib.sdv_stitch_line_counts.restype = C.c_size_t
+    lib.sdv_stitch_line_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_vis_render_asm_lines.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    eng = lib.sdv_engine_create(0)
+    buf = np.zeros(len(want_lines) + 8, dtype=sa.ASM_DTYPE)
+    assert lib.sdv_set_stitch_line_output(eng, buf.ctypes.data, 10) == 0
+    rc, p, f = ea.emu_stitch(lib, eng, recs, st)
+    assert rc != 0 and b"assembled lines are needed" in lib.sdv_last_error(eng) and lib.sdv_stitch_line_count(eng) == len(want_lines)
+    assert lib.sdv_set_stitch_line_output(eng, buf.ctypes.data, len(buf)) == 0
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    cuts = [0, int(ends[len(ends) // 2]) + 1, len(recs)]
+    w, h = ra.SIZE[kind]
+    got_lines, got_per, canv = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, p, f = ea.emu_stitch(lib, eng, recs[a:b], st if a == 0 else None)
+        assert rc == 0
+        n = lib.sdv_stitch_line_count(eng)
+        per = np.zeros(64, dtype=np.uint32)
+        k = lib.sdv_stitch_line_counts(eng, per.ctypes.data, len(per))
+        per = np.ascontiguousarray(per[:k])
+        assert int(per.sum()) == n and k == int((f["service_type"] == 0).sum())
+        got_lines.append(buf[:n].copy()); got_per += per.tolist()
+        out = np.zeros((max(k, 1), h, w), dtype=np.uint32)
+        assert lib.sdv_vis_render_asm_lines(eng, kind, buf.ctypes.data, n, per.ctypes.data, k, out.ctypes.data, k, None) == 0
+        canv.append(out[:k])
+    lib.sdv_engine_destroy(eng)
+    assert np.concatenate(got_lines).tobytes() == want_lines.tobytes() and got_per == want_per.tolist()
+    want, _ = ra.run_oracle_asm(kind, want_lines, want_per)
+    assert (np.concatenate(canv) == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(ra.ASM_CASES))
+def test_gpu_asm_lines_and_their_canvases_match_oracle(name):
+    import torch
+    from sdvpcmdecoder_amd import Engine, StitchSettings
+    import stitch_cases as sc
+    import stitch_api as sa
+    import oracle_run
+    kind, want_lines, want_per = ra.make_asm_input(name)
+    recs, st = sc.make_input(ra.ASM_CASES[name][1], lambda luma: oracle_run.oracle_binarize(luma, mode=2))
+    eng = Engine(0)
+    eng.set_stitch_settings(StitchSettings.from_buffer_copy(bytes(st)))
+    buf = torch.zeros((len(want_lines) + 8, 32), dtype=torch.uint8, device="cuda")
+    blk = torch.zeros((len(want_lines) + 8, 72), dtype=torch.uint8, device="cuda")
+    eng.set_stitch_line_output(buf)
+    eng.set_stitch_block_output(blk)                        # both feeds at once
+    d = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), 48)).cuda()
+    pairs, frames = eng.stitch_frames(d)
+    n = eng.stitch_line_count()
+    got = buf[:n].cpu().numpy().reshape(-1).view(sa.ASM_DTYPE)
+    per = eng.stitch_line_counts()
+    assert got.tobytes() == want_lines.tobytes() and per.tolist() == want_per.tolist()
+    assert eng.stitch_block_count() == pairs.shape[0] // 3
+    canvases = eng.vis_render_asm_lines(kind, buf[:n].contiguous(), per).cpu().numpy().view(np.uint32)
+    want, _ = ra.run_oracle_asm(kind, want_lines, want_per)
+    assert (canvases == want).all(), _diff(canvases, want, np.ones_like(want, dtype=bool))
+    if name in ra.ASM_GOLDEN:
+        z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
+        assert ra.digest(canvases, ra.written_blocks(kind, want_per)) == str(z["canvases_sha256"])
