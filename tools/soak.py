@@ -31,6 +31,7 @@ for case in range(n_cases):
     want, want_stats = oracle_binarize(luma, mode=2, first_frame_no=1, new_file=True, end_file=True)
     st = sa.default_settings()
     want_p, want_f, want_b = sa.run_cpu_blocks(orc, "orc_", want, st)
+    want_al, want_aper = sa.last_asm_lines(orc, "orc_")
     t_cpu = time.time() - t0
     eng = Engine(0); eng.setBinarizationMode(2)
     pst = StitchSettings(); C.memmove(C.byref(pst), C.byref(st), C.sizeof(pst)); eng.set_stitch_settings(pst)
@@ -39,6 +40,9 @@ for case in range(n_cases):
     blocks, canv_l, canv_b = [], [], []
     import render_api as ra
     blk_buf = torch.zeros((len(want_b) + 64, 72), dtype=torch.uint8, device='cuda'); eng.set_stitch_block_output(blk_buf)
+    asm_buf = torch.zeros((len(want_al) + 64, 32), dtype=torch.uint8, device='cuda'); eng.set_stitch_line_output(asm_buf)
+    asm_lines, asm_per, canv_a = [], [], []
+    akind = ra.STC007_ASM_PAL if height == 576 else ra.STC007_ASM_NTSC
     bkind = ra.STC007_BLOCKS_PAL if height == 576 else ra.STC007_BLOCKS_NTSC
     d = torch.from_numpy(luma).cuda()
     for a, b in zip(cuts[:-1], cuts[1:]):
@@ -48,6 +52,8 @@ for case in range(n_cases):
         # the visualiser's feeds of this call: the line canvases of its frames, its data blocks and their canvases
         nb = eng.stitch_block_count(); blocks.append(blk_buf[:nb].cpu().numpy().reshape(-1).view(sa.BLOCK_DTYPE).copy())
         canv_l.append(eng.vis_render_lines(ra.STC007, lines.contiguous(), (b - a) + (1 if b == n else 0)).cpu().numpy().view(np.uint32))
+        na = eng.stitch_line_count(); asm_lines.append(asm_buf[:na].cpu().numpy().reshape(-1).view(sa.ASM_DTYPE).copy()); ap_ = eng.stitch_line_counts(); asm_per += ap_.tolist()
+        canv_a.append(eng.vis_render_asm_lines(akind, asm_buf[:na].contiguous(), ap_).cpu().numpy().view(np.uint32) if len(ap_) else np.zeros((0,) + ra.SIZE[akind][::-1], dtype=np.uint32))
         fr_ = f.cpu().numpy().reshape(-1).view(sa.FRASM_DTYPE); per_ = fr_["blocks_total"][fr_["service_type"] == 0].astype(np.uint32)
         canv_b.append(eng.vis_render_blocks(bkind, blk_buf[:nb].contiguous(), per_).cpu().numpy().view(np.uint32) if len(per_) else np.zeros((0,) + ra.SIZE[bkind][::-1], dtype=np.uint32))
         recs.append(lines.cpu().numpy().reshape(-1).view(LINE_DTYPE).copy()); stats.append(stt.cpu().numpy().copy())
@@ -59,6 +65,8 @@ for case in range(n_cases):
     per_all = want_f["blocks_total"][want_f["service_type"] == 0].astype(np.uint32)
     ok = ok and blocks.tobytes() == want_b.tobytes() and (np.concatenate(canv_l) == ra.run_oracle(ra.STC007, want)[0]).all() \
         and (np.concatenate(canv_b) == ra.run_oracle_blocks(bkind, want_b, np.ascontiguousarray(per_all))[0]).all()
+    ok = ok and np.concatenate(asm_lines).tobytes() == want_al.tobytes() and asm_per == want_aper.tolist() \
+        and (np.concatenate(canv_a) == ra.run_oracle_asm(akind, want_al, want_aper)[0]).all()
     # ... and on through the audio stage, burst by burst as the stitch calls delivered them, in a random masking mode
     import audio_api as au
     a_mode = int(rng.integers(0, 7))
