@@ -300,7 +300,7 @@ def main():
     if use_dist and not args.no_stitch:
         try:
             from sdvpcmdecoder_amd.sharded import ShardedDecoder
-            ns = min(n, 2500)                                   # frames per rank of this leg
+            ns = n                                              # frames per rank of this leg: as many as in the timed loop
             total = ns * world
             dec = ShardedDecoder(eng, rank, world, torch_all_gather(dev if backend == "nccl" else None), H)
             f0, f1 = dec.frames_needed(total)
