@@ -168,3 +168,26 @@ def test_cpp_host_program_sharded_two_ranks_one_gpu(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     assert b"".join((tmp_path / f"out.rank{r}.pairs").read_bytes() for r in range(2)) == want_p.tobytes()
     assert b"".join((tmp_path / f"out.rank{r}.frames").read_bytes() for r in range(2)) == want_f.tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_sharded_noisy_tape_decodes_no_range_twice(tmp_path):
+    """A tape that plays with noise on it: the binarizer's levels are what the first lines of the tape measured (sticky), not what a warm-up further
+    down would measure.  Rank 0 publishes its state after its first frames, rank 1 warms up from it: no range is decoded twice, and the two parts
+    are the sequential decode."""
+    from sdvpcmdecoder_amd import build as b
+    exe = b.build_example_sharded()
+    n = 150                 # (75 frames per rank: the stitcher's statistics rings, 65 deep, are full where rank 1 takes over, as its warm-up assumes)
+    luma, _, _ = synth.stc007_frames(n, seed=77, noise_sigma=5.0)
+    recs, _ = oracle_binarize(luma, mode=2, new_file=True, end_file=True)
+    want_p, want_f = sa.run_cpu(libs.load_oracle(), "orc_", recs, sa.default_settings())
+    _, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    os.makedirs(tmp_path / "comm")
+    procs = [subprocess.Popen([exe, str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "out"), "file:" + str(tmp_path / "comm")],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0"), stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ranges decoded again: binarize 0, stitch 0" in o for o in outs), outs
+    assert b"".join((tmp_path / f"out.rank{r}.pairs").read_bytes() for r in range(2)) == want_p.tobytes()
+    assert b"".join((tmp_path / f"out.rank{r}.frames").read_bytes() for r in range(2)) == want_f.tobytes()
