@@ -354,7 +354,8 @@ typedef struct sdv_stitch_info {
     uint32_t steps;             /* stitcher turns (frame pairs) completed by the call */
     uint32_t rounds;            /* parallel rounds until every turn had run from its predecessor's final output */
     uint32_t steps_launched;    /* turn executions over all rounds */
-    uint32_t _pad;
+    uint32_t pipelined;         /* 1: the call ran its analysis and first round without waiting for the host (a stream that plays);
+                                 * 2: ... and the field order and resolution histories were saturated, so the host's check needed no replay of them */
     float device_ms;            /* analysis + rounds + packing on the device (profiling on) */
     float _pad2;
 } sdv_stitch_info;

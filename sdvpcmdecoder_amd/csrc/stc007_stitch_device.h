@@ -294,6 +294,7 @@ struct WsSrc {
 struct FrameBrief { uint32_t frame_number; uint8_t flags, field_res[2], _pad; };     /* what the host needs of a FrameLocal */
 struct AnalyzeArgs {
     RecSrc src; const uint32_t *seg_end; uint32_t n_seg;      /* seg_end[k] = index of the k-th END_FRAME record */
+    uint32_t *ctl;                                            /* pipelined call: n_seg is the launch width, ctl[CTL_NSEG] the count (NULL otherwise) */
     Cfg cfg; FrameLocal *fl; FrameBrief *brief; SLine *fields;
     unsigned long long *timing;     /* optional: 8 cycle stamps per frame (SDV_STITCH_TIMING=1), NULL otherwise */
 };
@@ -590,6 +591,8 @@ struct StepArgs {
      * the turns write straight into the caller's buffers at k * guess; NULL = per-turn slots, packed by the compact kernel */
     sdv_sample_pair *direct_pairs; sdv_frame_asm *direct_frasm; uint32_t guess_pairs, guess_frasm;
     uint32_t first_round;
+    const uint32_t *ctl; uint32_t est_seg;  /* pipelined call: the turns are 0 .. n_seg - 2 of the counted segments, `work` is NULL (every turn, first buffers), */
+    uint8_t pipe_order, pipe_res;           /* ... and prob_order / prob_res are these two for every turn */
     unsigned long long *timing;             /* optional: 8 cycle stamps per step (SDV_STITCH_TIMING=1), NULL otherwise */
     sdv_block_rec *blocks; const uint32_t *block_ofs;   /* optional (the visualiser's feed): turn k's data blocks go to blocks[block_ofs[k] ..], newBlockProcessed :6626 */
     uint32_t *asm_cnt; sdv_asm_line_rec *asm_lines; const uint32_t *asm_ofs;   /* optional: how many assembled lines turn k hands to the visualiser (newLineProcessed :6696) / where they go */
@@ -1549,7 +1552,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     s.q = q_lds ? q_lds : a.ws + (size_t)slot * QCAP; s.overflow = false; s.ring = ring; s.pairbuf = pairbuf;
     s.blocks_out = a.blocks ? a.blocks + a.block_ofs[k] : NULL;
     s.asm_cnt_out = a.asm_cnt ? a.asm_cnt + k : NULL; s.asm_out = a.asm_lines ? a.asm_lines + a.asm_ofs[k] : NULL;
-    s.prob_order = (uint8_t)uni(a.prob_order[k]); s.prob_res = (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
+    s.prob_order = a.ctl ? a.pipe_order : (uint8_t)uni(a.prob_order[k]); s.prob_res = a.ctl ? a.pipe_res : (uint8_t)uni(a.prob_res[k]); s.push_order = ORDER_UNK;
     const bool direct = a.direct_pairs != NULL;
     s.out_pairs = direct ? a.direct_pairs + (size_t)k * a.guess_pairs : a.pairs + (size_t)k * PAIR_SLOT; s.n_pairs = 0;
     s.pair_cap = direct ? a.guess_pairs : (uint32_t)PAIR_SLOT; s.clipped = false;
@@ -1634,7 +1637,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
  * outcome is the template's decisions on frame j's own geometry, and its hand-over lines are the unpatched tail of
  * frame j assembled with those paddings.  The prediction only has to be right often: every turn compares what it really
  * produced with the prediction its successor was started from, and the successor is re-run on any difference. */
-struct PredictStArgs { const SLine *fields; const FrameLocal *fl; const StepChain *tmpl; StepChain *out; uint32_t first, n; };
+struct PredictStArgs { const SLine *fields; const FrameLocal *fl; const StepChain *tmpl; StepChain *out; uint32_t first, n; const uint32_t *ctl; uint32_t est_seg; };
 __device__ inline void predict_st_body(const PredictStArgs &a, uint32_t j, int lane)
 {
     StepChain *o = &a.out[j];
@@ -1698,7 +1701,7 @@ __device__ inline void compact_body(const CompactArgs &a, uint32_t k, int lane, 
 /* ---- END_FRAME search: positions of the END_FRAME records, in stream order -------------------------------------- */
 /* Pass 0 counts the END_FRAMEs per chunk and leaves every record's service type in a byte array; after the host's prefix sum
  * pass 1 writes the segment ends from those bytes (5 MB instead of the 235 MB of records of a 10 000-frame batch). */
-struct SegArgs { RecSrc src; uint32_t n_recs; uint8_t *svc; uint32_t *block_count; const uint32_t *block_ofs; uint32_t *seg_end; int write; };
+struct SegArgs { RecSrc src; uint32_t n_recs; uint8_t *svc; uint32_t *block_count; const uint32_t *block_ofs; uint32_t *seg_end; int write; uint32_t seg_cap; /* 0 = no bound on the seg_end index */ };
 enum { SEG_CHUNK = 1024 };
 __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 {
@@ -1713,22 +1716,51 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
         if (i < hi) { if (a.write) srv = a.svc[i]; else { srv = a.src.at(i).service_type; a.svc[i] = srv; } }
         const bool ef = srv == SDV_SRV_END_FRAME;
         const uint64_t m = __ballot(ef);
-        if (a.write && ef) a.seg_end[base + cnt + (uint32_t)__popcll(m & lanemask_lt(lane))] = i;
+        if (a.write && ef) {
+            const uint32_t at = base + cnt + (uint32_t)__popcll(m & lanemask_lt(lane));
+            if (a.seg_cap == 0 || at < a.seg_cap) a.seg_end[at] = i;
+        }
         cnt += (uint32_t)__popcll(m);
     }
     if (!a.write && lane == 0) a.block_count[blk] = cnt;
 }
+/* The pipelined call (stitch_engine.inc, "a stream that plays"): the host does not wait for the counts - one wave turns them into offsets and leaves
+ * the number of frame segments in ctl[CTL_NSEG]; the kernels behind read it from there, launched as wide as the host's estimate. */
+enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_WORDS = 2 };
+struct ScanArgs { const uint32_t *block_count; uint32_t *block_ofs; uint32_t nblk; uint32_t *ctl; uint32_t *next_work; };
+__device__ inline void seg_scan_body(const ScanArgs &a, int lane)
+{
+    /* every lane takes a contiguous run of the counts; one scan over the 64 run totals in between */
+    const uint32_t per = (a.nblk + 63u) / 64u;
+    uint32_t lo = (uint32_t)lane * per, hi = lo + per;
+    if (lo > a.nblk) lo = a.nblk;
+    if (hi > a.nblk) hi = a.nblk;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += a.block_count[i];
+    uint32_t incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl((int)incl, lane >= d ? lane - d : lane); if (lane >= d) incl += o; }
+    uint32_t run = incl - sum;
+    for (uint32_t i = lo; i < hi; i++) { a.block_ofs[i] = run; run += a.block_count[i]; }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (lane == 0) { a.ctl[CTL_NSEG] = total; a.ctl[CTL_ABORT] = 0; *a.next_work = 0; }
+}
+/* how many segments / turns the kernels of a pipelined call work on: the counted ones, as far as the launch covers them */
+__device__ inline uint32_t ctl_nseg(const uint32_t *ctl, uint32_t est) { const uint32_t n = ctl[CTL_NSEG]; return n < est ? n : est; }
 } // namespace sdvs
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_stitch_seg_scan(sdvs::ScanArgs a) { sdvs::seg_scan_body(a, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 {
     __shared__ uint32_t meta[sdvs::ANALYZE_LDS_WORDS];
     static_assert(sizeof(meta) >= sdvs::RING_SMALL * sizeof(sdv_deint_line), "the ring of the resolution trials lives in the staging area");
     const uint32_t k = blockIdx.x;
+    if (a.ctl && k >= sdvs::ctl_nseg(a.ctl, a.n_seg)) return;
     const uint32_t n = a.seg_end[k] - (k == 0 ? 0u : a.seg_end[k - 1] + 1u);
     if (n <= sdvs::ANALYZE_LDS) sdvs::analyze_body<true>(a, k, (int)threadIdx.x, meta);
     else sdvs::analyze_body<false>(a, k, (int)threadIdx.x, meta);
+    /* frames the turns must not be run on before the host has seen them (foreign lines, file boundaries): the kernels behind stand down */
+    if (a.ctl && threadIdx.x == 0 && (a.brief[k].flags & (sdvs::FL_BAD_NUMBERS | sdvs::FL_END_FILE | sdvs::FL_NEW_FILE))) atomicOr(&a.ctl[sdvs::CTL_ABORT], 1u);
 }
 #ifndef SDV_ST_WAVES
 #define SDV_ST_WAVES 4   /* 128 VGPRs + 100 B scratch: 4 096 resident waves share the turns; 1.73 ms per 10 000-frame call vs 1.83 (3 waves, no scratch) and 1.78 (5) */
@@ -1737,19 +1769,32 @@ __global__ void __launch_bounds__(64, SDV_ST_WAVES) sdv_k_stitch_step(sdvs::Step
 {
     __shared__ sdv_deint_line ring[sdvs::RING];
     __shared__ uint32_t pairbuf[64 * 9];
+    uint32_t n_work = a.n_work;
+    if (a.ctl) {
+        const uint32_t ns = sdvs::ctl_nseg(a.ctl, a.est_seg);
+        if (a.ctl[sdvs::CTL_ABORT] || ns < 2) return;
+        n_work = ns - 1;
+    }
     for (;;) {
         uint32_t w = 0;
         if (threadIdx.x == 0) w = atomicAdd(a.next_work, 1u);
         w = (uint32_t)__shfl((int)w, 0);
-        if (w >= a.n_work) break;
+        if (w >= n_work) break;
 #if defined(SDV_ST_QUEUE_LDS) && !defined(SDV_EMU)
         __shared__ sdvs::SLine q_lds[sdvs::QCAP];          /* experiment: conv_queue of the turn in LDS (32 KB per wave) */
-        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x, ring, pairbuf, q_lds);
+        sdvs::step_body(a, a.work ? a.work[w] : w, blockIdx.x, (int)threadIdx.x, ring, pairbuf, q_lds);
 #else
-        sdvs::step_body(a, a.work[w], blockIdx.x, (int)threadIdx.x, ring, pairbuf);
+        sdvs::step_body(a, a.work ? a.work[w] : w, blockIdx.x, (int)threadIdx.x, ring, pairbuf);
 #endif
     }
 }
-__global__ void __launch_bounds__(64) sdv_k_stitch_predict(sdvs::PredictStArgs a) { sdvs::predict_st_body(a, a.first + blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_stitch_predict(sdvs::PredictStArgs a)
+{
+    if (a.ctl) {        /* pipelined call: hand-overs for the turns 0 .. n_seg - 3 of the counted segments */
+        const uint32_t ns = sdvs::ctl_nseg(a.ctl, a.est_seg);
+        if (a.ctl[sdvs::CTL_ABORT] || ns < 2 || a.first + blockIdx.x >= ns - 2) return;
+    }
+    sdvs::predict_st_body(a, a.first + blockIdx.x, (int)threadIdx.x);
+}
 __global__ void __launch_bounds__(64) sdv_k_stitch_compact(sdvs::CompactArgs a) { sdvs::compact_body(a, blockIdx.x, (int)threadIdx.x, 64); }
 #endif

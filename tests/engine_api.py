@@ -19,7 +19,7 @@ class RunInfo(C.Structure):
 
 
 class StitchInfo(C.Structure):
-    _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("_pad", C.c_uint32),
+    _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("pipelined", C.c_uint32),
                 ("device_ms", C.c_float), ("_pad2", C.c_float)]
 
 

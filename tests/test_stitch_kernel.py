@@ -11,6 +11,7 @@ import libs
 import stitch_api as sa
 import stitch_cases as sc
 from oracle_run import oracle_binarize
+from sdvpcmdecoder_amd import synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EMU_CASES = ["ntsc_clean", "ntsc_bad5", "ntsc_burst300", "pal_bad5", "f1_16bit_bad5", "ntsc_ctrlblk", "ntsc_bff", "ntsc_drift",
@@ -62,6 +63,133 @@ def test_emu_streaming_calls_equal_one_call(emu, oracle_lib):
     emu.sdv_engine_destroy(eng)
     pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def _frame_cuts(recs, frames_per_call):
+    """Cut positions behind the END_FRAME record of every frames_per_call[i]-th frame (the rest goes with the last call)."""
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    cuts, k = [0], 0
+    for c in frames_per_call:
+        k += c
+        if k - 1 >= len(ends) - 1:
+            break
+        cuts.append(int(ends[k - 1]) + 1)
+    cuts.append(len(recs))
+    return cuts
+
+
+def _pipelined_tape(n=20, seed=401, second=None, end_file=True, **first):
+    """n clean frames (and, with `second`, frames of another kind behind them, numbered on), END_FILE at the end."""
+    luma, _, _ = synth.stc007_frames(n, seed=seed, noise_sigma=2.0, **first)
+    recs, _ = oracle_binarize(np.ascontiguousarray(luma), mode=2)
+    if second is not None:
+        kw = dict(second)
+        m = kw.pop("n")
+        if kw.pop("f1", False):
+            rng = np.random.default_rng(seed + 1000)
+            kw["words"] = synth.interleave_stream_f1(rng.integers(0, 1 << 16, size=(m * 2 * 245, 6), dtype=np.uint32))
+        luma2, _, _ = synth.stc007_frames(m, seed=seed + 1, noise_sigma=2.0, **kw)
+        recs2, _ = oracle_binarize(np.ascontiguousarray(luma2), mode=2, first_frame_no=1 + n, new_file=False)
+        recs = np.concatenate([recs, recs2])
+    return sa.with_end_file(recs) if end_file else recs
+
+
+PIPE_CASES = {
+    # name: (tape kwargs, frames per call, damage, calls expected to run pipelined at least)
+    "plays": (dict(n=20), [3] * 7, None, 3),
+    # 65 turns fill the field order history: from there on the host's check is the short one (pipelined == 2), until the errors come
+    "plays_long": (dict(n=112), [12] * 10, (23, 0.03, 0, 97), 6),
+    "ragged_calls": (dict(n=20), [3, 3, 3, 6, 1, 2, 2], None, 1),
+    "burst_behind_a_steady_start": (dict(n=20), [4] * 5, (21, 0.0, 700, 9), 1),
+    "single_errors_behind_a_steady_start": (dict(n=20), [4] * 5, (22, 0.05, 0, 9), 1),
+    "resolution_changes": (dict(n=10, second=dict(n=10, f1=True)), [3] * 7, None, 1),
+    "field_order_changes": (dict(n=10, second=dict(n=10, bff=True)), [3] * 7, None, 1),
+    # shorter frames than the calls before had: more of them than the launch was made for, the call starts over
+    "more_frames_than_estimated": (dict(n=9, height=576, lines_per_field=294, second=dict(n=21)), [3, 3, 3, 14, 3, 3], None, 1),
+}
+
+
+@pytest.mark.parametrize("name", list(PIPE_CASES))
+def test_emu_pipelined_calls_equal_one_call(name, emu, oracle_lib):
+    """A stream that plays is stitched without waiting for the host between the stages (stitch_engine.inc "1p"): whatever the later calls meet -
+    more frames than the estimate, damage, another resolution or field order, the end of the file - the PCM stream is the sequential one's."""
+    tape_kw, per_call, dmg, want_piped = PIPE_CASES[name]
+    recs = _pipelined_tape(**tape_kw)
+    if dmg is not None:
+        seed, p_bad, burst, from_frame = dmg
+        ends = np.nonzero(recs["service_type"] == 5)[0]
+        a = int(ends[from_frame - 1]) + 1
+        tail = sc.damage(recs[a:], seed, p_bad, burst=burst)
+        recs = np.concatenate([recs[:a], tail])
+    st = sa.default_settings()
+    want_p, want_f = sa.run_cpu(libs.load_oracle(), "orc_", recs, st)
+    eng = emu.sdv_engine_create(0)
+    cuts = _frame_cuts(recs, per_call)
+    got_p, got_f, piped = [], [], []
+    info = ea.StitchInfo()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, p, f = ea.emu_stitch(emu, eng, recs[a:b], st if a == 0 else None, pair_cap=30000, frame_cap=64)
+        assert rc == 0, (a, b)
+        got_p.append(p.copy()); got_f.append(f.copy())
+        assert emu.sdv_get_stitch_info(eng, C.byref(info)) == 0
+        piped.append(int(info.pipelined))
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), (_diff(pairs, frames, want_p, want_f), piped)
+    assert sum(1 for x in piped if x) >= want_piped, piped
+    if name == "plays_long":
+        assert piped[6] == 2 and piped[7] == 2, piped
+    assert piped[0] == 0 and piped[-1] == 0, piped          # a cold start and the call with the end of the file never are
+
+
+def test_emu_pipelined_calls_feed_the_visualiser(emu, oracle_lib):
+    """The data blocks and the assembled lines of pipelined calls (their turns are run once more from the final hand-overs; the first
+    round of such a call never went through the host's per-turn arrays) equal those of the sequential run."""
+    recs = _pipelined_tape(n=14)
+    st = sa.default_settings()
+    _, _, want_blocks = sa.run_cpu_blocks(libs.load_oracle(), "orc_", recs, st)
+    want_lines, _ = sa.last_asm_lines(libs.load_oracle(), "orc_")
+    emu.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    emu.sdv_stitch_block_count.restype = C.c_size_t
+    emu.sdv_stitch_block_count.argtypes = [C.c_void_p]
+    emu.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    emu.sdv_stitch_line_count.restype = C.c_size_t
+    emu.sdv_stitch_line_count.argtypes = [C.c_void_p]
+    eng = emu.sdv_engine_create(0)
+    bbuf = np.zeros(len(want_blocks) + 8, dtype=sa.BLOCK_DTYPE)
+    lbuf = np.zeros(len(want_lines) + 8, dtype=sa.ASM_DTYPE)
+    assert emu.sdv_set_stitch_block_output(eng, bbuf.ctypes.data, len(bbuf)) == 0
+    assert emu.sdv_set_stitch_line_output(eng, lbuf.ctypes.data, len(lbuf)) == 0
+    cuts = _frame_cuts(recs, [3] * 5)
+    blocks, lines, piped = [], [], []
+    info = ea.StitchInfo()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rc, _, _ = ea.emu_stitch(emu, eng, recs[a:b], st if a == 0 else None, pair_cap=30000, frame_cap=64)
+        assert rc == 0
+        blocks.append(bbuf[:emu.sdv_stitch_block_count(eng)].copy()); lines.append(lbuf[:emu.sdv_stitch_line_count(eng)].copy())
+        assert emu.sdv_get_stitch_info(eng, C.byref(info)) == 0
+        piped.append(int(info.pipelined))
+    emu.sdv_engine_destroy(eng)
+    assert sum(1 for x in piped if x) >= 2, piped
+    assert np.concatenate(blocks).tobytes() == want_blocks.tobytes()
+    assert np.concatenate(lines).tobytes() == want_lines.tobytes()
+
+
+def test_emu_pipelined_call_reports_what_the_host_would_have_refused(emu, oracle_lib):
+    """Frame numbers that do not increase are refused before the turns run; a pipelined call has run them already - the call fails all the same."""
+    recs = _pipelined_tape(n=14, end_file=False)
+    st = sa.default_settings()
+    eng = emu.sdv_engine_create(0)
+    cuts = _frame_cuts(recs, [3, 3, 3, 3])
+    info = ea.StitchInfo()
+    for a, b in zip(cuts[:3], cuts[1:4]):
+        rc, _, _ = ea.emu_stitch(emu, eng, recs[a:b], st if a == 0 else None, pair_cap=30000, frame_cap=64)
+        assert rc == 0
+    assert emu.sdv_get_stitch_info(eng, C.byref(info)) == 0 and info.pipelined == 1
+    again = recs[cuts[2]:cuts[3]].copy()            # the frames of the last call once more: numbers go backwards
+    rc, _, _ = ea.emu_stitch(emu, eng, again, None, pair_cap=30000, frame_cap=64)
+    assert rc == -4 and b"frame numbers" in emu.sdv_last_error(eng)      # SDV_ERR_UNSUPPORTED
+    emu.sdv_engine_destroy(eng)
 
 
 def test_emu_empty_and_tiny_inputs(emu, oracle_lib):

@@ -31,4 +31,4 @@ for it in range(reps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     info = eng.stitch_info()
-    print(f"n={n} it={it}: wall {dt*1e3:.2f} ms device {info.device_ms:.2f} ms steps {info.steps} rounds {info.rounds} launched {info.steps_launched} pairs {p.shape[0]}", flush=True)
+    print(f"n={n} it={it}: wall {dt*1e3:.2f} ms device {info.device_ms:.2f} ms steps {info.steps} rounds {info.rounds} piped {info.pipelined} launched {info.steps_launched} pairs {p.shape[0]}", flush=True)
