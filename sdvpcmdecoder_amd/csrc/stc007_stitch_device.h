@@ -1726,7 +1726,7 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 }
 /* The pipelined call (stitch_engine.inc, "a stream that plays"): the host does not wait for the counts - one wave turns them into offsets and leaves
  * the number of frame segments in ctl[CTL_NSEG]; the kernels behind read it from there, launched as wide as the host's estimate. */
-enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_WORDS = 2 };
+enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_NEXT = 2 /* the turn kernel's work queue head */, CTL_WORDS = 3 };
 struct ScanArgs { const uint32_t *block_count; uint32_t *block_ofs; uint32_t nblk; uint32_t *ctl; uint32_t *next_work; };
 __device__ inline void seg_scan_body(const ScanArgs &a, int lane)
 {

@@ -52,7 +52,7 @@ def _separate(eng, fmt, luma):
     return pairs, frames, stats
 
 
-def _fused_host(lib, h, fmt, luma, with_audio, stop=1, give_stats=True):
+def _fused_host(lib, h, fmt, luma, with_audio, stop=1, give_stats=True, first_frame_no=1, flags=1 | 4):
     luma = np.ascontiguousarray(luma)
     n, hgt, w = luma.shape
     cap = (n + 2) * 1800 + 8192
@@ -61,7 +61,7 @@ def _fused_host(lib, h, fmt, luma, with_audio, stop=1, give_stats=True):
     stats = np.zeros(n + 1, dtype=ea.STATS_DTYPE)
     pur = np.zeros(8, dtype=A.PURGE_DTYPE)
     npairs, nfr, npur, nm = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
-    rc = lib.sdv_decode_frames(h, fmt, luma.ctypes.data, w, w * hgt, w, hgt, n, 1, 1 | 4, pairs.ctypes.data, cap, C.byref(npairs), frames.ctypes.data, len(frames),
+    rc = lib.sdv_decode_frames(h, fmt, luma.ctypes.data, w, w * hgt, w, hgt, n, first_frame_no, flags, pairs.ctypes.data, cap, C.byref(npairs), frames.ctypes.data, len(frames),
                                C.byref(nfr), stats.ctypes.data if give_stats else None, len(stats) if give_stats else 0, 1 if with_audio else 0, stop,
                                pur.ctypes.data, len(pur), C.byref(npur), C.byref(nm), None)
     assert rc == 0, lib.sdv_last_error(h)
@@ -92,6 +92,31 @@ def test_emu_fused_equals_separate_calls(fmt, emu_lib, oracle_lib):
     if fmt == STC007:
         assert masked > 0       # the lost lines left samples the error correction could not restore
     c.close()
+
+
+def test_emu_fused_stream_in_calls_equals_one_call(emu_lib, oracle_lib):
+    """A source decoded a few frames per call (NEW_FILE with the first, END_FILE with the last): the calls in between hand records of known
+    layout to the stitch stage, which then neither looks for the frame ends nor waits for its analysis (sdv_stitch_info.pipelined)."""
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    luma = _tape(STC007, 12)
+    a = EmuEngine(lib)
+    lib.sdv_set_pcm_type(a.h, STC007, 0)
+    want_p, want_f, want_s, _, _ = _fused_host(lib, a.h, STC007, luma, with_audio=False)
+    a.close()
+    b = EmuEngine(lib)
+    lib.sdv_set_pcm_type(b.h, STC007, 0)
+    got_p, got_f, got_s, piped = [], [], [], []
+    info = ea.StitchInfo()
+    for k in range(0, 12, 2):
+        flags = (1 if k == 0 else 0) | (4 if k == 10 else 0)
+        p, f, st, _, _ = _fused_host(lib, b.h, STC007, luma[k:k + 2], with_audio=False, first_frame_no=1 + k, flags=flags)
+        got_p.append(p.copy()); got_f.append(f.copy()); got_s.append(st[:2 + (1 if k == 10 else 0)].copy())
+        assert lib.sdv_get_stitch_info(b.h, C.byref(info)) == 0
+        piped.append(int(info.pipelined))
+    b.close()
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s).tobytes() == want_s[:13].tobytes()
+    assert piped[0] == 0 and piped[-1] == 0 and sum(1 for x in piped if x) >= 2, piped
 
 
 def test_emu_fused_refuses_bad_arguments(emu_lib):
