@@ -600,6 +600,15 @@ __device__ inline void conv_body(const ConvArgs1 &a, size_t i)
 __global__ void __launch_bounds__(64) sdv_k_pcm1_bin_to_line(sdvp1::ConvArgs1 a) { sdvp1::conv_body(a, (size_t)blockIdx.x * 64u + threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_segments(sdvp1::SegArgs1 a) { sdvp1::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_pcm1_scan(sdvp1::ScanArgs1 a) { sdvp1::scan_body(a, (int)threadIdx.x); }
+/* What the host wants to know at the end of a stitch call (PCM-1 and PCM-16x0 engines) lies in four places; this puts it behind the four status
+ * words so that one small copy brings all of it: stat[4..5] = pairs of the call, stat[6] = frame descriptors, stat[7] = index of the last END_FRAME. */
+struct sdv_stitch_tail_args { uint32_t *stat; const uint64_t *pair_total; const uint32_t *frasm_total; const uint32_t *last_end; };
+__global__ void __launch_bounds__(64) sdv_k_stitch_tail(sdv_stitch_tail_args a)
+{
+    if (threadIdx.x != 0) return;
+    const uint64_t p = *a.pair_total;
+    a.stat[4] = (uint32_t)p; a.stat[5] = (uint32_t)(p >> 32); a.stat[6] = *a.frasm_total; a.stat[7] = *a.last_end;
+}
 __global__ void __launch_bounds__(64) sdv_k_pcm1_hist(sdvp1::HistArgs1 a) { sdvp1::hist_body(a, (int)threadIdx.x); }
 struct sdv_p1_hist_clear_args { void *hist; };
 __global__ void __launch_bounds__(64) sdv_k_pcm1_hist_clear(sdv_p1_hist_clear_args a) { sdvp1::hist_clear_body(a.hist, (int)threadIdx.x); }
