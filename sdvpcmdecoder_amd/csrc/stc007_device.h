@@ -135,6 +135,8 @@ struct FrameArgs {
     int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch ... */
     const int *frame_list;          /* ... or, when set, the frames frame_list[0 .. grid) */
     uint8_t *flag;                  /* [n_total] VF_*: how frame f left the chain (written by the frame itself when it is done) */
+    uint8_t *refs;                  /* [2 * n_total] or NULL: the reference level frame f was started from and the one it hands on (the scheduler's
+                                     * guess at what a frame does with another level: engine.inc, "a level that passes through") */
     int n_total;                    /* frames of the call */
     int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
     int end_file_frame;             /* frame index of the filler frame that closes the file (no pixels: FILLER lines, END_FILE), or -1 */
@@ -1720,6 +1722,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
     a.flag[f] = fl;
+    if (a.refs) { a.refs[2 * f] = a.states_in[f].bin.in_def_reference; a.refs[2 * f + 1] = o.bin.in_def_reference; }
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
