@@ -1104,9 +1104,17 @@ __device__ inline SweepEnt sweep_one_level(const Bin &b, const sdv_bin_preset &p
 
 /* Binarizer::sweepRefLevel: lanes take levels high_lvl, high_lvl-1, ...  Level L of the reference starts
  * from whatever source-CRC word level L+1 left in the shared temp line (PCMLine::clear() through a base
- * pointer does not reset the STC007Line part, :3629).  That word only matters when it is 0x0000 (then
- * "calc_crc == source CRC" holds before anything was read), so levels are evaluated independently with a
- * non-zero carried word and the whole sweep is replayed serially in the rare case any level left 0x0000. */
+ * pointer does not reset the STC007Line part, :3629).  That word only matters when it is 0x0000: then
+ * "calc_crc == source CRC" holds before anything was read and the level takes another way through the loop
+ * body.  Which non-zero word arrives makes no difference, and neither does the end-marker stage that is
+ * carried the same way (findSTC007Coordinates overwrites it before it looks at it; a line without a start
+ * marker has no markers whatever it says).  So a level has two possible outcomes - started from a non-zero
+ * word, started from 0x0000 - and each outcome says which of the two the next level takes: the lanes evaluate
+ * the first for their levels, the second as well when a zero word is about (the group above left one, or one
+ * of these 64 levels did), and the chain through the lanes is then a walk over two bit masks.
+ * (Through round 3 a zero word anywhere made every lane replay the whole sweep level by level - and on lines
+ * that only read near black the levels near white read sixteen zero bits: 60 % of the time of a tape with
+ * unreadable lines.) */
 __device__ inline void sweep_ref_level(const Bin &b, const sdv_bin_preset &ps, WaveLds &lds, const Line &pcm_line)
 {
     Coords forced_coords; calc_forced_coords(b, ps, forced_coords);
@@ -1114,34 +1122,38 @@ __device__ inline void sweep_ref_level(const Bin &b, const sdv_bin_preset &ps, W
     if (ps.min_ref_lvl > low_lvl) low_lvl = ps.min_ref_lvl;
     if (ps.max_ref_lvl < high_lvl) high_lvl = ps.max_ref_lvl;
     int lane = lane_id();
-    bool zero_seen = false;
-    uint16_t silent_word8 = (uint16_t)~CRC_SILENT;
+    bool carry_zero = false;            /* wave-uniform: the level above this group's first one left 0x0000 */
+    const uint16_t silent_word8 = (uint16_t)~CRC_SILENT;
     for (int base = (int)high_lvl; base >= (int)low_lvl; base -= 64) {
         int lvl = base - lane;
         bool active = lvl >= (int)low_lvl;
         uint16_t w8 = silent_word8; uint8_t med = MARK_ED_START; bool rd = false;
         SweepEnt e; e.result = REF_NO_PCM; e.hyst = 0; e.shift = 0; e.pad = 0; e.crc = 0; e.start = 0; e.stop = 0; e.pad2 = 0;
-        if (active) {
-            e = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, silent_word8, MARK_ED_START, &w8, &med, &rd);
-            if (e.result != REF_NO_PCM) lds.sweep[lvl] = e;
-            if (rd && w8 == 0) zero_seen = true;
+        if (active) e = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, silent_word8, MARK_ED_START, &w8, &med, &rd);
+        const uint64_t m_act = __ballot(active);
+        const uint64_t m_nz = __ballot(active && w8 == 0);             /* left 0x0000 when started from a non-zero word (only a read can do that) */
+        const bool need_z = carry_zero || m_nz != 0ull;
+        bool use_z = false;
+        SweepEnt ez = e;
+        if (need_z) {
+            uint16_t w8z = 0; uint8_t medz = MARK_ED_START; bool rdz = false;
+            if (active) ez = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, 0, MARK_ED_START, &w8z, &medz, &rdz);
+            const uint64_t m_zz = __ballot(active && w8z == 0);         /* ... when started from 0x0000 */
+            uint64_t m_in = 0ull;                                       /* lanes whose level is started from 0x0000 */
+            bool z = carry_zero;
+            for (int i = 0; i < 64 && ((m_act >> i) & 1ull); i++) {
+                if (z) m_in |= 1ull << i;
+                z = ((z ? m_zz : m_nz) >> i) & 1ull;
+            }
+            carry_zero = z;
+            use_z = (m_in >> lane) & 1ull;
         }
-        if (__ballot(zero_seen) != 0ull) zero_seen = true;
+        if (active) {
+            const SweepEnt pick = use_z ? ez : e;
+            if (pick.result != REF_NO_PCM) lds.sweep[lvl] = pick;
+        }
     }
     __syncthreads();
-    if (zero_seen) {
-        /* exact serial replay (all lanes redundantly, results identical) */
-        for (int i = lane; i < 256; i += 64) { SweepEnt z; z.result = 0; z.hyst = z.shift = 0x0f; z.pad = 0; z.crc = 0; z.start = z.stop = 0; z.pad2 = 0; lds.sweep[i] = z; }
-        __syncthreads();
-        uint16_t w8 = silent_word8; uint8_t med = MARK_ED_START;
-        for (int lvl = (int)high_lvl; lvl >= (int)low_lvl; lvl--) {
-            bool rd; uint16_t w8n; uint8_t medn;
-            SweepEnt e = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, w8, med, &w8n, &medn, &rd);
-            w8 = w8n; med = medn;
-            if (e.result != REF_NO_PCM && lane == 0) lds.sweep[lvl] = e;
-        }
-        __syncthreads();
-    }
 }
 
 /* Binarizer::calcRefLevelBySweep (binarizer.cpp:3821-4120) */

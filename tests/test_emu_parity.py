@@ -232,3 +232,17 @@ def test_emu_tall_frames_keep_their_histories(emu_lib, oracle_lib, height, lpf):
     _, _, info = emu_run(emu_lib, steady, 2, flags=0, first=7, eng=eng)
     emu_lib.sdv_engine_destroy(eng)
     assert info.rounds == 1 and info.frames_general == 0
+
+
+def test_emu_unreadable_cells_sweep_every_level(emu_lib, oracle_lib):
+    """A bit cell inverted on some lines: their reference level sweep runs over every level, the levels near white leave a zero source CRC word
+    (two outcomes per level, chained through the lanes - stc007_device.h sweep_ref_level); the scheduler carries the level such a sweep settles on
+    along the chain (engine.inc, "a level that passes through")."""
+    from test_gpu_parity import _unreadable_cells
+    luma, _, _ = synth.stc007_frames(6, seed=78, noise_sigma=4.0, height=120, lines_per_field=60)
+    luma = _unreadable_cells(luma, every=23)
+    want, want_stats = oracle_binarize(np.ascontiguousarray(luma), mode=2)
+    got, got_stats, info = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    assert int((((got["flags"] & 64) == 0) & (got["service_type"] == 0)).sum()) > 6      # data lines without SDV_LF_CRC_VALID: each of them was swept

@@ -201,3 +201,34 @@ def test_hip_dropouts_across_calls(torch_cuda, seed):
     got = np.concatenate(got)
     assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
     assert np.concatenate(got_stats).tobytes() == want_stats.tobytes()
+
+
+def _unreadable_cells(luma, every=53, seed=53):
+    """A bit cell inverted on one line in `every`: no reference level makes the CRC of such a line come out (the reference level sweep of
+    MODE_NORMAL runs over every level for nothing), and the levels near white read sixteen zero bits as the source CRC word."""
+    rng = np.random.default_rng(seed)
+    out = luma.copy()
+    flat = out.reshape(-1, out.shape[-1])
+    w = flat.shape[1]
+    for r in range(0, flat.shape[0], every):
+        x = 12 + int(rng.integers(4, 132)) * (w - 24) // 137
+        flat[r, x:x + 5] = np.clip(230 - flat[r, x:x + 5].astype(np.int16), 0, 255).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("pal", [False, True])
+def test_hip_unreadable_cells_sweep_every_level(torch_cuda, pal):
+    """SURVEY 8d C3's kind of damage: lines whose sweep finds nothing, in every frame; the chain of the sweep's levels (a level that leaves a
+    zero source CRC word sends the next one another way) is resolved from two outcomes per level - bit-exact with the sequential oracle, and the
+    scheduler carries a reference level that passes through along the chain (rounds stay far below the frame count)."""
+    kw = dict(height=576, lines_per_field=294) if pal else {}
+    n = 40
+    luma, _, _ = synth.stc007_frames(n, seed=77, noise_sigma=4.0, **kw)
+    luma = _unreadable_cells(luma)
+    want, want_stats = oracle_binarize(np.ascontiguousarray(luma), mode=2)
+    got, got_stats, info = gpu_run(torch_cuda, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
+    unread = int((((got["flags"] & 64) == 0) & (got["service_type"] == 0)).sum())     # data lines without SDV_LF_CRC_VALID: each of them was swept
+    assert unread > 5 * n, unread
+    assert info.rounds <= 24, info.rounds
