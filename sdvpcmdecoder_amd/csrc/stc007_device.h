@@ -135,8 +135,9 @@ struct FrameArgs {
     int frame_lo, frame_hi;         /* frames [lo, hi) are processed by this launch ... */
     const int *frame_list;          /* ... or, when set, the frames frame_list[0 .. grid) */
     uint8_t *flag;                  /* [n_total] VF_*: how frame f left the chain (written by the frame itself when it is done) */
-    uint8_t *refs;                  /* [2 * n_total] or NULL: the reference level frame f was started from and the one it hands on (the scheduler's
-                                     * guess at what a frame does with another level: engine.inc, "a level that passes through") */
+    uint8_t *refs;                  /* [3 * n_total] or NULL: the reference level frame f was started from, the one it hands on, and whether it pushed one pair
+                                     * into its coordinate history (the scheduler's guess at what a frame does with another state: engine.inc, "a level that
+                                     * passes through", "the history moves on") */
     int n_total;                    /* frames of the call */
     int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
     int end_file_frame;             /* frame index of the filler frame that closes the file (no pixels: FILLER lines, END_FILE), or -1 */
@@ -1734,7 +1735,14 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
     a.flag[f] = fl;
-    if (a.refs) { a.refs[2 * f] = a.states_in[f].bin.in_def_reference; a.refs[2 * f + 1] = o.bin.in_def_reference; }
+    if (a.refs) {
+        const sdv_v2d_state &in = a.states_in[f];
+        /* did the frame just push one pair into its 16-frame coordinate history (the rest moved down a slot)? */
+        bool pushed = in.n_long_valid == COORD_LONG_HISTORY && o.n_long_valid == COORD_LONG_HISTORY && in.long_valid_doubled_mask == 0 && o.long_valid_doubled_mask == 0;
+        for (int i = 0; i + 1 < COORD_LONG_HISTORY && pushed; i++)
+            pushed = o.long_valid[i].data_start == in.long_valid[i + 1].data_start && o.long_valid[i].data_stop == in.long_valid[i + 1].data_stop;
+        a.refs[3 * f] = in.bin.in_def_reference; a.refs[3 * f + 1] = o.bin.in_def_reference; a.refs[3 * f + 2] = pushed ? 1 : 0;
+    }
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
