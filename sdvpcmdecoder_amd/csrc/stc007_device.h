@@ -1403,6 +1403,7 @@ struct V2D {
     uint16_t good_coords_in_field, pcm_lines_in_field, line_in_field_cnt;
     Coords frame_avg;
     int n_last, n_long, nfv, nfi;
+    int long_pushes;                        /* pairs pushed into the full 16-frame history by this frame (the scheduler's "the history moves on") */
     uint16_t last_words[8];                 /* last_stc007_line.words (only the words are ever compared) */
     /* FrameBinDescriptor signal_quality */
     uint16_t q_line_length, q_odd, q_even, q_pcm_odd, q_pcm_even, q_bad_odd, q_bad_even, q_dup_odd, q_dup_even;
@@ -1589,7 +1590,7 @@ __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, u
             if (v.n_long == COORD_LONG_HISTORY) for (int i = 0; i < COORD_LONG_HISTORY - 1; i++) lds.long_keys[i] = lds.long_keys[i + 1];
             lds.long_keys[v.n_long == COORD_LONG_HISTORY ? COORD_LONG_HISTORY - 1 : v.n_long] = coords_key(v.frame_avg.start, v.frame_avg.stop);
         }
-        if (v.n_long < COORD_LONG_HISTORY) v.n_long++;
+        if (v.n_long < COORD_LONG_HISTORY) v.n_long++; else v.long_pushes++;
         __syncthreads();
     } else {
         coords_clear(v.frame_avg);
@@ -1678,7 +1679,7 @@ __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state 
     v.bin.line_length = 0; v.bin.scan_start = v.bin.scan_end = 0; v.bin.mark_start_max = 0; v.bin.mark_end_min = 0xFFFF; v.bin.estimated_ppb = 0;
     v.bin.was_bw_scanned = false; v.bin.vl_doubled = false;
     v.reset_stats = s->reset_stats != 0;
-    v.n_last = s->n_last_valid; v.n_long = s->n_long_valid;
+    v.n_last = s->n_last_valid; v.n_long = s->n_long_valid; v.long_pushes = 0;
     for (int i = 0; i < COORD_HISTORY_DEPTH; i++) lds.lv_keys[i] = coords_key(s->last_valid[i].data_start, s->last_valid[i].data_stop);
     for (int i = 0; i < COORD_LONG_HISTORY; i++) lds.long_keys[i] = coords_key(s->long_valid[i].data_start, s->long_valid[i].data_stop);
     v.field_state = FIELD_INIT;
@@ -1735,14 +1736,13 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
     a.flag[f] = fl;
+#ifndef SDV_EXP_NOREFS       /* (experiment: what the scheduler's bookkeeping costs the kernel) */
     if (a.refs) {
-        const sdv_v2d_state &in = a.states_in[f];
-        /* did the frame just push one pair into its 16-frame coordinate history (the rest moved down a slot)? */
-        bool pushed = in.n_long_valid == COORD_LONG_HISTORY && o.n_long_valid == COORD_LONG_HISTORY && in.long_valid_doubled_mask == 0 && o.long_valid_doubled_mask == 0;
-        for (int i = 0; i + 1 < COORD_LONG_HISTORY && pushed; i++)
-            pushed = o.long_valid[i].data_start == in.long_valid[i + 1].data_start && o.long_valid[i].data_stop == in.long_valid[i + 1].data_stop;
-        a.refs[3 * f] = in.bin.in_def_reference; a.refs[3 * f + 1] = o.bin.in_def_reference; a.refs[3 * f + 2] = pushed ? 1 : 0;
+        /* (one pair pushed into a full history, the rest moved down a slot: counted where it happens - reading the incoming history again here cost 3 % of the kernel) */
+        const bool pushed = v.long_pushes == 1 && v.n_long == COORD_LONG_HISTORY && !a.doubled;
+        a.refs[3 * f] = a.states_in[f].bin.in_def_reference; a.refs[3 * f + 1] = o.bin.in_def_reference; a.refs[3 * f + 2] = pushed ? 1 : 0;
     }
+#endif
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
