@@ -45,6 +45,3 @@ cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out
 tail -1 $R/gpurun_out/prof_vis.log
 # PMC passes of the stitch kernels, the PCM-16x0 analysis, the prescans and the audio plan
 bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="
-# the bench line once more, now that this box's PMC passes exist: refresh profiles/ in this copy of the tree (bench.py takes `roofline.traffic`
-# from profiles/rNN_pmc_<kernel>.json when the source hash matches), so that the line, the kernel stats and the counters come from one box
-cd $R && python tools/refresh_profiles.py r03 > /dev/null 2>&1; python bench.py > gpurun_out/bench_full_final.json 2> gpurun_out/bench_full_final.err; echo "final bench rc=$?"
