@@ -802,9 +802,11 @@ class Engine:
 
     # ---- the workers back to back (sdv_decode_frames) ---------------------------------------------
     def decode_frames(self, pcm_type: int, luma, first_frame_no: int = 1, new_file: bool = False, doubled: bool = False, end_file: bool = False,
-                      with_audio: bool = False, audio_stop: bool = False, stream=None):
+                      with_audio: bool = False, audio_stop: bool = False, stream=None, out_pairs=None, out_frames=None, out_stats=None):
         """Video frames -> PCMSamplePair in one call: the format's VideoToDigital worker, its data stitcher and - with_audio - the AudioProcessor;
         the line records (and the raw pair stream) stay inside the engine.  luma: torch.uint8 CUDA tensor (n_frames, height, width).
+        out_pairs / out_frames / out_stats: the caller's buffers ((>= (n + 2) * 1800 + 8192, 12), (>= n + 16, 64 / 52 / 56), (>= n (+ 1), 32) uint8),
+        allocated per call when not given.
         Returns (pairs (n, 12), frame descriptors (n, 64 / 52 / 56), frame stats (n, 32)) and, with_audio, also (purges (n, 16), masked)."""
         import torch
         assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 3 and luma.stride(2) == 1
@@ -812,9 +814,15 @@ class Engine:
         flags = (FLAG_NEW_FILE if new_file else 0) | (FLAG_DOUBLED if doubled else 0) | (FLAG_END_FILE if end_file else 0)
         fr_bytes = {PCM_STC007: 64, 0: 52, 1: 56}[pcm_type]
         nst = n + (1 if end_file else 0)
-        out_pairs = torch.empty(((n + 2) * 1800 + 8192, 12), dtype=torch.uint8, device=luma.device)
-        out_frames = torch.empty((n + 16, fr_bytes), dtype=torch.uint8, device=luma.device)
-        out_stats = torch.empty((nst, 32), dtype=torch.uint8, device=luma.device)
+        if out_pairs is None:
+            out_pairs = torch.empty(((n + 2) * 1800 + 8192, 12), dtype=torch.uint8, device=luma.device)
+        if out_frames is None:
+            out_frames = torch.empty((n + 16, fr_bytes), dtype=torch.uint8, device=luma.device)
+        if out_stats is None:
+            out_stats = torch.empty((nst, 32), dtype=torch.uint8, device=luma.device)
+        for t, cols in ((out_pairs, 12), (out_frames, fr_bytes), (out_stats, 32)):
+            assert t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2 and t.shape[1] == cols and t.is_contiguous()
+        assert out_stats.shape[0] >= nst
         out_purges = torch.empty((16, 16), dtype=torch.uint8, device=luma.device)
         sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
         n_pairs, n_fr, n_pur, masked = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
