@@ -27,6 +27,12 @@ for case in range(n_cases):
     if rng.random() < 0.5:
         k = int(rng.integers(n // 3, n - 10))
         luma[k:] = np.roll(luma[k:], int(rng.integers(2, 8)), axis=2)
+    if rng.random() < 0.4:          # unreadable lines: a bit cell inverted on one line in `every` (the reference level sweep finds nothing)
+        every = int(rng.choice([53, 97, 211]))
+        flat = luma.reshape(-1, width)
+        for r in range(int(rng.integers(0, every)), flat.shape[0], every):
+            x = 12 + int(rng.integers(4, 132)) * (width - 24) // 137
+            flat[r, x:x + 5] = np.clip(230 - flat[r, x:x + 5].astype(np.int16), 0, 255).astype(np.uint8)
     t0 = time.time()
     want, want_stats = oracle_binarize(luma, mode=2, first_frame_no=1, new_file=True, end_file=True)
     st = sa.default_settings()
