@@ -168,3 +168,34 @@ def test_gpu_fused_equals_separate_calls(fmt, oracle_lib):
     w_out, _, w_pur, w_masked, hit = A.run_cpu(oracle_lib, "orc_", wp, A.DROP_INTER_LIN_WORD, np.array([len(wp)], dtype=np.uint64), 1)
     assert hit == 0 and ga.cpu().numpy().tobytes() == w_out.tobytes() and pur.cpu().numpy().tobytes() == w_pur.tobytes() and masked == w_masked
     assert gf3.cpu().numpy().tobytes() == want_f.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("damaged", [False, True])
+def test_gpu_fused_stream_in_calls_equals_one_call(damaged):
+    """1 200 frames through sdv_decode_frames in eight calls (NEW_FILE with the first, END_FILE with the last) against one call over all of them:
+    the calls in between take the pipelined way through the stitch stage (records of known layout, no wait for the analysis, the next call's
+    state copied ahead of the read-back) - with lost lines in some frames the assumptions fail now and then and the classic way takes over."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, synth
+    n, per = 1200, 150
+    luma, _ = synth.stc007_frames_torch(n, seed=31, device="cuda", noise_sigma=3.0)
+    if damaged:
+        rng = np.random.default_rng(5)
+        for f in rng.choice(np.arange(10, n - 10), size=40, replace=False):
+            luma[int(f), int(rng.integers(30, 450))] = 16
+    one = Engine(0); one.setPCMType(STC007)
+    wp, wf, ws = one.decode_frames(STC007, luma, first_frame_no=1, new_file=True, end_file=True)
+    want_p, want_f, want_s = wp.cpu().numpy().copy(), wf.cpu().numpy().copy(), ws.cpu().numpy().copy()
+    eng = Engine(0); eng.setPCMType(STC007)
+    got_p, got_f, got_s, piped = [], [], [], []
+    for k in range(0, n, per):
+        p, f, st = eng.decode_frames(STC007, luma[k:k + per], first_frame_no=1 + k, new_file=k == 0, end_file=k + per == n)
+        got_p.append(p.cpu().numpy().copy()); got_f.append(f.cpu().numpy().copy()); got_s.append(st.cpu().numpy().copy())
+        piped.append(int(eng.stitch_info().pipelined))
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes()
+    assert np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s)[:n].tobytes() == want_s[:n].tobytes()
+    assert piped[0] == 0 and piped[-1] == 0, piped
+    if not damaged:
+        assert sum(1 for x in piped if x) >= 4, piped
