@@ -281,7 +281,7 @@ typedef struct sdv_run_info {
     uint32_t frames_launched;   /* frame decodes executed, including re-decodes after a misprediction */
     uint32_t frames_general;    /* of those, by the full kernel (the lean one has no general path and gives such frames up) */
     float kernel_ms;            /* HIP-event time of the frame kernel launches of this call (sdv_set_profiling) */
-    float _pad2;
+    uint32_t sweeps;            /* reference-level sweeps (Binarizer::calcRefLevelBySweep) settled by the sweep kernels for this call */
 } sdv_run_info;
 int sdv_get_run_info(const sdv_engine *e, sdv_run_info *out);
 /* Bracket every frame-kernel launch with hipEvents on the caller's stream and report the sum in sdv_run_info. */

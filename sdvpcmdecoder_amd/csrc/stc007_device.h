@@ -149,6 +149,9 @@ struct FrameArgs {
     sdv_frame_stats *stats;         /* [n frames] */
     uint32_t *scratch;              /* per frame 2*height u32 (frame_valid / frame_invalid coordinate keys) */
     const uint8_t *frame_flags;     /* [n frames] SDV_FRAME_* of the caller (sdv_set_frame_flags), or NULL */
+    struct SweepMemo *memo;         /* outcomes of reference-level sweeps and requests for more (stc007_sweep_device.h): the pool, ... */
+    int32_t *memo_head;             /* ... [n_total] the newest entry of frame f (-1: none), ... */
+    int32_t *memo_count; int32_t memo_cap;   /* ... entries handed out (may run past the capacity: those requests were dropped) */
 };
 /* a dropped frame: VideoInFFMPEG::insertDummyFrame(false, true) sends its lines as empty VideoLines (vin_ffmpeg.cpp:367-522) */
 __device__ __forceinline__ bool frame_is_empty(const FrameArgs &a, int f) { return a.frame_flags && f < a.n_total && f != a.end_file_frame && (a.frame_flags[f] & SDV_FRAME_EMPTY); }
@@ -188,6 +191,15 @@ struct Bin {                        /* Binarizer (binarizer.h:306-337) */
 struct Markers { uint8_t st_stage, ed_stage; uint16_t st1s, st1e, st3e, ed_start, ed_end; bool has_start; };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch (0..7 the frame loop, 8..15 the general path) */
+__device__ unsigned long long sdv_k1_cycles[16];
+#define K1_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define K1_ADD(i, t0, t1) do { if (lane_id() == 0) atomicAdd(&sdv_k1_cycles[i], (t1) - (t0)); } while (0)
+#else
+#define K1_T(var) do { } while (0)
+#define K1_ADD(i, t0, t1) do { } while (0)
+#endif
+
 /* Wave-uniform values that reach us through vector memory (global/LDS/scratch loads) are re-declared
  * uniform so the compiler keeps them in SGPRs and branches on them with scalar branches. */
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -544,12 +556,12 @@ __device__ inline void read_pcm_data(Bin &b, Line &l, const WaveLds &lds)
 }
 
 /* ======================================================================================== */
-/* Serial (one candidate per lane) versions used inside the lane-parallel searches           */
+/* Marker search                                                                             */
 /* ======================================================================================== */
 
 /* Binarizer::searchSTC007Markers (binarizer.cpp:5275-5595) for one hysteresis level; pure function of the
  * staged scanline, the line's ref_level and the scan limits.  Runs independently in every lane. */
-__device__ inline Markers search_markers(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, uint8_t ref_level, uint8_t hyst_lvl)
+__device__ inline Markers search_markers_px(const Bin &b, const sdv_bin_preset &ps, const uint8_t *px, uint8_t ref_level, uint8_t hyst_lvl)
 {
     Markers m;
     uint8_t stage = MARK_ST_START, pv;
@@ -562,7 +574,7 @@ __device__ inline Markers search_markers(const Bin &b, const sdv_bin_preset &ps,
     if (pixel_limit > b.line_length) pixel_limit = b.line_length;
     uint16_t pixel = b.scan_start;
     while (pixel < pixel_limit) {
-        pv = lds.px[pixel];
+        pv = px[pixel];
         if (stage == MARK_ST_START) {
             if (pixel > b.mark_start_max) break;
             if (pv >= bin_low) { st1s = pixel; stage = MARK_ST_TOP_1; }
@@ -593,7 +605,7 @@ __device__ inline Markers search_markers(const Bin &b, const sdv_bin_preset &ps,
         else pixel_limit = 0;
         pixel = b.scan_end;
         while (pixel > pixel_limit) {
-            pv = lds.px[pixel];
+            pv = px[pixel];
             if (stage == MARK_ED_START) {
                 if (pixel < b.mark_end_min) break;
                 if (pv >= bin_low) { ed_end = (uint16_t)(pixel + 1); stage = MARK_ED_TOP; }
@@ -622,31 +634,12 @@ __device__ inline void apply_markers(Line &l, const Markers &m)
     l.coords_set = has_markers(l);
 }
 
-/* Binarizer::findSTC007Coordinates (binarizer.cpp:6047-6113), per-lane serial version (used inside the
- * reference sweep where every lane owns a different reference level). */
-__device__ inline void find_coordinates_serial(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, Line &l)
-{
-    bool have = false; uint32_t best_key = 0;
-    uint8_t carried_ed = l.mark_ed;      /* temp_line keeps mark_ed_stage between iterations when START is missing */
-    Markers best;                        /* the reference searches once more with the level it picked (level 0 when none qualified): the same search, the same result */
-    for (uint8_t h = 0; h < 24; h++) {
-        Markers m = search_markers(b, ps, lds, l.ref_level, h);
-        if (h == 0) best = m;
-        if (m.has_start) carried_ed = m.ed_stage;
-        if (m.has_start && carried_ed == MARK_ED_LEN_OK) {
-            uint32_t k = coords_key((int16_t)m.st1e, (int16_t)m.ed_start);
-            if (!have || k < best_key) { best_key = k; best = m; have = true; }   /* ties keep the lower hysteresis */
-        }
-    }
-    apply_markers(l, best);
-}
-
-/* wave-parallel version: lanes 0..23 each try one hysteresis level */
+/* Binarizer::findSTC007Coordinates (binarizer.cpp:6047-6113): lanes 0..23 each try one hysteresis level */
 __device__ inline void find_coordinates_wave(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, Line &l)
 {
     int lane = lane_id();
     uint8_t h = (uint8_t)(lane < 24 ? lane : 23);
-    Markers m = search_markers(b, ps, lds, l.ref_level, h);
+    Markers m = search_markers_px(b, ps, lds.px, l.ref_level, h);
     bool ok = (lane < 24) && m.has_start && (m.ed_stage == MARK_ED_LEN_OK);
     uint32_t k = coords_key((int16_t)m.st1e, (int16_t)m.ed_start);
     uint64_t okm = __ballot(ok);
@@ -670,59 +663,6 @@ __device__ inline void find_coordinates_wave(const Bin &b, const sdv_bin_preset 
     r.ed_end = (uint16_t)__shfl((int)m.ed_end, best);
     r.has_start = (r.st_stage == MARK_ST_BOT_2);
     apply_markers(l, r);
-}
-
-/* serial fill (one lane = one candidate): Binarizer::fillSTC007 literally */
-__device__ inline void fill_stc007_serial(Line &l, const WaveLds &lds, int stage)
-{
-    bool prev_high = false;
-    uint16_t w = 0; int bitpos = 13, widx = 0;
-    uint16_t crc = 0xFFFF;
-    for (int bit = 0; bit < BITS_DATA; bit++) {
-        uint8_t pv = lds.px[shift_clamp(l, bit_center(l, bit), stage)];
-        int v;
-        if (!prev_high) { v = pv > l.ref_low; if (v) prev_high = true; }
-        else { v = pv >= l.ref_high; if (!v) prev_high = false; }
-        if (v) w |= (uint16_t)(1u << bitpos);
-        if (bit < 112) crc = crc16_step(crc, v);
-        if (bitpos == 0) {
-            l.words[widx] = w; w = 0; widx++;
-            bitpos = (bit == 111) ? 16 : 14;
-        }
-        bitpos--;
-    }
-    l.word_crc07 = l.word_valid07 = false;
-    l.calc_crc = crc;
-}
-__device__ inline bool fill_data_words_serial(Line &l, const WaveLds &lds, uint8_t ref_delta, uint8_t shift_stg)
-{
-    if (ref_delta > HYST_DEPTH_MAX) return false;
-    if (shift_stg > SHIFT_STAGES_MAX) return false;
-    uint8_t low_ref = get_low_level(l.ref_level, ref_delta), high_ref = get_high_level(l.ref_level, ref_delta);
-    l.ref_low = low_ref; l.ref_high = high_ref;
-    if (low_ref <= l.black) { set_invalid_crc(l); return false; }
-    if (high_ref >= l.white) { set_invalid_crc(l); return false; }
-    l.hyst = ref_delta; l.shift = shift_stg;
-    fill_stc007_serial(l, lds, shift_stg);
-    return true;
-}
-__device__ inline void read_pcm_data_serial(uint8_t hyst_lim, uint8_t shift_lim, Line &l, const WaveLds &lds)
-{
-    set_ppb(l, l.coords);
-    if (hyst_lim > HYST_DEPTH_MAX) hyst_lim = HYST_DEPTH_MAX;
-    if (shift_lim > SHIFT_STAGES_MAX) shift_lim = SHIFT_STAGES_MAX;
-    uint8_t valid_delta = 0, valid_shift = 0;
-    bool found = false;
-    for (int h = 0; h <= (int)hyst_lim && !found; h++) {
-        bool invalid_hyst = false;
-        for (int s = 0; s <= (int)shift_lim; s++) {
-            if (!fill_data_words_serial(l, lds, (uint8_t)h, (uint8_t)s)) { invalid_hyst = true; break; }
-            if (crc_valid(l)) { found = true; valid_delta = (uint8_t)h; valid_shift = (uint8_t)s; break; }
-        }
-        if (invalid_hyst) break;
-    }
-    if (found) return;
-    fill_data_words_serial(l, lds, valid_delta, valid_shift);
 }
 
 
@@ -959,42 +899,134 @@ __device__ inline void sweep_invalidate_non_frequent(WaveLds &lds, uint8_t low_l
         index--;
     }
 }
-/* crcs: the table the indices count from (WaveLds::sweep, or a row inside it) */
-__device__ inline uint8_t pick_level_by_crc_stats_at(const SweepEnt *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
-                                                     uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :1985-2140 */
+/* ---- 256 levels as four 64-bit words: the selections below walk over runs of set bits, not over levels ---- */
+struct M256 { uint64_t w[4]; };
+__device__ __forceinline__ M256 m256_zero() { M256 m; m.w[0] = m.w[1] = m.w[2] = m.w[3] = 0ull; return m; }
+__device__ __forceinline__ M256 m256_not(const M256 &a) { M256 m; m.w[0] = ~a.w[0]; m.w[1] = ~a.w[1]; m.w[2] = ~a.w[2]; m.w[3] = ~a.w[3]; return m; }
+__device__ __forceinline__ M256 m256_and(const M256 &a, const M256 &b) { M256 m; m.w[0] = a.w[0] & b.w[0]; m.w[1] = a.w[1] & b.w[1]; m.w[2] = a.w[2] & b.w[2]; m.w[3] = a.w[3] & b.w[3]; return m; }
+__device__ __forceinline__ bool m256_any(const M256 &a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) != 0ull; }
+__device__ __forceinline__ int m256_count(const M256 &a) { return __popcll(a.w[0]) + __popcll(a.w[1]) + __popcll(a.w[2]) + __popcll(a.w[3]); }
+__device__ __forceinline__ void m256_set(M256 &m, int i)
 {
-    bool good_ref_det = false, range_lock = false, second_start_lock = false;
-    uint8_t index, low_depth = 0xFF, low_shift = 0xFF, low_ref = 0, high_ref = 0, tst_low_ref = 0, tst_high_ref = 0, picked_ref;
-    index = high_lvl;
-    while (index >= low_lvl) {
-        if ((crcs[index].result == target_result) && (crcs[index].hyst <= max_hyst) && (crcs[index].shift <= max_shift)) {
-            good_ref_det = true;
-            if (crcs[index].hyst < low_depth) { low_depth = crcs[index].hyst; low_shift = crcs[index].shift; high_ref = index; }
-            else if (crcs[index].hyst == low_depth) if (crcs[index].shift < low_shift) { low_shift = crcs[index].shift; high_ref = index; }
-        }
-        if (index == low_lvl) break;
-        index--;
+#pragma unroll
+    for (int g = 0; g < 4; g++) m.w[g] |= (g == (i >> 6)) ? (1ull << (i & 63)) : 0ull;
+}
+__device__ __forceinline__ bool m256_test(const M256 &m, int i)
+{
+    uint64_t x = 0ull;
+#pragma unroll
+    for (int g = 0; g < 4; g++) x = (g == (i >> 6)) ? m.w[g] : x;
+    return ((x >> (i & 63)) & 1ull) != 0ull;
+}
+/* bits lo..hi (inclusive; empty when hi < lo) */
+__device__ inline M256 m256_range(int lo, int hi)
+{
+    M256 m = m256_zero();
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int a = lo - 64 * g, b = hi - 64 * g;         /* the range in this word's own bit numbers */
+        if (b < 0 || a > 63 || hi < lo) continue;
+        const uint64_t up = b >= 63 ? ~0ull : ((2ull << b) - 1ull), dn = a <= 0 ? ~0ull : (~0ull << a);
+        m.w[g] = up & dn;
     }
-    if (!good_ref_det) return SPAN_NOT_FOUND;
-    index = high_ref;
-    while (index >= low_lvl) {
-        if ((crcs[index].result == target_result) && (crcs[index].hyst == low_depth) && (crcs[index].shift == low_shift)) {
-            if (!range_lock) low_ref = index;
-            else { if (!second_start_lock) { tst_high_ref = index; second_start_lock = true; } tst_low_ref = index; }
-        } else {
-            range_lock = true;
-            if (second_start_lock) {
-                second_start_lock = false;
-                if (((int)tst_high_ref - (int)tst_low_ref) >= ((int)high_ref - (int)low_ref)) { low_ref = tst_low_ref; high_ref = tst_high_ref; }
-            }
-        }
-        if (index == low_lvl) break;
-        index--;
+    return m;
+}
+/* the highest set bit at or below p (p < 0: none), -1 when there is none */
+__device__ inline int m256_top_le(const M256 &m, int p)
+{
+    int r = -1;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int hi = p - 64 * g;
+        if (hi < 0) continue;
+        uint64_t x = m.w[g];
+        if (hi < 63) x &= (2ull << hi) - 1ull;
+        if (x) r = 64 * g + 63 - __clzll(x);
     }
-    picked_ref = (uint8_t)(high_ref - low_ref);
-    picked_ref = picked_ref / 2;
-    picked_ref = (uint8_t)(low_ref + picked_ref);
-    *ref_result = picked_ref;
+    return r;
+}
+
+/* Second half of pickLevelByCRCStats (binarizer.cpp:2060-2140): E = the levels that carry the target result at the lowest (depth, stage),
+ * none below low_lvl; high_ref = the highest of them.  The reference walks down from there: the run that starts at high_ref is the span to
+ * beat, every further run that a non-member CLOSES inside [low_lvl, ..] replaces it when it is at least as long (so of equally long runs
+ * the lowest wins, and a run still open at low_lvl is never looked at).  Here: from run to run with count-leading-zeros. */
+__device__ inline void pick_longest_run(const M256 &E, int low_lvl, int &low_ref, int &high_ref)
+{
+    const M256 nE = m256_not(E);
+    int z = m256_top_le(nE, high_ref);                      /* the non-member that closes the first run (below low_lvl: it stays open) */
+    low_ref = z + 1 > low_lvl ? z + 1 : low_lvl;
+    while (z >= low_lvl) {
+        const int h = m256_top_le(E, z - 1);
+        if (h < low_lvl) break;
+        z = m256_top_le(nE, h);
+        if (z < low_lvl) break;                             /* open at the low end */
+        if ((h - (z + 1)) >= (high_ref - low_ref)) { low_ref = z + 1; high_ref = h; }
+    }
+}
+/* First half of pickLevelByCRCStatsOpt (binarizer.cpp:2178-2262): the widest run of usable levels inside [low_lvl, high_lvl], of equally
+ * wide ones the lowest; a run of two or more levels that reaches low_lvl is taken whatever its width, a single level there is not. */
+__device__ inline bool pick_widest_region(const M256 &good, int low_lvl, int high_lvl, int &reg_lo, int &reg_hi)
+{
+    const M256 ngood = m256_not(good);
+    bool lock = false;
+    reg_lo = reg_hi = 0;
+    for (int pos = high_lvl; pos >= low_lvl;) {
+        const int h = m256_top_le(good, pos);
+        if (h < low_lvl) break;
+        const int z = m256_top_le(ngood, h);
+        if (z < low_lvl) { if (h > low_lvl) { reg_lo = low_lvl; reg_hi = h; lock = true; } break; }
+        if ((h - z) >= (reg_hi - reg_lo + 1)) { reg_lo = z + 1; reg_hi = h; lock = true; }
+        pos = z;
+    }
+    return lock;
+}
+/* Second half of pickLevelByCRCStatsOpt (binarizer.cpp:2263-2383) over the usable levels from high_lvl down, `at(i)` = (depth << 8 | stage) of level i:
+ * a lower depth, or the same depth with a lower stage, restarts the span there; levels equal to the best extend it downwards, five of them end
+ * the walk, and so do five levels that are worse since the last restart. */
+template <class At>
+__device__ inline bool pick_opt_walk(const M256 &good, int low_lvl, int high_lvl, uint8_t max_ref_lvl, At at, uint8_t *ref_result)
+{
+    bool any = false;
+    uint32_t best = 0xFFFFFFFFu;
+    int low_ref = max_ref_lvl, high_ref = max_ref_lvl, hold = 0, same = MIN_VALID_CRCS;
+    for (int pos = high_lvl; pos >= low_lvl;) {
+        const int i = m256_top_le(good, pos);
+        if (i < low_lvl) break;
+        const uint32_t k = at(i);
+        any = true;
+        if (k < best) {
+            if ((k >> 8) == (best >> 8)) same = MIN_VALID_CRCS;    /* the same depth, a lower stage */
+            best = k; low_ref = high_ref = i; hold = MIN_VALID_CRCS;
+        } else if (k == best) { low_ref = i; if (--same == 0) break; }
+        else if (--hold == 0) break;
+        pos = i - 1;
+    }
+    if (!any) return false;
+    *ref_result = (uint8_t)(low_ref + (uint8_t)(high_ref - low_ref) / 2);
+    return true;
+}
+
+/* pickLevelByCRCStats (binarizer.cpp:1985-2140) on a table in memory, for one lane on its own: the levels with the target result within the limits
+ * as a mask, the lowest (depth, stage) among them, then pick_longest_run over those that have it.
+ * crcs: the table the indices count from (WaveLds::sweep, or a row inside it) */
+__device__ inline uint8_t pick_level_by_crc_stats_at(const SweepEnt *crcs, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
+                                                     uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)
+{
+    uint32_t best = 0xFFFFFFFFu;
+    for (int i = low_lvl; i <= (int)high_lvl; i++) {
+        const SweepEnt e = crcs[i];
+        const uint32_t k = ((uint32_t)e.hyst << 8) | e.shift;
+        if (e.result == target_result && e.hyst <= max_hyst && e.shift <= max_shift && k < best) best = k;
+    }
+    if (best == 0xFFFFFFFFu) return SPAN_NOT_FOUND;
+    M256 E = m256_zero();
+    for (int i = low_lvl; i <= (int)high_lvl; i++) {
+        const SweepEnt e = crcs[i];
+        if (e.result == target_result && (((uint32_t)e.hyst << 8) | e.shift) == best) m256_set(E, i);
+    }
+    int high_ref = m256_top_le(E, high_lvl), low_ref;
+    pick_longest_run(E, low_lvl, low_ref, high_ref);
+    *ref_result = (uint8_t)(low_ref + (uint8_t)(high_ref - low_ref) / 2);
     return SPAN_OK;
 }
 __device__ inline uint8_t pick_level_by_crc_stats(const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
@@ -1002,54 +1034,23 @@ __device__ inline uint8_t pick_level_by_crc_stats(const WaveLds &lds, uint8_t *r
 {
     return pick_level_by_crc_stats_at(lds.sweep, ref_result, low_lvl, high_lvl, target_result, max_hyst, max_shift);
 }
+/* pickLevelByCRCStatsOpt (binarizer.cpp:2143-2383) on WaveLds::sweep, for one lane on its own */
 __device__ inline uint8_t pick_level_by_crc_stats_opt(const sdv_bin_preset &ps, const WaveLds &lds, uint8_t *ref_result, uint8_t low_lvl, uint8_t high_lvl,
-                                                      uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)   /* :2143-2383 */
+                                                      uint8_t target_result, uint8_t max_hyst, uint8_t max_shift)
 {
     const SweepEnt *crcs = lds.sweep;
-    bool range_lock = false, good_ref_det = false;
-    uint8_t index, hold_cnt, same_cnt, low_depth, low_shift = 0, high_shift = 0, low_ref = 0, high_ref = 0, picked_ref;
-    index = high_lvl;
-    while (index >= low_lvl) {
-        if ((crcs[index].result == target_result) && (crcs[index].hyst <= max_hyst) && (crcs[index].shift <= max_shift)) {
-            if (!good_ref_det) { good_ref_det = true; low_ref = high_ref = index; }
-            else { low_ref = index; if (low_ref == low_lvl) { low_shift = low_ref; high_shift = high_ref; range_lock = true; } }
-        } else if (good_ref_det) {
-            if (((int)high_ref - (int)low_ref + 1) >= ((int)high_shift - (int)low_shift + 1)) { low_shift = low_ref; high_shift = high_ref; range_lock = true; }
-            good_ref_det = false;
-        }
-        if (index == low_lvl) break;
-        index--;
+    M256 good = m256_zero();
+    for (int i = low_lvl; i <= (int)high_lvl; i++) {
+        const SweepEnt e = crcs[i];
+        if (e.result == target_result && e.hyst <= max_hyst && e.shift <= max_shift) m256_set(good, i);
     }
-    if (range_lock) { high_lvl = high_shift; low_lvl = low_shift; }
-    good_ref_det = false;
-    hold_cnt = 0; low_depth = low_shift = 255; same_cnt = MIN_VALID_CRCS;
-    low_ref = high_ref = ps.max_ref_lvl;
-    index = high_lvl;
-    while (index >= low_lvl) {
-        if ((crcs[index].result == target_result) && (crcs[index].hyst <= max_hyst) && (crcs[index].shift <= max_shift)) {
-            good_ref_det = true;
-            if (low_depth > crcs[index].hyst) { low_depth = crcs[index].hyst; low_shift = crcs[index].shift; low_ref = high_ref = index; hold_cnt = MIN_VALID_CRCS; }
-            else if (low_depth == crcs[index].hyst) {
-                if (low_shift > crcs[index].shift) { low_shift = crcs[index].shift; low_ref = high_ref = index; same_cnt = MIN_VALID_CRCS; hold_cnt = MIN_VALID_CRCS; }
-                else if (low_shift == crcs[index].shift) { low_ref = index; same_cnt--; if (same_cnt == 0) { hold_cnt = 0; break; } }
-                else { hold_cnt--; if (hold_cnt == 0) break; }
-            } else { hold_cnt--; if (hold_cnt == 0) break; }
-        }
-        if (index == low_lvl) break;
-        index--;
-    }
-    if (good_ref_det) {
-        picked_ref = (uint8_t)(high_ref - low_ref);
-        picked_ref = picked_ref / 2;
-        picked_ref = (uint8_t)(low_ref + picked_ref);
-        *ref_result = picked_ref;
-        return SPAN_OK;
-    }
-    return SPAN_NOT_FOUND;
+    int lo = low_lvl, hi = high_lvl, rl, rh;
+    if (pick_widest_region(good, lo, hi, rl, rh)) { lo = rl; hi = rh; }
+    return pick_opt_walk(good, lo, hi, ps.max_ref_lvl, [&](int i) -> uint32_t { return ((uint32_t)crcs[i].hyst << 8) | crcs[i].shift; }, ref_result) ? SPAN_OK : SPAN_NOT_FOUND;
 }
 
 /* ======================================================================================== */
-/* Reference level sweep (binarizer.cpp:3551-4120)                                           */
+/* Reference level sweep (binarizer.cpp:3551-4120): see stc007_sweep_device.h                */
 /* ======================================================================================== */
 
 __device__ inline void calc_forced_coords(const Bin &b, const sdv_bin_preset &ps, Coords &fc)   /* :631-641 */
@@ -1061,155 +1062,44 @@ __device__ inline void calc_forced_coords(const Bin &b, const sdv_bin_preset &ps
         if (b.vl_doubled) { fc.start = (int16_t)(fc.start + ps.horiz_start); fc.stop = (int16_t)(fc.stop - ps.horiz_stop); }
     }
 }
+__device__ inline void bin_set_mode(Bin &b, uint8_t m);
+__device__ inline uint32_t wave_min_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o < v ? o : v; } return v; }
+__device__ inline uint32_t wave_max_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o > v ? o : v; } return v; }
+__device__ inline bool pod_coords_valid(int16_t s, int16_t e) { return s != NO_COORD_LEFT && e != NO_COORD_RIGHT && s < e; }
+} // namespace sdv
+#include "stc007_sweep_device.h"
+namespace sdv {
 
-/* One sweep level (body of the while loop, :3626-3816) evaluated by ONE lane from a given carried
- * source-CRC word.  Returns the entry to store (result REF_NO_PCM = nothing stored). */
-__device__ inline SweepEnt sweep_one_level(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, const Coords &forced_coords,
-                                           uint8_t low_lvl, uint8_t high_lvl, uint8_t ref_index, uint16_t carried_word8, uint8_t carried_mark_ed,
-                                           uint16_t *word8_out, uint8_t *mark_ed_out, bool *did_read)
+/* Binarizer::calcRefLevelBySweep (binarizer.cpp:3821-4120) in the frame kernel: the sweep itself, its vote and its pick are taken from the
+ * outcome the sweep kernels left for this line (stc007_sweep_device.h); what is done here is what the reference does with the level picked.
+ * Without an outcome the line leaves a request and goes on as if the sweep had found nothing: the frame is decoded again once the request is
+ * settled, so what is made of the line here never reaches the caller. */
+__device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &l, SweepHook &hook)
 {
-    Line t;
-    stc_clear(t);                       /* only the base part matters; STC parts that persist are passed in explicitly */
-    pcmline_clear(t);                   /* :3629 PCMLine::clear(): calc_crc = 0 */
-    t.words[8] = carried_word8;
-    t.mark_ed = carried_mark_ed;
-    set_source_pixels(t, 0, (uint16_t)(b.line_length - 1));
-    t.coords.doubled = b.vl_doubled;
-    t.black = low_lvl; t.white = high_lvl; t.ref_level = ref_index;
-    bool read = false, searched = false;
-    if (!coords_valid(forced_coords)) {
-        if (coords_valid(b.in_coord)) {
-            bool skip_bin = false;
-            if (ps.en_good_no_marker) {
-                find_coordinates_serial(b, ps, lds, t);
-                if (!has_markers(t)) skip_bin = true; else searched = true;
-            }
-            if (skip_bin) { t.coords = b.in_coord; read_pcm_data_serial(b.hyst_lim, b.shift_lim, t, lds); read = true; }
-        }
-    }
-    if (!crc_valid(t)) {
-        /* (a line whose markers were found above is searched again by the reference, with the same pixels and the same level: nothing has touched the line
-         * in between, the search leaves what it left - not repeated) */
-        if (!coords_valid(forced_coords)) { if (!searched) find_coordinates_serial(b, ps, lds, t); }
-        else { t.coords = forced_coords; t.coords_set = true; }
-        if (t.coords_set) { read_pcm_data_serial(b.hyst_lim, b.shift_lim, t, lds); read = true; }
-    }
-    if (t.hyst > 0x0F) t.hyst = 0x0F;
-    SweepEnt e; e.result = REF_NO_PCM; e.hyst = 0; e.shift = 0; e.pad = 0; e.crc = 0; e.start = 0; e.stop = 0; e.pad2 = 0;
-    if (crc_valid(t) && coords_valid(t.coords)) e.result = REF_CRC_OK;
-    else if (t.coords_set) e.result = REF_BAD_CRC;
-    if (e.result != REF_NO_PCM) { e.start = t.coords.start; e.stop = t.coords.stop; e.hyst = t.hyst; e.shift = t.shift; e.crc = t.calc_crc; }
-    *word8_out = t.words[8]; *mark_ed_out = t.mark_ed; *did_read = read;
-    return e;
-}
-
-/* Binarizer::sweepRefLevel: lanes take levels high_lvl, high_lvl-1, ...  Level L of the reference starts
- * from whatever source-CRC word level L+1 left in the shared temp line (PCMLine::clear() through a base
- * pointer does not reset the STC007Line part, :3629).  That word only matters when it is 0x0000: then
- * "calc_crc == source CRC" holds before anything was read and the level takes another way through the loop
- * body.  Which non-zero word arrives makes no difference, and neither does the end-marker stage that is
- * carried the same way (findSTC007Coordinates overwrites it before it looks at it; a line without a start
- * marker has no markers whatever it says).  So a level has two possible outcomes - started from a non-zero
- * word, started from 0x0000 - and each outcome says which of the two the next level takes: the lanes evaluate
- * the first for their levels, the second as well when a zero word is about (the group above left one, or one
- * of these 64 levels did), and the chain through the lanes is then a walk over two bit masks.
- * (Through round 3 a zero word anywhere made every lane replay the whole sweep level by level - and on lines
- * that only read near black the levels near white read sixteen zero bits: 60 % of the time of a tape with
- * unreadable lines.) */
-__device__ inline void sweep_ref_level(const Bin &b, const sdv_bin_preset &ps, WaveLds &lds, const Line &pcm_line)
-{
-    Coords forced_coords; calc_forced_coords(b, ps, forced_coords);
-    uint8_t low_lvl = (uint8_t)(pcm_line.black + 1), high_lvl = (uint8_t)(pcm_line.white - 1);
-    if (ps.min_ref_lvl > low_lvl) low_lvl = ps.min_ref_lvl;
-    if (ps.max_ref_lvl < high_lvl) high_lvl = ps.max_ref_lvl;
-    int lane = lane_id();
-    bool carry_zero = false;            /* wave-uniform: the level above this group's first one left 0x0000 */
-    const uint16_t silent_word8 = (uint16_t)~CRC_SILENT;
-    for (int base = (int)high_lvl; base >= (int)low_lvl; base -= 64) {
-        int lvl = base - lane;
-        bool active = lvl >= (int)low_lvl;
-        uint16_t w8 = silent_word8; uint8_t med = MARK_ED_START; bool rd = false;
-        SweepEnt e; e.result = REF_NO_PCM; e.hyst = 0; e.shift = 0; e.pad = 0; e.crc = 0; e.start = 0; e.stop = 0; e.pad2 = 0;
-        if (active) e = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, silent_word8, MARK_ED_START, &w8, &med, &rd);
-        const uint64_t m_act = __ballot(active);
-        const uint64_t m_nz = __ballot(active && w8 == 0);             /* left 0x0000 when started from a non-zero word (only a read can do that) */
-        const bool need_z = carry_zero || m_nz != 0ull;
-        bool use_z = false;
-        SweepEnt ez = e;
-        if (need_z) {
-            uint16_t w8z = 0; uint8_t medz = MARK_ED_START; bool rdz = false;
-            if (active) ez = sweep_one_level(b, ps, lds, forced_coords, low_lvl, high_lvl, (uint8_t)lvl, 0, MARK_ED_START, &w8z, &medz, &rdz);
-            const uint64_t m_zz = __ballot(active && w8z == 0);         /* ... when started from 0x0000 */
-            uint64_t m_in = 0ull;                                       /* lanes whose level is started from 0x0000 */
-            bool z = carry_zero;
-            for (int i = 0; i < 64 && ((m_act >> i) & 1ull); i++) {
-                if (z) m_in |= 1ull << i;
-                z = ((z ? m_zz : m_nz) >> i) & 1ull;
-            }
-            carry_zero = z;
-            use_z = (m_in >> lane) & 1ull;
-        }
-        if (active) {
-            const SweepEnt pick = use_z ? ez : e;
-            if (pick.result != REF_NO_PCM) lds.sweep[lvl] = pick;
-        }
-    }
-    __syncthreads();
-}
-
-/* Binarizer::calcRefLevelBySweep (binarizer.cpp:3821-4120) */
-__device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &l)
-{
-    uint8_t fast_ref, valid_crc_cnt = 0, span_res;
     Coords forced_coords;
-    fast_ref = pick_center_ref_level(ps, l.black, l.white);
+    const uint8_t fast_ref = pick_center_ref_level(ps, l.black, l.white);
     b.hyst_lim = b.in_max_hyst; b.shift_lim = b.in_max_shift;
     calc_forced_coords(b, ps, forced_coords);
-    __syncthreads();
-    for (int i = lane_id(); i < 256; i += 64) { SweepEnt z; z.result = 0; z.hyst = z.shift = 0x0f; z.pad = 0; z.crc = 0; z.start = z.stop = 0; z.pad2 = 0; lds.sweep[i] = z; }
-    __syncthreads();
-    sweep_ref_level(b, ps, lds, l);
-    span_res = SPAN_NOT_FOUND;
-    __syncthreads();
-    if (lane_id() == 0) { crc_stats_reset(lds, MAX_COLL_CRCS + 1); lds.crc_stats[0].hyst = 0; lds.crc_stats[0].shift = 0; }
-    __syncthreads();
-    /* statistics and vote: serial; lane 0 mutates LDS, everyone then reads the same values */
-    uint8_t blk1 = (uint8_t)(l.black + 1), wht1 = (uint8_t)(l.white - 1);
-    if (lane_id() == 0) {
-        for (uint8_t bin_level = wht1; bin_level > l.black; bin_level--)
-            if (lds.sweep[bin_level].result == REF_CRC_OK) crc_stats_update(lds, lds.sweep[bin_level].crc, lds.sweep[bin_level].hyst, lds.sweep[bin_level].shift, valid_crc_cnt);
-        uint8_t first_cnt = valid_crc_cnt;
-        if (valid_crc_cnt > 0) {
-            crc_stats_most_frequent(lds, valid_crc_cnt);
-            sweep_invalidate_non_frequent(lds, blk1, wht1, valid_crc_cnt, lds.crc_stats[0].crc);
-        }
-        lds.crc_stats[0].idx = (uint8_t)((first_cnt > 0 ? 1 : 0) | (valid_crc_cnt > 0 ? 2 : 0));   /* hand the two flags to the other lanes */
+    SweepOutcome o;
+    if (!sweep_lookup(hook, l.black, l.white, b.in_coord, o)) {
+        sweep_request(hook, l.black, l.white, b.in_coord);
+        if (b.in_ref < ps.min_ref_lvl) hook.stop = true;
+        o.span1 = o.span2 = SPAN_NOT_FOUND; o.ref_level = 0; o.t_hyst = o.t_shift = 0; o.t_start = o.t_stop = 0;
     }
-    __syncthreads();
-    bool had_any = (lds.crc_stats[0].idx & 1) != 0, still_valid = (lds.crc_stats[0].idx & 2) != 0;
-    if (had_any && still_valid) {
-        if (lds.crc_stats[0].result < ps.min_valid_crcs) span_res = SPAN_TOO_NARROW;
-        else span_res = pick_level_by_crc_stats(lds, &l.ref_level, blk1, wht1, REF_CRC_OK, 0x0F, SHIFT_STAGES_MAX);
-    }
-    if (span_res == SPAN_OK) {
-        SweepEnt t = lds.sweep[l.ref_level];
+    if (o.span1 == SPAN_OK) {
+        l.ref_level = o.ref_level;
         l.ref_sweeped = true;
-        coords_set(l.coords, t.start, t.stop);
+        coords_set(l.coords, o.t_start, o.t_stop);
         l.coords_set = true;
         if (!coords_valid(forced_coords)) find_coordinates_wave(b, ps, lds, l);
-        b.hyst_lim = t.hyst;
+        b.hyst_lim = o.t_hyst;
         if (b.hyst_lim > HYST_DEPTH_MAX) b.hyst_lim = HYST_DEPTH_MAX;
-        b.shift_lim = t.shift;
+        b.shift_lim = o.t_shift;
     } else {
-        if (span_res == SPAN_TOO_NARROW) {
-            span_res = pick_level_by_crc_stats_opt(ps, lds, &l.ref_level, blk1, wht1, REF_CRC_OK, b.hyst_lim, b.shift_lim);
-            l.forced_bad = true;
-        } else {
-            span_res = pick_level_by_crc_stats(lds, &l.ref_level, blk1, wht1, REF_BAD_CRC, 0xFF, 0xFF);
-        }
-        if (span_res == SPAN_OK) {
-            SweepEnt t = lds.sweep[l.ref_level];
-            coords_set(l.coords, t.start, t.stop);
+        if (o.span1 == SPAN_TOO_NARROW) l.forced_bad = true;
+        if (o.span2 == SPAN_OK) {
+            l.ref_level = o.ref_level;
+            coords_set(l.coords, o.t_start, o.t_stop);
             l.coords_set = true;
             if (!coords_valid(forced_coords)) find_coordinates_wave(b, ps, lds, l);
         } else if (b.in_ref >= ps.min_ref_lvl) {
@@ -1268,23 +1158,15 @@ __device__ inline void bin_set_mode(Bin &b, uint8_t m)   /* :120-152 */
 /* Binarizer::processLine (binarizer.cpp:443-1724) for a regular (non-service, non-empty) line */
 /* that is already staged in lds.px.  Returns LB_RET_*.                                        */
 /* ======================================================================================== */
-__device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &out, uint32_t frame_no, uint16_t line_no, int width, bool doubled)
+__device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &out, uint32_t frame_no, uint16_t line_no, int width, bool doubled, SweepHook &hook)
 {
     Coords forced_coords;
     stc_clear(out);
     out.frame_number = frame_no; out.line_number = line_no;
-    b.line_length = (uint16_t)width; b.vl_doubled = doubled;
+    bin_line_geometry(b, ps, width, doubled);
     out.coords.doubled = doubled;
-    b.scan_start = 0; b.scan_end = (uint16_t)(b.line_length - 1);
     set_source_pixels(out, b.scan_start, b.scan_end);
     if (b.line_length < BITS_IN_LINE) return SDV_ERR_SHORT_LINE;
-    b.mark_start_max = (uint16_t)(b.line_length * ps.mark_max_dist);
-    b.mark_start_max = b.mark_start_max / 100;
-    b.mark_end_min = (uint16_t)(b.scan_end - b.mark_start_max);
-    b.mark_start_max = (uint16_t)(b.scan_start + b.mark_start_max);
-    uint32_t tmp_calc = (uint32_t)b.line_length * 128u;
-    tmp_calc = tmp_calc / BITS_IN_LINE;
-    b.estimated_ppb = (uint16_t)((tmp_calc + 64) / 128);
     coords_set(out.coords, (int16_t)b.scan_start, (int16_t)b.scan_end);
     calc_forced_coords(b, ps, forced_coords);
     if (ps.en_force_coords && coords_valid(forced_coords)) { out.coords = forced_coords; out.coords_set = true; }
@@ -1299,7 +1181,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
     for (;;) {
         stage_count++;
         if (state == STG_INPUT_ALL) {                       /* :774-931 */
-            if (!out.bw_set) find_black_white(b, ps, lds, out);
+            if (!out.bw_set) { K1_T(t0_); find_black_white(b, ps, lds, out); K1_T(t1_); K1_ADD(9, t0_, t1_); }
             if (!coords_valid(forced_coords)) out.coords = b.in_coord;
             out.ref_level = b.in_ref;
             out.ref_sweeped = false;
@@ -1312,14 +1194,14 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
                     out.coords = b.in_coord;
                     if (!has_markers(out)) force_level_find = true;
                 }
-                read_pcm_data(b, out, lds);
+                { K1_T(t0_); read_pcm_data(b, out, lds); K1_T(t1_); K1_ADD(11, t0_, t1_); }
                 if (crc_valid(out)) {
                     if (!force_level_find) { out.by_ext_tune = true; state = STG_DATA_OK; }
                     else state = STG_REF_FIND;
                 } else state = !coords_valid(forced_coords) ? STG_INPUT_LEVEL : STG_REF_FIND;
             }
         } else if (state == STG_INPUT_LEVEL) {              /* :932-1072 */
-            if (!b.was_bw_scanned) find_black_white(b, ps, lds, out);
+            if (!b.was_bw_scanned) { K1_T(t0_); find_black_white(b, ps, lds, out); K1_T(t1_); K1_ADD(9, t0_, t1_); }
             if (!coords_valid(forced_coords)) coords_set(out.coords, (int16_t)b.scan_start, (int16_t)b.scan_end);
             out.ref_level = b.in_ref;
             out.ref_sweeped = false;
@@ -1327,7 +1209,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
             else {
                 state = STG_REF_FIND;
                 if ((b.in_ref < out.white) && (b.in_ref > out.black)) {
-                    find_coordinates_wave(b, ps, lds, out);
+                    { K1_T(t0_); find_coordinates_wave(b, ps, lds, out); K1_T(t1_); K1_ADD(10, t0_, t1_); }
                     if (has_markers(out)) {
                         if (!coords_valid(b.in_coord) || coords_ne(out.coords, b.in_coord)) {
                             read_pcm_data(b, out, lds);
@@ -1355,7 +1237,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
                 }
             }
         } else if (state == STG_REF_SWEEP_RUN) {            /* :1391-1400 */
-            calc_ref_level_by_sweep(b, ps, lds, out);
+            { K1_T(t0_); calc_ref_level_by_sweep(b, ps, lds, out, hook); K1_T(t1_); K1_ADD(12, t0_, t1_); }
             state = STG_READ_PCM;
         } else if (state == STG_READ_PCM) {                 /* :1401-1533 */
             if (coords_valid(forced_coords)) { b.hyst_lim = HYST_DEPTH_SAFE; b.shift_lim = SHIFT_STAGES_MIN; }
@@ -1408,9 +1290,6 @@ struct V2D {
     /* FrameBinDescriptor signal_quality */
     uint16_t q_line_length, q_odd, q_even, q_pcm_odd, q_pcm_even, q_bad_odd, q_bad_even, q_dup_odd, q_dup_even;
 };
-
-__device__ inline uint32_t wave_min_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o < v ? o : v; } return v; }
-__device__ inline uint32_t wave_max_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o > v ? o : v; } return v; }
 
 /* VideoToDigital::medianCoordinates (videotodigital.cpp:348-371): element of rank n/2 under
  * CoordinatePair::operator<.  keys[] readable by every lane (LDS or own global stores). */
@@ -1637,7 +1516,6 @@ __device__ inline void v2d_make_uniform(V2D &v)
 
 /* The model of the chain (engine.inc, chain speculation): the state `m` frames behind s0 when every line of those frames decodes with the inherited
  * tuning - presets unchanged, the 9-entry window saturated with the one coordinate pair, one entry of it per frame pushed into the 16-frame history. */
-__device__ inline bool pod_coords_valid(int16_t s, int16_t e) { return s != NO_COORD_LEFT && e != NO_COORD_RIGHT && s < e; }
 __device__ inline sdv_v2d_state predict_state(const sdv_v2d_state &s0, int m, bool doubled, uint8_t min_ref_lvl)
 {
     sdv_v2d_state p = s0;
@@ -1690,7 +1568,7 @@ __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state 
     v.q_line_length = v.q_odd = v.q_even = v.q_pcm_odd = v.q_pcm_even = v.q_bad_odd = v.q_bad_even = v.q_dup_odd = v.q_dup_even = 0;
     v2d_make_uniform(v);
 }
-__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a)
+__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a, bool unsettled = false)
 {
     if (lane_id() != 0) return;
     sdv_v2d_state o;
@@ -1735,6 +1613,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (!same) fl |= VF_MOVED;
         if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
+    if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
     a.flag[f] = fl;
 #ifndef SDV_EXP_NOREFS       /* (experiment: what the scheduler's bookkeeping costs the kernel) */
     if (a.refs) {
@@ -2216,15 +2095,19 @@ __device__ inline void batch_finish(const FrameArgs &a, V2D &v, const BatchLane 
 
 /* General path for one regular line, out of line so that its register appetite (reference sweep, marker
  * searches) does not spill into the hot loop.  State crosses the call in memory. */
-struct SlowCtx { FrameArgs a; V2D v; Line wl; };
+struct SlowCtx { FrameArgs a; V2D v; Line wl; SweepHook hook; };
 
 __device__ __attribute__((noinline)) void slow_line(SlowCtx *c, WaveLds *lds, uint32_t frame_no, uint16_t line_num,
                                                     uint32_t *fv_keys, uint32_t *fi_keys, sdv_line_rec *rec)
 {
+    K1_T(t0_);
     bin_set_mode(c->v.bin, c->a.mode);
-    process_line(c->v.bin, c->a.preset, *lds, c->wl, frame_no, line_num, c->a.width, c->a.doubled != 0);
+    process_line(c->v.bin, c->a.preset, *lds, c->wl, frame_no, line_num, c->a.width, c->a.doubled != 0, c->hook);
+    K1_T(t1_);
     v2d_post_line(c->v, c->a, *lds, c->wl, fv_keys, fi_keys, (line_num % 2) == 0);
     emit_record(c->wl, rec);
+    K1_T(t2_);
+    K1_ADD(8, t0_, t2_); K1_ADD(13, t1_, t2_); K1_ADD(15, 0ull, 1ull);
 }
 
 /* A line of a dropped frame: Binarizer::processLine answers an empty VideoLine with a cleared line - silent words, CRC invalid
@@ -2247,14 +2130,6 @@ __device__ __attribute__((noinline)) void empty_line(SlowCtx *c, WaveLds *lds, u
  * paths gives the frame up: it marks its outgoing state (sdv_v2d_state::_pad[0]) and the engine decodes from that frame on
  * with the full kernel. */
 enum { STATE_ABORTED = 0xA5 };
-#ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch */
-__device__ unsigned long long sdv_k1_cycles[8];
-#define K1_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define K1_ADD(i, t0, t1) do { if (lane_id() == 0) atomicAdd(&sdv_k1_cycles[i], (t1) - (t0)); } while (0)
-#else
-#define K1_T(var) do { } while (0)
-#define K1_ADD(i, t0, t1) do { } while (0)
-#endif
 template <bool kLean>
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 {
@@ -2343,6 +2218,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     uint16_t line_num = 0;
     int start_field = 0, start_idx = 0;
     bool all_captured = false; uint32_t captured_key = 0;
+    bool sweep_pending = false;             /* a line of this frame went on without the sweep it asked for: the frame is decoded again */
 #if SDV_CAPTURE
     /* whole-frame capture (see capture_solve): only in the lean build, on the geometry the batch loop takes */
     if (kLean && pf.vec && a.width <= 1024 && (a.width & 15) == 0 && n_field[1] > 0 && (uint64_t)a.row_stride * (uint64_t)a.height < (1ull << 31) &&
@@ -2594,16 +2470,27 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 row_prefetch(pf, nxt, a.width);
             }
             line_num = (uint16_t)(field + 1 + 2 * idx);
-            if (!fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec)) {
+            K1_T(t_fl0);
+            const bool took_fast = fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec);
+            K1_T(t_fl1);
+            if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
+            if (!took_fast) {
                 if (kLean) {
                     if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
                     return;
                 } else {
                     SlowCtx c;
                     c.a = a; c.v = v;
+                    c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
+                    c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.pending = false; c.hook.stop = false;
                     slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
                     v = c.v;
                     v2d_make_uniform(v);
+                    sweep_pending = sweep_pending || uni(c.hook.pending) != 0;
+                    if (uni(c.hook.stop) != 0) {        /* (what was decoded of the frame is not final anyway) */
+                        if (lane == 0) a.flag[f] = VF_ABORTED;
+                        return;
+                    }
                 }
             }
             rec++; idx++;
@@ -2618,7 +2505,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     K1_T(t_ef0);
     v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f], all_captured ? &captured_key : nullptr);
     emit_record(wl, rec++);
-    v2d_store_state(v, lds, &a.states_out[f], a);
+    v2d_store_state(v, lds, &a.states_out[f], a, sweep_pending);
     K1_T(t_end);
     K1_ADD(3, t_ef0, t_end);
     K1_ADD(0, t_begin, t_end);

@@ -1,5 +1,6 @@
-"""Scheduler trace (developer build, SDV_SCHED_TRACE=1) of the PAL tape of SURVEY 8d C3: usage pal_trace.py [frames]"""
-import os, sys, time
+"""Developer aid: where the general path of the full frame kernel spends its cycles on the tape of SURVEY 8d C3 (library built with
+-DSDV_K1_STAMPS, passed in SDVPCM_LIB): usage slow_stamps.py [frames] [both|cells|lost]"""
+import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -20,15 +21,19 @@ if what in ("both", "cells"):
         flat[rows, xs + dx] = (230 - flat[rows, xs + dx].to(torch.int16)).clamp_(0, 255).to(torch.uint8)
 eng = Engine(0); eng.set_profiling(True); eng.setBinarizationMode(2)
 eng.binarize_frames(pal, first_frame_no=1, new_file=True)
-eng.binarize_frames(pal, first_frame_no=1 + n)
+eng.binarize_frames(lum, first_frame_no=1 + n)
+out = (C.c_ulonglong * 16)()
+eng.lib.sdv_debug_k1_cycles(out, 1)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 eng.binarize_frames(lum, first_frame_no=1 + 2 * n)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+eng.lib.sdv_debug_k1_cycles(out, 0)
 i = eng.run_info()
-print(f"{what}: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel, {i.sweeps} sweeps", flush=True)
-for rep in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    eng.binarize_frames(lum, first_frame_no=1 + (3 + rep) * n)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
-    i = eng.run_info()
-    print(f"  again: {dt:.2f} ms wall, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel, {i.sweeps} sweeps -> {n / dt * 1e3:.0f} frames/s", flush=True)
+print(f"{what}: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel, {i.sweeps} sweeps")
+v = list(out)
+fr = max(1, i.frames_general)
+names = {0: "frame total", 1: "batch loops", 2: "batch_finish", 3: "end of frame", 8: "slow_line total", 9: "find_black_white", 10: "find_coordinates (INPUT_LEVEL)",
+         11: "read_pcm_data (INPUT_ALL)", 12: "sweep lookup + apply", 13: "post_line + record", 14: "fast_line attempts that failed"}
+print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame)")
+for k, nm in names.items():
+    print(f"  {nm:34s} {v[k] / fr:12.0f} cycles per full-kernel frame" + (f"  {v[k] / max(1, v[15]):10.0f} per slow line" if k >= 8 else ""))
