@@ -693,14 +693,15 @@ __device__ inline bool find_black_white_p1(const BinCtx &c, WaveLds &lds, L1 &li
     uint32_t black_lvl_count, white_lvl_count, temp_calc;
     uint16_t search_lim;
     bool black_level_detected, white_level_detected;
-    useful_low = low_scan_limit = br_black = usefull_low_level(c.ps, lds);
-    useful_high = high_scan_limit = br_white = usefull_high_level(c.ps, lds);
+    const SpreadLevels sl = spread_levels(c.ps, lds);
+    useful_low = low_scan_limit = br_black = sl.low;
+    useful_high = high_scan_limit = br_white = sl.high;
     range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
     low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
     high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
     temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
     temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
-    search_lim = most_frequent_brightness_count(lds);
+    search_lim = sl.most_frequent;
     search_lim = search_lim / 64;
     brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
     while (brt_lev <= low_scan_limit) {

@@ -529,7 +529,7 @@ __device__ inline bool fill_data_words(Line &l, const WaveLds &lds, int32_t vp0,
  * (shift_crcs/hyst_crcs/crc_stats) reduce, for a single candidate, to "first (hysteresis, shift) pair in
  * lexicographic order with a valid CRC, else (0,0)"; the ladder stops at the first hysteresis depth whose
  * levels leave (black, white). */
-__device__ inline void read_pcm_data(Bin &b, Line &l, const WaveLds &lds)
+__device__ inline void read_pcm_data(Bin &b, Line &l, const WaveLds &lds, bool ladder_known_to_fail = false)
 {
     set_ppb(l, l.coords);
     int lane = lane_id();
@@ -540,7 +540,8 @@ __device__ inline void read_pcm_data(Bin &b, Line &l, const WaveLds &lds)
     if (!l.ref_sweeped) {
         valid_delta = 0; valid_shift = 0;
         bool found = false, last_is_target = false;
-        for (int h = 0; h <= (int)b.hyst_lim && !found; h++) {
+        /* (ladder_known_to_fail: the frame loop has been through exactly these reads for this line - fast_line - and none came out valid; what is left is the closing read) */
+        for (int h = 0; h <= (int)b.hyst_lim && !found && !ladder_known_to_fail; h++) {
             bool invalid_hyst = false;
             for (int s = 0; s <= (int)b.shift_lim; s++) {
                 if (!fill_data_words(l, lds, vp0, vp1, (uint8_t)h, (uint8_t)s)) { invalid_hyst = true; break; }
@@ -666,6 +667,70 @@ __device__ inline void find_coordinates_wave(const Bin &b, const sdv_bin_preset 
 }
 
 
+/* ---- 256 levels as four 64-bit words: the selections below walk over runs of set bits, not over levels ---- */
+struct M256 { uint64_t w[4]; };
+__device__ __forceinline__ M256 m256_zero() { M256 m; m.w[0] = m.w[1] = m.w[2] = m.w[3] = 0ull; return m; }
+__device__ __forceinline__ M256 m256_not(const M256 &a) { M256 m; m.w[0] = ~a.w[0]; m.w[1] = ~a.w[1]; m.w[2] = ~a.w[2]; m.w[3] = ~a.w[3]; return m; }
+__device__ __forceinline__ M256 m256_and(const M256 &a, const M256 &b) { M256 m; m.w[0] = a.w[0] & b.w[0]; m.w[1] = a.w[1] & b.w[1]; m.w[2] = a.w[2] & b.w[2]; m.w[3] = a.w[3] & b.w[3]; return m; }
+__device__ __forceinline__ bool m256_any(const M256 &a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) != 0ull; }
+__device__ __forceinline__ int m256_count(const M256 &a) { return __popcll(a.w[0]) + __popcll(a.w[1]) + __popcll(a.w[2]) + __popcll(a.w[3]); }
+__device__ __forceinline__ void m256_set(M256 &m, int i)
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++) m.w[g] |= (g == (i >> 6)) ? (1ull << (i & 63)) : 0ull;
+}
+__device__ __forceinline__ bool m256_test(const M256 &m, int i)
+{
+    uint64_t x = 0ull;
+#pragma unroll
+    for (int g = 0; g < 4; g++) x = (g == (i >> 6)) ? m.w[g] : x;
+    return ((x >> (i & 63)) & 1ull) != 0ull;
+}
+/* bits lo..hi (inclusive; empty when hi < lo) */
+__device__ inline M256 m256_range(int lo, int hi)
+{
+    M256 m = m256_zero();
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int a = lo - 64 * g, b = hi - 64 * g;         /* the range in this word's own bit numbers */
+        if (b < 0 || a > 63 || hi < lo) continue;
+        const uint64_t up = b >= 63 ? ~0ull : ((2ull << b) - 1ull), dn = a <= 0 ? ~0ull : (~0ull << a);
+        m.w[g] = up & dn;
+    }
+    return m;
+}
+/* the lowest set bit at or above p, 256 when there is none */
+__device__ inline int m256_bottom_ge(const M256 &m, int p)
+{
+    int r = 256;
+#pragma unroll
+    for (int g = 3; g >= 0; g--) {
+        const int lo = p - 64 * g;
+        if (lo > 63) continue;
+        uint64_t x = m.w[g];
+        if (lo > 0) x &= ~0ull << lo;
+        if (x) r = 64 * g + __ffsll((unsigned long long)x) - 1;
+    }
+    return r;
+}
+/* the highest set bit at or below p (p < 0: none), -1 when there is none */
+__device__ inline int m256_top_le(const M256 &m, int p)
+{
+    int r = -1;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int hi = p - 64 * g;
+        if (hi < 0) continue;
+        uint64_t x = m.w[g];
+        if (hi < 63) x &= (2ull << hi) - 1ull;
+        if (x) r = 64 * g + 63 - __clzll(x);
+    }
+    return r;
+}
+
+__device__ inline uint32_t wave_min_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o < v ? o : v; } return v; }
+__device__ inline uint32_t wave_max_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o > v ? o : v; } return v; }
+
 /* ======================================================================================== */
 /* AGC: BLACK / WHITE levels                                                                 */
 /* ======================================================================================== */
@@ -684,43 +749,35 @@ __device__ inline void hist_add_range(WaveLds &lds, int from, int to)
 }
 
 /* brightness-spread counters are uint16_t in the reference (binarizer.cpp:3125): a line is at most
- * 65535 px (uint16_t line_length), so no counter can wrap - 32-bit LDS counters are equivalent. */
-__device__ inline uint16_t most_frequent_brightness_count(const WaveLds &lds)   /* :2450-2468 */
+ * 65535 px (uint16_t line_length), so no counter can wrap - 32-bit LDS counters are equivalent.
+ *
+ * The three questions the reference asks of a finished brightness spread, for the whole wave at once (lane i holds levels i, i + 64, i + 128,
+ * i + 192): getMostFrequentBrightnessCount (binarizer.cpp:2450-2468) = the maximum over the lanes; getUsefullLowLevel (:2471-2513) = the lowest
+ * level below max_black_lvl that more than 1/64 of that many pixels have (0 when there is none: the reference's second, unfiltered pass starts where
+ * the first one ended - at max_black_lvl - and does nothing); getUsefullHighLevel (:2516-2557) = the highest such level from 255 down to
+ * min_white_lvl (255 when there is none; its unfiltered pass stops at once on the level the filtered one found).  Needs the spread complete and
+ * visible (hist_add_range ends with a barrier). */
+struct SpreadLevels { uint16_t most_frequent; uint8_t low, high; };
+__device__ inline SpreadLevels spread_levels(const sdv_bin_preset &ps, const WaveLds &lds)
 {
-    uint32_t hf = 0;
-    for (int lev = 255; lev >= 0; lev--) if (lds.hist[lev] > hf) hf = lds.hist[lev];
-    return (uint16_t)hf;
-}
-__device__ inline uint8_t usefull_low_level(const sdv_bin_preset &ps, const WaveLds &lds)   /* :2471-2513 */
-{
-    bool filtered_found = false;
-    uint8_t brt_lev = 0, lowest_lev = 0;
-    uint16_t min_freq = most_frequent_brightness_count(lds) / 64;
-    while (brt_lev < ps.max_black_lvl) {
-        if (lds.hist[brt_lev] > min_freq) { lowest_lev = brt_lev; filtered_found = true; break; }
-        brt_lev++;
-    }
-    if (!filtered_found)
-        while (brt_lev < ps.max_black_lvl) {
-            if (lds.hist[brt_lev] > 0) { lowest_lev = brt_lev; break; }
-            brt_lev++;
-        }
-    return lowest_lev;
-}
-__device__ inline uint8_t usefull_high_level(const sdv_bin_preset &ps, const WaveLds &lds)  /* :2516-2557 */
-{
-    uint8_t brt_lev = 255, highest_lev = 255;
-    uint16_t min_freq = most_frequent_brightness_count(lds) / 64;
-    while (brt_lev >= ps.min_white_lvl) {
-        if (lds.hist[brt_lev] > min_freq) { highest_lev = brt_lev; break; }
-        brt_lev--;
-    }
-    /* filtered_found is never set in the reference, so the unfiltered pass always follows */
-    while (brt_lev >= ps.min_white_lvl) {
-        if (lds.hist[brt_lev] > 0) { highest_lev = brt_lev; break; }
-        brt_lev--;
-    }
-    return highest_lev;
+    const int lane = lane_id();
+    uint32_t h[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) h[g] = lds.hist[64 * g + lane];
+    uint32_t m = h[0] > h[1] ? h[0] : h[1]; { const uint32_t m2 = h[2] > h[3] ? h[2] : h[3]; m = m > m2 ? m : m2; }
+    SpreadLevels r;
+    r.most_frequent = (uint16_t)uniu(wave_max_u32(m));
+    const uint32_t min_freq = r.most_frequent / 64;
+    M256 A;
+#pragma unroll
+    for (int g = 0; g < 4; g++) A.w[g] = __ballot(h[g] > min_freq);
+    int lo = 256;
+#pragma unroll
+    for (int g = 3; g >= 0; g--) if (A.w[g]) lo = 64 * g + __ffsll((unsigned long long)A.w[g]) - 1;
+    r.low = lo < (int)ps.max_black_lvl ? (uint8_t)lo : (uint8_t)0;
+    const int hi = m256_top_le(A, 255);
+    r.high = hi >= (int)ps.min_white_lvl ? (uint8_t)hi : (uint8_t)255;
+    return r;
 }
 
 /* Binarizer::findSTC007BW (binarizer.cpp:2684-3070); leaves the brightness spread to analyse in lds.hist */
@@ -737,8 +794,7 @@ __device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds 
     search_lim = (uint16_t)(b.scan_end - b.estimated_ppb * 20);
     hist_add_range(lds, search_lim, (int)b.scan_end + 1);
 
-    useful_low = low_scan_limit = usefull_low_level(ps, lds);
-    useful_high = high_scan_limit = br_mark_white = usefull_high_level(ps, lds);
+    { const SpreadLevels sl = spread_levels(ps, lds); useful_low = low_scan_limit = sl.low; useful_high = high_scan_limit = br_mark_white = sl.high; }
     range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
     high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 4));
     bin_high = range_limit / 8;
@@ -761,6 +817,25 @@ __device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds 
         bin_high = bin_low = bin_level;
         if (b.mark_end_min > (b.estimated_ppb * 6)) pixel_limit = (uint16_t)(b.mark_end_min - b.estimated_ppb * 6);
         else pixel_limit = 0;
+        const int n_stop = (int)b.scan_end - (int)pixel_limit;           /* pixels scan_end, scan_end - 1, ... the search may look at */
+        if (n_stop <= 256) {
+            /* the comparison of the whole window at once (bit i = pixel scan_end - i is at or above the level), the state machine from edge to edge */
+            M256 R;
+#pragma unroll
+            for (int g = 0; g < 4; g++) { const int i = 64 * g + lane_id(); R.w[g] = __ballot(i < n_stop && lds.px[i < n_stop ? (int)b.scan_end - i : 0] >= bin_level); }
+            const M256 nR = m256_not(R);
+            const int i_max = (int)b.scan_end - (int)b.mark_end_min;
+            for (int i = 0;;) {
+                const int j1 = m256_bottom_ge(R, i);
+                if (j1 >= n_stop || j1 > i_max) { stage = MARK_ED_START; break; }
+                ed_end = (uint16_t)(b.scan_end - j1 + 1); stage = MARK_ED_TOP;
+                const int j2 = m256_bottom_ge(nR, j1 + 1);
+                if (j2 >= n_stop) break;
+                ed_start = (uint16_t)(b.scan_end - j2 + 1);
+                if ((j2 - j1) >= (b.estimated_ppb * 2)) { stage = MARK_ED_LEN_OK; break; }
+                stage = MARK_ED_START; i = j2 + 1;
+            }
+        } else {
         pixel = b.scan_end;
         while (pixel > pixel_limit) {
             pv = lds.px[pixel];
@@ -776,6 +851,7 @@ __device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds 
                 }
             }
             pixel--;
+        }
         }
         line.mark_ed = stage;
         line.coords.stop = (int16_t)ed_start;
@@ -809,14 +885,15 @@ __device__ inline bool find_black_white(Bin &b, const sdv_bin_preset &ps, WaveLd
 
     find_stc007_bw(b, ps, lds, line);
 
-    useful_low = low_scan_limit = br_black = usefull_low_level(ps, lds);
-    useful_high = high_scan_limit = br_white = usefull_high_level(ps, lds);
+    const SpreadLevels sl = spread_levels(ps, lds);
+    useful_low = low_scan_limit = br_black = sl.low;
+    useful_high = high_scan_limit = br_white = sl.high;
     range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
     low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
     high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
     temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
     temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
-    search_lim = most_frequent_brightness_count(lds);
+    search_lim = sl.most_frequent;
     search_lim = search_lim / 64;
 
     brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
@@ -899,53 +976,6 @@ __device__ inline void sweep_invalidate_non_frequent(WaveLds &lds, uint8_t low_l
         index--;
     }
 }
-/* ---- 256 levels as four 64-bit words: the selections below walk over runs of set bits, not over levels ---- */
-struct M256 { uint64_t w[4]; };
-__device__ __forceinline__ M256 m256_zero() { M256 m; m.w[0] = m.w[1] = m.w[2] = m.w[3] = 0ull; return m; }
-__device__ __forceinline__ M256 m256_not(const M256 &a) { M256 m; m.w[0] = ~a.w[0]; m.w[1] = ~a.w[1]; m.w[2] = ~a.w[2]; m.w[3] = ~a.w[3]; return m; }
-__device__ __forceinline__ M256 m256_and(const M256 &a, const M256 &b) { M256 m; m.w[0] = a.w[0] & b.w[0]; m.w[1] = a.w[1] & b.w[1]; m.w[2] = a.w[2] & b.w[2]; m.w[3] = a.w[3] & b.w[3]; return m; }
-__device__ __forceinline__ bool m256_any(const M256 &a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) != 0ull; }
-__device__ __forceinline__ int m256_count(const M256 &a) { return __popcll(a.w[0]) + __popcll(a.w[1]) + __popcll(a.w[2]) + __popcll(a.w[3]); }
-__device__ __forceinline__ void m256_set(M256 &m, int i)
-{
-#pragma unroll
-    for (int g = 0; g < 4; g++) m.w[g] |= (g == (i >> 6)) ? (1ull << (i & 63)) : 0ull;
-}
-__device__ __forceinline__ bool m256_test(const M256 &m, int i)
-{
-    uint64_t x = 0ull;
-#pragma unroll
-    for (int g = 0; g < 4; g++) x = (g == (i >> 6)) ? m.w[g] : x;
-    return ((x >> (i & 63)) & 1ull) != 0ull;
-}
-/* bits lo..hi (inclusive; empty when hi < lo) */
-__device__ inline M256 m256_range(int lo, int hi)
-{
-    M256 m = m256_zero();
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int a = lo - 64 * g, b = hi - 64 * g;         /* the range in this word's own bit numbers */
-        if (b < 0 || a > 63 || hi < lo) continue;
-        const uint64_t up = b >= 63 ? ~0ull : ((2ull << b) - 1ull), dn = a <= 0 ? ~0ull : (~0ull << a);
-        m.w[g] = up & dn;
-    }
-    return m;
-}
-/* the highest set bit at or below p (p < 0: none), -1 when there is none */
-__device__ inline int m256_top_le(const M256 &m, int p)
-{
-    int r = -1;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int hi = p - 64 * g;
-        if (hi < 0) continue;
-        uint64_t x = m.w[g];
-        if (hi < 63) x &= (2ull << hi) - 1ull;
-        if (x) r = 64 * g + 63 - __clzll(x);
-    }
-    return r;
-}
-
 /* Second half of pickLevelByCRCStats (binarizer.cpp:2060-2140): E = the levels that carry the target result at the lowest (depth, stage),
  * none below low_lvl; high_ref = the highest of them.  The reference walks down from there: the run that starts at high_ref is the span to
  * beat, every further run that a non-member CLOSES inside [low_lvl, ..] replaces it when it is at least as long (so of equally long runs
@@ -1063,8 +1093,6 @@ __device__ inline void calc_forced_coords(const Bin &b, const sdv_bin_preset &ps
     }
 }
 __device__ inline void bin_set_mode(Bin &b, uint8_t m);
-__device__ inline uint32_t wave_min_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o < v ? o : v; } return v; }
-__device__ inline uint32_t wave_max_u32(uint32_t v) { for (int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl((int)v, lane_id() ^ d); v = o > v ? o : v; } return v; }
 __device__ inline bool pod_coords_valid(int16_t s, int16_t e) { return s != NO_COORD_LEFT && e != NO_COORD_RIGHT && s < e; }
 } // namespace sdv
 #include "stc007_sweep_device.h"
@@ -1083,7 +1111,9 @@ __device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps,
     SweepOutcome o;
     if (!sweep_lookup(hook, l.black, l.white, b.in_coord, o)) {
         sweep_request(hook, l.black, l.white, b.in_coord);
+#ifndef SDV_DBG_NO_STOP
         if (b.in_ref < ps.min_ref_lvl) hook.stop = true;
+#endif
         o.span1 = o.span2 = SPAN_NOT_FOUND; o.ref_level = 0; o.t_hyst = o.t_shift = 0; o.t_start = o.t_stop = 0;
     }
     if (o.span1 == SPAN_OK) {
@@ -1194,7 +1224,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
                     out.coords = b.in_coord;
                     if (!has_markers(out)) force_level_find = true;
                 }
-                { K1_T(t0_); read_pcm_data(b, out, lds); K1_T(t1_); K1_ADD(11, t0_, t1_); }
+                { K1_T(t0_); read_pcm_data(b, out, lds, hook.ladder_failed && !force_level_find); K1_T(t1_); K1_ADD(11, t0_, t1_); }
                 if (crc_valid(out)) {
                     if (!force_level_find) { out.by_ext_tune = true; state = STG_DATA_OK; }
                     else state = STG_REF_FIND;
@@ -1614,6 +1644,9 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
     if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
+#ifdef SDV_EMU_DEBUG2
+    if (f < 6) printf("DBG store f %d flag %02x unsettled %d in_ref %d\n", f, fl, (int)unsettled, (int)a.states_in[f].bin.in_def_reference);
+#endif
     a.flag[f] = fl;
 #ifndef SDV_EXP_NOREFS       /* (experiment: what the scheduler's bookkeeping costs the kernel) */
     if (a.refs) {
@@ -1709,7 +1742,7 @@ __device__ inline bool fast_eligible(const FrameArgs &a, const Bin &b)
 
 /* readPCMdata under the preset tuning for the scanline staged in LDS: the (hysteresis, shift) ladder of
  * binarizer.cpp:7769-7954 with the wave-parallel fill.  Returns false when no pair gives a valid CRC. */
-__device__ inline bool fast_decode(const FrameArgs &a, const WaveLds &lds, const Bin &b, Geo &g, const LaneConst &lc, FastBits &o)
+__device__ inline bool fast_decode(const FrameArgs &a, const WaveLds &lds, const Bin &b, uint8_t black, uint8_t white, Geo &g, const LaneConst &lc, FastBits &o)
 {
     const int lane = lane_id();
     const int32_t pixel_start = 0, pixel_stop = a.width - 1;
@@ -1726,7 +1759,7 @@ __device__ inline bool fast_decode(const FrameArgs &a, const WaveLds &lds, const
     bool found = false;
     for (int h = 0; h <= (int)hyst_lim && !found; h++) {
         ref_low = get_low_level(b.in_ref, (uint8_t)h); ref_high = get_high_level(b.in_ref, (uint8_t)h);
-        if (ref_low <= b.in_black || ref_high >= b.in_white) break;       /* fillDataWords level clipping */
+        if (ref_low <= black || ref_high >= white) break;       /* fillDataWords level clipping */
         for (int st = 0; st <= (int)shift_lim; st++) {
             int sh = (st == 0) ? 0 : ((st & 1) ? ((st + 1) >> 1) : -(st >> 1));
             int32_t x0 = g.vp0 + sh, x1 = g.vp1 + sh;
@@ -1846,15 +1879,34 @@ __device__ inline void bits_to_words(uint64_t s_lo, uint64_t s_hi, uint16_t *w)
     w[7] = rev14((uint32_t)((s_hi >> 34) & 0x3FFF));
 }
 
-/* one line through the fast path (decode already staged in LDS); false = not handled, nothing changed */
+/* one line through the fast path (decode already staged in LDS); false = not handled, nothing changed.
+ * kMeasure (full kernel only): the line behind one that did not read.  The worker took the black and white presets back then
+ * (videotodigital.cpp:1468-1521), so Binarizer::processLine measures the two levels from the line's own pixels (findBlackWhite) before it reads with
+ * the reference level and the coordinates that are still preset (STG_INPUT_ALL, binarizer.cpp:774-931) - the fast path with one step in front.
+ * ladder_failed: no (depth, stage) of the ladder read the line with the inherited tuning - the general path need not try them again. */
+template <bool kMeasure>
 __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &g, const LaneConst &lc,
-                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec)
+                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec, bool *ladder_failed)
 {
     const sdv_bin_preset &ps = a.preset;
     Bin &b = v.bin;
-    if (!fast_eligible(a, b)) return false;
+    uint8_t black = b.in_black, white = b.in_white, found_mark_ed = MARK_ED_START; uint16_t found_sp_ed = 0;
+    *ladder_failed = false;
+    if (!kMeasure) { if (!fast_eligible(a, b)) return false; }
+    else {
+        if (ps.en_force_coords || !ps.en_good_no_marker || are_bw_levels_preset(b, ps) || !is_ref_level_preset(b, ps) || !coords_valid(b.in_coord)) return false;
+        if (a.width < BITS_IN_LINE || (a.width - 1) < BITS_BETWEEN) return false;
+        Bin tb = b; Line t;
+        stc_clear(t);
+        bin_line_geometry(tb, ps, a.width, a.doubled != 0);
+        tb.was_bw_scanned = false;
+        if (!find_black_white(tb, ps, lds, t)) return false;
+        black = t.black; white = t.white; found_mark_ed = t.mark_ed; found_sp_ed = t.m_sp_ed;      /* (findSTC007BW leaves what it saw of the STOP marker in the line) */
+        if (b.in_ref >= white || b.in_ref <= black) return false;
+    }
     FastBits fb;
-    if (!fast_decode(a, lds, b, g, lc, fb) || fb.ctrl_block) return false;
+    if (!fast_decode(a, lds, b, black, white, g, lc, fb)) { *ladder_failed = !kMeasure; return false; }
+    if (fb.ctrl_block) return false;
     const int lane = lane_id();
     uint16_t w[9];
     bits_to_words(fb.s_lo, fb.s_hi, w);
@@ -1870,6 +1922,7 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
     if (a.check_line_copy) {
         if (v.field_state == FIELD_UNSAFE) {
             b.in_coord.doubled = doubled;                   /* setGoodParameters(): same levels, same pair */
+            if (kMeasure) bin_set_bw_levels(b, ps, black, white);
             if (ps.en_first_line_dup) forced_bad = true;
         } else {
             uint8_t diff = words_diff_bit_count(w, v.last_words);
@@ -1899,7 +1952,7 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
             }
         }
     }
-    if (!forced_bad) b.in_coord.doubled = doubled;           /* setGoodParameters(work_line) */
+    if (!forced_bad) { b.in_coord.doubled = doubled; if (kMeasure) bin_set_bw_levels(b, ps, black, white); }           /* setGoodParameters(work_line) */
     else { if (!even_line) v.q_bad_odd++; else v.q_bad_even++; }
     v.field_state = FIELD_INIT;
     if (!even_line) { v.q_odd++; v.q_pcm_odd++; } else { v.q_even++; v.q_pcm_even++; }
@@ -1914,10 +1967,10 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         for (int i = 0; i < 9; i++) r.words[i] = w[i];
         r.calc_crc = fb.calc_crc;
         r.data_start = b.in_coord.start; r.data_stop = b.in_coord.stop;
-        r.marker_start_bg_coord = 0; r.marker_start_ed_coord = 0; r.marker_stop_ed_coord = 0;
-        r.black_level = b.in_black; r.white_level = b.in_white; r.ref_low = fb.ref_low; r.ref_level = b.in_ref; r.ref_high = fb.ref_high;
+        r.marker_start_bg_coord = 0; r.marker_start_ed_coord = 0; r.marker_stop_ed_coord = found_sp_ed;
+        r.black_level = black; r.white_level = white; r.ref_low = fb.ref_low; r.ref_level = b.in_ref; r.ref_high = fb.ref_high;
         r.hysteresis_depth = fb.h; r.shift_stage = fb.s; r.service_type = SDV_SRV_NO;
-        r.mark_st_stage = MARK_ST_START; r.mark_ed_stage = MARK_ED_START;
+        r.mark_st_stage = MARK_ST_START; r.mark_ed_stage = found_mark_ed;
         r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | (forced_bad ? SDV_LF_FORCED_BAD : SDV_LF_CRC_VALID) | (doubled ? SDV_LF_FROM_DOUBLED : 0));
         r.word_state = forced_bad ? 0 : (uint8_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
         *rec = r;
@@ -2219,6 +2272,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     int start_field = 0, start_idx = 0;
     bool all_captured = false; uint32_t captured_key = 0;
     bool sweep_pending = false;             /* a line of this frame went on without the sweep it asked for: the frame is decoded again */
+#ifdef SDV_K1_STAMPS
+    int n_slow_lines = 0;
+#endif
 #if SDV_CAPTURE
     /* whole-frame capture (see capture_solve): only in the lean build, on the geometry the batch loop takes */
     if (kLean && pf.vec && a.width <= 1024 && (a.width & 15) == 0 && n_field[1] > 0 && (uint64_t)a.row_stride * (uint64_t)a.height < (1ull << 31) &&
@@ -2329,10 +2385,15 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
         }
     }
 #endif
-    for (int field = start_field; field < 2; field++) {
+    /* ... by a line nothing was tuned for: what is behind it hangs on what the sweep finds, the pass ends here (SweepHook::stop).  (Through the loop
+     * conditions, not with a return from inside the loop: with the return, hipcc 7.2 built a full kernel that lost one `rec++` - every record of the
+     * frame one slot early on the GPU, at -O1 to -O3 alike, while the same source was right under the emulator.) */
+    bool stop_frame = false;
+    int last_miss_field = -1, last_miss_idx = 0;
+    for (int field = start_field; field < 2 && !stop_frame; field++) {
         const int nl = n_field[field];
         int idx = field == start_field ? start_idx : 0;
-        while (idx < nl) {
+        while (idx < nl && !stop_frame) {
             bool staged = false;
             /* the batch loop is the 16-byte-vector, single-vector-per-lane case (rows aligned, width a multiple of 16 up to 1024:
              * SD video); everything else takes the sequential path below */
@@ -2453,6 +2514,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 K1_T(t_loop);
                 K1_ADD(1, t_batch, t_loop);
                 if (j > 0) {
+#ifdef SDV_DBG_PRINT
+                    if (lane == 0 && f == 0 && field == 0 && idx < 20) printf("DBG f0 batch idx %d n %d rec %ld\n", idx, j, (long)(rec - a.recs));
+#endif
                     batch_finish(a, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
                     K1_T(t_fin);
                     K1_ADD(2, t_loop, t_fin);
@@ -2471,7 +2535,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             }
             line_num = (uint16_t)(field + 1 + 2 * idx);
             K1_T(t_fl0);
-            const bool took_fast = fast_line(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec);
+            bool ladder_failed = false;
+            bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed);
+#ifndef SDV_DBG_NO_MEASURE
+            if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2); }
+#endif
             K1_T(t_fl1);
             if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
             if (!took_fast) {
@@ -2482,23 +2550,37 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     SlowCtx c;
                     c.a = a; c.v = v;
                     c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
-                    c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.pending = false; c.hook.stop = false;
+                    c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
                     slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
+#ifdef SDV_K1_STAMPS
+                    n_slow_lines++;
+#endif
                     v = c.v;
                     v2d_make_uniform(v);
-                    sweep_pending = sweep_pending || uni(c.hook.pending) != 0;
-                    if (uni(c.hook.stop) != 0) {        /* (what was decoded of the frame is not final anyway) */
-                        if (lane == 0) a.flag[f] = VF_ABORTED;
-                        return;
-                    }
+                    const bool missed = uni(c.hook.pending) != 0;
+                    sweep_pending = sweep_pending || missed;
+                    stop_frame = uni(c.hook.stop) != 0;
+                    /* Two sweeps owed within a few lines of a field: the first of them may be one that finds a level the line reads with, and with it
+                     * the tuning every line behind it needs - going on "as if it had found nothing" can leave all of those unreadable, each of them
+                     * asking for a sweep of its own (seen: 342 lines of one frame, 46 ms, on a tape whose level drifts within the frame).  The pass
+                     * over the frame ends here; it comes again when the two are settled. */
+                    if (missed) { if (last_miss_field == field && idx - last_miss_idx < 8) stop_frame = true; last_miss_field = field; last_miss_idx = idx; }
                 }
             }
+#ifdef SDV_DBG_PRINT
+            if (lane == 0 && f == 0 && field == 0 && idx < 3) printf("DBG f0 idx %d line %d rec %ld took_fast %d pending %d\n", idx, (int)line_num, (long)(rec - a.recs), (int)took_fast, (int)sweep_pending);
+#endif
             rec++; idx++;
         }
+        if (stop_frame) break;
         /* spliceFrame: END_FIELD carries the number the next line of the field would have had */
         line_num = (uint16_t)(field + 1 + 2 * nl);
         v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
         emit_record(wl, rec++);
+    }
+    if (stop_frame) {                       /* (what was decoded of the frame is not final anyway) */
+        if (lane == 0) a.flag[f] = VF_ABORTED;
+        return;
     }
     line_num = (uint16_t)(line_num + 2);
     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
@@ -2509,6 +2591,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     K1_T(t_end);
     K1_ADD(3, t_ef0, t_end);
     K1_ADD(0, t_begin, t_end);
+#ifdef SDV_K1_STAMPS
+    if (lane_id() == 0) atomicMax(&sdv_k1_cycles[7], ((unsigned long long)(t_end - t_begin) << 24) | ((unsigned long long)(n_slow_lines & 0x3FF) << 14) | (unsigned long long)(f & 0x3FFF));
+#endif
 }
 
 } // namespace sdv
@@ -2519,6 +2604,10 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
+#ifdef SDV_EMU_POISON_LDS       /* (test aid: the LDS of a real workgroup starts with whatever the last one left there) */
+    if (sdv::lane_id() == 0) memset(&lds, 0xA7, sizeof(lds));
+    __syncthreads();
+#endif
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f);
 }

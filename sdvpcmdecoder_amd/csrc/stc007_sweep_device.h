@@ -29,7 +29,7 @@ namespace sdv {
 
 /* ---- requests and outcomes ------------------------------------------------------------------- */
 enum { SWEEP_REQUESTED = 0, SWEEP_SETTLED = 1 };
-struct SweepMemo {                  /* 32 bytes */
+struct SweepMemo {                  /* 32 bytes, at 32-byte strides in a pool that starts 16-byte aligned */
     int32_t frame, next;            /* frame index of the call; the next entry of the same frame, -1 at the end */
     uint16_t row;                   /* row of the frame */
     uint8_t black, white;           /* the key: what the sweep of that line depends on besides its pixels and the settings ... */
@@ -47,23 +47,37 @@ struct SweepHook {
     SweepMemo *memo; int32_t *head; int32_t *count; int32_t cap;
     int32_t frame; uint16_t row;
     bool pending;                   /* out: a sweep of this frame was asked for, the line went on without it */
+    bool ladder_failed;             /* in: the frame loop tried the ladder of reads with the tuning the line inherits (fast_line), nothing read */
     bool stop;                      /* out: ... by a line that had no reference level preset: everything behind it hangs on what the sweep finds, the pass over the frame ends here */
 };
 
+/* an entry as eight words (two 16-byte loads), the same in every lane */
+struct SweepMemoWords { uint32_t w[8]; };
+static_assert(sizeof(SweepMemo) == 32, "SweepMemo is two 16-byte loads");
+__device__ inline SweepMemoWords sweep_memo_load(const SweepMemo *m)
+{
+    SweepMemoWords r;
+    const uint4 a = ((const uint4 *)m)[0], b = ((const uint4 *)m)[1];
+    r.w[0] = uniu(a.x); r.w[1] = uniu(a.y); r.w[2] = uniu(a.z); r.w[3] = uniu(a.w); r.w[4] = uniu(b.x); r.w[5] = uniu(b.y); r.w[6] = uniu(b.z); r.w[7] = uniu(b.w);
+    return r;
+}
+/* words 2, 3 of an entry: row | black << 16 | white << 24, in_start | in_stop << 16 */
+__device__ __forceinline__ uint32_t sweep_key_lo(uint16_t row, uint8_t black, uint8_t white) { return (uint32_t)row | ((uint32_t)black << 16) | ((uint32_t)white << 24); }
+__device__ __forceinline__ uint32_t sweep_key_hi(const Coords &c) { return (uint32_t)(uint16_t)c.start | ((uint32_t)(uint16_t)c.stop << 16); }
 /* wave-uniform; all lanes return the same */
 __device__ inline bool sweep_lookup(const SweepHook &h, uint8_t black, uint8_t white, const Coords &in_coord, SweepOutcome &o)
 {
+    const uint32_t k0 = sweep_key_lo(h.row, black, white), k1 = sweep_key_hi(in_coord);
     int idx = uni(h.head[h.frame]);
     for (int guard = 0; idx >= 0 && idx < h.cap && guard < (1 << 20); guard++) {
-        const SweepMemo &m = h.memo[idx];
-        const int row = uni(m.row), bk = uni(m.black), wh = uni(m.white), s0 = uni(m.in_start), s1 = uni(m.in_stop), st = uni(m.state);
-        if (row == (int)h.row && bk == (int)black && wh == (int)white && s0 == (int)in_coord.start && s1 == (int)in_coord.stop) {
-            if (st != SWEEP_SETTLED) return false;
-            o.span1 = (uint8_t)uni(m.span1); o.span2 = (uint8_t)uni(m.span2); o.ref_level = (uint8_t)uni(m.ref_level);
-            o.t_hyst = (uint8_t)uni(m.t_hyst); o.t_shift = (uint8_t)uni(m.t_shift); o.t_start = (int16_t)uni(m.t_start); o.t_stop = (int16_t)uni(m.t_stop);
+        const SweepMemoWords m = sweep_memo_load(&h.memo[idx]);
+        if (m.w[2] == k0 && m.w[3] == k1) {
+            if ((m.w[4] & 0xFFu) != SWEEP_SETTLED) return false;
+            o.span1 = (uint8_t)(m.w[4] >> 8); o.span2 = (uint8_t)(m.w[4] >> 16); o.ref_level = (uint8_t)(m.w[4] >> 24);
+            o.t_hyst = (uint8_t)m.w[5]; o.t_shift = (uint8_t)(m.w[5] >> 8); o.t_start = (int16_t)(m.w[5] >> 16); o.t_stop = (int16_t)(m.w[6] & 0xFFFFu);
             return true;
         }
-        idx = uni(m.next);
+        idx = (int)m.w[1];
     }
     return false;
 }
@@ -72,11 +86,12 @@ __device__ inline bool sweep_lookup(const SweepHook &h, uint8_t black, uint8_t w
 __device__ inline void sweep_request(SweepHook &h, uint8_t black, uint8_t white, const Coords &in_coord)
 {
     h.pending = true;
+    const uint32_t k0 = sweep_key_lo(h.row, black, white), k1 = sweep_key_hi(in_coord);
     int idx = uni(h.head[h.frame]);
     for (int guard = 0; idx >= 0 && idx < h.cap && guard < (1 << 20); guard++) {
-        const SweepMemo &m = h.memo[idx];
-        if (uni(m.row) == (int)h.row && uni(m.black) == (int)black && uni(m.white) == (int)white && uni(m.in_start) == (int)in_coord.start && uni(m.in_stop) == (int)in_coord.stop) return;
-        idx = uni(m.next);
+        const SweepMemoWords m = sweep_memo_load(&h.memo[idx]);
+        if (m.w[2] == k0 && m.w[3] == k1) return;
+        idx = (int)m.w[1];
     }
     if (lane_id() == 0) {
         const int slot = atomicAdd(h.count, 1);
@@ -108,7 +123,10 @@ struct SweepLds {
     uint64_t g_start[88][3];        /* [T - t_lo]: pixel p of the START window >= T, bit p */
     uint64_t g_stop[88][3];         /* ... pixel scan_end - i of the STOP window >= T, bit i */
 };
-enum { SWEEP_WINDOW_MAX = 192 };
+#ifndef SDV_DBG_SWEEP_WINDOW
+#define SDV_DBG_SWEEP_WINDOW 192
+#endif
+enum { SWEEP_WINDOW_MAX = 192, SWEEP_WINDOW_USE = SDV_DBG_SWEEP_WINDOW };
 
 /* the line geometry Binarizer::processLine derives from the line length (binarizer.cpp:600-641) */
 __device__ inline void bin_line_geometry(Bin &b, const sdv_bin_preset &ps, int width, bool doubled)
@@ -315,7 +333,7 @@ __device__ inline void sweep_levels_body(const SweepArgs &a, SweepLds &lds, int 
         int n_start = b.mark_start_max + ppb * 5; n_start &= 0xFFFF; if (n_start > b.line_length) n_start = b.line_length;
         const int end_limit = b.mark_end_min > ppb * 6 ? b.mark_end_min - ppb * 6 : 0;
         const int n_stop = scan_end - end_limit, i_max = scan_end - (int)b.mark_end_min;
-        if (n_start <= SWEEP_WINDOW_MAX && n_stop <= SWEEP_WINDOW_MAX) {
+        if (n_start <= SWEEP_WINDOW_USE && n_stop <= SWEEP_WINDOW_USE) {
             /* thresholds the 64 levels can ask for: the level itself and down to 23 below it (never below 1) */
             int t_lo = base - 63 - 23; if (t_lo < 1) t_lo = 1;
             const int n_t = base - t_lo + 1;                /* <= 87 */

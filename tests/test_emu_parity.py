@@ -246,3 +246,18 @@ def test_emu_unreadable_cells_sweep_every_level(emu_lib, oracle_lib):
     assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
     assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
     assert int((((got["flags"] & 64) == 0) & (got["service_type"] == 0)).sum()) > 6      # data lines without SDV_LF_CRC_VALID: each of them was swept
+
+
+def test_emu_crowd_waits_for_the_sweeps_of_its_first_frame(emu_lib, oracle_lib):
+    """Every frame of a full-size tape has lines no level reads: the lean kernel gives all of them up at once (a crowd), the first one goes to the
+    full kernel alone - and comes back as given up once more, because the reference-level sweeps it needs are only asked for by that pass
+    (stc007_sweep_device.h).  The crowd behind it has to go on waiting until those are settled: taking the unsettled pass for the frame's outcome
+    left its lines with the levels of a sweep that "found nothing"."""
+    from test_gpu_parity import _unreadable_cells
+    luma, _, _ = synth.stc007_frames(40, seed=77, noise_sigma=4.0)
+    luma = np.ascontiguousarray(_unreadable_cells(luma)[:12])
+    want, want_stats = oracle_binarize(luma, mode=2)
+    got, got_stats, info = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    assert info.sweeps > 50

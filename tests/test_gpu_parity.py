@@ -87,7 +87,6 @@ def test_hip_sparse_dropouts_settle_in_few_rounds(torch_cuda):
     assert got_stats.tobytes() == want_stats.tobytes()
     assert info.rounds <= 12, info.rounds                     # cold first frame (twice: its sweep) + first pass + the given-up frames (twice: their sweeps) + a handful
     assert 24 <= info.frames_general <= 6 * 24 + 2, info.frames_general
-    assert info.sweeps >= 24
 
 
 def test_hip_stream_continuation_and_rounds(torch_cuda):

@@ -32,8 +32,18 @@ i = eng.run_info()
 print(f"{what}: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel, {i.sweeps} sweeps")
 v = list(out)
 fr = max(1, i.frames_general)
-names = {0: "frame total", 1: "batch loops", 2: "batch_finish", 3: "end of frame", 8: "slow_line total", 9: "find_black_white", 10: "find_coordinates (INPUT_LEVEL)",
+names = {0: "frame total (sum)", 1: "batch loops", 2: "batch_finish", 3: "end of frame", 8: "slow_line total", 9: "find_black_white", 10: "find_coordinates (INPUT_LEVEL)",
          11: "read_pcm_data (INPUT_ALL)", 12: "sweep lookup + apply", 13: "post_line + record", 14: "fast_line attempts that failed"}
-print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame)")
+print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame); the slowest frame: index {v[7] & 0x3FFF}, {v[7] >> 24} cycles with {(v[7] >> 14) & 0x3FF} slow lines")
+import numpy as np
+from sdvpcmdecoder_amd import LINE_DTYPE
+fs = int(v[7] & 0x3FFF)
+lines, _ = eng.binarize_frames(lum, first_frame_no=1 + 3 * n)
+r = lines.cpu().numpy().view(LINE_DTYPE).reshape(-1)[fs * 579:(fs + 1) * 579]
+r = r[r["service_type"] == 0]
+import collections
+print("straggler frame records: flags histogram", collections.Counter(r["flags"].tolist()).most_common(8))
+print("ref levels", collections.Counter(r["ref_level"].tolist()).most_common(8))
+print("first 40 (line, flags, ref, black, white, start, stop):", [(int(x["line_number"]), int(x["flags"]), int(x["ref_level"]), int(x["black_level"]), int(x["white_level"]), int(x["data_start"]), int(x["data_stop"])) for x in r[:40]])
 for k, nm in names.items():
     print(f"  {nm:34s} {v[k] / fr:12.0f} cycles per full-kernel frame" + (f"  {v[k] / max(1, v[15]):10.0f} per slow line" if k >= 8 else ""))
