@@ -108,7 +108,7 @@ def cpu_worker(sample_path, mode, ready_path, go_path):
     oracle port) over the frames in `sample_path`, started when `go_path` appears.  Prints one JSON line."""
     import numpy as np
     import libs
-    luma = np.load(sample_path, mmap_mode="r")
+    luma = np.load(sample_path, mmap_mode="r")          # one copy of the pixels in the page cache for all workers (read only)
     kind = "port"
     run = None
     try:
@@ -125,8 +125,7 @@ def cpu_worker(sample_path, mode, ready_path, go_path):
     if run is None:
         from oracle_run import oracle_binarize
         libs.load_oracle()
-        run = lambda: oracle_binarize(np.ascontiguousarray(luma), mode=mode)      # noqa: E731
-    luma = np.ascontiguousarray(luma)                   # every worker its own copy of the pixels, as every core would have its own frames
+        run = lambda: oracle_binarize(luma, mode=mode)      # noqa: E731
     open(ready_path, "w").close()
     while not os.path.exists(go_path):
         time.sleep(0.002)
@@ -139,13 +138,35 @@ def cpu_worker(sample_path, mode, ready_path, go_path):
     print(json.dumps({"kind": kind, "frames": int(luma.shape[0]), "t0": t0, "t1": t1, "sha": hashlib.sha256(recs.tobytes()).hexdigest()}), flush=True)
 
 
-def cpu_baseline_all_cores(luma_sample, mode):
-    """the CPU path on every core of this host - os.cpu_count() fresh child processes, one reference worker each
-    (the reference itself runs the path on a single thread per stage; this is what a host-side shard over all cores would reach)."""
+def physical_cores():
+    """Cores of this host, not hardware threads: distinct (physical id, core id) pairs of /proc/cpuinfo (os.cpu_count() when that cannot be read)."""
+    try:
+        seen = set(); phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline_all_cores(luma_sample, mode, single_core_frames_per_s=None):
+    """the CPU path on every core of this host - one fresh child process per PHYSICAL core, one reference worker each (a worker is two
+    threads: the reference's own VideoToDigital worker and the feeder that plays the input plugin; a process per hardware thread oversubscribed
+    the host two to one and measured the scheduler).  The reference itself runs the path on a single thread per stage; this is what a host-side
+    shard over all cores would reach."""
     import subprocess
     import tempfile
     import numpy as np
-    cores = os.cpu_count() or 1
+    cores = physical_cores()
     d = tempfile.mkdtemp(prefix="sdv_cpu_")
     try:
         sample = os.path.join(d, "sample.npy")
@@ -169,11 +190,13 @@ def cpu_baseline_all_cores(luma_sample, mode):
             return {"error": "no worker finished", "cores": cores}
         wall = max(r["t1"] for r in res) - min(r["t0"] for r in res)
         frames = sum(r["frames"] for r in res)
-        return {"value": frames / wall, "unit": "frames/s", "cores": cores, "workers_finished": len(res), "kind": res[0]["kind"],
-                "per_worker_frames_per_s": frames / len(res) / (sum(r["t1"] - r["t0"] for r in res) / len(res)),
+        per_worker = frames / len(res) / (sum(r["t1"] - r["t0"] for r in res) / len(res))
+        return {"value": frames / wall, "unit": "frames/s", "cores": cores, "hardware_threads": os.cpu_count(), "workers_finished": len(res), "kind": res[0]["kind"],
+                "per_worker_frames_per_s": per_worker,
+                "per_worker_slowdown_vs_one_core_alone": (single_core_frames_per_s / per_worker) if single_core_frames_per_s else None,
                 "all_workers_decoded_the_same_records": len(set(r["sha"] for r in res)) == 1,
-                "sample": f"{len(res)} worker processes (os.cpu_count() = {cores}), each the first {res[0]['frames']} frames of the same synthetic batch, "
-                          f"{wall:.1f} s of wall time from the first start to the last finish"}
+                "sample": f"{len(res)} worker processes (one per physical core: {cores}; {os.cpu_count()} hardware threads), each the first {res[0]['frames']} frames of the "
+                          f"same synthetic batch, {wall:.1f} s of wall time from the first start to the last finish"}
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
@@ -191,7 +214,7 @@ def main():
     ap.add_argument("--mode", type=int, default=2, help="Binarizer mode (2 = NORMAL, the reference default)")
     ap.add_argument("--noise", type=float, default=4.0)
     ap.add_argument("--cpu-frames", type=int, default=3000)
-    ap.add_argument("--cpu-frames-all-cores", type=int, default=150, help="frames per worker of the all-core CPU baseline")
+    ap.add_argument("--cpu-frames-all-cores", type=int, default=1500, help="frames per worker of the all-core CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stitch", action="store_true", help="skip the extra stitch-stage measurement")
     args = ap.parse_args()
@@ -415,6 +438,7 @@ def main():
         os_p = torch.empty((npal, 32), dtype=torch.uint8, device=dev)
         sp_p = torch.empty((npal * 1764 + 65536, 12), dtype=torch.uint8, device=dev)
         sf_p = torch.empty((npal + 64, 64), dtype=torch.uint8, device=dev)
+        pal_keep = {}
         for tape_name in ("clean", "lost_lines_and_flipped_cells"):
             if tape_name != "clean":
                 # every frame damaged, ~11 lines per frame that read at no reference level: in NORMAL mode each of them costs the reference's full level
@@ -432,13 +456,16 @@ def main():
             eng.setBinarizationMode(args.mode)
             eng.reset_stream(); eng.reset_stitcher()
             eng.binarize_frames(luma_p, first_frame_no=1, new_file=True, out_lines=ol_p, out_stats=os_p, stream=stream)
-            eng.stitch_frames(ol_p[:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
+            pp0_, _ff0 = eng.stitch_frames(ol_p[:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
+            # the start of the tape for the CPU leg below: pixels, and what the GPU made of them (records and sample pairs)
+            k_cpu = min(npal, 300 if tape_name == "clean" else 40)
+            pal_keep[tape_name] = (luma_p[:k_cpu].cpu().numpy(), ol_p[:1 + k_cpu * (HP + 3)].cpu().numpy().copy(), pp0_[:k_cpu * 1764].cpu().numpy().copy())
             fno = 1 + npal
             eng.binarize_frames(luma_p, first_frame_no=fno, out_lines=ol_p[1:], out_stats=os_p, stream=stream)
             eng.stitch_frames(ol_p[1:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
             fno += npal
-            k_steps = max(1, min(args.steps, 3)) if tape_name == "clean" else 1
-            b_ms = s_ms = 0.0; b_rounds = s_rounds = b_general = 0
+            k_steps = max(1, min(args.steps, 3))
+            b_ms = s_ms = 0.0; b_rounds = s_rounds = b_general = 0; b_sweeps = 0
             for _ in range(k_steps):
                 torch.cuda.synchronize(dev); t1 = time.perf_counter()
                 eng.binarize_frames(luma_p, first_frame_no=fno, out_lines=ol_p[1:], out_stats=os_p, stream=stream)
@@ -446,12 +473,13 @@ def main():
                 pp_, ff_ = eng.stitch_frames(ol_p[1:1 + nrec_p], out_pairs=sp_p, out_frames=sf_p, stream=stream)
                 torch.cuda.synchronize(dev); t3 = time.perf_counter()
                 b_ms += (t2 - t1) * 1e3; s_ms += (t3 - t2) * 1e3
-                b_rounds += eng.run_info().rounds; b_general += eng.run_info().frames_general; s_rounds += eng.stitch_info().rounds
+                b_rounds += eng.run_info().rounds; b_general += eng.run_info().frames_general; b_sweeps += eng.run_info().sweeps; s_rounds += eng.stitch_info().rounds
                 fno += npal
             tot = (b_ms + s_ms) / k_steps
             pr = pp_[:, :].cpu().numpy().reshape(-1).view(np.dtype([("w", "<i2", (2,)), ("fl", "u1", (2,)), ("rate", "<u2"), ("e", "u1"), ("srv", "u1"), ("_p", "<u2")]))
             pal[tape_name] = {"frames_per_step": npal, "binarize_ms_per_step": b_ms / k_steps, "stitch_ms_per_step": s_ms / k_steps, "ms_per_step": tot,
                               "frames_per_s": npal / tot * 1e3, "binarize_rounds_per_step": b_rounds / k_steps, "frames_by_full_kernel_per_step": b_general / k_steps,
+                              "reference_level_sweeps_per_step": b_sweeps / k_steps, "timed_steps": k_steps,
                               "stitch_rounds_per_step": s_rounds / k_steps, "sample_pairs_per_step": int(pp_.shape[0]), "sample_rate": int(pr["rate"][len(pr) // 2]),
                               "samples_valid_share": float(((pr["fl"] & 2) != 0).mean()),
                               "roofline": {"bound": "hbm", "achieved": npal * PAL_BYTES / tot / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -485,12 +513,15 @@ def main():
             eng.binarize_frames(luma, first_frame_no=1, new_file=True, out_lines=out_lines, out_stats=out_stats, stream=stream)
             k_steps = max(1, min(args.steps, 3))
             d_ms = 0.0; d_kms = 0.0; d_rounds = d_launched = d_general = 0
-            for r_ in range(k_steps):
+            for r_ in range(-1, k_steps):               # (-1: once untimed - the first damaged batch of a process pays first uses: the full kernel's code, pinned buffers)
                 # (the jumps leave the window displaced at the end of the batch: every step starts from the clean tape's state again)
-                eng.binarize_frames(luma, first_frame_no=1 + (2 * r_ + 1) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+                eng.binarize_frames(luma, first_frame_no=1 + (2 * r_ + 3) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
                 torch.cuda.synchronize(dev); t1 = time.perf_counter()
-                eng.binarize_frames(lum, first_frame_no=1 + (2 * r_ + 2) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
-                torch.cuda.synchronize(dev); d_ms += (time.perf_counter() - t1) * 1e3
+                eng.binarize_frames(lum, first_frame_no=1 + (2 * r_ + 4) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+                torch.cuda.synchronize(dev)
+                if r_ < 0:
+                    continue
+                d_ms += (time.perf_counter() - t1) * 1e3
                 i_ = eng.run_info()
                 d_kms += i_.kernel_ms; d_rounds += i_.rounds; d_launched += i_.frames_launched; d_general += i_.frames_general
             damaged[kind] = {"events_per_step": per, "frames_per_step": n, "ms_per_step": d_ms / k_steps, "frames_per_s": n / (d_ms / k_steps) * 1e3,
@@ -769,6 +800,39 @@ def main():
                     audio[name]["cpu_baseline"] = {"value": nf / max(dtc - idle, 1e-6), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
                                                    "sample": f"the first {nf:.0f} frames of the tape, {dtc - idle:.2f} s of CPU work",
                                                    "bit_exact_vs_gpu_on_overlap": bool(cr[0][:len(first)].view(np.uint8).tobytes() == first.tobytes())}
+        if pal is not None and not args.no_cpu:
+            # configs[2] on the CPU: the real reference's VideoToDigital worker and STC007DataStitcher (or the oracle ports) over the start of each PAL tape
+            import libs as _libs
+            import stitch_api as _sa
+            use_ref = _libs.ref_available()
+            for tape_name, (lum_c, recs_g, pairs_g) in pal_keep.items():
+                try:
+                    fd = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)       # the workers log to stderr
+                    try:
+                        t0 = time.perf_counter()
+                        if use_ref:
+                            import importlib.util
+                            spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+                            mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+                            crecs, _cst = mg.run_ref(np.ascontiguousarray(lum_c), args.mode)
+                        else:
+                            from oracle_run import oracle_binarize
+                            crecs, _cst = oracle_binarize(np.ascontiguousarray(lum_c), mode=args.mode)
+                        t1 = time.perf_counter()
+                        cpairs, _cf = _sa.run_cpu(_libs.load_ref() if use_ref else _libs.load_oracle(), "ref_" if use_ref else "orc_", np.ascontiguousarray(crecs), _sa.default_settings())
+                        t2 = time.perf_counter()
+                    finally:
+                        os.dup2(fd, 2); os.close(devnull); os.close(fd)
+                    idle = 0.3 if use_ref else 0.0          # the driver's wait for the stitcher thread to go idle after the queue ran dry
+                    kk = min(len(cpairs), len(pairs_g))
+                    pal[tape_name]["cpu_baseline"] = {
+                        "value": len(lum_c) / max((t2 - t0) - idle, 1e-6), "unit": "frames/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                        "binarize_frames_per_s": len(lum_c) / (t1 - t0), "stitch_frames_per_s": len(lum_c) / max((t2 - t1) - idle, 1e-6),
+                        "sample": f"the first {len(lum_c)} frames of the tape, {t1 - t0:.1f} s in the VideoToDigital worker + {max((t2 - t1) - idle, 0):.1f} s in the stitcher",
+                        "bit_exact_vs_gpu_on_overlap": bool(crecs.tobytes() == recs_g.tobytes() and kk > 0 and
+                                                            cpairs[:kk].tobytes() == pairs_g.reshape(-1).view(_sa.PAIR_DTYPE)[:kk].tobytes())}
+                except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
+                    pal[tape_name]["cpu_baseline"] = {"error": repr(ex)}
         for key, (stage, _b, _f) in fmt_stages.items():
             out[key] = stage
         if not args.no_cpu and world == 1:
@@ -797,7 +861,7 @@ def main():
             cb["bit_exact_vs_gpu_on_overlap"] = bool(first_recs[:k].tobytes() == cpu_recs[:k].tobytes())
             out["cpu_baseline"] = cb
             try:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sample[:min(args.cpu_frames_all_cores, ncpu)], args.mode)
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(sample[:min(args.cpu_frames_all_cores, ncpu)], args.mode, cb["value"])
             except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
                 out["cpu_baseline_all_cores"] = {"error": repr(ex), "cores": os.cpu_count()}
             if stitch is not None:
@@ -868,7 +932,47 @@ def main():
                                                    f"cold: {len(cl)} lines in {dtc:.2f} s = {len(cl) / dtc:.0f} lines/s",
                                          "bit_exact_vs_gpu_on_overlap": bool(cw.tobytes() == wgot.view(pfa.BIN1_DTYPE).tobytes()
                                                                              and cc.tobytes() == cgot.view(pfa.BIN1_DTYPE).tobytes())}
-        print(json.dumps(out))
+        # The driver keeps the tail of what this prints: the line of BASELINE's metric goes LAST and stays short - the headline, its roofline and CPU
+        # baseline, and the other legs as plain numbers; everything else (the full objects of every leg) goes to stderr and, where the directory can be
+        # made, to gpurun_out/bench_details.json.
+        def pick(d, *path):
+            for k_ in path:
+                if not isinstance(d, dict) or k_ not in d:
+                    return None
+                d = d[k_]
+            return d
+        summary = {
+            "end_to_end_ms_per_step": pick(out, "end_to_end", "ms_per_step"), "end_to_end_frac": pick(out, "end_to_end", "roofline", "frac"),
+            "stitch_ms_per_step": pick(out, "stitch_stage", "ms_per_step"),
+            "pal_clean_frames_per_s": pick(out, "pal_stage", "clean", "frames_per_s"),
+            "pal_damaged_frames_per_s": pick(out, "pal_stage", "lost_lines_and_flipped_cells", "frames_per_s"),
+            "pal_damaged_binarize_ms_per_step": pick(out, "pal_stage", "lost_lines_and_flipped_cells", "binarize_ms_per_step"),
+            "pal_damaged_cpu_frames_per_s": pick(out, "pal_stage", "lost_lines_and_flipped_cells", "cpu_baseline", "value"),
+            "pal_bit_exact_vs_cpu": [pick(out, "pal_stage", "clean", "cpu_baseline", "bit_exact_vs_gpu_on_overlap"),
+                                     pick(out, "pal_stage", "lost_lines_and_flipped_cells", "cpu_baseline", "bit_exact_vs_gpu_on_overlap")],
+            "damaged_lost_lines_ms_per_step": pick(out, "damaged_tape", "lost_lines", "ms_per_step"),
+            "damaged_window_jumps_ms_per_step": pick(out, "damaged_tape", "window_jumps", "ms_per_step"),
+            "pcm1_frames_ms_per_step": pick(out, "pcm1_frames_stage", "ms_per_step"), "pcm16x0_frames_ms_per_step": pick(out, "pcm16x0_frames_stage", "ms_per_step"),
+            "pcm1_stitch_ms_per_step": pick(out, "pcm1_stage", "ms_per_step"),
+            "pcm16x0_si_ms_per_step": pick(out, "pcm16x0_stage", "si", "ms_per_step"), "pcm16x0_ei_ms_per_step": pick(out, "pcm16x0_stage", "ei", "ms_per_step"),
+            "audio_worn_tape_ms_per_step": pick(out, "audio_stage", "invalid_word_in_every_window", "ms_per_step"),
+            "cpu_all_cores_frames_per_s": pick(out, "cpu_baseline_all_cores", "value"), "cpu_all_cores": pick(out, "cpu_baseline_all_cores", "cores"),
+            "sharded_full_path_ms": pick(out, "sharded_full_path", "ms"),
+        }
+        short = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                                        "config", "roofline", "cpu_baseline") if k_ in out}
+        short["roofline"] = {k_: v_ for k_, v_ in out["roofline"].items() if k_ not in ("traffic_unit", "traffic_from_committed_profile")}
+        short["summary"] = {k_: v_ for k_, v_ in summary.items() if v_ is not None}
+        short["details"] = "the full objects of every leg: stderr of this run, gpurun_out/bench_details.json"
+        full = json.dumps(out)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "w") as fh:
+                fh.write(full + "\n")
+        except OSError:
+            pass
+        print(full, file=sys.stderr, flush=True)
+        print(json.dumps(short), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

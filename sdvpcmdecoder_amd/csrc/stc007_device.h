@@ -1632,7 +1632,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         for (unsigned i = 0; i < sizeof(sdv_v2d_state) / 4; i++) same = same && (mine[i] == next[i]);
         if (!same) fl = VF_BREAK;
     }
-    {
+    if (fl == VF_BREAK) {       /* (only asked of a frame whose link broke: on a tape that plays this is skipped) */
         /* ... "what it was started from" as the model sees it: one frame on, with the inherited tuning */
         const sdv_v2d_state exp = predict_state(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl);
         uint32_t own[sizeof(sdv_v2d_state) / 4];

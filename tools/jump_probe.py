@@ -21,4 +21,9 @@ for J in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1
     eng.binarize_frames(luma, first_frame_no=1 + n, new_file=False)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     i = eng.run_info()
-    print(f"jumps {J}: (wall ms, kernel ms, rounds, launched, by full kernel) {(round(dt, 2), round(i.kernel_ms, 2), i.rounds, i.frames_launched, i.frames_general)}", flush=True)
+    print(f"jumps {J}: (wall ms, kernel ms, rounds, launched, by full kernel, sweeps) {(round(dt, 2), round(i.kernel_ms, 2), i.rounds, i.frames_launched, i.frames_general, i.sweeps)}", flush=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.binarize_frames(luma, first_frame_no=1 + 2 * n, new_file=False)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+    i = eng.run_info()
+    print(f"   once more: {(round(dt, 2), round(i.kernel_ms, 2), i.rounds, i.frames_launched, i.frames_general, i.sweeps)}", flush=True)
