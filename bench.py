@@ -158,6 +158,23 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline_all_cores(luma_sample, mode, single_core_frames_per_s=None):
     """the CPU path on every core of this host - one fresh child process per PHYSICAL core, one reference worker each (a worker is two
     threads: the reference's own VideoToDigital worker and the feeder that plays the input plugin; a process per hardware thread oversubscribed
@@ -166,7 +183,15 @@ def cpu_baseline_all_cores(luma_sample, mode, single_core_frames_per_s=None):
     import subprocess
     import tempfile
     import numpy as np
-    cores = physical_cores()
+    phys = physical_cores()
+    quota = cpu_quota()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    # as many workers as cores this process may really use at once: physical cores, the CPUs it is allowed on, the container's CPU-time quota
+    # (the GPU boxes of the pool show 256 hardware threads and grant 16 CPUs' worth of time: 128 workers there measured the throttle - 12x one core)
+    cores = max(1, int(min(phys, affinity, quota if quota else phys)))
     d = tempfile.mkdtemp(prefix="sdv_cpu_")
     try:
         sample = os.path.join(d, "sample.npy")
@@ -191,11 +216,13 @@ def cpu_baseline_all_cores(luma_sample, mode, single_core_frames_per_s=None):
         wall = max(r["t1"] for r in res) - min(r["t0"] for r in res)
         frames = sum(r["frames"] for r in res)
         per_worker = frames / len(res) / (sum(r["t1"] - r["t0"] for r in res) / len(res))
-        return {"value": frames / wall, "unit": "frames/s", "cores": cores, "hardware_threads": os.cpu_count(), "workers_finished": len(res), "kind": res[0]["kind"],
+        return {"value": frames / wall, "unit": "frames/s", "cores": cores, "physical_cores": phys, "hardware_threads": os.cpu_count(), "cpu_quota_of_the_container": quota,
+                "workers_finished": len(res), "kind": res[0]["kind"],
                 "per_worker_frames_per_s": per_worker,
                 "per_worker_slowdown_vs_one_core_alone": (single_core_frames_per_s / per_worker) if single_core_frames_per_s else None,
                 "all_workers_decoded_the_same_records": len(set(r["sha"] for r in res)) == 1,
-                "sample": f"{len(res)} worker processes (one per physical core: {cores}; {os.cpu_count()} hardware threads), each the first {res[0]['frames']} frames of the "
+                "sample": f"{len(res)} worker processes (one per core this container may use at once: {cores} of {phys} physical cores, {os.cpu_count()} hardware threads, "
+                          f"CPU quota {quota}), each the first {res[0]['frames']} frames of the "
                           f"same synthetic batch, {wall:.1f} s of wall time from the first start to the last finish"}
     finally:
         import shutil

@@ -199,3 +199,144 @@ def test_gpu_fused_stream_in_calls_equals_one_call(damaged):
     assert piped[0] == 0 and piped[-1] == 0, piped
     if not damaged:
         assert sum(1 for x in piped if x) >= 4, piped
+
+
+# ---- the fused entry against the reference's own output and the sequential oracle (not against the separate calls) ------------------------
+def _load_gen(name):
+    import importlib.util
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(gold, name + ".py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg, gold
+
+
+def _damaged_tape(n, seed=91):
+    """Full-size NTSC frames with the kinds of damage the stitch stage and the speculation have to get through together: lost lines, lines no
+    reference level reads (their sweeps are settled by the sweep kernels between the passes), and a data window that moves half way."""
+    from sdvpcmdecoder_amd import synth
+    from test_gpu_parity import _unreadable_cells
+    luma = synth.stc007_frames(n, seed=seed, noise_sigma=4.0)[0].copy()
+    luma[:, 77::61] = 16
+    luma = _unreadable_cells(luma, every=211, seed=seed)
+    luma[n // 2:] = np.roll(luma[n // 2:], 5, axis=2)
+    return np.ascontiguousarray(luma)
+
+
+def _oracle_chain(oracle_lib, luma):
+    from oracle_run import oracle_binarize
+    recs, stats = oracle_binarize(luma, mode=2, first_frame_no=1, new_file=True, end_file=True)
+    pairs, frames = sa.run_cpu(oracle_lib, "orc_", recs, sa.default_settings())
+    return pairs, frames, stats
+
+
+def test_emu_fused_uneven_calls_equal_the_sequential_oracle(emu_lib, oracle_lib):
+    """A damaged tape through sdv_decode_frames in calls of 1, 3, 2 and 1 frames (emulator): pair stream, frame descriptors and frame statistics equal
+    what the oracle's two workers make of the whole tape one line after the other."""
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    from sdvpcmdecoder_amd import synth
+    from test_gpu_parity import _unreadable_cells
+    luma = synth.stc007_frames(7, seed=93, noise_sigma=4.0, height=120, lines_per_field=60)[0].copy()
+    luma[:, 33::29] = 16
+    luma = np.ascontiguousarray(_unreadable_cells(luma, every=47, seed=5))
+    want_p, want_f, want_s = _oracle_chain(oracle_lib, luma)
+    e = EmuEngine(lib)
+    lib.sdv_set_pcm_type(e.h, STC007, 0)
+    got_p, got_f, got_s = [], [], []
+    k = 0
+    for cnt in (1, 3, 2, 1):
+        p, f, st, _, _ = _fused_host(lib, e.h, STC007, luma[k:k + cnt], with_audio=False, first_frame_no=1 + k, flags=(1 if k == 0 else 0) | (4 if k + cnt == 7 else 0))
+        got_p.append(p.copy()); got_f.append(f.copy()); got_s.append(st[:cnt + (1 if k + cnt == 7 else 0)].copy())
+        k += cnt
+    e.close()
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s).view(np.uint8).tobytes() == want_s.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calls", [(4,), (1, 2, 1), (3, 1)])
+def test_gpu_fused_entry_matches_reference_golden_ntsc(calls):
+    """sdv_decode_frames over the file of tests/golden/e2e_ntsc_file.npz, in one call and in uneven ones: PCMSamplePair stream, FrameAsmSTC007 rows and
+    frame statistics equal what the REAL reference's VideoToDigital and STC007DataStitcher made of that file."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    mg, gold = _load_gen("make_golden_stitch")
+    import os
+    z = np.load(os.path.join(gold, "e2e_ntsc_file.npz"))
+    luma = mg.make_e2e_luma()
+    d = torch.from_numpy(luma).cuda()
+    eng = Engine(0); eng.setPCMType(STC007)
+    got_p, got_f, got_s, k = [], [], [], 0
+    for cnt in calls:
+        p, f, st = eng.decode_frames(STC007, d[k:k + cnt], first_frame_no=1 + k, new_file=k == 0, end_file=k + cnt == len(luma))
+        got_p.append(p.cpu().numpy().copy()); got_f.append(f.cpu().numpy().copy()); got_s.append(st.cpu().numpy().copy())
+        k += cnt
+    assert np.concatenate(got_p).tobytes() == np.ascontiguousarray(z["pairs"]).tobytes()
+    assert np.concatenate(got_f).tobytes() == np.ascontiguousarray(z["frames"]).tobytes()
+    assert np.concatenate(got_s).tobytes() == np.ascontiguousarray(z["stats"]).tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_fused_entry_with_audio_matches_reference_golden():
+    """... and with the AudioProcessor behind it: the masked stream the real AudioProcessor made of the real workers' output for that file
+    (tests/golden/e2e_ntsc_file_audio.npz)."""
+    import os
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    mg, gold = _load_gen("make_golden_stitch")
+    z = np.load(os.path.join(gold, "e2e_ntsc_file_audio.npz"))
+    d = torch.from_numpy(mg.make_e2e_luma()).cuda()
+    eng = Engine(0); eng.setPCMType(STC007)
+    eng.set_audio_masking(A.DROP_INTER_LIN_WORD)
+    out, _f, _s, pur, masked = eng.decode_frames(STC007, d, first_frame_no=1, new_file=True, end_file=True, with_audio=True, audio_stop=True)
+    assert out.cpu().numpy().tobytes() == np.ascontiguousarray(z["pairs"]).tobytes()
+    assert masked == int(z["masked"])
+    assert eng.wav_files(out, pur)[0] == np.ascontiguousarray(z["wav0"]).tobytes()      # the file the real SamplesToWAV wrote
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ei", [False, True])
+def test_gpu_fused_entry_matches_reference_golden_pcm16x0(ei):
+    """sdv_decode_frames(SDV_PCM_PCM16X0) over the file of tests/golden/e2e_pcm16x0_<si|ei>.npz, in one call and in calls of 2 + 3 frames: what the REAL
+    reference's VideoToDigital (TYPE_PCM16X0) and PCM16X0DataStitcher made of it."""
+    import os
+    import torch
+    from sdvpcmdecoder_amd import Engine, Pcm16x0StitchSettings
+    mg, gold = _load_gen("make_golden_pcm16")
+    z = np.load(os.path.join(gold, "e2e_pcm16x0_%s.npz" % ("ei" if ei else "si")))
+    luma, _audio = mg.make_e2e_luma(ei)
+    d = torch.from_numpy(np.ascontiguousarray(luma)).cuda()
+    for calls in ((len(luma),), (2, len(luma) - 2)):
+        eng = Engine(0); eng.setPCMType(PCM16X0)
+        eng.set_pcm16x0_stitch_settings(Pcm16x0StitchSettings.from_buffer_copy(bytes(p16.default_settings(format=p16.FORMAT_EI if ei else p16.FORMAT_SI))))
+        got_p, got_f, k = [], [], 0
+        for cnt in calls:
+            p, f, _st = eng.decode_frames(PCM16X0, d[k:k + cnt], first_frame_no=1 + k, new_file=k == 0, end_file=k + cnt == len(luma))
+            got_p.append(p.cpu().numpy().copy()); got_f.append(f.cpu().numpy().copy())
+            k += cnt
+        assert np.concatenate(got_p).tobytes() == np.ascontiguousarray(z["pairs"]).tobytes(), calls
+        assert np.concatenate(got_f).tobytes() == np.ascontiguousarray(z["frames"]).tobytes(), calls
+
+
+@pytest.mark.gpu
+def test_gpu_fused_uneven_calls_equal_the_sequential_oracle(oracle_lib):
+    """A damaged 40-frame tape (lost lines, unreadable lines, a window that moves) through sdv_decode_frames in uneven calls, so that the pipelined
+    way through the stitch stage, the classic one and the sweeps between the passes of the frame kernel all take turns: compared with the
+    sequential truth - the oracle's two workers over the whole tape - not with the engine's other entry points."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    n = 40
+    luma = _damaged_tape(n)
+    want_p, want_f, want_s = _oracle_chain(oracle_lib, luma)
+    d = torch.from_numpy(luma).cuda()
+    eng = Engine(0); eng.setPCMType(STC007)
+    got_p, got_f, got_s, k = [], [], [], 0
+    for cnt in (1, 7, 2, 13, 5, 11, 1):
+        p, f, st = eng.decode_frames(STC007, d[k:k + cnt], first_frame_no=1 + k, new_file=k == 0, end_file=k + cnt == n)
+        got_p.append(p.cpu().numpy().copy()); got_f.append(f.cpu().numpy().copy()); got_s.append(st.cpu().numpy().copy())
+        k += cnt
+    assert k == n
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes()
+    assert np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s).tobytes() == want_s.tobytes()
