@@ -28,7 +28,7 @@ enum { ORDER_TFF = 1, ORDER_BFF = 2 };
 /* per-frame marks found by the flags pass */
 enum { FF_NEW_FILE = 1, FF_END_FILE = 2, FF_FOREIGN = 4 };
 /* reasons a frame cannot be stitched statelessly (the reference would read sub-lines left over from earlier frames, or hold lines back) */
-enum { FE_FOREIGN = 1, FE_TOO_LONG = 2, FE_STALE = 4, FE_SHORT_QUEUE = 8, FE_MARKS = 16 };
+enum { FE_FOREIGN = 1, FE_TOO_LONG = 2, FE_MARKS = 16 };
 
 struct RecSrc1 {
     const sdv_pcm1_line_rec *carry; uint32_t n_carry; const sdv_pcm1_line_rec *recs;
@@ -439,9 +439,13 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         /* the lines earlier frames left at those places join the frame's staged lines (behind its own records) */
         const uint32_t s0 = stale_to[0] > cnt[0] ? stale_to[0] - cnt[0] : 0u, s1 = stale_to[1] > cnt[1] ? stale_to[1] - cnt[1] : 0u;
         const uint32_t room_from = kLds ? n_scan : 0u;      /* where `lines` is free */
-        if (kLds && a.cnt_in && room_from + s0 + s1 > (uint32_t)LDS_LINES) return true;        /* no room behind the frame's own lines: once more on the path that leaves `lines` free (nothing was written yet) */
-        if (!a.cnt_in || room_from + s0 + s1 > (uint32_t)LDS_LINES || stale_to[0] > LINES_PF || stale_to[1] > LINES_PF) err |= FE_STALE;
-        else {
+        if (kLds && room_from + s0 + s1 > (uint32_t)LDS_LINES) return true;        /* no room behind the frame's own lines: once more on the path that leaves `lines` free (nothing was written yet) */
+        /* There the room always suffices: a field is told to read at most LINES_PF places of its buffer - the manual offsets are int8, so the padding
+         * above a field is at most 128 lines and the trimmed field (245 lines minus that padding, pcm1datastitcher.cpp:896-909) never wraps - and
+         * LDS_LINES holds two fields.  (For the same reason the queue handed to PCM1Deinterleaver is always exactly one field:
+         * its DI_RET_NO_DATA, pcm1deinterleaver.cpp:104 / 119, cannot be reached through the stitcher - tests/test_pcm1.py walks all offsets.) */
+        static_assert(LDS_LINES >= 2 * LINES_PF, "the lines two fields can be told to take from earlier frames fit the staging buffer");
+        {
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const uint32_t base = room_from + (p ? s0 : 0u);
@@ -480,7 +484,6 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         const uint16_t *fidx = odd_field ? field_idx[0] : field_idx[1];
         const uint32_t f_top = odd_field ? top_pad[0] : top_pad[1], f_bot = odd_field ? bot_pad[0] : bot_pad[1], f_data = odd_field ? data[0] : data[1];
         const uint32_t f_lines = f_data <= SUBLINES_PF ? f_data / 3 : 0u;      /* addLinesFromField refuses more than a field (:960) */
-        if ((uint64_t)f_top + f_lines + f_bot < LINES_PF) err |= FE_SHORT_QUEUE;    /* DI_RET_NO_DATA: 8 cleared blocks of 92 pairs */
         /* The padded field is 245 lines of 3 sub-lines; a lane takes a line.  First the lines' flags as three 245-bit masks ... */
         uint64_t okm[4], pkm[4], plm[4];
         uint32_t li[4];

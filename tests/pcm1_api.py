@@ -74,11 +74,16 @@ CASES = {
     "manual_lost_first_frame": (5, dict(seed=325, p_bad=0.02, lines=(250, 255)), dict(auto_offset=0, odd_offset=0, even_offset=0)),
     "manual_lost_file_marks": (7, dict(seed=326, p_bad=0.03, lines=(251, 249), new_file=True, end_file=True), dict(auto_offset=0, odd_offset=-1, even_offset=2, use_ecc=0)),
     "manual_lost_long_frame": (6, dict(seed=327, p_bad=0.03, lines=(300, 296), header=1), dict(auto_offset=0, odd_offset=-3, even_offset=2)),     # > 544 records: the global-memory path
+    # manual line offsets at the ends of their range (setOddLineOffset / setEvenLineOffset take an int8) over fields that hold far fewer than 245 lines,
+    # some of them lost: the stitcher pads 128 lines above a field / skips 127 lines of it and still hands PCM1Deinterleaver a queue of exactly one
+    # field (pcm1datastitcher.cpp:809-923) - its DI_RET_NO_DATA (pcm1deinterleaver.cpp:104, 119) cannot be reached through the stitcher
+    "manual_short_fields": (5, dict(seed=331, p_bad=0.03, lines=(120, 96)), dict(auto_offset=0, odd_offset=-128, even_offset=127)),
+    "manual_short_fields_lost": (6, dict(seed=332, p_bad=0.04, lines=(131, 245), header=1), dict(auto_offset=0, odd_offset=127, even_offset=-128)),
     "overlong_frame": (3, dict(seed=321, lines=(990, 985), p_bad=0.02), {}),
     "overlong_frame_tagged": (3, dict(seed=322, lines=(990, 985), p_bad=0.02, new_file=True, end_file=True), {}),
 }
 GOLDEN = ("header_emph", "bad5", "noise_outside", "file_marks", "manual_offsets", "empty_frames", "stale_tag_inside", "overlong_frame_tagged",
-          "manual_lost_many", "manual_lost_first_frame")
+          "manual_lost_many", "manual_lost_first_frame", "manual_short_fields", "manual_short_fields_lost")
 
 
 def _older_number(recs, srv, which=0):
@@ -122,6 +127,7 @@ MANGLE = {
     "manual_lost_first_frame": _lose_lines(0.03, 3, first_frame_share=0.5),      # places no frame has written yet: default-constructed sub-lines
     "manual_lost_file_marks": _lose_lines(0.08, 4),
     "manual_lost_long_frame": _lose_lines(0.06, 5),
+    "manual_short_fields_lost": _lose_lines(0.10, 6),
     "stale_new_file": lambda r: _older_number(r, SRV_NEW_FILE),
     "stale_end_file": lambda r: _older_number(r, SRV_END_FILE),
     "stale_tag_inside": _tag_inside,

@@ -305,3 +305,30 @@ def test_gpu_video_to_audio(mode):
     frames = f.cpu().numpy().reshape(-1).view(p1.FRASM1_DTYPE)
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
     assert len(pairs) == 5 * 1470 and (pairs["sample_flags"] & 2).mean() > 0.95
+
+
+def test_manual_offsets_always_hand_the_deinterleaver_one_field():
+    """PCM1Deinterleaver::processBlock answers DI_RET_NO_DATA to a queue shorter than a field (pcm1deinterleaver.cpp:104, 119).  PCM1DataStitcher never
+    hands it one: with automatic offsets the padding is made to fill the field, and with manual ones (int8, setOddLineOffset / setEvenLineOffset) the
+    arithmetic of findFramePadding (pcm1datastitcher.cpp:809-923, uint16 fields, int expressions) comes out at exactly 735 sub-lines for every offset,
+    every bottom line and every number of lines the frame wrote - walked here in the reference's own types.  That is why the engine has no such case."""
+    def u16(x):
+        return x & 0xFFFF
+
+    def cdiv(a, b):             # C division: towards zero
+        q = abs(a) // b
+        return q if a >= 0 else -q
+    for ofs in range(-128, 128):
+        top_data = 2 * ofs + 1 if ofs > 0 else 1                # odd field; the even one: 2 ofs + 2 / 2 - the same arithmetic one line down
+        top_pad = 0 if ofs > 0 else u16(0 - ofs)
+        for bottom in range(0, 1300):
+            for cnt in (0, 1, 7, 100, 244, 245):                # lines the frame wrote into the field buffer
+                data = 3 * cnt
+                bp = u16(u16(cdiv(bottom - top_data, 2) + 1) + top_pad)
+                if bp > 245:
+                    bp = u16(bp - 245)
+                    b2 = u16(bottom - bp * 2)
+                    data = u16(u16(cdiv(b2 - top_data, 2) + 1) * 3)
+                bot = u16(cdiv(735 - data, 3) - top_pad)
+                queue = 3 * top_pad + (data if data <= 735 else 0) + 3 * bot
+                assert queue >= 735, (ofs, bottom, cnt, data, top_pad, bot)
