@@ -17,7 +17,8 @@
  *   RANK=r WORLD_SIZE=n [LOCAL_RANK=d] decode_tape_sharded <luma.raw> <width> <height> <n_frames> <out prefix> [rccl | file:<dir>] [warm-up frames [stitcher warm-up turns]]
  *       writes <out prefix>.rank<r>.pairs / .frames: the PCMSamplePair records and FrameAsmSTC007 descriptors of this rank's frames; concatenated in
  *       rank order they are what `decode_tape stc007` writes for the same file.
- *   Collective back ends: `rccl` (default; rank 0 publishes the ncclUniqueId in <out prefix>.ncclid) and `file:<dir>` (the all-gather through files
+ *   Collective back ends: `rccl` (default; rank 0 publishes the ncclUniqueId in <out prefix>.ncclid - per run, see RcclComm; give all ranks of a run the
+ *   same SDV_RUN_ID unless a launcher already sets TORCHELASTIC_RUN_ID / MASTER_PORT) and `file:<dir>` (the all-gather through files
  *   of a shared directory: for debugging and for the CPU test of this loop, which links the test-only emulator build of the engine and has no RCCL).
  *
  * Build: build.py build_example_sharded (g++, -lsdvpcm_hip -lamdhip64 -lrccl); the CPU test build: -DSDV_EXAMPLE_HOST_MEMORY against
@@ -28,6 +29,9 @@
 #include <rccl/rccl.h>
 #endif
 #include <chrono>
+#include <ctime>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,29 +68,55 @@ struct Comm {
 };
 #ifndef SDV_EXAMPLE_HOST_MEMORY
 #define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #x, ncclGetErrorString(r_)); exit(4); } } while (0)
+/* The rendezvous is per RUN: the file that carries rank 0's ncclUniqueId is named after the run (run_tag(): SDV_RUN_ID, else what the launchers set for
+ * all ranks of a job - TORCHELASTIC_RUN_ID, MASTER_ADDR:MASTER_PORT), starts with that tag, is removed by rank 0 before it publishes a new id and again
+ * once every rank has joined (ncclCommInitRank returns when all have), and a rank that finds a file of another run - or, without any tag, one written
+ * before it was started itself - keeps waiting.  An id file left by a job that died can therefore not be picked up by the next one. */
+static std::string run_tag()
+{
+    if (const char *v = getenv("SDV_RUN_ID")) return v;
+    std::string t;
+    if (const char *v = getenv("TORCHELASTIC_RUN_ID")) t = v;
+    if (const char *a = getenv("MASTER_ADDR")) { t += "@"; t += a; if (const char *p = getenv("MASTER_PORT")) { t += ":"; t += p; } }
+    return t;
+}
+struct IdFile { char magic[8]; char tag[120]; ncclUniqueId id; };
 struct RcclComm : Comm {
     ncclComm_t comm; hipStream_t stream; uint8_t *d_send, *d_recv; size_t cap;
     RcclComm(int r, int w, const std::string &id_file) : comm(NULL), stream(NULL), d_send(NULL), d_recv(NULL), cap(0)
     {
         rank = r; world = w;
-        ncclUniqueId id;
+        const std::string tag = run_tag();
+        const time_t started = time(NULL);
+        IdFile rec;
+        memset(&rec, 0, sizeof(rec));
         if (rank == 0) {
-            NCCL_OK(ncclGetUniqueId(&id));
-            const std::string tmp = id_file + ".tmp";
+            (void)remove(id_file.c_str());                    /* whatever an earlier run left */
+            memcpy(rec.magic, "SDVNCCL1", 8);
+            snprintf(rec.tag, sizeof(rec.tag), "%s", tag.c_str());
+            NCCL_OK(ncclGetUniqueId(&rec.id));
+            const std::string tmp = id_file + ".tmp" + std::to_string((long)getpid());
             FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); exit(4); }
+            if (!f || fwrite(&rec, sizeof(rec), 1, f) != 1) { fprintf(stderr, "cannot write %s\n", tmp.c_str()); exit(4); }
             fclose(f);
             rename(tmp.c_str(), id_file.c_str());
         } else {
             for (int tries = 0;; tries++) {
                 FILE *f = fopen(id_file.c_str(), "rb");
-                if (f) { const bool ok = fread(&id, sizeof(id), 1, f) == 1; fclose(f); if (ok) break; }
-                if (tries > 6000) { fprintf(stderr, "rank %d: no ncclUniqueId in %s\n", rank, id_file.c_str()); exit(4); }
+                if (f) {
+                    bool ok = fread(&rec, sizeof(rec), 1, f) == 1 && memcmp(rec.magic, "SDVNCCL1", 8) == 0 && tag == std::string(rec.tag, strnlen(rec.tag, sizeof(rec.tag)));
+                    struct stat sb;
+                    if (ok && tag.empty()) ok = fstat(fileno(f), &sb) == 0 && sb.st_mtime + 1 >= started;    /* no run tag to tell the runs apart: only a file written since this rank was started */
+                    fclose(f);
+                    if (ok) break;
+                }
+                if (tries > 6000) { fprintf(stderr, "rank %d: no ncclUniqueId of this run in %s (set SDV_RUN_ID to the same value for all ranks of a run)\n", rank, id_file.c_str()); exit(4); }
                 std::this_thread::sleep_for(std::chrono::milliseconds(10));
             }
         }
         HIP_OK(hipStreamCreate(&stream));
-        NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+        NCCL_OK(ncclCommInitRank(&comm, world, rec.id, rank));
+        if (rank == 0) (void)remove(id_file.c_str());         /* everybody has joined: nobody needs it any more */
     }
     ~RcclComm() { if (comm) ncclCommDestroy(comm); dev_free(d_send); dev_free(d_recv); if (stream) (void)hipStreamDestroy(stream); }
     void all_gather(const void *send, void *recv, size_t bytes) override
@@ -100,17 +130,30 @@ struct RcclComm : Comm {
 };
 #endif
 struct FileComm : Comm {
-    std::string dir; unsigned seq;
-    FileComm(int r, int w, const std::string &d) : dir(d), seq(0) { rank = r; world = w; }
+    std::string dir, tag; unsigned seq;
+    /* files of one run only: named after the run (SDV_RUN_ID / the launcher's variables, as above), a rank's file of gather k - 1 removed once gather k
+     * is through (every rank wrote its file of gather k after it had read all of k - 1) */
+    FileComm(int r, int w, const std::string &d) : dir(d), seq(0)
+    {
+        rank = r; world = w;
+        std::string t;
+        if (const char *v = getenv("SDV_RUN_ID")) t = v;
+        else { if (const char *v = getenv("TORCHELASTIC_RUN_ID")) t = v; if (const char *p = getenv("MASTER_PORT")) { t += "p"; t += p; } }
+        for (char &c : t) if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '-' || c == '_')) c = '_';
+        tag = t.empty() ? std::string("g") : "g" + t + "_";
+    }
+    std::string name(unsigned k, int r) const { return dir + "/" + tag + std::to_string(k) + ".r" + std::to_string(r); }
+    /* (the files of the very last gather stay: a rank cannot know that the others have read them, and waiting for them at exit would tie a fast rank to
+     * the slowest one's repair; they carry the run's name, another run never reads them) */
     void all_gather(const void *send, void *recv, size_t bytes) override
     {
-        const std::string mine = dir + "/g" + std::to_string(seq) + ".r" + std::to_string(rank);
+        const std::string mine = name(seq, rank);
         FILE *f = fopen((mine + ".tmp").c_str(), "wb");
         if (!f || fwrite(send, 1, bytes, f) != bytes) { fprintf(stderr, "rank %d: cannot write %s\n", rank, mine.c_str()); exit(4); }
         fclose(f);
         rename((mine + ".tmp").c_str(), mine.c_str());
         for (int r = 0; r < world; r++) {
-            const std::string theirs = dir + "/g" + std::to_string(seq) + ".r" + std::to_string(r);
+            const std::string theirs = name(seq, r);
             for (int tries = 0;; tries++) {
                 FILE *g = fopen(theirs.c_str(), "rb");
                 if (g) { const bool ok = fread((uint8_t *)recv + (size_t)r * bytes, 1, bytes, g) == bytes; fclose(g); if (ok) break; }
@@ -118,6 +161,7 @@ struct FileComm : Comm {
                 std::this_thread::sleep_for(std::chrono::milliseconds(2));
             }
         }
+        if (seq >= 1) (void)remove(name(seq - 1, rank).c_str());
         seq++;
     }
 };

@@ -370,7 +370,11 @@ __device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int l
                     if ((good[m] >> j) & 1) res[m]++;
                     else if (((brk[m] >> j) & 1) && res[m] > 0) res[m]--;
                 }
-        if (has_nx) ring[(uint32_t)nx % (uint32_t)RING_SMALL] = nxl;  /* slots of lines the next step no longer reads */
+        /* The slots of the next step's new lines hold lines of THIS step's gather8 (the ring is 192 deep, a step reads 64 + 112 of them): every
+         * lane's reads of the ring have to be done before any lane stores - made explicit here; the barrier at the top of the step then orders
+         * the stores before the next step's reads. */
+        SDV_LDS_WAVE_SYNC();
+        if (has_nx) ring[(uint32_t)nx % (uint32_t)RING_SMALL] = nxl;
     }
     if (res[0] > (ILV * 2)) {
         uint16_t t = (uint16_t)(res[1] * 128);

@@ -340,3 +340,49 @@ def test_gpu_fused_uneven_calls_equal_the_sequential_oracle(oracle_lib):
     assert np.concatenate(got_p).tobytes() == want_p.tobytes()
     assert np.concatenate(got_f).tobytes() == want_f.tobytes()
     assert np.concatenate(got_s).tobytes() == want_s.tobytes()
+
+
+def test_emu_stitch_and_fused_calls_interleaved_with_the_visualiser_feeds_toggled(emu_lib, oracle_lib):
+    """One stream fed alternately through sdv_decode_frames (records of known layout: the pipelined way through the stitch stage, the next call's state
+    copied ahead of the read-back) and through sdv_binarize_frames + sdv_stitch_frames, with the block and assembled-line outputs of the stitch stage
+    switched on and off in between (switched on they make the stage run its turns once more for the feed): the hand-over between the calls must not
+    depend on which way a call took.  The whole equals the sequential oracle; the emulator build also checks the state that was copied ahead against
+    the last turn's (SDV_DEV_AIDS, stitch_engine.inc)."""
+    from sdvpcmdecoder_amd import synth
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    n = 14
+    luma = np.ascontiguousarray(synth.stc007_frames(n, seed=97, noise_sigma=3.0, height=120, lines_per_field=60)[0])
+    want_p, want_f, _ = _oracle_chain(oracle_lib, luma)
+    e = EmuEngine(lib)
+    lib.sdv_set_pcm_type(e.h, STC007, 0)
+    blocks = np.zeros(4096, dtype=sa.BLOCK_DTYPE)
+    asm = np.zeros(64 * 1024, dtype=np.uint8)
+    got_p, got_f = [], []
+    piped = 0
+    info = ea.StitchInfo()
+    plan = [("fused", 2, None), ("fused", 2, None), ("fused", 2, "blocks"), ("split", 2, None), ("fused", 2, "lines"), ("fused", 2, None), ("fused", 2, "off")]
+    k = 0
+    for how, cnt, feed in plan:
+        if feed == "blocks":
+            assert lib.sdv_set_stitch_block_output(e.h, blocks.ctypes.data, len(blocks)) == 0
+        elif feed == "lines":
+            assert lib.sdv_set_stitch_block_output(e.h, None, 0) == 0
+            assert lib.sdv_set_stitch_line_output(e.h, asm.ctypes.data, len(asm) // 64) == 0
+        elif feed == "off":
+            assert lib.sdv_set_stitch_line_output(e.h, None, 0) == 0
+        flags = (1 if k == 0 else 0) | (4 if k + cnt == n else 0)
+        if how == "fused":
+            p, f, _st, _, _ = _fused_host(lib, e.h, STC007, luma[k:k + cnt], with_audio=False, first_frame_no=1 + k, flags=flags)
+        else:
+            recs, _stats = e.binarize_frames(luma[k:k + cnt], first_frame_no=1 + k, new_file=k == 0, end_file=k + cnt == n)
+            p, f = e.stitch_frames(recs)
+        got_p.append(p.copy()); got_f.append(f.copy())
+        assert lib.sdv_get_stitch_info(e.h, C.byref(info)) == 0
+        piped += int(info.pipelined)
+        k += cnt
+    e.close()
+    assert k == n
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert piped >= 2, piped

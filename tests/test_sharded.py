@@ -191,3 +191,28 @@ def test_cpp_host_program_sharded_noisy_tape_decodes_no_range_twice(tmp_path):
     assert all("ranges decoded again: binarize 0, stitch 0" in o for o in outs), outs
     assert b"".join((tmp_path / f"out.rank{r}.pairs").read_bytes() for r in range(2)) == want_p.tobytes()
     assert b"".join((tmp_path / f"out.rank{r}.frames").read_bytes() for r in range(2)) == want_f.tobytes()
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_sharded_rccl_two_ranks(tmp_path):
+    """Two ranks, a GPU each, ncclAllGather over the node's links (the multi-GPU node only: skipped on the one-GPU test boxes).  Run twice with the
+    same output prefix and different run ids: the id file of the first run must not be picked up by the second (the rendezvous is per run)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from sdvpcmdecoder_amd import build as b
+    import test_stitch_kernel as tsk
+    exe = b.build_example_sharded()
+    luma, z, want_p, want_f = tsk._e2e_fixture()
+    n, h, w = luma.shape
+    (tmp_path / "luma.raw").write_bytes(np.ascontiguousarray(luma).tobytes())
+    for run in ("first", "second"):
+        procs = [subprocess.Popen([exe, str(tmp_path / "luma.raw"), str(w), str(h), str(n), str(tmp_path / "out"), "rccl", "1", "1"],
+                                  env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", SDV_RUN_ID=run, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        assert not (tmp_path / "out.ncclid").exists()           # removed once both ranks had joined
+        pairs = b"".join((tmp_path / f"out.rank{r}.pairs").read_bytes() for r in range(2))
+        frames = b"".join((tmp_path / f"out.rank{r}.frames").read_bytes() for r in range(2))
+        assert pairs == want_p.tobytes() and frames == want_f.tobytes()
