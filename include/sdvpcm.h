@@ -744,7 +744,8 @@ size_t sdv_stitch_line_counts(sdv_engine *e, uint32_t *per_turn, size_t cap);
  * and leaves the drawing running on `stream`.  sdv_vis_reset: a new canvas (RenderPCM::startNewFrame).
  * The block canvas and the assembled-lines canvas of STC-007 follow below; those of PCM-1 / PCM-16x0 are not rebuilt. */
 enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2, SDV_VIS_STC007_BLOCKS_NTSC = 3, SDV_VIS_STC007_BLOCKS_PAL = 4,
-       SDV_VIS_STC007_ASM_NTSC = 5, SDV_VIS_STC007_ASM_PAL = 6 };
+       SDV_VIS_STC007_ASM_NTSC = 5, SDV_VIS_STC007_ASM_PAL = 6,
+       SDV_VIS_M2_SAMPLES = 0x100 };   /* or-ed to a block canvas: the blocks hold M2 samples (STC007DataBlock::setM2Format; getSample's M2 branch, stc007datablock.cpp:527-556) */
 int sdv_vis_canvas_size(int kind, uint32_t *width, uint32_t *height);
 int sdv_vis_reset(sdv_engine *e, int kind, void *stream);
 int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_recs, uint32_t *out_canvases, size_t canvases_cap, size_t *n_frames, void *stream);
@@ -754,8 +755,9 @@ int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_rec
  * SDV_VIS_STC007_BLOCKS_NTSC (654 x 490) or _PAL (654 x 588; the canvas follows the video standard, setLineCount).  blocks: the device
  * buffer sdv_set_stitch_block_output filled; frame_blocks: HOST array, how many of them belong to each of the n_frames frames
  * (sdv_frame_asm::blocks_total of the descriptors that are no file tags); blocks past the canvas' rows are dropped like in the reference.
- * out_canvases[f] = the canvas after frame f; the engine keeps the last one per kind.  Not covered: M2 sample format (getSample's other branch),
- * emphasis (the reference never sets it for STC-007, stc007datastitcher.cpp:6719).  Device pointers but frame_blocks; asynchronous on `stream`. */
+ * out_canvases[f] = the canvas after frame f; the engine keeps the last one per kind.  kind | SDV_VIS_M2_SAMPLES: the samples are drawn as
+ * getSample() expands M2 words (12 bits + range bit) and "near silence" is judged on the 16-bit scale, as for blocks with setM2Format(true).
+ * Not covered: emphasis (the reference never sets it for STC-007, stc007datastitcher.cpp:6719).  Device pointers but frame_blocks; asynchronous on `stream`. */
 int sdv_vis_render_blocks(sdv_engine *e, int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
                           uint32_t *out_canvases, size_t canvases_cap, void *stream);
 /* The assembled-lines window (renderAssembled, mainwindow.cpp:2000-2052): RenderPCM::renderNewLine(STC007Line) on the lines the stitcher hands over -

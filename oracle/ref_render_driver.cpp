@@ -136,12 +136,15 @@ extern "C" long ref_vis_render_blocks(int kind, const sdv_block_rec *blocks, siz
     });
     ren.setLivePlay(false);
     ren.startSTC007DBFrame();
+    const bool m2 = (kind & 0x100) != 0;           /* SDV_VIS_M2_SAMPLES: the blocks of a stream in M2 sample format (STC007DataStitcher sets it on every block) */
+    kind &= 0xFF;
     ren.setLineCount(kind == 4 ? FrameAsmDescriptor::VID_PAL : FrameAsmDescriptor::VID_NTSC);
     STC007DataBlock b;
     size_t at = 0;
     for (size_t f = 0; f < n_frames; f++) {
         for (uint32_t i = 0; i < frame_blocks[f] && at < n_blocks; i++, at++) {
             if (!to_block(blocks[at], b)) return -2;
+            b.setM2Format(m2);
             ren.renderNewBlock(b);
         }
         ren.prepareNewFrame((uint32_t)f); ren.displayIsReady();

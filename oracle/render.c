@@ -164,19 +164,30 @@ long orc_vis_render_lines(int kind, const void *recs, size_t n_recs, uint32_t *c
 }
 
 /* ---- the data blocks window (renderNewBlock(STC007DataBlock), renderpcm.cpp:1770-2051) ------------------------------------------------ */
-static int16_t blk_sample(const sdv_block_rec *b, int w) { return b->resolution == SDV_RES_16BIT ? (int16_t)b->words[w] : (int16_t)(b->words[w] << 2); }  /* getSample, not M2 */
-static bool blk_near_silence(const sdv_block_rec *b, int w)     /* isNearSilence :417-446 */
+static int16_t blk_sample(const sdv_block_rec *b, int w, bool m2)   /* STC007DataBlock::getSample, stc007datablock.cpp:507-562 */
 {
-    const int16_t v = blk_sample(b, w), lim = b->resolution == SDV_RES_16BIT ? 4 : 16;
+    uint16_t v = b->words[w];
+    if (!m2) return b->resolution == SDV_RES_16BIT ? (int16_t)v : (int16_t)(v << 2);
+    if ((v & (1 << 13)) == 0) return (int16_t)(uint16_t)(v << 3);          /* higher range: value x 8 */
+    {
+        const bool positive = (v & (1 << 12)) == 0;
+        v = (uint16_t)(v & ~(1 << 13));
+        if (!positive) v |= (1 << 15) | (1 << 14) | (1 << 13);
+        return (int16_t)v;
+    }
+}
+static bool blk_near_silence(const sdv_block_rec *b, int w, bool m2)     /* isNearSilence :417-446 */
+{
+    const int16_t v = blk_sample(b, w, m2), lim = (b->resolution == SDV_RES_16BIT || m2) ? 4 : 16;
     return v < lim && v >= -lim;
 }
-static void stc_block(const sdv_block_rec *b, uint32_t *px)
+static void stc_block(const sdv_block_rec *b, uint32_t *px, bool m2)
 {
     const bool fix_p = b->audio_state == SDV_AUD_FIX_P, fix_q = b->audio_state == SDV_AUD_FIX_Q, broken = b->audio_state == SDV_AUD_BROKEN;
     const bool valid = (b->word_valid & 0x3F) == 0x3F;                                 /* isBlockValid: no audio word left invalid */
     const bool cwd_audio = (b->cwd_fixed & 0x3F) != 0;                                  /* isAudioAlteredByCWD */
-    const bool almost_silent = (blk_near_silence(b, 0) || blk_near_silence(b, 2) || blk_near_silence(b, 4)) &&
-                               (blk_near_silence(b, 1) || blk_near_silence(b, 3) || blk_near_silence(b, 5));
+    const bool almost_silent = (blk_near_silence(b, 0, m2) || blk_near_silence(b, 2, m2) || blk_near_silence(b, 4, m2)) &&
+                               (blk_near_silence(b, 1, m2) || blk_near_silence(b, 3, m2) || blk_near_silence(b, 5, m2));
     const bool on_seam = b->w_line[0] > b->w_line[7];                                   /* getStartLine() > getStopLine() */
     for (int i = 0; i < 6; i++) {                                                        /* the status bar :1793-1861 */
         uint32_t c = PX_BLK;
@@ -188,7 +199,7 @@ static void stc_block(const sdv_block_rec *b, uint32_t *px)
         for (int j = 0; j < 6; j++) *px++ = c;
     }
     for (int w = 0; w < 6; w++) {                                                        /* the six samples, 16 bits each :1862-1993 */
-        const uint16_t v = (uint16_t)blk_sample(b, w);
+        const uint16_t v = (uint16_t)blk_sample(b, w, m2);
         const bool crc = (b->line_crc >> w) & 1, cwd = (b->cwd_fixed >> w) & 1, wv = (b->word_valid >> w) & 1;
         for (int bit = 15; bit >= 0; bit--) {
             const bool one = (v >> bit) & 1;
@@ -213,12 +224,14 @@ long orc_vis_render_blocks(int kind, const sdv_block_rec *blocks, size_t n_block
                            uint32_t *out, size_t out_cap)
 {
     uint32_t w, h;
+    const bool m2 = (kind & 0x100) != 0;           /* SDV_VIS_M2_SAMPLES */
+    kind &= 0xFF;
     orc_vis_canvas_size(kind, &w, &h);
     if (kind != ORC_VIS_STC007_BLOCKS_NTSC && kind != ORC_VIS_STC007_BLOCKS_PAL) return -1;
     size_t at = 0;
     for (size_t f = 0; f < n_frames; f++) {          /* newFrameAssembled -> prepareNewFrame: the canvas goes out, the fill row back to 0 */
         for (uint32_t i = 0; i < frame_blocks[f] && at < n_blocks; i++, at++)
-            if (i < h) stc_block(&blocks[at], canvas + (size_t)i * w);
+            if (i < h) stc_block(&blocks[at], canvas + (size_t)i * w, m2);
         if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
     }
     return (long)n_frames;

@@ -299,12 +299,20 @@ __device__ inline void fill_body(const VisArgs &a, uint32_t block, int lane)
 struct BlkArgs {
     const sdv_block_rec *blocks; const uint32_t *frame_ofs; uint32_t n_frames; int kind;
     uint32_t *out; uint32_t *wmask; uint32_t wmask_stride;
+    int m2;                         /* the blocks hold M2 samples (SDV_VIS_M2_SAMPLES) */
 };
 enum { BK_FIX_P = 1u << 18, BK_FIX_Q = 1u << 19, BK_BROKEN = 1u << 20, BK_VALID = 1u << 21, BK_CWD_AUDIO = 1u << 22, BK_SILENT = 1u << 23, BK_SEAM = 1u << 24 };
-__device__ inline int16_t blk_sample(const sdv_block_rec &b, int w) { return b.resolution == SDV_RES_16BIT ? (int16_t)b.words[w] : (int16_t)(b.words[w] << 2); }   /* getSample (not M2) */
-__device__ inline bool blk_near_silence(const sdv_block_rec &b, int w)      /* isNearSilence, stc007datablock.cpp:417-446 */
+__device__ inline int16_t blk_sample(const sdv_block_rec &b, int w, bool m2)      /* STC007DataBlock::getSample, stc007datablock.cpp:507-562 */
 {
-    const int v = blk_sample(b, w), lim = b.resolution == SDV_RES_16BIT ? 4 : 16;
+    const uint32_t v = b.words[w];
+    if (!m2) return b.resolution == SDV_RES_16BIT ? (int16_t)v : (int16_t)(v << 2);
+    if ((v & (1u << 13)) == 0) return (int16_t)(uint16_t)(v << 3);      /* M2, higher range: the value times eight */
+    const uint32_t low = v & ~(1u << 13);                               /* lower range: bit 12 is the sign, extended */
+    return (int16_t)(uint16_t)((v & (1u << 12)) ? (low | 0xE000u) : low);
+}
+__device__ inline bool blk_near_silence(const sdv_block_rec &b, int w, bool m2)      /* isNearSilence, stc007datablock.cpp:417-446 */
+{
+    const int v = blk_sample(b, w, m2), lim = (b.resolution == SDV_RES_16BIT || m2) ? 4 : 16;
     return v < lim && v >= -lim;
 }
 __device__ inline uint32_t block_pixel(uint32_t s01, uint32_t s23, uint32_t s45, uint32_t fl, uint32_t x)
@@ -351,10 +359,12 @@ __device__ inline void draw_blocks_body(const BlkArgs &a, uint32_t block, int la
     uint32_t s01 = 0, s23 = 0, s45 = 0, fl = 0;
     if (live) {
         const sdv_block_rec b = a.blocks[lo + row];
-        s01 = (uint32_t)(uint16_t)blk_sample(b, 0) | ((uint32_t)(uint16_t)blk_sample(b, 1) << 16);
-        s23 = (uint32_t)(uint16_t)blk_sample(b, 2) | ((uint32_t)(uint16_t)blk_sample(b, 3) << 16);
-        s45 = (uint32_t)(uint16_t)blk_sample(b, 4) | ((uint32_t)(uint16_t)blk_sample(b, 5) << 16);
-        const bool silent = (blk_near_silence(b, 0) || blk_near_silence(b, 2) || blk_near_silence(b, 4)) && (blk_near_silence(b, 1) || blk_near_silence(b, 3) || blk_near_silence(b, 5));
+        const bool m2 = a.m2 != 0;
+        s01 = (uint32_t)(uint16_t)blk_sample(b, 0, m2) | ((uint32_t)(uint16_t)blk_sample(b, 1, m2) << 16);
+        s23 = (uint32_t)(uint16_t)blk_sample(b, 2, m2) | ((uint32_t)(uint16_t)blk_sample(b, 3, m2) << 16);
+        s45 = (uint32_t)(uint16_t)blk_sample(b, 4, m2) | ((uint32_t)(uint16_t)blk_sample(b, 5, m2) << 16);
+        const bool silent = (blk_near_silence(b, 0, m2) || blk_near_silence(b, 2, m2) || blk_near_silence(b, 4, m2)) &&
+                            (blk_near_silence(b, 1, m2) || blk_near_silence(b, 3, m2) || blk_near_silence(b, 5, m2));
         fl = (uint32_t)(b.line_crc & 0x3F) | ((uint32_t)(b.cwd_fixed & 0x3F) << 6) | ((uint32_t)(b.word_valid & 0x3F) << 12) |
              (b.audio_state == SDV_AUD_FIX_P ? BK_FIX_P : 0u) | (b.audio_state == SDV_AUD_FIX_Q ? BK_FIX_Q : 0u) | (b.audio_state == SDV_AUD_BROKEN ? BK_BROKEN : 0u) |
              ((b.word_valid & 0x3F) == 0x3F ? BK_VALID : 0u) | ((b.cwd_fixed & 0x3F) ? BK_CWD_AUDIO : 0u) | (silent ? BK_SILENT : 0u) | (b.w_line[0] > b.w_line[7] ? BK_SEAM : 0u);

@@ -148,6 +148,9 @@ def digest(canvases, mask):
 
 # ---- the data blocks window (sdv_vis_render_blocks; RenderPCM::renderNewBlock(STC007DataBlock), renderpcm.cpp:1770-2051) ---------------------------
 # name: (canvas, scenario of tests/stitch_cases.py whose blocks are drawn)
+M2_SAMPLES = 0x100              # SDV_VIS_M2_SAMPLES, or-ed to a block canvas
+for _k in (STC007_BLOCKS_NTSC, STC007_BLOCKS_PAL):
+    SIZE[_k | M2_SAMPLES] = SIZE[_k]
 BLOCK_CASES = {
     "blk_clean": (STC007_BLOCKS_NTSC, "ntsc_clean"),
     "blk_bad5": (STC007_BLOCKS_NTSC, "ntsc_bad5"),                      # P and Q corrections
@@ -158,8 +161,10 @@ BLOCK_CASES = {
     "blk_silent": (STC007_BLOCKS_NTSC, "ntsc_silent_bad"),
     "blk_drift": (STC007_BLOCKS_NTSC, "ntsc_drift"),                    # seams that do not fit: blocks marked on the seam
     "blk_pal_on_ntsc_canvas": (STC007_BLOCKS_NTSC, "pal_bad5"),         # more blocks per frame than the canvas has rows
+    "blk_m2": (STC007_BLOCKS_NTSC | M2_SAMPLES, "ntsc_res14_m2"),       # a stream in M2 sample format: getSample's other branch, silence on the 16-bit scale
+    "blk_m2_silent": (STC007_BLOCKS_NTSC | M2_SAMPLES, "ntsc_silent_bad"),
 }
-BLOCK_GOLDEN = ("blk_bad5", "blk_burst", "blk_pal", "blk_16bit")
+BLOCK_GOLDEN = ("blk_bad5", "blk_burst", "blk_pal", "blk_16bit", "blk_m2")
 
 
 def make_block_input(name):
