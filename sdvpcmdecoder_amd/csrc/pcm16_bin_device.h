@@ -709,53 +709,10 @@ __device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &
     const uint16_t to = (uint16_t)(c.scan_end - pixel_limit / 64);
     hist_add_range(lds, (uint16_t)(to - eighth), to);
 
-    uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
-    uint32_t black_lvl_count, white_lvl_count, temp_calc;
-    uint16_t search_lim;
-    bool black_level_detected, white_level_detected;
-    const SpreadLevels sl = spread_levels(c.ps, lds);
-    useful_low = low_scan_limit = br_black = sl.low;
-    useful_high = high_scan_limit = br_white = sl.high;
-    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
-    low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
-    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
-    temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
-    temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
-    search_lim = sl.most_frequent;
-    search_lim = search_lim / 64;
-    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
-    while (brt_lev <= low_scan_limit) {
-        if (lds.hist[brt_lev] > black_lvl_count) {
-            black_lvl_count = lds.hist[brt_lev];
-            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
-        }
-        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
-        brt_lev++;
-    }
-    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
-    if (black_level_detected) {
-        while (brt_lev >= high_scan_limit) {
-            if ((int)brt_lev < ((int)br_black + (int)c.ps.min_contrast)) break;
-            if (lds.hist[brt_lev] > white_lvl_count) {
-                white_lvl_count = lds.hist[brt_lev];
-                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
-            }
-            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
-            brt_lev--;
-        }
-    }
-    if (black_level_detected && white_level_detected) {
-        bool invalidate = false;
-        if (br_white < br_black) invalidate = true;
-        else if (((int)br_white - (int)br_black) < (int)c.ps.min_contrast) invalidate = true;
-        else if (sweep_flag && (((int)br_white - (int)br_black) < (int)c.ps.min_valid_crcs)) invalidate = true;       /* Binarizer::do_ref_lvl_sweep: left by the last line that got as far as :1104 */
-        else if (br_black > c.ps.max_black_lvl) invalidate = true;
-        else if (br_white < c.ps.min_white_lvl) invalidate = true;
-        if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
-    }
+    const BwLevels bw = bw_from_spread(c.ps, spread_levels(c.ps, lds), sweep_flag);      /* Binarizer::do_ref_lvl_sweep: left by the last line that got as far as :1104 */
     was_bw_scanned = true;
-    line.black = br_black; line.white = br_white;
-    line.bw_set = black_level_detected && white_level_detected;
+    line.black = bw.black; line.white = bw.white;
+    line.bw_set = bw.set;
     return line.bw_set;
 }
 

@@ -152,6 +152,7 @@ struct FrameArgs {
     struct SweepMemo *memo;         /* outcomes of reference-level sweeps and requests for more (stc007_sweep_device.h): the pool, ... */
     int32_t *memo_head;             /* ... [n_total] the newest entry of frame f (-1: none), ... */
     int32_t *memo_count; int32_t memo_cap;   /* ... entries handed out (may run past the capacity: those requests were dropped) */
+    unsigned long long *bw_memo;    /* [n_total * height] or NULL: what findBlackWhite found on a line, kept from one decode of a frame to the next (find_black_white) */
 };
 /* a dropped frame: VideoInFFMPEG::insertDummyFrame(false, true) sends its lines as empty VideoLines (vin_ffmpeg.cpp:367-522) */
 __device__ __forceinline__ bool frame_is_empty(const FrameArgs &a, int f) { return a.frame_flags && f < a.n_total && f != a.end_file_frame && (a.frame_flags[f] & SDV_FRAME_EMPTY); }
@@ -757,15 +758,19 @@ __device__ inline void hist_add_range(WaveLds &lds, int from, int to)
  * the first one ended - at max_black_lvl - and does nothing); getUsefullHighLevel (:2516-2557) = the highest such level from 255 down to
  * min_white_lvl (255 when there is none; its unfiltered pass stops at once on the level the filtered one found).  Needs the spread complete and
  * visible (hist_add_range ends with a barrier). */
-struct SpreadLevels { uint16_t most_frequent; uint8_t low, high; };
+struct SpreadLevels { uint16_t most_frequent; uint8_t low, high; const uint32_t *counts; /* the spread itself (LDS) */ };
+/* the pixel count of one level.  (Read from LDS: a scan that takes the counts out of the lanes' registers with v_readlane instead was measured at
+ * twice the time of this one - 89 000 against 49 000 cycles per findBlackWhite.) */
+__device__ __forceinline__ uint32_t spread_at(const SpreadLevels &s, int lev) { return s.counts[lev]; }
 __device__ inline SpreadLevels spread_levels(const sdv_bin_preset &ps, const WaveLds &lds)
 {
     const int lane = lane_id();
+    SpreadLevels r;
+    r.counts = lds.hist;
     uint32_t h[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) h[g] = lds.hist[64 * g + lane];
     uint32_t m = h[0] > h[1] ? h[0] : h[1]; { const uint32_t m2 = h[2] > h[3] ? h[2] : h[3]; m = m > m2 ? m : m2; }
-    SpreadLevels r;
     r.most_frequent = (uint16_t)uniu(wave_max_u32(m));
     const uint32_t min_freq = r.most_frequent / 64;
     M256 A;
@@ -780,8 +785,64 @@ __device__ inline SpreadLevels spread_levels(const sdv_bin_preset &ps, const Wav
     return r;
 }
 
+/* The second half of Binarizer::findBlackWhite (binarizer.cpp:3290-3473), the same for the three formats: the black peak upwards from the lowest
+ * useful level and the white peak downwards from the highest one - the running maximum, taken once it tops 1/64 of the most frequent count, until the
+ * scan is 10 % / 12 % of the range past it - and the checks of the pair (contrast, limits; sweep_flag = Binarizer::do_ref_lvl_sweep, sticky).  The
+ * counts come out of the lanes' registers (spread_at). */
+struct BwLevels { uint8_t black, white; bool set; };
+__device__ inline BwLevels bw_from_spread(const sdv_bin_preset &ps, const SpreadLevels &sl, bool sweep_flag)
+{
+    uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
+    uint32_t black_lvl_count, white_lvl_count, temp_calc;
+    uint16_t search_lim;
+    bool black_level_detected, white_level_detected;
+    useful_low = low_scan_limit = br_black = sl.low;
+    useful_high = high_scan_limit = br_white = sl.high;
+    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
+    low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
+    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
+    temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
+    temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
+    search_lim = sl.most_frequent;
+    search_lim = search_lim / 64;
+    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
+    while (brt_lev <= low_scan_limit) {
+        const uint32_t cnt = spread_at(sl, brt_lev);
+        if (cnt > black_lvl_count) {
+            black_lvl_count = cnt;
+            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
+        }
+        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
+        brt_lev++;
+    }
+    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
+    if (black_level_detected) {
+        while (brt_lev >= high_scan_limit) {
+            if ((int)brt_lev < ((int)br_black + (int)ps.min_contrast)) break;
+            const uint32_t cnt = spread_at(sl, brt_lev);
+            if (cnt > white_lvl_count) {
+                white_lvl_count = cnt;
+                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
+            }
+            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
+            brt_lev--;
+        }
+    }
+    if (black_level_detected && white_level_detected) {
+        bool invalidate = false;
+        if (br_white < br_black) invalidate = true;
+        else if (((int)br_white - (int)br_black) < (int)ps.min_contrast) invalidate = true;
+        else if (sweep_flag && (((int)br_white - (int)br_black) < (int)ps.min_valid_crcs)) invalidate = true;
+        else if (br_black > ps.max_black_lvl) invalidate = true;
+        else if (br_white < ps.min_white_lvl) invalidate = true;
+        if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
+    }
+    BwLevels r; r.black = br_black; r.white = br_white; r.set = black_level_detected && white_level_detected;
+    return r;
+}
+
 /* Binarizer::findSTC007BW (binarizer.cpp:2684-3070); leaves the brightness spread to analyse in lds.hist */
-__device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &line)
+__device__ inline bool find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &line)    /* returns: a white level was seen (the line's STOP-marker fields were written) */
 {
     uint8_t brt_lev, stage, br_mark_white, useful_low, useful_high, high_scan_limit, low_scan_limit, range_limit, bin_level, bin_low, bin_high, pv;
     uint16_t pixel, pixel_limit, ed_start, ed_end, search_lim;
@@ -794,13 +855,15 @@ __device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds 
     search_lim = (uint16_t)(b.scan_end - b.estimated_ppb * 20);
     hist_add_range(lds, search_lim, (int)b.scan_end + 1);
 
-    { const SpreadLevels sl = spread_levels(ps, lds); useful_low = low_scan_limit = sl.low; useful_high = high_scan_limit = br_mark_white = sl.high; }
+    const SpreadLevels sl = spread_levels(ps, lds);
+    useful_low = low_scan_limit = sl.low; useful_high = high_scan_limit = br_mark_white = sl.high;
     range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
     high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 4));
     bin_high = range_limit / 8;
     brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
     while (brt_lev >= high_scan_limit) {
-        if (lds.hist[brt_lev] > white_lvl_count) { white_lvl_count = lds.hist[brt_lev]; br_mark_white = brt_lev; white_level_detected = true; }
+        const uint32_t cnt = spread_at(sl, brt_lev);
+        if (cnt > white_lvl_count) { white_lvl_count = cnt; br_mark_white = brt_lev; white_level_detected = true; }
         if (white_level_detected) if (((int)br_mark_white - (int)brt_lev) >= (int)bin_high) break;
         brt_lev--;
     }
@@ -873,62 +936,38 @@ __device__ inline void find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds 
             }
         }
     }
+    return white_level_detected;
 }
 
-/* Binarizer::findBlackWhite (binarizer.cpp:3116-3473), STC-007 branch */
-__device__ inline bool find_black_white(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &line)
+/* Binarizer::findBlackWhite (binarizer.cpp:3116-3473), STC-007 branch.
+ * memo: this line's slot of FrameArgs::bw_memo, or NULL.  What the search finds depends on the line's pixels and on one bit of the chain (the sticky
+ * do_ref_lvl_sweep) - not on the tuning a frame was started from - and a frame of a worn tape is decoded several times (passes that wait for sweeps,
+ * rounds of the speculation): the first decode leaves the outcome in the slot, the later ones take it from there (47 000 cycles -> one 8-byte load).
+ * Slot: bit 0 present, 1 the do_ref_lvl_sweep it was made with, 2 levels set, 3 STOP-marker fields written; black << 8, white << 16, stage << 24, the two
+ * STOP-marker coordinates in the upper half. */
+__device__ inline bool find_black_white(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &line, unsigned long long *memo = nullptr)
 {
-    uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
-    uint32_t black_lvl_count, white_lvl_count, temp_calc;
-    uint16_t search_lim;
-    bool black_level_detected, white_level_detected;
-
-    find_stc007_bw(b, ps, lds, line);
-
-    const SpreadLevels sl = spread_levels(ps, lds);
-    useful_low = low_scan_limit = br_black = sl.low;
-    useful_high = high_scan_limit = br_white = sl.high;
-    range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
-    low_scan_limit = (uint8_t)(low_scan_limit + (range_limit / 3));
-    high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 3));
-    temp_calc = range_limit; temp_calc = temp_calc * 10 / 100; bin_low = (uint8_t)temp_calc;
-    temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
-    search_lim = sl.most_frequent;
-    search_lim = search_lim / 64;
-
-    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
-    while (brt_lev <= low_scan_limit) {
-        if (lds.hist[brt_lev] > black_lvl_count) {
-            black_lvl_count = lds.hist[brt_lev];
-            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
-        }
-        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
-        brt_lev++;
-    }
-    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
-    if (black_level_detected) {
-        while (brt_lev >= high_scan_limit) {
-            if ((int)brt_lev < ((int)br_black + (int)ps.min_contrast)) break;
-            if (lds.hist[brt_lev] > white_lvl_count) {
-                white_lvl_count = lds.hist[brt_lev];
-                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
-            }
-            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
-            brt_lev--;
+    if (memo) {
+        const uint2 m = *(const uint2 *)memo;
+        const uint32_t lo = uniu(m.x), hi = uniu(m.y);
+        if ((lo & 1u) && ((lo >> 1) & 1u) == (b.do_ref_lvl_sweep ? 1u : 0u)) {
+            b.was_bw_scanned = true;
+            line.black = (uint8_t)(lo >> 8); line.white = (uint8_t)(lo >> 16); line.bw_set = (lo & 4u) != 0;
+            if (lo & 8u) { line.mark_ed = (uint8_t)(lo >> 24); line.coords.stop = (int16_t)(hi & 0xFFFFu); line.m_sp_ed = (uint16_t)(hi >> 16); }
+            return line.bw_set;
         }
     }
-    if (black_level_detected && white_level_detected) {
-        bool invalidate = false;
-        if (br_white < br_black) invalidate = true;
-        else if (((int)br_white - (int)br_black) < (int)ps.min_contrast) invalidate = true;
-        else if (b.do_ref_lvl_sweep && (((int)br_white - (int)br_black) < (int)ps.min_valid_crcs)) invalidate = true;
-        else if (br_black > ps.max_black_lvl) invalidate = true;
-        else if (br_white < ps.min_white_lvl) invalidate = true;
-        if (invalidate) { black_level_detected = white_level_detected = false; br_black = useful_low; br_white = useful_high; }
-    }
+    const bool wrote_stop = find_stc007_bw(b, ps, lds, line);
+    const BwLevels bw = bw_from_spread(ps, spread_levels(ps, lds), b.do_ref_lvl_sweep);
     b.was_bw_scanned = true;
-    line.black = br_black; line.white = br_white;
-    line.bw_set = black_level_detected && white_level_detected;
+    line.black = bw.black; line.white = bw.white;
+    line.bw_set = bw.set;
+    if (memo && lane_id() == 0) {
+        const uint32_t lo = 1u | (b.do_ref_lvl_sweep ? 2u : 0u) | (bw.set ? 4u : 0u) | (wrote_stop ? 8u : 0u) | ((uint32_t)bw.black << 8) | ((uint32_t)bw.white << 16) | ((uint32_t)line.mark_ed << 24);
+        const uint32_t hi = (uint32_t)(uint16_t)line.coords.stop | ((uint32_t)line.m_sp_ed << 16);
+        uint2 m; m.x = lo; m.y = hi;
+        *(uint2 *)memo = m;
+    }
     return line.bw_set;
 }
 
@@ -1211,7 +1250,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
     for (;;) {
         stage_count++;
         if (state == STG_INPUT_ALL) {                       /* :774-931 */
-            if (!out.bw_set) { K1_T(t0_); find_black_white(b, ps, lds, out); K1_T(t1_); K1_ADD(9, t0_, t1_); }
+            if (!out.bw_set) { K1_T(t0_); find_black_white(b, ps, lds, out, hook.bw_slot); K1_T(t1_); K1_ADD(9, t0_, t1_); }
             if (!coords_valid(forced_coords)) out.coords = b.in_coord;
             out.ref_level = b.in_ref;
             out.ref_sweeped = false;
@@ -1231,7 +1270,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
                 } else state = !coords_valid(forced_coords) ? STG_INPUT_LEVEL : STG_REF_FIND;
             }
         } else if (state == STG_INPUT_LEVEL) {              /* :932-1072 */
-            if (!b.was_bw_scanned) { K1_T(t0_); find_black_white(b, ps, lds, out); K1_T(t1_); K1_ADD(9, t0_, t1_); }
+            if (!b.was_bw_scanned) { K1_T(t0_); find_black_white(b, ps, lds, out, hook.bw_slot); K1_T(t1_); K1_ADD(9, t0_, t1_); }
             if (!coords_valid(forced_coords)) coords_set(out.coords, (int16_t)b.scan_start, (int16_t)b.scan_end);
             out.ref_level = b.in_ref;
             out.ref_sweeped = false;
@@ -1249,7 +1288,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
                 }
             }
         } else if (state == STG_REF_FIND) {                 /* :1073-1390 */
-            if (!b.was_bw_scanned) find_black_white(b, ps, lds, out);
+            if (!b.was_bw_scanned) find_black_white(b, ps, lds, out, hook.bw_slot);
             if (!out.bw_set) state = STG_NO_GOOD;
             else {
                 b.do_ref_lvl_sweep = (b.mode == SDV_MODE_NORMAL) || (b.mode == SDV_MODE_INSANE);
@@ -1886,7 +1925,7 @@ __device__ inline void bits_to_words(uint64_t s_lo, uint64_t s_hi, uint16_t *w)
  * ladder_failed: no (depth, stage) of the ladder read the line with the inherited tuning - the general path need not try them again. */
 template <bool kMeasure>
 __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &g, const LaneConst &lc,
-                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec, bool *ladder_failed)
+                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec, bool *ladder_failed, unsigned long long *bw_slot = nullptr)
 {
     const sdv_bin_preset &ps = a.preset;
     Bin &b = v.bin;
@@ -1900,7 +1939,7 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         stc_clear(t);
         bin_line_geometry(tb, ps, a.width, a.doubled != 0);
         tb.was_bw_scanned = false;
-        if (!find_black_white(tb, ps, lds, t)) return false;
+        if (!find_black_white(tb, ps, lds, t, bw_slot)) return false;
         black = t.black; white = t.white; found_mark_ed = t.mark_ed; found_sp_ed = t.m_sp_ed;      /* (findSTC007BW leaves what it saw of the STOP marker in the line) */
         if (b.in_ref >= white || b.in_ref <= black) return false;
     }
@@ -2538,7 +2577,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             bool ladder_failed = false;
             bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed);
 #ifndef SDV_DBG_NO_MEASURE
-            if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2); }
+            if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2, a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr); }
 #endif
             K1_T(t_fl1);
             if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
@@ -2551,6 +2590,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     c.a = a; c.v = v;
                     c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
                     c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
+                    c.hook.bw_slot = a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr;
                     slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
 #ifdef SDV_K1_STAMPS
                     n_slow_lines++;

@@ -47,6 +47,7 @@ struct SweepHook {
     SweepMemo *memo; int32_t *head; int32_t *count; int32_t cap;
     int32_t frame; uint16_t row;
     bool pending;                   /* out: a sweep of this frame was asked for, the line went on without it */
+    unsigned long long *bw_slot;    /* in: the line's slot of FrameArgs::bw_memo, or NULL */
     bool ladder_failed;             /* in: the frame loop tried the ladder of reads with the tuning the line inherits (fast_line), nothing read */
     bool stop;                      /* out: ... by a line that had no reference level preset: everything behind it hangs on what the sweep finds, the pass over the frame ends here */
 };
