@@ -289,7 +289,7 @@ __device__ inline void walk_rows_parallel(P16Lds &lds, int nl, int nr, int l0, i
     int last_read = -1;
     if (lane == 0) stats_reset(lds.lstats, MAX_COLL_CRCS);
     if (lane < P16_SEARCH_STEP_CNT) sw[SW_LEFT + lane] = sweep_blank();
-    __syncthreads();
+    SDV_WAVE_SYNC();
     const uint32_t colmask = nr >= 32 ? 0xFFFFFFFFu : ((1u << nr) - 1u);
     for (int row = 0; row < nl; row++) {
         if (!((rows_live >> row) & 1ull)) { last_read = (row * nr + nr - 1) * P16_SUBLINES + 2; continue; }
@@ -363,7 +363,7 @@ __device__ inline void walk_rows_parallel(P16Lds &lds, int nl, int nr, int l0, i
             }
         }
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     if (lane == 0) {
         uint8_t left_ofs = 0xFF;
         if (valid_left > 0) {
@@ -404,7 +404,7 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
     const int n_reads = nl * nr * P16_SUBLINES;
     const bool entry_forced = l.forced_bad;
     /* every read of the grid, as if the line object came to it clean: (row, col, part) in the reference's order */
-    __syncthreads();
+    SDV_WAVE_SYNC();
     for (int q = lane; q < n_reads; q += 64) {
         const int pair = q / P16_SUBLINES, part = q - pair * P16_SUBLINES, row = pair / nr, col = pair - row * nr;
         L16 t = l;
@@ -417,7 +417,7 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
         lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24)
                       | ((uint32_t)((t.forced_bad && !entry_forced) ? 1 : 0) << 25) | ((uint32_t)(picked ? 1 : 0) << 26);
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     /* rows of the grid in which something happens: a read that is valid, or a Bit Picker collision (the walk below leaves every other row
      * as it finds it, apart from noting its last read) */
     uint64_t rows_live;
@@ -549,10 +549,10 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
         if (valid_left > 0) { lds.vote[1] = sw[SW_LEFT + left_ofs].start; lds.vote[2] = sw[SW_LEFT + left_ofs].stop; }
         lds.vote[3] = last_read; lds.vote[4] = coll_read;
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     const bool found = lds.vote[0] != 0;
     const int f_start = lds.vote[1], f_stop = lds.vote[2], last_read = lds.vote[3], coll_read = lds.vote[4];
-    __syncthreads();
+    SDV_WAVE_SYNC();
     /* what the last read the reference made leaves in the line object: forced bad if a collision happened before it */
     if (last_read >= 0) {
         const int pair = last_read / P16_SUBLINES, part = last_read - pair * P16_SUBLINES, row = pair / nr, col = pair - row * nr;
@@ -644,9 +644,9 @@ __device__ inline void calc_ref_level_by_sweep_p16(BinCtx &c, const Bin &b, uint
     const uint8_t fast_ref = pick_center_ref_level(c.ps, l.black, l.white);
     const uint8_t blk1 = (uint8_t)(l.black + 1), wht1 = (uint8_t)(l.white - 1);
     hyst_lim = 0; shift_lim = SHIFT_STAGES_SAFE;
-    __syncthreads();
+    SDV_WAVE_SYNC();
     { const SweepEnt z = sweep_blank(); for (int i = lane; i < 256; i += 64) rs_store(lds.w, i, z); }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     sweep_ref_level_p16(c, b, part, scan_done, lds, l, vl_doubled);
     rs_unpack(lds.w);
     uint8_t span_res = SPAN_NOT_FOUND, valid_crc_cnt = 0;
@@ -661,7 +661,7 @@ __device__ inline void calc_ref_level_by_sweep_p16(BinCtx &c, const Bin &b, uint
         }
         lds.w.crc_stats[0].idx = (uint8_t)((first_cnt > 0 ? 1 : 0) | (valid_crc_cnt > 0 ? 2 : 0));
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     const bool had_any = (lds.w.crc_stats[0].idx & 1) != 0, still_valid = (lds.w.crc_stats[0].idx & 2) != 0;
     if (had_any && still_valid) {
         if (lds.w.crc_stats[0].result < c.ps.min_valid_crcs) span_res = SPAN_TOO_NARROW;
@@ -693,7 +693,7 @@ __device__ inline void calc_ref_level_by_sweep_p16(BinCtx &c, const Bin &b, uint
         }
         hyst_lim = 0; shift_lim = SHIFT_STAGES_MIN;            /* HYST_DEPTH_MIN */
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 
 /* findBlackWhite (binarizer.cpp:3116-3473) over the PCM-16x0 windows of the line (findPCM16X0BW, :2603-2681: one in each third) */
@@ -852,7 +852,7 @@ __device__ inline void line16_body(const LineArgs16 &a, P16Lds &lds, size_t li)
         process_line_p16<kInsane>(c, b, a.coord_search != 0, (uint8_t)(PART_LEFT + sub), scan_done, lds, out, a.doubled != 0);
         emit_rec(out, a.frame_number, (uint16_t)(a.first_line + li * a.line_step), a.doubled != 0, &a.out[3 * li + (size_t)sub]);
         if (a.scan_done && lane_id() == 0) a.scan_done[3 * li + (size_t)sub] = scan_done ? 1 : 0;
-        __syncthreads();
+        SDV_WAVE_SYNC();
     }
 }
 

@@ -84,7 +84,7 @@ __device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, i
                 q.pad[0] = scan_done ? 1 : 0;
                 q.pad[1] = out.bw_set ? 1 : 0;
                 if (lane_id() == 0) a16.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k] = q;
-                __syncthreads();
+                SDV_WAVE_SYNC();
             }
             return;
         }
@@ -243,17 +243,17 @@ __device__ inline void post_part16(V2D16 &w, const FrameArgs &a, Lds16 &lds, L16
         }
         if (crc_valid_ignore_forced(wl)) {
             const uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
-            __syncthreads();
+            SDV_WAVE_SYNC();
             {   /* the window moves up by one when it is full: every lane carries one entry (no serial chain through LDS) */
                 const int ln = lane_id();
                 const bool full = v.n_last == LV16;
                 const uint32_t moved = (full && ln < LV16 - 1) ? lds.lv_keys16[ln + 1] : 0u;
-                __syncthreads();
+                SDV_WAVE_SYNC();
                 if (full && ln < LV16 - 1) lds.lv_keys16[ln] = moved;
                 if (ln == 0) lds.lv_keys16[full ? LV16 - 1 : v.n_last] = key;
             }
             if (v.n_last < LV16) v.n_last++;
-            __syncthreads();
+            SDV_WAVE_SYNC();
             fv_keys[v.nfv++] = key;
             if (a.coordinate_damper && !ps.en_force_coords && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
                 Coords target; coords_clear(target);
@@ -481,9 +481,9 @@ __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, cons
     v.nfv += n_sub;
     {   /* the window of last valid coordinates: n_sub more entries of the same key */
         int fill_to = v.n_last + n_sub; if (fill_to > LV16) fill_to = LV16;
-        __syncthreads();
+        SDV_WAVE_SYNC();
         if (lane >= v.n_last && lane < fill_to) lds.lv_keys16[lane] = key;
-        __syncthreads();
+        SDV_WAVE_SYNC();
         v.n_last = fill_to;
     }
     {   /* what the last line leaves behind: its words for the duplicate test, and the line object of its last part */
@@ -619,6 +619,7 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
     v.q_pcm_odd = (uint16_t)(v.q_pcm_odd / P16_SUBLINES); v.q_pcm_even = (uint16_t)(v.q_pcm_even / P16_SUBLINES);
     v.q_bad_odd = (uint16_t)(v.q_bad_odd / P16_SUBLINES); v.q_bad_even = (uint16_t)(v.q_bad_even / P16_SUBLINES);
     {   /* the median of the frame's valid coordinates is what v2d_end_frame pushes into long_valid_coords (:1668-1682) */
+        __syncthreads();        /* (keys stored to global memory by other lanes than the ones that read them now) */
         uint32_t mk = 0; bool pushed = median_keys(fv_keys, v.nfv, &mk);
         if (pushed) { const Coords mc = key_to_coords(mk, false); pushed = coords_valid(mc); }
         if (lane_id() == 0) { uint2 m; m.x = pushed ? mk : 0u; m.y = pushed ? 1u : 0u; a16.frame_med[f] = m; }

@@ -444,7 +444,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
     const int n_cand = nl * nr;
     const bool entry_forced = l.forced_bad;
     uint32_t first_coll = 0xFFFFFFFFu;
-    __syncthreads();
+    SDV_WAVE_SYNC();
     for (int q = lane; q < n_cand; q += 64) {
         const int row = q / nr, col = q - row * nr;
         L1 t = l;
@@ -456,7 +456,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
         if (t.forced_bad && !entry_forced && first_coll == 0xFFFFFFFFu) first_coll = (uint32_t)q;
     }
     first_coll = wave_min_u32(first_coll);
-    __syncthreads();
+    SDV_WAVE_SYNC();
     /* rows of the grid with a read that is valid (behind the first collision nothing is) */
     uint64_t rows_live;
     {
@@ -469,7 +469,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
         uint8_t valid_left = 0;         /* lane 0's */
         if (lane == 0) stats_reset(lds.lstats, MAX_COLL_CRCS);
         if (lane < P1_SEARCH_STEP_CNT) lds.w.sweep[P1_LEFT_BASE + lane] = sweep_blank();
-        __syncthreads();
+        SDV_WAVE_SYNC();
         for (int row = 0; row < nl; row++) {
             SweepEnt le = sweep_blank(); le.result = REF_BAD_CRC; le.crc = 0; le.hyst = HYST_DEPTH_MAX; le.shift = SHIFT_STAGES_MAX;     /* nothing reads in this row, or its vote is void */
             if ((rows_live >> row) & 1ull) {
@@ -495,7 +495,7 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
             }
             if (lane == 0) lds.w.sweep[P1_LEFT_BASE + row] = le;
         }
-        __syncthreads();
+        SDV_WAVE_SYNC();
         if (lane == 0) {
             uint8_t left_ofs = 0xFF;
             if (valid_left > 0) {
@@ -508,10 +508,10 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
             if (valid_left > 0) { lds.vote[1] = lds.w.sweep[left_ofs].start; lds.vote[2] = lds.w.sweep[left_ofs].stop; }
         }
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     const bool found = lds.vote[0] != 0;
     const int f_start = lds.vote[1], f_stop = lds.vote[2];
-    __syncthreads();
+    SDV_WAVE_SYNC();
     /* what the last candidate leaves in the line object, forced bad if a collision happened on the way */
     if (n_cand > 0) {
         if (first_coll != 0xFFFFFFFFu && first_coll < (uint32_t)(n_cand - 1)) l.forced_bad = true;
@@ -572,16 +572,16 @@ __device__ inline void rs_unpack(WaveLds &w)
 {
     const int lane = lane_id();
     uint32_t a[4], b[4];
-    __syncthreads();
+    SDV_WAVE_SYNC();
     for (int k = 0; k < 4; k++) { a[k] = w.hist[lane + 64 * k]; b[k] = rs_words(w)[lane + 64 * k]; }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     for (int k = 0; k < 4; k++) {
         SweepEnt e = sweep_blank();
         e.crc = (uint16_t)(a[k] & 0xFFFF); e.hyst = (uint8_t)((a[k] >> 16) & 0xF); e.shift = (uint8_t)((a[k] >> 20) & 0xF); e.result = (uint8_t)(a[k] >> 24);
         e.start = (int16_t)(b[k] & 0xFFFF); e.stop = (int16_t)(b[k] >> 16);
         w.sweep[lane + 64 * k] = e;
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 
 /* Binarizer::sweepRefLevel (binarizer.cpp:3551-3817) with a PCM1Line as the trial line.  The first-try read from the preset
@@ -628,9 +628,9 @@ __device__ inline void calc_ref_level_by_sweep_p1(BinCtx &c, const Bin &b, P1Lds
     const uint8_t fast_ref = pick_center_ref_level(c.ps, l.black, l.white);
     const uint8_t blk1 = (uint8_t)(l.black + 1), wht1 = (uint8_t)(l.white - 1);
     hyst_lim = 0; shift_lim = SHIFT_STAGES_SAFE;
-    __syncthreads();
+    SDV_WAVE_SYNC();
     { const SweepEnt z = sweep_blank(); for (int i = lane; i < 256; i += 64) rs_store(lds.w, i, z); }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     sweep_ref_level_p1(c, b, lds, l, vl_doubled);
     rs_unpack(lds.w);
     uint8_t span_res = SPAN_NOT_FOUND, valid_crc_cnt = 0;
@@ -645,7 +645,7 @@ __device__ inline void calc_ref_level_by_sweep_p1(BinCtx &c, const Bin &b, P1Lds
         }
         lds.w.crc_stats[0].idx = (uint8_t)((first_cnt > 0 ? 1 : 0) | (valid_crc_cnt > 0 ? 2 : 0));
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
     const bool had_any = (lds.w.crc_stats[0].idx & 1) != 0, still_valid = (lds.w.crc_stats[0].idx & 2) != 0;
     if (had_any && still_valid) {
         if (lds.w.crc_stats[0].result < c.ps.min_valid_crcs) span_res = SPAN_TOO_NARROW;
@@ -677,7 +677,7 @@ __device__ inline void calc_ref_level_by_sweep_p1(BinCtx &c, const Bin &b, P1Lds
         }
         hyst_lim = 0; shift_lim = SHIFT_STAGES_MIN;            /* HYST_DEPTH_MIN */
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 
 /* findBlackWhite (binarizer.cpp:3116-3473) over the PCM-1 part of the line (findPCM1BW, :2560-2600) */
@@ -719,13 +719,13 @@ __device__ inline void emit_rec(const L1 &l, uint32_t frame, uint16_t line_no, b
 __device__ inline void stage_row(uint8_t *px, const uint8_t *row, int width)
 {
     const int lane = lane_id();
-    __syncthreads();
+    SDV_WAVE_SYNC();
     if (((((uintptr_t)row) | (uintptr_t)width) & 15) == 0) {            /* 16 bytes per lane */
         for (int p = lane * 16; p < width; p += 64 * 16) *(uint4 *)&px[p] = *(const uint4 *)(row + p);
     } else {
         for (int p = lane; p < width; p += 64) px[p] = row[p];
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 
 /* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, for the video line staged in lds.w.px: the stage machine from
@@ -886,9 +886,9 @@ __device__ inline void lines_kernel_body(const sdvp1b::LineArgs1 &a, sdvp1b::P1L
         int i = (int)blockIdx.x;
         while (i < n) {
             sdvp1b::line_body<kInsane>(a, lds, (size_t)a.list[i]);
-            __syncthreads();
+            SDV_WAVE_SYNC();
             if (sdv::lane_id() == 0) lds.vote[3] = (int)gridDim.x + atomicAdd(&a.counters[1], 1);
-            __syncthreads();
+            SDV_WAVE_SYNC();
             i = lds.vote[3];
         }
     } else {

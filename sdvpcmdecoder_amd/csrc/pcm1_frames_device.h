@@ -93,7 +93,7 @@ __device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int
                 if (crc_valid(out)) { q.start = out.coords.start; q.stop = out.coords.stop; q.ref = out.ref_level; q.valid = 1; }
                 q.pad[1] = out.bw_set || out.service == SDV_SRV_HEADER_LINE ? 1 : 0;      /* (a Header line is only recognised behind the levels) */
                 if (lane_id() == 0) a1.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k] = q;
-                __syncthreads();
+                SDV_WAVE_SYNC();
             }
             return;
         }
@@ -265,17 +265,17 @@ __device__ inline void v2d1_post_line(V2D1 &w, const FrameArgs &a, WaveLds &lds,
         }
         if (crc_valid_ignore_forced(wl)) {
             const uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
-            __syncthreads();
+            SDV_WAVE_SYNC();
             {   /* the window moves up by one when it is full: every lane carries one entry (no serial chain through LDS) */
                 const int ln = lane_id();
                 const bool full = v.n_last == COORD_HISTORY_DEPTH;
                 const uint32_t moved = (full && ln < COORD_HISTORY_DEPTH - 1) ? lds.lv_keys[ln + 1] : 0u;
-                __syncthreads();
+                SDV_WAVE_SYNC();
                 if (full && ln < COORD_HISTORY_DEPTH - 1) lds.lv_keys[ln] = moved;
                 if (ln == 0) lds.lv_keys[full ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
             }
             if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
-            __syncthreads();
+            SDV_WAVE_SYNC();
             fv_keys[v.nfv++] = key;
             if (a.coordinate_damper && !ps.en_force_coords && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
                 Coords target; coords_clear(target);
@@ -489,9 +489,9 @@ __device__ inline int batch1(V2D1 &w, const FrameArgs &a, WaveLds &lds, const Le
     v.nfv += n_ok;
     {
         int fill_to = v.n_last + n_ok; if (fill_to > COORD_HISTORY_DEPTH) fill_to = COORD_HISTORY_DEPTH;
-        __syncthreads();
+        SDV_WAVE_SYNC();
         if (lane >= v.n_last && lane < fill_to) lds.lv_keys[lane] = key;
-        __syncthreads();
+        SDV_WAVE_SYNC();
         v.n_last = fill_to;
     }
     {   /* what the last line leaves behind */
@@ -572,6 +572,7 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
     v2d1_service_line(w, a, wl, SDV_SRV_END_FRAME);
     v.q_odd = v.q_even = P1_LINES_PF;                               /* :1638-1642 */
     {   /* the median of the frame's valid coordinates is what v2d_end_frame pushes into long_valid_coords (:1668-1682) */
+        __syncthreads();        /* (keys stored to global memory by other lanes than the ones that read them now) */
         uint32_t mk = 0; bool pushed = median_keys(fv_keys, v.nfv, &mk);
         if (pushed) { const Coords mc = key_to_coords(mk, false); pushed = coords_valid(mc); }
         if (lane_id() == 0) { uint2 m; m.x = pushed ? mk : 0u; m.y = pushed ? 1u : 0u; a1.frame_med[f] = m; }

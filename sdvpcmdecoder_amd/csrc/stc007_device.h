@@ -192,6 +192,16 @@ struct Bin {                        /* Binarizer (binarizer.h:306-337) */
 struct Markers { uint8_t st_stage, ed_stage; uint16_t st1s, st1e, st3e, ed_start, ed_end; bool has_start; };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+/* Every kernel of the binarize paths is a workgroup of ONE wavefront.  What its phases need between them is that the LDS writes of some lanes come
+ * before the LDS reads of others - which the LDS gives a wave for nothing (its instructions are carried out in order); the compiler only has to keep
+ * the order.  __syncthreads() does more: it waits for every memory operation the wave has in flight (s_waitcnt vmcnt(0)) - the next row on its way
+ * from HBM, the last record on its way out - before every phase of every line: a line taken one at a time cost 38 000 cycles, 33 000 of them
+ * waiting at these barriers.  SDV_WAVE_SYNC orders without waiting (as stc007_stitch_device.h has done since round 2). */
+#ifdef SDV_EMU
+#define SDV_WAVE_SYNC() __syncthreads()
+#else
+#define SDV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 #ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch (0..7 the frame loop, 8..15 the general path) */
 __device__ unsigned long long sdv_k1_cycles[16];
 #define K1_T(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -738,15 +748,15 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) { for (int d = 1; d < 64; d 
 
 __device__ inline void hist_clear(WaveLds &lds)
 {
-    __syncthreads();
+    SDV_WAVE_SYNC();
     for (int i = lane_id(); i < 256; i += 64) lds.hist[i] = 0;
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 /* adds pixels [from, to) (ascending) to the histogram, lanes striding */
 __device__ inline void hist_add_range(WaveLds &lds, int from, int to)
 {
     for (int p = from + lane_id(); p < to; p += 64) atomicAdd(&lds.hist[lds.px[p]], 1u);
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 
 /* brightness-spread counters are uint16_t in the reference (binarizer.cpp:3125): a line is at most
@@ -1361,32 +1371,41 @@ struct V2D {
 };
 
 /* VideoToDigital::medianCoordinates (videotodigital.cpp:348-371): element of rank n/2 under
- * CoordinatePair::operator<.  keys[] readable by every lane (LDS or own global stores). */
+ * CoordinatePair::operator<.  keys[] readable by every lane (LDS or own global stores).
+ * The keys are 32-bit numbers in that order, so the element of a given rank is found bit by bit from the top (a radix select): per bit the lanes
+ * count, among the keys that still match the bits chosen so far, those with a 0 there - 32 passes over n / 64 keys per lane, whatever n is.
+ * (Through round 3 every lane ranked its key against all n: n * n / 64 reads - a frame whose lines had found two different windows, 486 keys,
+ * took 14 million cycles for this one number and held its whole launch up; the sub-line lists of PCM-16x0 are three times as long.) */
 __device__ inline bool median_keys(const uint32_t *keys, int n, uint32_t *out_key)
 {
     if (n <= 0) return false;
-    int lane = lane_id();
+    const int lane = lane_id();
     /* common case: every entry identical (steady tuning) -> one ballot */
-    uint32_t k0 = keys[0];
+    const uint32_t k0 = keys[0];
     bool differs = false;
     for (int j = lane; j < n; j += 64) differs = differs || (keys[j] != k0);
     if (__ballot(differs) == 0ull) { *out_key = uniu(k0); return true; }
-    int target = n / 2;
-    uint32_t res = 0;
-    for (int base = 0; base < n; base += 64) {          /* uniform trip count */
-        int i = base + lane;
-        bool hit = false; uint32_t ki = 0;
-        if (i < n) {
-            ki = keys[i];
-            int less = 0, leq = 0;
-            for (int j = 0; j < n; j++) { uint32_t kj = keys[j]; less += (kj < ki); leq += (kj <= ki); }
-            hit = (less <= target) && (target < leq);
-        }
-        uint64_t m = __ballot(hit);
-        if (m != 0ull) { res = uniu((uint32_t)__shfl((int)ki, __ffsll((unsigned long long)m) - 1)); *out_key = res; return true; }
+    uint32_t target = (uint32_t)(n / 2);
+    if (n <= 64) {              /* the short histories (9 lines, 16 frames): a lane per key, its rank by one pass over the others */
+        const uint32_t ki = keys[lane < n ? lane : 0];
+        uint32_t less = 0, leq = 0;
+        for (int j = 0; j < n; j++) { const uint32_t kj = keys[j]; less += (kj < ki); leq += (kj <= ki); }
+        const uint64_t m = __ballot(lane < n && less <= target && target < leq);
+        *out_key = uniu((uint32_t)__shfl((int)ki, m ? __ffsll((unsigned long long)m) - 1 : 0));
+        return m != 0ull;
     }
-    *out_key = res;
-    return false;
+    uint32_t prefix = 0, mask = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        uint32_t zeros = 0;
+        for (int j = lane; j < n; j += 64) { const uint32_t k = keys[j]; zeros += ((k & mask) == prefix && ((k >> bit) & 1u) == 0u) ? 1u : 0u; }
+        uint32_t total = 0;     /* the lanes' counts (< 64 each for n < 4096) summed bit plane by bit plane: six ballots instead of six shuffles */
+#pragma unroll
+        for (int q = 0; q < 6; q++) total += (uint32_t)__popcll(__ballot((zeros >> q) & 1u)) << q;
+        if (target >= total) { target -= total; prefix |= 1u << bit; }
+        mask |= 1u << bit;
+    }
+    *out_key = prefix;
+    return true;
 }
 
 __device__ inline Coords key_to_coords(uint32_t k, bool doubled) { Coords c; c.start = key_start(k); c.stop = key_stop(k); c.doubled = doubled; return c; }
@@ -1464,13 +1483,13 @@ __device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, L
         if (crc_valid_ignore_forced(wl)) {
             uint32_t key = coords_key(wl.coords.start, wl.coords.stop);
             /* last_valid_coord_list: push_back, keep the newest COORD_HISTORY_DEPTH */
-            __syncthreads();
+            SDV_WAVE_SYNC();
             if (lane_id() == 0) {
                 if (v.n_last == COORD_HISTORY_DEPTH) for (int i = 0; i < COORD_HISTORY_DEPTH - 1; i++) lds.lv_keys[i] = lds.lv_keys[i + 1];
                 lds.lv_keys[v.n_last == COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
             }
             if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
-            __syncthreads();
+            SDV_WAVE_SYNC();
             fv_keys[v.nfv++] = key;
             if (a.coordinate_damper && !ps.en_force_coords && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
                 Coords target; coords_clear(target);
@@ -1523,6 +1542,7 @@ __device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, L
 __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, uint32_t frame_no, const uint32_t *fv_keys, const uint32_t *fi_keys, sdv_frame_stats *out,
                                   const uint32_t *uniform_key = nullptr)
 {
+    __syncthreads();            /* the coordinate keys of the frame's lines were stored to global memory by other lanes than the ones that read them below: wait for them */
     if (v.q_pcm_odd > v.q_odd) v.q_pcm_odd = v.q_odd;
     if (v.q_pcm_even > v.q_even) v.q_pcm_even = v.q_even;
     if (v.q_bad_odd > v.q_odd) v.q_bad_odd = v.q_odd;
@@ -1533,13 +1553,13 @@ __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, u
     if (uniform_key && v.nfv > 0) v.frame_avg = key_to_coords(*uniform_key, a.doubled != 0);
     else if (median_keys(fv_keys, v.nfv, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
     if (coords_valid(v.frame_avg)) {
-        __syncthreads();
+        SDV_WAVE_SYNC();
         if (lane_id() == 0) {
             if (v.n_long == COORD_LONG_HISTORY) for (int i = 0; i < COORD_LONG_HISTORY - 1; i++) lds.long_keys[i] = lds.long_keys[i + 1];
             lds.long_keys[v.n_long == COORD_LONG_HISTORY ? COORD_LONG_HISTORY - 1 : v.n_long] = coords_key(v.frame_avg.start, v.frame_avg.stop);
         }
         if (v.n_long < COORD_LONG_HISTORY) v.n_long++; else v.long_pushes++;
-        __syncthreads();
+        SDV_WAVE_SYNC();
     } else {
         coords_clear(v.frame_avg);
         if (median_keys(fi_keys, v.nfi, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
@@ -1719,7 +1739,7 @@ __device__ inline void row_prefetch(RowPrefetch &pf, const uint8_t *row, int wid
 }
 __device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width)
 {
-    __syncthreads();
+    SDV_WAVE_SYNC();
     int lane = lane_id();
     const uint8_t *row = pf.row;
     if (pf.vec) {
@@ -1730,7 +1750,7 @@ __device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width
     } else {
         for (int i = lane; i < width; i += 64) lds.px[i] = row[i];
     }
-    __syncthreads();
+    SDV_WAVE_SYNC();
 }
 
 __device__ inline void emit_record(const Line &wl, sdv_line_rec *dst)
@@ -1944,7 +1964,10 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         if (b.in_ref >= white || b.in_ref <= black) return false;
     }
     FastBits fb;
+    K1_T(t_fd0);
     if (!fast_decode(a, lds, b, black, white, g, lc, fb)) { *ladder_failed = !kMeasure; return false; }
+    K1_T(t_fd1);
+    K1_ADD(6, t_fd0, t_fd1);
     if (fb.ctrl_block) return false;
     const int lane = lane_id();
     uint16_t w[9];
@@ -1971,13 +1994,13 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
     }
     {
         uint32_t key = coords_key(b.in_coord.start, b.in_coord.stop);
-        __syncthreads();
+        SDV_WAVE_SYNC();
         if (lane == 0) {
             if (v.n_last == COORD_HISTORY_DEPTH) for (int i = 0; i < COORD_HISTORY_DEPTH - 1; i++) lds.lv_keys[i] = lds.lv_keys[i + 1];
             lds.lv_keys[v.n_last == COORD_HISTORY_DEPTH ? COORD_HISTORY_DEPTH - 1 : v.n_last] = key;
         }
         if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
-        __syncthreads();
+        SDV_WAVE_SYNC();
         fv_keys[v.nfv++] = key;
         if (a.coordinate_damper && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
             Coords target; coords_clear(target);
@@ -2395,7 +2418,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
                 emit_record(wl, rec++);
                 start_field = 1; start_idx = 0;
-                __syncthreads();
+                SDV_WAVE_SYNC();
                 for (int c = 0; c < n_chunks && whole; c++) {
                     const int cn1 = n1 - 64 * c < 64 ? (n1 - 64 * c > 0 ? n1 - 64 * c : 0) : 64;
                     if (cn1 <= 0) break;
@@ -2406,7 +2429,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     if (n_ok1 > 0) { batch_finish(a, v, bl, n_ok1, frame_no, (uint16_t)(2 + 2 * (64 * c)), fv_keys, rec); rec += n_ok1; }
                     if (n_ok1 < cn1) { whole = false; start_idx = 64 * c + n_ok1; }
                 }
-                __syncthreads();
+                SDV_WAVE_SYNC();
                 if (whole) {
                     line_num = (uint16_t)(2 + 2 * n1);
                     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
@@ -2475,11 +2498,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                                 pf.vq[i - 1] = ((const uint4 *)pf.rowq[i - 1])[pf.i0];
                             }
                         pf.nq = NR - 1;
-                        __syncthreads();
+                        SDV_WAVE_SYNC();
                         ((uint4 *)lds.px)[lane] = pf.v0;
 #pragma unroll
                         for (int u = 0; u < NL - 1; u++) ((uint4 *)lds.px)[64 * (u + 1) + lane] = pf.vq[u];
-                        __syncthreads();
+                        SDV_WAVE_SYNC();
                         {   /* the queue moves up by NL rows and NL new rows are requested at its end: one pointer step inside the field,
                              * past its end one of the rows looked up per batch */
                             const uint8_t *prev = NR > 1 ? pf.rowq[NR - 2] : pf.row;       /* the last row requested so far */
@@ -2524,9 +2547,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 }
                 for (; !redo && j < nb; j++) {
                     {   /* row_commit / row_prefetch of the plain case, without their case distinctions */
-                        __syncthreads();
+                        SDV_WAVE_SYNC();
                         ((uint4 *)lds.px)[lane] = pf.v0;
-                        __syncthreads();
+                        SDV_WAVE_SYNC();
                         int k = idx + j + 1;                    /* next row in decode order */
                         if (pf.nq > 0) {                        /* already fetched by the multi-line loop */
                             pf.row = pf.rowq[0]; pf.v0 = pf.vq[0];
@@ -2581,6 +2604,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 #endif
             K1_T(t_fl1);
             if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
+            if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
             if (!took_fast) {
                 if (kLean) {
                     if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
@@ -2646,7 +2670,7 @@ __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv:
     __shared__ sdv::WaveLds lds;
 #ifdef SDV_EMU_POISON_LDS       /* (test aid: the LDS of a real workgroup starts with whatever the last one left there) */
     if (sdv::lane_id() == 0) memset(&lds, 0xA7, sizeof(lds));
-    __syncthreads();
+    SDV_WAVE_SYNC();
 #endif
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f);

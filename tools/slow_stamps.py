@@ -8,8 +8,19 @@ from sdvpcmdecoder_amd import Engine, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 what = sys.argv[2] if len(sys.argv) > 2 else "both"
 dev = "cuda"
-pal, _ = synth.stc007_frames_torch(n, seed=7, device=dev, width=720, height=576, lines_per_field=294, noise_sigma=4.0, cyclic=True)
-lum = pal.clone()
+if what == "jumps":     # the window-jump tape of bench.py (damaged_tape.window_jumps): NTSC, the picture moves sideways at 16 places per 10 000 frames
+    import numpy as np
+    pal, _ = synth.stc007_frames_torch(n, seed=2, device=dev, noise_sigma=4.0, cyclic=True)
+    lum = pal.clone()
+    rng_d = np.random.default_rng(16); at = 0
+    for f_ in sorted(rng_d.choice(np.arange(50, n - 50), size=max(1, n // 625), replace=False)):
+        to = at
+        while to == at:
+            to = int(rng_d.integers(-8, 9))
+        lum[int(f_):] = torch.roll(pal[int(f_):], to, dims=2); at = to
+else:
+    pal, _ = synth.stc007_frames_torch(n, seed=7, device=dev, width=720, height=576, lines_per_field=294, noise_sigma=4.0, cyclic=True)
+    lum = pal.clone()
 if what in ("both", "lost"):
     lum[:, 96::97, :] = 16
 if what in ("both", "cells"):
@@ -22,6 +33,8 @@ if what in ("both", "cells"):
 eng = Engine(0); eng.set_profiling(True); eng.setBinarizationMode(2)
 eng.binarize_frames(pal, first_frame_no=1, new_file=True)
 eng.binarize_frames(lum, first_frame_no=1 + n)
+if what == "jumps":
+    eng.binarize_frames(pal, first_frame_no=1 + n)      # back to the clean tape's state
 out = (C.c_ulonglong * 16)()
 eng.lib.sdv_debug_k1_cycles(out, 1)
 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -34,12 +47,14 @@ v = list(out)
 fr = max(1, i.frames_general)
 names = {0: "frame total (sum)", 1: "batch loops", 2: "batch_finish", 3: "end of frame", 8: "slow_line total", 9: "find_black_white", 10: "find_coordinates (INPUT_LEVEL)",
          11: "read_pcm_data (INPUT_ALL)", 12: "sweep lookup + apply", 13: "post_line + record", 14: "fast_line attempts that failed"}
+print(f"lines through fast_line one by one (full kernel): {v[5]} ({v[5] / fr:.1f} per frame), {v[4] / max(1, v[5]):.0f} cycles each, of which the ladder of reads {v[6] / max(1, v[5]):.0f}")
 print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame); the slowest frame: index {v[7] & 0x3FFF}, {v[7] >> 24} cycles with {(v[7] >> 14) & 0x3FF} slow lines")
 import numpy as np
 from sdvpcmdecoder_amd import LINE_DTYPE
 fs = int(v[7] & 0x3FFF)
 lines, _ = eng.binarize_frames(lum, first_frame_no=1 + 3 * n)
-r = lines.cpu().numpy().view(LINE_DTYPE).reshape(-1)[fs * 579:(fs + 1) * 579]
+hh = lum.shape[1] + 3
+r = lines.cpu().numpy().view(LINE_DTYPE).reshape(-1)[fs * hh:(fs + 1) * hh]
 r = r[r["service_type"] == 0]
 import collections
 print("straggler frame records: flags histogram", collections.Counter(r["flags"].tolist()).most_common(8))
