@@ -35,7 +35,7 @@ def algorithmic_bytes_per_frame(width, height):
 
 
 HOT_KERNEL = "sdv_k_stc007_frames_lean"
-PMC_PROFILE = os.path.join("profiles", "r03_pmc_%s.json" % HOT_KERNEL)
+PMC_PROFILE = os.path.join("profiles", "r04_pmc_%s.json" % HOT_KERNEL)
 
 
 def measured_hbm_traffic(frames_per_launch, workload):

@@ -17,7 +17,9 @@ HIP_LIB = os.path.join(PKG, "libsdvpcm_hip.so")
 
 # the sources a kernel is compiled from and launched by (its device header, the engine that configures the launch, the C-ABI)
 KERNEL_SOURCES = {
-    "sdv_k_stc007_frames": ("stc007_device.h", "engine.inc"),
+    "sdv_k_stc007_frames": ("stc007_device.h", "stc007_sweep_device.h", "engine.inc"),
+    "sdv_k_stc007_sweep": ("stc007_device.h", "stc007_sweep_device.h", "engine.inc"),
+    "sdv_k_hist_carry": ("stc007_device.h", "engine.inc"),
     "sdv_k_pcm1_lines": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_engine.inc"),
     "sdv_k_pcm1_frames": ("pcm1_stitch_device.h", "pcm1_engine.inc"),
     "sdv_k_pcm1_frames_bin": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_frames_device.h", "pcm1_frames_engine.inc"),
@@ -54,7 +56,7 @@ def _newer(target, sources):
 
 def build_hip(force=False):
     csrc = os.path.join(PKG, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("sdvpcm_hip.hip", "stc007_device.h", "stc007_deint_device.h", "stc007_stitch_device.h", "engine.inc",
+    srcs = [os.path.join(csrc, f) for f in ("sdvpcm_hip.hip", "stc007_device.h", "stc007_sweep_device.h", "stc007_deint_device.h", "stc007_stitch_device.h", "engine.inc",
                                               "stitch_engine.inc", "pcm1_stitch_device.h", "pcm1_bin_device.h", "pcm1_engine.inc", "pcm1_frames_device.h", "pcm1_frames_engine.inc", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc", "pcm16_engine.inc", "pcm16_stitch_device.h", "audio_device.h", "audio_engine.inc", "vis_device.h", "vis_engine.inc")] + \
            [os.path.join(ROOT, "include", "sdvpcm.h")]
     if not force and not _newer(HIP_LIB, srcs):
@@ -125,7 +127,7 @@ def build_emu(force=False):
     d = os.path.join(ROOT, "tests", "emu")
     out = os.path.join(d, "libsdvpcm_emu.so")
     srcs = [os.path.join(d, "emu_engine.cpp"), os.path.join(d, "hip_emu.h"),
-            os.path.join(PKG, "csrc", "stc007_device.h"), os.path.join(PKG, "csrc", "stc007_deint_device.h"),
+            os.path.join(PKG, "csrc", "stc007_device.h"), os.path.join(PKG, "csrc", "stc007_sweep_device.h"), os.path.join(PKG, "csrc", "stc007_deint_device.h"),
             os.path.join(PKG, "csrc", "engine.inc"), os.path.join(PKG, "csrc", "stc007_stitch_device.h"),
             os.path.join(PKG, "csrc", "stitch_engine.inc"),
             os.path.join(PKG, "csrc", "pcm1_stitch_device.h"), os.path.join(PKG, "csrc", "pcm1_bin_device.h"), os.path.join(PKG, "csrc", "pcm1_engine.inc"), os.path.join(PKG, "csrc", "pcm1_frames_device.h"), os.path.join(PKG, "csrc", "pcm1_frames_engine.inc"), os.path.join(PKG, "csrc", "pcm16_bin_device.h"), os.path.join(PKG, "csrc", "pcm16_frames_device.h"), os.path.join(PKG, "csrc", "pcm16_frames_engine.inc"), os.path.join(PKG, "csrc", "pcm16_engine.inc"), os.path.join(PKG, "csrc", "pcm16_stitch_device.h"), os.path.join(PKG, "csrc", "audio_device.h"), os.path.join(PKG, "csrc", "audio_engine.inc"),

@@ -40,12 +40,6 @@
 #ifndef SDV_BATCH_LINES
 #define SDV_BATCH_LINES 2           /* batch loop: scanlines per iteration (their decode chains are independent and interleave); 1 = off */
 #endif
-#ifndef SDV_INTERLEAVE2
-#define SDV_INTERLEAVE2 1
-#endif
-#ifndef SDV_CAPTURE
-#define SDV_CAPTURE 1               /* whole-frame capture in the lean kernel (capture_solve); 0 = the round-1 row-staging loop only */
-#endif
 #ifndef SDV_NT_RECORDS
 #define SDV_NT_RECORDS 1           /* the batch path writes its records with streaming stores: 0.756 -> 0.740 ms per 10 000 frames (means of eight alternating runs) */
 #endif
@@ -203,7 +197,7 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #define SDV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 #ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch (0..7 the frame loop, 8..15 the general path) */
-__device__ unsigned long long sdv_k1_cycles[16];
+__device__ unsigned long long sdv_k1_cycles[24];
 #define K1_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define K1_ADD(i, t0, t1) do { if (lane_id() == 0) atomicAdd(&sdv_k1_cycles[i], (t1) - (t0)); } while (0)
 #else
@@ -1160,9 +1154,7 @@ __device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps,
     SweepOutcome o;
     if (!sweep_lookup(hook, l.black, l.white, b.in_coord, o)) {
         sweep_request(hook, l.black, l.white, b.in_coord);
-#ifndef SDV_DBG_NO_STOP
         if (b.in_ref < ps.min_ref_lvl) hook.stop = true;
-#endif
         o.span1 = o.span2 = SPAN_NOT_FOUND; o.ref_level = 0; o.t_hyst = o.t_shift = 0; o.t_start = o.t_stop = 0;
     }
     if (o.span1 == SPAN_OK) {
@@ -1519,9 +1511,6 @@ __device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, L
                 if (!coords_valid(preset_coords)) preset_coords = v.frame_avg;
             }
             v.field_state = FIELD_INIT;
-#ifdef SDV_EMU_DEBUG
-            if (lane_id()==0) { printf("DBG bad line %u/%u n_last=%d preset=(%d,%d) keys:", wl.frame_number, wl.line_number, v.n_last, preset_coords.start, preset_coords.stop); for (int i=0;i<v.n_last;i++) printf(" (%d,%d)", key_start(lds.lv_keys[i]), key_stop(lds.lv_keys[i])); printf("\n"); }
-#endif
             bin_set_data_coordinates(v.bin, preset_coords);
             bin_set_bw_levels(v.bin, ps, 0, 0);
         } else {
@@ -1703,17 +1692,12 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
     }
     if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
-#ifdef SDV_EMU_DEBUG2
-    if (f < 6) printf("DBG store f %d flag %02x unsettled %d in_ref %d\n", f, fl, (int)unsettled, (int)a.states_in[f].bin.in_def_reference);
-#endif
     a.flag[f] = fl;
-#ifndef SDV_EXP_NOREFS       /* (experiment: what the scheduler's bookkeeping costs the kernel) */
     if (a.refs) {
         /* (one pair pushed into a full history, the rest moved down a slot: counted where it happens - reading the incoming history again here cost 3 % of the kernel) */
         const bool pushed = v.long_pushes == 1 && v.n_long == COORD_LONG_HISTORY && !a.doubled;
         a.refs[3 * f] = a.states_in[f].bin.in_def_reference; a.refs[3 * f + 1] = o.bin.in_def_reference; a.refs[3 * f + 2] = pushed ? 1 : 0;
     }
-#endif
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
@@ -1975,6 +1959,7 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
     w[8] = fb.calc_crc;
 
     /* ---- VideoToDigital bookkeeping for a line with valid CRC (videotodigital.cpp:1155-1396, 1524-1633) ---- */
+    K1_T(t_bk0);
     const bool even_line = (line_num % 2) == 0;
     const bool doubled = a.doubled != 0;
     bool forced_bad = false;
@@ -1992,6 +1977,7 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
             if (!stc_is_almost_silent(t) && diff <= (BITS_DATA / BIT_DIFF_THRES_DIV)) { forced_bad = true; if (!even_line) v.q_dup_odd++; else v.q_dup_even++; }
         }
     }
+    K1_T(t_bk1);
     {
         uint32_t key = coords_key(b.in_coord.start, b.in_coord.stop);
         SDV_WAVE_SYNC();
@@ -2002,6 +1988,8 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         if (v.n_last < COORD_HISTORY_DEPTH) v.n_last++;
         SDV_WAVE_SYNC();
         fv_keys[v.nfv++] = key;
+        K1_T(t_bk2);
+        K1_ADD(16, t_bk0, t_bk1); K1_ADD(17, t_bk1, t_bk2);
         if (a.coordinate_damper && (v.n_last > (COORD_HISTORY_DEPTH / 2))) {
             Coords target; coords_clear(target);
             uint32_t k;
@@ -2013,7 +2001,10 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
                 if (((int)ds <= -(int)in_delta) || ((int)ds >= (int)in_delta) || ((int)de <= -(int)in_delta) || ((int)de >= (int)in_delta)) forced_bad = true;
             }
         }
+        K1_T(t_bk2b);
+        K1_ADD(18, t_bk2, t_bk2b);
     }
+    K1_T(t_bk3);
     if (!forced_bad) { b.in_coord.doubled = doubled; if (kMeasure) bin_set_bw_levels(b, ps, black, white); }           /* setGoodParameters(work_line) */
     else { if (!even_line) v.q_bad_odd++; else v.q_bad_even++; }
     v.field_state = FIELD_INIT;
@@ -2037,6 +2028,8 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         r.word_state = forced_bad ? 0 : (uint8_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
         *rec = r;
     }
+    K1_T(t_bk4);
+    K1_ADD(19, t_bk3, t_bk4);
     return true;
 }
 
@@ -2337,7 +2330,6 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 #ifdef SDV_K1_STAMPS
     int n_slow_lines = 0;
 #endif
-#if SDV_CAPTURE
     /* whole-frame capture (see capture_solve): only in the lean build, on the geometry the batch loop takes */
     if (kLean && pf.vec && a.width <= 1024 && (a.width & 15) == 0 && n_field[1] > 0 && (uint64_t)a.row_stride * (uint64_t)a.height < (1ull << 31) &&
         batch_eligible(a, lds, v, geo)) {
@@ -2446,7 +2438,6 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             K1_ADD(4, t_cap, t_cap1);
         }
     }
-#endif
     /* ... by a line nothing was tuned for: what is behind it hangs on what the sweep finds, the pass ends here (SweepHook::stop).  (Through the loop
      * conditions, not with a return from inside the loop: with the return, hipcc 7.2 built a full kernel that lost one `rec++` - every record of the
      * frame one slot early on the GPU, at -O1 to -O3 alike, while the same source was right under the emulator.) */
@@ -2522,7 +2513,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                         FastBits fx[NL]; bool okx[NL]; FastCells cx[NL];
 #pragma unroll
                         for (int u = 0; u < NL; u++) cx[u] = fast_sample(lds, pre, 1024 * u);      /* all LDS reads first */
-                        if (NL == 2 && SDV_INTERLEAVE2) fast_try0_x2(cx[0], cx[1], pre, lc, fx[0], fx[1], okx[0], okx[1]);
+                        if (NL == 2) fast_try0_x2(cx[0], cx[1], pre, lc, fx[0], fx[1], okx[0], okx[1]);
                         else {
 #pragma unroll
                             for (int u = 0; u < NL; u++) okx[u] = fast_try0(cx[u], pre, lc, fx[u]);
@@ -2576,9 +2567,6 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 K1_T(t_loop);
                 K1_ADD(1, t_batch, t_loop);
                 if (j > 0) {
-#ifdef SDV_DBG_PRINT
-                    if (lane == 0 && f == 0 && field == 0 && idx < 20) printf("DBG f0 batch idx %d n %d rec %ld\n", idx, j, (long)(rec - a.recs));
-#endif
                     batch_finish(a, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
                     K1_T(t_fin);
                     K1_ADD(2, t_loop, t_fin);
@@ -2599,9 +2587,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             K1_T(t_fl0);
             bool ladder_failed = false;
             bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed);
-#ifndef SDV_DBG_NO_MEASURE
             if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2, a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr); }
-#endif
             K1_T(t_fl1);
             if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
             if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
@@ -2631,9 +2617,6 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     if (missed) { if (last_miss_field == field && idx - last_miss_idx < 8) stop_frame = true; last_miss_field = field; last_miss_idx = idx; }
                 }
             }
-#ifdef SDV_DBG_PRINT
-            if (lane == 0 && f == 0 && field == 0 && idx < 3) printf("DBG f0 idx %d line %d rec %ld took_fast %d pending %d\n", idx, (int)line_num, (long)(rec - a.recs), (int)took_fast, (int)sweep_pending);
-#endif
             rec++; idx++;
         }
         if (stop_frame) break;
@@ -2668,10 +2651,6 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
-#ifdef SDV_EMU_POISON_LDS       /* (test aid: the LDS of a real workgroup starts with whatever the last one left there) */
-    if (sdv::lane_id() == 0) memset(&lds, 0xA7, sizeof(lds));
-    SDV_WAVE_SYNC();
-#endif
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f);
 }

@@ -124,10 +124,7 @@ struct SweepLds {
     uint64_t g_start[88][3];        /* [T - t_lo]: pixel p of the START window >= T, bit p */
     uint64_t g_stop[88][3];         /* ... pixel scan_end - i of the STOP window >= T, bit i */
 };
-#ifndef SDV_DBG_SWEEP_WINDOW
-#define SDV_DBG_SWEEP_WINDOW 192
-#endif
-enum { SWEEP_WINDOW_MAX = 192, SWEEP_WINDOW_USE = SDV_DBG_SWEEP_WINDOW };
+enum { SWEEP_WINDOW_MAX = 192 };
 
 /* the line geometry Binarizer::processLine derives from the line length (binarizer.cpp:600-641) */
 __device__ inline void bin_line_geometry(Bin &b, const sdv_bin_preset &ps, int width, bool doubled)
@@ -334,7 +331,7 @@ __device__ inline void sweep_levels_body(const SweepArgs &a, SweepLds &lds, int 
         int n_start = b.mark_start_max + ppb * 5; n_start &= 0xFFFF; if (n_start > b.line_length) n_start = b.line_length;
         const int end_limit = b.mark_end_min > ppb * 6 ? b.mark_end_min - ppb * 6 : 0;
         const int n_stop = scan_end - end_limit, i_max = scan_end - (int)b.mark_end_min;
-        if (n_start <= SWEEP_WINDOW_USE && n_stop <= SWEEP_WINDOW_USE) {
+        if (n_start <= SWEEP_WINDOW_MAX && n_stop <= SWEEP_WINDOW_MAX) {
             /* thresholds the 64 levels can ask for: the level itself and down to 23 below it (never below 1) */
             int t_lo = base - 63 - 23; if (t_lo < 1) t_lo = 1;
             const int n_t = base - t_lo + 1;                /* <= 87 */
@@ -369,7 +366,6 @@ __device__ inline void sweep_levels_body(const SweepArgs &a, SweepLds &lds, int 
             }
         } else if (active) {
             /* marker windows wider than the masks (a very wide frame, or settings that search half the line): pixel by pixel */
-            WaveLds *none = nullptr; (void)none;
             int best = 0x7FFFFFFF, ed_start = 0;
             for (int h = 0; h < 24; h++) {
                 const Markers mk = search_markers_px(b, ps, lds.px, (uint8_t)lvl, (uint8_t)h);

@@ -4,11 +4,11 @@ R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_pcm1f $R/gpurun_out/p1fpmc1 $R/gpurun_out/p1fpmc2 $R/gpurun_out/p1fpmc3 $R/gpurun_out/p1fpmc4
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pcm1f -- python3 $R/tools/pcm1_front_prof.py 2000 10 > $R/gpurun_out/prof_pcm1f.log 2>&1; echo "rocprof pcm1 front rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/p1fpmc1 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc1.err; echo "p1fpmc1 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/p1fpmc2 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc2.err; echo "p1fpmc2 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p1fpmc3 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc3.err; echo "p1fpmc3 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p1fpmc4 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc4.err; echo "p1fpmc4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pcm1f -- python3 $R/tools/pcm1_front_prof.py 2000 10 > $R/gpurun_out/prof_pcm1f.log 2>&1; echo "rocprof pcm1 front rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/p1fpmc1 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc1.err; echo "p1fpmc1 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/p1fpmc2 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc2.err; echo "p1fpmc2 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p1fpmc3 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc3.err; echo "p1fpmc3 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_lines' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p1fpmc4 -- python3 $R/tools/pcm1_front_prof.py 2000 1 > /dev/null 2> $R/gpurun_out/p1fpmc4.err; echo "p1fpmc4 rc=$?"
 cd $R
 python3 - <<'PY'
 import csv, glob

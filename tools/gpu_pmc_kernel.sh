@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 K=$1; P=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${P}1 $R/gpurun_out/${P}2 $R/gpurun_out/${P}3 $R/gpurun_out/${P}4
-rocprofv3 --kernel-include-regex "$K" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/${P}1 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}1.err; echo "${P}1 rc=$?"
-rocprofv3 --kernel-include-regex "$K" --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/${P}2 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}2.err; echo "${P}2 rc=$?"
-rocprofv3 --kernel-include-regex "$K" --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${P}3 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}3.err; echo "${P}3 rc=$?"
-rocprofv3 --kernel-include-regex "$K" --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}4 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}4.err; echo "${P}4 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex "$K" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/${P}1 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}1.err; echo "${P}1 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex "$K" --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/${P}2 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}2.err; echo "${P}2 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex "$K" --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${P}3 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}3.err; echo "${P}3 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex "$K" --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}4 -- python3 "$@" > /dev/null 2> $R/gpurun_out/${P}4.err; echo "${P}4 rc=$?"

@@ -11,19 +11,19 @@ SDV_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --
 SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --frames 4000 --no-cpu 2> gpurun_out/bench_2rank.err | tail -1 > gpurun_out/bench_2rank_gloo.json; echo "2-rank rc=$?"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_bench $R/gpurun_out/prof_stitch $R/gpurun_out/pmc1 $R/gpurun_out/pmc2 $R/gpurun_out/pmc3 $R/gpurun_out/pmc4
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err; echo "rocprof bench rc=$?"
-( cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stitch -- python3 tools/stitch_prof.py 10000 5 cont > gpurun_out/prof_stitch.log 2>&1 ); echo "rocprof stitch rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc1.err; echo "pmc1 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/pmc2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc2.err; echo "pmc2 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc3.err; echo "pmc3 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc4.err; echo "pmc4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err; echo "rocprof bench rc=$?"
+( cd $R && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stitch -- python3 tools/stitch_prof.py 10000 5 cont > gpurun_out/prof_stitch.log 2>&1 ); echo "rocprof stitch rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc1.err; echo "pmc1 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/pmc2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc2.err; echo "pmc2 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc3.err; echo "pmc3 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc4.err; echo "pmc4 rc=$?"
 # PCM-1 back half: kernel stats and PMC passes of its frame kernel
 rm -rf $R/gpurun_out/prof_pcm1 $R/gpurun_out/p1pmc1 $R/gpurun_out/p1pmc2 $R/gpurun_out/p1pmc3 $R/gpurun_out/p1pmc4
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pcm1 -- python3 $R/tools/pcm1_prof.py 10000 20 > $R/gpurun_out/prof_pcm1.log 2>&1; echo "rocprof pcm1 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/p1pmc1 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc1.err; echo "p1pmc1 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/p1pmc2 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc2.err; echo "p1pmc2 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p1pmc3 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc3.err; echo "p1pmc3 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p1pmc4 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc4.err; echo "p1pmc4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_pcm1 -- python3 $R/tools/pcm1_prof.py 10000 20 > $R/gpurun_out/prof_pcm1.log 2>&1; echo "rocprof pcm1 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/p1pmc1 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc1.err; echo "p1pmc1 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/p1pmc2 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc2.err; echo "p1pmc2 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p1pmc3 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc3.err; echo "p1pmc3 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_pcm1_frames' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p1pmc4 -- python3 $R/tools/pcm1_prof.py 10000 2 > /dev/null 2> $R/gpurun_out/p1pmc4.err; echo "p1pmc4 rc=$?"
 # PCM-1 front half: kernel stats and PMC passes of its line kernel
 bash $R/tools/gpu_pcm1_front_pmc.sh 2>&1 | grep "rc="
 
@@ -33,15 +33,17 @@ bash $R/tools/gpu_frames_prof.sh 2>&1 | grep "rc="
 bash $R/tools/gpu_pcm16_prof.sh 10000 2>&1 | grep "rc=\|frames/s"
 # AudioProcessor stage: kernel stats over the three tapes of tools/audio_prof.py
 rm -rf $R/gpurun_out/prof_audio
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_audio -- python3 $R/tools/audio_prof.py 10000 5 > $R/gpurun_out/prof_audio.log 2>&1; echo "rocprof audio rc=$?"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_audio -- python3 $R/tools/audio_prof.py 10000 5 > $R/gpurun_out/prof_audio.log 2>&1; echo "rocprof audio rc=$?"
 grep "it=4" $R/gpurun_out/prof_audio.log
 # ... and the HBM traffic of its streaming pass (sdv_k_ap_prepare: input -> the caller's buffer + bitmaps), PMC passes on the clean tape
 rm -rf $R/gpurun_out/apmc3 $R/gpurun_out/apmc4
-rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/apmc3 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc3.err; echo "apmc3 rc=$?"
-rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/apmc4 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc4.err; echo "apmc4 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/apmc3 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc3.err; echo "apmc3 rc=$?"
+timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_ap_prepare' --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/apmc4 -- python3 $R/tools/audio_prof.py 10000 1 > /dev/null 2> $R/gpurun_out/apmc4.err; echo "apmc4 rc=$?"
 # visualiser canvases: kernel stats
 rm -rf $R/gpurun_out/prof_vis
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vis -- python3 $R/tools/vis_prof.py 2000 4 > $R/gpurun_out/prof_vis.log 2>&1; echo "rocprof vis rc=$?"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_vis -- python3 $R/tools/vis_prof.py 2000 4 > $R/gpurun_out/prof_vis.log 2>&1; echo "rocprof vis rc=$?"
 tail -1 $R/gpurun_out/prof_vis.log
 # PMC passes of the stitch kernels, the PCM-16x0 analysis, the prescans and the audio plan
 bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="
+# round 4: the damaged-tape kernels (general frame kernel, the two sweep kernels, the histogram carry) on the C3 PAL tape
+bash $R/tools/gpu_pmc_round4.sh 2>&1 | grep "rc="

@@ -8,7 +8,7 @@ n = 10000
 eng = Engine(0)
 luma, _ = synth.stc007_frames_torch(n, seed=2, device='cuda', noise_sigma=4.0, cyclic=True)
 eng.binarize_frames(luma, first_frame_no=1, new_file=True)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 eng.lib.sdv_debug_k1_cycles(out, 1)
 eng.binarize_frames(luma, first_frame_no=1 + n, new_file=False)
 torch.cuda.synchronize()

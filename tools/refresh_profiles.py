@@ -3,7 +3,7 @@
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r03'      # the round the summaries are named for
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r04'      # the round the summaries are named for
 
 
 def newest(pat):
@@ -61,3 +61,11 @@ print('value', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['f
 for k in ('stitch_stage', 'pcm1_stage', 'pcm1_front_stage', 'pcm16x0_stage', 'audio_stage'):
     if k in d: print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ('note', 'cpu_baseline')})
 print('cpu', d['cpu_baseline']['value'], d['stitch_stage']['cpu_baseline']['value'], d['pcm1_stage']['cpu_baseline']['value'], d.get('host_fed', {}).get('h2d_gb_per_s'))
+
+# round 4: the kernels of the damaged-tape path (tools/gpu_pmc_round4.sh), on the C3 PAL tape of tools/pal_trace.py
+C3 = "tools/pal_trace.py 2000 both: 2000 PAL frames, every 97th line lost, a cell inverted on one line in 53"
+for kernel, prefix in (("sdv_k_stc007_frames", "fullpmc"), ("sdv_k_stc007_sweep_levels", "swlpmc"), ("sdv_k_stc007_sweep_pick", "swppmc"), ("sdv_k_hist_carry", "hcpmc")):
+    if glob.glob(f'gpurun_out/{prefix}1/**/*_counter_collection.csv', recursive=True):
+        subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', kernel, f'profiles/{RND}_pmc_{kernel}.json', prefix, C3], stdout=subprocess.DEVNULL)
+if glob.glob('gpurun_out/prof_c3/*/*kernel_stats.csv'):
+    trim(newest('gpurun_out/prof_c3/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_c3_tape_kernel_stats.csv')

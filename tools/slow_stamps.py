@@ -35,7 +35,7 @@ eng.binarize_frames(pal, first_frame_no=1, new_file=True)
 eng.binarize_frames(lum, first_frame_no=1 + n)
 if what == "jumps":
     eng.binarize_frames(pal, first_frame_no=1 + n)      # back to the clean tape's state
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 eng.lib.sdv_debug_k1_cycles(out, 1)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 eng.binarize_frames(lum, first_frame_no=1 + 2 * n)
@@ -48,6 +48,7 @@ fr = max(1, i.frames_general)
 names = {0: "frame total (sum)", 1: "batch loops", 2: "batch_finish", 3: "end of frame", 8: "slow_line total", 9: "find_black_white", 10: "find_coordinates (INPUT_LEVEL)",
          11: "read_pcm_data (INPUT_ALL)", 12: "sweep lookup + apply", 13: "post_line + record", 14: "fast_line attempts that failed"}
 print(f"lines through fast_line one by one (full kernel): {v[5]} ({v[5] / fr:.1f} per frame), {v[4] / max(1, v[5]):.0f} cycles each, of which the ladder of reads {v[6] / max(1, v[5]):.0f}")
+print(f"   bookkeeping of a line taken by fast_line (lean + full, per call): dup check {v[16] / max(1, v[5]):.0f}, 9-line window + key {v[17] / max(1, v[5]):.0f}, damper {v[18] / max(1, v[5]):.0f}, counters + record {v[19] / max(1, v[5]):.0f}")
 print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame); the slowest frame: index {v[7] & 0x3FFF}, {v[7] >> 24} cycles with {(v[7] >> 14) & 0x3FF} slow lines")
 import numpy as np
 from sdvpcmdecoder_amd import LINE_DTYPE
