@@ -144,7 +144,7 @@ struct FrameArgs {
     uint32_t *scratch;              /* per frame 2*height u32 (frame_valid / frame_invalid coordinate keys) */
     const uint8_t *frame_flags;     /* [n frames] SDV_FRAME_* of the caller (sdv_set_frame_flags), or NULL */
     struct SweepMemo *memo;         /* outcomes of reference-level sweeps and requests for more (stc007_sweep_device.h): the pool, ... */
-    int32_t *memo_head;             /* ... [n_total] the newest entry of frame f (-1: none), ... */
+    int32_t *memo_head;             /* ... [n_total * height] the newest entry of a line (-1: none), ... */
     int32_t *memo_count; int32_t memo_cap;   /* ... entries handed out (may run past the capacity: those requests were dropped) */
     unsigned long long *bw_memo;    /* [n_total * height] or NULL: what findBlackWhite found on a line, kept from one decode of a frame to the next (find_black_white) */
 };
@@ -198,11 +198,18 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #endif
 #ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch (0..7 the frame loop, 8..15 the general path) */
 __device__ unsigned long long sdv_k1_cycles[24];
+/* summed per frame in LDS and added to the totals once, at the end of the frame: an atomic per stamp on one address held up every load
+ * behind it (a stamped build ran 10-70 % slower than the plain one) */
+__shared__ unsigned long long sdv_k1_lds[24];
 #define K1_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define K1_ADD(i, t0, t1) do { if (lane_id() == 0) atomicAdd(&sdv_k1_cycles[i], (t1) - (t0)); } while (0)
+#define K1_ADD(i, t0, t1) do { if (lane_id() == 0) sdv_k1_lds[i] += (t1) - (t0); } while (0)
+#define K1_BEGIN() do { if (lane_id() < 24) sdv_k1_lds[lane_id()] = 0; SDV_WAVE_SYNC(); } while (0)
+#define K1_FLUSH() do { SDV_WAVE_SYNC(); if (lane_id() < 24 && lane_id() != 7 && sdv_k1_lds[lane_id()] != 0) atomicAdd(&sdv_k1_cycles[lane_id()], sdv_k1_lds[lane_id()]); } while (0)
 #else
 #define K1_T(var) do { } while (0)
 #define K1_ADD(i, t0, t1) do { } while (0)
+#define K1_BEGIN() do { } while (0)
+#define K1_FLUSH() do { } while (0)
 #endif
 
 /* Wave-uniform values that reach us through vector memory (global/LDS/scratch loads) are re-declared
@@ -2241,6 +2248,7 @@ enum { STATE_ABORTED = 0xA5 };
 template <bool kLean>
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 {
+    K1_BEGIN();
     K1_T(t_begin);
     V2D v; Line wl;
     v2d_load_state(v, lds, &a.states_in[f], a);
@@ -2575,6 +2583,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 if (j == nb) continue;
                 staged = !redo;                                 /* line idx sits in LDS and needs the sequential path */
             }
+            K1_T(t_st0);
             if (!staged) {
                 pf.nq = 0;
                 row_commit(lds, pf, a.width);
@@ -2585,6 +2594,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
             }
             line_num = (uint16_t)(field + 1 + 2 * idx);
             K1_T(t_fl0);
+            K1_ADD(21, t_st0, t_fl0);
             bool ladder_failed = false;
             bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed);
             if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2, a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr); }
@@ -2596,10 +2606,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
                     return;
                 } else {
+                    K1_T(t_sc0);
                     SlowCtx c;
                     c.a = a; c.v = v;
                     c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
-                    c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
+                    c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.line = f * a.height + (2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
                     c.hook.bw_slot = a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr;
                     slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
 #ifdef SDV_K1_STAMPS
@@ -2607,6 +2618,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 #endif
                     v = c.v;
                     v2d_make_uniform(v);
+                    K1_T(t_sc1);
+                    K1_ADD(20, t_sc0, t_sc1);
                     const bool missed = uni(c.hook.pending) != 0;
                     sweep_pending = sweep_pending || missed;
                     stop_frame = uni(c.hook.stop) != 0;
@@ -2627,6 +2640,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     }
     if (stop_frame) {                       /* (what was decoded of the frame is not final anyway) */
         if (lane == 0) a.flag[f] = VF_ABORTED;
+        K1_FLUSH();
         return;
     }
     line_num = (uint16_t)(line_num + 2);
@@ -2638,6 +2652,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
     K1_T(t_end);
     K1_ADD(3, t_ef0, t_end);
     K1_ADD(0, t_begin, t_end);
+    K1_FLUSH();
 #ifdef SDV_K1_STAMPS
     if (lane_id() == 0) atomicMax(&sdv_k1_cycles[7], ((unsigned long long)(t_end - t_begin) << 24) | ((unsigned long long)(n_slow_lines & 0x3FF) << 14) | (unsigned long long)(f & 0x3FFF));
 #endif

@@ -30,7 +30,7 @@ namespace sdv {
 /* ---- requests and outcomes ------------------------------------------------------------------- */
 enum { SWEEP_REQUESTED = 0, SWEEP_SETTLED = 1 };
 struct SweepMemo {                  /* 32 bytes, at 32-byte strides in a pool that starts 16-byte aligned */
-    int32_t frame, next;            /* frame index of the call; the next entry of the same frame, -1 at the end */
+    int32_t frame, next;            /* frame index of the call; the next entry of the same line of that frame, -1 at the end */
     uint16_t row;                   /* row of the frame */
     uint8_t black, white;           /* the key: what the sweep of that line depends on besides its pixels and the settings ... */
     int16_t in_start, in_stop;      /* ... the levels the line measured and the binarizer's preset data coordinates */
@@ -46,6 +46,7 @@ struct SweepOutcome { uint8_t span1, span2, ref_level, t_hyst, t_shift; int16_t 
 struct SweepHook {
     SweepMemo *memo; int32_t *head; int32_t *count; int32_t cap;
     int32_t frame; uint16_t row;
+    int32_t line;                   /* frame * height + row: the line's list head */
     bool pending;                   /* out: a sweep of this frame was asked for, the line went on without it */
     unsigned long long *bw_slot;    /* in: the line's slot of FrameArgs::bw_memo, or NULL */
     bool ladder_failed;             /* in: the frame loop tried the ladder of reads with the tuning the line inherits (fast_line), nothing read */
@@ -69,7 +70,7 @@ __device__ __forceinline__ uint32_t sweep_key_hi(const Coords &c) { return (uint
 __device__ inline bool sweep_lookup(const SweepHook &h, uint8_t black, uint8_t white, const Coords &in_coord, SweepOutcome &o)
 {
     const uint32_t k0 = sweep_key_lo(h.row, black, white), k1 = sweep_key_hi(in_coord);
-    int idx = uni(h.head[h.frame]);
+    int idx = uni(h.head[h.line]);
     for (int guard = 0; idx >= 0 && idx < h.cap && guard < (1 << 20); guard++) {
         const SweepMemoWords m = sweep_memo_load(&h.memo[idx]);
         if (m.w[2] == k0 && m.w[3] == k1) {
@@ -88,7 +89,7 @@ __device__ inline void sweep_request(SweepHook &h, uint8_t black, uint8_t white,
 {
     h.pending = true;
     const uint32_t k0 = sweep_key_lo(h.row, black, white), k1 = sweep_key_hi(in_coord);
-    int idx = uni(h.head[h.frame]);
+    int idx = uni(h.head[h.line]);
     for (int guard = 0; idx >= 0 && idx < h.cap && guard < (1 << 20); guard++) {
         const SweepMemoWords m = sweep_memo_load(&h.memo[idx]);
         if (m.w[2] == k0 && m.w[3] == k1) return;
@@ -98,11 +99,11 @@ __device__ inline void sweep_request(SweepHook &h, uint8_t black, uint8_t white,
         const int slot = atomicAdd(h.count, 1);
         if (slot < h.cap) {         /* a full pool: the count tells the engine, which makes room and decodes the frame again */
             SweepMemo m;
-            m.frame = h.frame; m.next = h.head[h.frame]; m.row = h.row; m.black = black; m.white = white; m.in_start = in_coord.start; m.in_stop = in_coord.stop;
+            m.frame = h.frame; m.next = h.head[h.line]; m.row = h.row; m.black = black; m.white = white; m.in_start = in_coord.start; m.in_stop = in_coord.stop;
             m.state = SWEEP_REQUESTED; m.span1 = m.span2 = SPAN_NOT_FOUND; m.ref_level = m.t_hyst = m.t_shift = 0; m.t_start = m.t_stop = 0;
             for (int i = 0; i < 6; i++) m._pad[i] = 0;
             h.memo[slot] = m;
-            h.head[h.frame] = slot;
+            h.head[h.line] = slot;
         }
     }
     __syncthreads();

@@ -1,7 +1,7 @@
 """PCM-1 front half: the oracle's restatement of Binarizer::processLine with a PCM1Line output
 (oracle/bin_pcm1.c: black/white search, marker-less coordinate search over the 25 x 25 grid with CRC voting, Bit Picker, header
 detection) against the real reference - live when oracle/_ref is built, and through the committed fixtures
-(tests/golden/pcm1front_*.npz, made by make_golden_pcm1_front.py) everywhere.  No HIP kernel for this row yet."""
+(tests/golden/pcm1front_*.npz, made by make_golden_pcm1_front.py) everywhere; the HIP line kernel (sdv_pcm1_binarize_lines) is compared with the same fixtures in the gpu-marked tests."""
 import hashlib
 import os
 

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
-SDVPCM_LIB=build/variants/stamps.so timeout 300 python tools/slow_stamps.py 2000 both 2>&1 | tail -14
-timeout 300 python tools/pal_trace.py 2000 both 2>&1 | tail -4
-timeout 300 python tools/jump_probe.py 10000 16 2>&1 | tail -2
+SDVPCM_LIB=build/variants/stamps.so timeout 300 python tools/slow_stamps.py 2000 both 2>&1 | grep -v "first 40\|amdgpu"
+SDVPCM_LIB=build/variants/stamps.so timeout 300 python tools/slow_stamps.py 10000 jumps 2>&1 | grep -v "first 40\|amdgpu"

@@ -6,7 +6,8 @@ R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/bench_full.json
+python bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/bench_line.json
+cp gpurun_out/bench_details.json gpurun_out/bench_full.json      # the full objects of this run (later bench runs of this script write the file again)
 SDV_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu 2> gpurun_out/bench_nccl1.err | tail -1 > gpurun_out/bench_nccl_1rank.json; echo "nccl 1-rank rc=$?"
 SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --frames 4000 --no-cpu 2> gpurun_out/bench_2rank.err | tail -1 > gpurun_out/bench_2rank_gloo.json; echo "2-rank rc=$?"
 cd /tmp && export TMPDIR=/tmp
@@ -47,3 +48,15 @@ tail -1 $R/gpurun_out/prof_vis.log
 bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="
 # round 4: the damaged-tape kernels (general frame kernel, the two sweep kernels, the histogram carry) on the C3 PAL tape
 bash $R/tools/gpu_pmc_round4.sh 2>&1 | grep "rc="
+# the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r04_profiles/; the raw counter and trace files stay
+# on the box (gpurun only merges 64 MiB back)
+cd $R && python tools/refresh_profiles.py r04 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
+rm -rf gpurun_out/r04_profiles && mkdir -p gpurun_out/r04_profiles && cp profiles/r04_* gpurun_out/r04_profiles/
+find gpurun_out -name "*.csv" -size +256k -delete; find gpurun_out -name "*.db" -delete
+du -sh gpurun_out | tail -1
+# scheduler traces of the two damaged tapes (developer build, when one was sent along)
+if [ -f build/variants/dev.so ]; then
+  SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/pal_trace.py 2000 both > gpurun_out/pal_trace_both.log 2>&1
+  SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/jump_probe.py 10000 16 > gpurun_out/jump_trace.log 2>&1
+  timeout 1200 python tools/soak.py 16 4000 > gpurun_out/soak_r04.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r04.log
+fi

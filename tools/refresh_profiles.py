@@ -32,7 +32,8 @@ if glob.glob('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'):
     trim(newest('gpurun_out/prof_pcm1f/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_pcm1_front_kernel_stats.csv')
     subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines', f'profiles/{RND}_pmc_sdv_k_pcm1_lines.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
     subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', 'sdv_k_pcm1_lines_lean', f'profiles/{RND}_pmc_sdv_k_pcm1_lines_lean.json', 'p1fpmc'], stdout=subprocess.DEVNULL)
-shutil.copy('gpurun_out/bench_full.json', f'profiles/{RND}_bench_full.json')
+shutil.copy('gpurun_out/bench_full.json', f'profiles/{RND}_bench_full.json')       # every leg's full object (bench.py's gpurun_out/bench_details.json)
+if os.path.exists('gpurun_out/bench_line.json'): shutil.copy('gpurun_out/bench_line.json', f'profiles/{RND}_bench_line.json')      # the one line the driver reads
 shutil.copy('gpurun_out/bench_2rank_gloo.json', f'profiles/{RND}_bench_2rank_gloo_one_gpu.json')
 if os.path.exists('gpurun_out/bench_nccl_1rank.json') and os.path.getsize('gpurun_out/bench_nccl_1rank.json') > 100:
     shutil.copy('gpurun_out/bench_nccl_1rank.json', f'profiles/{RND}_bench_nccl_1rank.json')
@@ -64,8 +65,9 @@ print('cpu', d['cpu_baseline']['value'], d['stitch_stage']['cpu_baseline']['valu
 
 # round 4: the kernels of the damaged-tape path (tools/gpu_pmc_round4.sh), on the C3 PAL tape of tools/pal_trace.py
 C3 = "tools/pal_trace.py 2000 both: 2000 PAL frames, every 97th line lost, a cell inverted on one line in 53"
-for kernel, prefix in (("sdv_k_stc007_frames", "fullpmc"), ("sdv_k_stc007_sweep_levels", "swlpmc"), ("sdv_k_stc007_sweep_pick", "swppmc"), ("sdv_k_hist_carry", "hcpmc")):
+JUMPS = "tools/jump_probe.py 10000 16: 10 000 NTSC frames, the data window jumps 16 times"
+for kernel, prefix, workload in (("sdv_k_stc007_frames", "fullpmc", C3), ("sdv_k_stc007_sweep_levels", "swlpmc", C3), ("sdv_k_stc007_sweep_pick", "swppmc", C3), ("sdv_k_hist_carry", "hcpmc", JUMPS)):
     if glob.glob(f'gpurun_out/{prefix}1/**/*_counter_collection.csv', recursive=True):
-        subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', kernel, f'profiles/{RND}_pmc_{kernel}.json', prefix, C3], stdout=subprocess.DEVNULL)
+        subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', kernel, f'profiles/{RND}_pmc_{kernel}.json', prefix, workload], stdout=subprocess.DEVNULL)
 if glob.glob('gpurun_out/prof_c3/*/*kernel_stats.csv'):
     trim(newest('gpurun_out/prof_c3/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_c3_tape_kernel_stats.csv')

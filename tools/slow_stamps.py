@@ -46,7 +46,9 @@ print(f"{what}: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} round
 v = list(out)
 fr = max(1, i.frames_general)
 names = {0: "frame total (sum)", 1: "batch loops", 2: "batch_finish", 3: "end of frame", 8: "slow_line total", 9: "find_black_white", 10: "find_coordinates (INPUT_LEVEL)",
-         11: "read_pcm_data (INPUT_ALL)", 12: "sweep lookup + apply", 13: "post_line + record", 14: "fast_line attempts that failed"}
+         11: "read_pcm_data (INPUT_ALL)", 12: "sweep lookup + apply", 13: "post_line + record", 14: "fast_line attempts that failed",
+         20: "general-path detour incl. context copies", 21: "row staging ahead of sequential lines", 4: "fast_line calls that took the line", 6: "fast_decode (ladder of reads)",
+         16: "fast_line: dup check", 17: "fast_line: 9-line window + key", 18: "fast_line: damper", 19: "fast_line: counters + record"}
 print(f"lines through fast_line one by one (full kernel): {v[5]} ({v[5] / fr:.1f} per frame), {v[4] / max(1, v[5]):.0f} cycles each, of which the ladder of reads {v[6] / max(1, v[5]):.0f}")
 print(f"   bookkeeping of a line taken by fast_line (lean + full, per call): dup check {v[16] / max(1, v[5]):.0f}, 9-line window + key {v[17] / max(1, v[5]):.0f}, damper {v[18] / max(1, v[5]):.0f}, counters + record {v[19] / max(1, v[5]):.0f}")
 print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame); the slowest frame: index {v[7] & 0x3FFF}, {v[7] >> 24} cycles with {(v[7] >> 14) & 0x3FF} slow lines")
