@@ -535,6 +535,47 @@ int sdv_set_pcm1_stitch_settings(sdv_engine *e, const sdv_pcm1_stitch_settings *
 int sdv_pcm1_stitch_frames(sdv_engine *e, const sdv_pcm1_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                            size_t *n_pairs, sdv_frame_asm_pcm1 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* ---- what PCM1DataStitcher hands to the visualiser ----------------------------------------------------------------- */
+/* One PCM1DataBlock as outputDataBlock emits it with newBlockProcessed (pcm1datastitcher.cpp:1333; pcm1datablock.h:84-98): the 184 words of an
+ * interleave block (182 in the last block of a field) with the per-word flags PCM1Deinterleaver::setWordData left (pcm1deinterleaver.cpp:150-278).
+ * 576 bytes.  stop_line of a field's last block is not comparable with the reference: it reads the sub-line one past the end of its queue
+ * (:204-211 with stripe_len 46 for block 7 - index 735 of 735); the record holds the number the next line would have had. */
+enum { SDV_P1B_SHORT = 1 << 0,          /* isShortLength(): words 182, 183 do not exist */
+       SDV_P1B_EMPHASIS = 1 << 1 };     /* hasEmphasis() */
+enum { SDV_P1W_CRC_OK = 1 << 0,         /* isWordCRCOk() / isWordValid() */
+       SDV_P1W_PICKED_LEFT = 1 << 1,    /* hasPickedSample(): the sub-line's left word had bits picked (first sub-line of a line only) */
+       SDV_P1W_PICKED_WORD = 1 << 2 };  /* hasPickedWord(): that, or the line's CRC was picked */
+typedef struct sdv_pcm1_block_rec {
+    uint32_t frame_number;          /* of the block's first sub-line */
+    uint16_t start_line, stop_line; /* line numbers as the stitcher re-numbers the lines of its queue (addLinesFromField, :952-1016) */
+    uint8_t interleave_num;         /* 0..7 within the field */
+    uint8_t flags;                  /* SDV_P1B_* */
+    uint16_t sample_rate;
+    uint16_t words[184];            /* getWord(): 13-bit words, L R L R ... */
+    uint8_t word_flags[184];        /* SDV_P1W_* */
+    uint8_t _pad[12];
+} sdv_pcm1_block_rec;
+/* One PCM1SubLine of the stitcher's queue as performDeinterleave hands it to the visualiser (newLineProcessed, :1392-1407; pcm1subline.h:83-93):
+ * a third of a PCM-1 line after trimming and padding.  16 bytes.  A frame has 2 x 735 places; the places of lines earlier frames left in the
+ * field buffers (manual line offsets) are not handed over by the reference (their frame number is another one): SDV_P1S_SKIP. */
+enum { SDV_P1S_BW_SET = 1 << 0, SDV_P1S_CRC_VALID = 1 << 1, SDV_P1S_SKIP = 1 << 7 };
+typedef struct sdv_pcm1_asm_line_rec {
+    uint32_t frame_number;
+    uint16_t line_number;           /* re-numbered by the stitcher: 1, 3, 5 ... / 2, 4, 6 ... down the padded field */
+    uint16_t words[2];              /* getLeft(), getRight() */
+    uint8_t picked_bits_left, picked_bits_right;
+    uint8_t line_part;              /* PCM1SubLine::PART_LEFT / _MIDDLE / _RIGHT */
+    uint8_t flags;                  /* SDV_P1S_* */
+    uint8_t _pad[2];
+} sdv_pcm1_asm_line_rec;
+/* With a block buffer set (device memory; NULL: off, the default) every sdv_pcm1_stitch_frames call also writes the blocks of its frames, 16 per
+ * frame in the order of the sample pairs (block j of a frame = its pairs 92 j .. 92 j + 91, file tags aside); with a line buffer the 1470 sub-lines
+ * per frame.  The counts of the last call (or what it needed, when it failed with SDV_ERR_BAD_ARG for lack of room). */
+int sdv_set_pcm1_stitch_block_output(sdv_engine *e, sdv_pcm1_block_rec *out_blocks, size_t blocks_cap);
+size_t sdv_pcm1_stitch_block_count(sdv_engine *e);
+int sdv_set_pcm1_stitch_line_output(sdv_engine *e, sdv_pcm1_asm_line_rec *out_lines, size_t lines_cap);
+size_t sdv_pcm1_stitch_line_count(sdv_engine *e);
+
 /* The PCM1Line queue between the two halves: sdv_pcm1_binarize_frames writes sdv_pcm1_bin_rec (everything Binarizer::processLine leaves in a
  * PCM1Line), sdv_pcm1_stitch_frames reads sdv_pcm1_line_rec (what PCM1DataStitcher looks at).  Record i of `in` -> record i of `out`; device
  * pointers, asynchronous on `stream`. */

@@ -124,6 +124,8 @@ typedef struct {
     p1_frasm f1; p1_sub odd[P1_SUBLINES_PF], even[P1_SUBLINES_PF]; p1_sub *q; size_t qn, qcap;
     bool header_present, emphasis_set, file_start, file_end;
     sdv_sample_pair *out; size_t out_n, out_cap; sdv_frame_asm_pcm1 *frames; size_t frames_n, frames_cap;
+    /* the visualiser's feeds (newBlockProcessed / newLineProcessed), when asked for */
+    sdv_pcm1_block_rec *vb; size_t vb_n, vb_cap; sdv_pcm1_asm_line_rec *vl; size_t vl_n, vl_cap;
 } p1_stitcher;
 
 static void q_push(p1_stitcher *s, const p1_sub *l)
@@ -173,10 +175,47 @@ static void add_lines(p1_stitcher *s, p1_sub *field, uint16_t start, uint16_t co
         if (field[i].part == 2) *last_line = (uint16_t)(field[i].line_number + 2);
     }
 }
+/* the block as outputDataBlock hands it to the visualiser (newBlockProcessed, :1333) */
+static void vis_block(p1_stitcher *s, const p1_block *b)
+{
+    if (s->vb && s->vb_n < s->vb_cap) {
+        sdv_pcm1_block_rec *o = &s->vb[s->vb_n];
+        memset(o, 0, sizeof(*o));
+        o->frame_number = b->frame_number; o->start_line = b->start_line; o->stop_line = b->stop_line; o->interleave_num = b->interleave_num;
+        /* the last block of a field: setWordData reads its stop line one sub-line past the end of the queue (:204-211, stripe_len 46) - undefined in
+         * the reference; here the number that line would have had */
+        if (b->interleave_num == P1_INT_BLK - 1 && s->qn >= P1_MIN_DEINT) o->stop_line = (uint16_t)(s->q[P1_MIN_DEINT - 1].line_number + 2);
+        o->flags = (uint8_t)((b->short_blk ? SDV_P1B_SHORT : 0) | (b->emphasis ? SDV_P1B_EMPHASIS : 0));
+        o->sample_rate = b->sample_rate;
+        for (int i = 0; i < P1_WORD_CNT; i++) {
+            o->words[i] = b->words[i];
+            o->word_flags[i] = (uint8_t)((b->word_crc[i] ? SDV_P1W_CRC_OK : 0) | (b->picked_left[i] ? SDV_P1W_PICKED_LEFT : 0) |
+                                         ((b->picked_left[i] || b->picked_crc[i]) ? SDV_P1W_PICKED_WORD : 0));
+        }
+    }
+    s->vb_n++;
+}
 static void perform_deinterleave(p1_stitcher *s)   /* :1382-1453 */
 {
     p1_block b;
     p1_frasm *f = &s->f1;
+    /* the whole queue to the visualiser (newLineProcessed, :1392-1407): the sub-lines of this frame; 735 places per field here */
+    for (size_t i = 0; i < (size_t)P1_MIN_DEINT; i++) {
+        if (s->vl && s->vl_n < s->vl_cap) {
+            sdv_pcm1_asm_line_rec *o = &s->vl[s->vl_n];
+            memset(o, 0, sizeof(*o));
+            o->frame_number = f->frame_number; o->words[0] = o->words[1] = P1_BIT_RANGE; o->flags = SDV_P1S_SKIP;
+            if (i < s->qn) {
+                const p1_sub *l = &s->q[i];
+                o->line_number = l->line_number; o->line_part = l->part;
+                if (l->frame_number == f->frame_number) {
+                    o->words[0] = l->words[0]; o->words[1] = l->words[1]; o->picked_bits_left = l->picked_left; o->picked_bits_right = l->picked_right;
+                    o->flags = (uint8_t)((l->bw_set ? SDV_P1S_BW_SET : 0) | (l->crc ? SDV_P1S_CRC_VALID : 0));
+                }
+            }
+        }
+        s->vl_n++;
+    }
     for (int iblk = 0; iblk < P1_INT_BLK; iblk++) {
         blk_clear(&b);
         if (s->qn >= P1_MIN_DEINT) {            /* processBlock: DI_RET_NO_DATA leaves the cleared block */
@@ -199,6 +238,7 @@ static void perform_deinterleave(p1_stitcher *s)   /* :1382-1453 */
             p.sample_flags[1] = (uint8_t)((valid ? SDV_SF_BLOCK_OK : 0) | (((w + 1) < blk_word_count(&b) && b.word_crc[w + 1]) ? SDV_SF_WORD_VALID : 0));
             out_pair(s, &p);
         }
+        vis_block(s, &b);
     }
 }
 
@@ -352,14 +392,25 @@ void orc_default_pcm1_stitch_settings(sdv_pcm1_stitch_settings *st)
 long orc_pcm1_stitch_run(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                          sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames)
 {
+    return orc_pcm1_stitch_run_vis(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL, 0, NULL, NULL, 0, NULL);
+}
+/* ... with the visualiser's feeds: blocks (16 per frame) and sub-lines (1470 per frame) next to the pairs */
+long orc_pcm1_stitch_run_vis(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                             sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm1_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                             sdv_pcm1_asm_line_rec *lines, size_t lines_cap, size_t *n_lines)
+{
     p1_stitcher *s = (p1_stitcher *)calloc(1, sizeof(p1_stitcher));
     s->st = *st; s->out = out; s->out_cap = out_cap; s->frames = frames; s->frames_cap = frames_cap;
+    for (int i = 0; i < P1_SUBLINES_PF; i++) { sub_clear(&s->odd[i]); sub_clear(&s->even[i]); }     /* the field buffers of a new stitcher: cleared sub-lines (silent words) */
+    s->vb = blocks; s->vb_cap = blocks_cap; s->vl = lines; s->vl_cap = lines_cap;
     frasm_clear(&s->f1);
     size_t lo = 0;
     for (size_t i = 0; i < n_recs; i++)
         if (recs[i].service_type == SDV_SRV_END_FRAME) { stitch_frame(s, recs, lo, i, recs[i].frame_number); lo = i + 1; }
     long n = s->out_n > out_cap ? -1 : (long)s->out_n;
     if (n_frames) *n_frames = s->frames_n;
+    if (n_blocks) *n_blocks = s->vb_n;
+    if (n_lines) *n_lines = s->vl_n;
     free(s->q); free(s);
     return n;
 }

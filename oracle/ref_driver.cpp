@@ -645,10 +645,57 @@ static void frasm1_to_pod(FrameAsmPCM1 &f, sdv_frame_asm_pcm1 *o)
                          (f.odd_emphasis ? SDV_FA1_ODD_EMPHASIS : 0) | (f.even_emphasis ? SDV_FA1_EVEN_EMPHASIS : 0));
 }
 
+/* a PCM1DataBlock through its public interface (what the visualiser can ask of it) */
+static void pcm1_block_to_rec(PCM1DataBlock &b, sdv_pcm1_block_rec *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->frame_number = b.frame_number; o->start_line = b.start_line; o->stop_line = b.stop_line; o->interleave_num = b.interleave_num;
+    o->flags = (uint8_t)((b.isShortLength() ? SDV_P1B_SHORT : 0) | (b.hasEmphasis() ? SDV_P1B_EMPHASIS : 0));
+    o->sample_rate = b.sample_rate;
+    const bool was_short = b.isShortLength();
+    b.setNormalLength();                   /* (getWord and the flags answer for words 182, 183 of a short block as well that way; a copy is worked on) */
+    for (int i = 0; i < PCM1DataBlock::WORD_CNT; i++) {
+        o->words[i] = b.getWord((uint8_t)i);
+        o->word_flags[i] = (uint8_t)((b.isWordCRCOk((uint8_t)i) ? SDV_P1W_CRC_OK : 0) | (b.hasPickedSample((uint8_t)i) ? SDV_P1W_PICKED_LEFT : 0) |
+                                     (b.hasPickedWord((uint8_t)i) ? SDV_P1W_PICKED_WORD : 0));
+    }
+    if (was_short) b.setShortLength();
+}
+static long ref_pcm1_stitch_run_impl(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                     sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm1_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                                     sdv_pcm1_asm_line_rec *vlines, size_t vlines_cap, size_t *n_vlines);
 extern "C" long ref_pcm1_stitch_run(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                     sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames)
 {
+    return ref_pcm1_stitch_run_impl(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL, 0, NULL, NULL, 0, NULL);
+}
+/* ... with what the stitcher hands to the visualiser: newBlockProcessed (16 blocks per frame) and newLineProcessed (the sub-lines of its queue that carry
+ * the frame's number, in the order they are handed over: the engine's 1470 places per frame without the ones marked SDV_P1S_SKIP). */
+extern "C" long ref_pcm1_stitch_run_vis(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                        sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm1_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                                        sdv_pcm1_asm_line_rec *vlines, size_t vlines_cap, size_t *n_vlines)
+{
+    return ref_pcm1_stitch_run_impl(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, blocks, blocks_cap, n_blocks, vlines, vlines_cap, n_vlines);
+}
+static long ref_pcm1_stitch_run_impl(const sdv_pcm1_line_rec *recs, size_t n_recs, const sdv_pcm1_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                     sdv_frame_asm_pcm1 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm1_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                                     sdv_pcm1_asm_line_rec *vlines, size_t vlines_cap, size_t *n_vlines)
+{
     PCM1DataStitcher *ds = new PCM1DataStitcher();
+    size_t blocks_seen = 0, vlines_seen = 0;
+    if (blocks || vlines) {
+        QObject::connect(ds, &PCM1DataStitcher::newBlockProcessed, [&](PCM1DataBlock b) { if (blocks && blocks_seen < blocks_cap) pcm1_block_to_rec(b, &blocks[blocks_seen]); blocks_seen++; });
+        QObject::connect(ds, &PCM1DataStitcher::newLineProcessed, [&](PCM1SubLine l) {
+            if (vlines && vlines_seen < vlines_cap) {
+                sdv_pcm1_asm_line_rec *o = &vlines[vlines_seen];
+                memset(o, 0, sizeof(*o));
+                o->frame_number = l.frame_number; o->line_number = l.line_number; o->words[0] = l.getLeft(); o->words[1] = l.getRight();
+                o->picked_bits_left = l.picked_bits_left; o->picked_bits_right = l.picked_bits_right; o->line_part = l.getLinePart();
+                o->flags = (uint8_t)((l.hasBWSet() ? SDV_P1S_BW_SET : 0) | (l.isCRCValid() ? SDV_P1S_CRC_VALID : 0));
+            }
+            vlines_seen++;
+        });
+    }
     std::deque<PCM1Line> in_q;
     std::deque<PCMSamplePair> out_q;
     QMutex in_mtx, out_mtx, fr_mtx;
@@ -695,6 +742,8 @@ extern "C" long ref_pcm1_stitch_run(const sdv_pcm1_line_rec *recs, size_t n_recs
     size_t nf = fr.size() < frames_cap ? fr.size() : frames_cap;
     for (size_t i = 0; i < nf; i++) frasm1_to_pod(fr[i], &frames[i]);
     if (n_frames) *n_frames = fr.size();
+    if (n_blocks) *n_blocks = blocks_seen;
+    if (n_vlines) *n_vlines = vlines_seen;
     delete ds;
     return overflow ? -1 : got;
 }

@@ -139,6 +139,8 @@ struct FrameArgs1 {
      * reached that far, or `hist`, the buffers as the calls before left them. */
     uint32_t *cnt_out, *kept_out;               /* per frame: odd | even << 16 lines split; per frame 2 x 245 record indices */
     const uint32_t *cnt_in, *kept_in; const void *hist;     /* hist: 2 x 245 Line16 */
+    /* the visualiser's feeds (sdv_set_pcm1_stitch_block_output / _line_output): 16 blocks and 1470 sub-lines per frame, or NULL */
+    sdv_pcm1_block_rec *out_blocks; uint64_t blocks_cap; sdv_pcm1_asm_line_rec *out_asm; uint64_t asm_cap;
 };
 
 
@@ -485,8 +487,11 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         const uint32_t f_top = odd_field ? top_pad[0] : top_pad[1], f_bot = odd_field ? bot_pad[0] : bot_pad[1], f_data = odd_field ? data[0] : data[1];
         const uint32_t f_lines = f_data <= SUBLINES_PF ? f_data / 3 : 0u;      /* addLinesFromField refuses more than a field (:960) */
         /* The padded field is 245 lines of 3 sub-lines; a lane takes a line.  First the lines' flags as three 245-bit masks ... */
-        uint64_t okm[4], pkm[4], plm[4];
+        uint64_t okm[4], pkm[4], plm[4], nvm[4];
         uint32_t li[4];
+        /* (a place of the field buffer that no frame has ever written holds a cleared sub-line, part 0: the stitcher's line counter does not move on
+         * behind it, addLinesFromField :974-978 - only the visualiser's feeds carry those numbers) */
+        auto stale_at = [&](uint32_t i) -> bool { return kLds ? i >= n_scan : (i & 0x8000u) != 0; };
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const uint32_t pl = (uint32_t)(c * 64 + lane);
@@ -494,7 +499,17 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             li[c] = is_line ? fidx[pl - f_top] : P1_NONE;
             const uint32_t fl = is_line ? (kLds ? (uint32_t)lines[li[c]].fl : (uint32_t)line_at(li[c]).fl) : 0u;
             okm[c] = __ballot((fl & LF_OK) != 0); pkm[c] = __ballot((fl & LF_PICK) != 0); plm[c] = __ballot((fl & LF_PICKL) != 0);
+            nvm[c] = (a.out_blocks || a.out_asm) ? __ballot(is_line && stale_at(li[c]) && (fl & LF_DATA) == 0) : 0ull;
         }
+        auto rows_unnumbered_below = [&](uint32_t row) -> uint32_t {
+            uint32_t n = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if (row >= 64u * (uint32_t)(w + 1)) n += (uint32_t)__popcll(nvm[w]);
+                else if (row > 64u * (uint32_t)w) n += (uint32_t)__popcll(nvm[w] & ((1ull << (row - 64u * (uint32_t)w)) - 1ull));
+            }
+            return n;
+        };
         okm[3] |= ~0ull << (LINES_PF - 192);                    /* lines past the field do not exist: not "bad" */
         if (fld == 0) P1_STAMP(5);
         /* ... then the blocks: block b is sub-lines [92 b, 92 b + 92) (the last one: 91), i.e. whole lines plus a partial line at
@@ -542,6 +557,76 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             const uint32_t flags = ((valid_blocks >> blk) & 1u ? (uint32_t)SDV_SF_BLOCK_OK : 0u) | (ok ? (uint32_t)SDV_SF_WORD_VALID : 0u);
             if (o < lim)
                 store_pair((sdv_sample_pair *)(base + o * 12u), make_pair3(p1_sample((uint16_t)(ww & 0xFFFF)), p1_sample((uint16_t)(ww >> 16)), flags, 44100, emphasis_set, 0));
+        }
+        /* the visualiser's feeds.  newBlockProcessed (:1333): the block as PCM1Deinterleaver::setWordData filled it - pair pr of block blk is its words
+         * 2 pr, 2 pr + 1 (what the loop above reads); newLineProcessed (:1392-1407): the queue itself, sub-line after sub-line.  The stitcher numbers the
+         * lines of its queue anew (addFieldPadding / addLinesFromField, :952-1073): 1, 3, 5 ... down the odd field, 2, 4, 6 ... down the even one. */
+        if (a.out_blocks || a.out_asm) {
+            const uint64_t d = (pofs - fofs) / (uint64_t)(2 * SUBLINES_PF - 1);       /* frames ahead of this one that are no file tags: their pairs minus their descriptors */
+            const uint32_t first_line = odd_field ? 1u : 2u;
+            if (a.out_blocks) {
+                const uint64_t bb = d * 16u + 8u * (uint32_t)fld;
+                for (uint32_t c = 0; c < SUBLINES_PF + 1; c += 64) {
+                    const uint32_t o = c + (uint32_t)lane;                              /* o = 735: the two words the last block does not have */
+                    const uint32_t blk = o < SUBLINES_PF ? o / 92 : 7u, pr = o - 92 * blk;
+                    if (o > SUBLINES_PF || bb + blk >= a.blocks_cap) continue;
+                    sdv_pcm1_block_rec *b = &a.out_blocks[bb + blk];
+                    uint32_t ww = (uint32_t)BIT_RANGE | ((uint32_t)BIT_RANGE << 16), f0 = 0, f1 = 0;
+                    if (o < SUBLINES_PF) {
+                        const uint32_t sub = 92 * blk + ((((blk & 1) == 0) == ((pr & 1) != 0)) ? 0u : 46u) + (pr >> 1);
+                        const uint32_t pl = sub / 3, part = sub - 3 * pl;
+                        if (pl >= f_top && pl - f_top < f_lines) {
+                            const Line16 l = line_at(fidx[pl - f_top]);
+                            ww = part == 0 ? (l.w[0] | ((uint32_t)l.w[1] << 16)) : (part == 1 ? (l.w[2] | ((uint32_t)l.w[3] << 16)) : (l.w[4] | ((uint32_t)l.w[5] << 16)));
+                            const uint32_t ok = (l.fl & LF_OK) ? (uint32_t)SDV_P1W_CRC_OK : 0u, pc = (l.fl & LF_PICK) ? (uint32_t)SDV_P1W_PICKED_WORD : 0u;
+                            f0 = ok | pc | ((part == 0 && (l.fl & LF_PICKL)) ? (uint32_t)(SDV_P1W_PICKED_LEFT | SDV_P1W_PICKED_WORD) : 0u); f1 = ok | pc;
+                        }
+                    }
+                    *(uint32_t *)&b->words[2 * pr] = ww;
+                    b->word_flags[2 * pr] = (uint8_t)f0; b->word_flags[2 * pr + 1] = (uint8_t)f1;
+                    if (pr == 0) {
+                        const uint32_t r0 = (92 * blk) / 3, r1 = (92 * blk + 91) / 3;
+                        /* the number of the block's first sub-line: the frame's - a filler line of the odd field went into the field buffer as a cleared
+                         * PCM1Line, number 0 (splitFrameToFields, :713-717); lines earlier frames left in the field buffers count as this frame's */
+                        uint32_t fno = frame;
+                        if (r0 >= f_top && r0 - f_top < f_lines) {
+                            const uint32_t l0i = fidx[r0 - f_top];
+                            if (odd_field && !stale_at(l0i) && a.src.at(lo + l0i).service_type == SDV_SRV_FILLER) fno = 0;
+                        }
+                        b->frame_number = fno;
+                        b->start_line = (uint16_t)(first_line + 2 * (r0 - rows_unnumbered_below(r0))); b->stop_line = (uint16_t)(first_line + 2 * (r1 - rows_unnumbered_below(r1)));
+                        b->interleave_num = (uint8_t)blk; b->flags = (uint8_t)((blk == 7 ? SDV_P1B_SHORT : 0) | (emphasis_set ? SDV_P1B_EMPHASIS : 0));
+                        b->sample_rate = 44100;
+                        for (int i = 0; i < 12; i++) b->_pad[i] = 0;
+                    }
+                }
+            }
+            if (a.out_asm) {
+                const uint64_t lb = d * (uint64_t)(2 * SUBLINES_PF) + (uint64_t)SUBLINES_PF * (uint32_t)fld;
+                for (uint32_t c = 0; c < SUBLINES_PF; c += 64) {
+                    const uint32_t sub = c + (uint32_t)lane, pl = sub / 3, part = sub - 3 * pl;
+                    if (sub >= SUBLINES_PF || lb + sub >= a.asm_cap) continue;
+                    sdv_pcm1_asm_line_rec r;
+                    r.frame_number = frame; r.line_number = (uint16_t)(first_line + 2 * (pl - rows_unnumbered_below(pl))); r.words[0] = r.words[1] = (uint16_t)BIT_RANGE;
+                    r.picked_bits_left = r.picked_bits_right = 0; r.line_part = (uint8_t)part; r.flags = 0; r._pad[0] = r._pad[1] = 0;
+                    if (pl >= f_top && pl - f_top < f_lines) {
+                        const uint32_t li1 = fidx[pl - f_top];
+                        const bool own = kLds ? li1 < n_scan : (li1 & 0x8000u) == 0;       /* else: a line an earlier frame left in the field buffer */
+                        if (!own) { r.flags = SDV_P1S_SKIP; if ((line_at(li1).fl & LF_DATA) == 0) r.line_part = 0; }
+                        else {
+                            const Line16 l = line_at(li1);
+                            const sdv_pcm1_line_rec &src = a.src.at(lo + li1);
+                            if (odd_field && src.service_type == SDV_SRV_FILLER) r.flags = SDV_P1S_SKIP;     /* went in with frame number 0 (:713-717): not handed over */
+                            else {
+                                r.words[0] = l.w[2 * part]; r.words[1] = l.w[2 * part + 1];
+                                r.flags = (uint8_t)(((l.fl & LF_BW) ? SDV_P1S_BW_SET : 0) | ((l.fl & LF_VALID) ? SDV_P1S_CRC_VALID : 0));
+                                if (l.fl & (LF_PICK | LF_PICKL)) { r.picked_bits_left = part == 0 ? src.picked_bits_left : 0; r.picked_bits_right = src.picked_bits_right; }
+                            }
+                        }
+                    }
+                    a.out_asm[lb + sub] = r;
+                }
+            }
         }
         po += SUBLINES_PF;
     }

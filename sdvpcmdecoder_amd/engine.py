@@ -138,6 +138,11 @@ def load_library(path: str | None = None):
     lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_stitch_block_count.restype = C.c_size_t
     lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
+    for nm in ("sdv_set_pcm1_stitch_block_output", "sdv_set_pcm1_stitch_line_output"):
+        getattr(lib, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    for nm in ("sdv_pcm1_stitch_block_count", "sdv_pcm1_stitch_line_count"):
+        getattr(lib, nm).restype = C.c_size_t
+        getattr(lib, nm).argtypes = [C.c_void_p]
     lib.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_stitch_line_count.restype = C.c_size_t
     lib.sdv_stitch_line_count.argtypes = [C.c_void_p]
@@ -541,6 +546,31 @@ class Engine:
             break
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
+
+    def set_pcm1_stitch_block_output(self, blocks):
+        """sdv_set_pcm1_stitch_block_output: `blocks` = (cap, 576) uint8 CUDA tensor the following pcm1_stitch_frames calls fill with their
+        PCM1DataBlocks, 16 per frame (None: off).  The tensor must stay alive while it is set."""
+        self._p1_block_out = blocks
+        if blocks is None:
+            self._check(self.lib.sdv_set_pcm1_stitch_block_output(self._h, None, 0))
+        else:
+            assert blocks.is_cuda and blocks.is_contiguous() and blocks.shape[1] == 576
+            self._check(self.lib.sdv_set_pcm1_stitch_block_output(self._h, C.c_void_p(blocks.data_ptr()), blocks.shape[0]))
+
+    def pcm1_stitch_block_count(self) -> int:
+        return int(self.lib.sdv_pcm1_stitch_block_count(self._h))
+
+    def set_pcm1_stitch_line_output(self, lines):
+        """sdv_set_pcm1_stitch_line_output: `lines` = (cap, 16) uint8 CUDA tensor for the sub-lines of the stitcher's queue, 1470 per frame."""
+        self._p1_line_out = lines
+        if lines is None:
+            self._check(self.lib.sdv_set_pcm1_stitch_line_output(self._h, None, 0))
+        else:
+            assert lines.is_cuda and lines.is_contiguous() and lines.shape[1] == 16
+            self._check(self.lib.sdv_set_pcm1_stitch_line_output(self._h, C.c_void_p(lines.data_ptr()), lines.shape[0]))
+
+    def pcm1_stitch_line_count(self) -> int:
+        return int(self.lib.sdv_pcm1_stitch_line_count(self._h))
 
     def pcm1_bin_to_line_recs(self, bin_recs, out=None, stream=None):
         """The records pcm1_binarize_frames returns ((n, 40) sdv_pcm1_bin_rec) as the records pcm1_stitch_frames takes ((n, 32) sdv_pcm1_line_rec)."""

@@ -97,6 +97,26 @@ def emu_pcm1_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None
     return rc, pairs[:min(npairs.value, pair_cap)], frames[:min(nframes.value, frame_cap)]
 
 
+def emu_pcm1_stitch_vis(lib, eng, recs, settings=None, blocks=True, lines=True, block_cap=None, line_cap=None):
+    """... with the visualiser's feeds switched on (sdv_set_pcm1_stitch_block_output / _line_output): (rc, pairs, frames, blocks, sub-lines)."""
+    import pcm1_api as p1
+    for nm in ("sdv_set_pcm1_stitch_block_output", "sdv_set_pcm1_stitch_line_output"):
+        getattr(lib, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    for nm in ("sdv_pcm1_stitch_block_count", "sdv_pcm1_stitch_line_count"):
+        getattr(lib, nm).restype = C.c_size_t
+        getattr(lib, nm).argtypes = [C.c_void_p]
+    nfr = int((recs["service_type"] == 5).sum()) + 2
+    bl = np.zeros(block_cap if block_cap is not None else nfr * 16, dtype=p1.BLOCK1_DTYPE)
+    ln = np.zeros(line_cap if line_cap is not None else nfr * 1470, dtype=p1.ASM1_DTYPE)
+    assert lib.sdv_set_pcm1_stitch_block_output(eng, bl.ctypes.data if blocks else None, len(bl)) == 0
+    assert lib.sdv_set_pcm1_stitch_line_output(eng, ln.ctypes.data if lines else None, len(ln)) == 0
+    rc, pairs, frames = emu_pcm1_stitch(lib, eng, recs, settings)
+    nb, nl = lib.sdv_pcm1_stitch_block_count(eng), lib.sdv_pcm1_stitch_line_count(eng)
+    emu_pcm1_stitch_vis.last_counts = (nb, nl)          # what the call made (or needed)
+    assert lib.sdv_set_pcm1_stitch_block_output(eng, None, 0) == 0 and lib.sdv_set_pcm1_stitch_line_output(eng, None, 0) == 0
+    return rc, pairs, frames, bl[:min(nb, len(bl))].copy(), ln[:min(nl, len(ln))].copy()
+
+
 def emu_pcm16_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
     """Host-memory call (emulator build only): one sdv_pcm16x0_stitch_frames call over `recs`."""
     import pcm16_api as p16

@@ -160,5 +160,45 @@ def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None, overflow_ok=Fa
     return pairs[:n], frames[:min(nf.value, frame_cap)]
 
 
+# ---- what the stitcher hands to the visualiser (sdv_set_pcm1_stitch_block_output / _line_output) ----------------------------------------------
+BLOCK1_DTYPE = np.dtype([("frame_number", "<u4"), ("start_line", "<u2"), ("stop_line", "<u2"), ("interleave_num", "u1"), ("flags", "u1"), ("sample_rate", "<u2"),
+                         ("words", "<u2", (184,)), ("word_flags", "u1", (184,)), ("_pad", "u1", (12,))])
+ASM1_DTYPE = np.dtype([("frame_number", "<u4"), ("line_number", "<u2"), ("words", "<u2", (2,)), ("picked_bits_left", "u1"), ("picked_bits_right", "u1"),
+                       ("line_part", "u1"), ("flags", "u1"), ("_pad", "u1", (2,))])
+assert BLOCK1_DTYPE.itemsize == 576 and ASM1_DTYPE.itemsize == 16
+P1S_SKIP = 0x80
+
+
+def run_cpu_vis(lib, prefix, recs, st):
+    """(pairs, frames, blocks, sub-lines): the stitcher's run with the two feeds of the visualiser switched on."""
+    f = getattr(lib, prefix + "pcm1_stitch_run_vis")
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm1Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == SRV_END_FRAME).sum()) + 2
+    pairs = np.zeros(nfr * 1472 + 16, dtype=PAIR_DTYPE)
+    frames = np.zeros(nfr + 8, dtype=FRASM1_DTYPE)
+    blocks = np.zeros(nfr * 16, dtype=BLOCK1_DTYPE)
+    lines = np.zeros(nfr * 1470, dtype=ASM1_DTYPE)
+    nf, nb, nl = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, len(pairs), frames.ctypes.data, len(frames), C.byref(nf),
+          blocks.ctypes.data, len(blocks), C.byref(nb), lines.ctypes.data, len(lines), C.byref(nl))
+    assert n >= 0 and nb.value <= len(blocks) and nl.value <= len(lines)
+    return pairs[:n], frames[:nf.value], blocks[:nb.value], lines[:nl.value]
+
+
+VIS_GOLDEN = ("bad5", "picked_forced", "header_emph", "manual_lost_lines", "bff")
+
+
+def comparable_blocks(blocks, stale_frames=False):
+    """Blocks with what the reference leaves undefined taken out: the stop line of a field's last block (read one sub-line past the end of the queue)."""
+    b = blocks.copy()
+    b["stop_line"][b["interleave_num"] == 7] = 0
+    if stale_frames:
+        b["frame_number"] = 0
+    return b
+
+
 def digest(pairs, frames):
     return hashlib.sha256(pairs.tobytes() + frames.tobytes()).hexdigest()
