@@ -783,9 +783,15 @@ size_t sdv_stitch_line_counts(sdv_engine *e, uint32_t *per_turn, size_t cap);
  * reference leaves those rows uninitialised).  Records behind the last END_FRAME are not drawn: pass whole frames.  *n_frames = frames in
  * `recs`; more than canvases_cap: SDV_ERR_BAD_ARG, nothing drawn.  Device pointers; the call reads one small array back (the frame count)
  * and leaves the drawing running on `stream`.  sdv_vis_reset: a new canvas (RenderPCM::startNewFrame).
- * The block canvas and the assembled-lines canvas of STC-007 follow below; those of PCM-1 / PCM-16x0 are not rebuilt. */
+ *   SDV_VIS_PCM1_ASM         sdv_pcm1_asm_line_rec     624 x 490   (startPCM1SubFrame: the assembled-lines window of PCM-1, renderNewLine(PCM1SubLine),
+ *                                                                   renderpcm.cpp:626-741, on what sdv_set_pcm1_stitch_line_output wrote: 1470 records are a
+ *                                                                   frame - no END_FRAME records here -, records marked SDV_P1S_SKIP are not drawn)
+ * The block canvases and the assembled-lines canvas of STC-007 follow below. */
 enum { SDV_VIS_STC007_LINES = 0, SDV_VIS_PCM1_LINES = 1, SDV_VIS_PCM16X0_LINES = 2, SDV_VIS_STC007_BLOCKS_NTSC = 3, SDV_VIS_STC007_BLOCKS_PAL = 4,
        SDV_VIS_STC007_ASM_NTSC = 5, SDV_VIS_STC007_ASM_PAL = 6,
+       SDV_VIS_PCM1_BLOCKS = 7,         /* sdv_vis_render_blocks on sdv_pcm1_block_rec: 858 x 368 (startPCM1DBFrame), 23 rows of 8 words per block */
+       SDV_VIS_PCM1_ASM = 8,            /* sdv_vis_render_lines on sdv_pcm1_asm_line_rec: 624 x 490 (startPCM1SubFrame), three sub-lines per row */
+       SDV_VIS_PCM16X0_BLOCKS = 9,      /* sdv_vis_render_blocks on sdv_pcm16x0_block_rec: 678 x 490 (startPCM1600DBFrame), one row per block */
        SDV_VIS_M2_SAMPLES = 0x100 };   /* or-ed to a block canvas: the blocks hold M2 samples (STC007DataBlock::setM2Format; getSample's M2 branch, stc007datablock.cpp:527-556) */
 int sdv_vis_canvas_size(int kind, uint32_t *width, uint32_t *height);
 int sdv_vis_reset(sdv_engine *e, int kind, void *stream);
@@ -798,8 +804,14 @@ int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_rec
  * (sdv_frame_asm::blocks_total of the descriptors that are no file tags); blocks past the canvas' rows are dropped like in the reference.
  * out_canvases[f] = the canvas after frame f; the engine keeps the last one per kind.  kind | SDV_VIS_M2_SAMPLES: the samples are drawn as
  * getSample() expands M2 words (12 bits + range bit) and "near silence" is judged on the 16-bit scale, as for blocks with setM2Format(true).
- * Not covered: emphasis (the reference never sets it for STC-007, stc007datastitcher.cpp:6719).  Device pointers but frame_blocks; asynchronous on `stream`. */
-int sdv_vis_render_blocks(sdv_engine *e, int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
+ * Not covered: emphasis (the reference never sets it for STC-007, stc007datastitcher.cpp:6719).  Device pointers but frame_blocks; asynchronous on `stream`.
+ * SDV_VIS_PCM1_BLOCKS: renderNewBlock(PCM1DataBlock) (renderpcm.cpp:1171-1400) on the sdv_pcm1_block_rec buffer sdv_set_pcm1_stitch_block_output
+ * filled (frame_blocks[f] = 16): a block is 23 rows of eight words - per row a status bar (picked / invalid marks per word, block validity, near
+ * silence), the eight 16-bit samples, the block's parity in the field and the emphasis mark.
+ * SDV_VIS_PCM16X0_BLOCKS: renderNewBlock(PCM16X0DataBlock) (:1403-1768) on sdv_pcm16x0_block_rec (sdv_set_pcm16x0_stitch_block_output; frame_blocks[f] =
+ * sdv_frame_asm_pcm16x0::blocks_total): one row per block - Bit Picker / P-correction marks per sub-block, the six samples, format and BROKEN marks.
+ * `blocks` points to the record type of the kind. */
+int sdv_vis_render_blocks(sdv_engine *e, int kind, const void *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
                           uint32_t *out_canvases, size_t canvases_cap, void *stream);
 /* The assembled-lines window (renderAssembled, mainwindow.cpp:2000-2052): RenderPCM::renderNewLine(STC007Line) on the lines the stitcher hands over -
  * the line buffer sdv_set_stitch_line_output filled - where every word has its own state after the CWD pass (grey: read, green: repaired, yellow / red:

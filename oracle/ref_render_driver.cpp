@@ -78,6 +78,26 @@ extern "C" long ref_vis_render_lines(int kind, const void *recs, size_t n_recs, 
         frames++;
     });
     ren.setLivePlay(false);
+    if (kind == 8) {        /* the assembled-lines window of PCM-1 (mainwindow.cpp:2034-2040): renderNewLine(PCM1SubLine) on the sub-lines the stitcher handed over
+                             * (the records not marked SDV_P1S_SKIP), prepareNewFrame behind every frame's 1470 places */
+        ren.startPCM1SubFrame();
+        const sdv_pcm1_asm_line_rec *l = (const sdv_pcm1_asm_line_rec *)recs;
+        PCM1SubLine sl;
+        for (size_t i = 0; i < n_recs; i++) {
+            if (!(l[i].flags & SDV_P1S_SKIP)) {
+                sl.clear();
+                sl.frame_number = l[i].frame_number; sl.line_number = l[i].line_number;
+                sl.picked_bits_left = l[i].picked_bits_left; sl.picked_bits_right = l[i].picked_bits_right;
+                sl.setLinePart(l[i].line_part); sl.setLeft(l[i].words[0]); sl.setRight(l[i].words[1]);
+                sl.setBWLevels((l[i].flags & SDV_P1S_BW_SET) != 0); sl.setCRCValid((l[i].flags & SDV_P1S_CRC_VALID) != 0);
+                ren.renderNewLine(sl);
+            }
+            if ((i + 1) % 1470 == 0) { ren.prepareNewFrame((uint32_t)(i / 1470)); ren.displayIsReady(); }
+        }
+        if (width) *width = w;
+        if (height) *height = h;
+        return frames;
+    }
     if (kind == 0) { ren.startSTC007NTSCFrame(); ren.setLineCount(FrameAsmDescriptor::VID_UNKNOWN); }
     else if (kind == 1) ren.startPCM1Frame();
     else ren.startPCM1600Frame();
@@ -120,10 +140,24 @@ static bool to_block(const sdv_block_rec &r, STC007DataBlock &b)
     return ok;
 }
 
-/* kind: 3 NTSC (490 rows), 4 PAL (588 rows).  frame_blocks[f] blocks belong to frame f.  Returns the frames, -2 if a record cannot be expressed. */
-extern "C" long ref_vis_render_blocks(int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
+/* an sdv_pcm1_block_rec back into a PCM1DataBlock through its public interface: setWord takes the two Bit Picker flags apart (picked_left, picked_crc);
+ * the record holds hasPickedSample (= picked_left) and hasPickedWord (= either) - picked_crc = hasPickedWord gives the same two answers */
+#include "pcm1datablock.h"
+static void to_pcm1_block(const sdv_pcm1_block_rec &r, PCM1DataBlock &b)
+{
+    b.clear();
+    b.frame_number = r.frame_number; b.start_line = r.start_line; b.stop_line = r.stop_line; b.interleave_num = r.interleave_num; b.sample_rate = r.sample_rate;
+    if (r.flags & SDV_P1B_SHORT) b.setShortLength(); else b.setNormalLength();     /* (first: setShortLength wipes the words from 181 on, pcm1datablock.cpp:87-98) */
+    for (int i = 0; i < PCM1DataBlock::WORD_CNT; i++)                               /* (setWord ignores what a short block does not have) */
+        b.setWord((uint8_t)i, r.words[i], (r.word_flags[i] & SDV_P1W_CRC_OK) != 0, (r.word_flags[i] & SDV_P1W_PICKED_LEFT) != 0, (r.word_flags[i] & SDV_P1W_PICKED_WORD) != 0);
+    b.setEmphasis((r.flags & SDV_P1B_EMPHASIS) != 0);
+}
+/* kind: 3 NTSC (490 rows), 4 PAL (588 rows), 7 PCM-1 (sdv_pcm1_block_rec, 23 rows per block).  frame_blocks[f] blocks belong to frame f.  Returns the
+ * frames, -2 if a record cannot be expressed. */
+extern "C" long ref_vis_render_blocks(int kind, const void *blocks_, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
                                       uint32_t *out, size_t out_cap, uint32_t *width, uint32_t *height)
 {
+    const sdv_block_rec *blocks = (const sdv_block_rec *)blocks_;
     if (!QCoreApplication::instance()) new QCoreApplication(q_argc, q_argv);
     RenderPCM ren;
     long frames = 0;
@@ -135,6 +169,19 @@ extern "C" long ref_vis_render_blocks(int kind, const sdv_block_rec *blocks, siz
         frames++;
     });
     ren.setLivePlay(false);
+    if (kind == 7) {        /* mainwindow.cpp:2097-2101: startPCM1DBFrame, renderNewBlock(PCM1DataBlock), prepareNewFrame per assembled frame */
+        ren.startPCM1DBFrame();
+        const sdv_pcm1_block_rec *pb = (const sdv_pcm1_block_rec *)blocks_;
+        PCM1DataBlock b1;
+        size_t at1 = 0;
+        for (size_t f = 0; f < n_frames; f++) {
+            for (uint32_t i = 0; i < frame_blocks[f] && at1 < n_blocks; i++, at1++) { to_pcm1_block(pb[at1], b1); ren.renderNewBlock(b1); }
+            ren.prepareNewFrame((uint32_t)f); ren.displayIsReady();
+        }
+        if (width) *width = w;
+        if (height) *height = h;
+        return frames;
+    }
     ren.startSTC007DBFrame();
     const bool m2 = (kind & 0x100) != 0;           /* SDV_VIS_M2_SAMPLES: the blocks of a stream in M2 sample format (STC007DataStitcher sets it on every block) */
     kind &= 0xFF;

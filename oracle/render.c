@@ -31,6 +31,9 @@ void orc_vis_canvas_size(int kind, uint32_t *w, uint32_t *h)
         case ORC_VIS_STC007_BLOCKS_PAL: *w = 6 * (6 + 16 * 6 + 7); *h = 588; break;      /* ... + setLineCount(VID_PAL), mainwindow.cpp:2093 */
         case ORC_VIS_STC007_ASM_NTSC: *w = 5 * 137; *h = 490; break;                     /* startSTC007NTSCFrame (+ setLineCount(VID_NTSC)), mainwindow.cpp:2032, 2046 */
         case ORC_VIS_STC007_ASM_PAL: *w = 5 * 137; *h = 588; break;
+        case ORC_VIS_PCM1_BLOCKS: *w = 6 * (8 + 3 + 8 * 16 + 4); *h = (184 / 8) * 8 * 2; break;     /* startPCM1DBFrame :158-161 */
+        case ORC_VIS_PCM1_ASM: *w = 8 * (94 - 16); *h = 490; break;                              /* startPCM1SubFrame :134-137 */
+        case ORC_VIS_PCM16X0_BLOCKS: *w = 6 * (9 + 16 * 6 + 8); *h = 490; break;                 /* startPCM1600DBFrame :164-167 */
         default: *w = *h = 0;
     }
 }
@@ -138,12 +141,39 @@ static bool pcm16_subline(const sdv_pcm16x0_bin_rec *r, uint32_t *row)
     return part == 2;
 }
 
+/* renderNewLine(PCM1SubLine) :626-741; returns true when the row is finished (PART_RIGHT) */
+static bool pcm1_subline(const sdv_pcm1_asm_line_rec *r, uint32_t *row)
+{
+    const bool crc_valid = (r->flags & SDV_P1S_CRC_VALID) != 0, bw = (r->flags & SDV_P1S_BW_SET) != 0;
+    int part = r->line_part; if (part > 2) part = 0;
+    uint32_t *px = row + (size_t)part * 26 * 8;
+    int line_bit = 0;
+    for (int w = 0; w < 2; w++)
+        for (int b = 12; b >= 0; b--, line_bit++) {
+            const bool picked = line_bit < r->picked_bits_left && r->line_part == 0;
+            const uint32_t c = bit_colour(((r->words[w] >> b) & 1) != 0, crc_valid, false, bw, picked);
+            for (int j = 0; j < 8; j++) *px++ = c;
+        }
+    return r->line_part == 2;
+}
+
 long orc_vis_render_lines(int kind, const void *recs, size_t n_recs, uint32_t *canvas, uint32_t *out, size_t out_cap)
 {
     uint32_t w, h, fill = 0;
     long frames = 0;
     orc_vis_canvas_size(kind, &w, &h);
     if (!w) return -1;
+    if (kind == ORC_VIS_PCM1_ASM) {         /* the sub-lines the PCM-1 stitcher hands over, 1470 places per frame (newFrameAssembled -> prepareNewFrame behind them) */
+        const sdv_pcm1_asm_line_rec *l = (const sdv_pcm1_asm_line_rec *)recs;
+        for (size_t i = 0; i < n_recs; i++) {
+            if (!(l[i].flags & SDV_P1S_SKIP) && fill < h && pcm1_subline(&l[i], canvas + (size_t)fill * w)) fill++;
+            if ((i + 1) % 1470 == 0) {
+                if ((size_t)frames < out_cap) memcpy(out + (size_t)frames * w * h, canvas, (size_t)w * h * 4);
+                frames++; fill = 0;
+            }
+        }
+        return frames;
+    }
     for (size_t i = 0; i < n_recs; i++) {
         uint8_t srv;
         if (kind == ORC_VIS_STC007) srv = ((const sdv_line_rec *)recs)[i].service_type;
@@ -220,13 +250,86 @@ static void stc_block(const sdv_block_rec *b, uint32_t *px, bool m2)
     }
 }
 
-long orc_vis_render_blocks(int kind, const sdv_block_rec *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames, uint32_t *canvas,
+/* ---- renderNewBlock(PCM1DataBlock) :1171-1400: 23 rows of eight words; returns the rows drawn ------------------------------------------- */
+static int16_t p1_sample(uint16_t w)        /* PCM1DataBlock::getSample, pcm1datablock.cpp:309-348 */
+{
+    if ((w & (1 << 12)) == 0) return (int16_t)(uint16_t)(w << 4);
+    {
+        const bool positive = (w & (1 << 11)) == 0;
+        w = (uint16_t)(w & ~(1 << 12));
+        w = (uint16_t)(w << 2);
+        if (!positive) w |= (1 << 15) | (1 << 14);
+        return (int16_t)w;
+    }
+}
+static uint32_t pcm1_block(const sdv_pcm1_block_rec *b, uint32_t *canvas, uint32_t w_px, uint32_t fill, uint32_t h)
+{
+    const bool is_short = (b->flags & SDV_P1B_SHORT) != 0;
+    const int count = is_short ? 182 : 184;
+    bool valid = true, silent = true;
+    uint32_t drawn_rows = 0;
+    if (fill >= h) return 0;                                                            /* :1183-1189 */
+    for (int i = 0; i < count; i++) {
+        const int16_t v = p1_sample(b->words[i]);
+        if (!(b->word_flags[i] & SDV_P1W_CRC_OK)) valid = false;                        /* isBlockValid: getErrorsAudio() == 0 */
+        if (v >= 16 || v < -16) silent = false;                                         /* isAlmostSilent :229-244 */
+    }
+    for (int line = 0; line < 184 / 8; line++) {
+        uint32_t *px = canvas + (size_t)fill * w_px;
+        const int w0 = line * 8;
+        for (int i = 0; i < 8 + 3; i++) {                                               /* the status bar :1213-1283 */
+            uint32_t c = PX_BLK;
+            if (i < 8) {
+                const bool there = !is_short || (w0 + i) < 182;
+                if (i % 2 == 0) { if (there) { if (b->word_flags[w0 + i] & SDV_P1W_PICKED_LEFT) c = B1_BLU; else if (b->word_flags[w0 + i] & SDV_P1W_PICKED_WORD) c = B0_BLU; } }
+                else if (there && !(b->word_flags[w0 + i] & SDV_P1W_CRC_OK)) c = B1_YEL;
+            } else if (i == 8) { if (!valid) c = B1_RED; }
+            else if (i == 10) c = silent ? LIM_MARK : LIM_OK;
+            for (int j = 0; j < 6; j++) *px++ = c;
+        }
+        for (int w = w0; w < w0 + 8; w++) {                                             /* the samples :1286-1352 */
+            const uint16_t v = (uint16_t)p1_sample(b->words[w]);
+            for (int bit = 15; bit >= 0; bit--) {
+                const bool one = (v >> bit) & 1;
+                uint32_t c;
+                if (is_short && w >= 182) c = PX_BLK;
+                else if (!(b->word_flags[w] & SDV_P1W_CRC_OK)) c = one ? B1_RED : B0_RED;
+                else if (b->word_flags[w] & SDV_P1W_PICKED_LEFT) c = one ? B1_BLU : B0_BLU;
+                else c = one ? B1_GRY : PX_BLK;
+                for (int j = 0; j < 6; j++) *px++ = c;
+            }
+        }
+        for (int i = 0; i < 4; i++) {                                                   /* parity of the block in its field, emphasis :1355-1387 */
+            uint32_t c = PX_BLK;
+            if (i == 0) c = (b->interleave_num % 2 == 0) ? LIM_OK : LIM_MARK;
+            else if (i == 2) { if (b->flags & SDV_P1B_EMPHASIS) c = B0_GRN; }
+            for (int j = 0; j < 6; j++) *px++ = c;
+        }
+        drawn_rows++;
+        if (fill < h) fill++;
+        if (fill >= h) break;               /* (scanLine past the image: the reference draws nowhere it can be seen; a block never straddles the end - 23 divides 368) */
+    }
+    return drawn_rows;
+}
+
+long orc_vis_render_blocks(int kind, const void *blocks_, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames, uint32_t *canvas,
                            uint32_t *out, size_t out_cap)
 {
     uint32_t w, h;
     const bool m2 = (kind & 0x100) != 0;           /* SDV_VIS_M2_SAMPLES */
     kind &= 0xFF;
     orc_vis_canvas_size(kind, &w, &h);
+    if (kind == ORC_VIS_PCM1_BLOCKS) {
+        const sdv_pcm1_block_rec *pb = (const sdv_pcm1_block_rec *)blocks_;
+        size_t at1 = 0;
+        for (size_t f = 0; f < n_frames; f++) {
+            uint32_t fill = 0;
+            for (uint32_t i = 0; i < frame_blocks[f] && at1 < n_blocks; i++, at1++) fill += pcm1_block(&pb[at1], canvas, w, fill, h);
+            if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
+        }
+        return (long)n_frames;
+    }
+    const sdv_block_rec *blocks = (const sdv_block_rec *)blocks_;
     if (kind != ORC_VIS_STC007_BLOCKS_NTSC && kind != ORC_VIS_STC007_BLOCKS_PAL) return -1;
     size_t at = 0;
     for (size_t f = 0; f < n_frames; f++) {          /* newFrameAssembled -> prepareNewFrame: the canvas goes out, the fill row back to 0 */

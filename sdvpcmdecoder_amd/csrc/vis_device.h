@@ -41,11 +41,15 @@ __host__ __device__ inline Geometry geometry(int kind)
     else if (kind == SDV_VIS_STC007_BLOCKS_PAL) { g.w = 6 * 109; g.h = 588; g.cells_per_row = 1; }      /* ... setLineCount(VID_PAL) */
     else if (kind == SDV_VIS_STC007_ASM_NTSC) { g.w = 5 * 137; g.h = 490; g.cells_per_row = 1; }         /* startSTC007NTSCFrame, setLineCount(VID_NTSC): the assembled lines */
     else if (kind == SDV_VIS_STC007_ASM_PAL) { g.w = 5 * 137; g.h = 588; g.cells_per_row = 1; }
+    else if (kind == SDV_VIS_PCM1_BLOCKS) { g.w = 6 * (8 + 3 + 8 * 16 + 4); g.h = 23 * 8 * 2; g.cells_per_row = 1; }     /* startPCM1DBFrame: 858 x 368 */
+    else if (kind == SDV_VIS_PCM1_ASM) { g.w = 8 * 78; g.h = 490; g.cells_per_row = 3; }                             /* startPCM1SubFrame */
+    else if (kind == SDV_VIS_PCM16X0_BLOCKS) { g.w = 6 * (9 + 16 * 6 + 8); g.h = 490; g.cells_per_row = 1; }          /* startPCM1600DBFrame: 678 x 490 */
     return g;
 }
 /* pixels [x0, x1) of a cell */
 __host__ __device__ inline void cell_span(int kind, uint32_t part, uint32_t &x0, uint32_t &x1)
 {
+    if (kind == SDV_VIS_PCM1_ASM) { x0 = part * 26u * 8u; x1 = x0 + 26u * 8u; return; }        /* renderpcm.cpp:647-655 */
     if (kind != SDV_VIS_PCM16X0_LINES) { x0 = 0; x1 = geometry(kind).w; return; }
     x0 = part == 0 ? 0u : part == 1 ? 4u * 64u : 4u * 129u;
     x1 = part == 0 ? 4u * 64u : part == 1 ? 4u * 129u : 4u * 193u;
@@ -88,6 +92,21 @@ template <> __device__ inline Rec classify<sdv_pcm16x0_bin_rec>(const sdv_pcm16x
     return c;
 }
 
+/* the sub-lines of the PCM-1 stitcher's queue: 1470 records are a frame (there are no END_FRAME records - the last record of a frame ends it, and
+ * is drawn like the others); a record the stitcher did not hand over is not drawn and ends no row */
+enum { P1_ASM_PER_FRAME = 1470 };
+template <> __device__ inline Rec classify<sdv_pcm1_asm_line_rec>(const sdv_pcm1_asm_line_rec *recs, uint32_t i, uint32_t n, int kind)
+{
+    Rec c; c.end = c.drawn = c.adv = false; c.part = 0;
+    if (i >= n) return c;
+    c.end = (i + 1u) % (uint32_t)P1_ASM_PER_FRAME == 0u;
+    c.drawn = (recs[i].flags & SDV_P1S_SKIP) == 0;
+    const uint32_t part = recs[i].line_part;
+    c.adv = c.drawn && part == 2;                       /* renderpcm.cpp:733-739 */
+    c.part = part > 2 ? 0u : part;                      /* :646-648 */
+    return c;
+}
+
 template <class R> __device__ inline void count_body(const VisArgs &a, uint32_t chunk, int lane)
 {
     const Rec c = classify((const R *)a.recs, chunk * 64u + (uint32_t)lane, a.n_recs, a.kind);
@@ -101,7 +120,7 @@ template <class R> __device__ inline void index_body(const VisArgs &a, uint32_t 
     const Rec c = classify((const R *)a.recs, i, a.n_recs, a.kind);
     const uint64_t em = __ballot(c.end), am = __ballot(c.adv);
     const uint32_t f = a.base_end[chunk] + (uint32_t)__popcll(em & lanemask_lt(lane)), adv = a.base_adv[chunk] + (uint32_t)__popcll(am & lanemask_lt(lane));
-    if (c.end && f + 1 < a.n_frames) a.frame_adv0[f + 1] = adv;
+    if (c.end && f + 1 < a.n_frames) a.frame_adv0[f + 1] = adv + (c.adv ? 1u : 0u);       /* (a record that ends its frame and a row: PCM-1 sub-lines) */
     if (i == 0) a.frame_adv0[0] = 0;
 }
 
@@ -184,6 +203,17 @@ __device__ inline Look look_of(const sdv_pcm16x0_bin_rec &r)    /* :743-936 */
     k.hi_h = (uint32_t)(hi >> 32); k.hi_l = (uint32_t)hi; k.lo_h = k.lo_l = 0;
     return k;
 }
+__device__ inline Look look_of(const sdv_pcm1_asm_line_rec &r)  /* :626-741 */
+{
+    Look k; k.aux = 0;
+    uint64_t hi = 0;
+    hi = push(hi, r.words[0], 13); hi = push(hi, r.words[1], 13);
+    hi <<= 38;                                              /* 26 bits, left-aligned */
+    colours(k, (r.flags & SDV_P1S_CRC_VALID) != 0, false, (r.flags & SDV_P1S_BW_SET) != 0);
+    k.pick = r.line_part == 0 ? (uint32_t)r.picked_bits_left : 0u;          /* the mark belongs to the left part of a line (:686, :711) */
+    k.hi_h = (uint32_t)(hi >> 32); k.hi_l = (uint32_t)hi; k.lo_h = k.lo_l = 0;
+    return k;
+}
 __device__ inline uint32_t bit_of(const Look &k, uint32_t b)
 {
     const uint32_t w = b < 32 ? k.hi_h : b < 64 ? k.hi_l : b < 96 ? k.lo_h : k.lo_l;
@@ -215,6 +245,13 @@ template <> __device__ inline uint32_t pixel<sdv_pcm16x0_bin_rec>(const Look &k,
     return picked ? (v ? k.p1 : k.p0) : (v ? k.c1 : k.c0);
 }
 
+template <> __device__ inline uint32_t pixel<sdv_pcm1_asm_line_rec>(const Look &k, uint32_t x, uint32_t)
+{
+    const uint32_t b = x / 8u;
+    const uint32_t v = bit_of(k, b);
+    return b < k.pick ? (v ? k.p1 : k.p0) : (v ? k.c1 : k.c0);
+}
+
 template <class R> __device__ inline void draw_body(const VisArgs &a, uint32_t chunk, int lane)
 {
     const R *recs = (const R *)a.recs;
@@ -226,12 +263,12 @@ template <class R> __device__ inline void draw_body(const VisArgs &a, uint32_t c
     bool live = c.drawn && f < a.n_frames;          /* records behind the last END_FRAME belong to a frame that has not ended */
     uint32_t row = 0;
     if (live) { row = adv - a.frame_adv0[f]; live = row < g.h; }       /* "line overflow": the canvas is full (renderpcm.cpp:955-961) */
-    if (live && g.cells_per_row > 1 && !c.adv) {
+    if (live && g.cells_per_row > 1 && !c.adv && !(c.end && c.drawn)) {
         /* a left or middle sub-line is drawn over by the next one of its kind that comes before the row ends */
         for (uint32_t j = i + 1; j < a.n_recs; j++) {
             const Rec n = classify(recs, j, a.n_recs, a.kind);
+            if (n.drawn && n.part == c.part) { live = false; break; }       /* (n.adv: part 2, never c.part here) */
             if (n.end || n.adv) break;
-            if (n.drawn && n.part == c.part) { live = false; break; }
         }
     }
     Look k = Look();
@@ -378,6 +415,93 @@ __device__ inline void draw_blocks_body(const BlkArgs &a, uint32_t block, int la
     }
 }
 
+/* ---- the data blocks window of PCM-1: renderNewBlock(PCM1DataBlock), renderpcm.cpp:1171-1400 -------------------------------------------------
+ * A block is 23 rows of eight words: row r of a frame belongs to block r / 23 and shows its words 8 (r % 23) .. + 7.  A wave takes 64 rows; a lane
+ * packs what its row shows (eight samples, eight word marks, the block's marks), the wave then writes row after row. */
+struct P1BlkArgs { const sdv_pcm1_block_rec *blocks; const uint32_t *frame_ofs; uint32_t n_frames; int kind; uint32_t *out; uint32_t *wmask; uint32_t wmask_stride; };
+enum { P1BK_ROWS = 23, P1BK_INVALID = 1u << 24, P1BK_SILENT = 1u << 25, P1BK_ODD = 1u << 26, P1BK_EMPH = 1u << 27 };
+__device__ inline int16_t p1blk_sample(uint32_t w)        /* PCM1DataBlock::getSample, pcm1datablock.cpp:309-348 */
+{
+    if ((w & (1u << 12)) == 0) return (int16_t)(uint16_t)(w << 4);
+    const uint32_t v = (w & ~(1u << 12)) << 2;
+    return (int16_t)(uint16_t)((w & (1u << 11)) ? (v | 0xC000u) : v);
+}
+/* fl: bits 0..7 word there (not past a short block's end), 8..15 word invalid, 16..23 word mark (2 bits per pair would do; per word: picked sample),
+ * pk: bits 0..7 hasPickedWord per word */
+__device__ inline uint32_t p1_block_pixel(const uint32_t (&s)[4], uint32_t fl, uint32_t pk, uint32_t x)
+{
+    const uint32_t b = x / 6u;
+    if (b < 11u) {                                          /* the status bar :1213-1283 */
+        if (b < 8u) {
+            const bool there = (fl >> b) & 1u;
+            if ((b & 1u) == 0) return !there ? (uint32_t)PX_BLK : ((fl >> (16u + b)) & 1u) ? (uint32_t)B1_BLU : ((pk >> b) & 1u) ? (uint32_t)B0_BLU : (uint32_t)PX_BLK;
+            return (there && ((fl >> (8u + b)) & 1u)) ? (uint32_t)B1_YEL : (uint32_t)PX_BLK;
+        }
+        if (b == 8u) return (fl & P1BK_INVALID) ? (uint32_t)B1_RED : (uint32_t)PX_BLK;
+        if (b == 10u) return (fl & P1BK_SILENT) ? (uint32_t)LIM_MARK : (uint32_t)LIM_OK;
+        return PX_BLK;
+    }
+    if (b < 139u) {                                         /* eight samples :1286-1352 */
+        const uint32_t w = (b - 11u) / 16u, bit = 15u - ((b - 11u) % 16u);
+        if (!((fl >> w) & 1u)) return PX_BLK;
+        const uint32_t v = (w & 1u) ? s[w >> 1] >> 16 : s[w >> 1] & 0xFFFFu;
+        const bool one = (v >> bit) & 1u;
+        if ((fl >> (8u + w)) & 1u) return one ? (uint32_t)B1_RED : (uint32_t)B0_RED;
+        if ((fl >> (16u + w)) & 1u) return one ? (uint32_t)B1_BLU : (uint32_t)B0_BLU;
+        return one ? (uint32_t)B1_GRY : (uint32_t)PX_BLK;
+    }
+    const uint32_t i = b - 139u;                            /* the block's parity in the field, emphasis :1355-1387 */
+    if (i == 0) return (fl & P1BK_ODD) ? (uint32_t)LIM_MARK : (uint32_t)LIM_OK;
+    if (i == 2) return (fl & P1BK_EMPH) ? (uint32_t)B0_GRN : (uint32_t)PX_BLK;
+    return PX_BLK;
+}
+__device__ inline void draw_p1_blocks_body(const P1BlkArgs &a, uint32_t block, int lane)
+{
+    const Geometry g = geometry(a.kind);
+    const uint32_t chunks = (g.h + 63u) / 64u, f = block / chunks, c = block % chunks;
+    const uint32_t lo = a.frame_ofs[f], nb = a.frame_ofs[f + 1] - lo, n = nb * (uint32_t)P1BK_ROWS;
+    /* a block that starts past the canvas is dropped whole (:1183-1189); one that starts on it draws all of its rows that fit */
+    const uint32_t rows = n < g.h ? n : g.h;
+    if (lane < 2) {
+        const uint32_t first = 64u * c + 32u * (uint32_t)lane, word = 2u * c + (uint32_t)lane;
+        if (word < a.wmask_stride) a.wmask[(size_t)f * a.wmask_stride + word] = rows <= first ? 0u : rows - first >= 32u ? 0xFFFFFFFFu : (1u << (rows - first)) - 1u;
+    }
+    const uint32_t row = 64u * c + (uint32_t)lane;
+    const bool live = row < rows;
+    uint32_t s[4] = { 0, 0, 0, 0 }, fl = 0, pk = 0;
+    if (live) {
+        const sdv_pcm1_block_rec &b = a.blocks[lo + row / (uint32_t)P1BK_ROWS];
+        const uint32_t w0 = 8u * (row % (uint32_t)P1BK_ROWS), count = (b.flags & SDV_P1B_SHORT) ? 182u : 184u;
+        bool invalid = false, silent = true;
+        for (uint32_t w = 0; w < count; w++) {              /* isBlockValid (:190-199), isAlmostSilent (:229-244) */
+            invalid = invalid || !(b.word_flags[w] & SDV_P1W_CRC_OK);
+            const int v = p1blk_sample(b.words[w]);
+            silent = silent && v < 16 && v >= -16;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t w = w0 + k;
+            const uint32_t v = (uint32_t)(uint16_t)p1blk_sample(b.words[w]);
+            s[k >> 1] |= (k & 1u) ? v << 16 : v;
+            if (w < count) fl |= 1u << k;
+            if (!(b.word_flags[w] & SDV_P1W_CRC_OK)) fl |= 1u << (8u + k);
+            if (b.word_flags[w] & SDV_P1W_PICKED_LEFT) fl |= 1u << (16u + k);
+            if (b.word_flags[w] & SDV_P1W_PICKED_WORD) pk |= 1u << k;
+        }
+        fl |= (invalid ? P1BK_INVALID : 0u) | (silent ? P1BK_SILENT : 0u) | ((b.interleave_num & 1u) ? P1BK_ODD : 0u) | ((b.flags & SDV_P1B_EMPHASIS) ? P1BK_EMPH : 0u);
+    }
+    const uint64_t lm = __ballot(live);
+    for (int j = 0; j < 64; j++) {
+        if (!((lm >> j) & 1ull)) continue;
+        uint32_t sj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) sj[q] = (uint32_t)__shfl((int)s[q], j);
+        const uint32_t jfl = (uint32_t)__shfl((int)fl, j), jpk = (uint32_t)__shfl((int)pk, j);
+        uint32_t *dst = a.out + ((size_t)f * g.h + 64u * c + (uint32_t)j) * g.w;
+        for (uint32_t x = (uint32_t)lane; x < g.w; x += 64u) dst[x] = p1_block_pixel(sj, jfl, jpk, x);
+    }
+}
+
 /* ---- the assembled-lines window: renderNewLine(STC007Line) on the stitcher's lines (sdv_asm_line_rec): every word in the colour of its own state ---- */
 struct AsmArgs {
     const sdv_asm_line_rec *lines; const uint32_t *frame_ofs; uint32_t n_frames; int kind;
@@ -447,7 +571,9 @@ __device__ inline void blank_body(const BlankArgs &a, uint32_t i) { if (i < a.n_
 SDV_VIS_KERNELS(sdv_line_rec, stc007)
 SDV_VIS_KERNELS(sdv_pcm1_bin_rec, pcm1)
 SDV_VIS_KERNELS(sdv_pcm16x0_bin_rec, pcm16x0)
+SDV_VIS_KERNELS(sdv_pcm1_asm_line_rec, p1asm)
 __global__ void __launch_bounds__(64) sdv_k_vis_draw_blocks(sdvvis::BlkArgs a) { sdvvis::draw_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_vis_draw_p1_blocks(sdvvis::P1BlkArgs a) { sdvvis::draw_p1_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_draw_asm(sdvvis::AsmArgs a) { sdvvis::draw_asm_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_last(sdvvis::VisArgs a) { sdvvis::last_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_fill(sdvvis::VisArgs a) { sdvvis::fill_body(a, blockIdx.x, (int)threadIdx.x); }

@@ -63,3 +63,21 @@ if __name__ == "__main__":
         np.savez_compressed(path, lines_sha256=hashlib.sha256(lines.tobytes()).hexdigest(), canvases_sha256=ra.digest(ref, mask),
                             last_canvas=np.where(mask[-1], ref[-1], 0).astype(np.uint32))
         print(f"{name}: {len(lines)} lines -> {len(ref)} canvases of {ref.shape[2]} x {ref.shape[1]}, {os.path.getsize(path)} bytes")
+    for name in ra.P1VIS_GOLDEN:          # the two windows of the PCM-1 stitcher: the real stitcher's blocks and sub-lines on the real RenderPCM
+        if only and name not in only:
+            continue
+        import libs
+        import pcm1_api as p1
+        recs, st = p1.make_input(name)
+        pairs, frames, blocks, lines_ref = p1.run_cpu_vis(libs.load_ref(), "ref_", recs, st)
+        per = np.full(int((frames["service_type"] == 0).sum()), 16, dtype=np.uint32)
+        # the places of the engine's line buffer (1470 per frame, the ones the stitcher does not hand over marked): the oracle's, whose handed-over ones equal the real stitcher's
+        _, _, lines = ra.make_p1vis_input(name)
+        assert lines[lines["flags"] != 0x80].tobytes() == lines_ref.tobytes()
+        bref = ra.run_ref_blocks(ra.PCM1_BLOCKS, np.ascontiguousarray(blocks), per)
+        lref = ra.run_ref_lines_into(ra.PCM1_ASM, lines, len(per))
+        lmask = ra.written_p1_asm(lines)
+        path = os.path.join(HERE, "render_p1vis_" + name + ".npz")
+        np.savez_compressed(path, block_canvases_sha256=ra.digest(bref, ra.written_p1_blocks(per)), line_canvases_sha256=ra.digest(lref, lmask),
+                            last_line_canvas=np.where(lmask[-1], lref[-1], 0).astype(np.uint32))
+        print(f"{name}: {len(blocks)} blocks, {len(lines_ref)} sub-lines -> {len(per)} canvases each, {os.path.getsize(path)} bytes")

@@ -11,9 +11,9 @@ import pcm1_frames_api as p1f
 import pcm16_frames_api as p16f
 from sdvpcmdecoder_amd import synth
 
-STC007, PCM1, PCM16X0, STC007_BLOCKS_NTSC, STC007_BLOCKS_PAL, STC007_ASM_NTSC, STC007_ASM_PAL = 0, 1, 2, 3, 4, 5, 6
+STC007, PCM1, PCM16X0, STC007_BLOCKS_NTSC, STC007_BLOCKS_PAL, STC007_ASM_NTSC, STC007_ASM_PAL, PCM1_BLOCKS, PCM1_ASM, PCM16X0_BLOCKS = range(10)
 SIZE = {STC007: (685, 650), PCM1: (752, 490), PCM16X0: (772, 490), STC007_BLOCKS_NTSC: (654, 490), STC007_BLOCKS_PAL: (654, 588),
-        STC007_ASM_NTSC: (685, 490), STC007_ASM_PAL: (685, 588)}   # width, height of the canvas
+        STC007_ASM_NTSC: (685, 490), STC007_ASM_PAL: (685, 588), PCM1_BLOCKS: (858, 368), PCM1_ASM: (624, 490), PCM16X0_BLOCKS: (678, 490)}   # width, height of the canvas
 BLANK = 0xFF000000                                                          # a canvas nothing was drawn on yet (QImage::fill(Qt::black))
 SRV_FILLER, SRV_END_FRAME = 3, 5
 LF_BW_SET, LF_COORDS_SET, LF_FORCED_BAD, LF_CRC_VALID = 8, 16, 32, 64
@@ -261,3 +261,68 @@ def run_oracle_asm(kind, lines, per, canvas=None):
 
 def run_ref_asm(kind, lines, per):
     return _run_asm(libs.load_ref(), "ref_vis_render_asm_lines", kind, lines, per, None)
+
+
+# ---- the two windows of the PCM-1 stitcher: its data blocks (renderNewBlock(PCM1DataBlock), renderpcm.cpp:1171-1400) and the sub-lines of its queue
+# (renderNewLine(PCM1SubLine), :626-741) -------------------------------------------------------------------------------------------------------------
+# name: scenario of tests/pcm1_api.py whose feeds are drawn
+P1VIS_CASES = ("bad5", "picked_forced", "header_emph", "fillers", "short_fields", "bff", "manual_lost_lines", "file_marks")
+P1VIS_GOLDEN = ("bad5", "picked_forced", "manual_lost_lines")
+
+
+def make_p1vis_input(name):
+    """(blocks, blocks per frame, sub-lines) of a scenario as the oracle's stitcher hands them over."""
+    import pcm1_api as p1
+    recs, st = p1.make_input(name)
+    pairs, frames, blocks, lines = p1.run_cpu_vis(libs.load_oracle(), "orc_", recs, st)
+    per = np.full(int((frames["service_type"] == 0).sum()), 16, dtype=np.uint32)
+    assert int(per.sum()) == len(blocks) and len(lines) == 1470 * len(per)
+    return np.ascontiguousarray(blocks), per, np.ascontiguousarray(lines)
+
+
+def written_p1_blocks(per_frame):
+    w, h = SIZE[PCM1_BLOCKS]
+    rows = np.minimum(np.maximum.accumulate(per_frame.astype(np.int64) * 23), h)
+    return (np.arange(h)[None, :, None] < rows[:, None, None]) & np.ones((1, 1, w), dtype=bool)
+
+
+def written_p1_asm(lines):
+    """[frame, row, width] bool: the pixels some frame up to this one has drawn (a sub-line covers its third of the row)."""
+    w, h = SIZE[PCM1_ASM]
+    seen = np.zeros((h, w), dtype=bool)
+    out = []
+    for f in range(len(lines) // 1470):
+        fill = 0
+        for r in lines[f * 1470:(f + 1) * 1470]:
+            if r["flags"] & 0x80 or fill >= h:
+                continue
+            part = int(r["line_part"])
+            seen[fill, part * 208:(part + 1) * 208] = True
+            fill += 1 if part == 2 else 0
+        out.append(seen.copy())
+    return np.array(out).reshape(-1, h, w)
+
+
+def run_oracle_lines_into(kind, recs, n, canvas=None):
+    """orc_vis_render_lines for the kinds that have no END_FRAME records (n frames are known to the caller)."""
+    lib = libs.load_oracle()
+    w, h = SIZE[kind]
+    out = np.zeros((n, h, w), dtype=np.uint32)
+    if canvas is None:
+        canvas = np.full((h, w), BLANK, dtype=np.uint32)
+    lib.orc_vis_render_lines.restype = C.c_long
+    lib.orc_vis_render_lines.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+    assert lib.orc_vis_render_lines(kind, recs.ctypes.data, len(recs), canvas.ctypes.data, out.ctypes.data, n) == n
+    return out, canvas
+
+
+def run_ref_lines_into(kind, recs, n):
+    lib = libs.load_ref()
+    w, h = SIZE[kind]
+    out = np.zeros((n, h, w), dtype=np.uint32)
+    lib.ref_vis_render_lines.restype = C.c_long
+    lib.ref_vis_render_lines.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rw, rh = C.c_uint32(0), C.c_uint32(0)
+    got = lib.ref_vis_render_lines(kind, recs.ctypes.data, len(recs), out.ctypes.data, n, C.byref(rw), C.byref(rh))
+    assert got == n and (rw.value, rh.value) == (w, h), (got, n, rw.value, rh.value)
+    return out

@@ -118,7 +118,7 @@ def test_emu_calls_continue_on_the_kept_canvas(emu):
     assert rc == 0 and n == 0
     w, h = C.c_uint32(0), C.c_uint32(0)
     assert emu.sdv_vis_canvas_size(kind, C.byref(w), C.byref(h)) == 0 and (w.value, h.value) == ra.SIZE[kind]
-    assert emu.sdv_vis_canvas_size(7, C.byref(w), C.byref(h)) != 0
+    assert emu.sdv_vis_canvas_size(10, C.byref(w), C.byref(h)) != 0          # no such canvas
     emu.sdv_engine_destroy(eng)
 
 
@@ -412,3 +412,104 @@ def test_gpu_asm_lines_and_their_canvases_match_oracle(name):
     if name in ra.ASM_GOLDEN:
         z = np.load(os.path.join(GOLD, "render_" + name + ".npz"))
         assert ra.digest(canvases, ra.written_blocks(kind, want_per)) == str(z["canvases_sha256"])
+
+
+# ---- the two windows of the PCM-1 stitcher: sdv_set_pcm1_stitch_block_output -> sdv_vis_render_blocks(SDV_VIS_PCM1_BLOCKS), sdv_set_pcm1_stitch_line_output
+# -> sdv_vis_render_lines(SDV_VIS_PCM1_ASM) -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.ref
+@pytest.mark.parametrize("name", ra.P1VIS_CASES)
+def test_oracle_pcm1_stitcher_canvases_match_live_reference(name, oracle_lib):
+    """The real RenderPCM on the oracle's blocks and sub-lines (tests/test_pcm1_vis.py: those equal the real stitcher's)."""
+    if not libs.ref_available():
+        pytest.skip("reference build (oracle/_ref) not available")
+    blocks, per, lines = ra.make_p1vis_input(name)
+    out, _ = ra.run_oracle_blocks(ra.PCM1_BLOCKS, blocks, per)
+    ref = ra.run_ref_blocks(ra.PCM1_BLOCKS, blocks, per)
+    mask = ra.written_p1_blocks(per)
+    assert (_masked(out, mask) == _masked(ref, mask)).all(), _diff(out, ref, mask)
+    out, _ = ra.run_oracle_lines_into(ra.PCM1_ASM, lines, len(per))
+    ref = ra.run_ref_lines_into(ra.PCM1_ASM, lines, len(per))
+    mask = ra.written_p1_asm(lines)
+    assert (_masked(out, mask) == _masked(ref, mask)).all(), _diff(out, ref, mask)
+
+
+@pytest.mark.parametrize("name", ra.P1VIS_GOLDEN)
+def test_oracle_pcm1_stitcher_canvases_match_golden(name, oracle_lib):
+    z = np.load(os.path.join(GOLD, "render_p1vis_" + name + ".npz"))
+    blocks, per, lines = ra.make_p1vis_input(name)
+    out, _ = ra.run_oracle_blocks(ra.PCM1_BLOCKS, blocks, per)
+    assert ra.digest(out, ra.written_p1_blocks(per)) == str(z["block_canvases_sha256"])
+    out, _ = ra.run_oracle_lines_into(ra.PCM1_ASM, lines, len(per))
+    mask = ra.written_p1_asm(lines)
+    assert ra.digest(out, mask) == str(z["line_canvases_sha256"])
+    assert (_masked(out[-1], mask[-1]) == z["last_line_canvas"]).all()
+
+
+def _emu_p1vis(emu, blocks, per, lines, calls=1):
+    import engine_api as ea
+    lib = ea.bind(emu)
+    lib.sdv_vis_render_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    eng = lib.sdv_engine_create(0)
+    bc, lc = [], []
+    n = len(per)
+    cuts = [0, n] if calls == 1 else [0, n // 2, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        w, h = ra.SIZE[ra.PCM1_BLOCKS]
+        out = np.zeros((b - a, h, w), dtype=np.uint32)
+        pb, pp = np.ascontiguousarray(blocks[16 * a:16 * b]), np.ascontiguousarray(per[a:b])
+        assert lib.sdv_vis_render_blocks(eng, ra.PCM1_BLOCKS, pb.ctypes.data, len(pb), pp.ctypes.data, len(pp), out.ctypes.data, len(pp), None) == 0
+        bc.append(out)
+        rc, out, got = _emu_run(emu, eng, ra.PCM1_ASM, np.ascontiguousarray(lines[1470 * a:1470 * b]), cap=b - a)
+        assert rc == 0 and got == b - a
+        lc.append(out)
+    lib.sdv_engine_destroy(eng)
+    return np.concatenate(bc), np.concatenate(lc)
+
+
+@pytest.mark.parametrize("name", ra.P1VIS_CASES)
+def test_emu_pcm1_stitcher_canvases_match_oracle(name, emu):
+    blocks, per, lines = ra.make_p1vis_input(name)
+    bc, lc = _emu_p1vis(emu, blocks, per, lines)
+    want, _ = ra.run_oracle_blocks(ra.PCM1_BLOCKS, blocks, per)
+    assert (bc == want).all(), _diff(bc, want, np.ones_like(want, dtype=bool))
+    want, _ = ra.run_oracle_lines_into(ra.PCM1_ASM, lines, len(per))
+    assert (lc == want).all(), _diff(lc, want, np.ones_like(want, dtype=bool))
+
+
+def test_emu_pcm1_stitcher_canvases_in_two_calls(emu):
+    blocks, per, lines = ra.make_p1vis_input("manual_lost_lines")
+    bc, lc = _emu_p1vis(emu, blocks, per, lines, calls=2)
+    want, _ = ra.run_oracle_blocks(ra.PCM1_BLOCKS, blocks, per)
+    assert (bc == want).all()
+    want, _ = ra.run_oracle_lines_into(ra.PCM1_ASM, lines, len(per))
+    assert (lc == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ra.P1VIS_CASES)
+def test_gpu_pcm1_stitcher_feeds_to_canvases_match_oracle(name):
+    """Records -> sdv_pcm1_stitch_frames with both feeds set -> the two canvases, all on the device."""
+    import torch
+    import pcm1_api as p1
+    from sdvpcmdecoder_amd import Engine, Pcm1StitchSettings
+    blocks, per, lines = ra.make_p1vis_input(name)
+    recs, st = p1.make_input(name)
+    eng = Engine(0)
+    eng.set_pcm1_stitch_settings(Pcm1StitchSettings.from_buffer_copy(bytes(st)))
+    bl = torch.zeros((len(blocks) + 16, 576), dtype=torch.uint8, device="cuda")
+    ln = torch.zeros((len(lines) + 1470, 16), dtype=torch.uint8, device="cuda")
+    eng.set_pcm1_stitch_block_output(bl); eng.set_pcm1_stitch_line_output(ln)
+    d = torch.from_numpy(np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), 32)).cuda()
+    eng.pcm1_stitch_frames(d)
+    nb, nl = eng.pcm1_stitch_block_count(), eng.pcm1_stitch_line_count()
+    assert nb == len(blocks) and nl == len(lines)
+    bc = eng.vis_render_blocks(ra.PCM1_BLOCKS, bl[:nb].contiguous(), per).cpu().numpy().view(np.uint32)
+    lc = eng.vis_render_lines(ra.PCM1_ASM, ln[:nl].contiguous(), len(per)).cpu().numpy().view(np.uint32)
+    want, _ = ra.run_oracle_blocks(ra.PCM1_BLOCKS, blocks, per)
+    assert (bc == want).all(), _diff(bc, want, np.ones_like(want, dtype=bool))
+    want, _ = ra.run_oracle_lines_into(ra.PCM1_ASM, lines, len(per))
+    assert (lc == want).all(), _diff(lc, want, np.ones_like(want, dtype=bool))
+    if name in ra.P1VIS_GOLDEN:
+        z = np.load(os.path.join(GOLD, "render_p1vis_" + name + ".npz"))
+        assert ra.digest(bc, ra.written_p1_blocks(per)) == str(z["block_canvases_sha256"])
+        assert ra.digest(lc, ra.written_p1_asm(lines)) == str(z["line_canvases_sha256"])
