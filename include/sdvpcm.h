@@ -638,6 +638,32 @@ int sdv_saturate_pcm16x0_stitch_stats(sdv_engine *e);
 int sdv_pcm16x0_stitch_frames(sdv_engine *e, const sdv_pcm16x0_bin_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                               size_t *n_pairs, sdv_frame_asm_pcm16x0 *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* One PCM16X0DataBlock as outputDataBlock hands it to the visualiser with newBlockProcessed (pcm16x0datastitcher.cpp:5116; pcm16x0datablock.h:120-140):
+ * three sub-blocks of three words (two samples and their parity word, on three sub-lines 35 / 490 apart), after P-code correction and the
+ * stitcher's seam / BROKEN masking.  Stored the way the class stores it, by line of the interleave (LINE_1, LINE_2, LINE_3); which line holds a
+ * sub-block's left and right sample follows from the order flag (getWordToLine, pcm16x0datablock.cpp:1029-1155: with odd order sub-blocks 1 and 3 have
+ * R on LINE_1 and L on LINE_3, sub-block 2 the other way round; even order swaps all three; LINE_2 is the parity word).  32 bytes.
+ * Where the words came from (frame_number, start_line ... queue_order of the object) is not carried: the stitch kernels do not track it and RenderPCM
+ * does not look at it. */
+enum { SDV_P16B_EVEN_ORDER = 1 << 0, SDV_P16B_EI_FORMAT = 1 << 1, SDV_P16B_EMPHASIS = 1 << 2, SDV_P16B_CODE = 1 << 3 };
+typedef struct sdv_pcm16x0_block_rec {
+    uint16_t words[3][3];           /* [sub-block][line] */
+    uint16_t word_crc;              /* bit 3 * sub-block + line: the word's sub-line passed its CRC (isWordCRCOk) */
+    uint16_t word_valid;            /* ... the word is valid after correction and masking (isWordValid) */
+    uint8_t picked_left;            /* bit line: hasPickedLeft(line) */
+    uint8_t picked_crc;             /* bit line: hasPickedCRC(line) */
+    uint8_t audio_state[3];         /* per sub-block: 0 AUD_ORIG, 1 AUD_FIX_P, 2 AUD_BROKEN */
+    uint8_t flags;                  /* SDV_P16B_* */
+    uint16_t sample_rate;
+    uint8_t _pad[2];
+} sdv_pcm16x0_block_rec;
+/* With a block buffer set (device memory; NULL: off, the default) every sdv_pcm16x0_stitch_frames call also writes the blocks it turns into sample
+ * pairs: block j of the call = its pairs 3 j .. 3 j + 2, file tags aside; sdv_frame_asm_pcm16x0::blocks_total / 3 of them belong to a frame
+ * (the descriptor counts sub-blocks).  The count of the last call (or what it needed, when it failed with SDV_ERR_BAD_ARG for lack of room). */
+int sdv_set_pcm16x0_stitch_block_output(sdv_engine *e, sdv_pcm16x0_block_rec *out_blocks, size_t blocks_cap);
+size_t sdv_pcm16x0_stitch_block_count(sdv_engine *e);
+
+
 /* ---- AudioProcessor: dropout masking on the PCMSamplePair stream ---------------------------- */
 /* AudioProcessor::DROP_* (audioprocessor.h:83-93), set with setMasking (audioprocessor.cpp:1532-1574) */
 enum { SDV_DROP_IGNORE = 0, SDV_DROP_MUTE_BLOCK = 1, SDV_DROP_MUTE_WORD = 2, SDV_DROP_HOLD_BLOCK = 3, SDV_DROP_HOLD_WORD = 4,
@@ -809,7 +835,7 @@ int sdv_vis_render_lines(sdv_engine *e, int kind, const void *recs, size_t n_rec
  * filled (frame_blocks[f] = 16): a block is 23 rows of eight words - per row a status bar (picked / invalid marks per word, block validity, near
  * silence), the eight 16-bit samples, the block's parity in the field and the emphasis mark.
  * SDV_VIS_PCM16X0_BLOCKS: renderNewBlock(PCM16X0DataBlock) (:1403-1768) on sdv_pcm16x0_block_rec (sdv_set_pcm16x0_stitch_block_output; frame_blocks[f] =
- * sdv_frame_asm_pcm16x0::blocks_total): one row per block - Bit Picker / P-correction marks per sub-block, the six samples, format and BROKEN marks.
+ * sdv_frame_asm_pcm16x0::blocks_total / 3 - the descriptor counts sub-blocks): one row per block - Bit Picker / P-correction marks per sub-block, the six samples, format and BROKEN marks.
  * `blocks` points to the record type of the kind. */
 int sdv_vis_render_blocks(sdv_engine *e, int kind, const void *blocks, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames,
                           uint32_t *out_canvases, size_t canvases_cap, void *stream);

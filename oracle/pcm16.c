@@ -367,6 +367,7 @@ typedef struct {
     p16_ring stats_emph, stats_code, stats_srate, stats_padding;
     uint16_t f1_srate; bool f1_emph, f1_code, file_start, file_end;
     sdv_sample_pair *out; size_t out_n, out_cap; sdv_frame_asm_pcm16x0 *frames; size_t frames_n, frames_cap;
+    sdv_pcm16x0_block_rec *vb; size_t vb_n, vb_cap;         /* the visualiser's feed (newBlockProcessed), when asked for */
 } p16_stitcher;
 enum { EMPH_UNKNOWN, EMPH_OFF, EMPH_ON, CONTENT_UNKNOWN = 0, CONTENT_AUDIO, CONTENT_CODE };
 
@@ -1087,9 +1088,27 @@ static void fill_frame_for_output(p16_stitcher *s)
     }
 }
 
+/* a PCM16X0DataBlock as the visualiser's feed carries it (include/sdvpcm.h): by line, as the class stores it */
+static void blk_to_vis_rec(const p16_block *b, sdv_pcm16x0_block_rec *o)
+{
+    memset(o, 0, sizeof(*o));
+    for (int i = 0; i < 3; i++) {
+        for (int l = 0; l < 3; l++) {
+            o->words[i][l] = b->words[i][l];
+            if (b->word_crc[i][l]) o->word_crc |= (uint16_t)(1u << (3 * i + l));
+            if (b->word_valid[i][l]) o->word_valid |= (uint16_t)(1u << (3 * i + l));
+        }
+        if (b->picked_left[i]) o->picked_left |= (uint8_t)(1u << i);
+        if (b->picked_crc[i]) o->picked_crc |= (uint8_t)(1u << i);
+        o->audio_state[i] = b->audio_state[i];
+    }
+    o->flags = (uint8_t)((b->order_even ? SDV_P16B_EVEN_ORDER : 0) | (b->ei_format ? SDV_P16B_EI_FORMAT : 0) | (b->emphasis ? SDV_P16B_EMPHASIS : 0) | (b->code ? SDV_P16B_CODE : 0));
+    o->sample_rate = b->sample_rate;
+}
 /* outputDataBlock :4973-5117 */
 static void output_data_block(p16_stitcher *s, const p16_block *b)
 {
+    if (s->vb) { if (s->vb_n < s->vb_cap) blk_to_vis_rec(b, &s->vb[s->vb_n]); s->vb_n++; }      /* emit newBlockProcessed(*in_block) :5116 (the pairs do not change it) */
     for (int blk = 0; blk < 3; blk++) {
         bool state, lv, rv, lf, rf;
         if (!blk_broken(b, blk)) {
@@ -1184,7 +1203,13 @@ void orc_default_pcm16x0_stitch_settings(sdv_pcm16x0_stitch_settings *st)
 long orc_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                             sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames)
 {
+    return orc_pcm16x0_stitch_run_vis(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL, 0, NULL);
+}
+long orc_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
+{
     p16_stitcher *s = (p16_stitcher *)calloc(1, sizeof(p16_stitcher));
+    s->vb = blocks; s->vb_cap = blocks_cap;
     s->st = *st; s->ignore_crc = !st->use_ecc;
     s->out = out; s->out_cap = out_cap; s->frames = frames; s->frames_cap = frames_cap;
     s->trim = (p16_sub *)malloc(BUF_TRIM * sizeof(p16_sub));
@@ -1198,6 +1223,7 @@ long orc_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, cons
         if (recs[i].service_type == SDV_SRV_END_FRAME) { stitch_frame(s, recs, lo, i, recs[i].frame_number); lo = i + 1; }
     long n = s->out_n > out_cap ? -1 : (long)s->out_n;
     if (n_frames) *n_frames = s->frames_n;
+    if (n_blocks) *n_blocks = s->vb_n;
     free(s->trim); free(s->pq.buf); free(s->conv); free(s);
     return n;
 }

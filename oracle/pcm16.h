@@ -24,6 +24,9 @@ void orc_pcm16x0_deint_blocks(const sdv_pcm16x0_bin_rec *lines, size_t n_lines, 
 void orc_default_pcm16x0_stitch_settings(sdv_pcm16x0_stitch_settings *st);
 long orc_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                             sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames);
+/* ... with the visualiser's feed: the blocks outputDataBlock hands to newBlockProcessed, next to the pairs */
+long orc_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks);
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,7 @@ int ref_bin_process(void *h, const uint8_t *px, int len, uint32_t frame, uint16_
 
 /* ------------------------------------------------------------------ VideoToDigital level */
 #include <thread>
+#include <functional>
 #include <chrono>
 #include <QMutex>
 #include <QObject>
@@ -958,10 +959,52 @@ static void frasm16_to_pod(FrameAsmPCM16x0 &f, sdv_frame_asm_pcm16x0 *o)
                          (f.silence ? SDV_FA16_SILENCE : 0) | (f.padding_ok ? SDV_FA16_PADDING_OK : 0) | (f.ei_format ? SDV_FA16_EI_FORMAT : 0));
 }
 
+/* a PCM16X0DataBlock through its public interface, by line as the record holds it (getWordToLine, pcm16x0datablock.cpp:1029-1155, restated: the class
+ * answers by word) */
+static void pcm16_block_to_rec(PCM16X0DataBlock &b, sdv_pcm16x0_block_rec *o)
+{
+    memset(o, 0, sizeof(*o));
+    const bool even = b.isOrderEven();
+    for (uint8_t i = 0; i < 3; i++) {
+        for (uint8_t w = 0; w < 3; w++) {
+            const bool l_first = ((i & 1) != 0) != even;
+            const int line = w == PCM16X0DataBlock::WORD_P ? 1 : (((w == PCM16X0DataBlock::WORD_L) == l_first) ? 0 : 2);
+            o->words[i][line] = b.getWord(i, w);
+            if (b.isWordCRCOk(i, w)) o->word_crc |= (uint16_t)(1u << (3 * i + line));
+            if (b.isWordValid(i, w)) o->word_valid |= (uint16_t)(1u << (3 * i + line));
+        }
+        if (b.hasPickedLeft(i)) o->picked_left |= (uint8_t)(1u << i);
+        if (b.hasPickedCRC(i)) o->picked_crc |= (uint8_t)(1u << i);
+        o->audio_state[i] = b.getAudioState(i);
+    }
+    o->flags = (uint8_t)((even ? SDV_P16B_EVEN_ORDER : 0) | (b.isInEIFormat() ? SDV_P16B_EI_FORMAT : 0) | (b.hasEmphasis() ? SDV_P16B_EMPHASIS : 0) | (b.hasCode() ? SDV_P16B_CODE : 0));
+    o->sample_rate = b.sample_rate;
+}
+/* hooks of the run for the visualiser's feed: every block the stitcher emits with newBlockProcessed, every frame it reports (no file tag) */
+struct ref_p16_hooks { std::function<void(PCM16X0DataBlock &)> on_block; std::function<void(uint32_t)> on_frame; };
+long ref_pcm16x0_stitch_run_hooks(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                  sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, ref_p16_hooks *hooks);
 extern "C" long ref_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                        sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames)
 {
+    return ref_pcm16x0_stitch_run_hooks(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, NULL);
+}
+extern "C" long ref_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                           sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
+{
+    size_t seen = 0;
+    ref_p16_hooks h;
+    h.on_block = [&](PCM16X0DataBlock &b) { if (blocks && seen < blocks_cap) pcm16_block_to_rec(b, &blocks[seen]); seen++; };
+    const long n = ref_pcm16x0_stitch_run_hooks(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, &h);
+    if (n_blocks) *n_blocks = seen;
+    return n;
+}
+long ref_pcm16x0_stitch_run_hooks(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                  sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, ref_p16_hooks *hooks)
+{
     PCM16X0DataStitcher *ds = new PCM16X0DataStitcher();
+    if (hooks && hooks->on_block) QObject::connect(ds, &PCM16X0DataStitcher::newBlockProcessed, [hooks](PCM16X0DataBlock b) { hooks->on_block(b); });
+    if (hooks && hooks->on_frame) QObject::connect(ds, &PCM16X0DataStitcher::guiUpdFrameAsm, [hooks](FrameAsmPCM16x0 d) { if (!d.isServNewFile() && !d.isServEndFile()) hooks->on_frame(d.frame_number); });
     std::deque<PCM16X0SubLine> in_q;
     std::deque<PCMSamplePair> out_q;
     QMutex in_mtx, out_mtx, fr_mtx;

@@ -253,3 +253,41 @@ extern "C" long ref_vis_render_asm_lines(int kind, const sdv_asm_line_rec *lines
     if (height) *height = h;
     return frames;
 }
+
+/* ---- the data blocks window of PCM-16x0, both ends real: PCM16X0DataStitcher's newBlockProcessed blocks go straight into RenderPCM::renderNewBlock, a
+ * prepareNewFrame per frame the stitcher reports (mainwindow.cpp:2102-2106: startPCM1600DBFrame; newFrameAssembled -> prepareNewFrame).  The
+ * object cannot be put together again from a record through its public interface (a word that passed its CRC and is not valid comes out of
+ * markAsUnsafe only), so the canvases are made where the objects are. */
+#include <functional>
+#include "pcm16x0datastitcher.h"
+struct ref_p16_hooks { std::function<void(PCM16X0DataBlock &)> on_block; std::function<void(uint32_t)> on_frame; };
+long ref_pcm16x0_stitch_run_hooks(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                  sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, ref_p16_hooks *hooks);
+extern "C" long ref_vis_pcm16x0_stitch_block_canvases(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st,
+                                                      uint32_t *out, size_t out_cap, uint32_t *width, uint32_t *height)
+{
+    if (!QCoreApplication::instance()) new QCoreApplication(q_argc, q_argv);
+    RenderPCM ren;
+    long frames = 0;
+    uint32_t w = 0, h = 0;
+    QObject::connect(&ren, &RenderPCM::renderedFrame, [&](QImage img) {
+        w = (uint32_t)img.width(); h = (uint32_t)img.height();
+        if ((size_t)frames < out_cap)
+            for (uint32_t y = 0; y < h; y++) memcpy(out + ((size_t)frames * h + y) * w, img.constScanLine((int)y), (size_t)w * 4);
+        frames++;
+    });
+    ren.setLivePlay(false);
+    ren.startPCM1600DBFrame();
+    ref_p16_hooks hk;
+    hk.on_block = [&](PCM16X0DataBlock &b) { ren.renderNewBlock(b); };
+    hk.on_frame = [&](uint32_t frame_no) { ren.prepareNewFrame(frame_no); ren.displayIsReady(); };
+    const size_t nfr = n_recs / 100 + 16;
+    std::vector<sdv_sample_pair> pairs(n_recs * 3 + 4096);
+    std::vector<sdv_frame_asm_pcm16x0> fr(nfr);
+    size_t nf = 0;
+    const long n = ref_pcm16x0_stitch_run_hooks(recs, n_recs, st, pairs.data(), pairs.size(), fr.data(), fr.size(), &nf, &hk);
+    if (n < 0) return -1;
+    if (width) *width = w;
+    if (height) *height = h;
+    return frames;
+}

@@ -312,6 +312,65 @@ static uint32_t pcm1_block(const sdv_pcm1_block_rec *b, uint32_t *canvas, uint32
     return drawn_rows;
 }
 
+/* ---- renderNewBlock(PCM16X0DataBlock) :1403-1768: one row per block; the predicates are PCM16X0DataBlock's (pcm16x0datablock.cpp), asked of the record --- */
+static int p16_line_of(const sdv_pcm16x0_block_rec *b, int blk, int word)      /* getWordToLine :1029-1155; word 0 = L, 1 = R */
+{
+    const bool l_first = ((blk & 1) != 0) != ((b->flags & SDV_P16B_EVEN_ORDER) != 0);
+    return ((word == 0) == l_first) ? 0 : 2;
+}
+static bool p16_crc(const sdv_pcm16x0_block_rec *b, int blk, int line) { return (b->word_crc >> (3 * blk + line)) & 1; }
+static bool p16_val(const sdv_pcm16x0_block_rec *b, int blk, int line) { return (b->word_valid >> (3 * blk + line)) & 1; }
+static void pcm16_block(const sdv_pcm16x0_block_rec *b, uint32_t *px)
+{
+    bool valid = true, broken_any = false, silent = false;
+    for (int i = 0; i < 3; i++) {
+        if (!p16_val(b, i, 0) || !p16_val(b, i, 2)) valid = false;                     /* isBlockValid(): getErrorsFixedAudio() == 0, :510-517, :724-757 */
+        if (b->audio_state[i] == 2) broken_any = true;                                  /* isDataBroken() :571-590 */
+        {   /* isAlmostSilent :630-642: some sub-block with both samples within +-4 */
+            const int16_t l = (int16_t)b->words[i][p16_line_of(b, i, 0)], r = (int16_t)b->words[i][p16_line_of(b, i, 1)];
+            if (l < 4 && l >= -4 && r < 4 && r >= -4) silent = true;
+        }
+    }
+    const bool pl1 = (b->picked_left & 1) || (b->picked_left & 4);                      /* hasPickedLeftBySub(SUBBLK_1) :311-322 */
+    for (int i = 0; i < 9; i++) {                                                       /* the status bar :1423-1511 */
+        uint32_t c = PX_BLK;
+        const int sb = i / 2;
+        if (i < 6) {
+            const bool fixed_p = b->audio_state[sb] == 1;                               /* isDataFixedByP(blk) :520-539 */
+            const bool pcrc = (b->picked_crc & 1) || (b->picked_crc & 4) || ((b->picked_crc & 2) && fixed_p);     /* hasPickedCRCBySub(blk) :335-357 */
+            if (i % 2 == 0) { if (i == 0 && pl1) c = B1_BLU; else if (pcrc) c = B0_BLU; }
+            else if (fixed_p) c = B1_GRN;
+        } else if (i == 6) { if (!valid) c = B1_RED; }
+        else if (i == 8) c = silent ? LIM_MARK : LIM_OK;
+        for (int j = 0; j < 6; j++) *px++ = c;
+    }
+    for (int blk = 0; blk < 3; blk++)                                                   /* the six samples :1513-1712 */
+        for (int word = 0; word < 2; word++) {
+            const int line = p16_line_of(b, blk, word);
+            const uint16_t v = b->words[blk][line];
+            const bool crc = p16_crc(b, blk, line), wv = p16_val(b, blk, line), picked = blk == 0 && ((b->picked_left >> line) & 1);    /* hasPickedSample :408-434 */
+            for (int bit = 15; bit >= 0; bit--) {
+                const bool one = (v >> bit) & 1;
+                uint32_t c = one ? B1_GRY : PX_BLK;
+                if (!valid) {
+                    if (b->audio_state[blk] != 2) { if (!crc) c = one ? B1_RED : B0_RED; else if (picked) c = one ? B1_BLU : B0_BLU; }
+                    else if (!wv) c = one ? B1_MGN : B0_MGN;
+                } else if (b->audio_state[blk] == 1) { if (!crc) c = one ? B1_GRN : B0_GRN; else if (picked) c = one ? B1_BLU : B0_BLU; }
+                else if (!wv) c = one ? B1_RED : B0_RED;
+                else if (picked) c = one ? B1_BLU : B0_BLU;
+                for (int j = 0; j < 6; j++) *px++ = c;
+            }
+        }
+    for (int i = 0; i < 8; i++) {                                                       /* format, emphasis, BROKEN :1714-1757 */
+        uint32_t c = PX_BLK;
+        if (i == 0) c = LIM_OK;
+        else if (i == 2) { if (b->flags & SDV_P16B_EI_FORMAT) c = B1_BLU; }
+        else if (i == 3) { if (b->flags & SDV_P16B_EMPHASIS) c = B0_GRN; }
+        else if (i == 5 || i == 6) { if (broken_any) c = B1_MGN; }
+        for (int j = 0; j < 6; j++) *px++ = c;
+    }
+}
+
 long orc_vis_render_blocks(int kind, const void *blocks_, size_t n_blocks, const uint32_t *frame_blocks, size_t n_frames, uint32_t *canvas,
                            uint32_t *out, size_t out_cap)
 {
@@ -325,6 +384,16 @@ long orc_vis_render_blocks(int kind, const void *blocks_, size_t n_blocks, const
         for (size_t f = 0; f < n_frames; f++) {
             uint32_t fill = 0;
             for (uint32_t i = 0; i < frame_blocks[f] && at1 < n_blocks; i++, at1++) fill += pcm1_block(&pb[at1], canvas, w, fill, h);
+            if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
+        }
+        return (long)n_frames;
+    }
+    if (kind == ORC_VIS_PCM16X0_BLOCKS) {
+        const sdv_pcm16x0_block_rec *pb = (const sdv_pcm16x0_block_rec *)blocks_;
+        size_t at16 = 0;
+        for (size_t f = 0; f < n_frames; f++) {
+            for (uint32_t i = 0; i < frame_blocks[f] && at16 < n_blocks; i++, at16++)
+                if (i < h) pcm16_block(&pb[at16], canvas + (size_t)i * w);
             if (f < out_cap) memcpy(out + f * (size_t)w * h, canvas, (size_t)w * h * 4);
         }
         return (long)n_frames;

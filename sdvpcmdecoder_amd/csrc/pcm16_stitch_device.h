@@ -413,6 +413,8 @@ struct FrameArgs16s {
     State16 *state;
     sdv_sample_pair *out_pairs; uint64_t pairs_cap; sdv_frame_asm_pcm16x0 *out_frames; uint32_t frames_cap;
     uint32_t *stat;             /* [0] = OR of FE_*, [1] = first frame index with an error, [2] = file tags seen */
+    /* the visualiser's feed (sdv_set_pcm16x0_stitch_block_output): the blocks next to the pairs; vblk_ofs like frasm_ofs, in blocks */
+    uint32_t *vblk_ofs; sdv_pcm16x0_block_rec *out_blocks; uint64_t blocks_cap;
 };
 
 #ifndef SDV_P16_LDS_SUBS
@@ -1440,6 +1442,7 @@ __device__ inline void carry_body(const FrameArgs16s &a, int lane)
     const uint32_t lim = ei ? (uint32_t)FRAME_SUBS : (uint32_t)SI_TRUE, blk_it = ei ? (uint32_t)EI_OFS : (uint32_t)SI_OFS;
     uint32_t R = a.state->rem_n;
     uint64_t pbase = a.pair_ofs[a.seg_base]; uint32_t fbase = a.frasm_ofs[a.seg_base];
+    uint32_t bbase = a.vblk_ofs ? a.vblk_ofs[a.seg_base] : 0u;
     for (uint32_t c0 = 0; c0 < a.n_batch; c0 += 64) {
         const uint32_t kb = c0 + (uint32_t)lane; const bool act = kb < a.n_batch;
         const uint32_t marks = act ? a.ana[kb].marks : 0u, S = act ? a.dec[kb].total : 0u;      /* the tags that carry the frame's own number: what its trim search saw (:300-330) */
@@ -1455,22 +1458,26 @@ __device__ inline void carry_body(const FrameArgs16s &a, int lane)
         const uint32_t r_in = (newf || endf) ? 0u : (lane == 0 ? R : r_prev);
         const uint32_t n_it = endf ? 0u : (r_in + S) / lim;
         const uint32_t pairs = !act ? 0u : (endf ? 1u : 3u * blk_it * n_it + (newf ? 1u : 0u)), frasm = !act ? 0u : (endf ? 1u : 1u + (newf ? 1u : 0u));
-        uint64_t ps = pairs; uint32_t fs = frasm;
+        const uint32_t vblocks = (!act || endf) ? 0u : blk_it * n_it;
+        uint64_t ps = pairs; uint32_t fs = frasm, bs = vblocks;
         for (int d = 1; d < 64; d <<= 1) {
             const int src = lane >= d ? lane - d : lane;
             const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)ps, src), hi = (uint32_t)__shfl((int)(uint32_t)(ps >> 32), src), of = (uint32_t)__shfl((int)fs, src);
-            if (lane >= d) { ps += ((uint64_t)hi << 32) | lo; fs += of; }
+            const uint32_t ob = (uint32_t)__shfl((int)bs, src);
+            if (lane >= d) { ps += ((uint64_t)hi << 32) | lo; fs += of; bs += ob; }
         }
         if (act) {
             a.dec[kb].rem_in = (uint16_t)r_in; a.dec[kb].n_it = (uint16_t)n_it;
             a.pair_ofs[a.seg_base + kb] = pbase + ps - pairs; a.frasm_ofs[a.seg_base + kb] = fbase + fs - frasm;
+            if (a.vblk_ofs) a.vblk_ofs[a.seg_base + kb] = bbase + bs - vblocks;
         }
         const uint32_t last = (a.n_batch - c0 < 64u ? a.n_batch - c0 : 64u) - 1u;
         R = (uint32_t)__shfl((int)r_out, (int)last);
         pbase += ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ps >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)ps, 63);
         fbase += (uint32_t)__shfl((int)fs, 63);
+        bbase += (uint32_t)__shfl((int)bs, 63);
     }
-    if (lane == 0) { a.pair_ofs[a.seg_base + a.n_batch] = pbase; a.frasm_ofs[a.seg_base + a.n_batch] = fbase; a.state->rem_n = R; }
+    if (lane == 0) { a.pair_ofs[a.seg_base + a.n_batch] = pbase; a.frasm_ofs[a.seg_base + a.n_batch] = fbase; a.state->rem_n = R; if (a.vblk_ofs) a.vblk_ofs[a.seg_base + a.n_batch] = bbase; }
     if (R != 0) {               /* the batch's last frame leaves sub-lines behind: a copy for the frame that follows it (next batch or next call) */
         const uint32_t kb = a.n_batch - 1;
         const Dec16 d = a.dec[kb];
@@ -1641,6 +1648,23 @@ __device__ inline void emit_body(const FrameArgs16s &a, uint32_t kb, int lane)
             if (all) last_broken = (int32_t)(c + 63u - (uint32_t)__clzll((unsigned long long)all));
         }
         if (nonsilent && (int32_t)t - lb < (int32_t)cfg.broke_mask) b_mark_unsafe(b);
+        if (act && a.out_blocks) {          /* newBlockProcessed (:5116): the block as it is now */
+            const uint64_t bi = (uint64_t)a.vblk_ofs[k] + t;
+            if (bi < a.blocks_cap) {
+                sdv_pcm16x0_block_rec r;
+#pragma unroll
+                for (int s = 0; s < 3; s++) {
+#pragma unroll
+                    for (int l = 0; l < 3; l++) r.words[s][l] = b.w[s][l];
+                    r.audio_state[s] = b.state[s];
+                }
+                r.word_crc = (uint16_t)(b.crc & 0x1FFu); r.word_valid = (uint16_t)(b.valid & 0x1FFu);
+                r.picked_left = (uint8_t)(b.pleft & 7u); r.picked_crc = (uint8_t)(b.pcrc & 7u);
+                r.flags = (uint8_t)((b.even ? SDV_P16B_EVEN_ORDER : 0) | (ei ? SDV_P16B_EI_FORMAT : 0) | (d.emph ? SDV_P16B_EMPHASIS : 0) | (d.code ? SDV_P16B_CODE : 0));
+                r.sample_rate = rate; r._pad[0] = r._pad[1] = 0;
+                a.out_blocks[bi] = r;
+            }
+        }
         if (act) {
             const bool all_valid = b_valid_all(b);
 #pragma unroll

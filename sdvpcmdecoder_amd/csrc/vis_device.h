@@ -502,6 +502,94 @@ __device__ inline void draw_p1_blocks_body(const P1BlkArgs &a, uint32_t block, i
     }
 }
 
+/* ---- the data blocks window of PCM-16x0: renderNewBlock(PCM16X0DataBlock), renderpcm.cpp:1403-1768: one row per block ------------------------------ */
+struct P16BlkArgs { const sdv_pcm16x0_block_rec *blocks; const uint32_t *frame_ofs; uint32_t n_frames; int kind; uint32_t *out; uint32_t *wmask; uint32_t wmask_stride; };
+/* fl: bits 0..5 crc of sample 2 blk + word, 6..11 valid, 12..17 picked sample, 18..23 state of the sample's sub-block (2 bits each: 18 + 2 blk),
+ * 24 block valid, 25 some sub-block BROKEN, 26 almost silent, 27 EI, 28 emphasis; st: the nine status colours are worked out per pixel from
+ * pk: bit 0 picked left (sub-block 1), bits 1..3 picked CRC by sub-block */
+enum { P16K_VALID = 1u << 24, P16K_BROKEN = 1u << 25, P16K_SILENT = 1u << 26, P16K_EI = 1u << 27, P16K_EMPH = 1u << 28 };
+__device__ inline uint32_t p16_block_pixel(const uint32_t (&s)[3], uint32_t fl, uint32_t pk, uint32_t x)
+{
+    const uint32_t b = x / 6u;
+    if (b < 9u) {                                           /* the status bar :1423-1511 */
+        if (b < 6u) {
+            const uint32_t sb = b / 2u, st = (fl >> (18u + 2u * sb)) & 3u;
+            if ((b & 1u) == 0) return (b == 0 && (pk & 1u)) ? (uint32_t)B1_BLU : ((pk >> (1u + sb)) & 1u) ? (uint32_t)B0_BLU : (uint32_t)PX_BLK;
+            return st == 1u ? (uint32_t)B1_GRN : (uint32_t)PX_BLK;
+        }
+        if (b == 6u) return (fl & P16K_VALID) ? (uint32_t)PX_BLK : (uint32_t)B1_RED;
+        if (b == 8u) return (fl & P16K_SILENT) ? (uint32_t)LIM_MARK : (uint32_t)LIM_OK;
+        return PX_BLK;
+    }
+    if (b < 105u) {                                         /* the six samples :1513-1712 */
+        const uint32_t w = (b - 9u) / 16u, bit = 15u - ((b - 9u) % 16u), blk = w >> 1;
+        const uint32_t v = (w & 1u) ? s[blk] >> 16 : s[blk] & 0xFFFFu;
+        const bool one = (v >> bit) & 1u, crc = (fl >> w) & 1u, wv = (fl >> (6u + w)) & 1u, picked = (fl >> (12u + w)) & 1u;
+        const uint32_t st = (fl >> (18u + 2u * blk)) & 3u;
+        const uint32_t plain = one ? (uint32_t)B1_GRY : (uint32_t)PX_BLK, blue = one ? (uint32_t)B1_BLU : (uint32_t)B0_BLU;
+        if (!(fl & P16K_VALID)) {
+            if (st != 2u) return !crc ? (one ? (uint32_t)B1_RED : (uint32_t)B0_RED) : picked ? blue : plain;
+            return !wv ? (one ? (uint32_t)B1_MGN : (uint32_t)B0_MGN) : plain;
+        }
+        if (st == 1u) return !crc ? (one ? (uint32_t)B1_GRN : (uint32_t)B0_GRN) : picked ? blue : plain;
+        if (!wv) return one ? (uint32_t)B1_RED : (uint32_t)B0_RED;
+        return picked ? blue : plain;
+    }
+    const uint32_t i = b - 105u;                            /* format, emphasis, BROKEN :1714-1757 */
+    if (i == 0) return LIM_OK;
+    if (i == 2) return (fl & P16K_EI) ? (uint32_t)B1_BLU : (uint32_t)PX_BLK;
+    if (i == 3) return (fl & P16K_EMPH) ? (uint32_t)B0_GRN : (uint32_t)PX_BLK;
+    if (i == 5 || i == 6) return (fl & P16K_BROKEN) ? (uint32_t)B1_MGN : (uint32_t)PX_BLK;
+    return PX_BLK;
+}
+__device__ inline void draw_p16_blocks_body(const P16BlkArgs &a, uint32_t block, int lane)
+{
+    const Geometry g = geometry(a.kind);
+    const uint32_t chunks = (g.h + 63u) / 64u, f = block / chunks, c = block % chunks;
+    const uint32_t lo = a.frame_ofs[f], n = a.frame_ofs[f + 1] - lo, rows = n < g.h ? n : g.h;
+    if (lane < 2) {
+        const uint32_t first = 64u * c + 32u * (uint32_t)lane, word = 2u * c + (uint32_t)lane;
+        if (word < a.wmask_stride) a.wmask[(size_t)f * a.wmask_stride + word] = rows <= first ? 0u : rows - first >= 32u ? 0xFFFFFFFFu : (1u << (rows - first)) - 1u;
+    }
+    const uint32_t row = 64u * c + (uint32_t)lane;
+    const bool live = row < rows;
+    uint32_t s[3] = { 0, 0, 0 }, fl = 0, pk = 0;
+    if (live) {
+        const sdv_pcm16x0_block_rec b = a.blocks[lo + row];
+        const bool even = (b.flags & SDV_P16B_EVEN_ORDER) != 0;
+        bool valid = true, broken = false, silent = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {
+            const bool l_first = ((i & 1u) != 0) != even;                       /* getWordToLine, pcm16x0datablock.cpp:1029-1155 */
+            const uint32_t ll = l_first ? 0u : 2u, lr = l_first ? 2u : 0u;
+            const uint32_t wl = b.words[i][ll], wr = b.words[i][lr];
+            s[i] = wl | (wr << 16);
+            const uint32_t cl = (b.word_crc >> (3u * i + ll)) & 1u, cr = (b.word_crc >> (3u * i + lr)) & 1u;
+            const uint32_t vl = (b.word_valid >> (3u * i + ll)) & 1u, vr = (b.word_valid >> (3u * i + lr)) & 1u;
+            fl |= (cl << (2u * i)) | (cr << (2u * i + 1u)) | (vl << (6u + 2u * i)) | (vr << (7u + 2u * i)) | ((uint32_t)(b.audio_state[i] & 3u) << (18u + 2u * i));
+            if (i == 0) fl |= (((uint32_t)b.picked_left >> ll) & 1u) << 12u | (((uint32_t)b.picked_left >> lr) & 1u) << 13u;
+            valid = valid && vl && vr;
+            broken = broken || b.audio_state[i] == 2;
+            const int sl = (int16_t)(uint16_t)wl, sr = (int16_t)(uint16_t)wr;
+            silent = silent || (sl < 4 && sl >= -4 && sr < 4 && sr >= -4);
+            const bool pcrc = (b.picked_crc & 1u) || (b.picked_crc & 4u) || ((b.picked_crc & 2u) && b.audio_state[i] == 1);
+            pk |= pcrc ? 1u << (1u + i) : 0u;
+        }
+        pk |= ((b.picked_left & 1u) || (b.picked_left & 4u)) ? 1u : 0u;
+        fl |= (valid ? P16K_VALID : 0u) | (broken ? P16K_BROKEN : 0u) | (silent ? P16K_SILENT : 0u) | ((b.flags & SDV_P16B_EI_FORMAT) ? P16K_EI : 0u) | ((b.flags & SDV_P16B_EMPHASIS) ? P16K_EMPH : 0u);
+    }
+    const uint64_t lm = __ballot(live);
+    for (int j = 0; j < 64; j++) {
+        if (!((lm >> j) & 1ull)) continue;
+        uint32_t sj[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) sj[q] = (uint32_t)__shfl((int)s[q], j);
+        const uint32_t jfl = (uint32_t)__shfl((int)fl, j), jpk = (uint32_t)__shfl((int)pk, j);
+        uint32_t *dst = a.out + ((size_t)f * g.h + 64u * c + (uint32_t)j) * g.w;
+        for (uint32_t x = (uint32_t)lane; x < g.w; x += 64u) dst[x] = p16_block_pixel(sj, jfl, jpk, x);
+    }
+}
+
 /* ---- the assembled-lines window: renderNewLine(STC007Line) on the stitcher's lines (sdv_asm_line_rec): every word in the colour of its own state ---- */
 struct AsmArgs {
     const sdv_asm_line_rec *lines; const uint32_t *frame_ofs; uint32_t n_frames; int kind;
@@ -574,6 +662,7 @@ SDV_VIS_KERNELS(sdv_pcm16x0_bin_rec, pcm16x0)
 SDV_VIS_KERNELS(sdv_pcm1_asm_line_rec, p1asm)
 __global__ void __launch_bounds__(64) sdv_k_vis_draw_blocks(sdvvis::BlkArgs a) { sdvvis::draw_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_draw_p1_blocks(sdvvis::P1BlkArgs a) { sdvvis::draw_p1_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_vis_draw_p16_blocks(sdvvis::P16BlkArgs a) { sdvvis::draw_p16_blocks_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_draw_asm(sdvvis::AsmArgs a) { sdvvis::draw_asm_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_last(sdvvis::VisArgs a) { sdvvis::last_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_vis_fill(sdvvis::VisArgs a) { sdvvis::fill_body(a, blockIdx.x, (int)threadIdx.x); }

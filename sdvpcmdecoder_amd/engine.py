@@ -138,9 +138,9 @@ def load_library(path: str | None = None):
     lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_stitch_block_count.restype = C.c_size_t
     lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
-    for nm in ("sdv_set_pcm1_stitch_block_output", "sdv_set_pcm1_stitch_line_output"):
+    for nm in ("sdv_set_pcm1_stitch_block_output", "sdv_set_pcm1_stitch_line_output", "sdv_set_pcm16x0_stitch_block_output"):
         getattr(lib, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-    for nm in ("sdv_pcm1_stitch_block_count", "sdv_pcm1_stitch_line_count"):
+    for nm in ("sdv_pcm1_stitch_block_count", "sdv_pcm1_stitch_line_count", "sdv_pcm16x0_stitch_block_count"):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = [C.c_void_p]
     lib.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -571,6 +571,19 @@ class Engine:
 
     def pcm1_stitch_line_count(self) -> int:
         return int(self.lib.sdv_pcm1_stitch_line_count(self._h))
+
+    def set_pcm16x0_stitch_block_output(self, blocks):
+        """sdv_set_pcm16x0_stitch_block_output: `blocks` = (cap, 32) uint8 CUDA tensor the following pcm16x0_stitch_frames calls fill with their
+        PCM16X0DataBlocks (None: off).  The tensor must stay alive while it is set."""
+        self._p16_block_out = blocks
+        if blocks is None:
+            self._check(self.lib.sdv_set_pcm16x0_stitch_block_output(self._h, None, 0))
+        else:
+            assert blocks.is_cuda and blocks.is_contiguous() and blocks.shape[1] == 32
+            self._check(self.lib.sdv_set_pcm16x0_stitch_block_output(self._h, C.c_void_p(blocks.data_ptr()), blocks.shape[0]))
+
+    def pcm16x0_stitch_block_count(self) -> int:
+        return int(self.lib.sdv_pcm16x0_stitch_block_count(self._h))
 
     def pcm1_bin_to_line_recs(self, bin_recs, out=None, stream=None):
         """The records pcm1_binarize_frames returns ((n, 40) sdv_pcm1_bin_rec) as the records pcm1_stitch_frames takes ((n, 32) sdv_pcm1_line_rec)."""

@@ -117,6 +117,22 @@ def emu_pcm1_stitch_vis(lib, eng, recs, settings=None, blocks=True, lines=True, 
     return rc, pairs, frames, bl[:min(nb, len(bl))].copy(), ln[:min(nl, len(ln))].copy()
 
 
+def emu_pcm16_stitch_vis(lib, eng, recs, settings=None, block_cap=None):
+    """... with the visualiser's block feed switched on (sdv_set_pcm16x0_stitch_block_output): (rc, pairs, frames, blocks)."""
+    import pcm16_api as p16
+    lib.sdv_set_pcm16x0_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_pcm16x0_stitch_block_count.restype = C.c_size_t
+    lib.sdv_pcm16x0_stitch_block_count.argtypes = [C.c_void_p]
+    nfr = int((recs["service_type"] == 5).sum()) + 2
+    bl = np.zeros(block_cap if block_cap is not None else nfr * 800 + 16, dtype=p16.VBLOCK16_DTYPE)
+    assert lib.sdv_set_pcm16x0_stitch_block_output(eng, bl.ctypes.data, len(bl)) == 0
+    rc, pairs, frames = emu_pcm16_stitch(lib, eng, recs, settings)
+    nb = lib.sdv_pcm16x0_stitch_block_count(eng)
+    emu_pcm16_stitch_vis.last_count = nb
+    assert lib.sdv_set_pcm16x0_stitch_block_output(eng, None, 0) == 0
+    return rc, pairs, frames, bl[:min(nb, len(bl))].copy()
+
+
 def emu_pcm16_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
     """Host-memory call (emulator build only): one sdv_pcm16x0_stitch_frames call over `recs`."""
     import pcm16_api as p16

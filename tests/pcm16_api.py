@@ -165,6 +165,31 @@ def run_cpu(lib, prefix, recs, st, pair_cap=None, frame_cap=None, overflow_ok=Fa
     return pairs[:n], frames[:min(nf.value, frame_cap)]
 
 
+# ---- what the stitcher hands to the visualiser (sdv_set_pcm16x0_stitch_block_output): sdv_pcm16x0_block_rec --------------------------------------
+VBLOCK16_DTYPE = np.dtype([("words", "<u2", (3, 3)), ("word_crc", "<u2"), ("word_valid", "<u2"), ("picked_left", "u1"), ("picked_crc", "u1"),
+                           ("audio_state", "u1", (3,)), ("flags", "u1"), ("sample_rate", "<u2"), ("_pad", "u1", (2,))])
+assert VBLOCK16_DTYPE.itemsize == 32
+VIS_GOLDEN = ("si_bad10", "si_picked_forced", "ei_bad10", "si_file_marks")
+
+
+def run_cpu_vis(lib, prefix, recs, st):
+    """(pairs, frames, blocks): the stitcher's run with the visualiser's block feed switched on."""
+    f = getattr(lib, prefix + "pcm16x0_stitch_run_vis")
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm16Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == SRV_END_FRAME).sum()) + 2
+    pairs = np.zeros(nfr * 2400 + 16, dtype=PAIR_DTYPE)
+    frames = np.zeros(nfr + 8, dtype=FRASM16_DTYPE)
+    blocks = np.zeros(nfr * 800 + 16, dtype=VBLOCK16_DTYPE)
+    nf, nb = C.c_size_t(0), C.c_size_t(0)
+    n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, len(pairs), frames.ctypes.data, len(frames), C.byref(nf),
+          blocks.ctypes.data, len(blocks), C.byref(nb))
+    assert n >= 0 and nb.value <= len(blocks)
+    return pairs[:n], frames[:nf.value], blocks[:nb.value]
+
+
 def run_blocks(lib, prefix, recs, n_blocks, ei=False, force=True, p_code=True, ignore_crc=False, first_shift=0, first_even=False):
     f = getattr(lib, prefix + "pcm16x0_deint_blocks")
     f.restype = None
