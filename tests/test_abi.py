@@ -60,6 +60,7 @@ def test_header_is_plain_c(tmp_path):
                    '#define CHECK(t, n) typedef char check_##t[(sizeof(t) == (n)) ? 1 : -1]\n'
                    'CHECK(sdv_line_rec, 48); CHECK(sdv_frame_stats, 32); CHECK(sdv_v2d_state, 120); CHECK(sdv_deint_line, 24);\n'
                    'CHECK(sdv_block_rec, 72); CHECK(sdv_sample_pair, 12); CHECK(sdv_frame_asm, 64); CHECK(sdv_stitch_settings, 16); CHECK(sdv_audio_purge, 16);\n'
+                   'CHECK(sdv_pcm1_block_rec, 576); CHECK(sdv_pcm1_asm_line_rec, 16); CHECK(sdv_pcm16x0_block_rec, 32); CHECK(sdv_asm_line_rec, 32);\n'
                    'int main(void) { sdv_engine *e = sdv_engine_create(0); sdv_engine_destroy(e); return 0; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
