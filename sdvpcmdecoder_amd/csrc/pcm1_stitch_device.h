@@ -243,7 +243,8 @@ __device__ inline Line16 compact(const sdv_pcm1_line_rec &r, uint32_t frame, boo
 }
 
 /* one wave, one frame.  kLds: the frame's lines are staged in `lines` (LDS) by the first sweep; otherwise later sweeps read the records again. */
-template <bool kLds>
+/* kVis: the visualiser's feeds are written as well (a build of its own: the frames of a caller who does not ask for them pay nothing) */
+template <bool kLds, bool kVis>
 __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uint32_t lo, uint32_t n, Line16 *lines, uint16_t (*field_idx)[LINES_PF + 3])
 {
     const uint32_t frame = a.src.at(lo + n).frame_number;           /* the END_FRAME record */
@@ -499,7 +500,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             li[c] = is_line ? fidx[pl - f_top] : P1_NONE;
             const uint32_t fl = is_line ? (kLds ? (uint32_t)lines[li[c]].fl : (uint32_t)line_at(li[c]).fl) : 0u;
             okm[c] = __ballot((fl & LF_OK) != 0); pkm[c] = __ballot((fl & LF_PICK) != 0); plm[c] = __ballot((fl & LF_PICKL) != 0);
-            nvm[c] = (a.out_blocks || a.out_asm) ? __ballot(is_line && stale_at(li[c]) && (fl & LF_DATA) == 0) : 0ull;
+            nvm[c] = kVis ? __ballot(is_line && stale_at(li[c]) && (fl & LF_DATA) == 0) : 0ull;
         }
         auto rows_unnumbered_below = [&](uint32_t row) -> uint32_t {
             uint32_t n = 0;
@@ -561,7 +562,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
         /* the visualiser's feeds.  newBlockProcessed (:1333): the block as PCM1Deinterleaver::setWordData filled it - pair pr of block blk is its words
          * 2 pr, 2 pr + 1 (what the loop above reads); newLineProcessed (:1392-1407): the queue itself, sub-line after sub-line.  The stitcher numbers the
          * lines of its queue anew (addFieldPadding / addLinesFromField, :952-1073): 1, 3, 5 ... down the odd field, 2, 4, 6 ... down the even one. */
-        if (a.out_blocks || a.out_asm) {
+        if (kVis) {
             const uint64_t d = (pofs - fofs) / (uint64_t)(2 * SUBLINES_PF - 1);       /* frames ahead of this one that are no file tags: their pairs minus their descriptors */
             const uint32_t first_line = odd_field ? 1u : 2u;
             if (a.out_blocks) {
@@ -707,7 +708,18 @@ __global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
     const uint32_t k = blockIdx.x;
     const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, n = a.seg_end[k] - lo;
     bool again = true;
-    if (n <= sdvp1::LDS_LINES) again = sdvp1::frame_body<true>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
-    if (again) { __syncthreads(); (void)sdvp1::frame_body<false>(a, k, (int)threadIdx.x, lo, n, lines, field_idx); }
+    if (n <= sdvp1::LDS_LINES) again = sdvp1::frame_body<true, false>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
+    if (again) { __syncthreads(); (void)sdvp1::frame_body<false, false>(a, k, (int)threadIdx.x, lo, n, lines, field_idx); }
+}
+/* ... with the visualiser's feeds (sdv_set_pcm1_stitch_block_output / _line_output) */
+__global__ void __launch_bounds__(64) sdv_k_pcm1_frames_vis(sdvp1::FrameArgs1 a)
+{
+    alignas(16) __shared__ sdvp1::Line16 lines[sdvp1::LDS_LINES];
+    __shared__ uint16_t field_idx[2][sdvp1::LINES_PF + 3];
+    const uint32_t k = blockIdx.x;
+    const uint32_t lo = k == 0 ? 0u : a.seg_end[k - 1] + 1u, n = a.seg_end[k] - lo;
+    bool again = true;
+    if (n <= sdvp1::LDS_LINES) again = sdvp1::frame_body<true, true>(a, k, (int)threadIdx.x, lo, n, lines, field_idx);
+    if (again) { __syncthreads(); (void)sdvp1::frame_body<false, true>(a, k, (int)threadIdx.x, lo, n, lines, field_idx); }
 }
 #endif
