@@ -13,6 +13,9 @@ SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_bench $R/gpurun_out/prof_stitch $R/gpurun_out/pmc1 $R/gpurun_out/pmc2 $R/gpurun_out/pmc3 $R/gpurun_out/pmc4
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.err; echo "rocprof bench rc=$?"
+# ... and of the headline leg alone (no other leg launches the lean kernel there: its average is the launch duration the roofline line quotes)
+rm -rf $R/gpurun_out/prof_headline
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_headline -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu --no-stitch > $R/gpurun_out/prof_headline.json 2> $R/gpurun_out/prof_headline.err; echo "rocprof headline rc=$?"
 ( cd $R && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stitch -- python3 tools/stitch_prof.py 10000 5 cont > gpurun_out/prof_stitch.log 2>&1 ); echo "rocprof stitch rc=$?"
 timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc1.err; echo "pmc1 rc=$?"
 timeout 600 rocprofv3 --kernel-include-regex 'sdv_k_stc007_frames_lean' --pmc SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/pmc2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-stitch > /dev/null 2> $R/gpurun_out/pmc2.err; echo "pmc2 rc=$?"

@@ -24,6 +24,9 @@ def trim(src, dst):
 
 trim(newest('gpurun_out/prof_bench/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_kernel_stats.csv')
 trim(newest('gpurun_out/prof_stitch/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_stitch_kernel_stats.csv')
+if glob.glob('gpurun_out/prof_headline/*/*kernel_stats.csv'):
+    trim(newest('gpurun_out/prof_headline/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_headline_kernel_stats.csv')
+    shutil.copy('gpurun_out/prof_headline.json', f'profiles/{RND}_rocprofv3_headline_bench_line.json')
 trim(newest('gpurun_out/prof_pcm1/*/*kernel_stats.csv'), f'profiles/{RND}_rocprofv3_pcm1_kernel_stats.csv')
 for d, name in (('prof_p1f', 'pcm1_frames'), ('prof_p16f', 'pcm16x0_frames'), ('prof_p16s', 'pcm16x0_stitch'), ('prof_audio', 'audio')):
     if glob.glob(f'gpurun_out/{d}/*/*kernel_stats.csv'):
