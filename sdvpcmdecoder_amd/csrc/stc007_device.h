@@ -2245,9 +2245,19 @@ __device__ __attribute__((noinline)) void empty_line(SlowCtx *c, WaveLds *lds, u
  * paths gives the frame up: it marks its outgoing state (sdv_v2d_state::_pad[0]) and the engine decodes from that frame on
  * with the full kernel. */
 enum { STATE_ABORTED = 0xA5 };
+/* sc (full kernel): the context of the general path, in LDS - one copy for the wave.  (It lived on the stack of the frame loop before: scratch memory,
+ * every field the general path read of it a trip to global memory, a few dozen of them one behind the other per line: C3 PAL tape 28.4 -> 25.6 ms.)
+ * The general path is wave-uniform code: every lane computes the same values and stores them to the same place, in lockstep.  The emulator runs the
+ * lanes as threads of their own between collectives, where a shared read-modify-write would be seen half done: it keeps a copy per lane. */
+#ifdef SDV_EMU
+#define SDV_SLOW_CTX(c) SlowCtx c; sc_args_set = false
+#else
+#define SDV_SLOW_CTX(c) SlowCtx &c = *sc
+#endif
 template <bool kLean>
-__device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
+__device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowCtx *sc = nullptr)
 {
+    bool sc_args_set = false;           /* sc->a = a: once per frame */
     K1_BEGIN();
     K1_T(t_begin);
     V2D v; Line wl;
@@ -2277,9 +2287,13 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                 const int nl = field == 0 ? (a.height + 1) / 2 : a.height / 2;
                 for (int i = 0; i < nl; i++) {
                     ln = (uint16_t)(field + 1 + 2 * i);
-                    SlowCtx c;
-                    c.a = a; c.v = v;
+                    SDV_SLOW_CTX(c);
+                    SDV_WAVE_SYNC();
+                    if (!sc_args_set) { c.a = a; sc_args_set = true; }
+                    c.v = v;
+                    SDV_WAVE_SYNC();
                     empty_line(&c, &lds, frame_no, ln, fv_keys, fi_keys, rec++);
+                    SDV_WAVE_SYNC();
                     v = c.v;
                     v2d_make_uniform(v);
                 }
@@ -2607,15 +2621,19 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
                     return;
                 } else {
                     K1_T(t_sc0);
-                    SlowCtx c;
-                    c.a = a; c.v = v;
+                    SDV_SLOW_CTX(c);
+                    SDV_WAVE_SYNC();
+                    if (!sc_args_set) { c.a = a; sc_args_set = true; }
+                    c.v = v;
                     c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
                     c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.line = f * a.height + (2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
                     c.hook.bw_slot = a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr;
+                    SDV_WAVE_SYNC();
                     slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
 #ifdef SDV_K1_STAMPS
                     n_slow_lines++;
 #endif
+                    SDV_WAVE_SYNC();
                     v = c.v;
                     v2d_make_uniform(v);
                     K1_T(t_sc1);
@@ -2666,8 +2684,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f)
 __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
+    __shared__ sdv::SlowCtx slow_ctx;
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
-    if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f);
+    if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f, &slow_ctx);
 }
 #ifndef SDV_LEAN_WAVES_PER_EU
 #define SDV_LEAN_WAVES_PER_EU 5   /* 1.26 ms vs 1.46 (4), 1.28 (6), 1.45 (8) per 10 000 frames (profiles/r01_tuning_notes.md) */
