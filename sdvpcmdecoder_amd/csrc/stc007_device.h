@@ -574,6 +574,26 @@ __device__ inline void read_pcm_data(Bin &b, Line &l, const WaveLds &lds, bool l
 
 /* Binarizer::searchSTC007Markers (binarizer.cpp:5275-5595) for one hysteresis level; pure function of the
  * staged scanline, the line's ref_level and the scan limits.  Runs independently in every lane. */
+enum { SWEEP_WINDOW_MAX = 192 };    /* pixels of a marker search window the mask forms below cover (a 720-px line: 68 / 73; doubled: 136 / 146) */
+__device__ __forceinline__ int m192_first_set(const uint64_t *w, int p)        /* the lowest set bit at or above p; SWEEP_WINDOW_MAX when there is none */
+{
+    int r = SWEEP_WINDOW_MAX;
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+        const int lo = p - 64 * k;
+        if (lo > 63) continue;
+        uint64_t x = w[k];
+        if (lo > 0) x &= ~0ull << lo;
+        if (x) r = 64 * k + __ffsll((unsigned long long)x) - 1;
+    }
+    return r;
+}
+__device__ __forceinline__ int m192_first_clear(const uint64_t *w, int p)
+{
+    const uint64_t n[3] = { ~w[0], ~w[1], ~w[2] };
+    return m192_first_set(n, p);
+}
+
 __device__ inline Markers search_markers_px(const Bin &b, const sdv_bin_preset &ps, const uint8_t *px, uint8_t ref_level, uint8_t hyst_lvl)
 {
     Markers m;
@@ -647,12 +667,86 @@ __device__ inline void apply_markers(Line &l, const Markers &m)
     l.coords_set = has_markers(l);
 }
 
+/* searchSTC007Markers for the 24 hysteresis depths of one reference level at once, lane = depth: the same two state machines as search_markers_px,
+ * stepping from edge to edge on threshold masks instead of from pixel to pixel (a lane read some 170 pixels from LDS one behind the other: 17 000
+ * cycles a search).  The masks - pixel >= threshold over the START window [0, n_start) and, mirrored, over the STOP window - are made by the wave
+ * (a lane per pixel, a ballot per threshold: the 24 low levels and the reference level itself); every lane keeps the one of its depth.  What the
+ * machines leave behind when they do not get through (stage, the coordinates of earlier attempts) is carried along as the pixel loop does. */
+__device__ inline Markers search_markers_masks(const Bin &b, const sdv_bin_preset &ps, const uint8_t *px, uint8_t ref_level, int n_start, int n_stop)
+{
+    const int lane = lane_id();
+    const int ppb = b.estimated_ppb, scan_end = b.scan_end;
+    uint64_t L[3] = { 0, 0, 0 }, H[3] = { 0, 0, 0 }, R[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if (64 * c >= n_start && 64 * c >= n_stop) break;
+        const int p = 64 * c + lane;
+        const int vs = p < n_start ? (int)px[b.scan_start + p] : -1, ve = p < n_stop ? (int)px[scan_end - p] : -1;
+        H[c] = __ballot(vs >= (int)ref_level); R[c] = __ballot(ve >= (int)ref_level);
+        for (int d = 0; d < 24; d++) {
+            int t = get_low_level(ref_level, (uint8_t)d);
+            if (t < ps.min_ref_lvl) t = ps.min_ref_lvl;
+            const uint64_t m = __ballot(vs >= t);
+            L[c] = lane == d ? m : L[c];
+        }
+    }
+    Markers m;
+    uint8_t stage = MARK_ST_START;
+    int st1s = -(int)b.scan_start, st1e = -(int)b.scan_start, st3e = -(int)b.scan_start;     /* (0 once the window's start is added: never assigned) */
+    const int max_rel = (int)b.mark_start_max - (int)b.scan_start;
+    for (int p = 0;;) {                                     /* forward: "1010" (binarizer.cpp:5310-5405) */
+        const int q1 = m192_first_set(L, p);
+        if (q1 >= n_start || q1 > max_rel) { stage = MARK_ST_START; break; }
+        st1s = q1; stage = MARK_ST_TOP_1;
+        const int q2 = m192_first_clear(L, q1 + 1);
+        if (q2 >= n_start) break;
+        st1e = q2; stage = MARK_ST_BOT_1;
+        const int q3 = m192_first_set(H, q2 + 1);
+        if (q3 >= n_start) break;
+        if ((q3 - q2) > ppb * 2 || (q3 - q2) < ppb / 2) { stage = MARK_ST_START; p = q3 + 1; if (p >= n_start) break; continue; }
+        stage = MARK_ST_TOP_2;
+        const int q4 = m192_first_clear(H, q3 + 1);
+        if (q4 >= n_start) break;
+        st3e = q4;
+        if ((q4 - q3) > ppb * 2 || (q4 - q3) < ppb / 2) { stage = MARK_ST_START; p = q4 + 1; if (p >= n_start) break; continue; }
+        stage = MARK_ST_BOT_2;
+        break;
+    }
+    m.st_stage = stage; m.st1s = (uint16_t)(b.scan_start + st1s); m.st1e = (uint16_t)(b.scan_start + st1e); m.st3e = (uint16_t)(b.scan_start + st3e);
+    m.has_start = stage == MARK_ST_BOT_2;
+    stage = MARK_ED_START;
+    int ed_start = 0, ed_end = 0;
+    if (m.has_start) {                                      /* backward: "01111" (:5410-5455) */
+        const int i_max = scan_end - (int)b.mark_end_min;
+        for (int i = 0;;) {
+            const int j1 = m192_first_set(R, i);
+            if (j1 >= n_stop || j1 > i_max) { stage = MARK_ED_START; break; }
+            ed_end = scan_end - j1 + 1; stage = MARK_ED_TOP;
+            const int j2 = m192_first_clear(R, j1 + 1);
+            if (j2 >= n_stop) break;
+            ed_start = scan_end - j2 + 1;
+            if ((j2 - j1) >= ppb * 2 && (j2 - j1) <= ppb * 5) { stage = MARK_ED_LEN_OK; break; }
+            stage = MARK_ED_START;
+            i = j2 + 1;
+            if (i >= n_stop) break;
+        }
+    }
+    m.ed_stage = stage; m.ed_start = (uint16_t)ed_start; m.ed_end = (uint16_t)ed_end;
+    return m;
+}
+
 /* Binarizer::findSTC007Coordinates (binarizer.cpp:6047-6113): lanes 0..23 each try one hysteresis level */
 __device__ inline void find_coordinates_wave(const Bin &b, const sdv_bin_preset &ps, const WaveLds &lds, Line &l)
 {
     int lane = lane_id();
     uint8_t h = (uint8_t)(lane < 24 ? lane : 23);
-    Markers m = search_markers_px(b, ps, lds.px, l.ref_level, h);
+    /* the windows of the two searches (binarizer.cpp:5300-5308, :5408-5418) */
+    int n_start = (b.mark_start_max + b.estimated_ppb * 5) & 0xFFFF; if (n_start > b.line_length) n_start = b.line_length;
+    n_start -= b.scan_start;
+    const int end_limit = b.mark_end_min > b.estimated_ppb * 6 ? b.mark_end_min - b.estimated_ppb * 6 : 0;
+    const int n_stop = (int)b.scan_end - end_limit;
+    Markers m = (n_start > 0 && n_start <= SWEEP_WINDOW_MAX && n_stop > 0 && n_stop <= SWEEP_WINDOW_MAX) ? search_markers_masks(b, ps, lds.px, l.ref_level, n_start, n_stop)
+                                                                                                       : search_markers_px(b, ps, lds.px, l.ref_level, h);
     bool ok = (lane < 24) && m.has_start && (m.ed_stage == MARK_ED_LEN_OK);
     uint32_t k = coords_key((int16_t)m.st1e, (int16_t)m.ed_start);
     uint64_t okm = __ballot(ok);

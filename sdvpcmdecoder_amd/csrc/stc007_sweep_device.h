@@ -125,7 +125,6 @@ struct SweepLds {
     uint64_t g_start[88][3];        /* [T - t_lo]: pixel p of the START window >= T, bit p */
     uint64_t g_stop[88][3];         /* ... pixel scan_end - i of the STOP window >= T, bit i */
 };
-enum { SWEEP_WINDOW_MAX = 192 };
 
 /* the line geometry Binarizer::processLine derives from the line length (binarizer.cpp:600-641) */
 __device__ inline void bin_line_geometry(Bin &b, const sdv_bin_preset &ps, int width, bool doubled)
@@ -141,25 +140,7 @@ __device__ inline void bin_line_geometry(Bin &b, const sdv_bin_preset &ps, int w
     b.estimated_ppb = (uint16_t)((tmp_calc + 64) / 128);
 }
 
-/* ---- markers from threshold masks -------------------------------------------------------------- */
-__device__ __forceinline__ int m192_first_set(const uint64_t *w, int p)        /* the lowest set bit at or above p; SWEEP_WINDOW_MAX when there is none */
-{
-    int r = SWEEP_WINDOW_MAX;
-#pragma unroll
-    for (int k = 2; k >= 0; k--) {
-        const int lo = p - 64 * k;
-        if (lo > 63) continue;
-        uint64_t x = w[k];
-        if (lo > 0) x &= ~0ull << lo;
-        if (x) r = 64 * k + __ffsll((unsigned long long)x) - 1;
-    }
-    return r;
-}
-__device__ __forceinline__ int m192_first_clear(const uint64_t *w, int p)
-{
-    const uint64_t n[3] = { ~w[0], ~w[1], ~w[2] };
-    return m192_first_set(n, p);
-}
+/* ---- markers from threshold masks (m192_first_set / m192_first_clear: stc007_device.h) ---------------------- */
 /* START marker "1010" (binarizer.cpp:5310-5405) on L = pixel >= low threshold, H = pixel >= reference level, pixels [0, n_px):
  * returns whether the marker was found; st1e = where the data starts (end of the first "1") */
 __device__ inline bool start_marker_masks(const uint64_t *L, const uint64_t *H, int n_px, int mark_start_max, int ppb, int &st1e)
