@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""The table of measured numbers in DESIGN.md (between the two `numbers:` markers) from profiles/<round>_bench_full.json: usage design_numbers.py [r04]"""
+import json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_full.json")))
+def g(*p):
+    x = d
+    for k in p:
+        x = x[k]
+    return x
+pal, dm = d["pal_stage"], d["damaged_tape"]
+c3 = pal["lost_lines_and_flipped_cells"]
+pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_sdv_k_stc007_frames_lean.json")))
+fetch = next(v["FETCH_SIZE"] for v in pmc.values() if isinstance(v, dict) and "FETCH_SIZE" in v)
+write = next(v["WRITE_SIZE"] for v in pmc.values() if isinstance(v, dict) and "WRITE_SIZE" in v)
+traffic = (2 * fetch + write) * 1024 if fetch < 1e8 else fetch + write        # (FETCH_SIZE counts 2 KiB... see bench.py: the same correction)
+rows = [
+    ("**headline**: `sdv_binarize_frames`, configs[1]",
+     f"{d['value'] / 1e6:.2f} M frames/s, {d['ms_per_step']:.3f} ms per step; lean kernel {g('roofline', 'avg_launch_ms'):.3f} ms per launch = {g('roofline', 'achieved') / 1000:.2f} TB/s algorithmic = **{g('roofline', 'frac'):.3f} of the 8 TB/s peak**",
+     "boxes of the pool: 0.737 … 0.81 ms per launch in this round's runs (frac 0.634 … 0.576; `profiles/r04_k1_ab_across_rounds.txt`); PMC traffic 1.05 × algorithmic (`profiles/r04_pmc_sdv_k_stc007_frames_lean.json`)"),
+    ("CPU baseline (real reference, `oracle/_ref`)", f"{g('cpu_baseline', 'value'):.0f} frames/s on one core; {g('cpu_baseline_all_cores', 'value'):.0f} frames/s with a worker on each of the {g('cpu_baseline_all_cores', 'cores')} cores the container is granted", "bit-exact on the overlap"),
+    ("frames → pairs, fused (`sdv_decode_frames`)", f"{g('end_to_end', 'ms_per_step'):.3f} ms = {g('end_to_end', 'frames_per_s') / 1e6:.2f} M frames/s, {g('end_to_end', 'roofline', 'frac'):.2f} of peak on 377 232 B per frame", "kernels: K1 0.8 + analyze 0.28 + step 0.37 + small ones 0.1"),
+    ("stitch stage alone", f"{g('stitch_stage', 'stitch_ms_per_step'):.3f} ms ({g('stitch_stage', 'stitch_device_ms_per_step'):.3f} ms on the device)", f"CPU: {g('stitch_stage', 'cpu_baseline', 'value'):.0f} frames/s"),
+    ("PAL (configs[2]) clean, binarize + stitch", f"{pal['clean']['ms_per_step']:.2f} ms = {pal['clean']['frames_per_s'] / 1e6:.2f} M frames/s", ""),
+    ("PAL C3 tape (2000 frames; every 97th line lost, a cell inverted on one line in 53)",
+     f"binarize {c3['binarize_ms_per_step']:.1f} ms ({2000 / c3['binarize_ms_per_step']:.0f} k frames/s; round 3: 272 ms), {c3['binarize_rounds_per_step']:.0f} rounds, {c3['reference_level_sweeps_per_step']:.0f} sweeps; + stitch {c3['stitch_ms_per_step']:.1f} ms → **{c3['frames_per_s'] / 1e3:.1f} k frames/s** (round 3: 7.2 k)",
+     f"CPU (real reference): {c3['cpu_baseline']['value']:.0f} frames/s, bit-exact on the overlap"),
+    ("16 lost lines / 16 window jumps per 10 000 frames", f"{dm['lost_lines']['ms_per_step']:.2f} ms ({dm['lost_lines']['rounds_per_step']:.0f} rounds) / {dm['window_jumps']['ms_per_step']:.1f} ms ({dm['window_jumps']['rounds_per_step']:.0f} rounds, {dm['window_jumps']['frames_by_full_kernel_per_step']:.0f} frames through the general kernel)", "the verdict's 10 ms for the jumps is not reached (§10)"),
+    ("PCM-1: line kernel / frame driver / stitch", f"{g('pcm1_front_stage', 'ms_per_step'):.2f} ms per 980 000 lines / {g('pcm1_frames_stage', 'ms_per_step'):.2f} ms / {g('pcm1_stage', 'ms_per_step'):.2f} ms", f"CPU: {g('pcm1_frames_stage', 'cpu_baseline', 'value'):.0f} frames/s (frame driver)"),
+    ("PCM-16x0: frame driver / stitch SI / EI", f"{g('pcm16x0_frames_stage', 'ms_per_step'):.2f} ms / {g('pcm16x0_stage', 'si', 'ms_per_step'):.2f} ms / {g('pcm16x0_stage', 'ei', 'ms_per_step'):.2f} ms", f"CPU: {g('pcm16x0_frames_stage', 'cpu_baseline', 'value'):.0f} frames/s (frame driver)"),
+    ("AudioProcessor: clean / dropout every 25 frames / invalid word in every window", f"{g('audio_stage', 'clean', 'ms_per_step'):.2f} / {g('audio_stage', 'dropout_every_25_frames', 'ms_per_step'):.2f} / {g('audio_stage', 'invalid_word_in_every_window', 'ms_per_step'):.2f} ms", "CPU: 1.3–2.8 k frames/s"),
+]
+table = f"| what (10 000 NTSC frames per step unless said) | measured (`profiles/{rnd}_bench_full.json`, one box) | note |\n|---|---|---|\n" + "".join(f"| {a} | {b} | {c} |\n" for a, b, c in rows)
+path = os.path.join(ROOT, "DESIGN.md")
+s = open(path).read()
+a, b = "<!-- numbers: begin (tools/design_numbers.py) -->\n", "<!-- numbers: end -->\n"
+if a in s:
+    s = s[:s.index(a) + len(a)] + table + s[s.index(b):]
+else:
+    i = s.index("| what (10 000 NTSC frames per step unless said)")
+    j = s.index("\nKernel profiles of this round")
+    s = s[:i] + a + table + b + s[j:]
+open(path, "w").write(s)
+print(table)
