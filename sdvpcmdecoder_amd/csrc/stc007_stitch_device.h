@@ -329,53 +329,139 @@ template <int N> struct RingSrcN {
 };
 typedef RingSrcN<RING> RingSrc;
 
-/* STC007DataStitcher::getFieldResolution (stc007datastitcher.cpp:996-1211) for one field buffer, blocks split over the lanes */
-__device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int lane, sdv_deint_line *ring)
+/* What getFieldResolution asks of a block decoded in one of the two modes - "valid, checkable, not silent" and "BROKEN" - has a short form for the
+ * block a tape that plays is made of: every word passed its CRC (in 16-bit mode: and the S bits of its line).  processBlock (forced check, P code,
+ * no Q code, no CWD, fixed resolution) then only compares the P word with the XOR of the six samples: equal -> the block is valid as it stands (and
+ * silent when all six are zero), not equal -> BROKEN (stc007deinterleaver.cpp:286-1123 via the first short cut of sdvd::process_block). */
+/* STC007DataStitcher::getFieldResolution (stc007datastitcher.cpp:996-1211) for one field buffer, blocks split over the lanes.
+ * The field is staged once in LDS in the form the trial needs of a line - per word k < 7 sixteen bits (the 14-bit word and the two S bits a 16-bit sample
+ * takes from the line's Q word), and the line's per-word CRC flags - transposed, so that the 64 blocks of a step read consecutive halfwords: block i
+ * takes word k of line i + 16 k.  A block whose words all passed their CRC is decided from those (probe of the clean block, above: the P word against
+ * the XOR of the samples, in either resolution); only a block with a failed word goes through processBlock itself, on lines gathered from the field
+ * buffer.  (Through round 4 every block of every field went through two processBlock calls on lines kept in an LDS ring: 130 000 cycles a frame.) */
+enum { RES_PITCH = BUF_FIELD + 2 };
+__device__ inline uint8_t field_resolution(const Cfg &cfg, const Field &f, int lane, uint32_t *lds_words, unsigned long long *tm = nullptr)
 {
     if (cfg.preset_audio_res == SRES_14BIT) return SRES_14BIT;
     if (cfg.preset_audio_res == SRES_16BIT) return SRES_16BIT;
     if (f.size > BUF_FIELD || f.size <= MIN_DEINT) return SRES_UNKNOWN;
-    int test = f.size - MIN_DEINT;
+    const int test = f.size - MIN_DEINT;
+    uint16_t *e16 = (uint16_t *)lds_words;            /* [k][line] for k < 7, then the flags: bits 0..7 word_crc_ok, bit 15: not a line the short form can take */
     FieldSrc src; src.f = f;
-    RingSrcN<RING_SMALL> rs; rs.ring = ring;
+    SDV_LDS_WAVE_SYNC();                                              /* whoever used the staging area before is done with it */
+    /* (the lines of a lane asked for together, ahead of the first use: one trip to the field buffer instead of five, one behind the other) */
+    constexpr int STAGE_TRIPS = (BUF_FIELD + 63) / 64;
+    SLine ls[STAGE_TRIPS];
+#pragma unroll
+    for (int u = 0; u < STAGE_TRIPS; u++) { const int j = lane + 64 * u; if (j < f.size) ls[u] = f.get(j); }
+#pragma unroll
+    for (int u = 0; u < STAGE_TRIPS; u++) {
+        const int j = lane + 64 * u;
+        if (j >= f.size) break;
+        const sdv_deint_line d = view(ls[u]);
+        uint32_t odd = cfg.m2 ? 1u : 0u;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            odd |= (uint32_t)d.words[k] >> 14;
+            e16[k * RES_PITCH + j] = (uint16_t)((d.words[k] & 0x3FFFu) | (((uint32_t)d.words[sdvd::WORD_Q0] >> (12 - 2 * k)) & 3u) << 14);
+        }
+        e16[7 * RES_PITCH + j] = (uint16_t)(d.word_crc_ok | (odd ? 0x8000u : 0u));
+    }
+    SDV_LDS_WAVE_SYNC();
+#ifndef SDV_EMU
+    if (tm && lane == 0) tm[5] = (unsigned long long)__builtin_readcyclecounter();
+    unsigned slow_chunks = 0;
+#endif
     uint16_t res[2] = { 0, 0 };
-    SDV_LDS_WAVE_SYNC();                                              /* whoever used the ring before is done with it */
-    for (int i = lane; i < RING_SPAN && i < f.size; i += 64) ring[i] = src.line((size_t)i);
     for (int c = 0; c * 64 < test; c++) {
-        int i = c * 64 + lane;
-        bool act = i < test;
+        const int i = c * 64 + lane;
+        const bool act = i < test;
+        /* per mode: the words that failed (bit k), the XOR of the seven words, the six samples */
+        uint32_t bad14 = 0, bad16 = 0, plain = act ? 1u : 0u, p14 = 0, p16 = 0, w14v[6] = { 0, 0, 0, 0, 0, 0 }, any16 = 0;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t fl = e16[7 * RES_PITCH + i + ILV * k];
+                const uint32_t ck = (fl >> k) & 1u, cq = (fl >> sdvd::WORD_Q0) & 1u;
+                plain &= (fl >> 15) ^ 1u;
+                bad14 |= (ck ^ 1u) << k;
+                if (k < 7) {
+                    bad16 |= ((ck & cq) ^ 1u) << k;
+                    const uint32_t e = e16[k * RES_PITCH + i + ILV * k];
+                    const uint32_t w14 = e & 0x3FFFu, w16 = ((w14 << 2) + (e >> 14)) & 0xFFFFu;
+                    p14 ^= w14; p16 ^= w16;
+                    if (k < 6) { w14v[k] = w14; any16 |= w16; }
+                }
+            }
+        }
+        /* The short forms (processBlock with forced check, P code, no Q code, no CWD, one attempt - stc007deinterleaver.cpp:286-1123):
+         *   no failed word        P syndrome 0 -> valid as it stands; else BROKEN
+         *   one failed word, 14 bit: an audio word is restored from P (never BROKEN, one error may still be checked: counts unless silent); the P word:
+         *                         nothing to check, the audio stands; the Q word: as with no failed word
+         *   one failed word, 16 bit: restored or left alone, but a block with an error cannot be checked: neither counted nor BROKEN
+         * anything else goes through processBlock. */
+        const int n14 = __popc(bad14), n16 = __popc(bad16);
+        bool g14 = false, k14 = false, g16 = false, k16 = false;
+        const bool short14 = act && plain && n14 <= 1, short16 = act && plain && n16 <= 1;
+        if (short14) {
+            uint32_t any = 0;
+            const int k0 = n14 ? __ffs((int)bad14) - 1 : 8;
+#pragma unroll
+            for (int k = 0; k < 6; k++) any |= (k == k0) ? (p14 ^ w14v[k]) : w14v[k];      /* (a failed audio word: the value the P code restores) */
+            if (k0 < 7) g14 = any != 0;
+            else { k14 = p14 != 0; g14 = !k14 && any != 0; }
+        }
+        if (short16) { if (n16 == 0) { k16 = p16 != 0; g16 = !k16 && any16 != 0; } }
         uint64_t good[2], brk[2];
-        const int nx = c * 64 + RING_SPAN + lane;                     /* the next step's new lines: asked for now, stored behind this step's decodes */
-        const bool has_nx = nx < f.size && (c + 1) * 64 < test;
-        sdv_deint_line nxl; if (has_nx) nxl = src.line((size_t)nx);
-        SDV_LDS_WAVE_SYNC();
+        const bool slow = act && !(short14 && short16);               /* the lines themselves, from the field buffer */
         sdvd::Lines8 l8;
-        if (act) sdvd::gather8(rs, (size_t)i, l8);
+#ifdef SDV_EMU
+        if (act) sdvd::gather8(src, (size_t)i, l8);                   /* (the emulator checks every short form against processBlock) */
+#else
+        if (slow) sdvd::gather8(src, (size_t)i, l8);
+        if (__ballot(slow)) slow_chunks++;
+#endif
         for (int m = 0; m < 2; m++) {
-            bool g = false, k = false;
+            bool g = m == 0 ? g14 : g16, k = m == 0 ? k14 : k16;
+            const bool short_form = m == 0 ? short14 : short16;
+#ifdef SDV_EMU
             if (act) {
+#else
+            if (act && !short_form) {
+#endif
                 Block b;
                 sdvd::process_block(deint_cfg(m == 0 ? SDV_RES_MODE_14BIT : SDV_RES_MODE_16BIT, false, true, true, false, false), l8, 0, b);
-                g = blk_valid(b) && can_force_check(b) && !blk_silent(b, cfg.m2);
-                k = b.audio_state == SDV_AUD_BROKEN;
+                const bool g2 = blk_valid(b) && can_force_check(b) && !blk_silent(b, cfg.m2), k2 = b.audio_state == SDV_AUD_BROKEN;
+#ifdef SDV_EMU
+                if (short_form && (g != g2 || k != k2)) {
+                    fprintf(stderr, "field_resolution: short form of block %d mode %d says (%d, %d), processBlock (%d, %d); failed words %x / %x\n", i, m, (int)g, (int)k, (int)g2, (int)k2, bad14, bad16);
+                    abort();
+                }
+#endif
+                g = g2; k = k2;
             }
             good[m] = __ballot(g); brk[m] = __ballot(k);
         }
+        /* The counters (:1147-1168): a block that counts adds one, a BROKEN one takes one away - never below zero.  Block after block that is
+         * x <- max(x + d, 0); over a step of 64 blocks: x + S_n or S_n - min S_k, whichever is larger (S_k the running sum of the d up to block k) -
+         * every lane its S_k from two population counts, the minimum across the wave.  (A 14-bit tape gives a BROKEN block at nearly every place of
+         * its 16-bit trial: the loop over the blocks ran in every step, 15 000 cycles each.) */
         int cnt = test - c * 64; if (cnt > 64) cnt = 64;
-        if ((brk[0] | brk[1]) == 0) {                /* no broken block: the counters only go up (the usual case) */
-            res[0] = (uint16_t)(res[0] + __popcll(good[0])); res[1] = (uint16_t)(res[1] + __popcll(good[1]));
-        } else
-            for (int j = 0; j < cnt; j++)
-                for (int m = 0; m < 2; m++) {
-                    if ((good[m] >> j) & 1) res[m]++;
-                    else if (((brk[m] >> j) & 1) && res[m] > 0) res[m]--;
-                }
-        /* The slots of the next step's new lines hold lines of THIS step's gather8 (the ring is 192 deep, a step reads 64 + 112 of them): every
-         * lane's reads of the ring have to be done before any lane stores - made explicit here; the barrier at the top of the step then orders
-         * the stores before the next step's reads. */
-        SDV_LDS_WAVE_SYNC();
-        if (has_nx) ring[(uint32_t)nx % (uint32_t)RING_SMALL] = nxl;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            if (brk[m] == 0) { res[m] = (uint16_t)(res[m] + __popcll(good[m])); continue; }
+            const uint64_t upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+            int sk = (int)__popcll(good[m] & upto) - (int)__popcll(brk[m] & upto);
+            const int sn = __shfl(sk, cnt - 1);
+            if (lane >= cnt) sk = 0x7FFFFFFF;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl(sk, lane ^ d); sk = o < sk ? o : sk; }
+            const int a = (int)res[m] + sn, b = sn - sk;
+            res[m] = (uint16_t)(a > b ? a : b);
+        }
     }
+#ifndef SDV_EMU
+    if (tm && lane == 0) { tm[6] = (unsigned long long)__builtin_readcyclecounter(); tm[7] = slow_chunks; }
+#endif
     if (res[0] > (ILV * 2)) {
         uint16_t t = (uint16_t)(res[1] * 128);
         t = (uint16_t)(t / res[0]);
@@ -392,7 +478,7 @@ enum { AM_G = 1 << 16,          /* data line, CRC valid, not forced bad */
        AM_MK = 1 << 18,         /* data line with both markers found */
        AM_DATA = 1 << 19, AM_FILLER = 1 << 20, AM_NEW_FILE = 1 << 21, AM_END_FILE = 1 << 22, AM_CTRL = 1 << 23,
        ANALYZE_LDS = 1024,      /* records staged per frame; longer segments compute the word from the record on every access */
-       ANALYZE_LDS_WORDS = 1152 };    /* ... and the same LDS holds the RING_SMALL lines of the resolution trials afterwards */
+       ANALYZE_LDS_WORDS = 1184 };    /* ... and the same LDS holds the staged field of the resolution trials afterwards (8 x RES_PITCH halfwords) */
 struct Rec48 { uint4 q0, q1, q2; };      /* an sdv_line_rec as three 16-byte loads */
 static_assert(sizeof(sdv_line_rec) == 48, "record layout");
 __device__ inline uint32_t rec_meta(const Rec48 &r, uint32_t fnum, bool &bad_number)
@@ -557,7 +643,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
     uint8_t fres[2];
     for (int p = 0; p < 2; p++) {
         Field f; f.lines = field_lines(a.fields, k, p); f.size = (int)cnt[p];
-        fres[p] = field_resolution(a.cfg, f, lane, (sdv_deint_line *)meta);
+        fres[p] = field_resolution(a.cfg, f, lane, meta, (p == 0 && a.timing) ? a.timing + (size_t)k * 8 : nullptr);
     }
     if (lane == 0) {
         fl->field_res[0] = fres[0]; fl->field_res[1] = fres[1];
@@ -1757,7 +1843,7 @@ __global__ void __launch_bounds__(64) sdv_k_stitch_seg_scan(sdvs::ScanArgs a) { 
 __global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 {
     __shared__ uint32_t meta[sdvs::ANALYZE_LDS_WORDS];
-    static_assert(sizeof(meta) >= sdvs::RING_SMALL * sizeof(sdv_deint_line), "the ring of the resolution trials lives in the staging area");
+    static_assert(sizeof(meta) >= 8 * sdvs::RES_PITCH * sizeof(uint16_t), "the staged field of the resolution trials lives in the staging area");
     const uint32_t k = blockIdx.x;
     if (a.ctl && k >= sdvs::ctl_nseg(a.ctl, a.n_seg)) return;
     const uint32_t n = a.seg_end[k] - (k == 0 ? 0u : a.seg_end[k - 1] + 1u);
