@@ -895,6 +895,42 @@ __device__ inline SpreadLevels spread_levels(const sdv_bin_preset &ps, const Wav
  * scan is 10 % / 12 % of the range past it - and the checks of the pair (contrast, limits; sweep_flag = Binarizer::do_ref_lvl_sweep, sticky).  The
  * counts come out of the lanes' registers (spread_at). */
 struct BwLevels { uint8_t black, white; bool set; };
+/* The walks over the brightness spread that look for a peak (binarizer.cpp:2450-2558, :3280-3400): from `start` in steps of `step` over `n` levels, the
+ * level with the highest count so far is marked whenever a new highest count is also above `min_count`; the walk ends `stop_dist` levels behind the
+ * mark.  found = a level was marked; level = the last mark ahead of the end of the walk.  One level per lane (n <= 64): the highest count so far as a
+ * prefix maximum across the wave, the marks and the end of the walk from two ballots - the serial form read the spread one level at a time from
+ * LDS, some 20 levels per walk and three walks per findBlackWhite (6 000 of its 9 500 cycles). */
+struct PeakWalk { bool found; uint8_t level; };
+__device__ inline PeakWalk peak_walk(const SpreadLevels &sl, int start, int step, int n, uint32_t min_count, int stop_dist)
+{
+    PeakWalk r; r.found = false; r.level = 0;
+    if (n <= 0) return r;
+    if (n > 64) {               /* (a spread wider than 192 levels: as the reference walks) */
+        uint32_t top = 0;
+        for (int t = 0; t < n; t++) {
+            const int lev = start + step * t;
+            const uint32_t cnt = spread_at(sl, lev);
+            if (cnt > top) { top = cnt; if (top > min_count) { r.level = (uint8_t)lev; r.found = true; } }
+            if (r.found) { const int d = (lev - (int)r.level) * step; if (d >= stop_dist) break; }
+        }
+        return r;
+    }
+    const int lane = lane_id();
+    const bool act = lane < n;
+    const uint32_t cnt = act ? spread_at(sl, start + step * lane) : 0u;
+    uint32_t pm = cnt;                                  /* inclusive prefix maximum */
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl((int)pm, lane >= d ? lane - d : lane); if (lane >= d && o > pm) pm = o; }
+    uint32_t prev = (uint32_t)__shfl((int)pm, lane > 0 ? lane - 1 : 0); if (lane == 0) prev = 0u;
+    const uint64_t marks = __ballot(act && cnt > prev && cnt > min_count);
+    const uint64_t upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+    const uint64_t mine = marks & upto;
+    const int last = mine ? 63 - (int)__clzll((long long)mine) : -1;
+    const uint64_t ends = __ballot(act && last >= 0 && (lane - last) >= stop_dist);
+    const uint64_t seen = ends ? marks & ((ends & (0ull - ends)) | ((ends & (0ull - ends)) - 1ull)) : marks;        /* the marks up to the lane the walk ends in */
+    if (seen) { r.found = true; r.level = (uint8_t)(start + step * (63 - (int)__clzll((long long)seen))); }
+    return r;
+}
+
 __device__ inline BwLevels bw_from_spread(const sdv_bin_preset &ps, const SpreadLevels &sl, bool sweep_flag)
 {
     uint8_t brt_lev, br_black, br_white, useful_low, useful_high, low_scan_limit, high_scan_limit, range_limit, bin_low, bin_high;
@@ -910,28 +946,16 @@ __device__ inline BwLevels bw_from_spread(const sdv_bin_preset &ps, const Spread
     temp_calc = range_limit; temp_calc = temp_calc * 12 / 100; bin_high = (uint8_t)temp_calc;
     search_lim = sl.most_frequent;
     search_lim = search_lim / 64;
-    brt_lev = useful_low; black_lvl_count = 0; black_level_detected = false;
-    while (brt_lev <= low_scan_limit) {
-        const uint32_t cnt = spread_at(sl, brt_lev);
-        if (cnt > black_lvl_count) {
-            black_lvl_count = cnt;
-            if (black_lvl_count > search_lim) { br_black = brt_lev; black_level_detected = true; }
-        }
-        if (black_level_detected) if (((int)brt_lev - (int)br_black) >= (int)bin_low) break;
-        brt_lev++;
+    (void)brt_lev; (void)black_lvl_count; (void)white_lvl_count;
+    {   /* the black peak, upwards from the lowest useful level (:3330-3362) */
+        const PeakWalk w = peak_walk(sl, useful_low, 1, (int)low_scan_limit - (int)useful_low + 1, search_lim, bin_low);
+        black_level_detected = w.found; if (w.found) br_black = w.level;
     }
-    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
-    if (black_level_detected) {
-        while (brt_lev >= high_scan_limit) {
-            if ((int)brt_lev < ((int)br_black + (int)ps.min_contrast)) break;
-            const uint32_t cnt = spread_at(sl, brt_lev);
-            if (cnt > white_lvl_count) {
-                white_lvl_count = cnt;
-                if (white_lvl_count > search_lim) { br_white = brt_lev; white_level_detected = true; }
-            }
-            if (white_level_detected) if (((int)br_white - (int)brt_lev) >= (int)bin_high) break;
-            brt_lev--;
-        }
+    white_level_detected = false;
+    if (black_level_detected) {     /* the white peak, downwards - not closer to the black level than the least contrast (:3364-3400) */
+        int lowest = high_scan_limit; if (lowest < (int)br_black + (int)ps.min_contrast) lowest = (int)br_black + (int)ps.min_contrast;
+        const PeakWalk w = peak_walk(sl, useful_high, -1, (int)useful_high - lowest + 1, search_lim, bin_high);
+        white_level_detected = w.found; if (w.found) br_white = w.level;
     }
     if (black_level_detected && white_level_detected) {
         bool invalidate = false;
@@ -965,12 +989,10 @@ __device__ inline bool find_stc007_bw(Bin &b, const sdv_bin_preset &ps, WaveLds 
     range_limit = (uint8_t)(high_scan_limit - low_scan_limit);
     high_scan_limit = (uint8_t)(high_scan_limit - (range_limit / 4));
     bin_high = range_limit / 8;
-    brt_lev = useful_high; white_lvl_count = 0; white_level_detected = false;
-    while (brt_lev >= high_scan_limit) {
-        const uint32_t cnt = spread_at(sl, brt_lev);
-        if (cnt > white_lvl_count) { white_lvl_count = cnt; br_mark_white = brt_lev; white_level_detected = true; }
-        if (white_level_detected) if (((int)br_mark_white - (int)brt_lev) >= (int)bin_high) break;
-        brt_lev--;
+    (void)brt_lev; (void)white_lvl_count;
+    {   /* the white peak of the two ends of the line, downwards over the top quarter of the range (:2760-2790) */
+        const PeakWalk w = peak_walk(sl, useful_high, -1, (int)useful_high - (int)high_scan_limit + 1, 0u, bin_high);
+        white_level_detected = w.found; if (w.found) br_mark_white = w.level;
     }
     pixel_limit = (uint16_t)(b.scan_end - b.scan_start);
     temp_calc = pixel_limit / 8;
