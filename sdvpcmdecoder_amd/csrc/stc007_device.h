@@ -2066,7 +2066,11 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
         stc_clear(t);
         bin_line_geometry(tb, ps, a.width, a.doubled != 0);
         tb.was_bw_scanned = false;
-        if (!find_black_white(tb, ps, lds, t, bw_slot)) return false;
+        K1_T(t_m0);
+        const bool bw_found = find_black_white(tb, ps, lds, t, bw_slot);
+        K1_T(t_m1);
+        K1_ADD(22, t_m0, t_m1); K1_ADD(23, 0ull, 1ull);
+        if (!bw_found) return false;
         black = t.black; white = t.white; found_mark_ed = t.mark_ed; found_sp_ed = t.m_sp_ed;      /* (findSTC007BW leaves what it saw of the STOP marker in the line) */
         if (b.in_ref >= white || b.in_ref <= black) return false;
     }

@@ -51,6 +51,7 @@ names = {0: "frame total (sum)", 1: "batch loops", 2: "batch_finish", 3: "end of
          16: "fast_line: dup check", 17: "fast_line: 9-line window + key", 18: "fast_line: damper", 19: "fast_line: counters + record"}
 print(f"lines through fast_line one by one (full kernel): {v[5]} ({v[5] / fr:.1f} per frame), {v[4] / max(1, v[5]):.0f} cycles each, of which the ladder of reads {v[6] / max(1, v[5]):.0f}")
 print(f"   bookkeeping of a line taken by fast_line (lean + full, per call): dup check {v[16] / max(1, v[5]):.0f}, 9-line window + key {v[17] / max(1, v[5]):.0f}, damper {v[18] / max(1, v[5]):.0f}, counters + record {v[19] / max(1, v[5]):.0f}")
+print(f"lines that measured black and white ahead of the fast read (fast_line<true>): {v[23]} ({v[23] / fr:.1f} per frame), {v[22] / max(1, v[23]):.0f} cycles each for findBlackWhite")
 print(f"slow lines: {v[15]} ({v[15] / fr:.1f} per full-kernel frame); the slowest frame: index {v[7] & 0x3FFF}, {v[7] >> 24} cycles with {(v[7] >> 14) & 0x3FF} slow lines")
 import numpy as np
 from sdvpcmdecoder_amd import LINE_DTYPE
