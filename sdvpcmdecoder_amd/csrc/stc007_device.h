@@ -2585,11 +2585,17 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
      * frame one slot early on the GPU, at -O1 to -O3 alike, while the same source was right under the emulator.) */
     bool stop_frame = false;
     int last_miss_field = -1, last_miss_idx = 0;
+    /* Lines that read, but not on the first rung of the ladder (a data window a pixel or two beside the preset coordinates: the lines of a frame
+     * started from a state ahead of a small jump of the window, or a tape that sits like that): the two-lines-a-turn loop of the batch ends on every
+     * one of them and the line went through the one-line path - 10 000 cycles each, a batch attempt included.  Once a line was read like that the
+     * batches take one line a turn and walk the ladder on the staged row themselves (phase B books any rung); eight lines in a row on the first
+     * rung bring the fast loop back. */
+    bool sticky_rung = false; int first_rung_run = 0;
     for (int field = start_field; field < 2 && !stop_frame; field++) {
         const int nl = n_field[field];
         int idx = field == start_field ? start_idx : 0;
         while (idx < nl && !stop_frame) {
-            bool staged = false;
+            bool staged = false, batch_gave_way = false;
             /* the batch loop is the 16-byte-vector, single-vector-per-lane case (rows aligned, width a multiple of 16 up to 1024:
              * SD video); everything else takes the sequential path below */
             FastPre pre; pre.ok = false;
@@ -2606,7 +2612,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     if (field == 0 && (k - nl) < n_field[1]) return frame + (size_t)(2 * (k - nl) + 1) * a.row_stride;
                     return frame;
                 };
-                if (SDV_BATCH_LINES > 1) {
+                if (SDV_BATCH_LINES > 1 && !sticky_rung) {
                     constexpr int NLA = SDV_ROWQ + 1 + (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2);
                     const uint8_t *after[NLA];                  /* the rows that follow this field in decode order */
 #pragma unroll
@@ -2698,9 +2704,12 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                         }
                     }
                     FastBits fb;
-                    /* only the first rung of the ladder inside the batch: a line that needs another shift stage or hysteresis
-                     * depth ends the batch and takes the sequential path below (keeps this loop's control flow flat) */
-                    if (!fast_try0(fast_sample(lds, pre, 0), pre, lc, fb) || ctrl_block_maybe(fb.s_lo)) break;
+                    /* the first rung of the ladder; while lines need other rungs (sticky_rung) the whole ladder, on the row as it is staged.  A line
+                     * that reads on no rung ends the batch and takes the sequential path below. */
+                    const bool first_rung = fast_try0(fast_sample(lds, pre, 0), pre, lc, fb);
+                    if (!first_rung && !(sticky_rung && fast_decode(a, lds, v.bin, v.bin.in_black, v.bin.in_white, geo, lc, fb))) break;
+                    if (ctrl_block_maybe(fb.s_lo)) break;
+                    if (!first_rung) first_rung_run = 0; else if (sticky_rung && ++first_rung_run >= 8) sticky_rung = false;
                     bool mine = lane == j;
                     bl.d0 = mine ? (uint32_t)fb.s_lo : bl.d0; bl.d1 = mine ? (uint32_t)(fb.s_lo >> 32) : bl.d1;
                     bl.d2 = mine ? (uint32_t)fb.s_hi : bl.d2; bl.d3 = mine ? (uint32_t)(fb.s_hi >> 32) : bl.d3;
@@ -2716,6 +2725,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 }
                 if (j == nb) continue;
                 staged = !redo;                                 /* line idx sits in LDS and needs the sequential path */
+                batch_gave_way = true;
             }
             K1_T(t_st0);
             if (!staged) {
@@ -2733,6 +2743,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed);
             if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2, a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr); }
             K1_T(t_fl1);
+            if (took_fast && batch_gave_way && !sticky_rung) { sticky_rung = true; first_rung_run = 0; }      /* (a line the batch ended on, read by the ladder) */
             if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
             if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
             if (!took_fast) {

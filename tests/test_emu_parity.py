@@ -261,3 +261,27 @@ def test_emu_crowd_waits_for_the_sweeps_of_its_first_frame(emu_lib, oracle_lib):
     assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
     assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
     assert info.sweeps > 50
+
+
+def _jittered_tape(n, seed, jit, **kw):
+    """A tape whose lines sit a few pixels beside the coordinates the worker keeps preset: from the third frame on every row is moved by its own
+    -jit..jit pixels - the lines read, but on another rung of the hysteresis x shift ladder than the first."""
+    luma, _, _ = synth.stc007_frames(n, seed=seed, **kw)
+    luma = luma.copy()
+    rng = np.random.default_rng(seed)
+    for f in range(2, n):
+        for r in range(luma.shape[1]):
+            luma[f, r] = np.roll(luma[f, r], int(rng.integers(-jit, jit + 1)))
+    return luma
+
+
+@pytest.mark.parametrize("seed,jit,height", [(501, 2, 160), (502, 3, 160), (503, 3, 486)])
+def test_emu_lines_that_read_on_other_rungs_of_the_ladder(emu_lib, oracle_lib, seed, jit, height):
+    """The batches of the frame loop walk the ladder themselves once lines need it (sticky_rung, stc007_device.h): records as the sequential worker's."""
+    luma = _jittered_tape(5, seed, jit, height=height, noise_sigma=3.0)
+    want, want_stats = oracle_binarize(luma, mode=2)
+    data = want[want["service_type"] == 0]
+    assert int(((data["shift_stage"] != 0) | (data["hysteresis_depth"] != 0)).sum()) > len(data) // 12, "the tape is meant to need the ladder on many lines"
+    got, stats, info = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert stats.view(np.uint8).tobytes() == want_stats.tobytes()

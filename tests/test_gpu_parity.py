@@ -233,3 +233,25 @@ def test_hip_unreadable_cells_sweep_every_level(torch_cuda, pal):
     unread = int((((got["flags"] & 64) == 0) & (got["service_type"] == 0)).sum())     # data lines without SDV_LF_CRC_VALID: each of them was swept
     assert unread > 5 * n, unread
     assert info.rounds <= 24, info.rounds
+
+
+@pytest.mark.parametrize("seed,jit", [(511, 2), (512, 3)])
+def test_hip_lines_that_read_on_other_rungs_of_the_ladder(torch_cuda, seed, jit):
+    """A tape whose rows sit a few pixels beside the preset coordinates (every row moved by its own -jit..jit pixels): the lines read on other rungs
+    of the hysteresis x shift ladder; the batches of the frame loop then walk the ladder themselves (sticky_rung).  Against the sequential oracle."""
+    n = 40
+    luma, _, _ = synth.stc007_frames(n, seed=seed, noise_sigma=3.0)
+    luma = luma.copy()
+    rng = np.random.default_rng(seed)
+    shifts = rng.integers(-jit, jit + 1, size=(n, luma.shape[1]))
+    shifts[:2] = 0
+    for f in range(2, n):
+        for r in range(luma.shape[1]):
+            if shifts[f, r]:
+                luma[f, r] = np.roll(luma[f, r], int(shifts[f, r]))
+    want, want_stats = oracle_binarize(luma, mode=2)
+    data = want[want["service_type"] == 0]
+    assert int(((data["shift_stage"] != 0) | (data["hysteresis_depth"] != 0)).sum()) > len(data) // 12
+    got, got_stats, info = gpu_run(torch_cuda, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
