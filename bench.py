@@ -493,6 +493,7 @@ def main():
             fno += npal
             k_steps = max(1, min(args.steps, 3))
             b_ms = s_ms = 0.0; b_rounds = s_rounds = b_general = 0; b_sweeps = 0
+            eng.set_profiling(False)                    # wall clock as a caller sees it: no event pair around every round of the damaged tape
             for _ in range(k_steps):
                 torch.cuda.synchronize(dev); t1 = time.perf_counter()
                 eng.binarize_frames(luma_p, first_frame_no=fno, out_lines=ol_p[1:], out_stats=os_p, stream=stream)
@@ -502,6 +503,7 @@ def main():
                 b_ms += (t2 - t1) * 1e3; s_ms += (t3 - t2) * 1e3
                 b_rounds += eng.run_info().rounds; b_general += eng.run_info().frames_general; b_sweeps += eng.run_info().sweeps; s_rounds += eng.stitch_info().rounds
                 fno += npal
+            eng.set_profiling(True)
             tot = (b_ms + s_ms) / k_steps
             pr = pp_[:, :].cpu().numpy().reshape(-1).view(np.dtype([("w", "<i2", (2,)), ("fl", "u1", (2,)), ("rate", "<u2"), ("e", "u1"), ("srv", "u1"), ("_p", "<u2")]))
             pal[tape_name] = {"frames_per_step": npal, "binarize_ms_per_step": b_ms / k_steps, "stitch_ms_per_step": s_ms / k_steps, "ms_per_step": tot,
@@ -543,14 +545,19 @@ def main():
             for r_ in range(-1, k_steps):               # (-1: once untimed - the first damaged batch of a process pays first uses: the full kernel's code, pinned buffers)
                 # (the jumps leave the window displaced at the end of the batch: every step starts from the clean tape's state again)
                 eng.binarize_frames(luma, first_frame_no=1 + (2 * r_ + 3) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
+                # the wall clock of the call as a caller sees it: without the engine's event pair around every round (sdv_set_profiling), which is
+                # what the untimed first pass reads the kernel time from
+                eng.set_profiling(r_ < 0)
                 torch.cuda.synchronize(dev); t1 = time.perf_counter()
                 eng.binarize_frames(lum, first_frame_no=1 + (2 * r_ + 4) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
                 torch.cuda.synchronize(dev)
+                eng.set_profiling(True)
+                i_ = eng.run_info()
                 if r_ < 0:
+                    d_kms = i_.kernel_ms * k_steps
                     continue
                 d_ms += (time.perf_counter() - t1) * 1e3
-                i_ = eng.run_info()
-                d_kms += i_.kernel_ms; d_rounds += i_.rounds; d_launched += i_.frames_launched; d_general += i_.frames_general
+                d_rounds += i_.rounds; d_launched += i_.frames_launched; d_general += i_.frames_general
             damaged[kind] = {"events_per_step": per, "frames_per_step": n, "ms_per_step": d_ms / k_steps, "frames_per_s": n / (d_ms / k_steps) * 1e3,
                              "kernel_ms_per_step": d_kms / k_steps, "rounds_per_step": d_rounds / k_steps, "frames_launched_per_step": d_launched / k_steps,
                              "frames_by_full_kernel_per_step": d_general / k_steps}
