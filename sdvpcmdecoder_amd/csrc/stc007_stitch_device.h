@@ -271,6 +271,12 @@ struct FieldSrc {
 struct PadQueue {
     Field f1, f2; int a0, n0, npad, n2; uint32_t pad_frame; uint16_t pad_line0; bool m2;
     __device__ inline int size() const { return n0 + npad + n2; }
+    __device__ inline const SLine *src(int i) const        /* where place i is read from; NULL: a padding line */
+    {
+        if (i < n0) return f1.lines + (a0 + i);
+        if (i < n0 + npad) return nullptr;
+        return f2.lines + (i - n0 - npad);
+    }
     __device__ inline SLine get(int i) const
     {
         if (i < n0) return f1.get(a0 + i);
@@ -481,6 +487,27 @@ enum { AM_G = 1 << 16,          /* data line, CRC valid, not forced bad */
        ANALYZE_LDS_WORDS = 1184 };    /* ... and the same LDS holds the staged field of the resolution trials afterwards (8 x RES_PITCH halfwords) */
 struct Rec48 { uint4 q0, q1, q2; };      /* an sdv_line_rec as three 16-byte loads */
 static_assert(sizeof(sdv_line_rec) == 48, "record layout");
+/* sline_from_rec() of a record held in registers: the first 26 bytes of the two layouts are the same */
+__device__ inline SLine sline_from_raw(const Rec48 &r)
+{
+    static_assert(sizeof(SLine) == 32, "line layout");
+    const uint32_t srv = r.q2.z >> 24, flags = (r.q2.w >> 16) & 0xFF, mst = r.q2.w & 0xFF, med = (r.q2.w >> 8) & 0xFF, ref = r.q2.y >> 24;
+    uint32_t w[8];
+    if (srv != SDV_SRV_NO && srv != SDV_SRV_CTRL_BLOCK) {      /* filler: PCMLine::clear() on a cleared line */
+        w[0] = r.q0.x; w[1] = r.q0.y & 0xFFFFu; w[2] = w[3] = w[4] = 0; w[5] = (uint32_t)(uint16_t)~CRC_SILENT << 16; w[6] = 0; w[7] = 0;
+    } else {
+        const int16_t ds = (int16_t)(r.q1.z >> 16), de = (int16_t)(r.q1.w & 0xFFFF);
+        const bool forced = (flags & SDV_LF_FORCED_BAD) != 0;
+        const bool cv = ds != NO_COORD_L && de != NO_COORD_R && ds < de;
+        const uint32_t lf = (forced ? SL_FORCED_BAD : 0u) | (cv ? SL_COORDS_VALID : 0u) | ((flags & SDV_LF_BW_SET) ? SL_BW_SET : 0u) | ((mst == MST_BOT_2 && med == MED_LEN_OK) ? SL_MARKERS : 0u);
+        const uint32_t calc = r.q1.z & 0xFFFFu, w8 = r.q1.y >> 16;
+        const uint32_t wm = (!forced && calc == w8) ? 0x1FFu : 0u;
+        w[0] = r.q0.x; w[1] = r.q0.y; w[2] = r.q0.z; w[3] = r.q0.w; w[4] = r.q1.x; w[5] = r.q1.y;
+        w[6] = calc | (wm << 16); w[7] = wm | (lf << 16) | (ref << 24);
+    }
+    SLine l; __builtin_memcpy(&l, w, 32);
+    return l;
+}
 __device__ inline uint32_t rec_meta(const Rec48 &r, uint32_t fnum, bool &bad_number)
 {
     const uint32_t line = r.q0.y & 0xFFFF, w8 = r.q1.y >> 16, crc = r.q1.z & 0xFFFF, srv = r.q2.z >> 24;
@@ -584,32 +611,46 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
     AN_STAMP(2);
     /* pass 3 (splitFramesToFields :737-985): the field buffers, valid counts, mean reference level */
     uint32_t cnt[2] = { 0, 0 }, valid[2] = { 0, 0 }, ref_all[2] = { 0, 0 }, ref_ok[2] = { 0, 0 };
-    for (uint32_t c = 0; c < n; c += 64) {
-        uint32_t i = c + (uint32_t)lane;
-        bool act = i < n, sel = false, odd = false, ok = false;
-        uint16_t ln = 0; uint32_t ref = 0;
-        if (act) {
-            const uint32_t m = meta_at(i);
-            if (m & (AM_DATA | AM_FILLER)) {
-                ln = (uint16_t)(m & 0xFFFF); odd = (ln % 2) != 0;
-                int p = odd ? 0 : 1;
-                bool in = ln >= top[p] && ln <= bottom[p];
-                if (!odd) in = in && ((top[1] != bottom[1]) || (top[1] != 0));
-                sel = in;
-                if (m & AM_DATA) { ok = (m & AM_G) != 0; ref = m >> 24; }
-            }
+    /* (the records of four steps asked for at once, as in pass 1: a step's lines are stored where the steps before it have counted to,
+     * one round trip to the L2 per step would be all this pass spends its time on) */
+    for (uint32_t c4 = 0; c4 < n; c4 += 256) {
+        SLine made[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = c4 + 64u * (uint32_t)u + (uint32_t)lane;
+            const Rec48 *src = (const Rec48 *)&a.src.at(start + (i < n ? i : n - 1));
+            Rec48 r; r.q0 = src->q0; r.q1 = src->q1; r.q2 = src->q2;
+            made[u] = sline_from_raw(r);
         }
-        /* f_max_line and the reference-level sums: per lane here, across the lanes once after the pass */
-        if (ln > max_line) max_line = ln;
-        for (int p = 0; p < 2; p++) {
-            bool mine = sel && (odd == (p == 0));
-            uint64_t m = __ballot(mine);
-            uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
-            bool kept = mine && rank < BUF_FIELD;
-            if (kept) a.fields[((size_t)k * 2 + (size_t)p) * BUF_FIELD + rank] = sline_from_rec(a.src.at(start + i));
-            uint64_t mk = __ballot(kept), mv = __ballot(kept && ok);
-            ref_all[p] += kept ? ref : 0; ref_ok[p] += (kept && ok) ? ref : 0;
-            cnt[p] += (uint32_t)__popcll(mk); valid[p] += (uint32_t)__popcll(mv);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t c = c4 + 64u * (uint32_t)u, i = c + (uint32_t)lane;
+            if (c >= n) break;
+            bool act = i < n, sel = false, odd = false, ok = false;
+            uint16_t ln = 0; uint32_t ref = 0;
+            if (act) {
+                const uint32_t m = meta_at(i);
+                if (m & (AM_DATA | AM_FILLER)) {
+                    ln = (uint16_t)(m & 0xFFFF); odd = (ln % 2) != 0;
+                    int p = odd ? 0 : 1;
+                    bool in = ln >= top[p] && ln <= bottom[p];
+                    if (!odd) in = in && ((top[1] != bottom[1]) || (top[1] != 0));
+                    sel = in;
+                    if (m & AM_DATA) { ok = (m & AM_G) != 0; ref = m >> 24; }
+                }
+            }
+            /* f_max_line and the reference-level sums: per lane here, across the lanes once after the pass */
+            if (ln > max_line) max_line = ln;
+            for (int p = 0; p < 2; p++) {
+                bool mine = sel && (odd == (p == 0));
+                uint64_t m = __ballot(mine);
+                uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
+                bool kept = mine && rank < BUF_FIELD;
+                if (kept) a.fields[((size_t)k * 2 + (size_t)p) * BUF_FIELD + rank] = made[u];
+                uint64_t mk = __ballot(kept), mv = __ballot(kept && ok);
+                ref_all[p] += kept ? ref : 0; ref_ok[p] += (kept && ok) ? ref : 0;
+                cnt[p] += (uint32_t)__popcll(mk); valid[p] += (uint32_t)__popcll(mv);
+            }
         }
     }
     for (int ofs = 32; ofs > 0; ofs >>= 1) {
@@ -751,20 +792,53 @@ struct Step {
         pq.a0 = fa.size > keep ? fa.size - keep : 0;
         pq.n0 = fa.size - pq.a0;
         pq.npad = padding;
-        if (fa.size > 0) { SLine l = fa.get(fa.size - 1); pq.pad_frame = uni(l.frame); pq.pad_line0 = (uint16_t)uni((uint32_t)(l.line + 2)); }
-        else { pq.pad_frame = 0; pq.pad_line0 = 2; }
+        pq.pad_frame = 0; pq.pad_line0 = 2;
         pq.n2 = fb.size > (MIN_DEINT + ILV / 2) ? (MIN_DEINT + ILV / 2) : fb.size;
         const int n = pq.size();
         if (n < MIN_DEINT) return DS_NO_DATA;
         const uint8_t unchecked_lim = cfg.en_q ? cfg.max_unch_14 : cfg.max_unch_16;
+#if SDV_ST_TRY_BATCH
+        /* one round trip for all that is read before the first block: the field lines among the first 176 places of the queue and the
+         * line the padding counts on from (places 0 and 112, which say what resolution the trial runs in, are among the former) */
+        SLine got[3], lastl;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = lane + 64 * u;
+            got[u].frame = 0; got[u].line = 0;
+            if (i < RING_SPAN && i < n) { const SLine *sp = pq.src(i); if (sp) got[u] = *sp; }
+        }
+        if (fa.size > 0) { lastl = fa.get(fa.size - 1); pq.pad_frame = uni(lastl.frame); pq.pad_line0 = (uint16_t)uni((uint32_t)(lastl.line + 2)); }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int i = lane + 64 * u;
+            if (i < RING_SPAN && i < n && !pq.src(i)) got[u] = pq.get(i);
+        }
+        uint8_t mode = SDV_RES_MODE_14BIT;
+        if (!cfg.m2) {
+            if (n <= MIN_DEINT) mode = (uint8_t)SDV_RES_MODE_14BIT_AUTO;
+            else {
+                static_assert(MIN_DEINT == 112, "place 112 = lane 48 of the second step");
+                const uint32_t fr0 = (uint32_t)__shfl((int)got[0].frame, 0), ln0 = (uint32_t)__shfl((int)got[0].line, 0);
+                const uint32_t fr1 = (uint32_t)__shfl((int)got[1].frame, MIN_DEINT - 64), ln1 = (uint32_t)__shfl((int)got[1].line, MIN_DEINT - 64);
+                mode = (uint8_t)uni(res_mode_for_seam(line_res(fr0, (uint16_t)ln0), line_res(fr1, (uint16_t)ln1)));
+            }
+        }
+#else
+        if (fa.size > 0) { SLine l = fa.get(fa.size - 1); pq.pad_frame = uni(l.frame); pq.pad_line0 = (uint16_t)uni((uint32_t)(l.line + 2)); }
         uint8_t mode = SDV_RES_MODE_14BIT;
         if (!cfg.m2) mode = n <= MIN_DEINT ? (uint8_t)SDV_RES_MODE_14BIT_AUTO : (uint8_t)uni(block_res_mode(pq.get(0), pq.get(MIN_DEINT)));
+#endif
         const sdv_deint_settings ds = deint_cfg(mode, cfg.ignore_crc, true, cfg.en_p, cfg.en_q, false);
         const int nblk = n - MIN_DEINT;
         uint16_t valid_cnt = 0, silence_cnt = 0, uncheck_cnt = 0, broken_count = 0, valid_max = 0, silence_max = 0, uncheck_max = 0;
         RingSrc rs; rs.ring = ring;
         SDV_LDS_WAVE_SYNC();                                          /* whoever used the ring before is done with it */
+#if SDV_ST_TRY_BATCH
+#pragma unroll
+        for (int u = 0; u < 3; u++) { const int i = lane + 64 * u; if (i < RING_SPAN && i < n) ring[i] = view(got[u]); }
+#else
         for (int i = lane; i < RING_SPAN && i < n; i += 64) ring[i] = pq.line((size_t)i);
+#endif
         for (int c = 0; c * 64 < nblk; c++) {
             int i = c * 64 + lane;
             bool v = false, sl = false, u = false, br = false;
@@ -1129,24 +1203,61 @@ struct Step {
         const bool forced = (l.flags & SL_FORCED_BAD) != 0, failed = forced || ((l.wcrc & 0xFF) != 0xFF);
         return failed && ((!crc_valid_if(l) && (l.flags & SL_COORDS_VALID) && !forced) || crc_valid(l));
     }
+/* How many steps' lines the turn kernel asks for at once where it copies lines (1 = a step at a time).  The analysis kernel gains a lot
+ * from asking for four steps at once (its pass 3); the turn kernel loses by it, every time: it runs at its 128-register limit and what the
+ * batches hold in registers is spilled elsewhere (per 10 000-frame call, stitch kernels together: none 0.68 ms, queue fill x4 0.70,
+ * tail + hand-over x2 0.72, the trial's first 176 lines x3 0.73; profiles/r04_tuning_notes.md section 7) */
+#ifndef SDV_ST_FILL_U
+#define SDV_ST_FILL_U 1
+#endif
+#ifndef SDV_ST_TAIL_U
+#define SDV_ST_TAIL_U 1
+#endif
+#ifndef SDV_ST_RING_U
+#define SDV_ST_RING_U 1
+#endif
+#ifndef SDV_ST_TRY_BATCH
+#define SDV_ST_TRY_BATCH 0
+#endif
+    /* the frame number of the queue's last line when the writers below know it without asking the memory (prescan_frame's question) */
+    uint32_t q_last_frame; bool q_last_known;
     __device__ inline uint16_t add_lines(const Field &f, uint16_t start, uint16_t count, uint16_t &last_line)
     {
         if (!(BUF_FIELD >= (int)start && BUF_FIELD >= (int)start + (int)count)) return 0;
-        for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) { const SLine l = f.get(start + i); cwd_cand |= cwd_candidate(l); q[qn + i] = l; }
-        if (count > 0) last_line = (uint16_t)uni((uint32_t)(f.get(start + count - 1).line + 2));
-        qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; }
+        if (count == 0) return 0;
+        /* four steps' lines asked for at once (a field is one such batch); the last of them says where the numbering goes on */
+        const int e = (int)count - 1;
+        uint32_t e_line = 0, e_frame = 0;
+        for (int i0 = 0; i0 < (int)count; i0 += 64 * SDV_ST_FILL_U) {
+            SLine l[SDV_ST_FILL_U];
+#pragma unroll
+            for (int u = 0; u < SDV_ST_FILL_U; u++) { const int i = i0 + 64 * u + lane; l[u].frame = 0; l[u].line = 0; if (i < (int)count) l[u] = f.get(start + i); }
+#pragma unroll
+            for (int u = 0; u < SDV_ST_FILL_U; u++) {
+                const int i = i0 + 64 * u + lane;
+                if (i < (int)count && qn + i < QCAP) { cwd_cand |= cwd_candidate(l[u]); q[qn + i] = l[u]; }
+                if (i == e) { e_line = l[u].line; e_frame = l[u].frame; }
+            }
+        }
+        last_line = (uint16_t)((uint32_t)__shfl((int)e_line, e & 63) + 2u);
+        q_last_frame = (uint32_t)__shfl((int)e_frame, e & 63); q_last_known = true;
+        qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; q_last_known = false; }
         return count;
     }
     __device__ inline uint16_t add_padding(uint32_t frame, uint16_t count, uint16_t &last_line)
     {
         for (int i = lane; i < (int)count; i += 64) if (qn + i < QCAP) q[qn + i] = sline_empty(frame, (uint16_t)(last_line + 2 * i));
         last_line = (uint16_t)(last_line + 2 * count);
-        qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; }
+        if (count > 0) { q_last_frame = frame; q_last_known = true; }
+        qn += count; if (qn > QCAP) { qn = QCAP; overflow = true; q_last_known = false; }
         return count;
     }
     bool overflow;
 
-    /* ---- fillFrameForOutput (:4588-5387) ---- */
+    /* ---- fillFrameForOutput (:4588-5387) ----
+     * Every branch of the reference's decision tree adds the same kinds of things in the same order - [padding a], lines of the first
+     * field, [padding b], lines of the second field, [padding c], [padding d] - so the tree only says how much of each, and the
+     * queue is written at one place behind it. */
     __device__ inline void fill_frame_for_output()
     {
         uint16_t c1, c2, last_line = 0, lines_to_fill = 0, added_inner = 0, added_outer = 0;
@@ -1166,10 +1277,13 @@ struct Step {
         const bool insert_top_line = cfg.fix_cut_above != 0;
         const uint32_t fr = f1.frame_number;
         const uint16_t first_ln = order == ORDER_TFF ? 1 : 2, second_ln = order == ORDER_TFF ? 2 : 1;
-#define FIRST()  (last_line = first_ln)
-#define SECOND() (last_line = second_ln)
-#define LINES(p, st, cnt) add_lines((p), (uint16_t)(st), (uint16_t)(cnt), last_line)
-#define PAD(cnt) add_padding(fr, (uint16_t)(cnt), last_line)
+        uint16_t pa = 0, s1 = 0, n1 = 0, pb = 0, s2 = 0, n2 = 0, pc = 0, pd = 0;       /* the plan */
+#define L1(st, cnt) (s1 = (uint16_t)(st), n1 = (uint16_t)(cnt))
+#define L2(st, cnt) (s2 = (uint16_t)(st), n2 = (uint16_t)(cnt))
+#define PA(cnt) (pa = (uint16_t)(cnt))
+#define PB(cnt) (pb = (uint16_t)(cnt))
+#define PC(cnt) (pc = (uint16_t)(cnt))
+#define PD(cnt) (pd = (uint16_t)(cnt))
         if (file_start) {
             f0.frame_number = 0;
             f0.even_resolution = f0.odd_resolution = order == ORDER_TFF ? f1.odd_resolution : f1.even_resolution;
@@ -1184,23 +1298,23 @@ struct Step {
                 if (f1.outer_padding_ok) {
                     lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding + f1.outer_padding);
                     if ((target * 2) == lines_to_fill) {
-                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                        SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                        L1(0, c1); added_inner = PB(f1.inner_padding);
+                        L2(0, c2); added_outer = PC(f1.outer_padding);
                     } else if ((target * 2) > lines_to_fill) {
                         lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                        SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding); added_outer = (uint16_t)(added_outer + PAD(lines_to_fill));
+                        L1(0, c1); added_inner = PB(f1.inner_padding);
+                        L2(0, c2); added_outer = PC(f1.outer_padding); added_outer = (uint16_t)(added_outer + PD(lines_to_fill));
                         f1.outer_padding_ok = 0; set_order_unknown(f2);
                     } else {
                         lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding);
                         if ((target * 2) >= lines_to_fill) {
                             lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                            FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                            SECOND(); LINES(p2, 0, c2); added_outer = PAD(lines_to_fill);
+                            L1(0, c1); added_inner = PB(f1.inner_padding);
+                            L2(0, c2); added_outer = PC(lines_to_fill);
                         } else {
                             lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                            FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                            SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                            L1(0, c1); added_inner = PB(f1.inner_padding);
+                            L2(0, c2 - lines_to_fill);
                         }
                         f1.outer_padding_ok = 0; set_order_unknown(f2);
                     }
@@ -1208,34 +1322,34 @@ struct Step {
                     lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding);
                     if ((target * 2) >= lines_to_fill) {
                         lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                        SECOND(); LINES(p2, 0, c2); added_outer = PAD(lines_to_fill);
+                        L1(0, c1); added_inner = PB(f1.inner_padding);
+                        L2(0, c2); added_outer = PC(lines_to_fill);
                     } else {
                         lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                        FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                        SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                        L1(0, c1); added_inner = PB(f1.inner_padding);
+                        L2(0, c2 - lines_to_fill);
                     }
                 }
             } else if (f1.outer_padding_ok) {
                 lines_to_fill = (uint16_t)(c1 + c2 + f1.outer_padding);
                 if ((target * 2) >= lines_to_fill) {
                     lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(lines_to_fill);
-                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                    L1(0, c1); added_inner = PB(lines_to_fill);
+                    L2(0, c2); added_outer = PC(f1.outer_padding);
                 } else {
                     lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                    FIRST(); LINES(p1, 0, c1);
-                    SECOND(); LINES(p2, lines_to_fill, c2 - lines_to_fill); added_outer = PAD(f1.outer_padding);
+                    L1(0, c1);
+                    L2(lines_to_fill, c2 - lines_to_fill); added_outer = PC(f1.outer_padding);
                 }
             } else {
                 lines_to_fill = (uint16_t)(c1 + c2);
                 if ((target * 2) >= lines_to_fill) {
-                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(target - c1);
-                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(target - c2);
+                    L1(0, c1); added_inner = PB(target - c1);
+                    L2(0, c2); added_outer = PC(target - c2);
                 } else {
                     lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                    FIRST(); LINES(p1, 0, c1);
-                    SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                    L1(0, c1);
+                    L2(0, c2 - lines_to_fill);
                 }
             }
         } else if (f1.inner_padding_ok) {
@@ -1243,63 +1357,66 @@ struct Step {
                 lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding + f1.outer_padding);
                 if ((target * 2) >= lines_to_fill) {
                     lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                    FIRST(); added_inner = PAD(lines_to_fill); LINES(p1, 0, c1); added_inner = (uint16_t)(added_inner + PAD(f1.inner_padding));
-                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                    added_inner = PA(lines_to_fill); L1(0, c1); added_inner = (uint16_t)(added_inner + PB(f1.inner_padding));
+                    L2(0, c2); added_outer = PC(f1.outer_padding);
                 } else {
                     lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                    FIRST(); LINES(p1, lines_to_fill, c1 - lines_to_fill); added_inner = PAD(f1.inner_padding);
-                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                    L1(lines_to_fill, c1 - lines_to_fill); added_inner = PB(f1.inner_padding);
+                    L2(0, c2); added_outer = PC(f1.outer_padding);
                 }
             } else {
                 lines_to_fill = (uint16_t)(c1 + c2 + f1.inner_padding);
                 if ((target * 2) >= lines_to_fill) {
                     lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(lines_to_fill);
+                    L1(0, c1); added_inner = PB(f1.inner_padding);
+                    L2(0, c2); added_outer = PC(lines_to_fill);
                 } else {
                     lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                    FIRST(); LINES(p1, 0, c1); added_inner = PAD(f1.inner_padding);
-                    SECOND(); LINES(p2, 0, c2 - lines_to_fill);
+                    L1(0, c1); added_inner = PB(f1.inner_padding);
+                    L2(0, c2 - lines_to_fill);
                 }
             }
         } else if (f1.outer_padding_ok) {
             lines_to_fill = (uint16_t)(c1 + c2 + f1.outer_padding);
             if ((target * 2) >= lines_to_fill) {
                 lines_to_fill = (uint16_t)((target * 2) - lines_to_fill);
-                FIRST(); LINES(p1, 0, c1); added_inner = PAD(lines_to_fill);
-                SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                L1(0, c1); added_inner = PB(lines_to_fill);
+                L2(0, c2); added_outer = PC(f1.outer_padding);
             } else {
                 lines_to_fill = (uint16_t)(lines_to_fill - (target * 2));
-                FIRST(); LINES(p1, 0, c1 - lines_to_fill);
-                SECOND(); LINES(p2, 0, c2); added_outer = PAD(f1.outer_padding);
+                L1(0, c1 - lines_to_fill);
+                L2(0, c2); added_outer = PC(f1.outer_padding);
             }
         } else {
             lines_to_fill = (uint16_t)(c1 + c2);
             if ((target * 2) >= lines_to_fill) {
-                FIRST();
                 if (insert_top_line && c1 > 0 && c2 > 0) {
                     if (order == ORDER_BFF) {
-                        added_outer = PAD(1); LINES(p1, 0, c1); c1++; added_inner = PAD(target - c1);
-                        SECOND(); LINES(p2, 0, c2); added_outer = (uint16_t)(added_outer + PAD(target - c2));
+                        added_outer = PA(1); L1(0, c1); c1++; added_inner = PB(target - c1);
+                        L2(0, c2); added_outer = (uint16_t)(added_outer + PC(target - c2));
                     } else {
-                        LINES(p1, 0, c1); added_inner = PAD(target - c1 + 1);
-                        SECOND(); LINES(p2, 0, c2); c2++; added_outer = PAD(target - c2);
+                        L1(0, c1); added_inner = PB(target - c1 + 1);
+                        L2(0, c2); c2++; added_outer = PC(target - c2);
                     }
                 } else {
-                    LINES(p1, 0, c1); added_inner = PAD(target - c1);
-                    SECOND(); LINES(p2, 0, c2); added_outer = PAD(target - c2);
+                    L1(0, c1); added_inner = PB(target - c1);
+                    L2(0, c2); added_outer = PC(target - c2);
                 }
             } else {
-                FIRST();
-                if (c1 < target) { LINES(p1, 0, c1); added_inner = PAD(target - c1); } else LINES(p1, 0, target);
-                SECOND();
-                if (c2 < target) { LINES(p2, 0, c2); added_outer = PAD(target - c2); } else LINES(p2, 0, target);
+                if (c1 < target) { L1(0, c1); added_inner = PB(target - c1); } else L1(0, target);
+                if (c2 < target) { L2(0, c2); added_outer = PC(target - c2); } else L2(0, target);
             }
         }
-#undef FIRST
-#undef SECOND
-#undef LINES
-#undef PAD
+#undef L1
+#undef L2
+#undef PA
+#undef PB
+#undef PC
+#undef PD
+        last_line = first_ln;
+        add_padding(fr, pa, last_line); add_lines(p1, s1, n1, last_line); add_padding(fr, pb, last_line);
+        last_line = second_ln;
+        add_lines(p2, s2, n2, last_line); add_padding(fr, pc, last_line); add_padding(fr, pd, last_line);
         if (file_end) { last_line = 1; add_padding(f2.frame_number, MIN_DEINT, last_line); }
         f1.inner_padding = added_inner;
         f1.outer_padding = added_outer;
@@ -1424,6 +1541,7 @@ struct Step {
         if (!cfg.en_cwd) return;
         bool next = false;
         const int qn_own = qn;                                        /* the queue without frame B's look-ahead lines */
+        const bool own_known = q_last_known && qn > 0; const uint32_t own_frame = q_last_frame;
         if (f1.outer_padding_ok && order_set(f1)) {                   /* fillNextFieldForCWD :5390-5456 */
             uint16_t last_line = f1.field_order == ORDER_TFF ? 1 : 2;
             Field p = f1.field_order == ORDER_TFF ? field(2, 0) : field(2, 1);
@@ -1436,7 +1554,9 @@ struct Step {
         for (;;) { bool more = perform_cwd(); __syncthreads(); if (!more) break; }
         if (next) {                                                   /* removeNextFieldAfterCWD: every trailing line of frame B */
             qn = qn_own;                                              /* the look-ahead lines are frame B's by construction ... */
-            while (qn > 0 && uni(q[qn - 1].frame) == f2.frame_number) qn--;      /* ... and so is the end-of-file flush, if any */
+            /* ... and so is the end-of-file flush, if any (the writers usually know the frame of the line the queue ended with: no need to ask) */
+            if (!(own_known && own_frame != f2.frame_number))
+                while (qn > 0 && uni(q[qn - 1].frame) == f2.frame_number) qn--;
         }
     }
 
@@ -1502,7 +1622,17 @@ struct Step {
         }
         RingSrc src; src.ring = ring;
         __syncthreads();                                              /* whoever used the ring before is done with it */
-        for (int i = lane; i < RING_SPAN && i < qn; i += 64) ring[i] = view(q[i]);
+        {
+#if SDV_ST_RING_U == 3
+            SLine got[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int i = lane + 64 * u; if (i < RING_SPAN && i < qn) got[u] = q[i]; }
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int i = lane + 64 * u; if (i < RING_SPAN && i < qn) ring[i] = view(got[u]); }
+#else
+            for (int i = lane; i < RING_SPAN && i < qn; i += 64) ring[i] = view(q[i]);
+#endif
+        }
         uint16_t rate = (cfg.preset_sample_rate == 44100 || cfg.preset_sample_rate == 44056) ? cfg.preset_sample_rate
                         : (f1.video_standard == VID_NTSC ? (uint16_t)44056 : (uint16_t)44100);        /* setBlockSampleRate :6455-6480 */
         uint8_t cd = broken_countdown;
@@ -1649,15 +1779,31 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
     s.f0 = in->f0; make_uniform(s.f0);
     s.last_pad_counter = (uint8_t)uni(in->last_pad_counter); s.broken_countdown = (uint8_t)uni(in->broken_countdown);
     s.qn = (int)uni(in->tail_n);
-    s.cwd_cand = false;
-    for (int i = lane; i < s.qn; i += 64) { const SLine l = in->tail[i]; s.cwd_cand |= Step::cwd_candidate(l); s.q[i] = l; }
+    s.cwd_cand = false; s.q_last_known = false; s.q_last_frame = 0;
+    {   /* the lines the turn before left over: at most 112, both steps asked for at once */
+        static_assert(MIN_DEINT <= 128, "two steps");
+        SLine t[2];
+#if SDV_ST_TAIL_U == 2
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int i = lane + 64 * u; t[u].frame = 0; if (i < s.qn) t[u] = in->tail[i]; }
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int i = lane + 64 * u; if (i < s.qn) { s.cwd_cand |= Step::cwd_candidate(t[u]); s.q[i] = t[u]; } }
+#else
+        for (int u = 0; u < 2; u++) { const int i = lane + 64 * u; t[u].frame = 0; if (i < s.qn) { t[u] = in->tail[i]; s.cwd_cand |= Step::cwd_candidate(t[u]); s.q[i] = t[u]; } }
+#endif
+        if (s.qn > 0) {
+            const int e = s.qn - 1;
+            const uint32_t fr = e < 64 ? t[0].frame : t[1].frame;
+            s.q_last_frame = (uint32_t)__shfl((int)fr, e & 63); s.q_last_known = true;
+        }
+    }
     /* waitForTwoFrames / findFramesTrim / splitFramesToFields results come from the analysis pass */
     frasm_clear(s.f1); frasm_clear(s.f2);
     s.f1.frame_number = s.l1.frame_number; s.f2.frame_number = s.l2.frame_number;
     s.file_start = (s.l1.flags & FL_NEW_FILE) != 0;
     s.file_end = ((s.l1.flags | s.l2.flags) & FL_END_FILE) != 0;
     frasm_set_trim(s.f1, s.l1); frasm_set_trim(s.f2, s.l2);
-    if (s.file_start) reset_state(s);
+    if (s.file_start) { reset_state(s); s.q_last_known = false; }
     frasm_set_counts(s.f1, s.l1); frasm_set_counts(s.f2, s.l2);
     frasm_clear_asm_stats(s.f1);
     s.f1.odd_ref = s.l1.ref[0]; s.f1.even_ref = s.l1.ref[1];
@@ -1702,6 +1848,21 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
         __builtin_memcpy(xw, &s.f0, sizeof(Frasm)); __builtin_memcpy(yw, &of, sizeof(Frasm));
         for (unsigned i = 0; i < sizeof(Frasm) / 4; i++) diff = diff || xw[i] != yw[i];
         diff = diff || old->last_pad_counter != s.last_pad_counter || old->broken_countdown != s.broken_countdown || old->tail_n != (uint16_t)tail_n;
+#if SDV_ST_TAIL_U == 2
+        SLine tl[2], tol[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) { const int i = lane + 64 * h; if (i < tail_n) { tl[h] = s.q[s.tail_ofs + i]; tol[h] = old->tail[i]; } }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int i = lane + 64 * h;
+            if (i < tail_n) {
+                uint32_t u[8], v[8];
+                __builtin_memcpy(u, &tl[h], 32); __builtin_memcpy(v, &tol[h], 32);
+                for (int w = 0; w < 8; w++) diff = diff || u[w] != v[w];
+                out->tail[i] = tl[h];
+            }
+        }
+#else
         for (int i = lane; i < tail_n; i += 64) {
             const SLine l = s.q[s.tail_ofs + i], ol = old->tail[i];
             uint32_t u[8], v[8];
@@ -1709,6 +1870,7 @@ __device__ inline void step_body(const StepArgs &a, uint32_t work, uint32_t slot
             for (int w = 0; w < 8; w++) diff = diff || u[w] != v[w];
             out->tail[i] = l;
         }
+#endif
         if (lane == 0) { out->f0 = s.f0; out->last_pad_counter = s.last_pad_counter; out->broken_countdown = s.broken_countdown; out->tail_n = (uint16_t)tail_n; out->_pad[0] = out->_pad[1] = out->_pad[2] = 0; }
     }
     const bool changed = __ballot(diff) != 0;
@@ -1840,7 +2002,10 @@ __device__ inline uint32_t ctl_nseg(const uint32_t *ctl, uint32_t est) { const u
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_seg_scan(sdvs::ScanArgs a) { sdvs::seg_scan_body(a, (int)threadIdx.x); }
-__global__ void __launch_bounds__(64) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
+#ifndef SDV_AN_WAVES
+#define SDV_AN_WAVES 3
+#endif
+__global__ void __launch_bounds__(64, SDV_AN_WAVES) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 {
     __shared__ uint32_t meta[sdvs::ANALYZE_LDS_WORDS];
     static_assert(sizeof(meta) >= 8 * sdvs::RES_PITCH * sizeof(uint16_t), "the staged field of the resolution trials lives in the staging area");
