@@ -662,6 +662,18 @@ typedef struct sdv_pcm16x0_block_rec {
  * (the descriptor counts sub-blocks).  The count of the last call (or what it needed, when it failed with SDV_ERR_BAD_ARG for lack of room). */
 int sdv_set_pcm16x0_stitch_block_output(sdv_engine *e, sdv_pcm16x0_block_rec *out_blocks, size_t blocks_cap);
 size_t sdv_pcm16x0_stitch_block_count(sdv_engine *e);
+/* The assembled sub-lines: what performDeinterleave hands to newLineProcessed before it decodes the frame (pcm16x0datastitcher.cpp:5196-5213) - the
+ * sub-lines fillFrameForOutput queued for the frame (:4594-4690), trimmed and padded to 2 x 735.  They are written as records of the binarizer's own
+ * type, because the window that shows them is drawn by the renderer of the lines window (renderAssembled->startPCM1600Frame + renderNewLine(PCM16X0SubLine),
+ * mainwindow.cpp:2040-2044): sdv_vis_render_lines(SDV_VIS_PCM16X0_LINES) on this buffer draws the reference's "re-assembled" window.  A sub-line that
+ * came from the stream is its input record with the queue order addLinesFromField gave it (:4470) and, where prescanForFalsePosCRCs forced it bad
+ * (:800-820), SDV_LF_FORCED_BAD set - SDV_LF_CRC_VALID says what isCRCValid() answers now; a padding sub-line is a cleared PCM16X0SubLine (silent words, CRC word inverted,
+ * Control Bit set, no levels or coordinates) with the frame's number, its part and the line number addFieldPadding counted to (:4552-4556).  Behind the
+ * sub-lines of every frame one SDV_SRV_END_FRAME record (where MainWindow emits newFrameAssembled, :3956).  A frame that carries END_FILE queues nothing
+ * and writes nothing.  Not covered: sub-lines a frame with the same number left in the queue (the reference would show them again).
+ * Device memory; NULL: off, the default.  The count of the last call (or what it needed, when it failed with SDV_ERR_BAD_ARG for lack of room). */
+int sdv_set_pcm16x0_stitch_line_output(sdv_engine *e, sdv_pcm16x0_bin_rec *out_lines, size_t lines_cap);
+size_t sdv_pcm16x0_stitch_line_count(sdv_engine *e);
 
 
 /* ---- AudioProcessor: dropout masking on the PCMSamplePair stream ---------------------------- */

@@ -27,6 +27,7 @@ typedef struct {
     uint32_t frame_number; uint16_t line_number, words[4], calc_crc, queue_order;
     uint8_t ref_level, picked_left, picked_right, line_part, service_type;
     bool control_bit, bw_set, forced_bad, coords_valid;
+    const sdv_pcm16x0_bin_rec *src;     /* the record the object was made from (NULL: made by the stitcher) - what the visualiser's feed hands back */
 } p16_sub;
 
 static void sub_clear(p16_sub *s)   /* PCM16X0SubLine::clear (pcm16x0subline.cpp:63-86) over PCMLine::clear (pcmline.cpp:95-115) */
@@ -42,6 +43,7 @@ static void sub_from_rec(const sdv_pcm16x0_bin_rec *r, p16_sub *s)
          * silent words against the inverted silent CRC, calc_crc 0, no levels - whatever else the record holds is ignored */
         sub_clear(s);
         s->calc_crc = 0; s->frame_number = r->frame_number; s->line_number = r->line_number; s->service_type = r->service_type;
+        s->src = r;
         return;
     }
     memset(s, 0, sizeof(*s));
@@ -51,6 +53,7 @@ static void sub_from_rec(const sdv_pcm16x0_bin_rec *r, p16_sub *s)
     s->picked_left = r->picked_bits_left; s->picked_right = r->picked_bits_right; s->line_part = r->line_part; s->service_type = r->service_type;
     s->control_bit = r->control_bit != 0; s->bw_set = (r->flags & SDV_LF_BW_SET) != 0; s->forced_bad = (r->flags & SDV_LF_FORCED_BAD) != 0;
     s->coords_valid = r->data_start != -32768 && r->data_stop != 32767 && r->data_start < r->data_stop;      /* CoordinatePair::areValid */
+    s->src = r;
 }
 static bool sub_crc_if(const p16_sub *s) { return s->calc_crc == s->words[3]; }          /* isCRCValidIgnoreForced (pcm16x0subline.cpp:284-291) */
 static bool sub_crc(const p16_sub *s) { return !s->forced_bad && sub_crc_if(s); }       /* PCMLine::isCRCValid (pcmline.cpp:360-367) */
@@ -367,6 +370,7 @@ typedef struct {
     p16_ring stats_emph, stats_code, stats_srate, stats_padding;
     uint16_t f1_srate; bool f1_emph, f1_code, file_start, file_end;
     sdv_sample_pair *out; size_t out_n, out_cap; sdv_frame_asm_pcm16x0 *frames; size_t frames_n, frames_cap;
+    sdv_pcm16x0_bin_rec *vl; size_t vl_n, vl_cap;           /* ... and its assembled sub-lines (newLineProcessed) */
     sdv_pcm16x0_block_rec *vb; size_t vb_n, vb_cap;         /* the visualiser's feed (newBlockProcessed), when asked for */
 } p16_stitcher;
 enum { EMPH_UNKNOWN, EMPH_OFF, EMPH_ON, CONTENT_UNKNOWN = 0, CONTENT_AUDIO, CONTENT_CODE };
@@ -1126,8 +1130,38 @@ static void output_data_block(p16_stitcher *s, const p16_block *b)
 }
 
 /* performDeinterleave :5165-5447 */
+/* a queued sub-line as a record of the binarizer's type: the object is a copy of what the record was made into, with a new queue_order (:4470) and,
+ * maybe, forced bad since (:800-820); a line the stitcher made itself (addFieldPadding :4537-4571) is a cleared PCM16X0SubLine with numbers and part */
+static void sub_to_vis_rec(const p16_sub *l, sdv_pcm16x0_bin_rec *o)
+{
+    if (l->src) {
+        *o = *l->src;
+        o->queue_order = l->queue_order;
+        if (l->forced_bad) o->flags |= SDV_LF_FORCED_BAD;
+        o->flags = (uint8_t)((o->flags & ~SDV_LF_CRC_VALID) | ((!sub_service(l) && sub_crc(l)) ? SDV_LF_CRC_VALID : 0));      /* isCRCValid() as it stands now */
+        return;
+    }
+    memset(o, 0, sizeof(*o));
+    o->frame_number = l->frame_number; o->line_number = l->line_number;
+    for (int i = 0; i < 4; i++) o->words[i] = l->words[i];
+    o->calc_crc = l->calc_crc; o->data_start = -32768; o->data_stop = 32767; o->queue_order = l->queue_order;
+    o->line_part = l->line_part; o->control_bit = l->control_bit ? 1 : 0; o->service_type = l->service_type;
+}
+static void vis_end_frame(p16_stitcher *s, uint32_t frame)       /* where MainWindow emits newFrameAssembled (mainwindow.cpp:3956) */
+{
+    if (!s->vl) return;
+    if (s->vl_n < s->vl_cap) {
+        p16_sub e; sub_clear(&e);
+        e.frame_number = frame; e.calc_crc = 0; e.service_type = SDV_SRV_END_FRAME;
+        sub_to_vis_rec(&e, &s->vl[s->vl_n]);
+    }
+    s->vl_n++;
+}
 static void perform_deinterleave(p16_stitcher *s, uint8_t format)
 {
+    if (s->vl)          /* "dump the whole line buffer out (for visualization)" :5196-5213 */
+        for (size_t i = s->conv_lo; i < s->conv_hi; i++)
+            if (s->conv[i].frame_number == s->f1.frame_number) { if (s->vl_n < s->vl_cap) sub_to_vis_rec(&s->conv[i], &s->vl[s->vl_n]); s->vl_n++; }
     p16_frasm *f = &s->f1;
     p16_di d = { !s->ignore_crc, s->st.p_correction != 0, s->ignore_crc, format == SDV_P16_FORMAT_EI };
     uint16_t frame_lim = d.ei_format ? EI_TRUE * 3 : SI_TRUE, interleave_lim = d.ei_format ? EI_OFS : SI_OFS, valid_cnt = 0;
@@ -1185,6 +1219,7 @@ static void stitch_frame(p16_stitcher *s, const sdv_pcm16x0_bin_rec *recs, size_
         f->odd_data_lines /= 3; f->even_data_lines /= 3; f->odd_valid_lines /= 3; f->even_valid_lines /= 3;
         f->odd_std_lines = f->even_std_lines = LINES_PF;
         out_frasm(s, f);
+        vis_end_frame(s, frame);
     } else {
         out_service(s, SDV_PAIR_SRV_END_FILE);
         reset_state(s);
@@ -1208,8 +1243,14 @@ long orc_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, cons
 long orc_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                 sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks)
 {
+    return orc_pcm16x0_stitch_run_feeds(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, blocks, blocks_cap, n_blocks, NULL, 0, NULL);
+}
+long orc_pcm16x0_stitch_run_feeds(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                  sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                                  sdv_pcm16x0_bin_rec *lines, size_t lines_cap, size_t *n_lines)
+{
     p16_stitcher *s = (p16_stitcher *)calloc(1, sizeof(p16_stitcher));
-    s->vb = blocks; s->vb_cap = blocks_cap;
+    s->vb = blocks; s->vb_cap = blocks_cap; s->vl = lines; s->vl_cap = lines_cap;
     s->st = *st; s->ignore_crc = !st->use_ecc;
     s->out = out; s->out_cap = out_cap; s->frames = frames; s->frames_cap = frames_cap;
     s->trim = (p16_sub *)malloc(BUF_TRIM * sizeof(p16_sub));
@@ -1224,6 +1265,7 @@ long orc_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, 
     long n = s->out_n > out_cap ? -1 : (long)s->out_n;
     if (n_frames) *n_frames = s->frames_n;
     if (n_blocks) *n_blocks = s->vb_n;
+    if (n_lines) *n_lines = s->vl_n;
     free(s->trim); free(s->pq.buf); free(s->conv); free(s);
     return n;
 }

@@ -27,6 +27,11 @@ long orc_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, cons
 /* ... with the visualiser's feed: the blocks outputDataBlock hands to newBlockProcessed, next to the pairs */
 long orc_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                 sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks);
+/* ... and with the assembled sub-lines performDeinterleave hands to newLineProcessed (:5196-5213), as records of the binarizer's type, an END_FRAME
+ * record behind every frame's (sdv_set_pcm16x0_stitch_line_output in include/sdvpcm.h) */
+long orc_pcm16x0_stitch_run_feeds(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                  sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                                  sdv_pcm16x0_bin_rec *lines, size_t lines_cap, size_t *n_lines);
 #ifdef __cplusplus
 }
 #endif

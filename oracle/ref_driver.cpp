@@ -912,6 +912,13 @@ static void rec_to_p16_line(const sdv_pcm16x0_bin_rec &r, PCM16X0SubLine &l)
     l.control_bit = r.control_bit != 0; l.line_part = r.line_part; l.queue_order = r.queue_order;
     l.setBWLevelsState((r.flags & SDV_LF_BW_SET) != 0);
     if (r.flags & SDV_LF_FORCED_BAD) l.setForcedBad();
+    /* what the stitcher does not look at but hands on to the visualiser with the sub-line (newLineProcessed): the rest of the binarizer's findings */
+    l.black_level = r.black_level; l.white_level = r.white_level; l.ref_low = r.ref_low; l.ref_high = r.ref_high;
+    l.hysteresis_depth = r.hysteresis_depth; l.shift_stage = r.shift_stage;
+    l.setDataCoordinatesState((r.flags & SDV_LF_COORDS_SET) != 0);
+    l.setSweepedReference((r.flags & SDV_LF_REF_SWEEPED) != 0); l.setSweepedCoordinates((r.flags & SDV_LF_COORDS_SWEEPED) != 0);
+    l.data_by_ext_tune = (r.flags & SDV_LF_BY_EXT_TUNE) != 0;
+    l.setFromDoubledState((r.flags & SDV_LF_FROM_DOUBLED) != 0);
 }
 
 extern "C" void ref_pcm16x0_deint_blocks(const sdv_pcm16x0_bin_rec *lines, size_t n_lines, int ei_format, int force_check, int p_code, int ignore_crc,
@@ -981,7 +988,7 @@ static void pcm16_block_to_rec(PCM16X0DataBlock &b, sdv_pcm16x0_block_rec *o)
     o->sample_rate = b.sample_rate;
 }
 /* hooks of the run for the visualiser's feed: every block the stitcher emits with newBlockProcessed, every frame it reports (no file tag) */
-struct ref_p16_hooks { std::function<void(PCM16X0DataBlock &)> on_block; std::function<void(uint32_t)> on_frame; };
+struct ref_p16_hooks { std::function<void(PCM16X0DataBlock &)> on_block; std::function<void(uint32_t)> on_frame; std::function<void(PCM16X0SubLine &)> on_line; };
 long ref_pcm16x0_stitch_run_hooks(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                   sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, ref_p16_hooks *hooks);
 extern "C" long ref_pcm16x0_stitch_run(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
@@ -999,11 +1006,35 @@ extern "C" long ref_pcm16x0_stitch_run_vis(const sdv_pcm16x0_bin_rec *recs, size
     if (n_blocks) *n_blocks = seen;
     return n;
 }
+/* ... with the assembled sub-lines newLineProcessed hands over (pcm16x0datastitcher.cpp:5203) as records, an END_FRAME record where MainWindow would emit
+ * newFrameAssembled (mainwindow.cpp:3956): what sdv_set_pcm16x0_stitch_line_output writes */
+extern "C" long ref_pcm16x0_stitch_run_feeds(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
+                                             sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, sdv_pcm16x0_block_rec *blocks, size_t blocks_cap, size_t *n_blocks,
+                                             sdv_pcm16x0_bin_rec *lines, size_t lines_cap, size_t *n_lines)
+{
+    size_t seen = 0, lseen = 0;
+    ref_p16_hooks h;
+    h.on_block = [&](PCM16X0DataBlock &b) { if (blocks && seen < blocks_cap) pcm16_block_to_rec(b, &blocks[seen]); seen++; };
+    h.on_line = [&](PCM16X0SubLine &l) { if (lines && lseen < lines_cap) p16_line_to_rec(l, &lines[lseen]); lseen++; };
+    h.on_frame = [&](uint32_t frame) {
+        if (lines && lseen < lines_cap) {
+            sdv_pcm16x0_bin_rec *r = &lines[lseen];
+            memset(r, 0, sizeof(*r));
+            r->frame_number = frame; r->words[3] = (uint16_t)~0x0E10; r->data_start = -32768; r->data_stop = 32767; r->control_bit = 1; r->service_type = SDV_SRV_END_FRAME;
+        }
+        lseen++;
+    };
+    const long n = ref_pcm16x0_stitch_run_hooks(recs, n_recs, st, out, out_cap, frames, frames_cap, n_frames, &h);
+    if (n_blocks) *n_blocks = seen;
+    if (n_lines) *n_lines = lseen;
+    return n;
+}
 long ref_pcm16x0_stitch_run_hooks(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                   sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, ref_p16_hooks *hooks)
 {
     PCM16X0DataStitcher *ds = new PCM16X0DataStitcher();
     if (hooks && hooks->on_block) QObject::connect(ds, &PCM16X0DataStitcher::newBlockProcessed, [hooks](PCM16X0DataBlock b) { hooks->on_block(b); });
+    if (hooks && hooks->on_line) QObject::connect(ds, &PCM16X0DataStitcher::newLineProcessed, [hooks](PCM16X0SubLine l) { hooks->on_line(l); });
     if (hooks && hooks->on_frame) QObject::connect(ds, &PCM16X0DataStitcher::guiUpdFrameAsm, [hooks](FrameAsmPCM16x0 d) { if (!d.isServNewFile() && !d.isServEndFile()) hooks->on_frame(d.frame_number); });
     std::deque<PCM16X0SubLine> in_q;
     std::deque<PCMSamplePair> out_q;

@@ -260,7 +260,7 @@ extern "C" long ref_vis_render_asm_lines(int kind, const sdv_asm_line_rec *lines
  * markAsUnsafe only), so the canvases are made where the objects are. */
 #include <functional>
 #include "pcm16x0datastitcher.h"
-struct ref_p16_hooks { std::function<void(PCM16X0DataBlock &)> on_block; std::function<void(uint32_t)> on_frame; };
+struct ref_p16_hooks { std::function<void(PCM16X0DataBlock &)> on_block; std::function<void(uint32_t)> on_frame; std::function<void(PCM16X0SubLine &)> on_line; };
 long ref_pcm16x0_stitch_run_hooks(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st, sdv_sample_pair *out, size_t out_cap,
                                   sdv_frame_asm_pcm16x0 *frames, size_t frames_cap, size_t *n_frames, ref_p16_hooks *hooks);
 extern "C" long ref_vis_pcm16x0_stitch_block_canvases(const sdv_pcm16x0_bin_rec *recs, size_t n_recs, const sdv_pcm16x0_stitch_settings *st,

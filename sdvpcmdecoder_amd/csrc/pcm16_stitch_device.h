@@ -60,8 +60,8 @@ enum { SF_CRC = 1,          /* isCRCValid() (the stitcher's own "forced bad" mar
        SF_SKIP = 128 };     /* a service line other than a filler */
 struct Sub { uint16_t w[3]; uint16_t line; uint8_t fl, part, ref, pickl; };       /* part: line_part, bit 7 set on a filler */
 static_assert(sizeof(Sub) == 12, "sub-line layout");
-enum { PART_FILLER = 0x80 };
-__device__ inline uint32_t sub_part(const Sub &s) { return s.part & 0x7Fu; }
+enum { PART_FILLER = 0x80, PART_FORCED = 0x40 /* setForcedBad() by prescanForFalsePosCRCs: only the assembled-lines feed asks */ };
+__device__ inline uint32_t sub_part(const Sub &s) { return s.part & 0x3Fu; }
 __device__ inline Sub sub_empty()       /* a cleared PCM16X0SubLine (pcm16x0subline.cpp:63-86): silent words, CRC off, Control Bit set */
 {
     Sub s; s.w[0] = s.w[1] = s.w[2] = 0; s.line = 0; s.fl = SF_CTRL; s.part = 0; s.ref = 0; s.pickl = 0; return s;
@@ -415,6 +415,9 @@ struct FrameArgs16s {
     uint32_t *stat;             /* [0] = OR of FE_*, [1] = first frame index with an error, [2] = file tags seen */
     /* the visualiser's feed (sdv_set_pcm16x0_stitch_block_output): the blocks next to the pairs; vblk_ofs like frasm_ofs, in blocks */
     uint32_t *vblk_ofs; sdv_pcm16x0_block_rec *out_blocks; uint64_t blocks_cap;
+    /* ... and the assembled sub-lines (sdv_set_pcm16x0_stitch_line_output): records per frame, an END_FRAME record behind them; field_src: the record
+     * every place of the field buffers was made from ([frame][2][735] like `fields`) */
+    uint32_t *vline_ofs; sdv_pcm16x0_bin_rec *out_lines; uint64_t lines_cap; uint32_t *field_src;
 };
 
 #ifndef SDV_P16_LDS_SUBS
@@ -721,6 +724,7 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
             const uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
             const bool take = in[p] && rank < SUBLINES_PF;
             if (take) { fout[p * SUBLINES_PF + rank] = sl; refs_all[p] += ref; if (ok) refs_ok[p] += ref; }     /* the field buffers (global: K-B' .. K-E read them) */
+            if (take && a.field_src) a.field_src[(size_t)kb * (2 * SUBLINES_PF) + p * SUBLINES_PF + rank] = lo + i;
             valid[p] += (uint32_t)__popcll(__ballot(take && ok));
             cnt[p] += (uint32_t)__popcll(m);
         }
@@ -761,8 +765,9 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
                 const bool c0 = (s0.fl & SF_CRC) != 0, c1 = (s1.fl & SF_CRC) != 0, c2 = (s2.fl & SF_CRC) != 0;
                 if ((c0 && !c1 && !c2 && s0.pickl != 0) || (!c0 && !c1 && c2 && (s2.fl & SF_PICKR))) {
                     s0.fl &= (uint8_t)~SF_CRC; s1.fl &= (uint8_t)~SF_CRC; s2.fl &= (uint8_t)~SF_CRC;
+                    s0.part |= PART_FORCED; s1.part |= PART_FORCED; s2.part |= PART_FORCED;
                     Sub *g = fout + p * SUBLINES_PF + 3 * t;
-                    g[0].fl = s0.fl; g[1].fl = s1.fl; g[2].fl = s2.fl;
+                    g[0].fl = s0.fl; g[1].fl = s1.fl; g[2].fl = s2.fl; g[0].part = s0.part; g[1].part = s1.part; g[2].part = s2.part;
                 }
             }
         }
@@ -1443,6 +1448,7 @@ __device__ inline void carry_body(const FrameArgs16s &a, int lane)
     uint32_t R = a.state->rem_n;
     uint64_t pbase = a.pair_ofs[a.seg_base]; uint32_t fbase = a.frasm_ofs[a.seg_base];
     uint32_t bbase = a.vblk_ofs ? a.vblk_ofs[a.seg_base] : 0u;
+    uint32_t lbase = a.vline_ofs ? a.vline_ofs[a.seg_base] : 0u;
     for (uint32_t c0 = 0; c0 < a.n_batch; c0 += 64) {
         const uint32_t kb = c0 + (uint32_t)lane; const bool act = kb < a.n_batch;
         const uint32_t marks = act ? a.ana[kb].marks : 0u, S = act ? a.dec[kb].total : 0u;      /* the tags that carry the frame's own number: what its trim search saw (:300-330) */
@@ -1459,30 +1465,110 @@ __device__ inline void carry_body(const FrameArgs16s &a, int lane)
         const uint32_t n_it = endf ? 0u : (r_in + S) / lim;
         const uint32_t pairs = !act ? 0u : (endf ? 1u : 3u * blk_it * n_it + (newf ? 1u : 0u)), frasm = !act ? 0u : (endf ? 1u : 1u + (newf ? 1u : 0u));
         const uint32_t vblocks = (!act || endf) ? 0u : blk_it * n_it;
-        uint64_t ps = pairs; uint32_t fs = frasm, bs = vblocks;
+        const uint32_t vlines = (!act || endf) ? 0u : S + 1u;          /* what the frame queues and the END_FRAME record behind it */
+        uint64_t ps = pairs; uint32_t fs = frasm, bs = vblocks, ls = vlines;
         for (int d = 1; d < 64; d <<= 1) {
             const int src = lane >= d ? lane - d : lane;
             const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)ps, src), hi = (uint32_t)__shfl((int)(uint32_t)(ps >> 32), src), of = (uint32_t)__shfl((int)fs, src);
-            const uint32_t ob = (uint32_t)__shfl((int)bs, src);
-            if (lane >= d) { ps += ((uint64_t)hi << 32) | lo; fs += of; bs += ob; }
+            const uint32_t ob = (uint32_t)__shfl((int)bs, src), ol = (uint32_t)__shfl((int)ls, src);
+            if (lane >= d) { ps += ((uint64_t)hi << 32) | lo; fs += of; bs += ob; ls += ol; }
         }
         if (act) {
             a.dec[kb].rem_in = (uint16_t)r_in; a.dec[kb].n_it = (uint16_t)n_it;
             a.pair_ofs[a.seg_base + kb] = pbase + ps - pairs; a.frasm_ofs[a.seg_base + kb] = fbase + fs - frasm;
             if (a.vblk_ofs) a.vblk_ofs[a.seg_base + kb] = bbase + bs - vblocks;
+            if (a.vline_ofs) a.vline_ofs[a.seg_base + kb] = lbase + ls - vlines;
         }
         const uint32_t last = (a.n_batch - c0 < 64u ? a.n_batch - c0 : 64u) - 1u;
         R = (uint32_t)__shfl((int)r_out, (int)last);
         pbase += ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(ps >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)ps, 63);
         fbase += (uint32_t)__shfl((int)fs, 63);
         bbase += (uint32_t)__shfl((int)bs, 63);
+        lbase += (uint32_t)__shfl((int)ls, 63);
     }
-    if (lane == 0) { a.pair_ofs[a.seg_base + a.n_batch] = pbase; a.frasm_ofs[a.seg_base + a.n_batch] = fbase; a.state->rem_n = R; if (a.vblk_ofs) a.vblk_ofs[a.seg_base + a.n_batch] = bbase; }
+    if (lane == 0) { a.pair_ofs[a.seg_base + a.n_batch] = pbase; a.frasm_ofs[a.seg_base + a.n_batch] = fbase; a.state->rem_n = R; if (a.vblk_ofs) a.vblk_ofs[a.seg_base + a.n_batch] = bbase; if (a.vline_ofs) a.vline_ofs[a.seg_base + a.n_batch] = lbase; }
     if (R != 0) {               /* the batch's last frame leaves sub-lines behind: a copy for the frame that follows it (next batch or next call) */
         const uint32_t kb = a.n_batch - 1;
         const Dec16 d = a.dec[kb];
         const Sub *fields = a.fields + (size_t)kb * (2 * SUBLINES_PF);
         for (uint32_t i = (uint32_t)lane; i < R; i += 64) a.rem_out[i] = conv_at(d, fields, d.total - R + i);
+    }
+}
+
+/* ---- the assembled sub-lines for the visualiser: what performDeinterleave hands to newLineProcessed (:5196-5213) -------------------------------
+ * The sub-lines fillFrameForOutput queued for the frame (:4594-4690) as records of the binarizer's own type, so that the lines window draws them
+ * (RenderPCM::renderNewLine(PCM16X0SubLine) is the renderer of both windows): a line of a field buffer is its source record with the queue order
+ * addLinesFromField gave it (:4470) and the stitcher's forced-bad mark (:800-820); a padding line is a cleared sub-line with the frame's number,
+ * the line number addFieldPadding counted to (:4552-4556: on from the last PART_RIGHT sub-line copied, or from 1 / 2) and its part. */
+__device__ inline sdv_pcm16x0_bin_rec asm_blank_rec(uint32_t frame, uint16_t line)
+{
+    sdv_pcm16x0_bin_rec r;
+    r.frame_number = frame; r.line_number = line;
+    r.words[0] = r.words[1] = r.words[2] = 0; r.words[3] = (uint16_t)~0x0E10; r.calc_crc = 0x0E10;       /* PCM16X0SubLine::clear: silent words, the CRC of silence inverted */
+    r.data_start = -32768; r.data_stop = 32767; r.queue_order = 0;
+    r.black_level = r.white_level = r.ref_low = r.ref_level = r.ref_high = 0; r.hysteresis_depth = r.shift_stage = 0;
+    r.service_type = SDV_SRV_NO; r.picked_bits_left = r.picked_bits_right = 0; r.flags = 0; r.line_part = 0; r.control_bit = 1; r._pad = 0;
+    return r;
+}
+__device__ inline void emit_lines_body(const FrameArgs16s &a, uint32_t kb, int lane)
+{
+    if (!a.out_lines) return;
+    const Dec16 d = a.dec[kb];
+    const Ana16 *an = &a.ana[kb];
+    if (an->marks & FF_END_FILE) return;            /* queues nothing */
+    const uint32_t frame = an->frame;
+    const uint64_t base = a.vline_ofs[a.seg_base + kb];
+    const Sub *fields = a.fields + (size_t)kb * (2 * SUBLINES_PF);
+    const uint32_t *fsrc = a.field_src + (size_t)kb * (2 * SUBLINES_PF);
+    const int p_first = d.field_order == ORDER_BFF ? 1 : 0;
+    uint32_t at = 0;
+    for (int f = 0; f < 2; f++) {
+        const int p = f == 0 ? p_first : 1 - p_first;
+        const uint32_t n_top = 3u * d.top_pad[p], n_data = d.data[p] <= SUBLINES_PF ? d.data[p] : 0u, n_bot = 3u * ((uint32_t)d.bot_pad[p] + d.extra[p]);
+        uint32_t last_line = (d.field_order == ORDER_TFF) == (f == 0) ? 1u : 2u;       /* getFirstFieldLineNum / getSecondFieldLineNum */
+        for (uint32_t i = (uint32_t)lane; i < n_top; i += 64) {
+            sdv_pcm16x0_bin_rec r = asm_blank_rec(frame, (uint16_t)(last_line + 2u * (i / 3u)));
+            r.line_part = (uint8_t)(i % 3u); r.queue_order = (uint16_t)(1u + i);
+            if (base + at + i < a.lines_cap) a.out_lines[base + at + i] = r;
+        }
+        last_line += 2u * d.top_pad[p]; at += n_top;
+        /* the data: source records; the last PART_RIGHT one says where the numbering goes on */
+        uint32_t right_at = 0xFFFFFFFFu;
+        for (uint32_t c = 0; c < n_data; c += 64) {
+            const uint32_t i = c + (uint32_t)lane;
+            bool right = false;
+            if (i < n_data) {
+                const uint32_t u = i + d.cut[p];
+                if (u < SUBLINES_PF) {
+                    const Sub sb = fields[p * SUBLINES_PF + u];
+                    sdv_pcm16x0_bin_rec r = a.src.at(fsrc[p * SUBLINES_PF + u]);
+                    r.queue_order = (uint16_t)(1u + n_top + i);
+                    if (sb.part & PART_FORCED) r.flags |= SDV_LF_FORCED_BAD;
+                    const bool crc_now = r.service_type == SDV_SRV_NO && !(r.flags & SDV_LF_FORCED_BAD) && r.calc_crc == r.words[3];      /* isCRCValid() as it stands now */
+                    r.flags = (uint8_t)((r.flags & ~SDV_LF_CRC_VALID) | (crc_now ? SDV_LF_CRC_VALID : 0));
+                    right = r.line_part == 2;
+                    if (base + at + i < a.lines_cap) a.out_lines[base + at + i] = r;
+                } else {                /* (conv_at's answer past the buffer: a cleared sub-line) */
+                    sdv_pcm16x0_bin_rec r = asm_blank_rec(0, 0); r.queue_order = (uint16_t)(1u + n_top + i);
+                    if (base + at + i < a.lines_cap) a.out_lines[base + at + i] = r;
+                }
+            }
+            const uint64_t m = __ballot(right);
+            if (m) right_at = c + 63u - (uint32_t)__clzll((unsigned long long)m);
+        }
+        if (right_at != 0xFFFFFFFFu) last_line = (uint32_t)a.src.at(fsrc[p * SUBLINES_PF + right_at + d.cut[p]]).line_number + 2u;
+        at += n_data;
+        for (uint32_t i = (uint32_t)lane; i < n_bot; i += 64) {
+            sdv_pcm16x0_bin_rec r = asm_blank_rec(frame, (uint16_t)(last_line + 2u * (i / 3u)));
+            r.line_part = (uint8_t)(i % 3u); r.queue_order = (uint16_t)(1u + n_top + n_data + i);
+            if (base + at + i < a.lines_cap) a.out_lines[base + at + i] = r;
+        }
+        at += n_bot;
+    }
+    if (lane == 0) {
+        sdv_pcm16x0_bin_rec r = asm_blank_rec(frame, 0);
+        r.calc_crc = 0; r.service_type = SDV_SRV_END_FRAME;       /* a service line: PCMLine::setServiceLine on a cleared sub-line */
+        if (base + at < a.lines_cap) a.out_lines[base + at] = r;
     }
 }
 
@@ -1736,4 +1822,5 @@ __global__ void __launch_bounds__(64) sdv_k_pcm16_flags(sdvp16::FrameArgs16s a)
     sdvp16::flags_body(a, (int)threadIdx.x, lds);
 }
 __global__ void __launch_bounds__(64) sdv_k_pcm16_emit(sdvp16::FrameArgs16s a) { sdvp16::emit_body(a, blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) sdv_k_pcm16_emit_lines(sdvp16::FrameArgs16s a) { sdvp16::emit_lines_body(a, blockIdx.x, (int)threadIdx.x); }
 #endif

@@ -138,9 +138,9 @@ def load_library(path: str | None = None):
     lib.sdv_set_stitch_block_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.sdv_stitch_block_count.restype = C.c_size_t
     lib.sdv_stitch_block_count.argtypes = [C.c_void_p]
-    for nm in ("sdv_set_pcm1_stitch_block_output", "sdv_set_pcm1_stitch_line_output", "sdv_set_pcm16x0_stitch_block_output"):
+    for nm in ("sdv_set_pcm1_stitch_block_output", "sdv_set_pcm1_stitch_line_output", "sdv_set_pcm16x0_stitch_block_output", "sdv_set_pcm16x0_stitch_line_output"):
         getattr(lib, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-    for nm in ("sdv_pcm1_stitch_block_count", "sdv_pcm1_stitch_line_count", "sdv_pcm16x0_stitch_block_count"):
+    for nm in ("sdv_pcm1_stitch_block_count", "sdv_pcm1_stitch_line_count", "sdv_pcm16x0_stitch_block_count", "sdv_pcm16x0_stitch_line_count"):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = [C.c_void_p]
     lib.sdv_set_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -584,6 +584,20 @@ class Engine:
 
     def pcm16x0_stitch_block_count(self) -> int:
         return int(self.lib.sdv_pcm16x0_stitch_block_count(self._h))
+
+    def set_pcm16x0_stitch_line_output(self, lines):
+        """sdv_set_pcm16x0_stitch_line_output: `lines` = (cap, 36) uint8 CUDA tensor the following pcm16x0_stitch_frames calls fill with the assembled
+        sub-lines of their frames as sdv_pcm16x0_bin_rec, an END_FRAME record behind every frame's (None: off) - what vis_render_lines(PCM16X0_LINES)
+        draws as the reference's re-assembled window.  The tensor must stay alive while it is set."""
+        self._p16_line_out = lines
+        if lines is None:
+            self._check(self.lib.sdv_set_pcm16x0_stitch_line_output(self._h, None, 0))
+        else:
+            assert lines.is_cuda and lines.is_contiguous() and lines.shape[1] == 36
+            self._check(self.lib.sdv_set_pcm16x0_stitch_line_output(self._h, C.c_void_p(lines.data_ptr()), lines.shape[0]))
+
+    def pcm16x0_stitch_line_count(self) -> int:
+        return int(self.lib.sdv_pcm16x0_stitch_line_count(self._h))
 
     def pcm1_bin_to_line_recs(self, bin_recs, out=None, stream=None):
         """The records pcm1_binarize_frames returns ((n, 40) sdv_pcm1_bin_rec) as the records pcm1_stitch_frames takes ((n, 32) sdv_pcm1_line_rec)."""

@@ -133,6 +133,21 @@ def emu_pcm16_stitch_vis(lib, eng, recs, settings=None, block_cap=None):
     return rc, pairs, frames, bl[:min(nb, len(bl))].copy()
 
 
+def emu_pcm16_stitch_lines(lib, eng, recs, settings=None, line_cap=None):
+    """... with the assembled sub-lines switched on (sdv_set_pcm16x0_stitch_line_output): (rc, pairs, frames, lines)."""
+    lib.sdv_set_pcm16x0_stitch_line_output.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.sdv_pcm16x0_stitch_line_count.restype = C.c_size_t
+    lib.sdv_pcm16x0_stitch_line_count.argtypes = [C.c_void_p]
+    nfr = int((recs["service_type"] == 5).sum()) + 2
+    ln = np.zeros(line_cap if line_cap is not None else nfr * 3000 + 16, dtype=recs.dtype)
+    assert lib.sdv_set_pcm16x0_stitch_line_output(eng, ln.ctypes.data, len(ln)) == 0
+    rc, pairs, frames = emu_pcm16_stitch(lib, eng, recs, settings)
+    nl = lib.sdv_pcm16x0_stitch_line_count(eng)
+    emu_pcm16_stitch_lines.last_count = nl
+    assert lib.sdv_set_pcm16x0_stitch_line_output(eng, None, 0) == 0
+    return rc, pairs, frames, ln[:min(nl, len(ln))].copy()
+
+
 def emu_pcm16_stitch(lib, eng, recs, settings=None, pair_cap=None, frame_cap=None):
     """Host-memory call (emulator build only): one sdv_pcm16x0_stitch_frames call over `recs`."""
     import pcm16_api as p16

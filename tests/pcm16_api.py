@@ -190,6 +190,25 @@ def run_cpu_vis(lib, prefix, recs, st):
     return pairs[:n], frames[:nf.value], blocks[:nb.value]
 
 
+def run_cpu_feeds(lib, prefix, recs, st):
+    """(pairs, frames, blocks, lines): ... and with the assembled sub-lines (sdv_set_pcm16x0_stitch_line_output): records of the input's own type."""
+    f = getattr(lib, prefix + "pcm16x0_stitch_run_feeds")
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Pcm16Settings), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                  C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    recs = np.ascontiguousarray(recs)
+    nfr = int((recs["service_type"] == SRV_END_FRAME).sum()) + 2
+    pairs = np.zeros(nfr * 2400 + 16, dtype=PAIR_DTYPE)
+    frames = np.zeros(nfr + 8, dtype=FRASM16_DTYPE)
+    blocks = np.zeros(nfr * 800 + 16, dtype=VBLOCK16_DTYPE)
+    lines = np.zeros(nfr * 3000 + 16, dtype=recs.dtype)
+    nf, nb, nl = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    n = f(recs.ctypes.data, len(recs), C.byref(st), pairs.ctypes.data, len(pairs), frames.ctypes.data, len(frames), C.byref(nf),
+          blocks.ctypes.data, len(blocks), C.byref(nb), lines.ctypes.data, len(lines), C.byref(nl))
+    assert n >= 0 and nb.value <= len(blocks) and nl.value <= len(lines)
+    return pairs[:n], frames[:nf.value], blocks[:nb.value], lines[:nl.value]
+
+
 def run_blocks(lib, prefix, recs, n_blocks, ei=False, force=True, p_code=True, ignore_crc=False, first_shift=0, first_even=False):
     f = getattr(lib, prefix + "pcm16x0_deint_blocks")
     f.restype = None

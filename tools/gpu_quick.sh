@@ -1,5 +1,5 @@
-# quick check of a change in the damaged-tape path: parity of the frame kernels, the two damaged tapes
+# quick GPU check of what was touched last:  gpurun -- 'bash tools/gpu_quick.sh'
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
-timeout 300 python tools/pal_trace.py 2000 both 2>&1 | tail -4
-timeout 300 python tools/jump_probe.py 10000 16 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_pcm16_asm.py tests/test_pcm16_vis.py tests/test_pcm16.py tests/test_stitch_kernel.py tests/test_decode_frames.py -m gpu -x -q 2>&1 | tail -3
+timeout 300 python tools/pcm16_prof.py 10000 3 2>&1 | tail -4
+timeout 300 python tools/fused_prof.py 2>&1 | tail -3
