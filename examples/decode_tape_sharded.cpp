@@ -10,9 +10,11 @@
  *   0. rank 0 decodes the first frames of its range and publishes its state (the binarizer's sticky levels), the others start their warm-up from it;
  *   1. rank r > 0 decodes a short warm-up just before its range and keeps the state it ends in - its prediction of what rank
  *      r - 1 will hand over;
- *   2. every rank decodes its range from that state, then all ranks all-gather their final states;
- *   3. a rank whose prediction differs from what its predecessor really ended in decodes its range again from the true state; repeated until every
- *      rank started from exactly its predecessor's final state.  The result is the sequential decode of the whole tape, whatever the guesses were.
+ *   2. every rank decodes its range from that state and runs the stitcher over the records straight away (warmed up the same way), then ONE all-gather
+ *      carries what both workers assumed and what they ended in, so that every rank knows every rank's verdict;
+ *   3. a rank whose prediction differs from what its predecessor really ended in decodes (or stitches) its range again from the true state; repeated
+ *      until every rank started from exactly its predecessor's final state.  The result is the sequential decode of the whole tape, whatever the
+ *      guesses were.  A tape that plays takes two all-gathers (step 0 and step 2).
  *
  *   RANK=r WORLD_SIZE=n [LOCAL_RANK=d] decode_tape_sharded <luma.raw> <width> <height> <n_frames> <out prefix> [rccl | file:<dir>] [warm-up frames [stitcher warm-up turns]]
  *       writes <out prefix>.rank<r>.pairs / .frames: the PCMSamplePair records and FrameAsmSTC007 descriptors of this rank's frames; concatenated in
@@ -166,16 +168,6 @@ struct FileComm : Comm {
     }
 };
 
-/* every rank reached the same verdict?  (one more tiny gather: a rank that has to decode again keeps everybody in the loop) */
-static bool all_ok(Comm &c, bool ok)
-{
-    std::vector<uint8_t> all((size_t)c.world);
-    const uint8_t mine = ok ? 1 : 0;
-    c.all_gather(&mine, all.data(), 1);
-    for (uint8_t v : all) if (!v) return false;
-    return true;
-}
-
 static bool write_file(const std::string &path, const void *p, size_t n)
 {
     FILE *f = fopen(path.c_str(), "wb");
@@ -272,58 +264,71 @@ int main(int argc, char **argv)
                                          d_whole + n_own_recs, n_extra, d_stats, n_in + 2, NULL));
     };
     run_range();
-    std::vector<sdv_v2d_state> finals((size_t)world);
-    for (;;) {
-        comm->all_gather(&fin, finals.data(), sizeof(sdv_v2d_state));
-        gathers++;
-        const bool ok = rank == 0 || memcmp(&predicted, &finals[(size_t)rank - 1], sizeof(predicted)) == 0;
-        if (all_ok(*comm, ok)) break;
-        if (!ok) {
-            binarize_redo++;
-            predicted = finals[(size_t)rank - 1];
-            SDV_OKAY(sdv_set_chain_state(eng, &predicted));
-            run_range();
-        }
-    }
 
-    /* ---- stitch stage (the STC007DataStitcher worker) ----------------------------------------------------------------------------------------- */
+    /* ---- stitch stage (the STC007DataStitcher worker), and one all-gather for both ------------------------------------------------------------
+     * The stitcher runs on the records straight away, before anybody knows whether the range was decoded from the right state: on a tape that plays it
+     * was, and then one all-gather carries what both stages assumed and what they ended with - every rank works out every rank's verdict from it, no
+     * second gather to agree on going on.  A rank whose binarizer guess was wrong decodes its range again and stitches it afresh; one whose stitcher
+     * guess alone was wrong feeds its records again from the true state. */
     const size_t n_whole = n_own_recs + n_extra;
     const size_t pairs_cap = n_whole * 4 + 8192, frames_cap = (size_t)n_own + 16, state_n = sdv_stitch_state_size();
     sdv_sample_pair *d_pairs = (sdv_sample_pair *)dev_alloc(pairs_cap * sizeof(sdv_sample_pair));
     sdv_frame_asm *d_frames = (sdv_frame_asm *)dev_alloc(frames_cap * sizeof(sdv_frame_asm));
     sdv_stitch_settings st; sdv_default_stitch_settings(&st);
     SDV_OKAY(sdv_set_stitch_settings(eng, &st));
-    SDV_OKAY(sdv_reset_stitcher(eng));
-    std::vector<uint8_t> s_pred(state_n, 0), s_final(state_n, 0), s_all(state_n * (size_t)world);
+    const size_t nb = sizeof(sdv_v2d_state), blob_n = 2 * nb + 2 * state_n;
+    std::vector<uint8_t> s_pred(state_n, 0), s_final(state_n, 0), blob(blob_n), blobs(blob_n * (size_t)world);
     size_t n_pairs = 0, n_fr = 0;
     const int s_lead = stitch_warmup < lead ? stitch_warmup : lead;
-    if (s_lead) {
-        /* warm-up turns lo - s_lead .. lo - 1 (output discarded); frame lo then waits inside the engine for its successor */
-        const size_t n_cat = (size_t)(s_lead + 1) * rpf;
-        sdv_line_rec *d_cat = (sdv_line_rec *)dev_alloc(n_cat * sizeof(sdv_line_rec));
-        d2d(d_cat, d_warm + (size_t)(lead - s_lead) * rpf, (size_t)s_lead * rpf * sizeof(sdv_line_rec));
-        d2d(d_cat + (size_t)s_lead * rpf, d_whole, rpf * sizeof(sdv_line_rec));
-        size_t np = 0, nf = 0;
-        SDV_OKAY(sdv_stitch_frames(eng, d_cat, n_cat, d_pairs, pairs_cap, &np, d_frames, frames_cap, &nf, NULL));
-        SDV_OKAY(sdv_saturate_stitch_stats(eng));
-        SDV_OKAY(sdv_get_stitch_state(eng, s_pred.data(), state_n));
-        SDV_OKAY(sdv_stitch_frames(eng, d_whole + rpf, n_whole - rpf, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
-        dev_free(d_cat);
-    } else {
-        SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
-    }
-    SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
+    enum { M_NONE, M_FRESH, M_STATE } mode = M_FRESH;
     for (;;) {
-        comm->all_gather(s_final.data(), s_all.data(), state_n);
-        gathers++;
-        const bool ok = rank == 0 || memcmp(s_pred.data(), s_all.data() + (size_t)(rank - 1) * state_n, state_n) == 0;
-        if (all_ok(*comm, ok)) break;
-        if (!ok) {
-            stitch_redo++;
-            memcpy(s_pred.data(), s_all.data() + (size_t)(rank - 1) * state_n, state_n);
+        if (mode == M_FRESH) {
+            SDV_OKAY(sdv_reset_stitcher(eng));
+            std::fill(s_pred.begin(), s_pred.end(), 0);
+            if (s_lead) {
+                /* warm-up turns lo - s_lead .. lo - 1 (output discarded); frame lo then waits inside the engine for its successor */
+                const size_t n_cat = (size_t)(s_lead + 1) * rpf;
+                sdv_line_rec *d_cat = (sdv_line_rec *)dev_alloc(n_cat * sizeof(sdv_line_rec));
+                d2d(d_cat, d_warm + (size_t)(lead - s_lead) * rpf, (size_t)s_lead * rpf * sizeof(sdv_line_rec));
+                d2d(d_cat + (size_t)s_lead * rpf, d_whole, rpf * sizeof(sdv_line_rec));
+                size_t np = 0, nf = 0;
+                SDV_OKAY(sdv_stitch_frames(eng, d_cat, n_cat, d_pairs, pairs_cap, &np, d_frames, frames_cap, &nf, NULL));
+                SDV_OKAY(sdv_saturate_stitch_stats(eng));
+                SDV_OKAY(sdv_get_stitch_state(eng, s_pred.data(), state_n));
+                SDV_OKAY(sdv_stitch_frames(eng, d_whole + rpf, n_whole - rpf, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+                dev_free(d_cat);
+            } else {
+                SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+            }
+            SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
+        } else if (mode == M_STATE) {
             SDV_OKAY(sdv_set_stitch_state(eng, s_pred.data(), state_n));        /* drops the waiting frame: the whole range is fed again */
             SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
             SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
+        }
+        mode = M_NONE;
+        memcpy(blob.data(), &predicted, nb); memcpy(blob.data() + nb, &fin, nb);
+        memcpy(blob.data() + 2 * nb, s_pred.data(), state_n); memcpy(blob.data() + 2 * nb + state_n, s_final.data(), state_n);
+        comm->all_gather(blob.data(), blobs.data(), blob_n);
+        gathers++;
+        auto part = [&](int r, size_t ofs) { return blobs.data() + (size_t)r * blob_n + ofs; };
+        bool all_bin = true, all_st = true, my_bin = true, my_st = true;
+        for (int r = 1; r < world; r++) {
+            const bool b_ok = memcmp(part(r, 0), part(r - 1, nb), nb) == 0, t_ok = memcmp(part(r, 2 * nb), part(r - 1, 2 * nb + state_n), state_n) == 0;
+            all_bin = all_bin && b_ok; all_st = all_st && t_ok;
+            if (r == rank) { my_bin = b_ok; my_st = t_ok; }
+        }
+        if (all_bin && all_st) break;
+        if (!my_bin) {
+            binarize_redo++;
+            memcpy(&predicted, part(rank - 1, nb), nb);
+            SDV_OKAY(sdv_set_chain_state(eng, &predicted));
+            run_range();
+            mode = M_FRESH;
+        } else if (all_bin && !my_st) {         /* (while a binarizer still decodes again, the stitcher states behind it are not final) */
+            stitch_redo++;
+            memcpy(s_pred.data(), part(rank - 1, 2 * nb + state_n), state_n);
+            mode = M_STATE;
         }
     }
     dev_sync();

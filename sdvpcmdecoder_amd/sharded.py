@@ -92,45 +92,53 @@ class ShardedDecoder:
                 extra, _ = eng.binarize_frames(luma[lead + n_own:], first_frame_no=first_frame_no + hi, new_file=False)
             return own, extra, final
         own, extra, final = run_range()
-        while True:
-            finals = self.all_gather(final)
-            self.stats["gathers"] += 1
-            ok = rank == 0 or predicted == finals[rank - 1]
-            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
-                break
-            if not ok:
-                self.stats["binarize_redo"] += 1
-                predicted = finals[rank - 1]
-                eng.set_chain_state(predicted)
-                own, extra, final = run_range()
 
-        # ---- stitch stage --------------------------------------------------------------------------------------------
-        # own = [NEW_FILE record on rank 0] + frames lo..hi-1 [+ the end-of-file frame on the last rank]
-        whole = _cat(own, extra) if extra is not None else own
-        eng.reset_stitcher()
-        s_pred = None
+        # ---- stitch stage, and one all-gather for both ---------------------------------------------------------------
+        # The stitcher runs on the records straight away, before anybody knows whether the range was decoded from the right state: on a tape
+        # that plays it was, and then one all-gather carries what both stages assumed and what they ended with (every rank works out every
+        # rank's verdict from it: no second gather to agree on going on).  A rank whose binarizer guess was wrong decodes its range again and
+        # stitches it afresh; one whose stitcher guess alone was wrong feeds its records again from the true state.
         s_lead = min(self.stitch_warmup, lead)
-        if s_lead:
-            # warm-up turns lo-s_lead .. lo-1 (output discarded); frame lo then waits inside the engine for its successor
-            eng.stitch_frames(_cat(warm[(lead - s_lead) * rpf:], own[:rpf]))
-            eng.saturate_stitch_stats()
-            s_pred = eng.get_stitch_state()
-            pairs, frames = eng.stitch_frames(whole[rpf:])
-        else:
-            pairs, frames = eng.stitch_frames(whole)
-        s_final = eng.get_stitch_state()
+        mode, s_pred, s_final, pairs, frames, whole = "fresh", None, None, None, None, None
         while True:
-            finals = self.all_gather(s_final)
-            self.stats["gathers"] += 1
-            ok = rank == 0 or s_pred == finals[rank - 1]
-            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
-                break
-            if not ok:
-                self.stats["stitch_redo"] += 1
-                s_pred = finals[rank - 1]
+            if mode == "fresh":
+                # own = [NEW_FILE record on rank 0] + frames lo..hi-1 [+ the end-of-file frame on the last rank]
+                whole = _cat(own, extra) if extra is not None else own
+                eng.reset_stitcher()
+                s_pred = None
+                if s_lead:
+                    # warm-up turns lo-s_lead .. lo-1 (output discarded); frame lo then waits inside the engine for its successor
+                    eng.stitch_frames(_cat(warm[(lead - s_lead) * rpf:], own[:rpf]))
+                    eng.saturate_stitch_stats()
+                    s_pred = eng.get_stitch_state()
+                    pairs, frames = eng.stitch_frames(whole[rpf:])
+                else:
+                    pairs, frames = eng.stitch_frames(whole)
+                s_final = eng.get_stitch_state()
+            elif mode == "state":
                 eng.set_stitch_state(s_pred)                  # drops the waiting frame: the whole range is fed again
                 pairs, frames = eng.stitch_frames(whole)
                 s_final = eng.get_stitch_state()
+            mode = None
+            nb, ns = len(final), len(s_final)
+            blobs = self.all_gather((predicted or bytes(nb)) + final + (s_pred or bytes(ns)) + s_final)
+            self.stats["gathers"] += 1
+            b_pred = [b[:nb] for b in blobs]; b_fin = [b[nb:2 * nb] for b in blobs]
+            t_pred = [b[2 * nb:2 * nb + ns] for b in blobs]; t_fin = [b[2 * nb + ns:] for b in blobs]
+            bin_ok = [r == 0 or b_pred[r] == b_fin[r - 1] for r in range(world)]
+            st_ok = [r == 0 or t_pred[r] == t_fin[r - 1] for r in range(world)]
+            if all(bin_ok) and all(st_ok):
+                break
+            if not bin_ok[rank]:
+                self.stats["binarize_redo"] += 1
+                predicted = b_fin[rank - 1]
+                eng.set_chain_state(predicted)
+                own, extra, final = run_range()
+                mode = "fresh"
+            elif all(bin_ok) and not st_ok[rank]:       # (while a binarizer still decodes again, the stitcher states behind it are not final)
+                self.stats["stitch_redo"] += 1
+                s_pred = t_fin[rank - 1]
+                mode = "state"
         return pairs, frames
 
 
@@ -208,42 +216,48 @@ class ShardedPcmDecoder:
             own = self._binarize(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
             return own, self._chain()
         own, final = run_range()
+        # ---- stitch stage, and one all-gather for both (as ShardedDecoder) ---------------------------------------------
+        pcm1 = self.fmt == "pcm1"               # PCM-1: nothing is carried from frame to frame - the stitcher has no state to check
+        s_lead = 0 if pcm1 else min(self.stitch_warmup, lead)
+        mode, s_pred, s_final, pairs, frames = "fresh", None, b"", None, None
         while True:
-            finals = self.all_gather(final)
-            self.stats["gathers"] += 1
-            ok = rank == 0 or predicted == finals[rank - 1]
-            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
-                break
-            if not ok:
-                self.stats["binarize_redo"] += 1
-                predicted = finals[rank - 1]
-                self._chain(predicted)
-                own, final = run_range()
-        # ---- stitch stage ---------------------------------------------------------------------------------------------
-        if self.fmt == "pcm1":
-            eng.set_pcm1_stitch_settings(self.stitch_settings)
-            return self._stitch(own)              # nothing is carried from frame to frame
-        eng.set_pcm16x0_stitch_settings(self.stitch_settings)          # a fresh stitcher
-        s_pred = None
-        s_lead = min(self.stitch_warmup, lead)
-        if s_lead:
-            self._stitch(warm[(lead - s_lead) * rpf:])              # output discarded
-            eng.saturate_pcm16x0_stitch_stats()
-            s_pred = eng.get_pcm16x0_stitch_state()
-        pairs, frames = self._stitch(own)
-        s_final = eng.get_pcm16x0_stitch_state()
-        while True:
-            finals = self.all_gather(s_final)
-            self.stats["gathers"] += 1
-            ok = rank == 0 or s_pred == finals[rank - 1]
-            if all(o[0] for o in self.all_gather(bytes([1 if ok else 0]))):
-                break
-            if not ok:
-                self.stats["stitch_redo"] += 1
-                s_pred = finals[rank - 1]
+            if mode == "fresh":
+                if pcm1:
+                    eng.set_pcm1_stitch_settings(self.stitch_settings)
+                    pairs, frames = self._stitch(own)
+                else:
+                    eng.set_pcm16x0_stitch_settings(self.stitch_settings)          # a fresh stitcher
+                    s_pred = None
+                    if s_lead:
+                        self._stitch(warm[(lead - s_lead) * rpf:])              # output discarded
+                        eng.saturate_pcm16x0_stitch_stats()
+                        s_pred = eng.get_pcm16x0_stitch_state()
+                    pairs, frames = self._stitch(own)
+                    s_final = eng.get_pcm16x0_stitch_state()
+            elif mode == "state":
                 eng.set_pcm16x0_stitch_state(s_pred)
                 pairs, frames = self._stitch(own)
                 s_final = eng.get_pcm16x0_stitch_state()
+            mode = None
+            nb, ns = len(final), len(s_final)
+            blobs = self.all_gather((predicted or bytes(nb)) + final + (s_pred or bytes(ns)) + s_final)
+            self.stats["gathers"] += 1
+            b_pred = [b[:nb] for b in blobs]; b_fin = [b[nb:2 * nb] for b in blobs]
+            t_pred = [b[2 * nb:2 * nb + ns] for b in blobs]; t_fin = [b[2 * nb + ns:] for b in blobs]
+            bin_ok = [r == 0 or b_pred[r] == b_fin[r - 1] for r in range(world)]
+            st_ok = [r == 0 or t_pred[r] == t_fin[r - 1] for r in range(world)]
+            if all(bin_ok) and all(st_ok):
+                break
+            if not bin_ok[rank]:
+                self.stats["binarize_redo"] += 1
+                predicted = b_fin[rank - 1]
+                self._chain(predicted)
+                own, final = run_range()
+                mode = "fresh"
+            elif all(bin_ok) and not st_ok[rank]:
+                self.stats["stitch_redo"] += 1
+                s_pred = t_fin[rank - 1]
+                mode = "state"
         return pairs, frames
 
 

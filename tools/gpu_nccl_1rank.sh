@@ -1,7 +1,21 @@
 # exercises the RCCL (backend "nccl") plumbing of the sharded bench loop with the one GPU of the test box: one rank, real collectives
 cd $GRAFT_REPO_ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python -m pytest tests/test_sharded.py -m gpu -x -q 2>&1 | tail -2
 SDV_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu --no-stitch 2> gpurun_out/bench_nccl_1rank.err | tail -1 > gpurun_out/bench_nccl_1rank.json; echo "rc=$?"
-cut -c1-700 gpurun_out/bench_nccl_1rank.json; tail -5 gpurun_out/bench_nccl_1rank.err
-SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --frames 4000 --no-cpu 2> gpurun_out/bench_2rank.err | tail -1 | cut -c1-300; echo "2-rank gloo rc=$?"
-python bench.py --steps 3 --warmup 1 --no-cpu | cut -c1-200
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_nccl_1rank.json').read()); print({k:d.get(k) for k in ('value','ms_per_step')}, d.get('summary',{}).get('sharded_full_path_ms'))
+e=open('gpurun_out/bench_nccl_1rank.err').read().strip().split('\n')
+for l in e[::-1]:
+    if l.startswith('{'):
+        f=json.loads(l); print(json.dumps(f.get('sharded_full_path'))[:900]); break
+PY
+SDV_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --frames 4000 --no-cpu 2> gpurun_out/bench_2rank.err | tail -1 > gpurun_out/bench_2rank_gloo_one_gpu.json; echo "2-rank gloo rc=$?"
+python - <<'PY'
+import json
+e=open('gpurun_out/bench_2rank.err').read().strip().split('\n')
+for l in e[::-1]:
+    if l.startswith('{'):
+        f=json.loads(l); print(json.dumps(f.get('sharded_full_path'))[:900]); break
+PY
