@@ -413,6 +413,12 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
     Bits512 ev0, ev1; bool have_ev = false, std_left = false;  /* std_left: they are all valid */                 /* validity of the pairs that stayed behind, as the scans left it */
     bool prev_adjacent = false;
     ev0.w = 0; ev1.w = 0;
+#if defined(SDV_AP_STATS) && !defined(SDV_EMU)
+    unsigned long long st_t[4] = { 0, 0, 0, 0 }; uint32_t st_n[4] = { 0, 0, 0, 0 }; unsigned long long st_mark = __builtin_readcyclecounter();
+#define AP_STAT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_t[i] += now_ - st_mark; st_n[i]++; st_mark = now_; } while (0)
+#else
+#define AP_STAT(i) ((void)0)
+#endif
     for (;;) {
         if (L >= (uint32_t)WIN) { flags |= RES_STALLED; break; }       /* a full window nothing can leave: the worker takes no more input */
         const uint32_t avail = total - (S + L);
@@ -442,6 +448,7 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
                 }
             }
             __syncthreads();
+            AP_STAT(0);
         }
         if (L == (uint32_t)KEEP && have_ev && std_left && total - S >= (uint32_t)WIN + (uint32_t)STRIDE) {
             /* Leap: with three valid pairs behind it, a full window whose last pair is valid closes every run it holds - it comes out
@@ -474,6 +481,7 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
             n_win += (uint32_t)__popcll((unsigned long long)lm);
             if (j_ev > 0) {
                 S += j_ev * (uint32_t)STRIDE; scanned = S + KEEP; prev_adjacent = true;
+                AP_STAT(1);
                 continue;
             }
         }
@@ -500,6 +508,7 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
                 const uint32_t m = (end - S - (uint32_t)WIN) / (uint32_t)STRIDE + 1u;
                 S += m * (uint32_t)STRIDE; L = KEEP;
                 scanned = S + KEEP; have_ev = false;
+                AP_STAT(2);
                 continue;
             }
             if (scan) scanned = S + n;
@@ -533,8 +542,13 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
         have_ev = true;
         S += pops; L = n - pops;
         { Bits512 z; z.w = ~(ev0.w & ev1.w); z.keep_below((int)L, lane); std_left = !z.any(); }
+        AP_STAT(3);
         if (at_end) break;
     }
+#if defined(SDV_AP_STATS) && !defined(SDV_EMU)
+    if (lane == 0 && total > 100000u) printf("[ap plan] stretch %u: %u pairs, %u windows listed; chunk loads %u (%llu cycles), leaps %u (%llu), clean skips %u (%llu), single windows %u (%llu)\n", s, total, n_win,
+                                             st_n[0], st_t[0], st_n[1], st_t[1], st_n[2], st_t[2], st_n[3], st_t[3]);
+#endif
     if (lane == 0) {
         StretchResult r; r.popped = S; r.scanned_upto = scanned; r.flags = flags; r.left = total - S; r.masked = 0; r.n_win = n_win; r._pad = 0;
         a.res[s] = r;
