@@ -328,7 +328,10 @@ __device__ inline uint32_t window_body(sdv_sample_pair *w, int n, bool file_end,
  * overlap (the pairs that stayed behind) holds a sample that was invalid in the input: such windows form a chain that one wave
  * works off in order, every other listed window is the head of a chain of its own. */
 enum { CHUNK_WORDS = 3072, CHUNK_PAD = 16, LEAP_WORDS = (STRIDE * 63 + WIN + 127) / 64 + 1 };
-struct PlanLds { uint64_t bm[2][CHUNK_WORDS + CHUNK_PAD]; };    /* word_valid of the two channels, staged */
+/* (a leap reads nine words per lane, the lanes 509 bits = 7.95 words apart: eight-word steps land sixteen lanes on the same LDS banks, so the staged
+ * words are kept nine apart - one unused word behind every eight) */
+__device__ __forceinline__ uint32_t bmi(uint32_t i) { return i + (i >> 3); }
+struct PlanLds { uint64_t bm[3][CHUNK_WORDS + CHUNK_PAD + (CHUNK_WORDS + CHUNK_PAD) / 8 + 1]; };    /* word_valid of the two channels, staged: word i at bmi(i); [2]: pairs with an invalid sample (what a leap asks) */
 struct WinRec { uint32_t w_pos; uint32_t pops; uint16_t n; uint8_t file_end, head; };
 struct PlanArgs { const Stretch *st; uint32_t n_st; const uint64_t *v0, *v1, *m0, *m1, *bad1; const uint8_t *bad2; const uint64_t *bad3; const uint32_t *has_mi; uint32_t n_words;
                   WinRec *wins; const uint32_t *win_base; StretchResult *res; };
@@ -377,6 +380,13 @@ struct Bits512 {
     }
 };
 /* 512 bits of a staged bitmap from bit position `rel` on */
+__device__ __forceinline__ void take512_staged(const uint64_t *bm, uint32_t rel, Bits512 &o, int lane)      /* ... of a bitmap staged in PlanLds */
+{
+    const uint32_t q = rel >> 6, r = rel & 63u;
+    const uint64_t x = lane < 9 ? bm[bmi(q + (uint32_t)lane)] : 0ull;
+    const uint64_t nx = lane_pull64(x, lane < 63 ? lane + 1 : 63);
+    o.w = lane < 8 ? (r ? (x >> r) | (nx << (64u - r)) : x) : 0ull;
+}
 __device__ __forceinline__ void take512(const uint64_t *bm, uint32_t rel, Bits512 &o, int lane)
 {
     const uint32_t q = rel >> 6, r = rel & 63u;
@@ -412,9 +422,12 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
     uint32_t chunk = 0xFFFFFFFFu;                           /* the first bitmap word staged in LDS */
     Bits512 ev0, ev1; bool have_ev = false, std_left = false;  /* std_left: they are all valid */                 /* validity of the pairs that stayed behind, as the scans left it */
     bool prev_adjacent = false;
+    /* pf: the validity of the pairs that stayed behind is known in the short form the quick step below keeps it in - channel c valid exactly below entry pw[c] */
+    bool pf = false; uint32_t pw0 = 0, pw1 = 0;
+    bool stopper = false;       /* the window at S is the one the last leap stopped at: no use asking again */
     ev0.w = 0; ev1.w = 0;
 #if defined(SDV_AP_STATS) && !defined(SDV_EMU)
-    unsigned long long st_t[4] = { 0, 0, 0, 0 }; uint32_t st_n[4] = { 0, 0, 0, 0 }; unsigned long long st_mark = __builtin_readcyclecounter();
+    unsigned long long st_t[5] = { 0, 0, 0, 0, 0 }; uint32_t st_n[5] = { 0, 0, 0, 0, 0 }; unsigned long long st_mark = __builtin_readcyclecounter();
 #define AP_STAT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); st_t[i] += now_ - st_mark; st_n[i]++; st_mark = now_; } while (0)
 #else
 #define AP_STAT(i) ((void)0)
@@ -432,25 +445,26 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
         if (chunk == 0xFFFFFFFFu || gw < chunk || gw + (uint32_t)LEAP_WORDS > chunk + (uint32_t)CHUNK_WORDS) {
             __syncthreads();
             chunk = gw;
-            /* (CHUNK_WORDS + CHUNK_PAD) / 64 = 48.25 rounds: eight rounds of loads in flight at a time */
-            for (uint32_t base = 0; base < (uint32_t)(CHUNK_WORDS + CHUNK_PAD); base += 512u) {
-                uint64_t x0[8], x1[8];
+            /* (CHUNK_WORDS + CHUNK_PAD) / 64 = 48.25 rounds: sixteen rounds of loads in flight at a time */
+            for (uint32_t base = 0; base < (uint32_t)(CHUNK_WORDS + CHUNK_PAD); base += 1024u) {
+                uint64_t x0[16], x1[16];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < 16; u++) {
                     const uint32_t i = base + (uint32_t)u * 64u + (uint32_t)lane, wi = chunk + i;
                     const bool in = i < (uint32_t)(CHUNK_WORDS + CHUNK_PAD) && wi < a.n_words;
                     x0[u] = in ? a.v0[wi] : ~0ull; x1[u] = in ? a.v1[wi] : ~0ull;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < 16; u++) {
                     const uint32_t i = base + (uint32_t)u * 64u + (uint32_t)lane;
-                    if (i < (uint32_t)(CHUNK_WORDS + CHUNK_PAD)) { lds.bm[0][i] = x0[u]; lds.bm[1][i] = x1[u]; }
+                    if (i < (uint32_t)(CHUNK_WORDS + CHUNK_PAD)) { const uint32_t at = bmi(i); lds.bm[0][at] = x0[u]; lds.bm[1][at] = x1[u]; lds.bm[2][at] = ~(x0[u] & x1[u]); }
                 }
             }
             __syncthreads();
             AP_STAT(0);
         }
-        if (L == (uint32_t)KEEP && have_ev && std_left && total - S >= (uint32_t)WIN + (uint32_t)STRIDE) {
+        const bool was_stopper = stopper; stopper = false;
+        if (!was_stopper && L == (uint32_t)KEEP && have_ev && std_left && total - S >= (uint32_t)WIN + (uint32_t)STRIDE) {
             /* Leap: with three valid pairs behind it, a full window whose last pair is valid closes every run it holds - it comes out
              * valid throughout and 509 pairs leave, whatever else is in it.  So from here the windows start 509 apart up to the first
              * one whose last pair is invalid: 64 candidates are tested at once, a lane each; those with an invalid sample are listed. */
@@ -458,17 +472,15 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
             const uint32_t P = gpos + (uint32_t)lane * (uint32_t)STRIDE, prel = P - chunk * 64u, pq = prel >> 6, pr = prel & 63u;
             bool last_bad = false, dirty = false, own3 = false;
             if ((uint32_t)lane < nact) {
-                uint64_t acc = 0;
-                for (int k = 0; k < 9; k++) {
-                    uint64_t x = ~(lds.bm[0][pq + k] & lds.bm[1][pq + k]);
-                    if (k == 0) x &= ~0ull << pr;
-                    if (k == 8) x &= pr ? ~(~0ull << pr) : 0ull;
-                    acc |= x;
-                }
-                dirty = acc != 0;
-                const uint32_t e = prel + (uint32_t)WIN - 1u;
-                last_bad = ((~(lds.bm[0][e >> 6] & lds.bm[1][e >> 6])) >> (e & 63u)) & 1ull;
-                for (uint32_t k = 0; k < (uint32_t)KEEP; k++) { const uint32_t f = prel + k; own3 = own3 || (((~(lds.bm[0][f >> 6] & lds.bm[1][f >> 6])) >> (f & 63u)) & 1ull); }
+                /* the nine words the window touches, read once: all three questions are answered from them */
+                uint64_t w[9];
+                const uint32_t b9 = bmi(pq), low = pq & 7u;
+#pragma unroll
+                for (int k = 0; k < 9; k++) w[k] = lds.bm[2][b9 + (uint32_t)k + ((low + (uint32_t)k) >> 3)];
+                const uint64_t first = w[0] & (~0ull << pr), last = pr ? w[8] & ~(~0ull << pr) : 0ull;
+                dirty = (first | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7] | last) != 0;
+                last_bad = pr ? (w[8] >> (pr - 1u)) & 1ull : (w[7] >> 63) & 1ull;                          /* pair 511 of the window */
+                own3 = (((w[0] >> pr) | (pr ? w[1] << (64u - pr) : 0ull)) & (uint64_t)((1u << KEEP) - 1u)) != 0;      /* its first three pairs */
             }
             const uint64_t evm = __ballot((uint32_t)lane < nact && last_bad);
             const uint32_t j_ev = evm ? (uint32_t)__ffsll((unsigned long long)evm) - 1u : nact;
@@ -481,13 +493,54 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
             n_win += (uint32_t)__popcll((unsigned long long)lm);
             if (j_ev > 0) {
                 S += j_ev * (uint32_t)STRIDE; scanned = S + KEEP; prev_adjacent = true;
+                pf = true; pw0 = pw1 = KEEP;
+                stopper = j_ev < nact;
                 AP_STAT(1);
                 continue;
             }
         }
         const uint32_t rel = gpos - chunk * 64u;
+        if (pf && have_ev && !has_mi && n == (uint32_t)WIN && pw0 >= 1u && pw1 >= 1u) {
+            /* Quick step, for the window a leap stops at and the ones behind it: a full window in the middle of a file whose pairs behind are valid up to
+             * a point in either channel (no earlier hole), and whose last valid sample in either channel is too close to the end for a ramp.  Then a scan
+             * repairs every run in front of a channel's last valid sample and nothing behind it (scan_validity: fv = 0, no ramp), the pairs wait from the
+             * first channel's last valid sample on, and what stays behind is in the same short form again: four questions to the bitmaps instead of the
+             * 512-bit walk below.  Anything else (a long run at the end, a stall, nothing invalid in reach) takes the walk. */
+            const uint32_t q0 = rel >> 6;
+            uint64_t x0 = 0, x1 = 0;
+            if (lane < 9) { x0 = lds.bm[0][bmi(q0 + (uint32_t)lane)]; x1 = lds.bm[1][bmi(q0 + (uint32_t)lane)]; }
+            const int wlo = (int)(rel & 63u);
+            const uint64_t m_new = lane < 9 ? word_range(lane, wlo + (int)L, wlo + WIN - 1) : 0ull, m_beh = lane < 9 ? word_range(lane, wlo, wlo + (int)L - 1) : 0ull;
+            const uint64_t v0 = x0 & m_new, v1 = x1 & m_new;
+            const uint64_t b0 = __ballot(v0 != 0), b1 = __ballot(v1 != 0);
+            int lv0 = (int)pw0 - 1, lv1 = (int)pw1 - 1;
+            if (b0) { const int j = 63 - __clzll((unsigned long long)b0); lv0 = 64 * j + 63 - __clzll((unsigned long long)lane_read64(v0, j)) - wlo; }
+            if (b1) { const int j = 63 - __clzll((unsigned long long)b1); lv1 = 64 * j + 63 - __clzll((unsigned long long)lane_read64(v1, j)) - wlo; }
+            const bool any_inv = pw0 < L || pw1 < L || __ballot((~(x0 & x1) & m_new) != 0) != 0;
+            const int wait0 = lv0 + 1, wait1 = lv1 + 1, first_wait = wait0 < wait1 ? wait0 : wait1;
+            int pp = first_wait - KEEP; if (pp > WIN - KEEP) pp = WIN - KEEP;
+            if (any_inv && lv0 >= WIN - (RAMP_DOWN + RAMP_UP + 1) && lv1 >= WIN - (RAMP_DOWN + RAMP_UP + 1) && pp > 0) {
+                const bool dep_q = __ballot((~(x0 & x1) & m_beh) != 0) != 0;
+                if (lane == 0) {
+                    WinRec rec; rec.w_pos = gpos; rec.pops = (uint32_t)pp; rec.n = (uint16_t)WIN; rec.file_end = 0; rec.head = (prev_adjacent && dep_q) ? 0 : 1;
+                    wins[n_win] = rec;
+                }
+                n_win++;
+#ifdef SDV_EMU
+                if (lane == 0) { static unsigned long hits = 0; static const bool tr = getenv("SDV_AP_QUICK_TRACE") != NULL; if (tr && (++hits % 1000) == 1) fprintf(stderr, "[ap quick step] %lu\n", hits); }
+#endif
+                scanned = S + n;
+                prev_adjacent = true;
+                S += (uint32_t)pp; L = (uint32_t)WIN - (uint32_t)pp;
+                pw0 = (uint32_t)(wait0 - pp); pw1 = (uint32_t)(wait1 - pp);
+                ev0.w = Bits512::range(lane, 0, (int)pw0 - 1); ev1.w = Bits512::range(lane, 0, (int)pw1 - 1);
+                std_left = pw0 >= L && pw1 >= L;
+                AP_STAT(4);
+                continue;
+            }
+        }
         Bits512 o0, o1, c0, c1;
-        take512(lds.bm[0], rel, o0, lane); take512(lds.bm[1], rel, o1, lane);
+        take512_staged(lds.bm[0], rel, o0, lane); take512_staged(lds.bm[1], rel, o1, lane);
         o0.keep_below((int)n, lane); o1.keep_below((int)n, lane);
         c0 = o0; c1 = o1;
         const uint64_t behind = Bits512::range(lane, 0, (int)L - 1);      /* the pairs that stayed behind */
@@ -507,7 +560,7 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
                 const uint32_t end = q < total ? q : total;
                 const uint32_t m = (end - S - (uint32_t)WIN) / (uint32_t)STRIDE + 1u;
                 S += m * (uint32_t)STRIDE; L = KEEP;
-                scanned = S + KEEP; have_ev = false;
+                scanned = S + KEEP; have_ev = false; pf = false;
                 AP_STAT(2);
                 continue;
             }
@@ -542,12 +595,13 @@ __device__ inline void plan_body(const PlanArgs &a, uint32_t s, PlanLds &lds, in
         have_ev = true;
         S += pops; L = n - pops;
         { Bits512 z; z.w = ~(ev0.w & ev1.w); z.keep_below((int)L, lane); std_left = !z.any(); }
+        pf = std_left; pw0 = pw1 = L;
         AP_STAT(3);
         if (at_end) break;
     }
 #if defined(SDV_AP_STATS) && !defined(SDV_EMU)
-    if (lane == 0 && total > 100000u) printf("[ap plan] stretch %u: %u pairs, %u windows listed; chunk loads %u (%llu cycles), leaps %u (%llu), clean skips %u (%llu), single windows %u (%llu)\n", s, total, n_win,
-                                             st_n[0], st_t[0], st_n[1], st_t[1], st_n[2], st_t[2], st_n[3], st_t[3]);
+    if (lane == 0 && total > 100000u) printf("[ap plan] stretch %u: %u pairs, %u windows listed; chunk loads %u (%llu cycles), leaps %u (%llu), clean skips %u (%llu), windows walked %u (%llu), quick steps %u (%llu)\n", s, total, n_win,
+                                             st_n[0], st_t[0], st_n[1], st_t[1], st_n[2], st_t[2], st_n[3], st_t[3], st_n[4], st_t[4]);
 #endif
     if (lane == 0) {
         StretchResult r; r.popped = S; r.scanned_upto = scanned; r.flags = flags; r.left = total - S; r.masked = 0; r.n_win = n_win; r._pad = 0;
