@@ -363,15 +363,30 @@ def main():
                 barrier()
                 ms = (time.perf_counter() - t1) * 1e3
                 ms_best = ms if ms_best is None else min(ms_best, ms)
+            one_engine_ms = None
+            if world == 1:      # the same job without the sharding protocol: the whole file, NEW_FILE .. END_FILE, through the fused entry of one engine (a cold start like the sharded passes)
+                from sdvpcmdecoder_amd.engine import PCM_STC007
+                for _ in range(3):
+                    eng.reset_stream(); eng.reset_stitcher()
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    o_pairs = eng.decode_frames(PCM_STC007, lum_s, first_frame_no=1, new_file=True, end_file=True)[0]
+                    torch.cuda.synchronize(dev)
+                    ms = (time.perf_counter() - t1) * 1e3
+                    one_engine_ms = ms if one_engine_ms is None else min(one_engine_ms, ms)
+                assert o_pairs.shape[0] == s_pairs.shape[0]
+                del o_pairs
             tt = torch.tensor([ms_best, float(s_pairs.shape[0]), float(dec.stats["binarize_redo"]), float(dec.stats["stitch_redo"])], dtype=torch.float64,
                               device=dev if backend == "nccl" else "cpu")
             mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
             sharded_full = {"frames": total, "frames_per_rank": ns, "ms": float(mx[0].item()), "frames_per_s": total / (float(mx[0].item()) / 1e3),
                             "sample_pairs": int(sm[1].item()), "ranges_decoded_again": {"binarize": int(sm[2].item()), "stitch": int(sm[3].item())},
+                            "one_engine_same_file_ms": one_engine_ms,
                             "note": "one synthetic NTSC tape of `frames` frames, NEW_FILE .. END_FILE, every rank its contiguous range with a 20-frame warm-up and one "
-                                    "successor frame; best of three passes, wall clock incl. the all-gathers of the hand-over states (120 B + 3.8 KB per rank); "
-                                    "not part of `value`"}
+                                    "successor frame; best of three passes, wall clock between two barriers incl. the all-gather of the hand-over states (2 x 120 B + 2 x 3.8 KB per "
+                                    "rank); one_engine_same_file_ms (one rank only): the same file through sdv_decode_frames of one engine, cold start as well - "
+                                    "the steady-state figure of end_to_end is a continuing tape; not part of `value`"}
             del lum_s, s_pairs, s_frames
             eng.reset_stream(); eng.reset_stitcher()
         except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
@@ -992,6 +1007,7 @@ def main():
             "audio_worn_tape_ms_per_step": pick(out, "audio_stage", "invalid_word_in_every_window", "ms_per_step"),
             "cpu_all_cores_frames_per_s": pick(out, "cpu_baseline_all_cores", "value"), "cpu_all_cores": pick(out, "cpu_baseline_all_cores", "cores"),
             "sharded_full_path_ms": pick(out, "sharded_full_path", "ms"),
+            "sharded_one_engine_same_file_ms": pick(out, "sharded_full_path", "one_engine_same_file_ms"),
         }
         short = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                                         "config", "roofline", "cpu_baseline") if k_ in out}

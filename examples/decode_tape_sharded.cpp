@@ -250,26 +250,10 @@ int main(int argc, char **argv)
         SDV_OKAY(sdv_binarize_frames(eng, d_luma, (size_t)width, frame_bytes, width, height, lead, (uint32_t)(1 + lo - lead), 0, d_warm, n_warm, d_stats, n_in + 2, NULL));
         SDV_OKAY(sdv_get_chain_state(eng, &predicted));
     }
-    auto run_range = [&]() {
-        if (k0 > 0) {       /* rank 0: the frames behind the ones it decoded first (it never has to decode anything again) */
-            if (k0 < n_own)
-                SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)k0 * frame_bytes, (size_t)width, frame_bytes, width, height, n_own - k0, (uint32_t)(1 + k0),
-                                             last ? SDV_FLAG_END_FILE : 0u, d_whole + head_recs, n_own_recs - head_recs, d_stats, n_in + 2, NULL));
-        } else
-        SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)lead * frame_bytes, (size_t)width, frame_bytes, width, height, n_own, (uint32_t)(1 + lo), own_flags,
-                                     d_whole, n_own_recs, d_stats, n_in + 2, NULL));
-        SDV_OKAY(sdv_get_chain_state(eng, &fin));
-        if (look)       /* the successor of this range's last stitcher turn (rank r + 1 decodes it again, as its first frame) */
-            SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)(lead + n_own) * frame_bytes, (size_t)width, frame_bytes, width, height, 1, (uint32_t)(1 + hi), 0,
-                                         d_whole + n_own_recs, n_extra, d_stats, n_in + 2, NULL));
-    };
-    run_range();
-
-    /* ---- stitch stage (the STC007DataStitcher worker), and one all-gather for both ------------------------------------------------------------
-     * The stitcher runs on the records straight away, before anybody knows whether the range was decoded from the right state: on a tape that plays it
-     * was, and then one all-gather carries what both stages assumed and what they ended with - every rank works out every rank's verdict from it, no
-     * second gather to agree on going on.  A rank whose binarizer guess was wrong decodes its range again and stitches it afresh; one whose stitcher
-     * guess alone was wrong feeds its records again from the true state. */
+    /* ---- the range: both workers back to back inside the engine (sdv_decode_frames), and one all-gather for both -------------------------------------
+     * The stitcher runs straight behind the binarizer, before anybody knows whether the range was decoded from the right state: on a tape that plays it
+     * was, and then one all-gather carries what both workers assumed and what they ended with - every rank works out every rank's verdict from it, no
+     * second gather to agree on going on.  A rank that assumed wrong runs its range again from the true states. */
     const size_t n_whole = n_own_recs + n_extra;
     const size_t pairs_cap = n_whole * 4 + 8192, frames_cap = (size_t)n_own + 16, state_n = sdv_stitch_state_size();
     sdv_sample_pair *d_pairs = (sdv_sample_pair *)dev_alloc(pairs_cap * sizeof(sdv_sample_pair));
@@ -280,33 +264,49 @@ int main(int argc, char **argv)
     std::vector<uint8_t> s_pred(state_n, 0), s_final(state_n, 0), blob(blob_n), blobs(blob_n * (size_t)world);
     size_t n_pairs = 0, n_fr = 0;
     const int s_lead = stitch_warmup < lead ? stitch_warmup : lead;
-    enum { M_NONE, M_FRESH, M_STATE } mode = M_FRESH;
-    for (;;) {
-        if (mode == M_FRESH) {
+    /* s_from: the stitcher state to start from instead of the warm-up's guess (NULL: a fresh stitcher); the binarizer's state is what the engine holds */
+    auto run_range = [&](const uint8_t *s_from) {
+        int start = 0;
+        n_pairs = 0; n_fr = 0;
+        auto fused = [&](int first, int count, unsigned fl) {       /* frames [first, first + count) of this rank's input through both workers, appended */
+            size_t np = 0, nf = 0, npur = 0; uint64_t masked = 0;
+            SDV_OKAY(sdv_decode_frames(eng, SDV_PCM_STC007, d_luma + (size_t)first * frame_bytes, (size_t)width, frame_bytes, width, height, count,
+                                       (uint32_t)(1 + lo - lead + first), fl, d_pairs + n_pairs, pairs_cap - n_pairs, &np, d_frames + n_fr, frames_cap - n_fr, &nf,
+                                       d_stats, n_in + 2, 0, 0, NULL, 0, &npur, &masked, NULL));
+            n_pairs += np; n_fr += nf;
+        };
+        if (s_from) {
+            SDV_OKAY(sdv_set_stitch_state(eng, s_from, state_n));       /* drops the waiting frame */
+            memcpy(s_pred.data(), s_from, state_n);
+        } else {
             SDV_OKAY(sdv_reset_stitcher(eng));
             std::fill(s_pred.begin(), s_pred.end(), 0);
-            if (s_lead) {
+            if (k0 > 0) {       /* rank 0 of several: the frames it decoded first go to the stitcher as records */
+                SDV_OKAY(sdv_stitch_frames(eng, d_whole, head_recs, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+                start = k0;
+            } else if (s_lead) {
                 /* warm-up turns lo - s_lead .. lo - 1 (output discarded); frame lo then waits inside the engine for its successor */
-                const size_t n_cat = (size_t)(s_lead + 1) * rpf;
+                const unsigned fl = (last && n_own == 1) ? SDV_FLAG_END_FILE : 0u;
+                const size_t n_first = sdv_binarize_records(height, 1, fl), n_cat = (size_t)s_lead * rpf + n_first;
                 sdv_line_rec *d_cat = (sdv_line_rec *)dev_alloc(n_cat * sizeof(sdv_line_rec));
                 d2d(d_cat, d_warm + (size_t)(lead - s_lead) * rpf, (size_t)s_lead * rpf * sizeof(sdv_line_rec));
-                d2d(d_cat + (size_t)s_lead * rpf, d_whole, rpf * sizeof(sdv_line_rec));
+                SDV_OKAY(sdv_binarize_frames(eng, d_luma + (size_t)lead * frame_bytes, (size_t)width, frame_bytes, width, height, 1, (uint32_t)(1 + lo), fl,
+                                             d_cat + (size_t)s_lead * rpf, n_first, d_stats, n_in + 2, NULL));
                 size_t np = 0, nf = 0;
                 SDV_OKAY(sdv_stitch_frames(eng, d_cat, n_cat, d_pairs, pairs_cap, &np, d_frames, frames_cap, &nf, NULL));
                 SDV_OKAY(sdv_saturate_stitch_stats(eng));
                 SDV_OKAY(sdv_get_stitch_state(eng, s_pred.data(), state_n));
-                SDV_OKAY(sdv_stitch_frames(eng, d_whole + rpf, n_whole - rpf, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
                 dev_free(d_cat);
-            } else {
-                SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
+                start = 1;
             }
-            SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
-        } else if (mode == M_STATE) {
-            SDV_OKAY(sdv_set_stitch_state(eng, s_pred.data(), state_n));        /* drops the waiting frame: the whole range is fed again */
-            SDV_OKAY(sdv_stitch_frames(eng, d_whole, n_whole, d_pairs, pairs_cap, &n_pairs, d_frames, frames_cap, &n_fr, NULL));
-            SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
         }
-        mode = M_NONE;
+        if (start < n_own) fused(lead + start, n_own - start, ((rank == 0 && start == 0) ? SDV_FLAG_NEW_FILE : 0u) | (last ? SDV_FLAG_END_FILE : 0u));
+        SDV_OKAY(sdv_get_chain_state(eng, &fin));
+        if (look) fused(lead + n_own, 1, 0u);       /* the successor of this range's last stitcher turn (rank r + 1 decodes it again, as its first frame) */
+        SDV_OKAY(sdv_get_stitch_state(eng, s_final.data(), state_n));
+    };
+    run_range(NULL);
+    for (;;) {
         memcpy(blob.data(), &predicted, nb); memcpy(blob.data() + nb, &fin, nb);
         memcpy(blob.data() + 2 * nb, s_pred.data(), state_n); memcpy(blob.data() + 2 * nb + state_n, s_final.data(), state_n);
         comm->all_gather(blob.data(), blobs.data(), blob_n);
@@ -323,12 +323,12 @@ int main(int argc, char **argv)
             binarize_redo++;
             memcpy(&predicted, part(rank - 1, nb), nb);
             SDV_OKAY(sdv_set_chain_state(eng, &predicted));
-            run_range();
-            mode = M_FRESH;
+            run_range(NULL);
         } else if (all_bin && !my_st) {         /* (while a binarizer still decodes again, the stitcher states behind it are not final) */
             stitch_redo++;
-            memcpy(s_pred.data(), part(rank - 1, 2 * nb + state_n), state_n);
-            mode = M_STATE;
+            SDV_OKAY(sdv_set_chain_state(eng, &predicted));       /* the records stayed inside the engine: the range runs again, from both true states */
+            std::vector<uint8_t> from(part(rank - 1, 2 * nb + state_n), part(rank - 1, 2 * nb + state_n) + state_n);
+            run_range(from.data());
         }
     }
     dev_sync();

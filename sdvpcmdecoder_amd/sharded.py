@@ -21,6 +21,9 @@ stitcher turn needs); the last rank appends the end-of-file frame instead."""
 from __future__ import annotations
 
 
+PCM_STC007 = 2          # sdv_set_pcm_type / sdv_decode_frames: the STC-007 chain (sdvpcmdecoder_amd.engine.PCM_STC007)
+
+
 def shard_bounds(n_frames: int, rank: int, world: int):
     return n_frames * rank // world, n_frames * (rank + 1) // world
 
@@ -77,49 +80,59 @@ class ShardedDecoder:
             warm, _ = eng.binarize_frames(luma[:lead], first_frame_no=first_frame_no + f0, new_file=False)
             predicted = eng.get_chain_state()
 
-        def run_range():
-            if head is not None:            # rank 0: the frames behind the ones it decoded first (it never has to decode anything again)
-                k0 = head.shape[0] // rpf
-                own = head
-                if k0 < n_own:
-                    rest, _ = eng.binarize_frames(luma[k0:n_own], first_frame_no=first_frame_no + k0, new_file=False, end_file=last)
-                    own = _cat(head, rest)
-            else:
-                own, _ = eng.binarize_frames(luma[lead:lead + n_own], first_frame_no=first_frame_no + lo, new_file=(rank == 0), end_file=last)
-            final = eng.get_chain_state()
-            extra = None
-            if look:        # the successor frame of this range's last stitcher turn (rank r+1 decodes it again as its first frame)
-                extra, _ = eng.binarize_frames(luma[lead + n_own:], first_frame_no=first_frame_no + hi, new_file=False)
-            return own, extra, final
-        own, extra, final = run_range()
-
-        # ---- stitch stage, and one all-gather for both ---------------------------------------------------------------
-        # The stitcher runs on the records straight away, before anybody knows whether the range was decoded from the right state: on a tape
-        # that plays it was, and then one all-gather carries what both stages assumed and what they ended with (every rank works out every
-        # rank's verdict from it: no second gather to agree on going on).  A rank whose binarizer guess was wrong decodes its range again and
-        # stitches it afresh; one whose stitcher guess alone was wrong feeds its records again from the true state.
+        # ---- the range: binarizer and stitcher back to back inside the engine (sdv_decode_frames), and one all-gather for both stages ------------
+        # The stitcher runs straight behind the binarizer, before anybody knows whether the range was decoded from the right state: on a tape that
+        # plays it was, and then one all-gather carries what both stages assumed and what they ended with (every rank works out every rank's
+        # verdict from it: no second gather to agree on going on).  A rank that assumed wrong runs its range again from the true states.
         s_lead = min(self.stitch_warmup, lead)
-        mode, s_pred, s_final, pairs, frames, whole = "fresh", None, None, None, None, None
-        while True:
-            if mode == "fresh":
-                # own = [NEW_FILE record on rank 0] + frames lo..hi-1 [+ the end-of-file frame on the last rank]
-                whole = _cat(own, extra) if extra is not None else own
+        fused = getattr(eng, "decode_frames", None)
+
+        def run_range(s_from=None):
+            """-> pairs, frames, final chain state, the stitcher state assumed (None: a fresh stitcher), its final state.
+            s_from: the stitcher state to start from instead of the warm-up's guess (the binarizer's state is what the engine holds)."""
+            out_p, out_f = [], []
+            start = 0
+            if s_from is not None:
+                eng.set_stitch_state(s_from)
+                s_pred = s_from
+            else:
                 eng.reset_stitcher()
                 s_pred = None
-                if s_lead:
+                if head is not None:         # rank 0 of several: the frames it decoded first go to the stitcher as records
+                    p, f = eng.stitch_frames(head)
+                    out_p.append(p); out_f.append(f)
+                    start = head.shape[0] // rpf
+                elif s_lead:
                     # warm-up turns lo-s_lead .. lo-1 (output discarded); frame lo then waits inside the engine for its successor
-                    eng.stitch_frames(_cat(warm[(lead - s_lead) * rpf:], own[:rpf]))
+                    first, _ = eng.binarize_frames(luma[lead:lead + 1], first_frame_no=first_frame_no + lo, new_file=False, end_file=(last and n_own == 1))
+                    eng.stitch_frames(_cat(warm[(lead - s_lead) * rpf:], first))
                     eng.saturate_stitch_stats()
                     s_pred = eng.get_stitch_state()
-                    pairs, frames = eng.stitch_frames(whole[rpf:])
+                    start = 1
+            if start < n_own:
+                kw = dict(first_frame_no=first_frame_no + lo + start, new_file=(rank == 0 and start == 0), end_file=last)
+                if fused is not None:
+                    p, f = fused(PCM_STC007, luma[lead + start:lead + n_own], **kw)[:2]
+                else:                        # an engine object without the fused entry: the two workers one after the other
+                    recs, _ = eng.binarize_frames(luma[lead + start:lead + n_own], **kw)
+                    p, f = eng.stitch_frames(recs)
+                out_p.append(p); out_f.append(f)
+            final = eng.get_chain_state()
+            if look:        # the successor frame of this range's last stitcher turn (rank r+1 decodes it again as its first frame)
+                if fused is not None:
+                    p, f = fused(PCM_STC007, luma[lead + n_own:], first_frame_no=first_frame_no + hi, new_file=False)[:2]
                 else:
-                    pairs, frames = eng.stitch_frames(whole)
-                s_final = eng.get_stitch_state()
-            elif mode == "state":
-                eng.set_stitch_state(s_pred)                  # drops the waiting frame: the whole range is fed again
-                pairs, frames = eng.stitch_frames(whole)
-                s_final = eng.get_stitch_state()
-            mode = None
+                    recs, _ = eng.binarize_frames(luma[lead + n_own:], first_frame_no=first_frame_no + hi, new_file=False)
+                    p, f = eng.stitch_frames(recs)
+                out_p.append(p); out_f.append(f)
+            s_final = eng.get_stitch_state()
+            pairs, frames = out_p[0], out_f[0]
+            for p, f in zip(out_p[1:], out_f[1:]):
+                pairs, frames = _cat(pairs, p), _cat(frames, f)
+            return pairs, frames, final, s_pred, s_final
+
+        pairs, frames, final, s_pred, s_final = run_range()
+        while True:
             nb, ns = len(final), len(s_final)
             blobs = self.all_gather((predicted or bytes(nb)) + final + (s_pred or bytes(ns)) + s_final)
             self.stats["gathers"] += 1
@@ -133,12 +146,11 @@ class ShardedDecoder:
                 self.stats["binarize_redo"] += 1
                 predicted = b_fin[rank - 1]
                 eng.set_chain_state(predicted)
-                own, extra, final = run_range()
-                mode = "fresh"
+                pairs, frames, final, s_pred, s_final = run_range()
             elif all(bin_ok) and not st_ok[rank]:       # (while a binarizer still decodes again, the stitcher states behind it are not final)
                 self.stats["stitch_redo"] += 1
-                s_pred = t_fin[rank - 1]
-                mode = "state"
+                eng.set_chain_state(predicted)                # the records stayed inside the engine: the range runs again, from both true states
+                pairs, frames, final, s_pred, s_final = run_range(s_from=t_fin[rank - 1])
         return pairs, frames
 
 

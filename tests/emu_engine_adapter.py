@@ -39,6 +39,28 @@ class EmuEngine:
         assert rc == 0, self.lib.sdv_last_error(self.h)
         return pairs.copy(), frames.copy()
 
+    def decode_frames(self, pcm_type, luma, first_frame_no=1, new_file=False, end_file=False):
+        """sdv_decode_frames on host memory: (pairs, frame descriptors, frame stats) like Engine.decode_frames."""
+        import stitch_api as sa
+        lib = self.lib
+        lib.sdv_decode_frames.restype = C.c_int
+        lib.sdv_decode_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint,
+                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_void_p]
+        assert pcm_type == 2, "the adapter's fused call: STC-007"
+        luma = np.ascontiguousarray(luma)
+        n, hgt, w = luma.shape
+        cap = (n + 2) * 1800 + 8192
+        pairs = np.zeros(cap, dtype=sa.PAIR_DTYPE)
+        frames = np.zeros(n + 16, dtype=sa.FRASM_DTYPE)
+        stats = np.zeros(n + 1, dtype=ea.STATS_DTYPE)
+        npairs, nfr, npur, nm = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+        rc = lib.sdv_decode_frames(self.h, pcm_type, luma.ctypes.data, w, w * hgt, w, hgt, n, first_frame_no, (1 if new_file else 0) | (4 if end_file else 0),
+                                   pairs.ctypes.data, cap, C.byref(npairs), frames.ctypes.data, len(frames), C.byref(nfr), stats.ctypes.data, len(stats), 0, 0,
+                                   None, 0, C.byref(npur), C.byref(nm), None)
+        assert rc == 0, lib.sdv_last_error(self.h)
+        return pairs[:npairs.value].copy(), frames[:nfr.value].copy(), stats
+
     def set_stitch_settings(self, st):
         assert self.lib.sdv_set_stitch_settings(self.h, C.byref(st)) == 0
 

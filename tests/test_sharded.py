@@ -23,7 +23,7 @@ def test_shard_bounds_cover_the_tape():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
 
 
-@pytest.mark.parametrize("n_frames,warmup,s_warm,expect_redo", [(6, 3, 2, False), (10, 3, 2, True)])
+@pytest.mark.parametrize("n_frames,warmup,s_warm,expect_redo", [(6, 3, 2, False), (10, 3, 2, True), (6, 3, 0, False)])
 def test_two_ranks_one_tape(tmp_path, emu_lib, oracle_lib, n_frames, warmup, s_warm, expect_redo):
     world = 2
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), WORLD_SIZE=str(world))
@@ -42,6 +42,8 @@ def test_two_ranks_one_tape(tmp_path, emu_lib, oracle_lib, n_frames, warmup, s_w
     assert len(frames) == len(want_f) and frames.tobytes() == want_f.tobytes()
     # a warm-up shorter than the predecessor's history cannot reproduce its coordinate history: the repair has to run
     assert (parts[1]["redo"][0] >= 1) == expect_redo, parts[1]["redo"]
+    if s_warm == 0:         # a stitcher that starts cold cannot have guessed its predecessor's state: the range runs again from the true one
+        assert parts[1]["redo"][1] >= 1, parts[1]["redo"]
 
 
 def test_two_ranks_binarize_loop(tmp_path, emu_lib, oracle_lib):
