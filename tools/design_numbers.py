@@ -20,7 +20,7 @@ rows = [
      f"{d['value'] / 1e6:.2f} M frames/s, {d['ms_per_step']:.3f} ms per step; lean kernel {g('roofline', 'avg_launch_ms'):.3f} ms per launch = {g('roofline', 'achieved') / 1000:.2f} TB/s algorithmic = **{g('roofline', 'frac'):.3f} of the 8 TB/s peak**",
      "boxes of the pool: 0.737 … 0.81 ms per launch in this round's runs (frac 0.634 … 0.576; `profiles/r04_k1_ab_across_rounds.txt`); PMC traffic 1.05 × algorithmic (`profiles/r04_pmc_sdv_k_stc007_frames_lean.json`)"),
     ("CPU baseline (real reference, `oracle/_ref`)", f"{g('cpu_baseline', 'value'):.0f} frames/s on one core; {g('cpu_baseline_all_cores', 'value'):.0f} frames/s with a worker on each of the {g('cpu_baseline_all_cores', 'cores')} cores the container is granted", "bit-exact on the overlap"),
-    ("frames → pairs, fused (`sdv_decode_frames`)", f"{g('end_to_end', 'ms_per_step'):.3f} ms = {g('end_to_end', 'frames_per_s') / 1e6:.2f} M frames/s, {g('end_to_end', 'roofline', 'frac'):.2f} of peak on 377 232 B per frame", "kernels: K1 0.8 + analyze 0.28 + step 0.37 + small ones 0.1"),
+    ("frames → pairs, fused (`sdv_decode_frames`)", f"{g('end_to_end', 'ms_per_step'):.3f} ms = {g('end_to_end', 'frames_per_s') / 1e6:.2f} M frames/s, {g('end_to_end', 'roofline', 'frac'):.2f} of peak on 377 232 B per frame", "kernels (`profiles/r04_rocprofv3_stitch_kernel_stats.csv`): K1 0.81 + analyze 0.18 (start of the round: 0.28) + step 0.39 + predict, segments, scan 0.12"),
     ("stitch stage alone", f"{g('stitch_stage', 'stitch_ms_per_step'):.3f} ms ({g('stitch_stage', 'stitch_device_ms_per_step'):.3f} ms on the device)", f"CPU: {g('stitch_stage', 'cpu_baseline', 'value'):.0f} frames/s"),
     ("PAL (configs[2]) clean, binarize + stitch", f"{pal['clean']['ms_per_step']:.2f} ms = {pal['clean']['frames_per_s'] / 1e6:.2f} M frames/s", ""),
     ("PAL C3 tape (2000 frames; every 97th line lost, a cell inverted on one line in 53)",
