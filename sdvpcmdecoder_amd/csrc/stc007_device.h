@@ -1791,6 +1791,8 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
     }
     o._pad[0] = o._pad[1] = 0;
     *s = o;
+    /* the last frame of the call: its state also behind the flags, where the host's one read-back per round finds it (engine.inc: tail_ofs) */
+    if (s == &a.states_out[a.n_total - 1]) *reinterpret_cast<sdv_v2d_state *>(a.flag + (((size_t)a.n_total + 15) & ~(size_t)15)) = o;
     /* the check of the chain, by the frame itself: was the next frame started from this state?  (and: is it the state the frame itself was started
      * from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
     const int f = (int)(s - a.states_out);
