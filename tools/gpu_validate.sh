@@ -61,5 +61,5 @@ du -sh gpurun_out | tail -1
 if [ -f build/variants/dev.so ]; then
   SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/pal_trace.py 2000 both > gpurun_out/pal_trace_both.log 2>&1
   SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/jump_probe.py 10000 16 > gpurun_out/jump_trace.log 2>&1
-  timeout 1200 python tools/soak.py 16 4000 > gpurun_out/soak_r04.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r04.log
 fi
+timeout 1200 python tools/soak.py 16 4000 > gpurun_out/soak_r04.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r04.log
