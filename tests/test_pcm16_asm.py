@@ -5,6 +5,7 @@ lines window (RenderPCM::renderNewLine(PCM16X0SubLine), renderpcm.cpp:743-937: s
   oracle (oracle/pcm16.c, oracle/render.c)  vs  the real stitcher's sub-lines and the real RenderPCM on them (live, when oracle/_ref is built) and the
                                                 committed fixtures;
   HIP kernels                               vs  the oracle: on the emulator, and through the C-ABI on the GPU (-m gpu)."""
+import functools
 import hashlib
 import os
 
@@ -21,6 +22,7 @@ CASES = [n for n in p16.CASES if n not in p16.LIVELOCK and n not in ("si_lost_lo
 ASM_GOLDEN = ("si_bad10", "si_picked_forced", "ei_bad10", "si_file_marks", "si_lost_sublines")
 
 
+@functools.lru_cache(maxsize=None)        # (the tests of a case share one run of the oracle; nobody writes into what it returns)
 def _oracle(name):
     recs, st = p16.make_input(name)
     pairs, frames, blocks, lines = p16.run_cpu_feeds(libs.load_oracle(), "orc_", recs, st)

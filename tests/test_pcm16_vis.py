@@ -5,6 +5,7 @@ records next to the sample pairs (sdv_set_pcm16x0_stitch_block_output) and Rende
                                                 built) and the committed fixtures;
   HIP kernels                               vs  the oracle: on the emulator, and through the C-ABI on the GPU (-m gpu)."""
 import ctypes as C
+import functools
 import hashlib
 import os
 
@@ -21,6 +22,7 @@ CASES = [n for n in p16.CASES if n not in p16.LIVELOCK and n not in ("si_lost_lo
 RENDER_CASES = ("si_bad10", "si_picked_forced", "si_burst", "si_file_marks", "si_rate_emph", "ei_bad10", "ei_picked", "si_lost_sublines", "si_no_p")
 
 
+@functools.lru_cache(maxsize=None)        # (the tests of a case share one run of the oracle; nobody writes into what it returns)
 def _oracle(name):
     recs, st = p16.make_input(name)
     pairs, frames, blocks = p16.run_cpu_vis(libs.load_oracle(), "orc_", recs, st)
