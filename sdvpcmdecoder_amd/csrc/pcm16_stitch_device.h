@@ -418,6 +418,7 @@ struct FrameArgs16s {
     /* ... and the assembled sub-lines (sdv_set_pcm16x0_stitch_line_output): records per frame, an END_FRAME record behind them; field_src: the record
      * every place of the field buffers was made from ([frame][2][735] like `fields`) */
     uint32_t *vline_ofs; sdv_pcm16x0_bin_rec *out_lines; uint64_t lines_cap; uint32_t *field_src;
+    const State16 *state_snap;  /* EI: the stream's state when the call began (NULL: the analysis makes full padding tables) */
 };
 
 #ifndef SDV_P16_LDS_SUBS
@@ -587,6 +588,58 @@ __device__ inline bool best_padding(const Stats *tab, int n, int lane, Stats &m,
 }
 
 /* K-A: one wave, one frame.  kLds: the frame's sub-lines are staged in LDS; otherwise every access compacts the record again. */
+/* (the padding history in registers: the in-order pass K-B keeps it, the analysis asks it what a tape that plays will lock on) */
+/* the value lane `idx` holds, idx the same in every lane: v_readlane_b32 (no trip through LDS) */
+#ifdef SDV_EMU
+__device__ inline uint32_t lane_read(uint32_t v, uint32_t idx) { return (uint32_t)__shfl((int)v, (int)idx); }
+#else
+__device__ inline uint32_t lane_read(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)sdvs::uni(idx)); }
+#endif
+/* stats_padding (circarray<uint8_t, 65>, :243) in registers: lane i holds slot i (slot 64 is uniform), and a histogram of the values in
+ * the ring - lane v counts value v and value 64 + v - so that getProbablePadding (:4368-4423) is one wave reduction */
+struct PadHist { uint32_t ring_lo, ring64, hist0, hist1; int pos, nvalid; };
+__device__ inline void hist_load(PadHist &h, const State16 &s, int lane)
+{
+    h.ring_lo = s.pad_ring[lane]; h.ring64 = s.pad_ring[64]; h.pos = s.pad_pos;
+    uint32_t h0 = 0, h1 = 0; int nv = 0;
+    for (int i = 0; i < STATS_DEPTH; i++) {
+        const uint32_t v = s.pad_ring[i];
+        nv += v != INVALID_PAD ? 1 : 0; h0 += v == (uint32_t)lane ? 1u : 0u; h1 += v == (uint32_t)lane + 64u ? 1u : 0u;
+    }
+    h.hist0 = h0; h.hist1 = h1; h.nvalid = nv;
+}
+__device__ inline void hist_store(const PadHist &h, State16 &s, int lane)
+{
+    s.pad_ring[lane] = (uint8_t)h.ring_lo;
+    if (lane == 0) { s.pad_ring[64] = (uint8_t)h.ring64; s.pad_pos = h.pos; }
+}
+__device__ inline void hist_reset(PadHist &h) { h.ring_lo = h.ring64 = INVALID_PAD; h.hist0 = h.hist1 = 0; h.pos = 0; h.nvalid = 0; }    /* clearPadStats (:4349-4352) */
+__device__ inline void push_padding(PadHist &h, uint32_t v, int lane)       /* updatePadStats(v, true) (:4355-4365) */
+{
+    const uint32_t in_lo = lane_read(h.ring_lo, (uint32_t)(h.pos < 64 ? h.pos : 0));
+    const uint32_t old = h.pos < 64 ? in_lo : h.ring64;
+    h.ring_lo = (h.pos < 64 && lane == h.pos) ? v : h.ring_lo;
+    h.ring64 = h.pos < 64 ? h.ring64 : v;
+    /* plain arithmetic on both counters (no conditional stores: they would be turned into a store through a selected address) */
+    const uint32_t lane_u = (uint32_t)lane;
+    h.hist0 = h.hist0 + (v == lane_u ? 1u : 0u) - ((old != INVALID_PAD && old == lane_u) ? 1u : 0u);
+    h.hist1 = h.hist1 + (v == lane_u + 64u ? 1u : 0u) - ((old != INVALID_PAD && old == lane_u + 64u) ? 1u : 0u);
+    h.nvalid += old == INVALID_PAD ? 1 : 0;
+    h.pos = (h.pos + 1) % STATS_DEPTH;
+}
+__device__ inline uint8_t probable_padding(const PadHist &h, int lane)      /* the value that occurs most often, the smallest of them on a tie */
+{
+    if (h.nvalid == 0) return INVALID_PAD;
+    /* the largest count, bit by bit (counts are below 128): lanes whose count lacks a bit that another one has drop out */
+    uint64_t a0 = ~0ull, a1 = (1ull << (MAX_PAD_EI - 64)) - 1;
+#pragma unroll
+    for (int bit = 6; bit >= 0; bit--) {
+        const uint64_t m0 = __ballot((h.hist0 >> bit) & 1u) & a0, m1 = __ballot((h.hist1 >> bit) & 1u) & a1;
+        if (m0 | m1) { a0 = m0; a1 = m1; }
+    }
+    return a0 ? (uint8_t)(__ffsll((unsigned long long)a0) - 1) : (uint8_t)(64 + __ffsll((unsigned long long)a1) - 1);
+}
+
 template <bool kLds>
 __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane, uint32_t lo, uint32_t n, AnaLds &lds)
 {
@@ -775,6 +828,7 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
     __syncthreads();
     auto field_at = [&](int p, int u) -> Sub { return (u >= 0 && u < (int)data[p]) ? fld_ref(p, (uint32_t)u) : sub_empty(); };
     Ana16 *const out = &a.ana[kb];
+    int ei_hint = -1;           /* EI: the one padding the table was made for (-1: all of them) */
     /* 5. the padding tables */
     const DiCfg pad_cfg = { true, true, ei ? cfg.ignore_crc != 0 : false };
     if (!ei) {
@@ -836,7 +890,8 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
         const int c1 = (int)data[p1], c2 = (int)data[p2];
         auto n_blocks_of = [&](int pad) -> int { const int size = c1 + 3 * pad + c2; return size >= EI_TRUE ? size - 2 * EI_OFS - 1 : 0; };
         auto q_at = [&](int pad, int i) -> Sub { return i < c1 ? field_at(p1, i) : (i < c1 + 3 * pad ? sub_empty() : field_at(p2, i - c1 - 3 * pad)); };
-        const int n_max = n_blocks_of(MAX_PAD_EI - 1);
+        auto sweep = [&](int pad_lo, int pad_hi) {
+        const int n_max = n_blocks_of(pad_hi);
         BurstsW u0 = { 0, 0, 0, 0, 0, 0, 0, 0 }, u1 = u0;      /* the counters of padding `lane` and padding `lane + 64` */
         for (int i0 = 0; i0 < n_max; i0 += 64) {
             const int i = i0 + lane;
@@ -858,7 +913,7 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
                 n_slow = 0;
             };
 #pragma unroll 1
-            for (int pad = 0; pad < MAX_PAD_EI; pad++) {
+            for (int pad = pad_lo; pad <= pad_hi; pad++) {
                 const int nb = n_blocks_of(pad);
                 uint32_t c = 0;
                 if (i < nb) {
@@ -876,7 +931,7 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
             }
             flush_slow();
             {
-                const int nb0 = n_blocks_of(lane) - i0, nb1 = lane + 64 < MAX_PAD_EI ? n_blocks_of(lane + 64) - i0 : 0;
+                const int nb0 = (lane >= pad_lo && lane <= pad_hi) ? n_blocks_of(lane) - i0 : 0, nb1 = (lane + 64 >= pad_lo && lane + 64 <= pad_hi) ? n_blocks_of(lane + 64) - i0 : 0;
                 if (nb0 > 0) bursts_word(u0, lds.ei.m[lane][0], lds.ei.m[lane][1], lds.ei.m[lane][2], lds.ei.m[lane][3], (uint32_t)(nb0 < 64 ? nb0 : 64), MAX_SIL_EI, MAX_UNCH_EI);
                 if (nb1 > 0) { const int pd = lane + 64; bursts_word(u1, lds.ei.m[pd][0], lds.ei.m[pd][1], lds.ei.m[pd][2], lds.ei.m[pd][3], (uint32_t)(nb1 < 64 ? nb1 : 64), MAX_SIL_EI, MAX_UNCH_EI); }
             }
@@ -886,13 +941,33 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const int pad = lane + 64 * half;
-            if (pad < MAX_PAD_EI) {
+            if (pad >= pad_lo && pad <= pad_hi) {
                 const BurstsW &u = half ? u1 : u0;
                 Stats st; st.valid = (uint16_t)u.vm; st.silent = (uint16_t)u.sm; st.unchecked = (uint16_t)u.um; st.broken = (uint16_t)u.bm;
                 if (n_blocks_of(pad) <= 0) { st.valid = 0; st.silent = st.unchecked = st.broken = 0xFF; }
                 out->st[pad] = st;
             }
         }
+        };
+        /* A tape that plays locks on the padding its history holds, frame after frame, and asks nothing else of the sweep: with a history at hand when
+         * the call began (a.state_snap) the table is made for that padding alone, and for all 81 only where it does not pass (or the frame carries a
+         * file tag).  The in-order pass says when a frame so treated would have needed more - another probable padding than the one assumed -, and the
+         * call is made again with full tables (pcm16_engine.inc). */
+        int hint = -1;
+        if (a.state_snap && !(seen & 3u)) {
+            PadHist hs; hist_load(hs, *a.state_snap, lane);
+            const uint32_t r = probable_padding(hs, lane);
+            if (hs.nvalid == STATS_DEPTH && r < (uint32_t)MAX_PAD_EI) hint = (int)r;
+        }
+        if (hint >= 0) {
+            if (lane < 64) { Stats z; z.valid = 0; z.silent = z.unchecked = z.broken = 0xFF; out->st[lane] = z; if (lane + 64 < MAX_PAD_EI) out->st[lane + 64] = z; }
+            __syncthreads();
+            sweep(hint, hint);
+            __syncthreads();
+            if (stats_verdict(out->st[hint], true) != DS_OK) hint = -1;
+        }
+        if (hint < 0) sweep(0, MAX_PAD_EI - 1);
+        ei_hint = hint;
         __syncthreads();
         {
             Stats m; m.valid = m.silent = m.unchecked = m.broken = 0; uint32_t mi = 0; uint16_t mb = 0;
@@ -923,6 +998,10 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
             pk.sweep_lock[0] = out->best_found[0] && m.unchecked <= MAX_UNCH_EI && m.silent < MAX_SIL_EI;
             pk.elig[0] = !((data[0] < MIN_FILL_EI && data[1] < MIN_FILL_EI) || (data[0] + data[1]) < (2 * MIN_FILL_EI)) && data[p1] >= MIN_FILL_EI && cfg.p_correction;
         }
+        if (ei && ei_hint >= 0) { pk._pad[0] = 1; pk._pad[1] = (uint8_t)ei_hint; }      /* ok[] says something about this padding only; no sweep winner */
+#ifdef SDV_EMU
+        if (ei && ei_hint >= 0 && getenv("SDV_P16_HINT_SKEW")) pk.ok[0] = pk.ok[1] = 0;        /* test hook: the in-order pass must find the table wanting and the call run again */
+#endif
         if (lane == 0) a.pick[kb] = pk;
     }
     /* 6. Control Bit offsets: the searches a lane per starting position, the rest on lane 0 */
@@ -951,57 +1030,6 @@ __device__ inline void analyse_body(const FrameArgs16s &a, uint32_t kb, int lane
 }
 
 /* ---- K-B: the decisions, frames in order, one wave ------------------------------------------------------------------------------- */
-/* the value lane `idx` holds, idx the same in every lane: v_readlane_b32 (no trip through LDS) */
-#ifdef SDV_EMU
-__device__ inline uint32_t lane_read(uint32_t v, uint32_t idx) { return (uint32_t)__shfl((int)v, (int)idx); }
-#else
-__device__ inline uint32_t lane_read(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)sdvs::uni(idx)); }
-#endif
-/* stats_padding (circarray<uint8_t, 65>, :243) in registers: lane i holds slot i (slot 64 is uniform), and a histogram of the values in
- * the ring - lane v counts value v and value 64 + v - so that getProbablePadding (:4368-4423) is one wave reduction */
-struct PadHist { uint32_t ring_lo, ring64, hist0, hist1; int pos, nvalid; };
-__device__ inline void hist_load(PadHist &h, const State16 &s, int lane)
-{
-    h.ring_lo = s.pad_ring[lane]; h.ring64 = s.pad_ring[64]; h.pos = s.pad_pos;
-    uint32_t h0 = 0, h1 = 0; int nv = 0;
-    for (int i = 0; i < STATS_DEPTH; i++) {
-        const uint32_t v = s.pad_ring[i];
-        nv += v != INVALID_PAD ? 1 : 0; h0 += v == (uint32_t)lane ? 1u : 0u; h1 += v == (uint32_t)lane + 64u ? 1u : 0u;
-    }
-    h.hist0 = h0; h.hist1 = h1; h.nvalid = nv;
-}
-__device__ inline void hist_store(const PadHist &h, State16 &s, int lane)
-{
-    s.pad_ring[lane] = (uint8_t)h.ring_lo;
-    if (lane == 0) { s.pad_ring[64] = (uint8_t)h.ring64; s.pad_pos = h.pos; }
-}
-__device__ inline void hist_reset(PadHist &h) { h.ring_lo = h.ring64 = INVALID_PAD; h.hist0 = h.hist1 = 0; h.pos = 0; h.nvalid = 0; }    /* clearPadStats (:4349-4352) */
-__device__ inline void push_padding(PadHist &h, uint32_t v, int lane)       /* updatePadStats(v, true) (:4355-4365) */
-{
-    const uint32_t in_lo = lane_read(h.ring_lo, (uint32_t)(h.pos < 64 ? h.pos : 0));
-    const uint32_t old = h.pos < 64 ? in_lo : h.ring64;
-    h.ring_lo = (h.pos < 64 && lane == h.pos) ? v : h.ring_lo;
-    h.ring64 = h.pos < 64 ? h.ring64 : v;
-    /* plain arithmetic on both counters (no conditional stores: they would be turned into a store through a selected address) */
-    const uint32_t lane_u = (uint32_t)lane;
-    h.hist0 = h.hist0 + (v == lane_u ? 1u : 0u) - ((old != INVALID_PAD && old == lane_u) ? 1u : 0u);
-    h.hist1 = h.hist1 + (v == lane_u + 64u ? 1u : 0u) - ((old != INVALID_PAD && old == lane_u + 64u) ? 1u : 0u);
-    h.nvalid += old == INVALID_PAD ? 1 : 0;
-    h.pos = (h.pos + 1) % STATS_DEPTH;
-}
-__device__ inline uint8_t probable_padding(const PadHist &h, int lane)      /* the value that occurs most often, the smallest of them on a tie */
-{
-    if (h.nvalid == 0) return INVALID_PAD;
-    /* the largest count, bit by bit (counts are below 128): lanes whose count lacks a bit that another one has drop out */
-    uint64_t a0 = ~0ull, a1 = (1ull << (MAX_PAD_EI - 64)) - 1;
-#pragma unroll
-    for (int bit = 6; bit >= 0; bit--) {
-        const uint64_t m0 = __ballot((h.hist0 >> bit) & 1u) & a0, m1 = __ballot((h.hist1 >> bit) & 1u) & a1;
-        if (m0 | m1) { a0 = m0; a1 = m1; }
-    }
-    return a0 ? (uint8_t)(__ffsll((unsigned long long)a0) - 1) : (uint8_t)(64 + __ffsll((unsigned long long)a1) - 1);
-}
-
 /* cutFieldTop (:836-865) as far as the sizes go: the field buffer itself is read through `cut` */
 __device__ inline void cut_field_top(uint16_t &f_size, uint16_t &cut, uint16_t cut_cnt)
 {
@@ -1279,6 +1307,7 @@ __device__ inline void choose_body(const FrameArgs16s &a, int lane)
     PadHist st;
     hist_load(st, *a.state, lane);
     const bool ei = a.cfg.format == SDV_P16_FORMAT_EI;
+    bool need_full = false;
     for (uint32_t c0 = 0; c0 < a.n_batch; c0 += 64) {
         const uint32_t nc = a.n_batch - c0 < 64 ? a.n_batch - c0 : 64u;
         uint4 q0 = { 0, 0, 0, 0 }, q1 = { 0, 0, 0, 0 };                /* ok[0], ok[1] | best_pad, sweep_lock, elig, marks */
@@ -1294,6 +1323,7 @@ __device__ inline void choose_body(const FrameArgs16s &a, int lane)
             const uint32_t P = s0 ? (uint32_t)__ffsll((unsigned long long)s0) - 1u : 64u + (uint32_t)(s1 ? __ffsll((unsigned long long)s1) - 1 : 0);
             const uint32_t marks_l = (q1.y >> 16) & 0xFF;
             bool fits = saturated && P < (ei ? (uint32_t)MAX_PAD_EI : (uint32_t)MAX_PAD_SI) && !(marks_l & (FF_NEW_FILE | FF_END_FILE));
+            if ((q1.y >> 24) & 1u) fits = fits && P == (q1.z & 0xFFu);         /* (a table made for one padding answers for that padding only) */
             uint32_t word = 0, pushes = 0;
             const int n_fields = ei ? 1 : 2;
             for (int p = 0; p < n_fields; p++) {
@@ -1382,6 +1412,7 @@ __device__ inline void choose_body(const FrameArgs16s &a, int lane)
                         if (mode) push_padding(st, pad, lane);
                     }
                     word |= (mode << (8 * p)) | (pad << (16 + 8 * p));
+                    if (((meta2 >> 24) & 1u) && mode != 1) need_full = true;        /* the frame's table was made for the padding the call began with: this frame needed more */
                 }
             }
             if ((uint32_t)lane == j) mine = word;
@@ -1389,6 +1420,7 @@ __device__ inline void choose_body(const FrameArgs16s &a, int lane)
         if ((uint32_t)lane < nc) *(uint32_t *)&a.choice[c0 + lane] = mine;
     }
     hist_store(st, *a.state, lane);
+    if (need_full && lane == 0) a.stat[3] = 1;          /* the call is made again with full tables (pcm16_engine.inc) */
 }
 /* K-B, the rest: a lane per frame */
 __device__ inline void finish_body(const FrameArgs16s &a, uint32_t kb)

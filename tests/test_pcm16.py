@@ -463,6 +463,50 @@ def test_emu_long_tape_matches_oracle(ei, hurt, emu, oracle_lib):
     assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
 
 
+@pytest.mark.parametrize("cuts", [(75, 110), (68, 69, 101, 140)])
+def test_emu_long_ei_tape_in_calls_matches_oracle(cuts, emu, oracle_lib):
+    """The EI tape above in several calls: from the second call on the padding history is full when a call begins, so the analysis makes its padding
+    tables for that one padding (round 4) - all of them again for the hurt frames (70, 71, 100, 131), and the whole call once more where the history
+    says something else in the middle of it (the second tape: its later frames are padded otherwise)."""
+    recs = _long_tape(True, True)
+    st = p16.default_settings(format=2)
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", recs, st)
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    eng = emu.sdv_engine_create(0)
+    got_p, got_f = [], []
+    lo = 0
+    for k, c in enumerate(list(cuts) + [150]):
+        hi = int(ends[c - 1]) + 1
+        rc, pairs, frames = ea.emu_pcm16_stitch(emu, eng, recs[lo:hi], st if k == 0 else None)
+        assert rc == 0
+        got_p.append(pairs); got_f.append(frames)
+        lo = hi
+    emu.sdv_engine_destroy(eng)
+    pairs, frames = np.concatenate(got_p), np.concatenate(got_f)
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
+def test_emu_ei_call_runs_again_with_full_tables(emu, oracle_lib, monkeypatch, capfd):
+    """The way back when a frame needed more than the one padding its table was made for: the emulator build's hook makes every such frame say so
+    (SDV_P16_HINT_SKEW), the call then runs once more with full tables - the same answer, and the trace shows the second attempt."""
+    recs = _long_tape(True, True)
+    st = p16.default_settings(format=2)
+    want_p, want_f = p16.run_cpu(oracle_lib, "orc_", recs, st)
+    ends = np.nonzero(recs["service_type"] == 5)[0]
+    cut = int(ends[79]) + 1
+    eng = emu.sdv_engine_create(0)
+    rc, p0, f0 = ea.emu_pcm16_stitch(emu, eng, recs[:cut], st)
+    assert rc == 0
+    monkeypatch.setenv("SDV_P16_HINT_SKEW", "1"); monkeypatch.setenv("SDV_P16_HINT_TRACE", "1")
+    rc, p1, f1 = ea.emu_pcm16_stitch(emu, eng, recs[cut:], None)
+    assert rc == 0
+    emu.sdv_engine_destroy(eng)
+    err = capfd.readouterr().err
+    assert "attempt 0: hint on" in err and "needs full tables: 1" in err and "attempt 1: hint off" in err, err
+    pairs, frames = np.concatenate([p0, p1]), np.concatenate([f0, f1])
+    assert _same(pairs, frames, want_p, want_f), _diff(pairs, frames, want_p, want_f)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ei", [False, True])
 def test_gpu_long_damaged_tape_matches_oracle(ei, oracle_lib):
