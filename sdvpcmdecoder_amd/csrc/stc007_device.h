@@ -196,6 +196,13 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #else
 #define SDV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
+#ifndef SDV_OPAQUE
+#ifdef SDV_EMU
+#define SDV_OPAQUE(x) ((void)0)
+#else
+#define SDV_OPAQUE(x) asm volatile("" : "+v"(x))      /* the compiler knows nothing about x from here on: what is derived from it is worked out behind this point */
+#endif
+#endif
 #ifdef SDV_K1_STAMPS        /* developer aid (variant builds only): cycles per part of a frame, summed over the frames of a launch (0..7 the frame loop, 8..15 the general path) */
 __device__ unsigned long long sdv_k1_cycles[24];
 /* summed per frame in LDS and added to the totals once, at the end of the frame: an atomic per stamp on one address held up every load
@@ -1491,27 +1498,35 @@ struct V2D {
  * count, among the keys that still match the bits chosen so far, those with a 0 there - 32 passes over n / 64 keys per lane, whatever n is.
  * (Through round 3 every lane ranked its key against all n: n * n / 64 reads - a frame whose lines had found two different windows, 486 keys,
  * took 14 million cycles for this one number and held its whole launch up; the sub-line lists of PCM-16x0 are three times as long.) */
-__device__ inline bool median_keys(const uint32_t *keys, int n, uint32_t *out_key)
+struct MedianKey { bool ok; uint32_t key; };
+__device__ inline MedianKey median_keys_of(const uint32_t *keys, int n)
 {
-    if (n <= 0) return false;
-    const int lane = lane_id();
+    MedianKey out; out.ok = false; out.key = 0;
+    if (n <= 0) return out;
+    /* (the lane number made opaque here: the function is inlined at five places of the frame loop, and what its loops derive from the lane number
+     * - unrolled strides, trip counts - would be worked out once ahead of the loop and kept in registers the loop does not have) */
+    int lane = lane_id();
+    SDV_OPAQUE(lane);
     /* common case: every entry identical (steady tuning) -> one ballot */
     const uint32_t k0 = keys[0];
     bool differs = false;
+#pragma unroll 1
     for (int j = lane; j < n; j += 64) differs = differs || (keys[j] != k0);
-    if (__ballot(differs) == 0ull) { *out_key = uniu(k0); return true; }
+    if (__ballot(differs) == 0ull) { out.ok = true; out.key = uniu(k0); return out; }
     uint32_t target = (uint32_t)(n / 2);
     if (n <= 64) {              /* the short histories (9 lines, 16 frames): a lane per key, its rank by one pass over the others */
         const uint32_t ki = keys[lane < n ? lane : 0];
         uint32_t less = 0, leq = 0;
         for (int j = 0; j < n; j++) { const uint32_t kj = keys[j]; less += (kj < ki); leq += (kj <= ki); }
         const uint64_t m = __ballot(lane < n && less <= target && target < leq);
-        *out_key = uniu((uint32_t)__shfl((int)ki, m ? __ffsll((unsigned long long)m) - 1 : 0));
-        return m != 0ull;
+        out.key = uniu((uint32_t)__shfl((int)ki, m ? __ffsll((unsigned long long)m) - 1 : 0));
+        out.ok = m != 0ull;
+        return out;
     }
     uint32_t prefix = 0, mask = 0;
     for (int bit = 31; bit >= 0; bit--) {
         uint32_t zeros = 0;
+#pragma unroll 2
         for (int j = lane; j < n; j += 64) { const uint32_t k = keys[j]; zeros += ((k & mask) == prefix && ((k >> bit) & 1u) == 0u) ? 1u : 0u; }
         uint32_t total = 0;     /* the lanes' counts (< 64 each for n < 4096) summed bit plane by bit plane: six ballots instead of six shuffles */
 #pragma unroll
@@ -1519,9 +1534,10 @@ __device__ inline bool median_keys(const uint32_t *keys, int n, uint32_t *out_ke
         if (target >= total) { target -= total; prefix |= 1u << bit; }
         mask |= 1u << bit;
     }
-    *out_key = prefix;
-    return true;
+    out.ok = true; out.key = prefix;
+    return out;
 }
+__device__ __forceinline__ bool median_keys(const uint32_t *keys, int n, uint32_t *out_key) { const MedianKey m = median_keys_of(keys, n); *out_key = m.key; return m.ok; }
 
 __device__ inline Coords key_to_coords(uint32_t k, bool doubled) { Coords c; c.start = key_start(k); c.stop = key_stop(k); c.doubled = doubled; return c; }
 
@@ -1652,7 +1668,7 @@ __device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, L
 /* END_FRAME bookkeeping (videotodigital.cpp:1636-1714) */
 /* uniform_key: every entry of fv_keys is known to hold this key (a frame that was captured whole) - its median without reading them */
 __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, uint32_t frame_no, const uint32_t *fv_keys, const uint32_t *fi_keys, sdv_frame_stats *out,
-                                  const uint32_t *uniform_key = nullptr)
+                                  bool have_uniform_key = false, uint32_t uniform_key = 0)
 {
     __syncthreads();            /* the coordinate keys of the frame's lines were stored to global memory by other lanes than the ones that read them below: wait for them */
     if (v.q_pcm_odd > v.q_odd) v.q_pcm_odd = v.q_odd;
@@ -1662,7 +1678,7 @@ __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, u
     bool not_sure = false;
     uint32_t k;
     coords_clear(v.frame_avg);
-    if (uniform_key && v.nfv > 0) v.frame_avg = key_to_coords(*uniform_key, a.doubled != 0);
+    if (have_uniform_key && v.nfv > 0) v.frame_avg = key_to_coords(uniform_key, a.doubled != 0);
     else if (median_keys(fv_keys, v.nfv, &k)) v.frame_avg = key_to_coords(k, a.doubled != 0);
     if (coords_valid(v.frame_avg)) {
         SDV_WAVE_SYNC();
@@ -1717,33 +1733,45 @@ __device__ inline void v2d_make_uniform(V2D &v)
 
 /* The model of the chain (engine.inc, chain speculation): the state `m` frames behind s0 when every line of those frames decodes with the inherited
  * tuning - presets unchanged, the 9-entry window saturated with the one coordinate pair, one entry of it per frame pushed into the 16-frame history. */
-__device__ inline sdv_v2d_state predict_state(const sdv_v2d_state &s0, int m, bool doubled, uint8_t min_ref_lvl)
+/* (halfword by halfword: the frame kernels make a state a dword per lane, the predict kernel a whole state per thread - one model for both) */
+enum { V2D_STATE_HALVES = sizeof(sdv_v2d_state) / 2, V2D_H_LAST = 9, V2D_H_LONG = 27 };      /* halfword 9: last_valid[0], halfword 27: long_valid[0] */
+static_assert(offsetof(sdv_v2d_state, last_valid) == 2 * V2D_H_LAST && offsetof(sdv_v2d_state, long_valid) == 2 * V2D_H_LONG && offsetof(sdv_v2d_state, n_last_valid) == 12 &&
+              offsetof(sdv_v2d_state, long_valid_doubled_mask) == 16 && sizeof(sdv_v2d_state) == 120, "the chain state is put together halfword by halfword");
+__device__ inline uint16_t predict_half(const sdv_v2d_state &s0, int m, bool doubled, uint8_t min_ref_lvl, int h)
 {
-    sdv_v2d_state p = s0;
+    const uint16_t *raw = reinterpret_cast<const uint16_t *>(&s0);
     /* What the frames in between will measure: what the last frame measured - the newest entry of the multi-frame history (on a
      * tape that plays every entry is the same; after a jump of the data window the history is a mix for 16 frames, and a frame
      * leaves the binarizer tuned to what it saw, not to the median it was started with, videotodigital.cpp:808-821, :1369) */
     int16_t cs = s0.bin.in_def_start, ce = s0.bin.in_def_stop;
-    if (s0.n_long_valid > 0) { cs = s0.long_valid[s0.n_long_valid - 1].data_start; ce = s0.long_valid[s0.n_long_valid - 1].data_stop; }
+    const int n_long0 = s0.n_long_valid;
+    if (n_long0 > 0) { cs = (int16_t)raw[V2D_H_LONG + 2 * (n_long0 - 1)]; ce = (int16_t)raw[V2D_H_LONG + 2 * (n_long0 - 1) + 1]; }
     const bool steady = (s0.bin.in_def_reference >= min_ref_lvl) && pod_coords_valid(cs, ce) && !s0.reset_stats;
-    if (steady) {
-        p.bin.in_def_start = cs; p.bin.in_def_stop = ce; p.bin.in_def_from_doubled = doubled ? 1 : 0;
-        p.n_last_valid = COORD_HISTORY_DEPTH;
-        for (int i = 0; i < COORD_HISTORY_DEPTH; i++) { p.last_valid[i].data_start = cs; p.last_valid[i].data_stop = ce; }
-        const int total = (int)s0.n_long_valid + m;
-        const int keep = total > COORD_LONG_HISTORY ? COORD_LONG_HISTORY : total;
-        const int drop = total - keep;             /* oldest entries that fell out of the window */
-        for (int i = 0; i < COORD_LONG_HISTORY; i++) {
-            const int src = i + drop;
-            if (i >= keep) { p.long_valid[i].data_start = 0; p.long_valid[i].data_stop = 0; }
-            else if (src < (int)s0.n_long_valid) p.long_valid[i] = s0.long_valid[src];
-            else { p.long_valid[i].data_start = cs; p.long_valid[i].data_stop = ce; }
-        }
-        p.n_long_valid = (uint8_t)keep;
-        const uint16_t lm = doubled ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : 0, gm = doubled ? (uint16_t)((1u << keep) - 1u) : 0;
-        p.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); p.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
-        p.long_valid_doubled_mask = gm;
+    const uint16_t same = raw[h];
+    if (!steady) return same;
+    const int total = n_long0 + m;
+    const int keep = total > COORD_LONG_HISTORY ? COORD_LONG_HISTORY : total;
+    const int drop = total - keep;             /* oldest entries that fell out of the window */
+    if (h == 2) return (uint16_t)cs;
+    if (h == 3) return (uint16_t)ce;
+    if (h == 4) return (uint16_t)((same & 0xFF00u) | (doubled ? 1u : 0u));                          /* in_def_from_doubled */
+    if (h == 6) return (uint16_t)(COORD_HISTORY_DEPTH | (keep << 8));                               /* n_last_valid, n_long_valid */
+    if (h == 7) return doubled ? (uint16_t)((1u << COORD_HISTORY_DEPTH) - 1u) : (uint16_t)0;        /* last_valid_doubled_mask */
+    if (h == 8) return doubled ? (uint16_t)((1u << keep) - 1u) : (uint16_t)0;                       /* long_valid_doubled_mask */
+    if (h >= V2D_H_LAST && h < V2D_H_LONG) return (uint16_t)(((h - V2D_H_LAST) & 1) ? ce : cs);
+    if (h >= V2D_H_LONG && h < V2D_H_LONG + 2 * COORD_LONG_HISTORY) {
+        const int i = (h - V2D_H_LONG) >> 1, which = (h - V2D_H_LONG) & 1, src = i + drop;
+        if (i >= keep) return 0;
+        if (src < n_long0) return raw[V2D_H_LONG + 2 * src + which];
+        return (uint16_t)(which ? ce : cs);
     }
+    return same;
+}
+__device__ inline sdv_v2d_state predict_state(const sdv_v2d_state &s0, int m, bool doubled, uint8_t min_ref_lvl)
+{
+    sdv_v2d_state p;
+    uint16_t *out = reinterpret_cast<uint16_t *>(&p);
+    for (int h = 0; h < (int)V2D_STATE_HALVES; h++) out[h] = predict_half(s0, m, doubled, min_ref_lvl, h);
     return p;
 }
 
@@ -1769,60 +1797,81 @@ __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state 
     v.q_line_length = v.q_odd = v.q_even = v.q_pcm_odd = v.q_pcm_even = v.q_bad_odd = v.q_bad_even = v.q_dup_odd = v.q_dup_even = 0;
     v2d_make_uniform(v);
 }
+/* halfword h of the outgoing chain state */
+__device__ inline uint32_t v2d_state_half(const V2D &v, const WaveLds &lds, const FrameArgs &a, int h)
+{
+    if (h >= V2D_H_LAST && h < V2D_H_LONG + 2 * COORD_LONG_HISTORY) {
+        const bool lng = h >= V2D_H_LONG;
+        const int k = h - (lng ? V2D_H_LONG : V2D_H_LAST), e = k >> 1;
+        if (e >= (lng ? v.n_long : v.n_last)) return 0;
+        const uint32_t key = lng ? lds.long_keys[e] : lds.lv_keys[e];
+        return (uint32_t)(uint16_t)((k & 1) ? key_stop(key) : key_start(key));
+    }
+    switch (h) {
+    case 0: return (uint32_t)v.bin.in_black | ((uint32_t)v.bin.in_white << 8);
+    case 1: return (uint32_t)v.bin.in_ref;                                                  /* (sdv_bin_state::do_ref_lvl_sweep = 0: the flag has its own field) */
+    case 2: return (uint32_t)(uint16_t)v.bin.in_coord.start;
+    case 3: return (uint32_t)(uint16_t)v.bin.in_coord.stop;
+    case 4: return v.bin.in_coord.doubled ? 1u : 0u;
+    case 5: return (v.bin.do_ref_lvl_sweep ? 1u : 0u) | (v.reset_stats ? 0x100u : 0u);
+    case 6: return (uint32_t)(uint8_t)v.n_last | ((uint32_t)(uint8_t)v.n_long << 8);
+    case 7: return a.doubled ? (uint32_t)(uint16_t)((1u << v.n_last) - 1u) : 0u;
+    case 8: return a.doubled ? (uint32_t)(uint16_t)((1u << v.n_long) - 1u) : 0u;
+    default: return 0;                                                                      /* _pad */
+    }
+}
+/* The state goes out a dword per lane (lanes 0 .. 29), and the check of the chain - was the next frame started from this state? - is a ballot.  (It
+ * was put together by lane 0 alone on the stack before: the histories are indexed by how full they are, and that was the lean kernel's scratch memory.) */
 __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a, bool unsettled = false)
 {
-    if (lane_id() != 0) return;
-    sdv_v2d_state o;
-    o.bin.in_def_black = v.bin.in_black; o.bin.in_def_white = v.bin.in_white; o.bin.in_def_reference = v.bin.in_ref; o.bin.do_ref_lvl_sweep = 0;
-    o.bin.in_def_start = v.bin.in_coord.start; o.bin.in_def_stop = v.bin.in_coord.stop;
-    o.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.bin._pad2 = 0;
-    o.do_ref_lvl_sweep = v.bin.do_ref_lvl_sweep ? 1 : 0; o.reset_stats = v.reset_stats ? 1 : 0;
-    o.n_last_valid = (uint8_t)v.n_last; o.n_long_valid = (uint8_t)v.n_long;
-    uint16_t lm = a.doubled ? (uint16_t)((1u << v.n_last) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
-    o.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); o.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
-    o.long_valid_doubled_mask = gm;
-    for (int i = 0; i < COORD_HISTORY_DEPTH; i++) {
-        if (i < v.n_last) { o.last_valid[i].data_start = key_start(lds.lv_keys[i]); o.last_valid[i].data_stop = key_stop(lds.lv_keys[i]); }
-        else { o.last_valid[i].data_start = 0; o.last_valid[i].data_stop = 0; }
-    }
-    for (int i = 0; i < COORD_LONG_HISTORY; i++) {
-        if (i < v.n_long) { o.long_valid[i].data_start = key_start(lds.long_keys[i]); o.long_valid[i].data_stop = key_stop(lds.long_keys[i]); }
-        else { o.long_valid[i].data_start = 0; o.long_valid[i].data_stop = 0; }
-    }
-    o._pad[0] = o._pad[1] = 0;
-    *s = o;
+    enum { NDW = sizeof(sdv_v2d_state) / 4 };
+    const int lane = lane_id();
+    const bool in = lane < NDW;
+    const int dw = in ? lane : 0;
+    SDV_WAVE_SYNC();            /* (the histories were written by lane 0) */
+    const uint32_t mine = v2d_state_half(v, lds, a, 2 * dw) | (v2d_state_half(v, lds, a, 2 * dw + 1) << 16);
+    const int f = (int)(s - a.states_out);
+    if (in) reinterpret_cast<uint32_t *>(s)[dw] = mine;
     /* the last frame of the call: its state also behind the flags, where the host's one read-back per round finds it (engine.inc: tail_ofs) */
-    if (s == &a.states_out[a.n_total - 1]) *reinterpret_cast<sdv_v2d_state *>(a.flag + (((size_t)a.n_total + 15) & ~(size_t)15)) = o;
+    if (in && f == a.n_total - 1) reinterpret_cast<uint32_t *>(a.flag + (((size_t)a.n_total + 15) & ~(size_t)15))[dw] = mine;
     /* the check of the chain, by the frame itself: was the next frame started from this state?  (and: is it the state the frame itself was started
      * from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
-    const int f = (int)(s - a.states_out);
     uint8_t fl = VF_OK;
-    uint32_t mine[sizeof(sdv_v2d_state) / 4];
-    __builtin_memcpy(mine, &o, sizeof(o));
     if (f + 1 < a.n_total) {
-        const uint32_t *next = (const uint32_t *)&a.states_in[f + 1];
-        bool same = true;
-        for (unsigned i = 0; i < sizeof(sdv_v2d_state) / 4; i++) same = same && (mine[i] == next[i]);
-        if (!same) fl = VF_BREAK;
+        const uint32_t next = reinterpret_cast<const uint32_t *>(&a.states_in[f + 1])[dw];
+        if (__ballot(in && next != mine) != 0ull) fl = VF_BREAK;
     }
     if (fl == VF_BREAK) {       /* (only asked of a frame whose link broke: on a tape that plays this is skipped) */
         /* ... "what it was started from" as the model sees it: one frame on, with the inherited tuning */
-        const sdv_v2d_state exp = predict_state(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl);
-        uint32_t own[sizeof(sdv_v2d_state) / 4];
-        __builtin_memcpy(own, &exp, sizeof(exp));
+        const uint32_t own = (uint32_t)predict_half(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw) |
+                             ((uint32_t)predict_half(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw + 1) << 16);
         /* dword 0: in_def_black, in_def_white, in_def_reference (+ a pad byte); dword 2, byte 2: do_ref_lvl_sweep - the rest are coordinates and histories */
-        bool same = true;
-        for (unsigned i = 1; i < sizeof(sdv_v2d_state) / 4; i++) same = same && ((i == 2 ? (mine[i] ^ own[i]) & 0xFF00FFFFu : mine[i] ^ own[i]) == 0);
-        if (!same) fl |= VF_MOVED;
-        if (mine[0] != own[0] || ((mine[2] ^ own[2]) & 0x00FF0000u)) fl |= VF_RETUNED;
+        const uint32_t d = mine ^ own;
+        if (__ballot(in && dw >= 1 && (dw == 2 ? d & 0xFF00FFFFu : d) != 0) != 0ull) fl |= VF_MOVED;
+        if (__ballot(in && ((dw == 0 && d != 0) || (dw == 2 && (d & 0x00FF0000u) != 0))) != 0ull) fl |= VF_RETUNED;
     }
     if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
-    a.flag[f] = fl;
-    if (a.refs) {
-        /* (one pair pushed into a full history, the rest moved down a slot: counted where it happens - reading the incoming history again here cost 3 % of the kernel) */
-        const bool pushed = v.long_pushes == 1 && v.n_long == COORD_LONG_HISTORY && !a.doubled;
-        a.refs[3 * f] = a.states_in[f].bin.in_def_reference; a.refs[3 * f + 1] = o.bin.in_def_reference; a.refs[3 * f + 2] = pushed ? 1 : 0;
+    if (lane == 0) {
+        a.flag[f] = fl;
+        if (a.refs) {
+            /* (one pair pushed into a full history, the rest moved down a slot: counted where it happens - reading the incoming history again here cost 3 % of the kernel) */
+            const bool pushed = v.long_pushes == 1 && v.n_long == COORD_LONG_HISTORY && !a.doubled;
+            a.refs[3 * f] = a.states_in[f].bin.in_def_reference; a.refs[3 * f + 1] = v.bin.in_ref; a.refs[3 * f + 2] = pushed ? 1 : 0;
+        }
     }
+}
+/* a frame given up: its state goes out as it came in, marked (dword 29, byte 2 = _pad[0]) */
+__device__ inline void v2d_give_up(const FrameArgs &a, int f)
+{
+    enum { NDW = sizeof(sdv_v2d_state) / 4 };
+    static_assert(offsetof(sdv_v2d_state, _pad) == 118, "the mark of a frame given up");
+    const int lane = lane_id();
+    if (lane < NDW) {
+        uint32_t d = reinterpret_cast<const uint32_t *>(&a.states_in[f])[lane];
+        if (lane == NDW - 1) d = (d & 0xFF00FFFFu) | ((uint32_t)0xA5 << 16);      /* STATE_ABORTED */
+        reinterpret_cast<uint32_t *>(&a.states_out[f])[lane] = d;
+    }
+    if (lane == 0) a.flag[f] = VF_ABORTED;
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
@@ -1855,16 +1904,34 @@ __device__ inline void row_commit(WaveLds &lds, const RowPrefetch &pf, int width
         uint4 *dst = (uint4 *)lds.px;
         dst[lane] = pf.v0;                      /* lanes past the row write into the unused end of px (64 x 16 <= SDV_MAX_WIDTH) */
         if (width > 1024) { int nvec = width >> 4; if (lane + 64 < nvec) dst[lane + 64] = pf.v1; }
-        if (width & 15) for (int i = (width & ~15) + lane; i < width; i += 64) lds.px[i] = row[i];
+        /* (the byte loops are the odd geometries' path: what they derive from the lane number is worked out here, not ahead of the frame loop, which
+         * has no registers to keep it in) */
+        if (width & 15) {
+            int i0 = (width & ~15) + lane;
+            SDV_OPAQUE(i0);
+#pragma unroll 1
+            for (int i = i0; i < width; i += 64) lds.px[i] = row[i];
+        }
     } else {
-        for (int i = lane; i < width; i += 64) lds.px[i] = row[i];
+        int i0 = lane;
+        SDV_OPAQUE(i0);
+#pragma unroll 1
+        for (int i = i0; i < width; i += 64) lds.px[i] = row[i];
     }
     SDV_WAVE_SYNC();
 }
 
 __device__ inline void emit_record(const Line &wl, sdv_line_rec *dst)
 {
-    if (lane_id() == 0) { sdv_line_rec r; line_to_rec(wl, &r); *dst = r; }
+    if (lane_id() == 0) {
+        sdv_line_rec r; line_to_rec(wl, &r);
+        /* (a service line's record is constants but for three fields, and the compiler sets such a record up dwords ahead of the loops it is stored
+         * in - in registers the frame loop has to spill.  With one field it cannot see through, the record is made where it is stored.) */
+        uint32_t fno = r.frame_number; SDV_OPAQUE(fno); r.frame_number = fno;
+        uint32_t ref = r.ref_level; SDV_OPAQUE(ref); r.ref_level = (uint8_t)ref;
+        uint32_t crc = r.calc_crc; SDV_OPAQUE(crc); r.calc_crc = (uint16_t)crc;
+        *dst = r;
+    }
 }
 
 /* ======================================================================================== */
@@ -2246,9 +2313,21 @@ __device__ inline bool batch_eligible(const FrameArgs &a, const WaveLds &lds, co
     return true;
 }
 
-/* phase B for `n` (1..64) decoded lines: lane k owns line k of the batch */
-__device__ inline void batch_finish(const FrameArgs &a, V2D &v, const BatchLane &bl, int n, uint32_t frame_no, uint16_t first_line_num,
-                                    uint32_t *fv_keys, sdv_line_rec *rec)
+/* Where phase B stages the records of a batch on their way out: 64 slots of 16 bytes in the per-wave LDS, behind the lines the
+ * whole-frame capture parks (five chunks of 64 lines x four words) and inside the room of the general path's sweep table, which no
+ * path holds anything in across a batch. */
+enum { REC_STAGE_OFS = 5120, REC_STAGE_BYTES = 1024 };
+static_assert(REC_STAGE_OFS >= ((SDV_MAX_HEIGHT / 2 + 63) / 64) * 4 * 64 * sizeof(uint32_t), "the parked lines of a field of SDV_MAX_HEIGHT / 2 lines end in front of the record stage");
+static_assert(REC_STAGE_OFS >= SDV_PX_BYTES && REC_STAGE_OFS + REC_STAGE_BYTES <= offsetof(WaveLds, crc_stats), "the record stage lies behind the staged scanlines and in front of the histories");
+#ifndef SDV_COALESCED_RECORDS
+#define SDV_COALESCED_RECORDS 1     /* 0: every lane stores its own record (three 16-byte stores at a pitch of 48 bytes) */
+#endif
+
+/* phase B for `n` (1..64) decoded lines: lane k owns line k of the batch.  write_keys: the lines' coordinate keys go to the frame's list (the
+ * whole-frame capture leaves them out: while it lasts every line has the one pair the frame was started with, and the list is filled in
+ * only when the capture ends early) */
+__device__ inline void batch_finish(const FrameArgs &a, WaveLds &lds, V2D &v, const BatchLane &bl, int n, uint32_t frame_no, uint16_t first_line_num,
+                                    uint32_t *fv_keys, sdv_line_rec *rec, bool write_keys = true)
 {
     const sdv_bin_preset &ps = a.preset;
     Bin &b = v.bin;
@@ -2284,33 +2363,55 @@ __device__ inline void batch_finish(const FrameArgs &a, V2D &v, const BatchLane 
     }
     uint64_t dup_m = __ballot(active && dup), bad_m = __ballot(active && forced_bad);
     uint64_t setgood_m = __ballot(active && ((a.check_line_copy && first_unsafe) || !forced_bad));
-    /* record */
-    if (active) {
-        uint8_t h = (uint8_t)((bl.meta >> 16) & 0xF), sft = (uint8_t)((bl.meta >> 20) & 0xF);
-        sdv_line_rec r;
-        r.frame_number = frame_no; r.line_number = (uint16_t)(first_line_num + 2 * lane);
-        for (int i = 0; i < 8; i++) r.words[i] = w[i];
-        r.words[8] = (uint16_t)(bl.meta & 0xFFFF);
-        r.calc_crc = (uint16_t)(bl.meta & 0xFFFF);
-        r.data_start = b.in_coord.start; r.data_stop = b.in_coord.stop;
-        r.marker_start_bg_coord = 0; r.marker_start_ed_coord = 0; r.marker_stop_ed_coord = 0;
-        r.black_level = b.in_black; r.white_level = b.in_white;
-        r.ref_low = get_low_level(b.in_ref, h); r.ref_level = b.in_ref; r.ref_high = get_high_level(b.in_ref, h);
-        r.hysteresis_depth = h; r.shift_stage = sft; r.service_type = SDV_SRV_NO;
-        r.mark_st_stage = MARK_ST_START; r.mark_ed_stage = MARK_ED_START;
-        r.flags = (uint8_t)(SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | (forced_bad ? SDV_LF_FORCED_BAD : SDV_LF_CRC_VALID) | (doubled ? SDV_LF_FROM_DOUBLED : 0));
-        r.word_state = forced_bad ? 0 : (uint8_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
+    /* the record (sdv_line_rec, 48 bytes) as its twelve dwords */
+    const uint32_t h = (bl.meta >> 16) & 0xF, sft = (bl.meta >> 20) & 0xF, crc = bl.meta & 0xFFFF;
+    const uint32_t lf = SDV_LF_BY_EXT_TUNE | SDV_LF_BW_SET | (forced_bad ? SDV_LF_FORCED_BAD : SDV_LF_CRC_VALID) | (doubled ? SDV_LF_FROM_DOUBLED : 0);
+    const uint32_t wst = forced_bad ? 0u : (uint32_t)(SDV_WS_WORD_CRC | SDV_WS_WORD_VALID);
+    uint4 g0, g1, g2;
+    g0.x = frame_no;
+    g0.y = (uint32_t)(uint16_t)(first_line_num + 2 * lane) | (p01 << 16);
+    g0.z = (p01 >> 16) | (p23 << 16);
+    g0.w = (p23 >> 16) | (p45 << 16);
+    g1.x = (p45 >> 16) | (p67 << 16);
+    g1.y = (p67 >> 16) | (crc << 16);                            /* words[7], words[8] = the CRC as read (= as calculated: the line read) */
+    g1.z = crc | ((uint32_t)(uint16_t)b.in_coord.start << 16);   /* calc_crc, data_start */
+    g1.w = (uint32_t)(uint16_t)b.in_coord.stop;                  /* data_stop, marker_start_bg_coord = 0 */
+    g2.x = 0;                                                    /* marker_start_ed_coord, marker_stop_ed_coord */
+    g2.y = (uint32_t)b.in_black | ((uint32_t)b.in_white << 8) | ((uint32_t)get_low_level(b.in_ref, (uint8_t)h) << 16) | ((uint32_t)b.in_ref << 24);
+    g2.z = (uint32_t)get_high_level(b.in_ref, (uint8_t)h) | (h << 8) | (sft << 16) | ((uint32_t)SDV_SRV_NO << 24);
+    g2.w = (uint32_t)MARK_ST_START | ((uint32_t)MARK_ED_START << 8) | (lf << 16) | (wst << 24);
+    static_assert(sizeof(sdv_line_rec) == 48 && offsetof(sdv_line_rec, words) == 6 && offsetof(sdv_line_rec, calc_crc) == 24 && offsetof(sdv_line_rec, data_stop) == 28 &&
+                  offsetof(sdv_line_rec, black_level) == 36 && offsetof(sdv_line_rec, ref_high) == 40 && offsetof(sdv_line_rec, mark_st_stage) == 44 && offsetof(sdv_line_rec, word_state) == 47,
+                  "the record is put together dword by dword");
+    uint4 *const dst = (uint4 *)rec;
 #if SDV_NT_RECORDS && !defined(SDV_EMU)
-        {   /* the records are written once and read by a later kernel: streaming stores */
-            typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
-            const nt_u32x4 *src = (const nt_u32x4 *)&r; nt_u32x4 *dst = (nt_u32x4 *)&rec[lane];
-            __builtin_nontemporal_store(src[0], dst); __builtin_nontemporal_store(src[1], dst + 1); __builtin_nontemporal_store(src[2], dst + 2);
-        }
+    /* the records are written once and read by a later kernel: streaming stores */
+    auto put = [](const uint4 &val, uint4 *where) { typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4))); nt_u32x4 t = { val.x, val.y, val.z, val.w }; __builtin_nontemporal_store(t, (nt_u32x4 *)where); };
 #else
-        rec[lane] = r;
+    auto put = [](const uint4 &val, uint4 *where) { *where = val; };
 #endif
-        fv_keys[v.nfv + lane] = coords_key(b.in_coord.start, b.in_coord.stop);
+#if SDV_COALESCED_RECORDS
+    {   /* The n records are 3 n pieces of 16 bytes; piece p lies in lane p / 3.  They change lanes through the stage, 64 pieces at a time, so that
+         * a store instruction covers 1 KB of consecutive addresses (lane i writes piece 64 c + i) - stored from the lanes that made them a store
+         * covers every third piece of 3 KB, and the three stores of a record reach the memory side as three partial lines. */
+        uint4 *const stage = (uint4 *)((uint8_t *)&lds + REC_STAGE_OFS);
+        const int pieces = 3 * n;
+        for (int c = 0; 64 * c < pieces; c++) {
+            SDV_WAVE_SYNC();
+            const int p0 = 3 * lane - 64 * c;           /* my first piece, counted from the start of this pass */
+            if (active) {
+                if ((unsigned)p0 < 64u) stage[p0] = g0;
+                if ((unsigned)(p0 + 1) < 64u) stage[p0 + 1] = g1;
+                if ((unsigned)(p0 + 2) < 64u) stage[p0 + 2] = g2;
+            }
+            SDV_WAVE_SYNC();
+            if (64 * c + lane < pieces) put(stage[lane], dst + 64 * c + lane);
+        }
     }
+#else
+    if (active) { put(g0, dst + 3 * lane); put(g1, dst + 3 * lane + 1); put(g2, dst + 3 * lane + 2); }
+#endif
+    if (active && write_keys) fv_keys[v.nfv + lane] = coords_key(b.in_coord.start, b.in_coord.stop);
     /* wave-uniform state after the n lines */
     int nd = __popcll(dup_m), nb = __popcll(bad_m);
     v.nfv += n;
@@ -2366,7 +2467,7 @@ __device__ __attribute__((noinline)) void empty_line(SlowCtx *c, WaveLds *lds, u
  * occupancy at 3 waves per SIMD; without it the loop fits 5.  A lean wave that meets a line it cannot take through the fast
  * paths gives the frame up: it marks its outgoing state (sdv_v2d_state::_pad[0]) and the engine decodes from that frame on
  * with the full kernel. */
-enum { STATE_ABORTED = 0xA5 };
+enum { STATE_ABORTED = 0xA5 };       /* (v2d_give_up) */
 /* sc (full kernel): the context of the general path, in LDS - one copy for the wave.  (It lived on the stack of the frame loop before: scratch memory,
  * every field the general path read of it a trip to global memory, a few dozen of them one behind the other per line: C3 PAL tape 28.4 -> 25.6 ms.)
  * The general path is wave-uniform code: every lane computes the same values and stores them to the same place, in lockstep.  The emulator runs the
@@ -2400,7 +2501,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     v2d_begin_frame(v, a, lds);
     if (frame_is_empty(a, f)) {
         if (kLean) {            /* to the full kernel: the bookkeeping of lines that do not read lives there */
-            if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
+            v2d_give_up(a, f);
             return;
         } else {
             uint16_t ln = 0;
@@ -2482,8 +2583,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             K1_T(t_cap);
             const int n0 = n_field[0], n1 = n_field[1];
             const int n_chunks = (n0 + 63) / 64;
-            uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][5 words][lane], over px + hist + sweep + park_room */
-            static_assert(offsetof(WaveLds, crc_stats) >= ((SDV_MAX_HEIGHT / 2 + 63) / 64) * 5 * 64 * sizeof(uint32_t), "the parked lines of a field of SDV_MAX_HEIGHT / 2 lines must fit in front of the histories");
+            uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][4 words][lane], over px + hist + the front of sweep (up to REC_STAGE_OFS) */
             uint32_t ok1_packed = 0;                            /* lines of field 1 that read, per chunk (7 bits each) */
             const uint32_t rs = (uint32_t)a.row_stride;         /* offsets inside a frame fit 32 bits (checked above) */
             const uint32_t lo = pre.ref_low, hi = pre.ref_high;
@@ -2537,14 +2637,14 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 ok1_packed |= (uint32_t)n_ok1 << (7 * c);
                 K1_T(t_s1);
                 K1_ADD(5, t_s0, t_s1);
-                /* field 1 waits for the end of field 0 */
-                park[(c * 5 + 0) * 64 + lane] = (uint32_t)o1.s_lo; park[(c * 5 + 1) * 64 + lane] = (uint32_t)(o1.s_lo >> 32);
-                park[(c * 5 + 2) * 64 + lane] = (uint32_t)o1.s_hi; park[(c * 5 + 3) * 64 + lane] = (uint32_t)(o1.s_hi >> 32);
-                park[(c * 5 + 4) * 64 + lane] = (uint32_t)o1.crc;
+                /* field 1 waits for the end of field 0: the cells only (of a line that read the CRC as calculated is the one in its cells, and
+                 * only such lines are taken from here) */
+                park[(c * 4 + 0) * 64 + lane] = (uint32_t)o1.s_lo; park[(c * 4 + 1) * 64 + lane] = (uint32_t)(o1.s_lo >> 32);
+                park[(c * 4 + 2) * 64 + lane] = (uint32_t)o1.s_hi; park[(c * 4 + 3) * 64 + lane] = (uint32_t)(o1.s_hi >> 32);
                 /* field 0 goes through the per-line bookkeeping now */
                 BatchLane bl;
                 bl.d0 = (uint32_t)o0.s_lo; bl.d1 = (uint32_t)(o0.s_lo >> 32); bl.d2 = (uint32_t)o0.s_hi; bl.d3 = (uint32_t)(o0.s_hi >> 32); bl.meta = (uint32_t)o0.crc;
-                if (n_ok0 > 0) { batch_finish(a, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec); rec += n_ok0; }
+                if (n_ok0 > 0) { batch_finish(a, lds, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec, false); rec += n_ok0; }
                 K1_T(t_s2);
                 K1_ADD(6, t_s1, t_s2);
                 if (n_ok0 < cn0) { whole = false; start_field = 0; start_idx = 64 * c + n_ok0; }
@@ -2560,9 +2660,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     if (cn1 <= 0) break;
                     const int n_ok1 = (int)((ok1_packed >> (7 * c)) & 0x7F);
                     BatchLane bl;
-                    bl.d0 = park[(c * 5 + 0) * 64 + lane]; bl.d1 = park[(c * 5 + 1) * 64 + lane]; bl.d2 = park[(c * 5 + 2) * 64 + lane];
-                    bl.d3 = park[(c * 5 + 3) * 64 + lane]; bl.meta = park[(c * 5 + 4) * 64 + lane];
-                    if (n_ok1 > 0) { batch_finish(a, v, bl, n_ok1, frame_no, (uint16_t)(2 + 2 * (64 * c)), fv_keys, rec); rec += n_ok1; }
+                    bl.d0 = park[(c * 4 + 0) * 64 + lane]; bl.d1 = park[(c * 4 + 1) * 64 + lane]; bl.d2 = park[(c * 4 + 2) * 64 + lane];
+                    bl.d3 = park[(c * 4 + 3) * 64 + lane]; bl.meta = (uint32_t)rev16(bl.d3 >> 16);
+                    if (n_ok1 > 0) { batch_finish(a, lds, v, bl, n_ok1, frame_no, (uint16_t)(2 + 2 * (64 * c)), fv_keys, rec, false); rec += n_ok1; }
                     if (n_ok1 < cn1) { whole = false; start_idx = 64 * c + n_ok1; }
                 }
                 SDV_WAVE_SYNC();
@@ -2575,6 +2675,10 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 }
             }
             if (start_field < 2) {      /* the row-staging loop below takes over: its first row */
+                /* (the coordinate keys of the lines taken so far, left out above: all of them the pair the frame was started with) */
+                const uint32_t key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
+#pragma unroll 1
+                for (int i = lane; i < v.nfv; i += 64) fv_keys[i] = key;
                 pf.nq = 0;
                 row_prefetch(pf, frame + (size_t)(2 * start_idx + start_field) * a.row_stride, a.width);
             }
@@ -2720,7 +2824,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 K1_T(t_loop);
                 K1_ADD(1, t_batch, t_loop);
                 if (j > 0) {
-                    batch_finish(a, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
+                    batch_finish(a, lds, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
                     K1_T(t_fin);
                     K1_ADD(2, t_loop, t_fin);
                     rec += j; idx += j;
@@ -2750,7 +2854,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
             if (!took_fast) {
                 if (kLean) {
-                    if (lane == 0) { sdv_v2d_state o = a.states_in[f]; o._pad[0] = STATE_ABORTED; a.states_out[f] = o; a.flag[f] = VF_ABORTED; }
+                    v2d_give_up(a, f);
                     return;
                 } else {
                     K1_T(t_sc0);
@@ -2797,7 +2901,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     line_num = (uint16_t)(line_num + 2);
     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
     K1_T(t_ef0);
-    v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f], all_captured ? &captured_key : nullptr);
+    v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f], all_captured, captured_key);
     emit_record(wl, rec++);
     v2d_store_state(v, lds, &a.states_out[f], a, sweep_pending);
     K1_T(t_end);

@@ -174,11 +174,7 @@ __device__ inline bool stop_marker_masks(const uint64_t *R, int n_px, int i_max 
 }
 
 /* ---- reads --------------------------------------------------------------------------------------- */
-#ifdef SDV_EMU
-#define SDV_OPAQUE(x) ((void)0)
-#else
-#define SDV_OPAQUE(x) asm volatile("" : "+v"(x))
-#endif
+/* (SDV_OPAQUE: stc007_device.h) */
 struct LaneRead { bool any_fill, valid; uint8_t hyst, shift; uint16_t crc, w8; };
 /* the cell bytes of pixel-shift stage `stage` (PCMLine::getVideoPixeBylCalc, pcmline.cpp:249-311), four to a word, cell 0 in the low byte of row[0] */
 __device__ __forceinline__ void gather_cells(const uint8_t *px, uint32_t (&row)[32], uint32_t psm, uint32_t hpsm, int pso, int stage, int px_lo, int px_hi)

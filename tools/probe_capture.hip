@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64, WPE) k_capture_dma(Args a)
     const int x0 = (int)(((uint32_t)(lane + 3) * psm + hpsm) / 128) + 12, x1 = (int)(((uint32_t)(lane + 67) * psm + hpsm) / 128) + 12;
     uint32_t b0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint4 acc = {0, 0, 0, 0};
+    uint4 hold[8] = {};
     constexpr int NP = H / 2;
     auto issue = [&](int k, int slot) {
         const uint8_t *src = frame + (size_t)k * (2 * W) + lane * 16;
@@ -134,6 +135,20 @@ __global__ void __launch_bounds__(64, WPE) k_capture_dma(Args a)
                 if (j == 63 || k == NP - 1) {
                     uint4 r0 = {b0[0] ^ b0[4], b0[1] ^ b0[5], b0[2] ^ b0[6], b0[3] ^ b0[7]}, r1 = {b1[0] ^ b1[4], b1[1] ^ b1[5], b1[2] ^ b1[6], b1[3] ^ b1[7]};
                     uint4 *o = a.out + ((size_t)(ST == 6 ? (f & 31) : f) * 512 + (size_t)(k & ~63) * 2) * 3;
+                    if (ST >= 7) {
+                        /* round 5: lane-contiguous streaming stores; BPL bytes per line (16 / 32 / 48), a burst every 64 << BSH row pairs */
+                        constexpr int BPL = ST == 10 ? 48 : (ST == 11 ? 32 : 16), BSH = ST == 8 ? 1 : (ST == 9 ? 2 : 0), NB = 1 << BSH;
+                        const int chunk = k >> 6;
+#pragma unroll
+                        for (int u = 0; u < NB; u++) if ((chunk & (NB - 1)) == u) { hold[2 * u] = r0; hold[2 * u + 1] = r1; }
+                        if (WR && ((chunk & (NB - 1)) == NB - 1 || k == NP - 1)) {
+                            uint4 *ob = a.out + (size_t)f * 1536 + (size_t)(chunk & ~(NB - 1)) * 128 * (BPL / 16);
+#pragma unroll
+                            for (int u = 0; u < 2 * NB; u++)
+#pragma unroll
+                                for (int w = 0; w < BPL / 16; w++) NT(hold[u], &ob[(u * (BPL / 16) + w) * 64 + lane]);
+                        }
+                    } else
                     if (WR && lane <= j) {
                         if (ST == 5) { o[lane] = r0; o[64 + lane] = r1; }
                         else if (ST == 0 || ST == 4 || ST == 6) { o[lane * 3] = r0; o[lane * 3 + 1] = r1; o[lane * 3 + 2] = r0; o[(64 + lane) * 3] = r1; o[(64 + lane) * 3 + 1] = r0; o[(64 + lane) * 3 + 2] = r1; }
@@ -188,6 +203,19 @@ int main(int argc, char **argv)
     const double gb = (double)bytes / 1e9, gbw = (double)n * 489 * 48 / 1e9;
 #define RUN(name, kern) do { float ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(n), dim3(64), 0, 0, a); }, 10); \
         printf("%-34s %7.3f ms  %6.2f TB/s read  (%6.2f TB/s read+write)\n", name, ms, gb / ms, (gb + gbw) / ms); } while (0)
+    if (argc > 2 && atoi(argv[2]) == 5) {        /* round 5: what the write stream costs by bytes per line and by burst length */
+        RUN("dma D=3 w5 no writes", (k_capture_dma<3, 5, false, true>));
+        RUN("dma D=3 w5 plain 48 B (3 x 16 per lane)", (k_capture_dma<3, 5, true, true, 0>));
+        RUN("dma D=3 w5 nt contiguous 48 B, burst 64", (k_capture_dma<3, 5, true, true, 10>));
+        RUN("dma D=3 w5 nt contiguous 32 B, burst 64", (k_capture_dma<3, 5, true, true, 11>));
+        RUN("dma D=3 w5 plain contiguous 16 B, burst 64", (k_capture_dma<3, 5, true, true, 5>));
+        RUN("dma D=3 w5 nt contiguous 16 B, burst 64", (k_capture_dma<3, 5, true, true, 7>));
+        RUN("dma D=3 w5 nt contiguous 16 B, burst 128", (k_capture_dma<3, 5, true, true, 8>));
+        RUN("dma D=3 w5 nt contiguous 16 B, burst 256", (k_capture_dma<3, 5, true, true, 9>));
+        RUN("dma D=3 w4 nt contiguous 16 B, burst 256", (k_capture_dma<3, 4, true, true, 9>));
+        RUN("dma D=3 w5 no writes", (k_capture_dma<3, 5, false, true>));
+        return 0;
+    }
     RUN("write only 24 KB per frame", k_write_only);
     RUN("stream, 8 waves/SIMD", (k_stream<8>));
     RUN("stream, 5 waves/SIMD", (k_stream<5>));
