@@ -2584,7 +2584,15 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             const int n0 = n_field[0], n1 = n_field[1];
             const int n_chunks = (n0 + 63) / 64;
             uint32_t *park = (uint32_t *)lds.px;                /* field-1 lines wait here: [chunk][4 words][lane], over px + hist + the front of sweep (up to REC_STAGE_OFS) */
-            uint32_t ok1_packed = 0;                            /* lines of field 1 that read, per chunk (7 bits each) */
+            uint64_t ok0_packed = 0, ok1_packed = 0;            /* lines of field 0 / 1 that read, per chunk (7 bits each) */
+            /* Field 0's lines wait too, in registers (the cells of chunk c in hold[c], picked by compares: the chunk loop stays a loop): every record of
+             * the frame is written when the capture has ended, in one burst.  (Written chunk by chunk - eight bursts of 3 KB spread over the frame - the
+             * same bytes cost more: the memory side turns from reading to writing and back for each of them; tools/probe_capture.hip, variant 5.) */
+            enum { HOLD_CHUNKS = (SDV_MAX_HEIGHT / 2 + 63) / 64 };
+            uint32_t hold[HOLD_CHUNKS][4];
+#pragma unroll
+            for (int u = 0; u < HOLD_CHUNKS; u++) hold[u][0] = hold[u][1] = hold[u][2] = hold[u][3] = 0;
+            int n_done = 0;                                     /* chunks captured */
             const uint32_t rs = (uint32_t)a.row_stride;         /* offsets inside a frame fit 32 bits (checked above) */
             const uint32_t lo = pre.ref_low, hi = pre.ref_high;
             const uint32_t x0 = (uint32_t)pre.x0, x1 = (uint32_t)pre.x1;
@@ -2634,21 +2642,32 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 const uint64_t okm0 = __ballot(ok0 || lane >= cn0), okm1 = __ballot(ok1 || lane >= cn1);
                 const int n_ok0 = okm0 == ~0ull ? cn0 : (__ffsll((unsigned long long)~okm0) - 1);
                 const int n_ok1 = okm1 == ~0ull ? cn1 : (__ffsll((unsigned long long)~okm1) - 1);
-                ok1_packed |= (uint32_t)n_ok1 << (7 * c);
+                ok0_packed |= (uint64_t)n_ok0 << (7 * c); ok1_packed |= (uint64_t)n_ok1 << (7 * c);
                 K1_T(t_s1);
                 K1_ADD(5, t_s0, t_s1);
                 /* field 1 waits for the end of field 0: the cells only (of a line that read the CRC as calculated is the one in its cells, and
                  * only such lines are taken from here) */
                 park[(c * 4 + 0) * 64 + lane] = (uint32_t)o1.s_lo; park[(c * 4 + 1) * 64 + lane] = (uint32_t)(o1.s_lo >> 32);
                 park[(c * 4 + 2) * 64 + lane] = (uint32_t)o1.s_hi; park[(c * 4 + 3) * 64 + lane] = (uint32_t)(o1.s_hi >> 32);
-                /* field 0 goes through the per-line bookkeeping now */
-                BatchLane bl;
-                bl.d0 = (uint32_t)o0.s_lo; bl.d1 = (uint32_t)(o0.s_lo >> 32); bl.d2 = (uint32_t)o0.s_hi; bl.d3 = (uint32_t)(o0.s_hi >> 32); bl.meta = (uint32_t)o0.crc;
-                if (n_ok0 > 0) { batch_finish(a, lds, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec, false); rec += n_ok0; }
-                K1_T(t_s2);
-                K1_ADD(6, t_s1, t_s2);
+#pragma unroll
+                for (int u = 0; u < HOLD_CHUNKS; u++)
+                    if (c == u) { hold[u][0] = (uint32_t)o0.s_lo; hold[u][1] = (uint32_t)(o0.s_lo >> 32); hold[u][2] = (uint32_t)o0.s_hi; hold[u][3] = (uint32_t)(o0.s_hi >> 32); }
+                n_done = c + 1;
                 if (n_ok0 < cn0) { whole = false; start_field = 0; start_idx = 64 * c + n_ok0; }
             }
+            /* field 0 goes through the per-line bookkeeping */
+            K1_T(t_s1b);
+            for (int c = 0; c < n_done; c++) {
+                const int n_ok0 = (int)((ok0_packed >> (7 * c)) & 0x7F);
+                BatchLane bl; bl.d0 = bl.d1 = bl.d2 = bl.d3 = 0;
+#pragma unroll
+                for (int u = 0; u < HOLD_CHUNKS; u++)
+                    if (c == u) { bl.d0 = hold[u][0]; bl.d1 = hold[u][1]; bl.d2 = hold[u][2]; bl.d3 = hold[u][3]; }
+                bl.meta = (uint32_t)rev16(bl.d3 >> 16);
+                if (n_ok0 > 0) { batch_finish(a, lds, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec, false); rec += n_ok0; }
+            }
+            K1_T(t_s2);
+            K1_ADD(6, t_s1b, t_s2);
             if (whole) {
                 line_num = (uint16_t)(1 + 2 * n0);
                 v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
@@ -2926,7 +2945,8 @@ __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv:
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<false>(a, lds, f, &slow_ctx);
 }
 #ifndef SDV_LEAN_WAVES_PER_EU
-#define SDV_LEAN_WAVES_PER_EU 5   /* 1.26 ms vs 1.46 (4), 1.28 (6), 1.45 (8) per 10 000 frames (profiles/r01_tuning_notes.md) */
+#define SDV_LEAN_WAVES_PER_EU 4   /* 128 registers: the capture holds a field's cells in registers without spilling.  Round 5, one box, ms per 10 000 frames: 0.688 (4) against
+                                   * 0.765 (5: 96 registers, 6 of them spilled); the capture itself does not care (round 5's first build: 0.782 with 4 and with 5) */
 #endif
 __global__ void __launch_bounds__(64, SDV_LEAN_WAVES_PER_EU) sdv_k_stc007_frames_lean(sdv::FrameArgs a)
 {
