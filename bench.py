@@ -218,6 +218,8 @@ def cpu_baseline_all_cores(luma_sample, mode, single_core_frames_per_s=None):
         per_worker = frames / len(res) / (sum(r["t1"] - r["t0"] for r in res) / len(res))
         return {"value": frames / wall, "unit": "frames/s", "cores": cores, "physical_cores": phys, "hardware_threads": os.cpu_count(), "cpu_quota_of_the_container": quota,
                 "workers_finished": len(res), "kind": res[0]["kind"],
+                "workers_rule": "min(physical cores, CPU affinity, cgroup CPU quota) since round 4; the BENCH files of rounds 1-3 ran a worker per hardware thread "
+                                "(256 on the pool's boxes, 16 of them runnable at once) - compare round over round by per_worker_frames_per_s x cores",
                 "per_worker_frames_per_s": per_worker,
                 "per_worker_slowdown_vs_one_core_alone": (single_core_frames_per_s / per_worker) if single_core_frames_per_s else None,
                 "all_workers_decoded_the_same_records": len(set(r["sha"] for r in res)) == 1,
@@ -557,24 +559,26 @@ def main():
             eng.binarize_frames(luma, first_frame_no=1, new_file=True, out_lines=out_lines, out_stats=out_stats, stream=stream)
             k_steps = max(1, min(args.steps, 3))
             d_ms = 0.0; d_kms = 0.0; d_rounds = d_launched = d_general = 0
-            for r_ in range(-1, k_steps):               # (-1: once untimed - the first damaged batch of a process pays first uses: the full kernel's code, pinned buffers)
+            for r_ in range(-2, k_steps):               # (-2: once untimed - the first damaged batch of a process pays first uses: the full kernel's code, pinned buffers;
+                                                        #  -1: once more untimed with the engine's event pairs on: where the kernel time comes from)
                 # (the jumps leave the window displaced at the end of the batch: every step starts from the clean tape's state again)
                 eng.binarize_frames(luma, first_frame_no=1 + (2 * r_ + 3) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
                 # the wall clock of the call as a caller sees it: without the engine's event pair around every round (sdv_set_profiling), which is
                 # what the untimed first pass reads the kernel time from
-                eng.set_profiling(r_ < 0)
+                eng.set_profiling(r_ == -1)
                 torch.cuda.synchronize(dev); t1 = time.perf_counter()
                 eng.binarize_frames(lum, first_frame_no=1 + (2 * r_ + 4) * n, out_lines=out_lines[1:], out_stats=out_stats, stream=stream)
                 torch.cuda.synchronize(dev)
                 eng.set_profiling(True)
                 i_ = eng.run_info()
                 if r_ < 0:
-                    d_kms = i_.kernel_ms * k_steps
+                    if r_ == -1:
+                        d_kms = i_.kernel_ms * k_steps
                     continue
                 d_ms += (time.perf_counter() - t1) * 1e3
                 d_rounds += i_.rounds; d_launched += i_.frames_launched; d_general += i_.frames_general
             damaged[kind] = {"events_per_step": per, "frames_per_step": n, "ms_per_step": d_ms / k_steps, "frames_per_s": n / (d_ms / k_steps) * 1e3,
-                             "kernel_ms_per_step": d_kms / k_steps, "rounds_per_step": d_rounds / k_steps, "frames_launched_per_step": d_launched / k_steps,
+                             "kernel_ms_per_step": d_kms / k_steps, "kernel_ms_from": "a separate warm pass with an event pair around every round (not one of the timed passes)", "rounds_per_step": d_rounds / k_steps, "frames_launched_per_step": d_launched / k_steps,
                              "frames_by_full_kernel_per_step": d_general / k_steps}
             del lum
         eng.reset_stream()

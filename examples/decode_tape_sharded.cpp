@@ -108,7 +108,11 @@ struct RcclComm : Comm {
                 if (f) {
                     bool ok = fread(&rec, sizeof(rec), 1, f) == 1 && memcmp(rec.magic, "SDVNCCL1", 8) == 0 && tag == std::string(rec.tag, strnlen(rec.tag, sizeof(rec.tag)));
                     struct stat sb;
-                    if (ok && tag.empty()) ok = fstat(fileno(f), &sb) == 0 && sb.st_mtime + 1 >= started;    /* no run tag to tell the runs apart: only a file written since this rank was started */
+                    /* ... and only a file written about when this rank was started: since then when there is no run tag to tell the runs apart; with a tag, not
+                     * more than half a minute before (the ranks of a run are started together, rank 0 may be ahead by a little) - an id left under the same
+                     * tag by a run that died (a constant SDV_RUN_ID, the same MASTER_ADDR:MASTER_PORT again) is older than that, and rank 0 removes it first
+                     * thing anyway */
+                    if (ok) ok = fstat(fileno(f), &sb) == 0 && sb.st_mtime + (tag.empty() ? 1 : 30) >= started;
                     fclose(f);
                     if (ok) break;
                 }
@@ -225,8 +229,7 @@ int main(int argc, char **argv)
     /* ---- binarize stage (the VideoToDigital worker) ------------------------------------------------------------------------------------------- */
     unsigned gathers = 0, binarize_redo = 0, stitch_redo = 0;
     SDV_OKAY(sdv_reset_stream(eng));
-    sdv_v2d_state predicted, fin;
-    memset(&predicted, 0, sizeof(predicted));
+    sdv_v2d_state predicted = {}, fin = {};          /* (both travel in the all-gather blob: a rank without a warm-up sends zeros, as sharded.py does) */
     /* The binarizer's levels are sticky - a line that reads from the levels it inherits does not measure them again - so on a tape that plays they are
      * what the first lines of the TAPE measured, which no warm-up further down can find out.  Rank 0 decodes the first frames of its range first and
      * publishes the state it has then; the other ranks start their warm-up from it (a warm-up of 20 frames refills the histories either way). */

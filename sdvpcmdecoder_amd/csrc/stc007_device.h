@@ -119,6 +119,7 @@ struct WaveLds {
  * 2 the successor was started from something else */
 enum { VF_OK = 0, VF_ABORTED = 1, VF_BREAK = 2,
        VF_KIND = 0x0F,
+       VF_SLOW = 0x20,              /* lines of the frame went through the general path (full kernel only): the frame did need that kernel - what the scheduler's "worn tape" is decided on */
        VF_MOVED = 0x40,             /* the frame leaves the chain with other coordinates / histories than the model makes of what it was started from */
        VF_RETUNED = 0x80 };         /* ... with other black / white / reference levels */
 struct FrameArgs {
@@ -1822,7 +1823,7 @@ __device__ inline uint32_t v2d_state_half(const V2D &v, const WaveLds &lds, cons
 }
 /* The state goes out a dword per lane (lanes 0 .. 29), and the check of the chain - was the next frame started from this state? - is a ballot.  (It
  * was put together by lane 0 alone on the stack before: the histories are indexed by how full they are, and that was the lean kernel's scratch memory.) */
-__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a, bool unsettled = false)
+__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a, bool unsettled = false, uint8_t extra_flags = 0)
 {
     enum { NDW = sizeof(sdv_v2d_state) / 4 };
     const int lane = lane_id();
@@ -1852,7 +1853,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
     }
     if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
     if (lane == 0) {
-        a.flag[f] = fl;
+        a.flag[f] = (uint8_t)(fl | extra_flags);
         if (a.refs) {
             /* (one pair pushed into a full history, the rest moved down a slot: counted where it happens - reading the incoming history again here cost 3 % of the kernel) */
             const bool pushed = v.long_pushes == 1 && v.n_long == COORD_LONG_HISTORY && !a.doubled;
@@ -2572,6 +2573,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     int start_field = 0, start_idx = 0;
     bool all_captured = false; uint32_t captured_key = 0;
     bool sweep_pending = false;             /* a line of this frame went on without the sweep it asked for: the frame is decoded again */
+    bool used_general = false;              /* a line of this frame took the general path */
 #ifdef SDV_K1_STAMPS
     int n_slow_lines = 0;
 #endif
@@ -2877,6 +2879,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     return;
                 } else {
                     K1_T(t_sc0);
+                    used_general = true;
                     SDV_SLOW_CTX(c);
                     SDV_WAVE_SYNC();
                     if (!sc_args_set) { c.a = a; sc_args_set = true; }
@@ -2922,7 +2925,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     K1_T(t_ef0);
     v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f], all_captured, captured_key);
     emit_record(wl, rec++);
-    v2d_store_state(v, lds, &a.states_out[f], a, sweep_pending);
+    v2d_store_state(v, lds, &a.states_out[f], a, sweep_pending, used_general ? (uint8_t)VF_SLOW : (uint8_t)0);
     K1_T(t_end);
     K1_ADD(3, t_ef0, t_end);
     K1_ADD(0, t_begin, t_end);

@@ -234,6 +234,34 @@ def test_emu_tall_frames_keep_their_histories(emu_lib, oracle_lib, height, lpf):
     assert info.rounds == 1 and info.frames_general == 0
 
 
+def test_emu_worn_tape_mark_comes_and_goes(emu_lib, oracle_lib):
+    """The scheduler starts a call on the full kernel when most frames of the last call took lines through the general path ("worn tape").
+    A cold one-frame call must not set that mark (round 4: it did, and the mark never came off again - every later frame of a clean tape went
+    through the full kernel), a call full of damaged frames sets it, a clean call takes it off again; the records equal the oracle's all the way."""
+    from test_gpu_parity import _unreadable_cells
+    clean, _, _ = synth.stc007_frames(30, seed=91, noise_sigma=3.0, height=96, lines_per_field=48)
+    want, _ = oracle_binarize(clean, mode=2)
+    per = 96 + 3
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    emu_lib.sdv_set_mode(eng, 2)
+    got0, _, _ = emu_run(emu_lib, clean[:1], 2, eng=eng)                          # the cold frame alone
+    got1, _, info = emu_run(emu_lib, clean[1:13], 2, flags=0, first=2, eng=eng)
+    assert info.frames_general == 0, "a clean tape behind a one-frame cold call: nothing for the full kernel"
+    assert np.concatenate([got0, got1]).tobytes() == want[:1 + 13 * per].tobytes()
+    # damage in every frame: the lean kernel gives the frames up, the call ends marked
+    worn = np.ascontiguousarray(_unreadable_cells(clean[13:25].copy(), every=7))
+    want_w, _ = oracle_binarize(np.concatenate([clean[:13], worn, clean[25:]]), mode=2)
+    got2, _, info2 = emu_run(emu_lib, worn, 2, flags=0, first=14, eng=eng)
+    assert got2.tobytes() == want_w[1 + 13 * per:1 + 25 * per].tobytes()
+    assert info2.frames_general > 0
+    # ... so the next call starts on the full kernel; its frames are clean: the mark comes off, the call behind it is the lean kernel's again
+    more, _, _ = synth.stc007_frames(40, seed=92, noise_sigma=3.0, height=96, lines_per_field=48)
+    _, _, info3 = emu_run(emu_lib, more[:12], 2, flags=0, first=26, eng=eng)
+    _, _, info4 = emu_run(emu_lib, more[12:24], 2, flags=0, first=38, eng=eng)
+    emu_lib.sdv_engine_destroy(eng)
+    assert info3.frames_general >= 12 and info4.frames_general == 0, (info3.frames_general, info4.frames_general)
+
+
 def test_emu_unreadable_cells_sweep_every_level(emu_lib, oracle_lib):
     """A bit cell inverted on some lines: their reference level sweep runs over every level, the levels near white leave a zero source CRC word
     (two outcomes per level, chained through the lanes - stc007_device.h sweep_ref_level); the scheduler carries the level such a sweep settles on

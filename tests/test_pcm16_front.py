@@ -14,6 +14,27 @@ import pcm16_front_api as pf
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+REF_KAT_WORDS, REF_KAT_CRC = (0xD527, 0x9C36, 0x02A5), 0xFB40       # pcmtester.cpp:45-49
+
+
+def _kat_lines():
+    """Video lines whose three sub-lines all carry the reference's CRC test vector (words and CRCC as in PCMTester::testPCM16x0CRCC), clean and
+    with a little noise, and the presets of a cold Binarizer for every pass."""
+    from sdvpcmdecoder_amd import synth
+    w4 = np.tile(np.array(REF_KAT_WORDS + (REF_KAT_CRC,), dtype=np.uint16), (4, 3, 1))
+    luma = synth.render_lines(synth.pcm16x0_line_bits(w4, np.ones(4, dtype=np.int64)), width=720, x0=5, x1=714, noise_sigma=0.0)
+    luma[2:] = synth.render_lines(synth.pcm16x0_line_bits(w4[2:], np.ones(2, dtype=np.int64)), width=720, x0=5, x1=714, noise_sigma=3.0, rng=np.random.default_rng(7))
+    cold = np.zeros(3 * len(luma), dtype=pf.STATE_DTYPE); cold["start"], cold["stop"] = -32768, 32767
+    return luma, cold
+
+
+def _check_kat_records(got):
+    """the first pass of every line (nothing preset: it searches the coordinates) reads the vector and calculates the reference's CRC for it"""
+    first = got[0::3]
+    assert (first["words"][:, :3] == np.array(REF_KAT_WORDS, dtype=np.uint16)).all(), first["words"]
+    assert (first["words"][:, 3] == REF_KAT_CRC).all() and (first["calc_crc"] == REF_KAT_CRC).all() and ((first["flags"] & pf.LF_CRC_VALID) != 0).all()
+
+
 def _diff(a, b, ra, rb):
     for i in range(min(len(a), len(b))):
         if a[i].tobytes() != b[i].tobytes() or ra[i] != rb[i]:
@@ -29,7 +50,15 @@ def test_crc_known_answers(oracle_lib):
     f.restype = C.c_uint16
     f.argtypes = [C.POINTER(C.c_uint16)]
     assert f((C.c_uint16 * 3)(0, 0, 0)) == 0x0E10
+    # the reference's own known answer (PCMTester::testPCM16x0CRCC, pcmtester.cpp:40-56): 0xD527 0x9C36 0x02A5 -> 0xFB40
+    assert f((C.c_uint16 * 3)(*REF_KAT_WORDS)) == REF_KAT_CRC
     from sdvpcmdecoder_amd import synth
+    assert int(synth.pcm16x0_crc_words(np.array(REF_KAT_WORDS, dtype=np.uint32))) == REF_KAT_CRC
+    if libs.ref_available():
+        g0 = libs.load_ref().ref_pcm16x0_crc
+        g0.restype = C.c_uint16
+        g0.argtypes = [C.POINTER(C.c_uint16)]
+        assert g0((C.c_uint16 * 3)(*REF_KAT_WORDS)) == REF_KAT_CRC
     rng = np.random.default_rng(1)
     w = rng.integers(0, 1 << 16, size=(64, 3), dtype=np.uint32)
     want = synth.pcm16x0_crc_words(w)
@@ -144,6 +173,21 @@ def test_emu_lines_match_oracle(name, emu, oracle_lib):
     assert (scans == seq_scans).all()
 
 
+def test_reference_crc_vector_through_oracle_and_emulator(emu, oracle_lib):
+    """0xD527 0x9C36 0x02A5 -> 0xFB40 (pcmtester.cpp:40-56) as pixels: the oracle's Binarizer and the kernel source on the emulator read the words and
+    calculate that CRC; the live reference does when it is built."""
+    luma, cold = _kat_lines()
+    want, _ = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, cold, mode=2)
+    _check_kat_records(want)
+    lib, eng = emu
+    rc, got, _ = pf.run_engine_lines(lib, eng, luma, cold, mode=2)
+    assert rc == 0 and got.tobytes() == want.tobytes()
+    _check_kat_records(got)
+    if libs.ref_available():
+        ref, _ = pf.run_lines_with_states(libs.load_ref(), "ref_bin16_", luma, cold, mode=2)
+        assert ref.tobytes() == want.tobytes()
+
+
 def test_emu_lines_argument_checks(emu):
     lib, eng = emu
     luma = np.zeros((2, 720), np.uint8)
@@ -190,6 +234,16 @@ def test_gpu_lines_match_golden_from_reference(name):
     rows, at = pf.data_rows(len(pf.make_case(name)[0]), pf.make_case(name)[1])
     idx = (at[:, None] + np.arange(3)[None, :]).reshape(-1)
     assert (scans == g["scans"][idx]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_reference_crc_vector(oracle_lib):
+    """0xD527 0x9C36 0x02A5 -> 0xFB40 (pcmtester.cpp:40-56) as pixels through sdv_pcm16x0_binarize_lines on the GPU"""
+    luma, cold = _kat_lines()
+    got, _ = _gpu_lines(luma, cold, mode=2)
+    _check_kat_records(got)
+    want, _ = pf.run_lines_with_states(oracle_lib, "orc_bin16_", luma, cold, mode=2)
+    assert got.tobytes() == want.tobytes()
 
 
 @pytest.mark.gpu
