@@ -716,6 +716,33 @@ __device__ inline bool find_black_white_p16(const BinCtx &c, WaveLds &lds, L16 &
     return line.bw_set;
 }
 
+/* Stage STG_INPUT_ALL of processLine alone (binarizer.cpp:774-931), for the lean build of the frame kernel: a part whose reference level and
+ * coordinates are preset - its levels measured first when they are not (the part behind one that was marked bad) - is read with them, ladder and
+ * Bit Picker included; true when that ends in STG_DATA_OK, i.e. the part is done.  false: the part needs the stages behind it (nothing is decided,
+ * `out` is not to be used) - the frame goes to the full build. */
+__device__ inline bool input_all_p16(const BinCtx &c, const Bin &b, uint8_t part, WaveLds &lds, L16 &out, bool vl_doubled)
+{
+    if (c.ps.en_force_coords) return false;
+    if (!(is_ref_level_preset(b, c.ps) && coords_valid(b.in_coord))) return false;
+    p16_clear(out);
+    out.line_part = part == PART_MIDDLE ? 1 : (part == PART_RIGHT ? 2 : 0);
+    out.coords.doubled = vl_doubled;
+    if (c.scan_end > c.scan_start && P16_BITS <= (c.scan_end - c.scan_start)) { out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end; }
+    bool was_bw_scanned = false;
+    if (are_bw_levels_preset(b, c.ps)) { out.black = b.in_black; out.white = b.in_white; out.bw_set = true; }
+    if (!out.bw_set) find_black_white_p16(c, lds, out, was_bw_scanned, b.do_ref_lvl_sweep);
+    out.coords = b.in_coord;
+    out.ref_level = b.in_ref;
+    if (!out.bw_set) return false;
+    if (b.in_ref >= out.white || b.in_ref <= out.black) return false;
+    read_pcm_data<true>(c, out, lds.px, part, b.in_max_hyst, b.in_max_shift);
+    if (!crc_valid(out)) return false;
+    out.by_ext_tune = true;
+    if (out.forced_bad) return false;
+    out.coords_set = true;
+    return true;
+}
+
 /* Binarizer::processLine (binarizer.cpp:443-1724), PCM16X0SubLine output, one part of the video line staged in lds.w.px */
 template <bool kInsane>          /* the build for MODE_INSANE: see process_line_p1 */
 __device__ inline void process_line_p16(BinCtx &c, Bin &b, bool coord_search, uint8_t part, bool &scan_done, P16Lds &lds, L16 &out, bool vl_doubled)

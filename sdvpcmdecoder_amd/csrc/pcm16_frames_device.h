@@ -103,6 +103,13 @@ struct V2D16 {
     uint64_t lw0, lw1, lw2;         /* the data words of last_pcm16x0_p0/p1/p2_line (the 48 data cells; named members: an indexed array would put the whole state into scratch) */
 };
 
+/* one of three values by an index 0..2, by masks: written as `i == 0 ? a : (i == 1 ? b : c)` over members of one object the compiler makes it one
+ * load through a computed address - and an object that is addressed like that lives in scratch memory, all of it (the frame's whole state did) */
+__device__ __forceinline__ uint64_t pick3_u64(int i, uint64_t a, uint64_t b, uint64_t c)
+{
+    const uint64_t ma = i == 0 ? ~0ull : 0ull, mb = i == 1 ? ~0ull : 0ull, mc = (i != 0 && i != 1) ? ~0ull : 0ull;
+    return (a & ma) | (b & mb) | (c & mc);
+}
 __device__ inline void load_state16(V2D16 &w, Lds16 &lds, const State16 *s, const FrameArgs &a)
 {
     v2d_load_state(w.v, lds.p.w, &s->s, a);
@@ -125,33 +132,59 @@ __device__ inline bool link_holds16(const FrameArgs &a, int f, const State16 &ou
     return same;
 }
 
+/* The chain after frame f, a dword per lane (State16 is 48 dwords: the pattern of v2d_store_state, stc007_device.h - put together by one lane on the
+ * stack it was the frame kernel's scratch memory); the link to frame f+1 is checked by the frame itself, as link_holds16 does. */
+__device__ inline uint32_t state16_half(const V2D16 &w, const Lds16 &lds, const FrameArgs &a, int h)
+{
+    const V2D &v = w.v;
+    enum { H_MORE = sizeof(sdv_v2d_state) / 2 };        /* halfword 60: more[0] */
+    if ((h >= V2D_H_LAST && h < V2D_H_LONG) || (h >= H_MORE && h < H_MORE + 2 * (LV16 - COORD_HISTORY_DEPTH))) {
+        const int k = h < V2D_H_LONG ? h - V2D_H_LAST : h - H_MORE + 2 * COORD_HISTORY_DEPTH, e = k >> 1;      /* entry e of the window of 27 */
+        if (e >= v.n_last) return 0;
+        const uint32_t key = lds.lv_keys16[e];
+        return (uint32_t)(uint16_t)((k & 1) ? key_stop(key) : key_start(key));
+    }
+    if (h >= V2D_H_LONG && h < V2D_H_LONG + 2 * COORD_LONG_HISTORY) {
+        const int k = h - V2D_H_LONG, e = k >> 1;
+        if (e >= v.n_long) return 0;
+        const uint32_t key = lds.p.w.long_keys[e];
+        return (uint32_t)(uint16_t)((k & 1) ? key_stop(key) : key_start(key));
+    }
+    const int n9 = v.n_last < COORD_HISTORY_DEPTH ? v.n_last : COORD_HISTORY_DEPTH;
+    switch (h) {
+    case 0: return (uint32_t)v.bin.in_black | ((uint32_t)v.bin.in_white << 8);
+    case 1: return (uint32_t)v.bin.in_ref;
+    case 2: return (uint32_t)(uint16_t)v.bin.in_coord.start;
+    case 3: return (uint32_t)(uint16_t)v.bin.in_coord.stop;
+    case 4: return v.bin.in_coord.doubled ? 1u : 0u;
+    case 5: return (v.bin.do_ref_lvl_sweep ? 1u : 0u) | (v.reset_stats ? 0x100u : 0u);
+    case 6: return (uint32_t)(uint8_t)v.n_last | ((uint32_t)(uint8_t)v.n_long << 8);
+    case 7: return a.doubled ? (uint32_t)(uint16_t)((1u << n9) - 1u) : 0u;
+    case 8: return a.doubled ? (uint32_t)(uint16_t)((1u << v.n_long) - 1u) : 0u;
+    case 59: return (uint32_t)(uint8_t)(w.prescan_ref ^ 128) << 8;      /* _pad[0] = 0, _pad[1] = prescan_ref */
+    default: return 0;
+    }
+}
 __device__ inline void store_state16(const V2D16 &w, const Lds16 &lds, const FrameArgs16 &a16, int f)
 {
-    if (lane_id() != 0) return;
+    enum { NDW = sizeof(State16) / 4 };
+    static_assert(NDW <= 64 && offsetof(State16, more) == sizeof(sdv_v2d_state) && sizeof(sdv_bin_state) == 10, "a dword of the state per lane");
     const FrameArgs &a = a16.f;
-    const V2D &v = w.v;
-    State16 o;
-    o.s.bin.in_def_black = v.bin.in_black; o.s.bin.in_def_white = v.bin.in_white; o.s.bin.in_def_reference = v.bin.in_ref; o.s.bin.do_ref_lvl_sweep = 0;
-    o.s.bin.in_def_start = v.bin.in_coord.start; o.s.bin.in_def_stop = v.bin.in_coord.stop;
-    o.s.bin.in_def_from_doubled = v.bin.in_coord.doubled ? 1 : 0; o.s.bin._pad2 = 0;
-    o.s.do_ref_lvl_sweep = v.bin.do_ref_lvl_sweep ? 1 : 0; o.s.reset_stats = v.reset_stats ? 1 : 0;
-    o.s.n_last_valid = (uint8_t)v.n_last; o.s.n_long_valid = (uint8_t)v.n_long;
-    const int n9 = v.n_last < COORD_HISTORY_DEPTH ? v.n_last : COORD_HISTORY_DEPTH;
-    const uint16_t lm = a.doubled ? (uint16_t)((1u << n9) - 1u) : 0, gm = a.doubled ? (uint16_t)((1u << v.n_long) - 1u) : 0;
-    o.s.last_valid_doubled_mask_lo = (uint8_t)(lm & 0xFF); o.s.last_valid_doubled_mask_hi = (uint8_t)(lm >> 8);
-    o.s.long_valid_doubled_mask = gm;
-    for (int i = 0; i < LV16; i++) {
-        sdv_coord cc; cc.data_start = 0; cc.data_stop = 0;
-        if (i < v.n_last) { cc.data_start = key_start(lds.lv_keys16[i]); cc.data_stop = key_stop(lds.lv_keys16[i]); }
-        if (i < COORD_HISTORY_DEPTH) o.s.last_valid[i] = cc; else o.more[i - COORD_HISTORY_DEPTH] = cc;
+    const int lane = lane_id();
+    const bool in = lane < NDW;
+    const int dw = in ? lane : 0;
+    SDV_WAVE_SYNC();            /* (the histories were written by lane 0) */
+    const uint32_t mine = state16_half(w, lds, a, 2 * dw) | (state16_half(w, lds, a, 2 * dw + 1) << 16);
+    if (in) reinterpret_cast<uint32_t *>(&a16.states_out[f])[dw] = mine;
+    uint8_t fl = VF_OK;
+    if (f + 1 < a.n_total) {
+        const uint32_t next = reinterpret_cast<const uint32_t *>(&a16.states_in[f + 1])[dw];
+        /* when the worker prescans frame f+1 it resets its Binarizer first (prescanCoordinates :221): what this frame left preset there - the first ten
+         * bytes of the state - does not reach frame f+1 and does not count */
+        const uint32_t cmp = prescan_runs(a, f + 1) ? (dw < 2 ? 0u : (dw == 2 ? 0xFFFF0000u : 0xFFFFFFFFu)) : 0xFFFFFFFFu;
+        if (__ballot(in && ((next ^ mine) & cmp) != 0) != 0ull) fl = VF_BREAK;
     }
-    for (int i = 0; i < COORD_LONG_HISTORY; i++) {
-        if (i < v.n_long) { o.s.long_valid[i].data_start = key_start(lds.p.w.long_keys[i]); o.s.long_valid[i].data_stop = key_stop(lds.p.w.long_keys[i]); }
-        else { o.s.long_valid[i].data_start = 0; o.s.long_valid[i].data_stop = 0; }
-    }
-    o.s._pad[0] = 0; o.s._pad[1] = (uint8_t)(w.prescan_ref ^ 128);
-    a16.states_out[f] = o;
-    a.flag[f] = (f + 1 < a.n_total && !link_holds16(a, f, o, a16.states_in[f + 1])) ? VF_BREAK : VF_OK;
+    if (lane == 0) a.flag[f] = fl;
 }
 
 __device__ inline void begin_frame16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, int f)   /* :772-822 */
@@ -234,7 +267,7 @@ __device__ inline void post_part16(V2D16 &w, const FrameArgs &a, Lds16 &lds, L16
                 set_good_parameters_p16(v.bin, ps, wl);
                 if (ps.en_first_line_dup) { wl.forced_bad = true; force_bad_line = true; }
             } else {
-                const uint64_t lw = part == 0 ? w.lw0 : (part == 1 ? w.lw1 : w.lw2);
+                const uint64_t lw = pick3_u64(part, w.lw0, w.lw1, w.lw2);
                 const int diff = __popcll(((wl.v >> 16) ^ lw) & 0x00FF00FF00FFull);     /* per word the XOR is truncated to uint8_t */
                 const int16_t s0 = (int16_t)get_word(wl, 0), s2 = (int16_t)get_word(wl, 2);
                 const bool almost_silent = (!(s0 >= 4) && !(s0 < -4)) || (!(s2 >= 4) && !(s2 < -4));                      /* pcm16x0subline.cpp:291-318 */
@@ -319,7 +352,7 @@ __device__ inline uint32_t lane_read32(uint32_t x, uint32_t idx) { return (uint3
  * at once - goes through process_line_p16 from the start. */
 struct Lean16 {
     uint32_t key_coords, key_levels;        /* what `x` etc. were computed for; key_levels = 0xFFFFFFFF: nothing yet */
-    uint16_t x[3], x_ctrl;                  /* lane's pixel in the left / middle / right part; the Control Bit's pixel */
+    uint16_t x0, x1, x2, x_ctrl;            /* lane's pixel in the left / middle / right part (named members: an array indexed by the part puts the frame's state into scratch memory); the Control Bit's pixel */
     uint8_t low, high, bits_l, bits_r;
     bool usable;
     uint32_t psm, hpsm; int16_t pso;
@@ -341,7 +374,7 @@ __device__ inline bool lean16_prepare(Lean16 &n, const BinCtx &c, const Bin &b)
         set_ppb(t, t.coords);
         n.psm = t.psm; n.hpsm = t.hpsm; n.pso = t.pso;
         const int lane = lane_id();
-        for (int q = 0; q < 3; q++) n.x[q] = (uint16_t)pixel_of(t, part_start_bit((uint8_t)(PART_LEFT + q)) + lane, 0);
+        n.x0 = (uint16_t)pixel_of(t, part_start_bit((uint8_t)PART_LEFT) + lane, 0); n.x1 = (uint16_t)pixel_of(t, part_start_bit((uint8_t)PART_MIDDLE) + lane, 0); n.x2 = (uint16_t)pixel_of(t, part_start_bit((uint8_t)PART_RIGHT) + lane, 0);
         n.x_ctrl = (uint16_t)pixel_of(t, 2 * P16_DATA, 0);
         n.low = get_low_level(b.in_ref, 0); n.high = get_high_level(b.in_ref, 0);
         n.usable = !(n.low <= b.in_black) && !(n.high >= b.in_white);
@@ -368,7 +401,8 @@ __device__ inline bool lean_part16(Lean16 &n, const BinCtx &c, const Bin &b, uin
     if (!lean16_prepare(n, c, b)) return false;
     const int lane = lane_id();
     const int q = part == PART_LEFT ? 0 : (part == PART_MIDDLE ? 1 : 2);
-    const uint8_t p0 = px_row[q == 0 ? n.x[0] : (q == 1 ? n.x[1] : n.x[2])];
+    const uint32_t xq = (uint32_t)pick3_u64(q, n.x0, n.x1, n.x2);
+    const uint8_t p0 = px_row[xq];
     const uint64_t a_lo = __ballot(p0 > n.low), b_lo = __ballot(p0 >= n.high);
     uint64_t s_lo, s_hi;
     solve_automaton(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
@@ -402,6 +436,9 @@ __device__ inline bool lean_part16(Lean16 &n, const BinCtx &c, const Bin &b, uin
  * coordinate damper sees a delta of zero).  The first line with a part that does not read, or that repeats the line above, ends the run:
  * it and what follows take the part-by-part path.  Returns the number of video lines taken. */
 enum { BATCH16_LINES = 21 };
+#ifndef SDV_P16_CAPTURE_D
+#define SDV_P16_CAPTURE_D 7         /* batch16: lines in flight (a divisor of BATCH16_LINES) */
+#endif
 __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, const Lean16 &n, const uint8_t *frame, int field, int idx, int nl,
                               uint32_t frame_no, sdv_pcm16x0_bin_rec *rec, uint32_t *fv_keys, L16 &wl)
 {
@@ -414,29 +451,52 @@ __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, cons
     if (__ballot(lane < v.n_last && lds.lv_keys16[lane < LV16 ? lane : 0] != key) != 0ull) return 0;
     int n_lines = nl - idx; if (n_lines > BATCH16_LINES) n_lines = BATCH16_LINES;
     const uint8_t low = n.low, high = n.high, ref = v.bin.in_ref;
-    /* phase A */
+    /* Phase A, the pattern of the STC-007 capture (stc007_device.h): per line four byte gathers per lane straight from the frame, D lines in flight
+     * (a line costs its share of the memory's bandwidth, not a trip to it), two ballots per part, the masks parked in the lane that owns the part;
+     * then every lane solves its own part - automaton and CRC. */
     uint32_t v_lo = 0, v_hi = 0, cb = 0;
     int n_ok = 0;
-    for (int l = 0; l < n_lines; l++) {
-        const uint8_t *rowp = frame + (size_t)(2 * (idx + l) + field) * a.row_stride;
-        const uint8_t p0 = rowp[n.x[0]], p1 = rowp[n.x[1]], p2 = rowp[n.x[2]], pc = rowp[n.x_ctrl];
-        bool ok = true;
+    {
+        constexpr int D = SDV_P16_CAPTURE_D;
+        static_assert(BATCH16_LINES % D == 0, "whole groups of D lines make a run of up to BATCH16_LINES");
+        const uint32_t rs2 = 2u * (uint32_t)a.row_stride;
+        const uint8_t *row0 = frame + (size_t)(2 * idx + field) * a.row_stride;
+        const uint32_t x0 = n.x0, x1 = n.x1, x2 = n.x2, xc = n.x_ctrl;
+        uint8_t q[D][4];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            const uint8_t px = q == 0 ? p0 : (q == 1 ? p1 : p2);
-            const uint64_t a_lo = __ballot(px > low), b_lo = __ballot(px >= high);
-            uint64_t s_lo, s_hi;
-            solve_automaton(a_lo, 0ull, b_lo, 0ull, s_lo, s_hi);
-            const uint64_t cells = __brevll(s_lo);
-            const int par = __popcll(cells & c_crc16.k[lane & 15]) & 1;
-            const uint16_t crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc16.base);
-            ok = ok && crc == (uint16_t)(cells & 0xFFFF);
-            const int j = 3 * l + q;
-            v_lo = write_lane(v_lo, (uint32_t)cells, j); v_hi = write_lane(v_hi, (uint32_t)(cells >> 32), j);
-            cb = write_lane(cb, pc < ref ? 0u : 1u, j);
+        for (int d = 0; d < D; d++) {
+            const uint32_t o = (uint32_t)(d < n_lines ? d : n_lines - 1) * rs2;
+            q[d][0] = sdvp1f::lean_load_u8(row0 + (o + x0)); q[d][1] = sdvp1f::lean_load_u8(row0 + (o + x1)); q[d][2] = sdvp1f::lean_load_u8(row0 + (o + x2)); q[d][3] = sdvp1f::lean_load_u8(row0 + (o + xc));
         }
-        if (!ok) break;
-        n_ok = l + 1;
+        uint32_t ra0 = 0, ra1 = 0, rb0 = 0, rb1 = 0;
+        for (int j0 = 0; j0 < n_lines; j0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int j = j0 + d;
+                const uint8_t p0 = q[d][0], p1 = q[d][1], p2 = q[d][2], pc = q[d][3];
+                const uint64_t a0 = __ballot(p0 > low), b0 = __ballot(p0 >= high), a1 = __ballot(p1 > low), b1 = __ballot(p1 >= high), a2 = __ballot(p2 > low), b2 = __ballot(p2 >= high);
+                const uint32_t cbit = uniu(pc < ref ? 0u : 1u);
+                {
+                    const int jn = j + D < n_lines ? j + D : n_lines - 1; const uint32_t o = (uint32_t)jn * rs2;
+                    q[d][0] = sdvp1f::lean_load_u8(row0 + (o + x0)); q[d][1] = sdvp1f::lean_load_u8(row0 + (o + x1)); q[d][2] = sdvp1f::lean_load_u8(row0 + (o + x2)); q[d][3] = sdvp1f::lean_load_u8(row0 + (o + xc));
+                }
+                ra0 = write_lane(ra0, (uint32_t)a0, 3 * j); ra1 = write_lane(ra1, (uint32_t)(a0 >> 32), 3 * j); rb0 = write_lane(rb0, (uint32_t)b0, 3 * j); rb1 = write_lane(rb1, (uint32_t)(b0 >> 32), 3 * j);
+                ra0 = write_lane(ra0, (uint32_t)a1, 3 * j + 1); ra1 = write_lane(ra1, (uint32_t)(a1 >> 32), 3 * j + 1); rb0 = write_lane(rb0, (uint32_t)b1, 3 * j + 1); rb1 = write_lane(rb1, (uint32_t)(b1 >> 32), 3 * j + 1);
+                ra0 = write_lane(ra0, (uint32_t)a2, 3 * j + 2); ra1 = write_lane(ra1, (uint32_t)(a2 >> 32), 3 * j + 2); rb0 = write_lane(rb0, (uint32_t)b2, 3 * j + 2); rb1 = write_lane(rb1, (uint32_t)(b2 >> 32), 3 * j + 2);
+                cb = write_lane(cb, cbit, 3 * j); cb = write_lane(cb, cbit, 3 * j + 1); cb = write_lane(cb, cbit, 3 * j + 2);
+            }
+        }
+        uint64_t s_lo, s_hi;
+        solve_automaton_lane((uint64_t)ra0 | ((uint64_t)ra1 << 32), 0ull, (uint64_t)rb0 | ((uint64_t)rb1 << 32), 0ull, s_lo, s_hi);
+        const uint64_t cells = __brevll(s_lo);
+        uint32_t crc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) crc |= (uint32_t)(__popcll(cells & c_crc16.k[k]) & 1) << k;
+        crc ^= c_crc16.base;
+        const bool ok = (uint16_t)crc == (uint16_t)(cells & 0xFFFF);
+        const uint64_t okm = __ballot(ok || lane >= 3 * n_lines);
+        n_ok = okm == ~0ull ? n_lines : (__ffsll((unsigned long long)~okm) - 1) / 3;
+        v_lo = (uint32_t)cells; v_hi = (uint32_t)(cells >> 32);
     }
     if (n_ok == 0) return 0;
     /* phase B: lane j = part j % 3 of line j / 3 */
@@ -446,7 +506,7 @@ __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, cons
     if (a.check_line_copy) {
         const int src = lane >= 3 ? lane - 3 : lane;
         uint64_t above = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(words >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)words, src);
-        if (lane < 3) above = lane == 0 ? w.lw0 : (lane == 1 ? w.lw1 : w.lw2);
+        if (lane < 3) above = pick3_u64(lane, w.lw0, w.lw1, w.lw2);
         const int diff = __popcll((words ^ above) & 0x00FF00FF00FFull);
         const int16_t s0 = (int16_t)(uint16_t)(mine >> 48), s2 = (int16_t)(uint16_t)(mine >> 16);
         const bool almost_silent = (!(s0 >= 4) && !(s0 < -4)) || (!(s2 >= 4) && !(s2 < -4));
@@ -508,10 +568,16 @@ __device__ inline int batch16(V2D16 &w, const FrameArgs16 &a16, Lds16 &lds, cons
     return n_ok;
 }
 
-template <bool kInsane>
+/* kLean: the build without Binarizer::processLine's search stages - a frame with a part the tuning it inherits does not read is given up (its flag says
+ * VF_ABORTED) and decoded again by the full build (pcm16_frames_engine.inc); the pattern of the STC-007 frame kernels. */
+template <bool kInsane, bool kLean = false>
 __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
 {
     const FrameArgs &a = a16.f;
+    if (kLean && (f == a.end_file_frame || frame_is_empty(a, f))) {          /* frames without pixels: the full build's */
+        if (lane_id() == 0) a.flag[f] = VF_ABORTED;
+        return;
+    }
     V2D16 w; L16 wl;
     load_state16(w, lds, &a16.states_in[f], a);
     V2D &v = w.v;
@@ -588,8 +654,10 @@ __device__ inline void frame_body16(const FrameArgs16 &a16, Lds16 &lds, int f)
 #if SDV_P16_ABLATE == 1
                 p16_clear(wl);
 #else
-                if (!(SDV_P16_LEAN && lean_part16(lean, c, v.bin, (uint8_t)(PART_LEFT + sub), lds.p.w.px, wl)))
-                    process_line_p16<kInsane>(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
+                if (!(SDV_P16_LEAN && lean_part16(lean, c, v.bin, (uint8_t)(PART_LEFT + sub), lds.p.w.px, wl))) {
+                    if (kLean) { if (!input_all_p16(c, v.bin, (uint8_t)(PART_LEFT + sub), lds.p.w, wl, doubled)) { if (lane_id() == 0) a.flag[f] = VF_ABORTED; return; } }
+                    else process_line_p16<kInsane>(c, v.bin, coord_search, (uint8_t)(PART_LEFT + sub), scan_done, lds.p, wl, doubled);
+                }
 #endif
                 P16_T(t_d); P16_ADD(1, t_c, t_d);
 #if SDV_P16_ABLATE != 2
@@ -787,6 +855,16 @@ __global__ void __launch_bounds__(64, SDV_P16_WAVES_PER_EU) sdv_k_pcm16_frames_b
 }
 SDV_P16F_KERNELS(, false)
 SDV_P16F_KERNELS(_insane, true)
+#ifndef SDV_P16F_LEAN_WAVES_PER_EU
+#define SDV_P16F_LEAN_WAVES_PER_EU 4
+#endif
+/* the lean build of the frame kernel (every mode: what it holds - parts that read from what they inherit - is the same in all of them) */
+__global__ void __launch_bounds__(64, SDV_P16F_LEAN_WAVES_PER_EU) sdv_k_pcm16_frames_lean(sdvp16f::FrameArgs16 a)
+{
+    __shared__ sdvp16f::Lds16 lds;
+    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x;
+    sdvp16f::frame_body16<false, true>(a, lds, f);
+}
 #ifndef SDV_EMU
 __global__ void sdv_k_pcm16_predict(sdvp16f::PredictArgs16 a)
 {

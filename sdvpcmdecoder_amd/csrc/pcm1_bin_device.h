@@ -235,7 +235,9 @@ __device__ inline void pick_cut_bits_by_trial(L1 &l, int left_bits, int right_bi
 }
 
 /* pickCutBitsUpPCM1 (binarizer.cpp:6116-6596) */
-__device__ inline void pick_cut_bits(const BinCtx &c, L1 &l)
+/* (forced in line, like process_line_p1 below: as functions of their own they take the line and the Binarizer by address - and an object whose address is
+ * taken lives in scratch memory, all of it, in every kernel that calls them) */
+__device__ __forceinline__ void pick_cut_bits(const BinCtx &c, L1 &l)
 {
     int left_bits = 0, right_bits = 0;
     l.picked_l = l.picked_r = 0;
@@ -728,6 +730,32 @@ __device__ inline void stage_row(uint8_t *px, const uint8_t *row, int width)
     SDV_WAVE_SYNC();
 }
 
+/* Stage STG_INPUT_ALL of processLine alone (binarizer.cpp:774-931), for the lean build of the frame kernel: a line whose reference level and
+ * coordinates are preset - its levels measured first when they are not (the first line of a frame behind the prescan, the line behind one that did
+ * not read) - is read with them, ladder and Bit Picker included; true when that ends in STG_DATA_OK, i.e. the line is done.  false: the line needs the
+ * stages behind it (nothing is decided, `out` is not to be used) - the frame goes to the full build. */
+__device__ inline bool input_all_p1(const BinCtx &c, const Bin &b, WaveLds &lds, L1 &out, bool vl_doubled)
+{
+    if (c.ps.en_force_coords) return false;
+    if (!(is_ref_level_preset(b, c.ps) && coords_valid(b.in_coord))) return false;
+    p1_clear(out);
+    out.coords.doubled = vl_doubled;
+    if (c.scan_end > c.scan_start && P1_BITS <= (c.scan_end - c.scan_start)) { out.pixel_start = c.scan_start; out.pixel_stop = c.scan_end; }
+    bool was_bw_scanned = false;
+    if (are_bw_levels_preset(b, c.ps)) { out.black = b.in_black; out.white = b.in_white; out.bw_set = true; }
+    if (!out.bw_set) find_black_white_p1(c, lds, out, was_bw_scanned, b.do_ref_lvl_sweep);
+    out.coords = b.in_coord;
+    out.ref_level = b.in_ref;
+    if (!out.bw_set) return false;
+    if (b.in_ref >= out.white || b.in_ref <= out.black) return false;
+    read_pcm_data<true>(c, out, lds.px, b.in_max_hyst, b.in_max_shift);
+    if (!crc_valid(out)) return false;
+    out.by_ext_tune = true;
+    if (out.forced_bad) return false;
+    if (has_header(out)) set_service(out, SDV_SRV_HEADER_LINE);
+    return true;
+}
+
 /* Binarizer::processLine (binarizer.cpp:443-1724), PCM1Line output, for the video line staged in lds.w.px: the stage machine from
  * what the caller has preset on its Binarizer (`b`: in_black / in_white / in_ref / in_coord, limits by mode) to the finished line.
  * A pure function of the pixels, the presets, the mode and the fine settings. */
@@ -735,7 +763,7 @@ __device__ inline void stage_row(uint8_t *px, const uint8_t *row, int width)
  * with it in the same function their register allocation and their rates suffer - measured 736 k -> 574-648 k frames/s for the PCM-1
  * frame driver, 372 k -> 240 k for the PCM-16x0 one) */
 template <bool kInsane>
-__device__ inline void process_line_p1(BinCtx &c, Bin &b, bool coord_search, P1Lds &lds, L1 &out, bool vl_doubled)
+__device__ __forceinline__ void process_line_p1(BinCtx &c, Bin &b, bool coord_search, P1Lds &lds, L1 &out, bool vl_doubled)
 {
     p1_clear(out);
     out.coords.doubled = vl_doubled;

@@ -82,6 +82,7 @@ __device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int
         const int row = frame_buf_row(a, f, (k + 1) * gap);
         if (row >= 0) {
             stage_row(lds.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
+#pragma unroll 1
             for (int variant = 0; variant < (sweep_flag_matters(a.preset) ? 2 : 1); variant++) {
                 BinCtx c; Bin b;
                 b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord);       /* setGoodParameters() (:221) */
@@ -323,6 +324,14 @@ __device__ inline void v2d1_post_line(V2D1 &w, const FrameArgs &a, WaveLds &lds,
 #ifndef SDV_P1_BATCH
 #define SDV_P1_BATCH 1              /* runs of lines that read from one tuning take batch1, single ones lean_line1 */
 #endif
+#ifndef SDV_P1_CAPTURE_D
+#define SDV_P1_CAPTURE_D 8          /* batch1: lines in flight */
+#endif
+#ifdef SDV_EMU
+__device__ __forceinline__ uint8_t lean_load_u8(const uint8_t *p) { return *p; }
+#else
+__device__ __forceinline__ uint8_t lean_load_u8(const uint8_t *p) { return __builtin_nontemporal_load(p); }      /* read once */
+#endif
 #ifdef SDV_EMU
 __device__ inline uint32_t lane_read32(uint32_t x, uint32_t idx) { return (uint32_t)__shfl((int)x, (int)idx); }
 #else
@@ -378,8 +387,9 @@ __device__ inline bool lean1_prepare(Lean1 &n, const BinCtx &c, const Bin &b)
     return n.usable && c.force_bit_picker;
 }
 /* one read of a line under the tuning in n: the cells as two masks (cell b = bit b), the CRC over them; false when the CRC does not match
- * or the line is a Header */
-__device__ inline bool lean_read1(const Lean1 &n, uint8_t p0, uint8_t p1, uint64_t &s_lo, uint64_t &s_hi, u128 &cells, uint16_t &crc)
+ * or the line is a Header (*header says which: a Header is read, all 94 cells of it - the first rung of the ladder takes it, pick_cut_bits
+ * leaves a line alone that is valid, and a Header is valid whatever its CRC, pcm1line.cpp:314-323) */
+__device__ inline bool lean_read1(const Lean1 &n, uint8_t p0, uint8_t p1, uint64_t &s_lo, uint64_t &s_hi, u128 &cells, uint16_t &crc, bool *header = nullptr)
 {
     const int lane = lane_id();
     const bool second = lane + 64 < P1_BITS;
@@ -391,9 +401,11 @@ __device__ inline bool lean_read1(const Lean1 &n, uint8_t p0, uint8_t p1, uint64
     const uint64_t klo = (lane < 16) ? c_crc1.klo[lane & 15] : 0ull, khi = (lane < 16) ? c_crc1.khi[lane & 15] : 0ull;
     const int par = (__popcll(s_lo & klo) + __popcll(s_hi & khi)) & 1;
     crc = (uint16_t)((uint16_t)(__ballot(par) & 0xFFFF) ^ c_crc1.base);
-    if (crc != (uint16_t)(cells & 0xFFFF)) return false;
     L1 t; t.v = cells;
-    return !has_header(t);
+    const bool hdr = has_header(t);
+    if (header) *header = hdr;
+    if (hdr) return false;
+    return crc == (uint16_t)(cells & 0xFFFF);
 }
 __device__ inline void lean_fill_line1(const Lean1 &n, const FrameArgs &a, const Bin &b, u128 cells, uint16_t crc, L1 &out)
 {
@@ -412,8 +424,16 @@ __device__ inline void lean_fill_line1(const Lean1 &n, const FrameArgs &a, const
 __device__ inline bool lean_line1(Lean1 &n, const BinCtx &c, const FrameArgs &a, const Bin &b, const uint8_t *px_row, L1 &out)
 {
     if (!lean1_prepare(n, c, b)) return false;
-    uint64_t s_lo, s_hi; u128 cells; uint16_t crc;
-    if (!lean_read1(n, px_row[n.x0], px_row[n.x1], s_lo, s_hi, cells, crc)) return false;
+    uint64_t s_lo, s_hi; u128 cells; uint16_t crc; bool header = false;
+    if (!lean_read1(n, px_row[n.x0], px_row[n.x1], s_lo, s_hi, cells, crc, &header)) {
+        if (!header) return false;
+        /* a Header line: read like any line (STG_INPUT_ALL, valid on the first rung), then made a service line (STG_DATA_OK, binarizer.cpp:1534-1621:
+         * PCMLine::setServiceLine clears the base class's members - levels, coordinates, flags, the calculated CRC - and leaves the words and the
+         * picked bits) */
+        lean_fill_line1(n, a, b, cells, crc, out);
+        set_service(out, SDV_SRV_HEADER_LINE);
+        return true;
+    }
     lean_fill_line1(n, a, b, cells, crc, out);
     return true;
 }
@@ -432,12 +452,41 @@ __device__ inline int batch1(V2D1 &w, const FrameArgs &a, WaveLds &lds, const Le
     int n_lines = nl - idx; if (n_lines > 64) n_lines = 64;
     uint32_t m0 = 0, m1 = 0, m2 = 0;
     int n_ok = 0;
-    for (int l = 0; l < n_lines; l++) {
-        const uint8_t *rowp = frame + (size_t)(2 * (idx + l) + field) * a.row_stride;
-        uint64_t s_lo, s_hi; u128 cells; uint16_t crc;
-        if (!lean_read1(n, rowp[n.x0], rowp[n.x1], s_lo, s_hi, cells, crc)) break;
-        m0 = park_lane(m0, (uint32_t)s_lo, l); m1 = park_lane(m1, (uint32_t)(s_lo >> 32), l); m2 = park_lane(m2, (uint32_t)s_hi, l);
-        n_ok = l + 1;
+    {   /* Phase A, the pattern of the STC-007 capture (stc007_device.h): per line two byte gathers per lane straight from the frame (D lines in
+         * flight: a line costs its share of the memory's bandwidth, not one trip to it), four ballots, and the masks parked in the lane that owns the
+         * line; then every lane solves its own line - automaton and CRC.  A line that does not read ends the run: what was fetched behind it is
+         * fetched again by whatever takes that line. */
+        constexpr int D = SDV_P1_CAPTURE_D;
+        static_assert(64 % D == 0, "whole groups of D lines make a run of up to 64");
+        const uint32_t rs2 = 2u * (uint32_t)a.row_stride;
+        const uint8_t *row0 = frame + (size_t)(2 * idx + field) * a.row_stride;
+        const uint32_t x0 = n.x0, x1 = n.x1, lo = n.low, hi = n.high;
+        const bool second = lane + 64 < P1_BITS;
+        uint8_t q[D][2];
+#pragma unroll
+        for (int d = 0; d < D; d++) { const uint32_t o = (uint32_t)(d < n_lines ? d : n_lines - 1) * rs2; q[d][0] = lean_load_u8(row0 + (o + x0)); q[d][1] = lean_load_u8(row0 + (o + x1)); }
+        uint32_t ra0 = 0, ra1 = 0, ra2 = 0, rb0 = 0, rb1 = 0, rb2 = 0;
+        for (int j0 = 0; j0 < n_lines; j0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int j = j0 + d;
+                const uint8_t p0 = q[d][0], p1 = q[d][1];
+                const uint64_t a_lo = __ballot(p0 > lo), b_lo = __ballot(p0 >= hi), a_hi = __ballot(second && p1 > lo), b_hi = __ballot(second && p1 >= hi);
+                { const int jn = j + D < n_lines ? j + D : n_lines - 1; const uint32_t o = (uint32_t)jn * rs2; q[d][0] = lean_load_u8(row0 + (o + x0)); q[d][1] = lean_load_u8(row0 + (o + x1)); }
+                ra0 = park_lane(ra0, (uint32_t)a_lo, j); ra1 = park_lane(ra1, (uint32_t)(a_lo >> 32), j); ra2 = park_lane(ra2, (uint32_t)a_hi, j);
+                rb0 = park_lane(rb0, (uint32_t)b_lo, j); rb1 = park_lane(rb1, (uint32_t)(b_lo >> 32), j); rb2 = park_lane(rb2, (uint32_t)b_hi, j);
+            }
+        }
+        uint64_t s_lo, s_hi;
+        solve_automaton_lane((uint64_t)ra0 | ((uint64_t)ra1 << 32), (uint64_t)ra2, (uint64_t)rb0 | ((uint64_t)rb1 << 32), (uint64_t)rb2, s_lo, s_hi);
+        s_hi &= (1ull << (P1_BITS - 64)) - 1ull;
+        const u128 cells = ((u128)__brevll(s_lo) << 30) | (u128)(__brevll(s_hi) >> 34);
+        const uint16_t crc = crc_of_masks(s_lo, s_hi);
+        L1 t; t.v = cells;
+        const bool ok = crc == (uint16_t)(cells & 0xFFFF) && !has_header(t);
+        const uint64_t okm = __ballot(ok || lane >= n_lines);
+        n_ok = okm == ~0ull ? n_lines : (__ffsll((unsigned long long)~okm) - 1);
+        m0 = (uint32_t)s_lo; m1 = (uint32_t)(s_lo >> 32); m2 = (uint32_t)s_hi;
     }
     if (n_ok == 0) return 0;
     /* phase B: lane j = line j of the run */
@@ -503,11 +552,16 @@ __device__ inline int batch1(V2D1 &w, const FrameArgs &a, WaveLds &lds, const Le
     return n_ok;
 }
 
-/* one frame */
-template <bool kInsane>
+/* one frame.  kLean: the build without Binarizer::processLine's search stages - a frame with a line the tuning it inherits does not read is given up
+ * (its flag says VF_ABORTED) and decoded again by the full build (pcm1_frames_engine.inc); the pattern of the STC-007 frame kernels. */
+template <bool kInsane, bool kLean = false>
 __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
 {
     const FrameArgs &a = a1.f;
+    if (kLean && (f == a.end_file_frame || frame_is_empty(a, f))) {          /* frames without pixels: the full build's */
+        if (lane_id() == 0) a.flag[f] = VF_ABORTED;
+        return;
+    }
     V2D1 w; L1 wl;
     v2d1_load_state(w, lds.w, &a.states_in[f], a);
     V2D &v = w.v;
@@ -555,7 +609,10 @@ __device__ inline void frame_body1(const FrameArgs1 &a1, P1Lds &lds, int f)
             /* :853-884: the real-time modes stop searching once a field has produced enough good lines */
             bool coord_search = true;
             if (a.mode == SDV_MODE_DRAFT || a.mode == SDV_MODE_FAST) coord_search = !(v.good_coords_in_field > 2 || v.pcm_lines_in_field > 2);
-            if (!(SDV_P1_BATCH && lean_line1(lean, c, a, v.bin, lds.w.px, wl))) process_line_p1<kInsane>(c, v.bin, coord_search, lds, wl, doubled);
+            if (!(SDV_P1_BATCH && lean_line1(lean, c, a, v.bin, lds.w.px, wl))) {
+                if (kLean) { if (!input_all_p1(c, v.bin, lds.w, wl, doubled)) { if (lane_id() == 0) a.flag[f] = VF_ABORTED; return; } }
+                else process_line_p1<kInsane>(c, v.bin, coord_search, lds, wl, doubled);
+            }
             v2d1_post_line(w, a, lds.w, wl, fv_keys, fi_keys, (line_num % 2) == 0);
             emit_rec(wl, frame_no, line_num, doubled, rec++);
         }
@@ -744,6 +801,16 @@ __global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_frames_bi
 }
 SDV_P1F_KERNELS(, false)
 SDV_P1F_KERNELS(_insane, true)
+#ifndef SDV_P1F_LEAN_WAVES_PER_EU
+#define SDV_P1F_LEAN_WAVES_PER_EU 4
+#endif
+/* the lean build of the frame kernel (every mode: what it holds - lines that read from what they inherit - is the same in all of them) */
+__global__ void __launch_bounds__(64, SDV_P1F_LEAN_WAVES_PER_EU) sdv_k_pcm1_frames_lean(sdvp1f::FrameArgs1 a)
+{
+    __shared__ sdvp1b::P1Lds lds;
+    const int f = a.f.frame_list ? a.f.frame_list[blockIdx.x] : a.f.frame_lo + (int)blockIdx.x;
+    sdvp1f::frame_body1<false, true>(a, lds, f);
+}
 #ifndef SDV_EMU
 __global__ void sdv_k_pcm1_predict(sdvp1f::PredictArgs1 a)
 {
