@@ -246,6 +246,7 @@ def main():
     ap.add_argument("--cpu-frames-all-cores", type=int, default=1500, help="frames per worker of the all-core CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stitch", action="store_true", help="skip the extra stitch-stage measurement")
+    ap.add_argument("--configs4-frames", type=int, default=100000, help="length of the one tape of BASELINE configs[4] (sharded over the ranks: strong scaling); 0 = skip that leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -393,6 +394,61 @@ def main():
             eng.reset_stream(); eng.reset_stitcher()
         except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
             sharded_full = {"error": repr(ex)}
+
+    # BASELINE configs[4], literally: ONE tape of 100 000 NTSC frames, NEW_FILE .. END_FILE, frames -> PCMSamplePair, sharded over the ranks of the
+    # job in contiguous frame ranges (ShardedDecoder; 12 500 frames per rank at N = 8) - strong scaling: the tape stays, the ranks share it.  Runs at
+    # every N (at N = 1 through the same code, the "all-gather" being the rank's own bytes when no process group exists), so that the driver's
+    # 1/2/4/8 runs give the curve north_star asks for.  Reported as absolute frames/s and as a fraction of the HBM roofline on SURVEY 8d's bytes.
+    configs4 = None
+    if args.configs4_frames > 0 and not args.no_stitch:
+        try:
+            from sdvpcmdecoder_amd.sharded import ShardedDecoder
+            total = args.configs4_frames
+            if use_dist:
+                assert dist.get_world_size() == args.gpus == world, "the process group does not have --gpus ranks"
+                gather4 = torch_all_gather(dev if backend == "nccl" else None)
+            else:
+                gather4 = lambda b: [b]         # noqa: E731 - one rank: what it would receive from itself
+            dec4 = ShardedDecoder(eng, rank, world, gather4, H)
+            g0, g1 = dec4.frames_needed(total)
+            torch.cuda.synchronize(dev)
+            tg = time.perf_counter()
+            lum4, _ = synth.stc007_frames_torch(total, seed=5, device=dev, width=W, height=H, noise_sigma=args.noise, frame_range=(g0, g1))
+            torch.cuda.synchronize(dev)
+            gen_s = time.perf_counter() - tg
+            eng.reset_stream(); eng.reset_stitcher()
+            ms4 = []
+            for _ in range(3):                                   # the first pass pays the allocations
+                barrier()
+                t1 = time.perf_counter()
+                p4, f4 = dec4.decode(lum4, total, first_frame_no=1)
+                barrier()
+                ms4.append((time.perf_counter() - t1) * 1e3)
+            t4 = torch.tensor([min(ms4), float(p4.shape[0]), float(dec4.stats["binarize_redo"]), float(dec4.stats["stitch_redo"]), float(g1 - g0)], dtype=torch.float64,
+                              device=dev if (use_dist and backend == "nccl") else "cpu")
+            mx4, sm4 = t4.clone(), t4.clone()
+            if use_dist:
+                dist.all_reduce(mx4, op=dist.ReduceOp.MAX); dist.all_reduce(sm4, op=dist.ReduceOp.SUM)
+            best4 = float(mx4[0].item())
+            E2E_BYTES4 = W * H + H * 32 + 1470 * 8      # 377 232 B per NTSC frame, frames -> PCMSamplePair
+            configs4 = {"workload": "configs[4]: one %d-frame synthetic STC-007 NTSC stream, NEW_FILE .. END_FILE, frames -> PCMSamplePair, sharded over %d rank(s) in contiguous "
+                                    "frame ranges with one all-gather of the hand-over states" % (total, world),
+                        "scaling": "strong", "frames": total, "ranks": world, "frames_per_rank": (total + world - 1) // world,
+                        "frames_rendered_per_rank_max": int(mx4[4].item()),
+                        "ms": best4, "frames_per_s": total / (best4 / 1e3),
+                        "roofline": {"bound": "hbm", "achieved": total * E2E_BYTES4 / best4 / 1e6, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                     "frac": total * E2E_BYTES4 / best4 / 1e6 / (HBM_PEAK_GBS * world), "algorithmic_bytes_per_frame": E2E_BYTES4,
+                                     "note": "whole-job bytes over the wall clock of the slowest rank, against the HBM peak of all ranks' GPUs"},
+                        "sample_pairs": int(sm4[1].item()), "ranges_decoded_again": {"binarize": int(sm4[2].item()), "stitch": int(sm4[3].item())},
+                        "all_gathers_per_pass": dec4.stats["gathers"] // 3,
+                        "backend": (backend if use_dist else "none (one process)"), "process_group_ranks": (dist.get_world_size() if use_dist else 1),
+                        "passes_ms": ms4, "tape_render_s": gen_s,
+                        "note": "best of three passes, wall clock between two barriers (max over the ranks), cold start of a file every pass; not part of `value` "
+                                "(which is BASELINE's per-GPU batch, weak scaling)"}
+            del lum4, p4, f4
+            eng.reset_stream(); eng.reset_stitcher()
+        except Exception as ex:     # noqa: BLE001 - an extra figure must not take the benchmark line down
+            configs4 = {"error": repr(ex)}
 
     # beyond BASELINE's metric: the stitch stage (STC007DataStitcher -> PCMSamplePair) over the records just produced, and the
     # whole path frames -> PCM, both as a continuing stream (every step continues the tape, like the binarize steps above)
@@ -800,6 +856,8 @@ def main():
             out["roofline"]["traffic_from_committed_profile"] = stale
         if sharded_full is not None:
             out["sharded_full_path"] = sharded_full
+        if configs4 is not None:
+            out["configs4_strong"] = configs4
         if world == 1 and not args.no_stitch:
             # the boundary takes device pointers; a caller that keeps its frames in host memory pays this on top (never part of `value`)
             try:
@@ -1010,6 +1068,9 @@ def main():
             "pcm16x0_si_ms_per_step": pick(out, "pcm16x0_stage", "si", "ms_per_step"), "pcm16x0_ei_ms_per_step": pick(out, "pcm16x0_stage", "ei", "ms_per_step"),
             "audio_worn_tape_ms_per_step": pick(out, "audio_stage", "invalid_word_in_every_window", "ms_per_step"),
             "cpu_all_cores_frames_per_s": pick(out, "cpu_baseline_all_cores", "value"), "cpu_all_cores": pick(out, "cpu_baseline_all_cores", "cores"),
+            "configs4_frames": pick(out, "configs4_strong", "frames"), "configs4_ranks": pick(out, "configs4_strong", "ranks"), "configs4_scaling": pick(out, "configs4_strong", "scaling"),
+            "configs4_ms": pick(out, "configs4_strong", "ms"), "configs4_frames_per_s": pick(out, "configs4_strong", "frames_per_s"),
+            "configs4_frac": pick(out, "configs4_strong", "roofline", "frac"), "configs4_process_group_ranks": pick(out, "configs4_strong", "process_group_ranks"),
             "sharded_full_path_ms": pick(out, "sharded_full_path", "ms"),
             "sharded_one_engine_same_file_ms": pick(out, "sharded_full_path", "one_engine_same_file_ms"),
         }
