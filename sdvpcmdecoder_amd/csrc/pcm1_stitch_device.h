@@ -211,6 +211,14 @@ enum { LDS_LINES = SDV_P1_LDS_LINES };   /* a 525-line frame's 490 PCM lines + s
  *   b = { words[5] | words[6] << 16, calc_crc | ref_level << 16 | picked_bits_left << 24, picked_bits_right | service_type << 8 | flags << 16, pad } */
 struct Raw32 { uint4 a, b; };
 static_assert(sizeof(sdv_pcm1_line_rec) == 32, "record layout");
+/* words 2 part, 2 part + 1 of a line, by masks: as `l.w[2 * part]`, or as a choice between members by `part`, the compiler reads the line through a computed
+ * address - and a line that is addressed like that lives in scratch memory (the visualiser's build of the frame kernel: 256 registers and 328 bytes of it) */
+__device__ __forceinline__ uint32_t line_word_pair(const Line16 &l, uint32_t part)
+{
+    const uint32_t p0 = (uint32_t)l.w[0] | ((uint32_t)l.w[1] << 16), p1 = (uint32_t)l.w[2] | ((uint32_t)l.w[3] << 16), p2 = (uint32_t)l.w[4] | ((uint32_t)l.w[5] << 16);
+    const uint32_t m0 = part == 0 ? ~0u : 0u, m1 = part == 1 ? ~0u : 0u, m2 = part >= 2 ? ~0u : 0u;
+    return (p0 & m0) | (p1 & m1) | (p2 & m2);
+}
 struct LineBits { uint32_t w01, w23, w45, meta; };      /* the bytes of a Line16: meta = line | fl << 16 | ref << 24 */
 static_assert(sizeof(Line16) == 16 && sizeof(LineBits) == 16, "line layout");
 
@@ -553,7 +561,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             if (o < lim && pl >= f_top && pl - f_top < f_lines) {
                 const uint32_t li1 = fidx[pl - f_top];
                 if (kLds) { ww = ((const uint32_t *)lines[li1].w)[part]; ok = (lines[li1].fl & LF_OK) != 0; }
-                else { const Line16 l = line_at(li1); ww = part == 0 ? (l.w[0] | ((uint32_t)l.w[1] << 16)) : (part == 1 ? (l.w[2] | ((uint32_t)l.w[3] << 16)) : (l.w[4] | ((uint32_t)l.w[5] << 16))); ok = (l.fl & LF_OK) != 0; }
+                else { const Line16 l = line_at(li1); ww = line_word_pair(l, part); ok = (l.fl & LF_OK) != 0; }
             }
             const uint32_t flags = ((valid_blocks >> blk) & 1u ? (uint32_t)SDV_SF_BLOCK_OK : 0u) | (ok ? (uint32_t)SDV_SF_WORD_VALID : 0u);
             if (o < lim)
@@ -567,6 +575,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             const uint32_t first_line = odd_field ? 1u : 2u;
             if (a.out_blocks) {
                 const uint64_t bb = d * 16u + 8u * (uint32_t)fld;
+#pragma unroll 1
                 for (uint32_t c = 0; c < SUBLINES_PF + 1; c += 64) {
                     const uint32_t o = c + (uint32_t)lane;                              /* o = 735: the two words the last block does not have */
                     const uint32_t blk = o < SUBLINES_PF ? o / 92 : 7u, pr = o - 92 * blk;
@@ -578,7 +587,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
                         const uint32_t pl = sub / 3, part = sub - 3 * pl;
                         if (pl >= f_top && pl - f_top < f_lines) {
                             const Line16 l = line_at(fidx[pl - f_top]);
-                            ww = part == 0 ? (l.w[0] | ((uint32_t)l.w[1] << 16)) : (part == 1 ? (l.w[2] | ((uint32_t)l.w[3] << 16)) : (l.w[4] | ((uint32_t)l.w[5] << 16)));
+                            ww = line_word_pair(l, part);
                             const uint32_t ok = (l.fl & LF_OK) ? (uint32_t)SDV_P1W_CRC_OK : 0u, pc = (l.fl & LF_PICK) ? (uint32_t)SDV_P1W_PICKED_WORD : 0u;
                             f0 = ok | pc | ((part == 0 && (l.fl & LF_PICKL)) ? (uint32_t)(SDV_P1W_PICKED_LEFT | SDV_P1W_PICKED_WORD) : 0u); f1 = ok | pc;
                         }
@@ -604,6 +613,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
             }
             if (a.out_asm) {
                 const uint64_t lb = d * (uint64_t)(2 * SUBLINES_PF) + (uint64_t)SUBLINES_PF * (uint32_t)fld;
+#pragma unroll 1
                 for (uint32_t c = 0; c < SUBLINES_PF; c += 64) {
                     const uint32_t sub = c + (uint32_t)lane, pl = sub / 3, part = sub - 3 * pl;
                     if (sub >= SUBLINES_PF || lb + sub >= a.asm_cap) continue;
@@ -619,7 +629,7 @@ __device__ inline bool frame_body(const FrameArgs1 &a, uint32_t k, int lane, uin
                             const sdv_pcm1_line_rec &src = a.src.at(lo + li1);
                             if (odd_field && src.service_type == SDV_SRV_FILLER) r.flags = SDV_P1S_SKIP;     /* went in with frame number 0 (:713-717): not handed over */
                             else {
-                                r.words[0] = l.w[2 * part]; r.words[1] = l.w[2 * part + 1];
+                                { const uint32_t wp = line_word_pair(l, part); r.words[0] = (uint16_t)wp; r.words[1] = (uint16_t)(wp >> 16); }
                                 r.flags = (uint8_t)(((l.fl & LF_BW) ? SDV_P1S_BW_SET : 0) | ((l.fl & LF_VALID) ? SDV_P1S_CRC_VALID : 0));
                                 if (l.fl & (LF_PICK | LF_PICKL)) { r.picked_bits_left = part == 0 ? src.picked_bits_left : 0; r.picked_bits_right = src.picked_bits_right; }
                             }
@@ -701,7 +711,7 @@ __global__ void __launch_bounds__(64) sdv_k_stitch_tail(sdv_stitch_tail_args a)
 __global__ void __launch_bounds__(64) sdv_k_pcm1_hist(sdvp1::HistArgs1 a) { sdvp1::hist_body(a, (int)threadIdx.x); }
 struct sdv_p1_hist_clear_args { void *hist; };
 __global__ void __launch_bounds__(64) sdv_k_pcm1_hist_clear(sdv_p1_hist_clear_args a) { sdvp1::hist_clear_body(a.hist, (int)threadIdx.x); }
-__global__ void __launch_bounds__(64) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
+__global__ void __launch_bounds__(64, 4) sdv_k_pcm1_frames(sdvp1::FrameArgs1 a)
 {
     alignas(16) __shared__ sdvp1::Line16 lines[sdvp1::LDS_LINES];
     __shared__ uint16_t field_idx[2][sdvp1::LINES_PF + 3];
