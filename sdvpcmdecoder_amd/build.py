@@ -23,6 +23,10 @@ KERNEL_SOURCES = {
     "sdv_k_pcm1_lines": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_engine.inc"),
     "sdv_k_pcm1_frames": ("pcm1_stitch_device.h", "pcm1_engine.inc"),
     "sdv_k_pcm1_frames_bin": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_frames_device.h", "pcm1_frames_engine.inc"),
+    "sdv_k_pcm1_frames_lean": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_frames_device.h", "pcm1_frames_engine.inc"),
+    "sdv_k_pcm1_prescan": ("stc007_device.h", "pcm1_bin_device.h", "pcm1_frames_device.h", "pcm1_frames_engine.inc"),
+    "sdv_k_pcm16_frames_lean": ("stc007_device.h", "pcm1_bin_device.h", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc"),
+    "sdv_k_pcm16_prescan": ("stc007_device.h", "pcm1_bin_device.h", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc"),
     "sdv_k_ap_": ("audio_device.h", "audio_engine.inc"),
     "sdv_k_pcm16_frames_bin": ("stc007_device.h", "pcm1_bin_device.h", "pcm16_bin_device.h", "pcm16_frames_device.h", "pcm16_frames_engine.inc"),
 }

@@ -49,12 +49,12 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $
 tail -1 $R/gpurun_out/prof_vis.log
 # PMC passes of the stitch kernels, the PCM-16x0 analysis, the prescans and the audio plan
 bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="
-# round 4: the damaged-tape kernels (general frame kernel, the two sweep kernels, the histogram carry) on the C3 PAL tape
+# the damaged-tape kernels (general frame kernel, the two sweep kernels, the histogram carry) on the C3 PAL tape
 bash $R/tools/gpu_pmc_round4.sh 2>&1 | grep "rc="
 # the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r04_profiles/; the raw counter and trace files stay
 # on the box (gpurun only merges 64 MiB back)
-cd $R && python tools/refresh_profiles.py r04 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
-rm -rf gpurun_out/r04_profiles && mkdir -p gpurun_out/r04_profiles && cp profiles/r04_* gpurun_out/r04_profiles/
+cd $R && python tools/refresh_profiles.py r05 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
+rm -rf gpurun_out/r05_profiles && mkdir -p gpurun_out/r05_profiles && cp profiles/r05_* gpurun_out/r05_profiles/
 find gpurun_out -name "*.csv" -size +256k -delete; find gpurun_out -name "*.db" -delete
 du -sh gpurun_out | tail -1
 # scheduler traces of the two damaged tapes (developer build, when one was sent along)
@@ -62,4 +62,4 @@ if [ -f build/variants/dev.so ]; then
   SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/pal_trace.py 2000 both > gpurun_out/pal_trace_both.log 2>&1
   SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/jump_probe.py 10000 16 > gpurun_out/jump_trace.log 2>&1
 fi
-timeout 1200 python tools/soak.py 16 4000 > gpurun_out/soak_r04.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r04.log
+timeout 1200 python tools/soak.py 16 4000 > gpurun_out/soak_r05.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r05.log

@@ -3,7 +3,7 @@
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r04'      # the round the summaries are named for
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r05'      # the round the summaries are named for
 
 
 def newest(pat):
@@ -52,7 +52,10 @@ for kern, prefix, name, workload in (
         ('sdv_k_pcm16_analyse', 'p16epmc', 'sdv_k_pcm16_analyse_ei', 'tools/pcm16_prof.py 10000 1 ei: 3072 frames per launch (three batches)'),
         ('sdv_k_pcm1_prescan', 'p1fpre', 'sdv_k_pcm1_prescan', 'tools/pcm1_frames_prof.py 10000 1: 10 000 frames, four prescan lines per frame, last mode of the run (NORMAL)'),
         ('sdv_k_pcm16_prescan', 'p16fpre', 'sdv_k_pcm16_prescan', 'tools/pcm16_frames_prof.py 10000 1: 10 000 frames, four prescan lines per frame, last mode of the run (NORMAL)'),
-        ('sdv_k_pcm16_frames_bin', 'p16fpre', 'sdv_k_pcm16_frames_bin', 'tools/pcm16_frames_prof.py 10000 1: 10 000 frames per launch, last mode of the run (NORMAL)'),
+        ('sdv_k_pcm16_frames_bin', 'p16fpre', 'sdv_k_pcm16_frames_bin', 'tools/pcm16_frames_prof.py 10000 1: the frames the lean build gave up, last mode of the run (NORMAL)'),
+        ('sdv_k_pcm16_frames_lean', 'p16fpre', 'sdv_k_pcm16_frames_lean', 'tools/pcm16_frames_prof.py 10000 1: 10 000 frames per launch, last mode of the run (NORMAL)'),
+        ('sdv_k_pcm1_frames_lean', 'p1fpre', 'sdv_k_pcm1_frames_lean', 'tools/pcm1_frames_prof.py 10000 1: 10 000 frames per launch, last mode of the run (NORMAL)'),
+        ('sdv_k_pcm1_frames_bin', 'p1fpre', 'sdv_k_pcm1_frames_bin', 'tools/pcm1_frames_prof.py 10000 1: the frames the lean build gave up, last mode of the run (NORMAL)'),
         ('sdv_k_ap_plan', 'applan', 'sdv_k_ap_plan', 'tools/audio_prof.py 10000 1: last tape of the run (an invalid word in every window)')):
     if glob.glob(f'gpurun_out/{prefix}1/**/*_counter_collection.csv', recursive=True):
         subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', kern, f'profiles/{RND}_pmc_{name}.json', prefix, workload], stdout=subprocess.DEVNULL)
