@@ -357,7 +357,7 @@ typedef struct sdv_stitch_info {
     uint32_t pipelined;         /* 1: the call ran its analysis and first round without waiting for the host (a stream that plays);
                                  * 2: ... and the field order and resolution histories were saturated, so the host's check needed no replay of them */
     float device_ms;            /* analysis + rounds + packing on the device (profiling on) */
-    float _pad2;
+    uint32_t direct_frames;     /* sdv_decode_frames: frames whose lines the frame kernel wrote into the stitch stage's field buffers itself (no line records) */
 } sdv_stitch_info;
 
 /* Defaults of the STC007DataStitcher constructor / setDefaultFineSettings (stc007datastitcher.cpp:20-31, 7228-7236),

@@ -148,7 +148,15 @@ struct FrameArgs {
     int32_t *memo_head;             /* ... [n_total * height] the newest entry of a line (-1: none), ... */
     int32_t *memo_count; int32_t memo_cap;   /* ... entries handed out (may run past the capacity: those requests were dropped) */
     unsigned long long *bw_memo;    /* [n_total * height] or NULL: what findBlackWhite found on a line, kept from one decode of a frame to the next (find_black_white) */
+    /* the fused entry (sdv_decode_frames), a tape that plays: a frame the whole-frame capture takes from end to end goes straight into the stitcher's field
+     * buffers - 32-byte lines in field order, what sdv_k_stitch_analyze would make of the frame's 48-byte records - and leaves a summary instead of records */
+    void *direct_fields;            /* the stitcher's field buffers (SLine[segments][2][direct_pitch]), or NULL */
+    struct DirectFrame *direct_frames;      /* [n_total] what frame f left there (flag 0: nothing, its records are in recs) */
+    int direct_seg_ofs, direct_pitch;       /* frame f is the stitcher's segment f + direct_seg_ofs; lines per field buffer */
 };
+/* what a frame that went straight into the field buffers tells the analysis kernel (stc007_stitch_device.h, analyze_body) */
+struct DirectFrame { uint32_t frame_number; uint16_t n[2], bad[2]; uint8_t ref, flag, _pad[2]; };
+enum { DSL_FORCED_BAD = 1, DSL_COORDS_VALID = 2, DSL_BW_SET = 4 };      /* SLine::flags as the stitcher names them (SL_*, checked there) */
 /* a dropped frame: VideoInFFMPEG::insertDummyFrame(false, true) sends its lines as empty VideoLines (vin_ffmpeg.cpp:367-522) */
 __device__ __forceinline__ bool frame_is_empty(const FrameArgs &a, int f) { return a.frame_flags && f < a.n_total && f != a.end_file_frame && (a.frame_flags[f] & SDV_FRAME_EMPTY); }
 
@@ -2328,7 +2336,7 @@ static_assert(REC_STAGE_OFS >= SDV_PX_BYTES && REC_STAGE_OFS + REC_STAGE_BYTES <
  * whole-frame capture leaves them out: while it lasts every line has the one pair the frame was started with, and the list is filled in
  * only when the capture ends early) */
 __device__ inline void batch_finish(const FrameArgs &a, WaveLds &lds, V2D &v, const BatchLane &bl, int n, uint32_t frame_no, uint16_t first_line_num,
-                                    uint32_t *fv_keys, sdv_line_rec *rec, bool write_keys = true)
+                                    uint32_t *fv_keys, sdv_line_rec *rec, bool write_keys = true, uint4 *direct_dst = nullptr, int *n_forced = nullptr)
 {
     const sdv_bin_preset &ps = a.preset;
     Bin &b = v.bin;
@@ -2384,6 +2392,27 @@ __device__ inline void batch_finish(const FrameArgs &a, WaveLds &lds, V2D &v, co
     static_assert(sizeof(sdv_line_rec) == 48 && offsetof(sdv_line_rec, words) == 6 && offsetof(sdv_line_rec, calc_crc) == 24 && offsetof(sdv_line_rec, data_stop) == 28 &&
                   offsetof(sdv_line_rec, black_level) == 36 && offsetof(sdv_line_rec, ref_high) == 40 && offsetof(sdv_line_rec, mark_st_stage) == 44 && offsetof(sdv_line_rec, word_state) == 47,
                   "the record is put together dword by dword");
+    if (n_forced) *n_forced = __popcll(bad_m);
+    if (direct_dst) {
+        /* the line as the stitcher keeps it (SLine, 32 bytes: the record's first six dwords, then calc_crc | word_crc mask, word_valid mask | flags |
+         * reference level - sline_from_raw, stc007_stitch_device.h), straight into the field buffer: two pieces of 16 bytes per line through the stage */
+        const uint32_t wm = forced_bad ? 0u : 0x1FFu, slf = (forced_bad ? (uint32_t)DSL_FORCED_BAD : 0u) | (uint32_t)DSL_COORDS_VALID | (uint32_t)DSL_BW_SET;
+        uint4 h1;
+        h1.x = g1.x; h1.y = g1.y; h1.z = crc | (wm << 16); h1.w = wm | (slf << 16) | ((uint32_t)b.in_ref << 24);
+        uint4 *const stage = (uint4 *)((uint8_t *)&lds + REC_STAGE_OFS);
+        const int pieces = 2 * n;
+        for (int c = 0; 64 * c < pieces; c++) {
+            SDV_WAVE_SYNC();
+            const int p0 = 2 * lane - 64 * c;
+            if (active && (unsigned)p0 < 64u) { stage[p0] = g0; stage[p0 + 1] = h1; }
+            SDV_WAVE_SYNC();
+#if SDV_NT_RECORDS && !defined(SDV_EMU)
+            if (64 * c + lane < pieces) { const uint4 q = stage[lane]; typedef uint32_t v4u __attribute__((ext_vector_type(4))); v4u t; t.x = q.x; t.y = q.y; t.z = q.z; t.w = q.w; __builtin_nontemporal_store(t, (v4u *)(direct_dst + 64 * c + lane)); }
+#else
+            if (64 * c + lane < pieces) direct_dst[64 * c + lane] = stage[lane];
+#endif
+        }
+    } else {
     uint4 *const dst = (uint4 *)rec;
 #if SDV_NT_RECORDS && !defined(SDV_EMU)
     /* the records are written once and read by a later kernel: streaming stores */
@@ -2412,6 +2441,7 @@ __device__ inline void batch_finish(const FrameArgs &a, WaveLds &lds, V2D &v, co
 #else
     if (active) { put(g0, dst + 3 * lane); put(g1, dst + 3 * lane + 1); put(g2, dst + 3 * lane + 2); }
 #endif
+    }
     if (active && write_keys) fv_keys[v.nfv + lane] = coords_key(b.in_coord.start, b.in_coord.stop);
     /* wave-uniform state after the n lines */
     int nd = __popcll(dup_m), nb = __popcll(bad_m);
@@ -2482,6 +2512,10 @@ template <bool kLean>
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowCtx *sc = nullptr)
 {
     bool sc_args_set = false;           /* sc->a = a: once per frame */
+    /* every decode of a frame says anew where its lines went (the last one counts): this build at the end of the frame, with everything else it writes - a
+     * store at the head of the frame is a write in the middle of the other frames' reads; the general build, which decodes the frames this one gave up, here */
+    if (!kLean && a.direct_frames && lane_id() == 0) a.direct_frames[f].flag = 0;
+    DirectFrame dsum; dsum.frame_number = 0; dsum.n[0] = dsum.n[1] = dsum.bad[0] = dsum.bad[1] = 0; dsum.ref = 0; dsum.flag = 0; dsum._pad[0] = dsum._pad[1] = 0;
     K1_BEGIN();
     K1_T(t_begin);
     V2D v; Line wl;
@@ -2572,6 +2606,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     uint16_t line_num = 0;
     int start_field = 0, start_idx = 0;
     bool all_captured = false; uint32_t captured_key = 0;
+    bool frame_direct = false;              /* the frame's lines went straight into the stitcher's field buffers (no records) */
     bool sweep_pending = false;             /* a line of this frame went on without the sweep it asked for: the frame is decoded again */
     bool used_general = false;              /* a line of this frame took the general path */
 #ifdef SDV_K1_STAMPS
@@ -2657,6 +2692,20 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 n_done = c + 1;
                 if (n_ok0 < cn0) { whole = false; start_field = 0; start_idx = 64 * c + n_ok0; }
             }
+            /* Straight into the stitcher's field buffers (FrameArgs::direct_fields) when the capture took every line of both fields: known here, before
+             * anything of the frame is written.  Not the last frame of the call (the stitcher keeps that one's records for the next call), not a frame with
+             * a service line of its own in front of it. */
+            bool direct = false;
+            if (a.direct_fields && whole && f + 1 < a.n_total && f != a.new_file_frame && n0 <= a.direct_pitch && n1 <= a.direct_pitch) {
+                direct = true;
+                for (int c = 0; c < n_chunks; c++) {
+                    const int cn1 = n1 - 64 * c < 64 ? (n1 - 64 * c > 0 ? n1 - 64 * c : 0) : 64;
+                    if ((int)((ok1_packed >> (7 * c)) & 0x7F) != cn1) direct = false;
+                }
+            }
+            uint4 *const dfield0 = direct ? (uint4 *)a.direct_fields + ((size_t)(f + a.direct_seg_ofs) * 2u) * (size_t)a.direct_pitch * 2u : nullptr;      /* (a line is two uint4) */
+            uint4 *const dfield1 = direct ? dfield0 + (size_t)a.direct_pitch * 2u : nullptr;
+            int forced0 = 0, forced1 = 0;
             /* field 0 goes through the per-line bookkeeping */
             K1_T(t_s1b);
             for (int c = 0; c < n_done; c++) {
@@ -2666,14 +2715,17 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 for (int u = 0; u < HOLD_CHUNKS; u++)
                     if (c == u) { bl.d0 = hold[u][0]; bl.d1 = hold[u][1]; bl.d2 = hold[u][2]; bl.d3 = hold[u][3]; }
                 bl.meta = (uint32_t)rev16(bl.d3 >> 16);
-                if (n_ok0 > 0) { batch_finish(a, lds, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec, false); rec += n_ok0; }
+                int nf = 0;
+                if (n_ok0 > 0) { batch_finish(a, lds, v, bl, n_ok0, frame_no, (uint16_t)(1 + 2 * (64 * c)), fv_keys, rec, false, direct ? dfield0 + 128 * c : nullptr, &nf); rec += n_ok0; }
+                forced0 += nf;
             }
             K1_T(t_s2);
             K1_ADD(6, t_s1b, t_s2);
             if (whole) {
                 line_num = (uint16_t)(1 + 2 * n0);
                 v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
-                emit_record(wl, rec++);
+                if (!direct) emit_record(wl, rec);
+                rec++;
                 start_field = 1; start_idx = 0;
                 SDV_WAVE_SYNC();
                 for (int c = 0; c < n_chunks && whole; c++) {
@@ -2683,16 +2735,24 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     BatchLane bl;
                     bl.d0 = park[(c * 4 + 0) * 64 + lane]; bl.d1 = park[(c * 4 + 1) * 64 + lane]; bl.d2 = park[(c * 4 + 2) * 64 + lane];
                     bl.d3 = park[(c * 4 + 3) * 64 + lane]; bl.meta = (uint32_t)rev16(bl.d3 >> 16);
-                    if (n_ok1 > 0) { batch_finish(a, lds, v, bl, n_ok1, frame_no, (uint16_t)(2 + 2 * (64 * c)), fv_keys, rec, false); rec += n_ok1; }
+                    int nf = 0;
+                    if (n_ok1 > 0) { batch_finish(a, lds, v, bl, n_ok1, frame_no, (uint16_t)(2 + 2 * (64 * c)), fv_keys, rec, false, direct ? dfield1 + 128 * c : nullptr, &nf); rec += n_ok1; }
+                    forced1 += nf;
                     if (n_ok1 < cn1) { whole = false; start_idx = 64 * c + n_ok1; }
                 }
                 SDV_WAVE_SYNC();
                 if (whole) {
                     line_num = (uint16_t)(2 + 2 * n1);
                     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
-                    emit_record(wl, rec++);
+                    if (!direct) emit_record(wl, rec);
+                    rec++;
                     start_field = 2;
                     all_captured = true; captured_key = coords_key(v.bin.in_coord.start, v.bin.in_coord.stop);
+                    frame_direct = direct;
+                    if (direct) {
+                        dsum.frame_number = frame_no; dsum.n[0] = (uint16_t)n0; dsum.n[1] = (uint16_t)n1; dsum.bad[0] = (uint16_t)forced0; dsum.bad[1] = (uint16_t)forced1;
+                        dsum.ref = v.bin.in_ref; dsum.flag = 1;
+                    }
                 }
             }
             if (start_field < 2) {      /* the row-staging loop below takes over: its first row */
@@ -2924,7 +2984,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
     K1_T(t_ef0);
     v2d_end_frame(v, a, lds, frame_no, fv_keys, fi_keys, &a.stats[f], all_captured, captured_key);
-    emit_record(wl, rec++);
+    if (!frame_direct) emit_record(wl, rec);
+    rec++;
+    if (a.direct_frames && (kLean || frame_direct) && lane_id() == 0) a.direct_frames[f] = dsum;
     v2d_store_state(v, lds, &a.states_out[f], a, sweep_pending, used_general ? (uint8_t)VF_SLOW : (uint8_t)0);
     K1_T(t_end);
     K1_ADD(3, t_ef0, t_end);

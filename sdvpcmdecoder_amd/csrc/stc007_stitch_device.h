@@ -29,7 +29,7 @@ using sdvd::Block;
 enum { VID_UNKNOWN = 0, VID_PAL, VID_NTSC, VID_MAX };
 enum { ORDER_UNK = 0, ORDER_TFF, ORDER_BFF, ORDER_MAX };
 enum { LINES_PF_NTSC = 245, LINES_PF_PAL = 294, LINES_PF_MAX_PAL = 294 + 16, LINES_PF_MAX_NTSC = 294 - 32 };   /* config.h:80-81, stc007datastitcher.h */
-enum { BUF_FIELD = 294, BUF_TRIM = 3 * 640 * 3, MIN_GOOD_LINES_PF = 245 - 8, MIN_FILL_LINES_PF = 56 };
+enum { BUF_FIELD = 294, FIELD_PITCH = 296 /* lines from one field buffer to the next: BUF_FIELD rounded up to a whole number of 128-byte lines */, BUF_TRIM = 3 * 640 * 3, MIN_GOOD_LINES_PF = 245 - 8, MIN_FILL_LINES_PF = 56 };
 enum { MAX_PADDING_14BIT = 32, MAX_PADDING_16BIT = 16, MAX_BURST_SILENCE = 8, MAX_BURST_BROKEN = 1, MAX_BURST_UNCH_DELTA = 8 };
 enum { SRES_UNKNOWN = 0, SRES_14BIT, SRES_16BIT, SRES_MAX };
 enum { DS_NO_DATA = 0, DS_SILENCE, DS_BROKE, DS_NO_PAD, DS_OK };
@@ -261,8 +261,8 @@ struct Field {
     const SLine *lines; int size;               /* size = data lines */
     __device__ inline SLine get(int i) const { return lines[i]; }
 };
-/* the field buffers of all frames: BUF_FIELD lines for (frame k, odd) then (frame k, even), written by the analysis pass */
-__device__ inline const SLine *field_lines(const SLine *fields, uint32_t k, int parity) { return fields + ((size_t)k * 2 + (size_t)parity) * BUF_FIELD; }
+/* the field buffers of all frames: BUF_FIELD lines (at a pitch of FIELD_PITCH) for (frame k, odd) then (frame k, even), written by the analysis pass */
+__device__ inline const SLine *field_lines(const SLine *fields, uint32_t k, int parity) { return fields + ((size_t)k * 2 + (size_t)parity) * FIELD_PITCH; }
 struct FieldSrc {
     Field f;
     __device__ inline sdv_deint_line line(size_t i) const { return view(f.get((int)i)); }
@@ -303,7 +303,11 @@ struct AnalyzeArgs {
     uint32_t *ctl;                                            /* pipelined call: n_seg is the launch width, ctl[CTL_NSEG] the count (NULL otherwise) */
     Cfg cfg; FrameLocal *fl; FrameBrief *brief; SLine *fields;
     unsigned long long *timing;     /* optional: 8 cycle stamps per frame (SDV_STITCH_TIMING=1), NULL otherwise */
+    /* the fused entry: segment k = direct_ofs + f is frame f of the binarize call; where direct[f].flag is set the frame kernel has put the frame's lines into
+     * fields itself and left no records (stc007_device.h, FrameArgs::direct_fields) */
+    const sdv::DirectFrame *direct; uint32_t direct_ofs, direct_n;
 };
+static_assert((int)sdv::DSL_FORCED_BAD == (int)SL_FORCED_BAD && (int)sdv::DSL_COORDS_VALID == (int)SL_COORDS_VALID && (int)sdv::DSL_BW_SET == (int)SL_BW_SET, "the frame kernel writes SLine::flags");
 
 __device__ inline uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 /* the turn's control values are the same in every lane: say so, and they live in scalar registers */
@@ -535,8 +539,41 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
     AN_STAMP(0);
     const uint32_t start = k == 0 ? 0u : a.seg_end[k - 1] + 1u, end = a.seg_end[k];      /* [start, end) + END_FRAME at end */
     const uint32_t n = end - start;
-    const uint32_t fnum = a.src.at(end).frame_number;
     FrameLocal *fl = &a.fl[k];
+    if (a.direct && k >= a.direct_ofs && k - a.direct_ofs < a.direct_n && a.direct[k - a.direct_ofs].flag) {
+        /* A frame the frame kernel's capture took from end to end: every line a data line that read (CRC valid, forced bad or not), in field order in
+         * the field buffers already.  What the three passes below find on such a frame follows from the counts: the trim is the first and the last line
+         * of either field (every line passes findFramesTrim's test), every line is kept, the valid ones are those not forced bad, they all carry the one
+         * reference level, no Control Block, no file mark.  Left to do: the resolution trials. */
+        const sdv::DirectFrame d = a.direct[k - a.direct_ofs];
+        const uint32_t n0 = d.n[0], n1 = d.n[1];
+        if (lane == 0) {
+            fl->frame_number = d.frame_number; fl->seg_start = start; fl->seg_len = n + 1;
+            fl->top[0] = 1; fl->bottom[0] = (uint16_t)(1 + 2 * (n0 - 1)); fl->top[1] = 2; fl->bottom[1] = (uint16_t)(2 + 2 * (n1 - 1));
+            fl->data_lines[0] = (uint16_t)n0; fl->data_lines[1] = (uint16_t)n1;
+            fl->valid_lines[0] = (uint16_t)(n0 - d.bad[0]); fl->valid_lines[1] = (uint16_t)(n1 - d.bad[1]);
+            fl->ref[0] = d.ref; fl->ref[1] = d.ref;
+            fl->max_line = (uint16_t)((1 + 2 * (n0 - 1)) > (2 + 2 * (n1 - 1)) ? (1 + 2 * (n0 - 1)) : (2 + 2 * (n1 - 1)));
+            fl->flags = (uint8_t)(FL_TRIM_OK | (n > BUF_TRIM / 2 ? FL_BAD_NUMBERS : 0));
+            for (int i = 0; i < 5; i++) fl->ctrl[i] = -1;
+        }
+        __syncthreads();
+        AN_STAMP(1); AN_STAMP(2); AN_STAMP(3);
+        uint8_t fres[2];
+        for (int p = 0; p < 2; p++) {
+            Field f; f.lines = field_lines(a.fields, k, p); f.size = (int)(p == 0 ? n0 : n1);
+            fres[p] = field_resolution(a.cfg, f, lane, meta, (p == 0 && a.timing) ? a.timing + (size_t)k * 8 : nullptr);
+        }
+        if (lane == 0) {
+            fl->field_res[0] = fres[0]; fl->field_res[1] = fres[1];
+            FrameBrief br; br.frame_number = d.frame_number; br.flags = (uint8_t)(FL_TRIM_OK | (n > BUF_TRIM / 2 ? FL_BAD_NUMBERS : 0)); br.field_res[0] = fres[0]; br.field_res[1] = fres[1]; br._pad = 0;
+            a.brief[k] = br;
+            if (a.ctl) atomicAdd(&a.ctl[3 /* CTL_DIRECT */], 1u);
+        }
+        AN_STAMP(4);
+        return;
+    }
+    const uint32_t fnum = a.src.at(end).frame_number;
     auto meta_at = [&](uint32_t i) -> uint32_t {
         if (kLds) return meta[i];
         const Rec48 *src = (const Rec48 *)&a.src.at(start + i);
@@ -646,7 +683,7 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
                 uint64_t m = __ballot(mine);
                 uint32_t rank = cnt[p] + (uint32_t)__popcll(m & lanemask_lt(lane));
                 bool kept = mine && rank < BUF_FIELD;
-                if (kept) a.fields[((size_t)k * 2 + (size_t)p) * BUF_FIELD + rank] = made[u];
+                if (kept) a.fields[((size_t)k * 2 + (size_t)p) * FIELD_PITCH + rank] = made[u];
                 uint64_t mk = __ballot(kept), mv = __ballot(kept && ok);
                 ref_all[p] += kept ? ref : 0; ref_ok[p] += (kept && ok) ? ref : 0;
                 cnt[p] += (uint32_t)__popcll(mk); valid[p] += (uint32_t)__popcll(mv);
@@ -1978,7 +2015,7 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 }
 /* The pipelined call (stitch_engine.inc, "a stream that plays"): the host does not wait for the counts - one wave turns them into offsets and leaves
  * the number of frame segments in ctl[CTL_NSEG]; the kernels behind read it from there, launched as wide as the host's estimate. */
-enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_NEXT = 2 /* the turn kernel's work queue head */, CTL_WORDS = 3 };
+enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_NEXT = 2 /* the turn kernel's work queue head */, CTL_DIRECT = 3 /* frames the analysis found in the field buffers already */, CTL_WORDS = 4 };
 struct ScanArgs { const uint32_t *block_count; uint32_t *block_ofs; uint32_t nblk; uint32_t *ctl; uint32_t *next_work; };
 __device__ inline void seg_scan_body(const ScanArgs &a, int lane)
 {

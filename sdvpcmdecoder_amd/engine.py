@@ -83,7 +83,7 @@ class Pcm16x0StitchSettings(C.Structure):
 
 class StitchInfo(C.Structure):
     _fields_ = [("steps", C.c_uint32), ("rounds", C.c_uint32), ("steps_launched", C.c_uint32), ("pipelined", C.c_uint32),
-                ("device_ms", C.c_float), ("_pad2", C.c_float)]
+                ("device_ms", C.c_float), ("direct_frames", C.c_uint32)]
 
 
 PAIR_DTYPE = np.dtype([("audio_word", "<i2", (2,)), ("sample_flags", "u1", (2,)), ("sample_rate", "<u2"),

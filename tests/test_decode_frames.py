@@ -109,18 +109,48 @@ def test_emu_fused_stream_in_calls_equals_one_call(clean, emu_lib, oracle_lib):
     a.close()
     b = EmuEngine(lib)
     lib.sdv_set_pcm_type(b.h, STC007, 0)
-    got_p, got_f, got_s, piped = [], [], [], []
+    got_p, got_f, got_s, piped, direct = [], [], [], [], []
     info = ea.StitchInfo()
     for k in range(0, 12, 2):
         flags = (1 if k == 0 else 0) | (4 if k == 10 else 0)
         p, f, st, _, _ = _fused_host(lib, b.h, STC007, luma[k:k + 2], with_audio=False, first_frame_no=1 + k, flags=flags)
         got_p.append(p.copy()); got_f.append(f.copy()); got_s.append(st[:2 + (1 if k == 10 else 0)].copy())
         assert lib.sdv_get_stitch_info(b.h, C.byref(info)) == 0
-        piped.append(int(info.pipelined))
+        piped.append(int(info.pipelined)); direct.append(int(info.direct_frames))
     b.close()
     assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
     assert np.concatenate(got_s).tobytes() == want_s[:13].tobytes()
     assert piped[0] == 0 and piped[-1] == 0 and sum(1 for x in piped if x) >= 2, piped
+    # frames the whole-frame capture takes go into the stitch stage's field buffers without line records (the calls of a stream that plays)
+    assert direct[0] == 0 and direct[-1] == 0 and all(d <= 2 for d in direct), direct
+    if clean:
+        assert sum(direct) >= 4, (direct, piped)
+
+
+def test_emu_fused_direct_frames_decoded_again_with_records(emu_lib, oracle_lib, monkeypatch):
+    """The way back of the frames that went straight into the field buffers: should the stitch call not take the path they were written for, the
+    binarize stage runs again from the stream state it started with and leaves records (forced here by a switch of the developer builds)."""
+    from sdvpcmdecoder_amd import synth
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    luma = synth.stc007_frames(12, seed=12, noise_sigma=4.0)[0].copy()
+    a = EmuEngine(lib)
+    lib.sdv_set_pcm_type(a.h, STC007, 0)
+    want_p, want_f, want_s, _, _ = _fused_host(lib, a.h, STC007, luma, with_audio=False)
+    a.close()
+    for switch in ("SDV_DIRECT_FORCE_RETRY", "SDV_NO_DIRECT_FIELDS"):
+        monkeypatch.setenv(switch, "1")
+        b = EmuEngine(lib)
+        lib.sdv_set_pcm_type(b.h, STC007, 0)
+        got_p, got_f, got_s = [], [], []
+        info = ea.StitchInfo()
+        for k in range(0, 12, 3):
+            p, f, st, _, _ = _fused_host(lib, b.h, STC007, luma[k:k + 3], with_audio=False, first_frame_no=1 + k, flags=(1 if k == 0 else 0) | (4 if k == 9 else 0))
+            got_p.append(p.copy()); got_f.append(f.copy()); got_s.append(st[:3 + (1 if k == 9 else 0)].copy())
+            assert lib.sdv_get_stitch_info(b.h, C.byref(info)) == 0 and info.direct_frames == 0
+        b.close()
+        monkeypatch.delenv(switch)
+        assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
+        assert np.concatenate(got_s).tobytes() == want_s[:13].tobytes()
 
 
 def test_emu_fused_refuses_bad_arguments(emu_lib):

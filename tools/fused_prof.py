@@ -17,4 +17,4 @@ for it in range(reps):
     p, f, st = eng.decode_frames(2, luma, first_frame_no=fn, new_file=it == 0, out_pairs=fp, out_frames=ff, out_stats=fs)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     fn += n
-    print(f"n={n} it={it}: wall {dt*1e3:.3f} ms pairs {p.shape[0]} pipelined {eng.stitch_info().pipelined}", flush=True)
+    print(f"n={n} it={it}: wall {dt*1e3:.3f} ms pairs {p.shape[0]} pipelined {eng.stitch_info().pipelined} direct {eng.stitch_info().direct_frames}", flush=True)
