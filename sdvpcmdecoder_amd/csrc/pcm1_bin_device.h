@@ -26,6 +26,9 @@ typedef unsigned __int128 u128;
 
 enum { P1_BITS = 94, P1_WORD_BITS = 13, P1_CRC_BITS = 16, P1_CRC_SILENT = 0xECBF };
 enum { P1_SEARCH_STEP_DIV = 4, P1_SEARCH_MAX_OFS = 12, P1_SEARCH_STEP_CNT = (P1_SEARCH_MAX_OFS + 1) * 2, P1_GRID = 2 * P1_SEARCH_MAX_OFS + 1 };   /* binarizer.h:254-256 */
+#ifndef SDV_P1_SHARED_READS
+#define SDV_P1_SHARED_READS 1      /* the coordinate search reads every cell pattern once (search_pcm1_data) */
+#endif
 enum { P1_LEFT_BASE = 32 };         /* where the left-coordinate results sit in WaveLds::sweep (the right ones use 0..25) */
 
 struct LineArgs1 {
@@ -337,6 +340,71 @@ __device__ inline void read_pcm_data(const BinCtx &c, L1 &l, const uint8_t *px_r
     }
 }
 
+/* ---- the coordinate search with shared reads --------------------------------------------------------------------------------
+ * What fillPCM1 reads depends on the candidate through two numbers only: where the first cell sits (coords.start + the pixel shift of the stage) and the cell
+ * pitch (from coords.stop - coords.start).  On a grid with a step of one pixel the candidates of one anti-diagonal (start + 1, stop + 1 from one to the next)
+ * share the pitch, and pixel-shift stage 1 (+1) / 2 (-1) of a candidate reads exactly the cells that stage 0 of its neighbour up / down the diagonal reads.
+ * So the grid is walked along its diagonals, a run of consecutive candidates per lane, every read made once and used by the three candidates it belongs
+ * to: 625 + 2 per run instead of 3 x 625 reads.  Everything behind the read (Bit Picker, the stop at the first valid CRC, what stays in the line when
+ * nothing reads) is run per candidate and stage as before, on the shared cells. */
+struct RawRead1 { u128 v; uint16_t crc; };
+__device__ inline RawRead1 raw_read_pcm1(const L1 &l, const uint8_t *px_row, int32_t first_px, uint8_t ref_low, uint8_t ref_high)     /* fill_pcm1 with the first cell at first_px */
+{
+    int32_t acc = (int32_t)l.hpsm + first_px * 128;
+    const int32_t lo = l.pixel_start, hi = (int32_t)l.pixel_stop - 1;
+    uint32_t a0, a1, a2, b0, b1, b2;
+    compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, ref_low, ref_high, a0, b0);
+    compare_cells32<32>(px_row, acc, (int32_t)l.psm, lo, hi, ref_low, ref_high, a1, b1);
+    compare_cells32<P1_BITS - 64>(px_row, acc, (int32_t)l.psm, lo, hi, ref_low, ref_high, a2, b2);
+    uint64_t s_lo, s_hi;
+    solve_automaton_lane((uint64_t)a0 | ((uint64_t)a1 << 32), (uint64_t)a2, (uint64_t)b0 | ((uint64_t)b1 << 32), (uint64_t)b2, s_lo, s_hi);
+    s_hi &= (1ull << (P1_BITS - 64)) - 1ull;
+    RawRead1 r;
+    r.v = ((u128)__brevll(s_lo) << 30) | (u128)(__brevll(s_hi) >> 34);
+    r.crc = crc_of_masks(s_lo, s_hi);
+    return r;
+}
+/* read_pcm_data for a candidate of the search - hysteresis depth 0 only, pixel-shift stages 0 .. 2, levels that do not clip, no level sweep behind the
+ * line - with the cells of stage 0 / 1 / 2 handed in (at / up / down) */
+__device__ inline void read_pcm_data_shared(const BinCtx &c, L1 &l, const RawRead1 &at, const RawRead1 &up, const RawRead1 &down)
+{
+    set_ppb(l, l.coords);
+    const uint8_t low_ref = get_low_level(l.ref_level, 0), high_ref = get_high_level(l.ref_level, 0);
+    auto fill = [&](uint8_t s) {            /* fill_data_words(c, l, px_row, 0, s) */
+        l.ref_low = low_ref; l.ref_high = high_ref; l.hyst = 0; l.shift = s;
+        /* (picked by masks: `s == 0 ? at : ...` over objects becomes one load through a selected address, and then all three live in scratch memory) */
+        const uint64_t m0 = s == 0 ? ~0ull : 0ull, m1 = s == 1 ? ~0ull : 0ull, m2 = s >= 2 ? ~0ull : 0ull;
+        const uint64_t v_lo = ((uint64_t)at.v & m0) | ((uint64_t)up.v & m1) | ((uint64_t)down.v & m2);
+        const uint64_t v_hi = ((uint64_t)(at.v >> 64) & m0) | ((uint64_t)(up.v >> 64) & m1) | ((uint64_t)(down.v >> 64) & m2);
+        l.v = ((u128)v_hi << 64) | (u128)v_lo;
+        l.calc_crc = (uint16_t)((at.crc & (uint32_t)m0) | (up.crc & (uint32_t)m1) | (down.crc & (uint32_t)m2));
+        if ((!crc_valid(l) && (l.ref_level > c.ps.min_white_lvl) && ((c.ps.left_bit_pick != 0) || (c.ps.right_bit_pick != 0))) || c.force_bit_picker)
+            pick_cut_bits(c, l);
+    };
+    bool found = false;
+    const bool entry_forced = l.forced_bad;
+    bool kept = false;
+    u128 k_v = 0; uint16_t k_crc = 0; uint8_t k_pl = 0, k_pr = 0;
+#pragma unroll 1
+    for (uint8_t s = 0; s <= SHIFT_STAGES_SAFE; s++) {
+        fill(s);
+        if (crc_valid(l)) { found = true; break; }
+        if (s == 0 && c.force_bit_picker) { kept = true; k_v = l.v; k_crc = l.calc_crc; k_pl = l.picked_l; k_pr = l.picked_r; }
+    }
+    if (!found) {
+        if (kept && l.forced_bad == entry_forced) { l.v = k_v; l.calc_crc = k_crc; l.picked_l = k_pl; l.picked_r = k_pr; l.hyst = 0; l.shift = 0; }
+        else fill(0);
+    }
+}
+/* the runs of the 25 x 25 grid in diagonal order (tools/gen_diag_table.py 25 2: at most 14 reads per lane) */
+#ifdef SDV_EMU
+static const uint16_t c_p1_runs[65] = {
+#else
+__device__ __constant__ const uint16_t c_p1_runs[65] = {
+#endif
+    0, 6, 15, 25, 35, 45, 55, 66, 78, 90, 100, 110, 120, 132, 142, 153, 165, 175, 187, 197, 209, 219, 231, 243, 253, 265, 276, 288, 300, 312, 324, 334, 346, 356, 368, 378,
+    390, 400, 412, 422, 434, 444, 454, 466, 476, 488, 498, 508, 520, 532, 542, 552, 562, 572, 582, 592, 602, 610, 619, 625, 625, 625, 625, 625, 625 };
+
 __device__ inline void stats_reset(CrcStat *a, int count) { for (int i = 0; i < count; i++) { a[i].result = 0; a[i].crc = 0; a[i].hyst = a[i].shift = 0x0f; a[i].idx = 0; } }
 __device__ inline void stats_update(CrcStat *a, uint16_t crc, uint8_t hyst, uint8_t shift, uint8_t &valid_cnt)   /* :1789-1826 */
 {
@@ -447,15 +515,48 @@ __device__ inline bool search_pcm1_data(BinCtx &c, L1 &l, P1Lds &lds, Coords dat
     const bool entry_forced = l.forced_bad;
     uint32_t first_coll = 0xFFFFFFFFu;
     SDV_WAVE_SYNC();
+    auto note = [&](const L1 &t, int q) {
+        uint8_t hy = t.hyst;
+        if (t.picked_l != 0 && t.picked_r != 0) hy = 0x0E; else if (t.picked_r != 0) hy = 0x0D; else if (t.picked_l != 0) hy = 0x0C;
+        lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24);
+        if (t.forced_bad && !entry_forced) first_coll = first_coll < (uint32_t)q ? first_coll : (uint32_t)q;
+    };
+    const uint8_t low0 = get_low_level(l.ref_level, 0), high0 = get_high_level(l.ref_level, 0);
+    if (SDV_P1_SHARED_READS && scan_step == 1 && nl == P1_GRID && nr == P1_GRID && shift_lim == SHIFT_STAGES_SAFE && !l.ref_sweeped && low0 > l.black && high0 < l.white) {
+        /* the grid along its diagonals (see read_pcm_data_shared): this lane's run of cells, diagonal d = row + col, rows upwards */
+        int u = c_p1_runs[lane]; const int u_end = c_p1_runs[lane + 1];
+        int d = 0, row = 0;
+        if (u < u_end) { int left = u; for (;;) { const int len = (d < P1_GRID ? d : 2 * (P1_GRID - 1) - d) + 1; if (left < len) break; left -= len; d++; } row = (d < P1_GRID ? 0 : d - (P1_GRID - 1)) + left; }     /* (a lane without a run has no cell to find) */
+        RawRead1 w_down, w_at, w_up;            /* the reads at start - 1, start, start + 1 of the cell that is evaluated next */
+        w_down.v = w_at.v = w_up.v = 0; w_down.crc = w_at.crc = w_up.crc = 0;
+        int k = 0;                              /* reads made for the current stretch of a diagonal */
+        L1 geo = l;                             /* carries the cell pitch of the diagonal */
+        while (__ballot(u < u_end) != 0ull) {
+            if (u < u_end) {
+                if (k == 0) { Coords dc; coords_set(dc, (int16_t)(l0 + row), (int16_t)(r1 - (d - row))); set_ppb(geo, dc); }
+                w_down = w_at; w_at = w_up;
+                w_up = raw_read_pcm1(geo, lds.w.px, (int32_t)(l0 + row) - 1 + (k < 2 ? k : 2), low0, high0);    /* `row` is the cell evaluated next */
+                k++;
+                if (k >= 3) {
+                    const int col = d - row, q = row * nr + col;
+                    L1 t = l;
+                    coords_set(t.coords, (int16_t)(l0 + row), (int16_t)(r1 - col));
+                    read_pcm_data_shared(c, t, w_at, w_up, w_down);
+                    note(t, q);
+                    u++;
+                    const int row_last = d < P1_GRID ? d : P1_GRID - 1;
+                    if (row == row_last) { d++; row = d < P1_GRID ? 0 : d - (P1_GRID - 1); k = 0; }
+                    else row++;
+                }
+            }
+        }
+    } else
     for (int q = lane; q < n_cand; q += 64) {
         const int row = q / nr, col = q - row * nr;
         L1 t = l;
         coords_set(t.coords, (int16_t)(l0 + row * scan_step), (int16_t)(r1 - col * scan_step));
         read_pcm_data<false>(c, t, lds.w.px, hyst_lim, shift_lim);
-        uint8_t hy = t.hyst;
-        if (t.picked_l != 0 && t.picked_r != 0) hy = 0x0E; else if (t.picked_r != 0) hy = 0x0D; else if (t.picked_l != 0) hy = 0x0C;
-        lds.grid[q] = (uint32_t)(uint16_t)(t.v & 0xFFFF) | ((uint32_t)(hy & 0xF) << 16) | ((uint32_t)(t.shift & 0xF) << 20) | ((uint32_t)(crc_valid(t) ? 1 : 0) << 24);
-        if (t.forced_bad && !entry_forced && first_coll == 0xFFFFFFFFu) first_coll = (uint32_t)q;
+        note(t, q);
     }
     first_coll = wave_min_u32(first_coll);
     SDV_WAVE_SYNC();
