@@ -76,12 +76,14 @@ template <bool kInsane>
 __device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int k)
 {
     const FrameArgs &a = a1.f;
+    K1_BEGIN(); K1_T(tq0_);
     PrescanRes r; r.start = r.stop = 0; r.ref = 0; r.valid = 0; r.pad[0] = r.pad[1] = 0;
     if (prescan_runs(a, f)) {
         const int gap = frame_buf_lines(a, f) / (COORD_CHECK_PARTS - 1);
         const int row = frame_buf_row(a, f, (k + 1) * gap);
         if (row >= 0) {
             stage_row(lds.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
+            K1_T(tq1_); K1_ADD(16, tq0_, tq1_);
 #pragma unroll 1
             for (int variant = 0; variant < (sweep_flag_matters(a.preset) ? 2 : 1); variant++) {
                 BinCtx c; Bin b;
@@ -96,6 +98,7 @@ __device__ inline void prescan_body(const FrameArgs1 &a1, P1Lds &lds, int f, int
                 if (lane_id() == 0) a1.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k] = q;
                 SDV_WAVE_SYNC();
             }
+            K1_T(tq2_); K1_ADD(23, tq0_, tq2_); K1_FLUSH();
             return;
         }
     }
@@ -786,8 +789,11 @@ __device__ inline void verify_body1(const VerifyArgs1 &a, int k)
 } // namespace sdvp1f
 
 /* two builds of the two kernels: MODE_INSANE (with the reference level sweep) and every other mode (process_line_p1) */
+#ifndef SDV_P1PRE_WAVES_PER_EU
+#define SDV_P1PRE_WAVES_PER_EU SDV_P1B_WAVES_PER_EU
+#endif
 #define SDV_P1F_KERNELS(SUFFIX, INSANE) \
-__global__ void __launch_bounds__(64, SDV_P1B_WAVES_PER_EU) sdv_k_pcm1_prescan##SUFFIX(sdvp1f::FrameArgs1 a) \
+__global__ void __launch_bounds__(64, SDV_P1PRE_WAVES_PER_EU) sdv_k_pcm1_prescan##SUFFIX(sdvp1f::FrameArgs1 a) \
 { \
     __shared__ sdvp1b::P1Lds lds; \
     const int i = (int)blockIdx.x, f = a.f.frame_list ? a.f.frame_list[i / sdvp1f::COORD_CHECK_LINES] : a.f.frame_lo + i / sdvp1f::COORD_CHECK_LINES; \
