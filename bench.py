@@ -485,7 +485,10 @@ def main():
             st_rounds += eng.stitch_info().rounds
             st_dev_ms += eng.stitch_info().device_ms
             frame_no += n
-        # the same tape through the fused entry with the audio stage behind it: video -> masked PCM (sdv_decode_frames, all three workers)
+        # the same tape through the fused entry with the audio stage behind it: video -> masked PCM (sdv_decode_frames, all three workers).
+        # Wall clock as a caller sees it: without the engine's event pairs (sdv_set_profiling is a diagnostic; with it on the fused entry does not queue its
+        # stitch kernels behind the frame kernel ahead of the host's look at that round).
+        eng.set_profiling(False)
         eng.set_audio_masking(5)        # DROP_INTER_LIN_BLOCK
         full_ms = 0.0
         for _ in range(k_steps):
@@ -505,6 +508,7 @@ def main():
             torch.cuda.synchronize(dev)
             fused_ms += (time.perf_counter() - t1) * 1e3
             frame_no += n
+        eng.set_profiling(True)
         e2e_best_ms = min(e2e_ms, fused_ms) / k_steps
         E2E_BYTES = W * H + H * 32 + 1470 * 8           # 349 920 B luma + 486 x 32 B line records + 1470 x 8 B sample pairs = 377 232 B per NTSC frame
         end_to_end = {"workload": f"{n}-frame NTSC STC-007 batch resident in HBM, frames -> PCMSamplePair (binarize + stitch + deinterleave + P/Q ECC), continuing tape",
