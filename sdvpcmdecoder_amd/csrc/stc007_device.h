@@ -112,6 +112,7 @@ struct WaveLds {
     CrcStat crc_stats[MAX_COLL_CRCS + 1];
     uint32_t lv_keys[COORD_HISTORY_DEPTH];   /* last_valid_coord_list as sort keys (videotodigital.cpp:707) */
     uint32_t long_keys[COORD_LONG_HISTORY];  /* long_valid_coords (videotodigital.cpp:710) */
+    uint32_t state_in[32];                   /* the chain state the frame was started from (sdv_v2d_state, a dword per lane: v2d_stage_state_in) */
 };
 
 /* ---- launch parameters ---------------------------------------------------------------------- */
@@ -153,6 +154,10 @@ struct FrameArgs {
     void *direct_fields;            /* the stitcher's field buffers (SLine[segments][2][direct_pitch]), or NULL */
     struct DirectFrame *direct_frames;      /* [n_total] what frame f left there (flag 0: nothing, its records are in recs) */
     int direct_seg_ofs, direct_pitch;       /* frame f is the stitcher's segment f + direct_seg_ofs; lines per field buffer */
+    /* The first round of a call on a tape that plays: every frame is started from the model's state (predict_half) behind ONE known state, `base` at frame
+     * base_frame - the wave makes it itself instead of reading what a kernel in front of this one wrote to states_in (which then holds nothing yet: the
+     * engine fills it in when the round was not the last, engine.inc). */
+    uint8_t predict_in_kernel; int base_frame; sdv_v2d_state base;
 };
 /* what a frame that went straight into the field buffers tells the analysis kernel (stc007_stitch_device.h, analyze_body) */
 struct DirectFrame { uint32_t frame_number; uint16_t n[2], bad[2]; uint8_t ref, flag, _pad[2]; };
@@ -1784,6 +1789,25 @@ __device__ inline sdv_v2d_state predict_state(const sdv_v2d_state &s0, int m, bo
     return p;
 }
 
+/* The state frame f is started from, a dword per lane in WaveLds::state_in: what the chain speculation put into states_in[f], or (FrameArgs::predict_in_kernel)
+ * the model's state f - base_frame frames behind `base`, made here.  dword `dw` of the state frame f + 1 was / will be started from: v2d_next_state_dword. */
+__device__ inline uint32_t v2d_model_dword(const FrameArgs &a, int f, int dw)
+{
+    const int m = f - a.base_frame;
+    if (m <= 0) return reinterpret_cast<const uint32_t *>(&a.base)[dw];
+    return (uint32_t)predict_half(a.base, m, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw) | ((uint32_t)predict_half(a.base, m, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw + 1) << 16);
+}
+__device__ inline void v2d_stage_state_in(const FrameArgs &a, WaveLds &lds, int f)
+{
+    enum { NDW = sizeof(sdv_v2d_state) / 4 };
+    static_assert(NDW <= 32, "WaveLds::state_in holds a chain state");
+    const int lane = lane_id();
+    SDV_WAVE_SYNC();
+    if (lane < NDW) lds.state_in[lane] = a.predict_in_kernel ? v2d_model_dword(a, f, lane) : reinterpret_cast<const uint32_t *>(&a.states_in[f])[lane];
+    SDV_WAVE_SYNC();
+}
+__device__ inline const sdv_v2d_state *v2d_state_in(const WaveLds &lds) { return reinterpret_cast<const sdv_v2d_state *>(lds.state_in); }
+
 /* ---- chain state <-> registers ---------------------------------------------------------------- */
 __device__ inline void v2d_load_state(V2D &v, WaveLds &lds, const sdv_v2d_state *s, const FrameArgs &a)
 {
@@ -1847,13 +1871,14 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
      * from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
     uint8_t fl = VF_OK;
     if (f + 1 < a.n_total) {
-        const uint32_t next = reinterpret_cast<const uint32_t *>(&a.states_in[f + 1])[dw];
+        const uint32_t next = a.predict_in_kernel ? v2d_model_dword(a, f + 1, dw) : reinterpret_cast<const uint32_t *>(&a.states_in[f + 1])[dw];
         if (__ballot(in && next != mine) != 0ull) fl = VF_BREAK;
     }
     if (fl == VF_BREAK) {       /* (only asked of a frame whose link broke: on a tape that plays this is skipped) */
         /* ... "what it was started from" as the model sees it: one frame on, with the inherited tuning */
-        const uint32_t own = (uint32_t)predict_half(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw) |
-                             ((uint32_t)predict_half(a.states_in[f], 1, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw + 1) << 16);
+        const sdv_v2d_state &was = *v2d_state_in(lds);
+        const uint32_t own = (uint32_t)predict_half(was, 1, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw) |
+                             ((uint32_t)predict_half(was, 1, a.doubled != 0, a.preset.min_ref_lvl, 2 * dw + 1) << 16);
         /* dword 0: in_def_black, in_def_white, in_def_reference (+ a pad byte); dword 2, byte 2: do_ref_lvl_sweep - the rest are coordinates and histories */
         const uint32_t d = mine ^ own;
         if (__ballot(in && dw >= 1 && (dw == 2 ? d & 0xFF00FFFFu : d) != 0) != 0ull) fl |= VF_MOVED;
@@ -1865,18 +1890,18 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (a.refs) {
             /* (one pair pushed into a full history, the rest moved down a slot: counted where it happens - reading the incoming history again here cost 3 % of the kernel) */
             const bool pushed = v.long_pushes == 1 && v.n_long == COORD_LONG_HISTORY && !a.doubled;
-            a.refs[3 * f] = a.states_in[f].bin.in_def_reference; a.refs[3 * f + 1] = v.bin.in_ref; a.refs[3 * f + 2] = pushed ? 1 : 0;
+            a.refs[3 * f] = v2d_state_in(lds)->bin.in_def_reference; a.refs[3 * f + 1] = v.bin.in_ref; a.refs[3 * f + 2] = pushed ? 1 : 0;
         }
     }
 }
 /* a frame given up: its state goes out as it came in, marked (dword 29, byte 2 = _pad[0]) */
-__device__ inline void v2d_give_up(const FrameArgs &a, int f)
+__device__ inline void v2d_give_up(const FrameArgs &a, const WaveLds &lds, int f)
 {
     enum { NDW = sizeof(sdv_v2d_state) / 4 };
     static_assert(offsetof(sdv_v2d_state, _pad) == 118, "the mark of a frame given up");
     const int lane = lane_id();
     if (lane < NDW) {
-        uint32_t d = reinterpret_cast<const uint32_t *>(&a.states_in[f])[lane];
+        uint32_t d = lds.state_in[lane];
         if (lane == NDW - 1) d = (d & 0xFF00FFFFu) | ((uint32_t)0xA5 << 16);      /* STATE_ABORTED */
         reinterpret_cast<uint32_t *>(&a.states_out[f])[lane] = d;
     }
@@ -2519,7 +2544,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     K1_BEGIN();
     K1_T(t_begin);
     V2D v; Line wl;
-    v2d_load_state(v, lds, &a.states_in[f], a);
+    v2d_stage_state_in(a, lds, f);
+    v2d_load_state(v, lds, v2d_state_in(lds), a);
     const uint32_t frame_no = a.first_frame_no + (uint32_t)f;
     const uint8_t *frame = a.luma + (size_t)f * a.frame_stride;
     uint32_t *fv_keys = a.scratch + (size_t)f * 2u * (size_t)a.height;
@@ -2536,7 +2562,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     v2d_begin_frame(v, a, lds);
     if (frame_is_empty(a, f)) {
         if (kLean) {            /* to the full kernel: the bookkeeping of lines that do not read lives there */
-            v2d_give_up(a, f);
+            v2d_give_up(a, lds, f);
             return;
         } else {
             uint16_t ln = 0;
@@ -2935,7 +2961,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
             if (!took_fast) {
                 if (kLean) {
-                    v2d_give_up(a, f);
+                    v2d_give_up(a, lds, f);
                     return;
                 } else {
                     K1_T(t_sc0);
