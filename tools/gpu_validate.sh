@@ -51,7 +51,7 @@ tail -1 $R/gpurun_out/prof_vis.log
 bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="
 # the damaged-tape kernels (general frame kernel, the two sweep kernels, the histogram carry) on the C3 PAL tape
 bash $R/tools/gpu_pmc_round4.sh 2>&1 | grep "rc="
-# the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r04_profiles/; the raw counter and trace files stay
+# the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r05_profiles/; the raw counter and trace files stay
 # on the box (gpurun only merges 64 MiB back)
 cd $R && python tools/refresh_profiles.py r05 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
 rm -rf gpurun_out/r05_profiles && mkdir -p gpurun_out/r05_profiles && cp profiles/r05_* gpurun_out/r05_profiles/

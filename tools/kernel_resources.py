@@ -29,13 +29,20 @@ def parse(text):
     return out
 
 
+def plain_name(mangled):
+    m = re.match(r"_Z(\d+)", mangled)
+    return mangled[m.end():m.end() + int(m.group(1))] if m else mangled
+
+
 def table(res, md=False, only=None):
     rows = []
-    for k in sorted(res):
+    for k in sorted(res, key=plain_name):
         if only and not any(s in k for s in only):
             continue
         r = res[k]
-        rows.append((k, r.get("vgpr", 0), r.get("agpr", 0), r.get("sgpr", 0), r.get("vgpr_spill", 0), r.get("sgpr_spill", 0), r.get("scratch", 0), r.get("lds", 0), r.get("occupancy", 0)))
+        if md and "sdv_k_" not in k:
+            continue
+        rows.append((plain_name(k) if md else k, r.get("vgpr", 0), r.get("agpr", 0), r.get("sgpr", 0), r.get("vgpr_spill", 0), r.get("sgpr_spill", 0), r.get("scratch", 0), r.get("lds", 0), r.get("occupancy", 0)))
     hdr = ("kernel", "VGPR", "AGPR", "SGPR", "VGPR spills", "SGPR spills", "scratch B/lane", "LDS B", "waves/SIMD")
     if md:
         s = "| " + " | ".join(hdr) + " |\n|" + "---|" * len(hdr) + "\n"
