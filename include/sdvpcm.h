@@ -356,7 +356,8 @@ typedef struct sdv_stitch_info {
     uint32_t steps_launched;    /* turn executions over all rounds */
     uint32_t pipelined;         /* 1: the call ran its analysis and first round without waiting for the host (a stream that plays);
                                  * 2: ... and the field order and resolution histories were saturated, so the host's check needed no replay of them;
-                                 * + 4: (sdv_decode_frames) the stage's kernels were queued right behind the frame kernel, ahead of the host's look at its round */
+                                 * + 4: (sdv_decode_frames) the stage's kernels were queued right behind the frame kernel, ahead of the host's look at its round;
+                                 * + 8: ... they had been, the frame kernel's round was not its last, and the stage was run again on the final records */
     float device_ms;            /* analysis + rounds + packing on the device (profiling on) */
     uint32_t direct_frames;     /* sdv_decode_frames: frames whose lines the frame kernel wrote into the stitch stage's field buffers itself (no line records) */
 } sdv_stitch_info;

@@ -373,6 +373,58 @@ def test_gpu_fused_uneven_calls_equal_the_sequential_oracle(oracle_lib):
     assert np.concatenate(got_s).tobytes() == want_s.tobytes()
 
 
+def _tape_clean_then_damaged(n=15, bad_from=9):
+    """Frames that play, then frames with lost lines: the call that meets them has its frame stage run more than one round."""
+    from sdvpcmdecoder_amd import synth
+    luma = synth.stc007_frames(n, seed=12, noise_sigma=4.0)[0].copy()
+    luma[bad_from:, 77::61] = 16
+    return luma
+
+
+def test_emu_fused_stitch_queued_ahead_is_made_over_when_the_frame_stage_needs_more_rounds(emu_lib, oracle_lib):
+    """Calls of three frames: while the tape plays the stitch kernels of a call are queued behind the frame kernel's first round (pipelined & 4); the call
+    that meets the damage had them queued too - its frame stage then took more rounds and the stitch stage was run again on the final records (& 8)."""
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    luma = _tape_clean_then_damaged()
+    a = EmuEngine(lib)
+    lib.sdv_set_pcm_type(a.h, STC007, 0)
+    want_p, want_f, want_s, _, _ = _fused_host(lib, a.h, STC007, luma, with_audio=False)
+    a.close()
+    b = EmuEngine(lib)
+    lib.sdv_set_pcm_type(b.h, STC007, 0)
+    got_p, got_f, got_s, piped = [], [], [], []
+    info = ea.StitchInfo()
+    for k in range(0, 15, 3):
+        p, f, st, _, _ = _fused_host(lib, b.h, STC007, luma[k:k + 3], with_audio=False, first_frame_no=1 + k, flags=(1 if k == 0 else 0) | (4 if k == 12 else 0))
+        got_p.append(p.copy()); got_f.append(f.copy()); got_s.append(st[:3 + (1 if k == 12 else 0)].copy())
+        assert lib.sdv_get_stitch_info(b.h, C.byref(info)) == 0
+        piped.append(int(info.pipelined))
+    b.close()
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s).tobytes() == want_s[:16].tobytes()
+    assert any(x & 4 for x in piped) and any(x & 8 for x in piped), piped
+
+
+@pytest.mark.gpu
+def test_gpu_fused_stitch_queued_ahead_is_made_over_when_the_frame_stage_needs_more_rounds(oracle_lib):
+    """The same on the GPU (where the queued kernels really run beside the host's look at the flags), against the sequential oracle."""
+    import torch
+    from sdvpcmdecoder_amd import Engine
+    luma = _tape_clean_then_damaged(n=30, bad_from=21)
+    want_p, want_f, want_s = _oracle_chain(oracle_lib, luma)
+    d = torch.from_numpy(luma).cuda()
+    eng = Engine(0); eng.setPCMType(STC007)
+    got_p, got_f, got_s, piped = [], [], [], []
+    for k in range(0, 30, 3):
+        p, f, st = eng.decode_frames(STC007, d[k:k + 3], first_frame_no=1 + k, new_file=k == 0, end_file=k + 3 == 30)
+        got_p.append(p.cpu().numpy().copy()); got_f.append(f.cpu().numpy().copy()); got_s.append(st.cpu().numpy().copy())
+        piped.append(int(eng.stitch_info().pipelined))
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes()
+    assert np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s).tobytes() == want_s.tobytes()
+    assert any(x & 4 for x in piped) and any(x & 8 for x in piped), piped
+
+
 def test_emu_stitch_and_fused_calls_interleaved_with_the_visualiser_feeds_toggled(emu_lib, oracle_lib):
     """One stream fed alternately through sdv_decode_frames (records of known layout: the pipelined way through the stitch stage, the next call's state
     copied ahead of the read-back) and through sdv_binarize_frames + sdv_stitch_frames, with the block and assembled-line outputs of the stitch stage
