@@ -54,7 +54,7 @@ bash $R/tools/gpu_pmc_round4.sh 2>&1 | grep "rc="
 # the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r05_profiles/; the raw counter and trace files stay
 # on the box (gpurun only merges 64 MiB back)
 cd $R && python tools/refresh_profiles.py r05 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
-rm -rf gpurun_out/r05_profiles && mkdir -p gpurun_out/r05_profiles && cp profiles/r05_* gpurun_out/r05_profiles/
+rm -rf gpurun_out/r05_profiles && mkdir -p gpurun_out/r05_profiles && cp profiles/r05_* gpurun_out/r05_profiles/ && rm -f gpurun_out/r05_profiles/*.md gpurun_out/r05_profiles/*.txt   # (the hand-written notes and tables do not come back: a copy from the box would overwrite what was written meanwhile)
 find gpurun_out -name "*.csv" -size +256k -delete; find gpurun_out -name "*.db" -delete
 du -sh gpurun_out | tail -1
 # scheduler traces of the two damaged tapes (developer build, when one was sent along)
