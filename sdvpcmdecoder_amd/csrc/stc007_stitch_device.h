@@ -568,7 +568,6 @@ __device__ inline void analyze_body(const AnalyzeArgs &a, uint32_t k, int lane, 
             fl->field_res[0] = fres[0]; fl->field_res[1] = fres[1];
             FrameBrief br; br.frame_number = d.frame_number; br.flags = (uint8_t)(FL_TRIM_OK | (n > BUF_TRIM / 2 ? FL_BAD_NUMBERS : 0)); br.field_res[0] = fres[0]; br.field_res[1] = fres[1]; br._pad = 0;
             a.brief[k] = br;
-            if (a.ctl) atomicAdd(&a.ctl[3 /* CTL_DIRECT */], 1u);
         }
         AN_STAMP(4);
         return;
@@ -2015,7 +2014,7 @@ __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
 }
 /* The pipelined call (stitch_engine.inc, "a stream that plays"): the host does not wait for the counts - one wave turns them into offsets and leaves
  * the number of frame segments in ctl[CTL_NSEG]; the kernels behind read it from there, launched as wide as the host's estimate. */
-enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_NEXT = 2 /* the turn kernel's work queue head */, CTL_DIRECT = 3 /* frames the analysis found in the field buffers already */, CTL_WORDS = 4 };
+enum { CTL_NSEG = 0, CTL_ABORT = 1, CTL_NEXT = 2 /* the turn kernel's work queue head */, CTL_WORDS = 3 };
 struct ScanArgs { const uint32_t *block_count; uint32_t *block_ofs; uint32_t nblk; uint32_t *ctl; uint32_t *next_work; };
 __device__ inline void seg_scan_body(const ScanArgs &a, int lane)
 {
@@ -2040,14 +2039,19 @@ __device__ inline uint32_t ctl_nseg(const uint32_t *ctl, uint32_t est) { const u
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_seg_scan(sdvs::ScanArgs a) { sdvs::seg_scan_body(a, (int)threadIdx.x); }
 #ifndef SDV_AN_WAVES
+#ifndef SDV_AN_WAVES
 #define SDV_AN_WAVES 3
+#endif
 #endif
 __global__ void __launch_bounds__(64, SDV_AN_WAVES) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 {
     __shared__ uint32_t meta[sdvs::ANALYZE_LDS_WORDS];
     static_assert(sizeof(meta) >= 8 * sdvs::RES_PITCH * sizeof(uint16_t), "the staged field of the resolution trials lives in the staging area");
-    const uint32_t k = blockIdx.x;
-    if (a.ctl && k >= sdvs::ctl_nseg(a.ctl, a.n_seg)) return;
+    /* The last frame of a call goes first: in the fused entry it is the one frame that is analysed from its records (the frame kernel writes every other frame
+     * into the field buffers itself, AnalyzeArgs::direct), ten times the work of the others - started last it was the kernel's tail, 50 us on its own. */
+    const uint32_t n_seg = a.ctl ? sdvs::ctl_nseg(a.ctl, a.n_seg) : a.n_seg;
+    if (blockIdx.x >= n_seg) return;
+    const uint32_t k = blockIdx.x == 0 ? n_seg - 1 : blockIdx.x - 1;
     const uint32_t n = a.seg_end[k] - (k == 0 ? 0u : a.seg_end[k - 1] + 1u);
     if (n <= sdvs::ANALYZE_LDS) sdvs::analyze_body<true>(a, k, (int)threadIdx.x, meta);
     else sdvs::analyze_body<false>(a, k, (int)threadIdx.x, meta);
