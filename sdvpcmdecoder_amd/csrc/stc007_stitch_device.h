@@ -2071,10 +2071,14 @@ __global__ void __launch_bounds__(64, SDV_ST_WAVES) sdv_k_stitch_step(sdvs::Step
         if (a.ctl[sdvs::CTL_ABORT] || ns < 2) return;
         n_work = ns - 1;
     }
-    for (;;) {
-        uint32_t w = 0;
-        if (threadIdx.x == 0) w = atomicAdd(a.next_work, 1u);
-        w = (uint32_t)__shfl((int)w, 0);
+    /* the turns are shared through a queue; a wave's first turn is its own number (the queue hands out what lies behind the launch width: 4 096 waves asking
+     * one address for their first turn at the same moment stood in line for tens of microseconds) */
+    for (bool first_turn = true;; first_turn = false) {
+        uint32_t w = blockIdx.x;
+        if (!first_turn) {
+            if (threadIdx.x == 0) w = gridDim.x + atomicAdd(a.next_work, 1u);
+            w = (uint32_t)__shfl((int)w, 0);
+        }
         if (w >= n_work) break;
 #if defined(SDV_ST_QUEUE_LDS) && !defined(SDV_EMU)
         __shared__ sdvs::SLine q_lds[sdvs::QCAP];          /* experiment: conv_queue of the turn in LDS (32 KB per wave) */
