@@ -619,17 +619,17 @@ __device__ inline void exec_body(const ExecArgs &a, uint32_t slot, WinLds &lds, 
     const uint32_t s = lo, n_win = a.res[s].n_win;
     uint32_t k = slot - a.win_base[s];
     if (k >= n_win || !a.wins[slot].head) return;
+    unsigned long long masked = 0;          /* of this wave's windows: one addition to the stretch's count at the end (every window adding to the one address stood in line) */
     for (;;) {
         const WinRec rec = a.wins[a.win_base[s] + k];
         uint32_t mk = 0;
         const uint32_t pops = window_body(a.w + rec.w_pos, (int)rec.n, rec.file_end != 0, a.how, lds, mk, lane);
-        if (lane == 0) {
-            if (mk) atomicAdd((unsigned long long *)&a.res[s].masked, (unsigned long long)mk);
-            if (pops != rec.pops) atomicOr(&a.res[s].flags, (uint32_t)RES_PLAN_MISMATCH);
-        }
+        masked += mk;
+        if (lane == 0 && pops != rec.pops) atomicOr(&a.res[s].flags, (uint32_t)RES_PLAN_MISMATCH);
         k++;
         if (k >= n_win || a.wins[a.win_base[s] + k].head) break;
     }
+    if (lane == 0 && masked) atomicAdd((unsigned long long *)&a.res[s].masked, masked);
 }
 
 /* ---- emit: W -> the caller's buffer, and what waits for the next call ------------------------------------------------- */
