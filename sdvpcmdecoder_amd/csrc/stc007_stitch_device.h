@@ -1989,6 +1989,7 @@ __device__ inline void compact_body(const CompactArgs &a, uint32_t k, int lane, 
 /* ---- END_FRAME search: positions of the END_FRAME records, in stream order -------------------------------------- */
 /* Pass 0 counts the END_FRAMEs per chunk and leaves every record's service type in a byte array; after the host's prefix sum
  * pass 1 writes the segment ends from those bytes (5 MB instead of the 235 MB of records of a 10 000-frame batch). */
+struct LayoutArgs { uint32_t *ctl, *seg_end; uint32_t n_seg, n_carry, carry_frames, recs_per_frame; };     /* n_seg = frames of the call + the carried one */
 struct SegArgs { RecSrc src; uint32_t n_recs; uint8_t *svc; uint32_t *block_count; const uint32_t *block_ofs; uint32_t *seg_end; int write; uint32_t seg_cap; /* 0 = no bound on the seg_end index */ };
 enum { SEG_CHUNK = 1024 };
 __device__ inline void seg_body(const SegArgs &a, uint32_t blk, int lane)
@@ -2038,6 +2039,14 @@ __device__ inline uint32_t ctl_nseg(const uint32_t *ctl, uint32_t est) { const u
 
 __global__ void __launch_bounds__(64) sdv_k_stitch_segments(sdvs::SegArgs a) { sdvs::seg_body(a, blockIdx.x, (int)threadIdx.x); }
 __global__ void __launch_bounds__(64) sdv_k_stitch_seg_scan(sdvs::ScanArgs a) { sdvs::seg_scan_body(a, (int)threadIdx.x); }
+/* records of known layout (the fused entry): the control words and the segment ends are arithmetic - made here, by a kernel in stream order (a copy from the
+ * host between two kernels costs two hand-overs between the compute queue and the copy engine) */
+__global__ void __launch_bounds__(64) sdv_k_stitch_layout(sdvs::LayoutArgs a)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i == 0) { a.ctl[sdvs::CTL_NSEG] = a.n_seg; a.ctl[sdvs::CTL_ABORT] = 0; a.ctl[sdvs::CTL_NEXT] = 0; }
+    if (i < a.n_seg) a.seg_end[i] = a.carry_frames ? (i == 0 ? a.n_carry - 1u : a.n_carry + i * a.recs_per_frame - 1u) : a.n_carry + (i + 1u) * a.recs_per_frame - 1u;
+}
 #ifndef SDV_AN_WAVES
 #ifndef SDV_AN_WAVES
 #define SDV_AN_WAVES 3
