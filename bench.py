@@ -580,12 +580,23 @@ def main():
                 b_ms += (t2 - t1) * 1e3; s_ms += (t3 - t2) * 1e3
                 b_rounds += eng.run_info().rounds; b_general += eng.run_info().frames_general; b_sweeps += eng.run_info().sweeps; s_rounds += eng.stitch_info().rounds
                 fno += npal
+            fused_p_ms = None
+            if tape_name == "clean":        # ... and the same frames through the fused entry (one call: the records stay in the engine)
+                fused_p_ms = 0.0
+                for r_ in range(-1, k_steps):
+                    torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                    eng.decode_frames(2, luma_p, first_frame_no=fno, with_audio=False, stream=stream, out_pairs=sp_p, out_frames=sf_p, out_stats=os_p)
+                    torch.cuda.synchronize(dev)
+                    if r_ >= 0: fused_p_ms += (time.perf_counter() - t1) * 1e3
+                    fno += npal
+                fused_p_ms /= k_steps
             eng.set_profiling(True)
             tot = (b_ms + s_ms) / k_steps
             pr = pp_[:, :].cpu().numpy().reshape(-1).view(np.dtype([("w", "<i2", (2,)), ("fl", "u1", (2,)), ("rate", "<u2"), ("e", "u1"), ("srv", "u1"), ("_p", "<u2")]))
             pal[tape_name] = {"frames_per_step": npal, "binarize_ms_per_step": b_ms / k_steps, "stitch_ms_per_step": s_ms / k_steps, "ms_per_step": tot,
                               "frames_per_s": npal / tot * 1e3, "binarize_rounds_per_step": b_rounds / k_steps, "frames_by_full_kernel_per_step": b_general / k_steps,
                               "reference_level_sweeps_per_step": b_sweeps / k_steps, "timed_steps": k_steps,
+                              "fused_entry_ms_per_step": fused_p_ms,
                               "stitch_rounds_per_step": s_rounds / k_steps, "sample_pairs_per_step": int(pp_.shape[0]), "sample_rate": int(pr["rate"][len(pr) // 2]),
                               "samples_valid_share": float(((pr["fl"] & 2) != 0).mean()),
                               "roofline": {"bound": "hbm", "achieved": npal * PAL_BYTES / tot / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1059,7 +1070,7 @@ def main():
         summary = {
             "end_to_end_ms_per_step": pick(out, "end_to_end", "ms_per_step"), "end_to_end_frac": pick(out, "end_to_end", "roofline", "frac"),
             "stitch_ms_per_step": pick(out, "stitch_stage", "ms_per_step"),
-            "pal_clean_frames_per_s": pick(out, "pal_stage", "clean", "frames_per_s"),
+            "pal_clean_frames_per_s": pick(out, "pal_stage", "clean", "frames_per_s"), "pal_clean_fused_entry_ms_per_step": pick(out, "pal_stage", "clean", "fused_entry_ms_per_step"),
             "pal_damaged_frames_per_s": pick(out, "pal_stage", "lost_lines_and_flipped_cells", "frames_per_s"),
             "pal_damaged_binarize_ms_per_step": pick(out, "pal_stage", "lost_lines_and_flipped_cells", "binarize_ms_per_step"),
             "pal_damaged_cpu_frames_per_s": pick(out, "pal_stage", "lost_lines_and_flipped_cells", "cpu_baseline", "value"),

@@ -40,7 +40,7 @@ if c4:
     rows.append(("**configs[4]**: one 100 000-frame stream, NEW_FILE … END_FILE, frames → pairs (`ShardedDecoder`, strong scaling)", f"{c4['ms']:.2f} ms = {c4['frames_per_s'] / 1e6:.2f} M frames/s at {c4['ranks']} rank, {c4['roofline']['frac']:.2f} of peak on 377 232 B per frame", "the same leg runs at every N (`bench.py --gpus N`): the tape is cut into N frame ranges, one all-gather of the hand-over states"))
 rows += [
     ("stitch stage alone", f"{g('stitch_stage', 'stitch_ms_per_step'):.3f} ms ({g('stitch_stage', 'stitch_device_ms_per_step'):.3f} ms on the device)", f"CPU: {g('stitch_stage', 'cpu_baseline', 'value'):.0f} frames/s"),
-    ("PAL (configs[2]) clean, binarize + stitch", f"{pal['clean']['ms_per_step']:.2f} ms = {pal['clean']['frames_per_s'] / 1e6:.2f} M frames/s", ""),
+    ("PAL (configs[2]) clean, binarize + stitch", f"{pal['clean']['ms_per_step']:.2f} ms = {pal['clean']['frames_per_s'] / 1e6:.2f} M frames/s for the two entry points one after the other" + (f"; fused entry {pal['clean']['fused_entry_ms_per_step']:.2f} ms = {pal['clean']['frames_per_step'] / pal['clean']['fused_entry_ms_per_step'] / 1e3:.2f} M frames/s" if pal['clean'].get('fused_entry_ms_per_step') else ""), f"{pal['clean']['frames_per_step']} frames of 720 x 576 per step"),
     ("PAL C3 tape (2000 frames; every 97th line lost, a cell inverted on one line in 53)",
      f"binarize {c3['binarize_ms_per_step']:.1f} ms ({2000 / c3['binarize_ms_per_step']:.0f} k frames/s), {c3['binarize_rounds_per_step']:.0f} rounds, {c3['reference_level_sweeps_per_step']:.0f} sweeps; + stitch {c3['stitch_ms_per_step']:.1f} ms → **{c3['frames_per_s'] / 1e3:.1f} k frames/s**",
      f"CPU (real reference): {c3['cpu_baseline']['value']:.0f} frames/s, bit-exact on the overlap; not improved this round (§10)"),
