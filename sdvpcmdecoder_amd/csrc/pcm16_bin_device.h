@@ -405,6 +405,7 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
     const bool entry_forced = l.forced_bad;
     /* every read of the grid, as if the line object came to it clean: (row, col, part) in the reference's order */
     SDV_WAVE_SYNC();
+    K1_T(ts0_);
     for (int q = lane; q < n_reads; q += 64) {
         const int pair = q / P16_SUBLINES, part = q - pair * P16_SUBLINES, row = pair / nr, col = pair - row * nr;
         L16 t = l;
@@ -418,6 +419,7 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
                       | ((uint32_t)((t.forced_bad && !entry_forced) ? 1 : 0) << 25) | ((uint32_t)(picked ? 1 : 0) << 26);
     }
     SDV_WAVE_SYNC();
+    K1_T(ts1_); K1_ADD(19, ts0_, ts1_);
     /* rows of the grid in which something happens: a read that is valid, or a Bit Picker collision (the walk below leaves every other row
      * as it finds it, apart from noting its last read) */
     uint64_t rows_live;
@@ -431,7 +433,8 @@ __device__ inline bool search_pcm16_data(BinCtx &c, L16 &l, P16Lds &lds, Coords 
     /* The walk over the grid and the votes.  Without a Bit Picker collision anywhere (and a line object that is not forced bad to begin
      * with) the rows do not influence each other's reads and a row is worked on by the whole wave (walk_rows_parallel); otherwise the
      * walk is replayed cell by cell on lane 0. */
-    if (!any_coll && !entry_forced && nr <= 32) walk_rows_parallel(lds, nl, nr, l0, r1, scan_step, rows_live);
+    K1_T(ts2_); K1_ADD(18, ts1_, ts2_);
+    if (!any_coll && !entry_forced && nr <= 32) { walk_rows_parallel(lds, nl, nr, l0, r1, scan_step, rows_live); K1_T(ts3_); K1_ADD(20, ts2_, ts3_); }
     else if (lane == 0) {
         SweepEnt *sw = lds.w.sweep;
         uint8_t valid_left = 0, left_ofs = 0xFF;

@@ -64,12 +64,14 @@ template <bool kInsane>
 __device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, int k)
 {
     const FrameArgs &a = a16.f;
+    K1_BEGIN(); K1_T(tq0_);
     PrescanRes r; r.start = r.stop = 0; r.ref = 0; r.valid = 0; r.pad[0] = r.pad[1] = 0;
     if (prescan_runs(a, f)) {
         const int gap = frame_buf_lines(a, f) / (COORD_CHECK_PARTS - 1);
         const int row = frame_buf_row(a, f, (k + 1) * gap);
         if (row >= 0) {
             sdvp1b::stage_row(lds.p.w.px, a.luma + (size_t)f * a.frame_stride + (size_t)row * a.row_stride, a.width);
+            K1_T(tq1_); K1_ADD(16, tq0_, tq1_);
             /* both values of the Binarizer's sticky sweep flag where it matters (pcm1_frames_device.h, PrescanRes) */
             for (int variant = 0; variant < (sweep_flag_matters(a.preset) ? 2 : 1); variant++) {
                 BinCtx c; Bin b;
@@ -86,6 +88,7 @@ __device__ inline void prescan_body(const FrameArgs16 &a16, Lds16 &lds, int f, i
                 if (lane_id() == 0) a16.prescan[((size_t)variant * a.n_total + f) * COORD_CHECK_LINES + k] = q;
                 SDV_WAVE_SYNC();
             }
+            K1_T(tq2_); K1_ADD(23, tq0_, tq2_); K1_FLUSH();
             return;
         }
     }
