@@ -373,6 +373,58 @@ def test_gpu_fused_uneven_calls_equal_the_sequential_oracle(oracle_lib):
     assert np.concatenate(got_s).tobytes() == want_s.tobytes()
 
 
+@pytest.mark.parametrize("geometry", ["odd_height", "pal"])
+def test_emu_fused_direct_frames_other_geometries(geometry, emu_lib, oracle_lib):
+    """Frames without records (the frame kernel writes the stitch stage's field buffers itself) with fields of unequal length - a frame of 485 rows: 243 + 242
+    lines - and with the 288 lines per field of a PAL frame (five chunks of 64 lines): calls of two frames against one call over the whole tape."""
+    from sdvpcmdecoder_amd import synth
+    lib = A.bind_product(_bind(ea.bind(emu_lib)))
+    if geometry == "odd_height":
+        luma = np.ascontiguousarray(synth.stc007_frames(10, seed=14, noise_sigma=4.0)[0][:, :485, :])
+    else:
+        luma = synth.stc007_frames(10, seed=15, height=576, lines_per_field=294, noise_sigma=4.0)[0].copy()
+    a = EmuEngine(lib)
+    lib.sdv_set_pcm_type(a.h, STC007, 0)
+    want_p, want_f, want_s, _, _ = _fused_host(lib, a.h, STC007, luma, with_audio=False)
+    a.close()
+    b = EmuEngine(lib)
+    lib.sdv_set_pcm_type(b.h, STC007, 0)
+    got_p, got_f, direct = [], [], []
+    info = ea.StitchInfo()
+    for k in range(0, 10, 2):
+        p, f, st, _, _ = _fused_host(lib, b.h, STC007, luma[k:k + 2], with_audio=False, first_frame_no=1 + k, flags=(1 if k == 0 else 0) | (4 if k == 8 else 0))
+        got_p.append(p.copy()); got_f.append(f.copy())
+        assert lib.sdv_get_stitch_info(b.h, C.byref(info)) == 0
+        direct.append(int(info.direct_frames))
+    b.close()
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert sum(direct) >= 2, direct
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geometry", ["odd_height", "pal"])
+def test_gpu_fused_direct_frames_other_geometries(geometry, oracle_lib):
+    """The same on the GPU, against the sequential oracle."""
+    import torch
+    from sdvpcmdecoder_amd import Engine, synth
+    if geometry == "odd_height":
+        luma = np.ascontiguousarray(synth.stc007_frames(12, seed=14, noise_sigma=4.0)[0][:, :485, :])
+    else:
+        luma = synth.stc007_frames(12, seed=15, height=576, lines_per_field=294, noise_sigma=4.0)[0].copy()
+    want_p, want_f, want_s = _oracle_chain(oracle_lib, luma)
+    d = torch.from_numpy(luma).cuda()
+    eng = Engine(0); eng.setPCMType(STC007)
+    got_p, got_f, got_s, direct = [], [], [], []
+    for k in range(0, 12, 3):
+        p, f, st = eng.decode_frames(STC007, d[k:k + 3], first_frame_no=1 + k, new_file=k == 0, end_file=k + 3 == 12)
+        got_p.append(p.cpu().numpy().copy()); got_f.append(f.cpu().numpy().copy()); got_s.append(st.cpu().numpy().copy())
+        direct.append(int(eng.stitch_info().direct_frames))
+    assert np.concatenate(got_p).tobytes() == want_p.tobytes()
+    assert np.concatenate(got_f).tobytes() == want_f.tobytes()
+    assert np.concatenate(got_s).tobytes() == want_s.tobytes()
+    assert sum(direct) >= 2, direct
+
+
 def _tape_clean_then_damaged(n=15, bad_from=9):
     """Frames that play, then frames with lost lines: the call that meets them has its frame stage run more than one round."""
     from sdvpcmdecoder_amd import synth
