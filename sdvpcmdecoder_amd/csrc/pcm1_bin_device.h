@@ -477,6 +477,10 @@ __device__ inline uint32_t row_vote(uint32_t m, uint32_t crc, const uint32_t *gr
     const int lane = lane_id();
     const bool mine = lane < 32 && ((m >> (lane & 31)) & 1u);
     uint32_t eq = 0;        /* the other columns' CRCs are read where the candidate reads left them (grid_row[j * stride], low 16 bits) */
+    /* (a tape that plays: every column that reads valid carries the one CRC - then every lane's answer is the set of those columns) */
+    const uint32_t c_first = row_read(crc, lo);
+    if (__ballot(mine && crc != c_first) == 0ull) eq = crc == c_first ? m : 0u;
+    else
     for (int j = lo; j <= hi; j++) if ((m >> j) & 1u) { const uint32_t cj = grid_row[j * stride] & 0xFFFFu; eq |= (cj == crc ? 1u : 0u) << j; }
     const uint32_t cnt = (uint32_t)__popc(eq), first = (uint32_t)(__ffs((int)eq) - 1);
     const uint32_t top = wave_max_u32(mine ? ((cnt << 8) | (31u - first)) : 0u);
