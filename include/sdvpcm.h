@@ -370,6 +370,10 @@ void sdv_default_stitch_settings(sdv_stitch_settings *st);
 int sdv_set_stitch_settings(sdv_engine *e, const sdv_stitch_settings *st);
 /* A freshly constructed STC007DataStitcher: statistics, previous-frame memory and queued lines are dropped. */
 int sdv_reset_stitcher(sdv_engine *e);
+/* Like every entry point of an engine this is a call of the engine's one worker thread (the engine is as little re-entrant as the
+ * Binarizer it replaces): `direct_frames` of a fused call is counted here, on first asking, with one small synchronous read-back
+ * from the device - not a getter to poll from another thread while a decode call runs.  After a call that returned an error
+ * every field is zero. */
 int sdv_get_stitch_info(const sdv_engine *e, sdv_stitch_info *out);
 
 /* The stitcher's stream state as an opaque blob (previous frame's descriptor, statistics rings, the 112 hand-over lines):

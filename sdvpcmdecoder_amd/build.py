@@ -58,6 +58,22 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
 
 
+HIP_DEV_LIB = os.path.join(PKG, "libsdvpcm_hip_dev.so")
+
+
+def build_hip_dev(force=False):
+    """TEST ONLY: the developer build of the same sources (-DSDV_DEV_AIDS: the scheduler's off-switches and traces can be set through the environment).
+    The product never loads it; tests/test_decode_frames.py runs the fused entry's defensive ways through it on the GPU, in a process of its own."""
+    csrc = os.path.join(PKG, "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip", ".inc"))] + [os.path.join(ROOT, "include", "sdvpcm.h")]
+    if not force and not _newer(HIP_DEV_LIB, srcs):
+        return HIP_DEV_LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "-DSDV_DEV_AIDS", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                           "-o", HIP_DEV_LIB, os.path.join(csrc, "sdvpcm_hip.hip")], cwd=csrc)
+    return HIP_DEV_LIB
+
+
 def build_hip(force=False):
     csrc = os.path.join(PKG, "csrc")
     srcs = [os.path.join(csrc, f) for f in ("sdvpcm_hip.hip", "stc007_device.h", "stc007_sweep_device.h", "stc007_deint_device.h", "stc007_stitch_device.h", "engine.inc",
@@ -144,7 +160,18 @@ def build_emu(force=False):
 
 
 def build_all():
-    build_hip()
+    # the two builds of the HIP library side by side (each is one hipcc run of a minute and a half)
+    import threading
+    dev_err = []
+    def _dev():
+        try: build_hip_dev()
+        except Exception as ex: dev_err.append(ex)
+    th = threading.Thread(target=_dev); th.start()
+    try:
+        build_hip()
+    finally:
+        th.join()
+    if dev_err: raise dev_err[0]
     build_example()
     build_example_sharded()
     build_oracle()

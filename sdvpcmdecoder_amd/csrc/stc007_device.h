@@ -153,7 +153,8 @@ struct FrameArgs {
      * buffers - 32-byte lines in field order, what sdv_k_stitch_analyze would make of the frame's 48-byte records - and leaves a summary instead of records */
     void *direct_fields;            /* the stitcher's field buffers (SLine[segments][2][direct_pitch]), or NULL */
     struct DirectFrame *direct_frames;      /* [n_total] what frame f left there (flag 0: nothing, its records are in recs) */
-    int direct_seg_ofs, direct_pitch;       /* frame f is the stitcher's segment f + direct_seg_ofs; lines per field buffer */
+    int direct_seg_ofs, direct_pitch;       /* frame f is the stitcher's segment f + direct_seg_ofs; lines from one field buffer to the next */
+    int direct_lines;                       /* lines a field buffer holds (the stitcher's BUF_FIELD: a longer field goes through its records, as on the record path) */
     /* The first round of a call on a tape that plays: every frame is started from the model's state (predict_half) behind ONE known state, `base` at frame
      * base_frame - the wave makes it itself instead of reading what a kernel in front of this one wrote to states_in (which then holds nothing yet: the
      * engine fills it in when the round was not the last, engine.inc). */
@@ -2722,7 +2723,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
              * anything of the frame is written.  Not the last frame of the call (the stitcher keeps that one's records for the next call), not a frame with
              * a service line of its own in front of it. */
             bool direct = false;
-            if (a.direct_fields && whole && f + 1 < a.n_total && f != a.new_file_frame && n0 <= a.direct_pitch && n1 <= a.direct_pitch) {
+            if (a.direct_fields && whole && f + 1 < a.n_total && f != a.new_file_frame && n0 <= a.direct_lines && n1 <= a.direct_lines) {
                 direct = true;
                 for (int c = 0; c < n_chunks; c++) {
                     const int cn1 = n1 - 64 * c < 64 ? (n1 - 64 * c > 0 ? n1 - 64 * c : 0) : 64;

@@ -2048,9 +2048,7 @@ __global__ void __launch_bounds__(64) sdv_k_stitch_layout(sdvs::LayoutArgs a)
     if (i < a.n_seg) a.seg_end[i] = a.carry_frames ? (i == 0 ? a.n_carry - 1u : a.n_carry + i * a.recs_per_frame - 1u) : a.n_carry + (i + 1u) * a.recs_per_frame - 1u;
 }
 #ifndef SDV_AN_WAVES
-#ifndef SDV_AN_WAVES
 #define SDV_AN_WAVES 3
-#endif
 #endif
 __global__ void __launch_bounds__(64, SDV_AN_WAVES) sdv_k_stitch_analyze(sdvs::AnalyzeArgs a)
 {

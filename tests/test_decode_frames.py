@@ -373,16 +373,25 @@ def test_gpu_fused_uneven_calls_equal_the_sequential_oracle(oracle_lib):
     assert np.concatenate(got_s).tobytes() == want_s.tobytes()
 
 
-@pytest.mark.parametrize("geometry", ["odd_height", "pal"])
+def _geometry_tape(geometry, n):
+    from sdvpcmdecoder_amd import synth
+    if geometry == "odd_height":
+        return np.ascontiguousarray(synth.stc007_frames(n, seed=14, noise_sigma=4.0)[0][:, :485, :])
+    if geometry == "pal":
+        return synth.stc007_frames(n, seed=15, height=576, lines_per_field=294, noise_sigma=4.0)[0].copy()
+    if geometry == "field_buffer_full":         # 588 rows: both fields exactly the 294 lines a field buffer of the stitcher holds (stc007datastitcher.h: BUF_SIZE_FIELD)
+        return synth.stc007_frames(n, seed=16, height=588, lines_per_field=294, noise_sigma=4.0)[0].copy()
+    assert geometry == "field_too_long"         # 590 rows: 295 lines per field, one more than a field buffer holds - such a frame must go through its records
+    return synth.stc007_frames(n, seed=17, height=590, lines_per_field=295, noise_sigma=4.0)[0].copy()
+
+
+@pytest.mark.parametrize("geometry", ["odd_height", "pal", "field_buffer_full", "field_too_long"])
 def test_emu_fused_direct_frames_other_geometries(geometry, emu_lib, oracle_lib):
     """Frames without records (the frame kernel writes the stitch stage's field buffers itself) with fields of unequal length - a frame of 485 rows: 243 + 242
-    lines - and with the 288 lines per field of a PAL frame (five chunks of 64 lines): calls of two frames against one call over the whole tape."""
-    from sdvpcmdecoder_amd import synth
+    lines - with the 288 lines per field of a PAL frame (five chunks of 64 lines), with fields that fill a field buffer to its last line and with fields one line
+    longer than that (no frame of those may go without records): calls of two frames against one call over the whole tape."""
     lib = A.bind_product(_bind(ea.bind(emu_lib)))
-    if geometry == "odd_height":
-        luma = np.ascontiguousarray(synth.stc007_frames(10, seed=14, noise_sigma=4.0)[0][:, :485, :])
-    else:
-        luma = synth.stc007_frames(10, seed=15, height=576, lines_per_field=294, noise_sigma=4.0)[0].copy()
+    luma = _geometry_tape(geometry, 10)
     a = EmuEngine(lib)
     lib.sdv_set_pcm_type(a.h, STC007, 0)
     want_p, want_f, want_s, _, _ = _fused_host(lib, a.h, STC007, luma, with_audio=False)
@@ -398,19 +407,17 @@ def test_emu_fused_direct_frames_other_geometries(geometry, emu_lib, oracle_lib)
         direct.append(int(info.direct_frames))
     b.close()
     assert np.concatenate(got_p).tobytes() == want_p.tobytes() and np.concatenate(got_f).tobytes() == want_f.tobytes()
-    assert sum(direct) >= 2, direct
+    if geometry == "field_too_long": assert sum(direct) == 0, direct
+    else: assert sum(direct) >= 2, direct
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geometry", ["odd_height", "pal"])
+@pytest.mark.parametrize("geometry", ["odd_height", "pal", "field_buffer_full", "field_too_long"])
 def test_gpu_fused_direct_frames_other_geometries(geometry, oracle_lib):
     """The same on the GPU, against the sequential oracle."""
     import torch
-    from sdvpcmdecoder_amd import Engine, synth
-    if geometry == "odd_height":
-        luma = np.ascontiguousarray(synth.stc007_frames(12, seed=14, noise_sigma=4.0)[0][:, :485, :])
-    else:
-        luma = synth.stc007_frames(12, seed=15, height=576, lines_per_field=294, noise_sigma=4.0)[0].copy()
+    from sdvpcmdecoder_amd import Engine
+    luma = _geometry_tape(geometry, 12)
     want_p, want_f, want_s = _oracle_chain(oracle_lib, luma)
     d = torch.from_numpy(luma).cuda()
     eng = Engine(0); eng.setPCMType(STC007)
@@ -422,7 +429,53 @@ def test_gpu_fused_direct_frames_other_geometries(geometry, oracle_lib):
     assert np.concatenate(got_p).tobytes() == want_p.tobytes()
     assert np.concatenate(got_f).tobytes() == want_f.tobytes()
     assert np.concatenate(got_s).tobytes() == want_s.tobytes()
-    assert sum(direct) >= 2, direct
+    if geometry == "field_too_long": assert sum(direct) == 0, direct
+    else: assert sum(direct) >= 2, direct
+
+
+_RETRY_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from sdvpcmdecoder_amd import Engine, synth
+STC007 = 2
+luma = synth.stc007_frames(12, seed=12, noise_sigma=4.0)[0].copy()
+d = torch.from_numpy(luma).cuda()
+def run(switch):
+    eng = Engine(0); eng.setPCMType(STC007)
+    out = []; direct = []; piped = []
+    for k in range(0, 12, 3):
+        if switch and k >= 6: os.environ[switch] = "1"          # the first calls arm the direct fields and queue the stitch stage ahead; then the switch
+        p, f, st = eng.decode_frames(STC007, d[k:k + 3], first_frame_no=1 + k, new_file=k == 0, end_file=k + 3 == 12)
+        out.append((p.cpu().numpy().tobytes(), f.cpu().numpy().tobytes(), st.cpu().numpy().tobytes()))
+        i = eng.stitch_info(); direct.append(int(i.direct_frames)); piped.append(int(i.pipelined))
+    if switch: del os.environ[switch]
+    return out, direct, piped
+want, d0, p0 = run(None)
+assert sum(d0) >= 2, d0
+for switch in ("SDV_DIRECT_FORCE_RETRY", "SDV_NO_DIRECT_FIELDS", "SDV_NO_QUEUE_AHEAD", "SDV_NO_PREDICT_IN_KERNEL"):
+    got, d1, p1 = run(switch)
+    assert got == want, switch
+    if switch in ("SDV_DIRECT_FORCE_RETRY", "SDV_NO_DIRECT_FIELDS"): assert d1[2] == 0 and d1[3] == 0, (switch, d1)
+    if switch == "SDV_NO_QUEUE_AHEAD": assert not any(x & 4 for x in p1[2:]), p1
+print("RETRY_OK", d0, p0)
+"""
+
+
+@pytest.mark.gpu
+def test_gpu_fused_way_back_with_records_on_a_developer_build():
+    """The fused entry's defensive ways on real hardware (stream order, the asynchronous read-back and its event are trivial under the emulator): the frames
+    that went straight into the field buffers decoded again with records from the restored stream state (SDV_STITCH_RETRY_WITH_RECORDS), a call without direct
+    fields, without the stitch stage queued ahead, without the in-kernel prediction.  The product library cannot be steered there from outside (its two checks agree
+    by construction, it does not read the environment): this runs the developer build of the same sources (build.py: libsdvpcm_hip_dev.so, -DSDV_DEV_AIDS) in a
+    process of its own and compares every way with the default one, call by call."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "sdvpcmdecoder_amd", "libsdvpcm_hip_dev.so")
+    if not os.path.exists(dev): pytest.skip("no developer build of the HIP library (sdvpcmdecoder_amd/build.py: build_hip_dev)")
+    env = dict(os.environ); env["SDVPCM_LIB"] = dev
+    r = subprocess.run([sys.executable, "-c", _RETRY_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RETRY_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def _tape_clean_then_damaged(n=15, bad_from=9):
