@@ -120,6 +120,8 @@ struct WaveLds {
  * 2 the successor was started from something else */
 enum { VF_OK = 0, VF_ABORTED = 1, VF_BREAK = 2,
        VF_KIND = 0x0F,
+       VF_HIST = 0x10,              /* (with VF_BREAK) the state the successor was started from differs from this frame's in the 16-frame coordinate history: the scheduler's
+                                     * "the history moves on" has something to do behind this link even when the frame itself only re-tuned its levels */
        VF_SLOW = 0x20,              /* lines of the frame went through the general path (full kernel only): the frame did need that kernel - what the scheduler's "worn tape" is decided on */
        VF_MOVED = 0x40,             /* the frame leaves the chain with other coordinates / histories than the model makes of what it was started from */
        VF_RETUNED = 0x80 };         /* ... with other black / white / reference levels */
@@ -134,6 +136,8 @@ struct FrameArgs {
     uint8_t *refs;                  /* [3 * n_total] or NULL: the reference level frame f was started from, the one it hands on, and whether it pushed one pair
                                      * into its coordinate history (the scheduler's guess at what a frame does with another state: engine.inc, "a level that
                                      * passes through", "the history moves on") */
+    uint8_t *sig;                   /* [n_total] or NULL: where a frame the lean kernel gave up saw the line begin that it gave up on (give_up_signature) - frames that
+                                     * gave up side by side over a window that jumped are told apart by it (engine.inc, the crowd rule) */
     int n_total;                    /* frames of the call */
     int new_file_frame;             /* frame index that is preceded by a NEW_FILE service line, or -1 */
     int end_file_frame;             /* frame index of the filler frame that closes the file (no pixels: FILLER lines, END_FILE), or -1 */
@@ -1871,9 +1875,15 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
     /* the check of the chain, by the frame itself: was the next frame started from this state?  (and: is it the state the frame itself was started
      * from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
     uint8_t fl = VF_OK;
+    bool hist_off = false;
     if (f + 1 < a.n_total) {
         const uint32_t next = a.predict_in_kernel ? v2d_model_dword(a, f + 1, dw) : reinterpret_cast<const uint32_t *>(&a.states_in[f + 1])[dw];
-        if (__ballot(in && next != mine) != 0ull) fl = VF_BREAK;
+        if (__ballot(in && next != mine) != 0ull) {
+            fl = VF_BREAK;
+            /* long_valid[]: halfwords V2D_H_LONG .. V2D_H_LONG + 31 = the high half of dword 13, dwords 14 .. 28, the low half of dword 29 */
+            const uint32_t d = next ^ mine;
+            hist_off = __ballot(in && ((dw == 13 && (d & 0xFFFF0000u)) || (dw >= 14 && dw <= 28 && d) || (dw == 29 && (d & 0x0000FFFFu)))) != 0ull;
+        }
     }
     if (fl == VF_BREAK) {       /* (only asked of a frame whose link broke: on a tape that plays this is skipped) */
         /* ... "what it was started from" as the model sees it: one frame on, with the inherited tuning */
@@ -1884,6 +1894,7 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         const uint32_t d = mine ^ own;
         if (__ballot(in && dw >= 1 && (dw == 2 ? d & 0xFF00FFFFu : d) != 0) != 0ull) fl |= VF_MOVED;
         if (__ballot(in && ((dw == 0 && d != 0) || (dw == 2 && (d & 0x00FF0000u) != 0))) != 0ull) fl |= VF_RETUNED;
+        if (hist_off) fl |= VF_HIST;
     }
     if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
     if (lane == 0) {
@@ -1895,8 +1906,25 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         }
     }
 }
+/* Where the line a lean wave gives its frame up on begins: the first pixel of the staged row at or above the reference level (the rising edge of the START
+ * marker on a line that holds PCM), in pixels of an undoubled line, 0xFF when there is none below 254.  Not a measurement anything is decoded with: frames that
+ * give up side by side because the data window is no longer where their state says tell the scheduler by it whether they look at one window or at several
+ * (engine.inc: only the first frame of each goes to the general kernel, the others wait for what it finds). */
+__device__ inline uint8_t give_up_signature(const FrameArgs &a, const WaveLds &lds, uint8_t ref_level)
+{
+    const int lane = lane_id();
+    const int base = 16 * lane;
+    uint32_t first = 0xFFFFu;
+    if (base < a.width && base < 1024) {
+#pragma unroll 1
+        for (int i = 15; i >= 0; i--) { const int x = base + i; if (x < a.width && lds.px[x] >= ref_level) first = (uint32_t)x; }
+    }
+    first = wave_min_u32(first);
+    if (a.doubled) first >>= 1;
+    return first < 254u ? (uint8_t)first : (uint8_t)0xFF;
+}
 /* a frame given up: its state goes out as it came in, marked (dword 29, byte 2 = _pad[0]) */
-__device__ inline void v2d_give_up(const FrameArgs &a, const WaveLds &lds, int f)
+__device__ inline void v2d_give_up(const FrameArgs &a, const WaveLds &lds, int f, uint8_t sig = 0xFF)
 {
     enum { NDW = sizeof(sdv_v2d_state) / 4 };
     static_assert(offsetof(sdv_v2d_state, _pad) == 118, "the mark of a frame given up");
@@ -1906,7 +1934,7 @@ __device__ inline void v2d_give_up(const FrameArgs &a, const WaveLds &lds, int f
         if (lane == NDW - 1) d = (d & 0xFF00FFFFu) | ((uint32_t)0xA5 << 16);      /* STATE_ABORTED */
         reinterpret_cast<uint32_t *>(&a.states_out[f])[lane] = d;
     }
-    if (lane == 0) a.flag[f] = VF_ABORTED;
+    if (lane == 0) { a.flag[f] = VF_ABORTED; if (a.sig) a.sig[f] = sig; }
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
@@ -2962,7 +2990,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
             if (!took_fast) {
                 if (kLean) {
-                    v2d_give_up(a, lds, f);
+                    v2d_give_up(a, lds, f, a.sig ? give_up_signature(a, lds, v.bin.in_ref) : (uint8_t)0xFF);      /* (the line sits in LDS: staged by the batch that ended on it, or just above) */
                     return;
                 } else {
                     K1_T(t_sc0);

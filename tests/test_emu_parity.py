@@ -189,6 +189,34 @@ def test_emu_window_jump_settles_in_few_rounds(emu_lib, oracle_lib):
     assert info.rounds <= 10, info.rounds
 
 
+def test_emu_crowd_over_several_windows_is_led_by_the_first_frame_of_each(emu_lib, oracle_lib, monkeypatch):
+    """The data window jumps five times in a call, every time out of reach of the state the frames were started from: behind the first jump every lean
+    wave gives up - one crowd over five windows.  The waves leave where the line they gave up on began (FrameArgs::sig) and the scheduler sends the first frame
+    of every window to the general kernel at once, not the crowd's first frame only (which finds the next window two rounds later, and so on): fewer rounds,
+    fewer frames through the general kernel, the same records as the sequential oracle either way."""
+    n = 160
+    luma0, _, _ = synth.stc007_frames(n, seed=5, height=24, noise_sigma=3.0)
+    luma = luma0.copy()
+    for f, to in [(30, 6), (55, -7), (80, 4), (105, -5), (130, 8)]:
+        luma[f:] = np.roll(luma0[f:], to, axis=2)
+    want, want_stats = oracle_binarize(np.concatenate([luma0[:20], luma]), mode=2)
+    seen = {}
+    for switch in (None, "SDV_SCHED_NO_SIG"):
+        if switch: monkeypatch.setenv(switch, "1")
+        eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+        emu_lib.sdv_set_mode(eng, 2)
+        a, sa, _ = emu_run(emu_lib, luma0[:20], 2, eng=eng)
+        b, sb, info = emu_run(emu_lib, luma, 2, flags=0, first=21, eng=eng)
+        emu_lib.sdv_engine_destroy(eng)
+        if switch: monkeypatch.delenv(switch)
+        got = np.concatenate([a, b])
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert np.concatenate([sa, sb]).view(np.uint8).tobytes() == want_stats.tobytes()
+        seen[switch] = (info.rounds, info.frames_general)
+    assert seen[None][0] < seen["SDV_SCHED_NO_SIG"][0] and seen[None][1] < seen["SDV_SCHED_NO_SIG"][1], seen
+    assert seen[None][0] <= 8, seen
+
+
 def test_emu_bad_arguments(emu_lib):
     eng = C.c_void_p(emu_lib.sdv_engine_create(0))
     buf = np.zeros((1, 8, 200), np.uint8)
