@@ -20,9 +20,10 @@
 extern "C" {
 #endif
 
-#define SDV_ABI_VERSION 4   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only);
+#define SDV_ABI_VERSION 5   /* 2: output capacities on sdv_binarize_frames / sdv_pcm1_binarize_lines; 3: sdv_audio_process, sdv_wav_pack, sdv_wav_header, sdv_decode_frames (additions only);
                              * 4: sdv_pcm16x0_binarize_lines, sdv_audio_stalled, sdv_set_frame_flags, sdv_double_width, sdv_vis_render_lines (additions); the calls that used to refuse PCM-16x0 frames of the wrong size and the
-                             * AudioProcessor's dead ends now follow the reference; the PCM-16x0 stitch state blob grew by conv_queue's remainder */
+                             * AudioProcessor's dead ends now follow the reference; the PCM-16x0 stitch state blob grew by conv_queue's remainder;
+                             * 5: sdv_run_info grew by frames_met (at its end), sdv_binarize_lines (addition) */
 
 /* ---- status codes ---------------------------------------------------------------------------
  * 0..4 mirror Binarizer::LB_RET_* (binarizer.h:268-275); 16.. mirror STC007Deinterleaver::DI_RET_*
@@ -282,6 +283,8 @@ typedef struct sdv_run_info {
     uint32_t frames_general;    /* of those, by the full kernel (the lean one has no general path and gives such frames up) */
     float kernel_ms;            /* HIP-event time of the frame kernel launches of this call (sdv_set_profiling) */
     uint32_t sweeps;            /* reference-level sweeps (Binarizer::calcRefLevelBySweep) settled by the sweep kernels for this call */
+    uint32_t frames_met;        /* of frames_general: decodes that ended early, on a line where the state was the one the frame's last complete decode had there
+                                 * (the rest of the frame could only come out the same: DESIGN.md, "a pass that meets the last one") */
 } sdv_run_info;
 int sdv_get_run_info(const sdv_engine *e, sdv_run_info *out);
 /* Bracket every frame-kernel launch with hipEvents on the caller's stream and report the sum in sdv_run_info. */

@@ -136,6 +136,10 @@ struct FrameArgs {
     uint8_t *refs;                  /* [3 * n_total] or NULL: the reference level frame f was started from, the one it hands on, and whether it pushed one pair
                                      * into its coordinate history (the scheduler's guess at what a frame does with another state: engine.inc, "a level that
                                      * passes through", "the history moves on") */
+    /* Trajectory snapshots of the general kernel (tc_*, below: "a pass that meets the last one"): per frame two sets of TC_ENTRIES snapshots, a header of
+     * two words (which set holds the last complete pass + 1, or 0; its entries), and a second list of coordinate keys beside `scratch`.  NULL: off. */
+    struct TcSnap *tc_snaps; uint32_t *tc_hdr; uint32_t *tc_keys;
+    const uint8_t *skip;            /* [n_total] or NULL: frames of this launch that need not be decoded again (v2d_relink) */
     uint8_t *sig;                   /* [n_total] or NULL: where a frame the lean kernel gave up saw the line begin that it gave up on (give_up_signature) - frames that
                                      * gave up side by side over a window that jumped are told apart by it (engine.inc, the crowd rule) */
     int n_total;                    /* frames of the call */
@@ -1858,22 +1862,14 @@ __device__ inline uint32_t v2d_state_half(const V2D &v, const WaveLds &lds, cons
     default: return 0;                                                                      /* _pad */
     }
 }
-/* The state goes out a dword per lane (lanes 0 .. 29), and the check of the chain - was the next frame started from this state? - is a ballot.  (It
- * was put together by lane 0 alone on the stack before: the histories are indexed by how full they are, and that was the lean kernel's scratch memory.) */
-__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a, bool unsettled = false, uint8_t extra_flags = 0)
+/* The check of the chain, by the frame itself: was the next frame started from the state this one hands on (`mine`: dword `lane` of it)?  (and: is it the state
+ * the frame itself was started from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
+__device__ inline uint8_t v2d_link_flags(const FrameArgs &a, const WaveLds &lds, int f, uint32_t mine)
 {
     enum { NDW = sizeof(sdv_v2d_state) / 4 };
     const int lane = lane_id();
     const bool in = lane < NDW;
     const int dw = in ? lane : 0;
-    SDV_WAVE_SYNC();            /* (the histories were written by lane 0) */
-    const uint32_t mine = v2d_state_half(v, lds, a, 2 * dw) | (v2d_state_half(v, lds, a, 2 * dw + 1) << 16);
-    const int f = (int)(s - a.states_out);
-    if (in) reinterpret_cast<uint32_t *>(s)[dw] = mine;
-    /* the last frame of the call: its state also behind the flags, where the host's one read-back per round finds it (engine.inc: tail_ofs) */
-    if (in && f == a.n_total - 1) reinterpret_cast<uint32_t *>(a.flag + (((size_t)a.n_total + 15) & ~(size_t)15))[dw] = mine;
-    /* the check of the chain, by the frame itself: was the next frame started from this state?  (and: is it the state the frame itself was started
-     * from - a frame that hands on what it got tells nothing new, one that does not has most likely tuned itself to its own pixels) */
     uint8_t fl = VF_OK;
     bool hist_off = false;
     if (f + 1 < a.n_total) {
@@ -1896,6 +1892,35 @@ __device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d
         if (__ballot(in && ((dw == 0 && d != 0) || (dw == 2 && (d & 0x00FF0000u) != 0))) != 0ull) fl |= VF_RETUNED;
         if (hist_off) fl |= VF_HIST;
     }
+    return fl;
+}
+/* A frame the round need not decode again (FrameArgs::skip: the state it is started from is the one its last decode was started from, and that decode went to
+ * the end of the frame): records, descriptor and the state it hands on are in place; what may have changed is what its successor is started from. */
+__device__ inline void v2d_relink(const FrameArgs &a, const WaveLds &lds, int f)
+{
+    enum { NDW = sizeof(sdv_v2d_state) / 4 };
+    const int lane = lane_id();
+    const uint32_t mine = reinterpret_cast<const uint32_t *>(&a.states_out[f])[lane < NDW ? lane : 0];
+    const uint8_t keep = (uint8_t)(uniu(a.flag[f]) & VF_SLOW);
+    const uint8_t fl = v2d_link_flags(a, lds, f, mine);
+    SDV_WAVE_SYNC();
+    if (lane == 0) a.flag[f] = (uint8_t)(fl | keep);
+}
+/* The state goes out a dword per lane (lanes 0 .. 29), and the check of the chain is a ballot.  (It
+ * was put together by lane 0 alone on the stack before: the histories are indexed by how full they are, and that was the lean kernel's scratch memory.) */
+__device__ inline void v2d_store_state(const V2D &v, const WaveLds &lds, sdv_v2d_state *s, const FrameArgs &a, bool unsettled = false, uint8_t extra_flags = 0)
+{
+    enum { NDW = sizeof(sdv_v2d_state) / 4 };
+    const int lane = lane_id();
+    const bool in = lane < NDW;
+    const int dw = in ? lane : 0;
+    SDV_WAVE_SYNC();            /* (the histories were written by lane 0) */
+    const uint32_t mine = v2d_state_half(v, lds, a, 2 * dw) | (v2d_state_half(v, lds, a, 2 * dw + 1) << 16);
+    const int f = (int)(s - a.states_out);
+    if (in) reinterpret_cast<uint32_t *>(s)[dw] = mine;
+    /* the last frame of the call: its state also behind the flags, where the host's one read-back per round finds it (engine.inc: tail_ofs) */
+    if (in && f == a.n_total - 1) reinterpret_cast<uint32_t *>(a.flag + (((size_t)a.n_total + 15) & ~(size_t)15))[dw] = mine;
+    uint8_t fl = v2d_link_flags(a, lds, f, mine);
     if (unsettled) fl = VF_ABORTED;         /* a sweep is owed to this frame: to be decoded again, from the same state */
     if (lane == 0) {
         a.flag[f] = (uint8_t)(fl | extra_flags);
@@ -1935,6 +1960,63 @@ __device__ inline void v2d_give_up(const FrameArgs &a, const WaveLds &lds, int f
         reinterpret_cast<uint32_t *>(&a.states_out[f])[lane] = d;
     }
     if (lane == 0) { a.flag[f] = VF_ABORTED; if (a.sig) a.sig[f] = sig; }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * A pass that meets the last one (general kernel, damaged tapes).  A frame of a damaged tape is decoded several times - from a guessed state, again when its
+ * sweeps are settled, again when its predecessor turned out to hand on another state - and every pass walks the whole frame although the passes differ only
+ * up to the first line that tunes the binarizer to its own pixels again (a lost line takes the black and white presets back, a sweep sets the reference
+ * level): from the line on where the state of this pass equals the state the last pass had there, this pass would only do the same thing again, record for record.
+ * So a complete pass leaves snapshots of the state ahead of the lines it took one by one (where the state can change), and a later pass that arrives at such a
+ * line with the same state stops there: the records behind are in place, the counters and coordinate keys of the rest of the frame are added from what the
+ * last pass noted, and the frame ends from the last pass's final state.
+ * What "state" is: everything a line's decode and its bookkeeping read - presets of the binarizer, field state, the 9-line window, the previous line's words,
+ * the frame's start coordinates (TcSnap dwords 0 .. TC_CMP_DWORDS-1).  What is only counted (frame statistics, the lists of coordinate keys) is carried as
+ * differences.  A pass is "complete" when it ran to the end of the frame with every sweep it asked for at hand (the memo only grows, so the same lookups hit again).
+ * --------------------------------------------------------------------------------------------- */
+enum { TC_ENTRIES = 64, TC_SNAP_DWORDS = 32, TC_CMP_DWORDS = 17, TC_USED_DWORDS = 25, TC_FINAL = TC_ENTRIES - 1, TC_POS_NONE = 0xFFFF };
+struct TcSnap { uint32_t d[TC_SNAP_DWORDS]; };
+/* dword `dw` of the snapshot of the state as it is now, ahead of line `pos` (= field * 1024 + index in the field) */
+__device__ inline uint32_t tc_dword(const V2D &v, const WaveLds &lds, int dw, uint32_t pos, bool used_general)
+{
+    switch (dw) {
+    case 0: case 1: case 2: case 3: case 4: case 5: case 6: case 7: case 8: return dw < v.n_last ? lds.lv_keys[dw] : 0u;
+    case 9: return (uint32_t)v.last_words[0] | ((uint32_t)v.last_words[1] << 16);
+    case 10: return (uint32_t)v.last_words[2] | ((uint32_t)v.last_words[3] << 16);
+    case 11: return (uint32_t)v.last_words[4] | ((uint32_t)v.last_words[5] << 16);
+    case 12: return (uint32_t)v.last_words[6] | ((uint32_t)v.last_words[7] << 16);
+    case 13: return (uint32_t)(uint16_t)v.bin.in_coord.start | ((uint32_t)(uint16_t)v.bin.in_coord.stop << 16);
+    case 14: return (uint32_t)(uint16_t)v.frame_avg.start | ((uint32_t)(uint16_t)v.frame_avg.stop << 16);
+    case 15: return (uint32_t)v.bin.in_black | ((uint32_t)v.bin.in_white << 8) | ((uint32_t)v.bin.in_ref << 16) |
+                    ((v.bin.in_coord.doubled ? 1u : 0u) | (v.bin.do_ref_lvl_sweep ? 2u : 0u) | (v.frame_avg.doubled ? 4u : 0u)) << 24;
+    case 16: return (uint32_t)v.field_state | ((uint32_t)(uint8_t)v.n_last << 8);
+    /* (17: reserved) ... what was counted so far: */
+    case 18: return (pos & 0xFFFFu) | (used_general ? 0x10000u : 0u);
+    case 19: return (uint32_t)(uint16_t)v.nfv | ((uint32_t)(uint16_t)v.nfi << 16);
+    case 20: return (uint32_t)v.q_line_length | ((uint32_t)v.q_odd << 16);
+    case 21: return (uint32_t)v.q_even | ((uint32_t)v.q_pcm_odd << 16);
+    case 22: return (uint32_t)v.q_pcm_even | ((uint32_t)v.q_bad_odd << 16);
+    case 23: return (uint32_t)v.q_bad_even | ((uint32_t)v.q_dup_odd << 16);
+    case 24: return (uint32_t)v.q_dup_even;
+    default: return 0u;
+    }
+}
+__device__ inline void tc_write(TcSnap *dst, const V2D &v, const WaveLds &lds, uint32_t pos, bool used_general)
+{
+    const int lane = lane_id();
+    SDV_WAVE_SYNC();                    /* (the 9-line window is written by lane 0) */
+    if (lane < TC_USED_DWORDS) dst->d[lane] = tc_dword(v, lds, lane, pos, used_general);
+}
+/* the counters of a snapshot staged in LDS (w[0 .. 31]) */
+struct TcCounts { int nfv, nfi; uint16_t q[9]; bool used_general; };
+__device__ inline TcCounts tc_counts(const uint32_t *w)
+{
+    TcCounts c;
+    c.used_general = (w[18] & 0x10000u) != 0;
+    c.nfv = (int)(w[19] & 0xFFFF); c.nfi = (int)(w[19] >> 16);
+    c.q[0] = (uint16_t)w[20]; c.q[1] = (uint16_t)(w[20] >> 16); c.q[2] = (uint16_t)w[21]; c.q[3] = (uint16_t)(w[21] >> 16); c.q[4] = (uint16_t)w[22];
+    c.q[5] = (uint16_t)(w[22] >> 16); c.q[6] = (uint16_t)w[23]; c.q[7] = (uint16_t)(w[23] >> 16); c.q[8] = (uint16_t)w[24];
+    return c;
 }
 
 /* Scanline staging: HBM -> registers (coalesced 16-byte loads, issued one line AHEAD so the HBM latency
@@ -2184,7 +2266,8 @@ __device__ inline void bits_to_words(uint64_t s_lo, uint64_t s_hi, uint16_t *w)
  * ladder_failed: no (depth, stage) of the ladder read the line with the inherited tuning - the general path need not try them again. */
 template <bool kMeasure>
 __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &g, const LaneConst &lc,
-                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec, bool *ladder_failed, unsigned long long *bw_slot = nullptr)
+                                 uint32_t frame_no, uint16_t line_num, uint32_t *fv_keys, sdv_line_rec *rec, bool *ladder_failed, unsigned long long *bw_slot = nullptr,
+                                 int *rung_out = nullptr /* the line was taken: its shift stage when it read at hysteresis depth 0, else -1 */)
 {
     const sdv_bin_preset &ps = a.preset;
     Bin &b = v.bin;
@@ -2212,6 +2295,7 @@ __device__ inline bool fast_line(const FrameArgs &a, WaveLds &lds, V2D &v, Geo &
     K1_T(t_fd1);
     K1_ADD(6, t_fd0, t_fd1);
     if (fb.ctrl_block) return false;
+    if (rung_out) *rung_out = fb.h == 0 ? (int)fb.s : -1;
     const int lane = lane_id();
     uint16_t w[9];
     bits_to_words(fb.s_lo, fb.s_hi, w);
@@ -2328,6 +2412,8 @@ __device__ __forceinline__ void capture_park(CaptureRaw &r, uint64_t a_lo, uint6
 }
 /* solve_automaton + the CRC of fill_stc007 for one line per LANE (every lane its own masks): returns the cells and whether the line
  * reads (CRC as read == CRC calculated, and not the start of a Control Block) */
+/* (kAnyPattern: the CRC alone - the caller looks at the Control Block pattern itself) */
+template <bool kAnyPattern = false>
 __device__ inline bool capture_solve(const CaptureRaw &r, BatchLaneOut &o)
 {
     const uint64_t a_lo = (uint64_t)r.a0 | ((uint64_t)r.a1 << 32), a_hi = (uint64_t)r.a2 | ((uint64_t)r.a3 << 32);
@@ -2343,7 +2429,23 @@ __device__ inline bool capture_solve(const CaptureRaw &r, BatchLaneOut &o)
     for (int j = 0; j < 16; j++) crc |= (uint32_t)((__popcll(s_lo & c_crc.klo[j]) + __popcll(s_hi & c_crc.khi[j])) & 1) << j;
     crc ^= c_crc.init;
     o.s_lo = s_lo; o.s_hi = s_hi; o.crc = (uint16_t)crc;
-    return (uint16_t)crc == rev16((uint32_t)((s_hi >> 48) & 0xFFFF)) && !ctrl_block_maybe(s_lo);
+    return (uint16_t)crc == rev16((uint32_t)((s_hi >> 48) & 0xFFFF)) && (kAnyPattern || !ctrl_block_maybe(s_lo));
+}
+
+/* ... as a call (general build: its frame loop has no registers to spare for the solve's 64-bit arithmetic; the masks go in and the cells come out in registers) */
+struct SolveOut { uint32_t d0, d1, d2, d3, crc_reads; };          /* crc_reads: the CRC calculated | (it is the one read) << 16 */
+#ifndef SDV_EMU
+__device__ __attribute__((noinline)) SolveOut capture_solve_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+#else
+__device__ inline SolveOut capture_solve_call(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+#endif
+{
+    CaptureRaw c; c.a0 = a0; c.a1 = a1; c.a2 = a2; c.a3 = a3; c.b0 = b0; c.b1 = b1; c.b2 = b2; c.b3 = b3;
+    BatchLaneOut o;
+    const bool reads = capture_solve<true>(c, o);
+    SolveOut r; r.d0 = (uint32_t)o.s_lo; r.d1 = (uint32_t)(o.s_lo >> 32); r.d2 = (uint32_t)o.s_hi; r.d3 = (uint32_t)(o.s_hi >> 32);
+    r.crc_reads = (uint32_t)o.crc | (reads ? 0x10000u : 0u);
+    return r;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -2574,6 +2676,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     K1_T(t_begin);
     V2D v; Line wl;
     v2d_stage_state_in(a, lds, f);
+    if (a.skip && uniu(a.skip[f])) { v2d_relink(a, lds, f); return; }
     v2d_load_state(v, lds, v2d_state_in(lds), a);
     const uint32_t frame_no = a.first_frame_no + (uint32_t)f;
     const uint8_t *frame = a.luma + (size_t)f * a.frame_stride;
@@ -2587,6 +2690,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
     lc.klo = (lane_id() < 16) ? c_crc.klo[lane_id() & 15] : 0ull;
     lc.khi = (lane_id() < 16) ? c_crc.khi[lane_id() & 15] : 0ull;
     const int lane = lane_id();
+    /* a pass that meets the last one (TcSnap, above): general kernel only.  (A frame this kernel has decoded is not given to the lean kernel again within the
+     * call - engine.inc, hard[] - so nothing else writes the frame's records between two passes of this kernel.) */
+    bool tc_on = false, tc_met = false; uint32_t tc_prev = 0, tc_prev_n = 0; int tc_w = 0, tc_wbuf = 0;
+    TcSnap *tc_wr = nullptr; const TcSnap *tc_rd = nullptr; const uint32_t *tc_rd_keys = nullptr;
+    uint32_t tc_my_pos = TC_POS_NONE;       /* lane i: the line entry i of the last pass stands ahead of */
 
     v2d_begin_frame(v, a, lds);
     if (frame_is_empty(a, f)) {
@@ -2648,6 +2756,21 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
         return;
     }
     if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
+    if (!kLean && a.tc_hdr) {
+        tc_on = true;
+        tc_prev = uniu(a.tc_hdr[2 * f]); tc_prev_n = uniu(a.tc_hdr[2 * f + 1]);
+        if (tc_prev > 2u || tc_prev_n > (uint32_t)TC_FINAL) tc_prev = 0;
+        tc_wbuf = tc_prev == 1u ? 1 : 0;         /* this pass writes the other set: the last pass's is read while this one goes */
+        tc_wr = a.tc_snaps + ((size_t)f * 2u + (size_t)tc_wbuf) * TC_ENTRIES;
+        if (tc_prev) {
+            tc_rd = a.tc_snaps + ((size_t)f * 2u + (size_t)(tc_prev - 1u)) * TC_ENTRIES;
+            tc_my_pos = lane < (int)tc_prev_n ? (tc_rd[lane].d[18] & 0xFFFFu) : (uint32_t)TC_POS_NONE;
+            tc_rd_keys = (tc_prev == 2u ? a.tc_keys : a.scratch) + (size_t)f * 2u * (size_t)a.height;
+        }
+        if (tc_wbuf) { fv_keys = a.tc_keys + (size_t)f * 2u * (size_t)a.height; fi_keys = fv_keys + a.height; }
+        SDV_WAVE_SYNC();
+        if (lane == 0) a.tc_hdr[2 * f] = 0;     /* what this pass leaves counts only once it has ended complete (below) */
+    }
     /* decode order of VideoInFFMPEG::spliceFrame (vin_ffmpeg.cpp:281-347): field 0 = rows 0,2,4.., field 1 = rows 1,3,5.. */
     const int n_field[2] = { (a.height + 1) / 2, a.height / 2 };
     RowPrefetch pf;
@@ -2833,10 +2956,80 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
      * batches take one line a turn and walk the ladder on the staged row themselves (phase B books any rung); eight lines in a row on the first
      * rung bring the fast loop back. */
     bool sticky_rung = false; int first_rung_run = 0;
-    for (int field = start_field; field < 2 && !stop_frame; field++) {
+    int calm_lines = 0;         /* lines taken by batches since the last line that went through the general path */
+    int rb_lines = 16;          /* lines the next batch of that kind takes on: a batch decodes all of its lines before it knows where it ends, so a tape whose lines also fail
+                                 * now and then (every one ends a batch) would decode most lines twice or more with batches of 64 - doubled by every batch that went through */
+    int rung_hint = 0;          /* while sticky: the shift stage (at hysteresis depth 0) the last line taken on its own read at, 0 when it needed a deeper hysteresis */
+    /* ahead of line `pos`: leave a snapshot; has the last complete pass stood here with the same state?  Then the rest of the frame is its - see TcSnap. */
+    auto tc_point = [&](uint32_t pos) -> bool {
+        if (!tc_on) return false;
+        if (tc_w < TC_FINAL) { tc_write(tc_wr + tc_w, v, lds, pos, used_general); tc_w++; }
+        if (!tc_prev) return false;
+        const uint64_t at_m = __ballot(tc_my_pos == pos);
+        if (at_m == 0ull) return false;
+        const int r = __ffsll((unsigned long long)at_m) - 1;
+        const uint32_t theirs = lane < TC_SNAP_DWORDS ? tc_rd[r].d[lane < TC_SNAP_DWORDS ? lane : 0] : 0u;
+        const uint32_t mine = tc_dword(v, lds, lane < TC_USED_DWORDS ? lane : 0, pos, used_general);
+#if defined(SDV_EMU) && defined(SDV_DEV_AIDS)
+        if (getenv("SDV_TC_DEBUG")) {
+            const uint64_t dm = __ballot(lane < TC_CMP_DWORDS && mine != theirs);
+            if (lane == 0) fprintf(stderr, "[tc] frame %d pos %u: differing dwords %05llx%s\n", f, pos, (unsigned long long)dm, dm ? "" : "  -> met");
+            if (dm && ((dm >> lane) & 1)) fprintf(stderr, "[tc]    dword %d: now %08x, last pass %08x\n", lane, mine, theirs);
+        }
+#endif
+        if (__ballot(lane < TC_CMP_DWORDS && mine != theirs) != 0ull) return false;
+        /* met.  The last pass's snapshot here and its final one, staged where every lane can read them (the brightness spread's room) */
+        uint32_t *const stg = lds.hist;
+        SDV_WAVE_SYNC();
+        if (lane < TC_SNAP_DWORDS) { stg[lane] = theirs; stg[TC_SNAP_DWORDS + lane] = tc_rd[TC_FINAL].d[lane]; }
+        SDV_WAVE_SYNC();
+        const TcCounts was = tc_counts(stg), fin = tc_counts(stg + TC_SNAP_DWORDS);
+        /* the coordinate keys of the lines behind: the last pass's, behind this pass's */
+#pragma unroll 1
+        for (int i = was.nfv + lane; i < fin.nfv; i += 64) fv_keys[v.nfv + (i - was.nfv)] = tc_rd_keys[i];
+#pragma unroll 1
+        for (int i = was.nfi + lane; i < fin.nfi; i += 64) fi_keys[v.nfi + (i - was.nfi)] = tc_rd_keys[a.height + i];
+        /* the last pass's later snapshots are this pass's too, with what this pass has counted otherwise up to here (dwords 19 .. 24: two 16-bit counters each) */
+        {
+            const uint32_t d_lo = (mine & 0xFFFFu) - (theirs & 0xFFFFu), d_hi = (mine >> 16) - (theirs >> 16);
+            const bool counted = lane >= 19 && lane < TC_USED_DWORDS;
+#pragma unroll 1
+            for (int e = r + 1; e < (int)tc_prev_n && tc_w < TC_FINAL; e++) {
+                uint32_t x = lane < TC_SNAP_DWORDS ? tc_rd[e].d[lane < TC_SNAP_DWORDS ? lane : 0] : 0u;
+                if (counted) x = (((x & 0xFFFFu) + d_lo) & 0xFFFFu) | ((((x >> 16) + d_hi) & 0xFFFFu) << 16);
+                if (lane == 18 && used_general) x |= 0x10000u;
+                if (lane < TC_USED_DWORDS) tc_wr[tc_w].d[lane] = x;
+                tc_w++;
+            }
+        }
+        /* the frame's counters at its end ... */
+        v.nfv += fin.nfv - was.nfv; v.nfi += fin.nfi - was.nfi;
+        if (fin.q[0] > v.q_line_length) v.q_line_length = fin.q[0];          /* (the line length is noted, not counted: 0 or the width) */
+        v.q_odd = (uint16_t)(v.q_odd + fin.q[1] - was.q[1]); v.q_even = (uint16_t)(v.q_even + fin.q[2] - was.q[2]);
+        v.q_pcm_odd = (uint16_t)(v.q_pcm_odd + fin.q[3] - was.q[3]); v.q_pcm_even = (uint16_t)(v.q_pcm_even + fin.q[4] - was.q[4]);
+        v.q_bad_odd = (uint16_t)(v.q_bad_odd + fin.q[5] - was.q[5]); v.q_bad_even = (uint16_t)(v.q_bad_even + fin.q[6] - was.q[6]);
+        v.q_dup_odd = (uint16_t)(v.q_dup_odd + fin.q[7] - was.q[7]); v.q_dup_even = (uint16_t)(v.q_dup_even + fin.q[8] - was.q[8]);
+        used_general = used_general || fin.used_general;
+        /* ... and its state there (the frame's start coordinates do not change within a frame, the histories of frames are this pass's own) */
+        const uint32_t *const fs = stg + TC_SNAP_DWORDS;
+        v.n_last = (int)((fs[16] >> 8) & 0xFFu); v.field_state = (uint8_t)(fs[16] & 0xFFu);
+        SDV_WAVE_SYNC();
+        if (lane < COORD_HISTORY_DEPTH) lds.lv_keys[lane] = fs[lane];
+        SDV_WAVE_SYNC();
+        for (int i = 0; i < 4; i++) { v.last_words[2 * i] = (uint16_t)fs[9 + i]; v.last_words[2 * i + 1] = (uint16_t)(fs[9 + i] >> 16); }
+        v.bin.in_coord.start = (int16_t)(uint16_t)fs[13]; v.bin.in_coord.stop = (int16_t)(uint16_t)(fs[13] >> 16);
+        v.bin.in_black = (uint8_t)fs[15]; v.bin.in_white = (uint8_t)(fs[15] >> 8); v.bin.in_ref = (uint8_t)(fs[15] >> 16);
+        v.bin.in_coord.doubled = ((fs[15] >> 24) & 1u) != 0; v.bin.do_ref_lvl_sweep = ((fs[15] >> 24) & 2u) != 0;
+        v2d_make_uniform(v);
+        if (lane == 0 && a.memo_count) atomicAdd(a.memo_count + 1, 1);      /* (sdv_run_info::frames_met) */
+        return true;
+    };
+    bool tc_due = !kLean && tc_on;          /* the state may have changed since the last look: at the head of the frame, behind every line taken on its own */
+    for (int field = start_field; field < 2 && !stop_frame && !tc_met; field++) {
         const int nl = n_field[field];
         int idx = field == start_field ? start_idx : 0;
-        while (idx < nl && !stop_frame) {
+        while (idx < nl && !stop_frame && !tc_met) {
+            if (!kLean && tc_due) { tc_due = false; if (tc_point((uint32_t)(field * 1024 + idx))) { tc_met = true; break; } }
             bool staged = false, batch_gave_way = false;
             /* the batch loop is the 16-byte-vector, single-vector-per-lane case (rows aligned, width a multiple of 16 up to 1024:
              * SD video); everything else takes the sequential path below */
@@ -2854,7 +3047,97 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     if (field == 0 && (k - nl) < n_field[1]) return frame + (size_t)(2 * (k - nl) + 1) * a.row_stride;
                     return frame;
                 };
-                if (SDV_BATCH_LINES > 1 && !sticky_rung) {
+                /* A tape that sits a few pixels beside the coordinates the binarizer holds reads every line on the same later shift stage, and the coordinates
+                 * stay as they are (a line that reads hands its coordinates on).  Taking such lines one a turn through the ladder of reads cost 2.2 us a line - a
+                 * chain of dependent steps per rung, 10 000 such frames 2.7 ms against 0.7 ms on the first rung.  Here a batch is taken the capture's way: per
+                 * line the comparison masks of the shift stages 0 .. rung_hint (hysteresis depth 0) are parked in the lane that owns the line, then every lane
+                 * solves its own line stage by stage; the first stage whose CRC holds is the line's (binarizer.cpp:7769-7954: the first pair that reads
+                 * wins).  A line that reads on none of them ends the batch and takes the sequential path with the whole ladder. */
+                /* (general build: only on a stretch of the frame that reads - 48 lines since the last one through the general path.  On a tape with damage every
+                 * few dozen lines the stretches are short, lines that read on a later stage are single events there, and taking every line of the next batch
+                 * through all the stages for them cost the C3 tape a fifth of its speed; the frames this build decodes behind a jump of the window - general
+                 * path on their first lines, then 480 lines on the stage the new coordinates put them on - are the ones it is here for.) */
+                if ((kLean || calm_lines >= 48) && sticky_rung && rung_hint >= 1 && rung_hint <= SHIFT_STAGES_MAX && rung_hint <= (int)v.bin.in_max_shift) {
+                    const int n_rungs = rung_hint + 1;
+                    /* (the masks wait in LDS, eight words per line and stage, behind the staged row - up to the end of the sweep table's room, which nothing holds
+                     * anything in across a batch; kept in registers like the capture's they were 40 registers the lean build does not have) */
+                    enum { RB_OFS = 1024, RB_SLOTS = (REC_STAGE_OFS + REC_STAGE_BYTES - RB_OFS) / 32 };
+                    static_assert(RB_OFS + RB_SLOTS * 32 <= offsetof(WaveLds, crc_stats), "the parked masks end in front of the histories");
+                    uint4 *const rb = (uint4 *)((uint8_t *)&lds + RB_OFS);          /* [line][stage][2] */
+                    if (nb > RB_SLOTS / n_rungs) nb = RB_SLOTS / n_rungs;
+                    if (nb > rb_lines) nb = rb_lines;
+                    const int32_t x_hi_lim = a.width - 2;          /* fast_decode: clamped to [pixel_start, pixel_stop - 1] */
+                    for (int jj = 0; jj < nb; jj++) {
+                        SDV_WAVE_SYNC();
+                        ((uint4 *)lds.px)[lane] = pf.v0;
+                        SDV_WAVE_SYNC();
+                        {   /* the next row in decode order (as the one-line loop below) */
+                            const int k = idx + jj + 1;
+                            if (pf.nq > 0) {
+                                pf.row = pf.rowq[0]; pf.v0 = pf.vq[0];
+#pragma unroll
+                                for (int u = 0; u + 1 < SDV_ROWQ; u++) { pf.rowq[u] = pf.rowq[u + 1]; pf.vq[u] = pf.vq[u + 1]; }
+                                pf.nq--;
+                            } else { pf.row = row_in_order(k); pf.v0 = ((const uint4 *)pf.row)[pf.i0]; }
+                        }
+                        uint8_t p0[SHIFT_STAGES_MAX + 1], p1[SHIFT_STAGES_MAX + 1];
+#pragma unroll
+                        for (int r = 0; r <= SHIFT_STAGES_MAX; r++) {       /* all reads of the row first */
+                            const int32_t sh = shift_of_stage(r);
+                            int32_t xa = geo.vp0 + sh, xb = geo.vp1 + sh;
+                            xa = xa < 0 ? 0 : (xa > x_hi_lim ? x_hi_lim : xa); xb = xb < 0 ? 0 : (xb > x_hi_lim ? x_hi_lim : xb);
+                            p0[r] = r < n_rungs ? lds.px[xa] : (uint8_t)0; p1[r] = r < n_rungs ? lds.px[xb] : (uint8_t)0;
+                        }
+#pragma unroll
+                        for (int r = 0; r <= SHIFT_STAGES_MAX; r++)
+                            if (r < n_rungs) {
+                                const uint64_t a_lo = __ballot(p0[r] > pre.ref_low), a_hi = __ballot(p1[r] > pre.ref_low);
+                                const uint64_t b_lo = __ballot(p0[r] >= pre.ref_high), b_hi = __ballot(p1[r] >= pre.ref_high);
+                                if (lane == 0) {
+                                    uint4 *const d = rb + (size_t)(jj * n_rungs + r) * 2u;
+                                    d[0] = uint4{(uint32_t)a_lo, (uint32_t)(a_lo >> 32), (uint32_t)a_hi, (uint32_t)(a_hi >> 32)};
+                                    d[1] = uint4{(uint32_t)b_lo, (uint32_t)(b_lo >> 32), (uint32_t)b_hi, (uint32_t)(b_hi >> 32)};
+                                }
+                            }
+                    }
+                    SDV_WAVE_SYNC();
+                    int my_rung = -1; BatchLaneOut mine; mine.s_lo = mine.s_hi = 0; mine.crc = 0;
+                    {
+                        const uint4 *const my = rb + (size_t)((lane < nb ? lane : 0) * n_rungs) * 2u;
+#pragma unroll 1
+                        for (int r = 0; r < n_rungs; r++) {
+                            const uint4 ma = my[2 * r], mb = my[2 * r + 1];
+                            BatchLaneOut o; bool reads;
+                            if (kLean) {
+                                CaptureRaw c; c.a0 = ma.x; c.a1 = ma.y; c.a2 = ma.z; c.a3 = ma.w; c.b0 = mb.x; c.b1 = mb.y; c.b2 = mb.z; c.b3 = mb.w;
+                                reads = capture_solve<true>(c, o);
+                            } else {        /* (the general build lives at the edge of its register budget: inlined, the solve cost it 48 more spilled registers and the damaged tapes a quarter of their speed) */
+                                const SolveOut so = capture_solve_call(ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w);
+                                o.s_lo = (uint64_t)so.d0 | ((uint64_t)so.d1 << 32); o.s_hi = (uint64_t)so.d2 | ((uint64_t)so.d3 << 32); o.crc = (uint16_t)so.crc_reads;
+                                reads = (so.crc_reads & 0x10000u) != 0;
+                            }
+                            if (my_rung < 0 && reads) { my_rung = r; mine = o; }
+                        }
+                    }
+                    SDV_WAVE_SYNC();            /* (the room is batch_finish's record stage next) */
+                    const bool taken = my_rung >= 0 && !ctrl_block_maybe(mine.s_lo);
+                    const uint64_t taken_m = __ballot(taken || lane >= nb);
+                    const int n_ok = taken_m == ~0ull ? nb : (__ffsll((unsigned long long)~taken_m) - 1);
+                    bl.d0 = (uint32_t)mine.s_lo; bl.d1 = (uint32_t)(mine.s_lo >> 32); bl.d2 = (uint32_t)mine.s_hi; bl.d3 = (uint32_t)(mine.s_hi >> 32);
+                    bl.meta = (uint32_t)mine.crc | ((uint32_t)(my_rung < 0 ? 0 : my_rung) << 20);
+                    j = n_ok;
+#if defined(SDV_EMU) && defined(SDV_DEV_AIDS)
+                    if (lane == 0 && getenv("SDV_RB_DEBUG")) fprintf(stderr, "[rb] frame %d field %d idx %d: %d of %d lines taken on %d stages (%s)\n", f, field, idx, n_ok, nb, n_rungs, kLean ? "lean" : "general");
+#endif
+                    {   /* the stage the lines taken needed at most: the next batch tries no further; a batch of first-stage lines ends the sticky mode */
+                        const uint32_t top = wave_max_u32(lane < n_ok && my_rung > 0 ? (uint32_t)my_rung : 0u);
+                        if (n_ok >= 8 && top == 0u) { sticky_rung = false; first_rung_run = 0; }
+                        else if (n_ok >= 8 && (int)top < rung_hint) rung_hint = (int)top;
+                    }
+                    if (n_ok < nb) { redo = true; pf.nq = 0; row_prefetch(pf, row_in_order(idx + n_ok), a.width); rb_lines = 16; }
+                    else if (rb_lines < 64) rb_lines *= 2;
+                }
+                if (SDV_BATCH_LINES > 1 && !sticky_rung && !redo && j == 0) {
                     constexpr int NLA = SDV_ROWQ + 1 + (SDV_BATCH_LINES > 1 ? SDV_BATCH_LINES : 2);
                     const uint8_t *after[NLA];                  /* the rows that follow this field in decode order */
 #pragma unroll
@@ -2963,7 +3246,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     batch_finish(a, lds, v, bl, j, frame_no, (uint16_t)(field + 1 + 2 * idx), fv_keys, rec);
                     K1_T(t_fin);
                     K1_ADD(2, t_loop, t_fin);
-                    rec += j; idx += j;
+                    rec += j; idx += j; calm_lines += j;
                 }
                 if (j == nb) continue;
                 staged = !redo;                                 /* line idx sits in LDS and needs the sequential path */
@@ -2982,10 +3265,14 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
             K1_T(t_fl0);
             K1_ADD(21, t_st0, t_fl0);
             bool ladder_failed = false;
-            bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed);
+            int line_rung = -1;
+            bool took_fast = fast_line<false>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &ladder_failed, nullptr, &line_rung);
             if (!kLean && !took_fast && !ladder_failed) { bool lf2; took_fast = fast_line<true>(a, lds, v, geo, lc, frame_no, line_num, fv_keys, rec, &lf2, a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr); }
             K1_T(t_fl1);
-            if (took_fast && batch_gave_way && !sticky_rung) { sticky_rung = true; first_rung_run = 0; }      /* (a line the batch ended on, read by the ladder) */
+            if (took_fast && batch_gave_way) {                  /* (a line the batch ended on, read by the ladder) */
+                if (!sticky_rung) { sticky_rung = true; first_rung_run = 0; }
+                rung_hint = line_rung > 0 ? line_rung : 0;
+            }
             if (!took_fast) K1_ADD(14, t_fl0, t_fl1);
             if (!kLean && took_fast) { K1_ADD(4, t_fl0, t_fl1); K1_ADD(5, 0ull, 1ull); }
             if (!took_fast) {
@@ -2994,7 +3281,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     return;
                 } else {
                     K1_T(t_sc0);
-                    used_general = true;
+                    used_general = true; calm_lines = 0;
                     SDV_SLOW_CTX(c);
                     SDV_WAVE_SYNC();
                     if (!sc_args_set) { c.a = a; sc_args_set = true; }
@@ -3023,8 +3310,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 }
             }
             rec++; idx++;
+            tc_due = !kLean && tc_on;
         }
-        if (stop_frame) break;
+        if (stop_frame || tc_met) break;
         /* spliceFrame: END_FIELD carries the number the next line of the field would have had */
         line_num = (uint16_t)(field + 1 + 2 * nl);
         v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FIELD);
@@ -3034,6 +3322,14 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
         if (lane == 0) a.flag[f] = VF_ABORTED;
         K1_FLUSH();
         return;
+    }
+    if (tc_met) {               /* the rest of the frame is the last pass's: on to the END_FRAME record */
+        rec = a.recs + rec_base + (f == a.new_file_frame ? 1 : 0) + (size_t)a.height + 2u;
+        line_num = (uint16_t)(2 + 2 * n_field[1]);
+    }
+    if (tc_on && !sweep_pending) {      /* a complete pass: its snapshots are the ones the next pass of this frame looks at */
+        tc_write(tc_wr + TC_FINAL, v, lds, TC_POS_NONE, used_general);
+        if (lane == 0) { a.tc_hdr[2 * f + 1] = (uint32_t)tc_w; a.tc_hdr[2 * f] = (uint32_t)(tc_wbuf + 1); }
     }
     line_num = (uint16_t)(line_num + 2);
     v2d_service_line(v, a, lds, wl, frame_no, line_num, SDV_SRV_END_FRAME);
@@ -3055,7 +3351,8 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
 } // namespace sdv
 
 #ifndef SDV_WAVES_PER_EU
-#define SDV_WAVES_PER_EU 8   /* measured best on MI355X (profiles/r01_tuning_notes.md) */
+#define SDV_WAVES_PER_EU 3   /* round 6: the general build needs 168 registers with the trajectory snapshots; asked for more waves than that allows (8, the setting of rounds 1-5) the compiler
+                              * takes 170 and the kernel drops to two waves per SIMD (8 000 PAL frames with lost lines 2.52 against 2.15 ms, profiles/r06_tuning_notes.md) */
 #endif
 __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv::FrameArgs a)
 {

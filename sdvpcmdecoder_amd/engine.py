@@ -93,7 +93,7 @@ assert PAIR_DTYPE.itemsize == 12 and C.sizeof(StitchSettings) == 16
 
 class RunInfo(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("frames_general", C.c_uint32),
-                ("kernel_ms", C.c_float), ("sweeps", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("sweeps", C.c_uint32), ("frames_met", C.c_uint32)]
 
 
 _lib = None

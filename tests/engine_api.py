@@ -15,7 +15,7 @@ assert STATS_DTYPE.itemsize == 32
 
 class RunInfo(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("rounds", C.c_uint32), ("frames_launched", C.c_uint32), ("frames_general", C.c_uint32),
-                ("kernel_ms", C.c_float), ("sweeps", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("sweeps", C.c_uint32), ("frames_met", C.c_uint32)]
 
 
 class StitchInfo(C.Structure):

@@ -217,6 +217,97 @@ def test_emu_crowd_over_several_windows_is_led_by_the_first_frame_of_each(emu_li
     assert seen[None][0] <= 8, seen
 
 
+@pytest.mark.parametrize("n,height,seed", [(30, 64, 3), (16, 200, 9)])
+def test_emu_a_pass_that_meets_the_last_one_changes_nothing(emu_lib, oracle_lib, monkeypatch, n, height, seed):
+    """A tape with lost lines and inverted cells in every frame: every frame goes through the general kernel several times (guessed state, sweeps settled,
+    predecessor's real state).  A later pass that reaches a line with the state the frame's last complete pass had there ends on it (stc007_device.h, TcSnap):
+    records, frame descriptors and the chain are those of the sequential oracle with and without that short cut, and the short cut is taken."""
+    luma0, _, _ = synth.stc007_frames(n, seed=seed, height=height, noise_sigma=4.0)
+    lum = luma0.copy()
+    lum[:, 16::17, :] = 16
+    flat = lum.reshape(-1, 720)
+    rng = np.random.default_rng(53)
+    rows = np.arange(0, flat.shape[0], 11)
+    xs = 12 + (rng.integers(4, 132, size=rows.shape) * (720 - 24)) // 137
+    for dx in range(5):
+        flat[rows, xs + dx] = np.clip(230 - flat[rows, xs + dx].astype(np.int16), 0, 255).astype(np.uint8)
+    want, want_stats = oracle_binarize(np.concatenate([luma0[:8], lum]), mode=2)
+    met = {}
+    for switch in (None, "SDV_NO_TC"):
+        if switch: monkeypatch.setenv(switch, "1")
+        eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+        emu_lib.sdv_set_mode(eng, 2)
+        a, sa, _ = emu_run(emu_lib, luma0[:8], 2, eng=eng)
+        b, sb, info = emu_run(emu_lib, lum, 2, flags=0, first=9, eng=eng)
+        emu_lib.sdv_engine_destroy(eng)
+        if switch: monkeypatch.delenv(switch)
+        got = np.concatenate([a, b])
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert np.concatenate([sa, sb]).view(np.uint8).tobytes() == want_stats.tobytes()
+        met[switch] = (info.frames_met, info.rounds, info.frames_general)
+    assert met[None][0] > 0 and met["SDV_NO_TC"][0] == 0, met
+    assert met[None][1:] == met["SDV_NO_TC"][1:], met           # (the short cut changes what a pass costs, not what the scheduler sees)
+
+
+@pytest.mark.parametrize("shift", [-2, 3])
+def test_emu_tape_that_sits_on_a_later_shift_stage(emu_lib, oracle_lib, shift):
+    """A tape that moves a few pixels to the side and stays there: the lines go on reading with the coordinates the binarizer holds (a line that reads hands them
+    on), on a later shift stage.  The lean kernel's batches then park the masks of every stage up to that one per line and solve a lane per line
+    (stc007_device.h: rung_hint); a line with a lost cell in between ends such a batch.  Against the sequential oracle."""
+    n = 14
+    luma, _, _ = synth.stc007_frames(n, seed=611, height=96, noise_sigma=4.0)
+    luma = luma.copy()
+    luma[3:] = np.roll(luma[3:], shift, axis=2)
+    luma[7, 30, 200:206] = 255 - luma[7, 30, 200:206]          # a line that reads on no stage, in the middle of a batch
+    luma[9, 51] = 16
+    want, want_stats = oracle_binarize(luma, mode=2)
+    data = want[(want["service_type"] == 0) & (want["frame_number"] > 4)]
+    assert int((data["shift_stage"] != 0).sum()) > len(data) * 8 // 10
+    got, got_stats, info = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+
+
+def test_emu_general_kernel_on_a_later_shift_stage(emu_lib, oracle_lib):
+    """The same regime in the general kernel: frames with a lost line near their top go there, and the 230 lines behind it sit on the later stage - the
+    general build takes its batches the same way once 48 lines in a row have read (stc007_device.h: calm_lines)."""
+    n = 8
+    luma, _, _ = synth.stc007_frames(n, seed=612, height=240, noise_sigma=4.0)
+    luma = luma.copy()
+    luma[2:] = np.roll(luma[2:], -2, axis=2)
+    luma[4, 3] = 16; luma[6, 8] = 16; luma[6, 150] = 16
+    want, want_stats = oracle_binarize(luma, mode=2)
+    got, got_stats, info = emu_run(emu_lib, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+    assert info.frames_general >= 2
+
+
+def test_emu_frames_the_model_gives_their_old_state_are_not_decoded_again(emu_lib, oracle_lib, monkeypatch):
+    """Repair rounds predict every frame behind an anchor that changed again; beyond the reach of the histories most frames get the state they were last decoded
+    from, and the frame kernels only look at what their successor was started from (v2d_relink).  The same records with and without that short cut."""
+    n = 120
+    luma0, _, _ = synth.stc007_frames(n, seed=9, height=24, noise_sigma=3.0)
+    luma = luma0.copy()
+    for f, to in [(25, 6), (50, -7), (90, 5)]:
+        luma[f:] = np.roll(luma0[f:], to, axis=2)
+    want, want_stats = oracle_binarize(np.concatenate([luma0[:20], luma]), mode=2)
+    seen = {}
+    for switch in (None, "SDV_SCHED_NO_SKIP"):
+        if switch: monkeypatch.setenv(switch, "1")
+        eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+        emu_lib.sdv_set_mode(eng, 2)
+        a, sa, _ = emu_run(emu_lib, luma0[:20], 2, eng=eng)
+        b, sb, info = emu_run(emu_lib, luma, 2, flags=0, first=21, eng=eng)
+        emu_lib.sdv_engine_destroy(eng)
+        if switch: monkeypatch.delenv(switch)
+        got = np.concatenate([a, b])
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert np.concatenate([sa, sb]).view(np.uint8).tobytes() == want_stats.tobytes()
+        seen[switch] = (info.rounds, info.frames_launched)
+    assert seen[None] == seen["SDV_SCHED_NO_SKIP"], seen
+
+
 def test_emu_bad_arguments(emu_lib):
     eng = C.c_void_p(emu_lib.sdv_engine_create(0))
     buf = np.zeros((1, 8, 200), np.uint8)

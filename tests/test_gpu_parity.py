@@ -255,3 +255,48 @@ def test_hip_lines_that_read_on_other_rungs_of_the_ladder(torch_cuda, seed, jit)
     got, got_stats, info = gpu_run(torch_cuda, luma, 2)
     assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
     assert got_stats.tobytes() == want_stats.tobytes()
+
+
+def _tape_beside_its_coordinates(n, shift, seed=611, jump_at=None, height=486, noise=4.0):
+    """Frames that play, then the same tape `shift` pixels to the side: every line still reads with the coordinates the binarizer holds, on a later shift stage."""
+    luma, _, _ = synth.stc007_frames(n, seed=seed, height=height, noise_sigma=noise)
+    luma = luma.copy()
+    at = 3 if jump_at is None else jump_at
+    luma[at:] = np.roll(luma[at:], shift, axis=2)
+    return luma
+
+
+@pytest.mark.parametrize("shift", [-2, 3])
+def test_hip_tape_that_sits_on_a_later_shift_stage(torch_cuda, shift):
+    """The whole tape a few pixels beside its coordinates (which stay: a line that reads hands them on): the batches of the lean kernel take the lines with
+    the masks of every shift stage up to the one in use parked per line and a lane per line solving them stage by stage.  Against the sequential oracle."""
+    n = 24
+    luma = _tape_beside_its_coordinates(n, shift)
+    want, want_stats = oracle_binarize(luma, mode=2)
+    data = want[(want["service_type"] == 0) & (want["frame_number"] > 4)]
+    assert int((data["shift_stage"] != 0).sum()) > len(data) * 9 // 10
+    got, got_stats, info = gpu_run(torch_cuda, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
+
+
+def test_hip_window_jumps_far_and_near(torch_cuda):
+    """Jumps of the data window out of reach of the coordinates (crowds of frames given up: a leader per window), jumps within reach (the lines read on another
+    shift stage from then on) and lost lines in between, in calls of uneven length: records, descriptors and the chain equal the sequential oracle's."""
+    from sdvpcmdecoder_amd import Engine
+    n = 150
+    luma0, _, _ = synth.stc007_frames(n, seed=615, height=120, noise_sigma=3.0)
+    luma = luma0.copy()
+    for f, to in [(20, 7), (41, 5), (60, -6), (75, -8), (99, 3), (120, 5)]:
+        luma[f:] = np.roll(luma0[f:], to, axis=2)
+    luma[33, 40] = 16; luma[88, 17::23] = 16
+    want, want_stats = oracle_binarize(luma, mode=2)
+    eng = Engine(0); eng.setBinarizationMode(2)
+    got, st, met, skipped = [], [], 0, 0
+    for lo, hi in [(0, 10), (10, 97), (97, 150)]:
+        r, s_, info = gpu_run(torch_cuda, luma[lo:hi], 2, new_file=lo == 0, first=1 + lo, eng=eng)
+        got.append(r); st.append(s_); met += info.frames_met
+    eng.close()
+    got = np.concatenate(got)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert np.concatenate(st).tobytes() == want_stats.tobytes()

@@ -25,10 +25,10 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 eng.binarize_frames(lum, first_frame_no=1 + 2 * n)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
 i = eng.run_info()
-print(f"{what}: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel, {i.sweeps} sweeps", flush=True)
+print(f"{what}: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel ({i.frames_met} met their last pass), {i.sweeps} sweeps", flush=True)
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     eng.binarize_frames(lum, first_frame_no=1 + (3 + rep) * n)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     i = eng.run_info()
-    print(f"  again: {dt:.2f} ms wall, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel, {i.sweeps} sweeps -> {n / dt * 1e3:.0f} frames/s", flush=True)
+    print(f"  again: {dt:.2f} ms wall, {i.kernel_ms:.2f} ms kernels, {i.rounds} rounds, {i.frames_launched} frame decodes, {i.frames_general} by the full kernel ({i.frames_met} met their last pass), {i.sweeps} sweeps -> {n / dt * 1e3:.0f} frames/s", flush=True)
