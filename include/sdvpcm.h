@@ -405,6 +405,20 @@ int sdv_saturate_stitch_stats(sdv_engine *e);
 int sdv_stitch_frames(sdv_engine *e, const sdv_line_rec *lines, size_t n_lines, sdv_sample_pair *out_pairs, size_t pairs_cap,
                       size_t *n_pairs, sdv_frame_asm *out_frames, size_t frames_cap, size_t *n_frames, void *stream);
 
+/* ---- STC-007, line by line -------------------------------------------------------------------------------------------
+ * Binarizer::processLine (binarizer.h:361, binarizer.cpp:443-1724) with an STC007Line as output, for n_lines video lines in one call: the per-line contract of
+ * the reference's Binarizer itself (setSource / setOutput / processLine, videotodigital.cpp:834-1003), without the bookkeeping VideoToDigital wraps around it -
+ * a host that keeps the reference's own per-line loop binds this.  Line i = luma + i*row_stride (width bytes), numbered first_line + i*line_step of frame
+ * frame_number.  presets[i] is what the caller had set on its Binarizer before that line (setGoodParameters / setReferenceLevel / setDataCoordinates /
+ * setBWLevels, binarizer.cpp:240-377; all zero or presets == NULL: nothing preset); mode and fine settings are the engine's (sdv_set_mode,
+ * sdv_set_bin_preset); flags: SDV_FLAG_DOUBLED.  The record is the line as processLine leaves it (the duplicate-line mark and the coordinate damper are
+ * VideoToDigital's: sdv_binarize_frames).  Service lines and empty lines carry no pixels and are the caller's to pass through.
+ * Returns SDV_ERR_SHORT_LINE for lines under 137 px (LB_RET_SHORT_LINE), SDV_ERR_BAD_ARG when out_lines (lines_cap records) cannot take n_lines.
+ * Device pointers.  The call returns when the records are complete (the reference-level sweeps of the lines that need one run between two passes over the lines). */
+int sdv_binarize_lines(sdv_engine *e, const uint8_t *luma, size_t row_stride, int width, size_t n_lines,
+                       const sdv_bin_state *presets, uint32_t frame_number, uint16_t first_line, uint16_t line_step,
+                       unsigned flags, sdv_line_rec *out_lines, size_t lines_cap, void *stream);
+
 /* ---- PCM-1 front half: one PCM1Line as Binarizer::processLine leaves it (pcm1line.h:59-146, pcmline.h:137-186) --------- */
 /* 40 bytes.  Record of the oracle and of the reference driver today; the engine's PCM-1 binarize
  * entry will emit the same record. */

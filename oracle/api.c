@@ -76,6 +76,9 @@ void orc_bin_set_state(void *hh, const sdv_bin_state *s)
     orc_binarizer_set_data_coordinates(&h->bin, c);
     orc_binarizer_set_bw_levels(&h->bin, s->in_def_black, s->in_def_white);
 }
+/* ... and the sticky do_ref_lvl_sweep member (no setter in the reference: it stays as the last line left it, binarizer.cpp:1104-1128; read by the level
+ * detection of the next line, :3409): the per-line entry of the engine (sdv_binarize_lines) takes it from the state */
+void orc_bin_set_state_full(void *hh, const sdv_bin_state *s) { orc_bin_set_state(hh, s); ((orc_bin_handle *)hh)->bin.do_ref_lvl_sweep = s->do_ref_lvl_sweep != 0; }
 int orc_bin_process(void *hh, const uint8_t *px, int len, uint32_t frame, uint16_t line, int service, int doubled, int empty,
                     sdv_line_rec *out)
 {

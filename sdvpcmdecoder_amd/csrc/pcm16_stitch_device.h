@@ -1308,10 +1308,15 @@ __device__ inline void choose_body(const FrameArgs16s &a, int lane)
     hist_load(st, *a.state, lane);
     const bool ei = a.cfg.format == SDV_P16_FORMAT_EI;
     bool need_full = false;
+    /* (the picks of the chunk behind the one being decided are on their way while it is: a chunk is a few hundred dependent instructions of one wave, and
+     * with the load at its head every chunk began with a trip to memory - a third of the kernel's 117 us per 1 024 frames) */
+    uint4 nq0 = { 0, 0, 0, 0 }, nq1 = { 0, 0, 0, 0 };
+    if ((uint32_t)lane < a.n_batch) { const uint4 *src = (const uint4 *)&a.pick[lane]; nq0 = src[0]; nq1 = src[1]; }
     for (uint32_t c0 = 0; c0 < a.n_batch; c0 += 64) {
         const uint32_t nc = a.n_batch - c0 < 64 ? a.n_batch - c0 : 64u;
-        uint4 q0 = { 0, 0, 0, 0 }, q1 = { 0, 0, 0, 0 };                /* ok[0], ok[1] | best_pad, sweep_lock, elig, marks */
-        if ((uint32_t)lane < nc) { const uint4 *src = (const uint4 *)&a.pick[c0 + lane]; q0 = src[0]; q1 = src[1]; }
+        const uint4 q0 = nq0, q1 = nq1;                                 /* ok[0], ok[1] | best_pad, sweep_lock, elig, marks */
+        nq0 = uint4{ 0, 0, 0, 0 }; nq1 = uint4{ 0, 0, 0, 0 };
+        if (c0 + 64u + (uint32_t)lane < a.n_batch) { const uint4 *src = (const uint4 *)&a.pick[c0 + 64u + (uint32_t)lane]; nq0 = src[0]; nq1 = src[1]; }
         uint32_t mine = 0;                      /* the Choice16 of frame c0 + lane, as a word */
         /* A tape that plays: the history holds one padding, 65 times over, and every frame's checks pass on it.  Then nothing of what the
          * frames do depends on their order - each locks on that padding (mode 1) and pushes it where it already is - and the 64 frames

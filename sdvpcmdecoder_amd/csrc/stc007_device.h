@@ -3348,6 +3348,60 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
 #endif
 }
 
+/* ---- one line per wave: Binarizer::processLine with an STC007Line as output (sdv_binarize_lines) ------------------------------
+ * What the frame kernels do per line of a frame, without the frame around it: the caller says what its Binarizer had been preset with before the line
+ * (sdv_bin_state), the line comes back as processLine leaves it - before the bookkeeping VideoToDigital adds (duplicate lines, the coordinate damper), which
+ * belongs to the frame entry.  A reference-level sweep is asked for and looked up like in the frame kernel (SweepHook; a list head per line): a line that
+ * waits for one is left undone and decoded again when the engine has settled the round's requests. */
+struct LineArgs7 {
+    const uint8_t *luma; size_t row_stride; int width; uint32_t n_lines;
+    const sdv_bin_state *states;        /* per line, or NULL: nothing preset */
+    uint32_t frame_number; uint16_t first_line, line_step;
+    uint8_t doubled, mode;
+    sdv_bin_preset preset;
+    sdv_line_rec *out;
+    uint8_t *done;                      /* per line: its record is final */
+    struct SweepMemo *memo; int32_t *memo_head; int32_t *memo_count; int32_t memo_cap;
+};
+enum { LINES_PER_MEMO_FRAME = 16384 };  /* (a sweep request names its pixels by frame and row: line i of the call is row i % 16384 of "frame" i / 16384) */
+__device__ inline void stc_line_body(const LineArgs7 &a, WaveLds &lds, uint32_t i)
+{
+    if (uniu(a.done[i])) return;
+    const int lane = lane_id();
+    const uint8_t *row = a.luma + (size_t)i * a.row_stride;
+    RowPrefetch pf;
+    pf.v0 = uint4{0, 0, 0, 0}; pf.v1 = uint4{0, 0, 0, 0};
+    for (int u = 0; u < SDV_ROWQ; u++) { pf.vq[u] = uint4{0, 0, 0, 0}; pf.rowq[u] = row; }
+    pf.nq = 0;
+    pf.vec = ((((uintptr_t)row) | (uintptr_t)a.row_stride) & 15) == 0 && a.width >= 16;
+    { int nvec = a.width >> 4; pf.i0 = lane < nvec ? lane : (nvec > 0 ? nvec - 1 : 0); }
+    row_prefetch(pf, row, a.width);
+    row_commit(lds, pf, a.width);
+    Bin b;
+    b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord); b.do_ref_lvl_sweep = false;
+    if (a.states) {         /* setReferenceLevel, setDataCoordinates, setBWLevels (binarizer.cpp:240-350) */
+        const sdv_bin_state st = a.states[i];
+        b.in_ref = st.in_def_reference;
+        Coords c; c.start = st.in_def_start; c.stop = st.in_def_stop; c.doubled = st.in_def_from_doubled != 0;
+        bin_set_data_coordinates(b, c);
+        bin_set_bw_levels(b, a.preset, st.in_def_black, st.in_def_white);
+        b.do_ref_lvl_sweep = st.do_ref_lvl_sweep != 0;
+    }
+    bin_set_mode(b, a.mode);
+    b.hyst_lim = 0; b.shift_lim = 0;
+    b.line_length = 0; b.scan_start = b.scan_end = 0; b.mark_start_max = 0; b.mark_end_min = 0xFFFF; b.estimated_ppb = 0;
+    b.was_bw_scanned = false; b.vl_doubled = false;
+    SweepHook hook;
+    hook.memo = a.memo; hook.head = a.memo_head; hook.count = a.memo_count; hook.cap = a.memo_cap;
+    hook.frame = (int32_t)(i / (uint32_t)LINES_PER_MEMO_FRAME); hook.row = (uint16_t)(i % (uint32_t)LINES_PER_MEMO_FRAME); hook.line = (int32_t)i;
+    hook.pending = false; hook.bw_slot = nullptr; hook.ladder_failed = false; hook.stop = false;
+    Line out;
+    process_line(b, a.preset, lds, out, a.frame_number, (uint16_t)(a.first_line + i * a.line_step), a.width, a.doubled != 0, hook);
+    if (uni(hook.pending) != 0) return;             /* comes again with the sweep's outcome at hand */
+    emit_record(out, &a.out[i]);
+    if (lane == 0) a.done[i] = 1;
+}
+
 } // namespace sdv
 
 #ifndef SDV_WAVES_PER_EU
@@ -3370,5 +3424,10 @@ __global__ void __launch_bounds__(64, SDV_LEAN_WAVES_PER_EU) sdv_k_stc007_frames
     __shared__ sdv::WaveLds lds;
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<true>(a, lds, f);
+}
+__global__ void __launch_bounds__(64) sdv_k_stc007_lines(sdv::LineArgs7 a)
+{
+    __shared__ sdv::WaveLds lds;
+    for (uint32_t i = blockIdx.x; i < a.n_lines; i += gridDim.x) { sdv::stc_line_body(a, lds, i); __syncthreads(); }
 }
 #endif

@@ -166,6 +166,9 @@ def load_library(path: str | None = None):
     lib.sdv_pcm16x0_binarize_frames.argtypes = lib.sdv_binarize_frames.argtypes
     lib.sdv_pcm16x0_binarize_records.restype = C.c_size_t
     lib.sdv_pcm16x0_binarize_records.argtypes = [C.c_int, C.c_int, C.c_uint]
+    lib.sdv_binarize_lines.restype = C.c_int
+    lib.sdv_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16,
+                                       C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_pcm1_binarize_lines.restype = C.c_int
     lib.sdv_pcm1_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16,
                                             C.c_uint16, C.c_uint, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -651,6 +654,25 @@ class Engine:
             break
         self._check(rc)
         return out_pairs[:npairs.value], out_frames[:nframes.value]
+
+    def binarize_lines(self, luma, presets=None, frame_number: int = 1, first_line: int = 1, line_step: int = 1, doubled: bool = False, out_lines=None, stream=None):
+        """Binarizer::processLine with an STC007Line output for every row of `luma` (torch.uint8 CUDA tensor (n_lines, width), rows contiguous) in one
+        call.  `presets`: None or a torch.uint8 CUDA tensor (n_lines, 10) of sdv_bin_state - what the caller's Binarizer had been given before each line.
+        Returns a torch.uint8 CUDA tensor (n_lines, 48) of sdv_line_rec, the lines as processLine leaves them (no VideoToDigital bookkeeping)."""
+        import torch
+        assert luma.is_cuda and luma.dtype == torch.uint8 and luma.dim() == 2 and luma.stride(1) == 1
+        n, w = luma.shape
+        if presets is not None:
+            assert presets.is_cuda and presets.dtype == torch.uint8 and presets.shape == (n, 10) and presets.is_contiguous()
+        if out_lines is None:
+            out_lines = torch.empty((n, 48), dtype=torch.uint8, device=luma.device)
+        _check_out(out_lines, 48, luma.device, "out_lines")
+        sptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(torch.cuda.current_stream(luma.device).cuda_stream)
+        rc = self.lib.sdv_binarize_lines(self._h, C.c_void_p(luma.data_ptr()), luma.stride(0), w, n,
+                                         None if presets is None else C.c_void_p(presets.data_ptr()), frame_number, first_line, line_step,
+                                         FLAG_DOUBLED if doubled else 0, C.c_void_p(out_lines.data_ptr()), out_lines.shape[0], sptr)
+        self._check(rc)
+        return out_lines[:n]
 
     def pcm1_binarize_lines(self, luma, presets=None, frame_number: int = 1, first_line: int = 1, line_step: int = 1, doubled: bool = False,
                             coord_search: bool = True, out_lines=None, stream=None):
