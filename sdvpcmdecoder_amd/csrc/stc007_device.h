@@ -46,6 +46,9 @@
 #ifndef SDV_CAPTURE_D
 #define SDV_CAPTURE_D 4             /* capture loop: row pairs in flight */
 #endif
+#ifndef SDV_RB_GENERAL
+#define SDV_RB_GENERAL 1            /* the batches of a tape on a later shift stage (rung_hint) in the general build too */
+#endif
 #ifndef SDV_PREFETCH_ITERS
 #define SDV_PREFETCH_ITERS 1         /* multi-line loop: iterations of rows in flight ahead of the one being decoded */
 #endif
@@ -1298,6 +1301,7 @@ namespace sdv {
  * outcome the sweep kernels left for this line (stc007_sweep_device.h); what is done here is what the reference does with the level picked.
  * Without an outcome the line leaves a request and goes on as if the sweep had found nothing: the frame is decoded again once the request is
  * settled, so what is made of the line here never reaches the caller. */
+template <int kWho>        /* (see process_line) */
 __device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &l, SweepHook &hook)
 {
     Coords forced_coords;
@@ -1382,6 +1386,12 @@ __device__ inline void bin_set_mode(Bin &b, uint8_t m)   /* :120-152 */
 /* Binarizer::processLine (binarizer.cpp:443-1724) for a regular (non-service, non-empty) line */
 /* that is already staged in lds.px.  Returns LB_RET_*.                                        */
 /* ======================================================================================== */
+/* kWho: which kernel the copy belongs to (0 the general frame kernel, 1 its build without snapshots, 2 the per-line kernel).  Every kernel has its own copy of the
+ * general path (slow_line<kWho> and what it calls once), for the compiler's sake: a function with two callers is no longer inlined into them - the binarizer,
+ * the line and the sweep hook this one takes by reference then live in scratch memory - and a function shared by kernels of different launch bounds is compiled
+ * for the registers of one of them and paid for by all (seen: a fifth of the general kernel's speed on the damaged tapes; 248 registers and one wave per SIMD
+ * for every kernel that shared the path with a kernel without a bound). */
+template <int kWho>
 __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &lds, Line &out, uint32_t frame_no, uint16_t line_no, int width, bool doubled, SweepHook &hook)
 {
     Coords forced_coords;
@@ -1461,7 +1471,7 @@ __device__ inline int process_line(Bin &b, const sdv_bin_preset &ps, WaveLds &ld
                 }
             }
         } else if (state == STG_REF_SWEEP_RUN) {            /* :1391-1400 */
-            { K1_T(t0_); calc_ref_level_by_sweep(b, ps, lds, out, hook); K1_T(t1_); K1_ADD(12, t0_, t1_); }
+            { K1_T(t0_); calc_ref_level_by_sweep<kWho>(b, ps, lds, out, hook); K1_T(t1_); K1_ADD(12, t0_, t1_); }
             state = STG_READ_PCM;
         } else if (state == STG_READ_PCM) {                 /* :1401-1533 */
             if (coords_valid(forced_coords)) { b.hyst_lim = HYST_DEPTH_SAFE; b.shift_lim = SHIFT_STAGES_MIN; }
@@ -2620,16 +2630,17 @@ __device__ inline void batch_finish(const FrameArgs &a, WaveLds &lds, V2D &v, co
 
 /* General path for one regular line, out of line so that its register appetite (reference sweep, marker
  * searches) does not spill into the hot loop.  State crosses the call in memory. */
-struct SlowCtx { FrameArgs a; V2D v; Line wl; SweepHook hook; };
+struct SlowCtx { FrameArgs a; V2D v; Line wl; SweepHook hook; bool line_only; /* (the per-line kernel: the line as processLine leaves it, none of the worker's bookkeeping) */ };
 
+template <int kWho>
 __device__ __attribute__((noinline)) void slow_line(SlowCtx *c, WaveLds *lds, uint32_t frame_no, uint16_t line_num,
                                                     uint32_t *fv_keys, uint32_t *fi_keys, sdv_line_rec *rec)
 {
     K1_T(t0_);
     bin_set_mode(c->v.bin, c->a.mode);
-    process_line(c->v.bin, c->a.preset, *lds, c->wl, frame_no, line_num, c->a.width, c->a.doubled != 0, c->hook);
+    process_line<kWho>(c->v.bin, c->a.preset, *lds, c->wl, frame_no, line_num, c->a.width, c->a.doubled != 0, c->hook);
     K1_T(t1_);
-    v2d_post_line(c->v, c->a, *lds, c->wl, fv_keys, fi_keys, (line_num % 2) == 0);
+    if (!c->line_only) v2d_post_line(c->v, c->a, *lds, c->wl, fv_keys, fi_keys, (line_num % 2) == 0);
     emit_record(c->wl, rec);
     K1_T(t2_);
     K1_ADD(8, t0_, t2_); K1_ADD(13, t1_, t2_); K1_ADD(15, 0ull, 1ull);
@@ -2664,7 +2675,11 @@ enum { STATE_ABORTED = 0xA5 };       /* (v2d_give_up) */
 #else
 #define SDV_SLOW_CTX(c) SlowCtx &c = *sc
 #endif
-template <bool kLean>
+/* kMeet (general build): with the trajectory snapshots ("a pass that meets the last one", TcSnap) and the batches of a tape on a later shift stage.  Both cost
+ * the general build registers it does not have (168 with 45 of them spilled, against 154 and none): a sixth of its speed on a tape where neither helps - damage in
+ * every few dozen lines that re-tunes the binarizer for good each time (4 % of the decodes meet their last pass).  The engine picks the build by
+ * what the last call showed (engine.inc, plain_general). */
+template <bool kLean, bool kMeet = true>
 __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowCtx *sc = nullptr)
 {
     bool sc_args_set = false;           /* sc->a = a: once per frame */
@@ -2756,7 +2771,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
         return;
     }
     if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
-    if (!kLean && a.tc_hdr) {
+    if (!kLean && kMeet && a.tc_hdr) {
         tc_on = true;
         tc_prev = uniu(a.tc_hdr[2 * f]); tc_prev_n = uniu(a.tc_hdr[2 * f + 1]);
         if (tc_prev > 2u || tc_prev_n > (uint32_t)TC_FINAL) tc_prev = 0;
@@ -3024,12 +3039,12 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
         if (lane == 0 && a.memo_count) atomicAdd(a.memo_count + 1, 1);      /* (sdv_run_info::frames_met) */
         return true;
     };
-    bool tc_due = !kLean && tc_on;          /* the state may have changed since the last look: at the head of the frame, behind every line taken on its own */
+    bool tc_due = !kLean && kMeet && tc_on;          /* the state may have changed since the last look: at the head of the frame, behind every line taken on its own */
     for (int field = start_field; field < 2 && !stop_frame && !tc_met; field++) {
         const int nl = n_field[field];
         int idx = field == start_field ? start_idx : 0;
         while (idx < nl && !stop_frame && !tc_met) {
-            if (!kLean && tc_due) { tc_due = false; if (tc_point((uint32_t)(field * 1024 + idx))) { tc_met = true; break; } }
+            if (!kLean && kMeet && tc_due) { tc_due = false; if (tc_point((uint32_t)(field * 1024 + idx))) { tc_met = true; break; } }
             bool staged = false, batch_gave_way = false;
             /* the batch loop is the 16-byte-vector, single-vector-per-lane case (rows aligned, width a multiple of 16 up to 1024:
              * SD video); everything else takes the sequential path below */
@@ -3057,7 +3072,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                  * few dozen lines the stretches are short, lines that read on a later stage are single events there, and taking every line of the next batch
                  * through all the stages for them cost the C3 tape a fifth of its speed; the frames this build decodes behind a jump of the window - general
                  * path on their first lines, then 480 lines on the stage the new coordinates put them on - are the ones it is here for.) */
-                if ((kLean || calm_lines >= 48) && sticky_rung && rung_hint >= 1 && rung_hint <= SHIFT_STAGES_MAX && rung_hint <= (int)v.bin.in_max_shift) {
+                if ((kLean || (kMeet && SDV_RB_GENERAL && calm_lines >= 48)) && sticky_rung && rung_hint >= 1 && rung_hint <= SHIFT_STAGES_MAX && rung_hint <= (int)v.bin.in_max_shift) {
                     const int n_rungs = rung_hint + 1;
                     /* (the masks wait in LDS, eight words per line and stage, behind the staged row - up to the end of the sweep table's room, which nothing holds
                      * anything in across a batch; kept in registers like the capture's they were 40 registers the lean build does not have) */
@@ -3285,12 +3300,12 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     SDV_SLOW_CTX(c);
                     SDV_WAVE_SYNC();
                     if (!sc_args_set) { c.a = a; sc_args_set = true; }
-                    c.v = v;
+                    c.v = v; c.line_only = false;
                     c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
                     c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.line = f * a.height + (2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
                     c.hook.bw_slot = a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr;
                     SDV_WAVE_SYNC();
-                    slow_line(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
+                    slow_line<(kMeet ? 0 : 1)>(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
 #ifdef SDV_K1_STAMPS
                     n_slow_lines++;
 #endif
@@ -3310,7 +3325,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                 }
             }
             rec++; idx++;
-            tc_due = !kLean && tc_on;
+            tc_due = !kLean && kMeet && tc_on;
         }
         if (stop_frame || tc_met) break;
         /* spliceFrame: END_FIELD carries the number the next line of the field would have had */
@@ -3323,11 +3338,11 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
         K1_FLUSH();
         return;
     }
-    if (tc_met) {               /* the rest of the frame is the last pass's: on to the END_FRAME record */
+    if (kMeet && tc_met) {      /* the rest of the frame is the last pass's: on to the END_FRAME record */
         rec = a.recs + rec_base + (f == a.new_file_frame ? 1 : 0) + (size_t)a.height + 2u;
         line_num = (uint16_t)(2 + 2 * n_field[1]);
     }
-    if (tc_on && !sweep_pending) {      /* a complete pass: its snapshots are the ones the next pass of this frame looks at */
+    if (kMeet && tc_on && !sweep_pending) {      /* a complete pass: its snapshots are the ones the next pass of this frame looks at */
         tc_write(tc_wr + TC_FINAL, v, lds, TC_POS_NONE, used_general);
         if (lane == 0) { a.tc_hdr[2 * f + 1] = (uint32_t)tc_w; a.tc_hdr[2 * f] = (uint32_t)(tc_wbuf + 1); }
     }
@@ -3364,7 +3379,7 @@ struct LineArgs7 {
     struct SweepMemo *memo; int32_t *memo_head; int32_t *memo_count; int32_t memo_cap;
 };
 enum { LINES_PER_MEMO_FRAME = 16384 };  /* (a sweep request names its pixels by frame and row: line i of the call is row i % 16384 of "frame" i / 16384) */
-__device__ inline void stc_line_body(const LineArgs7 &a, WaveLds &lds, uint32_t i)
+__device__ inline void stc_line_body(const LineArgs7 &a, WaveLds &lds, SlowCtx *sc, uint32_t i)
 {
     if (uniu(a.done[i])) return;
     const int lane = lane_id();
@@ -3377,13 +3392,21 @@ __device__ inline void stc_line_body(const LineArgs7 &a, WaveLds &lds, uint32_t 
     { int nvec = a.width >> 4; pf.i0 = lane < nvec ? lane : (nvec > 0 ? nvec - 1 : 0); }
     row_prefetch(pf, row, a.width);
     row_commit(lds, pf, a.width);
-    Bin b;
+    /* the general path's context (in LDS, one for the wave - the emulator keeps a copy per lane: SDV_SLOW_CTX) with what the line needs of it */
+#ifdef SDV_EMU
+    SlowCtx c;
+#else
+    SlowCtx &c = *sc;
+#endif
+    SDV_WAVE_SYNC();
+    c.a.width = a.width; c.a.doubled = a.doubled; c.a.mode = a.mode; c.a.preset = a.preset; c.a.m2_format = 0;
+    Bin &b = c.v.bin;
     b.in_black = b.in_white = b.in_ref = 0; coords_clear(b.in_coord); b.do_ref_lvl_sweep = false;
     if (a.states) {         /* setReferenceLevel, setDataCoordinates, setBWLevels (binarizer.cpp:240-350) */
         const sdv_bin_state st = a.states[i];
         b.in_ref = st.in_def_reference;
-        Coords c; c.start = st.in_def_start; c.stop = st.in_def_stop; c.doubled = st.in_def_from_doubled != 0;
-        bin_set_data_coordinates(b, c);
+        Coords cc; cc.start = st.in_def_start; cc.stop = st.in_def_stop; cc.doubled = st.in_def_from_doubled != 0;
+        bin_set_data_coordinates(b, cc);
         bin_set_bw_levels(b, a.preset, st.in_def_black, st.in_def_white);
         b.do_ref_lvl_sweep = st.do_ref_lvl_sweep != 0;
     }
@@ -3391,14 +3414,14 @@ __device__ inline void stc_line_body(const LineArgs7 &a, WaveLds &lds, uint32_t 
     b.hyst_lim = 0; b.shift_lim = 0;
     b.line_length = 0; b.scan_start = b.scan_end = 0; b.mark_start_max = 0; b.mark_end_min = 0xFFFF; b.estimated_ppb = 0;
     b.was_bw_scanned = false; b.vl_doubled = false;
-    SweepHook hook;
-    hook.memo = a.memo; hook.head = a.memo_head; hook.count = a.memo_count; hook.cap = a.memo_cap;
-    hook.frame = (int32_t)(i / (uint32_t)LINES_PER_MEMO_FRAME); hook.row = (uint16_t)(i % (uint32_t)LINES_PER_MEMO_FRAME); hook.line = (int32_t)i;
-    hook.pending = false; hook.bw_slot = nullptr; hook.ladder_failed = false; hook.stop = false;
-    Line out;
-    process_line(b, a.preset, lds, out, a.frame_number, (uint16_t)(a.first_line + i * a.line_step), a.width, a.doubled != 0, hook);
-    if (uni(hook.pending) != 0) return;             /* comes again with the sweep's outcome at hand */
-    emit_record(out, &a.out[i]);
+    c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
+    c.hook.frame = (int32_t)(i / (uint32_t)LINES_PER_MEMO_FRAME); c.hook.row = (uint16_t)(i % (uint32_t)LINES_PER_MEMO_FRAME); c.hook.line = (int32_t)i;
+    c.hook.pending = false; c.hook.bw_slot = nullptr; c.hook.ladder_failed = false; c.hook.stop = false;
+    c.line_only = true;
+    SDV_WAVE_SYNC();
+    slow_line<2>(&c, &lds, a.frame_number, (uint16_t)(a.first_line + i * a.line_step), nullptr, nullptr, &a.out[i]);
+    SDV_WAVE_SYNC();
+    if (uni(c.hook.pending) != 0) return;             /* comes again with the sweep's outcome at hand (the record left now is written over then) */
     if (lane == 0) a.done[i] = 1;
 }
 
@@ -3419,15 +3442,29 @@ __global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_frames(sdv:
 #define SDV_LEAN_WAVES_PER_EU 4   /* 128 registers: the capture holds a field's cells in registers without spilling.  Round 5, one box, ms per 10 000 frames: 0.688 (4) against
                                    * 0.765 (5: 96 registers, 6 of them spilled); the capture itself does not care (round 5's first build: 0.782 with 4 and with 5) */
 #endif
+/* the general build without snapshots and later-stage batches (frame_body, kMeet) */
+#ifndef SDV_PLAIN_WAVES_PER_EU
+#define SDV_PLAIN_WAVES_PER_EU 8    /* (asked for more waves than it can have the compiler settles on fewer registers and no spills: the setting of rounds 1-5 for this build) */
+#endif
+__global__ void __launch_bounds__(64, SDV_PLAIN_WAVES_PER_EU) sdv_k_stc007_frames_plain(sdv::FrameArgs a)
+{
+    __shared__ sdv::WaveLds lds;
+    __shared__ sdv::SlowCtx slow_ctx;
+    int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
+    if (a.frame_list || f < a.frame_hi) sdv::frame_body<false, false>(a, lds, f, &slow_ctx);
+}
 __global__ void __launch_bounds__(64, SDV_LEAN_WAVES_PER_EU) sdv_k_stc007_frames_lean(sdv::FrameArgs a)
 {
     __shared__ sdv::WaveLds lds;
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<true>(a, lds, f);
 }
-__global__ void __launch_bounds__(64) sdv_k_stc007_lines(sdv::LineArgs7 a)
+/* (the bound of the general kernels: the general path is one function for all of them and is given the registers of its most generous caller - which every
+ * caller then has to set aside) */
+__global__ void __launch_bounds__(64, SDV_WAVES_PER_EU) sdv_k_stc007_lines(sdv::LineArgs7 a)
 {
     __shared__ sdv::WaveLds lds;
-    for (uint32_t i = blockIdx.x; i < a.n_lines; i += gridDim.x) { sdv::stc_line_body(a, lds, i); __syncthreads(); }
+    __shared__ sdv::SlowCtx slow_ctx;
+    for (uint32_t i = blockIdx.x; i < a.n_lines; i += gridDim.x) { sdv::stc_line_body(a, lds, &slow_ctx, i); __syncthreads(); }
 }
 #endif

@@ -166,9 +166,10 @@ def load_library(path: str | None = None):
     lib.sdv_pcm16x0_binarize_frames.argtypes = lib.sdv_binarize_frames.argtypes
     lib.sdv_pcm16x0_binarize_records.restype = C.c_size_t
     lib.sdv_pcm16x0_binarize_records.argtypes = [C.c_int, C.c_int, C.c_uint]
-    lib.sdv_binarize_lines.restype = C.c_int
-    lib.sdv_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16,
-                                       C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
+    if hasattr(lib, "sdv_binarize_lines"):      # (SDVPCM_LIB may name a build of an earlier ABI: tuning comparisons across rounds)
+        lib.sdv_binarize_lines.restype = C.c_int
+        lib.sdv_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint16,
+                                           C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.sdv_pcm1_binarize_lines.restype = C.c_int
     lib.sdv_pcm1_binarize_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint16,
                                             C.c_uint16, C.c_uint, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]

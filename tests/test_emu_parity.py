@@ -308,6 +308,34 @@ def test_emu_frames_the_model_gives_their_old_state_are_not_decoded_again(emu_li
     assert seen[None] == seen["SDV_SCHED_NO_SKIP"], seen
 
 
+def test_emu_worn_tape_without_meetings_takes_the_plain_general_kernel(emu_lib, oracle_lib):
+    """A tape with an unreadable cell in every fifth line: every frame goes through the general kernel, and hardly a decode meets the frame's last pass (each
+    damaged line re-tunes the binarizer for good).  The engine sees that in the first call and gives the calls behind it to the build of the general kernel
+    without snapshots (engine.inc, plain_general; stc007_device.h, kMeet) - the records stay the sequential oracle's."""
+    n, h = 12, 96
+    luma0, _, _ = synth.stc007_frames(4 * n, seed=31, height=h, noise_sigma=4.0)
+    lum = luma0.copy()
+    flat = lum.reshape(-1, 720)
+    rng = np.random.default_rng(5)
+    rows = np.arange(3, flat.shape[0], 5)
+    xs = 12 + (rng.integers(4, 132, size=rows.shape) * (720 - 24)) // 137
+    for dx in range(5):
+        flat[rows, xs + dx] = np.clip(230 - flat[rows, xs + dx].astype(np.int16), 0, 255).astype(np.uint8)
+    want, want_stats = oracle_binarize(lum, mode=2)
+    eng = C.c_void_p(emu_lib.sdv_engine_create(0))
+    emu_lib.sdv_set_mode(eng, 2)
+    got, gs, met, general = [], [], [], []
+    for k in range(4):
+        b, sb, info = emu_run(emu_lib, lum[k * n:(k + 1) * n], 2, flags=1 if k == 0 else 0, first=1 + k * n, eng=eng)
+        got.append(b); gs.append(sb); met.append(info.frames_met); general.append(info.frames_general)
+    emu_lib.sdv_engine_destroy(eng)
+    got = np.concatenate(got)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert np.concatenate(gs).view(np.uint8).tobytes() == want_stats.tobytes()
+    assert all(g >= n for g in general), general
+    assert met[1:] == [0, 0, 0], met            # (the build without snapshots meets nothing)
+
+
 def test_emu_bad_arguments(emu_lib):
     eng = C.c_void_p(emu_lib.sdv_engine_create(0))
     buf = np.zeros((1, 8, 200), np.uint8)
