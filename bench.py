@@ -35,7 +35,14 @@ def algorithmic_bytes_per_frame(width, height):
 
 
 HOT_KERNEL = "sdv_k_stc007_frames_lean"
-PMC_PROFILE = os.path.join("profiles", "r04_pmc_%s.json" % HOT_KERNEL)
+def _newest_pmc_profile():
+    """profiles/rNN_pmc_<hot kernel>.json of the latest round that has one (the PMC passes are made once per round, on the sources as committed)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % HOT_KERNEL)))
+    return os.path.relpath(found[-1], ROOT) if found else os.path.join("profiles", "r06_pmc_%s.json" % HOT_KERNEL)
+
+
+PMC_PROFILE = _newest_pmc_profile()
 
 
 def measured_hbm_traffic(frames_per_launch, workload):
@@ -608,16 +615,21 @@ def main():
     # the data window per 10 000 frames - the workloads of tools/dropout_probe.py / tools/jump_probe.py, on the tape `value` was measured on
     damaged = None
     if not args.no_stitch and world == 1:
-        damaged = {"note": "sdv_binarize_frames over the benchmark's tape with damage, continuing stream, wall clock per batch; rounds = launches of the frame kernels "
+        damaged = {"note": "sdv_binarize_frames over the benchmark's tape with damage (16 lost lines / 16 jumps of the data window per 10 000 frames; the whole tape two pixels beside its coordinates; "
+                           "every 97th row of every frame lost), continuing stream, wall clock per batch; rounds = launches of the frame kernels "
                            "until every frame was decoded from its predecessor's real state; frames_launched counts re-decodes; frames_by_full_kernel those that "
                            "needed the kernel with the general path; compare with `value` (clean tape, 1 round); not part of `value`"}
         per = max(1, n // 625)                          # 16 per 10 000 frames
         rng_d = np.random.default_rng(16)
-        for kind in ("lost_lines", "window_jumps"):
+        for kind in ("lost_lines", "window_jumps", "beside_coordinates", "lost_lines_in_every_frame"):
             lum = luma.clone()
             if kind == "lost_lines":
                 for f_ in sorted(rng_d.choice(np.arange(50, n - 50), size=per, replace=False)):
                     lum[int(f_), int(rng_d.integers(40, 440))] = 16
+            elif kind == "beside_coordinates":          # the whole tape two pixels beside the coordinates the binarizer holds: every line reads, on a later shift stage
+                lum = torch.roll(luma, -2, dims=2)
+            elif kind == "lost_lines_in_every_frame":   # every 97th row of every frame lost: every frame through the general kernel, several times
+                lum[:, 96::97, :] = 16
             else:
                 at = 0
                 for f_ in sorted(rng_d.choice(np.arange(50, n - 50), size=per, replace=False)):
@@ -648,7 +660,7 @@ def main():
                     continue
                 d_ms += (time.perf_counter() - t1) * 1e3
                 d_rounds += i_.rounds; d_launched += i_.frames_launched; d_general += i_.frames_general
-            damaged[kind] = {"events_per_step": per, "frames_per_step": n, "ms_per_step": d_ms / k_steps, "frames_per_s": n / (d_ms / k_steps) * 1e3,
+            damaged[kind] = {"events_per_step": per if kind in ("lost_lines", "window_jumps") else None, "frames_per_step": n, "ms_per_step": d_ms / k_steps, "frames_per_s": n / (d_ms / k_steps) * 1e3,
                              "kernel_ms_per_step": d_kms / k_steps, "kernel_ms_from": "a separate warm pass with an event pair around every round (not one of the timed passes)", "rounds_per_step": d_rounds / k_steps, "frames_launched_per_step": d_launched / k_steps,
                              "frames_by_full_kernel_per_step": d_general / k_steps}
             del lum
@@ -1078,6 +1090,8 @@ def main():
                                      pick(out, "pal_stage", "lost_lines_and_flipped_cells", "cpu_baseline", "bit_exact_vs_gpu_on_overlap")],
             "damaged_lost_lines_ms_per_step": pick(out, "damaged_tape", "lost_lines", "ms_per_step"),
             "damaged_window_jumps_ms_per_step": pick(out, "damaged_tape", "window_jumps", "ms_per_step"),
+            "damaged_beside_coordinates_ms_per_step": pick(out, "damaged_tape", "beside_coordinates", "ms_per_step"),
+            "damaged_lost_lines_in_every_frame_ms_per_step": pick(out, "damaged_tape", "lost_lines_in_every_frame", "ms_per_step"),
             "pcm1_frames_ms_per_step": pick(out, "pcm1_frames_stage", "ms_per_step"), "pcm16x0_frames_ms_per_step": pick(out, "pcm16x0_frames_stage", "ms_per_step"),
             "pcm1_stitch_ms_per_step": pick(out, "pcm1_stage", "ms_per_step"),
             "pcm16x0_si_ms_per_step": pick(out, "pcm16x0_stage", "si", "ms_per_step"), "pcm16x0_ei_ms_per_step": pick(out, "pcm16x0_stage", "ei", "ms_per_step"),

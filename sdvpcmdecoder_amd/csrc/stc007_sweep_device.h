@@ -508,7 +508,10 @@ __device__ inline void sweep_pick_body(const SweepArgs &a, int req)
 
 } // namespace sdv
 
-__global__ void __launch_bounds__(64, 4) sdv_k_stc007_sweep_levels(sdv::SweepArgs a)
+#ifndef SDV_SWEEP_WAVES
+#define SDV_SWEEP_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, SDV_SWEEP_WAVES) sdv_k_stc007_sweep_levels(sdv::SweepArgs a)
 {
     __shared__ sdv::SweepLds lds;
     sdv::sweep_levels_body(a, lds, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3));

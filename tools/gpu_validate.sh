@@ -51,10 +51,10 @@ tail -1 $R/gpurun_out/prof_vis.log
 bash $R/tools/gpu_pmc_round3.sh 2>&1 | grep "rc="
 # the damaged-tape kernels (general frame kernel, the two sweep kernels, the histogram carry) on the C3 PAL tape
 bash $R/tools/gpu_pmc_round4.sh 2>&1 | grep "rc="
-# the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r05_profiles/; the raw counter and trace files stay
+# the summaries are made here (same tree, same source hash) and travel back under gpurun_out/r06_profiles/; the raw counter and trace files stay
 # on the box (gpurun only merges 64 MiB back)
-cd $R && python tools/refresh_profiles.py r05 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
-rm -rf gpurun_out/r05_profiles && mkdir -p gpurun_out/r05_profiles && cp profiles/r05_* gpurun_out/r05_profiles/ && rm -f gpurun_out/r05_profiles/*.md gpurun_out/r05_profiles/*.txt   # (the hand-written notes and tables do not come back: a copy from the box would overwrite what was written meanwhile)
+cd $R && python tools/refresh_profiles.py r06 > gpurun_out/refresh_profiles.log 2>&1; echo "refresh rc=$?"
+rm -rf gpurun_out/r06_profiles && mkdir -p gpurun_out/r06_profiles && cp profiles/r06_* gpurun_out/r06_profiles/ && rm -f gpurun_out/r06_profiles/*.md gpurun_out/r06_profiles/*.txt   # (the hand-written notes and tables do not come back: a copy from the box would overwrite what was written meanwhile)
 find gpurun_out -name "*.csv" -size +256k -delete; find gpurun_out -name "*.db" -delete
 du -sh gpurun_out | tail -1
 # scheduler traces of the two damaged tapes (developer build, when one was sent along)
@@ -62,4 +62,4 @@ if [ -f build/variants/dev.so ]; then
   SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/pal_trace.py 2000 both > gpurun_out/pal_trace_both.log 2>&1
   SDVPCM_LIB=build/variants/dev.so SDV_SCHED_TRACE=1 timeout 300 python tools/jump_probe.py 10000 16 > gpurun_out/jump_trace.log 2>&1
 fi
-timeout 1200 python tools/soak.py 16 4000 > gpurun_out/soak_r05.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r05.log
+timeout 1200 python tools/soak.py 12 3000 > gpurun_out/soak_r06.log 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_r06.log

@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdvpcmdecoder_amd.build import source_hash
 kernel = sys.argv[1] if len(sys.argv) > 1 else "sdv_k_stc007_frames_lean"
-out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05_pmc_%s.json" % kernel
+out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r06_pmc_%s.json" % kernel
 prefix = sys.argv[3] if len(sys.argv) > 3 else "pmc"          # directory prefix under gpurun_out/ (pmc1..4, p1pmc1..4)
 res = {}
 for p in tuple(prefix + str(i) for i in (1, 2, 3, 4)):

@@ -3,7 +3,7 @@
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-RND = sys.argv[1] if len(sys.argv) > 1 else 'r05'      # the round the summaries are named for
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r06'      # the round the summaries are named for
 
 
 def newest(pat):
