@@ -160,6 +160,7 @@ struct FrameArgs {
     int32_t *memo_head;             /* ... [n_total * height] the newest entry of a line (-1: none), ... */
     int32_t *memo_count; int32_t memo_cap;   /* ... entries handed out (may run past the capacity: those requests were dropped) */
     unsigned long long *bw_memo;    /* [n_total * height] or NULL: what findBlackWhite found on a line, kept from one decode of a frame to the next (find_black_white) */
+    struct SweepEnt *fat_levels;    /* sdv_k_stc007_frames_fat: 256 entries per workgroup of the launch (stc007_sweep_device.h, fat_sweep) */
     /* the fused entry (sdv_decode_frames), a tape that plays: a frame the whole-frame capture takes from end to end goes straight into the stitcher's field
      * buffers - 32-byte lines in field order, what sdv_k_stitch_analyze would make of the frame's 48-byte records - and leaves a summary instead of records */
     void *direct_fields;            /* the stitcher's field buffers (SLine[segments][2][direct_pitch]), or NULL */
@@ -221,6 +222,14 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 #define SDV_WAVE_SYNC() __syncthreads()
 #else
 #define SDV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+/* ... and where the wave does have to wait for what it has in flight (lanes that read from global memory what other lanes of the wave stored): all that
+ * __syncthreads() is for a workgroup of one wave (the compiler drops the barrier itself there), spelled without the barrier - the same code in the one-wave
+ * kernels, and no rendezvous with the waves beside it in sdv_k_stc007_frames_fat, whose barriers are its protocol (stc007_sweep_device.h, fat_sweep). */
+#ifdef SDV_EMU
+#define SDV_BLOCK_SYNC() __syncthreads()
+#else
+#define SDV_BLOCK_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 #ifndef SDV_OPAQUE
 #ifdef SDV_EMU
@@ -1310,9 +1319,17 @@ __device__ inline void calc_ref_level_by_sweep(Bin &b, const sdv_bin_preset &ps,
     calc_forced_coords(b, ps, forced_coords);
     SweepOutcome o;
     if (!sweep_lookup(hook, l.black, l.white, b.in_coord, o)) {
-        sweep_request(hook, l.black, l.white, b.in_coord);
-        if (b.in_ref < ps.min_ref_lvl) hook.stop = true;
-        o.span1 = o.span2 = SPAN_NOT_FOUND; o.ref_level = 0; o.t_hyst = o.t_shift = 0; o.t_start = o.t_stop = 0;
+        const int slot = sweep_request(hook, l.black, l.white, b.in_coord);
+        bool have = false;
+        if (kWho == 3 && hook.fat && slot >= 0) {       /* sdv_k_stc007_frames_fat: settled by the waves beside this one, now */
+            fat_sweep(hook, slot);
+            have = sweep_lookup(hook, l.black, l.white, b.in_coord, o);
+            if (have) hook.pending = false;
+        }
+        if (!have) {
+            if (b.in_ref < ps.min_ref_lvl) hook.stop = true;
+            o.span1 = o.span2 = SPAN_NOT_FOUND; o.ref_level = 0; o.t_hyst = o.t_shift = 0; o.t_start = o.t_stop = 0;
+        }
     }
     if (o.span1 == SPAN_OK) {
         l.ref_level = o.ref_level;
@@ -1386,7 +1403,7 @@ __device__ inline void bin_set_mode(Bin &b, uint8_t m)   /* :120-152 */
 /* Binarizer::processLine (binarizer.cpp:443-1724) for a regular (non-service, non-empty) line */
 /* that is already staged in lds.px.  Returns LB_RET_*.                                        */
 /* ======================================================================================== */
-/* kWho: which kernel the copy belongs to (0 the general frame kernel, 1 its build without snapshots, 2 the per-line kernel).  Every kernel has its own copy of the
+/* kWho: which kernel the copy belongs to (0 the general frame kernel, 1 its build without snapshots, 2 the per-line kernel, 3 the frame kernel of small rounds).  Every kernel has its own copy of the
  * general path (slow_line<kWho> and what it calls once), for the compiler's sake: a function with two callers is no longer inlined into them - the binarizer,
  * the line and the sweep hook this one takes by reference then live in scratch memory - and a function shared by kernels of different launch bounds is compiled
  * for the registers of one of them and paid for by all (seen: a fifth of the general kernel's speed on the damaged tapes; 248 registers and one wave per SIMD
@@ -1703,7 +1720,7 @@ __device__ inline void v2d_post_line(V2D &v, const FrameArgs &a, WaveLds &lds, L
 __device__ inline void v2d_end_frame(V2D &v, const FrameArgs &a, WaveLds &lds, uint32_t frame_no, const uint32_t *fv_keys, const uint32_t *fi_keys, sdv_frame_stats *out,
                                   bool have_uniform_key = false, uint32_t uniform_key = 0)
 {
-    __syncthreads();            /* the coordinate keys of the frame's lines were stored to global memory by other lanes than the ones that read them below: wait for them */
+    SDV_BLOCK_SYNC();           /* the coordinate keys of the frame's lines were stored to global memory by other lanes than the ones that read them below: wait for them */
     if (v.q_pcm_odd > v.q_odd) v.q_pcm_odd = v.q_odd;
     if (v.q_pcm_even > v.q_even) v.q_pcm_even = v.q_even;
     if (v.q_bad_odd > v.q_odd) v.q_bad_odd = v.q_odd;
@@ -2679,8 +2696,8 @@ enum { STATE_ABORTED = 0xA5 };       /* (v2d_give_up) */
  * the general build registers it does not have (168 with 45 of them spilled, against 154 and none): a sixth of its speed on a tape where neither helps - damage in
  * every few dozen lines that re-tunes the binarizer for good each time (4 % of the decodes meet their last pass).  The engine picks the build by
  * what the last call showed (engine.inc, plain_general). */
-template <bool kLean, bool kMeet = true>
-__device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowCtx *sc = nullptr)
+template <bool kLean, bool kMeet = true, bool kFat = false>
+__device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowCtx *sc = nullptr, FatLds *fat = nullptr, SweepEnt *fat_levels = nullptr)
 {
     bool sc_args_set = false;           /* sc->a = a: once per frame */
     /* every decode of a frame says anew where its lines went (the last one counts): this build at the end of the frame, with everything else it writes - a
@@ -2771,6 +2788,7 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
         return;
     }
     if (f == a.new_file_frame) { v2d_service_line(v, a, lds, wl, frame_no, 0, SDV_SRV_NEW_FILE); emit_record(wl, rec++); }
+    if (kFat && a.tc_hdr && lane == 0) a.tc_hdr[2 * f] = 0;     /* (a pass of the build without snapshots: what the last pass with them left no longer describes the frame's records) */
     if (!kLean && kMeet && a.tc_hdr) {
         tc_on = true;
         tc_prev = uniu(a.tc_hdr[2 * f]); tc_prev_n = uniu(a.tc_hdr[2 * f + 1]);
@@ -3304,8 +3322,9 @@ __device__ inline void frame_body(const FrameArgs &a, WaveLds &lds, int f, SlowC
                     c.hook.memo = a.memo; c.hook.head = a.memo_head; c.hook.count = a.memo_count; c.hook.cap = a.memo_cap;
                     c.hook.frame = f; c.hook.row = (uint16_t)(2 * idx + field); c.hook.line = f * a.height + (2 * idx + field); c.hook.pending = false; c.hook.stop = false; c.hook.ladder_failed = ladder_failed;
                     c.hook.bw_slot = a.bw_memo ? a.bw_memo + ((size_t)f * (size_t)a.height + (size_t)(2 * idx + field)) : nullptr;
+                    c.hook.fat = kFat ? fat : nullptr; c.hook.fa = &c.a; c.hook.fat_levels = fat_levels;
                     SDV_WAVE_SYNC();
-                    slow_line<(kMeet ? 0 : 1)>(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
+                    slow_line<(kFat ? 3 : kMeet ? 0 : 1)>(&c, &lds, frame_no, line_num, fv_keys, fi_keys, rec);
 #ifdef SDV_K1_STAMPS
                     n_slow_lines++;
 #endif
@@ -3452,6 +3471,20 @@ __global__ void __launch_bounds__(64, SDV_PLAIN_WAVES_PER_EU) sdv_k_stc007_frame
     __shared__ sdv::SlowCtx slow_ctx;
     int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
     if (a.frame_list || f < a.frame_hi) sdv::frame_body<false, false>(a, lds, f, &slow_ctx);
+}
+/* ... and of small rounds: the frame's wave and four that settle the sweeps it misses (stc007_sweep_device.h, fat_sweep) */
+__global__ void __launch_bounds__(64 * (1 + sdv::FAT_WORKERS)) sdv_k_stc007_frames_fat(sdv::FrameArgs a)
+{
+    __shared__ sdv::WaveLds lds;
+    __shared__ sdv::SlowCtx slow_ctx;
+    __shared__ sdv::FatLds fat;
+    const int f = a.frame_list ? a.frame_list[blockIdx.x] : a.frame_lo + (int)blockIdx.x;
+    sdv::SweepEnt *const levels = a.fat_levels + (size_t)blockIdx.x * 256u;
+#ifndef SDV_EMU
+    if (threadIdx.x >= 64) { sdv::fat_worker(a, fat, levels, (int)(threadIdx.x >> 6) - 1); return; }
+#endif
+    if (a.frame_list || f < a.frame_hi) sdv::frame_body<false, false, true>(a, lds, f, &slow_ctx, &fat, levels);
+    sdv::fat_exit(fat);
 }
 __global__ void __launch_bounds__(64, SDV_LEAN_WAVES_PER_EU) sdv_k_stc007_frames_lean(sdv::FrameArgs a)
 {

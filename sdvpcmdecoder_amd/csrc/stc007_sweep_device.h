@@ -51,6 +51,10 @@ struct SweepHook {
     unsigned long long *bw_slot;    /* in: the line's slot of FrameArgs::bw_memo, or NULL */
     bool ladder_failed;             /* in: the frame loop tried the ladder of reads with the tuning the line inherits (fast_line), nothing read */
     bool stop;                      /* out: ... by a line that had no reference level preset: everything behind it hangs on what the sweep finds, the pass over the frame ends here */
+    /* sdv_k_stc007_frames_fat only (fat_sweep, below): the waves beside the frame's own settle what it asks for while it waits */
+    struct FatLds *fat;             /* or NULL */
+    const FrameArgs *fa;            /* the launch parameters (what a sweep needs of them: pixels, geometry, settings) */
+    SweepEnt *fat_levels;           /* [256] the workgroup's room for what the levels leave */
 };
 
 /* an entry as eight words (two 16-byte loads), the same in every lane */
@@ -85,18 +89,20 @@ __device__ inline bool sweep_lookup(const SweepHook &h, uint8_t black, uint8_t w
 }
 /* (a request that is on the list already - left by an earlier pass over this frame and not settled, which does not happen, or by this
  * pass - is not entered twice) */
-__device__ inline void sweep_request(SweepHook &h, uint8_t black, uint8_t white, const Coords &in_coord)
+/* returns the entry (wave-uniform), -1 when the pool is full */
+__device__ inline int sweep_request(SweepHook &h, uint8_t black, uint8_t white, const Coords &in_coord)
 {
     h.pending = true;
     const uint32_t k0 = sweep_key_lo(h.row, black, white), k1 = sweep_key_hi(in_coord);
     int idx = uni(h.head[h.line]);
     for (int guard = 0; idx >= 0 && idx < h.cap && guard < (1 << 20); guard++) {
         const SweepMemoWords m = sweep_memo_load(&h.memo[idx]);
-        if (m.w[2] == k0 && m.w[3] == k1) return;
+        if (m.w[2] == k0 && m.w[3] == k1) return idx;
         idx = (int)m.w[1];
     }
+    int slot = 0;
     if (lane_id() == 0) {
-        const int slot = atomicAdd(h.count, 1);
+        slot = atomicAdd(h.count, 1);
         if (slot < h.cap) {         /* a full pool: the count tells the engine, which makes room and decodes the frame again */
             SweepMemo m;
             m.frame = h.frame; m.next = h.head[h.line]; m.row = h.row; m.black = black; m.white = white; m.in_start = in_coord.start; m.in_stop = in_coord.stop;
@@ -106,7 +112,9 @@ __device__ inline void sweep_request(SweepHook &h, uint8_t black, uint8_t white,
             h.head[h.line] = slot;
         }
     }
-    __syncthreads();
+    SDV_BLOCK_SYNC();
+    slot = uni(slot);
+    return slot < h.cap ? slot : -1;
 }
 
 /* ---- launch parameters of the two sweep kernels ------------------------------------------------ */
@@ -276,10 +284,10 @@ __device__ inline void sweep_stage_row(SweepLds &lds, const SweepArgs &a, const 
 {
     const uint8_t *row = a.luma + (size_t)uni(m.frame) * a.frame_stride + (size_t)uni(m.row) * a.row_stride;
     const int lane = lane_id();
-    __syncthreads();
+    SDV_BLOCK_SYNC();
     if (((((uintptr_t)row) | (uintptr_t)a.width) & 15) == 0) { for (int i = lane; i < (a.width >> 4); i += 64) ((uint4 *)lds.px)[i] = ((const uint4 *)row)[i]; }
     else for (int i = lane; i < a.width; i += 64) lds.px[i] = row[i];
-    __syncthreads();
+    SDV_BLOCK_SYNC();
 }
 
 __device__ inline void sweep_levels_body(const SweepArgs &a, SweepLds &lds, int req, int group)
@@ -326,7 +334,7 @@ __device__ inline void sweep_levels_body(const SweepArgs &a, SweepLds &lds, int 
                     if (ti < n_t) { gs[w] = __brev(ms); ge[w] = __brev(me); }
                 }
             }
-            __syncthreads();
+            SDV_BLOCK_SYNC();
             if (active) {
                 const uint64_t *H = lds.g_start[lvl - t_lo];
                 int ed_start = 0;
@@ -504,6 +512,60 @@ __device__ inline void sweep_pick_body(const SweepArgs &a, int req)
         m.t_start = (int16_t)(tc & 0xFFFF); m.t_stop = (int16_t)(tc >> 16);
         m.state = SWEEP_SETTLED;
     }
+}
+
+/* ---- the frame kernel of small rounds: a sweep settled while its frame waits ------------------------------ */
+/* A round of a few frames is as long as one frame takes: the machine stands idle around them, and a frame that misses a sweep costs a round of its own to be
+ * decoded again with the outcome.  sdv_k_stc007_frames_fat gives the frame's wave four more: they wait at the workgroup's barrier, and when the frame misses
+ * a sweep they settle it - a wave per 64 levels, then the first of them the pick, exactly what the two sweep kernels do with a request - while the frame's wave
+ * waits at the barrier in turn; it then goes on with the outcome, its pass is complete.  Barriers are the protocol (three per sweep, one at the end): the
+ * frame's wave and the sweep bodies do not use the workgroup barrier for anything else (SDV_BLOCK_SYNC, SDV_WAVE_SYNC).  [The emulator runs one wave per
+ * workgroup: the frame's wave does the work of the four itself.] */
+enum { FAT_RUN = 1, FAT_EXIT = 2, FAT_WORKERS = 4 };
+struct FatLds { SweepLds sw[FAT_WORKERS]; int32_t cmd, slot; };
+__device__ inline SweepArgs fat_sweep_args(const FrameArgs &a, SweepEnt *levels, int slot)
+{
+    SweepArgs sa;
+    sa.luma = a.luma; sa.frame_stride = a.frame_stride; sa.row_stride = a.row_stride; sa.width = a.width;
+    sa.doubled = a.doubled; sa.mode = a.mode; sa.preset = a.preset;
+    sa.memo = a.memo; sa.first = slot; sa.count = 1; sa.levels = levels;
+    return sa;
+}
+/* the frame's wave: entry `slot` of the pool is settled when this returns */
+__device__ inline void fat_sweep(SweepHook &h, int slot)
+{
+#ifdef SDV_EMU
+    static SweepLds emu_lds;
+    const SweepArgs sa = fat_sweep_args(*h.fa, h.fat_levels, slot);
+    for (int g = 0; g < 4; g++) sweep_levels_body(sa, emu_lds, 0, g);
+    SDV_BLOCK_SYNC();
+    sweep_pick_body(sa, 0);
+    SDV_BLOCK_SYNC();
+#else
+    if (lane_id() == 0) { h.fat->slot = slot; h.fat->cmd = FAT_RUN; }
+    __syncthreads();            /* the four take it from here */
+    __syncthreads();            /* ... the levels are done */
+    __syncthreads();            /* ... the pick is done: the entry holds the outcome */
+#endif
+}
+#ifndef SDV_EMU
+__device__ inline void fat_worker(const FrameArgs &a, FatLds &fat, SweepEnt *levels, int w)
+{
+    for (;;) {
+        __syncthreads();
+        if (uni(fat.cmd) == FAT_EXIT) break;
+        const SweepArgs sa = fat_sweep_args(a, levels, uni(fat.slot));
+        sweep_levels_body(sa, fat.sw[w], 0, w);
+        __syncthreads();
+        if (w == 0) sweep_pick_body(sa, 0);
+        __syncthreads();
+    }
+}
+#endif
+__device__ inline void fat_exit(FatLds &fat)
+{
+    if (lane_id() == 0) fat.cmd = FAT_EXIT;
+    __syncthreads();
 }
 
 } // namespace sdv

@@ -233,6 +233,7 @@ def test_emu_a_pass_that_meets_the_last_one_changes_nothing(emu_lib, oracle_lib,
         flat[rows, xs + dx] = np.clip(230 - flat[rows, xs + dx].astype(np.int16), 0, 255).astype(np.uint8)
     want, want_stats = oracle_binarize(np.concatenate([luma0[:8], lum]), mode=2)
     met = {}
+    monkeypatch.setenv("SDV_NO_FAT", "1")       # (rounds of a few frames take the build without snapshots that settles its sweeps itself: not what is looked at here)
     for switch in (None, "SDV_NO_TC"):
         if switch: monkeypatch.setenv(switch, "1")
         eng = C.c_void_p(emu_lib.sdv_engine_create(0))
@@ -247,6 +248,27 @@ def test_emu_a_pass_that_meets_the_last_one_changes_nothing(emu_lib, oracle_lib,
         met[switch] = (info.frames_met, info.rounds, info.frames_general)
     assert met[None][0] > 0 and met["SDV_NO_TC"][0] == 0, met
     assert met[None][1:] == met["SDV_NO_TC"][1:], met           # (the short cut changes what a pass costs, not what the scheduler sees)
+
+
+def test_emu_small_rounds_settle_their_sweeps_themselves(emu_lib, oracle_lib, monkeypatch):
+    """A round of a few frames goes through sdv_k_stc007_frames_fat: a frame that misses a reference-level sweep has it settled on the spot (by the four waves
+    beside its own on the GPU, by its own wave here) and goes on with the outcome - its pass is complete, no round to decode it again.  Records and frame
+    descriptors are the sequential oracle's either way, and the rounds are fewer."""
+    from test_gpu_parity import _unreadable_cells
+    luma, _, _ = synth.stc007_frames(16, seed=78, noise_sigma=4.0, height=120, lines_per_field=60)
+    luma = _unreadable_cells(luma, every=23)
+    luma[:, 50::31, :] = 16
+    want, want_stats = oracle_binarize(np.ascontiguousarray(luma), mode=2)
+    seen = {}
+    for switch in (None, "SDV_NO_FAT"):
+        if switch: monkeypatch.setenv(switch, "1")
+        got, got_stats, info = emu_run(emu_lib, luma, 2)
+        if switch: monkeypatch.delenv(switch)
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+        seen[switch] = (info.rounds, info.frames_general, info.sweeps)
+    assert seen[None][0] < seen["SDV_NO_FAT"][0] and seen[None][1] < seen["SDV_NO_FAT"][1], seen
+    assert seen[None][2] > 40, seen
 
 
 @pytest.mark.parametrize("shift", [-2, 3])

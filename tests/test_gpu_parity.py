@@ -235,6 +235,20 @@ def test_hip_unreadable_cells_sweep_every_level(torch_cuda, pal):
     assert info.rounds <= 24, info.rounds
 
 
+def test_hip_small_rounds_settle_their_sweeps_themselves(torch_cuda):
+    """Rounds of a few frames run in sdv_k_stc007_frames_fat: the four waves beside a frame's own settle the reference-level sweep it misses while it waits at
+    the workgroup's barrier, and the pass goes on with the outcome (stc007_sweep_device.h, fat_sweep).  Same tape as the emulator's test of that name: bit-exact
+    with the sequential oracle, in the rounds the emulator needs with that kernel (13 without it)."""
+    luma, _, _ = synth.stc007_frames(16, seed=78, noise_sigma=4.0, height=120, lines_per_field=60)
+    luma = _unreadable_cells(luma, every=23)
+    luma[:, 50::31, :] = 16
+    want, want_stats = oracle_binarize(np.ascontiguousarray(luma), mode=2)
+    got, got_stats, info = gpu_run(torch_cuda, luma, 2)
+    assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+    assert got_stats.tobytes() == want_stats.tobytes()
+    assert info.sweeps > 40 and info.rounds <= 10, (info.sweeps, info.rounds)
+
+
 @pytest.mark.parametrize("seed,jit", [(511, 2), (512, 3)])
 def test_hip_lines_that_read_on_other_rungs_of_the_ladder(torch_cuda, seed, jit):
     """A tape whose rows sit a few pixels beside the preset coordinates (every row moved by its own -jit..jit pixels): the lines read on other rungs
