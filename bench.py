@@ -353,6 +353,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # what the timed steps left (looked at below; the legs that follow decode other tapes into the same buffer)
+    timed_host = out_lines[1:1 + 8 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(8, H + 3).copy()
 
     # N > 1, beyond BASELINE's metric: the whole path frames -> PCMSamplePair for ONE tape sharded over the ranks (ShardedDecoder: warm-up,
     # all-gather of the two workers' hand-over states, verify, repair - DESIGN.md section 7), NEW_FILE .. END_FILE, timed as one job
@@ -846,8 +848,7 @@ def main():
         eng.reset_stream()
 
     # correctness of what was timed: all lines decode to the generator's words
-    recs = out_lines[1:1 + nrec].view(-1)  # device bytes
-    host = out_lines[1:1 + 8 * (H + 3)].cpu().numpy().view(LINE_DTYPE).reshape(8, H + 3)
+    host = timed_host
     lines = np.concatenate([host[:, :243], host[:, 244:487]], axis=1)
     f = np.arange(8)[:, None]
     r = np.arange(243)[None, :]
