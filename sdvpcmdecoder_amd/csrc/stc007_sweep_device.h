@@ -130,6 +130,7 @@ struct SweepArgs {
 };
 struct SweepLds {
     alignas(16) uint8_t px[SDV_MAX_WIDTH];
+    uint32_t wplanes[2][8][SWEEP_WINDOW_MAX / 32];      /* the two marker windows as bit planes: [window][bit of the pixel value][32 pixels] */
     uint64_t g_start[88][3];        /* [T - t_lo]: pixel p of the START window >= T, bit p */
     uint64_t g_stop[88][3];         /* ... pixel scan_end - i of the STOP window >= T, bit i */
 };
@@ -374,17 +375,39 @@ __device__ inline void sweep_levels_body(const SweepArgs &a, SweepLds &lds, int 
             /* thresholds the 64 levels can ask for: the level itself and down to 23 below it (never below 1) */
             int t_lo = base - 63 - 23; if (t_lo < 1) t_lo = 1;
             const int n_t = base - t_lo + 1;                /* <= 87 */
-            for (int tb = 0; tb < n_t; tb += 64) {
-                const int ti = tb + lane, T1 = t_lo + ti - 1;
-                uint32_t *gs = (uint32_t *)lds.g_start[ti < 88 ? ti : 0], *ge = (uint32_t *)lds.g_stop[ti < 88 ? ti : 0];
-                for (int w = 0; w < SWEEP_WINDOW_MAX / 32; w++) {
-                    uint32_t ms = 0, me = 0;
-                    for (int i = 0; i < 32; i++) {
-                        const int p = 32 * w + i;
-                        const int vs = p < n_start ? (int)lds.px[p] : 0, ve = p < n_stop ? (int)lds.px[scan_end - p] : 0;
-                        ms = shl1_sign(ms, T1 - vs); me = shl1_sign(me, T1 - ve);
+            /* ... from the bit planes of the two windows (see planes_from_cells): lanes 0 .. 47 turn eight pixels each, then a lane per threshold takes
+             * the carry through the eight planes, 32 pixels at a time (pixel by pixel this was a sixth of the kernel) */
+            if (lane < 2 * (SWEEP_WINDOW_MAX / 8)) {
+                const int win = lane / (SWEEP_WINDOW_MAX / 8), blk = lane % (SWEEP_WINDOW_MAX / 8);
+                uint32_t cx = 0, cy = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int p = 8 * blk + i;
+                    const uint32_t v = win == 0 ? (p < n_start ? (uint32_t)lds.px[p] : 0u) : (p < n_stop ? (uint32_t)lds.px[scan_end - p] : 0u);
+                    if (i < 4) cx |= v << (8 * i); else cy |= v << (8 * (i - 4));
+                }
+                uint32_t lo, hi;
+                transpose8(cx, cy, lo, hi);
+                uint8_t *pl = (uint8_t *)lds.wplanes[win];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { pl[k * (SWEEP_WINDOW_MAX / 8) + blk] = (uint8_t)(lo >> (8 * k)); pl[(4 + k) * (SWEEP_WINDOW_MAX / 8) + blk] = (uint8_t)(hi >> (8 * k)); }
+            }
+            SDV_BLOCK_SYNC();
+            for (int w = 0; w < SWEEP_WINDOW_MAX / 32; w++) {
+                uint32_t ps_[8], pe_[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { ps_[k] = lds.wplanes[0][k][w]; pe_[k] = lds.wplanes[1][k][w]; }
+                for (int tb = 0; tb < n_t; tb += 64) {
+                    const int ti = tb + lane;
+                    const uint32_t nt = ~(uint32_t)(t_lo + ti);         /* (t_lo + ti <= 255 + 23: a threshold above 255 is asked of no lane - ti >= n_t) */
+                    uint32_t cs = 0xFFFFFFFFu, ce = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t m = (uint32_t)0 - ((nt >> k) & 1u);
+                        cs = (m & (ps_[k] | cs)) | (~m & (ps_[k] & cs));
+                        ce = (m & (pe_[k] | ce)) | (~m & (pe_[k] & ce));
                     }
-                    if (ti < n_t) { gs[w] = __brev(ms); ge[w] = __brev(me); }
+                    if (ti < n_t) { ((uint32_t *)lds.g_start[ti])[w] = cs; ((uint32_t *)lds.g_stop[ti])[w] = ce; }
                 }
             }
             SDV_BLOCK_SYNC();
