@@ -17,8 +17,9 @@
  *     and their 24 hysteresis depths can ask for, as bit masks (192 pixels each); the two state machines of searchSTC007Markers
  *     (binarizer.cpp:5275-5595) then jump from edge to edge with find-first-set instead of walking pixel by pixel.  The STOP marker
  *     does not depend on the hysteresis depth: searched once per level, and the START searches only where it was found.
- *   - reads: the lane gathers the 128 cell bytes of a pixel-shift stage once (packed in 32 registers) and takes every hysteresis depth
- *     from them; automaton and CRC as bit arithmetic on the lane's own masks (solve_automaton_lane).
+ *   - reads: the lane gathers the 128 cell bytes of a pixel-shift stage once (packed in 32 registers), turns them into eight bit planes
+ *     (planes_from_cells) and takes every hysteresis depth from those - a comparison with a threshold is a carry through the planes;
+ *     automaton and CRC as bit arithmetic on the lane's own masks (solve_automaton_lane).
  *   - a level started from a zero source-CRC word (see sweep_pick_body) needs no second evaluation: its outcome follows from the
  *     first one's.
  */
