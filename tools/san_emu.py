@@ -32,6 +32,17 @@ lib.sdv_set_mode(eng, 2)
 rc, recs, stats = ea.emu_binarize(lib, eng, luma)
 assert rc == 0 and recs.tobytes() == want.tobytes()
 print("binarize emu ok")
+# small rounds that settle their sweeps themselves (sdv_k_stc007_frames_fat), the sweeps' comparisons on bit planes
+from test_gpu_parity import _unreadable_cells
+luma = _unreadable_cells(synth.stc007_frames(6, seed=78, noise_sigma=4.0, height=120, lines_per_field=60)[0], every=23)
+luma[:, 50::31, :] = 16
+want, wst = oracle_binarize(np.ascontiguousarray(luma), mode=2)
+eng = lib.sdv_engine_create(0)
+lib.sdv_set_mode(eng, 2)
+rc, recs, stats = ea.emu_binarize(lib, eng, luma)
+assert rc == 0 and recs.tobytes() == want.tobytes()
+lib.sdv_engine_destroy(eng)
+print("binarize emu (sweeps in small rounds) ok")
 import ctypes as C
 import pcm1_front_api as pf
 lib.sdv_engine_create.restype = C.c_void_p
