@@ -43,7 +43,7 @@ rows += [
     ("PAL (configs[2]) clean, binarize + stitch", f"{pal['clean']['ms_per_step']:.2f} ms = {pal['clean']['frames_per_s'] / 1e6:.2f} M frames/s for the two entry points one after the other" + (f"; fused entry {pal['clean']['fused_entry_ms_per_step']:.2f} ms = {pal['clean']['frames_per_step'] / pal['clean']['fused_entry_ms_per_step'] / 1e3:.2f} M frames/s" if pal['clean'].get('fused_entry_ms_per_step') else ""), f"{pal['clean']['frames_per_step']} frames of 720 x 576 per step"),
     ("PAL C3 tape (2000 frames; every 97th line lost, a cell inverted on one line in 53)",
      f"binarize {c3['binarize_ms_per_step']:.1f} ms ({2000 / c3['binarize_ms_per_step']:.0f} k frames/s), {c3['binarize_rounds_per_step']:.0f} rounds, {c3['reference_level_sweeps_per_step']:.0f} sweeps; + stitch {c3['stitch_ms_per_step']:.1f} ms → **{c3['frames_per_s'] / 1e3:.1f} k frames/s**",
-     f"CPU (real reference): {c3['cpu_baseline']['value']:.0f} frames/s, bit-exact on the overlap; round 5: the same (what was tried on it this round: `profiles/r06_tuning_notes.md` §2, §5, §7)"),
+     f"CPU (real reference): {c3['cpu_baseline']['value']:.0f} frames/s, bit-exact on the overlap; round 5: 90 k frames/s, 13 + 6 rounds (this round: small rounds that settle their sweeps themselves, sweep comparisons on bit planes - `profiles/r06_tuning_notes.md` §9, §10; what was tried besides: §2, §5, §7)"),
     ("16 lost lines / 16 window jumps per 10 000 frames", f"{dm['lost_lines']['ms_per_step']:.2f} ms ({dm['lost_lines']['rounds_per_step']:.0f} rounds) / {dm['window_jumps']['ms_per_step']:.1f} ms ({dm['window_jumps']['rounds_per_step']:.0f} rounds, {dm['window_jumps']['frames_by_full_kernel_per_step']:.0f} frames through the general kernel)", "kernel time of the rounds: " + f"{dm['lost_lines']['kernel_ms_per_step']:.2f} / {dm['window_jumps']['kernel_ms_per_step']:.2f} ms"),
     ("the whole tape two pixels beside its coordinates / every 97th row of every frame lost", f"{dm['beside_coordinates']['ms_per_step']:.2f} ms ({dm['beside_coordinates']['rounds_per_step']:.0f} rounds) / {dm['lost_lines_in_every_frame']['ms_per_step']:.2f} ms ({dm['lost_lines_in_every_frame']['rounds_per_step']:.0f} rounds, {dm['lost_lines_in_every_frame']['frames_by_full_kernel_per_step']:.0f} frame decodes by the general kernel)", "round 5 (same boxes, other tools): 2.7 ms per 10 000 frames beside their coordinates; `profiles/r06_tuning_notes.md` §2, §3") if 'beside_coordinates' in dm else ("damaged tapes, more", "-", "-"),
     ("PCM-1: line kernel / frame driver / stitch", f"{g('pcm1_front_stage', 'ms_per_step'):.2f} ms per 980 000 lines / {g('pcm1_frames_stage', 'ms_per_step'):.2f} ms / {g('pcm1_stage', 'ms_per_step'):.2f} ms", f"CPU: {g('pcm1_frames_stage', 'cpu_baseline', 'value'):.0f} frames/s (frame driver); round 4: 6.28 ms"),
