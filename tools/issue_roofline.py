@@ -11,7 +11,7 @@
 usage: issue_roofline.py [--md]"""
 import glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["sdv_k_stc007_sweep_levels", "sdv_k_stc007_sweep_pick", "sdv_k_stc007_frames", "sdv_k_stitch_analyze", "sdv_k_stitch_step", "sdv_k_pcm1_prescan", "sdv_k_pcm16_prescan",
+KERNELS = ["sdv_k_stc007_sweep_levels", "sdv_k_stc007_sweep_pick", "sdv_k_stc007_frames", "sdv_k_stc007_frames_plain", "sdv_k_stc007_frames_fat", "sdv_k_stitch_analyze", "sdv_k_stitch_step", "sdv_k_pcm1_prescan", "sdv_k_pcm16_prescan",
            "sdv_k_pcm1_frames_lean", "sdv_k_pcm16_frames_lean", "sdv_k_pcm16_analyse_si", "sdv_k_pcm16_analyse_ei", "sdv_k_ap_plan"]
 
 

@@ -72,7 +72,7 @@ print('cpu', d['cpu_baseline']['value'], d['stitch_stage']['cpu_baseline']['valu
 # round 4: the kernels of the damaged-tape path (tools/gpu_pmc_round4.sh), on the C3 PAL tape of tools/pal_trace.py
 C3 = "tools/pal_trace.py 2000 both: 2000 PAL frames, every 97th line lost, a cell inverted on one line in 53"
 JUMPS = "tools/jump_probe.py 10000 16: 10 000 NTSC frames, the data window jumps 16 times"
-for kernel, prefix, workload in (("sdv_k_stc007_frames", "fullpmc", C3), ("sdv_k_stc007_sweep_levels", "swlpmc", C3), ("sdv_k_stc007_sweep_pick", "swppmc", C3), ("sdv_k_hist_carry", "hcpmc", JUMPS)):
+for kernel, prefix, workload in (("sdv_k_stc007_frames", "fullpmc", C3), ("sdv_k_stc007_frames_plain", "plainpmc", C3), ("sdv_k_stc007_frames_fat", "fatpmc", C3), ("sdv_k_stc007_sweep_levels", "swlpmc", C3), ("sdv_k_stc007_sweep_pick", "swppmc", C3), ("sdv_k_hist_carry", "hcpmc", JUMPS)):
     if glob.glob(f'gpurun_out/{prefix}1/**/*_counter_collection.csv', recursive=True):
         subprocess.check_call([sys.executable, 'tools/pmc_to_json.py', kernel, f'profiles/{RND}_pmc_{kernel}.json', prefix, workload], stdout=subprocess.DEVNULL)
 if glob.glob('gpurun_out/prof_c3/*/*kernel_stats.csv'):
