@@ -250,6 +250,22 @@ def test_emu_a_pass_that_meets_the_last_one_changes_nothing(emu_lib, oracle_lib,
     assert met[None][1:] == met["SDV_NO_TC"][1:], met           # (the short cut changes what a pass costs, not what the scheduler sees)
 
 
+def test_emu_cold_chain_settles_its_first_sweep_in_one_pass(emu_lib, oracle_lib, monkeypatch):
+    """The first frame of a cold chain (nothing tuned: its first line goes through the reference-level sweep) is decoded alone, by the kernel that settles
+    the sweep while the frame waits: one round for it, one for the rest - and one more for the first frame without that kernel."""
+    luma, _, _ = synth.stc007_frames(4, seed=14, height=64, noise_sigma=3.0)
+    want, want_stats = oracle_binarize(luma, mode=2)
+    seen = {}
+    for switch in (None, "SDV_NO_FAT"):
+        if switch: monkeypatch.setenv(switch, "1")
+        got, got_stats, info = emu_run(emu_lib, luma, 2)
+        if switch: monkeypatch.delenv(switch)
+        assert got.tobytes() == want.tobytes(), golden_cases.diff_report(got, want)
+        assert got_stats.view(np.uint8).tobytes() == want_stats.tobytes()
+        seen[switch] = (info.rounds, info.sweeps)
+    assert seen[None] == (2, seen["SDV_NO_FAT"][1]) and seen["SDV_NO_FAT"][0] == 3 and seen[None][1] >= 1, seen
+
+
 def test_emu_small_rounds_settle_their_sweeps_themselves(emu_lib, oracle_lib, monkeypatch):
     """A round of a few frames goes through sdv_k_stc007_frames_fat: a frame that misses a reference-level sweep has it settled on the spot (by the four waves
     beside its own on the GPU, by its own wave here) and goes on with the outcome - its pass is complete, no round to decode it again.  Records and frame
